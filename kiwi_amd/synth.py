@@ -1,0 +1,879 @@
+"""Deterministic synthetic model + corpus generator.
+
+The real Kiwi model binaries are absent from the reference checkout (git-LFS
+pointers), so parity and throughput are measured on a synthetic model that has
+the *shape* of a Kiwi model:
+
+* the reserved default forms / morphemes laid out exactly as the reference's
+  ``KiwiBuilder::initMorphemes`` does (``/root/reference/src/KiwiBuilder.cpp:1108-1131``),
+* a dictionary of forms over normalised Hangul (CV syllable blocks + split-out
+  codas, ``src/StrUtils.h:494-521``) with homonyms, allomorphs, left-condition
+  features, pre-combined (chunked) morphemes, split irregular stems
+  (``combineSocket``), complex nouns and forms containing spaces,
+* a Kneser-Ney style n-gram model serialised in the reference's ``sj.knlm``
+  layout (``src/Knlm.hpp:1003-1167``), estimated from a synthetic morpheme
+  corpus so that the lattice search has a realistic score landscape.
+
+The output is a "raw model" section container (see ``container.py``) holding
+what ``KiwiBuilder`` holds right before ``build()`` bakes it; both the product's
+host-side baker (``kiwi_amd/csrc/model.cpp``) and the reference bridge
+(``oracle/ref_bridge.cpp``) consume that same file.
+"""
+from __future__ import annotations
+
+import math
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .container import write_container
+
+# --- POSTag numbering: /root/reference/include/kiwi/Types.h:195-227 -------------------------
+(UNKNOWN, NNG, NNP, NNB, VV, VA, MAG, NR, NP, VX, MM, MAJ, IC, XPN, XSN, XSV, XSA, XSM, XR,
+ VCP, VCN, SF, SP, SS, SSO, SSC, SE, SO, SW, SB, SL, SH, SN, W_URL, W_EMAIL, W_MENTION,
+ W_HASHTAG, W_SERIAL, W_EMOJI, JKS, JKC, JKG, JKO, JKB, JKV, JKQ, JX, JC, EP, EF, EC, ETN, ETM,
+ Z_CODA, Z_SIOT, USER0, USER1, USER2, USER3, USER4, P, TAG_MAX) = range(62)
+PV, PA = P, P + 1
+IRREGULAR = 0x80
+DEFAULT_TAG_SIZE = P                      # Types.h:257
+DEFAULT_FORM_SIZE = DEFAULT_TAG_SIZE + 26  # KiwiBuilder.cpp:40
+N_DEFAULT_MORPH = DEFAULT_FORM_SIZE + 3    # KiwiBuilder.cpp:1111
+
+# CondVowel / CondPolarity: Types.h:263-288
+(CV_NONE, CV_ANY, CV_VOWEL, CV_VOCALIC, CV_VOCALIC_H, CV_NON_VOWEL, CV_NON_VOCALIC,
+ CV_NON_VOCALIC_H, CV_APPLOSIVE) = range(9)
+CP_NONE, CP_POSITIVE, CP_NEGATIVE, CP_NON_ADJ = range(4)
+
+MORPH_DTYPE = np.dtype([
+    ("kform", "<u4"), ("lm_id", "<u4"), ("orig_id", "<u4"), ("combined", "<i4"),
+    ("user_score", "<f4"), ("chunk_ptr", "<u4"), ("tag", "u1"), ("vp_pack", "u1"),
+    ("sense_id", "u1"), ("socket", "u1"), ("dialect", "<u2"), ("n_chunks", "u1"), ("pad", "u1"),
+])
+assert MORPH_DTYPE.itemsize == 32
+
+SEED_BASE = 0x4B495749  # "KIWI" 
+
+
+def cv(onset: int, vowel: int) -> str:
+    return chr(0xAC00 + (onset * 21 + vowel) * 28)
+
+
+def coda(c: int) -> str:  # c in 1..27
+    return chr(0x11A7 + c)
+
+
+def is_coda(ch: str) -> bool:
+    return 0x11A8 <= ord(ch) <= 0x11C2
+
+
+def is_syll(ch: str) -> bool:
+    return 0xAC00 <= ord(ch) < 0xD7A4
+
+
+def join_hangul(norm: str) -> str:
+    """Inverse of the coda split for well-formed strings (syllable + coda -> composed)."""
+    out = []
+    for ch in norm:
+        o = ord(ch)
+        if is_coda(ch) and out and is_syll(out[-1]) and (ord(out[-1]) - 0xAC00) % 28 == 0:
+            out[-1] = chr(ord(out[-1]) + (o - 0x11A7))
+        else:
+            out.append(ch)
+    return "".join(out)
+
+
+def normalize_hangul(text: str) -> str:
+    out = []
+    for ch in text:
+        o = ord(ch)
+        if o == 0xB42C:
+            o = 0xB410
+        if 0xAC00 <= o < 0xD7A4:
+            c = (o - 0xAC00) % 28
+            out.append(chr(o - c))
+            if c:
+                out.append(chr(0x11A7 + c))
+        else:
+            out.append(chr(o))
+    return "".join(out)
+
+
+@dataclass
+class Morph:
+    kform: int
+    tag: int
+    vowel: int = CV_NONE
+    polar: int = CP_NONE
+    complex: bool = False
+    sense_id: int = 0
+    socket: int = 0
+    combined: int = 0
+    user_score: float = 0.0
+    lm_id: int = 0
+    orig_id: int = 0
+    chunks: list = field(default_factory=list)
+    chunk_pos: list = field(default_factory=list)
+    dialect: int = 0
+
+
+class RawModel:
+    def __init__(self):
+        self.forms: list[str] = []
+        self.form_cands: list[list[int]] = []
+        self.form_map: dict[str, int] = {}
+        self.morphs: list[Morph] = []
+        self.vocab_size = 0
+        self.knlm: bytes = b""
+        self._init_defaults()
+
+    # KiwiBuilder::initMorphemes (KiwiBuilder.cpp:1108-1131)
+    def _init_defaults(self):
+        self.forms = [""] * DEFAULT_FORM_SIZE
+        self.form_cands = [[] for _ in range(DEFAULT_FORM_SIZE)]
+        self.morphs = [Morph(0, UNKNOWN) for _ in range(N_DEFAULT_MORPH)]
+        for i in range(1, DEFAULT_TAG_SIZE):
+            self.form_cands[i - 1].append(i + 1)
+            self.morphs[i + 1].tag = i
+        for i in range(27):
+            f = i + DEFAULT_TAG_SIZE - 1
+            m = i + DEFAULT_TAG_SIZE + 1
+            self.form_cands[f].append(m)
+            self.forms[f] = chr(0x11A8 + i)
+            self.morphs[m].tag = Z_CODA
+            self.morphs[m].kform = f
+            self.morphs[m].user_score = -1.5
+        siot = 0x11BA - 0x11A8
+        self.form_cands[DEFAULT_TAG_SIZE + siot - 1].append(DEFAULT_TAG_SIZE + 28)
+        m = self.morphs[DEFAULT_TAG_SIZE + 28]
+        m.tag = Z_SIOT
+        m.kform = DEFAULT_TAG_SIZE + siot - 1
+        m.user_score = -1.5
+
+    def form_id(self, s: str) -> int:
+        fid = self.form_map.get(s)
+        if fid is None:
+            fid = len(self.forms)
+            self.forms.append(s)
+            self.form_cands.append([])
+            self.form_map[s] = fid
+        return fid
+
+    def add_morph(self, s: str, tag: int, **kw) -> int:
+        fid = self.form_id(s)
+        mid = len(self.morphs)
+        self.morphs.append(Morph(fid, tag, **kw))
+        self.form_cands[fid].append(mid)
+        return mid
+
+    def sections(self) -> dict:
+        form_ptr = np.zeros(len(self.forms) + 1, "<u4")
+        chars = []
+        for i, s in enumerate(self.forms):
+            chars.extend(ord(c) for c in s)
+            form_ptr[i + 1] = len(chars)
+        cand_ptr = np.zeros(len(self.forms) + 1, "<u4")
+        cands = []
+        for i, c in enumerate(self.form_cands):
+            cands.extend(c)
+            cand_ptr[i + 1] = len(cands)
+        rec = np.zeros(len(self.morphs), MORPH_DTYPE)
+        chunk_ids, chunk_pos = [], []
+        for i, m in enumerate(self.morphs):
+            r = rec[i]
+            r["kform"] = m.kform
+            r["lm_id"] = m.lm_id
+            r["orig_id"] = m.orig_id
+            r["combined"] = m.combined
+            r["user_score"] = m.user_score
+            r["chunk_ptr"] = len(chunk_ids)
+            r["tag"] = m.tag
+            r["vp_pack"] = (m.vowel & 0xF) | ((m.polar & 7) << 4) | (0x80 if m.complex else 0)
+            r["sense_id"] = m.sense_id
+            r["socket"] = m.socket
+            r["dialect"] = m.dialect
+            r["n_chunks"] = len(m.chunks)
+            chunk_ids.extend(m.chunks)
+            for a, b in m.chunk_pos:
+                chunk_pos.extend((a, b))
+        meta = np.array([len(self.forms), len(self.morphs), self.vocab_size, 0], "<u4")
+        return {
+            "meta": meta,
+            "form_ptr": form_ptr,
+            "form_chars": np.array(chars, "<u2"),
+            "form_cand_ptr": cand_ptr,
+            "form_cand": np.array(cands, "<u4"),
+            "morph": rec,
+            "chunk_ids": np.array(chunk_ids, "<u4"),
+            "chunk_pos": np.array(chunk_pos, "u1"),
+            "knlm": np.frombuffer(self.knlm, "u1"),
+        }
+
+    def save(self, path: str):
+        write_container(path, self.sections(), kind=b"KAMDRAW1")
+
+
+# ---------------------------------------------------------------------------------------------
+def _zipf_weights(n: int, s: float = 1.0) -> np.ndarray:
+    w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64), s)
+    return w / w.sum()
+
+
+class _Lex:
+    """Word lists per grammatical class with Zipf sampling weights."""
+
+    def __init__(self):
+        self.items: dict[str, list[int]] = {}
+        self.cum: dict[str, np.ndarray] = {}
+
+    def add(self, cls: str, mid: int):
+        self.items.setdefault(cls, []).append(mid)
+
+    def finalize(self):
+        for k, v in self.items.items():
+            self.cum[k] = np.cumsum(_zipf_weights(len(v)))
+
+    def sample(self, cls: str, rng) -> int:
+        v = self.items[cls]
+        return v[min(int(np.searchsorted(self.cum[cls], rng.random())), len(v) - 1)]
+
+
+def _ends_with_coda(s: str) -> bool:
+    return bool(s) and is_coda(s[-1])
+
+
+def _is_positive(s: str) -> bool:
+    # last vowel of the stem in {ㅏ,ㅑ,ㅗ,ㅛ} (FeatureTestor.cpp:60-78 restated for CV strings)
+    for ch in reversed(s):
+        if is_coda(ch):
+            continue
+        if not is_syll(ch):
+            break
+        v = ((ord(ch) - 0xAC00) // 28) % 21
+        return v in (0, 2, 8, 12)
+    return False
+
+
+def _vowel_ok(left: str, cond: int) -> bool:
+    """FeatureTestor::isMatched(begin,end,CondVowel) for our alphabet (FeatureTestor.cpp:6-58)."""
+    if cond == CV_NONE:
+        return True
+    if not left:
+        return False
+    if cond == CV_ANY:
+        return True
+    e = ord(left[-1])
+    if not (0xAC00 <= e <= 0xD7A4) and not (0x11A8 <= e <= 0x11C2):
+        return True
+    if cond in (CV_VOWEL, CV_VOCALIC, CV_VOCALIC_H):
+        if cond == CV_VOCALIC_H and e == 0x11C2:
+            return True
+        if cond in (CV_VOCALIC_H, CV_VOCALIC) and e == 0x11AF:
+            return True
+        return not (0x11A8 <= e <= 0x11C2)
+    if cond in (CV_NON_VOWEL, CV_NON_VOCALIC, CV_NON_VOCALIC_H):
+        if cond == CV_NON_VOCALIC_H and e == 0x11C2:
+            return False
+        if cond in (CV_NON_VOCALIC_H, CV_NON_VOCALIC) and e == 0x11AF:
+            return False
+        return not (0xAC00 <= e <= 0xD7A4)
+    return False
+
+
+@dataclass
+class SynthSpec:
+    n_words: int = 3000          # open-class dictionary entries (nouns/verbs/adverbs)
+    n_josa: int = 40
+    n_eomi: int = 90
+    n_contract: int = 300        # pre-combined (stem + ending) surface forms
+    n_irregular: int = 40        # split irregular stems (combineSocket)
+    n_complex: int = 150
+    n_spaced: int = 60           # forms containing a space
+    homonym_rate: float = 0.12
+    lm_sentences: int = 20000
+    lm_order: int = 3
+    use_htx: bool = False
+    seed: int = SEED_BASE
+
+
+FULL_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
+                      n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=4)
+SMALL_SPEC = SynthSpec()
+
+
+class SynthModel:
+    """Generates the raw model and keeps the generative grammar for corpus sampling."""
+
+    def __init__(self, spec: SynthSpec = SMALL_SPEC):
+        self.spec = spec
+        self.rng = np.random.default_rng(spec.seed)
+        self.raw = RawModel()
+        self.lex = _Lex()
+        self.contract: dict[tuple[int, int], list[str]] = {}   # (stem, eomi) -> surface strings
+        self.irregular: dict[int, tuple[int, int]] = {}        # full verb -> (left part, socket)
+        self.socket_right: dict[int, dict[int, str]] = {}      # socket -> {eomi -> right surface}
+        self._build_lexicon()
+        self._build_lm()
+
+    # -- random strings ----------------------------------------------------------------------
+    def _syll(self, coda_p=0.35) -> str:
+        r = self.rng
+        s = cv(int(r.integers(0, 19)), int(r.integers(0, 21)))
+        if r.random() < coda_p:
+            # common codas are more likely (ㄴ ㄹ ㅁ ㅇ ㄱ ㅂ ㅅ)
+            if r.random() < 0.8:
+                s += coda(int(r.choice([4, 8, 16, 21, 1, 17, 19])))
+            else:
+                s += coda(int(r.integers(1, 28)))
+        return s
+
+    def _word(self, lens=(1, 2, 3, 4), p=(0.10, 0.45, 0.33, 0.12), coda_p=0.35) -> str:
+        n = int(self.rng.choice(lens, p=p))
+        return "".join(self._syll(coda_p) for _ in range(n))
+
+    def _new_word(self, **kw) -> str:
+        for _ in range(100):
+            w = self._word(**kw)
+            if w not in self.raw.form_map:
+                return w
+        return w
+
+    # -- lexicon -----------------------------------------------------------------------------
+    def _build_lexicon(self):
+        sp, r, raw, lex = self.spec, self.rng, self.raw, self.lex
+        open_tags = [NNG, NNP, NNB, NP, NR, VV, VA, VX, MAG, MAJ, MM, IC, XR, VV | IRREGULAR, VA | IRREGULAR]
+        open_p = np.array([0.44, 0.14, 0.02, 0.01, 0.01, 0.13, 0.07, 0.01, 0.08, 0.01, 0.03, 0.01, 0.02, 0.01, 0.01])
+        open_p = open_p / open_p.sum()
+        cls_of = {NNG: "noun", NNP: "noun", NNB: "noun", NP: "noun", NR: "noun", VV: "verb", VA: "adj",
+                  VX: "verb", MAG: "adv", MAJ: "adv", MM: "det", IC: "adv", XR: "noun",
+                  VV | IRREGULAR: "verb", VA | IRREGULAR: "adj"}
+        existing: list[str] = []
+        for _ in range(sp.n_words):
+            tag = int(r.choice(open_tags, p=open_p))
+            if existing and r.random() < sp.homonym_rate:
+                s = existing[int(r.integers(0, len(existing)))]
+                if any(raw.morphs[m].tag == tag for m in raw.form_cands[raw.form_map[s]]):
+                    s = self._new_word()
+            else:
+                s = self._new_word()
+            kw = {}
+            if r.random() < 0.03:
+                kw["user_score"] = float(np.float32(r.choice([-3.0, -1.0, 0.5, 2.0])))
+            if r.random() < 0.05:
+                kw["sense_id"] = int(r.integers(1, 4))
+            mid = raw.add_morph(s, tag, **kw)
+            existing.append(s)
+            lex.add(cls_of[tag], mid)
+
+        # affixes
+        for tag, n, cls in ((XPN, 6, "xpn"), (XSN, 14, "xsn"), (XSV, 4, "xsv"), (XSA, 4, "xsa"), (XSM, 3, "xsm")):
+            for _ in range(n):
+                lex.add(cls, raw.add_morph(self._new_word(lens=(1, 2), p=(0.7, 0.3)), tag))
+        lex.add("vcp", raw.add_morph(cv(11, 20), VCP))     # 이
+        lex.add("vcn", raw.add_morph(cv(11, 0) + cv(2, 20), VCN))  # 아니
+
+        # josa: allomorph pairs conditioned on the left coda
+        josa_tags = [JKS, JKC, JKG, JKO, JKB, JKV, JKQ, JX, JC]
+        n_pairs = sp.n_josa // 3
+        for _ in range(n_pairs):
+            tag = int(r.choice(josa_tags))
+            a = raw.add_morph(self._new_word(lens=(1, 2), p=(0.75, 0.25), coda_p=0.2), tag, vowel=CV_NON_VOWEL)
+            b = raw.add_morph(self._new_word(lens=(1, 2), p=(0.75, 0.25), coda_p=0.2), tag, vowel=CV_VOWEL)
+            raw.morphs[b].lm_id = a          # allomorph -> canonical (Form.h:75-80)
+            lex.add("josa", a)
+            self.contract.setdefault(("allo", a), []).append(b)
+        for _ in range(sp.n_josa - 2 * n_pairs):
+            tag = int(r.choice(josa_tags))
+            if r.random() < 0.15:   # coda-initial josa, e.g. 'ᆫ', 'ᆯ'
+                s = coda(int(r.choice([4, 8]))) + ("" if r.random() < 0.5 else self._syll(0.1))
+                lex.add("josa", raw.add_morph(s, tag, vowel=CV_VOWEL))
+            else:
+                lex.add("josa", raw.add_morph(self._new_word(lens=(1, 2, 3), p=(0.5, 0.4, 0.1), coda_p=0.2), tag,
+                                              vowel=int(r.choice([CV_NONE, CV_ANY]))))
+
+        # eomi
+        eomi_tags = [EP, EF, EC, ETN, ETM]
+        eomi_cls = {EP: "ep", EF: "ef", EC: "ec", ETN: "etn", ETM: "etm"}
+        ep_ = np.array([0.08, 0.3, 0.4, 0.07, 0.15])
+        n_polar = sp.n_eomi // 5
+        a_syll, eo_syll = cv(11, 0), cv(11, 4)           # 아 / 어
+        for _ in range(n_polar):                         # 아/어 allomorph pairs
+            tag = int(r.choice([EF, EC, EP], p=[0.3, 0.6, 0.1]))
+            rest = "" if r.random() < 0.4 else self._word(lens=(1, 2), p=(0.7, 0.3), coda_p=0.15)
+            if (eo_syll + rest) in raw.form_map and any(
+                    raw.morphs[m].tag == tag for m in raw.form_cands[raw.form_map[eo_syll + rest]]):
+                continue
+            neg = raw.add_morph(eo_syll + rest, tag, polar=CP_NEGATIVE)
+            pos = raw.add_morph(a_syll + rest, tag, polar=CP_POSITIVE)
+            raw.morphs[pos].lm_id = neg
+            lex.add(eomi_cls[tag], neg)
+            self.contract.setdefault(("allo_polar", neg), []).append(pos)
+        for _ in range(sp.n_eomi - 2 * n_polar):
+            tag = int(r.choice(eomi_tags, p=ep_))
+            u = r.random()
+            if u < 0.25:      # coda-initial ending: needs a vowel-final stem
+                s = coda(int(r.choice([4, 8, 17, 16]))) + ("" if r.random() < 0.3 else
+                                                            self._word(lens=(1, 2), p=(0.7, 0.3), coda_p=0.15))
+                vw = int(r.choice([CV_VOWEL, CV_VOCALIC]))
+            elif u < 0.4:     # 으-initial style ending for consonant-final stems
+                s = cv(11, 18) + self._word(lens=(1, 2), p=(0.7, 0.3), coda_p=0.15)
+                vw = CV_NON_VOWEL
+            else:
+                s = self._new_word(lens=(1, 2, 3), p=(0.45, 0.4, 0.15), coda_p=0.15)
+                vw = int(r.choice([CV_NONE, CV_ANY, CV_NON_VOCALIC, CV_VOCALIC_H]))
+            pol = CP_NON_ADJ if r.random() < 0.06 else CP_NONE
+            fid = raw.form_map.get(s)
+            if fid is not None and any(raw.morphs[m].tag == tag for m in raw.form_cands[fid]):
+                continue
+            lex.add(eomi_cls[tag], raw.add_morph(s, tag, vowel=vw, polar=pol))
+
+        # quotes registered as dictionary forms (KiwiBuilder.cpp:2642-2662)
+        for q in ("'", '"'):
+            for tag in (SSO, SSC, SS):
+                raw.add_morph(q, tag)
+
+        base_end = len(raw.morphs)
+
+        # complex nouns: chunks + complex flag -> treated as single unless splitComplex (Form.h:174)
+        nouns = lex.items["noun"]
+        for _ in range(sp.n_complex):
+            a, b = int(r.choice(nouns)), int(r.choice(nouns))
+            sa, sb = raw.forms[raw.morphs[a].kform], raw.forms[raw.morphs[b].kform]
+            s = sa + sb
+            if s in raw.form_map:
+                continue
+            mid = raw.add_morph(s, NNG, complex=True, chunks=[a, b],
+                                chunk_pos=[(0, len(sa)), (len(sa), len(s))])
+            lex.add("noun", mid)
+        # forms with a space inside (multi-word proper nouns), Form::numSpaces (Form.cpp:95)
+        for _ in range(sp.n_spaced):
+            s = self._new_word(lens=(1, 2), p=(0.4, 0.6)) + " " + self._new_word(lens=(1, 2), p=(0.4, 0.6))
+            if s.replace(" ", "") in raw.form_map or s in raw.form_map:
+                continue
+            lex.add("noun", raw.add_morph(s, NNP))
+
+        # split irregular stems: full verb V (in vocab), left part L/P (socket s, combined -> V)
+        n_sockets = 4
+        pieces = {}
+        for s_id in range(1, n_sockets + 1):
+            pieces[s_id] = raw.add_morph(coda(int([17, 7, 19, 8][s_id - 1])), PV, socket=s_id)  # ㅂ ㄷ ㅅ ㄹ
+            self.socket_right[s_id] = {}
+        verbs = lex.items["verb"] + lex.items["adj"]
+        made = 0
+        for v in list(r.permutation(verbs)):
+            if made >= sp.n_irregular:
+                break
+            v = int(v)
+            sv = raw.forms[raw.morphs[v].kform]
+            if raw.morphs[v].tag & IRREGULAR == 0 or len(sv) < 2:
+                # turn some regular stems with a matching coda into irregular ones
+                if not _ends_with_coda(sv):
+                    continue
+            if not _ends_with_coda(sv) or " " in sv:
+                continue
+            s_id = int(r.integers(1, n_sockets + 1))
+            left = sv[:-1]
+            if not left or left in raw.form_map and any(
+                    raw.morphs[m].socket for m in raw.form_cands[raw.form_map[left]]):
+                continue
+            lid = raw.add_morph(left, PV if raw.morphs[v].tag & 0x7F == VV else PA, socket=s_id)
+            raw.morphs[lid].combined = v - lid
+            self.irregular[v] = (lid, s_id)
+            made += 1
+        self.vocab_end_candidates = len(raw.morphs)
+
+        # right parts for sockets: combined morpheme [piece/P, eomi] (KiwiBuilder.cpp:1618-1701)
+        eomis = lex.items.get("ec", []) + lex.items.get("ef", []) + lex.items.get("etm", [])
+        self._combined_start = len(raw.morphs)
+        for s_id in range(1, n_sockets + 1):
+            for e in r.permutation(eomis)[: max(4, len(eomis) // 6)]:
+                e = int(e)
+                se = raw.forms[raw.morphs[e].kform]
+                if is_coda(se[0]):
+                    continue
+                surf = self._syll(0.0) + se[1:]     # e.g. ㅂ + 어 -> 워
+                if surf in raw.form_map:
+                    continue
+                self._add_combined(surf, [pieces[s_id], e], [(0, 1), (0, len(surf))], socket=s_id,
+                                   vowel=CV_NONE, score=0.0)
+                self.socket_right[s_id][e] = surf
+        # contractions stem+eomi -> new surface, expands to several tokens (PathEvaluator.hpp:1135-1153)
+        stems = verbs
+        tries = 0
+        while sum(1 for k in self.contract if isinstance(k[0], int)) < sp.n_contract and tries < sp.n_contract * 4:
+            tries += 1
+            v, e = int(r.choice(stems)), int(r.choice(eomis))
+            if (v, e) in self.contract:
+                continue
+            sv, se = raw.forms[raw.morphs[v].kform], raw.forms[raw.morphs[e].kform]
+            if " " in sv or is_coda(se[0]):
+                continue
+            body = sv[:-1] if _ends_with_coda(sv) else sv
+            surf = body[:-1] + self._syll(0.3) + se[1:]
+            if not surf or surf in raw.form_map or is_coda(surf[0]):
+                continue
+            k = max(1, len(body) - 1)
+            self._add_combined(surf, [v, e], [(0, min(k + 1, len(surf))), (k, len(surf))], socket=0,
+                               vowel=CV_NONE, score=float(np.float32(r.choice([0.0, -0.5, -1.0]))))
+            self.contract[(v, e)] = [surf]
+        lex.finalize()
+        self.base_end = base_end
+
+    def _add_combined(self, surf, chunks, pos, socket, vowel, score):
+        raw = self.raw
+        mid = raw.add_morph(surf, UNKNOWN, chunks=list(chunks), chunk_pos=list(pos), socket=socket, vowel=vowel)
+        m = raw.morphs[mid]
+        m.user_score = float(np.float32(sum(raw.morphs[c].user_score for c in chunks) + score))
+        return mid
+
+    # -- language model ----------------------------------------------------------------------
+    def sample_sentence(self, rng, n_eojeol=None):
+        """Returns (morpheme-id sequence for the LM, list of eojeol surface strings (normalised))."""
+        lex, raw = self.lex, self.raw
+        n_eojeol = n_eojeol or int(rng.integers(2, 9))
+        lm_seq, surf = [], []
+        for ei in range(n_eojeol):
+            last = ei == n_eojeol - 1
+            u = rng.random()
+            if last or u < 0.33:
+                lm, s = self._verb_phrase(rng, final=last)
+            elif u < 0.88:
+                lm, s = self._noun_phrase(rng)
+            else:
+                m = lex.sample("adv" if rng.random() < 0.7 else "det", rng)
+                lm, s = [m], raw.forms[raw.morphs[m].kform]
+            lm_seq.extend(lm)
+            surf.append(s)
+        return lm_seq, surf
+
+    def _lmid(self, m):
+        mm = self.raw.morphs[m]
+        return mm.lm_id if mm.lm_id else m
+
+    def _attach(self, left: str, m: int, rng) -> tuple[int, str]:
+        """Pick the allomorph of suffix ``m`` that is compatible with ``left``."""
+        raw = self.raw
+        cands = [m] + self.contract.get(("allo", m), []) + self.contract.get(("allo_polar", m), [])
+        rng.shuffle(cands)
+        for c in cands:
+            mc = raw.morphs[c]
+            if not _vowel_ok(left, mc.vowel):
+                continue
+            if mc.polar == CP_POSITIVE and not _is_positive(left):
+                continue
+            if mc.polar == CP_NEGATIVE and _is_positive(left):
+                continue
+            s = raw.forms[mc.kform]
+            if is_coda(s[0]) and (not left or not is_syll(left[-1])):
+                continue
+            return c, s
+        return -1, ""
+
+    def _noun_phrase(self, rng):
+        lex, raw = self.lex, self.raw
+        lm, s = [], ""
+        if rng.random() < 0.05:
+            m = lex.sample("xpn", rng)
+            lm.append(m)
+            s += raw.forms[raw.morphs[m].kform]
+        n = lex.sample("noun", rng)
+        lm.append(n)
+        s += raw.forms[raw.morphs[n].kform]
+        if rng.random() < 0.1:
+            m = lex.sample("xsn", rng)
+            lm.append(m)
+            s += raw.forms[raw.morphs[m].kform]
+        if rng.random() < 0.75:
+            for _ in range(4):
+                j = lex.sample("josa", rng)
+                c, js = self._attach(s, j, rng)
+                if c >= 0:
+                    lm.append(c)
+                    s += js
+                    break
+        return lm, s
+
+    def _verb_phrase(self, rng, final):
+        lex, raw = self.lex, self.raw
+        lm, s = [], ""
+        u = rng.random()
+        if u < 0.12:
+            n = lex.sample("noun", rng)
+            x = lex.sample("xsv" if rng.random() < 0.6 else "xsa", rng)
+            lm += [n, x]
+            s = raw.forms[raw.morphs[n].kform] + raw.forms[raw.morphs[x].kform]
+            stem = x
+        elif u < 0.18:
+            n = lex.sample("noun", rng)
+            x = lex.items["vcp"][0]
+            lm += [n, x]
+            s = raw.forms[raw.morphs[n].kform] + raw.forms[raw.morphs[x].kform]
+            stem = x
+        else:
+            stem = lex.sample("verb" if rng.random() < 0.7 else "adj", rng)
+            lm.append(stem)
+            s = raw.forms[raw.morphs[stem].kform]
+        if rng.random() < 0.15 and "ep" in lex.items:
+            c, es = self._attach(s, lex.sample("ep", rng), rng)
+            if c >= 0:
+                lm.append(c)
+                s += es
+                stem = -1
+        cls = "ef" if final else ("ec" if rng.random() < 0.7 else "etm")
+        for _ in range(6):
+            e = lex.sample(cls, rng)
+            # contraction / irregular realisations only straight after the stem
+            if stem >= 0 and len(lm) == 1:
+                if (stem, e) in self.contract and rng.random() < 0.8:
+                    return [stem, e], self.contract[(stem, e)][0]
+                if stem in self.irregular:
+                    lid, s_id = self.irregular[stem]
+                    right = self.socket_right[s_id].get(e)
+                    if right is not None and rng.random() < 0.8:
+                        return [stem, e], raw.forms[raw.morphs[lid].kform] + right
+            c, es = self._attach(s, e, rng)
+            if c >= 0:
+                lm.append(c)
+                s += es
+                break
+        return lm, s
+
+    def _build_lm(self):
+        sp, raw = self.spec, self.raw
+        # every morpheme that is not a combined (chunked, tag unknown) entry is in the LM vocabulary
+        vocab = self._combined_start
+        raw.vocab_size = vocab
+        for i, m in enumerate(raw.morphs):
+            if i >= vocab:
+                m.lm_id = i                       # KiwiBuilder.cpp:1641
+            elif m.lm_id == 0 and i > 0:
+                m.lm_id = i                       # KiwiBuilder.cpp:906-921
+        rng = np.random.default_rng(sp.seed + 1)
+        sents = []
+        sf_id = SF + 1
+        for _ in range(sp.lm_sentences):
+            lm, _ = self.sample_sentence(rng)
+            sents.append([0] + [self._lmid(m) for m in lm] + [sf_id, 1])
+        htx = None
+        if sp.use_htx:
+            htx = np.array([(raw.morphs[i].tag & 0x7F) + vocab for i in range(vocab)], dtype=np.int64)
+        raw.knlm = build_knlm(sents, vocab, sp.lm_order, htx=htx)
+
+    # -- text corpus -------------------------------------------------------------------------
+    def make_corpus(self, n, seed, min_jamo=5, max_jamo=200, exact_jamo=None, oov_rate=0.03):
+        """Synthetic sentences (composed Hangul text). Length is measured in non-space
+        normalised units ("jamo")."""
+        rng = np.random.default_rng(seed)
+        out = []
+        for _ in range(n):
+            target = exact_jamo or int(rng.integers(min_jamo, max_jamo + 1))
+            words, total = [], 0
+            while total < target - 1:
+                _, surf = self.sample_sentence(rng, n_eojeol=int(rng.integers(1, 4)))
+                for w in surf:
+                    if rng.random() < oov_rate:
+                        w = "".join(self._rand_syll(rng) for _ in range(int(rng.integers(2, 6))))
+                    ns = len(w.replace(" ", ""))
+                    if total + ns > target - 1:
+                        # fill the remainder with an OOV run of exactly the missing size
+                        rem = target - 1 - total
+                        w = "".join(cv(int(rng.integers(0, 19)), int(rng.integers(0, 21))) for _ in range(rem))
+                        ns = rem
+                    if ns:
+                        words.append(w)
+                        total += ns
+                    if total >= target - 1:
+                        break
+            text = " ".join(words) + str(rng.choice([".", "?", "!"]))
+            out.append(join_hangul(text))
+        return out
+
+    @staticmethod
+    def _rand_syll(rng):
+        s = cv(int(rng.integers(0, 19)), int(rng.integers(0, 21)))
+        if rng.random() < 0.3:
+            s += coda(int(rng.integers(1, 28)))
+        return s
+
+
+# ---------------------------------------------------------------------------------------------
+def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_id=0, eos_id=1) -> bytes:
+    """Interpolated Kneser-Ney estimate serialised in the reference's uncompressed,
+    unquantised ``sj.knlm`` layout (reader: /root/reference/src/Knlm.hpp:1003-1167; header:
+    include/kiwi/Knlm.h:9-15).  History transforms (``htx``) are not generated here."""
+    assert htx is None, "history-transformed synthetic LMs are not generated yet"
+    flat = np.concatenate([np.asarray(s, dtype=np.int64) for s in sents])
+    lens = np.array([len(s) for s in sents], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    sid = np.repeat(np.arange(len(sents)), lens)
+    hist = flat if htx is None else htx[flat]
+    key_space = int(max(vocab_size, 0 if htx is None else int(htx.max()) + 1)) + 1
+    bits = max(1, (key_space - 1).bit_length())
+    assert bits * order <= 63
+    # n-gram tables: dict order -> (keys[n, order] sorted, counts)
+    grams = {}
+    n_tok = len(flat)
+    for n in range(1, order + 1):
+        idx = np.arange(n_tok - n + 1)
+        ok = sid[idx] == sid[idx + n - 1]
+        idx = idx[ok]
+        cols = [hist[idx + k] for k in range(n - 1)] + [flat[idx + n - 1]]
+        code = np.zeros(len(idx), dtype=np.int64)
+        for c in cols:
+            code = (code << bits) | c
+        u, cnt = np.unique(code, return_counts=True)
+        grams[n] = (u, cnt.astype(np.float64))
+
+    def split(code, n):
+        cols = []
+        for k in range(n):
+            cols.append((code >> (bits * (n - 1 - k))) & ((1 << bits) - 1))
+        return np.stack(cols, axis=1) if n else np.zeros((len(code), 0), np.int64)
+
+    # continuation counts for lower orders: N1+(• w) of the (n+1)-grams whose suffix is this n-gram
+    counts = {order: grams[order][1]}
+    for n in range(order - 1, 0, -1):
+        hi, _ = grams[n + 1]
+        # suffix of an (n+1)-gram in *mixed* key space: history part transformed, last raw
+        suffix = hi & ((1 << (bits * n)) - 1)
+        u, c = np.unique(suffix, return_counts=True)
+        cc = np.zeros(len(grams[n][0]))
+        pos = np.searchsorted(grams[n][0], u)
+        okm = (pos < len(grams[n][0]))
+        okm[okm] &= grams[n][0][pos[okm]] == u[okm]
+        cc[pos[okm]] = c[okm]
+        # n-grams that start a sentence (begin with <s>) keep their real count
+        first = (grams[n][0] >> (bits * (n - 1))) & ((1 << bits) - 1)
+        bos_key = bos_id if htx is None else int(htx[bos_id])
+        isbos = first == (bos_key if n > 1 else bos_id)
+        cc = np.where(isbos | (cc == 0), np.maximum(cc, grams[n][1] * (isbos | (cc == 0))), cc)
+        counts[n] = cc
+
+    # probabilities, top-down recursion on the context
+    uni_keys, uni_c = grams[1][0], counts[1]
+    uni_total = uni_c.sum()
+    p_uni = np.maximum(uni_c - discount, 0.05) / uni_total
+    p_uni = p_uni / p_uni.sum() * (1 - 1e-4)
+    prob = {1: p_uni}
+    gamma = {}
+    for n in range(2, order + 1):
+        keys, c = grams[n][0], counts[n]
+        ctx = keys >> bits
+        uctx, inv = np.unique(ctx, return_inverse=True)
+        tot = np.bincount(inv, weights=c)
+        n1 = np.bincount(inv)
+        g = discount * n1 / tot
+        # lower-order probability of the same word in the shortened context
+        low_key = keys & ((1 << (bits * (n - 1))) - 1)
+        if n - 1 == 1:
+            lp_pos = np.searchsorted(grams[1][0], low_key)
+            lower = prob[1][np.minimum(lp_pos, len(prob[1]) - 1)]
+        else:
+            # the shortened history is already in transformed space; the (n-1)-gram table shares it
+            lp_pos = np.searchsorted(grams[n - 1][0], low_key)
+            lp_pos = np.minimum(lp_pos, len(grams[n - 1][0]) - 1)
+            found = grams[n - 1][0][lp_pos] == low_key
+            lower = np.where(found, prob[n - 1][lp_pos], 1e-7)
+        prob[n] = np.maximum(c - discount, 0) / tot[inv] + g[inv] * lower
+        gamma[n - 1] = (uctx, g)
+
+    # --- trie assembly: node = context sequence; children keyed by next id ---------------------
+    # children of a context of length n-1 are the n-grams sharing it.  A child is a non-leaf node
+    # iff it is itself a context of some (n+1)-gram.  Context keys live in history space except
+    # that the *last* element of an n-gram key is raw; a child (ctx, w) as a context is (ctx, h(w)).
+    nodes_children = {}   # ctx tuple -> dict key -> [ll, gamma or None]
+    root = {}
+    nodes_children[()] = root
+    ll1 = np.log(prob[1])
+    for k, l in zip(grams[1][0].tolist(), ll1.tolist()):
+        root[int(k)] = [float(np.float32(l)), None]
+    ctx_gamma = {}
+    for n in range(1, order):
+        uctx, g = gamma[n]
+        cols = split(uctx, n)
+        for row, gv in zip(cols.tolist(), g.tolist()):
+            ctx_gamma[tuple(row)] = float(np.float32(math.log(max(gv, 1e-6))))
+    for n in range(2, order + 1):
+        cols = split(grams[n][0], n)
+        lls = np.log(np.maximum(prob[n], 1e-12))
+        for row, l in zip(cols.tolist(), lls.tolist()):
+            nodes_children.setdefault(tuple(row[:-1]), {})[int(row[-1])] = [float(np.float32(l)), None]
+    # make sure every context node exists as a child chain from the root (suffix/prefix closure)
+    for ctx in sorted(ctx_gamma, key=len):
+        for d in range(1, len(ctx) + 1):
+            par = nodes_children.setdefault(tuple(ctx[:d - 1]), {})
+            if ctx[d - 1] not in par:
+                par[ctx[d - 1]] = [-20.0, None]
+        nodes_children.setdefault(tuple(ctx), {})
+    # a context must also have all its suffixes as contexts so that `lower` links resolve to real
+    # nodes (Knlm.hpp:38-63)
+    for ctx in sorted(list(nodes_children), key=len, reverse=True):
+        for s in range(1, len(ctx)):
+            suf = tuple(ctx[s:])
+            if suf not in nodes_children:
+                nodes_children[suf] = {}
+                for d in range(1, len(suf) + 1):
+                    par = nodes_children.setdefault(tuple(suf[:d - 1]), {})
+                    if suf[d - 1] not in par:
+                        par[suf[d - 1]] = [-20.0, None]
+    # drop empty contexts (they are leaves)
+    nonleaf = {c for c, ch in nodes_children.items() if ch or c == ()}
+
+    node_sizes, keys_out, ll_nonleaf, gamma_nonleaf, ll_leaf = [], [], [], [], []
+
+    import sys
+    sys.setrecursionlimit(10000)
+
+    def emit(ctx, ll):
+        ch = nodes_children[ctx]
+        node_sizes.append(len(ch))
+        ll_nonleaf.append(ll)
+        gamma_nonleaf.append(ctx_gamma.get(ctx, -0.05) if ctx else 0.0)
+        ks = sorted(ch)
+        keys_out.extend(ks)
+        for k in ks:
+            child = ctx + (k,)
+            if child in nonleaf and len(child) < order:
+                emit(child, ch[k][0])
+            else:
+                node_sizes.append(0)
+                ll_leaf.append(ch[k][0])
+
+    emit((), 0.0)
+    key_size = 2 if key_space <= 0xFFFF else 4
+    kdt = "<u2" if key_size == 2 else "<u4"
+    node_arr = np.array(node_sizes, kdt)
+    assert max(node_sizes) < (1 << (8 * key_size))
+    key_arr = np.array(keys_out, kdt)
+    ll_arr = np.array(ll_nonleaf + ll_leaf, "<f4")
+    # leaf values are stored as float bit patterns and told apart from child offsets by their sign
+    assert (ll_arr[len(ll_nonleaf):] < 0).all()
+    gm_arr = np.array(gamma_nonleaf, "<f4")
+    htx_arr = None if htx is None else np.asarray(htx, kdt)
+
+    def al(x):
+        return (x + 15) & ~15
+    off = 96
+    node_off = off
+    off = al(off + node_arr.nbytes)
+    key_off = off
+    off = al(off + key_arr.nbytes)
+    ll_off = off
+    off = al(off + ll_arr.nbytes)
+    gamma_off = off
+    off = al(off + gm_arr.nbytes)
+    qtable_off = off
+    htx_off = 0
+    if htx_arr is not None:
+        htx_off = off
+        off = al(off + htx_arr.nbytes)
+    buf = bytearray(off)
+    struct.pack_into("<11Q4BI", buf, 0, len(node_sizes), node_off, key_off, ll_off, gamma_off, qtable_off,
+                     htx_off, unk_id, bos_id, eos_id, vocab_size, order, key_size, 4, 0, 0)
+    buf[node_off:node_off + node_arr.nbytes] = node_arr.tobytes()
+    buf[key_off:key_off + key_arr.nbytes] = key_arr.tobytes()
+    buf[ll_off:ll_off + ll_arr.nbytes] = ll_arr.tobytes()
+    buf[gamma_off:gamma_off + gm_arr.nbytes] = gm_arr.tobytes()
+    if htx_arr is not None:
+        buf[htx_off:htx_off + htx_arr.nbytes] = htx_arr.tobytes()
+    return bytes(buf)

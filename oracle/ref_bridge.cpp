@@ -1,0 +1,459 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product.
+//
+// Bridge that lets the REAL reference translation units (compiled where they lie under
+// /root/reference by oracle/Makefile into oracle/_ref/libkiwi_ref.so) run on the synthetic
+// "raw model" this repo generates (kiwi_amd/synth.py).  The reference cannot load its own
+// models here: the binaries are git-LFS pointers and src/KiwiBuilder.cpp does not compile
+// without Eigen.  So this file re-does, with the reference's own functions,
+// the part of KiwiBuilder::build() that bakes a Kiwi object
+// (/root/reference/src/KiwiBuilder.cpp:2385-2640): bake() (src/Form.cpp:93-141),
+// utils::sortWriteInvIdx (src/SortUtils.hpp:235), ContinuousTrie::buildWithCaching
+// (include/kiwi/Trie.hpp:444), utils::freezeTrie (src/FrozenTrie.hpp:176) and
+// lm::KnLangModelBase::create (src/Knlm.cpp:176).  Everything downstream -- Kiwi::analyze,
+// splitByTrie, BestPathFinder<KnLangModel>::findBestPath -- is the untouched reference.
+//
+// Private members of kiwi::Kiwi are reached through an explicit specialisation of
+// BestPathFinder<>, which Kiwi befriends for every template argument (include/kiwi/Kiwi.h:176).
+#include <cstring>
+#include <chrono>
+#include <fstream>
+#include <thread>
+#include <atomic>
+#include <numeric>
+
+#include <kiwi/Kiwi.h>
+#include <kiwi/Utils.h>
+#include <kiwi/Form.h>
+#include <kiwi/Knlm.h>
+#include <kiwi/Dataset.h>
+#include "ArchAvailable.h"
+#include "KTrie.h"
+#include "FrozenTrie.hpp"
+#include "StrUtils.h"
+#include "SortUtils.hpp"
+#include "PathEvaluator.h"
+#include "MathFunc.hpp"
+
+#include "../kiwi_amd/csrc/container.hpp"
+#include "../kiwi_amd/csrc/raw_model.hpp"
+
+namespace kiwi
+{
+	namespace lm
+	{
+		// src/archImpl/none.cpp:8-16 cannot be compiled (pulls Eigen); the scalar LSE it would
+		// instantiate is header-only (src/MathFunc.hpp:35-55), so instantiate it here.
+		template float logSumExp<ArchType::none>(const float* arr, size_t size);
+		template float logSumExp<ArchType::balanced>(const float* arr, size_t size);
+		template float logSumExp<ArchType::sse2>(const float* arr, size_t size);
+	}
+	// src/Dataset.cpp:805 (needs Eigen-dependent headers); only used by the optional OOV
+	// character model which the bridge never enables.
+	size_t ChrTokenizer::encodeOne(char32_t) const { throw std::runtime_error{ "ChrTokenizer unavailable in ref bridge" }; }
+}
+
+namespace kamd_ref { struct Access; }
+
+namespace kiwi
+{
+	static constexpr size_t defaultFormSize = defaultTagSize + 26; // src/KiwiBuilder.cpp:40
+
+	// restated file-local helpers of src/KiwiBuilder.cpp (not reachable from outside that TU)
+	static CondVowel reduceVowelR(CondVowel v, const Morpheme* m) // KiwiBuilder.cpp:2258-2278
+	{
+		if (v == m->vowel) return v;
+		if (CondVowel::vowel <= v && v <= CondVowel::vocalic_h)
+		{
+			if (CondVowel::vowel <= m->vowel && m->vowel <= CondVowel::vocalic_h) return std::max(v, m->vowel);
+			return CondVowel::none;
+		}
+		else if (CondVowel::non_vowel <= v && v <= CondVowel::non_vocalic_h)
+		{
+			if (CondVowel::non_vowel <= m->vowel && m->vowel <= CondVowel::non_vocalic_h) return std::min(v, m->vowel);
+			return CondVowel::none;
+		}
+		return CondVowel::none;
+	}
+	static CondPolarity reducePolarR(CondPolarity p, const Morpheme* m) { return p == m->polar ? p : CondPolarity::none; }
+	static Dialect reduceDialectR(Dialect d, const Morpheme* m)
+	{
+		if (d == Dialect::standard || m->dialect == Dialect::standard) return Dialect::standard;
+		return d | m->dialect;
+	}
+	static bool zCodaAppendableR(const KString& form, const Vector<uint32_t>& cand, const Vector<MorphemeRaw>& ms) // :2294-2323
+	{
+		if (form.empty() || !isHangulSyllable(form.back())) return false;
+		for (auto i : cand)
+		{
+			auto tag = ms[i].tag;
+			if (tag == POSTag::unknown && !ms[i].chunks.empty()) tag = ms[ms[i].chunks.back()].tag;
+			if (isJClass(tag) || isEClass(tag)) return true;
+		}
+		return false;
+	}
+	static bool zSiotAppendableR(const KString& form, const Vector<uint32_t>& cand, const Vector<MorphemeRaw>& ms) // :2325-2352
+	{
+		if (form.empty() || !isHangulSyllable(form.back()) || isHangulCoda(form.back())) return false;
+		for (auto i : cand)
+		{
+			const auto tag = ms[i].tag;
+			if (!isNNClass(tag)) continue;
+			if (ms[i].lmMorphemeId != getDefaultMorphemeId(tag)) return true;
+		}
+		return false;
+	}
+
+	template<>
+	struct BestPathFinder<kamd_ref::Access>
+	{
+		static Kiwi build(const kamd::RawModel& raw, ArchType arch)
+		{
+			// --- raw records -> FormRaw / MorphemeRaw (what KiwiBuilder holds before build()) ---
+			Vector<FormRaw> forms(raw.nForms());
+			Vector<MorphemeRaw> morphemes(raw.nMorphs());
+			for (size_t i = 0; i < raw.nForms(); ++i)
+			{
+				forms[i].form = KString{ (const char16_t*)raw.formChars + raw.formPtr[i], (const char16_t*)raw.formChars + raw.formPtr[i + 1] };
+				forms[i].candidate.assign(raw.formCand + raw.formCandPtr[i], raw.formCand + raw.formCandPtr[i + 1]);
+			}
+			for (size_t i = 0; i < raw.nMorphs(); ++i)
+			{
+				auto& r = raw.morph[i];
+				auto& m = morphemes[i];
+				m.kform = r.kform; m.tag = (POSTag)r.tag; m.vpPack = r.vpPack; m.senseId = r.senseId;
+				m.combineSocket = r.socket; m.combined = r.combined; m.userScore = r.userScore;
+				m.lmMorphemeId = r.lmId; m.origMorphemeId = r.origId; m.dialect = (Dialect)r.dialect;
+				for (size_t c = 0; c < r.nChunks; ++c)
+				{
+					m.chunks.emplace_back(raw.chunkIds[r.chunkPtr + c]);
+					m.chunkPositions.emplace_back(raw.chunkPos[(r.chunkPtr + c) * 2], raw.chunkPos[(r.chunkPtr + c) * 2 + 1]);
+				}
+			}
+
+			utils::MemoryOwner mem{ raw.knlmSize };
+			std::memcpy(mem.get(), raw.knlm, raw.knlmSize);
+			std::shared_ptr<lm::ILangModel> langMdl = lm::KnLangModelBase::create(utils::MemoryObject{ std::move(mem) }, arch);
+
+			// --- from here on: KiwiBuilder::build() with typos.empty() and no rule-combined morphemes ---
+			Kiwi ret{ arch, langMdl, false, false, false };
+			ret.forms.reserve(forms.size() + 1);
+			ret.morphemes.reserve(morphemes.size());
+			ret.globalConfig.integrateAllomorph = true;
+
+			for (auto& f : forms)
+			{
+				ret.forms.emplace_back(bake(f, ret.morphemes.data(), zCodaAppendableR(f.form, f.candidate, morphemes), zSiotAppendableR(f.form, f.candidate, morphemes)));
+			}
+			Vector<size_t> newFormIdMapper(ret.forms.size());
+			std::iota(newFormIdMapper.begin(), newFormIdMapper.begin() + defaultFormSize, 0);
+			utils::sortWriteInvIdx(ret.forms.begin() + defaultFormSize, ret.forms.end(), newFormIdMapper.begin() + defaultFormSize, defaultFormSize);
+			ret.forms.emplace_back();
+
+			uint8_t formHash = 0;
+			for (size_t i = 1; i < ret.forms.size(); ++i)
+			{
+				if (!ComparatorIgnoringSpace::equal(ret.forms[i].form, ret.forms[i - 1].form)) ++formHash;
+				ret.forms[i].formHash = formHash;
+			}
+			for (auto& m : morphemes)
+			{
+				ret.morphemes.emplace_back(bake(m, ret.morphemes.data(), ret.forms.data(), newFormIdMapper));
+			}
+
+			utils::ContinuousTrie<KTrie> formTrie{ defaultFormSize + 1 };
+			for (size_t i = 0; i < defaultFormSize; ++i) formTrie[i + 1].val = &ret.forms[i];
+
+			Vector<const Form*> sortedForms;
+			for (size_t i = defaultFormSize; i < ret.forms.size() - 1; ++i)
+			{
+				auto& f = ret.forms[i];
+				if (f.candidate.empty()) continue;
+				if (f.candidate[0]->vowel != CondVowel::none)
+					f.vowel = std::accumulate(f.candidate.begin(), f.candidate.end(), f.candidate[0]->vowel, reduceVowelR);
+				if (f.candidate[0]->polar != CondPolarity::none)
+					f.polar = std::accumulate(f.candidate.begin(), f.candidate.end(), f.candidate[0]->polar, reducePolarR);
+				f.hasJClass = std::any_of(f.candidate.begin(), f.candidate.end(), [&](const Morpheme* m)
+				{
+					return isJClass(m->tag) || m->tag == POSTag::ec || m->tag == POSTag::ef;
+				});
+				f.hasAnyFullMorphemes = std::any_of(f.candidate.begin(), f.candidate.end(), [&](const Morpheme* m)
+				{
+					const auto tag = clearIrregular(m->tag);
+					return m->dialect == Dialect::standard && tag != POSTag::unknown && tag != POSTag::pa && tag != POSTag::pv;
+				});
+				f.dialect = std::accumulate(f.candidate.begin(), f.candidate.end(), f.candidate[0]->dialect, reduceDialectR);
+				if (f.dialect != Dialect::standard) continue; // enabledDialects == standard
+				sortedForms.emplace_back(&f);
+			}
+			std::sort(sortedForms.begin(), sortedForms.end(), [](const Form* a, const Form* b)
+			{
+				return ComparatorIgnoringSpace::less(a->form, b->form);
+			});
+			size_t estimated = 0;
+			for (auto f : sortedForms) estimated += f->form.size();
+			formTrie.reserveMore(estimated);
+			decltype(formTrie)::CacheStore<KString> cache;
+			for (auto f : sortedForms) formTrie.buildWithCaching(removeSpace(f->form), f, cache);
+			ret.formTrie = utils::freezeTrie(std::move(formTrie), arch);
+
+			// KiwiBuilder::getSpecialMorphs (KiwiBuilder.cpp:2642-2662)
+			for (size_t i = 0; i < morphemes.size(); ++i)
+			{
+				auto& m = morphemes[i];
+				auto& fs = forms[m.kform].form;
+				size_t base;
+				if (fs == u"'") base = 0; else if (fs == u"\"") base = 3; else continue;
+				if (m.tag == POSTag::sso) ret.specialMorphIds[base + 0] = i;
+				else if (m.tag == POSTag::ssc) ret.specialMorphIds[base + 1] = i;
+				else if (m.tag == POSTag::ss) ret.specialMorphIds[base + 2] = i;
+			}
+			return ret;
+		}
+
+		static const Vector<Form>& forms(const Kiwi& k) { return k.forms; }
+		static const Vector<Morpheme>& morphemes(const Kiwi& k) { return k.morphemes; }
+		static KiwiConfig& config(Kiwi& k) { return k.globalConfig; }
+		static const lm::ILangModel* lm(const Kiwi& k) { return k.langMdl.get(); }
+		static const std::array<size_t, 6>& specialMorphs(const Kiwi& k) { return k.specialMorphIds; }
+
+		static size_t split(const Kiwi& k, Vector<KGraphNode>& nodes, U16StringView str, size_t startOffset, Match m, const KiwiConfig& cfg)
+		{
+			const PretokenizedSpanGroup::Span* pf = nullptr;
+			return (*reinterpret_cast<FnSplitByTrie>(k.dfSplitByTrie))(nodes, k.forms.data(), k.typoPtrs.data(), k.formTrie, str, startOffset,
+				m, Dialect::standard, cfg.maxUnkFormSize, cfg.maxUnkFormSizeFollowedByJClass, cfg.spaceTolerance,
+				nullptr, 2.5f, k.continualTypoCost, k.lengtheningTypoCost, pf, pf);
+		}
+	};
+}
+
+using Acc = kiwi::BestPathFinder<kamd_ref::Access>;
+
+struct RefHandle
+{
+	kamd::Container file;
+	kamd::RawModel raw;
+	kiwi::Kiwi kw;
+};
+
+namespace
+{
+	struct Writer
+	{
+		uint8_t* p; uint8_t* end; bool overflow = false; size_t need = 0;
+		template<class T> void put(T v)
+		{
+			need += sizeof(T);
+			if (p + sizeof(T) > end) { overflow = true; return; }
+			std::memcpy(p, &v, sizeof(T)); p += sizeof(T);
+		}
+		void putStr(const std::u16string& s)
+		{
+			put<uint32_t>((uint32_t)s.size());
+			for (auto c : s) put<uint16_t>(c);
+		}
+	};
+
+	kiwi::ArchType toArch(int a)
+	{
+		switch (a)
+		{
+		case 1: return kiwi::ArchType::balanced;
+		case 2: return kiwi::ArchType::sse2;
+		default: return kiwi::ArchType::none;
+		}
+	}
+}
+
+extern "C"
+{
+	void* kref_open(const char* rawModelPath, int arch)
+	{
+		try
+		{
+			auto h = std::make_unique<RefHandle>();
+			h->file.load(rawModelPath);
+			h->raw.bind(h->file);
+			h->kw = Acc::build(h->raw, toArch(arch));
+			return h.release();
+		}
+		catch (const std::exception& e)
+		{
+			fprintf(stderr, "kref_open: %s\n", e.what());
+			return nullptr;
+		}
+	}
+
+	void kref_close(void* h) { delete (RefHandle*)h; }
+
+	// 13 floats/ints mirroring KiwiConfig (include/kiwi/Kiwi.h:150-167); negative index = no change
+	void kref_set_config(void* hp, float cutOff, float spacePenalty, float typoCostWeight, uint32_t maxUnk, uint32_t maxUnkJ, uint32_t spaceTol, int integrateAllomorph)
+	{
+		auto& c = Acc::config(((RefHandle*)hp)->kw);
+		c.cutOffThreshold = cutOff; c.spacePenalty = spacePenalty; c.typoCostWeight = typoCostWeight;
+		c.maxUnkFormSize = maxUnk; c.maxUnkFormSizeFollowedByJClass = maxUnkJ; c.spaceTolerance = spaceTol;
+		c.integrateAllomorph = !!integrateAllomorph;
+	}
+
+	// Serialises the baked dictionary so that the product's baker can be compared field by field.
+	// forms: {u32 nChars, u16 chars[], u32 numSpaces, u8 vowel, u8 polar, u8 formHash, u8 flags, u16 dialect, u32 nCand, u32 cand[]}
+	// morphs: {u32 kformId, u8 tag, u8 vowel, u8 polar, u8 complex, u8 saisiot, u8 senseId, u8 socket, i32 combined, f32 userScore,
+	//          u32 lmId, u32 origId, u16 dialect, u32 nChunks, {u32 id, u8 b, u8 e}[]}
+	size_t kref_dump_dict(void* hp, uint8_t* out, size_t cap)
+	{
+		auto& kw = ((RefHandle*)hp)->kw;
+		auto& forms = Acc::forms(kw);
+		auto& morphs = Acc::morphemes(kw);
+		Writer w{ out, out + cap };
+		w.put<uint32_t>((uint32_t)forms.size());
+		w.put<uint32_t>((uint32_t)morphs.size());
+		for (auto& f : forms)
+		{
+			w.putStr(f.form);
+			w.put<uint32_t>(f.numSpaces);
+			w.put<uint8_t>((uint8_t)f.vowel); w.put<uint8_t>((uint8_t)f.polar); w.put<uint8_t>(f.formHash);
+			w.put<uint8_t>(f.zCodaAppendable | (f.zSiotAppendable << 1) | (f.hasJClass << 2) | (f.hasAnyFullMorphemes << 3));
+			w.put<uint16_t>((uint16_t)f.dialect);
+			w.put<uint32_t>((uint32_t)f.candidate.size());
+			for (auto c : f.candidate) w.put<uint32_t>((uint32_t)(c - morphs.data()));
+		}
+		for (auto& m : morphs)
+		{
+			uint32_t kf = 0;
+			for (; kf < forms.size(); ++kf) if (&forms[kf].form == m.kform) break; // linear; dumps are for small models
+			w.put<uint32_t>(kf);
+			w.put<uint8_t>((uint8_t)m.tag); w.put<uint8_t>((uint8_t)m.vowel); w.put<uint8_t>((uint8_t)m.polar);
+			w.put<uint8_t>(m.complex); w.put<uint8_t>(m.saisiot); w.put<uint8_t>(m.senseId); w.put<uint8_t>(m.combineSocket);
+			w.put<int32_t>(m.combined); w.put<float>(m.userScore);
+			w.put<uint32_t>(m.lmMorphemeId); w.put<uint32_t>(m.origMorphemeId); w.put<uint16_t>((uint16_t)m.dialect);
+			w.put<uint32_t>((uint32_t)m.chunks.size());
+			for (size_t c = 0; c < m.chunks.size(); ++c)
+			{
+				w.put<uint32_t>((uint32_t)(m.chunks[c] - morphs.data()));
+				w.put<uint8_t>(m.chunks.getSecond(c).first); w.put<uint8_t>(m.chunks.getSecond(c).second);
+			}
+		}
+		for (auto v : Acc::specialMorphs(kw)) w.put<uint32_t>((uint32_t)v);
+		return w.need;
+	}
+
+	// One Knlm step through the reference (src/Knlm.cpp:44-130). node in/out, returns ll.
+	float kref_lm_progress(void* hp, int32_t* node, uint32_t wid)
+	{
+		auto* lm = dynamic_cast<const kiwi::lm::KnLangModelBase*>(Acc::lm(((RefHandle*)hp)->kw));
+		ptrdiff_t n = *node;
+		float ll = lm->progress(n, wid);
+		*node = (int32_t)n;
+		return ll;
+	}
+
+	// Lattice of every chunk of `text` (already raw UTF-16; normalised inside exactly as Kiwi::analyze does,
+	// src/Kiwi.cpp:1028-1030,1095-1117).  Per chunk: {u32 nNodes, u32 splitEnd, nodes{u32 start,end,prev,sibling,
+	// i32 formId, u32 uformLen, u32 uformOff(in normalised str), u32 spaceErrors, f32 typoCost}[]} ; leading u32 nChunks.
+	size_t kref_split(void* hp, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
+	{
+		using namespace kiwi;
+		auto& kw = ((RefHandle*)hp)->kw;
+		KString norm; Vector<uint32_t> pos;
+		normalizeHangulWithPosition((const char16_t*)text, (const char16_t*)text + len, std::back_inserter(norm), std::back_inserter(pos));
+		if (!!((Match)match & Match::normalizeCoda)) normalizeCoda(norm.begin(), norm.end());
+		Writer w{ out, out + cap };
+		uint8_t* countPos = w.p; w.put<uint32_t>(0);
+		uint32_t nChunks = 0;
+		size_t splitEnd = 0;
+		Vector<KGraphNode> nodes;
+		auto& forms = Acc::forms(kw);
+		while (splitEnd < norm.size())
+		{
+			nodes.clear();
+			splitEnd = Acc::split(kw, nodes, U16StringView{ norm.data() + splitEnd, norm.size() - splitEnd }, splitEnd, (Match)match, Acc::config(kw));
+			++nChunks;
+			w.put<uint32_t>((uint32_t)nodes.size());
+			w.put<uint32_t>((uint32_t)splitEnd);
+			for (auto& n : nodes)
+			{
+				w.put<uint32_t>(n.startPos); w.put<uint32_t>(n.endPos); w.put<uint32_t>(n.prev); w.put<uint32_t>(n.sibling);
+				w.put<int32_t>(n.form ? (int32_t)(n.form - forms.data()) : -1);
+				w.put<uint32_t>((uint32_t)n.uform.size());
+				w.put<uint32_t>(n.uform.empty() ? 0 : (uint32_t)(n.uform.data() - norm.data()));
+				w.put<uint32_t>(n.spaceErrors);
+				w.put<float>(n.typoCost);
+			}
+		}
+		if (!w.overflow || countPos + 4 <= out + cap) std::memcpy(countPos, &nChunks, 4);
+		return w.need;
+	}
+
+	static void writeResults(Writer& w, const std::vector<kiwi::TokenResult>& res, const kiwi::Kiwi& kw)
+	{
+		auto& morphs = Acc::morphemes(kw);
+		w.put<uint32_t>((uint32_t)res.size());
+		for (auto& r : res)
+		{
+			w.put<float>(r.second);
+			w.put<uint32_t>((uint32_t)r.first.size());
+			for (auto& t : r.first)
+			{
+				w.putStr(t.str);
+				w.put<uint32_t>(t.position); w.put<uint32_t>(t.wordPosition); w.put<uint32_t>(t.sentPosition); w.put<uint32_t>(t.lineNumber);
+				w.put<uint16_t>(t.length); w.put<uint8_t>((uint8_t)t.tag); w.put<uint8_t>(t.senseId);
+				w.put<float>(t.score); w.put<float>(t.typoCost); w.put<uint32_t>(t.typoFormId); w.put<uint32_t>(t.pairedToken);
+				w.put<uint32_t>(t.subSentPosition); w.put<uint16_t>((uint16_t)t.dialect);
+				w.put<int32_t>(t.morph ? (int32_t)(t.morph - morphs.data()) : -1);
+			}
+		}
+	}
+
+	// Kiwi::analyze (src/Kiwi.cpp:1014-1158) on one text.  Returns bytes needed.
+	size_t kref_analyze(void* hp, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
+	{
+		auto& kw = ((RefHandle*)hp)->kw;
+		Writer w{ out, out + cap };
+		try
+		{
+			kiwi::AnalyzeOption opt{ (kiwi::Match)match };
+			opt.openEnding = !!openEnding;
+			auto res = kw.analyze(std::u16string{ (const char16_t*)text, (const char16_t*)text + len }, topN, opt);
+			writeResults(w, res, kw);
+		}
+		catch (const std::exception& e)
+		{
+			fprintf(stderr, "kref_analyze: %s\n", e.what());
+			return 0;
+		}
+		return w.need;
+	}
+
+	// CPU baseline: the reference analysing a batch with `threads` worker threads, like
+	// Kiwi::analyze(topN, reader, receiver) does with its pool (include/kiwi/Kiwi.h:402-454).
+	// texts are concatenated UTF-16 with offsets[n+1]. Returns wall seconds; *tokensOut = total top-1 tokens.
+	double kref_analyze_batch(void* hp, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut)
+	{
+		auto& kw = ((RefHandle*)hp)->kw;
+		std::atomic<uint32_t> next{ 0 };
+		std::atomic<uint64_t> tokens{ 0 };
+		auto work = [&]()
+		{
+			kiwi::AnalyzeOption opt{ (kiwi::Match)match };
+			uint64_t local = 0;
+			for (;;)
+			{
+				uint32_t i = next.fetch_add(1);
+				if (i >= n) break;
+				auto res = kw.analyze(std::u16string{ (const char16_t*)texts + offsets[i], (const char16_t*)texts + offsets[i + 1] }, topN, opt);
+				local += res[0].first.size();
+			}
+			tokens += local;
+		};
+		auto t0 = std::chrono::steady_clock::now();
+		if (threads <= 1) work();
+		else
+		{
+			std::vector<std::thread> ts;
+			for (int t = 0; t < threads; ++t) ts.emplace_back(work);
+			for (auto& t : ts) t.join();
+		}
+		auto t1 = std::chrono::steady_clock::now();
+		if (tokensOut) *tokensOut = tokens.load();
+		return std::chrono::duration<double>(t1 - t0).count();
+	}
+}

@@ -1,0 +1,145 @@
+"""TEST INFRASTRUCTURE: ctypes access to oracle/_ref/libkiwi_ref.so (the real reference TUs,
+see oracle/ref_bridge.cpp).  Only tests/, bench.py's cpu_baseline leg and the golden-vector
+generator import this."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_ref", "libkiwi_ref.so")
+
+MATCH_ALL = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 23)
+MATCH_ALL_WITH_NORMALIZING = MATCH_ALL | (1 << 16)
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+@dataclass
+class Token:
+    form: str
+    tag: int
+    position: int
+    length: int
+    word_position: int
+    sent_position: int
+    line_number: int
+    sense_id: int
+    score: float
+    typo_cost: float
+    typo_form_id: int
+    paired_token: int
+    sub_sent_position: int
+    dialect: int
+    morph_id: int
+
+
+class _Reader:
+    def __init__(self, buf):
+        self.b = buf
+        self.o = 0
+
+    def get(self, fmt):
+        v = struct.unpack_from("<" + fmt, self.b, self.o)
+        self.o += struct.calcsize("<" + fmt)
+        return v if len(v) > 1 else v[0]
+
+    def str16(self):
+        n = self.get("I")
+        s = bytes(self.b[self.o:self.o + 2 * n]).decode("utf-16-le", errors="surrogatepass")
+        self.o += 2 * n
+        return s
+
+
+def parse_results(buf) -> list:
+    r = _Reader(buf)
+    out = []
+    for _ in range(r.get("I")):
+        score = r.get("f")
+        toks = []
+        for _ in range(r.get("I")):
+            form = r.str16()
+            pos, wpos, spos, line = r.get("IIII")
+            length, tag, sense = r.get("HBB")
+            sc, tc, tfid, paired, subsent, dialect, mid = r.get("ffIIIHi")
+            toks.append(Token(form, tag, pos, length, wpos, spos, line, sense, sc, tc, tfid, paired, subsent, dialect, mid))
+        out.append((toks, score))
+    return out
+
+
+class RefKiwi:
+    def __init__(self, raw_model_path: str, arch: int = 0):
+        self.lib = C.CDLL(LIB_PATH)
+        L = self.lib
+        L.kref_open.restype = C.c_void_p
+        L.kref_open.argtypes = [C.c_char_p, C.c_int]
+        L.kref_close.argtypes = [C.c_void_p]
+        L.kref_set_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.kref_dump_dict.restype = C.c_size_t
+        L.kref_dump_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.kref_lm_progress.restype = C.c_float
+        L.kref_lm_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32]
+        L.kref_split.restype = C.c_size_t
+        L.kref_split.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t]
+        L.kref_analyze.restype = C.c_size_t
+        L.kref_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
+        L.kref_analyze_batch.restype = C.c_double
+        L.kref_analyze_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+        self.h = L.kref_open(raw_model_path.encode(), arch)
+        if not self.h:
+            raise RuntimeError("kref_open failed")
+        self._buf = np.zeros(1 << 20, np.uint8)
+
+    def close(self):
+        if self.h:
+            self.lib.kref_close(self.h)
+            self.h = None
+
+    def _call(self, fn, *args):
+        while True:
+            need = fn(*args, self._buf.ctypes.data, self._buf.nbytes)
+            if need <= self._buf.nbytes:
+                return self._buf[:need]
+            self._buf = np.zeros(int(need * 1.5), np.uint8)
+
+    def set_config(self, cut_off=8.0, space_penalty=7.0, typo_cost_weight=6.0, max_unk=6, max_unk_j=0xFFFFFFFF, space_tol=0, integrate_allomorph=True):
+        self.lib.kref_set_config(self.h, cut_off, space_penalty, typo_cost_weight, max_unk, max_unk_j, space_tol, int(integrate_allomorph))
+
+    def analyze(self, text: str, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING, open_ending=False):
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        buf = self._call(lambda *a: self.lib.kref_analyze(self.h, u.ctypes.data, len(u), top_n, match, int(open_ending), *a))
+        return parse_results(buf)
+
+    def split(self, text: str, match: int = MATCH_ALL_WITH_NORMALIZING):
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        buf = self._call(lambda *a: self.lib.kref_split(self.h, u.ctypes.data, len(u), match, *a))
+        r = _Reader(buf)
+        chunks = []
+        for _ in range(r.get("I")):
+            n, split_end = r.get("II")
+            nodes = [r.get("IIIIiIIIf") for _ in range(n)]
+            chunks.append((split_end, nodes))
+        return chunks
+
+    def lm_progress(self, node: int, wid: int):
+        n = C.c_int32(node)
+        ll = self.lib.kref_lm_progress(self.h, C.byref(n), wid)
+        return float(ll), int(n.value)
+
+    def dump_dict(self) -> bytes:
+        return bytes(self._call(lambda *a: self.lib.kref_dump_dict(self.h, *a)))
+
+    def analyze_batch(self, texts: list, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, threads=1):
+        enc = [np.frombuffer(t.encode("utf-16-le", errors="surrogatepass"), np.uint16) for t in texts]
+        offs = np.zeros(len(enc) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(e) for e in enc])
+        flat = np.concatenate(enc) if enc else np.zeros(0, np.uint16)
+        ntok = C.c_uint64(0)
+        sec = self.lib.kref_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(enc), top_n, match, threads, C.byref(ntok))
+        return float(sec), int(ntok.value)
