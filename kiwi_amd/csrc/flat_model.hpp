@@ -1,0 +1,163 @@
+// Flat ("baked") model: every pointer of the reference's in-memory Kiwi object replaced by an index,
+// laid out as plain arrays that are uploaded verbatim to HBM.
+//   forms/morphemes : /root/reference/include/kiwi/Form.h:142-257 (Morpheme 40 B, Form 56 B, pointer-rich)
+//   form trie       : /root/reference/include/kiwi/FrozenTrie.h:69-158 (Aho-Corasick automaton)
+//   Knlm            : /root/reference/include/kiwi/Knlm.h:17-24 + src/Knlm.hpp:1003-1167
+// The same POD views (DeviceModel) are used by the HIP kernels and, with host pointers, by host code.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "kchars.hpp"
+
+namespace kamd
+{
+	// ---- form record (16 B) ---------------------------------------------------------------------
+	enum FormFlag : uint8_t
+	{
+		FF_ZCODA_APPENDABLE = 1, FF_ZSIOT_APPENDABLE = 2, FF_HAS_JCLASS = 4, FF_HAS_ANY_FULL = 8,
+		FF_FIRST_IS_CODA = 16,   // isHangulCoda(form[0])            (KTrie.cpp:969)
+		FF_IS_STAG = 32,         // single special char sf..sw        (KTrie.cpp:971-972)
+		FF_STARTS_WITH_A = 64,   // form[0] == U+C544 '아'            (PathEvaluator.hpp:104)
+	};
+	struct FormRec
+	{
+		uint32_t candOff;    // into formCand[]
+		uint32_t charOff;    // into formChars[] (form string incl. spaces)
+		uint16_t candCnt;
+		uint8_t len;         // form.size()
+		uint8_t numSpaces;
+		uint8_t flags;
+		uint8_t vowel, polar, formHash;
+	};
+	static_assert(sizeof(FormRec) == 16, "FormRec");
+
+	// ---- morpheme record (32 B) -----------------------------------------------------------------
+	enum MorphFlag : uint16_t
+	{
+		MF_COMPLEX = 1, MF_SAISIOT = 2, MF_SINGLE = 4,      // Form.h:163-174
+		MF_HAS_COMPLEX = 8,                                 // Morpheme::hasComplex (Form.h:176-185)
+		MF_KFORM_EMPTY = 16,
+		// current-morpheme side of RuleBasedScorer (PathEvaluator.hpp:88-109)
+		MF_VOWEL_E = 32, MF_INF_J = 64, MF_BAD_PAIR_OF_L = 128, MF_CONTRACTABLE_E = 256,
+		// "하다/하게/하지" contraction guard (PathEvaluator.hpp:436-446)
+		MF_HA_CONTRACTION = 512,
+		MF_ENDS_WITH_SSC = 1024,                            // identifySpecialChr(kform.back()) == ssc (PathEvaluator.hpp:289)
+		MF_FIRST_WID_IS_P = 2048,                           // morphBase[firstWid].tag == P (PathEvaluator.hpp:604)
+		MF_ANY_REST_WID_IS_P = 4096,                        // any chunk i>=1 has tag P (PathEvaluator.hpp:616)
+		MF_IN_VOCAB_LAST = 8192,                            // lastMorph index < langVocabSize (PathEvaluator.hpp:551-558)
+	};
+	enum PrevFlag : uint8_t   // previous-morpheme side of RuleBasedScorer (PathEvaluator.hpp:111-181)
+	{
+		PF_IRREGULAR = 1, PF_INFLECTENDA_NP = 2, PF_VERB_L = 4, PF_POSITIVE_VERB = 8, PF_VERB_VOWEL = 16,
+		PF_VA_OR_XSA = 32, PF_E_NOT_EF = 64, PF_UNK_EF_SF = 128,
+	};
+	struct MorphRec
+	{
+		uint32_t lmId;        // lmMorphemeId; the first LM id fed is lmId (single) or chunkLm[chunkOff] (PathEvaluator.hpp:537-548)
+		uint32_t lastSeqId;   // wid recorded on the path (PathEvaluator.hpp:550-558)
+		uint32_t chunkOff;    // into chunkMorph[] / chunkLm[] / chunkPos[]
+		float userScore;
+		int32_t combinedId;   // absolute id of getCombined()
+		uint16_t flags;       // MorphFlag
+		uint16_t feat;        // left-feature mask of kform: bit v = isMatched(kform, CondVowel v), bit 9+p = CondPolarity p
+		uint8_t tag, vowel, polar, socket;
+		uint8_t nChunks, senseId, prevFlags, special;   // special: SpecialMorph (0..5) or 6 ; sbType in sbInfo[]
+	};
+	static_assert(sizeof(MorphRec) == 32, "MorphRec");
+
+	struct TrieNodeRec
+	{
+		uint32_t edgeOff;
+		uint16_t numNexts, depth;
+		int32_t fail;        // absolute node index, -1 for root
+		int32_t value;       // form id, TRIE_NONE, or TRIE_SUBMATCH
+	};
+	static_assert(sizeof(TrieNodeRec) == 16, "TrieNodeRec");
+	constexpr int32_t TRIE_NONE = -1, TRIE_SUBMATCH = -2;
+
+	struct LmNodeRec
+	{
+		uint32_t nextOff, numNexts;
+		int32_t lower;       // relative, as in the reference
+		float ll, gamma;
+	};
+	static_assert(sizeof(LmNodeRec) == 20, "LmNodeRec");
+
+	struct ModelHeader
+	{
+		uint32_t nForms, nMorphs, vocabSize, nTrieNodes, nTrieEdges, nLmNodes, nLmEdges;
+		int32_t bosNode;
+		float unkLl;
+		uint32_t specialMorph[6];
+		uint32_t maxFormLen;
+		uint32_t lmOrder;
+	};
+
+	// Pointers into one arena (host or device).
+	struct ModelView
+	{
+		ModelHeader h;
+		const FormRec* forms;
+		const uint16_t* formChars;
+		const uint32_t* formCand;
+		const MorphRec* morphs;
+		const uint32_t* chunkMorph;   // chunk morpheme ids
+		const uint32_t* chunkLm;      // chunks[i]->lmMorphemeId
+		const uint8_t* chunkPos;      // (begin,end) pairs
+		const uint8_t* sbInfo;        // per morph: sbType (0 for non-SB), see getSBType (src/Utils.cpp:264-298)
+		const TrieNodeRec* trie;
+		const uint16_t* trieKeys;     // sorted per node
+		const uint32_t* trieChild;    // absolute
+		const uint32_t* trieRoot;     // direct table [65536]: child of the root for each UTF-16 unit, 0 if none
+		const LmNodeRec* lmNodes;
+		const uint32_t* lmKeys;       // sorted per node
+		const int32_t* lmValues;      // >0 relative child offset, <=0 leaf ll float bits
+		const int32_t* lmRoot;        // all_value_data: direct table [vocab]
+	};
+
+	// Host-side owner.
+	struct FlatModel
+	{
+		ModelHeader h{};
+		std::vector<FormRec> forms;
+		std::vector<uint16_t> formChars;
+		std::vector<uint32_t> formCand;
+		std::vector<MorphRec> morphs;
+		std::vector<uint32_t> chunkMorph, chunkLm;
+		std::vector<uint8_t> chunkPos;
+		std::vector<uint8_t> sbInfo;
+		std::vector<uint32_t> morphKform;    // form id of each morpheme's kform (host-side result building)
+		std::vector<uint8_t> morphSenseDialect;
+		std::vector<TrieNodeRec> trie;
+		std::vector<uint16_t> trieKeys;
+		std::vector<uint32_t> trieChild;
+		std::vector<uint32_t> trieRoot;
+		std::vector<LmNodeRec> lmNodes;
+		std::vector<uint32_t> lmKeys;
+		std::vector<int32_t> lmValues;
+		std::vector<int32_t> lmRoot;
+
+		ModelView view() const
+		{
+			ModelView v;
+			v.h = h;
+			v.forms = forms.data(); v.formChars = formChars.data(); v.formCand = formCand.data();
+			v.morphs = morphs.data(); v.chunkMorph = chunkMorph.data(); v.chunkLm = chunkLm.data(); v.chunkPos = chunkPos.data();
+			v.sbInfo = sbInfo.data();
+			v.trie = trie.data(); v.trieKeys = trieKeys.data(); v.trieChild = trieChild.data(); v.trieRoot = trieRoot.data();
+			v.lmNodes = lmNodes.data(); v.lmKeys = lmKeys.data(); v.lmValues = lmValues.data(); v.lmRoot = lmRoot.data();
+			return v;
+		}
+
+		std::u16string formStr(uint32_t f) const
+		{
+			return std::u16string{ (const char16_t*)formChars.data() + forms[f].charOff, forms[f].len };
+		}
+	};
+
+	// model.cpp
+	void bakeModel(FlatModel& out, const std::string& rawModelPath);
+	// serialises the baked dictionary in the layout of oracle/ref_bridge.cpp:kref_dump_dict (tests compare both)
+	std::vector<uint8_t> dumpDict(const FlatModel& m);
+}

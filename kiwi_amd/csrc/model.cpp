@@ -1,0 +1,536 @@
+// Host-side model baker: raw model (what the reference's KiwiBuilder holds before build()) -> FlatModel.
+// Reproduces the observable result of KiwiBuilder::build() for a typo-free, standard-dialect build
+// (/root/reference/src/KiwiBuilder.cpp:2385-2640): form ordering and formHash (:2445-2455), per-form
+// reductions (:2478-2507), the form trie in creation order (include/kiwi/Trie.hpp:444-470) frozen into an
+// Aho-Corasick automaton (src/FrozenTrie.hpp:95-154), and the Knlm load-time expansion
+// (src/Knlm.hpp:1003-1167).  Everything is index based; nothing here is shared with oracle/_ref.
+#include <algorithm>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <numeric>
+#include <stdexcept>
+
+#include "flat_model.hpp"
+#include "raw_model.hpp"
+#include "hostutil.hpp"
+#include "feature.hpp"
+
+namespace kamd
+{
+	namespace
+	{
+		struct BuildNode
+		{
+			std::map<uint16_t, uint32_t> next;
+			int32_t val = TRIE_NONE;
+			uint16_t depth = 0;
+		};
+
+		uint8_t reduceVowel(uint8_t v, uint8_t mv) // KiwiBuilder.cpp:2258-2278
+		{
+			if (v == mv) return v;
+			if (CV_VOWEL <= v && v <= CV_VOCALIC_H)
+			{
+				if (CV_VOWEL <= mv && mv <= CV_VOCALIC_H) return std::max(v, mv);
+				return CV_NONE;
+			}
+			if (CV_NON_VOWEL <= v && v <= CV_NON_VOCALIC_H)
+			{
+				if (CV_NON_VOWEL <= mv && mv <= CV_NON_VOCALIC_H) return std::min(v, mv);
+				return CV_NONE;
+			}
+			return CV_NONE;
+		}
+
+		struct KnlmHeader // include/kiwi/Knlm.h:9-15
+		{
+			uint64_t num_nodes, node_offset, key_offset, ll_offset, gamma_offset, qtable_offset, htx_offset;
+			uint64_t unk_id, bos_id, eos_id, vocab_size;
+			uint8_t order, key_size, diff_size, quantized;
+			uint32_t extra_buf_size;
+		};
+
+		bool lmSearch(const FlatModel& m, const LmNodeRec& n, uint32_t key, int32_t& v)
+		{
+			const uint32_t* k = m.lmKeys.data() + n.nextOff;
+			const uint32_t* e = k + n.numNexts;
+			const uint32_t* it = std::lower_bound(k, e, key);
+			if (it == e || *it != key) return false;
+			v = m.lmValues[n.nextOff + (it - k)];
+			return true;
+		}
+
+		float lmValueAsFloat(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
+
+		// KnLangModel::progress (src/Knlm.cpp:44-130), host copy used only while baking (bos node)
+		float lmProgressHost(const FlatModel& m, int32_t& node, uint32_t next)
+		{
+			float acc = 0;
+			for (;;)
+			{
+				int32_t v;
+				const LmNodeRec* n = &m.lmNodes[node];
+				if (node == 0)
+				{
+					v = m.lmRoot[next];
+					if (v == 0) return acc + m.h.unkLl;
+				}
+				else if (!lmSearch(m, *n, next, v))
+				{
+					acc += n->gamma;
+					node += n->lower;
+					continue;
+				}
+				if (v > 0) { node += v; return acc + m.lmNodes[node].ll; }
+				int32_t cur = node;
+				while (m.lmNodes[cur].lower)
+				{
+					cur += m.lmNodes[cur].lower;
+					int32_t lv;
+					if (lmSearch(m, m.lmNodes[cur], next, lv) && lv > 0) { node = cur + lv; return acc + lmValueAsFloat(v); }
+				}
+				node = 0;
+				return acc + lmValueAsFloat(v);
+			}
+		}
+
+		float lmGetLL(const FlatModel& m, int32_t node, uint32_t next) // src/Knlm.cpp:10-42
+		{
+			int32_t v;
+			const LmNodeRec& n = m.lmNodes[node];
+			if (node == 0)
+			{
+				v = m.lmRoot[next];
+				if (v == 0) return m.h.unkLl;
+			}
+			else if (!lmSearch(m, n, next, v)) return n.gamma + lmGetLL(m, node + n.lower, next);
+			if (v > 0) return m.lmNodes[node + v].ll;
+			return lmValueAsFloat(v);
+		}
+
+		void loadKnlm(FlatModel& m, const uint8_t* blob, size_t size)
+		{
+			if (size < sizeof(KnlmHeader)) throw std::runtime_error{ "knlm: truncated header" };
+			KnlmHeader hd;
+			std::memcpy(&hd, blob, sizeof(hd));
+			if (hd.quantized) throw std::runtime_error{ "knlm: quantised/compressed language models are not supported by this loader yet" };
+			if (hd.htx_offset) throw std::runtime_error{ "knlm: history-transformed language models are not supported by this loader yet" };
+			if (hd.key_size != 2 && hd.key_size != 4) throw std::runtime_error{ "knlm: unsupported key size" };
+			const size_t nNodes = hd.num_nodes;
+			auto keyAt = [&](uint64_t off, size_t i) -> uint32_t
+			{
+				if (hd.key_size == 2) { uint16_t v; std::memcpy(&v, blob + off + 2 * i, 2); return v; }
+				uint32_t v; std::memcpy(&v, blob + off + 4 * i, 4); return v;
+			};
+			size_t nonLeaf = 0, leaf = 0;
+			for (size_t i = 0; i < nNodes; ++i) (keyAt(hd.node_offset, i) ? nonLeaf : leaf)++;
+			const size_t nKeys = (hd.ll_offset - hd.key_offset) / hd.key_size;
+			m.lmKeys.resize(nNodes ? nNodes - 1 : 0);
+			if (nKeys < m.lmKeys.size()) throw std::runtime_error{ "knlm: key section too small" };
+			for (size_t i = 0; i < m.lmKeys.size(); ++i) m.lmKeys[i] = keyAt(hd.key_offset, i);
+			const float* ll = (const float*)(blob + hd.ll_offset);
+			const float* gamma = (const float*)(blob + hd.gamma_offset);
+			const float* leafLl = ll + nonLeaf;
+
+			m.lmNodes.assign(nonLeaf, LmNodeRec{});
+			m.lmValues.assign(nNodes - 1, 0);
+			m.lmRoot.assign(hd.vocab_size, 0);
+			// pre-order node stream -> non-leaf node table + per-edge values (Knlm.hpp:1089-1122)
+			struct Range { size_t node, cur, end; };
+			std::vector<Range> st;
+			size_t ni = 0, li = 0, nextOff = 0;
+			for (size_t i = 0; i < nNodes; ++i)
+			{
+				const uint32_t sz = keyAt(hd.node_offset, i);
+				if (sz)
+				{
+					if (!st.empty()) m.lmValues[st.back().cur] = (int32_t)(ni - st.back().node);
+					auto& n = m.lmNodes[ni];
+					n.numNexts = sz; n.nextOff = (uint32_t)nextOff; n.ll = ll[ni]; n.gamma = gamma[ni];
+					st.push_back(Range{ ni, nextOff, nextOff + sz });
+					nextOff += sz;
+					++ni;
+				}
+				else
+				{
+					if (st.empty()) throw std::runtime_error{ "knlm: malformed node stream" };
+					std::memcpy(&m.lmValues[st.back().cur], &leafLl[li], 4);
+					st.back().cur++;
+					while (st.back().cur == st.back().end)
+					{
+						st.pop_back();
+						if (st.empty()) break;
+						st.back().cur++;
+					}
+					++li;
+				}
+			}
+			for (uint32_t i = 0; i < m.lmNodes[0].numNexts; ++i) m.lmRoot[m.lmKeys[i]] = m.lmValues[i];
+
+			m.h.nLmNodes = (uint32_t)nonLeaf;
+			m.h.nLmEdges = (uint32_t)m.lmKeys.size();
+			m.h.lmOrder = hd.order;
+			m.h.unkLl = 0;
+			m.h.unkLl = lmGetLL(m, 0, (uint32_t)hd.unk_id);   // Knlm.hpp:1147
+			// suffix ("lower") links by BFS (Knlm.hpp:38-63, 1153-1166)
+			std::deque<uint32_t> dq{ 0u };
+			while (!dq.empty())
+			{
+				const uint32_t p = dq.front(); dq.pop_front();
+				const LmNodeRec pn = m.lmNodes[p];
+				for (uint32_t i = 0; i < pn.numNexts; ++i)
+				{
+					const int32_t v = m.lmValues[pn.nextOff + i];
+					if (v <= 0) continue;
+					const uint32_t k = m.lmKeys[pn.nextOff + i];
+					const uint32_t child = p + v;
+					uint32_t node = p;
+					while (m.lmNodes[node].lower)
+					{
+						const uint32_t low = node + m.lmNodes[node].lower;
+						int32_t found;
+						if (lmSearch(m, m.lmNodes[low], k, found)) { node = low + found; goto done; }
+						node = low;
+					}
+				done:
+					m.lmNodes[child].lower = (int32_t)node - (int32_t)child;
+					dq.push_back(child);
+				}
+			}
+			int32_t bos = 0;
+			lmProgressHost(m, bos, (uint32_t)hd.bos_id);  // Knlm.hpp:1148-1149 (links are still zero there too)
+			m.h.bosNode = bos;
+		}
+	}
+
+	void bakeModel(FlatModel& m, const std::string& path)
+	{
+		Container file;
+		file.load(path);
+		RawModel raw;
+		raw.bind(file);
+		const size_t nF = raw.nForms(), nM = raw.nMorphs();
+		if (nF < kDefaultFormSize) throw std::runtime_error{ "raw model: missing default forms" };
+
+		std::vector<U16> rawForm(nF);
+		for (size_t i = 0; i < nF; ++i) rawForm[i].assign((const char16_t*)raw.formChars + raw.formPtr[i], (const char16_t*)raw.formChars + raw.formPtr[i + 1]);
+		auto rawTag = [&](uint32_t mi) { return raw.morph[mi].tag; };
+
+		// ---- form order: defaults fixed, the rest sorted by (string ignoring spaces, original index) ------
+		std::vector<uint32_t> order(nF);
+		std::iota(order.begin(), order.end(), 0u);
+		std::sort(order.begin() + kDefaultFormSize, order.end(), [&](uint32_t a, uint32_t b)
+		{
+			const int c = cmpIgnoringSpace(rawForm[a], rawForm[b]);
+			if (c == -1) return true;
+			if (cmpIgnoringSpace(rawForm[b], rawForm[a]) == -1) return false;
+			return a < b;
+		});
+		std::vector<uint32_t> newId(nF);
+		for (size_t i = 0; i < nF; ++i) newId[order[i]] = (uint32_t)i;
+
+		// ---- morphemes -----------------------------------------------------------------------------------
+		m.morphs.assign(nM, MorphRec{});
+		m.morphKform.resize(nM);
+		m.sbInfo.assign(nM, 0);
+		std::vector<uint8_t> complexRaw(nM);
+		for (size_t i = 0; i < nM; ++i)
+		{
+			const RawMorph& r = raw.morph[i];
+			MorphRec& o = m.morphs[i];
+			o.lmId = r.lmId; o.userScore = r.userScore; o.combinedId = (int32_t)i + r.combined;
+			o.tag = r.tag; o.vowel = r.vpPack & 0xF; o.polar = (r.vpPack >> 4) & 0x3; // Morpheme::polar is a 2-bit field (Form.h:147)
+			o.socket = r.socket; o.senseId = r.senseId; o.nChunks = r.nChunks;
+			o.chunkOff = (uint32_t)m.chunkMorph.size();
+			complexRaw[i] = (r.vpPack & 0x80) ? 1 : 0;
+			bool hasSaisiot = false;
+			for (size_t c = 0; c < r.nChunks; ++c)
+			{
+				const uint32_t cm = raw.chunkIds[r.chunkPtr + c];
+				m.chunkMorph.push_back(cm);
+				m.chunkLm.push_back(raw.morph[cm].lmId);
+				m.chunkPos.push_back(raw.chunkPos[(r.chunkPtr + c) * 2]);
+				m.chunkPos.push_back(raw.chunkPos[(r.chunkPtr + c) * 2 + 1]);
+				hasSaisiot = hasSaisiot || rawTag(cm) == T_Z_SIOT;
+			}
+			if (complexRaw[i] && !hasSaisiot) o.flags |= MF_COMPLEX;   // src/Form.cpp:135-137
+			if (complexRaw[i] && hasSaisiot) o.flags |= MF_SAISIOT;
+			if (r.nChunks == 0 || (o.flags & (MF_COMPLEX | MF_SAISIOT))) o.flags |= MF_SINGLE;
+			m.morphKform[i] = newId[r.kform];
+			if (r.dialect) throw std::runtime_error{ "raw model: dialect morphemes are not supported yet" };
+		}
+		const uint32_t vocab = (uint32_t)raw.vocabSize();
+		for (size_t i = 0; i < nM; ++i)
+		{
+			MorphRec& o = m.morphs[i];
+			const U16& kf = rawForm[raw.morph[i].kform];
+			const uint8_t tag = o.tag;
+			// hasComplex (Form.h:176-185)
+			bool hc = (m.morphs[o.combinedId].flags & MF_COMPLEX) != 0;
+			for (uint32_t c = 0; c < o.nChunks; ++c) hc = hc || (m.morphs[m.chunkMorph[o.chunkOff + c]].flags & MF_COMPLEX);
+			if (hc) o.flags |= MF_HAS_COMPLEX;
+			if (kf.empty()) o.flags |= MF_KFORM_EMPTY;
+			o.feat = featMask((const uint16_t*)kf.data(), (uint32_t)kf.size());
+			if (!kf.empty() && identifySpecialChr(kf.back()) == T_SSC) o.flags |= MF_ENDS_WITH_SSC;
+			const uint16_t f0 = kf.empty() ? 0 : kf[0];
+			if (isEClass(tag) && 0xC544 <= f0 && f0 <= 0xC774) o.flags |= MF_VOWEL_E;            // hasNoOnset: '아'..'이'
+			if ((tag == T_JKS || tag == T_JKC) && kf.size() == 1 && f0 == 0xAC00) o.flags |= MF_INF_J; // '가'
+			if (f0 == 0xC73C || f0 == 0xB290 || (0xC0AC <= f0 && f0 <= 0xC2DC)) o.flags |= MF_BAD_PAIR_OF_L; // '으','느','사'..'시'
+			if (isEClass(tag) && f0 == 0xC5B4) o.flags |= MF_CONTRACTABLE_E;                     // '어'
+			// first / last LM ids (PathEvaluator.hpp:537-558)
+			uint32_t lastMorph, firstWid;
+			if (o.flags & MF_SINGLE) { lastMorph = (uint32_t)o.combinedId; firstWid = o.lmId; }
+			else { lastMorph = m.chunkMorph[o.chunkOff + o.nChunks - 1]; firstWid = m.chunkLm[o.chunkOff]; }
+			o.lastSeqId = lastMorph >= vocab ? lastMorph : raw.morph[lastMorph].lmId;
+			if (lastMorph < vocab) o.flags |= MF_IN_VOCAB_LAST;
+			if (firstWid < nM && raw.morph[firstWid].tag == T_P) o.flags |= MF_FIRST_WID_IS_P;
+			for (uint32_t c = 1; c < o.nChunks; ++c)
+			{
+				const uint32_t w = m.chunkLm[o.chunkOff + c];
+				if (w < nM && raw.morph[w].tag == T_P) o.flags |= MF_ANY_REST_WID_IS_P;
+			}
+			if (!(o.flags & MF_SINGLE) && kf.size() == 1 && (f0 == 0xB2E4 || f0 == 0xAC8C || f0 == 0xC9C0)) // 다 게 지
+			{
+				const U16& c0 = rawForm[raw.morph[m.chunkMorph[o.chunkOff]].kform];
+				if (c0.size() == 1 && c0[0] == 0xD558) o.flags |= MF_HA_CONTRACTION; // 하
+			}
+			// previous-morpheme predicates (PathEvaluator.hpp:46-83)
+			uint8_t pf = 0;
+			if (isIrregularTag(tag)) pf |= PF_IRREGULAR;
+			if (tag == T_NP && kf.size() == 1 && (f0 == 0xB098 || f0 == 0xB108 || f0 == 0xC800)) pf |= PF_INFLECTENDA_NP; // 나 너 저
+			if (isVerbClass(tag) && !kf.empty() && kf.back() == 0x11AF) pf |= PF_VERB_L;
+			if (isVerbClass(tag) && matchPolar((const uint16_t*)kf.data(), (uint32_t)kf.size(), CP_POSITIVE)) pf |= PF_POSITIVE_VERB;
+			if (isVerbClass(tag) && !kf.empty() && !isHangulCoda(kf.back())) pf |= PF_VERB_VOWEL;
+			if (tag == T_VA || tag == T_XSA) pf |= PF_VA_OR_XSA;
+			if (isEClass(tag) && tag != T_EF) pf |= PF_E_NOT_EF;
+			if (tag == T_UNKNOWN || tag == T_EF || tag == T_SF) pf |= PF_UNK_EF_SF;
+			o.prevFlags = pf;
+			o.special = 6;
+			if (tag == T_SB) m.sbInfo[i] = (uint8_t)getSBType(joinHangul(kf));
+		}
+		// KiwiBuilder::getSpecialMorphs (KiwiBuilder.cpp:2642-2662)
+		for (auto& s : m.h.specialMorph) s = 0;
+		for (size_t i = 0; i < nM; ++i)
+		{
+			const U16& fs = rawForm[raw.morph[i].kform];
+			size_t base;
+			if (fs == u"'") base = 0; else if (fs == u"\"") base = 3; else continue;
+			const uint8_t tag = raw.morph[i].tag;
+			if (tag == T_SSO) m.h.specialMorph[base + 0] = (uint32_t)i;
+			else if (tag == T_SSC) m.h.specialMorph[base + 1] = (uint32_t)i;
+			else if (tag == T_SS) m.h.specialMorph[base + 2] = (uint32_t)i;
+		}
+		// determineSpecialMorphType: first matching slot wins (include/kiwi/Kiwi.h:517-524)
+		for (size_t i = 0; i < nM; ++i)
+			for (int s = 5; s >= 0; --s) if (m.h.specialMorph[s] == i) m.morphs[i].special = (uint8_t)s;
+
+		// ---- forms ---------------------------------------------------------------------------------------
+		m.forms.assign(nF + 1, FormRec{});
+		uint32_t maxLen = 0;
+		for (size_t ni = 0; ni < nF; ++ni)
+		{
+			const uint32_t ri = order[ni];
+			const U16& s = rawForm[ri];
+			if (s.size() > 255) throw std::runtime_error{ "raw model: form longer than 255 units" };
+			FormRec& f = m.forms[ni];
+			f.charOff = (uint32_t)m.formChars.size();
+			f.len = (uint8_t)s.size();
+			f.numSpaces = (uint8_t)std::count(s.begin(), s.end(), u' ');
+			m.formChars.insert(m.formChars.end(), s.begin(), s.end());
+			f.candOff = (uint32_t)m.formCand.size();
+			const uint32_t cb = raw.formCandPtr[ri], ce = raw.formCandPtr[ri + 1];
+			f.candCnt = (uint16_t)(ce - cb);
+			for (uint32_t c = cb; c < ce; ++c) m.formCand.push_back(raw.formCand[c]);
+			maxLen = std::max<uint32_t>(maxLen, f.len - f.numSpaces);
+			// zCoda / zSiot appendable (KiwiBuilder.cpp:2294-2352)
+			if (!s.empty() && isHangulSyllable(s.back()))
+			{
+				bool zc = false, zs = false;
+				for (uint32_t c = cb; c < ce; ++c)
+				{
+					const uint32_t mi = raw.formCand[c];
+					uint8_t tag = rawTag(mi);
+					if (tag == T_UNKNOWN && raw.morph[mi].nChunks) tag = rawTag(raw.chunkIds[raw.morph[mi].chunkPtr + raw.morph[mi].nChunks - 1]);
+					if (isJClass(tag) || isEClass(tag)) zc = true;
+					const uint8_t t2 = rawTag(mi);
+					if (isNNClass(t2) && raw.morph[mi].lmId != (uint32_t)clearIrregular(t2) + 1) zs = true;
+				}
+				if (zc) f.flags |= FF_ZCODA_APPENDABLE;
+				if (zs) f.flags |= FF_ZSIOT_APPENDABLE; // the extra !isHangulCoda(back) test there is implied by isHangulSyllable
+			}
+			if (!s.empty() && isHangulCoda(s[0])) f.flags |= FF_FIRST_IS_CODA;
+			if (s.size() == 1) { const uint8_t t = identifySpecialChr(s[0]); if (T_SF <= t && t <= T_SW) f.flags |= FF_IS_STAG; }
+			if (!s.empty() && s[0] == 0xC544) f.flags |= FF_STARTS_WITH_A;
+		}
+		m.forms[nF].charOff = (uint32_t)m.formChars.size();
+		m.forms[nF].candOff = (uint32_t)m.formCand.size();
+		m.formChars.push_back(0); // keeps &formChars[charOff] valid for the sentinel
+		{
+			uint8_t hash = 0;
+			for (size_t i = 1; i <= nF; ++i)
+			{
+				const U16 a = m.formStr((uint32_t)i), b = m.formStr((uint32_t)i - 1);
+				if (!equalIgnoringSpace(a, b)) ++hash;
+				m.forms[i].formHash = hash;
+			}
+		}
+		// per-form reductions + the list that goes into the trie (KiwiBuilder.cpp:2473-2515)
+		std::vector<uint32_t> sortedForms;
+		for (size_t i = kDefaultFormSize; i < nF; ++i)
+		{
+			FormRec& f = m.forms[i];
+			if (!f.candCnt) continue;
+			const uint32_t* cand = &m.formCand[f.candOff];
+			const MorphRec& c0 = m.morphs[cand[0]];
+			if (c0.vowel != CV_NONE) { uint8_t v = c0.vowel; for (uint32_t c = 0; c < f.candCnt; ++c) v = reduceVowel(v, m.morphs[cand[c]].vowel); f.vowel = v; }
+			if (c0.polar != CP_NONE) { uint8_t p = c0.polar; for (uint32_t c = 0; c < f.candCnt; ++c) p = (p == m.morphs[cand[c]].polar) ? p : (uint8_t)CP_NONE; f.polar = p; }
+			bool hasJ = false, anyFull = false;
+			for (uint32_t c = 0; c < f.candCnt; ++c)
+			{
+				const uint8_t t = m.morphs[cand[c]].tag;
+				hasJ = hasJ || isJClass(t) || t == T_EC || t == T_EF;
+				const uint8_t ct = clearIrregular(t);
+				anyFull = anyFull || (ct != T_UNKNOWN && ct != T_P && ct != T_P + 1);
+			}
+			if (hasJ) f.flags |= FF_HAS_JCLASS;
+			if (anyFull) f.flags |= FF_HAS_ANY_FULL;
+			sortedForms.push_back((uint32_t)i);
+		}
+		{
+			std::vector<U16> strs(nF + 1);
+			for (auto i : sortedForms) strs[i] = m.formStr(i);
+			// same algorithm + same comparator outcomes on the same input order as KiwiBuilder.cpp:2511-2514,
+			// so equal-ignoring-space forms end up in the same relative order.
+			std::sort(sortedForms.begin(), sortedForms.end(), [&](uint32_t a, uint32_t b) { return lessIgnoringSpace(strs[a], strs[b]); });
+		}
+
+		// ---- trie in creation order ----------------------------------------------------------------------
+		std::vector<BuildNode> bn(kDefaultFormSize + 1);
+		for (uint32_t i = 0; i < kDefaultFormSize; ++i) bn[i + 1].val = (int32_t)i;
+		{
+			U16 prev;
+			std::vector<uint32_t> ptrs;
+			for (auto fi : sortedForms)
+			{
+				U16 key;
+				for (auto c : m.formStr(fi)) if (c != u' ') key.push_back(c);
+				size_t common = 0;
+				while (common < std::min(prev.size(), key.size()) && prev[common] == key[common]) ++common;
+				ptrs.resize(key.size());
+				uint32_t node = common ? ptrs[common - 1] : 0;
+				for (size_t i = common; i < key.size(); ++i)
+				{
+					auto it = bn[node].next.find(key[i]);
+					uint32_t child;
+					if (it != bn[node].next.end()) child = it->second;
+					else
+					{
+						child = (uint32_t)bn.size();
+						bn.emplace_back();
+						bn[child].depth = bn[node].depth + 1;
+						bn[node].next[key[i]] = child;
+					}
+					node = child;
+					ptrs[i] = node;
+				}
+				if (bn[node].val == TRIE_NONE) bn[node].val = (int32_t)fi;
+				prev = key;
+			}
+		}
+		const size_t nT = bn.size();
+		m.trie.assign(nT, TrieNodeRec{});
+		m.trieRoot.assign(65536, 0);
+		for (size_t i = 0; i < nT; ++i)
+		{
+			auto& t = m.trie[i];
+			t.edgeOff = (uint32_t)m.trieKeys.size();
+			t.numNexts = (uint16_t)bn[i].next.size();
+			if (bn[i].next.size() > 65535) throw std::runtime_error{ "trie fan-out overflow" };
+			t.depth = bn[i].depth;
+			t.value = bn[i].val;
+			t.fail = -1;
+			for (auto& p : bn[i].next) { m.trieKeys.push_back(p.first); m.trieChild.push_back(p.second); }
+		}
+		for (auto& p : bn[0].next) m.trieRoot[p.first] = p.second;
+		auto findChild = [&](uint32_t node, uint16_t k) -> int64_t
+		{
+			const auto& t = m.trie[node];
+			const uint16_t* kb = m.trieKeys.data() + t.edgeOff;
+			const uint16_t* it = std::lower_bound(kb, kb + t.numNexts, k);
+			if (it == kb + t.numNexts || *it != k) return -1;
+			return m.trieChild[t.edgeOff + (it - kb)];
+		};
+		{
+			std::deque<uint32_t> dq{ 0u };
+			while (!dq.empty())
+			{
+				const uint32_t p = dq.front(); dq.pop_front();
+				const auto pt = m.trie[p];
+				for (uint32_t e = 0; e < pt.numNexts; ++e)
+				{
+					const uint16_t k = m.trieKeys[pt.edgeOff + e];
+					const uint32_t child = m.trieChild[pt.edgeOff + e];
+					// findFail (FrozenTrie.hpp:31-52): first proper suffix state that has an edge k
+					uint32_t n = p; int32_t f = 0;
+					for (;;)
+					{
+						if (m.trie[n].fail < 0) { f = (int32_t)n; break; }   // reached the root: child fails to the root
+						n = (uint32_t)m.trie[n].fail;
+						const int64_t c = findChild(n, k);
+						if (c >= 0) { f = (int32_t)c; break; }
+					}
+					m.trie[child].fail = f;
+					dq.push_back(child);
+				}
+				if (m.trie[p].value == TRIE_NONE)
+				{
+					// FrozenTrie.hpp:144-152 : mark "a proper suffix of this state is (or leads to) a form"
+					for (int32_t n = (int32_t)p; m.trie[n].fail >= 0; n = m.trie[n].fail)
+					{
+						if (m.trie[n].value == TRIE_NONE) continue;
+						m.trie[p].value = TRIE_SUBMATCH;
+						break;
+					}
+				}
+			}
+		}
+
+		m.h.nForms = (uint32_t)nF; m.h.nMorphs = (uint32_t)nM; m.h.vocabSize = vocab;
+		m.h.nTrieNodes = (uint32_t)nT; m.h.nTrieEdges = (uint32_t)m.trieKeys.size();
+		m.h.maxFormLen = maxLen;
+		if (maxLen > 64) throw std::runtime_error{ "dictionary form longer than 64 units: the trie-scan kernel's depth mask is 64 bits" };
+		loadKnlm(m, raw.knlm, raw.knlmSize);
+		if (vocab > m.lmRoot.size()) throw std::runtime_error{ "raw model: vocab larger than LM vocab" };
+	}
+
+	std::vector<uint8_t> dumpDict(const FlatModel& m)
+	{
+		std::vector<uint8_t> out;
+		auto put = [&](const void* p, size_t n) { out.insert(out.end(), (const uint8_t*)p, (const uint8_t*)p + n); };
+		auto put32 = [&](uint32_t v) { put(&v, 4); };
+		auto put16 = [&](uint16_t v) { put(&v, 2); };
+		auto put8 = [&](uint8_t v) { put(&v, 1); };
+		put32(m.h.nForms + 1); put32(m.h.nMorphs);
+		for (uint32_t i = 0; i <= m.h.nForms; ++i)
+		{
+			const FormRec& f = m.forms[i];
+			put32(f.len); put(m.formChars.data() + f.charOff, 2 * f.len);
+			put32(f.numSpaces); put8(f.vowel); put8(f.polar); put8(f.formHash); put8(f.flags & 15); put16(0);
+			put32(f.candCnt);
+			for (uint32_t c = 0; c < f.candCnt; ++c) put32(m.formCand[f.candOff + c]);
+		}
+		for (uint32_t i = 0; i < m.h.nMorphs; ++i)
+		{
+			const MorphRec& o = m.morphs[i];
+			put32(m.morphKform[i]); put8(o.tag); put8(o.vowel); put8(o.polar);
+			put8((o.flags & MF_COMPLEX) ? 1 : 0); put8((o.flags & MF_SAISIOT) ? 1 : 0); put8(o.senseId); put8(o.socket);
+			int32_t comb = o.combinedId - (int32_t)i; put(&comb, 4); put(&o.userScore, 4);
+			put32(o.lmId); put32(0 /* origMorphemeId: not used on the analyze path */); put16(0);
+			put32(o.nChunks);
+			for (uint32_t c = 0; c < o.nChunks; ++c) { put32(m.chunkMorph[o.chunkOff + c]); put8(m.chunkPos[2 * (o.chunkOff + c)]); put8(m.chunkPos[2 * (o.chunkOff + c) + 1]); }
+		}
+		for (auto v : m.h.specialMorph) put32(v);
+		return out;
+	}
+}

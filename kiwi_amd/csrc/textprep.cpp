@@ -1,0 +1,377 @@
+// Host-side text preparation (see textprep.hpp).  Pattern recognisers restate the regular
+// languages documented in /root/reference/src/PatternMatcher.cpp:53-364 as small hand-written scanners.
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+#include "textprep.hpp"
+
+namespace kamd
+{
+	namespace
+	{
+		struct ScriptRange { uint32_t lo, hi; uint8_t id; };
+		struct CpRange { uint32_t lo, hi; };
+#include "unicode_tables.inc"
+
+		template<class R, size_t N>
+		const R* findRange(const R(&tab)[N], uint32_t c)
+		{
+			size_t lo = 0, hi = N;
+			while (lo < hi)
+			{
+				const size_t mid = (lo + hi) / 2;
+				if (tab[mid].hi < c) lo = mid + 1; else hi = mid;
+			}
+			if (lo < N && tab[lo].lo <= c) return &tab[lo];
+			return nullptr;
+		}
+
+		inline bool isAlpha(uint32_t c) { return ('A' <= c && c <= 'Z') || ('a' <= c && c <= 'z'); }
+		inline bool isUpper(uint32_t c) { return 'A' <= c && c <= 'Z'; }
+		inline bool isDigit(uint32_t c) { return ('0' <= c && c <= '9') || (0xff10 <= c && c <= 0xff19); }
+		inline bool isAlnum(uint32_t c) { return isAlpha(c) || ('0' <= c && c <= '9'); }
+		inline bool inSet(uint32_t c, const char* lits) { return c < 128 && c != 0 && std::strchr(lits, (int)c) != nullptr; }
+		inline bool csEmailAccount(uint32_t c) { return isAlnum(c) || inSet(c, "-._%+"); }
+		inline bool csAlnumDotDash(uint32_t c) { return isAlnum(c) || inSet(c, "-."); }
+		inline bool csDomain(uint32_t c) { return isAlnum(c) || inSet(c, "-@:%._+~#="); }
+		inline bool csPath(uint32_t c) { return isAlnum(c) || inSet(c, "-()@:%_+.~#!?&/="); }
+		inline bool csHashtag(uint32_t c) { return !inSet(c, "# \t\n\r\v\f.,()[]<>{}"); }
+		inline bool csSpace(uint32_t c) { return inSet(c, " \t\n\r\v\f"); }
+
+		using P = const char16_t*;
+
+		// domain-ish run ending in ".xx": returns end of the last accepted TLD-like position
+		template<class Set>
+		P scanDomain(P b, P last, P none, Set&& set)
+		{
+			int state = 0;
+			P lastMatched = none;
+			for (; b != last && set(*b); ++b)
+			{
+				if (*b == '.') state = 1;
+				else if (isAlpha(*b))
+				{
+					if (state > 0) ++state;
+					if (state >= 3) lastMatched = b + 1;
+				}
+				else state = 0;
+			}
+			return lastMatched;
+		}
+
+		size_t testUrl(P first, P last)
+		{
+			P b;
+			auto starts = [&](const char* lit) { size_t n = std::strlen(lit); if ((size_t)(last - first) < n) return false; for (size_t i = 0; i < n; ++i) if (first[i] != (char16_t)lit[i]) return false; b = first + n; return true; };
+			if (!starts("http://") && !starts("https://")) return 0;
+			if (b == last || !csDomain(*b)) return 0;
+			++b;
+			P m = scanDomain(b, last, first, csDomain);
+			if (m == first) return 0;
+			b = m;
+			if (b != last && *b == ':')
+			{
+				++b;
+				if (b == last || !isDigit(*b)) return 0;
+				while (b != last && isDigit(*b)) ++b;
+			}
+			if (b != last && *b == '/')
+			{
+				++b;
+				while (b != last && csPath(*b)) ++b;
+			}
+			else if (b != last && !csSpace(*b)) return 0;
+			if (b[-1] == u'.' || b[-1] == u':') --b;
+			return b - first;
+		}
+
+		size_t testEmail(P first, P last)
+		{
+			P b = first;
+			if (b == last || !csEmailAccount(*b)) return 0;
+			while (b != last && csEmailAccount(*b)) ++b;
+			if (b == last || *b != '@') return 0;
+			++b;
+			if (b == last || !csAlnumDotDash(*b)) return 0;
+			++b;
+			return scanDomain(b, last, first, csAlnumDotDash) - first;
+		}
+
+		size_t testMention(P first, P last)
+		{
+			P b = first;
+			if (b == last || *b != '@') return 0;
+			++b;
+			if (b == last || !isAlpha(*b)) return 0;
+			++b;
+			while (b != last && csEmailAccount(*b)) ++b;
+			if (b[-1] == u'.' || b[-1] == u'%' || b[-1] == u'+' || b[-1] == u'-') --b;
+			if (b - first <= 3) return 0;
+			return b - first;
+		}
+
+		size_t testHashtag(P first, P last)
+		{
+			P b = first;
+			if (b == last || *b != '#') return 0;
+			++b;
+			if (b == last || !csHashtag(*b)) return 0;
+			while (b != last && csHashtag(*b)) ++b;
+			return b - first;
+		}
+
+		size_t testNumeric(char16_t left, P first, P last)
+		{
+			P b = first;
+			bool hasComma = false;
+			if (b == last || !isDigit(*b)) return 0;
+			while (b != last && isDigit(*b)) ++b;
+			while (b != last && *b == ',')
+			{
+				++b;
+				if (b + 2 >= last || !isDigit(b[0]) || !isDigit(b[1]) || !isDigit(b[2])) return b - 1 - first;
+				b += 3;
+				hasComma = true;
+			}
+			if (b == last || isSpace(*b) || isHangulSyllable(*b)) return b - first;
+			if (*b == '.')
+			{
+				++b;
+				if (!hasComma && !csAlnumDotDash(left) && (b == last || !csAlnumDotDash(*b))) return b - first;
+				if (b == last || !isDigit(*b)) return b - 1 - first;
+				while (b != last && isDigit(*b)) ++b;
+			}
+			if (b == last || *b != '.') return b - first;
+			return 0;
+		}
+
+		size_t testSerial(P first, P last)
+		{
+			P b = first;
+			if (b == last || !isDigit(*b)) return 0;
+			while (b != last && isDigit(*b)) ++b;
+			if (b == last) return 0;
+			const char16_t sep = *b;
+			if (!(sep == ':' || sep == '.' || sep == '-' || sep == '/')) return 0;
+			++b;
+			if (b != last && *b == ' ') ++b;
+			if (b == last || !isDigit(*b)) return 0;
+			while (b != last && isDigit(*b)) ++b;
+			if (sep == '.' && (b == last || *b != sep)) return 0;
+			while (b != last && *b == sep)
+			{
+				++b;
+				if (b != last && *b == ' ') ++b;
+				if (b == last || !isDigit(*b)) break;
+				while (b != last && isDigit(*b)) ++b;
+			}
+			if (b[-1] == ' ') --b;
+			return b - first;
+		}
+
+		size_t testAbbr(P first, P last)
+		{
+			P b = first;
+			if (b == last || !isAlpha(*b)) return 0;
+			size_t l = 0;
+			while (b != last && isAlpha(*b)) ++b, ++l;
+			if (b == last || *b != '.') return 0;
+			++b;
+			if (b != last && *b == ' ')
+			{
+				if (l > (isUpper(*first) ? 5u : 3u)) return 0;
+				return b - first;
+			}
+			if (l > 5) return 0;
+			while (b != last && isAlpha(*b))
+			{
+				l = 0;
+				while (b != last && isAlpha(*b)) ++b, ++l;
+				if (l > 5) return 0;
+				if (b != last && *b == '.') ++b;
+				else return b - first;
+			}
+			if (b[-1] == ' ') --b;
+			return b - first;
+		}
+
+		size_t testEmoji(P first, P last)
+		{
+			P b = first;
+			while (b + 1 < last)
+			{
+				uint32_t c0, c1 = 0;
+				P b1 = b;
+				if (isHighSurrogate(*b1)) { c0 = mergeSurrogate(b1[0], b1[1]); b1 += 2; }
+				else c0 = *b1++;
+				P b2 = b1;
+				if (b2 < last)
+				{
+					if (isHighSurrogate(*b2) && b2 + 1 < last) { c1 = mergeSurrogate(b2[0], b2[1]); b2 += 2; }
+					else c1 = *b2++;
+				}
+				const int r = isEmoji(c0, c1);
+				if (r == 1) b = b1; else if (r == 2) b = b2; else break;
+				if (b == last) return b - first;
+				if (0xfe00 <= *b && *b <= 0xfe0f)
+				{
+					++b;
+					if (b == last) return b - first;
+				}
+				else if (b + 1 < last && isHighSurrogate(b[0]))
+				{
+					const uint32_t m = mergeSurrogate(b[0], b[1]);
+					if (0x1f3fb <= m && m <= 0x1f3ff)
+					{
+						b += 2;
+						if (b == last) return b - first;
+					}
+				}
+				if (*b == 0x200d) { ++b; continue; }
+				break;
+			}
+			return b - first;
+		}
+	}
+
+	uint8_t chr2ScriptType(uint32_t c)
+	{
+		const ScriptRange* r = findRange(kScriptRanges, c);
+		return r ? r->id : 0;
+	}
+
+	const char* scriptName(uint8_t s) { return s < kScriptCount ? kScriptNames[s] : "Unknown"; }
+
+	int isEmoji(uint32_t c0, uint32_t c1)
+	{
+		if (findRange(kEmoji1, c0)) return 1;
+		if (!(c1 == 0xfe0f || (0x1f3fb <= c1 && c1 <= 0x1f3ff))) return 0;
+		if (findRange(kEmoji2, c0)) return 2;
+		return 0;
+	}
+
+	std::pair<size_t, uint8_t> matchPattern(char16_t left, const char16_t* first, const char16_t* last, uint64_t mo)
+	{
+		size_t n;
+		if ((mo & M_SERIAL) && (n = testSerial(first, last))) return { n, T_W_SERIAL };
+		if ((n = testNumeric(left, first, last))) return { n, T_SN };
+		if ((mo & M_HASHTAG) && (n = testHashtag(first, last))) return { n, T_W_HASHTAG };
+		if ((mo & M_EMAIL) && (n = testEmail(first, last))) return { n, T_W_EMAIL };
+		if ((mo & M_MENTION) && (n = testMention(first, last))) return { n, T_W_MENTION };
+		if ((mo & M_URL) && (n = testUrl(first, last))) return { n, T_W_URL };
+		if ((mo & M_EMOJI) && (n = testEmoji(first, last))) return { n, T_W_EMOJI };
+		if ((n = testAbbr(first, last))) return { n, T_SL };
+		return { 0, T_UNKNOWN };
+	}
+
+	void normalizeWithPosition(const char16_t* s, size_t n, U16& out, std::vector<uint32_t>& pos)
+	{
+		out.clear(); pos.clear();
+		out.reserve(n + n / 2); pos.reserve(n + 1);
+		for (size_t i = 0; i < n; ++i)
+		{
+			char16_t c = s[i];
+			pos.push_back((uint32_t)out.size());
+			if (c == 0xB42C) c = 0xB410;
+			if (0xAC00 <= c && c < 0xD7A4)
+			{
+				const int coda = (c - 0xAC00) % 28;
+				out.push_back((char16_t)(c - coda));
+				if (coda) out.push_back((char16_t)(coda + 0x11A7));
+			}
+			else out.push_back(c);
+		}
+		pos.push_back((uint32_t)out.size());
+	}
+
+	void normalizeCoda(U16& s) // src/StrUtils.h:637-703: "받침 + 같은 초성체" -> merged
+	{
+		static const char16_t toOnset[27] = { 0x3131, 0x3131, 0x3145, 0x3134, 0x3148, 0x314E, 0x3137, 0x3139, 0x3131, 0x3141, 0x3142, 0x3145, 0x314C, 0x314D,
+			0x314E, 0x3141, 0x3142, 0x3145, 0x3145, 0x3145, 0x3147, 0x3148, 0x314A, 0x314B, 0x314C, 0x314D, 0x314E };
+		static const char16_t conv[27] = { 0, 0x11A8, 0x11A8, 0, 0x11AB, 0x11AB, 0, 0, 0x11AF, 0x11AF, 0x11AF, 0x11AF, 0x11AF, 0x11AF, 0x11AF,
+			0, 0, 0x11B8, 0, 0x11BA, 0, 0, 0, 0, 0, 0, 0 };
+		char16_t before = 0;
+		for (size_t i = 0; i < s.size(); ++i)
+		{
+			if (0x11A8 <= before && before <= 0x11C2)
+			{
+				const int off = before - 0x11A8;
+				if (s[i] == toOnset[off]) s[i - 1] = conv[off] ? conv[off] : s[i];
+			}
+			before = s[i];
+		}
+	}
+
+	void prepareText(PreparedText& o, const char16_t* raw, size_t n, uint64_t mo, uint32_t textId)
+	{
+		normalizeWithPosition(raw, n, o.norm, o.position);
+		if (mo & M_NORMALIZE_CODA) normalizeCoda(o.norm);
+		const size_t L = o.norm.size();
+		o.cls.assign(L, 0); o.script.assign(L, 0);
+		for (size_t i = 0; i < L; ++i)
+		{
+			uint32_t c = o.norm[i];
+			uint32_t c1 = 0;
+			size_t nx = i + 1;
+			if (isHighSurrogate(c) && i + 1 < L) { c = mergeSurrogate(c, o.norm[i + 1]); nx = i + 2; }
+			if (nx < L)
+			{
+				c1 = o.norm[nx];
+				if (isHighSurrogate(c1) && nx + 1 < L) c1 = mergeSurrogate(c1, o.norm[nx + 1]);
+			}
+			o.cls[i] = identifySpecialChr(c);
+			o.script[i] = chr2ScriptType(c);
+			if (c >= 0x80 && isEmoji(c, c1)) o.cls[i] |= 0x80;
+		}
+		o.chunks.clear(); o.patterns.clear();
+		size_t splitEnd = 0;
+		while (splitEnd < L)
+		{
+			const char16_t* str = o.norm.data() + splitEnd;
+			const size_t sz = L - splitEnd;
+			ChunkDesc ch{};
+			ch.textId = textId; ch.startOffset = (uint32_t)splitEnd; ch.patBegin = (uint32_t)o.patterns.size();
+			size_t k = 0, contNonSpace = 0;
+			uint8_t lastType = T_UNKNOWN;
+			bool anyNonSpace = false;
+			for (; k < sz; ++k)
+			{
+				auto pm = matchPattern(k ? str[k - 1] : u' ', str + k, str + sz, mo);
+				if (pm.second != T_UNKNOWN)
+				{
+					o.patterns.push_back(PatternSpan{ (uint32_t)(k + pm.first), (uint32_t)pm.first, pm.second });
+					k += pm.first - 1;
+					continue;
+				}
+				uint32_t c32 = str[k];
+				if (isHighSurrogate(c32) && k + 1 < sz) c32 = mergeSurrogate(c32, str[k + 1]);
+				const uint8_t t = identifySpecialChr(c32);
+				if (t == T_UNKNOWN) contNonSpace = 0; else ++contNonSpace;
+				if (t == T_UNKNOWN && k >= (lastType == T_SF ? 4u : 4096u))
+				{
+					if (!isSpace(str[k - 3]) && !isSpace(str[k - 2])) break;
+				}
+				else if (contNonSpace >= 1024) break;
+				if (c32 >= 0x10000) ++k;
+				lastType = t;
+			}
+			if (k > sz) k = sz;
+			for (size_t i = 0; i < k; ++i) if (!isSpace(str[i])) { anyNonSpace = true; break; }
+			std::sort(o.patterns.begin() + ch.patBegin, o.patterns.end(), [](const PatternSpan& a, const PatternSpan& b)
+			{
+				if (a.end != b.end) return a.end < b.end;
+				if (a.length != b.length) return a.length < b.length;
+				return a.tag < b.tag;
+			});
+			ch.patEnd = (uint32_t)o.patterns.size();
+			ch.nChars = (uint32_t)k;
+			ch.empty = !anyNonSpace;
+			size_t stop = k;
+			if (ch.empty) while (stop < sz && isSpace(str[stop])) ++stop;   // KTrie.cpp:1505-1506
+			ch.nextOffset = (uint32_t)(splitEnd + stop);
+			o.chunks.push_back(ch);
+			if (stop == 0) throw std::runtime_error{ "prepareText: chunker made no progress" };
+			splitEnd += stop;
+		}
+	}
+}

@@ -1,0 +1,213 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product.
+// C entry points of the CPU oracle (lattice_oracle.hpp + viterbi_oracle.hpp).  The oracle shares the
+// host-side model baker and text preparation / result assembly code with the product (those are not the
+// hot path); the lattice construction and the best-path search are restated here independently of the
+// HIP kernels.  Output buffers use the same byte layout as oracle/ref_bridge.cpp so tests diff them directly.
+#include <chrono>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <thread>
+#include <atomic>
+#include "viterbi_oracle.hpp"
+
+using namespace korc;
+
+struct OracleHandle
+{
+	FlatModel model;
+	ModelView view;
+	SplitConfig scfg{ 0, 6, 0xFFFFFFFFu, 0 };
+	BestPathConfig bcfg;
+	bool integrateAllomorph = true;
+	Counters counters;
+};
+
+namespace
+{
+	struct Writer
+	{
+		uint8_t* p; uint8_t* end; size_t need = 0;
+		template<class T> void put(T v) { need += sizeof(T); if (p + sizeof(T) <= end) { std::memcpy(p, &v, sizeof(T)); p += sizeof(T); } }
+		void putStr(const U16& s) { put<uint32_t>((uint32_t)s.size()); for (auto c : s) put<uint16_t>(c); }
+	};
+
+	std::vector<TokenResult> analyzeOne(OracleHandle& h, Counters& cnt, const char16_t* text, uint32_t len, uint32_t topN, uint64_t match, bool openEnding,
+		std::vector<std::vector<LNode>>* latticesOut = nullptr)
+	{
+		if (topN != 1) throw std::runtime_error{ "oracle: only top-1 is restated" };
+		PreparedText pt;
+		prepareText(pt, text, len, match, 0);
+		SplitConfig sc = h.scfg; sc.match = match;
+		BestPathConfig bc = h.bcfg;
+		bc.splitComplex = match & M_SPLIT_COMPLEX; bc.splitSaisiot = match & M_SPLIT_SAISIOT; bc.mergeSaisiot = match & M_MERGE_SAISIOT;
+		bc.spaceTolerance = sc.spaceTol;
+		LatticeBuilder lb{ h.view, sc, cnt };
+		ResultBuilder rb{ h.model, topN, match, h.integrateAllomorph };
+		rb.begin(text, len, pt.position);
+		std::vector<LNode> nodes;
+		std::vector<PathResult> paths;
+		for (auto& ch : pt.chunks)
+		{
+			if (ch.empty) continue;
+			const bool ok = lb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.cls.data() + ch.startOffset, pt.script.data() + ch.startOffset,
+				pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset);
+			if (latticesOut) latticesOut->push_back(nodes);
+			if (!ok) continue;
+			BestPathConfig bc2 = bc;
+			bc2.openEnding = openEnding && ch.nextOffset == pt.norm.size();
+			BestPathSearch bp{ h.view, bc2, cnt };
+			bp.run(paths, pt.norm, pt.cls, nodes.data(), (uint32_t)nodes.size(), rb.spStates());
+			rb.insertPaths(paths);
+		}
+		return rb.finish(text, len);
+	}
+}
+
+extern "C"
+{
+	void* korc_open(const char* rawModelPath)
+	{
+		try
+		{
+			auto h = std::make_unique<OracleHandle>();
+			bakeModel(h->model, rawModelPath);
+			h->view = h->model.view();
+			return h.release();
+		}
+		catch (const std::exception& e) { fprintf(stderr, "korc_open: %s\n", e.what()); return nullptr; }
+	}
+	void korc_close(void* h) { delete (OracleHandle*)h; }
+
+	void korc_set_config(void* hp, float cutOff, float spacePenalty, float typoCostWeight, uint32_t maxUnk, uint32_t maxUnkJ, uint32_t spaceTol, int integrateAllomorph)
+	{
+		auto& h = *(OracleHandle*)hp;
+		h.bcfg.cutOff = cutOff; h.bcfg.spacePenalty = spacePenalty; h.bcfg.typoCostWeight = typoCostWeight;
+		h.scfg.maxUnk = maxUnk; h.scfg.maxUnkJ = maxUnkJ; h.scfg.spaceTol = spaceTol; h.integrateAllomorph = !!integrateAllomorph;
+	}
+
+	size_t korc_dump_dict(void* hp, uint8_t* out, size_t cap)
+	{
+		auto d = dumpDict(((OracleHandle*)hp)->model);
+		if (d.size() <= cap) std::memcpy(out, d.data(), d.size());
+		return d.size();
+	}
+
+	float korc_lm_progress(void* hp, int32_t* node, uint32_t wid)
+	{
+		auto& h = *(OracleHandle*)hp;
+		BestPathConfig bc; Counters c;
+		BestPathSearch bp{ h.view, bc, c };
+		return bp.lmProgress(*node, wid);
+	}
+
+	// same layout as kref_split (oracle/ref_bridge.cpp)
+	size_t korc_split(void* hp, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
+	{
+		auto& h = *(OracleHandle*)hp;
+		Writer w{ out, out + cap };
+		try
+		{
+			PreparedText pt;
+			prepareText(pt, (const char16_t*)text, len, match, 0);
+			SplitConfig sc = h.scfg; sc.match = match;
+			Counters cnt;
+			LatticeBuilder lb{ h.view, sc, cnt };
+			w.put<uint32_t>((uint32_t)pt.chunks.size());
+			std::vector<LNode> nodes;
+			for (auto& ch : pt.chunks)
+			{
+				if (ch.empty) { nodes.assign(2, LNode{}); }
+				else lb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.cls.data() + ch.startOffset, pt.script.data() + ch.startOffset,
+					pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset);
+				w.put<uint32_t>((uint32_t)nodes.size());
+				w.put<uint32_t>(ch.nextOffset);
+				for (auto& n : nodes)
+				{
+					w.put<uint32_t>(n.startPos); w.put<uint32_t>(n.endPos); w.put<uint32_t>(n.prev); w.put<uint32_t>(n.sibling);
+					w.put<int32_t>(n.form == NOFORM ? -1 : (int32_t)n.form);
+					w.put<uint32_t>(n.uformLen); w.put<uint32_t>(n.uformLen ? n.uformOff : 0);
+					w.put<uint32_t>(n.spaceErrors); w.put<float>(n.typoCost);
+				}
+			}
+		}
+		catch (const std::exception& e) { fprintf(stderr, "korc_split: %s\n", e.what()); return 0; }
+		return w.need;
+	}
+
+	static void writeResults(Writer& w, const std::vector<TokenResult>& res)
+	{
+		w.put<uint32_t>((uint32_t)res.size());
+		for (auto& r : res)
+		{
+			w.put<float>(r.second);
+			w.put<uint32_t>((uint32_t)r.first.size());
+			for (auto& t : r.first)
+			{
+				w.putStr(t.str);
+				w.put<uint32_t>(t.position); w.put<uint32_t>(t.wordPosition); w.put<uint32_t>(t.sentPosition); w.put<uint32_t>(t.lineNumber);
+				w.put<uint16_t>(t.length); w.put<uint8_t>(t.tag); w.put<uint8_t>(t.senseId);
+				w.put<float>(t.score); w.put<float>(t.typoCost); w.put<uint32_t>(t.typoFormId); w.put<uint32_t>(t.pairedToken);
+				w.put<uint32_t>(t.subSentPosition); w.put<uint16_t>(t.dialect); w.put<int32_t>(t.morph);
+			}
+		}
+	}
+
+	size_t korc_analyze(void* hp, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
+	{
+		auto& h = *(OracleHandle*)hp;
+		Writer w{ out, out + cap };
+		try
+		{
+			auto res = analyzeOne(h, h.counters, (const char16_t*)text, len, topN, match, !!openEnding);
+			writeResults(w, res);
+		}
+		catch (const std::exception& e) { fprintf(stderr, "korc_analyze: %s\n", e.what()); return 0; }
+		return w.need;
+	}
+
+	// CPU baseline ("port" kind): batch over `threads` workers; returns wall seconds
+	double korc_analyze_batch(void* hp, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut)
+	{
+		auto& h = *(OracleHandle*)hp;
+		std::atomic<uint32_t> next{ 0 };
+		std::atomic<uint64_t> tokens{ 0 };
+		std::vector<Counters> cnts(std::max(threads, 1));
+		auto work = [&](int tid)
+		{
+			uint64_t local = 0;
+			for (;;)
+			{
+				const uint32_t i = next.fetch_add(1);
+				if (i >= n) break;
+				auto res = analyzeOne(h, cnts[tid], (const char16_t*)texts + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), topN, match, false);
+				local += res[0].first.size();
+			}
+			tokens += local;
+		};
+		auto t0 = std::chrono::steady_clock::now();
+		if (threads <= 1) work(0);
+		else
+		{
+			std::vector<std::thread> ts;
+			for (int t = 0; t < threads; ++t) ts.emplace_back(work, t);
+			for (auto& t : ts) t.join();
+		}
+		auto t1 = std::chrono::steady_clock::now();
+		if (tokensOut) *tokensOut = tokens.load();
+		// fold counters
+		for (auto& c : cnts)
+		{
+			uint64_t* d = (uint64_t*)&h.counters; const uint64_t* s = (const uint64_t*)&c;
+			for (size_t k = 0; k < sizeof(Counters) / 8; ++k) { if (k == 13) d[k] = std::max(d[k], s[k]); else d[k] += s[k]; }
+		}
+		return std::chrono::duration<double>(t1 - t0).count();
+	}
+
+	void korc_counters(void* hp, uint64_t* out17, int reset)
+	{
+		auto& h = *(OracleHandle*)hp;
+		std::memcpy(out17, &h.counters, sizeof(Counters));
+		if (reset) h.counters = Counters{};
+	}
+}

@@ -1,0 +1,101 @@
+"""TEST INFRASTRUCTURE: ctypes access to oracle/_build/liboracle.so (this repo's CPU restatement of the
+hot path, oracle/*.hpp).  Same call surface and byte layouts as refbridge.RefKiwi so tests can diff them."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from refbridge import MATCH_ALL, MATCH_ALL_WITH_NORMALIZING, Token, _Reader, parse_results  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
+
+COUNTER_NAMES = ["inputUnits", "trieProbes", "trieProbeKeyBytes", "failHops", "candEmits", "otherNodes",
+                 "transitions", "candMorphs", "statesWritten", "lmProbes", "lmProbeKeyBytes", "lmRootProbes", "tokens",
+                 "maxPrevPaths", "nodesOver128", "nodesOver512", "lattNodes"]
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+class OracleKiwi:
+    def __init__(self, raw_model_path: str):
+        self.lib = C.CDLL(LIB_PATH)
+        L = self.lib
+        L.korc_open.restype = C.c_void_p
+        L.korc_open.argtypes = [C.c_char_p]
+        L.korc_close.argtypes = [C.c_void_p]
+        L.korc_set_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.korc_dump_dict.restype = C.c_size_t
+        L.korc_dump_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.korc_lm_progress.restype = C.c_float
+        L.korc_lm_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32]
+        L.korc_split.restype = C.c_size_t
+        L.korc_split.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t]
+        L.korc_analyze.restype = C.c_size_t
+        L.korc_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
+        L.korc_analyze_batch.restype = C.c_double
+        L.korc_analyze_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
+        L.korc_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.h = L.korc_open(raw_model_path.encode())
+        if not self.h:
+            raise RuntimeError("korc_open failed")
+        self._buf = np.zeros(1 << 20, np.uint8)
+
+    def close(self):
+        if self.h:
+            self.lib.korc_close(self.h)
+            self.h = None
+
+    def _call(self, fn, *args):
+        while True:
+            need = fn(*args, self._buf.ctypes.data, self._buf.nbytes)
+            if need <= self._buf.nbytes:
+                return self._buf[:need]
+            self._buf = np.zeros(int(need * 1.5), np.uint8)
+
+    def set_config(self, cut_off=8.0, space_penalty=7.0, typo_cost_weight=6.0, max_unk=6, max_unk_j=0xFFFFFFFF, space_tol=0, integrate_allomorph=True):
+        self.lib.korc_set_config(self.h, cut_off, space_penalty, typo_cost_weight, max_unk, max_unk_j, space_tol, int(integrate_allomorph))
+
+    def analyze(self, text: str, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING, open_ending=False):
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        buf = self._call(lambda *a: self.lib.korc_analyze(self.h, u.ctypes.data, len(u), top_n, match, int(open_ending), *a))
+        if len(buf) == 0:
+            raise RuntimeError("korc_analyze failed")
+        return parse_results(buf)
+
+    def split(self, text: str, match: int = MATCH_ALL_WITH_NORMALIZING):
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        buf = self._call(lambda *a: self.lib.korc_split(self.h, u.ctypes.data, len(u), match, *a))
+        r = _Reader(buf)
+        chunks = []
+        for _ in range(r.get("I")):
+            n, split_end = r.get("II")
+            nodes = [r.get("IIIIiIIIf") for _ in range(n)]
+            chunks.append((split_end, nodes))
+        return chunks
+
+    def lm_progress(self, node: int, wid: int):
+        n = C.c_int32(node)
+        ll = self.lib.korc_lm_progress(self.h, C.byref(n), wid)
+        return float(ll), int(n.value)
+
+    def dump_dict(self) -> bytes:
+        return bytes(self._call(lambda *a: self.lib.korc_dump_dict(self.h, *a)))
+
+    def analyze_batch(self, texts: list, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, threads=1):
+        enc = [np.frombuffer(t.encode("utf-16-le", errors="surrogatepass"), np.uint16) for t in texts]
+        offs = np.zeros(len(enc) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(e) for e in enc])
+        flat = np.concatenate(enc) if enc else np.zeros(0, np.uint16)
+        ntok = C.c_uint64(0)
+        sec = self.lib.korc_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(enc), top_n, match, threads, C.byref(ntok))
+        return float(sec), int(ntok.value)
+
+    def counters(self, reset=False) -> dict:
+        arr = np.zeros(len(COUNTER_NAMES), np.uint64)
+        self.lib.korc_counters(self.h, arr.ctypes.data, int(reset))
+        return dict(zip(COUNTER_NAMES, (int(x) for x in arr)))

@@ -1,0 +1,591 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product.
+//
+// CPU restatement of the reference's best-path search for one lattice, Knlm scoring, top-1:
+//   BestPathFinder<KnLangModel>::findBestPath      /root/reference/src/PathEvaluator.hpp:1178-1419
+//   PathEvaluator::operator() / evalSingleMorpheme  /root/reference/src/PathEvaluator.hpp:347-635
+//   RuleBasedScorer / insertToPathContainer / FormEvaluator  /root/reference/src/PathEvaluator.hpp:88-311
+//   BestPathConatiner top1 / top1Small / top1Medium /root/reference/src/BestPathContainer.hpp:230-483
+//   generateTokenList                               /root/reference/src/PathEvaluator.hpp:1038-1157
+//   KnLangModel::progress                           /root/reference/src/Knlm.cpp:44-130
+// top-N (> 1) containers are not restated yet: korc_analyze refuses topN != 1.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_set>
+#include "lattice_oracle.hpp"
+#include "../kiwi_amd/csrc/feature.hpp"
+#include "../kiwi_amd/csrc/post.hpp"
+
+namespace korc
+{
+	struct BestPathConfig
+	{
+		float cutOff = 8, spacePenalty = 7, typoCostWeight = 6, oovRuleScale = 4, oovRuleBias = 4;
+		uint32_t spaceTolerance = 0;
+		bool openEnding = false, splitComplex = false, splitSaisiot = false, mergeSaisiot = false;
+	};
+
+	constexpr uint8_t COMMON_ROOT = 0xFF;
+
+	struct WPath   // WordLL<KnLMState> (BestPathContainer.hpp:21-67)
+	{
+		int32_t lmNode = 0;
+		uint8_t prevRootId = 0, spState = 0, rootId = 0;
+		uint32_t morph = 0;
+		float accScore = 0, firstChunkScore = 0, accTypoCost = 0;
+		int32_t parentNode = -1, parentIdx = -1;
+		uint32_t wid = 0;
+		uint16_t ownFormId = 0;
+		uint8_t combineSocket = 0;
+	};
+
+	class BestPathSearch
+	{
+		const ModelView& M;
+		const BestPathConfig& cfg;
+		Counters& cnt;
+		const U16* norm = nullptr;   // normalised text
+		const LNode* graph = nullptr;
+		uint32_t G = 0;
+		std::vector<std::vector<WPath>> cache;
+		struct OwnForm { uint32_t off, len; };   // offsets into the normalised text, or into a form string (kind 1)
+		std::vector<std::pair<int, OwnForm>> ownForms;  // kind 0: text substring, kind 1: dictionary form (id in off)
+		std::vector<uint8_t> uniqStates;
+		std::vector<float> leftBoundary[2];
+
+		static uint32_t log2c(uint32_t v) { uint32_t l = 0; while ((1u << l) < v + 1) ++l; return l; }
+
+		bool lmSearch(const LmNodeRec& nd, uint32_t key, int32_t& v)
+		{
+			cnt.lmProbeKeyBytes += 2 * log2c(nd.numNexts) * 4;
+			const uint32_t* k = M.lmKeys + nd.nextOff;
+			const uint32_t* it = std::lower_bound(k, k + nd.numNexts, key);
+			if (it == k + nd.numNexts || *it != key) return false;
+			v = M.lmValues[nd.nextOff + (it - k)];
+			return true;
+		}
+		static float asFloat(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
+
+	public:
+		float lmProgress(int32_t& node, uint32_t next)
+		{
+			float acc = 0;
+			for (;;)
+			{
+				int32_t v;
+				const LmNodeRec* nd = &M.lmNodes[node];
+				if (node == 0)
+				{
+					cnt.lmRootProbes++;
+					v = M.lmRoot[next];
+					if (v == 0) return acc + M.h.unkLl;
+				}
+				else
+				{
+					cnt.lmProbes++;
+					if (!lmSearch(*nd, next, v)) { acc += nd->gamma; node += nd->lower; continue; }
+				}
+				if (v > 0) { node += v; return acc + M.lmNodes[node].ll; }
+				int32_t cur = node;
+				while (M.lmNodes[cur].lower)
+				{
+					cur += M.lmNodes[cur].lower;
+					int32_t lv;
+					cnt.lmProbes++;
+					if (lmSearch(M.lmNodes[cur], next, lv) && lv > 0) { node = cur + lv; return acc + asFloat(v); }
+				}
+				node = 0;
+				return acc + asFloat(v);
+			}
+		}
+
+	private:
+		const uint16_t* ownStr(uint16_t id, uint32_t& len) const
+		{
+			const auto& o = ownForms[id - 1];
+			len = o.second.len;
+			if (o.first == 1) return M.formChars + M.forms[o.second.off].charOff;
+			return (const uint16_t*)norm->data() + o.second.off;
+		}
+
+		bool hasLeftBoundary(const LNode* node) const  // PathEvaluator.hpp:24-44
+		{
+			const LNode* p = node - node->prev;
+			if (p->endPos == 0) return true;
+			if (p->endPos < node->startPos) return true;
+			if (p->uformLen)
+			{
+				const uint16_t c = (*norm)[p->uformOff + p->uformLen - 1];
+				const uint8_t tag = identifySpecialChr(c);
+				if (tag == T_SSC || c == u'"' || c == u'\'') return false;
+				if (T_SF <= tag && tag <= T_SB) return true;
+			}
+			return false;
+		}
+
+		struct Rule   // RuleBasedScorer (PathEvaluator.hpp:88-184)
+		{
+			uint8_t special; uint32_t sbType; int sbOrder;
+			bool vowelE, infJ, badPairOfL, positiveE, contractableE, snEndsWithPoint; uint8_t condP;
+			float operator()(const MorphRec& prev, uint8_t sp) const
+			{
+				float a = 0;
+				if (vowelE && (prev.prevFlags & PF_IRREGULAR)) a -= 10;
+				if (infJ && (prev.prevFlags & PF_INFLECTENDA_NP)) a -= 5;
+				if (badPairOfL && (prev.prevFlags & PF_VERB_L)) a -= 7;
+				if (positiveE && !(prev.prevFlags & PF_POSITIVE_VERB)) a -= 100;
+				if (contractableE && (prev.prevFlags & PF_VERB_VOWEL)) a -= 3;
+				if (condP == CP_NON_ADJ && (prev.prevFlags & PF_VA_OR_XSA)) a -= 10;
+				if (special <= 2) { if (special != (sp & 1)) a -= 2; }
+				else if (special <= 5) { if ((uint8_t)(special - 3) != ((sp >> 1) & 1)) a -= 2; }
+				if (sbType == 5) a -= 5;
+				if (sbType && (prev.prevFlags & PF_E_NOT_EF)) a -= 10;
+				if (sbType && (sp >> 2) == hashSb((uint8_t)sbType, (uint8_t)sbOrder)) a += 3;
+				if (snEndsWithPoint && (prev.prevFlags & PF_UNK_EF_SF)) a -= 5;
+				return a;
+			}
+			static uint8_t hashSb(uint8_t type, uint8_t order) { return (uint8_t)((((int)type << 1) ^ (type >> 7) ^ order) % 63 + 1); } // PathEvaluator.hpp:83-86
+		};
+
+		// ---- the three top-1 containers; `mode` 0 small, 1 medium, 2 hash set -----------------------
+		struct Key { int32_t lm; uint8_t prevRoot, sp; };
+		static size_t keyHash(const Key& k)   // Hash<WordLL>(lmState, prevRootId, spState) (BestPathContainer.hpp:80-85)
+		{
+			size_t r = (size_t)(int64_t)k.lm;  // std::hash<int32_t>
+			return ((uint16_t)k.prevRoot | ((uint16_t)k.sp << 8)) ^ ((r << 3) | (r >> 61));
+		}
+		struct SetHash { size_t operator()(const WPath& p) const { return keyHash(Key{ p.lmNode, p.prevRootId, p.spState }); } };
+		struct SetEq { bool operator()(const WPath& a, const WPath& b) const { return a.prevRootId == b.prevRootId && a.spState == b.spState && a.lmNode == b.lmNode; } };
+		std::vector<WPath> bucket[4];
+		std::unordered_set<WPath, SetHash, SetEq> hset;
+
+		void contClear() { for (auto& b : bucket) b.clear(); hset.clear(); }
+		void contInsert(int mode, const WPath& np)
+		{
+			if (mode == 2)
+			{
+				auto ins = hset.emplace(np);
+				if (!ins.second && np.accScore > ins.first->accScore) const_cast<WPath&>(*ins.first) = np;
+				return;
+			}
+			const size_t h = keyHash(Key{ np.lmNode, np.prevRootId, np.spState });
+			auto& b = bucket[mode == 1 ? ((h >> 8) & 3) : 0];
+			for (auto& t : b)
+			{
+				if (t.prevRootId == np.prevRootId && t.spState == np.spState && t.lmNode == np.lmNode)
+				{
+					if (np.accScore > t.accScore) { const uint8_t pr = t.prevRootId; t = np; t.prevRootId = pr; }
+					return;
+				}
+			}
+			if (b.size() < 128) b.push_back(np);
+		}
+		template<class Fn> void contEach(int mode, Fn&& fn)
+		{
+			if (mode == 2) { for (auto& p : hset) fn(p); return; }
+			for (auto& b : bucket) for (auto& p : b) fn(p);
+		}
+
+		void evalSingle(int mode, std::vector<WPath>& outv, uint32_t nodeIdx, uint16_t ownFormId, uint32_t morphId, float ignoreCondScore, float nodeLevelDiscount)
+		{
+			const LNode* node = graph + nodeIdx;
+			const MorphRec& cm = M.morphs[morphId];
+			const bool single = cm.flags & MF_SINGLE;
+			uint32_t firstWid = single ? cm.lmId : M.chunkLm[cm.chunkOff];
+			contClear();
+			cnt.candMorphs++;
+			const float additional = cm.userScore + nodeLevelDiscount + leftBoundary[hasLeftBoundary(node) ? 1 : 0][clearIrregular(cm.tag)] * 5.f;
+			Rule rule;
+			rule.special = cm.special;
+			rule.sbType = cm.tag == T_SB ? M.sbInfo[morphId] : 0;
+			rule.sbOrder = rule.sbType ? cm.senseId : 0;
+			rule.vowelE = cm.flags & MF_VOWEL_E; rule.infJ = cm.flags & MF_INF_J; rule.badPairOfL = cm.flags & MF_BAD_PAIR_OF_L;
+			rule.positiveE = isEClass(cm.tag) && node->form != NOFORM && (M.forms[node->form].flags & FF_STARTS_WITH_A);
+			rule.contractableE = cm.flags & MF_CONTRACTABLE_E;
+			rule.snEndsWithPoint = cm.tag == T_SN && node->uformLen && (*norm)[node->uformOff + node->uformLen - 1] == u'.';
+			rule.condP = cm.polar;
+
+			const LNode* pfirst = node - node->prev;
+			for (const LNode* prev = node->prev ? pfirst : nullptr; prev; prev = prev->sibling ? prev + prev->sibling : nullptr)
+			{
+				const auto& pc = cache[prev - graph];
+				for (uint32_t pi = 0; pi < pc.size(); ++pi)
+				{
+					const WPath& pp = pc[pi];
+					const MorphRec& pm = M.morphs[pp.morph];
+					if (pm.tag == T_Z_SIOT && (!isNNClass(cm.tag) || prev->endPos < node->startPos)) continue;
+					float cand = pp.accScore + additional;
+					float firstChunk = additional;
+					if (pp.combineSocket)
+					{
+						if (pp.combineSocket != cm.socket || single) continue;
+						if (prev->endPos < node->startPos)
+						{
+							if (cfg.spaceTolerance > 0) cand -= cfg.spacePenalty; else continue;
+						}
+						firstWid = M.morphs[M.morphs[pp.wid].combinedId].lmId;   // persists for later predecessors, as in the reference
+					}
+					// FormEvaluator (PathEvaluator.hpp:253-311)
+					{
+						uint16_t feat; bool sscLeft;
+						const MorphRec& wm = M.morphs[pp.wid];
+						if (pp.ownFormId)
+						{
+							uint32_t l; const uint16_t* s = ownStr(pp.ownFormId, l);
+							feat = featMask(s, l);
+							sscLeft = l && identifySpecialChr(s[l - 1]) == T_SSC;
+						}
+						else if (!(wm.flags & MF_KFORM_EMPTY)) { feat = wm.feat; sscLeft = wm.flags & MF_ENDS_WITH_SSC; }
+						else if (pm.tag == T_UNKNOWN && pm.nChunks)
+						{
+							const MorphRec& lm = M.morphs[M.chunkMorph[pm.chunkOff + pm.nChunks - 1]];
+							feat = lm.feat; sscLeft = lm.flags & MF_ENDS_WITH_SSC;
+						}
+						else { feat = pm.feat; sscLeft = pm.flags & MF_ENDS_WITH_SSC; }
+						if (pm.tag == T_SSC || sscLeft) {}
+						else if (ignoreCondScore != 0) cand += featTest(feat, cm.vowel, cm.polar) ? 0 : ignoreCondScore;
+						else if (!featTest(feat, cm.vowel, cm.polar)) continue;
+					}
+					int32_t lmNode = pp.lmNode;
+					if (cm.socket && single) {}
+					else
+					{
+						if (M.morphs[firstWid].tag == T_P) continue;
+						float ll = lmProgress(lmNode, firstWid);
+						cand += ll; firstChunk += ll;
+						if (!single)
+						{
+							bool bad = false;
+							for (uint32_t c = 1; c < cm.nChunks; ++c)
+							{
+								const uint32_t wid = M.chunkLm[cm.chunkOff + c];
+								if (M.morphs[wid].tag == T_P) { bad = true; break; }
+								ll = lmProgress(lmNode, wid);
+								cand += ll;
+							}
+							if (bad) continue;
+						}
+					}
+					cnt.transitions++;
+					// insertToPathContainer (PathEvaluator.hpp:193-251)
+					auto insert = [&](uint8_t rootId)
+					{
+						uint8_t sp = pp.spState;
+						if (rootId != COMMON_ROOT) sp = uniqStates[rootId];
+						const float rs = rule(M.morphs[pp.wid], sp);
+						if (rule.special == 0) sp |= 1; else if (rule.special == 1) sp &= ~1; else if (rule.special == 3) sp |= 2; else if (rule.special == 4) sp &= ~2;
+						if (rule.sbType) sp = (uint8_t)((sp & 3) | (Rule::hashSb((uint8_t)rule.sbType, (uint8_t)(rule.sbOrder + 1)) << 2));
+						WPath np;
+						np.morph = morphId; np.accScore = (cand + rs) - 0.f; np.firstChunkScore = (firstChunk + rs) - 0.f;
+						np.accTypoCost = pp.accTypoCost + node->typoCost;
+						np.parentNode = (int32_t)(prev - graph); np.parentIdx = (int32_t)pi;
+						np.lmNode = lmNode; np.spState = sp;
+						np.rootId = pp.rootId; np.prevRootId = pp.rootId;
+						if (rootId != COMMON_ROOT) np.rootId = rootId;
+						contInsert(mode, np);
+					};
+					const bool quote = rule.special == 0 || rule.special == 1 || rule.special == 3 || rule.special == 4;
+					if ((rule.sbType || quote) && pp.rootId == COMMON_ROOT) for (uint8_t r = 0; r < uniqStates.size(); ++r) insert(r);
+					else insert(COMMON_ROOT);
+				}
+			}
+			contEach(mode, [&](const WPath& p)
+			{
+				outv.push_back(p);
+				WPath& q = outv.back();
+				q.wid = cm.lastSeqId;
+				if (single) { q.combineSocket = cm.socket; q.ownFormId = ownFormId; }
+			});
+		}
+
+		void evaluate(uint32_t nodeIdx, uint16_t ownFormId, const uint32_t* cands, uint32_t nCands, float unkDiscount)
+		{
+			const LNode* node = graph + nodeIdx;
+			auto& nCache = cache[nodeIdx];
+			float wsDiscount = 0;
+			if (!node->uformLen && node->form != NOFORM && M.forms[node->form].len && node->spaceErrors) wsDiscount = -cfg.spacePenalty * node->spaceErrors;
+			const float typoDiscount = -node->typoCost * cfg.typoCostWeight;
+			const float nodeLevelDiscount = wsDiscount + typoDiscount + unkDiscount;
+			size_t totalPrev = 0;
+			const LNode* pfirst = node - node->prev;
+			for (const LNode* prev = node->prev ? pfirst : nullptr; prev; prev = prev->sibling ? prev + prev->sibling : nullptr) totalPrev += cache[prev - graph].size();
+			cnt.maxPrevPaths = std::max<uint64_t>(cnt.maxPrevPaths, totalPrev);
+			if (totalPrev > 128) cnt.nodesOver128++;
+			if (totalPrev > 512) cnt.nodesOver512++;
+			const int mode = totalPrev <= 128 ? 0 : totalPrev <= 512 ? 1 : 2;
+
+			for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
+			{
+				for (uint32_t ci = 0; ci < nCands; ++ci)
+				{
+					const uint32_t mid = cands[ci];
+					const MorphRec& cm = M.morphs[mid];
+					if (cfg.splitComplex && (cm.flags & MF_HAS_COMPLEX)) continue;
+					if (cm.tag == T_Z_CODA || cm.tag == T_Z_SIOT)
+					{
+						if (cm.tag == T_Z_SIOT && !(cfg.splitSaisiot || cfg.mergeSaisiot)) continue;
+						for (const LNode* prev = node->prev ? pfirst : nullptr; prev; prev = prev->sibling ? prev + prev->sibling : nullptr)
+						{
+							const auto& pc = cache[prev - graph];
+							for (uint32_t pi = 0; pi < pc.size(); ++pi)
+							{
+								const uint8_t lastTag = M.morphs[pc[pi].wid].tag;
+								if (cm.tag == T_Z_CODA ? (!isJClass(lastTag) && !isEClass(lastTag)) : !isNNClass(lastTag)) continue;
+								WPath np = pc[pi];
+								np.accScore += cm.userScore * cfg.typoCostWeight;
+								np.accTypoCost -= cm.userScore;
+								np.parentNode = (int32_t)(prev - graph); np.parentIdx = (int32_t)pi;
+								np.morph = cm.lmId; np.wid = cm.lmId;
+								nCache.push_back(np);
+							}
+						}
+						continue;
+					}
+					if (!(cm.flags & MF_SINGLE) && (cm.flags & MF_HA_CONTRACTION) && node->prev && (node - node->prev)->endPos < node->startPos) continue;
+					evalSingle(mode, nCache, nodeIdx, ownFormId, mid, ignoreCond ? -10.f : 0.f, nodeLevelDiscount);
+				}
+				if (!nCache.empty()) break;
+			}
+			std::vector<float> maxScores(1 + uniqStates.size(), -INFINITY);
+			for (auto& c : nCache)
+			{
+				if (M.morphs[c.morph].socket) continue;
+				const size_t r = c.rootId == COMMON_ROOT ? 0 : c.rootId + 1;
+				maxScores[r] = std::max(maxScores[r], c.accScore);
+			}
+			size_t valid = 0;
+			for (size_t i = 0; i < nCache.size(); ++i)
+			{
+				const size_t r = nCache[i].rootId == COMMON_ROOT ? 0 : nCache[i].rootId + 1;
+				if (nCache[i].accScore + cfg.cutOff < maxScores[r]) continue;
+				if (valid != i) nCache[valid] = nCache[i];
+				valid++;
+			}
+			nCache.resize(valid);
+		}
+
+		float unkScore(uint32_t len, bool emojiStart) const { return (emojiStart ? -10.f : 0.f) - (len * cfg.oovRuleScale + cfg.oovRuleBias); }
+
+		bool disconnected(std::vector<uint8_t>& reach, uint32_t scanStart) const   // PathEvaluator.hpp:1159-1176
+		{
+			if (reach[scanStart - 1]) return false;
+			std::fill(reach.begin() + scanStart, reach.end(), 0);
+			for (uint32_t i = scanStart; i < G; ++i)
+			{
+				const LNode* nd = graph + i;
+				for (const LNode* prev = nd->prev ? nd - nd->prev : nullptr; prev; prev = prev->sibling ? prev + prev->sibling : nullptr)
+					if (reach[prev - graph]) { reach[i] = 1; break; }
+			}
+			return reach[G - 1] == 0;
+		}
+
+		void tokenList(std::vector<PathTok>& ret, const WPath* result) const   // generateTokenList
+		{
+			std::vector<std::pair<const WPath*, uint32_t>> steps;   // (path, node index it lives in)
+			{
+				const WPath* s = result; int32_t nodeOf = -1;
+				for (;;)
+				{
+					const int32_t pn = s->parentNode, pidx = s->parentIdx;
+					if (pn < 0) break;
+					const WPath* par = &cache[pn][pidx];
+					if (par->parentNode < 0) break;
+					steps.emplace_back(par, (uint32_t)pn);
+					s = par; (void)nodeOf;
+				}
+			}
+			if (steps.empty()) return;
+			const WPath* prev = &cache[steps.back().first->parentNode][steps.back().first->parentIdx];
+			const uint32_t vocab = M.h.vocabSize;
+			auto unify = [&](uint32_t m) -> uint32_t
+			{
+				if (m >= vocab || M.morphs[m].combinedId != (int32_t)m) return m;
+				return M.morphs[m].lmId;
+			};
+			for (size_t si = steps.size(); si-- > 0;)
+			{
+				const WPath* cur = steps[si].first;
+				const LNode& g = graph[steps[si].second];
+				const MorphRec& mm = M.morphs[cur->morph];
+				const float scoreDiff = cur->accScore - prev->accScore;
+				float typoDiff = cur->accTypoCost - prev->accTypoCost;
+				const bool single = mm.flags & MF_SINGLE;
+				const bool saisiotSplit = cfg.splitSaisiot && (mm.flags & MF_SAISIOT);
+				const uint32_t numNew = (saisiotSplit || !single) ? mm.nChunks : 1;
+				const float firstScore = cur->firstChunkScore + typoDiff * cfg.typoCostWeight;
+				const float restScores = numNew > 1 ? (scoreDiff - cur->firstChunkScore) / (numNew - 1) : 0;
+				typoDiff /= numNew;
+				auto emit = [&](uint32_t morph, const U16& str, uint32_t b, uint32_t e, float sc)
+				{
+					PathTok t; t.morph = morph; t.str = str; t.begin = b; t.end = e; t.wordScore = sc; t.typoCost = typoDiff; t.typoFormId = 0; t.nodeId = steps[si].second;
+					ret.push_back(std::move(t));
+				};
+				auto chunkTok = [&](uint32_t c, float sc)
+				{
+					emit(unify(M.chunkMorph[mm.chunkOff + c]), U16{}, g.startPos + M.chunkPos[2 * (mm.chunkOff + c)], g.startPos + M.chunkPos[2 * (mm.chunkOff + c) + 1], sc);
+				};
+				if (saisiotSplit)
+				{
+					for (uint32_t c = 0; c < numNew; ++c) chunkTok(c, c == 0 ? firstScore : restScores);
+					ret.back().end = g.endPos;
+				}
+				else if (single)
+				{
+					U16 own;
+					if (cur->ownFormId) { uint32_t l; const uint16_t* s = ownStr(cur->ownFormId, l); own.assign((const char16_t*)s, l); }
+					emit(unify(cur->morph), own, g.startPos, g.endPos, firstScore);
+				}
+				else if (mm.socket)
+				{
+					PathTok& b = ret.back();
+					b.morph = (uint32_t)M.morphs[b.morph].combinedId;
+					b.end = g.startPos + M.chunkPos[2 * mm.chunkOff + 1];
+					b.wordScore = firstScore; b.typoCost = typoDiff; b.typoFormId = 0;
+					for (uint32_t c = 1; c < numNew; ++c) chunkTok(c, restScores);
+					ret.back().end = g.endPos;
+				}
+				else
+				{
+					for (uint32_t c = 0; c < numNew; ++c) chunkTok(c, c == 0 ? firstScore : restScores);
+					ret.back().end = g.endPos;
+				}
+				prev = cur;
+			}
+		}
+
+	public:
+		BestPathSearch(const ModelView& m, const BestPathConfig& c, Counters& k) : M(m), cfg(c), cnt(k)
+		{
+			// TagSequenceScorer (src/TagUtils.cpp:49-62), weight 5
+			leftBoundary[0].assign(T_MAX, 0.f); leftBoundary[1].assign(T_MAX, 0.f);
+			leftBoundary[0][T_NNP] = leftBoundary[0][T_NP] = leftBoundary[0][T_IC] = -1; leftBoundary[0][T_SB] = -3;
+			for (uint8_t r = 0; r < T_MAX; ++r) leftBoundary[1][r] = (isEClass(r) || isJClass(r) || isSuffixTag(r) || r == T_VCP) ? -1.f : 0.f;
+		}
+
+		const std::vector<std::vector<WPath>>& states() const { return cache; }
+
+		void run(std::vector<PathResult>& ret, const U16& normText, const std::vector<uint8_t>& cls, const LNode* g, uint32_t gsize, const std::vector<uint8_t>& prevSpStates)
+		{
+			norm = &normText; graph = g; G = gsize;
+			cache.assign(G, {}); ownForms.clear();
+			std::vector<uint8_t> reach(G, 0);
+			uniqStates = prevSpStates;
+			std::sort(uniqStates.begin(), uniqStates.end());
+			uniqStates.erase(std::unique(uniqStates.begin(), uniqStates.end()), uniqStates.end());
+			if (prevSpStates.empty()) uniqStates.push_back(0);
+
+			WPath bos; bos.morph = 0; bos.lmNode = M.h.bosNode; bos.rootId = COMMON_ROOT;
+			cache[0].push_back(bos);
+			reach[0] = 1;
+			const uint32_t unkCands[2] = { T_NNG + 1u, T_NNP + 1u }, unkLCands[1] = { T_NNP + 1u };
+
+			for (uint32_t i = 1; i + 1 < G; ++i)
+			{
+				const LNode* node = g + i;
+				uint16_t ownFormId = 0;
+				if (node->uformLen) { ownForms.push_back({ 0, OwnForm{ node->uformOff, node->uformLen } }); ownFormId = (uint16_t)ownForms.size(); }
+				auto emojiAt = [&](uint32_t off) { return (cls[off] & 0x80) != 0; };
+				if (node->form != NOFORM)
+				{
+					const FormRec& f = M.forms[node->form];
+					evaluate(i, ownFormId, M.formCand + f.candOff, f.candCnt, 0.f);
+					// "isPretokenizedNode" (PathEvaluator.hpp:1258-1263) is also true for a form whose only candidate is a chunked UNKNOWN-tag morpheme
+					const bool pretokLike = f.candCnt == 1 && M.morphs[M.formCand[f.candOff]].tag == T_UNKNOWN && M.morphs[M.formCand[f.candOff]].nChunks;
+					bool allPartial = node->typoCost == 0 && !pretokLike;
+					for (uint32_t c = 0; c < f.candCnt && allPartial; ++c)
+					{
+						const MorphRec& m = M.morphs[M.formCand[f.candOff + c]];
+						if (!(m.socket || !(m.flags & MF_SINGLE))) allPartial = false;
+					}
+					if (allPartial)
+					{
+						ownForms.push_back({ 1, OwnForm{ node->form, f.len } });
+						ownFormId = (uint16_t)ownForms.size();
+						const uint16_t* fs = M.formChars + f.charOff;
+						const bool emo = f.len && fs[0] >= 0x80 && isEmoji(fs[0], f.len > 1 ? fs[1] : 0);
+						evaluate(i, ownFormId, unkLCands, 1, unkScore(f.len, emo));
+					}
+					bool any = false;
+					for (auto& p : cache[i]) if (!p.combineSocket) { any = true; break; }
+					reach[i] = any;
+					if (disconnected(reach, i + 1))
+					{
+						ownForms.push_back({ 0, OwnForm{ node->startPos, node->endPos - node->startPos } });
+						ownFormId = (uint16_t)ownForms.size();
+						evaluate(i, ownFormId, unkCands, 2, unkScore(node->endPos - node->startPos, emojiAt(node->startPos)));
+					}
+				}
+				else evaluate(i, ownFormId, unkCands, 2, unkScore(node->uformLen, emojiAt(node->uformOff)));
+				cnt.statesWritten += cache[i].size();
+				if (getenv("KORC_DEBUG")) { fprintf(stderr, "node %u:", i); for (auto& p : cache[i]) fprintf(stderr, " [m%u w%u lm%d s%.9g par(%d,%d) r%u]", p.morph, p.wid, p.lmNode, p.accScore, p.parentNode, p.parentIdx, p.rootId); fprintf(stderr, "\n"); }
+			}
+
+			// end node (PathEvaluator.hpp:1320-1357)
+			auto& cand = cache[G - 1];
+			const LNode* endNode = g + G - 1;
+			for (const LNode* prev = endNode->prev ? endNode - endNode->prev : nullptr; prev; prev = prev->sibling ? prev + prev->sibling : nullptr)
+			{
+				const auto& pc = cache[prev - g];
+				for (uint32_t pi = 0; pi < pc.size(); ++pi)
+				{
+					const WPath& p = pc[pi];
+					if (p.combineSocket) continue;
+					const MorphRec& pm = M.morphs[p.morph];
+					if (!(pm.flags & MF_SINGLE) && pm.nChunks <= (pm.socket ? 2u : 1u) && !matchVowel(nullptr, 0, pm.vowel)) continue;
+					if (pm.tag == T_Z_SIOT) continue;
+					float c = p.accScore, first = 0;
+					int32_t lmNode = p.lmNode;
+					if (!cfg.openEnding)
+					{
+						c += (first = lmProgress(lmNode, 1));
+						if (p.spState & 1) c -= 2;
+						if (p.spState & 2) c -= 2;
+					}
+					WPath np;
+					np.accScore = c; np.firstChunkScore = first; np.accTypoCost = p.accTypoCost;
+					np.parentNode = (int32_t)(prev - g); np.parentIdx = (int32_t)pi; np.lmNode = lmNode;
+					if (p.rootId == COMMON_ROOT)
+					{
+						for (size_t r = 0; r < uniqStates.size(); ++r) { np.spState = uniqStates[r]; np.rootId = (uint8_t)r; cand.push_back(np); }
+					}
+					else { np.spState = p.spState; np.rootId = p.rootId; cand.push_back(np); }
+				}
+			}
+			std::sort(cand.begin(), cand.end(), [](const WPath& a, const WPath& b)
+			{
+				if (a.rootId < b.rootId) return true;
+				if (a.rootId > b.rootId) return false;
+				if (a.spState < b.spState) return true;
+				if (a.spState > b.spState) return false;
+				return a.accScore > b.accScore;
+			});
+			size_t numUniq = 0;
+			{
+				std::vector<uint32_t> seen;
+				for (auto& c : cand) { const uint32_t k = (uint32_t)c.rootId << 8 | c.spState; if (std::find(seen.begin(), seen.end(), k) == seen.end()) seen.push_back(k); }
+				numUniq = seen.size();
+			}
+			ret.clear();
+			if (cand.empty()) return;
+			const size_t perGroup = (size_t)std::ceil(1 * 2 / (double)numUniq);
+			size_t startIdx = 0;
+			uint32_t prevKey = (uint32_t)cand[0].rootId << 8 | cand[0].spState;
+			for (size_t i = 0; i < cand.size(); ++i)
+			{
+				const uint32_t k = (uint32_t)cand[i].rootId << 8 | cand[i].spState;
+				if (k != prevKey) { startIdx = i; prevKey = k; }
+				if (i - startIdx < perGroup)
+				{
+					PathResult pr;
+					tokenList(pr.path, &cand[i]);
+					pr.score = cand[i].accScore; pr.prevState = uniqStates[cand[i].rootId]; pr.curState = cand[i].spState;
+					cnt.tokens += pr.path.size();
+					ret.push_back(std::move(pr));
+				}
+			}
+			std::sort(ret.begin(), ret.end(), [](const PathResult& a, const PathResult& b) { return a.score > b.score; });
+		}
+	};
+}
