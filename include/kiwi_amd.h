@@ -1,0 +1,71 @@
+/* kiwi_amd.h -- low-level C ABI of the MI355X batched analyze path (libkiwi_hip.so).
+ *
+ * These entry points are what a binding of the reference would call in place of its per-sentence
+ * loop; the Kiwi-compatible drop-in symbols (kiwi_init / kiwi_analyze* / kiwi_res_*) are declared in
+ * kiwi_capi.h and are implemented on top of this layer.  Plain pointers and sizes only.
+ *
+ *   kamd_open            <- kiwi_init + KiwiBuilder::build          (/root/reference/src/capi/kiwi_c.cpp:717-736)
+ *   kamd_analyze_batch   <- Kiwi::analyze(topN, reader, receiver)   (/root/reference/include/kiwi/Kiwi.h:402-454)
+ *   kamd_stage/run/fetch <- the same, split so a benchmark can time the device part with inputs resident in HBM
+ *   kamd_res_*           <- kiwi_res_* accessors                     (/root/reference/src/capi/kiwi_c.cpp:1036-1285)
+ */
+#ifndef KIWI_AMD_H
+#define KIWI_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kamd_engine* kamd_engine_h;
+typedef struct kamd_batch* kamd_batch_h;     /* chunks of a batch staged in HBM */
+typedef struct kamd_results* kamd_results_h; /* per-text token lists */
+
+typedef struct
+{
+	uint32_t position, word_position, sent_position, line_number;
+	uint16_t length; uint8_t tag; uint8_t sense_or_script;
+	float score, typo_cost;
+	uint32_t typo_form_id, paired_token, sub_sent_position;
+	uint16_t dialect; uint16_t form_len;
+	int32_t morph_id;
+	uint64_t form_off;   /* offset of the UTF-16 form in kamd_res_forms() */
+} kamd_token_t;
+
+/* returns NULL on failure; kamd_last_error() (thread local) tells why.  device < 0: current/first device */
+kamd_engine_h kamd_open(const char* raw_model_path, int device);
+void kamd_close(kamd_engine_h h);
+const char* kamd_last_error(void);
+
+/* KiwiConfig fields used on this path (include/kiwi/Kiwi.h:150-167) */
+int kamd_set_config(kamd_engine_h h, float cut_off_threshold, float space_penalty, float typo_cost_weight,
+	uint32_t max_unk_form_size, uint32_t max_unk_form_size_followed_by_jclass, uint32_t space_tolerance, int integrate_allomorph);
+
+/* texts: concatenated UTF-16; offsets[n+1].  top_n must be 1 for now (-1 + error otherwise). */
+kamd_results_h kamd_analyze_batch(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n,
+	uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
+
+kamd_batch_h kamd_stage(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint64_t match_options, int open_ending, int host_threads);
+/* launches the kernels on the staged batch; ms_out[3] = {dictionary scan, lattice build, best-path search} (HIP events) */
+int kamd_run(kamd_engine_h h, kamd_batch_h b, float* ms_out);
+kamd_results_h kamd_fetch(kamd_engine_h h, kamd_batch_h b, uint32_t top_n);
+/* info[0]=chunks, [1]=non-space normalised units ("jamo"), [2]=device bytes of the staged batch */
+int kamd_batch_info(kamd_batch_h b, uint64_t* info3);
+void kamd_batch_close(kamd_batch_h b);
+
+uint32_t kamd_res_texts(kamd_results_h r);
+uint32_t kamd_res_size(kamd_results_h r, uint32_t text);                       /* number of analyses (<= top_n) */
+float kamd_res_prob(kamd_results_h r, uint32_t text, uint32_t index);
+uint32_t kamd_res_token_num(kamd_results_h r, uint32_t text, uint32_t index);
+const kamd_token_t* kamd_res_tokens(kamd_results_h r, uint32_t text, uint32_t index);
+const uint16_t* kamd_res_forms(kamd_results_h r);
+void kamd_res_close(kamd_results_h r);
+
+/* test hooks: baked dictionary dump and the lattices of one text, in the byte layouts of oracle/ref_bridge.cpp */
+size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap);
+size_t kamd_dump_lattices(kamd_engine_h h, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

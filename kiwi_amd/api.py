@@ -1,0 +1,245 @@
+"""ctypes access to the product library kiwi_amd/libkiwi_hip.so through its C ABI (include/kiwi_amd.h).
+
+There is deliberately no fallback: if the shared library (built by ``__graft_entry__.build()`` /
+``make -C kiwi_amd/csrc``) is missing or no HIP device is visible, opening an engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkiwi_hip.so")
+
+MATCH_ALL = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 23)
+MATCH_ALL_WITH_NORMALIZING = MATCH_ALL | (1 << 16)
+
+
+@dataclass
+class Token:
+    form: str
+    tag: int
+    position: int
+    length: int
+    word_position: int
+    sent_position: int
+    line_number: int
+    sense_id: int
+    score: float
+    typo_cost: float
+    typo_form_id: int
+    paired_token: int
+    sub_sent_position: int
+    dialect: int
+    morph_id: int
+
+
+TOKEN_DTYPE = np.dtype([
+    ("position", "<u4"), ("word_position", "<u4"), ("sent_position", "<u4"), ("line_number", "<u4"),
+    ("length", "<u2"), ("tag", "u1"), ("sense_or_script", "u1"), ("score", "<f4"), ("typo_cost", "<f4"),
+    ("typo_form_id", "<u4"), ("paired_token", "<u4"), ("sub_sent_position", "<u4"), ("dialect", "<u2"),
+    ("form_len", "<u2"), ("morph_id", "<i4"), ("form_off", "<u8")])
+assert TOKEN_DTYPE.itemsize == 56
+
+
+def load_library():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the analyze path has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.kamd_open.restype = C.c_void_p
+    L.kamd_open.argtypes = [C.c_char_p, C.c_int]
+    L.kamd_close.argtypes = [C.c_void_p]
+    L.kamd_last_error.restype = C.c_char_p
+    L.kamd_set_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.kamd_analyze_batch.restype = C.c_void_p
+    L.kamd_analyze_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+    L.kamd_stage.restype = C.c_void_p
+    L.kamd_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+    L.kamd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kamd_fetch.restype = C.c_void_p
+    L.kamd_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.kamd_batch_info.argtypes = [C.c_void_p, C.c_void_p]
+    L.kamd_batch_close.argtypes = [C.c_void_p]
+    L.kamd_res_texts.restype = C.c_uint32
+    L.kamd_res_texts.argtypes = [C.c_void_p]
+    L.kamd_res_size.restype = C.c_uint32
+    L.kamd_res_size.argtypes = [C.c_void_p, C.c_uint32]
+    L.kamd_res_prob.restype = C.c_float
+    L.kamd_res_prob.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.kamd_res_token_num.restype = C.c_uint32
+    L.kamd_res_token_num.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.kamd_res_tokens.restype = C.c_void_p
+    L.kamd_res_tokens.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.kamd_res_forms.restype = C.c_void_p
+    L.kamd_res_forms.argtypes = [C.c_void_p]
+    L.kamd_res_close.argtypes = [C.c_void_p]
+    L.kamd_dump_dict.restype = C.c_size_t
+    L.kamd_dump_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.kamd_dump_lattices.restype = C.c_size_t
+    L.kamd_dump_lattices.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t]
+    return L
+
+
+def declared_symbols(header="kiwi_amd.h"):
+    """Function names declared in include/<header> (used by the CPU-side ABI test)."""
+    hdr = open(os.path.join(os.path.dirname(HERE), "include", header), encoding="utf-8").read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:kamd|kiwi)_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def pack_texts(texts):
+    enc = [np.frombuffer(t.encode("utf-16-le", errors="surrogatepass"), np.uint16) for t in texts]
+    offs = np.zeros(len(enc) + 1, np.uint64)
+    if enc:
+        offs[1:] = np.cumsum([len(e) for e in enc])
+    flat = np.ascontiguousarray(np.concatenate(enc)) if enc and offs[-1] else np.zeros(1, np.uint16)
+    return flat, offs
+
+
+class Results:
+    def __init__(self, lib, handle):
+        self.lib, self.h = lib, handle
+
+    def close(self):
+        if self.h:
+            self.lib.kamd_res_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def n_texts(self):
+        return self.lib.kamd_res_texts(self.h)
+
+    def token_array(self, text, index=0):
+        n = self.lib.kamd_res_token_num(self.h, text, index)
+        if not n:
+            return np.zeros(0, TOKEN_DTYPE)
+        p = self.lib.kamd_res_tokens(self.h, text, index)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n * TOKEN_DTYPE.itemsize,)).view(TOKEN_DTYPE).copy()
+
+    def to_python(self):
+        """[(tokens, score)] per analysis, per text -- same shape as refbridge.parse_results."""
+        out = []
+        forms_p = self.lib.kamd_res_forms(self.h)
+        for t in range(self.n_texts()):
+            res = []
+            for i in range(self.lib.kamd_res_size(self.h, t)):
+                arr = self.token_array(t, i)
+                toks = []
+                for r in arr:
+                    fl, fo = int(r["form_len"]), int(r["form_off"])
+                    raw = C.string_at(forms_p + 2 * fo, 2 * fl) if fl else b""
+                    toks.append(Token(raw.decode("utf-16-le", errors="surrogatepass"), int(r["tag"]), int(r["position"]), int(r["length"]),
+                                      int(r["word_position"]), int(r["sent_position"]), int(r["line_number"]), int(r["sense_or_script"]),
+                                      float(r["score"]), float(r["typo_cost"]), int(r["typo_form_id"]), int(r["paired_token"]),
+                                      int(r["sub_sent_position"]), int(r["dialect"]), int(r["morph_id"])))
+                res.append((toks, float(self.lib.kamd_res_prob(self.h, t, i))))
+            out.append(res)
+        return out
+
+
+class Batch:
+    def __init__(self, lib, handle):
+        self.lib, self.h = lib, handle
+
+    def info(self):
+        a = np.zeros(3, np.uint64)
+        self.lib.kamd_batch_info(self.h, a.ctypes.data)
+        return {"chunks": int(a[0]), "units": int(a[1]), "device_bytes": int(a[2])}
+
+    def close(self):
+        if self.h:
+            self.lib.kamd_batch_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class KiwiAmd:
+    """Batched analyzer on one MI355X."""
+
+    def __init__(self, raw_model_path: str, device: int = -1):
+        self.lib = load_library()
+        self.h = self.lib.kamd_open(raw_model_path.encode(), device)
+        if not self.h:
+            raise RuntimeError("kamd_open failed: " + self.lib.kamd_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.kamd_close(self.h)
+            self.h = None
+
+    def _err(self, what):
+        return RuntimeError(f"{what} failed: " + self.lib.kamd_last_error().decode())
+
+    def set_config(self, cut_off=8.0, space_penalty=7.0, typo_cost_weight=6.0, max_unk=6, max_unk_j=0xFFFFFFFF, space_tol=0, integrate_allomorph=True):
+        self.lib.kamd_set_config(self.h, cut_off, space_penalty, typo_cost_weight, max_unk, max_unk_j, space_tol, int(integrate_allomorph))
+
+    def analyze_batch(self, texts, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Results:
+        flat, offs = pack_texts(texts)
+        r = self.lib.kamd_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), top_n, match, int(open_ending), host_threads)
+        if not r:
+            raise self._err("kamd_analyze_batch")
+        return Results(self.lib, r)
+
+    def analyze(self, text, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False):
+        return self.analyze_batch([text], top_n, match, open_ending, 1).to_python()[0]
+
+    def stage(self, texts, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Batch:
+        flat, offs = pack_texts(texts)
+        b = self.lib.kamd_stage(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), match, int(open_ending), host_threads)
+        if not b:
+            raise self._err("kamd_stage")
+        return Batch(self.lib, b)
+
+    def run(self, batch: Batch):
+        ms = np.zeros(3, np.float32)
+        if self.lib.kamd_run(self.h, batch.h, ms.ctypes.data) != 0:
+            raise self._err("kamd_run")
+        return {"scan_ms": float(ms[0]), "lattice_ms": float(ms[1]), "search_ms": float(ms[2])}
+
+    def fetch(self, batch: Batch, top_n=1) -> Results:
+        r = self.lib.kamd_fetch(self.h, batch.h, top_n)
+        if not r:
+            raise self._err("kamd_fetch")
+        return Results(self.lib, r)
+
+    def dump_dict(self) -> bytes:
+        buf = np.zeros(1 << 20, np.uint8)
+        while True:
+            n = self.lib.kamd_dump_dict(self.h, buf.ctypes.data, buf.nbytes)
+            if n <= buf.nbytes:
+                return bytes(buf[:n])
+            buf = np.zeros(int(n * 1.2), np.uint8)
+
+    def split(self, text, match=MATCH_ALL_WITH_NORMALIZING):
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        buf = np.zeros(1 << 20, np.uint8)
+        while True:
+            n = self.lib.kamd_dump_lattices(self.h, u.ctypes.data, len(u), match, buf.ctypes.data, buf.nbytes)
+            if n == 0:
+                raise self._err("kamd_dump_lattices")
+            if n <= buf.nbytes:
+                break
+            buf = np.zeros(int(n * 1.2), np.uint8)
+        o = 0
+        (nch,) = struct.unpack_from("<I", buf, o)
+        o += 4
+        chunks = []
+        for _ in range(nch):
+            nn, se = struct.unpack_from("<II", buf, o)
+            o += 8
+            nodes = []
+            for _ in range(nn):
+                nodes.append(struct.unpack_from("<IIIIiIIIf", buf, o))
+                o += 36
+            chunks.append((se, nodes))
+        return chunks

@@ -1,0 +1,130 @@
+// Low-level C ABI (include/kiwi_amd.h) over kamd::Engine.  Error convention mirrors the reference's C API:
+// nothing throws across the boundary; failures return NULL / negative and leave a thread-local message
+// (/root/reference/src/capi/kiwi_c.cpp:84, 95-114).
+#include <cstring>
+#include <memory>
+#include <string>
+#include "../../include/kiwi_amd.h"
+#include "engine.hpp"
+
+using namespace kamd;
+
+struct kamd_engine { std::unique_ptr<Engine> e; };
+struct kamd_batch { std::shared_ptr<StagedBatch> b; };
+struct kamd_results
+{
+	std::vector<std::vector<std::vector<kamd_token_t>>> toks;   // [text][analysis][token]
+	std::vector<std::vector<float>> scores;
+	std::vector<uint16_t> forms;
+};
+
+namespace
+{
+	thread_local std::string lastError;
+	template<class Fn, class R> R guarded(Fn&& fn, R fail)
+	{
+		try { return fn(); }
+		catch (const std::exception& e) { lastError = e.what(); }
+		catch (...) { lastError = "unknown error"; }
+		return fail;
+	}
+
+	std::vector<std::pair<const char16_t*, size_t>> views(const uint16_t* texts, const uint64_t* offsets, uint32_t n)
+	{
+		std::vector<std::pair<const char16_t*, size_t>> v(n);
+		for (uint32_t i = 0; i < n; ++i) v[i] = { (const char16_t*)texts + offsets[i], (size_t)(offsets[i + 1] - offsets[i]) };
+		return v;
+	}
+
+	kamd_results* pack(std::vector<std::vector<TokenResult>>&& res)
+	{
+		auto r = std::make_unique<kamd_results>();
+		r->toks.resize(res.size()); r->scores.resize(res.size());
+		for (size_t t = 0; t < res.size(); ++t)
+		{
+			for (auto& a : res[t])
+			{
+				r->scores[t].push_back(a.second);
+				r->toks[t].emplace_back();
+				for (auto& tk : a.first)
+				{
+					kamd_token_t o{};
+					o.position = tk.position; o.word_position = tk.wordPosition; o.sent_position = tk.sentPosition; o.line_number = tk.lineNumber;
+					o.length = tk.length; o.tag = tk.tag; o.sense_or_script = tk.senseId; o.score = tk.score; o.typo_cost = tk.typoCost;
+					o.typo_form_id = tk.typoFormId; o.paired_token = tk.pairedToken; o.sub_sent_position = tk.subSentPosition; o.dialect = tk.dialect;
+					o.morph_id = tk.morph; o.form_len = (uint16_t)tk.str.size(); o.form_off = r->forms.size();
+					r->forms.insert(r->forms.end(), tk.str.begin(), tk.str.end());
+					r->toks[t].back().push_back(o);
+				}
+			}
+		}
+		return r.release();
+	}
+}
+
+extern "C"
+{
+	kamd_engine_h kamd_open(const char* path, int device)
+	{
+		return guarded([&]() { auto h = std::make_unique<kamd_engine>(); h->e.reset(new Engine(path, device)); return h.release(); }, (kamd_engine*)nullptr);
+	}
+	void kamd_close(kamd_engine_h h) { delete h; }
+	const char* kamd_last_error(void) { return lastError.c_str(); }
+
+	int kamd_set_config(kamd_engine_h h, float cutOff, float spacePenalty, float typoCostWeight, uint32_t maxUnk, uint32_t maxUnkJ, uint32_t spaceTol, int integrateAllomorph)
+	{
+		if (!h) return -2;
+		auto& c = h->e->config;
+		c.cutOffThreshold = cutOff; c.spacePenalty = spacePenalty; c.typoCostWeight = typoCostWeight;
+		c.maxUnkFormSize = maxUnk; c.maxUnkFormSizeFollowedByJClass = maxUnkJ; c.spaceTolerance = spaceTol; c.integrateAllomorph = !!integrateAllomorph;
+		return 0;
+	}
+
+	kamd_results_h kamd_analyze_batch(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int openEnding, int hostThreads)
+	{
+		if (!h) { lastError = "invalid handle"; return nullptr; }
+		return guarded([&]() { return pack(h->e->analyzeBatch(views(texts, offsets, n), topN, match, !!openEnding, hostThreads)); }, (kamd_results*)nullptr);
+	}
+
+	kamd_batch_h kamd_stage(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint64_t match, int openEnding, int hostThreads)
+	{
+		if (!h) { lastError = "invalid handle"; return nullptr; }
+		return guarded([&]() { auto b = std::make_unique<kamd_batch>(); b->b = h->e->stage(views(texts, offsets, n), match, !!openEnding, hostThreads); return b.release(); }, (kamd_batch*)nullptr);
+	}
+	int kamd_run(kamd_engine_h h, kamd_batch_h b, float* ms)
+	{
+		if (!h || !b) return -2;
+		return guarded([&]() { auto t = h->e->run(*b->b); if (ms) { ms[0] = t.scanMs; ms[1] = t.latticeMs; ms[2] = t.searchMs; } return 0; }, -1);
+	}
+	kamd_results_h kamd_fetch(kamd_engine_h h, kamd_batch_h b, uint32_t topN)
+	{
+		if (!h || !b) { lastError = "invalid handle"; return nullptr; }
+		return guarded([&]() { return pack(h->e->fetch(*b->b, topN)); }, (kamd_results*)nullptr);
+	}
+	int kamd_batch_info(kamd_batch_h b, uint64_t* info)
+	{
+		if (!b) return -2;
+		info[0] = Engine::stagedChunks(*b->b); info[1] = Engine::stagedUnits(*b->b); info[2] = Engine::stagedDeviceBytes(*b->b);
+		return 0;
+	}
+	void kamd_batch_close(kamd_batch_h b) { delete b; }
+
+	uint32_t kamd_res_texts(kamd_results_h r) { return r ? (uint32_t)r->toks.size() : 0; }
+	uint32_t kamd_res_size(kamd_results_h r, uint32_t t) { return (r && t < r->toks.size()) ? (uint32_t)r->toks[t].size() : 0; }
+	float kamd_res_prob(kamd_results_h r, uint32_t t, uint32_t i) { return (r && t < r->scores.size() && i < r->scores[t].size()) ? r->scores[t][i] : 0.f; }
+	uint32_t kamd_res_token_num(kamd_results_h r, uint32_t t, uint32_t i) { return (r && t < r->toks.size() && i < r->toks[t].size()) ? (uint32_t)r->toks[t][i].size() : 0; }
+	const kamd_token_t* kamd_res_tokens(kamd_results_h r, uint32_t t, uint32_t i) { return (r && t < r->toks.size() && i < r->toks[t].size()) ? r->toks[t][i].data() : nullptr; }
+	const uint16_t* kamd_res_forms(kamd_results_h r) { return r ? r->forms.data() : nullptr; }
+	void kamd_res_close(kamd_results_h r) { delete r; }
+
+	size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap)
+	{
+		if (!h) return 0;
+		return guarded([&]() { auto d = dumpDict(h->e->model()); if (d.size() <= cap) std::memcpy(out, d.data(), d.size()); return d.size(); }, (size_t)0);
+	}
+	size_t kamd_dump_lattices(kamd_engine_h h, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
+	{
+		if (!h) return 0;
+		return guarded([&]() { auto d = h->e->dumpLattices((const char16_t*)text, len, match); if (d.size() <= cap) std::memcpy(out, d.data(), d.size()); return d.size(); }, (size_t)0);
+	}
+}

@@ -1,0 +1,120 @@
+// Device-side data layout of one analyse batch (all buffers live in HBM; plain pointers, no torch types).
+// A "chunk" is the unit one lattice is built for (the reference's per-call splitByTrie range,
+// /root/reference/src/KTrie.cpp:766-858); chunks of a batch are independent.
+#pragma once
+#include <cstdint>
+#include "flat_model.hpp"
+
+namespace kamd
+{
+	struct DevPattern { uint32_t end, length; uint32_t tag; };   // chunk-relative (textprep.hpp PatternSpan)
+
+	// lattice node, 20 B (reference: KGraphNode 56 B, src/KTrie.h:57-77)
+	struct DevNode
+	{
+		uint32_t form;                 // form id or NOFORM
+		uint16_t startPos, endPos;     // ns positions while building, chunk-relative string offsets when final
+		uint16_t prev, sibling;        // relative links, as in the reference
+		uint16_t uformOff, uformLen;   // chunk-relative substring for OOV / special / pattern nodes
+		uint16_t spaceErrors;
+		uint16_t flags;                // unused
+	};
+	static_assert(sizeof(DevNode) == 20, "DevNode");
+	constexpr uint32_t NOFORM = 0xFFFFFFFFu;
+
+	// search state, 40 B (reference: WordLL<KnLMState> 48 B, src/BestPathContainer.hpp:21-67)
+	struct DevState
+	{
+		int32_t lmNode;
+		float accScore, firstChunkScore, accTypoCost;
+		uint32_t parent;               // chunk-relative state index
+		uint32_t morph;
+		uint32_t wid;
+		uint16_t nodeId;
+		uint8_t rootId, spState;
+		uint8_t socket, ownKind;       // ownKind: 0 none, 1 node.uform, 2 node.form string, 3 text[node.start,node.end)
+		uint16_t leftFeat;             // feature mask of the left string as seen by the next morpheme (+ LF_* bits)
+		uint8_t prevFlags, pad;
+		uint16_t ownNode;              // node whose own form this path carries
+	};
+	static_assert(sizeof(DevState) == 40, "DevState");
+	constexpr uint16_t LF_SKIP_COND = 1u << 13;   // previous morpheme closes a bracket: left conditions are not applied
+	constexpr uint16_t LF_PREV_ZSIOT = 1u << 14;
+	constexpr uint8_t COMMON_ROOT = 0xFF;
+
+	// output token, 24 B (reference: PathNode 72 B, src/PathEvaluator.h:33-68)
+	struct DevToken
+	{
+		uint32_t morph;
+		uint16_t begin, end;           // chunk-relative offsets in the normalised text
+		float wordScore, typoCost;
+		uint32_t ownA;                 // ownKind 1/3: chunk-relative offset of the own form; 2: form id
+		uint16_t ownLen;
+		uint8_t ownKind, pad;
+	};
+	static_assert(sizeof(DevToken) == 24, "DevToken");
+
+	constexpr uint32_t kMaxPathsPerChunk = 8;
+	struct DevPathHeader { float score; uint32_t tokOff; uint16_t nTokens; uint8_t prevState, curState; };
+	struct DevChunkResult { uint32_t nPaths; uint32_t status; DevPathHeader paths[kMaxPathsPerChunk]; };
+
+	enum ChunkStatus : uint32_t
+	{
+		CS_OK = 0, CS_NO_LATTICE = 1,   // <= 2 nodes: contributes nothing (Kiwi.cpp:1119)
+		CS_ERR_MATCH_OVERFLOW = 16, CS_ERR_NODE_OVERFLOW = 17, CS_ERR_STATE_OVERFLOW = 18, CS_ERR_TOKEN_OVERFLOW = 19,
+		CS_ERR_PATH_OVERFLOW = 20, CS_ERR_TOO_LONG = 21, CS_ERR_PAIR_OVERFLOW = 22,
+	};
+
+	struct SearchParams   // KiwiConfig + per-call options (include/kiwi/Kiwi.h:150-167, 69-134)
+	{
+		uint64_t match;
+		float cutOff, spacePenalty, typoCostWeight, oovRuleScale, oovRuleBias;
+		uint32_t maxUnk, maxUnkJ, spaceTol;
+		uint32_t splitComplex, splitSaisiot, mergeSaisiot;
+	};
+
+	struct BatchView
+	{
+		uint32_t nChunks;
+		const uint16_t* chars;         // normalised text of all chunks, concatenated
+		const uint8_t* cls;            // per unit: character type (low 6 bits) | 0x80 emoji start
+		const uint8_t* script;         // per unit: script id
+		const uint32_t* charOff;       // [nChunks+1]
+		const uint32_t* patOff;        // [nChunks+1]
+		const DevPattern* patterns;
+		const uint32_t* spOff;         // [nChunks+1] into spStates: sorted unique previous SpecialStates of the chunk
+		const uint8_t* spStates;
+		const uint8_t* chunkFlags;     // bit0: openEnding applies to this chunk
+	};
+
+	// Scratch + outputs.  All per-chunk regions are laid out by the host from the chunk lengths
+	// (capacities are linear in the chunk length; a chunk that outgrows one reports CS_ERR_* and is re-run
+	// by the host with larger capacities).  "+c" slots: per-character arrays have one extra slot per chunk.
+	struct WorkView
+	{
+		uint16_t* nsToPos;             // [charOff[c] + c + i]
+		uint16_t* posToNs;             // [charOff[c] + c + i], i in [0, nChars]
+		uint8_t* cflag;                // [charOff[c] + i]  bit0 non-space, bit1 skipped by the dictionary scan
+		uint64_t* matchMask;           // [charOff[c] + c + e] per ns end position e: bit d-1 set <=> a form of d units ends at e
+		uint32_t* matchOff;            // [charOff[c] + c + e] offset of e's forms inside the chunk's matchForm region
+		uint32_t* nNs;                 // [c]
+		const uint32_t* matchBase;     // [nChunks+1]
+		uint32_t* matchForm;
+		const uint32_t* nodeBase;      // [nChunks+1]
+		DevNode* nodes;                // final lattice of chunk c at nodeBase[c]
+		DevNode* tmpNodes;             // build-order nodes, same offsets
+		uint32_t* endPosMap;           // [charOff[c] + c + p] : first | second<<16
+		uint16_t* tmpIdx;              // per node scratch (inverse permutation / BFS queue), 2 per node
+		uint32_t* nNodes;              // [c]
+		const uint64_t* stateBase;     // [nChunks+1]
+		DevState* states;
+		uint32_t* nodeStateOff;        // per node (same offsets as nodes): chunk-relative first state
+		uint32_t* nodeStateCnt;
+		uint8_t* reach;                // per node: the reference's `reachable` flags (PathEvaluator.hpp:1159-1176, 1286)
+		const uint64_t* tokenBase;     // [nChunks+1]
+		DevToken* tokens;
+		DevChunkResult* results;       // [c]
+		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
+		uint32_t bigScratchBytes;      // per wave
+	};
+}

@@ -1,0 +1,475 @@
+// Batch driver (see engine.hpp).  Device memory is plain hipMalloc'd arenas sized from the batch's chunk
+// lengths; one stream; three kernel launches per round.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <stdexcept>
+#include <thread>
+#include "engine.hpp"
+
+namespace kamd
+{
+	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W);
+	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P);
+	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder);
+
+	namespace
+	{
+		void hipCheck(hipError_t e, const char* what)
+		{
+			if (e != hipSuccess) throw std::runtime_error{ std::string{ "HIP error in " } + what + ": " + hipGetErrorString(e) };
+		}
+#define HIPCHECK(x) hipCheck((x), #x)
+
+		struct DevBuf
+		{
+			void* p = nullptr; size_t cap = 0;
+			DevBuf() = default;
+			DevBuf(const DevBuf&) = delete;
+			DevBuf& operator=(const DevBuf&) = delete;
+			~DevBuf() { if (p) (void)hipFree(p); }
+			void ensure(size_t n)
+			{
+				if (n <= cap) return;
+				if (p) (void)hipFree(p);
+				p = nullptr; cap = 0;
+				const size_t want = n + n / 8 + 256;
+				HIPCHECK(hipMalloc(&p, want));
+				cap = want;
+			}
+			template<class T> T* as() const { return reinterpret_cast<T*>(p); }
+		};
+
+		template<class T> void upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
+		{
+			b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+			if (!v.empty()) HIPCHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+		}
+
+		constexpr uint32_t kBigScratchBytes = (8 + 8 + 4) * 8192 + (4 * 5) * 4096;
+	}
+
+	struct ChunkRef { uint32_t text, chunk; std::vector<uint8_t> sp; bool openEnding; };
+
+	struct StagedBatch
+	{
+		std::vector<U16> raw;
+		std::vector<PreparedText> prep;
+		std::vector<ChunkRef> refs;
+		uint64_t match = 0;
+		uint32_t capScale = 1;
+		uint64_t units = 0, devBytes = 0;
+		// host layout
+		std::vector<uint32_t> charOff, patOff, spOff, matchBase, nodeBase;
+		std::vector<uint64_t> stateBase, tokenBase;
+		// device
+		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags;
+		DevBuf dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
+		DevBuf dStateBase, dStates, dNodeStOff, dNodeStCnt, dReach, dTokenBase, dTokens, dResults, dOrder;
+		BatchView bv{}; WorkView wv{};
+		std::vector<DevChunkResult> hResults;
+		std::vector<DevToken> hTokens;
+		bool ran = false;
+	};
+
+	struct Engine::Impl
+	{
+		FlatModel model;
+		ModelView dview{};
+		std::vector<std::unique_ptr<DevBuf>> modelBufs;
+		hipStream_t stream = nullptr;
+		hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+		int device = 0;
+		uint32_t persistBlocks = 0;
+		DevBuf bigScratch, counter;
+
+		template<class T> const T* up(const std::vector<T>& v)
+		{
+			modelBufs.emplace_back(new DevBuf);
+			DevBuf& b = *modelBufs.back();
+			b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+			if (!v.empty()) HIPCHECK(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+			return b.as<T>();
+		}
+	};
+
+	Engine::Engine(const std::string& path, int device) : impl(new Impl)
+	{
+		bakeModel(impl->model, path);
+		int nDev = 0;
+		if (hipGetDeviceCount(&nDev) != hipSuccess || nDev == 0)
+			throw std::runtime_error{ "kiwi_amd: no HIP device visible -- the analyze path has no CPU fallback" };
+		if (device < 0) device = 0;
+		impl->device = device;
+		HIPCHECK(hipSetDevice(device));
+		HIPCHECK(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));
+		for (auto& e : impl->ev) HIPCHECK(hipEventCreate(&e));
+		const FlatModel& m = impl->model;
+		ModelView& v = impl->dview;
+		v.h = m.h;
+		v.forms = impl->up(m.forms); v.formChars = impl->up(m.formChars); v.formCand = impl->up(m.formCand);
+		v.morphs = impl->up(m.morphs); v.chunkMorph = impl->up(m.chunkMorph); v.chunkLm = impl->up(m.chunkLm); v.chunkPos = impl->up(m.chunkPos);
+		v.sbInfo = impl->up(m.sbInfo);
+		v.trie = impl->up(m.trie); v.trieKeys = impl->up(m.trieKeys); v.trieChild = impl->up(m.trieChild); v.trieRoot = impl->up(m.trieRoot);
+		v.lmNodes = impl->up(m.lmNodes); v.lmKeys = impl->up(m.lmKeys); v.lmValues = impl->up(m.lmValues); v.lmRoot = impl->up(m.lmRoot);
+		hipDeviceProp_t prop;
+		HIPCHECK(hipGetDeviceProperties(&prop, device));
+		impl->persistBlocks = (uint32_t)prop.multiProcessorCount * 16;   // one-wave blocks; LDS footprint allows >= 16 per CU
+		impl->bigScratch.ensure((size_t)impl->persistBlocks * kBigScratchBytes);
+		impl->counter.ensure(64);
+	}
+
+	Engine::~Engine()
+	{
+		if (impl)
+		{
+			for (auto& e : impl->ev) if (e) (void)hipEventDestroy(e);
+			if (impl->stream) (void)hipStreamDestroy(impl->stream);
+		}
+	}
+
+	const FlatModel& Engine::model() const { return impl->model; }
+
+	namespace
+	{
+		void parallelFor(size_t n, int threads, const std::function<void(size_t)>& fn)
+		{
+			if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+			threads = (int)std::min<size_t>(threads, std::max<size_t>(1, n / 64));
+			if (threads <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+			std::atomic<size_t> next{ 0 };
+			std::exception_ptr err; std::atomic<bool> failed{ false };
+			auto work = [&]()
+			{
+				try
+				{
+					for (;;)
+					{
+						const size_t i = next.fetch_add(64);
+						if (i >= n || failed) break;
+						for (size_t k = i; k < std::min(n, i + 64); ++k) fn(k);
+					}
+				}
+				catch (...) { if (!failed.exchange(true)) err = std::current_exception(); }
+			};
+			std::vector<std::thread> ts;
+			for (int t = 0; t < threads; ++t) ts.emplace_back(work);
+			for (auto& t : ts) t.join();
+			if (err) std::rethrow_exception(err);
+		}
+	}
+
+	// Lays a set of chunks out in HBM.
+	static void layoutAndUpload(Engine::Impl& I, StagedBatch& b, const SearchParams&)
+	{
+		const size_t nC = b.refs.size();
+		b.charOff.assign(nC + 1, 0); b.patOff.assign(nC + 1, 0); b.spOff.assign(nC + 1, 0);
+		b.matchBase.assign(nC + 1, 0); b.nodeBase.assign(nC + 1, 0); b.stateBase.assign(nC + 1, 0); b.tokenBase.assign(nC + 1, 0);
+		std::vector<uint8_t> flags(nC), sp;
+		const uint64_t sc = b.capScale;
+		for (size_t c = 0; c < nC; ++c)
+		{
+			const auto& r = b.refs[c];
+			const ChunkDesc& d = b.prep[r.text].chunks[r.chunk];
+			const uint64_t n = d.nChars;
+			b.charOff[c + 1] = b.charOff[c] + (uint32_t)n;
+			b.patOff[c + 1] = b.patOff[c] + (d.patEnd - d.patBegin);
+			b.spOff[c + 1] = b.spOff[c] + (uint32_t)r.sp.size();
+			const uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
+			if ((uint64_t)b.matchBase[c] + mcap > 0xFFFFFFFFull || (uint64_t)b.nodeBase[c] + ncap > 0xFFFFFFFFull) throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
+			b.matchBase[c + 1] = b.matchBase[c] + (uint32_t)mcap;
+			b.nodeBase[c + 1] = b.nodeBase[c] + (uint32_t)ncap;
+			b.stateBase[c + 1] = b.stateBase[c] + scap;
+			b.tokenBase[c + 1] = b.tokenBase[c] + tcap;
+			flags[c] = r.openEnding ? 1 : 0;
+			sp.insert(sp.end(), r.sp.begin(), r.sp.end());
+		}
+		const size_t totChars = b.charOff[nC];
+		std::vector<uint16_t> chars(totChars); std::vector<uint8_t> cls(totChars), script(totChars);
+		std::vector<DevPattern> pats(b.patOff[nC]);
+		b.units = 0;
+		for (size_t c = 0; c < nC; ++c)
+		{
+			const auto& r = b.refs[c];
+			const PreparedText& pt = b.prep[r.text];
+			const ChunkDesc& d = pt.chunks[r.chunk];
+			std::memcpy(chars.data() + b.charOff[c], pt.norm.data() + d.startOffset, 2 * (size_t)d.nChars);
+			std::memcpy(cls.data() + b.charOff[c], pt.cls.data() + d.startOffset, d.nChars);
+			std::memcpy(script.data() + b.charOff[c], pt.script.data() + d.startOffset, d.nChars);
+			for (uint32_t k = d.patBegin; k < d.patEnd; ++k) pats[b.patOff[c] + (k - d.patBegin)] = DevPattern{ pt.patterns[k].end, pt.patterns[k].length, pt.patterns[k].tag };
+			for (uint32_t k = 0; k < d.nChars; ++k) if (!isSpace(pt.norm[d.startOffset + k])) ++b.units;
+		}
+		hipStream_t s = I.stream;
+		upload(b.dChars, chars, s); upload(b.dCls, cls, s); upload(b.dScript, script, s);
+		upload(b.dCharOff, b.charOff, s); upload(b.dPatOff, b.patOff, s); upload(b.dPatterns, pats, s);
+		upload(b.dSpOff, b.spOff, s); upload(b.dSp, sp, s); upload(b.dFlags, flags, s);
+		upload(b.dMatchBase, b.matchBase, s); upload(b.dNodeBase, b.nodeBase, s); upload(b.dStateBase, b.stateBase, s); upload(b.dTokenBase, b.tokenBase, s);
+		const size_t perChar = totChars + nC + 16;
+		const size_t totNodes = b.nodeBase[nC], totMatch = b.matchBase[nC];
+		const uint64_t totStates = b.stateBase[nC], totTokens = b.tokenBase[nC];
+		b.dNsToPos.ensure(perChar * 2); b.dPosToNs.ensure(perChar * 2); b.dCflag.ensure(perChar); b.dMask.ensure(perChar * 8); b.dMoff.ensure(perChar * 4);
+		b.dNNs.ensure(nC * 4 + 16); b.dMatchForm.ensure(totMatch * 4 + 16);
+		b.dNodes.ensure(totNodes * sizeof(DevNode) + 16); b.dTmpNodes.ensure(totNodes * sizeof(DevNode) + 16);
+		b.dEndPosMap.ensure(perChar * 4); b.dTmpIdx.ensure(totNodes * 4 + 16); b.dNNodes.ensure(nC * 4 + 16);
+		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
+		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
+		b.devBytes = 0;
+		for (const DevBuf* d : { &b.dChars, &b.dCls, &b.dScript, &b.dNsToPos, &b.dPosToNs, &b.dCflag, &b.dMask, &b.dMoff, &b.dMatchForm, &b.dNodes, &b.dTmpNodes, &b.dEndPosMap, &b.dTmpIdx,
+			&b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults }) b.devBytes += d->cap;
+
+		BatchView& bv = b.bv;
+		bv.nChunks = (uint32_t)nC; bv.chars = b.dChars.as<uint16_t>(); bv.cls = b.dCls.as<uint8_t>(); bv.script = b.dScript.as<uint8_t>();
+		bv.charOff = b.dCharOff.as<uint32_t>(); bv.patOff = b.dPatOff.as<uint32_t>(); bv.patterns = b.dPatterns.as<DevPattern>();
+		bv.spOff = b.dSpOff.as<uint32_t>(); bv.spStates = b.dSp.as<uint8_t>(); bv.chunkFlags = b.dFlags.as<uint8_t>();
+		WorkView& w = b.wv;
+		w.nsToPos = b.dNsToPos.as<uint16_t>(); w.posToNs = b.dPosToNs.as<uint16_t>(); w.cflag = b.dCflag.as<uint8_t>();
+		w.matchMask = b.dMask.as<uint64_t>(); w.matchOff = b.dMoff.as<uint32_t>(); w.nNs = b.dNNs.as<uint32_t>();
+		w.matchBase = b.dMatchBase.as<uint32_t>(); w.matchForm = b.dMatchForm.as<uint32_t>();
+		w.nodeBase = b.dNodeBase.as<uint32_t>(); w.nodes = b.dNodes.as<DevNode>(); w.tmpNodes = b.dTmpNodes.as<DevNode>();
+		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>();
+		w.stateBase = b.dStateBase.as<uint64_t>(); w.states = b.dStates.as<DevState>();
+		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();
+		w.tokenBase = b.dTokenBase.as<uint64_t>(); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
+		w.bigScratch = I.bigScratch.as<uint8_t>(); w.bigScratchBytes = kBigScratchBytes;
+		// longest chunks first: the persistent search waves pull work in this order
+		std::vector<uint32_t> order(nC);
+		std::iota(order.begin(), order.end(), 0u);
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return b.charOff[a + 1] - b.charOff[a] > b.charOff[c + 1] - b.charOff[c]; });
+		upload(b.dOrder, order, s);
+		HIPCHECK(hipStreamSynchronize(s));
+		b.ran = false;
+	}
+
+	static SearchParams makeParams(const EngineConfig& c, uint64_t match)
+	{
+		SearchParams p{};
+		p.match = match; p.cutOff = c.cutOffThreshold; p.spacePenalty = c.spacePenalty; p.typoCostWeight = c.typoCostWeight;
+		p.oovRuleScale = c.oovRuleScale; p.oovRuleBias = c.oovRuleBias;
+		p.maxUnk = c.maxUnkFormSize; p.maxUnkJ = c.maxUnkFormSizeFollowedByJClass; p.spaceTol = c.spaceTolerance;
+		p.splitComplex = (match & M_SPLIT_COMPLEX) ? 1 : 0; p.splitSaisiot = (match & M_SPLIT_SAISIOT) ? 1 : 0; p.mergeSaisiot = (match & M_MERGE_SAISIOT) ? 1 : 0;
+		return p;
+	}
+
+	static KernelTimes launchAll(Engine::Impl& I, StagedBatch& b, const SearchParams& sp)
+	{
+		KernelTimes t;
+		const uint32_t nC = (uint32_t)b.refs.size();
+		if (!nC) return t;
+		hipStream_t s = I.stream;
+		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), s));
+		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 64, s));
+		HIPCHECK(hipEventRecord(I.ev[0], s));
+		hipLaunchKernelGGL(k_dict_scan, dim3((nC + 3) / 4), dim3(256), 0, s, I.dview, b.bv, b.wv);
+		HIPCHECK(hipEventRecord(I.ev[1], s));
+		hipLaunchKernelGGL(k_build_lattice, dim3((nC + 63) / 64), dim3(64), 0, s, I.dview, b.bv, b.wv, sp);
+		HIPCHECK(hipEventRecord(I.ev[2], s));
+		const uint32_t blocks = std::min(I.persistBlocks, nC);
+		hipLaunchKernelGGL(k_best_path, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>());
+		HIPCHECK(hipEventRecord(I.ev[3], s));
+		HIPCHECK(hipGetLastError());
+		HIPCHECK(hipStreamSynchronize(s));
+		HIPCHECK(hipEventElapsedTime(&t.scanMs, I.ev[0], I.ev[1]));
+		HIPCHECK(hipEventElapsedTime(&t.latticeMs, I.ev[1], I.ev[2]));
+		HIPCHECK(hipEventElapsedTime(&t.searchMs, I.ev[2], I.ev[3]));
+		b.ran = true;
+		return t;
+	}
+
+	static void download(Engine::Impl& I, StagedBatch& b)
+	{
+		const size_t nC = b.refs.size();
+		b.hResults.resize(nC);
+		b.hTokens.resize(b.tokenBase[nC]);
+		if (!nC) return;
+		HIPCHECK(hipMemcpyAsync(b.hResults.data(), b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost, I.stream));
+		HIPCHECK(hipMemcpyAsync(b.hTokens.data(), b.dTokens.p, b.hTokens.size() * sizeof(DevToken), hipMemcpyDeviceToHost, I.stream));
+		HIPCHECK(hipStreamSynchronize(I.stream));
+	}
+
+	static void chunkPaths(std::vector<PathResult>& out, const FlatModel& m, const StagedBatch& b, size_t c)
+	{
+		out.clear();
+		const DevChunkResult& r = b.hResults[c];
+		const auto& ref = b.refs[c];
+		const PreparedText& pt = b.prep[ref.text];
+		const uint32_t so = pt.chunks[ref.chunk].startOffset;
+		for (uint32_t p = 0; p < r.nPaths; ++p)
+		{
+			PathResult pr;
+			pr.score = r.paths[p].score; pr.prevState = r.paths[p].prevState; pr.curState = r.paths[p].curState;
+			const DevToken* tk = b.hTokens.data() + b.tokenBase[c] + r.paths[p].tokOff;
+			for (uint32_t k = 0; k < r.paths[p].nTokens; ++k)
+			{
+				PathTok t;
+				t.morph = tk[k].morph; t.begin = tk[k].begin + so; t.end = tk[k].end + so; t.wordScore = tk[k].wordScore; t.typoCost = tk[k].typoCost;
+				if (tk[k].ownKind == 2) t.str = m.formStr(tk[k].ownA);
+				else if (tk[k].ownKind) t.str = pt.norm.substr(so + tk[k].ownA, tk[k].ownLen);
+				pr.path.push_back(std::move(t));
+			}
+			out.push_back(std::move(pr));
+		}
+		std::sort(out.begin(), out.end(), [](const PathResult& a, const PathResult& b2) { return a.score > b2.score; });   // PathEvaluator.hpp:1414-1417
+	}
+
+	std::shared_ptr<StagedBatch> Engine::stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads)
+	{
+		auto b = std::make_shared<StagedBatch>();
+		b->match = match;
+		b->raw.resize(texts.size()); b->prep.resize(texts.size());
+		parallelFor(texts.size(), hostThreads, [&](size_t i)
+		{
+			b->raw[i].assign(texts[i].first, texts[i].second);
+			prepareText(b->prep[i], texts[i].first, texts[i].second, match, (uint32_t)i);
+		});
+		for (size_t i = 0; i < texts.size(); ++i)
+		{
+			const auto& pt = b->prep[i];
+			for (size_t c = 0; c < pt.chunks.size(); ++c)
+			{
+				if (pt.chunks[c].empty) continue;
+				if (pt.chunks[c].nChars > 0xFFF0) throw std::runtime_error{ "chunk longer than 65520 units" };
+				b->refs.push_back(ChunkRef{ (uint32_t)i, (uint32_t)c, { 0 }, openEnding && pt.chunks[c].nextOffset == pt.norm.size() });
+			}
+		}
+		layoutAndUpload(*impl, *b, makeParams(config, match));
+		return b;
+	}
+
+	KernelTimes Engine::run(StagedBatch& b) { return launchAll(*impl, b, makeParams(config, b.match)); }
+	size_t Engine::stagedChunks(const StagedBatch& b) { return b.refs.size(); }
+	uint64_t Engine::stagedUnits(const StagedBatch& b) { return b.units; }
+	uint64_t Engine::stagedDeviceBytes(const StagedBatch& b) { return b.devBytes; }
+
+	// Runs an explicit list of chunks (used for re-runs with larger capacities or non-default special states).
+	static void runRefs(Engine& E, Engine::Impl& I, StagedBatch& parent, std::vector<ChunkRef> refs, uint32_t capScale,
+		std::vector<std::vector<PathResult>>& out)
+	{
+		StagedBatch b;
+		b.match = parent.match; b.capScale = capScale;
+		b.prep.swap(parent.prep);   // borrow
+		b.refs = std::move(refs);
+		try
+		{
+			const SearchParams sp = makeParams(E.config, b.match);
+			layoutAndUpload(I, b, sp);
+			launchAll(I, b, sp);
+			download(I, b);
+			out.resize(b.refs.size());
+			for (size_t c = 0; c < b.refs.size(); ++c)
+			{
+				if (b.hResults[c].status >= 16)
+				{
+					if (capScale >= 64) throw std::runtime_error{ "analyze: device scratch overflow (status " + std::to_string(b.hResults[c].status) + ") even at 64x capacity" };
+					std::vector<std::vector<PathResult>> one;
+					b.prep.swap(parent.prep);
+					runRefs(E, I, parent, { b.refs[c] }, capScale * 4, one);
+					b.prep.swap(parent.prep);
+					out[c] = std::move(one[0]);
+				}
+				else chunkPaths(out[c], I.model, b, c);
+			}
+		}
+		catch (...) { b.prep.swap(parent.prep); throw; }
+		b.prep.swap(parent.prep);
+	}
+
+	std::vector<std::vector<TokenResult>> Engine::fetch(StagedBatch& b, size_t topN)
+	{
+		if (topN != 1) throw std::invalid_argument{ "kiwi_amd: top_n > 1 is not implemented on the device path yet" };
+		if (!b.ran) run(b);
+		download(*impl, b);
+		const size_t nT = b.prep.size();
+		std::vector<std::vector<TokenResult>> ret(nT);
+		// chunk index of each text inside refs
+		std::vector<size_t> firstRef(nT + 1, 0);
+		for (auto& r : b.refs) firstRef[r.text + 1]++;
+		for (size_t i = 0; i < nT; ++i) firstRef[i + 1] += firstRef[i];
+		std::vector<PathResult> paths;
+		for (size_t i = 0; i < nT; ++i)
+		{
+			ResultBuilder rb{ impl->model, topN, b.match, config.integrateAllomorph };
+			rb.begin(b.raw[i].data(), b.raw[i].size(), b.prep[i].position);
+			for (size_t c = firstRef[i]; c < firstRef[i + 1]; ++c)
+			{
+				// special states actually carried into this chunk (Kiwi.cpp:1122-1140) vs. the ones it was searched with
+				std::vector<uint8_t> uniq = rb.spStates();
+				std::sort(uniq.begin(), uniq.end());
+				uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+				if (uniq.empty()) uniq.push_back(0);
+				const uint32_t st = b.hResults[c].status;
+				if (st >= 16 || uniq != b.refs[c].sp)
+				{
+					std::vector<std::vector<PathResult>> one;
+					ChunkRef r = b.refs[c]; r.sp = uniq;
+					runRefs(*this, *impl, b, { r }, st >= 16 ? b.capScale * 4 : b.capScale, one);
+					if (!one[0].empty()) rb.insertPaths(one[0]);
+					continue;
+				}
+				if (st == CS_NO_LATTICE) continue;
+				chunkPaths(paths, impl->model, b, c);
+				rb.insertPaths(paths);
+			}
+			ret[i] = rb.finish(b.raw[i].data(), b.raw[i].size());
+		}
+		return ret;
+	}
+
+	std::vector<std::vector<TokenResult>> Engine::analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
+		size_t topN, uint64_t match, bool openEnding, int hostThreads)
+	{
+		if (topN != 1) throw std::invalid_argument{ "kiwi_amd: top_n > 1 is not implemented on the device path yet" };
+		auto b = stage(texts, match, openEnding, hostThreads);
+		run(*b);
+		return fetch(*b, topN);
+	}
+
+	std::vector<uint8_t> Engine::dumpLattices(const char16_t* text, size_t n, uint64_t match)
+	{
+		std::vector<std::pair<const char16_t*, size_t>> texts{ { text, n } };
+		auto b = stage(texts, match, false, 1);
+		run(*b);
+		const size_t nC = b->refs.size();
+		std::vector<uint32_t> nNodes(nC);
+		std::vector<DevNode> nodes(b->nodeBase[nC]);
+		std::vector<DevChunkResult> res(nC);
+		if (nC)
+		{
+			HIPCHECK(hipMemcpy(nNodes.data(), b->dNNodes.p, nC * 4, hipMemcpyDeviceToHost));
+			HIPCHECK(hipMemcpy(nodes.data(), b->dNodes.p, nodes.size() * sizeof(DevNode), hipMemcpyDeviceToHost));
+			HIPCHECK(hipMemcpy(res.data(), b->dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost));
+		}
+		std::vector<uint8_t> out;
+		auto put32 = [&](uint32_t v) { out.insert(out.end(), (uint8_t*)&v, (uint8_t*)&v + 4); };
+		const PreparedText& pt = b->prep[0];
+		put32((uint32_t)pt.chunks.size());
+		size_t ri = 0;
+		for (size_t c = 0; c < pt.chunks.size(); ++c)
+		{
+			const ChunkDesc& d = pt.chunks[c];
+			if (d.empty)
+			{
+				put32(2); put32(d.nextOffset);
+				for (int k = 0; k < 2 * 9; ++k) put32(0);
+				continue;
+			}
+			if (res[ri].status >= 16) throw std::runtime_error{ "dumpLattices: device status " + std::to_string(res[ri].status) };
+			const uint32_t G = nNodes[ri];
+			put32(G); put32(d.nextOffset);
+			for (uint32_t k = 0; k < G; ++k)
+			{
+				const DevNode& nd = nodes[b->nodeBase[ri] + k];
+				const bool inner = k >= 1 && k + 1 < G;
+				put32(nd.startPos + ((inner || k + 1 == G) ? d.startOffset : 0)); put32(nd.endPos + ((inner || k + 1 == G) ? d.startOffset : 0));
+				put32(nd.prev); put32(nd.sibling);
+				put32(nd.form == NOFORM ? 0xFFFFFFFFu : nd.form);
+				put32(nd.uformLen); put32(nd.uformLen ? nd.uformOff + d.startOffset : 0);
+				put32(nd.spaceErrors); put32(0);
+			}
+			++ri;
+		}
+		return out;
+	}
+}

@@ -1,0 +1,56 @@
+// Batch driver around the HIP kernels: the MI355X counterpart of the reference's per-sentence loop in
+// Kiwi::analyze (/root/reference/src/Kiwi.cpp:1095-1141) and of its thread-pool batch driver
+// (/root/reference/include/kiwi/Kiwi.h:402-454).  Host code prepares chunks (textprep), the kernels build
+// lattices and search them, host code stitches chunk results into token lists (post).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+#include "device_types.hpp"
+#include "post.hpp"
+#include "textprep.hpp"
+
+namespace kamd
+{
+	struct EngineConfig   // KiwiConfig (include/kiwi/Kiwi.h:150-167)
+	{
+		bool integrateAllomorph = true;
+		float cutOffThreshold = 8, oovRuleScale = 4, oovRuleBias = 4, spacePenalty = 7, typoCostWeight = 6;
+		uint32_t maxUnkFormSize = 6, maxUnkFormSizeFollowedByJClass = 0xFFFFFFFFu, spaceTolerance = 0;
+	};
+
+	struct KernelTimes { float scanMs = 0, latticeMs = 0, searchMs = 0; };
+
+	struct StagedBatch;   // chunks of one round resident in HBM
+
+	class Engine
+	{
+	public:
+		struct Impl;
+	private:
+		std::unique_ptr<Impl> impl;
+	public:
+		EngineConfig config;
+		explicit Engine(const std::string& rawModelPath, int device = -1);
+		~Engine();
+		const FlatModel& model() const;
+
+		// Full path: prepare -> kernels -> results, for a batch of raw UTF-16 texts.  Results are per text.
+		std::vector<std::vector<TokenResult>> analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
+			size_t topN, uint64_t match, bool openEnding, int hostThreads = 0);
+
+		// Staged path (benchmarks): stage() does host preparation + upload of every chunk of the texts (one round,
+		// the common case where no quote/bullet state crosses chunk boundaries); run() launches the three kernels on
+		// the resident batch and returns their event-timed durations; fetch() downloads and assembles results.
+		std::shared_ptr<StagedBatch> stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads = 0);
+		KernelTimes run(StagedBatch& b);
+		std::vector<std::vector<TokenResult>> fetch(StagedBatch& b, size_t topN);
+		static size_t stagedChunks(const StagedBatch& b);
+		static uint64_t stagedUnits(const StagedBatch& b);     // non-space normalised units ("jamo")
+		static uint64_t stagedDeviceBytes(const StagedBatch& b);
+
+		// debugging / parity hooks: lattice of every chunk of one text in the layout of oracle's korc_split
+		std::vector<uint8_t> dumpLattices(const char16_t* text, size_t n, uint64_t match);
+	};
+}

@@ -19,6 +19,7 @@ namespace kamd
 		FF_FIRST_IS_CODA = 16,   // isHangulCoda(form[0])            (KTrie.cpp:969)
 		FF_IS_STAG = 32,         // single special char sf..sw        (KTrie.cpp:971-972)
 		FF_STARTS_WITH_A = 64,   // form[0] == U+C544 '아'            (PathEvaluator.hpp:104)
+		FF_ENDS_WITH_SSC = 128,  // identifySpecialChr(form.back()) == ssc (PathEvaluator.hpp:289, own-form case)
 	};
 	struct FormRec
 	{

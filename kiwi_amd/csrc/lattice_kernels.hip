@@ -1,0 +1,449 @@
+// HIP kernels for lattice construction on gfx950 (MI355X).
+//
+//  k_dict_scan   : one wavefront per chunk.  Lane s owns dictionary-scan start position s (looping when the
+//                  chunk has more than 64 positions) and walks the CSR-flattened form trie from the root along
+//                  str[s..]; the root transition is a direct table, deeper transitions a binary search over the
+//                  node's sorted child keys.  Every terminal reached at depth d ending at position e sets bit
+//                  d-1 of matchMask[e]; a wave-wide scan over popcounts turns the masks into packed per-end
+//                  form lists (longest first), which is exactly the candidate order the reference's
+//                  Aho-Corasick walk produces per character (goto/fail + submatch chain,
+//                  /root/reference/src/KTrie.cpp:1283-1311).  Order independent => embarrassingly parallel.
+//  k_build_lattice : one thread per chunk.  The reference's lattice bookkeeping is inherently sequential
+//                  (OOV insertion depends on the end of the most recently appended node, appends depend on
+//                  reachability: /root/reference/src/KTrie.cpp:15-43, 921-996, 1040-1137, 240-299), so each
+//                  thread replays it for its chunk over the packed match lists; 64 chunks advance per wave.
+// Memory-bound integer work: no MFMA; see DESIGN.md for the roofline accounting.
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+
+namespace kamd
+{
+	__device__ __forceinline__ uint32_t trieChild(const ModelView& M, uint32_t node, uint16_t c)
+	{
+		if (node == 0) return M.trieRoot[c];
+		const TrieNodeRec t = M.trie[node];
+		const uint16_t* keys = M.trieKeys + t.edgeOff;
+		uint32_t lo = 0, hi = t.numNexts;
+		while (lo < hi)
+		{
+			const uint32_t mid = (lo + hi) >> 1;
+			const uint16_t k = keys[mid];
+			if (k < c) lo = mid + 1; else hi = mid;
+		}
+		if (lo < t.numNexts && keys[lo] == c) return M.trieChild[t.edgeOff + lo];
+		return 0;
+	}
+
+	__global__ void __launch_bounds__(256) k_dict_scan(ModelView M, BatchView B, WorkView W)
+	{
+		const uint32_t lane = threadIdx.x & 63;
+		const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+		if (chunk >= B.nChunks) return;
+		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
+		const uint16_t* str = B.chars + cOff;
+		const uint8_t* cls = B.cls + cOff;
+		uint16_t* nsToPos = W.nsToPos + cOff + chunk;
+		uint16_t* posToNs = W.posToNs + cOff + chunk;
+		uint8_t* cflag = W.cflag + cOff;
+		uint64_t* mask = W.matchMask + cOff + chunk;
+		uint32_t* moff = W.matchOff + cOff + chunk;
+
+		// ---- 1. non-space index maps (Splitter::preparePattern tail, KTrie.cpp:837-854) ----------------
+		uint32_t nsCount = 0;
+		for (uint32_t base = 0; base < n; base += 64)
+		{
+			const uint32_t i = base + lane;
+			bool isNs = false, skip = false;
+			if (i < n)
+			{
+				const uint16_t c = str[i];
+				// a unit right after an (unpaired-so-far) high surrogate is always kept with it
+				uint32_t run = 0;
+				for (int32_t j = (int32_t)i - 1; j >= 0 && isHighSurrogate(str[j]); --j) ++run;
+				const bool second = run & 1;
+				isNs = second || !isSpace(c);
+				const bool pairStart = !second && isHighSurrogate(c) && i + 1 < n;
+				// units the dictionary walk never feeds to the trie: surrogate pairs, and space-class units
+				// (KTrie.cpp:1099-1116, 1218-1223); the ZWJ-after-symbol exception is resolved in k_build_lattice
+				skip = second || pairStart || ((cls[i] & 0x3F) == T_UNKNOWN);
+			}
+			const uint64_t bal = __ballot(isNs);
+			const uint32_t rank = nsCount + __popcll(bal & ((1ull << lane) - 1));
+			if (i < n)
+			{
+				posToNs[i] = (uint16_t)rank;
+				if (isNs) nsToPos[rank] = (uint16_t)i;
+				cflag[i] = (isNs ? 1 : 0) | (skip ? 2 : 0);
+			}
+			nsCount += __popcll(bal);
+		}
+		if (lane == 0) { posToNs[n] = (uint16_t)nsCount; W.nNs[chunk] = nsCount; }
+		const uint32_t nNs = nsCount;
+		for (uint32_t e = lane; e <= nNs; e += 64) mask[e] = 0;
+		__threadfence_block();
+
+		// ---- 2. trie walk, pass 1: mark terminals ------------------------------------------------------
+		for (uint32_t base = 0; base < nNs; base += 64)
+		{
+			const uint32_t s = base + lane;
+			if (s >= nNs) continue;
+			if (cflag[nsToPos[s]] & 2) continue;
+			uint32_t node = 0, depth = 0;
+			for (uint32_t i = s; i < nNs; ++i)
+			{
+				const uint32_t p = nsToPos[i];
+				if (cflag[p] & 2) continue;
+				node = trieChild(M, node, str[p]);
+				if (!node) break;
+				++depth;
+				if (M.trie[node].value >= 0) atomicOr((unsigned long long*)&mask[i + 1], 1ull << (depth - 1));
+			}
+		}
+		__threadfence_block();
+
+		// ---- 3. exclusive scan of popcounts -> per-end offsets ----------------------------------------
+		uint32_t total = 0;
+		for (uint32_t base = 0; base <= nNs; base += 64)
+		{
+			const uint32_t e = base + lane;
+			const uint32_t cnt = e <= nNs ? __popcll(mask[e]) : 0;
+			uint32_t incl = cnt;
+			for (uint32_t d = 1; d < 64; d <<= 1)
+			{
+				const uint32_t v = __shfl_up(incl, d);
+				if (lane >= d) incl += v;
+			}
+			if (e <= nNs) moff[e] = total + incl - cnt;
+			total += __shfl(incl, 63);
+		}
+		const uint32_t mBase = W.matchBase[chunk], mCap = W.matchBase[chunk + 1] - mBase;
+		if (total > mCap)
+		{
+			if (lane == 0) W.results[chunk].status = CS_ERR_MATCH_OVERFLOW;
+			return;
+		}
+		__threadfence_block();
+
+		// ---- 4. pass 2: fill packed form lists, longest form first within an end position -------------
+		uint32_t* forms = W.matchForm + mBase;
+		for (uint32_t base = 0; base < nNs; base += 64)
+		{
+			const uint32_t s = base + lane;
+			if (s >= nNs) continue;
+			if (cflag[nsToPos[s]] & 2) continue;
+			uint32_t node = 0, depth = 0;
+			for (uint32_t i = s; i < nNs; ++i)
+			{
+				const uint32_t p = nsToPos[i];
+				if (cflag[p] & 2) continue;
+				node = trieChild(M, node, str[p]);
+				if (!node) break;
+				++depth;
+				const int32_t v = M.trie[node].value;
+				if (v >= 0)
+				{
+					const uint64_t mk = mask[i + 1];
+					const uint32_t rank = depth >= 64 ? 0 : __popcll(mk >> depth);   // forms longer than this one come first
+					forms[moff[i + 1] + rank] = (uint32_t)v;
+				}
+			}
+		}
+	}
+
+	// ------------------------------------------------------------------------------------------------
+	struct LatticeCtx
+	{
+		const ModelView* M; const SearchParams* P;
+		const uint16_t* str; const uint16_t* nsToPos; const uint16_t* posToNs;
+		DevNode* out; uint32_t* endPosMap; uint32_t nOut, cap; bool overflow;
+	};
+
+	__device__ __forceinline__ bool latAppend(LatticeCtx& L, uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, uint32_t nMap)
+	{
+		const uint32_t ms = L.endPosMap[s];
+		if ((ms & 0xFFFF) == (ms >> 16)) return false;
+		if (L.nOut >= L.cap) { L.overflow = true; return false; }
+		const uint32_t id = L.nOut++;
+		DevNode nn;
+		nn.form = form; nn.startPos = (uint16_t)s; nn.endPos = (uint16_t)e; nn.prev = (uint16_t)(id - (ms & 0xFFFF)); nn.sibling = 0;
+		nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = 0; nn.flags = 0;
+		L.out[id] = nn;
+		if (e >= nMap) return true;
+		const uint32_t me = L.endPosMap[e];
+		if ((me & 0xFFFF) == (me >> 16)) L.endPosMap[e] = id | ((id + 1) << 16);
+		else
+		{
+			const uint32_t last = (me >> 16) - 1;
+			L.out[last].sibling = (uint16_t)(id - last);
+			L.endPosMap[e] = (me & 0xFFFF) | ((id + 1) << 16);
+		}
+		return true;
+	}
+
+	__device__ __forceinline__ uint32_t latNodeLen(const LatticeCtx& L, const DevNode& g)
+	{
+		if (g.uformLen) return g.uformLen;
+		const FormRec f = L.M->forms[g.form];
+		return f.len - f.numSpaces;
+	}
+
+	__device__ bool latHasForm(const LatticeCtx& L, uint32_t s, uint32_t e)   // Splitter::hasFormAlready (KTrie.cpp:897-905)
+	{
+		const uint32_t me = L.endPosMap[e];
+		uint32_t a = me & 0xFFFF; const uint32_t b = me >> 16;
+		if (a == b) return false;
+		if (a < 1) a = 1;
+		for (uint32_t i = a; i < b; ++i)
+		{
+			const DevNode g = L.out[i];
+			if (g.endPos == e && g.endPos - latNodeLen(L, g) == s && (g.form == NOFORM || (L.M->forms[g.form].flags & FF_HAS_ANY_FULL))) return true;
+		}
+		return false;
+	}
+
+	__device__ __forceinline__ void latTrim(const LatticeCtx& L, uint32_t off, uint32_t len, uint32_t& o, uint32_t& l)
+	{
+		while (len && isSpace(L.str[off + len - 1])) --len;
+		o = off; l = len;
+	}
+
+	__device__ void latInsertUnk(LatticeCtx& L, uint32_t s, uint32_t e, bool hasJ, uint32_t nMap)   // Splitter::insertUnkForm (KTrie.cpp:921-953)
+	{
+		if (s >= e || latHasForm(L, s, e)) return;
+		uint32_t lastPos = L.out[L.nOut - 1].endPos;
+		if (lastPos < e)
+		{
+			if (lastPos && isHangulCoda(L.str[L.nsToPos[lastPos]])) lastPos--;
+			if (lastPos != s && !latHasForm(L, lastPos, e))
+			{
+				uint32_t o, l; latTrim(L, L.nsToPos[lastPos], L.nsToPos[e - 1] + 1 - L.nsToPos[lastPos], o, l);
+				latAppend(L, lastPos, e, NOFORM, o, l, nMap);
+			}
+		}
+		const uint32_t limit = hasJ ? L.P->maxUnkJ : L.P->maxUnk;
+		if (e - s <= limit)
+		{
+			uint32_t o, l; latTrim(L, L.nsToPos[s], L.nsToPos[e - 1] + 1 - L.nsToPos[s], o, l);
+			latAppend(L, s, e, NOFORM, o, l, nMap);
+		}
+	}
+
+	__device__ __forceinline__ void latUnkPair(LatticeCtx& L, uint32_t boundary, uint32_t unkStart, uint32_t e, bool hasJ, uint32_t nMap)
+	{
+		if (boundary < unkStart) latInsertUnk(L, boundary, e, hasJ, nMap);
+		latInsertUnk(L, unkStart, e, hasJ, nMap);
+	}
+
+	__global__ void __launch_bounds__(64) k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P)
+	{
+		const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
+		if (chunk >= B.nChunks) return;
+		if (W.results[chunk].status >= 16) return;
+		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
+		const uint16_t* str = B.chars + cOff;
+		const uint8_t* cls = B.cls + cOff;
+		const uint8_t* script = B.script + cOff;
+		const uint8_t* cflag = W.cflag + cOff;
+		const uint32_t nNs = W.nNs[chunk];
+		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
+		const uint64_t* mask = W.matchMask + cOff + chunk;
+		const uint32_t* moff = W.matchOff + cOff + chunk;
+		const uint32_t* mforms = W.matchForm + W.matchBase[chunk];
+
+		LatticeCtx L;
+		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk;
+		L.out = W.tmpNodes + nBase; L.endPosMap = W.endPosMap + cOff + chunk; L.nOut = 0; L.cap = cap; L.overflow = false;
+		const uint32_t nMap = nNs + 1;
+		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { W.results[chunk].status = CS_ERR_TOO_LONG; return; }
+		for (uint32_t i = 0; i < nMap; ++i) L.endPosMap[i] = 0;     // first == second : empty
+		L.endPosMap[0] = 0 | (1u << 16);
+		{
+			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.flags = 0;
+			L.out[0] = bos; L.nOut = 1;
+		}
+		const DevPattern* pat = B.patterns + B.patOff[chunk];
+		const DevPattern* patEnd = B.patterns + B.patOff[chunk + 1];
+
+		uint8_t lastType = T_UNKNOWN, lastScript = 0;
+		uint32_t specialStart = 0, unkStart = 0, boundary = 0;
+		uint32_t resetNs = 0;   // dictionary matches starting before this ns position are void (see k_dict_scan step 1)
+		const uint8_t scriptVS = 98;
+		for (uint32_t j = 0; j < n; ++j)
+		{
+			const uint16_t ch = str[j];
+			const bool pair = isHighSurrogate(ch) && j + 1 < n;
+			const uint32_t c32 = pair ? mergeSurrogate(ch, str[j + 1]) : ch;
+			const bool inPattern = pat != patEnd && j >= pat->end - pat->length;
+			uint8_t type = cls[j] & 0x3F, sct = script[j];
+			bool overridden = false;
+			if (lastType == T_SW && (c32 == 0x200d || (0x1f3fb <= c32 && c32 <= 0x1f3ff) || sct == scriptVS)) { overridden = type == T_UNKNOWN; type = lastType; sct = lastScript; }
+			const uint8_t curT = inPattern ? (uint8_t)T_UNKNOWN : type;
+			const bool symL = lastType == T_SL || lastType == T_SH || lastType == T_SW;
+			const bool symC = curT == T_SL || curT == T_SH || curT == T_SW;
+			const bool discont = (symL && symC) ? (lastScript != sct) : (lastType != curT);
+			if (discont || lastType == T_SSO || lastType == T_SSC)
+			{
+				if (lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
+				{
+					const bool sj = T_SF <= lastType && lastType <= T_SW;
+					latUnkPair(L, boundary, unkStart, specialStart, sj, nMap);
+					uint32_t o, l; latTrim(L, L.nsToPos[specialStart], j - L.nsToPos[specialStart], o, l);
+					latAppend(L, specialStart, L.posToNs[j], lastType - 1u, o, l, nMap);
+				}
+				unkStart = specialStart;
+				specialStart = L.posToNs[j];
+				if (T_SF <= lastType && lastType <= T_SW) boundary = specialStart;
+			}
+			else if (type == T_MAX) unkStart = specialStart;
+			lastType = curT; lastScript = sct;
+
+			bool zcand = false; uint32_t zform = 0;
+			if (!pair)
+			{
+				if (type == T_UNKNOWN)
+				{
+					latUnkPair(L, boundary, unkStart, L.posToNs[j + 1], true, nMap);
+					boundary = specialStart = unkStart = L.posToNs[j + 1];
+					continue;
+				}
+				// a space-class unit promoted to a symbol was fed to the trie by the reference and reset the walk
+				if (overridden && (cflag[j] & 1)) resetNs = L.posToNs[j] + 1;
+				bool zc = false, zs = false;
+				const uint32_t p = L.posToNs[j];
+				if (p < nNs)
+				{
+					const uint32_t me = L.endPosMap[p];
+					for (uint32_t i = me & 0xFFFF; i < (me >> 16); ++i)
+					{
+						const DevNode g = L.out[i];
+						if (g.endPos != p || g.form == NOFORM) continue;
+						const uint8_t ff = M.forms[g.form].flags;
+						zc = zc || (ff & FF_ZCODA_APPENDABLE);
+						zs = zs || (ff & FF_ZSIOT_APPENDABLE);
+					}
+				}
+				if ((P.match & M_Z_CODA) && zc && isHangulCoda(ch) && (j + 1 >= n || !isHangulSyllable(str[j + 1]))) { zcand = true; zform = kDefaultTagSize + (ch - 0x11A8) - 1; }
+				else if ((P.match & (M_SPLIT_SAISIOT | M_MERGE_SAISIOT)) && zs && ch == 0x11BA && j + 1 < n && isHangulSyllable(str[j + 1])) { zcand = true; zform = kDefaultTagSize + (0x11BA - 0x11A8) - 1; }
+			}
+			if (pat != patEnd)
+			{
+				const uint32_t curEnd = j + (pair ? 2 : 1);
+				while (pat != patEnd && pat->end == curEnd)
+				{
+					const uint32_t ms = pat->end - pat->length;
+					const bool wj = T_W_URL <= pat->tag && pat->tag <= T_W_EMOJI;
+					latUnkPair(L, boundary, unkStart, L.posToNs[ms], wj, nMap);
+					latAppend(L, L.posToNs[ms], L.posToNs[pat->end], pat->tag - 1u, ms, pat->length, nMap);
+					++pat;
+				}
+			}
+			if (pair) { ++j; continue; }
+
+			// flushCandidates (KTrie.cpp:955-996) over [z-coda shortcut] + the packed dictionary matches ending here
+			const uint32_t endNs = L.posToNs[j + 1];
+			const uint32_t m0 = moff[endNs], m1 = m0 + __popcll(mask[endNs]);
+			for (uint32_t k = zcand ? m0 - 1 : m0; k != m1; ++k)
+			{
+				const bool isZ = zcand && k == m0 - 1;
+				const uint32_t fi = isZ ? zform : mforms[k];
+				const FormRec f = M.forms[fi];
+				const uint32_t flen = f.len - f.numSpaces;
+				if (flen > endNs) continue;
+				const uint32_t nb = endNs - flen, ne = endNs;
+				if (!isZ && nb < resetNs) continue;
+				if (!(f.flags & FF_FIRST_IS_CODA))
+				{
+					const bool hj = (f.flags & FF_HAS_JCLASS) || (f.flags & FF_IS_STAG);
+					if (boundary < nb) latInsertUnk(L, boundary, nb, hj, nMap);
+					latInsertUnk(L, unkStart, nb, hj, nMap);
+				}
+				// countSpaceErrors (KTrie.cpp:316-328)
+				uint32_t se = 0, off = 0;
+				const uint16_t* fs = M.formChars + f.charOff;
+				for (uint32_t i = 1; i < ne - nb; ++i)
+				{
+					const bool hasSpace = L.nsToPos[nb + i] - L.nsToPos[nb + i - 1] > 1;
+					const uint16_t fc = (i + off < f.len) ? fs[i + off] : 0;
+					if (hasSpace && fc != u' ') ++se;
+					if (fc == u' ') ++off;
+				}
+				if (se <= P.spaceTol)
+				{
+					if (latAppend(L, nb, ne, fi, 0, 0, nMap)) L.out[L.nOut - 1].spaceErrors = (uint16_t)se;
+				}
+			}
+		}
+		if (lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
+		{
+			const bool sj = T_SF <= lastType && lastType <= T_SW;
+			latUnkPair(L, boundary, unkStart, specialStart, sj, nMap);
+			uint32_t o, l; latTrim(L, L.nsToPos[specialStart], n - L.nsToPos[specialStart], o, l);
+			latAppend(L, specialStart, L.posToNs[n], lastType - 1u, o, l, nMap);
+			unkStart = specialStart;
+			if (sj) boundary = L.posToNs[n];
+		}
+		if (nNs && n == (uint32_t)L.nsToPos[nNs - 1] + 1) latUnkPair(L, boundary, unkStart, L.posToNs[n], true, nMap);
+		latAppend(L, nNs, nNs + 1, NOFORM, 0, 0, nMap);
+		L.out[L.nOut - 1].endPos = (uint16_t)nNs;
+		if (L.overflow || L.nOut + 1 >= cap) { W.results[chunk].status = CS_ERR_NODE_OVERFLOW; return; }
+
+		// ---- removeUnconnected (KTrie.cpp:240-299): backward BFS from the end node, then a stable order by end position
+		const uint32_t G = L.nOut;
+		uint16_t* queue = W.tmpIdx + 2ull * nBase;     // BFS queue, later the inverse permutation
+		uint16_t* connOrd = queue + cap;               // connected flag (bit 15) per old node
+		for (uint32_t i = 0; i < G; ++i) connOrd[i] = 0;
+		uint32_t qh = 0, qt = 0;
+		queue[qt++] = (uint16_t)(G - 1); connOrd[G - 1] = 1;
+		while (qh < qt)
+		{
+			const uint32_t id = queue[qh++];
+			const uint32_t sp = L.out[id].startPos;
+			const uint32_t me = L.endPosMap[sp];
+			for (uint32_t i = me & 0xFFFF; i < (me >> 16); ++i)
+			{
+				if (L.out[i].endPos != sp || connOrd[i]) continue;
+				connOrd[i] = 1; queue[qt++] = (uint16_t)i;
+			}
+		}
+		// new index of each connected node: nodes grouped by end position ascending, original order inside a group.
+		// The sibling chain of endPosMap[e] enumerates exactly the nodes ending at e in index order; the end-of-input
+		// node is not on any chain and sorts last among nodes ending at nNs.
+		uint16_t* inv = queue;
+		uint32_t nConn = 0;
+		for (uint32_t e = 0; e <= nNs; ++e)
+		{
+			const uint32_t me = L.endPosMap[e];
+			if ((me & 0xFFFF) == (me >> 16)) continue;
+			for (uint32_t i = me & 0xFFFF;;)
+			{
+				if (i != G - 1) inv[i] = connOrd[i] ? (uint16_t)nConn++ : (uint16_t)0xFFFF;
+				const uint32_t sib = L.out[i].sibling;
+				if (!sib) break;
+				i += sib;
+			}
+		}
+		inv[G - 1] = (uint16_t)nConn++;
+		DevNode* fin = W.nodes + nBase;
+		for (uint32_t idx = 0; idx < G; ++idx)
+		{
+			const uint32_t ni = inv[idx];
+			if (ni == 0xFFFF) continue;
+			DevNode nn = L.out[idx];
+			if (nn.prev) nn.prev = (uint16_t)(ni - inv[idx - nn.prev]);
+			if (nn.sibling)
+			{
+				const uint32_t ns = inv[idx + nn.sibling];
+				nn.sibling = ns == 0xFFFF ? 0 : (uint16_t)(ns - ni);
+			}
+			if (ni >= 1 && ni + 1 < nConn)
+			{
+				nn.startPos = L.nsToPos[nn.startPos];
+				nn.endPos = (uint16_t)(L.nsToPos[nn.endPos - 1] + 1);
+			}
+			else if (ni + 1 == nConn) nn.startPos = nn.endPos = (uint16_t)n;
+			fin[ni] = nn;
+		}
+		W.nNodes[chunk] = nConn;
+		if (nConn <= 2) W.results[chunk].status = CS_NO_LATTICE;
+	}
+}

@@ -362,6 +362,7 @@ namespace kamd
 			if (!s.empty() && isHangulCoda(s[0])) f.flags |= FF_FIRST_IS_CODA;
 			if (s.size() == 1) { const uint8_t t = identifySpecialChr(s[0]); if (T_SF <= t && t <= T_SW) f.flags |= FF_IS_STAG; }
 			if (!s.empty() && s[0] == 0xC544) f.flags |= FF_STARTS_WITH_A;
+			if (!s.empty() && identifySpecialChr(s.back()) == T_SSC) f.flags |= FF_ENDS_WITH_SSC;
 		}
 		m.forms[nF].charOff = (uint32_t)m.formChars.size();
 		m.forms[nF].candOff = (uint32_t)m.formCand.size();

@@ -53,7 +53,7 @@ namespace korc
 		struct OwnForm { uint32_t off, len; };   // offsets into the normalised text, or into a form string (kind 1)
 		std::vector<std::pair<int, OwnForm>> ownForms;  // kind 0: text substring, kind 1: dictionary form (id in off)
 		std::vector<uint8_t> uniqStates;
-		std::vector<float> leftBoundary[2];
+		float leftBoundary[2 * T_MAX + 1];   // [2][max] followed by `weight`: tag PA (== max) indexes one past a row, as in the reference
 
 		static uint32_t log2c(uint32_t v) { uint32_t l = 0; while ((1u << l) < v + 1) ++l; return l; }
 
@@ -196,7 +196,7 @@ namespace korc
 			uint32_t firstWid = single ? cm.lmId : M.chunkLm[cm.chunkOff];
 			contClear();
 			cnt.candMorphs++;
-			const float additional = cm.userScore + nodeLevelDiscount + leftBoundary[hasLeftBoundary(node) ? 1 : 0][clearIrregular(cm.tag)] * 5.f;
+			const float additional = cm.userScore + nodeLevelDiscount + leftBoundary[(hasLeftBoundary(node) ? T_MAX : 0) + clearIrregular(cm.tag)] * 5.f;
 			Rule rule;
 			rule.special = cm.special;
 			rule.sbType = cm.tag == T_SB ? M.sbInfo[morphId] : 0;
@@ -459,9 +459,10 @@ namespace korc
 		BestPathSearch(const ModelView& m, const BestPathConfig& c, Counters& k) : M(m), cfg(c), cnt(k)
 		{
 			// TagSequenceScorer (src/TagUtils.cpp:49-62), weight 5
-			leftBoundary[0].assign(T_MAX, 0.f); leftBoundary[1].assign(T_MAX, 0.f);
-			leftBoundary[0][T_NNP] = leftBoundary[0][T_NP] = leftBoundary[0][T_IC] = -1; leftBoundary[0][T_SB] = -3;
-			for (uint8_t r = 0; r < T_MAX; ++r) leftBoundary[1][r] = (isEClass(r) || isJClass(r) || isSuffixTag(r) || r == T_VCP) ? -1.f : 0.f;
+			for (auto& v : leftBoundary) v = 0;
+			leftBoundary[T_NNP] = leftBoundary[T_NP] = leftBoundary[T_IC] = -1; leftBoundary[T_SB] = -3;
+			for (uint8_t r = 0; r < T_MAX; ++r) leftBoundary[T_MAX + r] = (isEClass(r) || isJClass(r) || isSuffixTag(r) || r == T_VCP) ? -1.f : 0.f;
+			leftBoundary[2 * T_MAX] = 5.f;   // include/kiwi/TagUtils.h:10-12: the member after the table is `weight`
 		}
 
 		const std::vector<std::vector<WPath>>& states() const { return cache; }
