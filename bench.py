@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched analyze hot path (dictionary scan -> lattice -> Viterbi/Knlm) on MI355X.
+
+One "step" = one pass of the three HIP kernels over one batch whose inputs are already resident in HBM
+(BASELINE.json metric: sentences/sec on batched analyze(); workload = BASELINE configs[1]: 8k synthetic
+40-jamo sentences, Knlm, top-1).  Prints ONE JSON line (rank 0).  Multi-GPU: one process per GPU, each rank
+analyses its own shard of the same size (weak scaling; the path has no data-path collective).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def cpu_baseline(model_path, texts, budget_s=20.0):
+    """Times the CPU path on this box's host cores on a bounded sample of the same workload.
+    Uses the real reference TUs (oracle/_ref) when the prebuilt library travelled with the repo, else this
+    repo's CPU oracle ("port").  Also returns the oracle's ALG_BYTES event counts on its sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oraclelib
+    import refbridge
+    cores = os.cpu_count() or 1
+    orc = oraclelib.OracleKiwi(model_path)
+    sample = texts[:2048]
+    orc.counters(reset=True)
+    sec1, _ = orc.analyze_batch(sample, threads=1)
+    counts = orc.counters()
+    alg = oraclelib.alg_bytes(counts)
+    per_sentence = {k: v / len(sample) for k, v in alg.items()}
+    out = {"alg_bytes_per_sentence": per_sentence, "alg_sample": len(sample)}
+    if refbridge.available():
+        ref = refbridge.RefKiwi(model_path)
+        kind, runner = "reference", ref
+    else:
+        kind, runner = "port", orc
+    s1, _ = runner.analyze_batch(sample, threads=1)
+    rate1 = len(sample) / s1
+    n_mt = int(min(len(texts), max(2048, rate1 * cores * budget_s / 4)))
+    smt, _ = runner.analyze_batch(texts[:n_mt], threads=cores)
+    out["cpu_baseline"] = {"value": n_mt / smt, "unit": "sentences/s", "cores": cores, "kind": kind,
+                           "sample": f"{n_mt} sentences of the same workload on {cores} threads; single thread: {rate1:.0f} sentences/s on {len(sample)}"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+
+    if world > 1 and rank != 0:
+        torch.distributed.barrier()     # rank 0 generates / caches the model and corpus first
+    model_path, texts, desc = get_workload(args.workload)
+    if world > 1 and rank == 0:
+        torch.distributed.barrier()
+    # weak scaling: every rank analyses a same-sized shard; rotate so shards differ
+    n = len(texts)
+    shift = (rank * 977) % n
+    shard = texts[shift:] + texts[:shift]
+
+    eng = KiwiAmd(model_path, local_rank)
+    batch = eng.stage(shard)
+    info = batch.info()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        eng.run(batch)
+    sync()
+    t0 = time.perf_counter()
+    kt = {"scan_ms": 0.0, "lattice_ms": 0.0, "search_ms": 0.0}
+    for _ in range(args.steps):
+        r = eng.run(batch)          # launches + stream sync; per-kernel durations come from HIP events on the engine's stream
+        for k in kt:
+            kt[k] += r[k]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for k in kt:
+        kt[k] /= args.steps
+
+    # sanity: the staged batch really was analysed (token count > 0, no failed chunk)
+    res = eng.fetch(batch)
+    n_tok = sum(res.lib.kamd_res_token_num(res.h, i, 0) for i in range(min(256, n)))
+    assert n_tok > 0
+
+    if rank == 0:
+        total_sent = n * world * args.steps
+        value = total_sent / elapsed
+        out = {
+            "metric": "sentences/sec on batched analyze() (dictionary scan + lattice + Viterbi/Knlm, top-1)",
+            "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32+f32", "data": "synthetic",
+            "config": {"workload": desc, "sentences_per_gpu": n, "chunks_per_gpu": info["chunks"], "jamo_per_gpu": info["units"],
+                       "parallelism": f"shard{world}", "m_jamo_per_s": info["units"] * world * args.steps / elapsed / 1e6,
+                       "kernel_ms": kt, "device_bytes": info["device_bytes"]},
+        }
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(model_path, texts)
+            per = cb["alg_bytes_per_sentence"]
+            search_bytes = per["search"] * n
+            achieved = search_bytes / (kt["search_ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_best_path", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "alg_bytes_per_sentence": per, "all_kernels_achieved": per["total"] * n / ((kt["scan_ms"] + kt["lattice_ms"] + kt["search_ms"]) * 1e-3) / 1e9}
+            out["cpu_baseline"] = cb["cpu_baseline"]
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+/* kiwi_capi.h -- the subset of Kiwi's C API that carries the batched analyze path, re-implemented on the
+ * MI355X engine (libkiwi_hip.so).  Signatures, struct layouts, ownership and error conventions are those of
+ * /root/reference/include/kiwi/capi.h (v0.23.1); each declaration cites the line it replaces.  A program
+ * compiled against the reference's capi.h and linked with this library instead of libkiwi runs unchanged as
+ * long as it stays inside this subset (anything else is simply not exported: link error, not silent change).
+ *
+ * Differences a caller can observe:
+ *   - kiwi_init's model_path names a raw-model container (or a directory holding `kiwi_amd.raw`);
+ *     on-disk sj.morph / sj.knlm loaders are a "next" row.
+ *   - top_n > 1, blocklist, pretokenized spans, typo transformers and non-standard dialects are refused with
+ *     NULL/KIWIERR_FAIL + kiwi_error() instead of being silently ignored.
+ */
+#ifndef KIWI_CAPI_SUBSET_H
+#define KIWI_CAPI_SUBSET_H
+#include <stddef.h>
+#include <stdint.h>
+
+#define KIWIERR_FAIL -1            /* capi.h:17 */
+#define KIWIERR_INVALID_HANDLE -2  /* capi.h:18 */
+#define KIWIERR_INVALID_INDEX -3   /* capi.h:19 */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kiwi_s* kiwi_h;                       /* capi.h:29 */
+typedef struct kiwi_res* kiwi_res_h;                 /* capi.h:31 */
+typedef struct kiwi_morphset* kiwi_morphset_h;       /* capi.h:36 */
+typedef struct kiwi_pretokenized* kiwi_pretokenized_h; /* capi.h:37 */
+typedef struct kiwi_prepared_typo* kiwi_prepared_typo_h; /* capi.h:38 */
+typedef unsigned short kchar16_t;                    /* capi.h:39 */
+
+typedef struct {                                     /* capi.h:43-61 */
+	uint32_t chr_position, word_position, sent_position, line_number;
+	uint16_t length;
+	uint8_t tag;
+	union { uint8_t sense_id; uint8_t script; };
+	float score, typo_cost;
+	uint32_t typo_form_id, paired_token, sub_sent_position;
+	uint16_t dialect;
+} kiwi_token_info_t;
+
+typedef struct {                                     /* capi.h:72-86 */
+	uint8_t integrate_allomorph;
+	float cut_off_threshold, oov_rule_scale, oov_rule_bias, oov_chr_bias, oov_global_weight, oov_local_weight, oov_global_min_freq;
+	float space_penalty, typo_cost_weight;
+	uint32_t max_unk_form_size, max_unk_form_size_followed_by_j_class, space_tolerance;
+} kiwi_config_t;
+
+typedef struct {                                     /* capi.h:662-670 */
+	int match_options;
+	kiwi_morphset_h blocklist;
+	int open_ending;
+	int allowed_dialects;
+	float dialect_cost;
+	kiwi_prepared_typo_h typo_transformer;
+	float typo_threshold;
+} kiwi_analyze_option_t;
+
+typedef int (*kiwi_reader_t)(int, char*, void*);       /* capi.h:104 */
+typedef int (*kiwi_reader_w_t)(int, kchar16_t*, void*); /* capi.h:105 */
+typedef int (*kiwi_receiver_t)(int, kiwi_res_h, void*); /* capi.h:144 */
+
+enum { KIWI_NUM_THREADS = 0x8001, KIWI_GPU_BATCH_SIZE = 0x9001 };   /* capi.h:222 (+ one extension option) */
+
+const char* kiwi_version(void);                      /* capi.h:238 */
+const char* kiwi_error(void);                        /* capi.h:245 */
+void kiwi_clear_error(void);                         /* capi.h:252 */
+kiwi_h kiwi_init(const char* model_path, int num_threads, int options, int enabled_dialects);   /* capi.h:599 */
+void kiwi_set_global_config(kiwi_h handle, kiwi_config_t config);                                /* capi.h:607 */
+kiwi_config_t kiwi_get_global_config(kiwi_h handle);                                             /* capi.h:615 */
+void kiwi_set_option(kiwi_h handle, int option, int value);                                      /* capi.h:623 */
+int kiwi_get_option(kiwi_h handle, int option);                                                  /* capi.h:636 */
+kiwi_res_h kiwi_analyze_w(kiwi_h handle, const kchar16_t* text, int top_n, kiwi_analyze_option_t option, kiwi_pretokenized_h pretokenized); /* capi.h:684 */
+kiwi_res_h kiwi_analyze(kiwi_h handle, const char* text, int top_n, kiwi_analyze_option_t option, kiwi_pretokenized_h pretokenized);        /* capi.h:698 */
+int kiwi_analyze_mw(kiwi_h handle, kiwi_reader_w_t reader, kiwi_receiver_t receiver, void* user_data, int top_n, kiwi_analyze_option_t option); /* capi.h:711 */
+int kiwi_analyze_m(kiwi_h handle, kiwi_reader_t reader, kiwi_receiver_t receiver, void* user_data, int top_n, kiwi_analyze_option_t option);    /* capi.h:724 */
+int kiwi_close(kiwi_h handle);                                                                   /* capi.h:771 */
+const char* kiwi_tag_to_string(kiwi_h handle, uint8_t pos_tag);                                  /* capi.h:780 */
+int kiwi_res_size(kiwi_res_h result);                                                            /* capi.h:788 */
+float kiwi_res_prob(kiwi_res_h result, int index);                                               /* capi.h:797 */
+int kiwi_res_word_num(kiwi_res_h result, int index);                                             /* capi.h:806 */
+const kiwi_token_info_t* kiwi_res_token_info(kiwi_res_h result, int index, int num);             /* capi.h:816 */
+int kiwi_res_morpheme_id(kiwi_res_h result, int index, int num, kiwi_h kiwi_handle);             /* capi.h:827 */
+const kchar16_t* kiwi_res_form_w(kiwi_res_h result, int index, int num);                         /* capi.h:837 */
+const kchar16_t* kiwi_res_tag_w(kiwi_res_h result, int index, int num);                          /* capi.h:847 */
+const char* kiwi_res_form(kiwi_res_h result, int index, int num);                                /* capi.h:857 */
+const char* kiwi_res_tag(kiwi_res_h result, int index, int num);                                 /* capi.h:867 */
+int kiwi_res_position(kiwi_res_h result, int index, int num);                                    /* capi.h:877 */
+int kiwi_res_length(kiwi_res_h result, int index, int num);                                      /* capi.h:887 */
+int kiwi_res_word_position(kiwi_res_h result, int index, int num);                               /* capi.h:897 */
+int kiwi_res_sent_position(kiwi_res_h result, int index, int num);                               /* capi.h:907 */
+float kiwi_res_score(kiwi_res_h result, int index, int num);                                     /* capi.h:917 */
+float kiwi_res_typo_cost(kiwi_res_h result, int index, int num);                                 /* capi.h:927 */
+int kiwi_res_close(kiwi_res_h result);                                                           /* capi.h:937 */
+const char* kiwi_get_script_name(uint8_t script);                                                /* capi.h:1417 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,325 @@
+// Kiwi-compatible C API (include/kiwi_capi.h) on top of kamd::Engine: the drop-in boundary for
+// Kiwi::analyze.  Conventions follow /root/reference/src/capi/kiwi_c.cpp: handles are heap objects owned by the
+// caller, nothing throws across the boundary, failures are recorded in a thread-local slot read by kiwi_error().
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <sys/stat.h>
+#include "../../include/kiwi_capi.h"
+#include "engine.hpp"
+
+using namespace kamd;
+
+struct kiwi_s
+{
+	std::unique_ptr<Engine> engine;
+	int numThreads = 0;
+	int batchSize = 65536;
+};
+
+struct kiwi_res
+{
+	std::vector<TokenResult> res;
+	// the C struct is layout-compatible with the tail of the reference's TokenInfo (kiwi_c.cpp:1097); here it is materialised
+	std::vector<std::vector<kiwi_token_info_t>> info;
+	std::map<std::pair<int, int>, std::string> formBuf, tagBuf;
+	std::map<std::pair<int, int>, std::u16string> tagBufW;
+};
+
+namespace
+{
+	thread_local std::string currentError;
+	thread_local bool hasError = false;
+	void setError(const std::exception& e) { currentError = e.what(); hasError = true; }
+
+	const char* tagNames[] = { "UN", "NNG", "NNP", "NNB", "VV", "VA", "MAG", "NR", "NP", "VX", "MM", "MAJ", "IC", "XPN", "XSN", "XSV", "XSA", "XSM", "XR", "VCP", "VCN",
+		"SF", "SP", "SS", "SSO", "SSC", "SE", "SO", "SW", "SB", "SL", "SH", "SN", "W_URL", "W_EMAIL", "W_MENTION", "W_HASHTAG", "W_SERIAL", "W_EMOJI",
+		"JKS", "JKC", "JKG", "JKO", "JKB", "JKV", "JKQ", "JX", "JC", "EP", "EF", "EC", "ETN", "ETM", "Z_CODA", "Z_SIOT", "USER0", "USER1", "USER2", "USER3", "USER4", "@", "@" };
+	const char* tagToString(uint8_t t)   // src/Utils.cpp tagToString: irregular variants get an -I suffix
+	{
+		if (t & 0x80)
+		{
+			switch (t & 0x7F) { case T_VV: return "VV-I"; case T_VA: return "VA-I"; case T_VX: return "VX-I"; case T_XSA: return "XSA-I"; default: return "@"; }
+		}
+		return t < sizeof(tagNames) / sizeof(tagNames[0]) ? tagNames[t] : "@";
+	}
+
+	std::u16string utf8To16(const char* s, size_t n)   // src/StrUtils.h:228-303 (strict decoder, throws on malformed input)
+	{
+		std::u16string ret;
+		for (size_t i = 0; i < n; ++i)
+		{
+			uint32_t code, b = (uint8_t)s[i];
+			auto cont = [&]() -> uint32_t
+			{
+				if (++i == n) throw std::runtime_error{ "unexpected ending" };
+				const uint32_t c = (uint8_t)s[i];
+				if ((c & 0xC0) != 0x80) throw std::runtime_error{ "unexpected trailing byte" };
+				return c & 0x3F;
+			};
+			if ((b & 0xF8) == 0xF0) { code = (b & 7) << 18; code |= cont() << 12; code |= cont() << 6; code |= cont(); }
+			else if ((b & 0xF0) == 0xE0) { code = (b & 0xF) << 12; code |= cont() << 6; code |= cont(); }
+			else if ((b & 0xE0) == 0xC0) { code = (b & 0x1F) << 6; code |= cont(); }
+			else if ((b & 0x80) == 0) code = b;
+			else throw std::runtime_error{ "unicode error" };
+			if (code < 0x10000) ret.push_back((char16_t)code);
+			else if (code < 0x10FFFF) { code -= 0x10000; ret.push_back((char16_t)(0xD800 | (code >> 10))); ret.push_back((char16_t)(0xDC00 | (code & 0x3FF))); }
+			else throw std::runtime_error{ "unicode error" };
+		}
+		return ret;
+	}
+
+	std::string utf16To8(const std::u16string& s)
+	{
+		std::string ret;
+		for (size_t i = 0; i < s.size(); ++i)
+		{
+			uint32_t c = s[i];
+			if (isHighSurrogate(c) && i + 1 < s.size() && isLowSurrogate(s[i + 1])) c = mergeSurrogate(c, s[++i]);
+			if (c <= 0x7F) ret.push_back((char)c);
+			else if (c <= 0x7FF) { ret.push_back((char)(0xC0 | (c >> 6))); ret.push_back((char)(0x80 | (c & 0x3F))); }
+			else if (c <= 0xFFFF) { ret.push_back((char)(0xE0 | (c >> 12))); ret.push_back((char)(0x80 | ((c >> 6) & 0x3F))); ret.push_back((char)(0x80 | (c & 0x3F))); }
+			else { ret.push_back((char)(0xF0 | (c >> 18))); ret.push_back((char)(0x80 | ((c >> 12) & 0x3F))); ret.push_back((char)(0x80 | ((c >> 6) & 0x3F))); ret.push_back((char)(0x80 | (c & 0x3F))); }
+		}
+		return ret;
+	}
+
+	void checkOption(const kiwi_analyze_option_t& o, kiwi_pretokenized_h pt)
+	{
+		if (o.blocklist) throw std::invalid_argument{ "kiwi_amd: blocklist is not supported on the device path yet" };
+		if (o.typo_transformer) throw std::invalid_argument{ "kiwi_amd: typo transformers are not supported on the device path yet" };
+		if (o.allowed_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported on the device path yet" };
+		if (pt) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
+		if ((uint32_t)o.match_options & (3u << 8)) throw std::invalid_argument{ "`oovChrModel` option is set but the character-level noun model is not loaded." };
+		if ((uint32_t)o.match_options & (1u << 30)) throw std::invalid_argument{ "kiwi_amd: useOldSplitter is not supported" };
+	}
+
+	kiwi_res* makeRes(std::vector<TokenResult>&& r)
+	{
+		auto res = std::make_unique<kiwi_res>();
+		res->res = std::move(r);
+		res->info.resize(res->res.size());
+		for (size_t i = 0; i < res->res.size(); ++i)
+		{
+			for (auto& t : res->res[i].first)
+			{
+				kiwi_token_info_t o{};
+				o.chr_position = t.position; o.word_position = t.wordPosition; o.sent_position = t.sentPosition; o.line_number = t.lineNumber;
+				o.length = t.length; o.tag = t.tag; o.sense_id = t.senseId; o.score = t.score; o.typo_cost = t.typoCost; o.typo_form_id = t.typoFormId;
+				o.paired_token = t.pairedToken; o.sub_sent_position = t.subSentPosition; o.dialect = t.dialect;
+				res->info[i].push_back(o);
+			}
+		}
+		return res.release();
+	}
+
+	template<class ReadFn>
+	int analyzeMany(kiwi_h h, ReadFn&& readNext, kiwi_receiver_t receiver, void* ud, int topN, const kiwi_analyze_option_t& opt)
+	{
+		checkOption(opt, nullptr);
+		int readerIdx = 0, receiverIdx = 0;
+		bool done = false;
+		while (!done)
+		{
+			std::vector<std::u16string> texts;
+			while ((int)texts.size() < h->batchSize)
+			{
+				std::u16string s;
+				if (!readNext(readerIdx, s)) { done = true; break; }
+				++readerIdx;
+				texts.push_back(std::move(s));
+			}
+			if (texts.empty()) break;
+			std::vector<std::pair<const char16_t*, size_t>> views;
+			for (auto& t : texts) views.emplace_back(t.data(), t.size());
+			auto res = h->engine->analyzeBatch(views, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads);
+			for (auto& r : res) (*receiver)(receiverIdx++, makeRes(std::move(r)), ud);   // in input order; the receiver owns the result
+		}
+		return readerIdx;
+	}
+
+	bool validIdx(kiwi_res_h r, int index, int num)
+	{
+		return index >= 0 && (size_t)index < r->res.size() && num >= 0 && (size_t)num < r->res[index].first.size();
+	}
+}
+
+extern "C"
+{
+	const char* kiwi_version(void) { return "0.23.1+kiwi_amd"; }
+	const char* kiwi_error(void) { return hasError ? currentError.c_str() : nullptr; }
+	void kiwi_clear_error(void) { hasError = false; currentError.clear(); }
+
+	kiwi_h kiwi_init(const char* model_path, int num_threads, int options, int enabled_dialects)
+	{
+		try
+		{
+			(void)options;
+			if (enabled_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported" };
+			std::string path = model_path ? model_path : "";
+			struct stat st;
+			if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) path += "/kiwi_amd.raw";
+			auto h = std::make_unique<kiwi_s>();
+			h->engine.reset(new Engine(path, -1));
+			h->numThreads = num_threads < 0 ? 0 : (num_threads == 0 ? 1 : num_threads);
+			return h.release();
+		}
+		catch (const std::exception& e) { setError(e); return nullptr; }
+	}
+
+	int kiwi_close(kiwi_h handle)
+	{
+		if (!handle) return KIWIERR_INVALID_HANDLE;
+		delete handle;
+		return 0;
+	}
+
+	void kiwi_set_global_config(kiwi_h h, kiwi_config_t c)
+	{
+		if (!h) return;
+		auto& g = h->engine->config;
+		g.integrateAllomorph = !!c.integrate_allomorph; g.cutOffThreshold = c.cut_off_threshold; g.oovRuleScale = c.oov_rule_scale; g.oovRuleBias = c.oov_rule_bias;
+		g.spacePenalty = c.space_penalty; g.typoCostWeight = c.typo_cost_weight; g.maxUnkFormSize = c.max_unk_form_size;
+		g.maxUnkFormSizeFollowedByJClass = c.max_unk_form_size_followed_by_j_class; g.spaceTolerance = c.space_tolerance;
+	}
+
+	kiwi_config_t kiwi_get_global_config(kiwi_h h)
+	{
+		kiwi_config_t c{};
+		if (!h) return c;
+		const auto& g = h->engine->config;
+		c.integrate_allomorph = g.integrateAllomorph; c.cut_off_threshold = g.cutOffThreshold; c.oov_rule_scale = g.oovRuleScale; c.oov_rule_bias = g.oovRuleBias;
+		c.oov_chr_bias = 0; c.oov_global_weight = 35; c.oov_local_weight = 3; c.oov_global_min_freq = 4;
+		c.space_penalty = g.spacePenalty; c.typo_cost_weight = g.typoCostWeight; c.max_unk_form_size = g.maxUnkFormSize;
+		c.max_unk_form_size_followed_by_j_class = g.maxUnkFormSizeFollowedByJClass; c.space_tolerance = g.spaceTolerance;
+		return c;
+	}
+
+	void kiwi_set_option(kiwi_h h, int option, int value)
+	{
+		if (!h) return;
+		if (option == KIWI_NUM_THREADS) h->numThreads = value;
+		else if (option == KIWI_GPU_BATCH_SIZE && value > 0) h->batchSize = value;
+		else { currentError = "Invalid option value: " + std::to_string(option); hasError = true; }
+	}
+
+	int kiwi_get_option(kiwi_h h, int option)
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		if (option == KIWI_NUM_THREADS) return h->numThreads;
+		if (option == KIWI_GPU_BATCH_SIZE) return h->batchSize;
+		currentError = "Invalid option value: " + std::to_string(option); hasError = true;
+		return KIWIERR_FAIL;
+	}
+
+	kiwi_res_h kiwi_analyze_w(kiwi_h h, const kchar16_t* text, int top_n, kiwi_analyze_option_t opt, kiwi_pretokenized_h pt)
+	{
+		if (!h) return nullptr;
+		try
+		{
+			checkOption(opt, pt);
+			size_t n = 0; while (text[n]) ++n;
+			std::vector<std::pair<const char16_t*, size_t>> v{ { (const char16_t*)text, n } };
+			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1);
+			return makeRes(std::move(res[0]));
+		}
+		catch (const std::exception& e) { setError(e); return nullptr; }
+	}
+
+	kiwi_res_h kiwi_analyze(kiwi_h h, const char* text, int top_n, kiwi_analyze_option_t opt, kiwi_pretokenized_h pt)
+	{
+		if (!h) return nullptr;
+		try
+		{
+			checkOption(opt, pt);
+			const std::u16string u = utf8To16(text, std::strlen(text));
+			std::vector<std::pair<const char16_t*, size_t>> v{ { u.data(), u.size() } };
+			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1);
+			return makeRes(std::move(res[0]));
+		}
+		catch (const std::exception& e) { setError(e); return nullptr; }
+	}
+
+	int kiwi_analyze_mw(kiwi_h h, kiwi_reader_w_t reader, kiwi_receiver_t receiver, void* ud, int top_n, kiwi_analyze_option_t opt)
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		try
+		{
+			return analyzeMany(h, [&](int idx, std::u16string& out)
+			{
+				out.resize((size_t)(*reader)(idx, nullptr, ud));
+				if (out.empty()) return false;
+				(*reader)(idx, (kchar16_t*)&out[0], ud);
+				return true;
+			}, receiver, ud, top_n, opt);
+		}
+		catch (const std::exception& e) { setError(e); return KIWIERR_FAIL; }
+	}
+
+	int kiwi_analyze_m(kiwi_h h, kiwi_reader_t reader, kiwi_receiver_t receiver, void* ud, int top_n, kiwi_analyze_option_t opt)
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		try
+		{
+			return analyzeMany(h, [&](int idx, std::u16string& out)
+			{
+				std::string buf;
+				buf.resize((size_t)(*reader)(idx, nullptr, ud));
+				if (buf.empty()) return false;
+				(*reader)(idx, &buf[0], ud);
+				out = utf8To16(buf.data(), buf.size());
+				return true;
+			}, receiver, ud, top_n, opt);
+		}
+		catch (const std::exception& e) { setError(e); return KIWIERR_FAIL; }
+	}
+
+	const char* kiwi_tag_to_string(kiwi_h, uint8_t tag) { return tagToString(tag); }
+	const char* kiwi_get_script_name(uint8_t script) { return scriptName(script); }
+
+	int kiwi_res_size(kiwi_res_h r) { return r ? (int)r->res.size() : KIWIERR_INVALID_HANDLE; }
+	float kiwi_res_prob(kiwi_res_h r, int index) { return (r && index >= 0 && (size_t)index < r->res.size()) ? r->res[index].second : 0.f; }
+	int kiwi_res_word_num(kiwi_res_h r, int index)
+	{
+		if (!r) return KIWIERR_INVALID_HANDLE;
+		if (index < 0 || (size_t)index >= r->res.size()) return KIWIERR_INVALID_INDEX;
+		return (int)r->res[index].first.size();
+	}
+	const kiwi_token_info_t* kiwi_res_token_info(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? &r->info[index][num] : nullptr; }
+	int kiwi_res_morpheme_id(kiwi_res_h r, int index, int num, kiwi_h h)
+	{
+		if (!r || !h) return KIWIERR_INVALID_HANDLE;
+		if (!validIdx(r, index, num)) return KIWIERR_INVALID_INDEX;
+		return r->res[index].first[num].morph;
+	}
+	const kchar16_t* kiwi_res_form_w(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? (const kchar16_t*)r->res[index].first[num].str.c_str() : nullptr; }
+	const kchar16_t* kiwi_res_tag_w(kiwi_res_h r, int index, int num)
+	{
+		if (!r || !validIdx(r, index, num)) return nullptr;
+		auto& s = r->tagBufW[{ index, num }];
+		if (s.empty()) for (const char* p = tagToString(r->res[index].first[num].tag); *p; ++p) s.push_back((char16_t)*p);
+		return (const kchar16_t*)s.c_str();
+	}
+	const char* kiwi_res_form(kiwi_res_h r, int index, int num)
+	{
+		if (!r || !validIdx(r, index, num)) return nullptr;
+		auto it = r->formBuf.find({ index, num });
+		if (it == r->formBuf.end()) it = r->formBuf.emplace(std::make_pair(index, num), utf16To8(r->res[index].first[num].str)).first;
+		return it->second.c_str();
+	}
+	const char* kiwi_res_tag(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? tagToString(r->res[index].first[num].tag) : nullptr; }
+	int kiwi_res_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->res[index].first[num].position; }
+	int kiwi_res_length(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->res[index].first[num].length; }
+	int kiwi_res_word_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->res[index].first[num].wordPosition; }
+	int kiwi_res_sent_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->res[index].first[num].sentPosition; }
+	float kiwi_res_score(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? r->res[index].first[num].score : 0.f; }
+	float kiwi_res_typo_cost(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? r->res[index].first[num].typoCost : 0.f; }
+	int kiwi_res_close(kiwi_res_h r)
+	{
+		if (!r) return KIWIERR_INVALID_HANDLE;
+		delete r;
+		return 0;
+	}
+}

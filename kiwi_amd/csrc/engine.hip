@@ -452,7 +452,7 @@ namespace kamd
 			if (d.empty)
 			{
 				put32(2); put32(d.nextOffset);
-				for (int k = 0; k < 2 * 9; ++k) put32(0);
+				for (int k = 0; k < 2; ++k) { put32(0); put32(0); put32(0); put32(0); put32(0xFFFFFFFFu); put32(0); put32(0); put32(0); put32(0); }
 				continue;
 			}
 			if (res[ri].status >= 16) throw std::runtime_error{ "dumpLattices: device status " + std::to_string(res[ri].status) };

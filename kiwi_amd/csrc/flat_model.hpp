@@ -93,6 +93,7 @@ namespace kamd
 		uint32_t specialMorph[6];
 		uint32_t maxFormLen;
 		uint32_t lmOrder;
+		uint32_t lmKeyBytes;   // key width of the reference's in-memory Knlm (2 or 4): only used by ALG_BYTES accounting
 	};
 
 	// Pointers into one arena (host or device).

@@ -171,6 +171,7 @@ namespace kamd
 			m.h.nLmNodes = (uint32_t)nonLeaf;
 			m.h.nLmEdges = (uint32_t)m.lmKeys.size();
 			m.h.lmOrder = hd.order;
+			m.h.lmKeyBytes = hd.key_size;
 			m.h.unkLl = 0;
 			m.h.unkLl = lmGetLL(m, 0, (uint32_t)hd.unk_id);   // Knlm.hpp:1147
 			// suffix ("lower") links by BFS (Knlm.hpp:38-63, 1153-1166)

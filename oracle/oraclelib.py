@@ -99,3 +99,13 @@ class OracleKiwi:
         arr = np.zeros(len(COUNTER_NAMES), np.uint64)
         self.lib.korc_counters(self.h, arr.ctypes.data, int(reset))
         return dict(zip(COUNTER_NAMES, (int(x) for x in arr)))
+
+
+def alg_bytes(c: dict) -> dict:
+    """ALG_BYTES v1: algorithmic bytes from oracle event counts, no cache credit.
+    Returns the split used by bench.py: dictionary scan + lattice build ('lattice') and best-path search ('search')."""
+    lattice = (2 * c["inputUnits"] + c["trieProbes"] * (12 + 4) + c["trieProbeKeyBytes"] + c["failHops"] * 8
+               + c["candEmits"] * (16 + 24) + c["otherNodes"] * 24)
+    search = (c["transitions"] * 32 + c["candMorphs"] * 16 + c["statesWritten"] * 32
+              + c["lmProbes"] * (20 + 4) + c["lmProbeKeyBytes"] + c["lmRootProbes"] * 4 + c["tokens"] * 24)
+    return {"lattice": lattice, "search": search, "total": lattice + search}

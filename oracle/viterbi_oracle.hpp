@@ -59,7 +59,7 @@ namespace korc
 
 		bool lmSearch(const LmNodeRec& nd, uint32_t key, int32_t& v)
 		{
-			cnt.lmProbeKeyBytes += 2 * log2c(nd.numNexts) * 4;
+			cnt.lmProbeKeyBytes += 2 * log2c(nd.numNexts) * M.h.lmKeyBytes;
 			const uint32_t* k = M.lmKeys + nd.nextOff;
 			const uint32_t* it = std::lower_bound(k, k + nd.numNexts, key);
 			if (it == k + nd.numNexts || *it != key) return false;

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def small_model(tmp_path_factory):
+    """Deterministic small synthetic model shared by all tests (kiwi_amd/synth.py, seed 'KIWI')."""
+    from kiwi_amd.synth import SynthModel, SMALL_SPEC
+    d = os.path.join(ROOT, "_data")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "small.raw")
+    sm = SynthModel(SMALL_SPEC)
+    sm.raw.save(path)
+    return sm, path
+
+
+@pytest.fixture(scope="session")
+def oracle(small_model):
+    import subprocess
+    import oraclelib
+    if not oraclelib.available():
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+    return oraclelib.OracleKiwi(small_model[1])
+
+
+@pytest.fixture(scope="session")
+def reference(small_model):
+    """The real reference translation units (oracle/_ref); skipped where the prebuilt library is absent."""
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref/libkiwi_ref.so not built (needs /root/reference)")
+    return refbridge.RefKiwi(small_model[1])
+
+
+@pytest.fixture(scope="session")
+def engine(small_model):
+    from kiwi_amd.api import KiwiAmd
+    return KiwiAmd(small_model[1])

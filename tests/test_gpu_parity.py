@@ -1,0 +1,127 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs --
+bit-exact lattices, tokens, positions and fp32 path scores -- plus the committed golden vectors produced by
+the real reference, and size-independent properties at the benchmark batch size."""
+import json
+import os
+from dataclasses import astuple
+
+import numpy as np
+import pytest
+
+from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _norm(res):
+    return [([astuple(t) for t in a[0]], a[1]) for a in res]
+
+
+def test_native_library_is_loaded(engine):
+    maps = open("/proc/self/maps").read()
+    assert "libkiwi_hip.so" in maps
+
+
+def test_lattices_bit_exact_vs_oracle(engine, oracle, small_model):
+    sm, _ = small_model
+    for s in synthetic(sm, 150, 31, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 100, 32) + EDGE_TEXTS:
+        if not s.strip():
+            continue
+        assert engine.split(s) == oracle.split(s), s
+
+
+@pytest.mark.parametrize("kind", ["synthetic", "mix", "edge"])
+def test_tokens_bit_exact_vs_oracle(engine, oracle, small_model, kind):
+    sm, _ = small_model
+    texts = {"synthetic": lambda: synthetic(sm, 2000, 41, min_jamo=5, max_jamo=200),
+             "mix": lambda: dictionary_mix(sm, 1000, 42),
+             "edge": lambda: EDGE_TEXTS}[kind]()
+    got = engine.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(oracle.analyze(s)) == _norm(y), s
+
+
+def test_golden_vectors_from_reference(engine):
+    g = json.load(open(os.path.join(HERE, "golden", "small_model_golden.json"), encoding="utf-8"))
+    texts = [it["text"] for it in g["items"]]
+    got = engine.analyze_batch(texts).to_python()
+    for it, y in zip(g["items"], got):
+        toks = [[t.form, t.tag, t.position, t.length, t.word_position, t.sent_position, t.sense_id, t.morph_id] for t in y[0][0]]
+        assert toks == it["tokens"], it["text"]
+        assert y[0][1] == it["score"], it["text"]
+
+
+def test_against_real_reference_when_present(engine, reference, small_model):
+    sm, _ = small_model
+    texts = synthetic(sm, 500, 51, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 300, 52)
+    got = engine.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(reference.analyze(s)) == _norm(y), s
+
+
+def test_config_and_match_variants(engine, oracle, small_model):
+    sm, _ = small_model
+    texts = synthetic(sm, 200, 61, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 100, 62)
+    try:
+        for cfg in (dict(cut_off=5.0), dict(space_tol=2), dict(max_unk=3), dict(integrate_allomorph=False)):
+            oracle.set_config(**cfg)
+            engine.set_config(**cfg)
+            got = engine.analyze_batch(texts).to_python()
+            for s, y in zip(texts, got):
+                assert _norm(oracle.analyze(s)) == _norm(y), (cfg, s)
+        oracle.set_config()
+        engine.set_config()
+        for match in (0, (1 << 23) | (1 << 22), (1 << 23) | (1 << 25), (1 << 23) | (1 << 26), (1 << 23) | (1 << 17) | (1 << 18)):
+            got = engine.analyze_batch(texts, match=match).to_python()
+            for s, y in zip(texts, got):
+                assert _norm(oracle.analyze(s, match=match)) == _norm(y), (match, s)
+    finally:
+        oracle.set_config()
+        engine.set_config()
+
+
+def test_batch_properties_at_benchmark_size(engine, small_model):
+    """8k x 40-jamo batch (BASELINE config 2 shape): results do not depend on batch composition or order,
+    tokens tile the text left to right, and re-running the staged batch is idempotent."""
+    sm, _ = small_model
+    texts = synthetic(sm, 8192, 71, exact_jamo=40)
+    fields = [f for f in engine.analyze_batch(texts[:1]).token_array(0).dtype.names if f != "form_off"]   # form_off is batch-relative
+
+    def tok(r, i):
+        a = r.token_array(i)
+        return a[fields].tobytes()
+
+    res = engine.analyze_batch(texts)
+    arrs = [res.token_array(i) for i in range(len(texts))]
+    scores = np.array([res.lib.kamd_res_prob(res.h, i, 0) for i in range(len(texts))], np.float32)
+    for t, a in zip(texts, arrs):
+        assert len(a) > 0
+        pos = a["position"].astype(np.int64)
+        assert (np.diff(pos) >= 0).all()
+        assert int((pos + a["length"]).max()) <= len(t)
+    perm = np.random.default_rng(5).permutation(len(texts))
+    res2 = engine.analyze_batch([texts[i] for i in perm])
+    for j, i in enumerate(perm[:2000]):
+        assert arrs[i][fields].tobytes() == tok(res2, j)
+    sub = engine.analyze_batch(texts[100:164])
+    for j in range(64):
+        assert arrs[100 + j][fields].tobytes() == tok(sub, j)
+    b = engine.stage(texts)
+    engine.run(b)
+    engine.run(b)
+    r3 = engine.fetch(b)
+    s3 = np.array([r3.lib.kamd_res_prob(r3.h, i, 0) for i in range(len(texts))], np.float32)
+    assert (s3 == scores).all()
+    assert b.info()["chunks"] >= len(texts)
+
+
+def test_empty_and_degenerate_batches(engine):
+    assert engine.analyze_batch([]).n_texts() == 0
+    r = engine.analyze_batch(["", " ", "\n"]).to_python()
+    assert [len(x[0][0]) for x in r] == [0, 0, 0]
+
+
+def test_top_n_is_refused_loudly(engine):
+    with pytest.raises(RuntimeError):
+        engine.analyze_batch(["가나다"], top_n=3)

@@ -1,0 +1,70 @@
+"""CPU: pins the oracle (this repo's restatement) and the host-side baker against the REAL reference
+translation units compiled into oracle/_ref/libkiwi_ref.so (skipped where that library is absent), and
+against committed golden vectors generated from them (tests/golden/, always run)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_baked_dictionary_matches_reference(oracle, reference):
+    a, b = reference.dump_dict(), oracle.dump_dict()
+    assert len(a) == len(b)
+    # the reference's sentinel form (last form record) carries uninitialised flag bits: compare around it
+    diff = [i for i in range(len(a)) if a[i] != b[i]]
+    assert len(diff) <= 1, diff[:10]
+
+
+def test_knlm_progress_matches_reference(oracle, reference, small_model):
+    sm, _ = small_model
+    rng = np.random.default_rng(1)
+    for t in range(5000):
+        node = 0 if t % 3 == 0 else int(rng.integers(0, 3000))
+        wid = int(rng.integers(0, sm.raw.vocab_size))
+        assert reference.lm_progress(node, wid) == oracle.lm_progress(node, wid)
+
+
+@pytest.mark.parametrize("kind", ["synthetic", "mix", "edge"])
+def test_lattice_and_tokens_match_reference(oracle, reference, small_model, kind):
+    sm, _ = small_model
+    texts = {"synthetic": lambda: synthetic(sm, 400, 11, min_jamo=5, max_jamo=150),
+             "mix": lambda: dictionary_mix(sm, 400, 12),
+             "edge": lambda: EDGE_TEXTS}[kind]()
+    for s in texts:
+        assert reference.split(s) == oracle.split(s), s
+        assert reference.analyze(s) == oracle.analyze(s), s
+
+
+def test_config_variants_match_reference(oracle, reference, small_model):
+    sm, _ = small_model
+    texts = synthetic(sm, 60, 21, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 40, 22)
+    try:
+        for cfg in (dict(cut_off=5.0), dict(space_tol=2), dict(max_unk=3), dict(integrate_allomorph=False)):
+            oracle.set_config(**cfg)
+            reference.set_config(**cfg)
+            for s in texts:
+                assert reference.analyze(s) == oracle.analyze(s), (cfg, s)
+        for match in (0, (1 << 23), (1 << 23) | (1 << 17) | (1 << 18) | (1 << 19) | (1 << 20) | (1 << 21), (1 << 22) | (1 << 23), (1 << 23) | (1 << 25), (1 << 23) | (1 << 26), (1 << 23) | (1 << 24)):
+            oracle.set_config()
+            reference.set_config()
+            for s in texts[:50]:
+                assert reference.analyze(s, match=match) == oracle.analyze(s, match=match), (match, s)
+    finally:
+        oracle.set_config()
+        reference.set_config()
+
+
+def test_golden_vectors(oracle):
+    """tests/golden/small_model_golden.json was produced by tools/make_golden.py from the real reference TUs."""
+    path = os.path.join(HERE, "golden", "small_model_golden.json")
+    g = json.load(open(path, encoding="utf-8"))
+    for item in g["items"]:
+        got = oracle.analyze(item["text"])
+        toks = [[t.form, t.tag, t.position, t.length, t.word_position, t.sent_position, t.sense_id, t.morph_id] for t in got[0][0]]
+        assert toks == item["tokens"], item["text"]
+        assert abs(got[0][1] - item["score"]) == 0, item["text"]
