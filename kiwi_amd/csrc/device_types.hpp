@@ -16,9 +16,11 @@ namespace kamd
 		uint16_t startPos, endPos;     // ns positions while building, chunk-relative string offsets when final
 		uint16_t prev, sibling;        // relative links, as in the reference
 		uint16_t uformOff, uformLen;   // chunk-relative substring for OOV / special / pattern nodes
-		uint16_t spaceErrors;
-		uint16_t flags;                // unused
+		uint8_t spaceErrors;
+		uint8_t nflags;                // NF_* bits, filled by k_build_lattice for the search kernel
+		uint16_t nPrev;                // number of predecessor nodes (length of the prev/sibling chain)
 	};
+	enum NodeFlag : uint8_t { NF_SPACE_BEFORE = 1, NF_LEFT_BOUNDARY = 2, NF_UFORM_ENDS_POINT = 4 };
 	static_assert(sizeof(DevNode) == 20, "DevNode");
 	constexpr uint32_t NOFORM = 0xFFFFFFFFu;
 
@@ -38,8 +40,6 @@ namespace kamd
 		uint16_t ownNode;              // node whose own form this path carries
 	};
 	static_assert(sizeof(DevState) == 40, "DevState");
-	constexpr uint16_t LF_SKIP_COND = 1u << 13;   // previous morpheme closes a bracket: left conditions are not applied
-	constexpr uint16_t LF_PREV_ZSIOT = 1u << 14;
 	constexpr uint8_t COMMON_ROOT = 0xFF;
 
 	// output token, 24 B (reference: PathNode 72 B, src/PathEvaluator.h:33-68)
@@ -85,6 +85,7 @@ namespace kamd
 		const uint32_t* spOff;         // [nChunks+1] into spStates: sorted unique previous SpecialStates of the chunk
 		const uint8_t* spStates;
 		const uint8_t* chunkFlags;     // bit0: openEnding applies to this chunk
+		const uint32_t* textOffset;    // [nChunks] offset of the chunk inside its normalised text (Kiwi.cpp:1095-1117 `splitEnd`)
 	};
 
 	// Scratch + outputs.  All per-chunk regions are laid out by the host from the chunk lengths

@@ -3,18 +3,19 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <numeric>
 #include <stdexcept>
 #include <thread>
 #include "engine.hpp"
+#include "viterbi_kernel.hpp"
 
 namespace kamd
 {
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W);
 	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P);
-	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder);
 
 	namespace
 	{
@@ -49,7 +50,6 @@ namespace kamd
 			if (!v.empty()) HIPCHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
 		}
 
-		constexpr uint32_t kBigScratchBytes = (8 + 8 + 4) * 8192 + (4 * 5) * 4096;
 	}
 
 	struct ChunkRef { uint32_t text, chunk; std::vector<uint8_t> sp; bool openEnding; };
@@ -66,7 +66,7 @@ namespace kamd
 		std::vector<uint32_t> charOff, patOff, spOff, matchBase, nodeBase;
 		std::vector<uint64_t> stateBase, tokenBase;
 		// device
-		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags;
+		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags, dTextOff;
 		DevBuf dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
 		DevBuf dStateBase, dStates, dNodeStOff, dNodeStCnt, dReach, dTokenBase, dTokens, dResults, dOrder;
 		BatchView bv{}; WorkView wv{};
@@ -84,6 +84,7 @@ namespace kamd
 		hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
 		int device = 0;
 		uint32_t persistBlocks = 0;
+		int groupLanes = 8;   // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 64)
 		DevBuf bigScratch, counter;
 
 		template<class T> const T* up(const std::vector<T>& v)
@@ -112,13 +113,18 @@ namespace kamd
 		v.h = m.h;
 		v.forms = impl->up(m.forms); v.formChars = impl->up(m.formChars); v.formCand = impl->up(m.formCand);
 		v.morphs = impl->up(m.morphs); v.chunkMorph = impl->up(m.chunkMorph); v.chunkLm = impl->up(m.chunkLm); v.chunkPos = impl->up(m.chunkPos);
-		v.sbInfo = impl->up(m.sbInfo);
+		v.sbInfo = impl->up(m.sbInfo); v.morphPath = impl->up(m.morphPath);
 		v.trie = impl->up(m.trie); v.trieKeys = impl->up(m.trieKeys); v.trieChild = impl->up(m.trieChild); v.trieRoot = impl->up(m.trieRoot);
 		v.lmNodes = impl->up(m.lmNodes); v.lmKeys = impl->up(m.lmKeys); v.lmValues = impl->up(m.lmValues); v.lmRoot = impl->up(m.lmRoot);
 		hipDeviceProp_t prop;
 		HIPCHECK(hipGetDeviceProperties(&prop, device));
-		impl->persistBlocks = (uint32_t)prop.multiProcessorCount * 16;   // one-wave blocks; LDS footprint allows >= 16 per CU
-		impl->bigScratch.ensure((size_t)impl->persistBlocks * kBigScratchBytes);
+		impl->persistBlocks = (uint32_t)prop.multiProcessorCount * 16;   // one-wave blocks; more than can be resident is harmless
+		if (const char* g = std::getenv("KAMD_GROUP_LANES"))
+		{
+			const int v = std::atoi(g);
+			if (v == 4 || v == 8 || v == 16 || v == 64) impl->groupLanes = v;
+			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16 or 64" };
+		}
 		impl->counter.ensure(64);
 	}
 
@@ -169,6 +175,7 @@ namespace kamd
 		b.charOff.assign(nC + 1, 0); b.patOff.assign(nC + 1, 0); b.spOff.assign(nC + 1, 0);
 		b.matchBase.assign(nC + 1, 0); b.nodeBase.assign(nC + 1, 0); b.stateBase.assign(nC + 1, 0); b.tokenBase.assign(nC + 1, 0);
 		std::vector<uint8_t> flags(nC), sp;
+		std::vector<uint32_t> textOff(nC);
 		const uint64_t sc = b.capScale;
 		for (size_t c = 0; c < nC; ++c)
 		{
@@ -185,6 +192,7 @@ namespace kamd
 			b.stateBase[c + 1] = b.stateBase[c] + scap;
 			b.tokenBase[c + 1] = b.tokenBase[c] + tcap;
 			flags[c] = r.openEnding ? 1 : 0;
+			textOff[c] = d.startOffset;
 			sp.insert(sp.end(), r.sp.begin(), r.sp.end());
 		}
 		const size_t totChars = b.charOff[nC];
@@ -205,7 +213,7 @@ namespace kamd
 		hipStream_t s = I.stream;
 		upload(b.dChars, chars, s); upload(b.dCls, cls, s); upload(b.dScript, script, s);
 		upload(b.dCharOff, b.charOff, s); upload(b.dPatOff, b.patOff, s); upload(b.dPatterns, pats, s);
-		upload(b.dSpOff, b.spOff, s); upload(b.dSp, sp, s); upload(b.dFlags, flags, s);
+		upload(b.dSpOff, b.spOff, s); upload(b.dSp, sp, s); upload(b.dFlags, flags, s); upload(b.dTextOff, textOff, s);
 		upload(b.dMatchBase, b.matchBase, s); upload(b.dNodeBase, b.nodeBase, s); upload(b.dStateBase, b.stateBase, s); upload(b.dTokenBase, b.tokenBase, s);
 		const size_t perChar = totChars + nC + 16;
 		const size_t totNodes = b.nodeBase[nC], totMatch = b.matchBase[nC];
@@ -223,7 +231,7 @@ namespace kamd
 		BatchView& bv = b.bv;
 		bv.nChunks = (uint32_t)nC; bv.chars = b.dChars.as<uint16_t>(); bv.cls = b.dCls.as<uint8_t>(); bv.script = b.dScript.as<uint8_t>();
 		bv.charOff = b.dCharOff.as<uint32_t>(); bv.patOff = b.dPatOff.as<uint32_t>(); bv.patterns = b.dPatterns.as<DevPattern>();
-		bv.spOff = b.dSpOff.as<uint32_t>(); bv.spStates = b.dSp.as<uint8_t>(); bv.chunkFlags = b.dFlags.as<uint8_t>();
+		bv.spOff = b.dSpOff.as<uint32_t>(); bv.spStates = b.dSp.as<uint8_t>(); bv.chunkFlags = b.dFlags.as<uint8_t>(); bv.textOffset = b.dTextOff.as<uint32_t>();
 		WorkView& w = b.wv;
 		w.nsToPos = b.dNsToPos.as<uint16_t>(); w.posToNs = b.dPosToNs.as<uint16_t>(); w.cflag = b.dCflag.as<uint8_t>();
 		w.matchMask = b.dMask.as<uint64_t>(); w.matchOff = b.dMoff.as<uint32_t>(); w.nNs = b.dNNs.as<uint32_t>();
@@ -233,7 +241,7 @@ namespace kamd
 		w.stateBase = b.dStateBase.as<uint64_t>(); w.states = b.dStates.as<DevState>();
 		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();
 		w.tokenBase = b.dTokenBase.as<uint64_t>(); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
-		w.bigScratch = I.bigScratch.as<uint8_t>(); w.bigScratchBytes = kBigScratchBytes;
+		w.bigScratch = nullptr; w.bigScratchBytes = 0;   // bound at launch
 		// longest chunks first: the persistent search waves pull work in this order
 		std::vector<uint32_t> order(nC);
 		std::iota(order.begin(), order.end(), 0u);
@@ -266,8 +274,17 @@ namespace kamd
 		HIPCHECK(hipEventRecord(I.ev[1], s));
 		hipLaunchKernelGGL(k_build_lattice, dim3((nC + 63) / 64), dim3(64), 0, s, I.dview, b.bv, b.wv, sp);
 		HIPCHECK(hipEventRecord(I.ev[2], s));
-		const uint32_t blocks = std::min(I.persistBlocks, nC);
-		hipLaunchKernelGGL(k_best_path, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>());
+		const uint32_t nGroups = 64u / (uint32_t)I.groupLanes;
+		const uint32_t blocks = std::min(I.persistBlocks, (nC + nGroups - 1) / nGroups);
+		I.bigScratch.ensure((size_t)blocks * nGroups * sizeof(GroupScratch));
+		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)sizeof(GroupScratch);
+		switch (I.groupLanes)
+		{
+		case 4: hipLaunchKernelGGL(k_best_path<4>, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		case 8: hipLaunchKernelGGL(k_best_path<8>, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		case 16: hipLaunchKernelGGL(k_best_path<16>, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		default: hipLaunchKernelGGL(k_best_path<64>, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		}
 		HIPCHECK(hipEventRecord(I.ev[3], s));
 		HIPCHECK(hipGetLastError());
 		HIPCHECK(hipStreamSynchronize(s));

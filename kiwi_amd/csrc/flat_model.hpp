@@ -76,6 +76,8 @@ namespace kamd
 	};
 	static_assert(sizeof(TrieNodeRec) == 16, "TrieNodeRec");
 	constexpr int32_t TRIE_NONE = -1, TRIE_SUBMATCH = -2;
+	// bits 13..15 of a left-feature mask (bits 0..12: feature.hpp featMask)
+	constexpr uint16_t LF_STR_SSC = 1u << 13, LF_PREV_ZSIOT = 1u << 14, LF_TAG_SSC = 1u << 15;
 
 	struct LmNodeRec
 	{
@@ -108,6 +110,7 @@ namespace kamd
 		const uint32_t* chunkLm;      // chunks[i]->lmMorphemeId
 		const uint8_t* chunkPos;      // (begin,end) pairs
 		const uint8_t* sbInfo;        // per morph: sbType (0 for non-SB), see getSBType (src/Utils.cpp:264-298)
+		const uint32_t* morphPath;    // per morph: what a path ending in it exposes to its successor: leftFeat (low 16) | prevFlags << 16
 		const TrieNodeRec* trie;
 		const uint16_t* trieKeys;     // sorted per node
 		const uint32_t* trieChild;    // absolute
@@ -129,6 +132,7 @@ namespace kamd
 		std::vector<uint32_t> chunkMorph, chunkLm;
 		std::vector<uint8_t> chunkPos;
 		std::vector<uint8_t> sbInfo;
+		std::vector<uint32_t> morphPath;
 		std::vector<uint32_t> morphKform;    // form id of each morpheme's kform (host-side result building)
 		std::vector<uint8_t> morphSenseDialect;
 		std::vector<TrieNodeRec> trie;
@@ -146,7 +150,7 @@ namespace kamd
 			v.h = h;
 			v.forms = forms.data(); v.formChars = formChars.data(); v.formCand = formCand.data();
 			v.morphs = morphs.data(); v.chunkMorph = chunkMorph.data(); v.chunkLm = chunkLm.data(); v.chunkPos = chunkPos.data();
-			v.sbInfo = sbInfo.data();
+			v.sbInfo = sbInfo.data(); v.morphPath = morphPath.data();
 			v.trie = trie.data(); v.trieKeys = trieKeys.data(); v.trieChild = trieChild.data(); v.trieRoot = trieRoot.data();
 			v.lmNodes = lmNodes.data(); v.lmKeys = lmKeys.data(); v.lmValues = lmValues.data(); v.lmRoot = lmRoot.data();
 			return v;

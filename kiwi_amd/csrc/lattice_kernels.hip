@@ -166,7 +166,7 @@ namespace kamd
 		const uint32_t id = L.nOut++;
 		DevNode nn;
 		nn.form = form; nn.startPos = (uint16_t)s; nn.endPos = (uint16_t)e; nn.prev = (uint16_t)(id - (ms & 0xFFFF)); nn.sibling = 0;
-		nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = 0; nn.flags = 0;
+		nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = 0; nn.nflags = 0; nn.nPrev = 0;
 		L.out[id] = nn;
 		if (e >= nMap) return true;
 		const uint32_t me = L.endPosMap[e];
@@ -258,7 +258,7 @@ namespace kamd
 		for (uint32_t i = 0; i < nMap; ++i) L.endPosMap[i] = 0;     // first == second : empty
 		L.endPosMap[0] = 0 | (1u << 16);
 		{
-			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.flags = 0;
+			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0;
 			L.out[0] = bos; L.nOut = 1;
 		}
 		const DevPattern* pat = B.patterns + B.patOff[chunk];
@@ -369,7 +369,7 @@ namespace kamd
 				}
 				if (se <= P.spaceTol)
 				{
-					if (latAppend(L, nb, ne, fi, 0, 0, nMap)) L.out[L.nOut - 1].spaceErrors = (uint16_t)se;
+					if (latAppend(L, nb, ne, fi, 0, 0, nMap)) L.out[L.nOut - 1].spaceErrors = (uint8_t)(se > 255 ? 255 : se);
 				}
 			}
 		}
@@ -413,22 +413,57 @@ namespace kamd
 		for (uint32_t e = 0; e <= nNs; ++e)
 		{
 			const uint32_t me = L.endPosMap[e];
-			if ((me & 0xFFFF) == (me >> 16)) continue;
-			for (uint32_t i = me & 0xFFFF;;)
+			uint32_t chainConn = 0;
+			if ((me & 0xFFFF) != (me >> 16))
 			{
-				if (i != G - 1) inv[i] = connOrd[i] ? (uint16_t)nConn++ : (uint16_t)0xFFFF;
-				const uint32_t sib = L.out[i].sibling;
-				if (!sib) break;
-				i += sib;
+				for (uint32_t i = me & 0xFFFF;;)
+				{
+					if (i != G - 1)
+					{
+						if (connOrd[i]) { inv[i] = (uint16_t)nConn++; ++chainConn; }
+						else inv[i] = (uint16_t)0xFFFF;
+					}
+					const uint32_t sib = L.out[i].sibling;
+					if (!sib) break;
+					i += sib;
+				}
 			}
+			L.endPosMap[e] = chainConn;   // from here on: number of connected nodes ending at e
 		}
 		inv[G - 1] = (uint16_t)nConn++;
 		DevNode* fin = W.nodes + nBase;
+		const uint32_t textOff = B.textOffset[chunk];
 		for (uint32_t idx = 0; idx < G; ++idx)
 		{
 			const uint32_t ni = inv[idx];
 			if (ni == 0xFFFF) continue;
 			DevNode nn = L.out[idx];
+			const uint32_t startNs = nn.startPos;
+			uint8_t nf = 0;
+			if (ni >= 1)
+			{
+				// predecessor-dependent facts the search kernel needs once per node
+				const DevNode pn = L.out[idx - nn.prev];
+				const uint32_t startStr = (ni + 1 == nConn) ? n : (uint32_t)L.nsToPos[startNs];
+				const bool pnBos = (idx - nn.prev) == 0;
+				const uint32_t pnEndStr = pnBos ? 0 : (uint32_t)L.nsToPos[pn.endPos - 1] + 1;
+				// the reference compares absolute text offsets; the start node's end is 0 (PathEvaluator.hpp:24-31, 436, 568)
+				const bool spaceBefore = pnBos ? (textOff + startStr > 0) : (pnEndStr < startStr);
+				bool lb = pnBos || spaceBefore;
+				if (!lb && pn.uformLen)
+				{
+					const uint32_t lp = pn.uformOff + pn.uformLen - 1;
+					const uint16_t c = str[lp];
+					const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
+					if (tag == T_SSC || c == u'"' || c == u'\'') lb = false;
+					else if (T_SF <= tag && tag <= T_SB) lb = true;
+				}
+				if (spaceBefore) nf |= NF_SPACE_BEFORE;
+				if (lb) nf |= NF_LEFT_BOUNDARY;
+				if (nn.uformLen && str[nn.uformOff + nn.uformLen - 1] == u'.') nf |= NF_UFORM_ENDS_POINT;
+				nn.nPrev = (uint16_t)L.endPosMap[startNs];
+			}
+			nn.nflags = nf;
 			if (nn.prev) nn.prev = (uint16_t)(ni - inv[idx - nn.prev]);
 			if (nn.sibling)
 			{

@@ -310,6 +310,25 @@ namespace kamd
 			o.special = 6;
 			if (tag == T_SB) m.sbInfo[i] = (uint8_t)getSBType(joinHangul(kf));
 		}
+		// what a path that ends in morpheme i (recorded word id = lastSeqId) exposes to the next morpheme:
+		// FormEvaluator's choice of left string (PathEvaluator.hpp:261-291) and RuleBasedScorer's previous-morpheme tests
+		m.morphPath.assign(nM, 0);
+		for (size_t i = 0; i < nM; ++i)
+		{
+			const MorphRec& cm = m.morphs[i];
+			const MorphRec& wm = m.morphs[cm.lastSeqId];
+			uint16_t f;
+			if (!(wm.flags & MF_KFORM_EMPTY)) f = wm.feat | ((wm.flags & MF_ENDS_WITH_SSC) ? LF_STR_SSC : 0);
+			else if (cm.tag == T_UNKNOWN && cm.nChunks)
+			{
+				const MorphRec& lm = m.morphs[m.chunkMorph[cm.chunkOff + cm.nChunks - 1]];
+				f = lm.feat | ((lm.flags & MF_ENDS_WITH_SSC) ? LF_STR_SSC : 0);
+			}
+			else f = cm.feat | ((cm.flags & MF_ENDS_WITH_SSC) ? LF_STR_SSC : 0);
+			if (cm.tag == T_SSC) f |= LF_TAG_SSC;
+			if (cm.tag == T_Z_SIOT) f |= LF_PREV_ZSIOT;
+			m.morphPath[i] = (uint32_t)f | ((uint32_t)wm.prevFlags << 16);
+		}
 		// KiwiBuilder::getSpecialMorphs (KiwiBuilder.cpp:2642-2662)
 		for (auto& s : m.h.specialMorph) s = 0;
 		for (size_t i = 0; i < nM; ++i)

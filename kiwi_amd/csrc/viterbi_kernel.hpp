@@ -1,0 +1,19 @@
+// Launch-side declarations of the best-path search kernel (viterbi_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+
+namespace kamd
+{
+	constexpr uint32_t QCAP = 64;          // work items of one batch staged in LDS (per lane group)
+	constexpr uint32_t BIGQ = 2048;        // work items of one batch staged in HBM scratch (per lane group); beyond: CS_ERR_PAIR_OVERFLOW
+	constexpr uint32_t ENDCAP = 256;       // end-node candidates per chunk
+
+	struct EndCand { float score, fcs, typo; uint32_t parent; uint8_t rootId, sp; uint16_t pad; };
+	// scratch in HBM per lane group (items of oversized batches, end-node candidates)
+	struct GroupScratch { uint64_t key[BIGQ]; float score[BIGQ]; float fcs[BIGQ]; EndCand end[ENDCAP]; };
+
+	// G = lanes per chunk (4, 8, 16 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
+	template<int G>
+	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder);
+}
