@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkiwi_hip.so")
+LIB_PATH = os.environ.get("KAMD_LIB", os.path.join(HERE, "libkiwi_hip.so"))
 
 MATCH_ALL = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 23)
 MATCH_ALL_WITH_NORMALIZING = MATCH_ALL | (1 << 16)

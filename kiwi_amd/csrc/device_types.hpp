@@ -9,8 +9,8 @@ namespace kamd
 {
 	struct DevPattern { uint32_t end, length; uint32_t tag; };   // chunk-relative (textprep.hpp PatternSpan)
 
-	// lattice node, 20 B (reference: KGraphNode 56 B, src/KTrie.h:57-77)
-	struct DevNode
+	// lattice node, 32 B (reference: KGraphNode 56 B, src/KTrie.h:57-77)
+	struct alignas(16) DevNode
 	{
 		uint32_t form;                 // form id or NOFORM
 		uint16_t startPos, endPos;     // ns positions while building, chunk-relative string offsets when final
@@ -19,27 +19,42 @@ namespace kamd
 		uint8_t spaceErrors;
 		uint8_t nflags;                // NF_* bits, filled by k_build_lattice for the search kernel
 		uint16_t nPrev;                // number of predecessor nodes (length of the prev/sibling chain)
+		uint32_t packOff;              // first candidate record of this node in the chunk's candidate-pack region
+		uint16_t candCnt;              // candidate morphemes of `form`
+		uint8_t fflags;                // FormRec::flags
+		uint8_t flen;                  // FormRec::len
+		uint16_t ownFeat;              // left-feature mask (+ LF_STR_SSC) of the node's own surface string (uform)
+		uint16_t pad;
 	};
-	enum NodeFlag : uint8_t { NF_SPACE_BEFORE = 1, NF_LEFT_BOUNDARY = 2, NF_UFORM_ENDS_POINT = 4 };
-	static_assert(sizeof(DevNode) == 20, "DevNode");
+	enum NodeFlag : uint8_t { NF_SPACE_BEFORE = 1, NF_LEFT_BOUNDARY = 2, NF_UFORM_ENDS_POINT = 4, NF_ALL_PARTIAL = 8 };
+	static_assert(sizeof(DevNode) == 32, "DevNode");
+	// static part of a candidate record (k_expand_cands): MorphRec dwords 0..7, then {morpheme id, first LM id, sbType, 0}
+	struct alignas(16) Quad { uint32_t x, y, z, w; };
+	struct CandStatic { Quad m0, m1, x; };
 	constexpr uint32_t NOFORM = 0xFFFFFFFFu;
 
-	// search state, 40 B (reference: WordLL<KnLMState> 48 B, src/BestPathContainer.hpp:21-67)
-	struct DevState
+	// search state, 48 B = three 16-byte quads (reference: WordLL<KnLMState> 48 B, src/BestPathContainer.hpp:21-67).
+	// Quad 0 is everything a successor transition reads ("hot": one 16-byte load per work item); quads 1-2 are only
+	// needed when a state is created from its parent and by the back-trace.
+	struct alignas(16) DevState
 	{
 		int32_t lmNode;
-		float accScore, firstChunkScore, accTypoCost;
+		float accScore;
+		uint16_t leftFeat;             // feature mask of the left string as seen by the next morpheme (+ LF_* bits)
+		uint8_t rootId, spState;
+		uint8_t socket, prevFlags;
+		uint8_t dead;                  // pruned (PathEvaluator.hpp:503-511); dead states stay in place and are skipped
+		uint8_t ownKind;               // 0 none, 1 node.uform, 2 node.form string, 3 text[node.start,node.end)
+		float accTypoCost;
+		uint32_t wid;
 		uint32_t parent;               // chunk-relative state index
 		uint32_t morph;
-		uint32_t wid;
+		float firstChunkScore;
 		uint16_t nodeId;
-		uint8_t rootId, spState;
-		uint8_t socket, ownKind;       // ownKind: 0 none, 1 node.uform, 2 node.form string, 3 text[node.start,node.end)
-		uint16_t leftFeat;             // feature mask of the left string as seen by the next morpheme (+ LF_* bits)
-		uint8_t prevFlags, pad;
 		uint16_t ownNode;              // node whose own form this path carries
+		uint32_t pad0, pad1;
 	};
-	static_assert(sizeof(DevState) == 40, "DevState");
+	static_assert(sizeof(DevState) == 48, "DevState");
 	constexpr uint8_t COMMON_ROOT = 0xFF;
 
 	// output token, 24 B (reference: PathNode 72 B, src/PathEvaluator.h:33-68)
@@ -112,6 +127,8 @@ namespace kamd
 		uint32_t* nodeStateOff;        // per node (same offsets as nodes): chunk-relative first state
 		uint32_t* nodeStateCnt;
 		uint8_t* reach;                // per node: the reference's `reachable` flags (PathEvaluator.hpp:1159-1176, 1286)
+		const uint32_t* packBase;      // [nChunks+1] candidate-pack regions
+		CandStatic* packs;
 		const uint64_t* tokenBase;     // [nChunks+1]
 		DevToken* tokens;
 		DevChunkResult* results;       // [c]

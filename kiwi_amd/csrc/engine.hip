@@ -16,6 +16,7 @@ namespace kamd
 {
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W);
 	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P);
+	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W);
 
 	namespace
 	{
@@ -63,12 +64,12 @@ namespace kamd
 		uint32_t capScale = 1;
 		uint64_t units = 0, devBytes = 0;
 		// host layout
-		std::vector<uint32_t> charOff, patOff, spOff, matchBase, nodeBase;
+		std::vector<uint32_t> charOff, patOff, spOff, matchBase, nodeBase, packBase;
 		std::vector<uint64_t> stateBase, tokenBase;
 		// device
 		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags, dTextOff;
 		DevBuf dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
-		DevBuf dStateBase, dStates, dNodeStOff, dNodeStCnt, dReach, dTokenBase, dTokens, dResults, dOrder;
+		DevBuf dPackBase, dPacks, dStateBase, dStates, dNodeStOff, dNodeStCnt, dReach, dTokenBase, dTokens, dResults, dOrder;
 		BatchView bv{}; WorkView wv{};
 		std::vector<DevChunkResult> hResults;
 		std::vector<DevToken> hTokens;
@@ -84,7 +85,7 @@ namespace kamd
 		hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
 		int device = 0;
 		uint32_t persistBlocks = 0;
-		int groupLanes = 8;   // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 64)
+		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter;
 
 		template<class T> const T* up(const std::vector<T>& v)
@@ -112,18 +113,34 @@ namespace kamd
 		ModelView& v = impl->dview;
 		v.h = m.h;
 		v.forms = impl->up(m.forms); v.formChars = impl->up(m.formChars); v.formCand = impl->up(m.formCand);
-		v.morphs = impl->up(m.morphs); v.chunkMorph = impl->up(m.chunkMorph); v.chunkLm = impl->up(m.chunkLm); v.chunkPos = impl->up(m.chunkPos);
+		{
+			// device copy of the morpheme table: `feat` / `prevFlags` are replaced by the path-side values (FlatModel::morphPath)
+			std::vector<MorphRec> dm = m.morphs;
+			for (size_t i = 0; i < dm.size(); ++i) { dm[i].feat = (uint16_t)m.morphPath[i]; dm[i].prevFlags = (uint8_t)(m.morphPath[i] >> 16); }
+			v.morphs = impl->up(dm);
+			std::vector<CandStatic> unk(2);
+			for (int k = 0; k < 2; ++k)
+			{
+				const uint32_t mid = (k == 0 ? T_NNG : T_NNP) + 1u;
+				std::memcpy(&unk[k].m0, &dm[mid], 32);
+				const uint32_t firstWid = (dm[mid].flags & MF_SINGLE) ? dm[mid].lmId : m.chunkLm[dm[mid].chunkOff];
+				unk[k].x = Quad{ mid, firstWid, 0, 0 };
+			}
+			v.unkPacks = impl->up(unk);
+		}
+		v.chunkMorph = impl->up(m.chunkMorph); v.chunkLm = impl->up(m.chunkLm); v.chunkPos = impl->up(m.chunkPos);
 		v.sbInfo = impl->up(m.sbInfo); v.morphPath = impl->up(m.morphPath);
 		v.trie = impl->up(m.trie); v.trieKeys = impl->up(m.trieKeys); v.trieChild = impl->up(m.trieChild); v.trieRoot = impl->up(m.trieRoot);
 		v.lmNodes = impl->up(m.lmNodes); v.lmKeys = impl->up(m.lmKeys); v.lmValues = impl->up(m.lmValues); v.lmRoot = impl->up(m.lmRoot);
+		v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff);
 		hipDeviceProp_t prop;
 		HIPCHECK(hipGetDeviceProperties(&prop, device));
-		impl->persistBlocks = (uint32_t)prop.multiProcessorCount * 16;   // one-wave blocks; more than can be resident is harmless
+		impl->persistBlocks = (uint32_t)prop.multiProcessorCount * 32;   // one-wave blocks; more than can be resident is harmless
 		if (const char* g = std::getenv("KAMD_GROUP_LANES"))
 		{
 			const int v = std::atoi(g);
-			if (v == 4 || v == 8 || v == 16 || v == 64) impl->groupLanes = v;
-			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16 or 64" };
+			if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) impl->groupLanes = v;
+			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16, 32 or 64" };
 		}
 		impl->counter.ensure(64);
 	}
@@ -173,7 +190,7 @@ namespace kamd
 	{
 		const size_t nC = b.refs.size();
 		b.charOff.assign(nC + 1, 0); b.patOff.assign(nC + 1, 0); b.spOff.assign(nC + 1, 0);
-		b.matchBase.assign(nC + 1, 0); b.nodeBase.assign(nC + 1, 0); b.stateBase.assign(nC + 1, 0); b.tokenBase.assign(nC + 1, 0);
+		b.matchBase.assign(nC + 1, 0); b.nodeBase.assign(nC + 1, 0); b.packBase.assign(nC + 1, 0); b.stateBase.assign(nC + 1, 0); b.tokenBase.assign(nC + 1, 0);
 		std::vector<uint8_t> flags(nC), sp;
 		std::vector<uint32_t> textOff(nC);
 		const uint64_t sc = b.capScale;
@@ -189,6 +206,8 @@ namespace kamd
 			if ((uint64_t)b.matchBase[c] + mcap > 0xFFFFFFFFull || (uint64_t)b.nodeBase[c] + ncap > 0xFFFFFFFFull) throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
 			b.matchBase[c + 1] = b.matchBase[c] + (uint32_t)mcap;
 			b.nodeBase[c + 1] = b.nodeBase[c] + (uint32_t)ncap;
+			if ((uint64_t)b.packBase[c] + 3 * ncap > 0xFFFFFFFFull) throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
+			b.packBase[c + 1] = b.packBase[c] + (uint32_t)(3 * ncap);
 			b.stateBase[c + 1] = b.stateBase[c] + scap;
 			b.tokenBase[c + 1] = b.tokenBase[c] + tcap;
 			flags[c] = r.openEnding ? 1 : 0;
@@ -214,7 +233,7 @@ namespace kamd
 		upload(b.dChars, chars, s); upload(b.dCls, cls, s); upload(b.dScript, script, s);
 		upload(b.dCharOff, b.charOff, s); upload(b.dPatOff, b.patOff, s); upload(b.dPatterns, pats, s);
 		upload(b.dSpOff, b.spOff, s); upload(b.dSp, sp, s); upload(b.dFlags, flags, s); upload(b.dTextOff, textOff, s);
-		upload(b.dMatchBase, b.matchBase, s); upload(b.dNodeBase, b.nodeBase, s); upload(b.dStateBase, b.stateBase, s); upload(b.dTokenBase, b.tokenBase, s);
+		upload(b.dMatchBase, b.matchBase, s); upload(b.dNodeBase, b.nodeBase, s); upload(b.dPackBase, b.packBase, s); upload(b.dStateBase, b.stateBase, s); upload(b.dTokenBase, b.tokenBase, s);
 		const size_t perChar = totChars + nC + 16;
 		const size_t totNodes = b.nodeBase[nC], totMatch = b.matchBase[nC];
 		const uint64_t totStates = b.stateBase[nC], totTokens = b.tokenBase[nC];
@@ -222,11 +241,12 @@ namespace kamd
 		b.dNNs.ensure(nC * 4 + 16); b.dMatchForm.ensure(totMatch * 4 + 16);
 		b.dNodes.ensure(totNodes * sizeof(DevNode) + 16); b.dTmpNodes.ensure(totNodes * sizeof(DevNode) + 16);
 		b.dEndPosMap.ensure(perChar * 4); b.dTmpIdx.ensure(totNodes * 4 + 16); b.dNNodes.ensure(nC * 4 + 16);
+		b.dPacks.ensure((size_t)b.packBase[nC] * sizeof(CandStatic) + 16);
 		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
 		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
 		b.devBytes = 0;
 		for (const DevBuf* d : { &b.dChars, &b.dCls, &b.dScript, &b.dNsToPos, &b.dPosToNs, &b.dCflag, &b.dMask, &b.dMoff, &b.dMatchForm, &b.dNodes, &b.dTmpNodes, &b.dEndPosMap, &b.dTmpIdx,
-			&b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults }) b.devBytes += d->cap;
+			&b.dPacks, &b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults }) b.devBytes += d->cap;
 
 		BatchView& bv = b.bv;
 		bv.nChunks = (uint32_t)nC; bv.chars = b.dChars.as<uint16_t>(); bv.cls = b.dCls.as<uint8_t>(); bv.script = b.dScript.as<uint8_t>();
@@ -238,6 +258,7 @@ namespace kamd
 		w.matchBase = b.dMatchBase.as<uint32_t>(); w.matchForm = b.dMatchForm.as<uint32_t>();
 		w.nodeBase = b.dNodeBase.as<uint32_t>(); w.nodes = b.dNodes.as<DevNode>(); w.tmpNodes = b.dTmpNodes.as<DevNode>();
 		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>();
+		w.packBase = b.dPackBase.as<uint32_t>(); w.packs = b.dPacks.as<CandStatic>();
 		w.stateBase = b.dStateBase.as<uint64_t>(); w.states = b.dStates.as<DevState>();
 		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();
 		w.tokenBase = b.dTokenBase.as<uint64_t>(); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
@@ -273,17 +294,20 @@ namespace kamd
 		hipLaunchKernelGGL(k_dict_scan, dim3((nC + 3) / 4), dim3(256), 0, s, I.dview, b.bv, b.wv);
 		HIPCHECK(hipEventRecord(I.ev[1], s));
 		hipLaunchKernelGGL(k_build_lattice, dim3((nC + 63) / 64), dim3(64), 0, s, I.dview, b.bv, b.wv, sp);
+		hipLaunchKernelGGL(k_expand_cands, dim3(nC), dim3(64), 0, s, I.dview, b.bv, b.wv);
 		HIPCHECK(hipEventRecord(I.ev[2], s));
 		const uint32_t nGroups = 64u / (uint32_t)I.groupLanes;
 		const uint32_t blocks = std::min(I.persistBlocks, (nC + nGroups - 1) / nGroups);
 		I.bigScratch.ensure((size_t)blocks * nGroups * sizeof(GroupScratch));
 		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)sizeof(GroupScratch);
+		const uint32_t ldsBytes = searchKernelLdsBytes(I.groupLanes);
 		switch (I.groupLanes)
 		{
-		case 4: hipLaunchKernelGGL(k_best_path<4>, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
-		case 8: hipLaunchKernelGGL(k_best_path<8>, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
-		case 16: hipLaunchKernelGGL(k_best_path<16>, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
-		default: hipLaunchKernelGGL(k_best_path<64>, dim3(blocks), dim3(64), 0, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		case 4: hipLaunchKernelGGL(k_best_path<4>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		case 8: hipLaunchKernelGGL(k_best_path<8>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		case 32: hipLaunchKernelGGL(k_best_path<32>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		case 16: hipLaunchKernelGGL(k_best_path<16>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+		default: hipLaunchKernelGGL(k_best_path<64>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
 		}
 		HIPCHECK(hipEventRecord(I.ev[3], s));
 		HIPCHECK(hipGetLastError());

@@ -28,8 +28,16 @@ namespace kamd
 		uint16_t candCnt;
 		uint8_t len;         // form.size()
 		uint8_t numSpaces;
-		uint8_t flags;
-		uint8_t vowel, polar, formHash;
+		uint8_t flags;       // FormFlag
+		uint8_t flags2;      // FormFlag2
+		uint8_t vowelPolar;  // CondVowel | CondPolarity << 4 (kept for the dictionary dump; the new splitter does not test them)
+		uint8_t formHash;
+	};
+	enum FormFlag2 : uint8_t
+	{
+		// every candidate is a partial morpheme (split stem / chunked) and the form is not a lone chunked UNKNOWN-tag
+		// candidate: such nodes also get an unknown proper-noun reading (PathEvaluator.hpp:1258-1287)
+		FF2_ALL_PARTIAL = 1,
 	};
 	static_assert(sizeof(FormRec) == 16, "FormRec");
 
@@ -79,6 +87,16 @@ namespace kamd
 	// bits 13..15 of a left-feature mask (bits 0..12: feature.hpp featMask)
 	constexpr uint16_t LF_STR_SSC = 1u << 13, LF_PREV_ZSIOT = 1u << 14, LF_TAG_SSC = 1u << 15;
 
+	// Knlm edge hash (device lookup structure): bucket = 4 slots = 64 B; a lookup reads one bucket and, only when it
+	// is full, the next one.  Slot of edge (node, wid): value as in lmValues plus the log-likelihood the edge yields
+	// (child node's ll for value > 0, the leaf ll otherwise), so a hit needs no second load.
+	struct LmSlot { uint32_t node, wid; int32_t value; float ll; };
+	static_assert(sizeof(LmSlot) == 16, "LmSlot");
+	constexpr uint32_t LM_SLOT_EMPTY = 0xFFFFFFFFu;
+	struct LmRootRec { int32_t value; float ll; };      // root direct table entry: value 0 = unseen word
+	struct LmBackoff { int32_t lower; float gamma; };   // per node: what a miss needs
+	KAMD_HD uint32_t lmHashOf(uint32_t node, uint32_t wid) { uint32_t h = node * 0x9E3779B1u ^ (wid * 0x85EBCA77u); h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13; return h; }
+
 	struct LmNodeRec
 	{
 		uint32_t nextOff, numNexts;
@@ -119,6 +137,10 @@ namespace kamd
 		const uint32_t* lmKeys;       // sorted per node
 		const int32_t* lmValues;      // >0 relative child offset, <=0 leaf ll float bits
 		const int32_t* lmRoot;        // all_value_data: direct table [vocab]
+		const LmSlot* lmHash; uint32_t lmHashMask;   // bucket index mask (buckets of 4 slots)
+		const LmRootRec* lmRoot2;     // [vocab]
+		const LmBackoff* lmBackoff;   // [nLmNodes]
+		const void* unkPacks;         // device only: CandStatic[2] for the unknown-noun candidates NNG, NNP (PathEvaluator.hpp:1204-1206)
 	};
 
 	// Host-side owner.
@@ -143,6 +165,9 @@ namespace kamd
 		std::vector<uint32_t> lmKeys;
 		std::vector<int32_t> lmValues;
 		std::vector<int32_t> lmRoot;
+		std::vector<LmSlot> lmHash; uint32_t lmHashMask = 0;
+		std::vector<LmRootRec> lmRoot2;
+		std::vector<LmBackoff> lmBackoff;
 
 		ModelView view() const
 		{
@@ -153,6 +178,7 @@ namespace kamd
 			v.sbInfo = sbInfo.data(); v.morphPath = morphPath.data();
 			v.trie = trie.data(); v.trieKeys = trieKeys.data(); v.trieChild = trieChild.data(); v.trieRoot = trieRoot.data();
 			v.lmNodes = lmNodes.data(); v.lmKeys = lmKeys.data(); v.lmValues = lmValues.data(); v.lmRoot = lmRoot.data();
+			v.lmHash = lmHash.data(); v.lmHashMask = lmHashMask; v.lmRoot2 = lmRoot2.data(); v.lmBackoff = lmBackoff.data();
 			return v;
 		}
 

@@ -15,6 +15,7 @@
 // Memory-bound integer work: no MFMA; see DESIGN.md for the roofline accounting.
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
+#include "feature.hpp"
 
 namespace kamd
 {
@@ -166,7 +167,7 @@ namespace kamd
 		const uint32_t id = L.nOut++;
 		DevNode nn;
 		nn.form = form; nn.startPos = (uint16_t)s; nn.endPos = (uint16_t)e; nn.prev = (uint16_t)(id - (ms & 0xFFFF)); nn.sibling = 0;
-		nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = 0; nn.nflags = 0; nn.nPrev = 0;
+		nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = 0; nn.nflags = 0; nn.nPrev = 0; nn.packOff = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0;
 		L.out[id] = nn;
 		if (e >= nMap) return true;
 		const uint32_t me = L.endPosMap[e];
@@ -258,7 +259,7 @@ namespace kamd
 		for (uint32_t i = 0; i < nMap; ++i) L.endPosMap[i] = 0;     // first == second : empty
 		L.endPosMap[0] = 0 | (1u << 16);
 		{
-			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0;
+			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
 			L.out[0] = bos; L.nOut = 1;
 		}
 		const DevPattern* pat = B.patterns + B.patOff[chunk];
@@ -463,6 +464,21 @@ namespace kamd
 				if (nn.uformLen && str[nn.uformOff + nn.uformLen - 1] == u'.') nf |= NF_UFORM_ENDS_POINT;
 				nn.nPrev = (uint16_t)L.endPosMap[startNs];
 			}
+			if (nn.form != NOFORM)
+			{
+				const FormRec f = M.forms[nn.form];
+				nn.candCnt = f.candCnt; nn.fflags = f.flags; nn.flen = f.len;
+				if (f.flags2 & FF2_ALL_PARTIAL) nf |= NF_ALL_PARTIAL;
+			}
+			if (nn.uformLen)
+			{
+				uint16_t of = featMask(str + nn.uformOff, nn.uformLen) & 0x1FFF;
+				const uint32_t lp = nn.uformOff + nn.uformLen - 1;
+				const uint16_t c = str[lp];
+				const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
+				if (tag == T_SSC) of |= LF_STR_SSC;
+				nn.ownFeat = of;
+			}
 			nn.nflags = nf;
 			if (nn.prev) nn.prev = (uint16_t)(ni - inv[idx - nn.prev]);
 			if (nn.sibling)
@@ -478,7 +494,42 @@ namespace kamd
 			else if (ni + 1 == nConn) nn.startPos = nn.endPos = (uint16_t)n;
 			fin[ni] = nn;
 		}
+		{
+			uint32_t packTop = 0;
+			const uint32_t packCap = W.packBase[chunk + 1] - W.packBase[chunk];
+			for (uint32_t i = 0; i < nConn; ++i) { fin[i].packOff = packTop; packTop += fin[i].candCnt; }
+			if (packTop > packCap) { W.results[chunk].status = CS_ERR_NODE_OVERFLOW; return; }
+		}
 		W.nNodes[chunk] = nConn;
 		if (nConn <= 2) W.results[chunk].status = CS_NO_LATTICE;
+	}
+
+	// Static candidate records per lattice node (one block per chunk, one thread per node): resolves
+	// form -> candidate list -> morpheme record -> first LM id once, off the search kernel's dependent-load chain.
+	__global__ void __launch_bounds__(64) k_expand_cands(ModelView M, BatchView B, WorkView W)
+	{
+		const uint32_t chunk = blockIdx.x;
+		if (chunk >= B.nChunks) return;
+		if (W.results[chunk].status != CS_OK) return;
+		const uint32_t nBase = W.nodeBase[chunk], G = W.nNodes[chunk];
+		CandStatic* packs = W.packs + W.packBase[chunk];
+		for (uint32_t i = 1 + threadIdx.x; i + 1 < G; i += blockDim.x)
+		{
+			const DevNode nd = W.nodes[nBase + i];
+			if (nd.form == NOFORM) continue;
+			const uint32_t candOff = M.forms[nd.form].candOff;
+			for (uint32_t k = 0; k < nd.candCnt; ++k)
+			{
+				const uint32_t mid = M.formCand[candOff + k];
+				const uint4* mr = reinterpret_cast<const uint4*>(M.morphs + mid);
+				CandStatic o; const uint4 r0 = mr[0], r1 = mr[1];
+				o.m0 = Quad{ r0.x, r0.y, r0.z, r0.w }; o.m1 = Quad{ r1.x, r1.y, r1.z, r1.w };
+				const uint32_t flags = o.m1.y & 0xFFFF; const uint8_t tag = (uint8_t)o.m1.z;
+				const uint32_t firstWid = (flags & MF_SINGLE) ? o.m0.x : M.chunkLm[o.m0.z];
+				const uint32_t sbType = tag == T_SB ? M.sbInfo[mid] : 0;
+				o.x = Quad{ mid, firstWid, sbType, 0 };
+				packs[nd.packOff + k] = o;
+			}
+		}
 	}
 }

@@ -199,6 +199,37 @@ namespace kamd
 					dq.push_back(child);
 				}
 			}
+			// device lookup structures: edge hash, root table with the child's ll, per-node back-off record
+			m.lmBackoff.resize(nonLeaf);
+			for (size_t i = 0; i < nonLeaf; ++i) m.lmBackoff[i] = LmBackoff{ m.lmNodes[i].lower, m.lmNodes[i].gamma };
+			m.lmRoot2.assign(hd.vocab_size, LmRootRec{ 0, 0.f });
+			auto edgeLl = [&](uint32_t node, int32_t v) { return v > 0 ? m.lmNodes[node + v].ll : lmValueAsFloat(v); };
+			for (uint32_t i = 0; i < m.lmNodes[0].numNexts; ++i) m.lmRoot2[m.lmKeys[i]] = LmRootRec{ m.lmValues[i], edgeLl(0, m.lmValues[i]) };
+			{
+				const size_t nEdges = m.lmKeys.size() - m.lmNodes[0].numNexts;
+				size_t nBuckets = 1;
+				while (nBuckets * 2 < nEdges + 1) nBuckets <<= 1;   // 4 slots per bucket => load factor <= 0.5
+				m.lmHashMask = (uint32_t)(nBuckets - 1);
+				m.lmHash.assign(nBuckets * 4, LmSlot{ LM_SLOT_EMPTY, LM_SLOT_EMPTY, 0, 0.f });
+				for (uint32_t nd = 1; nd < nonLeaf; ++nd)
+				{
+					const LmNodeRec& r = m.lmNodes[nd];
+					for (uint32_t e = 0; e < r.numNexts; ++e)
+					{
+						const uint32_t wid = m.lmKeys[r.nextOff + e];
+						const int32_t v = m.lmValues[r.nextOff + e];
+						uint32_t b = lmHashOf(nd, wid) & m.lmHashMask;
+						for (;;)
+						{
+							LmSlot* s = &m.lmHash[(size_t)b * 4];
+							int k = 0;
+							while (k < 4 && s[k].node != LM_SLOT_EMPTY) ++k;
+							if (k < 4) { s[k] = LmSlot{ nd, wid, v, edgeLl(nd, v) }; break; }
+							b = (b + 1) & m.lmHashMask;
+						}
+					}
+				}
+			}
 			int32_t bos = 0;
 			lmProgressHost(m, bos, (uint32_t)hd.bos_id);  // Knlm.hpp:1148-1149 (links are still zero there too)
 			m.h.bosNode = bos;
@@ -404,8 +435,8 @@ namespace kamd
 			if (!f.candCnt) continue;
 			const uint32_t* cand = &m.formCand[f.candOff];
 			const MorphRec& c0 = m.morphs[cand[0]];
-			if (c0.vowel != CV_NONE) { uint8_t v = c0.vowel; for (uint32_t c = 0; c < f.candCnt; ++c) v = reduceVowel(v, m.morphs[cand[c]].vowel); f.vowel = v; }
-			if (c0.polar != CP_NONE) { uint8_t p = c0.polar; for (uint32_t c = 0; c < f.candCnt; ++c) p = (p == m.morphs[cand[c]].polar) ? p : (uint8_t)CP_NONE; f.polar = p; }
+			if (c0.vowel != CV_NONE) { uint8_t v = c0.vowel; for (uint32_t c = 0; c < f.candCnt; ++c) v = reduceVowel(v, m.morphs[cand[c]].vowel); f.vowelPolar = (uint8_t)((f.vowelPolar & 0xF0) | v); }
+			if (c0.polar != CP_NONE) { uint8_t p = c0.polar; for (uint32_t c = 0; c < f.candCnt; ++c) p = (p == m.morphs[cand[c]].polar) ? p : (uint8_t)CP_NONE; f.vowelPolar = (uint8_t)((f.vowelPolar & 0x0F) | (p << 4)); }
 			bool hasJ = false, anyFull = false;
 			for (uint32_t c = 0; c < f.candCnt; ++c)
 			{
@@ -413,6 +444,16 @@ namespace kamd
 				hasJ = hasJ || isJClass(t) || t == T_EC || t == T_EF;
 				const uint8_t ct = clearIrregular(t);
 				anyFull = anyFull || (ct != T_UNKNOWN && ct != T_P && ct != T_P + 1);
+			}
+			{
+				bool allPartial = true;
+				for (uint32_t c = 0; c < f.candCnt; ++c)
+				{
+					const MorphRec& mm = m.morphs[cand[c]];
+					if (!(mm.socket || !(mm.flags & MF_SINGLE))) allPartial = false;
+				}
+				if (f.candCnt == 1 && m.morphs[cand[0]].tag == T_UNKNOWN && m.morphs[cand[0]].nChunks) allPartial = false;
+				if (allPartial) f.flags2 |= FF2_ALL_PARTIAL;
 			}
 			if (hasJ) f.flags |= FF_HAS_JCLASS;
 			if (anyFull) f.flags |= FF_HAS_ANY_FULL;
@@ -537,7 +578,7 @@ namespace kamd
 		{
 			const FormRec& f = m.forms[i];
 			put32(f.len); put(m.formChars.data() + f.charOff, 2 * f.len);
-			put32(f.numSpaces); put8(f.vowel); put8(f.polar); put8(f.formHash); put8(f.flags & 15); put16(0);
+			put32(f.numSpaces); put8(f.vowelPolar & 0xF); put8(f.vowelPolar >> 4); put8(f.formHash); put8(f.flags & 15); put16(0);
 			put32(f.candCnt);
 			for (uint32_t c = 0; c < f.candCnt; ++c) put32(m.formCand[f.candOff + c]);
 		}

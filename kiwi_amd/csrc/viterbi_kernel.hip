@@ -10,6 +10,11 @@
 // candidates -- are scored G at a time, one per lane: side terms + the Knlm walk.  That puts 64 independent
 // dependent-load chains in flight per wave instead of ~5.
 //
+// Dependent-load levels per node are kept small: node facts come precomputed from k_build_lattice and are
+// prefetched one node ahead, per-node state ranges live in an LDS ring, the Knlm walk uses a bucketed edge hash
+// (one 64-byte bucket + the node's back-off record per level, the edge's log-likelihood stored in the slot),
+// and pruning never re-reads states: scores are staged in LDS and losers are only *marked* dead in HBM.
+//
 // De-duplication per (candidate, LM state, root, special state) -- the reference's per-morpheme hash
 // container (src/BestPathContainer.hpp:279-483) -- works on the scored items staged in LDS: an item is the
 // representative of its key iff no earlier item of the same candidate carries the key; the winner of a key is
@@ -31,27 +36,133 @@
 namespace kamd
 {
 	constexpr uint64_t KINVALID = ~0ull;
-
-	struct CandInfo   // per candidate of the current batch (LDS)
-	{
-		MorphRec rec; uint32_t morph; uint32_t qOff; uint32_t R; float additional;
-		uint16_t leftFeat; uint8_t prevFlags, sbType; uint8_t ruleBits; uint8_t pad[3];
-	};
+#ifdef KAMD_PROFILE
+	__device__ unsigned long long gProf[16];
+#define PROF(X, i) { const uint64_t t_ = wall_clock64(); (X).prof[i] += t_ - (X).profT; (X).profT = t_; }
+#else
+#define PROF(X, i)
+#endif
+	constexpr uint32_t SCAP = 32;    // new states of one node whose scores are staged in LDS for pruning
+	constexpr uint32_t RING = 32;    // most recent nodes whose state ranges are kept in LDS
+	enum StageBits : uint8_t { SB_SLOT_MASK = 0x1F, SB_DEAD = 0x20, SB_MORPH_SOCKET = 0x40, SB_STATE_SOCKET = 0x80 };
 	enum { RB_POSITIVE_E = 1, RB_SN_POINT = 2 };
 
-	__device__ __forceinline__ float asFloat(int32_t v) { return __int_as_float(v); }
+	// All LDS of the kernel is one dynamic array; per-group slices are addressed by byte offsets so that every access
+	// keeps its address space (ds_* instructions) even inside non-inlined helpers.
+	extern __shared__ __align__(16) uint8_t kSmem[];
 
-	__device__ __forceinline__ bool lmSearch(const ModelView& M, uint32_t nextOff, uint32_t numNexts, uint32_t key, int32_t& v)
+	template<int G>
+	struct Lay
 	{
-		const uint32_t* k = M.lmKeys + nextOff;
-		uint32_t lo = 0, hi = numNexts;
-		while (lo < hi)
+		static constexpr uint32_t MAXC = G < 8 ? G : 8;            // candidates per batch
+		static constexpr uint32_t KEY = 0;                          // u64[QCAP]
+		static constexpr uint32_t SCORE = KEY + 8 * QCAP;           // f32[QCAP]
+		static constexpr uint32_t FCS = SCORE + 4 * QCAP;
+		static constexpr uint32_t CAND = FCS + 4 * QCAP;           // 64-byte packed candidate records [MAXC]
+		static constexpr uint32_t STSCORE = CAND + 64 * MAXC;       // f32[SCAP]
+		static constexpr uint32_t STBITS = STSCORE + 4 * SCAP;      // u8[SCAP]
+		static constexpr uint32_t RBEG = STBITS + SCAP;             // u32[RING]
+		static constexpr uint32_t REND = RBEG + 4 * RING;
+		static constexpr uint32_t RLIVE = REND + 4 * RING;          // u16[RING]
+		static constexpr uint32_t SIZE = (RLIVE + 2 * RING + 15) & ~15u;
+		static constexpr uint32_t LB = (64 / G) * SIZE;              // f32[2*T_MAX+1], shared by the groups
+		static constexpr uint32_t TOTAL = LB + 4 * (2 * T_MAX + 1);
+	};
+	void searchKernelProfile(unsigned long long* out16, bool reset)
+	{
+#ifdef KAMD_PROFILE
+		(void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(gProf), 16 * sizeof(unsigned long long));
+		if (reset) { unsigned long long z[16] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof(z)); }
+#else
+		for (int i = 0; i < 16; ++i) out16[i] = 0;
+		(void)reset;
+#endif
+	}
+	uint32_t searchKernelLdsBytes(int G)
+	{
+		switch (G) { case 4: return Lay<4>::TOTAL; case 8: return Lay<8>::TOTAL; case 16: return Lay<16>::TOTAL; case 32: return Lay<32>::TOTAL; default: return Lay<64>::TOTAL; }
+	}
+
+	// candidate record as the scoring lanes see it (registers; 64 bytes in LDS)
+	struct Cand
+	{
+		uint32_t lmId, lastSeqId, chunkOff; float userScore;     // MorphRec dwords 0..3
+		int32_t combinedId; uint32_t flagsFeat, tagw, cntw;       // MorphRec dwords 4..7
+		uint32_t morph, qOff, R; float additional;
+		uint32_t sbw;        // sbType | firstWid of a chunked candidate is in firstWid
+		uint32_t ruleBits;
+		uint32_t firstWid;   // first LM id fed (lmId, or the first chunk's for chunked candidates)
+		__device__ __forceinline__ uint32_t flags() const { return flagsFeat & 0xFFFF; }
+		__device__ __forceinline__ uint8_t tag() const { return (uint8_t)tagw; }
+		__device__ __forceinline__ uint8_t vowel() const { return (uint8_t)(tagw >> 8); }
+		__device__ __forceinline__ uint8_t polar() const { return (uint8_t)(tagw >> 16); }
+		__device__ __forceinline__ uint8_t socket() const { return (uint8_t)(tagw >> 24); }
+		__device__ __forceinline__ uint32_t nChunks() const { return cntw & 0xFF; }
+		__device__ __forceinline__ uint8_t senseId() const { return (uint8_t)(cntw >> 8); }
+		__device__ __forceinline__ uint8_t special() const { return (uint8_t)(cntw >> 24); }
+		// the device copy of the morpheme table carries, in `feat` / `prevFlags`, what a PATH ending in the morpheme exposes
+		// to its successor (FlatModel::morphPath), not the morpheme's own form features
+		__device__ __forceinline__ uint16_t leftFeat() const { return (uint16_t)(flagsFeat >> 16); }
+		__device__ __forceinline__ uint8_t prevFlags() const { return (uint8_t)(cntw >> 16); }
+		__device__ __forceinline__ uint8_t sbType() const { return (uint8_t)sbw; }
+		__device__ __forceinline__ bool single() const { return flags() & MF_SINGLE; }
+		__device__ __forceinline__ bool quoteOrBullet() const { const uint8_t s = special(); return sbType() || s == 0 || s == 1 || s == 3 || s == 4; }
+	};
+	__device__ __forceinline__ Cand loadCand(uint32_t ldsOff)
+	{
+		const uint4* p = reinterpret_cast<const uint4*>(kSmem + ldsOff);
+		const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+		Cand o;
+		o.lmId = a.x; o.lastSeqId = a.y; o.chunkOff = a.z; o.userScore = __uint_as_float(a.w);
+		o.combinedId = (int32_t)b.x; o.flagsFeat = b.y; o.tagw = b.z; o.cntw = b.w;
+		o.morph = c.x; o.qOff = c.y; o.R = c.z; o.additional = __uint_as_float(c.w);
+		o.sbw = d.x; o.ruleBits = d.y; o.firstWid = d.z;
+		return o;
+	}
+
+	// hot quad of a state (first 16 bytes of DevState) as registers
+	struct Hot
+	{
+		int32_t lmNode; float accScore; uint32_t w2, w3;
+		__device__ __forceinline__ uint16_t leftFeat() const { return (uint16_t)w2; }
+		__device__ __forceinline__ uint8_t rootId() const { return (uint8_t)(w2 >> 16); }
+		__device__ __forceinline__ uint8_t spState() const { return (uint8_t)(w2 >> 24); }
+		__device__ __forceinline__ uint8_t socket() const { return (uint8_t)w3; }
+		__device__ __forceinline__ uint8_t prevFlags() const { return (uint8_t)(w3 >> 8); }
+		__device__ __forceinline__ bool dead() const { return (w3 >> 16) & 0xFF; }
+		__device__ __forceinline__ uint8_t ownKind() const { return (uint8_t)(w3 >> 24); }
+	};
+	__device__ __forceinline__ Hot loadHot(const DevState* st, uint32_t i)
+	{
+		const uint4 a = *reinterpret_cast<const uint4*>(st + i);
+		Hot h; h.lmNode = (int32_t)a.x; h.accScore = __uint_as_float(a.y); h.w2 = a.z; h.w3 = a.w;
+		return h;
+	}
+	__device__ __forceinline__ void storeState(DevState* st, uint32_t i, int32_t lmNode, float acc, float typo, uint32_t wid, uint16_t leftFeat, uint8_t rootId, uint8_t sp,
+		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode)
+	{
+		uint4* p = reinterpret_cast<uint4*>(st + i);
+		p[0] = make_uint4((uint32_t)lmNode, __float_as_uint(acc), (uint32_t)leftFeat | ((uint32_t)rootId << 16) | ((uint32_t)sp << 24),
+			(uint32_t)socket | ((uint32_t)prevFlags << 8) | ((uint32_t)ownKind << 24));
+		p[1] = make_uint4(__float_as_uint(typo), wid, parent, morph);
+		p[2] = make_uint4(__float_as_uint(fcs), (uint32_t)nodeId | ((uint32_t)ownNode << 16), 0, 0);
+	}
+
+	// edge (node, wid) of the Knlm trie through the bucketed hash built at load time (flat_model.hpp LmSlot)
+	__device__ __forceinline__ bool lmLookup(const ModelView& M, uint32_t node, uint32_t wid, int32_t& v, float& ll)
+	{
+		uint32_t b = lmHashOf(node, wid) & M.lmHashMask;
+		for (;;)
 		{
-			const uint32_t mid = (lo + hi) >> 1;
-			if (k[mid] < key) lo = mid + 1; else hi = mid;
+			const uint4* p = reinterpret_cast<const uint4*>(M.lmHash + (size_t)b * 4);
+			const uint4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+			if (s0.x == node && s0.y == wid) { v = (int32_t)s0.z; ll = __uint_as_float(s0.w); return true; }
+			if (s1.x == node && s1.y == wid) { v = (int32_t)s1.z; ll = __uint_as_float(s1.w); return true; }
+			if (s2.x == node && s2.y == wid) { v = (int32_t)s2.z; ll = __uint_as_float(s2.w); return true; }
+			if (s3.x == node && s3.y == wid) { v = (int32_t)s3.z; ll = __uint_as_float(s3.w); return true; }
+			if (s3.x == LM_SLOT_EMPTY) return false;   // slots fill front to back: a free last slot means the bucket never overflowed
+			b = (b + 1) & M.lmHashMask;
 		}
-		if (lo < numNexts && k[lo] == key) { v = M.lmValues[nextOff + lo]; return true; }
-		return false;
 	}
 
 	// KnLangModel::progress (src/Knlm.cpp:44-130); float additions in the same order
@@ -60,30 +171,32 @@ namespace kamd
 		float acc = 0;
 		for (;;)
 		{
-			int32_t v;
+			int32_t v; float ll;
 			if (node == 0)
 			{
-				v = M.lmRoot[next];
-				if (v == 0) return acc + M.h.unkLl;
+				const LmRootRec r = M.lmRoot2[next];
+				if (r.value == 0) return acc + M.h.unkLl;
+				v = r.value; ll = r.ll;
 			}
 			else
 			{
-				const LmNodeRec nd = M.lmNodes[node];
-				if (!lmSearch(M, nd.nextOff, nd.numNexts, next, v)) { acc += nd.gamma; node += nd.lower; continue; }
+				const LmBackoff bo = M.lmBackoff[node];      // independent of the bucket load: both are in flight together
+				if (!lmLookup(M, (uint32_t)node, next, v, ll)) { acc += bo.gamma; node += bo.lower; continue; }
 			}
-			if (v > 0) { node += v; return acc + M.lmNodes[node].ll; }
+			if (v > 0) { node += v; return acc + ll; }
+			// leaf: the new state is the longest suffix context that continues with `next` (Knlm.cpp:96-128)
 			int32_t cur = node;
 			for (;;)
 			{
-				const int32_t lower = M.lmNodes[cur].lower;
+				const int32_t lower = M.lmBackoff[cur].lower;
 				if (!lower) break;
 				cur += lower;
-				const LmNodeRec nd = M.lmNodes[cur];
-				int32_t lv;
-				if (lmSearch(M, nd.nextOff, nd.numNexts, next, lv) && lv > 0) { node = cur + lv; return acc + asFloat(v); }
+				int32_t lv; float l2;
+				if (cur == 0) { lv = M.lmRoot2[next].value; if (lv > 0) { node = lv; return acc + ll; } }
+				else if (lmLookup(M, (uint32_t)cur, next, lv, l2) && lv > 0) { node = cur + lv; return acc + ll; }
 			}
 			node = 0;
-			return acc + asFloat(v);
+			return acc + ll;
 		}
 	}
 
@@ -94,38 +207,33 @@ namespace kamd
 	}
 
 	// RuleBasedScorer::operator() (PathEvaluator.hpp:111-181)
-	__device__ __forceinline__ float ruleScore(const CandInfo& c, uint8_t prevFlags, uint8_t sp)
+	__device__ __forceinline__ float ruleScore(const Cand& c, uint8_t prevFlags, uint8_t sp)
 	{
 		float a = 0;
-		const uint16_t fl = c.rec.flags;
+		const uint32_t fl = c.flags();
 		if ((fl & MF_VOWEL_E) && (prevFlags & PF_IRREGULAR)) a -= 10;
 		if ((fl & MF_INF_J) && (prevFlags & PF_INFLECTENDA_NP)) a -= 5;
 		if ((fl & MF_BAD_PAIR_OF_L) && (prevFlags & PF_VERB_L)) a -= 7;
 		if ((c.ruleBits & RB_POSITIVE_E) && !(prevFlags & PF_POSITIVE_VERB)) a -= 100;
 		if ((fl & MF_CONTRACTABLE_E) && (prevFlags & PF_VERB_VOWEL)) a -= 3;
-		if (c.rec.polar == CP_NON_ADJ && (prevFlags & PF_VA_OR_XSA)) a -= 10;
-		const uint8_t special = c.rec.special;
+		if (c.polar() == CP_NON_ADJ && (prevFlags & PF_VA_OR_XSA)) a -= 10;
+		const uint8_t special = c.special();
 		if (special <= 2) { if (special != (sp & 1)) a -= 2; }
 		else if (special <= 5) { if ((uint8_t)(special - 3) != ((sp >> 1) & 1)) a -= 2; }
-		if (c.sbType == 5) a -= 5;
-		if (c.sbType && (prevFlags & PF_E_NOT_EF)) a -= 10;
-		if (c.sbType && (sp >> 2) == hashSb(c.sbType, c.rec.senseId)) a += 3;
+		const uint8_t sb = c.sbType();
+		if (sb == 5) a -= 5;
+		if (sb && (prevFlags & PF_E_NOT_EF)) a -= 10;
+		if (sb && (sp >> 2) == hashSb(sb, c.senseId())) a += 3;
 		if ((c.ruleBits & RB_SN_POINT) && (prevFlags & PF_UNK_EF_SF)) a -= 5;
 		return a;
 	}
 
-	__device__ __forceinline__ uint8_t nextSpState(const CandInfo& c, uint8_t sp)   // PathEvaluator.hpp:222-231
+	__device__ __forceinline__ uint8_t nextSpState(const Cand& c, uint8_t sp)   // PathEvaluator.hpp:222-231
 	{
-		const uint8_t special = c.rec.special;
+		const uint8_t special = c.special();
 		if (special == 0) sp |= 1; else if (special == 1) sp &= ~1; else if (special == 3) sp |= 2; else if (special == 4) sp &= ~2;
-		if (c.sbType) sp = (uint8_t)((sp & 3) | (hashSb(c.sbType, (uint32_t)c.rec.senseId + 1) << 2));
+		if (c.sbType()) sp = (uint8_t)((sp & 3) | (hashSb(c.sbType(), (uint32_t)c.senseId() + 1) << 2));
 		return sp;
-	}
-
-	__device__ __forceinline__ bool isQuoteOrBullet(const CandInfo& c)
-	{
-		const uint8_t s = c.rec.special;
-		return c.sbType || s == 0 || s == 1 || s == 3 || s == 4;
 	}
 
 	// ---------------------------------------------------------------------------------------------------
@@ -133,37 +241,62 @@ namespace kamd
 	struct GroupCtx
 	{
 		static constexpr uint64_t GMASK = G == 64 ? ~0ull : ((1ull << G) - 1);
-		const ModelView* M; const SearchParams* P; const float* lb;
-		uint32_t gl, gshift;
+		const ModelView* M; const SearchParams* P;
+		uint32_t gl, gshift, lds;       // lane in group, group's first lane, byte offset of the group's LDS slice
 		const DevNode* nodes; uint32_t Gn;
 		const uint16_t* str; const uint8_t* cls;
 		DevState* st; uint32_t stCap, stTop;
-		uint32_t* nodeStOff; uint32_t* nodeStCnt;
+		uint32_t* nodeStOff; uint32_t* nodeStCnt; uint16_t* nodeLive;   // HBM copies (far-back lookups, end node)
 		const uint8_t* uniq; uint32_t nUniq;
-		bool overflow, pairOverflow;
-		uint64_t* qKey; float* qScore; float* qFcs; CandInfo* ci;   // LDS, this group's slices
+		bool overflow, pairOverflow, stageOverflow;
 		GroupScratch* scratch;
+#ifdef KAMD_PROFILE
+		uint64_t prof[8]; uint64_t profT;
+#endif
 
 		__device__ __forceinline__ uint64_t ballot(bool p) const { return (__ballot(p) >> gshift) & GMASK; }
 		__device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0; }
 		__device__ __forceinline__ uint32_t prefix(uint64_t b) const { return __popcll(b & ((1ull << gl) - 1)); }
 		template<class T> __device__ __forceinline__ T bcast(T v, int srcLane) const { return __shfl(v, srcLane, G); }
+		// LDS accessors (address space preserved)
+		__device__ __forceinline__ uint64_t* qKey() const { return reinterpret_cast<uint64_t*>(kSmem + lds + Lay<G>::KEY); }
+		__device__ __forceinline__ float* qScore() const { return reinterpret_cast<float*>(kSmem + lds + Lay<G>::SCORE); }
+		__device__ __forceinline__ float* qFcs() const { return reinterpret_cast<float*>(kSmem + lds + Lay<G>::FCS); }
+		__device__ __forceinline__ uint32_t candOff(uint32_t k) const { return lds + Lay<G>::CAND + 64 * k; }
+		__device__ __forceinline__ uint32_t candQOff(uint32_t k) const { return reinterpret_cast<const uint32_t*>(kSmem + candOff(k))[9]; }
+		__device__ __forceinline__ float* stScore() const { return reinterpret_cast<float*>(kSmem + lds + Lay<G>::STSCORE); }
+		__device__ __forceinline__ uint8_t* stBits() const { return kSmem + lds + Lay<G>::STBITS; }
+		__device__ __forceinline__ uint32_t* ringBeg() const { return reinterpret_cast<uint32_t*>(kSmem + lds + Lay<G>::RBEG); }
+		__device__ __forceinline__ uint32_t* ringEnd() const { return reinterpret_cast<uint32_t*>(kSmem + lds + Lay<G>::REND); }
+		__device__ __forceinline__ uint16_t* ringLive() const { return reinterpret_cast<uint16_t*>(kSmem + lds + Lay<G>::RLIVE); }
+		__device__ __forceinline__ const float* lb() const { return reinterpret_cast<const float*>(kSmem + Lay<G>::LB); }
 	};
 
-	struct NodeEnv { uint32_t pBeg, nP; bool spaceBefore, leftBoundary, formStartsA, uformEndsPoint; };
+	struct NodeEnv { uint32_t pBeg, nP, nLive; uint32_t nodeIdx, nodeStart; uint8_t nflags, fflags; };
 
-	// One batch of regular candidates ci[0..nC) against the incoming paths [pBeg, pBeg+nP): Qtot work items.
+	// records a freshly written state of the current node for pruning / reachability (LDS; falls back to HBM when a node
+	// produces more than SCAP states)
+	template<int G>
+	__device__ __forceinline__ void stageState(GroupCtx<G>& X, uint32_t rel, float score, uint8_t rootId, bool morphSocket, bool stateSocket)
+	{
+		if (rel < SCAP)
+		{
+			X.stScore()[rel] = score;
+			X.stBits()[rel] = (uint8_t)((rootId == COMMON_ROOT ? 0 : rootId + 1u) | (morphSocket ? SB_MORPH_SOCKET : 0) | (stateSocket ? SB_STATE_SOCKET : 0));
+		}
+		else X.stageOverflow = true;
+	}
+
+	// One batch of regular candidates (packed records in LDS) against the incoming paths [pBeg, pBeg+nP): Qtot work items.
 	// mode: 0 small container, 1 medium (4 hash buckets), 2 large (PathEvaluator.hpp:447-466).
 	template<int G>
-	__device__ void evalBatch(GroupCtx<G>& X, uint32_t nC, uint32_t Qtot, uint32_t nodeIdx, const NodeEnv& E,
-		float ignoreCondScore, uint8_t ownKind, uint16_t ownFeat, int mode)
+	__device__ __noinline__ void evalBatch(GroupCtx<G>& X, uint32_t nC, uint32_t Qtot, const NodeEnv& E, float ignoreCondScore, uint8_t ownKind, uint16_t ownFeat, int mode)
 	{
 		const ModelView& M = *X.M;
 		const bool big = Qtot > QCAP;
-		uint64_t* qKey = big ? X.scratch->key : X.qKey;
-		float* qScore = big ? X.scratch->score : X.qScore;
-		float* qFcs = big ? X.scratch->fcs : X.qFcs;
 		const uint32_t pBeg = E.pBeg;
+		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
+		PROF(X, 1)
 
 		// ---- scoring pass: one work item per lane -------------------------------------------------------
 		for (uint32_t qb = 0; qb < Qtot; qb += G)
@@ -171,63 +304,66 @@ namespace kamd
 			const uint32_t q = qb + X.gl;
 			bool valid = q < Qtot;
 			uint32_t k = 0;
-			if (valid) { while (k + 1 < nC && q >= X.ci[k + 1].qOff) ++k; }
+			if (valid) { while (k + 1 < nC && q >= X.candQOff(k + 1)) ++k; }
 			float cand = 0, firstChunk = 0; int32_t lmNode = 0; uint8_t rootKey = 0, sp = 0;
 			if (valid)
 			{
-				const CandInfo& c = X.ci[k];
-				const MorphRec& cm = c.rec;
+				const Cand c = loadCand(X.candOff(k));
 				const uint32_t local = q - c.qOff;
 				const uint32_t p = local / c.R, r = local % c.R;
-				const DevState ps = X.st[pBeg + p];
-				const bool single = cm.flags & MF_SINGLE;
-				uint32_t firstWid = single ? cm.lmId : M.chunkLm[cm.chunkOff];
+				const Hot ps = loadHot(X.st, pBeg + p);
+				const bool single = c.single();
+				const uint8_t ctag = c.tag(), csock = c.socket();
+				uint32_t firstWid = c.firstWid; bool widReplaced = false;
 				do
 				{
-					if ((ps.leftFeat & LF_PREV_ZSIOT) && (!isNNClass(cm.tag) || E.spaceBefore)) { valid = false; break; }
+					if (ps.dead()) { valid = false; break; }
+					if ((ps.leftFeat() & LF_PREV_ZSIOT) && (!isNNClass(ctag) || spaceBefore)) { valid = false; break; }
 					cand = ps.accScore + c.additional;
 					firstChunk = c.additional;
-					if (ps.socket)
+					if (ps.socket())
 					{
-						if (ps.socket != cm.socket || single) { valid = false; break; }
-						if (E.spaceBefore)
+						if (ps.socket() != csock || single) { valid = false; break; }
+						if (spaceBefore)
 						{
 							if (X.P->spaceTol > 0) cand -= X.P->spacePenalty; else { valid = false; break; }
 						}
 					}
-					if (cm.socket && !single)
+					if (csock && !single)
 					{
 						// the reference keeps the combined word id of the latest matching split stem for all later predecessors
 						// (PathEvaluator.hpp:578-591: `firstWid` is assigned inside the loop and never reset)
 						for (int32_t pp = (int32_t)p; pp >= 0; --pp)
 						{
-							const DevState qs = X.st[pBeg + pp];
-							if (!qs.socket || qs.socket != cm.socket) continue;
-							if ((qs.leftFeat & LF_PREV_ZSIOT) && (!isNNClass(cm.tag) || E.spaceBefore)) continue;
-							if (E.spaceBefore && !(X.P->spaceTol > 0)) continue;
-							firstWid = M.morphs[M.morphs[qs.wid].combinedId].lmId;
+							const Hot qs = loadHot(X.st, pBeg + pp);
+							if (qs.dead() || !qs.socket() || qs.socket() != csock) continue;
+							if ((qs.leftFeat() & LF_PREV_ZSIOT) && (!isNNClass(ctag) || spaceBefore)) continue;
+							if (spaceBefore && !(X.P->spaceTol > 0)) continue;
+							firstWid = M.morphs[M.morphs[X.st[pBeg + pp].wid].combinedId].lmId; widReplaced = true;
 							break;
 						}
 					}
 					// FormEvaluator (PathEvaluator.hpp:293-310)
-					if (!(ps.leftFeat & (LF_STR_SSC | LF_TAG_SSC)))
+					if (!(ps.leftFeat() & (LF_STR_SSC | LF_TAG_SSC)))
 					{
-						const bool ok = featTest(ps.leftFeat & 0x1FFF, cm.vowel, cm.polar);
+						const bool ok = featTest(ps.leftFeat() & 0x1FFF, c.vowel(), c.polar());
 						if (ignoreCondScore != 0) cand += ok ? 0 : ignoreCondScore;
 						else if (!ok) { valid = false; break; }
 					}
 					lmNode = ps.lmNode;
-					if (!(cm.socket && single))
+					if (!(csock && single))
 					{
-						if (M.morphs[firstWid].tag == T_P) { valid = false; break; }
+						// prohibit <v> without <chunk> (PathEvaluator.hpp:604-608): static per candidate unless the word id was replaced above
+						if (widReplaced ? (M.morphs[firstWid].tag == T_P) : ((c.flags() & MF_FIRST_WID_IS_P) != 0)) { valid = false; break; }
 						float ll = lmProgress(M, lmNode, firstWid);
 						cand += ll; firstChunk += ll;
 						if (!single)
 						{
-							for (uint32_t ch = 1; ch < cm.nChunks; ++ch)
+							const uint32_t nCh = c.nChunks();
+							for (uint32_t ch = 1; ch < nCh; ++ch)
 							{
-								const uint32_t wid = M.chunkLm[cm.chunkOff + ch];
-								if (M.morphs[wid].tag == T_P) { valid = false; break; }
+								const uint32_t wid = M.chunkLm[c.chunkOff + ch];
+								if ((c.flags() & MF_ANY_REST_WID_IS_P) && M.morphs[wid].tag == T_P) { valid = false; break; }
 								ll = lmProgress(M, lmNode, wid);
 								cand += ll;
 							}
@@ -235,14 +371,14 @@ namespace kamd
 						}
 					}
 					// insertToPathContainer (PathEvaluator.hpp:193-251)
-					sp = ps.spState;
-					rootKey = ps.rootId;
-					if (isQuoteOrBullet(c))
+					sp = ps.spState();
+					rootKey = ps.rootId();
+					if (c.quoteOrBullet())
 					{
-						if (ps.rootId == COMMON_ROOT) sp = X.uniq[r];
+						if (rootKey == COMMON_ROOT) sp = X.uniq[r];
 						else if (r != 0) { valid = false; break; }   // a path already bound to a root is inserted once
 					}
-					const float rs = ruleScore(c, ps.prevFlags, sp);
+					const float rs = ruleScore(c, ps.prevFlags(), sp);
 					cand = cand + rs; firstChunk = firstChunk + rs;
 					sp = nextSpState(c, sp);
 				} while (0);
@@ -250,11 +386,13 @@ namespace kamd
 			if (q < Qtot)
 			{
 				// key: LM node | new special state | previous root | candidate ; r is recoverable from q
-				qKey[q] = valid ? ((uint64_t)(uint32_t)lmNode | ((uint64_t)sp << 32) | ((uint64_t)rootKey << 40) | ((uint64_t)k << 48)) : KINVALID;
-				qScore[q] = cand; qFcs[q] = firstChunk;
+				const uint64_t key = valid ? ((uint64_t)(uint32_t)lmNode | ((uint64_t)sp << 32) | ((uint64_t)rootKey << 40) | ((uint64_t)k << 48)) : KINVALID;
+				if (big) { X.scratch->key[q] = key; X.scratch->score[q] = cand; X.scratch->fcs[q] = firstChunk; }
+				else { X.qKey()[q] = key; X.qScore()[q] = cand; X.qFcs()[q] = firstChunk; }
 			}
 		}
 		__threadfence_block();
+		PROF(X, 2)
 
 		// ---- emission pass: representatives in container iteration order, each carrying its key's winner ----
 		const int nBuckets = mode == 1 ? 4 : 1;
@@ -265,18 +403,19 @@ namespace kamd
 			{
 				const uint32_t q = qb + X.gl;
 				bool rep = false; uint32_t qw = q; uint64_t key = KINVALID; uint32_t k = 0;
-				if (q < Qtot) key = qKey[q];
+				if (q < Qtot) key = big ? X.scratch->key[q] : X.qKey()[q];
 				if (key != KINVALID)
 				{
 					k = (uint32_t)(key >> 48);
-					const uint32_t lo = X.ci[k].qOff, hi = (k + 1 < nC) ? X.ci[k + 1].qOff : Qtot;
+					const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
 					rep = true;
 					float best = -INFINITY; bool haveBest = false;
 					for (uint32_t j = lo; j < hi; ++j)
 					{
-						if (qKey[j] != key) continue;
+						const uint64_t kj = big ? X.scratch->key[j] : X.qKey()[j];
+						if (kj != key) continue;
 						if (j < q) { rep = false; break; }
-						const float s = qScore[j];
+						const float s = big ? X.scratch->score[j] : X.qScore()[j];
 						if (!haveBest || s > best) { best = s; qw = j; haveBest = true; }
 					}
 					if (rep && mode == 1)
@@ -297,23 +436,22 @@ namespace kamd
 					const uint32_t pos = X.stTop + X.prefix(kbal);
 					if (pos < X.stCap)
 					{
-						const CandInfo& c = X.ci[k];
-						const uint64_t wkey = qKey[qw];
+						const Cand c = loadCand(X.candOff(k));
+						const uint64_t wkey = big ? X.scratch->key[qw] : X.qKey()[qw];
+						const float wscore = big ? X.scratch->score[qw] : X.qScore()[qw];
+						const float wfcs = big ? X.scratch->fcs[qw] : X.qFcs()[qw];
 						const uint32_t local = qw - c.qOff;
 						const uint32_t parent = pBeg + local / c.R, r = local % c.R;
-						const bool single = c.rec.flags & MF_SINGLE;
+						const float wtypo = X.st[parent].accTypoCost + 0.f;
+						const bool single = c.single();
 						const uint8_t rootKey = (uint8_t)(wkey >> 40);
-						DevState ns;
-						ns.lmNode = (int32_t)(uint32_t)wkey; ns.accScore = qScore[qw]; ns.firstChunkScore = qFcs[qw];
-						ns.accTypoCost = X.st[parent].accTypoCost + 0.f;
-						ns.parent = parent; ns.morph = c.morph; ns.wid = c.rec.lastSeqId; ns.nodeId = (uint16_t)nodeIdx;
-						ns.rootId = (isQuoteOrBullet(c) && rootKey == COMMON_ROOT) ? (uint8_t)r : rootKey;
-						ns.spState = (uint8_t)(wkey >> 32);
-						ns.socket = single ? c.rec.socket : 0;
-						ns.ownKind = single ? ownKind : 0; ns.ownNode = (single && ownKind) ? (uint16_t)nodeIdx : 0;
-						ns.leftFeat = (single && ownKind) ? (uint16_t)(ownFeat | (c.leftFeat & (LF_TAG_SSC | LF_PREV_ZSIOT))) : c.leftFeat;
-						ns.prevFlags = c.prevFlags; ns.pad = 0;
-						X.st[pos] = ns;
+						const uint8_t newRoot = (c.quoteOrBullet() && rootKey == COMMON_ROOT) ? (uint8_t)r : rootKey;
+						const uint8_t stSocket = single ? c.socket() : 0;
+						const bool own = single && ownKind;
+						const uint16_t lf = own ? (uint16_t)(ownFeat | (c.leftFeat() & (LF_TAG_SSC | LF_PREV_ZSIOT))) : c.leftFeat();
+						storeState(X.st, pos, (int32_t)(uint32_t)wkey, wscore, wtypo, c.lastSeqId, lf, newRoot, (uint8_t)(wkey >> 32), stSocket, c.prevFlags(),
+							own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0);
+						stageState<G>(X, pos - E.nodeStart, wscore, newRoot, c.socket() != 0, stSocket != 0);
 					}
 					else X.overflow = true;
 				}
@@ -322,28 +460,31 @@ namespace kamd
 			}
 		}
 		X.overflow = X.any(X.overflow);
+		X.stageOverflow = X.any(X.stageOverflow);
 		if (X.stTop > X.stCap) X.stTop = X.stCap;
 		__threadfence_block();
+		PROF(X, 3)
 	}
 
 	// z_coda / z_siot shortcut (PathEvaluator.hpp:389-432): copies of the qualifying incoming paths
 	template<int G>
-	__device__ void evalZShortcut(GroupCtx<G>& X, uint32_t zMorph, uint32_t nodeIdx, const NodeEnv& E)
+	__device__ __noinline__ void evalZShortcut(GroupCtx<G>& X, uint32_t zMorph, const NodeEnv& E)
 	{
 		const ModelView& M = *X.M;
 		const MorphRec cm = M.morphs[zMorph];
 		const uint32_t newMorph = cm.lmId;
-		const uint32_t mp = M.morphPath[newMorph];
-		const uint16_t lfMorph = (uint16_t)mp;
+		const MorphRec nm = M.morphs[newMorph];
+		const bool newMorphSocket = nm.socket != 0;
+		const uint16_t lfMorph = nm.feat;   // path-side value in the device table
 		for (uint32_t pb = 0; pb < E.nP; pb += G)
 		{
 			const uint32_t p = pb + X.gl;
-			bool keep = false; DevState ns;
+			bool keep = false; DevState ns{};
 			if (p < E.nP)
 			{
 				ns = X.st[E.pBeg + p];
 				const uint8_t lastTag = M.morphs[ns.wid].tag;
-				keep = cm.tag == T_Z_CODA ? (isJClass(lastTag) || isEClass(lastTag)) : isNNClass(lastTag);
+				keep = !ns.dead && (cm.tag == T_Z_CODA ? (isJClass(lastTag) || isEClass(lastTag)) : isNNClass(lastTag));
 			}
 			const uint64_t bal = X.ballot(keep);
 			if (keep)
@@ -353,34 +494,32 @@ namespace kamd
 				{
 					ns.accScore += cm.userScore * X.P->typoCostWeight;
 					ns.accTypoCost -= cm.userScore;
-					ns.parent = E.pBeg + p; ns.morph = newMorph; ns.wid = newMorph; ns.nodeId = (uint16_t)nodeIdx;
+					ns.parent = E.pBeg + p; ns.morph = newMorph; ns.wid = newMorph; ns.nodeId = (uint16_t)E.nodeIdx;
 					ns.leftFeat = ns.ownKind ? (uint16_t)((ns.leftFeat & (0x1FFF | LF_STR_SSC)) | (lfMorph & (LF_TAG_SSC | LF_PREV_ZSIOT))) : lfMorph;
-					ns.prevFlags = (uint8_t)(mp >> 16);
+					ns.prevFlags = nm.prevFlags;
 					X.st[pos] = ns;
+					stageState<G>(X, pos - E.nodeStart, ns.accScore, ns.rootId, newMorphSocket, ns.socket != 0);
 				}
 				else X.overflow = true;
 			}
 			X.stTop += __popcll(bal);
 		}
 		X.overflow = X.any(X.overflow);
+		X.stageOverflow = X.any(X.stageOverflow);
 		if (X.stTop > X.stCap) X.stTop = X.stCap;
 		__threadfence_block();
 	}
 
 	// PathEvaluator::operator() (PathEvaluator.hpp:347-512) for one candidate list
 	template<int G>
-	__device__ void evaluateNode(GroupCtx<G>& X, uint32_t nodeIdx, const DevNode& node, const NodeEnv& E,
-		const uint32_t* cands, uint32_t nCands, uint8_t ownKind, uint16_t ownFeat, float unkDiscount)
+	__device__ __noinline__ void evaluateNode(GroupCtx<G>& X, const NodeEnv& E, const CandStatic* cands, uint32_t nCands, uint8_t ownKind, uint16_t ownFeat, float nodeLevelDiscount)
 	{
 		const ModelView& M = *X.M;
 		const SearchParams& P = *X.P;
-		const uint32_t nodeStart = X.nodeStOff[nodeIdx];
-		float ws = 0;
-		if (!node.uformLen && node.form != NOFORM && M.forms[node.form].len && node.spaceErrors) ws = -P.spacePenalty * (float)node.spaceErrors;
-		const float typoDiscount = -0.f * P.typoCostWeight;
-		const float nodeLevelDiscount = ws + typoDiscount + unkDiscount;
-		const int mode = E.nP <= 128 ? 0 : E.nP <= 512 ? 1 : 2;
+		const int mode = E.nLive <= 128 ? 0 : E.nLive <= 512 ? 1 : 2;
+		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		enum { K_NONE = 0, K_SKIP = 1, K_Z = 2, K_REG = 3 };
+		constexpr int MAXC = Lay<G>::MAXC;
 
 		for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
 		{
@@ -389,27 +528,29 @@ namespace kamd
 			{
 				// ---- lane j classifies candidate c+j; then the group agrees on the next batch ----------------
 				const uint32_t idx = c + X.gl;
-				uint32_t kind = K_NONE, Q = 0, R = 1, mid = 0;
-				MorphRec cm{}; uint8_t sbType = 0;
-				if (idx < nCands)
+				uint32_t kind = K_NONE, Q = 0, R = 1, mid = 0, sbType = 0;
+				uint4 m0 = make_uint4(0, 0, 0, 0), m1 = make_uint4(0, 0, 0, 0);
+				uint4 mx = make_uint4(0, 0, 0, 0);
+				if (idx < nCands && X.gl < (uint32_t)MAXC)
 				{
-					mid = cands[idx];
-					cm = M.morphs[mid];
-					if (P.splitComplex && (cm.flags & MF_HAS_COMPLEX)) kind = K_SKIP;
-					else if (cm.tag == T_Z_CODA || cm.tag == T_Z_SIOT) kind = (cm.tag == T_Z_SIOT && !(P.splitSaisiot || P.mergeSaisiot)) ? K_SKIP : K_Z;
-					else if (!(cm.flags & MF_SINGLE) && (cm.flags & MF_HA_CONTRACTION) && node.prev && E.spaceBefore) kind = K_SKIP;
+					const uint4* cs = reinterpret_cast<const uint4*>(cands + idx);   // static record: one dependent level
+					m0 = cs[0]; m1 = cs[1]; mx = cs[2];
+					mid = mx.x; sbType = mx.z;
+					const uint32_t flags = m1.y & 0xFFFF; const uint8_t tag = (uint8_t)m1.z; const uint8_t special = (uint8_t)(m1.w >> 24);
+					if (P.splitComplex && (flags & MF_HAS_COMPLEX)) kind = K_SKIP;
+					else if (tag == T_Z_CODA || tag == T_Z_SIOT) kind = (tag == T_Z_SIOT && !(P.splitSaisiot || P.mergeSaisiot)) ? K_SKIP : K_Z;
+					else if (!(flags & MF_SINGLE) && (flags & MF_HA_CONTRACTION) && E.nodeIdx && spaceBefore) kind = K_SKIP;
 					else
 					{
 						kind = K_REG;
-						sbType = cm.tag == T_SB ? M.sbInfo[mid] : 0;
-						const bool quote = cm.special == 0 || cm.special == 1 || cm.special == 3 || cm.special == 4;
+						const bool quote = special == 0 || special == 1 || special == 3 || special == 4;
 						R = ((sbType || quote) && X.nUniq > 1) ? X.nUniq : 1;
 						Q = E.nP * R;
 					}
 				}
 				uint32_t nTake = 0, nC = 0, Qtot = 0, myK = 0xFFFFFFFFu, myOff = 0, zMorph = 0;
 				bool zShortcut = false;
-				for (int j = 0; j < G; ++j)
+				for (int j = 0; j < MAXC; ++j)
 				{
 					const uint32_t kj = X.bcast(kind, j);
 					const uint32_t Qj = X.bcast(Q, j);
@@ -430,25 +571,28 @@ namespace kamd
 				}
 				if (myK != 0xFFFFFFFFu)
 				{
-					CandInfo& o = X.ci[myK];
-					const uint32_t mp = M.morphPath[mid];
-					o.rec = cm; o.morph = mid; o.qOff = myOff; o.R = R;
-					o.additional = cm.userScore + nodeLevelDiscount + X.lb[(E.leftBoundary ? T_MAX : 0) + clearIrregular(cm.tag)] * 5.f;
-					o.leftFeat = (uint16_t)mp; o.prevFlags = (uint8_t)(mp >> 16);
-					o.sbType = sbType;
-					o.ruleBits = ((isEClass(cm.tag) && E.formStartsA) ? RB_POSITIVE_E : 0) | ((cm.tag == T_SN && E.uformEndsPoint) ? RB_SN_POINT : 0);
+					const uint8_t tag = (uint8_t)m1.z;
+					const float additional = __uint_as_float(m0.w) + nodeLevelDiscount + X.lb()[((E.nflags & NF_LEFT_BOUNDARY) ? T_MAX : 0) + clearIrregular(tag)] * 5.f;
+					const uint32_t ruleBits = ((isEClass(tag) && (E.fflags & FF_STARTS_WITH_A)) ? RB_POSITIVE_E : 0) | ((tag == T_SN && (E.nflags & NF_UFORM_ENDS_POINT)) ? RB_SN_POINT : 0);
+					uint4* o = reinterpret_cast<uint4*>(kSmem + X.candOff(myK));
+					o[0] = m0; o[1] = m1;
+					o[2] = make_uint4(mid, myOff, R, __float_as_uint(additional));
+					o[3] = make_uint4(sbType, ruleBits, mx.y, 0);
 				}
 				__threadfence_block();
 				c += nTake;
-				if (nC) evalBatch<G>(X, nC, Qtot, nodeIdx, E, ignoreCond ? -10.f : 0.f, ownKind, ownFeat, mode);
-				if (zShortcut) evalZShortcut<G>(X, zMorph, nodeIdx, E);
+				if (nC) evalBatch<G>(X, nC, Qtot, E, ignoreCond ? -10.f : 0.f, ownKind, ownFeat, mode);
+				if (zShortcut) evalZShortcut<G>(X, zMorph, E);
 			}
-			if (X.stTop > nodeStart) break;
+			if (X.stTop > E.nodeStart) break;
 		}
 
-		// ---- pruning (PathEvaluator.hpp:475-511): keep paths within cutOff of the best of their root ------
-		const uint32_t cnt = X.stTop - nodeStart;
+		// ---- pruning (PathEvaluator.hpp:475-511): paths further than cutOff below the best of their root die.
+		// Nothing is moved: dead paths keep their slot (marked in LDS and HBM) and are skipped by every consumer.
+		PROF(X, 1)
+		const uint32_t cnt = X.stTop - E.nodeStart;
 		if (!cnt) return;
+		const bool staged = !X.stageOverflow;
 		const uint32_t nRootSlots = 1 + X.nUniq;
 		for (uint32_t rs = 0; rs < nRootSlots; ++rs)
 		{
@@ -458,9 +602,10 @@ namespace kamd
 				const uint32_t i = b + X.gl;
 				if (i < cnt)
 				{
-					const DevState* s = &X.st[nodeStart + i];
-					const uint32_t slot = s->rootId == COMMON_ROOT ? 0 : s->rootId + 1u;
-					if (slot == rs) { anyOfRoot = true; if (!M.morphs[s->morph].socket) mx = fmaxf(mx, s->accScore); }
+					float sc; uint32_t slot; bool dead, msock;
+					if (staged) { const uint8_t bits = X.stBits()[i]; sc = X.stScore()[i]; slot = bits & SB_SLOT_MASK; dead = bits & SB_DEAD; msock = bits & SB_MORPH_SOCKET; }
+					else { const DevState* s = &X.st[E.nodeStart + i]; sc = s->accScore; slot = s->rootId == COMMON_ROOT ? 0 : s->rootId + 1u; dead = s->dead; msock = M.morphs[s->morph].socket != 0; }
+					if (!dead && slot == rs) { anyOfRoot = true; if (!msock) mx = fmaxf(mx, sc); }
 				}
 			}
 			for (int d = G / 2; d; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, G));
@@ -470,26 +615,22 @@ namespace kamd
 				const uint32_t i = b + X.gl;
 				if (i < cnt)
 				{
-					DevState* s = &X.st[nodeStart + i];
-					const uint32_t slot = s->rootId == COMMON_ROOT ? 0 : s->rootId + 1u;
-					if (slot == rs) s->pad = (s->accScore + P.cutOff < mx) ? 0 : 1;
+					if (staged)
+					{
+						const uint8_t bits = X.stBits()[i];
+						if (!(bits & SB_DEAD) && (uint32_t)(bits & SB_SLOT_MASK) == rs && X.stScore()[i] + P.cutOff < mx) { X.stBits()[i] = bits | SB_DEAD; X.st[E.nodeStart + i].dead = 1; }
+					}
+					else
+					{
+						DevState* s = &X.st[E.nodeStart + i];
+						const uint32_t slot = s->rootId == COMMON_ROOT ? 0 : s->rootId + 1u;
+						if (!s->dead && slot == rs && s->accScore + P.cutOff < mx) s->dead = 1;
+					}
 				}
 			}
 		}
 		__threadfence_block();
-		uint32_t out = 0;
-		for (uint32_t b = 0; b < cnt; b += G)
-		{
-			const uint32_t i = b + X.gl;
-			DevState s; bool keep = false;
-			if (i < cnt) { s = X.st[nodeStart + i]; keep = s.pad != 0; }
-			const uint64_t bal = X.ballot(keep);
-			__threadfence_block();
-			if (keep) { s.pad = 0; X.st[nodeStart + out + X.prefix(bal)] = s; }
-			out += __popcll(bal);
-			__threadfence_block();
-		}
-		X.stTop = nodeStart + out;
+		PROF(X, 4)
 	}
 
 	// libstdc++'s std::sort restated for the end-node candidate list (the reference sorts it with an unstable
@@ -579,22 +720,24 @@ namespace kamd
 	}
 
 	// generateTokenList (PathEvaluator.hpp:1038-1157) for one end candidate; single lane. Returns the token count or < 0.
-	__device__ __noinline__ int backTrace(const ModelView& M, const SearchParams& P, const DevNode* nodes, const DevState* st, uint32_t endParent, DevToken* out, uint32_t cap)
+	__device__ __noinline__ int backTrace(const ModelView& M, const SearchParams& P, const DevNode* nodes, const DevState* st, uint32_t endParent, DevToken* out, uint32_t cap, uint32_t* chain)
 	{
+		// walk the parent chain once (newest first), then emit oldest first
 		uint32_t nSteps = 0;
-		for (uint32_t s = endParent; st[s].parent != 0xFFFFFFFFu; s = st[s].parent) ++nSteps;
+		for (uint32_t s = endParent; ; )
+		{
+			const uint32_t par = st[s].parent;
+			if (par == 0xFFFFFFFFu) break;
+			if (nSteps >= CHAINCAP) return -3;
+			chain[nSteps++] = s;
+			s = par;
+		}
 		if (!nSteps) return 0;
 		int nTok = 0;
-		uint32_t prevIdx;
-		{
-			uint32_t s = endParent;
-			for (uint32_t k = 1; k < nSteps; ++k) s = st[s].parent;
-			prevIdx = st[s].parent;
-		}
+		uint32_t prevIdx = st[chain[nSteps - 1]].parent;
 		for (uint32_t step = nSteps; step-- > 0;)
 		{
-			uint32_t s = endParent;
-			for (uint32_t k = 0; k < step; ++k) s = st[s].parent;
+			const uint32_t s = chain[step];
 			const DevState cur = st[s];
 			const DevState prev = st[prevIdx];
 			const DevNode g = nodes[cur.nodeId];
@@ -673,7 +816,7 @@ namespace kamd
 			{
 				ps = X.st[pBeg + p];
 				const MorphRec pm = M.morphs[ps.morph];
-				ok = !ps.socket;
+				ok = !ps.socket && !ps.dead;
 				if (ok && !(pm.flags & MF_SINGLE) && pm.nChunks <= (pm.socket ? 2u : 1u) && pm.vowel != CV_NONE) ok = false;   // isMatched(nullptr, vowel)
 				if (ok && pm.tag == T_Z_SIOT) ok = false;
 				if (ok)
@@ -730,7 +873,7 @@ namespace kamd
 					if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
 					if (a - startIdx >= perGroup) continue;
 					if (nPaths >= kMaxPathsPerChunk) { status = CS_ERR_PATH_OVERFLOW; break; }
-					const int nt = backTrace(M, *X.P, X.nodes, X.st, endBuf[a].parent, tok + tokTop, tokCap - tokTop);
+					const int nt = backTrace(M, *X.P, X.nodes, X.st, endBuf[a].parent, tok + tokTop, tokCap - tokTop, X.scratch->chain);
 					if (nt < 0) { status = CS_ERR_TOKEN_OVERFLOW; break; }
 					DevPathHeader& ph = res->paths[nPaths++];
 					ph.score = endBuf[a].score; ph.tokOff = tokTop; ph.nTokens = (uint16_t)nt;
@@ -754,80 +897,83 @@ namespace kamd
 		X.nodes = W.nodes + nBase; X.Gn = W.nNodes[chunk];
 		X.str = B.chars + cOff; X.cls = B.cls + cOff;
 		X.st = W.states + W.stateBase[chunk]; X.stCap = (uint32_t)(W.stateBase[chunk + 1] - W.stateBase[chunk]); X.stTop = 0;
-		X.nodeStOff = W.nodeStateOff + nBase; X.nodeStCnt = W.nodeStateCnt + nBase;
+		X.nodeStOff = W.nodeStateOff + nBase; X.nodeStCnt = W.nodeStateCnt + nBase; X.nodeLive = W.tmpIdx + 2ull * nBase;
 		X.uniq = B.spStates + B.spOff[chunk]; X.nUniq = B.spOff[chunk + 1] - B.spOff[chunk];
 		X.overflow = false; X.pairOverflow = false;
 		const uint32_t Gn = X.Gn;
 		const bool openEnding = B.chunkFlags[chunk] & 1;
 		uint8_t* reach = W.reach + nBase;
+		if (X.nUniq + 1 > SB_SLOT_MASK) { if (X.gl == 0) { res->status = CS_ERR_PATH_OVERFLOW; res->nPaths = 0; } return; }
 
 		// start node (PathEvaluator.hpp:1224-1226)
 		if (X.gl == 0)
 		{
-			DevState bos;
-			bos.lmNode = M.h.bosNode; bos.accScore = 0; bos.firstChunkScore = 0; bos.accTypoCost = 0; bos.parent = 0xFFFFFFFFu;
-			bos.morph = 0; bos.wid = 0; bos.nodeId = 0; bos.rootId = COMMON_ROOT; bos.spState = 0; bos.socket = 0; bos.ownKind = 0;
-			const uint32_t mp = M.morphPath[0];
-			bos.leftFeat = (uint16_t)mp; bos.prevFlags = (uint8_t)(mp >> 16); bos.pad = 0; bos.ownNode = 0;
-			X.st[0] = bos;
-			X.nodeStOff[0] = 0; X.nodeStCnt[0] = 1;
+			const MorphRec m0 = M.morphs[0];
+			storeState(X.st, 0, M.h.bosNode, 0.f, 0.f, 0, m0.feat, COMMON_ROOT, 0, 0, m0.prevFlags, 0, 0xFFFFFFFFu, 0, 0.f, 0, 0);
+			X.nodeStOff[0] = 0; X.nodeStCnt[0] = 1; X.nodeLive[0] = 1;
+			X.ringBeg()[0] = 0; X.ringEnd()[0] = 1; X.ringLive()[0] = 1;
 		}
 		X.stTop = 1;
 		for (uint32_t k = X.gl; k < Gn; k += G) reach[k] = k == 0 ? 1 : 0;
 		__threadfence_block();
 
-		const uint32_t unkCands[2] = { T_NNG + 1u, T_NNP + 1u };
+		const CandStatic* unkPacks = reinterpret_cast<const CandStatic*>(M.unkPacks);
+		const CandStatic* packs = W.packs + W.packBase[chunk];
+		DevNode nextNode = X.nodes[Gn > 2 ? 1 : 0];
 		for (uint32_t i = 1; i + 1 < Gn; ++i)
 		{
-			const DevNode node = X.nodes[i];
+			const DevNode node = nextNode;
+			if (i + 2 < Gn) nextNode = X.nodes[i + 1];      // prefetch: in flight while this node is processed
 			NodeEnv E;
 			const uint32_t firstPrev = i - node.prev, lastPrev = firstPrev + node.nPrev - 1;
-			E.pBeg = X.nodeStOff[firstPrev];
-			E.nP = X.nodeStOff[lastPrev] + X.nodeStCnt[lastPrev] - E.pBeg;
-			E.spaceBefore = node.nflags & NF_SPACE_BEFORE; E.leftBoundary = node.nflags & NF_LEFT_BOUNDARY;
-			E.uformEndsPoint = node.nflags & NF_UFORM_ENDS_POINT;
-			E.formStartsA = false;
-			if (X.gl == 0) X.nodeStOff[i] = X.stTop;
-			__threadfence_block();
-
-			uint8_t ownKind = 0; uint16_t ownFeat = 0;
-			if (node.uformLen)
+			if (i - firstPrev < RING)
 			{
-				ownKind = 1;
-				ownFeat = featMask(X.str + node.uformOff, node.uformLen) & 0x1FFF;
-				const uint32_t lp = node.uformOff + node.uformLen - 1;
-				const uint16_t c = X.str[lp];
-				const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(X.cls[lp] & 0x3F);
-				if (tag == T_SSC) ownFeat |= LF_STR_SSC;
+				E.pBeg = X.ringBeg()[firstPrev & (RING - 1)];
+				E.nP = X.ringEnd()[lastPrev & (RING - 1)] - E.pBeg;
+				E.nLive = 0;
+				for (uint32_t j = firstPrev; j <= lastPrev; ++j) E.nLive += X.ringLive()[j & (RING - 1)];
 			}
+			else
+			{
+				E.pBeg = X.nodeStOff[firstPrev];
+				E.nP = X.nodeStOff[lastPrev] + X.nodeStCnt[lastPrev] - E.pBeg;
+				E.nLive = 0;
+				for (uint32_t j = firstPrev; j <= lastPrev; ++j) E.nLive += X.nodeLive[j];
+			}
+			E.nflags = node.nflags; E.fflags = node.fflags; E.nodeIdx = i;
+			const uint32_t nodeStart = X.stTop;
+			E.nodeStart = nodeStart;
+			X.stageOverflow = false;
+			float ws = 0;
+			if (!node.uformLen && node.form != NOFORM && node.flen && node.spaceErrors) ws = -P.spacePenalty * (float)node.spaceErrors;
+			const float baseDiscount = ws + (-0.f * P.typoCostWeight);   // whitespaceDiscount + typoDiscount (PathEvaluator.hpp:366-371)
+
+			PROF(X, 0)
+			const uint8_t ownKind = node.uformLen ? 1 : 0; const uint16_t ownFeat = node.ownFeat;
 			if (node.form != NOFORM)
 			{
-				const FormRec f = M.forms[node.form];
-				E.formStartsA = f.flags & FF_STARTS_WITH_A;
-				evaluateNode<G>(X, i, node, E, M.formCand + f.candOff, f.candCnt, ownKind, ownFeat, 0.f);
+				evaluateNode<G>(X, E, packs + node.packOff, node.candCnt, ownKind, ownFeat, baseDiscount + 0.f);
 				// forms whose candidates are all partial morphemes also get an unknown proper-noun reading (PathEvaluator.hpp:1277-1287)
-				bool notPartial = false;
-				for (uint32_t cb = 0; cb < f.candCnt; cb += G)
+				if (node.nflags & NF_ALL_PARTIAL)
 				{
-					const uint32_t ci = cb + X.gl;
-					if (ci < f.candCnt)
-					{
-						const MorphRec m = M.morphs[M.formCand[f.candOff + ci]];
-						if (!(m.socket || !(m.flags & MF_SINGLE))) notPartial = true;
-						if (f.candCnt == 1 && m.tag == T_UNKNOWN && m.nChunks) notPartial = true;   // "isPretokenizedNode" (:1258-1263)
-					}
-				}
-				if (!X.any(notPartial))
-				{
+					const FormRec f = M.forms[node.form];
 					const uint16_t* fs = M.formChars + f.charOff;
 					uint16_t of = featMask(fs, f.len) & 0x1FFF;
 					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
-					evaluateNode<G>(X, i, node, E, &unkCands[1], 1, 2, of, -((float)f.len * P.oovRuleScale + P.oovRuleBias));
+					evaluateNode<G>(X, E, unkPacks + 1, 1, 2, of, baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias));
 				}
 				// reachable[i] and the forward re-scan of the persistent flags (PathEvaluator.hpp:1159-1176, 1286-1299)
-				const uint32_t cntNow = X.stTop - X.nodeStOff[i];
+				const uint32_t cntNow = X.stTop - nodeStart;
 				bool anyFree = false;
-				for (uint32_t b = 0; b < cntNow; b += G) { const uint32_t k = b + X.gl; if (k < cntNow && !X.st[X.nodeStOff[i] + k].socket) anyFree = true; }
+				for (uint32_t b = 0; b < cntNow; b += G)
+				{
+					const uint32_t k = b + X.gl;
+					if (k < cntNow)
+					{
+						if (!X.stageOverflow) { const uint8_t bits = X.stBits()[k]; if (!(bits & (SB_DEAD | SB_STATE_SOCKET))) anyFree = true; }
+						else { const DevState* s = &X.st[nodeStart + k]; if (!s->dead && !s->socket) anyFree = true; }
+					}
+				}
 				anyFree = X.any(anyFree);
 				if (X.gl == 0) reach[i] = anyFree ? 1 : 0;
 				if (!anyFree)
@@ -856,17 +1002,35 @@ namespace kamd
 							if (tag == T_SSC) of |= LF_STR_SSC;
 						}
 						const float emo = (X.cls[node.startPos] & 0x80) ? -10.f : 0.f;
-						evaluateNode<G>(X, i, node, E, unkCands, 2, 3, of, emo - ((float)len * P.oovRuleScale + P.oovRuleBias));
+						evaluateNode<G>(X, E, unkPacks, 2, 3, of, baseDiscount + (emo - ((float)len * P.oovRuleScale + P.oovRuleBias)));
 					}
 				}
 			}
 			else
 			{
 				const float emo = (X.cls[node.uformOff] & 0x80) ? -10.f : 0.f;
-				evaluateNode<G>(X, i, node, E, unkCands, 2, ownKind, ownFeat, emo - ((float)node.uformLen * P.oovRuleScale + P.oovRuleBias));
+				evaluateNode<G>(X, E, unkPacks, 2, ownKind, ownFeat, baseDiscount + (emo - ((float)node.uformLen * P.oovRuleScale + P.oovRuleBias)));
 			}
-			if (X.gl == 0) X.nodeStCnt[i] = X.stTop - X.nodeStOff[i];
+			PROF(X, 0)
+			// node bookkeeping: state range + live count (LDS ring and HBM)
+			{
+				const uint32_t cntAll = X.stTop - nodeStart;
+				uint32_t live = 0;
+				for (uint32_t b = 0; b < cntAll; b += G)
+				{
+					const uint32_t k = b + X.gl;
+					bool alive = false;
+					if (k < cntAll) alive = !X.stageOverflow ? !(X.stBits()[k] & SB_DEAD) : !X.st[nodeStart + k].dead;
+					live += __popcll(X.ballot(alive));
+				}
+				if (X.gl == 0)
+				{
+					X.ringBeg()[i & (RING - 1)] = nodeStart; X.ringEnd()[i & (RING - 1)] = X.stTop; X.ringLive()[i & (RING - 1)] = (uint16_t)(live > 0xFFFF ? 0xFFFF : live);
+					X.nodeStOff[i] = nodeStart; X.nodeStCnt[i] = cntAll; X.nodeLive[i] = (uint16_t)(live > 0xFFFF ? 0xFFFF : live);
+				}
+			}
 			__threadfence_block();
+			PROF(X, 5)
 			if (X.overflow || X.pairOverflow) break;
 		}
 		if (X.overflow || X.pairOverflow)
@@ -875,42 +1039,43 @@ namespace kamd
 			return;
 		}
 		finishChunk<G>(X, W, chunk, openEnding, res);
+		PROF(X, 6)
+#ifdef KAMD_PROFILE
+		if (X.gl == 0) for (int k = 0; k < 8; ++k) { atomicAdd(&gProf[k], (unsigned long long)X.prof[k]); X.prof[k] = 0; }
+#endif
 	}
 
 	template<int G>
-	__global__ void __launch_bounds__(64) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder)
+#ifndef KAMD_WAVES_PER_SIMD
+#define KAMD_WAVES_PER_SIMD 2
+#endif
+	__global__ void __launch_bounds__(64, KAMD_WAVES_PER_SIMD) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder)
 	{
 		constexpr int NG = 64 / G;
-		__shared__ uint64_t sKey[NG * QCAP];
-		__shared__ float sScore[NG * QCAP];
-		__shared__ float sFcs[NG * QCAP];
-		__shared__ CandInfo sCand[NG * G];
-		__shared__ float sLb[2 * T_MAX + 1];
-
 		const uint32_t lane = threadIdx.x;
 		// TagSequenceScorer tables (src/TagUtils.cpp:49-62): [0..T_MAX) without, [T_MAX..2*T_MAX) with a left boundary.
 		// Tag PA (== T_MAX) indexes one past a row in the reference (include/kiwi/TagUtils.h:10-18): row 0 spills into
 		// row 1, row 1 spills into the `weight` member (5.0) -- reproduced by the flat layout plus one extra slot.
+		float* lb = reinterpret_cast<float*>(kSmem + Lay<G>::LB);
 		for (uint32_t t = lane; t < 2 * T_MAX + 1; t += 64)
 		{
 			float v = 0;
 			if (t == 2 * T_MAX) v = 5.f;
 			else if (t < T_MAX) { if (t == T_NNP || t == T_NP || t == T_IC) v = -1; else if (t == T_SB) v = -3; }
 			else { const uint8_t r = (uint8_t)(t - T_MAX); v = (isEClass(r) || isJClass(r) || isSuffixTag(r) || r == T_VCP) ? -1.f : 0.f; }
-			sLb[t] = v;
+			lb[t] = v;
 		}
 		__syncthreads();
 
-		// LDS addresses must not be folded into a constant aggregate (lld rejects addrspacecasts in static initialisers)
-		uint32_t opaqueZero = 0;
-		asm volatile("" : "+v"(opaqueZero));
 		GroupCtx<G> X;
 		const uint32_t gid = lane / G;
-		X.M = &M; X.P = &P; X.lb = sLb + opaqueZero;
-		X.gl = lane % G; X.gshift = gid * G;
-		X.qKey = sKey + gid * QCAP + opaqueZero; X.qScore = sScore + gid * QCAP + opaqueZero; X.qFcs = sFcs + gid * QCAP + opaqueZero;
-		X.ci = sCand + gid * G + opaqueZero;
+		X.M = &M; X.P = &P;
+		X.gl = lane % G; X.gshift = gid * G; X.lds = gid * Lay<G>::SIZE;
 		X.scratch = reinterpret_cast<GroupScratch*>(W.bigScratch) + ((size_t)blockIdx.x * NG + gid);
+#ifdef KAMD_PROFILE
+		for (int k = 0; k < 8; ++k) X.prof[k] = 0;
+		X.profT = wall_clock64();
+#endif
 
 		for (;;)
 		{
@@ -918,6 +1083,7 @@ namespace kamd
 			if (X.gl == 0) ci = atomicAdd(chunkCounter, 1u);
 			ci = X.bcast(ci, 0);
 			if (ci >= B.nChunks) break;
+			PROF(X, 7)
 			searchChunk<G>(X, B, W, chunkOrder ? chunkOrder[ci] : ci);
 		}
 	}
@@ -925,5 +1091,6 @@ namespace kamd
 	template __global__ void k_best_path<4>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
 	template __global__ void k_best_path<8>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
 	template __global__ void k_best_path<16>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
+	template __global__ void k_best_path<32>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
 	template __global__ void k_best_path<64>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
 }

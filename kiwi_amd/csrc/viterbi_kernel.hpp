@@ -5,13 +5,17 @@
 
 namespace kamd
 {
-	constexpr uint32_t QCAP = 64;          // work items of one batch staged in LDS (per lane group)
+	constexpr uint32_t QCAP = 32;          // work items of one batch staged in LDS (per lane group)
 	constexpr uint32_t BIGQ = 2048;        // work items of one batch staged in HBM scratch (per lane group); beyond: CS_ERR_PAIR_OVERFLOW
 	constexpr uint32_t ENDCAP = 256;       // end-node candidates per chunk
+	constexpr uint32_t CHAINCAP = 4096;    // morphemes on one best path
 
 	struct EndCand { float score, fcs, typo; uint32_t parent; uint8_t rootId, sp; uint16_t pad; };
 	// scratch in HBM per lane group (items of oversized batches, end-node candidates)
-	struct GroupScratch { uint64_t key[BIGQ]; float score[BIGQ]; float fcs[BIGQ]; EndCand end[ENDCAP]; };
+	struct GroupScratch { uint64_t key[BIGQ]; float score[BIGQ]; float fcs[BIGQ]; EndCand end[ENDCAP]; uint32_t chain[CHAINCAP]; };
+
+	uint32_t searchKernelLdsBytes(int G);
+	void searchKernelProfile(unsigned long long* out16, bool reset);   // phase cycle counters (builds with -DKAMD_PROFILE only)   // dynamic LDS the launch must request
 
 	// G = lanes per chunk (4, 8, 16 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
 	template<int G>
