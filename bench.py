@@ -58,25 +58,21 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    from kiwi_amd import dist
     from kiwi_amd.api import KiwiAmd
     from kiwi_amd.workloads import get_workload
+    rank, local_rank, world = dist.env_rank_world()
+    if world > 1:
+        dist.init("nccl", local_rank)
 
     if world > 1 and rank != 0:
-        torch.distributed.barrier()     # rank 0 generates / caches the model and corpus first
+        dist.barrier()     # rank 0 generates / caches the model and corpus first
     model_path, texts, desc = get_workload(args.workload)
     if world > 1 and rank == 0:
-        torch.distributed.barrier()
+        dist.barrier()
     # weak scaling: every rank analyses a same-sized shard; rotate so shards differ
     n = len(texts)
-    shift = (rank * 977) % n
-    shard = texts[shift:] + texts[:shift]
+    shard = dist.weak_shard(texts, rank)
 
     eng = KiwiAmd(model_path, local_rank)
     batch = eng.stage(shard)
@@ -84,8 +80,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
+        dist.barrier()
 
     for _ in range(args.warmup):
         eng.run(batch)
@@ -98,10 +93,7 @@ def main():
             kt[k] += r[k]
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dist.max_over_ranks(elapsed, device="cuda" if world > 1 else "cpu")
     for k in kt:
         kt[k] /= args.steps
 
@@ -109,6 +101,8 @@ def main():
     res = eng.fetch(batch)
     n_tok = sum(res.lib.kamd_res_token_num(res.h, i, 0) for i in range(min(256, n)))
     assert n_tok > 0
+    summary = dist.gather_counts([n, n_tok], device="cuda" if world > 1 else "cpu")   # the only result "gather": per-rank counts
+    assert len(summary) == world
 
     if rank == 0:
         total_sent = n * world * args.steps

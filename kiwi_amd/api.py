@@ -201,10 +201,10 @@ class KiwiAmd:
         return Batch(self.lib, b)
 
     def run(self, batch: Batch):
-        ms = np.zeros(3, np.float32)
+        ms = np.zeros(4, np.float32)
         if self.lib.kamd_run(self.h, batch.h, ms.ctypes.data) != 0:
             raise self._err("kamd_run")
-        return {"scan_ms": float(ms[0]), "lattice_ms": float(ms[1]), "search_ms": float(ms[2])}
+        return {"scan_ms": float(ms[0]), "lattice_ms": float(ms[1]), "search_ms": float(ms[2]), "search_launches": int(ms[3])}
 
     def fetch(self, batch: Batch, top_n=1) -> Results:
         r = self.lib.kamd_fetch(self.h, batch.h, top_n)

@@ -14,9 +14,9 @@
 
 namespace kamd
 {
-	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W);
-	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P);
-	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W);
+	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
+	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount);
+	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
 
 	namespace
 	{
@@ -74,6 +74,7 @@ namespace kamd
 		std::vector<DevChunkResult> hResults;
 		std::vector<DevToken> hTokens;
 		bool ran = false;
+		uint32_t subBatches = 0;
 	};
 
 	struct Engine::Impl
@@ -81,8 +82,9 @@ namespace kamd
 		FlatModel model;
 		ModelView dview{};
 		std::vector<std::unique_ptr<DevBuf>> modelBufs;
-		hipStream_t stream = nullptr;
-		hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+		hipStream_t stream = nullptr, stream2 = nullptr;   // lattice stages / search stage (sub-batches overlap)
+		std::vector<hipEvent_t> evs;
+		int subBatches = 0;   // 0 = automatic
 		int device = 0;
 		uint32_t persistBlocks = 0;
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
@@ -108,7 +110,8 @@ namespace kamd
 		impl->device = device;
 		HIPCHECK(hipSetDevice(device));
 		HIPCHECK(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));
-		for (auto& e : impl->ev) HIPCHECK(hipEventCreate(&e));
+		HIPCHECK(hipStreamCreateWithFlags(&impl->stream2, hipStreamNonBlocking));
+		if (const char* sb = std::getenv("KAMD_SUBBATCHES")) impl->subBatches = std::atoi(sb);
 		const FlatModel& m = impl->model;
 		ModelView& v = impl->dview;
 		v.h = m.h;
@@ -142,15 +145,16 @@ namespace kamd
 			if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) impl->groupLanes = v;
 			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16, 32 or 64" };
 		}
-		impl->counter.ensure(64);
+		impl->counter.ensure(256);
 	}
 
 	Engine::~Engine()
 	{
 		if (impl)
 		{
-			for (auto& e : impl->ev) if (e) (void)hipEventDestroy(e);
+			for (auto& e : impl->evs) if (e) (void)hipEventDestroy(e);
 			if (impl->stream) (void)hipStreamDestroy(impl->stream);
+			if (impl->stream2) (void)hipStreamDestroy(impl->stream2);
 		}
 	}
 
@@ -263,11 +267,7 @@ namespace kamd
 		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();
 		w.tokenBase = b.dTokenBase.as<uint64_t>(); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
 		w.bigScratch = nullptr; w.bigScratchBytes = 0;   // bound at launch
-		// longest chunks first: the persistent search waves pull work in this order
-		std::vector<uint32_t> order(nC);
-		std::iota(order.begin(), order.end(), 0u);
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) { return b.charOff[a + 1] - b.charOff[a] > b.charOff[c + 1] - b.charOff[c]; });
-		upload(b.dOrder, order, s);
+		b.subBatches = 0;
 		HIPCHECK(hipStreamSynchronize(s));
 		b.ran = false;
 	}
@@ -287,34 +287,77 @@ namespace kamd
 		KernelTimes t;
 		const uint32_t nC = (uint32_t)b.refs.size();
 		if (!nC) return t;
-		hipStream_t s = I.stream;
-		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), s));
-		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 64, s));
-		HIPCHECK(hipEventRecord(I.ev[0], s));
-		hipLaunchKernelGGL(k_dict_scan, dim3((nC + 3) / 4), dim3(256), 0, s, I.dview, b.bv, b.wv);
-		HIPCHECK(hipEventRecord(I.ev[1], s));
-		hipLaunchKernelGGL(k_build_lattice, dim3((nC + 63) / 64), dim3(64), 0, s, I.dview, b.bv, b.wv, sp);
-		hipLaunchKernelGGL(k_expand_cands, dim3(nC), dim3(64), 0, s, I.dview, b.bv, b.wv);
-		HIPCHECK(hipEventRecord(I.ev[2], s));
+		hipStream_t sA = I.stream, sB = I.stream2;
+		// Sub-batches: the lattice stages of sub-batch k+1 (few, long-running waves) overlap the search of sub-batch k
+		// (many latency-bound waves) on a second stream.
+		// Measured on MI355X (c2): both stages are bound by the serial latency of ONE chunk, not by the chunk count, so
+		// splitting only adds launches (S=1: 4.5 ms, S=2: 6.4 ms, S=4: 9.9 ms per 8192 chunks).  Kept as an option only.
+		uint32_t S = I.subBatches > 0 ? (uint32_t)I.subBatches : 1u;
+		S = std::min(S, std::min(nC, 16u));
+		if (b.subBatches != S)
+		{
+			// work order of the search kernel: longest chunks first inside each sub-batch
+			std::vector<uint32_t> order(nC);
+			std::iota(order.begin(), order.end(), 0u);
+			for (uint32_t k = 0; k < S; ++k)
+			{
+				const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S);
+				std::stable_sort(order.begin() + c0, order.begin() + c1, [&](uint32_t a, uint32_t c) { return b.charOff[a + 1] - b.charOff[a] > b.charOff[c + 1] - b.charOff[c]; });
+			}
+			upload(b.dOrder, order, sA);
+			b.subBatches = S;
+		}
+		const size_t nEv = 5 * (size_t)S + 2;
+		while (I.evs.size() < nEv) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); I.evs.push_back(e); }
+		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), sA));
+		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
 		const uint32_t nGroups = 64u / (uint32_t)I.groupLanes;
-		const uint32_t blocks = std::min(I.persistBlocks, (nC + nGroups - 1) / nGroups);
-		I.bigScratch.ensure((size_t)blocks * nGroups * sizeof(GroupScratch));
+		const uint32_t maxWork = (nC + S - 1) / S + 1;
+		const uint32_t maxBlocks = std::min(I.persistBlocks, (maxWork + nGroups - 1) / nGroups);
+		I.bigScratch.ensure((size_t)maxBlocks * nGroups * sizeof(GroupScratch) * std::min(S, 2u));
 		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)sizeof(GroupScratch);
 		const uint32_t ldsBytes = searchKernelLdsBytes(I.groupLanes);
-		switch (I.groupLanes)
+		for (uint32_t k = 0; k < S; ++k)
 		{
-		case 4: hipLaunchKernelGGL(k_best_path<4>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
-		case 8: hipLaunchKernelGGL(k_best_path<8>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
-		case 32: hipLaunchKernelGGL(k_best_path<32>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
-		case 16: hipLaunchKernelGGL(k_best_path<16>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
-		default: hipLaunchKernelGGL(k_best_path<64>, dim3(blocks), dim3(64), ldsBytes, s, I.dview, b.bv, b.wv, sp, I.counter.as<uint32_t>(), b.dOrder.as<uint32_t>()); break;
+			const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S), cn = c1 - c0;
+			hipEvent_t* e = &I.evs[5 * (size_t)k];
+			HIPCHECK(hipEventRecord(e[0], sA));
+			hipLaunchKernelGGL(k_dict_scan, dim3((cn + 3) / 4), dim3(256), 0, sA, I.dview, b.bv, b.wv, c0, cn);
+			HIPCHECK(hipEventRecord(e[1], sA));
+			hipLaunchKernelGGL(k_build_lattice, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn);
+			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn);
+			HIPCHECK(hipEventRecord(e[2], sA));
+			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));
+			HIPCHECK(hipEventRecord(e[3], sB));
+			const uint32_t blocks = std::min(I.persistBlocks, (cn + nGroups - 1) / nGroups);
+			// consecutive searches may overlap at their tails: alternate between two scratch halves
+			WorkView wv = b.wv;
+			wv.bigScratch = I.bigScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(GroupScratch) : 0);
+			uint32_t* counter = I.counter.as<uint32_t>() + k;
+			const uint32_t* order = b.dOrder.as<uint32_t>() + c0;
+			switch (I.groupLanes)
+			{
+			case 4: hipLaunchKernelGGL(k_best_path<4>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
+			case 8: hipLaunchKernelGGL(k_best_path<8>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
+			case 16: hipLaunchKernelGGL(k_best_path<16>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
+			case 32: hipLaunchKernelGGL(k_best_path<32>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
+			default: hipLaunchKernelGGL(k_best_path<64>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
+			}
+			HIPCHECK(hipEventRecord(e[4], sB));
 		}
-		HIPCHECK(hipEventRecord(I.ev[3], s));
 		HIPCHECK(hipGetLastError());
-		HIPCHECK(hipStreamSynchronize(s));
-		HIPCHECK(hipEventElapsedTime(&t.scanMs, I.ev[0], I.ev[1]));
-		HIPCHECK(hipEventElapsedTime(&t.latticeMs, I.ev[1], I.ev[2]));
-		HIPCHECK(hipEventElapsedTime(&t.searchMs, I.ev[2], I.ev[3]));
+		HIPCHECK(hipStreamSynchronize(sA));
+		HIPCHECK(hipStreamSynchronize(sB));
+		for (uint32_t k = 0; k < S; ++k)
+		{
+			hipEvent_t* e = &I.evs[5 * (size_t)k];
+			float a = 0, l = 0, r = 0;
+			HIPCHECK(hipEventElapsedTime(&a, e[0], e[1]));
+			HIPCHECK(hipEventElapsedTime(&l, e[1], e[2]));
+			HIPCHECK(hipEventElapsedTime(&r, e[3], e[4]));
+			t.scanMs += a; t.latticeMs += l; t.searchMs += r;
+		}
+		t.searchLaunches = S;
 		b.ran = true;
 		return t;
 	}

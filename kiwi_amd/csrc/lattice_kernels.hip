@@ -35,11 +35,12 @@ namespace kamd
 		return 0;
 	}
 
-	__global__ void __launch_bounds__(256) k_dict_scan(ModelView M, BatchView B, WorkView W)
+	__global__ void __launch_bounds__(256) k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount)
 	{
 		const uint32_t lane = threadIdx.x & 63;
-		const uint32_t chunk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-		if (chunk >= B.nChunks) return;
+		const uint32_t local = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+		if (local >= chunkCount) return;
+		const uint32_t chunk = chunkBegin + local;
 		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
 		const uint16_t* str = B.chars + cOff;
 		const uint8_t* cls = B.cls + cOff;
@@ -235,10 +236,11 @@ namespace kamd
 		latInsertUnk(L, unkStart, e, hasJ, nMap);
 	}
 
-	__global__ void __launch_bounds__(64) k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P)
+	__global__ void __launch_bounds__(64) k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount)
 	{
-		const uint32_t chunk = blockIdx.x * blockDim.x + threadIdx.x;
-		if (chunk >= B.nChunks) return;
+		const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+		if (local >= chunkCount) return;
+		const uint32_t chunk = chunkBegin + local;
 		if (W.results[chunk].status >= 16) return;
 		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
 		const uint16_t* str = B.chars + cOff;
@@ -506,10 +508,10 @@ namespace kamd
 
 	// Static candidate records per lattice node (one block per chunk, one thread per node): resolves
 	// form -> candidate list -> morpheme record -> first LM id once, off the search kernel's dependent-load chain.
-	__global__ void __launch_bounds__(64) k_expand_cands(ModelView M, BatchView B, WorkView W)
+	__global__ void __launch_bounds__(64) k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount)
 	{
-		const uint32_t chunk = blockIdx.x;
-		if (chunk >= B.nChunks) return;
+		if (blockIdx.x >= chunkCount) return;
+		const uint32_t chunk = chunkBegin + blockIdx.x;
 		if (W.results[chunk].status != CS_OK) return;
 		const uint32_t nBase = W.nodeBase[chunk], G = W.nNodes[chunk];
 		CandStatic* packs = W.packs + W.packBase[chunk];

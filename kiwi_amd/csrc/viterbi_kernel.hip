@@ -1049,7 +1049,7 @@ namespace kamd
 #ifndef KAMD_WAVES_PER_SIMD
 #define KAMD_WAVES_PER_SIMD 2
 #endif
-	__global__ void __launch_bounds__(64, KAMD_WAVES_PER_SIMD) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder)
+	__global__ void __launch_bounds__(64, KAMD_WAVES_PER_SIMD) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork)
 	{
 		constexpr int NG = 64 / G;
 		const uint32_t lane = threadIdx.x;
@@ -1082,15 +1082,15 @@ namespace kamd
 			uint32_t ci = 0;
 			if (X.gl == 0) ci = atomicAdd(chunkCounter, 1u);
 			ci = X.bcast(ci, 0);
-			if (ci >= B.nChunks) break;
+			if (ci >= nWork) break;
 			PROF(X, 7)
-			searchChunk<G>(X, B, W, chunkOrder ? chunkOrder[ci] : ci);
+			searchChunk<G>(X, B, W, chunkOrder[ci]);
 		}
 	}
 
-	template __global__ void k_best_path<4>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
-	template __global__ void k_best_path<8>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
-	template __global__ void k_best_path<16>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
-	template __global__ void k_best_path<32>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
-	template __global__ void k_best_path<64>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*);
+	template __global__ void k_best_path<4>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<8>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<16>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<32>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<64>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 }

@@ -19,5 +19,5 @@ namespace kamd
 
 	// G = lanes per chunk (4, 8, 16 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
 	template<int G>
-	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder);
+	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork);
 }

@@ -1,0 +1,67 @@
+"""Multi-GPU driver helpers: one process per GPU, texts sharded by rank, no data-path collective.
+
+The analyze path shards by independent texts; the only cross-rank traffic is a
+barrier, a MAX over ranks of the measured time, and an all-gather of per-rank result summaries (counts).
+On the GPU box the backend is "nccl" (= RCCL over xGMI); the CPU tests run the same code over "gloo".
+"""
+from __future__ import annotations
+
+import os
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard_indices(n_texts: int, rank: int, world: int):
+    """Strong-scaling split of one corpus: text i goes to rank i % world (keeps length mixes even)."""
+    return list(range(rank, n_texts, world))
+
+
+def weak_shard(texts, rank: int):
+    """Weak scaling (bench.py): every rank analyses a same-sized batch; rotate so batches differ."""
+    n = len(texts)
+    if not n:
+        return []
+    shift = (rank * 977) % n
+    return texts[shift:] + texts[:shift]
+
+
+def init(backend: str, device_index: int | None = None):
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return
+    if backend == "nccl":
+        torch.cuda.set_device(device_index or 0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device_index or 0))
+    else:
+        dist.init_process_group(backend)
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device: str = "cpu") -> float:
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_counts(values, device: str = "cpu"):
+    """All-gather of a small per-rank integer vector (e.g. [texts, tokens]); returns a list per rank."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(list(values), dtype=torch.int64, device=device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [t.tolist()]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [o.tolist() for o in out]
