@@ -120,6 +120,8 @@ namespace kamd
 		DevNode* nodes;                // final lattice of chunk c at nodeBase[c]
 		DevNode* tmpNodes;             // build-order nodes, same offsets
 		uint32_t* endPosMap;           // [charOff[c] + c + p] : first | second<<16
+		uint64_t* fullMask;            // [charOff[c] + c + e] bit L-1: a zero-cost node of length L that is unknown or has a full morpheme ends at e
+		uint8_t* zAt;                  // [charOff[c] + c + e] bit0/1: a form ending at e allows a trailing z-coda / saisiot
 		uint16_t* tmpIdx;              // per node scratch (inverse permutation / BFS queue), 2 per node
 		uint32_t* nNodes;              // [c]
 		const uint64_t* stateBase;     // [nChunks+1]

@@ -68,7 +68,7 @@ namespace kamd
 		std::vector<uint64_t> stateBase, tokenBase;
 		// device
 		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags, dTextOff;
-		DevBuf dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
+		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
 		DevBuf dPackBase, dPacks, dStateBase, dStates, dNodeStOff, dNodeStCnt, dReach, dTokenBase, dTokens, dResults, dOrder;
 		BatchView bv{}; WorkView wv{};
 		std::vector<DevChunkResult> hResults;
@@ -244,7 +244,7 @@ namespace kamd
 		b.dNsToPos.ensure(perChar * 2); b.dPosToNs.ensure(perChar * 2); b.dCflag.ensure(perChar); b.dMask.ensure(perChar * 8); b.dMoff.ensure(perChar * 4);
 		b.dNNs.ensure(nC * 4 + 16); b.dMatchForm.ensure(totMatch * 4 + 16);
 		b.dNodes.ensure(totNodes * sizeof(DevNode) + 16); b.dTmpNodes.ensure(totNodes * sizeof(DevNode) + 16);
-		b.dEndPosMap.ensure(perChar * 4); b.dTmpIdx.ensure(totNodes * 4 + 16); b.dNNodes.ensure(nC * 4 + 16);
+		b.dEndPosMap.ensure(perChar * 4); b.dFullMask.ensure(perChar * 8); b.dZAt.ensure(perChar); b.dTmpIdx.ensure(totNodes * 4 + 16); b.dNNodes.ensure(nC * 4 + 16);
 		b.dPacks.ensure((size_t)b.packBase[nC] * sizeof(CandStatic) + 16);
 		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
 		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
@@ -261,7 +261,7 @@ namespace kamd
 		w.matchMask = b.dMask.as<uint64_t>(); w.matchOff = b.dMoff.as<uint32_t>(); w.nNs = b.dNNs.as<uint32_t>();
 		w.matchBase = b.dMatchBase.as<uint32_t>(); w.matchForm = b.dMatchForm.as<uint32_t>();
 		w.nodeBase = b.dNodeBase.as<uint32_t>(); w.nodes = b.dNodes.as<DevNode>(); w.tmpNodes = b.dTmpNodes.as<DevNode>();
-		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>();
+		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.fullMask = b.dFullMask.as<uint64_t>(); w.zAt = b.dZAt.as<uint8_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>();
 		w.packBase = b.dPackBase.as<uint32_t>(); w.packs = b.dPacks.as<CandStatic>();
 		w.stateBase = b.dStateBase.as<uint64_t>(); w.states = b.dStates.as<DevState>();
 		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();

@@ -157,10 +157,11 @@ namespace kamd
 	{
 		const ModelView* M; const SearchParams* P;
 		const uint16_t* str; const uint16_t* nsToPos; const uint16_t* posToNs;
-		DevNode* out; uint32_t* endPosMap; uint32_t nOut, cap; bool overflow;
+		DevNode* out; uint32_t* endPosMap; uint64_t* fullMask; uint8_t* zAt; uint32_t nOut, cap; bool overflow;
 	};
 
-	__device__ __forceinline__ bool latAppend(LatticeCtx& L, uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, uint32_t nMap)
+	// `qual`: the node counts for hasFormAlready (zero typo cost and unknown-or-has-a-full-morpheme); `lenKey`: its length there
+	__device__ __forceinline__ bool latAppend(LatticeCtx& L, uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, uint32_t nMap, bool qual = false, uint32_t lenKey = 0, uint8_t zbits = 0)
 	{
 		const uint32_t ms = L.endPosMap[s];
 		if ((ms & 0xFFFF) == (ms >> 16)) return false;
@@ -171,6 +172,8 @@ namespace kamd
 		nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = 0; nn.nflags = 0; nn.nPrev = 0; nn.packOff = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0;
 		L.out[id] = nn;
 		if (e >= nMap) return true;
+		if (qual && lenKey >= 1 && lenKey <= 64) L.fullMask[e] |= 1ull << (lenKey - 1);
+		if (zbits) L.zAt[e] |= zbits;
 		const uint32_t me = L.endPosMap[e];
 		if ((me & 0xFFFF) == (me >> 16)) L.endPosMap[e] = id | ((id + 1) << 16);
 		else
@@ -191,6 +194,8 @@ namespace kamd
 
 	__device__ bool latHasForm(const LatticeCtx& L, uint32_t s, uint32_t e)   // Splitter::hasFormAlready (KTrie.cpp:897-905)
 	{
+		// nodes are indexed by (end, length) in a 64-bit mask per end position; only longer spans need the scan
+		if (e - s <= 64) return (L.fullMask[e] >> (e - s - 1)) & 1;
 		const uint32_t me = L.endPosMap[e];
 		uint32_t a = me & 0xFFFF; const uint32_t b = me >> 16;
 		if (a == b) return false;
@@ -219,14 +224,14 @@ namespace kamd
 			if (lastPos != s && !latHasForm(L, lastPos, e))
 			{
 				uint32_t o, l; latTrim(L, L.nsToPos[lastPos], L.nsToPos[e - 1] + 1 - L.nsToPos[lastPos], o, l);
-				latAppend(L, lastPos, e, NOFORM, o, l, nMap);
+				latAppend(L, lastPos, e, NOFORM, o, l, nMap, true, l);
 			}
 		}
 		const uint32_t limit = hasJ ? L.P->maxUnkJ : L.P->maxUnk;
 		if (e - s <= limit)
 		{
 			uint32_t o, l; latTrim(L, L.nsToPos[s], L.nsToPos[e - 1] + 1 - L.nsToPos[s], o, l);
-			latAppend(L, s, e, NOFORM, o, l, nMap);
+			latAppend(L, s, e, NOFORM, o, l, nMap, true, l);
 		}
 	}
 
@@ -255,10 +260,10 @@ namespace kamd
 
 		LatticeCtx L;
 		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk;
-		L.out = W.tmpNodes + nBase; L.endPosMap = W.endPosMap + cOff + chunk; L.nOut = 0; L.cap = cap; L.overflow = false;
+		L.out = W.tmpNodes + nBase; L.endPosMap = W.endPosMap + cOff + chunk; L.fullMask = W.fullMask + cOff + chunk; L.zAt = W.zAt + cOff + chunk; L.nOut = 0; L.cap = cap; L.overflow = false;
 		const uint32_t nMap = nNs + 1;
 		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { W.results[chunk].status = CS_ERR_TOO_LONG; return; }
-		for (uint32_t i = 0; i < nMap; ++i) L.endPosMap[i] = 0;     // first == second : empty
+		for (uint32_t i = 0; i < nMap; ++i) { L.endPosMap[i] = 0; L.fullMask[i] = 0; L.zAt[i] = 0; }    // first == second : empty
 		L.endPosMap[0] = 0 | (1u << 16);
 		{
 			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
@@ -313,18 +318,7 @@ namespace kamd
 				if (overridden && (cflag[j] & 1)) resetNs = L.posToNs[j] + 1;
 				bool zc = false, zs = false;
 				const uint32_t p = L.posToNs[j];
-				if (p < nNs)
-				{
-					const uint32_t me = L.endPosMap[p];
-					for (uint32_t i = me & 0xFFFF; i < (me >> 16); ++i)
-					{
-						const DevNode g = L.out[i];
-						if (g.endPos != p || g.form == NOFORM) continue;
-						const uint8_t ff = M.forms[g.form].flags;
-						zc = zc || (ff & FF_ZCODA_APPENDABLE);
-						zs = zs || (ff & FF_ZSIOT_APPENDABLE);
-					}
-				}
+				if (p < nNs) { const uint8_t zb = L.zAt[p]; zc = zb & FF_ZCODA_APPENDABLE; zs = zb & FF_ZSIOT_APPENDABLE; }
 				if ((P.match & M_Z_CODA) && zc && isHangulCoda(ch) && (j + 1 >= n || !isHangulSyllable(str[j + 1]))) { zcand = true; zform = kDefaultTagSize + (ch - 0x11A8) - 1; }
 				else if ((P.match & (M_SPLIT_SAISIOT | M_MERGE_SAISIOT)) && zs && ch == 0x11BA && j + 1 < n && isHangulSyllable(str[j + 1])) { zcand = true; zform = kDefaultTagSize + (0x11BA - 0x11A8) - 1; }
 			}
@@ -372,7 +366,7 @@ namespace kamd
 				}
 				if (se <= P.spaceTol)
 				{
-					if (latAppend(L, nb, ne, fi, 0, 0, nMap)) L.out[L.nOut - 1].spaceErrors = (uint8_t)(se > 255 ? 255 : se);
+					if (latAppend(L, nb, ne, fi, 0, 0, nMap, (f.flags & FF_HAS_ANY_FULL) != 0, flen, f.flags & 3)) L.out[L.nOut - 1].spaceErrors = (uint8_t)(se > 255 ? 255 : se);
 				}
 			}
 		}
