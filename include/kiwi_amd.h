@@ -46,8 +46,8 @@ kamd_results_h kamd_analyze_batch(kamd_engine_h h, const uint16_t* texts, const 
 	uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
 
 kamd_batch_h kamd_stage(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint64_t match_options, int open_ending, int host_threads);
-/* launches the kernels on the staged batch; ms_out[4] = {dictionary scan, lattice build (+ candidate expansion), best-path search}
-   summed over the sub-batches (HIP events on the launching streams), and the number of search launches */
+/* launches the kernels on the staged batch; ms_out[4] = {dictionary scan, lattice build (+ candidate expansion), best-path search,
+   end stage (candidate sort + back-trace)} in milliseconds, summed over the sub-batches (HIP events on the launching streams) */
 int kamd_run(kamd_engine_h h, kamd_batch_h b, float* ms_out);
 kamd_results_h kamd_fetch(kamd_engine_h h, kamd_batch_h b, uint32_t top_n);
 /* info[0]=chunks, [1]=non-space normalised units ("jamo"), [2]=device bytes of the staged batch */

@@ -204,7 +204,7 @@ class KiwiAmd:
         ms = np.zeros(4, np.float32)
         if self.lib.kamd_run(self.h, batch.h, ms.ctypes.data) != 0:
             raise self._err("kamd_run")
-        return {"scan_ms": float(ms[0]), "lattice_ms": float(ms[1]), "search_ms": float(ms[2]), "search_launches": int(ms[3])}
+        return {"scan_ms": float(ms[0]), "lattice_ms": float(ms[1]), "search_ms": float(ms[2]), "finish_ms": float(ms[3])}
 
     def fetch(self, batch: Batch, top_n=1) -> Results:
         r = self.lib.kamd_fetch(self.h, batch.h, top_n)

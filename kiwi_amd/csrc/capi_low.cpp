@@ -95,7 +95,7 @@ extern "C"
 	int kamd_run(kamd_engine_h h, kamd_batch_h b, float* ms)
 	{
 		if (!h || !b) return -2;
-		return guarded([&]() { auto t = h->e->run(*b->b); if (ms) { ms[0] = t.scanMs; ms[1] = t.latticeMs; ms[2] = t.searchMs; ms[3] = (float)t.searchLaunches; } return 0; }, -1);
+		return guarded([&]() { auto t = h->e->run(*b->b); if (ms) { ms[0] = t.scanMs; ms[1] = t.latticeMs; ms[2] = t.searchMs; ms[3] = t.finishMs; } return 0; }, -1);
 	}
 	kamd_results_h kamd_fetch(kamd_engine_h h, kamd_batch_h b, uint32_t topN)
 	{

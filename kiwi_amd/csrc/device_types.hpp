@@ -71,7 +71,9 @@ namespace kamd
 
 	constexpr uint32_t kMaxPathsPerChunk = 8;
 	struct DevPathHeader { float score; uint32_t tokOff; uint16_t nTokens; uint8_t prevState, curState; };
-	struct DevChunkResult { uint32_t nPaths; uint32_t status; DevPathHeader paths[kMaxPathsPerChunk]; };
+	// nEnd/endOff: end-node candidates of the chunk, left by k_best_path in the unused tail of the chunk's state arena
+	// (entry index endOff, 24-byte records) for k_finish_paths
+	struct DevChunkResult { uint32_t nPaths; uint32_t status; DevPathHeader paths[kMaxPathsPerChunk]; uint32_t nEnd, endOff; };
 
 	enum ChunkStatus : uint32_t
 	{
@@ -136,5 +138,19 @@ namespace kamd
 		DevChunkResult* results;       // [c]
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
 		uint32_t bigScratchBytes;      // per wave
+		uint32_t* beacon;              // developer aid (KAMD_BEACON builds): host-visible progress word per lane, or null
 	};
+
+#ifdef __HIPCC__
+	// Lanes of one wavefront exchange data through LDS / HBM between phases.  A memory fence alone orders one lane's own
+	// accesses; it does not stop the compiler from letting lanes that left a divergent loop early run ahead into the next
+	// phase (plain loads and stores may be duplicated into loop exits).  The wave barrier is a convergent no-op: every lane
+	// that reaches this point in the source reaches it together in the generated code, so the phases stay separated.
+	__device__ inline __attribute__((always_inline)) void waveSync()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	}
+#endif
 }

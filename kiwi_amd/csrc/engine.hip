@@ -1,6 +1,10 @@
 // Batch driver (see engine.hpp).  Device memory is plain hipMalloc'd arenas sized from the batch's chunk
 // lengths; one stream; three kernel launches per round.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <unistd.h>
+#include <cstdio>
+#include <cstring>
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -307,10 +311,11 @@ namespace kamd
 			upload(b.dOrder, order, sA);
 			b.subBatches = S;
 		}
-		const size_t nEv = 5 * (size_t)S + 2;
+		const size_t nEv = 6 * (size_t)S + 2;
 		while (I.evs.size() < nEv) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); I.evs.push_back(e); }
 		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), sA));
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
+		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
 		const uint32_t nGroups = 64u / (uint32_t)I.groupLanes;
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
 		const uint32_t maxBlocks = std::min(I.persistBlocks, (maxWork + nGroups - 1) / nGroups);
@@ -320,7 +325,7 @@ namespace kamd
 		for (uint32_t k = 0; k < S; ++k)
 		{
 			const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S), cn = c1 - c0;
-			hipEvent_t* e = &I.evs[5 * (size_t)k];
+			hipEvent_t* e = &I.evs[6 * (size_t)k];
 			HIPCHECK(hipEventRecord(e[0], sA));
 			hipLaunchKernelGGL(k_dict_scan, dim3((cn + 3) / 4), dim3(256), 0, sA, I.dview, b.bv, b.wv, c0, cn);
 			HIPCHECK(hipEventRecord(e[1], sA));
@@ -332,6 +337,16 @@ namespace kamd
 			const uint32_t blocks = std::min(I.persistBlocks, (cn + nGroups - 1) / nGroups);
 			// consecutive searches may overlap at their tails: alternate between two scratch halves
 			WorkView wv = b.wv;
+			wv.beacon = nullptr;
+#ifdef KAMD_BEACON
+			{
+				static uint32_t* hostBeacon = nullptr; static size_t hostBeaconN = 0;
+				const size_t need = (size_t)I.persistBlocks * 64;
+				if (hostBeaconN < need) { HIPCHECK(hipHostMalloc((void**)&hostBeacon, need * 4, hipHostMallocCoherent | hipHostMallocMapped)); hostBeaconN = need; }
+				memset(hostBeacon, 0, need * 4);
+				wv.beacon = hostBeacon;
+			}
+#endif
 			wv.bigScratch = I.bigScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(GroupScratch) : 0);
 			uint32_t* counter = I.counter.as<uint32_t>() + k;
 			const uint32_t* order = b.dOrder.as<uint32_t>() + c0;
@@ -344,18 +359,67 @@ namespace kamd
 			default: hipLaunchKernelGGL(k_best_path<64>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
 			}
 			HIPCHECK(hipEventRecord(e[4], sB));
+			hipLaunchKernelGGL(k_finish_paths, dim3((cn + 63) / 64), dim3(64), 0, sB, I.dview, b.bv, wv, sp, c0, cn);
+			HIPCHECK(hipEventRecord(e[5], sB));
+			if (getenv("KAMD_HANGDUMP"))
+			{
+				// developer aid: if the search kernel does not finish in 6 s, read back (on a third stream, while it is still
+				// running) how far every chunk got -- results, per-node state counts -- print the stragglers and exit
+				for (int ms = 0; ms < 6000 && hipEventQuery(e[4]) == hipErrorNotReady; ++ms) usleep(1000);
+				if (hipEventQuery(e[4]) == hipErrorNotReady)
+				{
+					hipStream_t sC; HIPCHECK(hipStreamCreateWithFlags(&sC, hipStreamNonBlocking));
+					std::vector<DevChunkResult> res(nC); std::vector<uint32_t> nn(nC), cnt(b.nodeBase[nC]), cntr(64);
+					HIPCHECK(hipMemcpyAsync(res.data(), b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost, sC));
+					HIPCHECK(hipMemcpyAsync(nn.data(), b.dNNodes.p, nC * 4, hipMemcpyDeviceToHost, sC));
+					HIPCHECK(hipMemcpyAsync(cnt.data(), b.dNodeStCnt.p, cnt.size() * 4, hipMemcpyDeviceToHost, sC));
+					HIPCHECK(hipMemcpyAsync(cntr.data(), I.counter.p, 256, hipMemcpyDeviceToHost, sC));
+					HIPCHECK(hipStreamSynchronize(sC));
+					fprintf(stderr, "[hangdump] search kernel still running; chunks %u, work counter %u, blocks %u, groups/wave %u\n", nC, cntr[k], blocks, nGroups);
+					uint32_t shown = 0, done = 0;
+					for (uint32_t c = 0; c < nC; ++c)
+					{
+						uint32_t reached = 0;
+						for (uint32_t j = 0; j < nn[c]; ++j) if (cnt[b.nodeBase[c] + j] == 0xFFFFFFFFu) break; else reached = j + 1;
+						const bool fin = res[c].status != CS_OK || res[c].nPaths != 0;
+						done += fin;
+						if (!fin && shown < 24) { ++shown; fprintf(stderr, "  chunk %u text %u: status %u nPaths %u nEnd %u endOff %u nodes %u, node records written up to %u\n", c, (uint32_t)b.refs[c].text, res[c].status, res[c].nPaths, res[c].nEnd, res[c].endOff, nn[c], reached); }
+					}
+					fprintf(stderr, "[hangdump] finished chunks: %u / %u\n", done, nC);
+					fflush(stderr);
+					_exit(7);
+				}
+			}
+#ifdef KAMD_BEACON
+			if (wv.beacon)
+			{
+				// developer aid: wait a bounded time for the search kernel; on a hang print where each lane was last seen
+				for (int ms = 0; ms < 8000 && hipEventQuery(e[4]) == hipErrorNotReady; ++ms) usleep(1000);
+				if (hipEventQuery(e[4]) == hipErrorNotReady)
+				{
+					std::map<uint32_t, uint32_t> hist;
+					for (uint32_t w = 0; w < blocks; ++w) for (uint32_t l = 0; l < 64; ++l) ++hist[wv.beacon[(size_t)w * 64 + l] >> 8 << 8];
+					fprintf(stderr, "[beacon] search kernel still running after 8 s; last phase words (code<<24|node<<8) : lanes\n");
+					for (auto& kv : hist) fprintf(stderr, "  %08x : %u\n", kv.first, kv.second);
+					for (uint32_t w = 0; w < std::min(blocks, 2u); ++w) { fprintf(stderr, "  wave %u:", w); for (uint32_t l = 0; l < 64; ++l) fprintf(stderr, " %08x", wv.beacon[(size_t)w * 64 + l]); fprintf(stderr, "\n"); }
+					fflush(stderr);
+					_exit(7);
+				}
+			}
+#endif
 		}
 		HIPCHECK(hipGetLastError());
 		HIPCHECK(hipStreamSynchronize(sA));
 		HIPCHECK(hipStreamSynchronize(sB));
 		for (uint32_t k = 0; k < S; ++k)
 		{
-			hipEvent_t* e = &I.evs[5 * (size_t)k];
-			float a = 0, l = 0, r = 0;
+			hipEvent_t* e = &I.evs[6 * (size_t)k];
+			float a = 0, l = 0, r = 0, f = 0;
 			HIPCHECK(hipEventElapsedTime(&a, e[0], e[1]));
 			HIPCHECK(hipEventElapsedTime(&l, e[1], e[2]));
 			HIPCHECK(hipEventElapsedTime(&r, e[3], e[4]));
-			t.scanMs += a; t.latticeMs += l; t.searchMs += r;
+			HIPCHECK(hipEventElapsedTime(&f, e[4], e[5]));
+			t.scanMs += a; t.latticeMs += l; t.searchMs += r; t.finishMs += f;
 		}
 		t.searchLaunches = S;
 		b.ran = true;

@@ -20,7 +20,7 @@ namespace kamd
 		uint32_t maxUnkFormSize = 6, maxUnkFormSizeFollowedByJClass = 0xFFFFFFFFu, spaceTolerance = 0;
 	};
 
-	struct KernelTimes { float scanMs = 0, latticeMs = 0, searchMs = 0; uint32_t searchLaunches = 1; };   // sums over the sub-batches of one run
+	struct KernelTimes { float scanMs = 0, latticeMs = 0, searchMs = 0, finishMs = 0; uint32_t searchLaunches = 1; };   // sums over the sub-batches of one run
 
 	struct StagedBatch;   // chunks of one round resident in HBM
 

@@ -82,7 +82,7 @@ namespace kamd
 		if (lane == 0) { posToNs[n] = (uint16_t)nsCount; W.nNs[chunk] = nsCount; }
 		const uint32_t nNs = nsCount;
 		for (uint32_t e = lane; e <= nNs; e += 64) mask[e] = 0;
-		__threadfence_block();
+		waveSync();
 
 		// ---- 2. trie walk, pass 1: mark terminals ------------------------------------------------------
 		for (uint32_t base = 0; base < nNs; base += 64)
@@ -101,7 +101,7 @@ namespace kamd
 				if (M.trie[node].value >= 0) atomicOr((unsigned long long*)&mask[i + 1], 1ull << (depth - 1));
 			}
 		}
-		__threadfence_block();
+		waveSync();
 
 		// ---- 3. exclusive scan of popcounts -> per-end offsets ----------------------------------------
 		uint32_t total = 0;
@@ -124,7 +124,7 @@ namespace kamd
 			if (lane == 0) W.results[chunk].status = CS_ERR_MATCH_OVERFLOW;
 			return;
 		}
-		__threadfence_block();
+		waveSync();
 
 		// ---- 4. pass 2: fill packed form lists, longest form first within an end position -------------
 		uint32_t* forms = W.matchForm + mBase;

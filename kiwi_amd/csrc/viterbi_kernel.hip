@@ -36,6 +36,44 @@
 namespace kamd
 {
 	constexpr uint64_t KINVALID = ~0ull;
+// Inlining level of the search kernel's stages.  Level 1 (default): the batch evaluation is inlined into evaluateNode,
+// which itself, the end stage and the Knlm walk stay real functions.  Fully inlined (level >= 2) the hipcc of ROCm 7.2
+// generated gfx950 code in which the end-stage loop of EVERY chunk never terminated (nested divergent loops, > 270 SGPRs
+// of lane masks spilled to VGPR lanes); tools/quick_gpu.py with KAMD_HANGDUMP=1 reproduces it.  Run time is the same.
+#ifndef KAMD_INL
+#define KAMD_INL 1
+#endif
+#if KAMD_INL >= 1
+#define INL1 __forceinline__
+#else
+#define INL1 __noinline__
+#endif
+#if KAMD_INL >= 2
+#define INL2 __forceinline__
+#else
+#define INL2 __noinline__
+#endif
+#if KAMD_INL >= 3
+#define INL3 __forceinline__
+#else
+#define INL3
+#endif
+#ifdef KAMD_BEACON
+	// KAMD_BEACON = level: 1 chunk/node marks only, 2 + per candidate list, 3 + per batch, 4 everything
+	__device__ constexpr bool beaconOn(uint32_t c) { return c <= 2 || c >= 0x0E || (KAMD_BEACON >= 2 && (c == 3 || c == 0x0C)) || (KAMD_BEACON >= 3 && (c == 4 || c == 0x0B)) || KAMD_BEACON >= 4; }
+#define BEACON(X, code) { if (beaconOn((uint32_t)(code) >> 24) && (X).beacon) __hip_atomic_store((X).beacon, (uint32_t)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+#else
+#define BEACON(X, code)
+#endif
+#ifdef KAMD_WATCH
+	// developer aid: every loop that could spin on corrupt input counts its trips; a tripped guard leaves a mark and breaks
+	__device__ unsigned int gWatch[32];
+#define GUARD_DECL(n) uint32_t n = 0;
+#define GUARD(n, limit, site) if (++n > (limit)) { atomicAdd(&gWatch[site], 1u); break; }
+#else
+#define GUARD_DECL(n)
+#define GUARD(n, limit, site)
+#endif
 #ifdef KAMD_PROFILE
 	__device__ unsigned long long gProf[16];
 #define PROF(X, i) { const uint64_t t_ = wall_clock64(); (X).prof[i] += t_ - (X).profT; (X).profT = t_; }
@@ -50,6 +88,14 @@ namespace kamd
 	// All LDS of the kernel is one dynamic array; per-group slices are addressed by byte offsets so that every access
 	// keeps its address space (ds_* instructions) even inside non-inlined helpers.
 	extern __shared__ __align__(16) uint8_t kSmem[];
+	// Every LDS access goes through an address_space(3) pointer, so it is a ds_* instruction by construction: a generic
+	// pointer that the optimiser cannot trace back to kSmem (e.g. merged with an HBM pointer in a select) would become a
+	// flat_* access, which is slower and waits on both memory counters.
+#define LDS_AS __attribute__((address_space(3)))
+	typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+	template<class T> __device__ __forceinline__ LDS_AS T* ldsPtr(uint32_t off) { return (LDS_AS T*)((LDS_AS uint8_t*)kSmem + off); }
+	__device__ __forceinline__ uint4 ldsLoad4(uint32_t off) { const u32x4_t v = *ldsPtr<u32x4_t>(off); return make_uint4(v.x, v.y, v.z, v.w); }
+	__device__ __forceinline__ void ldsStore4(uint32_t off, const uint4 a) { u32x4_t v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w; *ldsPtr<u32x4_t>(off) = v; }
 
 	template<int G>
 	struct Lay
@@ -64,12 +110,29 @@ namespace kamd
 		static constexpr uint32_t RBEG = STBITS + SCAP;             // u32[RING]
 		static constexpr uint32_t REND = RBEG + 4 * RING;
 		static constexpr uint32_t RLIVE = REND + 4 * RING;          // u16[RING]
-		static constexpr uint32_t SIZE = (RLIVE + 2 * RING + 15) & ~15u;
+		// G == 64 (one chunk per wave): the chunk's lattice, candidate records and path heads are kept LDS-resident, so
+		// that inside the node loop only the Knlm walk reads HBM
+		static constexpr uint32_t HCAP = G == 64 ? 256 : 0;         // hot state quads (+ typo cost) cached
+		static constexpr uint32_t NCAP = G == 64 ? 96 : 0;          // lattice nodes cached
+		static constexpr uint32_t PCAP = G == 64 ? 160 : 0;         // static candidate records cached
+		static constexpr uint32_t HOT = (RLIVE + 2 * RING + 15) & ~15u;   // uint4[HCAP]
+		static constexpr uint32_t HTYPO = HOT + 16 * HCAP;          // f32[HCAP]
+		static constexpr uint32_t NODES = HTYPO + 4 * HCAP;         // 32 B x NCAP
+		static constexpr uint32_t PACKS = NODES + 32 * NCAP;        // 48 B x (PCAP + 2): last two = the unknown-noun candidates
+		static constexpr uint32_t SIZE = (PACKS + 48 * (G == 64 ? PCAP + 2 : 0) + 15) & ~15u;
 		static constexpr uint32_t LB = (64 / G) * SIZE;              // f32[2*T_MAX+1], shared by the groups
 		static constexpr uint32_t TOTAL = LB + 4 * (2 * T_MAX + 1);
 	};
 	void searchKernelProfile(unsigned long long* out16, bool reset)
 	{
+#ifdef KAMD_WATCH
+		{
+			unsigned int w[32];
+			(void)hipMemcpyFromSymbol(w, HIP_SYMBOL(gWatch), sizeof(w));
+			for (int i = 0; i < 32; ++i) if (w[i]) fprintf(stderr, "[watch] guard %d tripped %u times\n", i, w[i]);
+			fprintf(stderr, "[watch] read\n");
+		}
+#endif
 #ifdef KAMD_PROFILE
 		(void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(gProf), 16 * sizeof(unsigned long long));
 		if (reset) { unsigned long long z[16] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof(z)); }
@@ -110,8 +173,7 @@ namespace kamd
 	};
 	__device__ __forceinline__ Cand loadCand(uint32_t ldsOff)
 	{
-		const uint4* p = reinterpret_cast<const uint4*>(kSmem + ldsOff);
-		const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+		const uint4 a = ldsLoad4(ldsOff), b = ldsLoad4(ldsOff + 16), c = ldsLoad4(ldsOff + 32), d = ldsLoad4(ldsOff + 48);
 		Cand o;
 		o.lmId = a.x; o.lastSeqId = a.y; o.chunkOff = a.z; o.userScore = __uint_as_float(a.w);
 		o.combinedId = (int32_t)b.x; o.flagsFeat = b.y; o.tagw = b.z; o.cntw = b.w;
@@ -152,8 +214,10 @@ namespace kamd
 	__device__ __forceinline__ bool lmLookup(const ModelView& M, uint32_t node, uint32_t wid, int32_t& v, float& ll)
 	{
 		uint32_t b = lmHashOf(node, wid) & M.lmHashMask;
+		GUARD_DECL(g1)
 		for (;;)
 		{
+			GUARD(g1, 100000, 1)
 			const uint4* p = reinterpret_cast<const uint4*>(M.lmHash + (size_t)b * 4);
 			const uint4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
 			if (s0.x == node && s0.y == wid) { v = (int32_t)s0.z; ll = __uint_as_float(s0.w); return true; }
@@ -166,11 +230,16 @@ namespace kamd
 	}
 
 	// KnLangModel::progress (src/Knlm.cpp:44-130); float additions in the same order
-	__device__ float lmProgress(const ModelView& M, int32_t& node, uint32_t next)
+	__device__ INL3 float lmProgress(const ModelView& M, int32_t& node, uint32_t next)
 	{
+#if defined(KAMD_ELIDE) && (KAMD_ELIDE & 1)
+		node = (int32_t)((lmHashOf((uint32_t)node, next) & 0xFFFFu) + 1); return -1.f;    // timing experiment: no Knlm memory traffic
+#endif
 		float acc = 0;
+		GUARD_DECL(g2)
 		for (;;)
 		{
+			GUARD(g2, 1000, 2)
 			int32_t v; float ll;
 			if (node == 0)
 			{
@@ -186,8 +255,10 @@ namespace kamd
 			if (v > 0) { node += v; return acc + ll; }
 			// leaf: the new state is the longest suffix context that continues with `next` (Knlm.cpp:96-128)
 			int32_t cur = node;
+			GUARD_DECL(g3)
 			for (;;)
 			{
+				GUARD(g3, 1000, 3)
 				const int32_t lower = M.lmBackoff[cur].lower;
 				if (!lower) break;
 				cur += lower;
@@ -241,7 +312,7 @@ namespace kamd
 	struct GroupCtx
 	{
 		static constexpr uint64_t GMASK = G == 64 ? ~0ull : ((1ull << G) - 1);
-		const ModelView* M; const SearchParams* P;
+		const ModelView& M; const SearchParams& P;
 		uint32_t gl, gshift, lds;       // lane in group, group's first lane, byte offset of the group's LDS slice
 		const DevNode* nodes; uint32_t Gn;
 		const uint16_t* str; const uint8_t* cls;
@@ -250,6 +321,7 @@ namespace kamd
 		const uint8_t* uniq; uint32_t nUniq;
 		bool overflow, pairOverflow, stageOverflow;
 		GroupScratch* scratch;
+		uint32_t* beacon;
 #ifdef KAMD_PROFILE
 		uint64_t prof[8]; uint64_t profT;
 #endif
@@ -259,20 +331,78 @@ namespace kamd
 		__device__ __forceinline__ uint32_t prefix(uint64_t b) const { return __popcll(b & ((1ull << gl) - 1)); }
 		template<class T> __device__ __forceinline__ T bcast(T v, int srcLane) const { return __shfl(v, srcLane, G); }
 		// LDS accessors (address space preserved)
-		__device__ __forceinline__ uint64_t* qKey() const { return reinterpret_cast<uint64_t*>(kSmem + lds + Lay<G>::KEY); }
-		__device__ __forceinline__ float* qScore() const { return reinterpret_cast<float*>(kSmem + lds + Lay<G>::SCORE); }
-		__device__ __forceinline__ float* qFcs() const { return reinterpret_cast<float*>(kSmem + lds + Lay<G>::FCS); }
+		__device__ __forceinline__ LDS_AS uint64_t* qKey() const { return ldsPtr<uint64_t>(lds + Lay<G>::KEY); }
+		__device__ __forceinline__ LDS_AS float* qScore() const { return ldsPtr<float>(lds + Lay<G>::SCORE); }
+		__device__ __forceinline__ LDS_AS float* qFcs() const { return ldsPtr<float>(lds + Lay<G>::FCS); }
 		__device__ __forceinline__ uint32_t candOff(uint32_t k) const { return lds + Lay<G>::CAND + 64 * k; }
-		__device__ __forceinline__ uint32_t candQOff(uint32_t k) const { return reinterpret_cast<const uint32_t*>(kSmem + candOff(k))[9]; }
-		__device__ __forceinline__ float* stScore() const { return reinterpret_cast<float*>(kSmem + lds + Lay<G>::STSCORE); }
-		__device__ __forceinline__ uint8_t* stBits() const { return kSmem + lds + Lay<G>::STBITS; }
-		__device__ __forceinline__ uint32_t* ringBeg() const { return reinterpret_cast<uint32_t*>(kSmem + lds + Lay<G>::RBEG); }
-		__device__ __forceinline__ uint32_t* ringEnd() const { return reinterpret_cast<uint32_t*>(kSmem + lds + Lay<G>::REND); }
-		__device__ __forceinline__ uint16_t* ringLive() const { return reinterpret_cast<uint16_t*>(kSmem + lds + Lay<G>::RLIVE); }
-		__device__ __forceinline__ const float* lb() const { return reinterpret_cast<const float*>(kSmem + Lay<G>::LB); }
+		__device__ __forceinline__ uint32_t candQOff(uint32_t k) const { return *ldsPtr<uint32_t>(candOff(k) + 36); }
+		__device__ __forceinline__ LDS_AS float* stScore() const { return ldsPtr<float>(lds + Lay<G>::STSCORE); }
+		__device__ __forceinline__ LDS_AS uint8_t* stBits() const { return ldsPtr<uint8_t>(lds + Lay<G>::STBITS); }
+		__device__ __forceinline__ LDS_AS uint32_t* ringBeg() const { return ldsPtr<uint32_t>(lds + Lay<G>::RBEG); }
+		__device__ __forceinline__ LDS_AS uint32_t* ringEnd() const { return ldsPtr<uint32_t>(lds + Lay<G>::REND); }
+		__device__ __forceinline__ LDS_AS uint16_t* ringLive() const { return ldsPtr<uint16_t>(lds + Lay<G>::RLIVE); }
+		__device__ __forceinline__ const LDS_AS float* lb() const { return ldsPtr<float>(Lay<G>::LB); }
 	};
 
 	struct NodeEnv { uint32_t pBeg, nP, nLive; uint32_t nodeIdx, nodeStart; uint8_t nflags, fflags; };
+
+	template<int G>
+	__device__ __forceinline__ Hot getHot(const GroupCtx<G>& X, uint32_t i)
+	{
+		if constexpr (Lay<G>::HCAP != 0)
+		{
+			if (i < Lay<G>::HCAP)
+			{
+				const uint4 a = ldsLoad4(X.lds + Lay<G>::HOT + 16 * i);
+				Hot h; h.lmNode = (int32_t)a.x; h.accScore = __uint_as_float(a.y); h.w2 = a.z; h.w3 = a.w;
+				return h;
+			}
+		}
+		return loadHot(X.st, i);
+	}
+	template<int G>
+	__device__ __forceinline__ float getTypo(const GroupCtx<G>& X, uint32_t i)
+	{
+		if constexpr (Lay<G>::HCAP != 0) { if (i < Lay<G>::HCAP) return ldsPtr<float>(X.lds + Lay<G>::HTYPO)[i]; }
+		return X.st[i].accTypoCost;
+	}
+	template<int G>
+	__device__ __forceinline__ void putState(GroupCtx<G>& X, uint32_t i, int32_t lmNode, float acc, float typo, uint32_t wid, uint16_t leftFeat, uint8_t rootId, uint8_t sp,
+		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode)
+	{
+		storeState(X.st, i, lmNode, acc, typo, wid, leftFeat, rootId, sp, socket, prevFlags, ownKind, parent, morph, fcs, nodeId, ownNode);
+		if constexpr (Lay<G>::HCAP != 0)
+		{
+			if (i < Lay<G>::HCAP)
+			{
+				ldsStore4(X.lds + Lay<G>::HOT + 16 * i, make_uint4((uint32_t)lmNode, __float_as_uint(acc),
+					(uint32_t)leftFeat | ((uint32_t)rootId << 16) | ((uint32_t)sp << 24), (uint32_t)socket | ((uint32_t)prevFlags << 8) | ((uint32_t)ownKind << 24)));
+				ldsPtr<float>(X.lds + Lay<G>::HTYPO)[i] = typo;
+			}
+		}
+	}
+	template<int G>
+	__device__ __forceinline__ void markDead(GroupCtx<G>& X, uint32_t i)
+	{
+		X.st[i].dead = 1;
+		if constexpr (Lay<G>::HCAP != 0) { if (i < Lay<G>::HCAP) ldsPtr<uint32_t>(X.lds + Lay<G>::HOT)[4 * i + 3] |= 1u << 16; }
+	}
+	template<int G>
+	__device__ __forceinline__ DevNode getNode(const GroupCtx<G>& X, uint32_t i)
+	{
+		if constexpr (Lay<G>::NCAP != 0)
+		{
+			if (i < Lay<G>::NCAP)
+			{
+				DevNode nd;
+				const uint4 a[2] = { ldsLoad4(X.lds + Lay<G>::NODES + 32 * i), ldsLoad4(X.lds + Lay<G>::NODES + 32 * i + 16) };
+				__builtin_memcpy(&nd, a, sizeof(nd));
+				return nd;
+			}
+		}
+		return X.nodes[i];
+	}
+
 
 	// records a freshly written state of the current node for pruning / reachability (LDS; falls back to HBM when a node
 	// produces more than SCAP states)
@@ -290,17 +420,20 @@ namespace kamd
 	// One batch of regular candidates (packed records in LDS) against the incoming paths [pBeg, pBeg+nP): Qtot work items.
 	// mode: 0 small container, 1 medium (4 hash buckets), 2 large (PathEvaluator.hpp:447-466).
 	template<int G>
-	__device__ __noinline__ void evalBatch(GroupCtx<G>& X, uint32_t nC, uint32_t Qtot, const NodeEnv& E, float ignoreCondScore, uint8_t ownKind, uint16_t ownFeat, int mode)
+	__device__ INL1 void evalBatch(GroupCtx<G>& X, uint32_t nC, uint32_t Qtot, const NodeEnv& E, float ignoreCondScore, uint8_t ownKind, uint16_t ownFeat, int mode)
 	{
-		const ModelView& M = *X.M;
+		const ModelView& M = X.M;
 		const bool big = Qtot > QCAP;
+		BEACON(X, 0x05000000u | (E.nodeIdx << 8) | Qtot)
 		const uint32_t pBeg = E.pBeg;
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		PROF(X, 1)
 
 		// ---- scoring pass: one work item per lane -------------------------------------------------------
+		GUARD_DECL(g7)
 		for (uint32_t qb = 0; qb < Qtot; qb += G)
 		{
+			GUARD(g7, 100000, 7)
 			const uint32_t q = qb + X.gl;
 			bool valid = q < Qtot;
 			uint32_t k = 0;
@@ -311,7 +444,7 @@ namespace kamd
 				const Cand c = loadCand(X.candOff(k));
 				const uint32_t local = q - c.qOff;
 				const uint32_t p = local / c.R, r = local % c.R;
-				const Hot ps = loadHot(X.st, pBeg + p);
+				const Hot ps = getHot<G>(X, pBeg + p);
 				const bool single = c.single();
 				const uint8_t ctag = c.tag(), csock = c.socket();
 				uint32_t firstWid = c.firstWid; bool widReplaced = false;
@@ -326,7 +459,7 @@ namespace kamd
 						if (ps.socket() != csock || single) { valid = false; break; }
 						if (spaceBefore)
 						{
-							if (X.P->spaceTol > 0) cand -= X.P->spacePenalty; else { valid = false; break; }
+							if (X.P.spaceTol > 0) cand -= X.P.spacePenalty; else { valid = false; break; }
 						}
 					}
 					if (csock && !single)
@@ -335,10 +468,10 @@ namespace kamd
 						// (PathEvaluator.hpp:578-591: `firstWid` is assigned inside the loop and never reset)
 						for (int32_t pp = (int32_t)p; pp >= 0; --pp)
 						{
-							const Hot qs = loadHot(X.st, pBeg + pp);
+							const Hot qs = getHot<G>(X, pBeg + pp);
 							if (qs.dead() || !qs.socket() || qs.socket() != csock) continue;
 							if ((qs.leftFeat() & LF_PREV_ZSIOT) && (!isNNClass(ctag) || spaceBefore)) continue;
-							if (spaceBefore && !(X.P->spaceTol > 0)) continue;
+							if (spaceBefore && !(X.P.spaceTol > 0)) continue;
 							firstWid = M.morphs[M.morphs[X.st[pBeg + pp].wid].combinedId].lmId; widReplaced = true;
 							break;
 						}
@@ -355,7 +488,9 @@ namespace kamd
 					{
 						// prohibit <v> without <chunk> (PathEvaluator.hpp:604-608): static per candidate unless the word id was replaced above
 						if (widReplaced ? (M.morphs[firstWid].tag == T_P) : ((c.flags() & MF_FIRST_WID_IS_P) != 0)) { valid = false; break; }
+						BEACON(X, 0x07000000u | (E.nodeIdx << 8))
 						float ll = lmProgress(M, lmNode, firstWid);
+						BEACON(X, 0x08000000u | (E.nodeIdx << 8))
 						cand += ll; firstChunk += ll;
 						if (!single)
 						{
@@ -391,16 +526,19 @@ namespace kamd
 				else { X.qKey()[q] = key; X.qScore()[q] = cand; X.qFcs()[q] = firstChunk; }
 			}
 		}
-		__threadfence_block();
+		waveSync();
 		PROF(X, 2)
+		BEACON(X, 0x09000000u | (E.nodeIdx << 8))
 
 		// ---- emission pass: representatives in container iteration order, each carrying its key's winner ----
 		const int nBuckets = mode == 1 ? 4 : 1;
 		for (int b = 0; b < nBuckets; ++b)
 		{
 			uint32_t emittedInBucket = 0;
+			GUARD_DECL(g8)
 			for (uint32_t qb = 0; qb < Qtot; qb += G)
 			{
+				GUARD(g8, 100000, 8)
 				const uint32_t q = qb + X.gl;
 				bool rep = false; uint32_t qw = q; uint64_t key = KINVALID; uint32_t k = 0;
 				if (q < Qtot) key = big ? X.scratch->key[q] : X.qKey()[q];
@@ -410,8 +548,10 @@ namespace kamd
 					const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
 					rep = true;
 					float best = -INFINITY; bool haveBest = false;
+					GUARD_DECL(g5)
 					for (uint32_t j = lo; j < hi; ++j)
 					{
+						GUARD(g5, 100000, 5)
 						const uint64_t kj = big ? X.scratch->key[j] : X.qKey()[j];
 						if (kj != key) continue;
 						if (j < q) { rep = false; break; }
@@ -442,14 +582,14 @@ namespace kamd
 						const float wfcs = big ? X.scratch->fcs[qw] : X.qFcs()[qw];
 						const uint32_t local = qw - c.qOff;
 						const uint32_t parent = pBeg + local / c.R, r = local % c.R;
-						const float wtypo = X.st[parent].accTypoCost + 0.f;
+						const float wtypo = getTypo<G>(X, parent) + 0.f;
 						const bool single = c.single();
 						const uint8_t rootKey = (uint8_t)(wkey >> 40);
 						const uint8_t newRoot = (c.quoteOrBullet() && rootKey == COMMON_ROOT) ? (uint8_t)r : rootKey;
 						const uint8_t stSocket = single ? c.socket() : 0;
 						const bool own = single && ownKind;
 						const uint16_t lf = own ? (uint16_t)(ownFeat | (c.leftFeat() & (LF_TAG_SSC | LF_PREV_ZSIOT))) : c.leftFeat();
-						storeState(X.st, pos, (int32_t)(uint32_t)wkey, wscore, wtypo, c.lastSeqId, lf, newRoot, (uint8_t)(wkey >> 32), stSocket, c.prevFlags(),
+						putState<G>(X, pos, (int32_t)(uint32_t)wkey, wscore, wtypo, c.lastSeqId, lf, newRoot, (uint8_t)(wkey >> 32), stSocket, c.prevFlags(),
 							own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0);
 						stageState<G>(X, pos - E.nodeStart, wscore, newRoot, c.socket() != 0, stSocket != 0);
 					}
@@ -462,15 +602,16 @@ namespace kamd
 		X.overflow = X.any(X.overflow);
 		X.stageOverflow = X.any(X.stageOverflow);
 		if (X.stTop > X.stCap) X.stTop = X.stCap;
-		__threadfence_block();
+		waveSync();
 		PROF(X, 3)
+		BEACON(X, 0x0A000000u | (E.nodeIdx << 8))
 	}
 
 	// z_coda / z_siot shortcut (PathEvaluator.hpp:389-432): copies of the qualifying incoming paths
 	template<int G>
-	__device__ __noinline__ void evalZShortcut(GroupCtx<G>& X, uint32_t zMorph, const NodeEnv& E)
+	__device__ INL1 void evalZShortcut(GroupCtx<G>& X, uint32_t zMorph, const NodeEnv& E)
 	{
-		const ModelView& M = *X.M;
+		const ModelView& M = X.M;
 		const MorphRec cm = M.morphs[zMorph];
 		const uint32_t newMorph = cm.lmId;
 		const MorphRec nm = M.morphs[newMorph];
@@ -492,12 +633,13 @@ namespace kamd
 				const uint32_t pos = X.stTop + X.prefix(bal);
 				if (pos < X.stCap)
 				{
-					ns.accScore += cm.userScore * X.P->typoCostWeight;
+					ns.accScore += cm.userScore * X.P.typoCostWeight;
 					ns.accTypoCost -= cm.userScore;
 					ns.parent = E.pBeg + p; ns.morph = newMorph; ns.wid = newMorph; ns.nodeId = (uint16_t)E.nodeIdx;
 					ns.leftFeat = ns.ownKind ? (uint16_t)((ns.leftFeat & (0x1FFF | LF_STR_SSC)) | (lfMorph & (LF_TAG_SSC | LF_PREV_ZSIOT))) : lfMorph;
 					ns.prevFlags = nm.prevFlags;
-					X.st[pos] = ns;
+					putState<G>(X, pos, ns.lmNode, ns.accScore, ns.accTypoCost, ns.wid, ns.leftFeat, ns.rootId, ns.spState, ns.socket, ns.prevFlags, ns.ownKind,
+						ns.parent, ns.morph, ns.firstChunkScore, ns.nodeId, ns.ownNode);
 					stageState<G>(X, pos - E.nodeStart, ns.accScore, ns.rootId, newMorphSocket, ns.socket != 0);
 				}
 				else X.overflow = true;
@@ -507,15 +649,15 @@ namespace kamd
 		X.overflow = X.any(X.overflow);
 		X.stageOverflow = X.any(X.stageOverflow);
 		if (X.stTop > X.stCap) X.stTop = X.stCap;
-		__threadfence_block();
+		waveSync();
 	}
 
 	// PathEvaluator::operator() (PathEvaluator.hpp:347-512) for one candidate list
 	template<int G>
-	__device__ __noinline__ void evaluateNode(GroupCtx<G>& X, const NodeEnv& E, const CandStatic* cands, uint32_t nCands, uint8_t ownKind, uint16_t ownFeat, float nodeLevelDiscount)
+	__device__ INL2 void evaluateNode(GroupCtx<G>& X, const NodeEnv& E, const CandStatic* cands, uint32_t ldsPack, uint32_t nCands, uint8_t ownKind, uint16_t ownFeat, float nodeLevelDiscount)
 	{
-		const ModelView& M = *X.M;
-		const SearchParams& P = *X.P;
+		const ModelView& M = X.M;
+		const SearchParams& P = X.P;
 		const int mode = E.nLive <= 128 ? 0 : E.nLive <= 512 ? 1 : 2;
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		enum { K_NONE = 0, K_SKIP = 1, K_Z = 2, K_REG = 3 };
@@ -524,17 +666,34 @@ namespace kamd
 		for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
 		{
 			uint32_t c = 0;
+			GUARD_DECL(g4)
 			while (c < nCands)
 			{
+				GUARD(g4, 100000, 4)
 				// ---- lane j classifies candidate c+j; then the group agrees on the next batch ----------------
+				BEACON(X, 0x04000000u | (E.nodeIdx << 8) | c)
 				const uint32_t idx = c + X.gl;
 				uint32_t kind = K_NONE, Q = 0, R = 1, mid = 0, sbType = 0;
 				uint4 m0 = make_uint4(0, 0, 0, 0), m1 = make_uint4(0, 0, 0, 0);
 				uint4 mx = make_uint4(0, 0, 0, 0);
 				if (idx < nCands && X.gl < (uint32_t)MAXC)
 				{
-					const uint4* cs = reinterpret_cast<const uint4*>(cands + idx);   // static record: one dependent level
-					m0 = cs[0]; m1 = cs[1]; mx = cs[2];
+					// static record: from the LDS-resident copy when the chunk's records fit, else one dependent HBM level
+					bool fromLds = false;
+					if constexpr (Lay<G>::PCAP != 0)
+					{
+						if (ldsPack + idx < Lay<G>::PCAP + 2)
+						{
+							const uint32_t po = X.lds + Lay<G>::PACKS + 48 * (ldsPack + idx);
+							m0 = ldsLoad4(po); m1 = ldsLoad4(po + 16); mx = ldsLoad4(po + 32);
+							fromLds = true;
+						}
+					}
+					if (!fromLds)
+					{
+						const uint4* cs = reinterpret_cast<const uint4*>(cands + idx);
+						m0 = cs[0]; m1 = cs[1]; mx = cs[2];
+					}
 					mid = mx.x; sbType = mx.z;
 					const uint32_t flags = m1.y & 0xFFFF; const uint8_t tag = (uint8_t)m1.z; const uint8_t special = (uint8_t)(m1.w >> 24);
 					if (P.splitComplex && (flags & MF_HAS_COMPLEX)) kind = K_SKIP;
@@ -574,12 +733,12 @@ namespace kamd
 					const uint8_t tag = (uint8_t)m1.z;
 					const float additional = __uint_as_float(m0.w) + nodeLevelDiscount + X.lb()[((E.nflags & NF_LEFT_BOUNDARY) ? T_MAX : 0) + clearIrregular(tag)] * 5.f;
 					const uint32_t ruleBits = ((isEClass(tag) && (E.fflags & FF_STARTS_WITH_A)) ? RB_POSITIVE_E : 0) | ((tag == T_SN && (E.nflags & NF_UFORM_ENDS_POINT)) ? RB_SN_POINT : 0);
-					uint4* o = reinterpret_cast<uint4*>(kSmem + X.candOff(myK));
-					o[0] = m0; o[1] = m1;
-					o[2] = make_uint4(mid, myOff, R, __float_as_uint(additional));
-					o[3] = make_uint4(sbType, ruleBits, mx.y, 0);
+					const uint32_t o = X.candOff(myK);
+					ldsStore4(o, m0); ldsStore4(o + 16, m1);
+					ldsStore4(o + 32, make_uint4(mid, myOff, R, __float_as_uint(additional)));
+					ldsStore4(o + 48, make_uint4(sbType, ruleBits, mx.y, 0));
 				}
-				__threadfence_block();
+				waveSync();
 				c += nTake;
 				if (nC) evalBatch<G>(X, nC, Qtot, E, ignoreCond ? -10.f : 0.f, ownKind, ownFeat, mode);
 				if (zShortcut) evalZShortcut<G>(X, zMorph, E);
@@ -590,6 +749,7 @@ namespace kamd
 		// ---- pruning (PathEvaluator.hpp:475-511): paths further than cutOff below the best of their root die.
 		// Nothing is moved: dead paths keep their slot (marked in LDS and HBM) and are skipped by every consumer.
 		PROF(X, 1)
+		BEACON(X, 0x0B000000u | (E.nodeIdx << 8))
 		const uint32_t cnt = X.stTop - E.nodeStart;
 		if (!cnt) return;
 		const bool staged = !X.stageOverflow;
@@ -597,8 +757,10 @@ namespace kamd
 		for (uint32_t rs = 0; rs < nRootSlots; ++rs)
 		{
 			float mx = -INFINITY; bool anyOfRoot = false;
+			GUARD_DECL(g10)
 			for (uint32_t b = 0; b < cnt; b += G)
 			{
+				GUARD(g10, 100000, 10)
 				const uint32_t i = b + X.gl;
 				if (i < cnt)
 				{
@@ -618,7 +780,7 @@ namespace kamd
 					if (staged)
 					{
 						const uint8_t bits = X.stBits()[i];
-						if (!(bits & SB_DEAD) && (uint32_t)(bits & SB_SLOT_MASK) == rs && X.stScore()[i] + P.cutOff < mx) { X.stBits()[i] = bits | SB_DEAD; X.st[E.nodeStart + i].dead = 1; }
+						if (!(bits & SB_DEAD) && (uint32_t)(bits & SB_SLOT_MASK) == rs && X.stScore()[i] + P.cutOff < mx) { X.stBits()[i] = bits | SB_DEAD; markDead<G>(X, E.nodeStart + i); }
 					}
 					else
 					{
@@ -629,7 +791,7 @@ namespace kamd
 				}
 			}
 		}
-		__threadfence_block();
+		waveSync();
 		PROF(X, 4)
 	}
 
@@ -643,7 +805,7 @@ namespace kamd
 		if (a.sp > b.sp) return false;
 		return a.score > b.score;
 	}
-	__device__ void insertionSortEnd(EndCand* v, int lo, int hi, bool guarded)
+	__device__ __forceinline__ void insertionSortEnd(EndCand* v, int lo, int hi, bool guarded)
 	{
 		for (int i = lo; i < hi; ++i)
 		{
@@ -652,7 +814,7 @@ namespace kamd
 			else { int j = i; while (endLess(val, v[j - 1])) { v[j] = v[j - 1]; --j; } v[j] = val; }
 		}
 	}
-	__device__ __noinline__ void sortEndCands(EndCand* v, int n)
+	__device__ __forceinline__ void sortEndCands(EndCand* v, int n)
 	{
 		if (n <= 16) { insertionSortEnd(v, 1, n, true); return; }
 		// introsort: median-of-three quick partitions down to 16-element runs (heap sort when the depth budget runs out),
@@ -720,7 +882,7 @@ namespace kamd
 	}
 
 	// generateTokenList (PathEvaluator.hpp:1038-1157) for one end candidate; single lane. Returns the token count or < 0.
-	__device__ __noinline__ int backTrace(const ModelView& M, const SearchParams& P, const DevNode* nodes, const DevState* st, uint32_t endParent, DevToken* out, uint32_t cap, uint32_t* chain)
+	__device__ INL3 int backTrace(const ModelView& M, const SearchParams& P, const DevNode* nodes, const DevState* st, uint32_t endParent, DevToken* out, uint32_t cap, uint32_t* chain, uint32_t chainCap)
 	{
 		// walk the parent chain once (newest first), then emit oldest first
 		uint32_t nSteps = 0;
@@ -728,7 +890,7 @@ namespace kamd
 		{
 			const uint32_t par = st[s].parent;
 			if (par == 0xFFFFFFFFu) break;
-			if (nSteps >= CHAINCAP) return -3;
+			if (nSteps >= chainCap) return -3;
 			chain[nSteps++] = s;
 			s = par;
 		}
@@ -796,20 +958,31 @@ namespace kamd
 		return nTok;
 	}
 
-	// End node (PathEvaluator.hpp:1320-1418): EOS transition, candidate sort, per-(root,state) selection, back-trace.
+	// End node, first half (PathEvaluator.hpp:1320-1358): EOS transition of every surviving path -> end-candidate list for k_finish_paths.
 	template<int G>
-	__device__ void finishChunk(GroupCtx<G>& X, const WorkView& W, uint32_t chunk, bool openEnding, DevChunkResult* res)
+	__device__ __noinline__ void finishChunk(GroupCtx<G>& X, const WorkView& W, uint32_t chunk, bool openEnding, DevChunkResult* res)
 	{
-		const ModelView& M = *X.M;
+		const ModelView& M = X.M;
 		const uint32_t Gn = X.Gn;
-		const DevNode en = X.nodes[Gn - 1];
+		const DevNode en = getNode<G>(X, Gn - 1);
 		const uint32_t firstPrev = Gn - 1 - en.prev;
 		const uint32_t pBeg = X.nodeStOff[firstPrev];
 		const uint32_t nP = (en.prev && en.nPrev) ? X.nodeStOff[firstPrev + en.nPrev - 1] + X.nodeStCnt[firstPrev + en.nPrev - 1] - pBeg : 0;
-		EndCand* endBuf = X.scratch->end;
+#ifdef KAMD_CRUMBS
+		if (X.gl == 0) { res->nEnd = 0xA2000000u; res->endOff = nP; }
+#endif
+		// candidates go to the unused tail of the chunk's state arena, followed by room for the back-trace chain (<= Gn steps)
+		EndCand* endBuf = reinterpret_cast<EndCand*>(X.st + X.stTop);
+		const uint64_t freeBytes = (uint64_t)(X.stCap - X.stTop) * sizeof(DevState);
+		const uint32_t endCap = freeBytes > (uint64_t)Gn * 4 ? (uint32_t)((freeBytes - (uint64_t)Gn * 4) / sizeof(EndCand)) : 0u;
 		uint32_t nEnd = 0; bool endOverflow = false;
+		GUARD_DECL(g11)
 		for (uint32_t pb = 0; pb < nP; pb += G)
 		{
+			GUARD(g11, 100000, 11)
+#ifdef KAMD_CRUMBS
+			if (X.gl == 0) res->nEnd = 0xA3000000u | pb;
+#endif
 			const uint32_t p = pb + X.gl;
 			bool ok = false; DevState ps{}; float c = 0, first = 0;
 			if (p < nP)
@@ -832,13 +1005,16 @@ namespace kamd
 					}
 				}
 			}
+#ifdef KAMD_CRUMBS
+			if (X.gl == 0) res->nEnd = 0xA4000000u | pb;
+#endif
 			const uint32_t mult = (ok && ps.rootId == COMMON_ROOT) ? X.nUniq : (ok ? 1u : 0u);
 			uint32_t incl = mult;
 			for (int d = 1; d < G; d <<= 1) { const uint32_t v = __shfl_up(incl, d, G); if ((int)X.gl >= d) incl += v; }
 			const uint32_t base = nEnd + incl - mult;
 			for (uint32_t r = 0; r < mult; ++r)
 			{
-				if (base + r < ENDCAP)
+				if (base + r < endCap)
 				{
 					EndCand e; e.score = c; e.fcs = first; e.typo = ps.accTypoCost; e.parent = pBeg + p; e.pad = 0;
 					if (ps.rootId == COMMON_ROOT) { e.rootId = (uint8_t)r; e.sp = X.uniq[r]; } else { e.rootId = ps.rootId; e.sp = ps.spState; }
@@ -847,49 +1023,66 @@ namespace kamd
 				else endOverflow = true;
 			}
 			nEnd += X.bcast(incl, G - 1);
+#ifdef KAMD_CRUMBS
+			if (X.gl == 0) res->nEnd = 0xA5000000u | pb;
+#endif
 		}
 		endOverflow = X.any(endOverflow);
-		__threadfence_block();
 		if (X.gl == 0)
 		{
-			uint32_t status = CS_OK; uint32_t nPaths = 0;
-			if (endOverflow) status = CS_ERR_PATH_OVERFLOW;
-			else
-			{
-				sortEndCands(endBuf, (int)nEnd);
-				uint32_t numUniq = 0;
-				for (uint32_t a = 0; a < nEnd; ++a)
-				{
-					bool seen = false;
-					for (uint32_t b = 0; b < a && !seen; ++b) seen = endBuf[b].rootId == endBuf[a].rootId && endBuf[b].sp == endBuf[a].sp;
-					if (!seen) ++numUniq;
-				}
-				const uint32_t perGroup = numUniq ? (2 + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq), topN = 1
-				DevToken* tok = W.tokens + W.tokenBase[chunk];
-				const uint32_t tokCap = (uint32_t)(W.tokenBase[chunk + 1] - W.tokenBase[chunk]);
-				uint32_t tokTop = 0, startIdx = 0;
-				for (uint32_t a = 0; a < nEnd && status == CS_OK; ++a)
-				{
-					if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
-					if (a - startIdx >= perGroup) continue;
-					if (nPaths >= kMaxPathsPerChunk) { status = CS_ERR_PATH_OVERFLOW; break; }
-					const int nt = backTrace(M, *X.P, X.nodes, X.st, endBuf[a].parent, tok + tokTop, tokCap - tokTop, X.scratch->chain);
-					if (nt < 0) { status = CS_ERR_TOKEN_OVERFLOW; break; }
-					DevPathHeader& ph = res->paths[nPaths++];
-					ph.score = endBuf[a].score; ph.tokOff = tokTop; ph.nTokens = (uint16_t)nt;
-					ph.prevState = X.uniq[endBuf[a].rootId]; ph.curState = endBuf[a].sp;
-					tokTop += (uint32_t)nt;
-				}
-			}
-			res->status = status; res->nPaths = status == CS_OK ? nPaths : 0;
+			res->nEnd = nEnd; res->endOff = X.stTop; res->nPaths = 0;
+			res->status = endOverflow ? CS_ERR_STATE_OVERFLOW : CS_OK;
 		}
 	}
 
-	template<int G>
-	__device__ void searchChunk(GroupCtx<G>& X, const BatchView& B, const WorkView& W, uint32_t chunk)
+	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418); one thread per chunk
+	__global__ void __launch_bounds__(64) k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount)
 	{
-		const ModelView& M = *X.M;
-		const SearchParams& P = *X.P;
+		const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+		if (t >= chunkCount) return;
+		const uint32_t chunk = chunkBegin + t;
+		DevChunkResult* res = &W.results[chunk];
+		if (res->status != CS_OK) return;
+		const uint32_t nEnd = res->nEnd;
+		const uint32_t nBase = W.nodeBase[chunk];
+		const uint32_t Gn = W.nNodes[chunk];
+		DevState* st = W.states + W.stateBase[chunk];
+		EndCand* endBuf = reinterpret_cast<EndCand*>(st + res->endOff);
+		uint32_t* chain = reinterpret_cast<uint32_t*>(endBuf + nEnd);
+		const uint8_t* uniq = B.spStates + B.spOff[chunk];
+		uint32_t status = CS_OK; uint32_t nPaths = 0;
+		sortEndCands(endBuf, (int)nEnd);
+		uint32_t numUniq = 0;
+		for (uint32_t a = 0; a < nEnd; ++a)
+		{
+			bool seen = false;
+			for (uint32_t b = 0; b < a && !seen; ++b) seen = endBuf[b].rootId == endBuf[a].rootId && endBuf[b].sp == endBuf[a].sp;
+			if (!seen) ++numUniq;
+		}
+		const uint32_t perGroup = numUniq ? (2 + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq), topN = 1
+		DevToken* tok = W.tokens + W.tokenBase[chunk];
+		const uint32_t tokCap = (uint32_t)(W.tokenBase[chunk + 1] - W.tokenBase[chunk]);
+		uint32_t tokTop = 0, startIdx = 0;
+		for (uint32_t a = 0; a < nEnd && status == CS_OK; ++a)
+		{
+			if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
+			if (a - startIdx >= perGroup) continue;
+			if (nPaths >= kMaxPathsPerChunk) { status = CS_ERR_PATH_OVERFLOW; break; }
+			const int nt = backTrace(M, P, W.nodes + nBase, st, endBuf[a].parent, tok + tokTop, tokCap - tokTop, chain, Gn);
+			if (nt < 0) { status = CS_ERR_TOKEN_OVERFLOW; break; }
+			DevPathHeader& ph = res->paths[nPaths++];
+			ph.score = endBuf[a].score; ph.tokOff = tokTop; ph.nTokens = (uint16_t)nt;
+			ph.prevState = uniq[endBuf[a].rootId]; ph.curState = endBuf[a].sp;
+			tokTop += (uint32_t)nt;
+		}
+		res->status = status; res->nPaths = status == CS_OK ? nPaths : 0;
+	}
+
+	template<int G>
+	__device__ INL3 void searchChunk(GroupCtx<G>& X, const BatchView& B, const WorkView& W, uint32_t chunk)
+	{
+		const ModelView& M = X.M;
+		const SearchParams& P = X.P;
 		DevChunkResult* res = &W.results[chunk];
 		if (res->status != CS_OK) { if (X.gl == 0) res->nPaths = 0; return; }
 		const uint32_t cOff = B.charOff[chunk];
@@ -905,25 +1098,43 @@ namespace kamd
 		uint8_t* reach = W.reach + nBase;
 		if (X.nUniq + 1 > SB_SLOT_MASK) { if (X.gl == 0) { res->status = CS_ERR_PATH_OVERFLOW; res->nPaths = 0; } return; }
 
+		if constexpr (Lay<G>::NCAP != 0)
+		{
+			// chunk prologue: lattice nodes and static candidate records become LDS-resident (coalesced 16-byte loads)
+			const uint32_t nN = Gn < Lay<G>::NCAP ? Gn : Lay<G>::NCAP;
+			const uint4* src = reinterpret_cast<const uint4*>(X.nodes);
+			for (uint32_t k = X.gl; k < 2 * nN; k += G) ldsStore4(X.lds + Lay<G>::NODES + 16 * k, src[k]);
+			const DevNode lastN = X.nodes[Gn - 1];
+			uint32_t nPk = lastN.packOff + lastN.candCnt;
+			if (nPk > Lay<G>::PCAP) nPk = Lay<G>::PCAP;
+			const uint4* psrc = reinterpret_cast<const uint4*>(W.packs + W.packBase[chunk]);
+			for (uint32_t k = X.gl; k < 3 * nPk; k += G) ldsStore4(X.lds + Lay<G>::PACKS + 16 * k, psrc[k]);
+			const uint4* usrc = reinterpret_cast<const uint4*>(M.unkPacks);
+			for (uint32_t k = X.gl; k < 6; k += G) ldsStore4(X.lds + Lay<G>::PACKS + 16 * (3 * Lay<G>::PCAP + k), usrc[k]);
+			waveSync();
+		}
 		// start node (PathEvaluator.hpp:1224-1226)
 		if (X.gl == 0)
 		{
 			const MorphRec m0 = M.morphs[0];
-			storeState(X.st, 0, M.h.bosNode, 0.f, 0.f, 0, m0.feat, COMMON_ROOT, 0, 0, m0.prevFlags, 0, 0xFFFFFFFFu, 0, 0.f, 0, 0);
+			putState<G>(X, 0, M.h.bosNode, 0.f, 0.f, 0, m0.feat, COMMON_ROOT, 0, 0, m0.prevFlags, 0, 0xFFFFFFFFu, 0, 0.f, 0, 0);
 			X.nodeStOff[0] = 0; X.nodeStCnt[0] = 1; X.nodeLive[0] = 1;
 			X.ringBeg()[0] = 0; X.ringEnd()[0] = 1; X.ringLive()[0] = 1;
 		}
 		X.stTop = 1;
 		for (uint32_t k = X.gl; k < Gn; k += G) reach[k] = k == 0 ? 1 : 0;
-		__threadfence_block();
+		waveSync();
 
 		const CandStatic* unkPacks = reinterpret_cast<const CandStatic*>(M.unkPacks);
 		const CandStatic* packs = W.packs + W.packBase[chunk];
-		DevNode nextNode = X.nodes[Gn > 2 ? 1 : 0];
+		DevNode nextNode = getNode<G>(X, Gn > 2 ? 1 : 0);
+		GUARD_DECL(g6)
 		for (uint32_t i = 1; i + 1 < Gn; ++i)
 		{
+			GUARD(g6, 70000, 6)
 			const DevNode node = nextNode;
-			if (i + 2 < Gn) nextNode = X.nodes[i + 1];      // prefetch: in flight while this node is processed
+			BEACON(X, 0x02000000u | (i << 8))
+			if (i + 2 < Gn) nextNode = getNode<G>(X, i + 1);      // prefetch: in flight while this node is processed
 			NodeEnv E;
 			const uint32_t firstPrev = i - node.prev, lastPrev = firstPrev + node.nPrev - 1;
 			if (i - firstPrev < RING)
@@ -931,7 +1142,8 @@ namespace kamd
 				E.pBeg = X.ringBeg()[firstPrev & (RING - 1)];
 				E.nP = X.ringEnd()[lastPrev & (RING - 1)] - E.pBeg;
 				E.nLive = 0;
-				for (uint32_t j = firstPrev; j <= lastPrev; ++j) E.nLive += X.ringLive()[j & (RING - 1)];
+				GUARD_DECL(g12)
+				for (uint32_t j = firstPrev; j <= lastPrev; ++j) { GUARD(g12, 100000, 12) E.nLive += X.ringLive()[j & (RING - 1)]; }
 			}
 			else
 			{
@@ -950,66 +1162,84 @@ namespace kamd
 
 			PROF(X, 0)
 			const uint8_t ownKind = node.uformLen ? 1 : 0; const uint16_t ownFeat = node.ownFeat;
-			if (node.form != NOFORM)
+			// up to three candidate lists per node, evaluated through ONE inlined copy of evaluateNode:
+			//   pass 0  the form's candidates, or the two unknown-word candidates of a formless node
+			//   pass 1  forms whose candidates are all partial morphemes also get an unknown proper-noun reading (PathEvaluator.hpp:1277-1287)
+			//   pass 2  a node that left the lattice disconnected gets the unknown-word candidates (PathEvaluator.hpp:1286-1299)
+			for (int pass = 0; pass < 3; ++pass)
 			{
-				evaluateNode<G>(X, E, packs + node.packOff, node.candCnt, ownKind, ownFeat, baseDiscount + 0.f);
-				// forms whose candidates are all partial morphemes also get an unknown proper-noun reading (PathEvaluator.hpp:1277-1287)
-				if (node.nflags & NF_ALL_PARTIAL)
+				const CandStatic* cl; uint32_t clLds, clN; uint8_t ok; uint16_t of; float disc;
+				if (pass == 0)
 				{
-					const FormRec f = M.forms[node.form];
-					const uint16_t* fs = M.formChars + f.charOff;
-					uint16_t of = featMask(fs, f.len) & 0x1FFF;
-					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
-					evaluateNode<G>(X, E, unkPacks + 1, 1, 2, of, baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias));
-				}
-				// reachable[i] and the forward re-scan of the persistent flags (PathEvaluator.hpp:1159-1176, 1286-1299)
-				const uint32_t cntNow = X.stTop - nodeStart;
-				bool anyFree = false;
-				for (uint32_t b = 0; b < cntNow; b += G)
-				{
-					const uint32_t k = b + X.gl;
-					if (k < cntNow)
+					if (node.form != NOFORM)
 					{
-						if (!X.stageOverflow) { const uint8_t bits = X.stBits()[k]; if (!(bits & (SB_DEAD | SB_STATE_SOCKET))) anyFree = true; }
-						else { const DevState* s = &X.st[nodeStart + k]; if (!s->dead && !s->socket) anyFree = true; }
+						cl = packs + node.packOff; clLds = (node.packOff + node.candCnt <= Lay<G>::PCAP) ? node.packOff : 0xFFFF0000u; clN = node.candCnt;
+						ok = ownKind; of = ownFeat; disc = baseDiscount + 0.f;
+					}
+					else
+					{
+						const float emo = (X.cls[node.uformOff] & 0x80) ? -10.f : 0.f;
+						cl = unkPacks; clLds = Lay<G>::PCAP; clN = 2; ok = ownKind; of = ownFeat;
+						disc = baseDiscount + (emo - ((float)node.uformLen * P.oovRuleScale + P.oovRuleBias));
 					}
 				}
-				anyFree = X.any(anyFree);
-				if (X.gl == 0) reach[i] = anyFree ? 1 : 0;
-				if (!anyFree)
+				else if (pass == 1)
 				{
-					uint32_t disc = 0;
+					if (node.form == NOFORM) break;
+					if (!(node.nflags & NF_ALL_PARTIAL)) continue;
+					const FormRec f = M.forms[node.form];
+					const uint16_t* fs = M.formChars + f.charOff;
+					of = featMask(fs, f.len) & 0x1FFF;
+					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
+					cl = unkPacks + 1; clLds = Lay<G>::PCAP + 1; clN = 1; ok = 2;
+					disc = baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias);
+				}
+				else
+				{
+					// reachable[i] and the forward re-scan of the persistent flags (PathEvaluator.hpp:1159-1176, 1286-1299)
+					const uint32_t cntNow = X.stTop - nodeStart;
+					bool anyFree = false;
+					for (uint32_t b = 0; b < cntNow; b += G)
+					{
+						const uint32_t k = b + X.gl;
+						if (k < cntNow)
+						{
+							if (!X.stageOverflow) { const uint8_t bits = X.stBits()[k]; if (!(bits & (SB_DEAD | SB_STATE_SOCKET))) anyFree = true; }
+							else { const DevState* s = &X.st[nodeStart + k]; if (!s->dead && !s->socket) anyFree = true; }
+						}
+					}
+					anyFree = X.any(anyFree);
+					if (X.gl == 0) reach[i] = anyFree ? 1 : 0;
+					if (anyFree) break;
+					uint32_t dc = 0;
 					if (X.gl == 0)
 					{
 						for (uint32_t k = i + 1; k < Gn; ++k)
 						{
-							const DevNode nk = X.nodes[k];
+							const DevNode nk = getNode<G>(X, k);
 							uint8_t r = 0;
 							if (nk.prev) for (uint32_t pj = k - nk.prev, e = pj + nk.nPrev; pj < e; ++pj) if (reach[pj]) { r = 1; break; }
 							reach[k] = r;
 						}
-						disc = reach[Gn - 1] ? 0 : 1;
+						dc = reach[Gn - 1] ? 0 : 1;
 					}
-					disc = X.bcast(disc, 0);
-					if (disc)
+					dc = X.bcast(dc, 0);
+					if (!dc) break;
+					const uint32_t len = node.endPos - node.startPos;
+					of = featMask(X.str + node.startPos, len) & 0x1FFF;
+					if (len)
 					{
-						const uint32_t len = node.endPos - node.startPos;
-						uint16_t of = featMask(X.str + node.startPos, len) & 0x1FFF;
-						if (len)
-						{
-							const uint16_t c = X.str[node.endPos - 1];
-							const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(X.cls[node.endPos - 1] & 0x3F);
-							if (tag == T_SSC) of |= LF_STR_SSC;
-						}
-						const float emo = (X.cls[node.startPos] & 0x80) ? -10.f : 0.f;
-						evaluateNode<G>(X, E, unkPacks, 2, 3, of, baseDiscount + (emo - ((float)len * P.oovRuleScale + P.oovRuleBias)));
+						const uint16_t c = X.str[node.endPos - 1];
+						const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(X.cls[node.endPos - 1] & 0x3F);
+						if (tag == T_SSC) of |= LF_STR_SSC;
 					}
+					const float emo = (X.cls[node.startPos] & 0x80) ? -10.f : 0.f;
+					cl = unkPacks; clLds = Lay<G>::PCAP; clN = 2; ok = 3;
+					disc = baseDiscount + (emo - ((float)len * P.oovRuleScale + P.oovRuleBias));
 				}
-			}
-			else
-			{
-				const float emo = (X.cls[node.uformOff] & 0x80) ? -10.f : 0.f;
-				evaluateNode<G>(X, E, unkPacks, 2, ownKind, ownFeat, baseDiscount + (emo - ((float)node.uformLen * P.oovRuleScale + P.oovRuleBias)));
+				BEACON(X, 0x03000000u | (i << 8) | pass)
+				evaluateNode<G>(X, E, cl, clLds, clN, ok, of, disc);
+				BEACON(X, 0x0C000000u | (i << 8) | pass)
 			}
 			PROF(X, 0)
 			// node bookkeeping: state range + live count (LDS ring and HBM)
@@ -1029,7 +1259,7 @@ namespace kamd
 					X.nodeStOff[i] = nodeStart; X.nodeStCnt[i] = cntAll; X.nodeLive[i] = (uint16_t)(live > 0xFFFF ? 0xFFFF : live);
 				}
 			}
-			__threadfence_block();
+			waveSync();
 			PROF(X, 5)
 			if (X.overflow || X.pairOverflow) break;
 		}
@@ -1038,7 +1268,12 @@ namespace kamd
 			if (X.gl == 0) { res->status = X.overflow ? CS_ERR_STATE_OVERFLOW : CS_ERR_PAIR_OVERFLOW; res->nPaths = 0; }
 			return;
 		}
+		BEACON(X, 0x0E000000u)
+#ifdef KAMD_CRUMBS
+		if (X.gl == 0) res->nEnd = 0xA1000000u;
+#endif
 		finishChunk<G>(X, W, chunk, openEnding, res);
+		BEACON(X, 0x11000000u)
 		PROF(X, 6)
 #ifdef KAMD_PROFILE
 		if (X.gl == 0) for (int k = 0; k < 8; ++k) { atomicAdd(&gProf[k], (unsigned long long)X.prof[k]); X.prof[k] = 0; }
@@ -1056,7 +1291,7 @@ namespace kamd
 		// TagSequenceScorer tables (src/TagUtils.cpp:49-62): [0..T_MAX) without, [T_MAX..2*T_MAX) with a left boundary.
 		// Tag PA (== T_MAX) indexes one past a row in the reference (include/kiwi/TagUtils.h:10-18): row 0 spills into
 		// row 1, row 1 spills into the `weight` member (5.0) -- reproduced by the flat layout plus one extra slot.
-		float* lb = reinterpret_cast<float*>(kSmem + Lay<G>::LB);
+		LDS_AS float* lb = ldsPtr<float>(Lay<G>::LB);
 		for (uint32_t t = lane; t < 2 * T_MAX + 1; t += 64)
 		{
 			float v = 0;
@@ -1067,22 +1302,26 @@ namespace kamd
 		}
 		__syncthreads();
 
-		GroupCtx<G> X;
 		const uint32_t gid = lane / G;
-		X.M = &M; X.P = &P;
+		GroupCtx<G> X{ M, P };
 		X.gl = lane % G; X.gshift = gid * G; X.lds = gid * Lay<G>::SIZE;
 		X.scratch = reinterpret_cast<GroupScratch*>(W.bigScratch) + ((size_t)blockIdx.x * NG + gid);
+		X.beacon = W.beacon ? W.beacon + (size_t)blockIdx.x * 64 + lane : nullptr;
+		BEACON(X, 0x01000000u)
 #ifdef KAMD_PROFILE
 		for (int k = 0; k < 8; ++k) X.prof[k] = 0;
 		X.profT = wall_clock64();
 #endif
 
+		GUARD_DECL(g9)
 		for (;;)
 		{
+			GUARD(g9, 10000000, 9)
 			uint32_t ci = 0;
 			if (X.gl == 0) ci = atomicAdd(chunkCounter, 1u);
 			ci = X.bcast(ci, 0);
 			if (ci >= nWork) break;
+			BEACON(X, 0x01100000u | ci)
 			PROF(X, 7)
 			searchChunk<G>(X, B, W, chunkOrder[ci]);
 		}

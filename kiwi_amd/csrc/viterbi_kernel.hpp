@@ -12,7 +12,7 @@ namespace kamd
 
 	struct EndCand { float score, fcs, typo; uint32_t parent; uint8_t rootId, sp; uint16_t pad; };
 	// scratch in HBM per lane group (items of oversized batches, end-node candidates)
-	struct GroupScratch { uint64_t key[BIGQ]; float score[BIGQ]; float fcs[BIGQ]; EndCand end[ENDCAP]; uint32_t chain[CHAINCAP]; };
+	struct GroupScratch { uint64_t key[BIGQ]; float score[BIGQ]; float fcs[BIGQ]; };
 
 	uint32_t searchKernelLdsBytes(int G);
 	void searchKernelProfile(unsigned long long* out16, bool reset);   // phase cycle counters (builds with -DKAMD_PROFILE only)   // dynamic LDS the launch must request
@@ -20,4 +20,7 @@ namespace kamd
 	// G = lanes per chunk (4, 8, 16 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
 	template<int G>
 	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork);
+	// End stage, one THREAD per chunk: restated std::sort of the end candidates, per-(root, state) selection and the
+	// back-trace into 24-byte tokens.  A separate launch so that 64 chunks share a wavefront in this strictly serial stage.
+	__global__ void k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount);
 }

@@ -4,10 +4,13 @@ import numpy as np
 from kiwi_amd.api import KiwiAmd
 from kiwi_amd.workloads import get_workload
 p, t, d = get_workload(sys.argv[1] if len(sys.argv) > 1 else "c2")
+print('workload ready', flush=True)
 e = KiwiAmd(p)
+print('engine ready', flush=True)
 e.lib.kamd_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
 b = e.stage(t)
-e.run(b)
+print('staged', flush=True)
+print(e.run(b), flush=True)
 a = np.zeros(16, np.uint64)
 e.lib.kamd_debug_profile(a.ctypes.data, 1)
 for _ in range(3):
