@@ -286,6 +286,9 @@ namespace kamd
 		return p;
 	}
 
+#ifdef KAMD_TIMELINE
+	static void* gTimeline = nullptr;
+#endif
 	static KernelTimes launchAll(Engine::Impl& I, StagedBatch& b, const SearchParams& sp)
 	{
 		KernelTimes t;
@@ -338,6 +341,12 @@ namespace kamd
 			// consecutive searches may overlap at their tails: alternate between two scratch halves
 			WorkView wv = b.wv;
 			wv.beacon = nullptr;
+#ifdef KAMD_TIMELINE
+			static DevBuf tlBuf;
+			tlBuf.ensure((size_t)nC * 96);
+			HIPCHECK(hipMemsetAsync(tlBuf.p, 0, (size_t)nC * 96, sB));
+			wv.beacon = tlBuf.as<uint32_t>(); gTimeline = tlBuf.p;
+#endif
 #ifdef KAMD_BEACON
 			{
 				static uint32_t* hostBeacon = nullptr; static size_t hostBeaconN = 0;
@@ -411,6 +420,39 @@ namespace kamd
 		HIPCHECK(hipGetLastError());
 		HIPCHECK(hipStreamSynchronize(sA));
 		HIPCHECK(hipStreamSynchronize(sB));
+#ifdef KAMD_TIMELINE
+		if (getenv("KAMD_TIMELINE_PRINT") && gTimeline)
+		{
+			// developer aid: per-chunk stamps of the search kernel (constant 100 MHz clock) -> where a chunk's time goes
+			std::vector<unsigned long long> tl((size_t)nC * 12);
+			HIPCHECK(hipMemcpy(tl.data(), gTimeline, tl.size() * 8, hipMemcpyDeviceToHost));
+			unsigned long long t0 = ~0ull, tEnd = 0;
+			for (uint32_t c = 0; c < nC; ++c) if (tl[12ull * c]) { t0 = std::min(t0, tl[12ull * c]); tEnd = std::max(tEnd, tl[12ull * c + 2]); }
+			std::vector<double> start, nodes, fin, perNode;
+			for (uint32_t c = 0; c < nC; ++c)
+			{
+				if (!tl[12ull * c] || !tl[12ull * c + 2]) continue;
+				start.push_back((tl[12ull * c] - t0) * 0.01); nodes.push_back((tl[12ull * c + 1] - tl[12ull * c]) * 0.01); fin.push_back((tl[12ull * c + 2] - tl[12ull * c + 1]) * 0.01);
+				perNode.push_back(nodes.back() / std::max<double>(1.0, (double)(uint32_t)tl[12ull * c + 3]));
+			}
+			auto stat = [](std::vector<double> v, const char* name)
+			{
+				if (v.empty()) return;
+				std::sort(v.begin(), v.end());
+				double sum = 0; for (double x : v) sum += x;
+				fprintf(stderr, "[timeline] %-26s mean %9.1f  p50 %9.1f  p90 %9.1f  p99 %9.1f  max %9.1f  (us, n=%zu)\n", name, sum / v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back(), v.size());
+			};
+			fprintf(stderr, "[timeline] first chunk start -> last chunk end: %.1f us\n", (tEnd - t0) * 0.01);
+			static const char* phName[8] = { "ph0 node setup", "ph1 classify/batch form", "ph2 scoring (+Knlm)", "ph3 emission", "ph4 prune", "ph5 bookkeeping", "ph6 passes/reach", "ph7" };
+			for (int k = 0; k < 7; ++k)
+			{
+				std::vector<double> v;
+				for (uint32_t c = 0; c < nC; ++c) if (tl[12ull * c] && tl[12ull * c + 2]) v.push_back(tl[12ull * c + 4 + k] * 0.01 / std::max<double>(1.0, (double)(uint32_t)tl[12ull * c + 3]));
+				stat(v, phName[k]);
+			}
+			stat(start, "chunk start offset"); stat(nodes, "node loop"); stat(fin, "end-candidate stage"); stat(perNode, "node loop / node");
+		}
+#endif
 		for (uint32_t k = 0; k < S; ++k)
 		{
 			hipEvent_t* e = &I.evs[6 * (size_t)k];

@@ -36,12 +36,12 @@
 namespace kamd
 {
 	constexpr uint64_t KINVALID = ~0ull;
-// Inlining level of the search kernel's stages.  Level 1 (default): the batch evaluation is inlined into evaluateNode,
-// which itself, the end stage and the Knlm walk stay real functions.  Fully inlined (level >= 2) the hipcc of ROCm 7.2
+// Inlining level of the node loop's stages (3 = everything inlined into the kernel: the lane-group context then lives in
+// registers).  The end-candidate stage (finishChunk) always stays a real function: inlined as well, the hipcc of ROCm 7.2
 // generated gfx950 code in which the end-stage loop of EVERY chunk never terminated (nested divergent loops, > 270 SGPRs
-// of lane masks spilled to VGPR lanes); tools/quick_gpu.py with KAMD_HANGDUMP=1 reproduces it.  Run time is the same.
+// of lane masks spilled to VGPR lanes); tools/quick_gpu.py with KAMD_HANGDUMP=1 shows where a chunk stops.
 #ifndef KAMD_INL
-#define KAMD_INL 1
+#define KAMD_INL 3
 #endif
 #if KAMD_INL >= 1
 #define INL1 __forceinline__
@@ -74,6 +74,11 @@ namespace kamd
 #define GUARD_DECL(n)
 #define GUARD(n, limit, site)
 #endif
+#ifdef KAMD_TIMELINE
+#define TLMARK(X, k) { if ((X).gl == 0) { LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>((X).lds + Lay<G>::TLACC); const unsigned long long t_ = wall_clock64(); a_[k] += t_ - a_[8]; a_[8] = t_; } }
+#else
+#define TLMARK(X, k)
+#endif
 #ifdef KAMD_PROFILE
 	__device__ unsigned long long gProf[16];
 #define PROF(X, i) { const uint64_t t_ = wall_clock64(); (X).prof[i] += t_ - (X).profT; (X).profT = t_; }
@@ -96,6 +101,15 @@ namespace kamd
 	template<class T> __device__ __forceinline__ LDS_AS T* ldsPtr(uint32_t off) { return (LDS_AS T*)((LDS_AS uint8_t*)kSmem + off); }
 	__device__ __forceinline__ uint4 ldsLoad4(uint32_t off) { const u32x4_t v = *ldsPtr<u32x4_t>(off); return make_uint4(v.x, v.y, v.z, v.w); }
 	__device__ __forceinline__ void ldsStore4(uint32_t off, const uint4 a) { u32x4_t v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w; *ldsPtr<u32x4_t>(off) = v; }
+	// DPP rotation inside a row of 16 lanes (= one lane group when G == 16): a register-to-register cross-lane move, no LDS
+	// round trip.  Which neighbour a lane receives is read off by rotating the lane index along with the data.
+	template<int N> __device__ __forceinline__ uint32_t rowRor(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xF, 0xF, false); }
+	template<int N> __device__ __forceinline__ float rowRorF(float v) { return __uint_as_float(rowRor<N>(__float_as_uint(v))); }
+	__device__ __forceinline__ float rowMax16(float v)
+	{
+		v = fmaxf(v, rowRorF<8>(v)); v = fmaxf(v, rowRorF<4>(v)); v = fmaxf(v, rowRorF<2>(v)); v = fmaxf(v, rowRorF<1>(v));
+		return v;
+	}
 
 	template<int G>
 	struct Lay
@@ -109,17 +123,22 @@ namespace kamd
 		static constexpr uint32_t STBITS = STSCORE + 4 * SCAP;      // u8[SCAP]
 		static constexpr uint32_t RBEG = STBITS + SCAP;             // u32[RING]
 		static constexpr uint32_t REND = RBEG + 4 * RING;
-		static constexpr uint32_t RLIVE = REND + 4 * RING;          // u16[RING]
+		static constexpr uint32_t RLIVE = REND + 4 * RING;          // u32[RING]: live paths of nodes 0..j (running total)
 		// G == 64 (one chunk per wave): the chunk's lattice, candidate records and path heads are kept LDS-resident, so
 		// that inside the node loop only the Knlm walk reads HBM
 		static constexpr uint32_t HCAP = G == 64 ? 256 : 0;         // hot state quads (+ typo cost) cached
 		static constexpr uint32_t NCAP = G == 64 ? 96 : 0;          // lattice nodes cached
 		static constexpr uint32_t PCAP = G == 64 ? 160 : 0;         // static candidate records cached
-		static constexpr uint32_t HOT = (RLIVE + 2 * RING + 15) & ~15u;   // uint4[HCAP]
+		static constexpr uint32_t HOT = (RLIVE + 4 * RING + 15) & ~15u;   // uint4[HCAP]
 		static constexpr uint32_t HTYPO = HOT + 16 * HCAP;          // f32[HCAP]
 		static constexpr uint32_t NODES = HTYPO + 4 * HCAP;         // 32 B x NCAP
 		static constexpr uint32_t PACKS = NODES + 32 * NCAP;        // 48 B x (PCAP + 2): last two = the unknown-noun candidates
+#ifdef KAMD_TIMELINE
+		static constexpr uint32_t TLACC = (PACKS + 48 * (G == 64 ? PCAP + 2 : 0) + 15) & ~15u;   // u64[9]: 8 phase sums + last stamp
+		static constexpr uint32_t SIZE = (TLACC + 80 + 15) & ~15u;
+#else
 		static constexpr uint32_t SIZE = (PACKS + 48 * (G == 64 ? PCAP + 2 : 0) + 15) & ~15u;
+#endif
 		static constexpr uint32_t LB = (64 / G) * SIZE;              // f32[2*T_MAX+1], shared by the groups
 		static constexpr uint32_t TOTAL = LB + 4 * (2 * T_MAX + 1);
 	};
@@ -313,6 +332,14 @@ namespace kamd
 	{
 		static constexpr uint64_t GMASK = G == 64 ? ~0ull : ((1ull << G) - 1);
 		const ModelView& M; const SearchParams& P;
+		__device__ __forceinline__ GroupCtx(const ModelView& m, const SearchParams& p) : M(m), P(p) {}
+		// same lane-group state, other copies of the model / parameter views
+		__device__ __forceinline__ GroupCtx(const GroupCtx& o, const ModelView& m, const SearchParams& p) : M(m), P(p)
+		{
+			gl = o.gl; gshift = o.gshift; lds = o.lds; nodes = o.nodes; Gn = o.Gn; str = o.str; cls = o.cls; st = o.st; stCap = o.stCap; stTop = o.stTop;
+			nodeStOff = o.nodeStOff; nodeStCnt = o.nodeStCnt; nodeLive = o.nodeLive; uniq = o.uniq; nUniq = o.nUniq;
+			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; beacon = o.beacon;
+		}
 		uint32_t gl, gshift, lds;       // lane in group, group's first lane, byte offset of the group's LDS slice
 		const DevNode* nodes; uint32_t Gn;
 		const uint16_t* str; const uint8_t* cls;
@@ -340,7 +367,7 @@ namespace kamd
 		__device__ __forceinline__ LDS_AS uint8_t* stBits() const { return ldsPtr<uint8_t>(lds + Lay<G>::STBITS); }
 		__device__ __forceinline__ LDS_AS uint32_t* ringBeg() const { return ldsPtr<uint32_t>(lds + Lay<G>::RBEG); }
 		__device__ __forceinline__ LDS_AS uint32_t* ringEnd() const { return ldsPtr<uint32_t>(lds + Lay<G>::REND); }
-		__device__ __forceinline__ LDS_AS uint16_t* ringLive() const { return ldsPtr<uint16_t>(lds + Lay<G>::RLIVE); }
+		__device__ __forceinline__ LDS_AS uint32_t* ringCum() const { return ldsPtr<uint32_t>(lds + Lay<G>::RLIVE); }
 		__device__ __forceinline__ const LDS_AS float* lb() const { return ldsPtr<float>(Lay<G>::LB); }
 	};
 
@@ -428,6 +455,12 @@ namespace kamd
 		const uint32_t pBeg = E.pBeg;
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		PROF(X, 1)
+		TLMARK(X, 1)
+
+		// Common case (G == 16): the whole batch fits the group once and the node uses the small container -- scores stay in
+		// registers and the per-key de-duplication runs on DPP rotations instead of LDS scans.
+		const bool fast = (G == 16) && Qtot <= (uint32_t)G && mode == 0;
+		uint64_t rKey = KINVALID; float rScore = 0, rFcs = 0;
 
 		// ---- scoring pass: one work item per lane -------------------------------------------------------
 		GUARD_DECL(g7)
@@ -522,81 +555,116 @@ namespace kamd
 			{
 				// key: LM node | new special state | previous root | candidate ; r is recoverable from q
 				const uint64_t key = valid ? ((uint64_t)(uint32_t)lmNode | ((uint64_t)sp << 32) | ((uint64_t)rootKey << 40) | ((uint64_t)k << 48)) : KINVALID;
-				if (big) { X.scratch->key[q] = key; X.scratch->score[q] = cand; X.scratch->fcs[q] = firstChunk; }
+				rKey = key; rScore = cand; rFcs = firstChunk;
+				if (fast) {}
+				else if (big) { X.scratch->key[q] = key; X.scratch->score[q] = cand; X.scratch->fcs[q] = firstChunk; }
 				else { X.qKey()[q] = key; X.qScore()[q] = cand; X.qFcs()[q] = firstChunk; }
 			}
 		}
 		waveSync();
 		PROF(X, 2)
+		TLMARK(X, 2)
 		BEACON(X, 0x09000000u | (E.nodeIdx << 8))
 
 		// ---- emission pass: representatives in container iteration order, each carrying its key's winner ----
-		const int nBuckets = mode == 1 ? 4 : 1;
-		for (int b = 0; b < nBuckets; ++b)
+		// writes the state of key `wkey` (winner item qw of candidate k) at arena slot pos
+		auto emitState = [&](uint32_t k, uint32_t qw, uint64_t wkey, float wscore, float wfcs, uint32_t pos)
 		{
-			uint32_t emittedInBucket = 0;
-			GUARD_DECL(g8)
-			for (uint32_t qb = 0; qb < Qtot; qb += G)
+			const Cand c = loadCand(X.candOff(k));
+			const uint32_t local = qw - c.qOff;
+			const uint32_t parent = pBeg + local / c.R, r = local % c.R;
+			const float wtypo = getTypo<G>(X, parent) + 0.f;
+			const bool single = c.single();
+			const uint8_t rootKey = (uint8_t)(wkey >> 40);
+			const uint8_t newRoot = (c.quoteOrBullet() && rootKey == COMMON_ROOT) ? (uint8_t)r : rootKey;
+			const uint8_t stSocket = single ? c.socket() : 0;
+			const bool own = single && ownKind;
+			const uint16_t lf = own ? (uint16_t)(ownFeat | (c.leftFeat() & (LF_TAG_SSC | LF_PREV_ZSIOT))) : c.leftFeat();
+			putState<G>(X, pos, (int32_t)(uint32_t)wkey, wscore, wtypo, c.lastSeqId, lf, newRoot, (uint8_t)(wkey >> 32), stSocket, c.prevFlags(),
+				own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0);
+			stageState<G>(X, pos - E.nodeStart, wscore, newRoot, c.socket() != 0, stSocket != 0);
+		};
+		if (fast)
+		{
+			if constexpr (G == 16)
 			{
-				GUARD(g8, 100000, 8)
-				const uint32_t q = qb + X.gl;
-				bool rep = false; uint32_t qw = q; uint64_t key = KINVALID; uint32_t k = 0;
-				if (q < Qtot) key = big ? X.scratch->key[q] : X.qKey()[q];
-				if (key != KINVALID)
-				{
-					k = (uint32_t)(key >> 48);
-					const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
-					rep = true;
-					float best = -INFINITY; bool haveBest = false;
-					GUARD_DECL(g5)
-					for (uint32_t j = lo; j < hi; ++j)
-					{
-						GUARD(g5, 100000, 5)
-						const uint64_t kj = big ? X.scratch->key[j] : X.qKey()[j];
-						if (kj != key) continue;
-						if (j < q) { rep = false; break; }
-						const float s = big ? X.scratch->score[j] : X.qScore()[j];
-						if (!haveBest || s > best) { best = s; qw = j; haveBest = true; }
-					}
-					if (rep && mode == 1)
-					{
-						// bucket = (h >> 8) & 3 of Hash<WordLL> (BestPathContainer.hpp:80-85, 323)
-						const uint64_t lmv = (uint64_t)(int64_t)(int32_t)(uint32_t)key;
-						const uint64_t hh = (uint64_t)(((key >> 40) & 0xFF) | (((key >> 32) & 0xFF) << 8)) ^ ((lmv << 3) | (lmv >> 61));
-						rep = (int)((hh >> 8) & 3) == b;
-					}
-				}
-				const uint64_t bal = X.ballot(rep);
-				// mode 1 runs exactly one candidate per batch, so the per-bucket rank is the container's per-bucket fill
-				const uint32_t rank = emittedInBucket + X.prefix(bal);
-				const bool keep = rep && (mode == 2 || rank < 128);   // a full bucket drops later keys (BestPathContainer.hpp:363-367)
-				const uint64_t kbal = X.ballot(keep);
-				if (keep)
+				const uint32_t q = X.gl;
+				const uint32_t keyLo = (uint32_t)rKey, keyHi = (uint32_t)(rKey >> 32);
+				bool rep = rKey != KINVALID;
+				float best = rScore; uint32_t qw = q;
+#define KAMD_ROT_STEP(N) { const uint32_t oi = rowRor<N>(q), ol = rowRor<N>(keyLo), oh = rowRor<N>(keyHi); const float os = rowRorF<N>(rScore); \
+				if (ol == keyLo && oh == keyHi) { if (oi < q) rep = false; if (os > best || (os == best && oi < qw)) { best = os; qw = oi; } } }
+				KAMD_ROT_STEP(1) KAMD_ROT_STEP(2) KAMD_ROT_STEP(3) KAMD_ROT_STEP(4) KAMD_ROT_STEP(5) KAMD_ROT_STEP(6) KAMD_ROT_STEP(7) KAMD_ROT_STEP(8)
+				KAMD_ROT_STEP(9) KAMD_ROT_STEP(10) KAMD_ROT_STEP(11) KAMD_ROT_STEP(12) KAMD_ROT_STEP(13) KAMD_ROT_STEP(14) KAMD_ROT_STEP(15)
+#undef KAMD_ROT_STEP
+				const float wfcs = X.bcast(rFcs, (int)qw);
+				const uint64_t kbal = X.ballot(rep);
+				if (rep)
 				{
 					const uint32_t pos = X.stTop + X.prefix(kbal);
-					if (pos < X.stCap)
-					{
-						const Cand c = loadCand(X.candOff(k));
-						const uint64_t wkey = big ? X.scratch->key[qw] : X.qKey()[qw];
-						const float wscore = big ? X.scratch->score[qw] : X.qScore()[qw];
-						const float wfcs = big ? X.scratch->fcs[qw] : X.qFcs()[qw];
-						const uint32_t local = qw - c.qOff;
-						const uint32_t parent = pBeg + local / c.R, r = local % c.R;
-						const float wtypo = getTypo<G>(X, parent) + 0.f;
-						const bool single = c.single();
-						const uint8_t rootKey = (uint8_t)(wkey >> 40);
-						const uint8_t newRoot = (c.quoteOrBullet() && rootKey == COMMON_ROOT) ? (uint8_t)r : rootKey;
-						const uint8_t stSocket = single ? c.socket() : 0;
-						const bool own = single && ownKind;
-						const uint16_t lf = own ? (uint16_t)(ownFeat | (c.leftFeat() & (LF_TAG_SSC | LF_PREV_ZSIOT))) : c.leftFeat();
-						putState<G>(X, pos, (int32_t)(uint32_t)wkey, wscore, wtypo, c.lastSeqId, lf, newRoot, (uint8_t)(wkey >> 32), stSocket, c.prevFlags(),
-							own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0);
-						stageState<G>(X, pos - E.nodeStart, wscore, newRoot, c.socket() != 0, stSocket != 0);
-					}
+					if (pos < X.stCap) emitState((uint32_t)(rKey >> 48), qw, rKey, best, wfcs, pos);
 					else X.overflow = true;
 				}
 				X.stTop += __popcll(kbal);
-				emittedInBucket += __popcll(bal);
+			}
+		}
+		else
+		{
+			const int nBuckets = mode == 1 ? 4 : 1;
+			for (int b = 0; b < nBuckets; ++b)
+			{
+				uint32_t emittedInBucket = 0;
+				GUARD_DECL(g8)
+				for (uint32_t qb = 0; qb < Qtot; qb += G)
+				{
+					GUARD(g8, 100000, 8)
+					const uint32_t q = qb + X.gl;
+					bool rep = false; uint32_t qw = q; uint64_t key = KINVALID; uint32_t k = 0;
+					if (q < Qtot) key = big ? X.scratch->key[q] : X.qKey()[q];
+					if (key != KINVALID)
+					{
+						k = (uint32_t)(key >> 48);
+						const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
+						rep = true;
+						float best = -INFINITY; bool haveBest = false;
+						GUARD_DECL(g5)
+						for (uint32_t j = lo; j < hi; ++j)
+						{
+							GUARD(g5, 100000, 5)
+							const uint64_t kj = big ? X.scratch->key[j] : X.qKey()[j];
+							if (kj != key) continue;
+							if (j < q) { rep = false; break; }
+							const float sj = big ? X.scratch->score[j] : X.qScore()[j];
+							if (!haveBest || sj > best) { best = sj; qw = j; haveBest = true; }
+						}
+						if (rep && mode == 1)
+						{
+							// bucket = (h >> 8) & 3 of Hash<WordLL> (BestPathContainer.hpp:80-85, 323)
+							const uint64_t lmv = (uint64_t)(int64_t)(int32_t)(uint32_t)key;
+							const uint64_t hh = (uint64_t)(((key >> 40) & 0xFF) | (((key >> 32) & 0xFF) << 8)) ^ ((lmv << 3) | (lmv >> 61));
+							rep = (int)((hh >> 8) & 3) == b;
+						}
+					}
+					const uint64_t bal = X.ballot(rep);
+					// mode 1 runs exactly one candidate per batch, so the per-bucket rank is the container's per-bucket fill
+					const uint32_t rank = emittedInBucket + X.prefix(bal);
+					const bool keep = rep && (mode == 2 || rank < 128);   // a full bucket drops later keys (BestPathContainer.hpp:363-367)
+					const uint64_t kbal = X.ballot(keep);
+					if (keep)
+					{
+						const uint32_t pos = X.stTop + X.prefix(kbal);
+						if (pos < X.stCap)
+						{
+							const uint64_t wkey = big ? X.scratch->key[qw] : X.qKey()[qw];
+							const float wscore = big ? X.scratch->score[qw] : X.qScore()[qw];
+							const float wfcs = big ? X.scratch->fcs[qw] : X.qFcs()[qw];
+							emitState(k, qw, wkey, wscore, wfcs, pos);
+						}
+						else X.overflow = true;
+					}
+					X.stTop += __popcll(kbal);
+					emittedInBucket += __popcll(bal);
+				}
 			}
 		}
 		X.overflow = X.any(X.overflow);
@@ -604,6 +672,7 @@ namespace kamd
 		if (X.stTop > X.stCap) X.stTop = X.stCap;
 		waveSync();
 		PROF(X, 3)
+		TLMARK(X, 3)
 		BEACON(X, 0x0A000000u | (E.nodeIdx << 8))
 	}
 
@@ -749,11 +818,36 @@ namespace kamd
 		// ---- pruning (PathEvaluator.hpp:475-511): paths further than cutOff below the best of their root die.
 		// Nothing is moved: dead paths keep their slot (marked in LDS and HBM) and are skipped by every consumer.
 		PROF(X, 1)
+		TLMARK(X, 1)
 		BEACON(X, 0x0B000000u | (E.nodeIdx << 8))
 		const uint32_t cnt = X.stTop - E.nodeStart;
 		if (!cnt) return;
 		const bool staged = !X.stageOverflow;
 		const uint32_t nRootSlots = 1 + X.nUniq;
+		if constexpr (G == 16)
+		{
+			if (staged && cnt <= 16)
+			{
+				// common case: the node's new paths fit the group once -- one LDS read per lane, maxima per root by DPP
+				const bool in = X.gl < cnt;
+				uint8_t bits = 0; float sc = 0;
+				if (in) { bits = X.stBits()[X.gl]; sc = X.stScore()[X.gl]; }
+				const uint32_t slot = bits & SB_SLOT_MASK;
+				const bool alive = in && !(bits & SB_DEAD);
+				bool kill = false;
+				for (uint32_t rs = 0; rs < nRootSlots; ++rs)
+				{
+					const bool mine = alive && slot == rs;
+					const float mx = rowMax16((mine && !(bits & SB_MORPH_SOCKET)) ? sc : -INFINITY);
+					if (mine && sc + P.cutOff < mx) kill = true;
+				}
+				if (kill) { X.stBits()[X.gl] = bits | SB_DEAD; markDead<G>(X, E.nodeStart + X.gl); }
+				waveSync();
+				PROF(X, 4)
+				TLMARK(X, 4)
+				return;
+			}
+		}
 		for (uint32_t rs = 0; rs < nRootSlots; ++rs)
 		{
 			float mx = -INFINITY; bool anyOfRoot = false;
@@ -793,6 +887,7 @@ namespace kamd
 		}
 		waveSync();
 		PROF(X, 4)
+		TLMARK(X, 4)
 	}
 
 	// libstdc++'s std::sort restated for the end-node candidate list (the reference sorts it with an unstable
@@ -960,7 +1055,7 @@ namespace kamd
 
 	// End node, first half (PathEvaluator.hpp:1320-1358): EOS transition of every surviving path -> end-candidate list for k_finish_paths.
 	template<int G>
-	__device__ __noinline__ void finishChunk(GroupCtx<G>& X, const WorkView& W, uint32_t chunk, bool openEnding, DevChunkResult* res)
+	__device__ __noinline__ void finishChunk(GroupCtx<G>& X, uint32_t chunk, bool openEnding, DevChunkResult* res)
 	{
 		const ModelView& M = X.M;
 		const uint32_t Gn = X.Gn;
@@ -1097,6 +1192,11 @@ namespace kamd
 		const bool openEnding = B.chunkFlags[chunk] & 1;
 		uint8_t* reach = W.reach + nBase;
 		if (X.nUniq + 1 > SB_SLOT_MASK) { if (X.gl == 0) { res->status = CS_ERR_PATH_OVERFLOW; res->nPaths = 0; } return; }
+#ifdef KAMD_TIMELINE
+		unsigned long long* tl = W.beacon ? reinterpret_cast<unsigned long long*>(W.beacon) + 12ull * chunk : nullptr;
+		if (tl && X.gl == 0) { tl[0] = wall_clock64(); tl[3] = ((unsigned long long)blockIdx.x << 32) | X.Gn; }
+		if (X.gl == 0) { LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>(X.lds + Lay<G>::TLACC); for (int k = 0; k < 8; ++k) a_[k] = 0; a_[8] = wall_clock64(); }
+#endif
 
 		if constexpr (Lay<G>::NCAP != 0)
 		{
@@ -1119,7 +1219,7 @@ namespace kamd
 			const MorphRec m0 = M.morphs[0];
 			putState<G>(X, 0, M.h.bosNode, 0.f, 0.f, 0, m0.feat, COMMON_ROOT, 0, 0, m0.prevFlags, 0, 0xFFFFFFFFu, 0, 0.f, 0, 0);
 			X.nodeStOff[0] = 0; X.nodeStCnt[0] = 1; X.nodeLive[0] = 1;
-			X.ringBeg()[0] = 0; X.ringEnd()[0] = 1; X.ringLive()[0] = 1;
+			X.ringBeg()[0] = 0; X.ringEnd()[0] = 1; X.ringCum()[0] = 1;
 		}
 		X.stTop = 1;
 		for (uint32_t k = X.gl; k < Gn; k += G) reach[k] = k == 0 ? 1 : 0;
@@ -1127,6 +1227,7 @@ namespace kamd
 
 		const CandStatic* unkPacks = reinterpret_cast<const CandStatic*>(M.unkPacks);
 		const CandStatic* packs = W.packs + W.packBase[chunk];
+		uint32_t cumLive = 1;    // live paths of nodes 0..i-1 (group-uniform)
 		DevNode nextNode = getNode<G>(X, Gn > 2 ? 1 : 0);
 		GUARD_DECL(g6)
 		for (uint32_t i = 1; i + 1 < Gn; ++i)
@@ -1137,13 +1238,12 @@ namespace kamd
 			if (i + 2 < Gn) nextNode = getNode<G>(X, i + 1);      // prefetch: in flight while this node is processed
 			NodeEnv E;
 			const uint32_t firstPrev = i - node.prev, lastPrev = firstPrev + node.nPrev - 1;
-			if (i - firstPrev < RING)
+			if (i - firstPrev + 1 < RING)
 			{
+				// state ranges and running live totals of the last RING nodes are in LDS: three independent reads
 				E.pBeg = X.ringBeg()[firstPrev & (RING - 1)];
 				E.nP = X.ringEnd()[lastPrev & (RING - 1)] - E.pBeg;
-				E.nLive = 0;
-				GUARD_DECL(g12)
-				for (uint32_t j = firstPrev; j <= lastPrev; ++j) { GUARD(g12, 100000, 12) E.nLive += X.ringLive()[j & (RING - 1)]; }
+				E.nLive = X.ringCum()[lastPrev & (RING - 1)] - (firstPrev ? X.ringCum()[(firstPrev - 1) & (RING - 1)] : 0u);
 			}
 			else
 			{
@@ -1161,6 +1261,7 @@ namespace kamd
 			const float baseDiscount = ws + (-0.f * P.typoCostWeight);   // whitespaceDiscount + typoDiscount (PathEvaluator.hpp:366-371)
 
 			PROF(X, 0)
+			TLMARK(X, 0)
 			const uint8_t ownKind = node.uformLen ? 1 : 0; const uint16_t ownFeat = node.ownFeat;
 			// up to three candidate lists per node, evaluated through ONE inlined copy of evaluateNode:
 			//   pass 0  the form's candidates, or the two unknown-word candidates of a formless node
@@ -1242,6 +1343,7 @@ namespace kamd
 				BEACON(X, 0x0C000000u | (i << 8) | pass)
 			}
 			PROF(X, 0)
+			TLMARK(X, 6)
 			// node bookkeeping: state range + live count (LDS ring and HBM)
 			{
 				const uint32_t cntAll = X.stTop - nodeStart;
@@ -1255,12 +1357,14 @@ namespace kamd
 				}
 				if (X.gl == 0)
 				{
-					X.ringBeg()[i & (RING - 1)] = nodeStart; X.ringEnd()[i & (RING - 1)] = X.stTop; X.ringLive()[i & (RING - 1)] = (uint16_t)(live > 0xFFFF ? 0xFFFF : live);
+					X.ringBeg()[i & (RING - 1)] = nodeStart; X.ringEnd()[i & (RING - 1)] = X.stTop; X.ringCum()[i & (RING - 1)] = cumLive + live;
 					X.nodeStOff[i] = nodeStart; X.nodeStCnt[i] = cntAll; X.nodeLive[i] = (uint16_t)(live > 0xFFFF ? 0xFFFF : live);
 				}
+				cumLive += live;
 			}
 			waveSync();
 			PROF(X, 5)
+			TLMARK(X, 5)
 			if (X.overflow || X.pairOverflow) break;
 		}
 		if (X.overflow || X.pairOverflow)
@@ -1269,12 +1373,26 @@ namespace kamd
 			return;
 		}
 		BEACON(X, 0x0E000000u)
+#ifdef KAMD_TIMELINE
+		if (tl && X.gl == 0) { tl[1] = wall_clock64(); LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>(X.lds + Lay<G>::TLACC); for (int k = 0; k < 8; ++k) tl[4 + k] = a_[k]; }
+#endif
 #ifdef KAMD_CRUMBS
 		if (X.gl == 0) res->nEnd = 0xA1000000u;
 #endif
-		finishChunk<G>(X, W, chunk, openEnding, res);
+		{
+			// the end stage is a real function call; it gets COPIES of the context and of the views, so that no address of X or of
+			// a kernel argument escapes and all of them stay in registers / the kernarg segment throughout the node loop (with the
+			// originals passed by reference, every X.field and M.pointer access in the node loop became a scratch load)
+			const ModelView Mc = X.M; const SearchParams Pc = X.P;
+			GroupCtx<G> Y(X, Mc, Pc);
+			finishChunk<G>(Y, chunk, openEnding, res);
+		}
+#ifdef KAMD_TIMELINE
+		if (tl && X.gl == 0) tl[2] = wall_clock64();
+#endif
 		BEACON(X, 0x11000000u)
 		PROF(X, 6)
+		TLMARK(X, 6)
 #ifdef KAMD_PROFILE
 		if (X.gl == 0) for (int k = 0; k < 8; ++k) { atomicAdd(&gProf[k], (unsigned long long)X.prof[k]); X.prof[k] = 0; }
 #endif
@@ -1303,7 +1421,7 @@ namespace kamd
 		__syncthreads();
 
 		const uint32_t gid = lane / G;
-		GroupCtx<G> X{ M, P };
+		GroupCtx<G> X(M, P);
 		X.gl = lane % G; X.gshift = gid * G; X.lds = gid * Lay<G>::SIZE;
 		X.scratch = reinterpret_cast<GroupScratch*>(W.bigScratch) + ((size_t)blockIdx.x * NG + gid);
 		X.beacon = W.beacon ? W.beacon + (size_t)blockIdx.x * 64 + lane : nullptr;
