@@ -141,6 +141,22 @@ namespace kamd
 		uint32_t* beacon;              // developer aid (KAMD_BEACON builds): host-visible progress word per lane, or null
 	};
 
+	// LDS layout of the wave-per-chunk lattice build (byte offsets): n text units, node capacity, packed-match capacity
+	struct LatticeLds { uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, endPosMap, fullMask, zAt, mforms, mfrec, out, queue, total; };
+	KAMD_HD LatticeLds latticeLdsLayout(uint32_t n, uint32_t nodeCap, uint32_t matchCap)
+	{
+		LatticeLds l; uint32_t o = 0;
+		auto take = [&](uint32_t bytes) { const uint32_t at = o; o = (o + bytes + 15u) & ~15u; return at; };
+		l.str = take(2 * n); l.cls = take(n); l.script = take(n); l.cflag = take(n);
+		l.nsToPos = take(2 * (n + 2)); l.posToNs = take(2 * (n + 2));
+		l.mask = take(8 * (n + 2)); l.moff = take(4 * (n + 2));
+		l.endPosMap = take(4 * (n + 2)); l.fullMask = take(8 * (n + 2)); l.zAt = take(n + 2);
+		l.mforms = take(4 * matchCap); l.mfrec = take(16 * matchCap);
+		l.out = take(32 * nodeCap); l.queue = take(4 * nodeCap);
+		l.total = o;
+		return l;
+	}
+
 #ifdef __HIPCC__
 	// Lanes of one wavefront exchange data through LDS / HBM between phases.  A memory fence alone orders one lane's own
 	// accesses; it does not stop the compiler from letting lanes that left a divergent loop early run ahead into the next

@@ -19,7 +19,8 @@
 namespace kamd
 {
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
-	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount);
+	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
+	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
 
 	namespace
@@ -289,6 +290,7 @@ namespace kamd
 #ifdef KAMD_TIMELINE
 	static void* gTimeline = nullptr;
 #endif
+	constexpr uint32_t kLatticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for
 	static KernelTimes launchAll(Engine::Impl& I, StagedBatch& b, const SearchParams& sp)
 	{
 		KernelTimes t;
@@ -332,7 +334,15 @@ namespace kamd
 			HIPCHECK(hipEventRecord(e[0], sA));
 			hipLaunchKernelGGL(k_dict_scan, dim3((cn + 3) / 4), dim3(256), 0, sA, I.dview, b.bv, b.wv, c0, cn);
 			HIPCHECK(hipEventRecord(e[1], sA));
-			hipLaunchKernelGGL(k_build_lattice, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn);
+			// wave-per-chunk build with the chunk's working set in LDS; chunks beyond the LDS budget go to the thread-per-chunk kernel
+			uint32_t latLds = 0; bool anyBig = false;
+			for (uint32_t c = c0; c < c1; ++c)
+			{
+				const uint32_t need = latticeLdsLayout(b.charOff[c + 1] - b.charOff[c], b.nodeBase[c + 1] - b.nodeBase[c], b.matchBase[c + 1] - b.matchBase[c]).total;
+				if (need <= kLatticeLdsBudget) latLds = std::max(latLds, need); else anyBig = true;
+			}
+			if (latLds) hipLaunchKernelGGL(k_build_lattice, dim3(cn), dim3(64), latLds, sA, I.dview, b.bv, b.wv, sp, c0, cn, latLds);
+			if (anyBig) hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, latLds);
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn);
 			HIPCHECK(hipEventRecord(e[2], sA));
 			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));

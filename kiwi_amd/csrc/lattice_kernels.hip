@@ -241,34 +241,20 @@ namespace kamd
 		latInsertUnk(L, unkStart, e, hasJ, nMap);
 	}
 
-	__global__ void __launch_bounds__(64) k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount)
+	// working arrays of one chunk's lattice build: HBM (thread-per-chunk variant) or the wave's LDS (wave-per-chunk variant)
+	struct LatticeMem
 	{
-		const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-		if (local >= chunkCount) return;
-		const uint32_t chunk = chunkBegin + local;
-		if (W.results[chunk].status >= 16) return;
-		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
-		const uint16_t* str = B.chars + cOff;
-		const uint8_t* cls = B.cls + cOff;
-		const uint8_t* script = B.script + cOff;
-		const uint8_t* cflag = W.cflag + cOff;
-		const uint32_t nNs = W.nNs[chunk];
-		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
-		const uint64_t* mask = W.matchMask + cOff + chunk;
-		const uint32_t* moff = W.matchOff + cOff + chunk;
-		const uint32_t* mforms = W.matchForm + W.matchBase[chunk];
+		const uint16_t* str; const uint8_t* cls; const uint8_t* script; const uint8_t* cflag;
+		const uint64_t* mask; const uint32_t* moff; const uint32_t* mforms; const FormRec* mfrec;   // mfrec: FormRec of every packed match, or null
+		uint16_t* queue; uint16_t* connOrd;
+	};
 
-		LatticeCtx L;
-		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk;
-		L.out = W.tmpNodes + nBase; L.endPosMap = W.endPosMap + cOff + chunk; L.fullMask = W.fullMask + cOff + chunk; L.zAt = W.zAt + cOff + chunk; L.nOut = 0; L.cap = cap; L.overflow = false;
-		const uint32_t nMap = nNs + 1;
-		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { W.results[chunk].status = CS_ERR_TOO_LONG; return; }
-		for (uint32_t i = 0; i < nMap; ++i) { L.endPosMap[i] = 0; L.fullMask[i] = 0; L.zAt[i] = 0; }    // first == second : empty
-		L.endPosMap[0] = 0 | (1u << 16);
-		{
-			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
-			L.out[0] = bos; L.nOut = 1;
-		}
+	// Splitter::splitByTrie replayed over the packed match lists (KTrie.cpp:1040-1137, 921-996): strictly sequential, one lane.
+	__device__ __forceinline__ void latticeSerialBuild(const ModelView& M, const BatchView& B, const SearchParams& P, LatticeCtx& L, const LatticeMem& Q,
+		uint32_t chunk, uint32_t n, uint32_t nNs, uint32_t nMap)
+	{
+		const uint16_t* str = Q.str; const uint8_t* cls = Q.cls; const uint8_t* script = Q.script; const uint8_t* cflag = Q.cflag;
+		const uint64_t* mask = Q.mask; const uint32_t* moff = Q.moff; const uint32_t* mforms = Q.mforms; const FormRec* mfrec = Q.mfrec;
 		const DevPattern* pat = B.patterns + B.patOff[chunk];
 		const DevPattern* patEnd = B.patterns + B.patOff[chunk + 1];
 
@@ -343,7 +329,7 @@ namespace kamd
 			{
 				const bool isZ = zcand && k == m0 - 1;
 				const uint32_t fi = isZ ? zform : mforms[k];
-				const FormRec f = M.forms[fi];
+				const FormRec f = (isZ || !mfrec) ? M.forms[fi] : mfrec[k];
 				const uint32_t flen = f.len - f.numSpaces;
 				if (flen > endNs) continue;
 				const uint32_t nb = endNs - flen, ne = endNs;
@@ -356,13 +342,21 @@ namespace kamd
 				}
 				// countSpaceErrors (KTrie.cpp:316-328)
 				uint32_t se = 0, off = 0;
-				const uint16_t* fs = M.formChars + f.charOff;
-				for (uint32_t i = 1; i < ne - nb; ++i)
+				if (!f.numSpaces)
 				{
-					const bool hasSpace = L.nsToPos[nb + i] - L.nsToPos[nb + i - 1] > 1;
-					const uint16_t fc = (i + off < f.len) ? fs[i + off] : 0;
-					if (hasSpace && fc != u' ') ++se;
-					if (fc == u' ') ++off;
+					// a form without spaces: every gap inside the span is an error; the form's characters are not needed
+					for (uint32_t i = 1; i < ne - nb; ++i) se += (L.nsToPos[nb + i] - L.nsToPos[nb + i - 1] > 1) ? 1u : 0u;
+				}
+				else
+				{
+					const uint16_t* fs = M.formChars + f.charOff;
+					for (uint32_t i = 1; i < ne - nb; ++i)
+					{
+						const bool hasSpace = L.nsToPos[nb + i] - L.nsToPos[nb + i - 1] > 1;
+						const uint16_t fc = (i + off < f.len) ? fs[i + off] : 0;
+						if (hasSpace && fc != u' ') ++se;
+						if (fc == u' ') ++off;
+					}
 				}
 				if (se <= P.spaceTol)
 				{
@@ -382,12 +376,14 @@ namespace kamd
 		if (nNs && n == (uint32_t)L.nsToPos[nNs - 1] + 1) latUnkPair(L, boundary, unkStart, L.posToNs[n], true, nMap);
 		latAppend(L, nNs, nNs + 1, NOFORM, 0, 0, nMap);
 		L.out[L.nOut - 1].endPos = (uint16_t)nNs;
-		if (L.overflow || L.nOut + 1 >= cap) { W.results[chunk].status = CS_ERR_NODE_OVERFLOW; return; }
+	}
 
-		// ---- removeUnconnected (KTrie.cpp:240-299): backward BFS from the end node, then a stable order by end position
+	// removeUnconnected, part 1 (KTrie.cpp:240-299): backward BFS from the end node, then the new index of every connected node.
+	// Returns the number of connected nodes; inv (= Q.queue) holds old -> new (0xFFFF: dropped); endPosMap[e] := connected nodes ending at e.
+	__device__ __forceinline__ uint32_t latticeConnect(LatticeCtx& L, const LatticeMem& Q, uint32_t cap, uint32_t nNs)
+	{
+		uint16_t* queue = Q.queue; uint16_t* connOrd = Q.connOrd;
 		const uint32_t G = L.nOut;
-		uint16_t* queue = W.tmpIdx + 2ull * nBase;     // BFS queue, later the inverse permutation
-		uint16_t* connOrd = queue + cap;               // connected flag (bit 15) per old node
 		for (uint32_t i = 0; i < G; ++i) connOrd[i] = 0;
 		uint32_t qh = 0, qt = 0;
 		queue[qt++] = (uint16_t)(G - 1); connOrd[G - 1] = 1;
@@ -428,68 +424,200 @@ namespace kamd
 			L.endPosMap[e] = chainConn;   // from here on: number of connected nodes ending at e
 		}
 		inv[G - 1] = (uint16_t)nConn++;
-		DevNode* fin = W.nodes + nBase;
-		const uint32_t textOff = B.textOffset[chunk];
-		for (uint32_t idx = 0; idx < G; ++idx)
+		return nConn;
+	}
+
+	// removeUnconnected, part 2: old node idx -> final record at its new index (predecessor-dependent facts the search kernel
+	// needs once per node included).  Returns the node's candidate count, or 0xFFFFFFFF for a dropped node.  Nodes are independent.
+	__device__ __forceinline__ uint32_t latticeEmitNode(const ModelView& M, const LatticeCtx& L, const uint16_t* str, const uint8_t* cls, const uint16_t* inv,
+		DevNode* fin, uint32_t idx, uint32_t n, uint32_t nConn, uint32_t textOff)
+	{
+		const uint32_t ni = inv[idx];
+		if (ni == 0xFFFF) return 0xFFFFFFFFu;
+		DevNode nn = L.out[idx];
+		const uint32_t startNs = nn.startPos;
+		uint8_t nf = 0;
+		if (ni >= 1)
 		{
-			const uint32_t ni = inv[idx];
-			if (ni == 0xFFFF) continue;
-			DevNode nn = L.out[idx];
-			const uint32_t startNs = nn.startPos;
-			uint8_t nf = 0;
-			if (ni >= 1)
+			// predecessor-dependent facts the search kernel needs once per node
+			const DevNode pn = L.out[idx - nn.prev];
+			const uint32_t startStr = (ni + 1 == nConn) ? n : (uint32_t)L.nsToPos[startNs];
+			const bool pnBos = (idx - nn.prev) == 0;
+			const uint32_t pnEndStr = pnBos ? 0 : (uint32_t)L.nsToPos[pn.endPos - 1] + 1;
+			// the reference compares absolute text offsets; the start node's end is 0 (PathEvaluator.hpp:24-31, 436, 568)
+			const bool spaceBefore = pnBos ? (textOff + startStr > 0) : (pnEndStr < startStr);
+			bool lb = pnBos || spaceBefore;
+			if (!lb && pn.uformLen)
 			{
-				// predecessor-dependent facts the search kernel needs once per node
-				const DevNode pn = L.out[idx - nn.prev];
-				const uint32_t startStr = (ni + 1 == nConn) ? n : (uint32_t)L.nsToPos[startNs];
-				const bool pnBos = (idx - nn.prev) == 0;
-				const uint32_t pnEndStr = pnBos ? 0 : (uint32_t)L.nsToPos[pn.endPos - 1] + 1;
-				// the reference compares absolute text offsets; the start node's end is 0 (PathEvaluator.hpp:24-31, 436, 568)
-				const bool spaceBefore = pnBos ? (textOff + startStr > 0) : (pnEndStr < startStr);
-				bool lb = pnBos || spaceBefore;
-				if (!lb && pn.uformLen)
-				{
-					const uint32_t lp = pn.uformOff + pn.uformLen - 1;
-					const uint16_t c = str[lp];
-					const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
-					if (tag == T_SSC || c == u'"' || c == u'\'') lb = false;
-					else if (T_SF <= tag && tag <= T_SB) lb = true;
-				}
-				if (spaceBefore) nf |= NF_SPACE_BEFORE;
-				if (lb) nf |= NF_LEFT_BOUNDARY;
-				if (nn.uformLen && str[nn.uformOff + nn.uformLen - 1] == u'.') nf |= NF_UFORM_ENDS_POINT;
-				nn.nPrev = (uint16_t)L.endPosMap[startNs];
-			}
-			if (nn.form != NOFORM)
-			{
-				const FormRec f = M.forms[nn.form];
-				nn.candCnt = f.candCnt; nn.fflags = f.flags; nn.flen = f.len;
-				if (f.flags2 & FF2_ALL_PARTIAL) nf |= NF_ALL_PARTIAL;
-			}
-			if (nn.uformLen)
-			{
-				uint16_t of = featMask(str + nn.uformOff, nn.uformLen) & 0x1FFF;
-				const uint32_t lp = nn.uformOff + nn.uformLen - 1;
+				const uint32_t lp = pn.uformOff + pn.uformLen - 1;
 				const uint16_t c = str[lp];
 				const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
-				if (tag == T_SSC) of |= LF_STR_SSC;
-				nn.ownFeat = of;
+				if (tag == T_SSC || c == u'"' || c == u'\'') lb = false;
+				else if (T_SF <= tag && tag <= T_SB) lb = true;
 			}
-			nn.nflags = nf;
-			if (nn.prev) nn.prev = (uint16_t)(ni - inv[idx - nn.prev]);
-			if (nn.sibling)
-			{
-				const uint32_t ns = inv[idx + nn.sibling];
-				nn.sibling = ns == 0xFFFF ? 0 : (uint16_t)(ns - ni);
-			}
-			if (ni >= 1 && ni + 1 < nConn)
-			{
-				nn.startPos = L.nsToPos[nn.startPos];
-				nn.endPos = (uint16_t)(L.nsToPos[nn.endPos - 1] + 1);
-			}
-			else if (ni + 1 == nConn) nn.startPos = nn.endPos = (uint16_t)n;
-			fin[ni] = nn;
+			if (spaceBefore) nf |= NF_SPACE_BEFORE;
+			if (lb) nf |= NF_LEFT_BOUNDARY;
+			if (nn.uformLen && str[nn.uformOff + nn.uformLen - 1] == u'.') nf |= NF_UFORM_ENDS_POINT;
+			nn.nPrev = (uint16_t)L.endPosMap[startNs];
 		}
+		if (nn.form != NOFORM)
+		{
+			const FormRec f = M.forms[nn.form];
+			nn.candCnt = f.candCnt; nn.fflags = f.flags; nn.flen = f.len;
+			if (f.flags2 & FF2_ALL_PARTIAL) nf |= NF_ALL_PARTIAL;
+		}
+		if (nn.uformLen)
+		{
+			uint16_t of = featMask(str + nn.uformOff, nn.uformLen) & 0x1FFF;
+			const uint32_t lp = nn.uformOff + nn.uformLen - 1;
+			const uint16_t c = str[lp];
+			const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
+			if (tag == T_SSC) of |= LF_STR_SSC;
+			nn.ownFeat = of;
+		}
+		nn.nflags = nf;
+		if (nn.prev) nn.prev = (uint16_t)(ni - inv[idx - nn.prev]);
+		if (nn.sibling)
+		{
+			const uint32_t ns = inv[idx + nn.sibling];
+			nn.sibling = ns == 0xFFFF ? 0 : (uint16_t)(ns - ni);
+		}
+		if (ni >= 1 && ni + 1 < nConn)
+		{
+			nn.startPos = L.nsToPos[nn.startPos];
+			nn.endPos = (uint16_t)(L.nsToPos[nn.endPos - 1] + 1);
+		}
+		else if (ni + 1 == nConn) nn.startPos = nn.endPos = (uint16_t)n;
+		nn.packOff = 0;
+		fin[ni] = nn;
+		return nn.candCnt;
+	}
+
+	// dynamic LDS of the wave-per-chunk variant
+	extern __shared__ __align__(16) uint8_t lSmem[];
+
+	// One WAVE per chunk.  The build itself is sequential (lane 0), but every access of it is an LDS access instead of a
+	// dependent HBM round trip: the chunk's text, index maps, packed matches (+ their form records) are staged into LDS by
+	// all lanes first, the node list grows in LDS, and the final reorder / per-node fact computation runs one node per lane.
+	// Chunks whose working set exceeds ldsBytes are left to k_build_lattice_big.
+	__global__ void __launch_bounds__(64) k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes)
+	{
+		if (blockIdx.x >= chunkCount) return;
+		const uint32_t lane = threadIdx.x;
+		const uint32_t chunk = chunkBegin + blockIdx.x;
+		if (W.results[chunk].status >= 16) return;
+		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
+		const uint32_t nNs = W.nNs[chunk];
+		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
+		const uint32_t mBase = W.matchBase[chunk], mCap = W.matchBase[chunk + 1] - mBase;
+		const LatticeLds lay = latticeLdsLayout(n, cap, mCap);
+		if (lay.total > ldsBytes) return;                      // k_build_lattice_big takes it
+		const uint32_t nMap = nNs + 1;
+		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { if (lane == 0) W.results[chunk].status = CS_ERR_TOO_LONG; return; }
+
+		uint16_t* str = reinterpret_cast<uint16_t*>(lSmem + lay.str);
+		uint8_t* cls = lSmem + lay.cls; uint8_t* script = lSmem + lay.script; uint8_t* cflag = lSmem + lay.cflag;
+		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(lSmem + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(lSmem + lay.posToNs);
+		uint64_t* mask = reinterpret_cast<uint64_t*>(lSmem + lay.mask); uint32_t* moff = reinterpret_cast<uint32_t*>(lSmem + lay.moff);
+		uint32_t* mforms = reinterpret_cast<uint32_t*>(lSmem + lay.mforms); FormRec* mfrec = reinterpret_cast<FormRec*>(lSmem + lay.mfrec);
+		// ---- stage the chunk into LDS (all lanes, coalesced) ----
+		{
+			const uint16_t* gstr = B.chars + cOff; const uint8_t* gcls = B.cls + cOff; const uint8_t* gscript = B.script + cOff; const uint8_t* gcflag = W.cflag + cOff;
+			const uint16_t* gn2p = W.nsToPos + cOff + chunk; const uint16_t* gp2n = W.posToNs + cOff + chunk;
+			const uint64_t* gmask = W.matchMask + cOff + chunk; const uint32_t* gmoff = W.matchOff + cOff + chunk;
+			for (uint32_t i = lane; i < n; i += 64) { str[i] = gstr[i]; cls[i] = gcls[i]; script[i] = gscript[i]; cflag[i] = gcflag[i]; }
+			for (uint32_t i = lane; i <= n; i += 64) { posToNs[i] = gp2n[i]; if (i < nNs) nsToPos[i] = gn2p[i]; }
+			for (uint32_t i = lane; i <= nNs; i += 64) { mask[i] = gmask[i]; moff[i] = gmoff[i]; }
+			const uint32_t mTot = gmoff[nNs] + __popcll(gmask[nNs]);
+			const uint32_t* gforms = W.matchForm + mBase;
+			for (uint32_t k = lane; k < mTot; k += 64) { const uint32_t fi = gforms[k]; mforms[k] = fi; mfrec[k] = M.forms[fi]; }
+		}
+		LatticeCtx L;
+		L.M = &M; L.P = &P; L.str = str; L.nsToPos = nsToPos; L.posToNs = posToNs;
+		L.out = reinterpret_cast<DevNode*>(lSmem + lay.out); L.endPosMap = reinterpret_cast<uint32_t*>(lSmem + lay.endPosMap);
+		L.fullMask = reinterpret_cast<uint64_t*>(lSmem + lay.fullMask); L.zAt = lSmem + lay.zAt; L.nOut = 0; L.cap = cap; L.overflow = false;
+		for (uint32_t i = lane; i < nMap; i += 64) { L.endPosMap[i] = 0; L.fullMask[i] = 0; L.zAt[i] = 0; }    // first == second : empty
+		waveSync();
+		LatticeMem Q{ str, cls, script, cflag, mask, moff, mforms, mfrec, reinterpret_cast<uint16_t*>(lSmem + lay.queue), reinterpret_cast<uint16_t*>(lSmem + lay.queue) + cap };
+		uint32_t nConn = 0, G = 0, err = 0;
+		if (lane == 0)
+		{
+			L.endPosMap[0] = 0 | (1u << 16);
+			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
+			L.out[0] = bos; L.nOut = 1;
+			latticeSerialBuild(M, B, P, L, Q, chunk, n, nNs, nMap);
+			if (L.overflow || L.nOut + 1 >= cap) err = CS_ERR_NODE_OVERFLOW;
+			else { G = L.nOut; nConn = latticeConnect(L, Q, cap, nNs); }
+		}
+		waveSync();
+		err = __shfl(err, 0); G = __shfl(G, 0); nConn = __shfl(nConn, 0);
+		if (err) { if (lane == 0) W.results[chunk].status = err; return; }
+
+		// ---- final records, one node per lane; candidate-record offsets by a wave scan over the new order ----
+		DevNode* fin = W.nodes + nBase;
+		const uint16_t* inv = Q.queue;
+		uint16_t* cc = Q.connOrd;                       // candidate count per NEW index (the connected flags are no longer needed)
+		const uint32_t textOff = B.textOffset[chunk];
+		waveSync();
+		for (uint32_t base = 0; base < G; base += 64)
+		{
+			const uint32_t idx = base + lane;
+			uint32_t cnt = 0xFFFFFFFFu;
+			if (idx < G) cnt = latticeEmitNode(M, L, str, cls, inv, fin, idx, n, nConn, textOff);
+			if (cnt != 0xFFFFFFFFu) cc[inv[idx]] = (uint16_t)cnt;
+		}
+		waveSync();
+		uint32_t packTop = 0;
+		for (uint32_t base = 0; base < nConn; base += 64)
+		{
+			const uint32_t i = base + lane;
+			const uint32_t c = i < nConn ? (uint32_t)cc[i] : 0u;
+			uint32_t incl = c;
+			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+			if (i < nConn) fin[i].packOff = packTop + incl - c;
+			packTop += __shfl(incl, 63);
+		}
+		if (lane == 0)
+		{
+			const uint32_t packCap = W.packBase[chunk + 1] - W.packBase[chunk];
+			if (packTop > packCap) W.results[chunk].status = CS_ERR_NODE_OVERFLOW;
+			else { W.nNodes[chunk] = nConn; if (nConn <= 2) W.results[chunk].status = CS_NO_LATTICE; }
+		}
+	}
+
+	// One THREAD per chunk, all working arrays in HBM: for chunks whose working set does not fit the LDS budget of k_build_lattice.
+	__global__ void __launch_bounds__(64) k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes)
+	{
+		const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+		if (local >= chunkCount) return;
+		const uint32_t chunk = chunkBegin + local;
+		if (W.results[chunk].status >= 16) return;
+		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
+		const uint32_t nNs = W.nNs[chunk];
+		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
+		if (latticeLdsLayout(n, cap, W.matchBase[chunk + 1] - W.matchBase[chunk]).total <= ldsBytes) return;   // done by the wave-per-chunk kernel
+		const uint16_t* str = B.chars + cOff;
+		const uint8_t* cls = B.cls + cOff;
+		LatticeCtx L;
+		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk;
+		L.out = W.tmpNodes + nBase; L.endPosMap = W.endPosMap + cOff + chunk; L.fullMask = W.fullMask + cOff + chunk; L.zAt = W.zAt + cOff + chunk; L.nOut = 0; L.cap = cap; L.overflow = false;
+		const uint32_t nMap = nNs + 1;
+		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { W.results[chunk].status = CS_ERR_TOO_LONG; return; }
+		for (uint32_t i = 0; i < nMap; ++i) { L.endPosMap[i] = 0; L.fullMask[i] = 0; L.zAt[i] = 0; }    // first == second : empty
+		L.endPosMap[0] = 0 | (1u << 16);
+		{
+			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
+			L.out[0] = bos; L.nOut = 1;
+		}
+		uint16_t* queue = W.tmpIdx + 2ull * nBase;
+		LatticeMem Q{ str, cls, B.script + cOff, W.cflag + cOff, W.matchMask + cOff + chunk, W.matchOff + cOff + chunk, W.matchForm + W.matchBase[chunk], nullptr, queue, queue + cap };
+		latticeSerialBuild(M, B, P, L, Q, chunk, n, nNs, nMap);
+		if (L.overflow || L.nOut + 1 >= cap) { W.results[chunk].status = CS_ERR_NODE_OVERFLOW; return; }
+		const uint32_t G = L.nOut;
+		const uint32_t nConn = latticeConnect(L, Q, cap, nNs);
+		DevNode* fin = W.nodes + nBase;
+		const uint32_t textOff = B.textOffset[chunk];
+		for (uint32_t idx = 0; idx < G; ++idx) latticeEmitNode(M, L, str, cls, queue, fin, idx, n, nConn, textOff);
 		{
 			uint32_t packTop = 0;
 			const uint32_t packCap = W.packBase[chunk + 1] - W.packBase[chunk];
