@@ -143,15 +143,20 @@ namespace kamd
 
 	// LDS layout of the wave-per-chunk lattice build (byte offsets): n text units, node capacity, packed-match capacity
 	struct LatticeLds { uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, endPosMap, fullMask, zAt, mforms, mfrec, out, queue, total; };
-	KAMD_HD LatticeLds latticeLdsLayout(uint32_t n, uint32_t nodeCap, uint32_t matchCap)
+	// LDS-side capacities are the typical need (3 per text unit), not the worst-case HBM capacities: a chunk that outgrows
+	// them at run time is handed to the thread-per-chunk kernel (flag kLatticeNeedsBig in nNodes[chunk])
+	constexpr uint32_t kLatticeNeedsBig = 0xFFFFFFFEu;
+	KAMD_HD uint32_t latticeLdsCap(uint32_t n, uint32_t hbmCap) { const uint32_t c = 3 * n + 32; return c < hbmCap ? c : hbmCap; }
+	KAMD_HD LatticeLds latticeLdsLayout(uint32_t n, uint32_t nodeCapHbm, uint32_t matchCapHbm)
 	{
+		const uint32_t nodeCap = latticeLdsCap(n, nodeCapHbm), matchCap = latticeLdsCap(n, matchCapHbm);
 		LatticeLds l; uint32_t o = 0;
 		auto take = [&](uint32_t bytes) { const uint32_t at = o; o = (o + bytes + 15u) & ~15u; return at; };
 		l.str = take(2 * n); l.cls = take(n); l.script = take(n); l.cflag = take(n);
 		l.nsToPos = take(2 * (n + 2)); l.posToNs = take(2 * (n + 2));
 		l.mask = take(8 * (n + 2)); l.moff = take(4 * (n + 2));
 		l.endPosMap = take(4 * (n + 2)); l.fullMask = take(8 * (n + 2)); l.zAt = take(n + 2);
-		l.mforms = take(4 * matchCap); l.mfrec = take(16 * matchCap);
+		l.mforms = take(4 * matchCap); l.mfrec = take(8 * matchCap);
 		l.out = take(32 * nodeCap); l.queue = take(4 * nodeCap);
 		l.total = o;
 		return l;

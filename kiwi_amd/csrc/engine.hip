@@ -320,6 +320,7 @@ namespace kamd
 		while (I.evs.size() < nEv) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); I.evs.push_back(e); }
 		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), sA));
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
+		HIPCHECK(hipMemsetAsync(b.dNNodes.p, 0, (size_t)nC * 4, sA));   // also clears the lattice kernels' hand-over flag
 		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
 		const uint32_t nGroups = 64u / (uint32_t)I.groupLanes;
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
@@ -342,7 +343,9 @@ namespace kamd
 				if (need <= kLatticeLdsBudget) latLds = std::max(latLds, need); else anyBig = true;
 			}
 			if (latLds) hipLaunchKernelGGL(k_build_lattice, dim3(cn), dim3(64), latLds, sA, I.dview, b.bv, b.wv, sp, c0, cn, latLds);
-			if (anyBig) hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, latLds);
+			// always launched: it also picks up chunks that outgrew their LDS copy at run time (returns at once otherwise)
+			(void)anyBig;
+			hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, latLds);
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn);
 			HIPCHECK(hipEventRecord(e[2], sA));
 			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));

@@ -245,7 +245,7 @@ namespace kamd
 	struct LatticeMem
 	{
 		const uint16_t* str; const uint8_t* cls; const uint8_t* script; const uint8_t* cflag;
-		const uint64_t* mask; const uint32_t* moff; const uint32_t* mforms; const FormRec* mfrec;   // mfrec: FormRec of every packed match, or null
+		const uint64_t* mask; const uint32_t* moff; const uint32_t* mforms; const uint2* mfrec;   // mfrec: {charOff, len | numSpaces << 8 | flags << 16} of every packed match, or null
 		uint16_t* queue; uint16_t* connOrd;
 	};
 
@@ -254,7 +254,7 @@ namespace kamd
 		uint32_t chunk, uint32_t n, uint32_t nNs, uint32_t nMap)
 	{
 		const uint16_t* str = Q.str; const uint8_t* cls = Q.cls; const uint8_t* script = Q.script; const uint8_t* cflag = Q.cflag;
-		const uint64_t* mask = Q.mask; const uint32_t* moff = Q.moff; const uint32_t* mforms = Q.mforms; const FormRec* mfrec = Q.mfrec;
+		const uint64_t* mask = Q.mask; const uint32_t* moff = Q.moff; const uint32_t* mforms = Q.mforms; const uint2* mfrec = Q.mfrec;
 		const DevPattern* pat = B.patterns + B.patOff[chunk];
 		const DevPattern* patEnd = B.patterns + B.patOff[chunk + 1];
 
@@ -329,7 +329,9 @@ namespace kamd
 			{
 				const bool isZ = zcand && k == m0 - 1;
 				const uint32_t fi = isZ ? zform : mforms[k];
-				const FormRec f = (isZ || !mfrec) ? M.forms[fi] : mfrec[k];
+				FormRec f;
+				if (isZ || !mfrec) f = M.forms[fi];
+				else { const uint2 r = mfrec[k]; f.charOff = r.x; f.len = (uint8_t)r.y; f.numSpaces = (uint8_t)(r.y >> 8); f.flags = (uint8_t)(r.y >> 16); f.candOff = 0; f.candCnt = 0; f.flags2 = 0; f.vowelPolar = 0; f.formHash = 0; }
 				const uint32_t flen = f.len - f.numSpaces;
 				if (flen > endNs) continue;
 				const uint32_t nb = endNs - flen, ne = endNs;
@@ -519,7 +521,7 @@ namespace kamd
 		uint8_t* cls = lSmem + lay.cls; uint8_t* script = lSmem + lay.script; uint8_t* cflag = lSmem + lay.cflag;
 		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(lSmem + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(lSmem + lay.posToNs);
 		uint64_t* mask = reinterpret_cast<uint64_t*>(lSmem + lay.mask); uint32_t* moff = reinterpret_cast<uint32_t*>(lSmem + lay.moff);
-		uint32_t* mforms = reinterpret_cast<uint32_t*>(lSmem + lay.mforms); FormRec* mfrec = reinterpret_cast<FormRec*>(lSmem + lay.mfrec);
+		uint32_t* mforms = reinterpret_cast<uint32_t*>(lSmem + lay.mforms); uint2* mfrec = reinterpret_cast<uint2*>(lSmem + lay.mfrec);
 		// ---- stage the chunk into LDS (all lanes, coalesced) ----
 		{
 			const uint16_t* gstr = B.chars + cOff; const uint8_t* gcls = B.cls + cOff; const uint8_t* gscript = B.script + cOff; const uint8_t* gcflag = W.cflag + cOff;
@@ -530,15 +532,21 @@ namespace kamd
 			for (uint32_t i = lane; i <= nNs; i += 64) { mask[i] = gmask[i]; moff[i] = gmoff[i]; }
 			const uint32_t mTot = gmoff[nNs] + __popcll(gmask[nNs]);
 			const uint32_t* gforms = W.matchForm + mBase;
-			for (uint32_t k = lane; k < mTot; k += 64) { const uint32_t fi = gforms[k]; mforms[k] = fi; mfrec[k] = M.forms[fi]; }
+			if (mTot > latticeLdsCap(n, mCap)) { if (lane == 0) W.nNodes[chunk] = kLatticeNeedsBig; return; }    // wave-uniform
+			for (uint32_t k = lane; k < mTot; k += 64)
+			{
+				const uint32_t fi = gforms[k]; const FormRec f = M.forms[fi];
+				mforms[k] = fi; mfrec[k] = make_uint2(f.charOff, (uint32_t)f.len | ((uint32_t)f.numSpaces << 8) | ((uint32_t)f.flags << 16));
+			}
 		}
 		LatticeCtx L;
 		L.M = &M; L.P = &P; L.str = str; L.nsToPos = nsToPos; L.posToNs = posToNs;
 		L.out = reinterpret_cast<DevNode*>(lSmem + lay.out); L.endPosMap = reinterpret_cast<uint32_t*>(lSmem + lay.endPosMap);
-		L.fullMask = reinterpret_cast<uint64_t*>(lSmem + lay.fullMask); L.zAt = lSmem + lay.zAt; L.nOut = 0; L.cap = cap; L.overflow = false;
+		L.fullMask = reinterpret_cast<uint64_t*>(lSmem + lay.fullMask); L.zAt = lSmem + lay.zAt; L.nOut = 0; L.cap = latticeLdsCap(n, cap); L.overflow = false;
+		const uint32_t ldsCap = L.cap;
 		for (uint32_t i = lane; i < nMap; i += 64) { L.endPosMap[i] = 0; L.fullMask[i] = 0; L.zAt[i] = 0; }    // first == second : empty
 		waveSync();
-		LatticeMem Q{ str, cls, script, cflag, mask, moff, mforms, mfrec, reinterpret_cast<uint16_t*>(lSmem + lay.queue), reinterpret_cast<uint16_t*>(lSmem + lay.queue) + cap };
+		LatticeMem Q{ str, cls, script, cflag, mask, moff, mforms, mfrec, reinterpret_cast<uint16_t*>(lSmem + lay.queue), reinterpret_cast<uint16_t*>(lSmem + lay.queue) + ldsCap };
 		uint32_t nConn = 0, G = 0, err = 0;
 		if (lane == 0)
 		{
@@ -546,12 +554,12 @@ namespace kamd
 			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
 			L.out[0] = bos; L.nOut = 1;
 			latticeSerialBuild(M, B, P, L, Q, chunk, n, nNs, nMap);
-			if (L.overflow || L.nOut + 1 >= cap) err = CS_ERR_NODE_OVERFLOW;
-			else { G = L.nOut; nConn = latticeConnect(L, Q, cap, nNs); }
+			if (L.overflow || L.nOut + 1 >= ldsCap) err = ldsCap < cap ? 0xFFFFu : (uint32_t)CS_ERR_NODE_OVERFLOW;   // 0xFFFF: outgrew the LDS copy only
+			else { G = L.nOut; nConn = latticeConnect(L, Q, ldsCap, nNs); }
 		}
 		waveSync();
 		err = __shfl(err, 0); G = __shfl(G, 0); nConn = __shfl(nConn, 0);
-		if (err) { if (lane == 0) W.results[chunk].status = err; return; }
+		if (err) { if (lane == 0) { if (err == 0xFFFFu) W.nNodes[chunk] = kLatticeNeedsBig; else W.results[chunk].status = err; } return; }
 
 		// ---- final records, one node per lane; candidate-record offsets by a wave scan over the new order ----
 		DevNode* fin = W.nodes + nBase;
@@ -595,7 +603,7 @@ namespace kamd
 		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
 		const uint32_t nNs = W.nNs[chunk];
 		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
-		if (latticeLdsLayout(n, cap, W.matchBase[chunk + 1] - W.matchBase[chunk]).total <= ldsBytes) return;   // done by the wave-per-chunk kernel
+		if (latticeLdsLayout(n, cap, W.matchBase[chunk + 1] - W.matchBase[chunk]).total <= ldsBytes && W.nNodes[chunk] != kLatticeNeedsBig) return;   // done by the wave-per-chunk kernel
 		const uint16_t* str = B.chars + cOff;
 		const uint8_t* cls = B.cls + cOff;
 		LatticeCtx L;
