@@ -48,6 +48,19 @@ def cpu_baseline(model_path, texts, budget_s=20.0):
     return out
 
 
+def measured_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, separate
+    rocprofv3 --pmc runs of this same command; see profiles/README.md).  None when no measurement of this workload is on file."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+        if t.get("workload") == workload:
+            return t["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +135,7 @@ def main():
             search_bytes = per["search"] * n
             achieved = search_bytes / (kt["search_ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_best_path", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, "k_best_path"),
                                "alg_bytes_per_sentence": per, "all_kernels_achieved": per["total"] * n / ((kt["scan_ms"] + kt["lattice_ms"] + kt["search_ms"] + kt["finish_ms"]) * 1e-3) / 1e9}
             out["cpu_baseline"] = cb["cpu_baseline"]
         print(json.dumps(out))

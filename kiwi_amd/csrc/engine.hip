@@ -92,6 +92,7 @@ namespace kamd
 		int subBatches = 0;   // 0 = automatic
 		int device = 0;
 		uint32_t persistBlocks = 0;
+		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter;
 
@@ -150,6 +151,7 @@ namespace kamd
 			if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) impl->groupLanes = v;
 			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16, 32 or 64" };
 		}
+		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
 		impl->counter.ensure(256);
 	}
 
@@ -290,7 +292,6 @@ namespace kamd
 #ifdef KAMD_TIMELINE
 	static void* gTimeline = nullptr;
 #endif
-	constexpr uint32_t kLatticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for
 	static KernelTimes launchAll(Engine::Impl& I, StagedBatch& b, const SearchParams& sp)
 	{
 		KernelTimes t;
@@ -340,7 +341,7 @@ namespace kamd
 			for (uint32_t c = c0; c < c1; ++c)
 			{
 				const uint32_t need = latticeLdsLayout(b.charOff[c + 1] - b.charOff[c], b.nodeBase[c + 1] - b.nodeBase[c], b.matchBase[c + 1] - b.matchBase[c]).total;
-				if (need <= kLatticeLdsBudget) latLds = std::max(latLds, need); else anyBig = true;
+				if (need <= I.latticeLdsBudget) latLds = std::max(latLds, need); else anyBig = true;
 			}
 			if (latLds) hipLaunchKernelGGL(k_build_lattice, dim3(cn), dim3(64), latLds, sA, I.dview, b.bv, b.wv, sp, c0, cn, latLds);
 			// always launched: it also picks up chunks that outgrew their LDS copy at run time (returns at once otherwise)
@@ -356,8 +357,8 @@ namespace kamd
 			wv.beacon = nullptr;
 #ifdef KAMD_TIMELINE
 			static DevBuf tlBuf;
-			tlBuf.ensure((size_t)nC * 96);
-			HIPCHECK(hipMemsetAsync(tlBuf.p, 0, (size_t)nC * 96, sB));
+			tlBuf.ensure((size_t)nC * 128);
+			HIPCHECK(hipMemsetAsync(tlBuf.p, 0, (size_t)nC * 128, sB));
 			wv.beacon = tlBuf.as<uint32_t>(); gTimeline = tlBuf.p;
 #endif
 #ifdef KAMD_BEACON
@@ -437,16 +438,16 @@ namespace kamd
 		if (getenv("KAMD_TIMELINE_PRINT") && gTimeline)
 		{
 			// developer aid: per-chunk stamps of the search kernel (constant 100 MHz clock) -> where a chunk's time goes
-			std::vector<unsigned long long> tl((size_t)nC * 12);
+			std::vector<unsigned long long> tl((size_t)nC * 16);
 			HIPCHECK(hipMemcpy(tl.data(), gTimeline, tl.size() * 8, hipMemcpyDeviceToHost));
 			unsigned long long t0 = ~0ull, tEnd = 0;
-			for (uint32_t c = 0; c < nC; ++c) if (tl[12ull * c]) { t0 = std::min(t0, tl[12ull * c]); tEnd = std::max(tEnd, tl[12ull * c + 2]); }
+			for (uint32_t c = 0; c < nC; ++c) if (tl[16ull * c]) { t0 = std::min(t0, tl[16ull * c]); tEnd = std::max(tEnd, tl[16ull * c + 2]); }
 			std::vector<double> start, nodes, fin, perNode;
 			for (uint32_t c = 0; c < nC; ++c)
 			{
-				if (!tl[12ull * c] || !tl[12ull * c + 2]) continue;
-				start.push_back((tl[12ull * c] - t0) * 0.01); nodes.push_back((tl[12ull * c + 1] - tl[12ull * c]) * 0.01); fin.push_back((tl[12ull * c + 2] - tl[12ull * c + 1]) * 0.01);
-				perNode.push_back(nodes.back() / std::max<double>(1.0, (double)(uint32_t)tl[12ull * c + 3]));
+				if (!tl[16ull * c] || !tl[16ull * c + 2]) continue;
+				start.push_back((tl[16ull * c] - t0) * 0.01); nodes.push_back((tl[16ull * c + 1] - tl[16ull * c]) * 0.01); fin.push_back((tl[16ull * c + 2] - tl[16ull * c + 1]) * 0.01);
+				perNode.push_back(nodes.back() / std::max<double>(1.0, (double)(uint32_t)tl[16ull * c + 3]));
 			}
 			auto stat = [](std::vector<double> v, const char* name)
 			{
@@ -456,12 +457,17 @@ namespace kamd
 				fprintf(stderr, "[timeline] %-26s mean %9.1f  p50 %9.1f  p90 %9.1f  p99 %9.1f  max %9.1f  (us, n=%zu)\n", name, sum / v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back(), v.size());
 			};
 			fprintf(stderr, "[timeline] first chunk start -> last chunk end: %.1f us\n", (tEnd - t0) * 0.01);
-			static const char* phName[8] = { "ph0 node setup", "ph1 classify/batch form", "ph2 scoring (+Knlm)", "ph3 emission", "ph4 prune", "ph5 bookkeeping", "ph6 passes/reach", "ph7" };
-			for (int k = 0; k < 7; ++k)
+			static const char* phName[12] = { "ph0 node setup", "ph1 cand record + misc", "ph2 scoring (+Knlm)", "ph3 emission: write states", "ph4 prune", "ph5 bookkeeping", "ph6 passes/reach", "ph7 emission: dedup", "ph8 classify (pack load)", "ph9 batch formation", "ph10", "ph11" };
+			for (int k = 0; k < 10; ++k)
 			{
 				std::vector<double> v;
-				for (uint32_t c = 0; c < nC; ++c) if (tl[12ull * c] && tl[12ull * c + 2]) v.push_back(tl[12ull * c + 4 + k] * 0.01 / std::max<double>(1.0, (double)(uint32_t)tl[12ull * c + 3]));
+				for (uint32_t c = 0; c < nC; ++c) if (tl[16ull * c] && tl[16ull * c + 2]) v.push_back(tl[16ull * c + 4 + k] * 0.01 / std::max<double>(1.0, (double)(uint32_t)tl[16ull * c + 3]));
 				stat(v, phName[k]);
+			}
+			{
+				std::vector<double> mhz;
+				for (uint32_t c = 0; c < nC; ++c) if (tl[16ull * c] && tl[16ull * c + 1] > tl[16ull * c]) mhz.push_back((double)tl[16ull * c + 15] / ((tl[16ull * c + 1] - tl[16ull * c]) * 0.01));
+				stat(mhz, "shader clock (MHz)");
 			}
 			stat(start, "chunk start offset"); stat(nodes, "node loop"); stat(fin, "end-candidate stage"); stat(perNode, "node loop / node");
 		}

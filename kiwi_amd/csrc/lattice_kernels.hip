@@ -659,7 +659,9 @@ namespace kamd
 				const uint32_t flags = o.m1.y & 0xFFFF; const uint8_t tag = (uint8_t)o.m1.z;
 				const uint32_t firstWid = (flags & MF_SINGLE) ? o.m0.x : M.chunkLm[o.m0.z];
 				const uint32_t sbType = tag == T_SB ? M.sbInfo[mid] : 0;
-				o.x = Quad{ mid, firstWid, sbType, 0 };
+				// 4th word: LM id of the second chunk of a chunked candidate (saves the search a dependent chunk-table load)
+				const uint32_t secondWid = (!(flags & MF_SINGLE) && (o.m1.w & 0xFF) >= 2) ? M.chunkLm[o.m0.z + 1] : 0;
+				o.x = Quad{ mid, firstWid, sbType, secondWid };
 				packs[nd.packOff + k] = o;
 			}
 		}

@@ -75,7 +75,7 @@ namespace kamd
 #define GUARD(n, limit, site)
 #endif
 #ifdef KAMD_TIMELINE
-#define TLMARK(X, k) { if ((X).gl == 0) { LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>((X).lds + Lay<G>::TLACC); const unsigned long long t_ = wall_clock64(); a_[k] += t_ - a_[8]; a_[8] = t_; } }
+#define TLMARK(X, k) { if ((X).gl == 0) { LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>((X).lds + Lay<G>::TLACC); const unsigned long long t_ = wall_clock64(); a_[k] += t_ - a_[12]; a_[12] = t_; } }
 #else
 #define TLMARK(X, k)
 #endif
@@ -134,8 +134,8 @@ namespace kamd
 		static constexpr uint32_t NODES = HTYPO + 4 * HCAP;         // 32 B x NCAP
 		static constexpr uint32_t PACKS = NODES + 32 * NCAP;        // 48 B x (PCAP + 2): last two = the unknown-noun candidates
 #ifdef KAMD_TIMELINE
-		static constexpr uint32_t TLACC = (PACKS + 48 * (G == 64 ? PCAP + 2 : 0) + 15) & ~15u;   // u64[9]: 8 phase sums + last stamp
-		static constexpr uint32_t SIZE = (TLACC + 80 + 15) & ~15u;
+		static constexpr uint32_t TLACC = (PACKS + 48 * (G == 64 ? PCAP + 2 : 0) + 15) & ~15u;   // u64[13]: 12 phase sums + last stamp
+		static constexpr uint32_t SIZE = (TLACC + 112 + 15) & ~15u;
 #else
 		static constexpr uint32_t SIZE = (PACKS + 48 * (G == 64 ? PCAP + 2 : 0) + 15) & ~15u;
 #endif
@@ -174,6 +174,7 @@ namespace kamd
 		uint32_t sbw;        // sbType | firstWid of a chunked candidate is in firstWid
 		uint32_t ruleBits;
 		uint32_t firstWid;   // first LM id fed (lmId, or the first chunk's for chunked candidates)
+		uint32_t secondWid;  // LM id of the second chunk (chunked candidates with >= 2 chunks)
 		__device__ __forceinline__ uint32_t flags() const { return flagsFeat & 0xFFFF; }
 		__device__ __forceinline__ uint8_t tag() const { return (uint8_t)tagw; }
 		__device__ __forceinline__ uint8_t vowel() const { return (uint8_t)(tagw >> 8); }
@@ -197,7 +198,7 @@ namespace kamd
 		o.lmId = a.x; o.lastSeqId = a.y; o.chunkOff = a.z; o.userScore = __uint_as_float(a.w);
 		o.combinedId = (int32_t)b.x; o.flagsFeat = b.y; o.tagw = b.z; o.cntw = b.w;
 		o.morph = c.x; o.qOff = c.y; o.R = c.z; o.additional = __uint_as_float(c.w);
-		o.sbw = d.x; o.ruleBits = d.y; o.firstWid = d.z;
+		o.sbw = d.x; o.ruleBits = d.y; o.firstWid = d.z; o.secondWid = d.w;
 		return o;
 	}
 
@@ -239,10 +240,13 @@ namespace kamd
 			GUARD(g1, 100000, 1)
 			const uint4* p = reinterpret_cast<const uint4*>(M.lmHash + (size_t)b * 4);
 			const uint4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
-			if (s0.x == node && s0.y == wid) { v = (int32_t)s0.z; ll = __uint_as_float(s0.w); return true; }
-			if (s1.x == node && s1.y == wid) { v = (int32_t)s1.z; ll = __uint_as_float(s1.w); return true; }
-			if (s2.x == node && s2.y == wid) { v = (int32_t)s2.z; ll = __uint_as_float(s2.w); return true; }
-			if (s3.x == node && s3.y == wid) { v = (int32_t)s3.z; ll = __uint_as_float(s3.w); return true; }
+			const bool h0 = (s0.x == node) & (s0.y == wid), h1 = (s1.x == node) & (s1.y == wid), h2 = (s2.x == node) & (s2.y == wid), h3 = (s3.x == node) & (s3.y == wid);
+			if (h0 | h1 | h2 | h3)
+			{
+				const uint32_t vz = h0 ? s0.z : h1 ? s1.z : h2 ? s2.z : s3.z, vw = h0 ? s0.w : h1 ? s1.w : h2 ? s2.w : s3.w;
+				v = (int32_t)vz; ll = __uint_as_float(vw);
+				return true;
+			}
 			if (s3.x == LM_SLOT_EMPTY) return false;   // slots fill front to back: a free last slot means the bucket never overflowed
 			b = (b + 1) & M.lmHashMask;
 		}
@@ -460,7 +464,7 @@ namespace kamd
 		// Common case (G == 16): the whole batch fits the group once and the node uses the small container -- scores stay in
 		// registers and the per-key de-duplication runs on DPP rotations instead of LDS scans.
 		const bool fast = (G == 16) && Qtot <= (uint32_t)G && mode == 0;
-		uint64_t rKey = KINVALID; float rScore = 0, rFcs = 0;
+		uint64_t rKey = KINVALID; float rScore = 0, rFcs = 0, rTypo = 0;
 
 		// ---- scoring pass: one work item per lane -------------------------------------------------------
 		GUARD_DECL(g7)
@@ -478,6 +482,7 @@ namespace kamd
 				const uint32_t local = q - c.qOff;
 				const uint32_t p = local / c.R, r = local % c.R;
 				const Hot ps = getHot<G>(X, pBeg + p);
+				if (fast) rTypo = getTypo<G>(X, pBeg + p);      // rides along with the hot quad: the winner's is picked up by a lane read later
 				const bool single = c.single();
 				const uint8_t ctag = c.tag(), csock = c.socket();
 				uint32_t firstWid = c.firstWid; bool widReplaced = false;
@@ -530,7 +535,7 @@ namespace kamd
 							const uint32_t nCh = c.nChunks();
 							for (uint32_t ch = 1; ch < nCh; ++ch)
 							{
-								const uint32_t wid = M.chunkLm[c.chunkOff + ch];
+								const uint32_t wid = ch == 1 ? c.secondWid : M.chunkLm[c.chunkOff + ch];
 								if ((c.flags() & MF_ANY_REST_WID_IS_P) && M.morphs[wid].tag == T_P) { valid = false; break; }
 								ll = lmProgress(M, lmNode, wid);
 								cand += ll;
@@ -568,12 +573,12 @@ namespace kamd
 
 		// ---- emission pass: representatives in container iteration order, each carrying its key's winner ----
 		// writes the state of key `wkey` (winner item qw of candidate k) at arena slot pos
-		auto emitState = [&](uint32_t k, uint32_t qw, uint64_t wkey, float wscore, float wfcs, uint32_t pos)
+		auto emitState = [&](uint32_t k, uint32_t qw, uint64_t wkey, float wscore, float wfcs, uint32_t pos, bool haveTypo, float parentTypo)
 		{
 			const Cand c = loadCand(X.candOff(k));
 			const uint32_t local = qw - c.qOff;
 			const uint32_t parent = pBeg + local / c.R, r = local % c.R;
-			const float wtypo = getTypo<G>(X, parent) + 0.f;
+			const float wtypo = (haveTypo ? parentTypo : getTypo<G>(X, parent)) + 0.f;
 			const bool single = c.single();
 			const uint8_t rootKey = (uint8_t)(wkey >> 40);
 			const uint8_t newRoot = (c.quoteOrBullet() && rootKey == COMMON_ROOT) ? (uint8_t)r : rootKey;
@@ -592,17 +597,23 @@ namespace kamd
 				const uint32_t keyLo = (uint32_t)rKey, keyHi = (uint32_t)(rKey >> 32);
 				bool rep = rKey != KINVALID;
 				float best = rScore; uint32_t qw = q;
+				// branch-free on purpose (bitwise logic on predicates + selects): 15 short dependent steps instead of 45 exec-mask branches
 #define KAMD_ROT_STEP(N) { const uint32_t oi = rowRor<N>(q), ol = rowRor<N>(keyLo), oh = rowRor<N>(keyHi); const float os = rowRorF<N>(rScore); \
-				if (ol == keyLo && oh == keyHi) { if (oi < q) rep = false; if (os > best || (os == best && oi < qw)) { best = os; qw = oi; } } }
+				const bool same = (ol == keyLo) & (oh == keyHi); \
+				rep = rep & !(same & (oi < q)); \
+				const bool better = same & ((os > best) | ((os == best) & (oi < qw))); \
+				best = better ? os : best; qw = better ? oi : qw; }
 				KAMD_ROT_STEP(1) KAMD_ROT_STEP(2) KAMD_ROT_STEP(3) KAMD_ROT_STEP(4) KAMD_ROT_STEP(5) KAMD_ROT_STEP(6) KAMD_ROT_STEP(7) KAMD_ROT_STEP(8)
 				KAMD_ROT_STEP(9) KAMD_ROT_STEP(10) KAMD_ROT_STEP(11) KAMD_ROT_STEP(12) KAMD_ROT_STEP(13) KAMD_ROT_STEP(14) KAMD_ROT_STEP(15)
 #undef KAMD_ROT_STEP
+				TLMARK(X, 7)
 				const float wfcs = X.bcast(rFcs, (int)qw);
+				const float wtyp = X.bcast(rTypo, (int)qw);
 				const uint64_t kbal = X.ballot(rep);
 				if (rep)
 				{
 					const uint32_t pos = X.stTop + X.prefix(kbal);
-					if (pos < X.stCap) emitState((uint32_t)(rKey >> 48), qw, rKey, best, wfcs, pos);
+					if (pos < X.stCap) emitState((uint32_t)(rKey >> 48), qw, rKey, best, wfcs, pos, true, wtyp);
 					else X.overflow = true;
 				}
 				X.stTop += __popcll(kbal);
@@ -658,7 +669,7 @@ namespace kamd
 							const uint64_t wkey = big ? X.scratch->key[qw] : X.qKey()[qw];
 							const float wscore = big ? X.scratch->score[qw] : X.qScore()[qw];
 							const float wfcs = big ? X.scratch->fcs[qw] : X.qFcs()[qw];
-							emitState(k, qw, wkey, wscore, wfcs, pos);
+							emitState(k, qw, wkey, wscore, wfcs, pos, false, 0.f);
 						}
 						else X.overflow = true;
 					}
@@ -776,6 +787,7 @@ namespace kamd
 						Q = E.nP * R;
 					}
 				}
+				TLMARK(X, 8)
 				uint32_t nTake = 0, nC = 0, Qtot = 0, myK = 0xFFFFFFFFu, myOff = 0, zMorph = 0;
 				bool zShortcut = false;
 				for (int j = 0; j < MAXC; ++j)
@@ -797,6 +809,7 @@ namespace kamd
 					++nC; Qtot += Qj; ++nTake;
 					if (mode != 0 || Qtot > QCAP) break;
 				}
+				TLMARK(X, 9)
 				if (myK != 0xFFFFFFFFu)
 				{
 					const uint8_t tag = (uint8_t)m1.z;
@@ -805,7 +818,7 @@ namespace kamd
 					const uint32_t o = X.candOff(myK);
 					ldsStore4(o, m0); ldsStore4(o + 16, m1);
 					ldsStore4(o + 32, make_uint4(mid, myOff, R, __float_as_uint(additional)));
-					ldsStore4(o + 48, make_uint4(sbType, ruleBits, mx.y, 0));
+					ldsStore4(o + 48, make_uint4(sbType, ruleBits, mx.y, mx.w));
 				}
 				waveSync();
 				c += nTake;
@@ -1193,9 +1206,10 @@ namespace kamd
 		uint8_t* reach = W.reach + nBase;
 		if (X.nUniq + 1 > SB_SLOT_MASK) { if (X.gl == 0) { res->status = CS_ERR_PATH_OVERFLOW; res->nPaths = 0; } return; }
 #ifdef KAMD_TIMELINE
-		unsigned long long* tl = W.beacon ? reinterpret_cast<unsigned long long*>(W.beacon) + 12ull * chunk : nullptr;
+		unsigned long long* tl = W.beacon ? reinterpret_cast<unsigned long long*>(W.beacon) + 16ull * chunk : nullptr;
+		const unsigned long long tlClk0 = clock64();
 		if (tl && X.gl == 0) { tl[0] = wall_clock64(); tl[3] = ((unsigned long long)blockIdx.x << 32) | X.Gn; }
-		if (X.gl == 0) { LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>(X.lds + Lay<G>::TLACC); for (int k = 0; k < 8; ++k) a_[k] = 0; a_[8] = wall_clock64(); }
+		if (X.gl == 0) { LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>(X.lds + Lay<G>::TLACC); for (int k = 0; k < 12; ++k) a_[k] = 0; a_[12] = wall_clock64(); }
 #endif
 
 		if constexpr (Lay<G>::NCAP != 0)
@@ -1374,7 +1388,7 @@ namespace kamd
 		}
 		BEACON(X, 0x0E000000u)
 #ifdef KAMD_TIMELINE
-		if (tl && X.gl == 0) { tl[1] = wall_clock64(); LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>(X.lds + Lay<G>::TLACC); for (int k = 0; k < 8; ++k) tl[4 + k] = a_[k]; }
+		if (tl && X.gl == 0) { const unsigned long long clkNow_ = clock64(); tl[1] = wall_clock64(); LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>(X.lds + Lay<G>::TLACC); for (int k = 0; k < 11; ++k) tl[4 + k] = a_[k]; tl[15] = clkNow_ - tlClk0; }
 #endif
 #ifdef KAMD_CRUMBS
 		if (X.gl == 0) res->nEnd = 0xA1000000u;

@@ -115,6 +115,25 @@ def test_batch_properties_at_benchmark_size(engine, small_model):
     assert b.info()["chunks"] >= len(texts)
 
 
+def test_lattice_hbm_kernel_matches_lds_kernel(engine, oracle, small_model, monkeypatch):
+    """The wave-per-chunk lattice build (working set in LDS) and the thread-per-chunk build (HBM) it hands large chunks to
+    produce the same lattices and tokens; KAMD_LATTICE_LDS=0 forces every chunk through the HBM kernel, a tiny budget mixes both."""
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    texts = synthetic(sm, 300, 91, min_jamo=5, max_jamo=200) + dictionary_mix(sm, 200, 92)
+    want = engine.analyze_batch(texts).to_python()
+    for budget in ("0", "6000"):
+        monkeypatch.setenv("KAMD_LATTICE_LDS", budget)
+        other = KiwiAmd(path)
+        got = other.analyze_batch(texts).to_python()
+        for s, x, y in zip(texts, want, got):
+            assert _norm(x) == _norm(y), (budget, s)
+        for s in texts[:40]:
+            assert other.split(s) == oracle.split(s), (budget, s)
+        other.close()
+    monkeypatch.delenv("KAMD_LATTICE_LDS")
+
+
 def test_empty_and_degenerate_batches(engine):
     assert engine.analyze_batch([]).n_texts() == 0
     r = engine.analyze_batch(["", " ", "\n"]).to_python()
