@@ -19,7 +19,7 @@
 namespace kamd
 {
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
-	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
+	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
 
@@ -80,6 +80,7 @@ namespace kamd
 		std::vector<DevToken> hTokens;
 		bool ran = false;
 		uint32_t subBatches = 0;
+		std::vector<uint32_t> order;   // host copy of dOrder (work order: longest chunk first inside each sub-batch)
 	};
 
 	struct Engine::Impl
@@ -315,6 +316,7 @@ namespace kamd
 				std::stable_sort(order.begin() + c0, order.begin() + c1, [&](uint32_t a, uint32_t c) { return b.charOff[a + 1] - b.charOff[a] > b.charOff[c + 1] - b.charOff[c]; });
 			}
 			upload(b.dOrder, order, sA);
+			b.order = order;
 			b.subBatches = S;
 		}
 		const size_t nEv = 6 * (size_t)S + 2;
@@ -336,17 +338,24 @@ namespace kamd
 			HIPCHECK(hipEventRecord(e[0], sA));
 			hipLaunchKernelGGL(k_dict_scan, dim3((cn + 3) / 4), dim3(256), 0, sA, I.dview, b.bv, b.wv, c0, cn);
 			HIPCHECK(hipEventRecord(e[1], sA));
-			// wave-per-chunk build with the chunk's working set in LDS; chunks beyond the LDS budget go to the thread-per-chunk kernel
-			uint32_t latLds = 0; bool anyBig = false;
-			for (uint32_t c = c0; c < c1; ++c)
+			// wave-per-chunk build with the chunk's working set in LDS.  The dynamic LDS size of a launch is uniform, so the
+			// work order (longest chunk first = largest LDS need first) is cut into size classes, one launch each: a batch of
+			// mixed lengths does not run at the occupancy its longest chunk allows.  Chunks beyond the budget, and chunks that
+			// outgrow their LDS copy at run time, are picked up by the thread-per-chunk kernel (returns at once otherwise).
 			{
-				const uint32_t need = latticeLdsLayout(b.charOff[c + 1] - b.charOff[c], b.nodeBase[c + 1] - b.nodeBase[c], b.matchBase[c + 1] - b.matchBase[c]).total;
-				if (need <= I.latticeLdsBudget) latLds = std::max(latLds, need); else anyBig = true;
+				auto needOf = [&](uint32_t c) { return latticeLdsLayout(b.charOff[c + 1] - b.charOff[c], b.nodeBase[c + 1] - b.nodeBase[c], b.matchBase[c + 1] - b.matchBase[c]).total; };
+				uint32_t i = c0;
+				while (i < c1 && needOf(b.order[i]) > I.latticeLdsBudget) ++i;
+				while (i < c1)
+				{
+					const uint32_t need = needOf(b.order[i]);
+					uint32_t j = i + 1;
+					while (j < c1 && (uint64_t)needOf(b.order[j]) * 4 >= (uint64_t)need * 3) ++j;      // <= 25 % of a class's LDS unused
+					hipLaunchKernelGGL(k_build_lattice, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need);
+					i = j;
+				}
+				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget);
 			}
-			if (latLds) hipLaunchKernelGGL(k_build_lattice, dim3(cn), dim3(64), latLds, sA, I.dview, b.bv, b.wv, sp, c0, cn, latLds);
-			// always launched: it also picks up chunks that outgrew their LDS copy at run time (returns at once otherwise)
-			(void)anyBig;
-			hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, latLds);
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn);
 			HIPCHECK(hipEventRecord(e[2], sA));
 			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));

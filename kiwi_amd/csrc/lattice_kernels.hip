@@ -502,11 +502,11 @@ namespace kamd
 	// dependent HBM round trip: the chunk's text, index maps, packed matches (+ their form records) are staged into LDS by
 	// all lanes first, the node list grows in LDS, and the final reorder / per-node fact computation runs one node per lane.
 	// Chunks whose working set exceeds ldsBytes are left to k_build_lattice_big.
-	__global__ void __launch_bounds__(64) k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes)
+	__global__ void __launch_bounds__(64) k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
 	{
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t lane = threadIdx.x;
-		const uint32_t chunk = chunkBegin + blockIdx.x;
+		const uint32_t chunk = chunkList[blockIdx.x];      // one launch per LDS size class: a slice of the longest-first work order
 		if (W.results[chunk].status >= 16) return;
 		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
 		const uint32_t nNs = W.nNs[chunk];
