@@ -69,7 +69,7 @@ namespace kamd
 	};
 	static_assert(sizeof(DevToken) == 24, "DevToken");
 
-	constexpr uint32_t kMaxPathsPerChunk = 8;
+	constexpr uint32_t kMaxPathsPerChunk = 16;
 	struct DevPathHeader { float score; uint32_t tokOff; uint16_t nTokens; uint8_t prevState, curState; };
 	// nEnd/endOff: end-node candidates of the chunk, left by k_best_path in the unused tail of the chunk's state arena
 	// (entry index endOff, 24-byte records) for k_finish_paths
@@ -88,7 +88,9 @@ namespace kamd
 		float cutOff, spacePenalty, typoCostWeight, oovRuleScale, oovRuleBias;
 		uint32_t maxUnk, maxUnkJ, spaceTol;
 		uint32_t splitComplex, splitSaisiot, mergeSaisiot;
+		uint32_t topN;                 // paths kept per (candidate, key): 1..kMaxTopN (BestPathContainer.hpp:151-222 for N > 1)
 	};
+	constexpr uint32_t kMaxTopN = 4;      // the end stage hands on ceil(2N / groups) <= kMaxPathsPerChunk paths
 
 	struct BatchView
 	{

@@ -80,6 +80,7 @@ namespace kamd
 		std::vector<DevToken> hTokens;
 		bool ran = false;
 		uint32_t subBatches = 0;
+		uint32_t topN = 1;            // the search of the last run() kept this many paths per key
 		std::vector<uint32_t> order;   // host copy of dOrder (work order: longest chunk first inside each sub-batch)
 	};
 
@@ -280,13 +281,14 @@ namespace kamd
 		b.ran = false;
 	}
 
-	static SearchParams makeParams(const EngineConfig& c, uint64_t match)
+	static SearchParams makeParams(const EngineConfig& c, uint64_t match, uint32_t topN = 1)
 	{
 		SearchParams p{};
 		p.match = match; p.cutOff = c.cutOffThreshold; p.spacePenalty = c.spacePenalty; p.typoCostWeight = c.typoCostWeight;
 		p.oovRuleScale = c.oovRuleScale; p.oovRuleBias = c.oovRuleBias;
 		p.maxUnk = c.maxUnkFormSize; p.maxUnkJ = c.maxUnkFormSizeFollowedByJClass; p.spaceTol = c.spaceTolerance;
 		p.splitComplex = (match & M_SPLIT_COMPLEX) ? 1 : 0; p.splitSaisiot = (match & M_SPLIT_SAISIOT) ? 1 : 0; p.mergeSaisiot = (match & M_MERGE_SAISIOT) ? 1 : 0;
+		p.topN = topN;
 		return p;
 	}
 
@@ -556,7 +558,7 @@ namespace kamd
 		return b;
 	}
 
-	KernelTimes Engine::run(StagedBatch& b) { return launchAll(*impl, b, makeParams(config, b.match)); }
+	KernelTimes Engine::run(StagedBatch& b) { return launchAll(*impl, b, makeParams(config, b.match, b.topN)); }
 	size_t Engine::stagedChunks(const StagedBatch& b) { return b.refs.size(); }
 	uint64_t Engine::stagedUnits(const StagedBatch& b) { return b.units; }
 	uint64_t Engine::stagedDeviceBytes(const StagedBatch& b) { return b.devBytes; }
@@ -566,12 +568,12 @@ namespace kamd
 		std::vector<std::vector<PathResult>>& out)
 	{
 		StagedBatch b;
-		b.match = parent.match; b.capScale = capScale;
+		b.match = parent.match; b.capScale = capScale; b.topN = parent.topN;
 		b.prep.swap(parent.prep);   // borrow
 		b.refs = std::move(refs);
 		try
 		{
-			const SearchParams sp = makeParams(E.config, b.match);
+			const SearchParams sp = makeParams(E.config, b.match, b.topN);
 			layoutAndUpload(I, b, sp);
 			launchAll(I, b, sp);
 			download(I, b);
@@ -596,8 +598,8 @@ namespace kamd
 
 	std::vector<std::vector<TokenResult>> Engine::fetch(StagedBatch& b, size_t topN)
 	{
-		if (topN != 1) throw std::invalid_argument{ "kiwi_amd: top_n > 1 is not implemented on the device path yet" };
-		if (!b.ran) run(b);
+		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
+		if (!b.ran || b.topN != (uint32_t)topN) { b.topN = (uint32_t)topN; run(b); }
 		download(*impl, b);
 		const size_t nT = b.prep.size();
 		std::vector<std::vector<TokenResult>> ret(nT);
@@ -638,8 +640,9 @@ namespace kamd
 	std::vector<std::vector<TokenResult>> Engine::analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
 		size_t topN, uint64_t match, bool openEnding, int hostThreads)
 	{
-		if (topN != 1) throw std::invalid_argument{ "kiwi_amd: top_n > 1 is not implemented on the device path yet" };
+		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
 		auto b = stage(texts, match, openEnding, hostThreads);
+		b->topN = (uint32_t)topN;
 		run(*b);
 		return fetch(*b, topN);
 	}

@@ -27,7 +27,8 @@
 // Reference behaviour reproduced: BestPathFinder::findBestPath (src/PathEvaluator.hpp:1178-1419),
 // PathEvaluator::operator()/evalSingleMorpheme (:347-635), RuleBasedScorer/insertToPathContainer/
 // FormEvaluator (:88-311), generateTokenList (:1038-1157), KnLangModel::progress (src/Knlm.cpp:44-130).
-// top-N > 1 is not implemented here (the host refuses it).
+// top-N (1 < N <= kMaxTopN): the N best paths per key are kept (each with its own values), pruning uses the N-th best score
+// of a root, the end stage hands on ceil(2N / groups) candidates per group; kept paths are handed on in item order (top-N).
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
 #include "feature.hpp"
@@ -597,16 +598,24 @@ namespace kamd
 				const uint32_t keyLo = (uint32_t)rKey, keyHi = (uint32_t)(rKey >> 32);
 				bool rep = rKey != KINVALID;
 				float best = rScore; uint32_t qw = q;
+				uint32_t beaten = 0;      // top-N: items of the same key that beat this one (higher score, or equal and earlier)
 				// branch-free on purpose (bitwise logic on predicates + selects): 15 short dependent steps instead of 45 exec-mask branches
 #define KAMD_ROT_STEP(N) { const uint32_t oi = rowRor<N>(q), ol = rowRor<N>(keyLo), oh = rowRor<N>(keyHi); const float os = rowRorF<N>(rScore); \
 				const bool same = (ol == keyLo) & (oh == keyHi); \
 				rep = rep & !(same & (oi < q)); \
 				const bool better = same & ((os > best) | ((os == best) & (oi < qw))); \
+				beaten += (same & ((os > rScore) | ((os == rScore) & (oi < q)))) ? 1u : 0u; \
 				best = better ? os : best; qw = better ? oi : qw; }
 				KAMD_ROT_STEP(1) KAMD_ROT_STEP(2) KAMD_ROT_STEP(3) KAMD_ROT_STEP(4) KAMD_ROT_STEP(5) KAMD_ROT_STEP(6) KAMD_ROT_STEP(7) KAMD_ROT_STEP(8)
 				KAMD_ROT_STEP(9) KAMD_ROT_STEP(10) KAMD_ROT_STEP(11) KAMD_ROT_STEP(12) KAMD_ROT_STEP(13) KAMD_ROT_STEP(14) KAMD_ROT_STEP(15)
 #undef KAMD_ROT_STEP
 				TLMARK(X, 7)
+				if (X.P.topN > 1)
+				{
+					// keep the N best of every key, each with its own values, in item order (top-N)
+					rep = rKey != KINVALID && beaten < X.P.topN;
+					qw = q; best = rScore;
+				}
 				const float wfcs = X.bcast(rFcs, (int)qw);
 				const float wtyp = X.bcast(rTypo, (int)qw);
 				const uint64_t kbal = X.ballot(rep);
@@ -638,6 +647,21 @@ namespace kamd
 						const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
 						rep = true;
 						float best = -INFINITY; bool haveBest = false;
+						if (X.P.topN > 1)
+						{
+							const float sq = big ? X.scratch->score[q] : X.qScore()[q];
+							uint32_t beaten = 0;
+							for (uint32_t j = lo; j < hi; ++j)
+							{
+								const uint64_t kj = big ? X.scratch->key[j] : X.qKey()[j];
+								if (kj != key || j == q) continue;
+								const float sj = big ? X.scratch->score[j] : X.qScore()[j];
+								if (sj > sq || (sj == sq && j < q)) ++beaten;
+							}
+							rep = beaten < X.P.topN;      // qw stays q: every kept item is written with its own values
+						}
+						else
+						{
 						GUARD_DECL(g5)
 						for (uint32_t j = lo; j < hi; ++j)
 						{
@@ -647,6 +671,7 @@ namespace kamd
 							if (j < q) { rep = false; break; }
 							const float sj = big ? X.scratch->score[j] : X.qScore()[j];
 							if (!haveBest || sj > best) { best = sj; qw = j; haveBest = true; }
+						}
 						}
 						if (rep && mode == 1)
 						{
@@ -659,7 +684,7 @@ namespace kamd
 					const uint64_t bal = X.ballot(rep);
 					// mode 1 runs exactly one candidate per batch, so the per-bucket rank is the container's per-bucket fill
 					const uint32_t rank = emittedInBucket + X.prefix(bal);
-					const bool keep = rep && (mode == 2 || rank < 128);   // a full bucket drops later keys (BestPathContainer.hpp:363-367)
+					const bool keep = rep && (mode == 2 || X.P.topN > 1 || rank < 128);   // a full bucket drops later keys (BestPathContainer.hpp:363-367)
 					const uint64_t kbal = X.ballot(keep);
 					if (keep)
 					{
@@ -738,7 +763,9 @@ namespace kamd
 	{
 		const ModelView& M = X.M;
 		const SearchParams& P = X.P;
-		const int mode = E.nLive <= 128 ? 0 : E.nLive <= 512 ? 1 : 2;
+		// top-N (> 1) uses one container for every size (PathEvaluator.hpp:450-453): batched like the small one, without its 128-key cap
+		const bool topn = P.topN > 1;
+		const int mode = topn ? 0 : E.nLive <= 128 ? 0 : E.nLive <= 512 ? 1 : 2;
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		enum { K_NONE = 0, K_SKIP = 1, K_Z = 2, K_REG = 3 };
 		constexpr int MAXC = Lay<G>::MAXC;
@@ -848,11 +875,28 @@ namespace kamd
 				const uint32_t slot = bits & SB_SLOT_MASK;
 				const bool alive = in && !(bits & SB_DEAD);
 				bool kill = false;
-				for (uint32_t rs = 0; rs < nRootSlots; ++rs)
+				if (!topn)
 				{
-					const bool mine = alive && slot == rs;
-					const float mx = rowMax16((mine && !(bits & SB_MORPH_SOCKET)) ? sc : -INFINITY);
-					if (mine && sc + P.cutOff < mx) kill = true;
+					for (uint32_t rs = 0; rs < nRootSlots; ++rs)
+					{
+						const bool mine = alive && slot == rs;
+						const float mx = rowMax16((mine && !(bits & SB_MORPH_SOCKET)) ? sc : -INFINITY);
+						if (mine && sc + P.cutOff < mx) kill = true;
+					}
+				}
+				else
+				{
+					// threshold = the N-th best score of the root (PathEvaluator.hpp:488-503): a path dies iff at least N
+					// socket-free paths of its root lie more than cutOff above it
+					const float lim = sc + P.cutOff;
+					const uint32_t mineKey = alive ? slot : 0xFFFFu;
+					const uint32_t qual = (alive && !(bits & SB_MORPH_SOCKET)) ? slot : 0xFFFEu;
+					uint32_t above = 0;
+#define KAMD_PRUNE_STEP(N) { const uint32_t oq = rowRor<N>(qual); const float os = rowRorF<N>(sc); above += ((oq == mineKey) & (lim < os)) ? 1u : 0u; }
+					KAMD_PRUNE_STEP(1) KAMD_PRUNE_STEP(2) KAMD_PRUNE_STEP(3) KAMD_PRUNE_STEP(4) KAMD_PRUNE_STEP(5) KAMD_PRUNE_STEP(6) KAMD_PRUNE_STEP(7) KAMD_PRUNE_STEP(8)
+					KAMD_PRUNE_STEP(9) KAMD_PRUNE_STEP(10) KAMD_PRUNE_STEP(11) KAMD_PRUNE_STEP(12) KAMD_PRUNE_STEP(13) KAMD_PRUNE_STEP(14) KAMD_PRUNE_STEP(15)
+#undef KAMD_PRUNE_STEP
+					kill = alive && above >= P.topN;
 				}
 				if (kill) { X.stBits()[X.gl] = bits | SB_DEAD; markDead<G>(X, E.nodeStart + X.gl); }
 				waveSync();
@@ -860,6 +904,46 @@ namespace kamd
 				TLMARK(X, 4)
 				return;
 			}
+		}
+		if (topn)
+		{
+			// general sizes: every path counts the socket-free paths of its root that lie more than cutOff above it; the verdicts
+			// are collected first (one bit per block of G paths in a lane-private mask) and applied after all counting is done
+			if (cnt > 64u * G) { X.pairOverflow = true; return; }
+			uint64_t verdict = 0;
+			for (uint32_t b = 0, blk = 0; b < cnt; b += G, ++blk)
+			{
+				const uint32_t i = b + X.gl;
+				if (i >= cnt) continue;
+				float sc; uint32_t slot; bool dead;
+				if (staged) { const uint8_t bits = X.stBits()[i]; sc = X.stScore()[i]; slot = bits & SB_SLOT_MASK; dead = bits & SB_DEAD; }
+				else { const DevState* s = &X.st[E.nodeStart + i]; sc = s->accScore; slot = s->rootId == COMMON_ROOT ? 0 : s->rootId + 1u; dead = s->dead; }
+				if (dead) continue;
+				const float lim = sc + P.cutOff;
+				uint32_t above = 0;
+				for (uint32_t j = 0; j < cnt; ++j)
+				{
+					float sj; uint32_t slj; bool dj, mj;
+					if (staged) { const uint8_t bj = X.stBits()[j]; sj = X.stScore()[j]; slj = bj & SB_SLOT_MASK; dj = bj & SB_DEAD; mj = bj & SB_MORPH_SOCKET; }
+					else { const DevState* t = &X.st[E.nodeStart + j]; sj = t->accScore; slj = t->rootId == COMMON_ROOT ? 0 : t->rootId + 1u; dj = t->dead; mj = M.morphs[t->morph].socket != 0; }
+					if (!dj && !mj && slj == slot && lim < sj) ++above;
+				}
+				if (above >= P.topN) verdict |= 1ull << blk;
+			}
+			waveSync();
+			for (uint32_t b = 0, blk = 0; b < cnt; b += G, ++blk)
+			{
+				const uint32_t i = b + X.gl;
+				if (i < cnt && ((verdict >> blk) & 1))
+				{
+					if (staged) { X.stBits()[i] = X.stBits()[i] | SB_DEAD; markDead<G>(X, E.nodeStart + i); }
+					else X.st[E.nodeStart + i].dead = 1;
+				}
+			}
+			waveSync();
+			PROF(X, 4)
+			TLMARK(X, 4)
+			return;
 		}
 		for (uint32_t rs = 0; rs < nRootSlots; ++rs)
 		{
@@ -1167,7 +1251,7 @@ namespace kamd
 			for (uint32_t b = 0; b < a && !seen; ++b) seen = endBuf[b].rootId == endBuf[a].rootId && endBuf[b].sp == endBuf[a].sp;
 			if (!seen) ++numUniq;
 		}
-		const uint32_t perGroup = numUniq ? (2 + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq), topN = 1
+		const uint32_t perGroup = numUniq ? (2 * P.topN + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq)
 		DevToken* tok = W.tokens + W.tokenBase[chunk];
 		const uint32_t tokCap = (uint32_t)(W.tokenBase[chunk + 1] - W.tokenBase[chunk]);
 		uint32_t tokTop = 0, startIdx = 0;

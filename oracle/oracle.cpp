@@ -35,11 +35,12 @@ namespace
 	std::vector<TokenResult> analyzeOne(OracleHandle& h, Counters& cnt, const char16_t* text, uint32_t len, uint32_t topN, uint64_t match, bool openEnding,
 		std::vector<std::vector<LNode>>* latticesOut = nullptr)
 	{
-		if (topN != 1) throw std::runtime_error{ "oracle: only top-1 is restated" };
+		if (topN < 1 || topN > 4) throw std::runtime_error{ "oracle: top_n must be 1..4" };
 		PreparedText pt;
 		prepareText(pt, text, len, match, 0);
 		SplitConfig sc = h.scfg; sc.match = match;
 		BestPathConfig bc = h.bcfg;
+		bc.topN = topN;
 		bc.splitComplex = match & M_SPLIT_COMPLEX; bc.splitSaisiot = match & M_SPLIT_SAISIOT; bc.mergeSaisiot = match & M_MERGE_SAISIOT;
 		bc.spaceTolerance = sc.spaceTol;
 		LatticeBuilder lb{ h.view, sc, cnt };

@@ -7,7 +7,12 @@
 //   BestPathConatiner top1 / top1Small / top1Medium /root/reference/src/BestPathContainer.hpp:230-483
 //   generateTokenList                               /root/reference/src/PathEvaluator.hpp:1038-1157
 //   KnLangModel::progress                           /root/reference/src/Knlm.cpp:44-130
-// top-N (> 1) containers are not restated yet: korc_analyze refuses topN != 1.
+// top-N (> 1): the reference keeps, per candidate morpheme, a min-heap of the N best paths per key in a thread_local
+// std::unordered_map (BestPathContainer.hpp:151-222); the ORDER in which it hands them on is the map's bucket order, which
+// depends on everything the thread analysed before (the map is never shrunk).  Only that order is not restated: here (and on
+// the device) the kept paths are handed on in insertion order.  Which paths are kept -- the N best per key, the earlier one
+// on equal scores -- and every score is the reference's; results can differ from a given reference run only where two
+// paths tie exactly.
 #pragma once
 #include <cmath>
 #include <cstdio>
@@ -24,6 +29,7 @@ namespace korc
 	{
 		float cutOff = 8, spacePenalty = 7, typoCostWeight = 6, oovRuleScale = 4, oovRuleBias = 4;
 		uint32_t spaceTolerance = 0;
+		uint32_t topN = 1;
 		bool openEnding = false, splitComplex = false, splitSaisiot = false, mergeSaisiot = false;
 	};
 
@@ -161,9 +167,12 @@ namespace korc
 		std::vector<WPath> bucket[4];
 		std::unordered_set<WPath, SetHash, SetEq> hset;
 
-		void contClear() { for (auto& b : bucket) b.clear(); hset.clear(); }
+		std::vector<WPath> titems;   // mode 3 (top-N): every inserted path of the current candidate, in insertion order
+
+		void contClear() { for (auto& b : bucket) b.clear(); hset.clear(); titems.clear(); }
 		void contInsert(int mode, const WPath& np)
 		{
+			if (mode == 3) { titems.push_back(np); return; }
 			if (mode == 2)
 			{
 				auto ins = hset.emplace(np);
@@ -184,6 +193,23 @@ namespace korc
 		}
 		template<class Fn> void contEach(int mode, Fn&& fn)
 		{
+			if (mode == 3)
+			{
+				// keep a path iff fewer than N paths of its key beat it (higher score, or equal score and inserted earlier)
+				for (size_t i = 0; i < titems.size(); ++i)
+				{
+					const WPath& a = titems[i];
+					uint32_t rank = 0;
+					for (size_t j = 0; j < titems.size(); ++j)
+					{
+						const WPath& b = titems[j];
+						if (j == i || b.prevRootId != a.prevRootId || b.spState != a.spState || b.lmNode != a.lmNode) continue;
+						if (b.accScore > a.accScore || (b.accScore == a.accScore && j < i)) ++rank;
+					}
+					if (rank < cfg.topN) fn(a);
+				}
+				return;
+			}
 			if (mode == 2) { for (auto& p : hset) fn(p); return; }
 			for (auto& b : bucket) for (auto& p : b) fn(p);
 		}
@@ -314,7 +340,7 @@ namespace korc
 			cnt.maxPrevPaths = std::max<uint64_t>(cnt.maxPrevPaths, totalPrev);
 			if (totalPrev > 128) cnt.nodesOver128++;
 			if (totalPrev > 512) cnt.nodesOver512++;
-			const int mode = totalPrev <= 128 ? 0 : totalPrev <= 512 ? 1 : 2;
+			const int mode = cfg.topN > 1 ? 3 : totalPrev <= 128 ? 0 : totalPrev <= 512 ? 1 : 2;
 
 			for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
 			{
@@ -348,12 +374,22 @@ namespace korc
 				}
 				if (!nCache.empty()) break;
 			}
+			// pruning threshold per root: the N-th best score (-inf while a root has fewer than N paths), PathEvaluator.hpp:475-503
+			const size_t N = cfg.topN;
 			std::vector<float> maxScores(1 + uniqStates.size(), -INFINITY);
-			for (auto& c : nCache)
 			{
-				if (M.morphs[c.morph].socket) continue;
-				const size_t r = c.rootId == COMMON_ROOT ? 0 : c.rootId + 1;
-				maxScores[r] = std::max(maxScores[r], c.accScore);
+				std::vector<std::vector<float>> best(1 + uniqStates.size());
+				for (auto& c : nCache)
+				{
+					if (M.morphs[c.morph].socket) continue;
+					best[c.rootId == COMMON_ROOT ? 0 : c.rootId + 1].push_back(c.accScore);
+				}
+				for (size_t r = 0; r < best.size(); ++r)
+				{
+					if (best[r].size() < N) continue;
+					std::sort(best[r].begin(), best[r].end(), std::greater<float>{});
+					maxScores[r] = best[r][N - 1];
+				}
 			}
 			size_t valid = 0;
 			for (size_t i = 0; i < nCache.size(); ++i)
@@ -570,7 +606,7 @@ namespace korc
 			}
 			ret.clear();
 			if (cand.empty()) return;
-			const size_t perGroup = (size_t)std::ceil(1 * 2 / (double)numUniq);
+			const size_t perGroup = (size_t)std::ceil(cfg.topN * 2 / (double)numUniq);
 			size_t startIdx = 0;
 			uint32_t prevKey = (uint32_t)cand[0].rootId << 8 | cand[0].spState;
 			for (size_t i = 0; i < cand.size(); ++i)

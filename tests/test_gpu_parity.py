@@ -140,6 +140,17 @@ def test_empty_and_degenerate_batches(engine):
     assert [len(x[0][0]) for x in r] == [0, 0, 0]
 
 
-def test_top_n_is_refused_loudly(engine):
+@pytest.mark.parametrize("top_n", [2, 3, 4])
+def test_top_n_bit_exact_vs_oracle(engine, oracle, small_model, top_n):
+    """top-N: the N best paths per key, N-th-best pruning, 2N end candidates -- same analyses, order and fp32 scores as the
+    oracle (its hand-on order: DESIGN.md, top-N)."""
+    sm, _ = small_model
+    texts = synthetic(sm, 400, 101, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 300, 102) + EDGE_TEXTS
+    got = engine.analyze_batch(texts, top_n=top_n).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(oracle.analyze(s, top_n=top_n)) == _norm(y), s
+
+
+def test_top_n_beyond_the_device_limit_is_refused_loudly(engine):
     with pytest.raises(RuntimeError):
-        engine.analyze_batch(["가나다"], top_n=3)
+        engine.analyze_batch(["가나다"], top_n=5)
