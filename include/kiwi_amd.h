@@ -41,7 +41,7 @@ const char* kamd_last_error(void);
 int kamd_set_config(kamd_engine_h h, float cut_off_threshold, float space_penalty, float typo_cost_weight,
 	uint32_t max_unk_form_size, uint32_t max_unk_form_size_followed_by_jclass, uint32_t space_tolerance, int integrate_allomorph);
 
-/* texts: concatenated UTF-16; offsets[n+1].  top_n must be 1 for now (-1 + error otherwise). */
+/* texts: concatenated UTF-16; offsets[n+1].  top_n in 1..4 (null + error otherwise); analyses beyond the best differ from a given reference run only in exact ties (top-N). */
 kamd_results_h kamd_analyze_batch(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n,
 	uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
 

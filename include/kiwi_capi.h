@@ -7,7 +7,7 @@
  * Differences a caller can observe:
  *   - kiwi_init's model_path names a raw-model container (or a directory holding `kiwi_amd.raw`);
  *     on-disk sj.morph / sj.knlm loaders are a "next" row.
- *   - top_n > 1, blocklist, pretokenized spans, typo transformers and non-standard dialects are refused with
+ *   - top_n > 4, blocklist, pretokenized spans, typo transformers and non-standard dialects are refused with
  *     NULL/KIWIERR_FAIL + kiwi_error() instead of being silently ignored.
  */
 #ifndef KIWI_CAPI_SUBSET_H
