@@ -95,6 +95,7 @@ namespace kamd
 		int device = 0;
 		uint32_t persistBlocks = 0;
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
+		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter;
 
@@ -146,13 +147,14 @@ namespace kamd
 		v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff);
 		hipDeviceProp_t prop;
 		HIPCHECK(hipGetDeviceProperties(&prop, device));
-		impl->persistBlocks = (uint32_t)prop.multiProcessorCount * 32;   // one-wave blocks; more than can be resident is harmless
+		impl->persistBlocks = (uint32_t)prop.multiProcessorCount * 12;   // one-wave persistent blocks: 3 waves per SIMD is the most the search kernel is built for
 		if (const char* g = std::getenv("KAMD_GROUP_LANES"))
 		{
 			const int v = std::atoi(g);
-			if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) impl->groupLanes = v;
+			if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) { impl->groupLanes = v; impl->groupLanesForced = true; }
 			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16, 32 or 64" };
 		}
+		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2 or 3" }; }
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
 		impl->counter.ensure(256);
 	}
@@ -327,7 +329,7 @@ namespace kamd
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
 		HIPCHECK(hipMemsetAsync(b.dNNodes.p, 0, (size_t)nC * 4, sA));   // also clears the lattice kernels' hand-over flag
 		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
-		const uint32_t nGroups = 64u / (uint32_t)I.groupLanes;
+		const uint32_t nGroups = 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
 		const uint32_t maxBlocks = std::min(I.persistBlocks, (maxWork + nGroups - 1) / nGroups);
 		I.bigScratch.ensure((size_t)maxBlocks * nGroups * sizeof(GroupScratch) * std::min(S, 2u));
@@ -362,7 +364,7 @@ namespace kamd
 			HIPCHECK(hipEventRecord(e[2], sA));
 			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));
 			HIPCHECK(hipEventRecord(e[3], sB));
-			const uint32_t blocks = std::min(I.persistBlocks, (cn + nGroups - 1) / nGroups);
+			const uint32_t blocks = std::min(I.persistBlocks, (cn + nGroups - 1) / nGroups);   // (upper bound; used by the developer dumps)
 			// consecutive searches may overlap at their tails: alternate between two scratch halves
 			WorkView wv = b.wv;
 			wv.beacon = nullptr;
@@ -384,14 +386,27 @@ namespace kamd
 			wv.bigScratch = I.bigScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(GroupScratch) : 0);
 			uint32_t* counter = I.counter.as<uint32_t>() + k;
 			const uint32_t* order = b.dOrder.as<uint32_t>() + c0;
-			switch (I.groupLanes)
+			// lane-group width / register budget: with few chunks the step is bound by the dependent chain of one chunk (16-lane
+			// groups, 2 waves per SIMD measured best on 8192 x 40 jamo); with many chunks it is a throughput problem and narrower
+			// groups + a third wave per SIMD win (65536 x 40 jamo: 6.9 vs 9.3 ms).  KAMD_GROUP_LANES / KAMD_WPS override.
+			const bool many = cn >= 32768;
+			const int gl = I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
+			const int wps = I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
+			const uint32_t nGroupsK = 64u / (uint32_t)gl;
+			const uint32_t blocksK = std::min(I.persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
+			const uint32_t ldsK = searchKernelLdsBytes(gl);
+#define KAMD_LAUNCH(GG, WW) hipLaunchKernelGGL((k_best_path<GG, WW>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn)
+			if (wps == 3 && gl == 8) KAMD_LAUNCH(8, 3);
+			else if (wps == 3 && gl == 16) KAMD_LAUNCH(16, 3);
+			else switch (gl)
 			{
-			case 4: hipLaunchKernelGGL(k_best_path<4>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
-			case 8: hipLaunchKernelGGL(k_best_path<8>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
-			case 16: hipLaunchKernelGGL(k_best_path<16>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
-			case 32: hipLaunchKernelGGL(k_best_path<32>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
-			default: hipLaunchKernelGGL(k_best_path<64>, dim3(blocks), dim3(64), ldsBytes, sB, I.dview, b.bv, wv, sp, counter, order, cn); break;
+			case 4: KAMD_LAUNCH(4, 2); break;
+			case 8: KAMD_LAUNCH(8, 2); break;
+			case 16: KAMD_LAUNCH(16, 2); break;
+			case 32: KAMD_LAUNCH(32, 2); break;
+			default: KAMD_LAUNCH(64, 2); break;
 			}
+#undef KAMD_LAUNCH
 			HIPCHECK(hipEventRecord(e[4], sB));
 			hipLaunchKernelGGL(k_finish_paths, dim3((cn + 63) / 64), dim3(64), 0, sB, I.dview, b.bv, wv, sp, c0, cn);
 			HIPCHECK(hipEventRecord(e[5], sB));

@@ -105,6 +105,8 @@ namespace kamd
 	// DPP rotation inside a row of 16 lanes (= one lane group when G == 16): a register-to-register cross-lane move, no LDS
 	// round trip.  Which neighbour a lane receives is read off by rotating the lane index along with the data.
 	template<int N> __device__ __forceinline__ uint32_t rowRor(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xF, 0xF, false); }
+	// `old` is what a lane receives when its source lane is switched off (an 8-lane group whose row neighbour took another path)
+	template<int N> __device__ __forceinline__ uint32_t rowRorOld(uint32_t v, uint32_t old) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x120 + N, 0xF, 0xF, false); }
 	template<int N> __device__ __forceinline__ float rowRorF(float v) { return __uint_as_float(rowRor<N>(__float_as_uint(v))); }
 	__device__ __forceinline__ float rowMax16(float v)
 	{
@@ -464,7 +466,11 @@ namespace kamd
 
 		// Common case (G == 16): the whole batch fits the group once and the node uses the small container -- scores stay in
 		// registers and the per-key de-duplication runs on DPP rotations instead of LDS scans.
+#ifdef KAMD_NO_FAST8
 		const bool fast = (G == 16) && Qtot <= (uint32_t)G && mode == 0;
+#else
+		const bool fast = (G == 16 || G == 8) && Qtot <= (uint32_t)G && mode == 0;
+#endif
 		uint64_t rKey = KINVALID; float rScore = 0, rFcs = 0, rTypo = 0;
 
 		// ---- scoring pass: one work item per lane -------------------------------------------------------
@@ -592,16 +598,17 @@ namespace kamd
 		};
 		if (fast)
 		{
-			if constexpr (G == 16)
+			if constexpr (G == 16 || G == 8)
 			{
-				const uint32_t q = X.gl;
+				// a DPP row is 16 lanes: one group (G == 16) or two (G == 8); rl = lane in the row, partners of another group are ignored
+				const uint32_t q = X.gl, rl = threadIdx.x & 15u;
 				const uint32_t keyLo = (uint32_t)rKey, keyHi = (uint32_t)(rKey >> 32);
 				bool rep = rKey != KINVALID;
 				float best = rScore; uint32_t qw = q;
 				uint32_t beaten = 0;      // top-N: items of the same key that beat this one (higher score, or equal and earlier)
 				// branch-free on purpose (bitwise logic on predicates + selects): 15 short dependent steps instead of 45 exec-mask branches
-#define KAMD_ROT_STEP(N) { const uint32_t oi = rowRor<N>(q), ol = rowRor<N>(keyLo), oh = rowRor<N>(keyHi); const float os = rowRorF<N>(rScore); \
-				const bool same = (ol == keyLo) & (oh == keyHi); \
+#define KAMD_ROT_STEP(N) { const uint32_t orl = rowRor<N>(rl), oi = orl & (G - 1), ol = rowRorOld<N>(keyLo, 0xFFFFFFFFu), oh = rowRorOld<N>(keyHi, 0xFFFFFFFFu); const float os = rowRorF<N>(rScore); \
+				const bool same = ((((orl ^ rl) & (16u - G)) == 0)) & (ol == keyLo) & (oh == keyHi); \
 				rep = rep & !(same & (oi < q)); \
 				const bool better = same & ((os > best) | ((os == best) & (oi < qw))); \
 				beaten += (same & ((os > rScore) | ((os == rScore) & (oi < q)))) ? 1u : 0u; \
@@ -864,9 +871,9 @@ namespace kamd
 		if (!cnt) return;
 		const bool staged = !X.stageOverflow;
 		const uint32_t nRootSlots = 1 + X.nUniq;
-		if constexpr (G == 16)
+		if constexpr (G == 16 || G == 8)
 		{
-			if (staged && cnt <= 16)
+			if (staged && cnt <= (uint32_t)G)
 			{
 				// common case: the node's new paths fit the group once -- one LDS read per lane, maxima per root by DPP
 				const bool in = X.gl < cnt;
@@ -875,7 +882,7 @@ namespace kamd
 				const uint32_t slot = bits & SB_SLOT_MASK;
 				const bool alive = in && !(bits & SB_DEAD);
 				bool kill = false;
-				if (!topn)
+				if (G == 16 && !topn)
 				{
 					for (uint32_t rs = 0; rs < nRootSlots; ++rs)
 					{
@@ -888,15 +895,17 @@ namespace kamd
 				{
 					// threshold = the N-th best score of the root (PathEvaluator.hpp:488-503): a path dies iff at least N
 					// socket-free paths of its root lie more than cutOff above it
+					// (top-1 is N = 1; the group id is part of the compared word, so the other group of an 8-lane pair never matches)
 					const float lim = sc + P.cutOff;
-					const uint32_t mineKey = alive ? slot : 0xFFFFu;
-					const uint32_t qual = (alive && !(bits & SB_MORPH_SOCKET)) ? slot : 0xFFFEu;
+					const uint32_t grp = (threadIdx.x & 15u) / G;
+					const uint32_t mineKey = alive ? (slot | (grp << 8)) : 0xFFFFu;
+					const uint32_t qual = (alive && !(bits & SB_MORPH_SOCKET)) ? (slot | (grp << 8)) : 0xFFFEu;
 					uint32_t above = 0;
-#define KAMD_PRUNE_STEP(N) { const uint32_t oq = rowRor<N>(qual); const float os = rowRorF<N>(sc); above += ((oq == mineKey) & (lim < os)) ? 1u : 0u; }
+#define KAMD_PRUNE_STEP(N) { const uint32_t oq = rowRorOld<N>(qual, 0xFFFEu); const float os = rowRorF<N>(sc); above += ((oq == mineKey) & (lim < os)) ? 1u : 0u; }
 					KAMD_PRUNE_STEP(1) KAMD_PRUNE_STEP(2) KAMD_PRUNE_STEP(3) KAMD_PRUNE_STEP(4) KAMD_PRUNE_STEP(5) KAMD_PRUNE_STEP(6) KAMD_PRUNE_STEP(7) KAMD_PRUNE_STEP(8)
 					KAMD_PRUNE_STEP(9) KAMD_PRUNE_STEP(10) KAMD_PRUNE_STEP(11) KAMD_PRUNE_STEP(12) KAMD_PRUNE_STEP(13) KAMD_PRUNE_STEP(14) KAMD_PRUNE_STEP(15)
 #undef KAMD_PRUNE_STEP
-					kill = alive && above >= P.topN;
+					kill = alive && above >= (topn ? P.topN : 1u);
 				}
 				if (kill) { X.stBits()[X.gl] = bits | SB_DEAD; markDead<G>(X, E.nodeStart + X.gl); }
 				waveSync();
@@ -1496,11 +1505,10 @@ namespace kamd
 #endif
 	}
 
-	template<int G>
-#ifndef KAMD_WAVES_PER_SIMD
-#define KAMD_WAVES_PER_SIMD 2
-#endif
-	__global__ void __launch_bounds__(64, KAMD_WAVES_PER_SIMD) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork)
+	// WPS = waves per SIMD the kernel is compiled for (register budget 512 / WPS): 2 is fastest when a batch is small enough
+	// to be latency-bound (c2: 8192 chunks), 3 (with a few spills) when there are chunks to fill the extra wave slots
+	template<int G, int WPS>
+	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork)
 	{
 		constexpr int NG = 64 / G;
 		const uint32_t lane = threadIdx.x;
@@ -1543,9 +1551,11 @@ namespace kamd
 		}
 	}
 
-	template __global__ void k_best_path<4>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
-	template __global__ void k_best_path<8>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
-	template __global__ void k_best_path<16>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
-	template __global__ void k_best_path<32>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
-	template __global__ void k_best_path<64>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<4, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<8, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<32, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_best_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 }

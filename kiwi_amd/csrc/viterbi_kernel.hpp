@@ -18,7 +18,7 @@ namespace kamd
 	void searchKernelProfile(unsigned long long* out16, bool reset);   // phase cycle counters (builds with -DKAMD_PROFILE only)   // dynamic LDS the launch must request
 
 	// G = lanes per chunk (4, 8, 16 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
-	template<int G>
+	template<int G, int WPS>
 	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork);
 	// End stage, one THREAD per chunk: restated std::sort of the end candidates, per-(root, state) selection and the
 	// back-trace into 24-byte tokens.  A separate launch so that 64 chunks share a wavefront in this strictly serial stage.

@@ -15,6 +15,8 @@ WORKLOADS = {
     "c2": ("full", 8192, dict(exact_jamo=40), 2),
     "c3": ("full", 65536, dict(min_jamo=5, max_jamo=200), 3),
     "small-c2": ("small", 8192, dict(exact_jamo=40), 2),
+    # c2 at the batch size the north-star throughput target is quoted on (>= 64k sentences): the throughput regime
+    "c2-64k": ("full", 65536, dict(exact_jamo=40), 12),
 }
 
 

@@ -134,6 +134,24 @@ def test_lattice_hbm_kernel_matches_lds_kernel(engine, oracle, small_model, monk
     monkeypatch.delenv("KAMD_LATTICE_LDS")
 
 
+@pytest.mark.parametrize("lanes,wps", [("8", "3"), ("8", "2"), ("16", "3"), ("4", "2"), ("32", "2"), ("64", "2")])
+def test_lane_group_variants_match_oracle(oracle, small_model, monkeypatch, lanes, wps):
+    """Every instantiation of the search kernel (lanes per chunk x register budget) gives the oracle's result; large batches
+    select 8 lanes / 3 waves per SIMD on their own (engine.hip), the others are reachable through KAMD_GROUP_LANES / KAMD_WPS."""
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    texts = synthetic(sm, 300, 121, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 150, 122) + EDGE_TEXTS
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    if lanes in ("8", "16"):
+        monkeypatch.setenv("KAMD_WPS", wps)
+    other = KiwiAmd(path)
+    for top_n in (1, 2):
+        got = other.analyze_batch(texts, top_n=top_n).to_python()
+        for s, y in zip(texts, got):
+            assert _norm(oracle.analyze(s, top_n=top_n)) == _norm(y), (lanes, wps, top_n, s)
+    other.close()
+
+
 def test_empty_and_degenerate_batches(engine):
     assert engine.analyze_batch([]).n_texts() == 0
     r = engine.analyze_batch(["", " ", "\n"]).to_python()
