@@ -487,7 +487,8 @@ namespace kamd
 			{
 				const Cand c = loadCand(X.candOff(k));
 				const uint32_t local = q - c.qOff;
-				const uint32_t p = local / c.R, r = local % c.R;
+				uint32_t p = local, r = 0;
+				if (c.R != 1) { p = local / c.R; r = local % c.R; }      // R > 1 only for quote / sentence-break candidates under several start states
 				const Hot ps = getHot<G>(X, pBeg + p);
 				if (fast) rTypo = getTypo<G>(X, pBeg + p);      // rides along with the hot quad: the winner's is picked up by a lane read later
 				const bool single = c.single();
@@ -584,7 +585,8 @@ namespace kamd
 		{
 			const Cand c = loadCand(X.candOff(k));
 			const uint32_t local = qw - c.qOff;
-			const uint32_t parent = pBeg + local / c.R, r = local % c.R;
+			uint32_t parent = pBeg + local, r = 0;
+			if (c.R != 1) { parent = pBeg + local / c.R; r = local % c.R; }
 			const float wtypo = (haveTypo ? parentTypo : getTypo<G>(X, parent)) + 0.f;
 			const bool single = c.single();
 			const uint8_t rootKey = (uint8_t)(wkey >> 40);
