@@ -6,7 +6,6 @@
 #include <string>
 #include "../../include/kiwi_amd.h"
 #include "engine.hpp"
-namespace kamd { void searchKernelProfile(unsigned long long* out16, bool reset); }
 
 using namespace kamd;
 
@@ -117,8 +116,6 @@ extern "C"
 	const kamd_token_t* kamd_res_tokens(kamd_results_h r, uint32_t t, uint32_t i) { return (r && t < r->toks.size() && i < r->toks[t].size()) ? r->toks[t][i].data() : nullptr; }
 	const uint16_t* kamd_res_forms(kamd_results_h r) { return r ? r->forms.data() : nullptr; }
 	void kamd_res_close(kamd_results_h r) { delete r; }
-
-	void kamd_debug_profile(unsigned long long* out16, int reset) { kamd::searchKernelProfile(out16, !!reset); }
 
 	size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap)
 	{

@@ -140,7 +140,7 @@ namespace kamd
 		DevChunkResult* results;       // [c]
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
 		uint32_t bigScratchBytes;      // per wave
-		uint32_t* beacon;              // developer aid (KAMD_BEACON builds): host-visible progress word per lane, or null
+		uint32_t* beacon;              // developer aid (KAMD_TIMELINE builds): per-chunk timeline records, else null
 	};
 
 	// LDS layout of the wave-per-chunk lattice build (byte offsets): n text units, node capacity, packed-match capacity

@@ -1,7 +1,6 @@
 // Batch driver (see engine.hpp).  Device memory is plain hipMalloc'd arenas sized from the batch's chunk
 // lengths; one stream; three kernel launches per round.
 #include <hip/hip_runtime.h>
-#include <map>
 #include <unistd.h>
 #include <cstdio>
 #include <cstring>
@@ -374,15 +373,6 @@ namespace kamd
 			HIPCHECK(hipMemsetAsync(tlBuf.p, 0, (size_t)nC * 128, sB));
 			wv.beacon = tlBuf.as<uint32_t>(); gTimeline = tlBuf.p;
 #endif
-#ifdef KAMD_BEACON
-			{
-				static uint32_t* hostBeacon = nullptr; static size_t hostBeaconN = 0;
-				const size_t need = (size_t)I.persistBlocks * 64;
-				if (hostBeaconN < need) { HIPCHECK(hipHostMalloc((void**)&hostBeacon, need * 4, hipHostMallocCoherent | hipHostMallocMapped)); hostBeaconN = need; }
-				memset(hostBeacon, 0, need * 4);
-				wv.beacon = hostBeacon;
-			}
-#endif
 			wv.bigScratch = I.bigScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(GroupScratch) : 0);
 			uint32_t* counter = I.counter.as<uint32_t>() + k;
 			const uint32_t* order = b.dOrder.as<uint32_t>() + c0;
@@ -439,23 +429,6 @@ namespace kamd
 					_exit(7);
 				}
 			}
-#ifdef KAMD_BEACON
-			if (wv.beacon)
-			{
-				// developer aid: wait a bounded time for the search kernel; on a hang print where each lane was last seen
-				for (int ms = 0; ms < 8000 && hipEventQuery(e[4]) == hipErrorNotReady; ++ms) usleep(1000);
-				if (hipEventQuery(e[4]) == hipErrorNotReady)
-				{
-					std::map<uint32_t, uint32_t> hist;
-					for (uint32_t w = 0; w < blocks; ++w) for (uint32_t l = 0; l < 64; ++l) ++hist[wv.beacon[(size_t)w * 64 + l] >> 8 << 8];
-					fprintf(stderr, "[beacon] search kernel still running after 8 s; last phase words (code<<24|node<<8) : lanes\n");
-					for (auto& kv : hist) fprintf(stderr, "  %08x : %u\n", kv.first, kv.second);
-					for (uint32_t w = 0; w < std::min(blocks, 2u); ++w) { fprintf(stderr, "  wave %u:", w); for (uint32_t l = 0; l < 64; ++l) fprintf(stderr, " %08x", wv.beacon[(size_t)w * 64 + l]); fprintf(stderr, "\n"); }
-					fflush(stderr);
-					_exit(7);
-				}
-			}
-#endif
 		}
 		HIPCHECK(hipGetLastError());
 		HIPCHECK(hipStreamSynchronize(sA));

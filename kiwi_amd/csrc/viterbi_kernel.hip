@@ -59,32 +59,10 @@ namespace kamd
 #else
 #define INL3
 #endif
-#ifdef KAMD_BEACON
-	// KAMD_BEACON = level: 1 chunk/node marks only, 2 + per candidate list, 3 + per batch, 4 everything
-	__device__ constexpr bool beaconOn(uint32_t c) { return c <= 2 || c >= 0x0E || (KAMD_BEACON >= 2 && (c == 3 || c == 0x0C)) || (KAMD_BEACON >= 3 && (c == 4 || c == 0x0B)) || KAMD_BEACON >= 4; }
-#define BEACON(X, code) { if (beaconOn((uint32_t)(code) >> 24) && (X).beacon) __hip_atomic_store((X).beacon, (uint32_t)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-#else
-#define BEACON(X, code)
-#endif
-#ifdef KAMD_WATCH
-	// developer aid: every loop that could spin on corrupt input counts its trips; a tripped guard leaves a mark and breaks
-	__device__ unsigned int gWatch[32];
-#define GUARD_DECL(n) uint32_t n = 0;
-#define GUARD(n, limit, site) if (++n > (limit)) { atomicAdd(&gWatch[site], 1u); break; }
-#else
-#define GUARD_DECL(n)
-#define GUARD(n, limit, site)
-#endif
 #ifdef KAMD_TIMELINE
 #define TLMARK(X, k) { if ((X).gl == 0) { LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>((X).lds + Lay<G>::TLACC); const unsigned long long t_ = wall_clock64(); a_[k] += t_ - a_[12]; a_[12] = t_; } }
 #else
 #define TLMARK(X, k)
-#endif
-#ifdef KAMD_PROFILE
-	__device__ unsigned long long gProf[16];
-#define PROF(X, i) { const uint64_t t_ = wall_clock64(); (X).prof[i] += t_ - (X).profT; (X).profT = t_; }
-#else
-#define PROF(X, i)
 #endif
 	constexpr uint32_t SCAP = 32;    // new states of one node whose scores are staged in LDS for pruning
 	constexpr uint32_t RING = 32;    // most recent nodes whose state ranges are kept in LDS
@@ -145,24 +123,6 @@ namespace kamd
 		static constexpr uint32_t LB = (64 / G) * SIZE;              // f32[2*T_MAX+1], shared by the groups
 		static constexpr uint32_t TOTAL = LB + 4 * (2 * T_MAX + 1);
 	};
-	void searchKernelProfile(unsigned long long* out16, bool reset)
-	{
-#ifdef KAMD_WATCH
-		{
-			unsigned int w[32];
-			(void)hipMemcpyFromSymbol(w, HIP_SYMBOL(gWatch), sizeof(w));
-			for (int i = 0; i < 32; ++i) if (w[i]) fprintf(stderr, "[watch] guard %d tripped %u times\n", i, w[i]);
-			fprintf(stderr, "[watch] read\n");
-		}
-#endif
-#ifdef KAMD_PROFILE
-		(void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(gProf), 16 * sizeof(unsigned long long));
-		if (reset) { unsigned long long z[16] = { 0 }; (void)hipMemcpyToSymbol(HIP_SYMBOL(gProf), z, sizeof(z)); }
-#else
-		for (int i = 0; i < 16; ++i) out16[i] = 0;
-		(void)reset;
-#endif
-	}
 	uint32_t searchKernelLdsBytes(int G)
 	{
 		switch (G) { case 4: return Lay<4>::TOTAL; case 8: return Lay<8>::TOTAL; case 16: return Lay<16>::TOTAL; case 32: return Lay<32>::TOTAL; default: return Lay<64>::TOTAL; }
@@ -237,10 +197,8 @@ namespace kamd
 	__device__ __forceinline__ bool lmLookup(const ModelView& M, uint32_t node, uint32_t wid, int32_t& v, float& ll)
 	{
 		uint32_t b = lmHashOf(node, wid) & M.lmHashMask;
-		GUARD_DECL(g1)
 		for (;;)
 		{
-			GUARD(g1, 100000, 1)
 			const uint4* p = reinterpret_cast<const uint4*>(M.lmHash + (size_t)b * 4);
 			const uint4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
 			const bool h0 = (s0.x == node) & (s0.y == wid), h1 = (s1.x == node) & (s1.y == wid), h2 = (s2.x == node) & (s2.y == wid), h3 = (s3.x == node) & (s3.y == wid);
@@ -258,14 +216,9 @@ namespace kamd
 	// KnLangModel::progress (src/Knlm.cpp:44-130); float additions in the same order
 	__device__ INL3 float lmProgress(const ModelView& M, int32_t& node, uint32_t next)
 	{
-#if defined(KAMD_ELIDE) && (KAMD_ELIDE & 1)
-		node = (int32_t)((lmHashOf((uint32_t)node, next) & 0xFFFFu) + 1); return -1.f;    // timing experiment: no Knlm memory traffic
-#endif
 		float acc = 0;
-		GUARD_DECL(g2)
 		for (;;)
 		{
-			GUARD(g2, 1000, 2)
 			int32_t v; float ll;
 			if (node == 0)
 			{
@@ -281,10 +234,8 @@ namespace kamd
 			if (v > 0) { node += v; return acc + ll; }
 			// leaf: the new state is the longest suffix context that continues with `next` (Knlm.cpp:96-128)
 			int32_t cur = node;
-			GUARD_DECL(g3)
 			for (;;)
 			{
-				GUARD(g3, 1000, 3)
 				const int32_t lower = M.lmBackoff[cur].lower;
 				if (!lower) break;
 				cur += lower;
@@ -345,7 +296,7 @@ namespace kamd
 		{
 			gl = o.gl; gshift = o.gshift; lds = o.lds; nodes = o.nodes; Gn = o.Gn; str = o.str; cls = o.cls; st = o.st; stCap = o.stCap; stTop = o.stTop;
 			nodeStOff = o.nodeStOff; nodeStCnt = o.nodeStCnt; nodeLive = o.nodeLive; uniq = o.uniq; nUniq = o.nUniq;
-			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; beacon = o.beacon;
+			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; tl = o.tl;
 		}
 		uint32_t gl, gshift, lds;       // lane in group, group's first lane, byte offset of the group's LDS slice
 		const DevNode* nodes; uint32_t Gn;
@@ -355,10 +306,7 @@ namespace kamd
 		const uint8_t* uniq; uint32_t nUniq;
 		bool overflow, pairOverflow, stageOverflow;
 		GroupScratch* scratch;
-		uint32_t* beacon;
-#ifdef KAMD_PROFILE
-		uint64_t prof[8]; uint64_t profT;
-#endif
+		unsigned long long* tl;     // per-chunk timeline record (KAMD_TIMELINE builds), else unused
 
 		__device__ __forceinline__ uint64_t ballot(bool p) const { return (__ballot(p) >> gshift) & GMASK; }
 		__device__ __forceinline__ bool any(bool p) const { return ballot(p) != 0; }
@@ -458,10 +406,8 @@ namespace kamd
 	{
 		const ModelView& M = X.M;
 		const bool big = Qtot > QCAP;
-		BEACON(X, 0x05000000u | (E.nodeIdx << 8) | Qtot)
 		const uint32_t pBeg = E.pBeg;
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
-		PROF(X, 1)
 		TLMARK(X, 1)
 
 		// Common case (G == 16): the whole batch fits the group once and the node uses the small container -- scores stay in
@@ -474,10 +420,8 @@ namespace kamd
 		uint64_t rKey = KINVALID; float rScore = 0, rFcs = 0, rTypo = 0;
 
 		// ---- scoring pass: one work item per lane -------------------------------------------------------
-		GUARD_DECL(g7)
 		for (uint32_t qb = 0; qb < Qtot; qb += G)
 		{
-			GUARD(g7, 100000, 7)
 			const uint32_t q = qb + X.gl;
 			bool valid = q < Qtot;
 			uint32_t k = 0;
@@ -534,9 +478,7 @@ namespace kamd
 					{
 						// prohibit <v> without <chunk> (PathEvaluator.hpp:604-608): static per candidate unless the word id was replaced above
 						if (widReplaced ? (M.morphs[firstWid].tag == T_P) : ((c.flags() & MF_FIRST_WID_IS_P) != 0)) { valid = false; break; }
-						BEACON(X, 0x07000000u | (E.nodeIdx << 8))
 						float ll = lmProgress(M, lmNode, firstWid);
-						BEACON(X, 0x08000000u | (E.nodeIdx << 8))
 						cand += ll; firstChunk += ll;
 						if (!single)
 						{
@@ -575,9 +517,7 @@ namespace kamd
 			}
 		}
 		waveSync();
-		PROF(X, 2)
 		TLMARK(X, 2)
-		BEACON(X, 0x09000000u | (E.nodeIdx << 8))
 
 		// ---- emission pass: representatives in container iteration order, each carrying its key's winner ----
 		// writes the state of key `wkey` (winner item qw of candidate k) at arena slot pos
@@ -643,10 +583,8 @@ namespace kamd
 			for (int b = 0; b < nBuckets; ++b)
 			{
 				uint32_t emittedInBucket = 0;
-				GUARD_DECL(g8)
 				for (uint32_t qb = 0; qb < Qtot; qb += G)
 				{
-					GUARD(g8, 100000, 8)
 					const uint32_t q = qb + X.gl;
 					bool rep = false; uint32_t qw = q; uint64_t key = KINVALID; uint32_t k = 0;
 					if (q < Qtot) key = big ? X.scratch->key[q] : X.qKey()[q];
@@ -671,10 +609,8 @@ namespace kamd
 						}
 						else
 						{
-						GUARD_DECL(g5)
 						for (uint32_t j = lo; j < hi; ++j)
 						{
-							GUARD(g5, 100000, 5)
 							const uint64_t kj = big ? X.scratch->key[j] : X.qKey()[j];
 							if (kj != key) continue;
 							if (j < q) { rep = false; break; }
@@ -716,9 +652,7 @@ namespace kamd
 		X.stageOverflow = X.any(X.stageOverflow);
 		if (X.stTop > X.stCap) X.stTop = X.stCap;
 		waveSync();
-		PROF(X, 3)
 		TLMARK(X, 3)
-		BEACON(X, 0x0A000000u | (E.nodeIdx << 8))
 	}
 
 	// z_coda / z_siot shortcut (PathEvaluator.hpp:389-432): copies of the qualifying incoming paths
@@ -782,12 +716,9 @@ namespace kamd
 		for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
 		{
 			uint32_t c = 0;
-			GUARD_DECL(g4)
 			while (c < nCands)
 			{
-				GUARD(g4, 100000, 4)
 				// ---- lane j classifies candidate c+j; then the group agrees on the next batch ----------------
-				BEACON(X, 0x04000000u | (E.nodeIdx << 8) | c)
 				const uint32_t idx = c + X.gl;
 				uint32_t kind = K_NONE, Q = 0, R = 1, mid = 0, sbType = 0;
 				uint4 m0 = make_uint4(0, 0, 0, 0), m1 = make_uint4(0, 0, 0, 0);
@@ -866,9 +797,7 @@ namespace kamd
 
 		// ---- pruning (PathEvaluator.hpp:475-511): paths further than cutOff below the best of their root die.
 		// Nothing is moved: dead paths keep their slot (marked in LDS and HBM) and are skipped by every consumer.
-		PROF(X, 1)
 		TLMARK(X, 1)
-		BEACON(X, 0x0B000000u | (E.nodeIdx << 8))
 		const uint32_t cnt = X.stTop - E.nodeStart;
 		if (!cnt) return;
 		const bool staged = !X.stageOverflow;
@@ -911,7 +840,6 @@ namespace kamd
 				}
 				if (kill) { X.stBits()[X.gl] = bits | SB_DEAD; markDead<G>(X, E.nodeStart + X.gl); }
 				waveSync();
-				PROF(X, 4)
 				TLMARK(X, 4)
 				return;
 			}
@@ -952,17 +880,14 @@ namespace kamd
 				}
 			}
 			waveSync();
-			PROF(X, 4)
 			TLMARK(X, 4)
 			return;
 		}
 		for (uint32_t rs = 0; rs < nRootSlots; ++rs)
 		{
 			float mx = -INFINITY; bool anyOfRoot = false;
-			GUARD_DECL(g10)
 			for (uint32_t b = 0; b < cnt; b += G)
 			{
-				GUARD(g10, 100000, 10)
 				const uint32_t i = b + X.gl;
 				if (i < cnt)
 				{
@@ -994,7 +919,6 @@ namespace kamd
 			}
 		}
 		waveSync();
-		PROF(X, 4)
 		TLMARK(X, 4)
 	}
 
@@ -1171,21 +1095,13 @@ namespace kamd
 		const uint32_t firstPrev = Gn - 1 - en.prev;
 		const uint32_t pBeg = X.nodeStOff[firstPrev];
 		const uint32_t nP = (en.prev && en.nPrev) ? X.nodeStOff[firstPrev + en.nPrev - 1] + X.nodeStCnt[firstPrev + en.nPrev - 1] - pBeg : 0;
-#ifdef KAMD_CRUMBS
-		if (X.gl == 0) { res->nEnd = 0xA2000000u; res->endOff = nP; }
-#endif
 		// candidates go to the unused tail of the chunk's state arena, followed by room for the back-trace chain (<= Gn steps)
 		EndCand* endBuf = reinterpret_cast<EndCand*>(X.st + X.stTop);
 		const uint64_t freeBytes = (uint64_t)(X.stCap - X.stTop) * sizeof(DevState);
 		const uint32_t endCap = freeBytes > (uint64_t)Gn * 4 ? (uint32_t)((freeBytes - (uint64_t)Gn * 4) / sizeof(EndCand)) : 0u;
 		uint32_t nEnd = 0; bool endOverflow = false;
-		GUARD_DECL(g11)
 		for (uint32_t pb = 0; pb < nP; pb += G)
 		{
-			GUARD(g11, 100000, 11)
-#ifdef KAMD_CRUMBS
-			if (X.gl == 0) res->nEnd = 0xA3000000u | pb;
-#endif
 			const uint32_t p = pb + X.gl;
 			bool ok = false; DevState ps{}; float c = 0, first = 0;
 			if (p < nP)
@@ -1208,9 +1124,6 @@ namespace kamd
 					}
 				}
 			}
-#ifdef KAMD_CRUMBS
-			if (X.gl == 0) res->nEnd = 0xA4000000u | pb;
-#endif
 			const uint32_t mult = (ok && ps.rootId == COMMON_ROOT) ? X.nUniq : (ok ? 1u : 0u);
 			uint32_t incl = mult;
 			for (int d = 1; d < G; d <<= 1) { const uint32_t v = __shfl_up(incl, d, G); if ((int)X.gl >= d) incl += v; }
@@ -1226,9 +1139,6 @@ namespace kamd
 				else endOverflow = true;
 			}
 			nEnd += X.bcast(incl, G - 1);
-#ifdef KAMD_CRUMBS
-			if (X.gl == 0) res->nEnd = 0xA5000000u | pb;
-#endif
 		}
 		endOverflow = X.any(endOverflow);
 		if (X.gl == 0)
@@ -1338,12 +1248,9 @@ namespace kamd
 		const CandStatic* packs = W.packs + W.packBase[chunk];
 		uint32_t cumLive = 1;    // live paths of nodes 0..i-1 (group-uniform)
 		DevNode nextNode = getNode<G>(X, Gn > 2 ? 1 : 0);
-		GUARD_DECL(g6)
 		for (uint32_t i = 1; i + 1 < Gn; ++i)
 		{
-			GUARD(g6, 70000, 6)
 			const DevNode node = nextNode;
-			BEACON(X, 0x02000000u | (i << 8))
 			if (i + 2 < Gn) nextNode = getNode<G>(X, i + 1);      // prefetch: in flight while this node is processed
 			NodeEnv E;
 			const uint32_t firstPrev = i - node.prev, lastPrev = firstPrev + node.nPrev - 1;
@@ -1369,7 +1276,6 @@ namespace kamd
 			if (!node.uformLen && node.form != NOFORM && node.flen && node.spaceErrors) ws = -P.spacePenalty * (float)node.spaceErrors;
 			const float baseDiscount = ws + (-0.f * P.typoCostWeight);   // whitespaceDiscount + typoDiscount (PathEvaluator.hpp:366-371)
 
-			PROF(X, 0)
 			TLMARK(X, 0)
 			const uint8_t ownKind = node.uformLen ? 1 : 0; const uint16_t ownFeat = node.ownFeat;
 			// up to three candidate lists per node, evaluated through ONE inlined copy of evaluateNode:
@@ -1447,11 +1353,8 @@ namespace kamd
 					cl = unkPacks; clLds = Lay<G>::PCAP; clN = 2; ok = 3;
 					disc = baseDiscount + (emo - ((float)len * P.oovRuleScale + P.oovRuleBias));
 				}
-				BEACON(X, 0x03000000u | (i << 8) | pass)
 				evaluateNode<G>(X, E, cl, clLds, clN, ok, of, disc);
-				BEACON(X, 0x0C000000u | (i << 8) | pass)
 			}
-			PROF(X, 0)
 			TLMARK(X, 6)
 			// node bookkeeping: state range + live count (LDS ring and HBM)
 			{
@@ -1472,7 +1375,6 @@ namespace kamd
 				cumLive += live;
 			}
 			waveSync();
-			PROF(X, 5)
 			TLMARK(X, 5)
 			if (X.overflow || X.pairOverflow) break;
 		}
@@ -1481,12 +1383,8 @@ namespace kamd
 			if (X.gl == 0) { res->status = X.overflow ? CS_ERR_STATE_OVERFLOW : CS_ERR_PAIR_OVERFLOW; res->nPaths = 0; }
 			return;
 		}
-		BEACON(X, 0x0E000000u)
 #ifdef KAMD_TIMELINE
 		if (tl && X.gl == 0) { const unsigned long long clkNow_ = clock64(); tl[1] = wall_clock64(); LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>(X.lds + Lay<G>::TLACC); for (int k = 0; k < 11; ++k) tl[4 + k] = a_[k]; tl[15] = clkNow_ - tlClk0; }
-#endif
-#ifdef KAMD_CRUMBS
-		if (X.gl == 0) res->nEnd = 0xA1000000u;
 #endif
 		{
 			// the end stage is a real function call; it gets COPIES of the context and of the views, so that no address of X or of
@@ -1499,12 +1397,7 @@ namespace kamd
 #ifdef KAMD_TIMELINE
 		if (tl && X.gl == 0) tl[2] = wall_clock64();
 #endif
-		BEACON(X, 0x11000000u)
-		PROF(X, 6)
 		TLMARK(X, 6)
-#ifdef KAMD_PROFILE
-		if (X.gl == 0) for (int k = 0; k < 8; ++k) { atomicAdd(&gProf[k], (unsigned long long)X.prof[k]); X.prof[k] = 0; }
-#endif
 	}
 
 	// WPS = waves per SIMD the kernel is compiled for (register budget 512 / WPS): 2 is fastest when a batch is small enough
@@ -1532,23 +1425,14 @@ namespace kamd
 		GroupCtx<G> X(M, P);
 		X.gl = lane % G; X.gshift = gid * G; X.lds = gid * Lay<G>::SIZE;
 		X.scratch = reinterpret_cast<GroupScratch*>(W.bigScratch) + ((size_t)blockIdx.x * NG + gid);
-		X.beacon = W.beacon ? W.beacon + (size_t)blockIdx.x * 64 + lane : nullptr;
-		BEACON(X, 0x01000000u)
-#ifdef KAMD_PROFILE
-		for (int k = 0; k < 8; ++k) X.prof[k] = 0;
-		X.profT = wall_clock64();
-#endif
+		X.tl = nullptr;
 
-		GUARD_DECL(g9)
 		for (;;)
 		{
-			GUARD(g9, 10000000, 9)
 			uint32_t ci = 0;
 			if (X.gl == 0) ci = atomicAdd(chunkCounter, 1u);
 			ci = X.bcast(ci, 0);
 			if (ci >= nWork) break;
-			BEACON(X, 0x01100000u | ci)
-			PROF(X, 7)
 			searchChunk<G>(X, B, W, chunkOrder[ci]);
 		}
 	}

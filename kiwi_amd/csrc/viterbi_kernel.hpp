@@ -15,9 +15,9 @@ namespace kamd
 	struct GroupScratch { uint64_t key[BIGQ]; float score[BIGQ]; float fcs[BIGQ]; };
 
 	uint32_t searchKernelLdsBytes(int G);
-	void searchKernelProfile(unsigned long long* out16, bool reset);   // phase cycle counters (builds with -DKAMD_PROFILE only)   // dynamic LDS the launch must request
 
-	// G = lanes per chunk (4, 8, 16 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
+	// G = lanes per chunk (4, 8, 16, 32 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
+	// WPS = waves per SIMD the instantiation is compiled for (2, or 3 for G = 8 / 16).
 	template<int G, int WPS>
 	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork);
 	// End stage, one THREAD per chunk: restated std::sort of the end candidates, per-(root, state) selection and the

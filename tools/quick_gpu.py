@@ -19,8 +19,3 @@ for s, y in zip(corpus, res):
     x = o.analyze(s)
     if [([astuple(t) for t in a[0]], a[1]) for a in x] != [([astuple(t) for t in a[0]], a[1]) for a in y]: bad += 1
 print("RESULT bad", bad, "/", n, flush=True)
-if os.environ.get("KAMD_WATCH_PRINT"):
-    import ctypes, numpy as np
-    a = np.zeros(16, np.uint64)
-    k.lib.kamd_debug_profile.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    k.lib.kamd_debug_profile(a.ctypes.data, 0)

@@ -1,4 +1,5 @@
-"""Developer aid: per-chunk / per-phase timeline of the search kernel (library built with -DKAMD_TIMELINE, see csrc/Makefile)."""
+"""Developer aid: per-chunk / per-phase timeline of the search kernel.  Build `make -C kiwi_amd/csrc timeline`, run with
+KAMD_LIB=$PWD/kiwi_amd/libkiwi_hip_timeline.so python tools/timeline.py [workload]."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kiwi_amd.api import KiwiAmd
