@@ -7,8 +7,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <thread>
@@ -30,19 +32,55 @@ namespace kamd
 		}
 #define HIPCHECK(x) hipCheck((x), #x)
 
+		// Device blocks released by a finished batch are kept for the next one: a batch needs ~40 regions (one of them ~1 GB
+		// for 8192 sentences), and hipMalloc/hipFree of those per batch cost more than the kernels.  Bounded, per process.
+		struct DevBlockCache
+		{
+			std::mutex mu; std::vector<std::pair<void*, size_t>> blocks; size_t bytes = 0;
+			static constexpr size_t kMaxBlocks = 256, kMaxBytes = 64ull << 30;
+			void* take(size_t n, size_t& capOut)
+			{
+				std::lock_guard<std::mutex> g{ mu };
+				size_t best = blocks.size();
+				for (size_t i = 0; i < blocks.size(); ++i)
+					if (blocks[i].second >= n && blocks[i].second <= 2 * n + (1u << 20) && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+				if (best == blocks.size()) return nullptr;
+				void* p = blocks[best].first; capOut = blocks[best].second; bytes -= capOut;
+				blocks.erase(blocks.begin() + best);
+				return p;
+			}
+			void give(void* p, size_t cap)
+			{
+				{
+					std::lock_guard<std::mutex> g{ mu };
+					if (blocks.size() < kMaxBlocks && bytes + cap <= kMaxBytes) { blocks.emplace_back(p, cap); bytes += cap; return; }
+				}
+				(void)hipFree(p);
+			}
+			void trim()
+			{
+				std::lock_guard<std::mutex> g{ mu };
+				for (auto& b : blocks) (void)hipFree(b.first);
+				blocks.clear(); bytes = 0;
+			}
+		};
+		DevBlockCache& devCache() { static DevBlockCache c; return c; }
+
 		struct DevBuf
 		{
 			void* p = nullptr; size_t cap = 0;
 			DevBuf() = default;
 			DevBuf(const DevBuf&) = delete;
 			DevBuf& operator=(const DevBuf&) = delete;
-			~DevBuf() { if (p) (void)hipFree(p); }
+			~DevBuf() { if (p) devCache().give(p, cap); }
 			void ensure(size_t n)
 			{
 				if (n <= cap) return;
-				if (p) (void)hipFree(p);
+				if (p) devCache().give(p, cap);
 				p = nullptr; cap = 0;
 				const size_t want = n + n / 8 + 256;
+				p = devCache().take(want, cap);
+				if (p) return;
 				HIPCHECK(hipMalloc(&p, want));
 				cap = want;
 			}
@@ -163,6 +201,7 @@ namespace kamd
 		if (impl)
 		{
 			for (auto& e : impl->evs) if (e) (void)hipEventDestroy(e);
+			devCache().trim();
 			if (impl->stream) (void)hipStreamDestroy(impl->stream);
 			if (impl->stream2) (void)hipStreamDestroy(impl->stream2);
 		}
@@ -172,9 +211,16 @@ namespace kamd
 
 	namespace
 	{
+		// developer aid: KAMD_HOST_TIMING=1 prints where the host side of stage() / fetch() spends its time
+		struct HostTimer
+		{
+			bool on = std::getenv("KAMD_HOST_TIMING") != nullptr; const char* what; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+			explicit HostTimer(const char* w) : what(w) {}
+			void lap(const char* name) { if (!on) return; const auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[host] %s: %s %.2f ms\n", what, name, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
+		};
 		void parallelFor(size_t n, int threads, const std::function<void(size_t)>& fn)
 		{
-			if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+			if (threads <= 0) threads = (int)std::min(48u, std::max(1u, std::thread::hardware_concurrency()));   // spawned per call: keep the spawn cost small
 			threads = (int)std::min<size_t>(threads, std::max<size_t>(1, n / 64));
 			if (threads <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
 			std::atomic<size_t> next{ 0 };
@@ -524,6 +570,7 @@ namespace kamd
 
 	std::shared_ptr<StagedBatch> Engine::stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads)
 	{
+		HostTimer tm{ "stage" };
 		auto b = std::make_shared<StagedBatch>();
 		b->match = match;
 		b->raw.resize(texts.size()); b->prep.resize(texts.size());
@@ -542,7 +589,9 @@ namespace kamd
 				b->refs.push_back(ChunkRef{ (uint32_t)i, (uint32_t)c, { 0 }, openEnding && pt.chunks[c].nextOffset == pt.norm.size() });
 			}
 		}
+		tm.lap("text preparation");
 		layoutAndUpload(*impl, *b, makeParams(config, match));
+		tm.lap("layout + device buffers + upload");
 		return b;
 	}
 
@@ -588,16 +637,20 @@ namespace kamd
 	{
 		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
 		if (!b.ran || b.topN != (uint32_t)topN) { b.topN = (uint32_t)topN; run(b); }
+		HostTimer tm{ "fetch" };
 		download(*impl, b);
+		tm.lap("download");
 		const size_t nT = b.prep.size();
 		std::vector<std::vector<TokenResult>> ret(nT);
 		// chunk index of each text inside refs
 		std::vector<size_t> firstRef(nT + 1, 0);
 		for (auto& r : b.refs) firstRef[r.text + 1]++;
 		for (size_t i = 0; i < nT; ++i) firstRef[i + 1] += firstRef[i];
-		std::vector<PathResult> paths;
-		for (size_t i = 0; i < nT; ++i)
+		// texts are independent: post-process them on host threads; a text whose chunk must be searched again (other start
+		// states than the speculative {0}, or a scratch overflow) needs the device and is finished afterwards, one by one
+		auto doText = [&](size_t i, bool mayRerun) -> bool
 		{
+			std::vector<PathResult> paths;
 			ResultBuilder rb{ impl->model, topN, b.match, config.integrateAllomorph };
 			rb.begin(b.raw[i].data(), b.raw[i].size(), b.prep[i].position);
 			for (size_t c = firstRef[i]; c < firstRef[i + 1]; ++c)
@@ -610,6 +663,7 @@ namespace kamd
 				const uint32_t st = b.hResults[c].status;
 				if (st >= 16 || uniq != b.refs[c].sp)
 				{
+					if (!mayRerun) return false;
 					std::vector<std::vector<PathResult>> one;
 					ChunkRef r = b.refs[c]; r.sp = uniq;
 					runRefs(*this, *impl, b, { r }, st >= 16 ? b.capScale * 4 : b.capScale, one);
@@ -621,7 +675,12 @@ namespace kamd
 				rb.insertPaths(paths);
 			}
 			ret[i] = rb.finish(b.raw[i].data(), b.raw[i].size());
-		}
+			return true;
+		};
+		std::vector<uint8_t> again(nT, 0);
+		parallelFor(nT, 0, [&](size_t i) { if (!doText(i, false)) again[i] = 1; });
+		for (size_t i = 0; i < nT; ++i) if (again[i]) doText(i, true);
+		tm.lap("post-processing");
 		return ret;
 	}
 
