@@ -47,11 +47,12 @@ TOKEN_DTYPE = np.dtype([
 assert TOKEN_DTYPE.itemsize == 56
 
 
-def load_library():
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+def load_library(lib_path=None):
+    lib_path = lib_path or LIB_PATH
+    if not os.path.exists(lib_path):
+        raise RuntimeError(f"{lib_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the analyze path has no CPU fallback)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     L.kamd_open.restype = C.c_void_p
     L.kamd_open.argtypes = [C.c_char_p, C.c_int]
     L.kamd_close.argtypes = [C.c_void_p]
@@ -166,8 +167,8 @@ class Batch:
 class KiwiAmd:
     """Batched analyzer on one MI355X."""
 
-    def __init__(self, raw_model_path: str, device: int = -1):
-        self.lib = load_library()
+    def __init__(self, raw_model_path: str, device: int = -1, lib_path: str = None):
+        self.lib = load_library(lib_path)     # lib_path: another build of the same library (tests: the small-capacity build)
         self.h = self.lib.kamd_open(raw_model_path.encode(), device)
         if not self.h:
             raise RuntimeError("kamd_open failed: " + self.lib.kamd_last_error().decode())

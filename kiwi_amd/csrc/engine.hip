@@ -336,6 +336,13 @@ namespace kamd
 		p.maxUnk = c.maxUnkFormSize; p.maxUnkJ = c.maxUnkFormSizeFollowedByJClass; p.spaceTol = c.spaceTolerance;
 		p.splitComplex = (match & M_SPLIT_COMPLEX) ? 1 : 0; p.splitSaisiot = (match & M_SPLIT_SAISIOT) ? 1 : 0; p.mergeSaisiot = (match & M_MERGE_SAISIOT) ? 1 : 0;
 		p.topN = topN;
+		p.smallMax = 128; p.mediumMax = 512; p.bucketCap = 128;
+		if (const char* l = std::getenv("KAMD_CONTAINER_LIMITS"))   // test hook: "small,medium,bucket"
+		{
+			unsigned a = 0, b = 0, c = 0;
+			if (std::sscanf(l, "%u,%u,%u", &a, &b, &c) == 3 && a <= b && c >= 1) { p.smallMax = a; p.mediumMax = b; p.bucketCap = c; }
+			else throw std::runtime_error{ "KAMD_CONTAINER_LIMITS must be small,medium,bucket" };
+		}
 		return p;
 	}
 

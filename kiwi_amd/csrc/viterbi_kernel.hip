@@ -64,8 +64,12 @@ namespace kamd
 #else
 #define TLMARK(X, k)
 #endif
+#ifdef KAMD_TEST_SMALL_CAPS
+	constexpr uint32_t SCAP = 4, RING = 4;
+#else
 	constexpr uint32_t SCAP = 32;    // new states of one node whose scores are staged in LDS for pruning
 	constexpr uint32_t RING = 32;    // most recent nodes whose state ranges are kept in LDS
+#endif
 	enum StageBits : uint8_t { SB_SLOT_MASK = 0x1F, SB_DEAD = 0x20, SB_MORPH_SOCKET = 0x40, SB_STATE_SOCKET = 0x80 };
 	enum { RB_POSITIVE_E = 1, RB_SN_POINT = 2 };
 
@@ -629,7 +633,7 @@ namespace kamd
 					const uint64_t bal = X.ballot(rep);
 					// mode 1 runs exactly one candidate per batch, so the per-bucket rank is the container's per-bucket fill
 					const uint32_t rank = emittedInBucket + X.prefix(bal);
-					const bool keep = rep && (mode == 2 || X.P.topN > 1 || rank < 128);   // a full bucket drops later keys (BestPathContainer.hpp:363-367)
+					const bool keep = rep && (mode == 2 || X.P.topN > 1 || rank < (mode == 1 ? X.P.bucketCap : 128u));   // a full bucket drops later keys (BestPathContainer.hpp:363-367)
 					const uint64_t kbal = X.ballot(keep);
 					if (keep)
 					{
@@ -708,7 +712,7 @@ namespace kamd
 		const SearchParams& P = X.P;
 		// top-N (> 1) uses one container for every size (PathEvaluator.hpp:450-453): batched like the small one, without its 128-key cap
 		const bool topn = P.topN > 1;
-		const int mode = topn ? 0 : E.nLive <= 128 ? 0 : E.nLive <= 512 ? 1 : 2;
+		const int mode = topn ? 0 : E.nLive <= P.smallMax ? 0 : E.nLive <= P.mediumMax ? 1 : 2;
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		enum { K_NONE = 0, K_SKIP = 1, K_Z = 2, K_REG = 3 };
 		constexpr int MAXC = Lay<G>::MAXC;
@@ -876,7 +880,7 @@ namespace kamd
 				if (i < cnt && ((verdict >> blk) & 1))
 				{
 					if (staged) { X.stBits()[i] = X.stBits()[i] | SB_DEAD; markDead<G>(X, E.nodeStart + i); }
-					else X.st[E.nodeStart + i].dead = 1;
+					else markDead<G>(X, E.nodeStart + i);
 				}
 			}
 			waveSync();
@@ -913,7 +917,7 @@ namespace kamd
 					{
 						DevState* s = &X.st[E.nodeStart + i];
 						const uint32_t slot = s->rootId == COMMON_ROOT ? 0 : s->rootId + 1u;
-						if (!s->dead && slot == rs && s->accScore + P.cutOff < mx) s->dead = 1;
+						if (!s->dead && slot == rs && s->accScore + P.cutOff < mx) markDead<G>(X, E.nodeStart + i);   // (also in the LDS copy of the hot quad, G == 64)
 					}
 				}
 			}

@@ -5,10 +5,13 @@
 
 namespace kamd
 {
+#ifdef KAMD_TEST_SMALL_CAPS
+	// test build (make smallcaps): tiny LDS staging capacities so that small lattices drive every fallback path
+	constexpr uint32_t QCAP = 4;
+#else
 	constexpr uint32_t QCAP = 32;          // work items of one batch staged in LDS (per lane group)
+#endif
 	constexpr uint32_t BIGQ = 2048;        // work items of one batch staged in HBM scratch (per lane group); beyond: CS_ERR_PAIR_OVERFLOW
-	constexpr uint32_t ENDCAP = 256;       // end-node candidates per chunk
-	constexpr uint32_t CHAINCAP = 4096;    // morphemes on one best path
 
 	struct EndCand { float score, fcs, typo; uint32_t parent; uint8_t rootId, sp; uint16_t pad; };
 	// scratch in HBM per lane group (items of oversized batches, end-node candidates)

@@ -87,6 +87,13 @@ extern "C"
 		h.scfg.maxUnk = maxUnk; h.scfg.maxUnkJ = maxUnkJ; h.scfg.spaceTol = spaceTol; h.integrateAllomorph = !!integrateAllomorph;
 	}
 
+	// test hook: container selection limits (defaults 128, 512, 128)
+	void korc_set_container_limits(void* hp, uint32_t smallMax, uint32_t mediumMax, uint32_t bucketCap)
+	{
+		auto& h = *(OracleHandle*)hp;
+		h.bcfg.smallMax = smallMax; h.bcfg.mediumMax = mediumMax; h.bcfg.bucketCap = bucketCap;
+	}
+
 	size_t korc_dump_dict(void* hp, uint8_t* out, size_t cap)
 	{
 		auto d = dumpDict(((OracleHandle*)hp)->model);

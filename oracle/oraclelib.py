@@ -30,6 +30,7 @@ class OracleKiwi:
         L.korc_close.argtypes = [C.c_void_p]
         L.korc_set_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.korc_dump_dict.restype = C.c_size_t
+        L.korc_set_container_limits.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.korc_dump_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.korc_lm_progress.restype = C.c_float
         L.korc_lm_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32]
@@ -59,6 +60,10 @@ class OracleKiwi:
 
     def set_config(self, cut_off=8.0, space_penalty=7.0, typo_cost_weight=6.0, max_unk=6, max_unk_j=0xFFFFFFFF, space_tol=0, integrate_allomorph=True):
         self.lib.korc_set_config(self.h, cut_off, space_penalty, typo_cost_weight, max_unk, max_unk_j, space_tol, int(integrate_allomorph))
+
+    def set_container_limits(self, small_max=128, medium_max=512, bucket_cap=128):
+        """Test hook: number of incoming paths up to which the small / medium container is used, and the per-bucket key cap."""
+        self.lib.korc_set_container_limits(self.h, small_max, medium_max, bucket_cap)
 
     def analyze(self, text: str, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING, open_ending=False):
         u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)

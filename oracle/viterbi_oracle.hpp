@@ -18,7 +18,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <unordered_set>
 #include "lattice_oracle.hpp"
 #include "../kiwi_amd/csrc/feature.hpp"
 #include "../kiwi_amd/csrc/post.hpp"
@@ -30,6 +29,9 @@ namespace korc
 		float cutOff = 8, spacePenalty = 7, typoCostWeight = 6, oovRuleScale = 4, oovRuleBias = 4;
 		uint32_t spaceTolerance = 0;
 		uint32_t topN = 1;
+		// container selection by number of incoming paths and the per-bucket key cap (BestPathContainer.hpp:275-277, 363-367);
+		// tests shrink them to drive the medium / large containers on small lattices
+		uint32_t smallMax = 128, mediumMax = 512, bucketCap = 128;
 		bool openEnding = false, splitComplex = false, splitSaisiot = false, mergeSaisiot = false;
 	};
 
@@ -162,21 +164,29 @@ namespace korc
 			size_t r = (size_t)(int64_t)k.lm;  // std::hash<int32_t>
 			return ((uint16_t)k.prevRoot | ((uint16_t)k.sp << 8)) ^ ((r << 3) | (r >> 61));
 		}
-		struct SetHash { size_t operator()(const WPath& p) const { return keyHash(Key{ p.lmNode, p.prevRootId, p.spState }); } };
-		struct SetEq { bool operator()(const WPath& a, const WPath& b) const { return a.prevRootId == b.prevRootId && a.spState == b.spState && a.lmNode == b.lmNode; } };
 		std::vector<WPath> bucket[4];
-		std::unordered_set<WPath, SetHash, SetEq> hset;
+		std::vector<WPath> lset;     // mode 2 (large): distinct keys in insertion order
 
 		std::vector<WPath> titems;   // mode 3 (top-N): every inserted path of the current candidate, in insertion order
 
-		void contClear() { for (auto& b : bucket) b.clear(); hset.clear(); titems.clear(); }
+		void contClear() { for (auto& b : bucket) b.clear(); lset.clear(); titems.clear(); }
 		void contInsert(int mode, const WPath& np)
 		{
 			if (mode == 3) { titems.push_back(np); return; }
 			if (mode == 2)
 			{
-				auto ins = hset.emplace(np);
-				if (!ins.second && np.accScore > ins.first->accScore) const_cast<WPath&>(*ins.first) = np;
+				// the reference's large container is a thread_local std::unordered_set that is never shrunk: its iteration order
+				// depends on what the thread analysed before.  Restated with insertion order (as for top-N): same paths, same
+				// scores; only the hand-on order among the kept paths -- i.e. tie-breaking further down -- can differ.
+				for (auto& t : lset)
+				{
+					if (t.prevRootId == np.prevRootId && t.spState == np.spState && t.lmNode == np.lmNode)
+					{
+						if (np.accScore > t.accScore) t = np;
+						return;
+					}
+				}
+				lset.push_back(np);
 				return;
 			}
 			const size_t h = keyHash(Key{ np.lmNode, np.prevRootId, np.spState });
@@ -189,7 +199,7 @@ namespace korc
 					return;
 				}
 			}
-			if (b.size() < 128) b.push_back(np);
+			if (b.size() < (mode == 1 ? cfg.bucketCap : 128u)) b.push_back(np);   // the small container's own capacity is 128 as well
 		}
 		template<class Fn> void contEach(int mode, Fn&& fn)
 		{
@@ -210,7 +220,7 @@ namespace korc
 				}
 				return;
 			}
-			if (mode == 2) { for (auto& p : hset) fn(p); return; }
+			if (mode == 2) { for (auto& p : lset) fn(p); return; }
 			for (auto& b : bucket) for (auto& p : b) fn(p);
 		}
 
@@ -340,7 +350,7 @@ namespace korc
 			cnt.maxPrevPaths = std::max<uint64_t>(cnt.maxPrevPaths, totalPrev);
 			if (totalPrev > 128) cnt.nodesOver128++;
 			if (totalPrev > 512) cnt.nodesOver512++;
-			const int mode = cfg.topN > 1 ? 3 : totalPrev <= 128 ? 0 : totalPrev <= 512 ? 1 : 2;
+			const int mode = cfg.topN > 1 ? 3 : totalPrev <= cfg.smallMax ? 0 : totalPrev <= cfg.mediumMax ? 1 : 2;
 
 			for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
 			{

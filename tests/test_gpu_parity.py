@@ -152,6 +152,32 @@ def test_lane_group_variants_match_oracle(oracle, small_model, monkeypatch, lane
     other.close()
 
 
+@pytest.mark.parametrize("lanes", ["16", "8", "64"])
+def test_fallback_paths_with_small_capacities(small_model, monkeypatch, lanes):
+    """The synthetic lattices are too unambiguous to reach the medium / large path containers (> 128 / > 512 incoming paths),
+    the HBM work-item queue (> 32 items of one candidate), the HBM pruning path (> 32 new paths of a node) or the far-back node
+    lookup (> 32 nodes back) on their own.  This runs a build of the same kernels with those capacities cut to 4
+    (`make smallcaps`) and the container limits cut to 3 / 8 incoming paths and 2 keys per bucket on BOTH sides, device and
+    oracle (a separate oracle instance), and demands identical output -- for top-1 and top-2."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    lib = os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip_smallcaps.so")
+    if not os.path.exists(lib):
+        pytest.skip("libkiwi_hip_smallcaps.so not built (make -C kiwi_amd/csrc smallcaps)")
+    texts = synthetic(sm, 300, 141, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 200, 142) + EDGE_TEXTS
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    monkeypatch.setenv("KAMD_CONTAINER_LIMITS", "3,8,2")
+    orc = oraclelib.OracleKiwi(path)
+    orc.set_container_limits(3, 8, 2)
+    dev = KiwiAmd(path, lib_path=lib)
+    for top_n in (1, 2):
+        got = dev.analyze_batch(texts, top_n=top_n).to_python()
+        for s, y in zip(texts, got):
+            assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (lanes, top_n, s)
+    dev.close()
+
+
 def test_empty_and_degenerate_batches(engine):
     assert engine.analyze_batch([]).n_texts() == 0
     r = engine.analyze_batch(["", " ", "\n"]).to_python()
