@@ -254,6 +254,7 @@ namespace kamd
 		std::vector<uint8_t> flags(nC), sp;
 		std::vector<uint32_t> textOff(nC);
 		const uint64_t sc = b.capScale;
+		const bool tinyArenas = std::getenv("KAMD_TEST_TINY_ARENAS") != nullptr;
 		for (size_t c = 0; c < nC; ++c)
 		{
 			const auto& r = b.refs[c];
@@ -262,7 +263,11 @@ namespace kamd
 			b.charOff[c + 1] = b.charOff[c] + (uint32_t)n;
 			b.patOff[c + 1] = b.patOff[c] + (d.patEnd - d.patBegin);
 			b.spOff[c + 1] = b.spOff[c] + (uint32_t)r.sp.size();
-			const uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
+			uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
+			if (tinyArenas)   // test hook (KAMD_TEST_TINY_ARENAS): regions far too small at scale 1, so that the overflow -> re-run ladder is exercised
+			{
+				mcap = (n / 2 + 8) * sc; ncap = std::min<uint64_t>((n / 2 + 8) * sc, 0xFFE0); scap = (n + 16) * sc; tcap = (n / 4 + 4) * sc;
+			}
 			if ((uint64_t)b.matchBase[c] + mcap > 0xFFFFFFFFull || (uint64_t)b.nodeBase[c] + ncap > 0xFFFFFFFFull) throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
 			b.matchBase[c + 1] = b.matchBase[c] + (uint32_t)mcap;
 			b.nodeBase[c + 1] = b.nodeBase[c] + (uint32_t)ncap;

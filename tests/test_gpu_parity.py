@@ -178,6 +178,21 @@ def test_fallback_paths_with_small_capacities(small_model, monkeypatch, lanes):
     dev.close()
 
 
+def test_overflow_rerun_ladder(oracle, small_model, monkeypatch):
+    """Per-chunk HBM regions are sized linearly in the chunk length; a chunk that outgrows one reports an error code and
+    the host re-runs it with 4x, 16x, 64x the capacity.  KAMD_TEST_TINY_ARENAS makes the regions far too small at scale 1, so
+    most chunks climb that ladder; the results must not change."""
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    texts = synthetic(sm, 150, 151, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 100, 152)
+    monkeypatch.setenv("KAMD_TEST_TINY_ARENAS", "1")
+    dev = KiwiAmd(path)
+    got = dev.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(oracle.analyze(s)) == _norm(y), s
+    dev.close()
+
+
 def test_empty_and_degenerate_batches(engine):
     assert engine.analyze_batch([]).n_texts() == 0
     r = engine.analyze_batch(["", " ", "\n"]).to_python()
