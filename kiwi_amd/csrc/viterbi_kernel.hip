@@ -221,12 +221,15 @@ namespace kamd
 	__device__ INL3 float lmProgress(const ModelView& M, int32_t& node, uint32_t next)
 	{
 		float acc = 0;
+		// the unigram record of `next` does not depend on the walk: fetched together with the first bucket probe, because
+		// most walks (a context miss, then the root) would otherwise pay a second dependent round trip for it
+		const LmRootRec rootRec = M.lmRoot2[next];
 		for (;;)
 		{
 			int32_t v; float ll;
 			if (node == 0)
 			{
-				const LmRootRec r = M.lmRoot2[next];
+				const LmRootRec r = rootRec;
 				if (r.value == 0) return acc + M.h.unkLl;
 				v = r.value; ll = r.ll;
 			}
@@ -244,7 +247,7 @@ namespace kamd
 				if (!lower) break;
 				cur += lower;
 				int32_t lv; float l2;
-				if (cur == 0) { lv = M.lmRoot2[next].value; if (lv > 0) { node = lv; return acc + ll; } }
+				if (cur == 0) { lv = rootRec.value; if (lv > 0) { node = lv; return acc + ll; } }
 				else if (lmLookup(M, (uint32_t)cur, next, lv, l2) && lv > 0) { node = cur + lv; return acc + ll; }
 			}
 			node = 0;
