@@ -8,10 +8,15 @@
 //                  form lists (longest first), which is exactly the candidate order the reference's
 //                  Aho-Corasick walk produces per character (goto/fail + submatch chain,
 //                  /root/reference/src/KTrie.cpp:1283-1311).  Order independent => embarrassingly parallel.
-//  k_build_lattice : one thread per chunk.  The reference's lattice bookkeeping is inherently sequential
+//  k_build_lattice : one WAVE per chunk.  The reference's lattice bookkeeping is inherently sequential
 //                  (OOV insertion depends on the end of the most recently appended node, appends depend on
-//                  reachability: /root/reference/src/KTrie.cpp:15-43, 921-996, 1040-1137, 240-299), so each
-//                  thread replays it for its chunk over the packed match lists; 64 chunks advance per wave.
+//                  reachability: /root/reference/src/KTrie.cpp:15-43, 921-996, 1040-1137, 240-299), so lane 0
+//                  replays it -- over an LDS-resident copy of the chunk's text, index maps, match masks and
+//                  packed matches that all lanes stage first, growing the node list in LDS -- and the final
+//                  per-node facts / re-ordering run one node per lane.  One launch per LDS size class.
+//  k_build_lattice_big : one thread per chunk, arrays in HBM: chunks beyond the LDS budget, or that outgrew
+//                  their LDS copy at run time.
+//  k_expand_cands : static candidate records per (node, candidate) for the search kernel.
 // Memory-bound integer work: no MFMA; see DESIGN.md for the roofline accounting.
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"

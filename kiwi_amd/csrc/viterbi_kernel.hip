@@ -16,13 +16,22 @@
 // and pruning never re-reads states: scores are staged in LDS and losers are only *marked* dead in HBM.
 //
 // De-duplication per (candidate, LM state, root, special state) -- the reference's per-morpheme hash
-// container (src/BestPathContainer.hpp:279-483) -- works on the scored items staged in LDS: an item is the
-// representative of its key iff no earlier item of the same candidate carries the key; the winner of a key is
-// the first item with the maximal score ("first inserted wins on ties").  Items are few (<= 64 per batch), so
-// this is a short broadcast scan of LDS, no atomics.  Group ballots (slices of the wave ballot) give container
-// order; pruning is a group max-reduction + ballot compaction.  States stream to a per-chunk arena in HBM
-// (40 B each); the end node, the restated std::sort, group selection and the back-trace run on the group's
-// first lane and emit 24-byte tokens.
+// container (src/BestPathContainer.hpp:279-483): an item is the representative of its key iff no earlier item
+// of the same candidate carries the key; the winner of a key is the first item with the maximal score ("first
+// inserted wins on ties").  Common case (a batch fits the group, small container; G = 8 or 16, where a group is
+// half / all of a 16-lane DPP row): keys and scores stay in registers and 15 branch-free row_ror steps decide
+// representative, winner and (top-N) rank; pruning is a 4-step DPP max or the same 15-step count.  Otherwise the
+// scored items are staged in LDS (<= QCAP) or per-group HBM scratch and scanned.  Group ballots (slices of the
+// wave ballot) give container order.  States stream to a per-chunk arena in HBM (48 B each: a 16-B hot quad read
+// by successors + 32 B for the back-trace); losers of the pruning are only *marked* dead.  The chunk ends with the
+// end-of-sentence transition of the surviving paths (finishChunk: a real function call that gets COPIES of the
+// context, so that the context itself and the kernel arguments stay in registers / the kernarg segment); sorting
+// them, the selection and the back-trace are k_finish_paths, one thread per chunk.
+//
+// Lanes of a group exchange data between phases through LDS / HBM; phases are separated by waveSync()
+// (wavefront fence + wave_barrier, device_types.hpp).  Developer aids: `make timeline` (per-chunk / per-phase
+// stamps, tools/timeline.py), KAMD_HANGDUMP=1 (engine.hip: reads per-chunk progress back while the kernel hangs),
+// `make smallcaps` (tiny LDS capacities: every fallback path in the parity suite).
 //
 // Reference behaviour reproduced: BestPathFinder::findBestPath (src/PathEvaluator.hpp:1178-1419),
 // PathEvaluator::operator()/evalSingleMorpheme (:347-635), RuleBasedScorer/insertToPathContainer/
