@@ -1,0 +1,193 @@
+"""GPU (-m gpu): the drop-in boundary itself -- Kiwi's own C API (include/kiwi_capi.h <- reference include/kiwi/capi.h) bound
+with ctypes exactly as a client of the reference would, against the CPU oracle: kiwi_init, kiwi_analyze{,_w,_m,_mw} with
+reader / receiver callbacks in input order, the kiwi_res_* accessors, config / option setters, error convention."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip.so")
+MATCH_ALL_WITH_NORMALIZING = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 23) | (1 << 16)
+
+
+class TokenInfo(C.Structure):      # kiwi_token_info_t (capi.h:43-61)
+    _fields_ = [("chr_position", C.c_uint32), ("word_position", C.c_uint32), ("sent_position", C.c_uint32), ("line_number", C.c_uint32),
+                ("length", C.c_uint16), ("tag", C.c_uint8), ("sense_id", C.c_uint8), ("score", C.c_float), ("typo_cost", C.c_float),
+                ("typo_form_id", C.c_uint32), ("paired_token", C.c_uint32), ("sub_sent_position", C.c_uint32), ("dialect", C.c_uint16)]
+
+
+class Config(C.Structure):         # kiwi_config_t (capi.h:72-86)
+    _fields_ = [("integrate_allomorph", C.c_uint8), ("cut_off_threshold", C.c_float), ("oov_rule_scale", C.c_float), ("oov_rule_bias", C.c_float),
+                ("oov_chr_bias", C.c_float), ("oov_global_weight", C.c_float), ("oov_local_weight", C.c_float), ("oov_global_min_freq", C.c_float),
+                ("space_penalty", C.c_float), ("typo_cost_weight", C.c_float),
+                ("max_unk_form_size", C.c_uint32), ("max_unk_form_size_followed_by_j_class", C.c_uint32), ("space_tolerance", C.c_uint32)]
+
+
+class Option(C.Structure):         # kiwi_analyze_option_t (capi.h:662-670)
+    _fields_ = [("match_options", C.c_int), ("blocklist", C.c_void_p), ("open_ending", C.c_int), ("allowed_dialects", C.c_int),
+                ("dialect_cost", C.c_float), ("typo_transformer", C.c_void_p), ("typo_threshold", C.c_float)]
+
+
+READER = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+READER_W = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+RECEIVER = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def capi():
+    L = C.CDLL(LIB)
+    L.kiwi_error.restype = C.c_char_p
+    L.kiwi_version.restype = C.c_char_p
+    L.kiwi_init.restype = C.c_void_p
+    L.kiwi_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+    L.kiwi_close.argtypes = [C.c_void_p]
+    L.kiwi_set_global_config.argtypes = [C.c_void_p, Config]
+    L.kiwi_get_global_config.restype = Config
+    L.kiwi_get_global_config.argtypes = [C.c_void_p]
+    L.kiwi_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.kiwi_get_option.argtypes = [C.c_void_p, C.c_int]
+    L.kiwi_analyze.restype = C.c_void_p
+    L.kiwi_analyze.argtypes = [C.c_void_p, C.c_char_p, C.c_int, Option, C.c_void_p]
+    L.kiwi_analyze_w.restype = C.c_void_p
+    L.kiwi_analyze_w.argtypes = [C.c_void_p, C.c_void_p, C.c_int, Option, C.c_void_p]
+    L.kiwi_analyze_m.argtypes = [C.c_void_p, READER, RECEIVER, C.c_void_p, C.c_int, Option]
+    L.kiwi_analyze_mw.argtypes = [C.c_void_p, READER_W, RECEIVER, C.c_void_p, C.c_int, Option]
+    for f in ("kiwi_res_size", "kiwi_res_close"):
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.kiwi_res_prob.restype = C.c_float
+    L.kiwi_res_prob.argtypes = [C.c_void_p, C.c_int]
+    L.kiwi_res_word_num.argtypes = [C.c_void_p, C.c_int]
+    L.kiwi_res_token_info.restype = C.POINTER(TokenInfo)
+    L.kiwi_res_token_info.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.kiwi_res_morpheme_id.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.kiwi_res_form.restype = C.c_char_p
+    L.kiwi_res_form.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.kiwi_res_tag.restype = C.c_char_p
+    L.kiwi_res_tag.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.kiwi_res_form_w.restype = C.POINTER(C.c_uint16)
+    L.kiwi_res_form_w.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    for f in ("kiwi_res_position", "kiwi_res_length", "kiwi_res_word_position", "kiwi_res_sent_position"):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.kiwi_res_score.restype = C.c_float
+    L.kiwi_res_score.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.kiwi_tag_to_string.restype = C.c_char_p
+    L.kiwi_tag_to_string.argtypes = [C.c_void_p, C.c_uint8]
+    return L
+
+
+def opt(match=MATCH_ALL_WITH_NORMALIZING, open_ending=0):
+    return Option(match, None, open_ending, 0, 0.0, None, 0.0)
+
+
+def read_result(L, k, r):
+    """kiwi_res_h -> [([(form, tag id, position, length, word pos, sent pos, score, morph id)], prob)]"""
+    out = []
+    for i in range(L.kiwi_res_size(r)):
+        toks = []
+        for j in range(L.kiwi_res_word_num(r, i)):
+            ti = L.kiwi_res_token_info(r, i, j).contents
+            form = L.kiwi_res_form(r, i, j).decode("utf-8")
+            assert L.kiwi_res_position(r, i, j) == ti.chr_position and L.kiwi_res_length(r, i, j) == ti.length
+            assert L.kiwi_res_word_position(r, i, j) == ti.word_position and L.kiwi_res_sent_position(r, i, j) == ti.sent_position
+            assert L.kiwi_res_score(r, i, j) == ti.score
+            assert L.kiwi_res_tag(r, i, j) == L.kiwi_tag_to_string(k, ti.tag)
+            fw = L.kiwi_res_form_w(r, i, j)
+            n = 0
+            while fw[n]:
+                n += 1
+            assert np.array(fw[:n], np.uint16).tobytes().decode("utf-16-le", errors="surrogatepass") == form
+            toks.append((form, ti.tag, ti.chr_position, ti.length, ti.word_position, ti.sent_position, ti.score, L.kiwi_res_morpheme_id(r, i, j, k)))
+        out.append((toks, L.kiwi_res_prob(r, i)))
+    return out
+
+
+def from_oracle(res):
+    return [([(t.form, t.tag, t.position, t.length, t.word_position, t.sent_position, t.score, t.morph_id) for t in a[0]], a[1]) for a in res]
+
+
+@pytest.fixture(scope="module")
+def kiwi(capi, small_model):
+    k = capi.kiwi_init(small_model[1].encode(), 0, 0, 0)
+    assert k, capi.kiwi_error()
+    yield k
+    assert capi.kiwi_close(k) == 0
+
+
+def test_version_and_init_errors(capi):
+    assert capi.kiwi_version()
+    assert not capi.kiwi_init(b"/nonexistent/model", 0, 0, 0)
+    assert capi.kiwi_error()
+
+
+def test_analyze_utf8_and_utf16(capi, kiwi, oracle, small_model):
+    sm, _ = small_model
+    for s in synthetic(sm, 40, 161, min_jamo=5, max_jamo=100) + [t for t in EDGE_TEXTS if t.strip() and "\x00" not in t][:30]:
+        try:
+            s.encode("utf-8")
+        except UnicodeEncodeError:
+            continue                     # lone surrogates have no UTF-8 form: covered by the UTF-16 entry point below
+        for top_n in (1, 2):
+            r = capi.kiwi_analyze(kiwi, s.encode("utf-8"), top_n, opt(), None)
+            assert r, capi.kiwi_error()
+            assert read_result(capi, kiwi, r) == from_oracle(oracle.analyze(s, top_n=top_n)), s
+            assert capi.kiwi_res_close(r) == 0
+        u = np.frombuffer((s + "\0").encode("utf-16-le", errors="surrogatepass"), np.uint16).copy()
+        r = capi.kiwi_analyze_w(kiwi, u.ctypes.data, 1, opt(), None)
+        assert r, capi.kiwi_error()
+        assert read_result(capi, kiwi, r) == from_oracle(oracle.analyze(s)), s
+        capi.kiwi_res_close(r)
+
+
+def test_analyze_many_delivers_in_input_order(capi, kiwi, oracle, small_model):
+    sm, _ = small_model
+    texts = [t for t in synthetic(sm, 300, 162, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 100, 163)]
+    enc = [t.encode("utf-8") for t in texts]
+    got = []
+
+    def reader(i, buf, ud):
+        if i >= len(enc):
+            return 0
+        if not buf:
+            return len(enc[i])                # capi.h:88-104: a null buffer asks for the size; 0 ends the stream
+        C.memmove(buf, enc[i], len(enc[i]))
+        return 0
+
+    def receiver(i, r, ud):
+        got.append((i, read_result(capi, kiwi, r)))
+        capi.kiwi_res_close(r)
+        return 0
+
+    capi.kiwi_set_option(kiwi, 0x9001, 128)   # KIWI_GPU_BATCH_SIZE: several device batches
+    assert capi.kiwi_get_option(kiwi, 0x9001) == 128
+    n = capi.kiwi_analyze_m(kiwi, READER(reader), RECEIVER(receiver), None, 1, opt())
+    assert n == len(texts), capi.kiwi_error()
+    assert [i for i, _ in got] == list(range(len(texts)))
+    for (i, y), s in zip(got, texts):
+        assert y == from_oracle(oracle.analyze(s)), s
+
+
+def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
+    cfg = capi.kiwi_get_global_config(kiwi)
+    assert cfg.cut_off_threshold == 8.0 and cfg.space_penalty == 7.0
+    s = "가나다라 마바사"
+    try:
+        cfg.cut_off_threshold = 5.0
+        capi.kiwi_set_global_config(kiwi, cfg)
+        oracle.set_config(cut_off=5.0)
+        r = capi.kiwi_analyze(kiwi, s.encode(), 1, opt(), None)
+        assert read_result(capi, kiwi, r) == from_oracle(oracle.analyze(s))
+        capi.kiwi_res_close(r)
+    finally:
+        cfg.cut_off_threshold = 8.0
+        capi.kiwi_set_global_config(kiwi, cfg)
+        oracle.set_config()
+    assert not capi.kiwi_analyze(kiwi, s.encode(), 9, opt(), None)          # top_n beyond the device limit: refused, not ignored
+    assert capi.kiwi_error()
+    o = opt()
+    o.blocklist = 1
+    assert not capi.kiwi_analyze(kiwi, s.encode(), 1, o, None)               # blocklists are a later row
