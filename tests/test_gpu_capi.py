@@ -191,3 +191,33 @@ def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
     o = opt()
     o.blocklist = 1
     assert not capi.kiwi_analyze(kiwi, s.encode(), 1, o, None)               # blocklists are a later row
+
+
+def test_c_client_program(oracle, small_model, tmp_path):
+    """a plain C program written against the C API header only is compiled with gcc, linked to the
+    library and run on a corpus; its printed tokens equal the oracle's."""
+    import subprocess
+    sm, path = small_model
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "kiwi_client")
+    subprocess.check_call(["gcc", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(HERE, "c_client", "client.c"),
+                           "-L" + os.path.join(root, "kiwi_amd"), "-lkiwi_hip", "-Wl,-rpath," + os.path.join(root, "kiwi_amd"), "-o", exe])
+    texts = [t for t in synthetic(sm, 200, 171, min_jamo=5, max_jamo=100) if "\n" not in t and "\r" not in t and t.strip()]
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join(texts) + "\n", encoding="utf-8")
+    out = subprocess.run([exe, path, str(corpus)], check=True, capture_output=True).stdout.decode("utf-8")
+    want = []
+    tag_names = None
+    for i, t in enumerate(texts):
+        res = oracle.analyze(t)
+        for tok in res[0][0]:
+            want.append((i, tok.form, tok.position, tok.length, "%.9g" % tok.score))
+        want.append((i, "#", "%.9g" % res[0][1]))
+    got = []
+    for ln in out.splitlines():
+        f = ln.split("\t")
+        if f[1] == "#":
+            got.append((int(f[0]), "#", f[2]))
+        else:
+            got.append((int(f[0]), f[1], int(f[3]), int(f[4]), f[5]))
+    assert got == want
