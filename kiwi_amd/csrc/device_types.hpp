@@ -145,7 +145,7 @@ namespace kamd
 	};
 
 	// LDS layout of the wave-per-chunk lattice build (byte offsets): n text units, node capacity, packed-match capacity
-	struct LatticeLds { uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, endPosMap, fullMask, zAt, mforms, mfrec, out, queue, total; };
+	struct LatticeLds { uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, endPosMap, fullMask, zAt, mforms, mfrec, out, spaceErr, queue, total; };
 	// LDS-side capacities are the typical need (3 per text unit), not the worst-case HBM capacities: a chunk that outgrows
 	// them at run time is handed to the thread-per-chunk kernel (flag kLatticeNeedsBig in nNodes[chunk])
 	constexpr uint32_t kLatticeNeedsBig = 0xFFFFFFFEu;
@@ -160,7 +160,7 @@ namespace kamd
 		l.mask = take(8 * (n + 2)); l.moff = take(4 * (n + 2));
 		l.endPosMap = take(4 * (n + 2)); l.fullMask = take(8 * (n + 2)); l.zAt = take(n + 2);
 		l.mforms = take(4 * matchCap); l.mfrec = take(8 * matchCap);
-		l.out = take(32 * nodeCap); l.queue = take(4 * nodeCap);
+		l.out = take(16 * nodeCap); l.spaceErr = take(nodeCap); l.queue = take(4 * nodeCap);     // 16-byte build nodes (lattice_kernels.hip BuildNode16)
 		l.total = o;
 		return l;
 	}

@@ -158,23 +158,46 @@ namespace kamd
 	}
 
 	// ------------------------------------------------------------------------------------------------
-	struct LatticeCtx
+	// lattice node while the build runs: the 32-byte record of the search kernel (HBM variant), or the 16 bytes of it that the
+	// build itself fills (LDS variant: the node list is the largest LDS array of a chunk; spaceErrors sits in a byte array beside it)
+	struct BuildNode16 { uint32_t form; uint16_t startPos, endPos, prev, sibling, uformOff, uformLen; };
+	template<class NodeT>
+	struct LatticeCtxT
 	{
+		using Node = NodeT;
+		uint8_t* spaceErr;      // BuildNode16 only
 		const ModelView* M; const SearchParams* P;
 		const uint16_t* str; const uint16_t* nsToPos; const uint16_t* posToNs;
-		DevNode* out; uint32_t* endPosMap; uint64_t* fullMask; uint8_t* zAt; uint32_t nOut, cap; bool overflow;
+		NodeT* out; uint32_t* endPosMap; uint64_t* fullMask; uint8_t* zAt; uint32_t nOut, cap; bool overflow;
+		__device__ __forceinline__ void setSpaceErrors(uint32_t id, uint8_t v) { if constexpr (sizeof(NodeT) == sizeof(DevNode)) out[id].spaceErrors = v; else spaceErr[id] = v; }
+		__device__ __forceinline__ DevNode full(uint32_t id) const
+		{
+			if constexpr (sizeof(NodeT) == sizeof(DevNode)) return out[id];
+			else
+			{
+				const NodeT g = out[id];
+				DevNode nn;
+				nn.form = g.form; nn.startPos = g.startPos; nn.endPos = g.endPos; nn.prev = g.prev; nn.sibling = g.sibling; nn.uformOff = g.uformOff; nn.uformLen = g.uformLen;
+				nn.spaceErrors = spaceErr[id]; nn.nflags = 0; nn.nPrev = 0; nn.packOff = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0;
+				return nn;
+			}
+		}
 	};
+	using LatticeCtx = LatticeCtxT<DevNode>;
 
 	// `qual`: the node counts for hasFormAlready (zero typo cost and unknown-or-has-a-full-morpheme); `lenKey`: its length there
-	__device__ __forceinline__ bool latAppend(LatticeCtx& L, uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, uint32_t nMap, bool qual = false, uint32_t lenKey = 0, uint8_t zbits = 0)
+	template<class LC>
+	__device__ __forceinline__ bool latAppend(LC& L, uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, uint32_t nMap, bool qual = false, uint32_t lenKey = 0, uint8_t zbits = 0)
 	{
 		const uint32_t ms = L.endPosMap[s];
 		if ((ms & 0xFFFF) == (ms >> 16)) return false;
 		if (L.nOut >= L.cap) { L.overflow = true; return false; }
 		const uint32_t id = L.nOut++;
-		DevNode nn;
+		typename LC::Node nn;
 		nn.form = form; nn.startPos = (uint16_t)s; nn.endPos = (uint16_t)e; nn.prev = (uint16_t)(id - (ms & 0xFFFF)); nn.sibling = 0;
-		nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = 0; nn.nflags = 0; nn.nPrev = 0; nn.packOff = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0;
+		nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen;
+		if constexpr (sizeof(typename LC::Node) == sizeof(DevNode)) { nn.spaceErrors = 0; nn.nflags = 0; nn.nPrev = 0; nn.packOff = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0; }
+		else L.spaceErr[id] = 0;
 		L.out[id] = nn;
 		if (e >= nMap) return true;
 		if (qual && lenKey >= 1 && lenKey <= 64) L.fullMask[e] |= 1ull << (lenKey - 1);
@@ -190,14 +213,16 @@ namespace kamd
 		return true;
 	}
 
-	__device__ __forceinline__ uint32_t latNodeLen(const LatticeCtx& L, const DevNode& g)
+	template<class LC>
+	__device__ __forceinline__ uint32_t latNodeLen(const LC& L, const typename LC::Node& g)
 	{
 		if (g.uformLen) return g.uformLen;
 		const FormRec f = L.M->forms[g.form];
 		return f.len - f.numSpaces;
 	}
 
-	__device__ bool latHasForm(const LatticeCtx& L, uint32_t s, uint32_t e)   // Splitter::hasFormAlready (KTrie.cpp:897-905)
+	template<class LC>
+	__device__ bool latHasForm(const LC& L, uint32_t s, uint32_t e)   // Splitter::hasFormAlready (KTrie.cpp:897-905)
 	{
 		// nodes are indexed by (end, length) in a 64-bit mask per end position; only longer spans need the scan
 		if (e - s <= 64) return (L.fullMask[e] >> (e - s - 1)) & 1;
@@ -207,19 +232,21 @@ namespace kamd
 		if (a < 1) a = 1;
 		for (uint32_t i = a; i < b; ++i)
 		{
-			const DevNode g = L.out[i];
+			const typename LC::Node g = L.out[i];
 			if (g.endPos == e && g.endPos - latNodeLen(L, g) == s && (g.form == NOFORM || (L.M->forms[g.form].flags & FF_HAS_ANY_FULL))) return true;
 		}
 		return false;
 	}
 
-	__device__ __forceinline__ void latTrim(const LatticeCtx& L, uint32_t off, uint32_t len, uint32_t& o, uint32_t& l)
+	template<class LC>
+	__device__ __forceinline__ void latTrim(const LC& L, uint32_t off, uint32_t len, uint32_t& o, uint32_t& l)
 	{
 		while (len && isSpace(L.str[off + len - 1])) --len;
 		o = off; l = len;
 	}
 
-	__device__ void latInsertUnk(LatticeCtx& L, uint32_t s, uint32_t e, bool hasJ, uint32_t nMap)   // Splitter::insertUnkForm (KTrie.cpp:921-953)
+	template<class LC>
+	__device__ void latInsertUnk(LC& L, uint32_t s, uint32_t e, bool hasJ, uint32_t nMap)   // Splitter::insertUnkForm (KTrie.cpp:921-953)
 	{
 		if (s >= e || latHasForm(L, s, e)) return;
 		uint32_t lastPos = L.out[L.nOut - 1].endPos;
@@ -240,7 +267,8 @@ namespace kamd
 		}
 	}
 
-	__device__ __forceinline__ void latUnkPair(LatticeCtx& L, uint32_t boundary, uint32_t unkStart, uint32_t e, bool hasJ, uint32_t nMap)
+	template<class LC>
+	__device__ __forceinline__ void latUnkPair(LC& L, uint32_t boundary, uint32_t unkStart, uint32_t e, bool hasJ, uint32_t nMap)
 	{
 		if (boundary < unkStart) latInsertUnk(L, boundary, e, hasJ, nMap);
 		latInsertUnk(L, unkStart, e, hasJ, nMap);
@@ -255,7 +283,8 @@ namespace kamd
 	};
 
 	// Splitter::splitByTrie replayed over the packed match lists (KTrie.cpp:1040-1137, 921-996): strictly sequential, one lane.
-	__device__ __forceinline__ void latticeSerialBuild(const ModelView& M, const BatchView& B, const SearchParams& P, LatticeCtx& L, const LatticeMem& Q,
+	template<class LC>
+	__device__ __forceinline__ void latticeSerialBuild(const ModelView& M, const BatchView& B, const SearchParams& P, LC& L, const LatticeMem& Q,
 		uint32_t chunk, uint32_t n, uint32_t nNs, uint32_t nMap)
 	{
 		const uint16_t* str = Q.str; const uint8_t* cls = Q.cls; const uint8_t* script = Q.script; const uint8_t* cflag = Q.cflag;
@@ -367,7 +396,7 @@ namespace kamd
 				}
 				if (se <= P.spaceTol)
 				{
-					if (latAppend(L, nb, ne, fi, 0, 0, nMap, (f.flags & FF_HAS_ANY_FULL) != 0, flen, f.flags & 3)) L.out[L.nOut - 1].spaceErrors = (uint8_t)(se > 255 ? 255 : se);
+					if (latAppend(L, nb, ne, fi, 0, 0, nMap, (f.flags & FF_HAS_ANY_FULL) != 0, flen, f.flags & 3)) L.setSpaceErrors(L.nOut - 1, (uint8_t)(se > 255 ? 255 : se));
 				}
 			}
 		}
@@ -387,7 +416,8 @@ namespace kamd
 
 	// removeUnconnected, part 1 (KTrie.cpp:240-299): backward BFS from the end node, then the new index of every connected node.
 	// Returns the number of connected nodes; inv (= Q.queue) holds old -> new (0xFFFF: dropped); endPosMap[e] := connected nodes ending at e.
-	__device__ __forceinline__ uint32_t latticeConnect(LatticeCtx& L, const LatticeMem& Q, uint32_t cap, uint32_t nNs)
+	template<class LC>
+	__device__ __forceinline__ uint32_t latticeConnect(LC& L, const LatticeMem& Q, uint32_t cap, uint32_t nNs)
 	{
 		uint16_t* queue = Q.queue; uint16_t* connOrd = Q.connOrd;
 		const uint32_t G = L.nOut;
@@ -436,18 +466,19 @@ namespace kamd
 
 	// removeUnconnected, part 2: old node idx -> final record at its new index (predecessor-dependent facts the search kernel
 	// needs once per node included).  Returns the node's candidate count, or 0xFFFFFFFF for a dropped node.  Nodes are independent.
-	__device__ __forceinline__ uint32_t latticeEmitNode(const ModelView& M, const LatticeCtx& L, const uint16_t* str, const uint8_t* cls, const uint16_t* inv,
+	template<class LC>
+	__device__ __forceinline__ uint32_t latticeEmitNode(const ModelView& M, const LC& L, const uint16_t* str, const uint8_t* cls, const uint16_t* inv,
 		DevNode* fin, uint32_t idx, uint32_t n, uint32_t nConn, uint32_t textOff)
 	{
 		const uint32_t ni = inv[idx];
 		if (ni == 0xFFFF) return 0xFFFFFFFFu;
-		DevNode nn = L.out[idx];
+		DevNode nn = L.full(idx);
 		const uint32_t startNs = nn.startPos;
 		uint8_t nf = 0;
 		if (ni >= 1)
 		{
 			// predecessor-dependent facts the search kernel needs once per node
-			const DevNode pn = L.out[idx - nn.prev];
+			const typename LC::Node pn = L.out[idx - nn.prev];
 			const uint32_t startStr = (ni + 1 == nConn) ? n : (uint32_t)L.nsToPos[startNs];
 			const bool pnBos = (idx - nn.prev) == 0;
 			const uint32_t pnEndStr = pnBos ? 0 : (uint32_t)L.nsToPos[pn.endPos - 1] + 1;
@@ -544,9 +575,10 @@ namespace kamd
 				mforms[k] = fi; mfrec[k] = make_uint2(f.charOff, (uint32_t)f.len | ((uint32_t)f.numSpaces << 8) | ((uint32_t)f.flags << 16));
 			}
 		}
-		LatticeCtx L;
+		LatticeCtxT<BuildNode16> L;
 		L.M = &M; L.P = &P; L.str = str; L.nsToPos = nsToPos; L.posToNs = posToNs;
-		L.out = reinterpret_cast<DevNode*>(lSmem + lay.out); L.endPosMap = reinterpret_cast<uint32_t*>(lSmem + lay.endPosMap);
+		L.spaceErr = lSmem + lay.spaceErr;
+		L.out = reinterpret_cast<BuildNode16*>(lSmem + lay.out); L.endPosMap = reinterpret_cast<uint32_t*>(lSmem + lay.endPosMap);
 		L.fullMask = reinterpret_cast<uint64_t*>(lSmem + lay.fullMask); L.zAt = lSmem + lay.zAt; L.nOut = 0; L.cap = latticeLdsCap(n, cap); L.overflow = false;
 		const uint32_t ldsCap = L.cap;
 		for (uint32_t i = lane; i < nMap; i += 64) { L.endPosMap[i] = 0; L.fullMask[i] = 0; L.zAt[i] = 0; }    // first == second : empty
@@ -556,8 +588,8 @@ namespace kamd
 		if (lane == 0)
 		{
 			L.endPosMap[0] = 0 | (1u << 16);
-			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
-			L.out[0] = bos; L.nOut = 1;
+			BuildNode16 bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0;
+			L.out[0] = bos; L.spaceErr[0] = 0; L.nOut = 1;
 			latticeSerialBuild(M, B, P, L, Q, chunk, n, nNs, nMap);
 			if (L.overflow || L.nOut + 1 >= ldsCap) err = ldsCap < cap ? 0xFFFFu : (uint32_t)CS_ERR_NODE_OVERFLOW;   // 0xFFFF: outgrew the LDS copy only
 			else { G = L.nOut; nConn = latticeConnect(L, Q, ldsCap, nNs); }
@@ -612,6 +644,7 @@ namespace kamd
 		const uint16_t* str = B.chars + cOff;
 		const uint8_t* cls = B.cls + cOff;
 		LatticeCtx L;
+		L.spaceErr = nullptr;
 		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk;
 		L.out = W.tmpNodes + nBase; L.endPosMap = W.endPosMap + cOff + chunk; L.fullMask = W.fullMask + cOff + chunk; L.zAt = W.zAt + cOff + chunk; L.nOut = 0; L.cap = cap; L.overflow = false;
 		const uint32_t nMap = nNs + 1;
