@@ -1263,11 +1263,9 @@ namespace kamd
 		const CandStatic* unkPacks = reinterpret_cast<const CandStatic*>(M.unkPacks);
 		const CandStatic* packs = W.packs + W.packBase[chunk];
 		uint32_t cumLive = 1;    // live paths of nodes 0..i-1 (group-uniform)
-		DevNode nextNode = getNode<G>(X, Gn > 2 ? 1 : 0);
 		for (uint32_t i = 1; i + 1 < Gn; ++i)
 		{
-			const DevNode node = nextNode;
-			if (i + 2 < Gn) nextNode = getNode<G>(X, i + 1);      // prefetch: in flight while this node is processed
+			const DevNode node = getNode<G>(X, i);      // (prefetching it one node ahead cost 8 VGPRs and was slower at every batch size)
 			NodeEnv E;
 			const uint32_t firstPrev = i - node.prev, lastPrev = firstPrev + node.nPrev - 1;
 			if (i - firstPrev + 1 < RING)
