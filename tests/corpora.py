@@ -2,6 +2,7 @@
 multi-sentence texts, emoji, surrogates, empty / whitespace-only inputs)."""
 
 EDGE_TEXTS = [
+    "가나다\x00", "abc\x00def 가\x00",      # U+0000 inside a text (the reference's own C test hands the terminator over as part of each line)
     "",
     " ",
     "   \n\t ",

@@ -162,6 +162,27 @@ def test_analyze_many_delivers_in_input_order(capi, kiwi, oracle, small_model):
         capi.kiwi_res_close(r)
         return 0
 
+    # the reference's own C test (test/test_c.cpp:48-55) counts and copies the terminator as part of each line
+    with_nul = []
+
+    def reader_nul(i, buf, ud):
+        if i >= 50:
+            return 0
+        if not buf:
+            return len(enc[i]) + 1
+        C.memmove(buf, enc[i] + b"\0", len(enc[i]) + 1)
+        return 0
+
+    def receiver_nul(i, r, ud):
+        with_nul.append(read_result(capi, kiwi, r))
+        capi.kiwi_res_close(r)
+        return 0
+
+    assert capi.kiwi_analyze_m(kiwi, READER(reader_nul), RECEIVER(receiver_nul), None, 1, opt()) == 50
+    for y, s in zip(with_nul, texts):
+        want = [([(t[0].split("\0")[0],) + t[1:] for t in a[0]], a[1]) for a in from_oracle(oracle.analyze(s + "\0"))]   # C strings end at the NUL
+        assert y == want, s
+
     capi.kiwi_set_option(kiwi, 0x9001, 128)   # KIWI_GPU_BATCH_SIZE: several device batches
     assert capi.kiwi_get_option(kiwi, 0x9001) == 128
     n = capi.kiwi_analyze_m(kiwi, READER(reader), RECEIVER(receiver), None, 1, opt())
