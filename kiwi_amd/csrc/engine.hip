@@ -135,6 +135,9 @@ namespace kamd
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter;
+		// the engine owns ONE pair of streams, one work counter and one scratch arena: device work of concurrent callers (the C API
+		// is callable from many threads, reference capi threading contract) is serialised per engine; host preparation is not
+		std::recursive_mutex deviceMu;
 
 		template<class T> const T* up(const std::vector<T>& v)
 		{
@@ -602,12 +605,17 @@ namespace kamd
 			}
 		}
 		tm.lap("text preparation");
+		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		layoutAndUpload(*impl, *b, makeParams(config, match));
 		tm.lap("layout + device buffers + upload");
 		return b;
 	}
 
-	KernelTimes Engine::run(StagedBatch& b) { return launchAll(*impl, b, makeParams(config, b.match, b.topN)); }
+	KernelTimes Engine::run(StagedBatch& b)
+	{
+		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		return launchAll(*impl, b, makeParams(config, b.match, b.topN));
+	}
 	size_t Engine::stagedChunks(const StagedBatch& b) { return b.refs.size(); }
 	uint64_t Engine::stagedUnits(const StagedBatch& b) { return b.units; }
 	uint64_t Engine::stagedDeviceBytes(const StagedBatch& b) { return b.devBytes; }
@@ -648,6 +656,7 @@ namespace kamd
 	std::vector<std::vector<TokenResult>> Engine::fetch(StagedBatch& b, size_t topN)
 	{
 		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
+		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		if (!b.ran || b.topN != (uint32_t)topN) { b.topN = (uint32_t)topN; run(b); }
 		HostTimer tm{ "fetch" };
 		download(*impl, b);
@@ -709,6 +718,7 @@ namespace kamd
 	std::vector<uint8_t> Engine::dumpLattices(const char16_t* text, size_t n, uint64_t match)
 	{
 		std::vector<std::pair<const char16_t*, size_t>> texts{ { text, n } };
+		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		auto b = stage(texts, match, false, 1);
 		run(*b);
 		const size_t nC = b->refs.size();

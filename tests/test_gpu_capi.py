@@ -192,6 +192,35 @@ def test_analyze_many_delivers_in_input_order(capi, kiwi, oracle, small_model):
         assert y == from_oracle(oracle.analyze(s)), s
 
 
+def test_concurrent_callers_on_one_handle(capi, kiwi, oracle, small_model):
+    """kiwi_analyze* is callable from many threads on one handle (reference capi threading contract): device work is
+    serialised per engine, results are unaffected."""
+    import threading
+    sm, _ = small_model
+    texts = synthetic(sm, 160, 181, min_jamo=5, max_jamo=80)
+    want = [from_oracle(oracle.analyze(s)) for s in texts]
+    got = [None] * len(texts)
+    errs = []
+
+    def work(t):
+        try:
+            for i in range(t, len(texts), 8):
+                r = capi.kiwi_analyze(kiwi, texts[i].encode("utf-8"), 1, opt(), None)
+                assert r, capi.kiwi_error()
+                got[i] = read_result(capi, kiwi, r)
+                capi.kiwi_res_close(r)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert got == want
+
+
 def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
     cfg = capi.kiwi_get_global_config(kiwi)
     assert cfg.cut_off_threshold == 8.0 and cfg.space_penalty == 7.0
