@@ -152,6 +152,8 @@ namespace kamd
 	Engine::Engine(const std::string& path, int device) : impl(new Impl)
 	{
 		bakeModel(impl->model, path);
+		if (!impl->model.sbgPtrs.empty())
+			throw std::runtime_error{ "kiwi_amd: this raw model carries SkipBigram tables; SkipBigram scoring is not built on the device path yet (Knlm models only)" };
 		int nDev = 0;
 		if (hipGetDeviceCount(&nDev) != hipSuccess || nDev == 0)
 			throw std::runtime_error{ "kiwi_amd: no HIP device visible -- the analyze path has no CPU fallback" };

@@ -6,6 +6,7 @@
 // The same POD views (DeviceModel) are used by the HIP kernels and, with host pointers, by host code.
 #pragma once
 #include <cstdint>
+#include <cmath>
 #include <string>
 #include <vector>
 #include "kchars.hpp"
@@ -143,6 +144,20 @@ namespace kamd
 		const void* unkPacks;         // device only: CandStatic[2] for the unknown-noun candidates NNG, NNP (PathEvaluator.hpp:1204-1206)
 	};
 
+	// SkipBigram tables (reference src/SkipBigramModel.hpp:40-105), kept apart from ModelView: only the CPU restatement uses
+	// them so far (the device scoring of this model type is a later row).
+	struct SbgView
+	{
+		uint32_t vocabSize = 0, windowSize = 0;
+		const uint32_t* ptrs = nullptr;        // [vocab + 1] into keys / comps
+		const uint32_t* keys = nullptr;        // history word ids, sorted per `next` word
+		const float* comps = nullptr;          // compensation per key
+		const float* discnts = nullptr;        // [vocab]
+		const uint8_t* valid = nullptr;        // [vocab]
+		float logWindowSize = 0;
+		bool present() const { return vocabSize != 0; }
+	};
+
 	// Host-side owner.
 	struct FlatModel
 	{
@@ -168,6 +183,17 @@ namespace kamd
 		std::vector<LmSlot> lmHash; uint32_t lmHashMask = 0;
 		std::vector<LmRootRec> lmRoot2;
 		std::vector<LmBackoff> lmBackoff;
+		std::vector<uint32_t> sbgPtrs, sbgKeys; std::vector<float> sbgComps, sbgDiscnts; std::vector<uint8_t> sbgValid; uint32_t sbgWindow = 0;
+
+		SbgView sbgView() const
+		{
+			SbgView v;
+			if (sbgPtrs.empty()) return v;
+			v.vocabSize = (uint32_t)sbgDiscnts.size(); v.windowSize = sbgWindow;
+			v.ptrs = sbgPtrs.data(); v.keys = sbgKeys.data(); v.comps = sbgComps.data(); v.discnts = sbgDiscnts.data(); v.valid = sbgValid.data();
+			v.logWindowSize = std::log((float)sbgWindow);
+			return v;
+		}
 
 		ModelView view() const
 		{

@@ -563,6 +563,29 @@ namespace kamd
 		m.h.maxFormLen = maxLen;
 		if (maxLen > 64) throw std::runtime_error{ "dictionary form longer than 64 units: the trie-scan kernel's depth mask is 64 bits" };
 		loadKnlm(m, raw.knlm, raw.knlmSize);
+		if (raw.sbg)
+		{
+			// SkipBigramModel blob, uncompressed + unquantised (reference src/SkipBigramModel.hpp:40-105): header{u64 vocabSize; u8 keySize,
+			// windowSize, compressed, quantize; u8 rsv[4]} | kSizes[vocab] | keyData[total] | discnts[vocab] f32 | compensations[total] f32 | validness[vocab]
+			const uint8_t* p = raw.sbg;
+			uint64_t vocab; std::memcpy(&vocab, p, 8);
+			const uint8_t keySize = p[8], window = p[9], compressed = p[10], quantize = p[11];
+			if (compressed || quantize || (keySize != 2 && keySize != 4) || window != 8) throw std::runtime_error{ "raw model: unsupported SkipBigram layout" };
+			p += 16;
+			auto key = [&](const uint8_t* q, size_t i) -> uint32_t { if (keySize == 2) { uint16_t v; std::memcpy(&v, q + 2 * i, 2); return v; } uint32_t v; std::memcpy(&v, q + 4 * i, 4); return v; };
+			m.sbgPtrs.assign(vocab + 1, 0);
+			for (size_t i = 0; i < vocab; ++i) m.sbgPtrs[i + 1] = m.sbgPtrs[i] + key(p, i);
+			const size_t total = m.sbgPtrs[vocab];
+			p += vocab * keySize;
+			m.sbgKeys.resize(total);
+			for (size_t i = 0; i < total; ++i) m.sbgKeys[i] = key(p, i);
+			p += total * keySize;
+			m.sbgDiscnts.resize(vocab); std::memcpy(m.sbgDiscnts.data(), p, vocab * 4); p += vocab * 4;
+			m.sbgComps.resize(total); if (total) std::memcpy(m.sbgComps.data(), p, total * 4); p += total * 4;
+			m.sbgValid.assign(p, p + vocab); p += vocab;
+			if ((size_t)(p - raw.sbg) > raw.sbgSize) throw std::runtime_error{ "raw model: truncated SkipBigram blob" };
+			m.sbgWindow = window;
+		}
 		if (vocab > m.lmRoot.size()) throw std::runtime_error{ "raw model: vocab larger than LM vocab" };
 	}
 

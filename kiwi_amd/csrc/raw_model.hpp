@@ -34,6 +34,8 @@ namespace kamd
 		const uint8_t* chunkPos = nullptr;
 		const uint8_t* knlm = nullptr;
 		size_t knlmSize = 0;
+		const uint8_t* sbg = nullptr;   // optional SkipBigram blob (reference skipbigram.mdl layout)
+		size_t sbgSize = 0;
 
 		size_t nForms() const { return meta[0]; }
 		size_t nMorphs() const { return meta[1]; }
@@ -57,6 +59,7 @@ namespace kamd
 			chunkPos = c.ptr<uint8_t>("chunk_pos");
 			auto s = c.get("knlm");
 			knlm = s.data; knlmSize = s.size;
+			if (c.has("sbg")) { auto g = c.get("sbg"); sbg = g.data; sbgSize = g.size; }
 		}
 	};
 }

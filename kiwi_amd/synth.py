@@ -125,6 +125,7 @@ class RawModel:
         self.morphs: list[Morph] = []
         self.vocab_size = 0
         self.knlm: bytes = b""
+        self.sbg: bytes = b""          # optional: SkipBigramModel blob
         self._init_defaults()
 
     # KiwiBuilder::initMorphemes (KiwiBuilder.cpp:1108-1131)
@@ -207,6 +208,7 @@ class RawModel:
             "chunk_ids": np.array(chunk_ids, "<u4"),
             "chunk_pos": np.array(chunk_pos, "u1"),
             "knlm": np.frombuffer(self.knlm, "u1"),
+            **({"sbg": np.frombuffer(self.sbg, "u1")} if self.sbg else {}),
         }
 
     def save(self, path: str):
@@ -293,12 +295,14 @@ class SynthSpec:
     lm_sentences: int = 20000
     lm_order: int = 3
     use_htx: bool = False
+    use_sbg: bool = False        # also emit a SkipBigram model (reference skipbigram.mdl layout) over the same vocabulary
     seed: int = SEED_BASE
 
 
 FULL_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
                       n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3)  # order 3: build_knlm packs an n-gram into 63 bits
 SMALL_SPEC = SynthSpec()
+SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
 
 
 class SynthModel:
@@ -658,6 +662,8 @@ class SynthModel:
         if sp.use_htx:
             htx = np.array([(raw.morphs[i].tag & 0x7F) + vocab for i in range(vocab)], dtype=np.int64)
         raw.knlm = build_knlm(sents, vocab, sp.lm_order, htx=htx)
+        if sp.use_sbg:
+            raw.sbg = build_sbg(sents, vocab, key_size=2 if vocab + 1 <= 0xFFFF else 4, seed=sp.seed + 2)
 
     # -- text corpus -------------------------------------------------------------------------
     def make_corpus(self, n, seed, min_jamo=5, max_jamo=200, exact_jamo=None, oov_rate=0.03):
@@ -877,3 +883,54 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
     if htx_arr is not None:
         buf[htx_off:htx_off + htx_arr.nbytes] = htx_arr.tobytes()
     return bytes(buf)
+
+
+def build_sbg(sents, vocab_size, key_size=2, window=8, max_keys_per_word=48, seed=0) -> bytes:
+    """Skip-bigram tables in the reference's uncompressed, unquantised ``skipbigram.mdl`` layout (reader:
+    /root/reference/src/SkipBigramModel.hpp:40-105; header: include/kiwi/SkipBigramModel.h:9-13):
+    header | kSizes[vocab] | keyData[total] (sorted per word) | discnts[vocab] f32 | compensations[total] f32 | validness[vocab] u8.
+    For a word ``next``, keyData holds the history words h (within the window) it was seen after, compensations the
+    log-likelihood-like value the reference substitutes for that pair, discnts[h] the discount added to the Knlm score."""
+    rng = np.random.default_rng(seed)
+    flat = np.concatenate([np.asarray(s, dtype=np.int64) for s in sents])
+    lens = np.array([len(s) for s in sents], dtype=np.int64)
+    sid = np.repeat(np.arange(len(sents)), lens)
+    pairs = []
+    for d in range(1, window + 1):
+        ok = sid[d:] == sid[:-d]
+        h, w = flat[:-d][ok], flat[d:][ok]
+        pairs.append(h * (vocab_size + 1) + w)
+    code, cnt = np.unique(np.concatenate(pairs), return_counts=True)
+    h_all, w_all = code // (vocab_size + 1), code % (vocab_size + 1)
+    keep = (h_all > 2) & (w_all > 2) & (cnt >= 2)          # no bos/eos/unk rows
+    h_all, w_all, cnt = h_all[keep], w_all[keep], cnt[keep].astype(np.float64)
+    uni = np.bincount(flat, minlength=vocab_size).astype(np.float64) + 1.0
+    order = np.lexsort((h_all, w_all))
+    h_all, w_all, cnt = h_all[order], w_all[order], cnt[order]
+    k_sizes = np.zeros(vocab_size, np.int64)
+    keys, comps = [], []
+    starts = np.searchsorted(w_all, np.arange(vocab_size + 1))
+    for w in range(vocab_size):
+        a, b = starts[w], starts[w + 1]
+        if a == b:
+            continue
+        hs, cs = h_all[a:b], cnt[a:b]
+        if len(hs) > max_keys_per_word:
+            top = np.sort(np.argsort(-cs, kind="stable")[:max_keys_per_word])
+            hs, cs = hs[top], cs[top]
+        k_sizes[w] = len(hs)
+        keys.append(hs)
+        # log P(w | h within the window), clipped to the range the reference's gate (ll > -13) lets through
+        comps.append(np.clip(np.log(cs / (uni[hs] * window)), -12.5, -0.05))
+    key_arr = np.concatenate(keys) if keys else np.zeros(0, np.int64)
+    cmp_arr = np.concatenate(comps) if comps else np.zeros(0, np.float64)
+    valid = (k_sizes > 0).astype(np.uint8)
+    # a few words are valid without any pair (the discount still applies to them as history), a few frequent ones invalid
+    extra = rng.random(vocab_size) < 0.05
+    valid[(k_sizes == 0) & extra & (np.arange(vocab_size) > 2)] = 1
+    discnts = np.where(valid > 0, -np.abs(rng.normal(0.7, 0.3, vocab_size)) - 0.05, 0.0)
+    kdt = "<u2" if key_size == 2 else "<u4"
+    assert k_sizes.max(initial=0) < (1 << (8 * key_size))
+    head = struct.pack("<Q8B", vocab_size, key_size, window, 0, 0, 0, 0, 0, 0)
+    return head + k_sizes.astype(kdt).tobytes() + key_arr.astype(kdt).tobytes() + discnts.astype("<f4").tobytes() \
+        + cmp_arr.astype("<f4").tobytes() + valid.tobytes()

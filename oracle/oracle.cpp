@@ -17,6 +17,7 @@ struct OracleHandle
 {
 	FlatModel model;
 	ModelView view;
+	SbgView sbg;          // present when the raw model carries SkipBigram tables
 	SplitConfig scfg{ 0, 6, 0xFFFFFFFFu, 0 };
 	BestPathConfig bcfg;
 	bool integrateAllomorph = true;
@@ -57,7 +58,7 @@ namespace
 			if (!ok) continue;
 			BestPathConfig bc2 = bc;
 			bc2.openEnding = openEnding && ch.nextOffset == pt.norm.size();
-			BestPathSearch bp{ h.view, bc2, cnt };
+			BestPathSearch bp{ h.view, bc2, cnt, h.sbg };
 			bp.run(paths, pt.norm, pt.cls, nodes.data(), (uint32_t)nodes.size(), rb.spStates());
 			rb.insertPaths(paths);
 		}
@@ -74,6 +75,7 @@ extern "C"
 			auto h = std::make_unique<OracleHandle>();
 			bakeModel(h->model, rawModelPath);
 			h->view = h->model.view();
+			h->sbg = h->model.sbgView();
 			return h.release();
 		}
 		catch (const std::exception& e) { fprintf(stderr, "korc_open: %s\n", e.what()); return nullptr; }
@@ -107,6 +109,18 @@ extern "C"
 		BestPathConfig bc; Counters c;
 		BestPathSearch bp{ h.view, bc, c };
 		return bp.lmProgress(*node, wid);
+	}
+
+	// One LM step of the model's state type (Knlm, or SkipBigram on top of it): node, ring position and 8 history words in / out
+	float korc_lm_next(void* hp, int32_t* node, uint32_t* pos, uint32_t* hist8, uint32_t wid)
+	{
+		auto& h = *(OracleHandle*)hp;
+		BestPathConfig bc; Counters c;
+		BestPathSearch bp{ h.view, bc, c, h.sbg };
+		WPath st; st.lmNode = *node; st.histPos = (uint8_t)*pos; for (int i = 0; i < 8; ++i) st.hist[i] = hist8[i];
+		const float ll = bp.lmNext(st, wid);
+		*node = st.lmNode; *pos = st.histPos; for (int i = 0; i < 8; ++i) hist8[i] = st.hist[i];
+		return ll;
 	}
 
 	// same layout as kref_split (oracle/ref_bridge.cpp)

@@ -31,6 +31,8 @@ class OracleKiwi:
         L.korc_set_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.korc_dump_dict.restype = C.c_size_t
         L.korc_set_container_limits.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.korc_lm_next.restype = C.c_float
+        L.korc_lm_next.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32]
         L.korc_dump_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.korc_lm_progress.restype = C.c_float
         L.korc_lm_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32]
@@ -87,6 +89,12 @@ class OracleKiwi:
         n = C.c_int32(node)
         ll = self.lib.korc_lm_progress(self.h, C.byref(n), wid)
         return float(ll), int(n.value)
+
+    def lm_next(self, node: int, pos: int, hist, wid: int):
+        """One step of the model's LM state type (Knlm, or SkipBigram on top of it) -> (ll, node, pos, hist[8])."""
+        n = C.c_int32(node); p = C.c_uint32(pos); h = np.array(hist, np.uint32)
+        ll = self.lib.korc_lm_next(self.h, C.byref(n), C.byref(p), h.ctypes.data, wid)
+        return float(ll), int(n.value), int(p.value), [int(x) for x in h]
 
     def dump_dict(self) -> bytes:
         return bytes(self._call(lambda *a: self.lib.korc_dump_dict(self.h, *a)))

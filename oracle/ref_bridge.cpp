@@ -25,6 +25,8 @@
 #include <kiwi/Utils.h>
 #include <kiwi/Form.h>
 #include <kiwi/Knlm.h>
+#include <kiwi/SkipBigramModel.h>
+#include "SkipBigramModel.hpp"
 #include <kiwi/Dataset.h>
 #include "ArchAvailable.h"
 #include "KTrie.h"
@@ -132,7 +134,15 @@ namespace kiwi
 
 			utils::MemoryOwner mem{ raw.knlmSize };
 			std::memcpy(mem.get(), raw.knlm, raw.knlmSize);
-			std::shared_ptr<lm::ILangModel> langMdl = lm::KnLangModelBase::create(utils::MemoryObject{ std::move(mem) }, arch);
+			std::shared_ptr<lm::ILangModel> langMdl;
+			if (raw.sbg)
+			{
+				// SkipBigram on top of the same Knlm (KiwiBuilder.cpp: ModelType::sbg): SkipBigramModelBase::create (src/SkipBigramModel.cpp:99)
+				utils::MemoryOwner smem{ raw.sbgSize };
+				std::memcpy(smem.get(), raw.sbg, raw.sbgSize);
+				langMdl = lm::SkipBigramModelBase::create(utils::MemoryObject{ std::move(mem) }, utils::MemoryObject{ std::move(smem) }, arch);
+			}
+			else langMdl = lm::KnLangModelBase::create(utils::MemoryObject{ std::move(mem) }, arch);
 
 			// --- from here on: KiwiBuilder::build() with typos.empty() and no rule-combined morphemes ---
 			Kiwi ret{ arch, langMdl, false, false, false };
@@ -343,6 +353,19 @@ extern "C"
 		ptrdiff_t n = *node;
 		float ll = lm->progress(n, wid);
 		*node = (int32_t)n;
+		return ll;
+	}
+
+	// One SkipBigram state step through the reference (SbgState::nextImpl, src/SkipBigramModel.hpp:169-182); 16-bit vocabulary only.
+	float kref_sbg_next(void* hp, int32_t* node, uint32_t* pos, uint32_t* hist8, uint32_t wid)
+	{
+		using Model = kiwi::lm::SkipBigramModel<kiwi::ArchType::none, uint16_t, 8>;
+		auto* lm = dynamic_cast<const Model*>(Acc::lm(((RefHandle*)hp)->kw));
+		if (!lm) return NAN;
+		typename Model::LmStateType st{ lm };
+		st.knlm.node = *node; st.historyPos = *pos; for (int i = 0; i < 8; ++i) st.history[i] = (uint16_t)hist8[i];
+		const float ll = st.next(lm, (uint16_t)wid);
+		*node = (int32_t)st.knlm.node; *pos = (uint32_t)st.historyPos; for (int i = 0; i < 8; ++i) hist8[i] = st.history[i];
 		return ll;
 	}
 

@@ -83,6 +83,8 @@ class RefKiwi:
         L.kref_set_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.kref_dump_dict.restype = C.c_size_t
         L.kref_dump_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.kref_sbg_next.restype = C.c_float
+        L.kref_sbg_next.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32]
         L.kref_lm_progress.restype = C.c_float
         L.kref_lm_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_uint32]
         L.kref_split.restype = C.c_size_t
@@ -131,6 +133,12 @@ class RefKiwi:
         n = C.c_int32(node)
         ll = self.lib.kref_lm_progress(self.h, C.byref(n), wid)
         return float(ll), int(n.value)
+
+    def sbg_next(self, node: int, pos: int, hist, wid: int):
+        """One SbgState::next step through the reference (16-bit vocabularies) -> (ll, node, pos, hist[8]); ll is NaN for non-SBG models."""
+        n = C.c_int32(node); p = C.c_uint32(pos); h = np.array(hist, np.uint32)
+        ll = self.lib.kref_sbg_next(self.h, C.byref(n), C.byref(p), h.ctypes.data, wid)
+        return float(ll), int(n.value), int(p.value), [int(x) for x in h]
 
     def dump_dict(self) -> bytes:
         return bytes(self._call(lambda *a: self.lib.kref_dump_dict(self.h, *a)))

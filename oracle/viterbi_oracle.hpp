@@ -40,6 +40,8 @@ namespace korc
 	struct WPath   // WordLL<KnLMState> (BestPathContainer.hpp:21-67)
 	{
 		int32_t lmNode = 0;
+		// SkipBigram state on top of the Knlm node (SbgState, SkipBigramModel.hpp:141-182): ring of the last 8 valid word ids
+		uint32_t hist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; uint8_t histPos = 0;
 		uint8_t prevRootId = 0, spState = 0, rootId = 0;
 		uint32_t morph = 0;
 		float accScore = 0, firstChunkScore = 0, accTypoCost = 0;
@@ -52,6 +54,7 @@ namespace korc
 	class BestPathSearch
 	{
 		const ModelView& M;
+		SbgView S;                       // absent (vocabSize == 0): plain Knlm scoring
 		const BestPathConfig& cfg;
 		Counters& cnt;
 		const U16* norm = nullptr;   // normalised text
@@ -107,6 +110,52 @@ namespace korc
 				node = 0;
 				return acc + asFloat(v);
 			}
+		}
+
+		// LmState::next: Knlm alone, or SbgState::nextImpl (SkipBigramModel.hpp:169-182) + SkipBigramModel::evaluate (:113-139) with
+		// the scalar logSumExp of MathFunc.hpp:43-56 (ArchType::none / balanced): same operations, same order, fp32
+		float lmNext(WPath& st, uint32_t next)
+		{
+			float ll = lmProgress(st.lmNode, next);
+			if (!S.present()) return ll;
+			if (next < S.vocabSize && S.valid[next])
+			{
+				if (ll > -13)
+				{
+					float arr[16];
+					for (int i = 0; i < 8; ++i) { arr[i] = ll; arr[8 + i] = -INFINITY; }
+					const uint32_t* kb = S.keys + S.ptrs[next]; const uint32_t* ke = S.keys + S.ptrs[next + 1];
+					for (int i = 0; i < 8; ++i)
+					{
+						arr[i] = S.discnts[st.hist[i]] + ll;
+						const uint32_t* it = std::lower_bound(kb, ke, st.hist[i]);
+						if (it != ke && *it == st.hist[i]) arr[8 + i] = S.comps[S.ptrs[next] + (it - kb)];
+					}
+					const float mx = *std::max_element(arr, arr + 16);
+					float sum = 0;
+					for (int i = 0; i < 16; ++i) sum += std::exp(arr[i] - mx);
+					ll = (std::log(sum) + mx) - S.logWindowSize;
+				}
+				st.hist[st.histPos] = next;
+				st.histPos = (uint8_t)((st.histPos + 1) % 8);
+			}
+			return ll;
+		}
+		static bool sameLm(const WPath& a, const WPath& b)   // LmState::operator== (Knlm node; + history ring and position for SBG)
+		{
+			if (a.lmNode != b.lmNode || a.histPos != b.histPos) return false;
+			for (int i = 0; i < 8; ++i) if (a.hist[i] != b.hist[i]) return false;
+			return true;
+		}
+		// PathHash equality of the top-N container (BestPathContainer.hpp:89-111; SBG: SkipBigramModel.cpp:8-35 compares the Knlm
+		// state and the LAST FOUR history words only)
+		bool sameTopNKey(const WPath& a, const WPath& b) const
+		{
+			if (a.prevRootId != b.prevRootId && !S.present()) return false;    // the SBG PathHash::operator== does not compare rootId
+			if (a.spState != b.spState || a.lmNode != b.lmNode) return false;
+			if (!S.present()) return true;
+			for (int i = 0; i < 4; ++i) if (a.hist[(a.histPos + 8 + i - 4) % 8] != b.hist[(b.histPos + 8 + i - 4) % 8]) return false;
+			return true;
 		}
 
 	private:
@@ -180,7 +229,7 @@ namespace korc
 				// scores; only the hand-on order among the kept paths -- i.e. tie-breaking further down -- can differ.
 				for (auto& t : lset)
 				{
-					if (t.prevRootId == np.prevRootId && t.spState == np.spState && t.lmNode == np.lmNode)
+					if (t.prevRootId == np.prevRootId && t.spState == np.spState && sameLm(t, np))
 					{
 						if (np.accScore > t.accScore) t = np;
 						return;
@@ -189,11 +238,19 @@ namespace korc
 				lset.push_back(np);
 				return;
 			}
-			const size_t h = keyHash(Key{ np.lmNode, np.prevRootId, np.spState });
+			size_t h;
+			if (!S.present()) h = keyHash(Key{ np.lmNode, np.prevRootId, np.spState });
+			else
+			{
+				// Hash<SbgState> (SkipBigramModel.hpp:187-201): Knlm hash folded with the 8 history words, then Hash<WordLL>'s mix
+				size_t r = (size_t)(int64_t)np.lmNode;
+				for (int i = 0; i < 8; ++i) r = (size_t)np.hist[i] ^ ((r << 3) | (r >> 61));
+				h = ((uint16_t)np.prevRootId | ((uint16_t)np.spState << 8)) ^ ((r << 3) | (r >> 61));
+			}
 			auto& b = bucket[mode == 1 ? ((h >> 8) & 3) : 0];
 			for (auto& t : b)
 			{
-				if (t.prevRootId == np.prevRootId && t.spState == np.spState && t.lmNode == np.lmNode)
+				if (t.prevRootId == np.prevRootId && t.spState == np.spState && sameLm(t, np))
 				{
 					if (np.accScore > t.accScore) { const uint8_t pr = t.prevRootId; t = np; t.prevRootId = pr; }
 					return;
@@ -213,7 +270,7 @@ namespace korc
 					for (size_t j = 0; j < titems.size(); ++j)
 					{
 						const WPath& b = titems[j];
-						if (j == i || b.prevRootId != a.prevRootId || b.spState != a.spState || b.lmNode != a.lmNode) continue;
+						if (j == i || !sameTopNKey(a, b)) continue;
 						if (b.accScore > a.accScore || (b.accScore == a.accScore && j < i)) ++rank;
 					}
 					if (rank < cfg.topN) fn(a);
@@ -284,12 +341,12 @@ namespace korc
 						else if (ignoreCondScore != 0) cand += featTest(feat, cm.vowel, cm.polar) ? 0 : ignoreCondScore;
 						else if (!featTest(feat, cm.vowel, cm.polar)) continue;
 					}
-					int32_t lmNode = pp.lmNode;
+					WPath lmSt = pp;               // the LM part (Knlm node [+ SkipBigram history]) advances on a copy of the incoming path
 					if (cm.socket && single) {}
 					else
 					{
 						if (M.morphs[firstWid].tag == T_P) continue;
-						float ll = lmProgress(lmNode, firstWid);
+						float ll = lmNext(lmSt, firstWid);
 						cand += ll; firstChunk += ll;
 						if (!single)
 						{
@@ -298,7 +355,7 @@ namespace korc
 							{
 								const uint32_t wid = M.chunkLm[cm.chunkOff + c];
 								if (M.morphs[wid].tag == T_P) { bad = true; break; }
-								ll = lmProgress(lmNode, wid);
+								ll = lmNext(lmSt, wid);
 								cand += ll;
 							}
 							if (bad) continue;
@@ -317,7 +374,8 @@ namespace korc
 						np.morph = morphId; np.accScore = (cand + rs) - 0.f; np.firstChunkScore = (firstChunk + rs) - 0.f;
 						np.accTypoCost = pp.accTypoCost + node->typoCost;
 						np.parentNode = (int32_t)(prev - graph); np.parentIdx = (int32_t)pi;
-						np.lmNode = lmNode; np.spState = sp;
+						np.lmNode = lmSt.lmNode; np.histPos = lmSt.histPos; for (int hi = 0; hi < 8; ++hi) np.hist[hi] = lmSt.hist[hi];
+						np.spState = sp;
 						np.rootId = pp.rootId; np.prevRootId = pp.rootId;
 						if (rootId != COMMON_ROOT) np.rootId = rootId;
 						contInsert(mode, np);
@@ -502,7 +560,7 @@ namespace korc
 		}
 
 	public:
-		BestPathSearch(const ModelView& m, const BestPathConfig& c, Counters& k) : M(m), cfg(c), cnt(k)
+		BestPathSearch(const ModelView& m, const BestPathConfig& c, Counters& k, const SbgView& sbg = SbgView{}) : M(m), S(sbg), cfg(c), cnt(k)
 		{
 			// TagSequenceScorer (src/TagUtils.cpp:49-62), weight 5
 			for (auto& v : leftBoundary) v = 0;
@@ -583,16 +641,16 @@ namespace korc
 					if (!(pm.flags & MF_SINGLE) && pm.nChunks <= (pm.socket ? 2u : 1u) && !matchVowel(nullptr, 0, pm.vowel)) continue;
 					if (pm.tag == T_Z_SIOT) continue;
 					float c = p.accScore, first = 0;
-					int32_t lmNode = p.lmNode;
+					WPath lmSt = p;
 					if (!cfg.openEnding)
 					{
-						c += (first = lmProgress(lmNode, 1));
+						c += (first = lmNext(lmSt, 1));
 						if (p.spState & 1) c -= 2;
 						if (p.spState & 2) c -= 2;
 					}
 					WPath np;
 					np.accScore = c; np.firstChunkScore = first; np.accTypoCost = p.accTypoCost;
-					np.parentNode = (int32_t)(prev - g); np.parentIdx = (int32_t)pi; np.lmNode = lmNode;
+					np.parentNode = (int32_t)(prev - g); np.parentIdx = (int32_t)pi; np.lmNode = lmSt.lmNode;
 					if (p.rootId == COMMON_ROOT)
 					{
 						for (size_t r = 0; r < uniqStates.size(); ++r) { np.spState = uniqStates[r]; np.rootId = (uint8_t)r; cand.push_back(np); }

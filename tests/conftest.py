@@ -25,6 +25,18 @@ def small_model(tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def small_sbg_model():
+    """The small synthetic model plus SkipBigram tables (same lexicon and Knlm; kiwi_amd/synth.py SMALL_SBG_SPEC)."""
+    from kiwi_amd.synth import SynthModel, SMALL_SBG_SPEC
+    d = os.path.join(ROOT, "_data")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "small-sbg.raw")
+    sm = SynthModel(SMALL_SBG_SPEC)
+    sm.raw.save(path)
+    return sm, path
+
+
+@pytest.fixture(scope="session")
 def oracle(small_model):
     import subprocess
     import oraclelib

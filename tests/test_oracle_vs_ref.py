@@ -97,3 +97,55 @@ def test_top_n_matches_reference_up_to_exact_ties(oracle, reference, small_model
             shape_diff += 1
     assert exact >= 0.6 * len(texts)
     assert shape_diff <= 0.01 * len(texts)
+
+
+def test_skipbigram_state_step_matches_reference(small_sbg_model):
+    """SbgState::next (Knlm step, validity gate, 8 discounted + 8 compensated terms, scalar logSumExp, history ring) of the
+    restatement against the real reference, bit for bit, over random word sequences."""
+    import struct
+    import oraclelib
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    sm, path = small_sbg_model
+    orc, ref = oraclelib.OracleKiwi(path), refbridge.RefKiwi(path)
+    rng = np.random.default_rng(7)
+    vocab = sm.raw.vocab_size
+    for _ in range(200):
+        so = (0, 0, [0] * 8)
+        sr = (0, 0, [0] * 8)
+        for _ in range(40):
+            w = int(rng.integers(0, vocab)) if rng.random() < 0.7 else int(rng.integers(3, 60))
+            a = orc.lm_next(*so, w)
+            b = ref.sbg_next(*sr, w)
+            assert struct.pack("f", a[0]) == struct.pack("f", b[0]) and a[1:] == b[1:], (so, w, a, b)
+            so, sr = a[1:], b[1:]
+
+
+def test_skipbigram_analyses_match_reference(small_sbg_model):
+    """Whole analyses under the SkipBigram model.  With the history ring in the LM state, nodes of these lattices collect
+    hundreds of distinct paths, i.e. the reference runs its LARGE container (a thread_local std::unordered_set whose iteration
+    order depends on what the thread analysed before) feeding capacity-limited medium containers.  Every text that stays
+    within the small / medium containers must match exactly; texts that use the large one must match in the vast majority."""
+    import oraclelib
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    sm, path = small_sbg_model
+    orc, ref = oraclelib.OracleKiwi(path), refbridge.RefKiwi(path)
+    texts = synthetic(sm, 300, 191, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 150, 192) + [t for t in EDGE_TEXTS if t.strip()]
+    prev = orc.counters()
+    n_large = bad_large = 0
+    for s in texts:
+        x = orc.analyze(s)
+        c = orc.counters()
+        large = c["nodesOver512"] > prev["nodesOver512"]
+        prev = c
+        y = ref.analyze(s)
+        same = [([astuple(t) for t in a[0]], a[1]) for a in x] == [([astuple(t) for t in a[0]], a[1]) for a in y]
+        if large:
+            n_large += 1
+            bad_large += not same
+        else:
+            assert same, s
+    assert bad_large <= max(2, n_large // 20), (bad_large, n_large)
