@@ -63,6 +63,8 @@ const uint16_t* kamd_res_forms(kamd_results_h r);
 void kamd_res_close(kamd_results_h r);
 
 /* test hooks: baked dictionary dump and the lattices of one text, in the byte layouts of oracle/ref_bridge.cpp */
+/* developer probe: exp_out[i] = expf, log_out[i] = logf of x[i] computed ON THE DEVICE by csrc/exact_math.hpp (bit-identical to glibc) */
+int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n);
 size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap);
 size_t kamd_dump_lattices(kamd_engine_h h, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);
 

@@ -18,6 +18,8 @@ struct kamd_results
 	std::vector<uint16_t> forms;
 };
 
+namespace kamd { void exactMathProbe(const float* x, float* e, float* l, uint32_t n); }
+
 namespace
 {
 	thread_local std::string lastError;
@@ -116,6 +118,11 @@ extern "C"
 	const kamd_token_t* kamd_res_tokens(kamd_results_h r, uint32_t t, uint32_t i) { return (r && t < r->toks.size() && i < r->toks[t].size()) ? r->toks[t][i].data() : nullptr; }
 	const uint16_t* kamd_res_forms(kamd_results_h r) { return r ? r->forms.data() : nullptr; }
 	void kamd_res_close(kamd_results_h r) { delete r; }
+
+	int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n)
+	{
+		return guarded([&]() { kamd::exactMathProbe(x, exp_out, log_out, n); return 0; }, -1);
+	}
 
 	size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap)
 	{

@@ -16,6 +16,7 @@
 #include <thread>
 #include "engine.hpp"
 #include "viterbi_kernel.hpp"
+#include "exact_math.hpp"
 
 namespace kamd
 {
@@ -336,6 +337,23 @@ namespace kamd
 		b.subBatches = 0;
 		HIPCHECK(hipStreamSynchronize(s));
 		b.ran = false;
+	}
+
+	// Probe of csrc/exact_math.hpp on the device (tests/test_gpu_exact_math.py): y[i] = expf_glibc(x[i]), z[i] = logf_glibc(x[i])
+	__global__ void k_exact_math_probe(const float* x, float* e, float* l, uint32_t n)
+	{
+		const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+		if (i < n) { e[i] = exact::expf_glibc(x[i]); l[i] = exact::logf_glibc(x[i]); }
+	}
+	void exactMathProbe(const float* x, float* e, float* l, uint32_t n)
+	{
+		DevBuf dx, de, dl;
+		dx.ensure((size_t)n * 4 + 16); de.ensure((size_t)n * 4 + 16); dl.ensure((size_t)n * 4 + 16);
+		HIPCHECK(hipMemcpy(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(k_exact_math_probe, dim3((n + 255) / 256), dim3(256), 0, 0, dx.as<float>(), de.as<float>(), dl.as<float>(), n);
+		HIPCHECK(hipGetLastError());
+		HIPCHECK(hipMemcpy(e, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		HIPCHECK(hipMemcpy(l, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	}
 
 	static SearchParams makeParams(const EngineConfig& c, uint64_t match, uint32_t topN = 1)
