@@ -139,6 +139,9 @@ def main():
                                "alg_bytes_per_sentence": per, "all_kernels_achieved": per["total"] * n / ((kt["scan_ms"] + kt["lattice_ms"] + kt["search_ms"] + kt["finish_ms"]) * 1e-3) / 1e9}
             out["cpu_baseline"] = cb["cpu_baseline"]
         print(json.dumps(out))
+    res.close()
+    batch.close()
+    eng.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -81,9 +81,11 @@ namespace kamd
 				p = nullptr; cap = 0;
 				const size_t want = n + n / 8 + 256;
 				p = devCache().take(want, cap);
-				if (p) return;
-				HIPCHECK(hipMalloc(&p, want));
-				cap = want;
+				if (!p) { HIPCHECK(hipMalloc(&p, want)); cap = want; }
+				// developer aid: KAMD_POISON=1 fills every (re)acquired block with 0xCD, so that a read of memory no kernel has written
+				// yet shows up the same way on every run (fresh and recycled blocks otherwise hold arbitrary bytes)
+				static const bool poison = std::getenv("KAMD_POISON") != nullptr;
+				if (poison) { HIPCHECK(hipMemset(p, 0xCD, cap)); HIPCHECK(hipDeviceSynchronize()); }   // (the engine's streams do not wait for the null stream)
 			}
 			template<class T> T* as() const { return reinterpret_cast<T*>(p); }
 		};
@@ -206,6 +208,8 @@ namespace kamd
 	{
 		if (impl)
 		{
+			(void)hipSetDevice(impl->device);
+			(void)hipDeviceSynchronize();
 			for (auto& e : impl->evs) if (e) (void)hipEventDestroy(e);
 			devCache().trim();
 			if (impl->stream) (void)hipStreamDestroy(impl->stream);

@@ -57,4 +57,6 @@ def reference(small_model):
 @pytest.fixture(scope="session")
 def engine(small_model):
     from kiwi_amd.api import KiwiAmd
-    return KiwiAmd(small_model[1])
+    eng = KiwiAmd(small_model[1])
+    yield eng
+    eng.close()          # release streams / events / device blocks before the interpreter (and the HIP runtime) shut down
