@@ -18,6 +18,7 @@ struct OracleHandle
 	FlatModel model;
 	ModelView view;
 	SbgView sbg;          // present when the raw model carries SkipBigram tables
+	PersistentContainers persistent;   // faithfulOrder: what the reference keeps thread_local (single-threaded entry points only)
 	SplitConfig scfg{ 0, 6, 0xFFFFFFFFu, 0 };
 	BestPathConfig bcfg;
 	bool integrateAllomorph = true;
@@ -33,7 +34,7 @@ namespace
 		void putStr(const U16& s) { put<uint32_t>((uint32_t)s.size()); for (auto c : s) put<uint16_t>(c); }
 	};
 
-	std::vector<TokenResult> analyzeOne(OracleHandle& h, Counters& cnt, const char16_t* text, uint32_t len, uint32_t topN, uint64_t match, bool openEnding,
+	std::vector<TokenResult> analyzeOne(OracleHandle& h, Counters& cnt, PersistentContainers* persistent, const char16_t* text, uint32_t len, uint32_t topN, uint64_t match, bool openEnding,
 		std::vector<std::vector<LNode>>* latticesOut = nullptr)
 	{
 		if (topN < 1 || topN > 4) throw std::runtime_error{ "oracle: top_n must be 1..4" };
@@ -58,7 +59,7 @@ namespace
 			if (!ok) continue;
 			BestPathConfig bc2 = bc;
 			bc2.openEnding = openEnding && ch.nextOffset == pt.norm.size();
-			BestPathSearch bp{ h.view, bc2, cnt, h.sbg };
+			BestPathSearch bp{ h.view, bc2, cnt, h.sbg, persistent };
 			bp.run(paths, pt.norm, pt.cls, nodes.data(), (uint32_t)nodes.size(), rb.spStates());
 			rb.insertPaths(paths);
 		}
@@ -87,6 +88,14 @@ extern "C"
 		auto& h = *(OracleHandle*)hp;
 		h.bcfg.cutOff = cutOff; h.bcfg.spacePenalty = spacePenalty; h.bcfg.typoCostWeight = typoCostWeight;
 		h.scfg.maxUnk = maxUnk; h.scfg.maxUnkJ = maxUnkJ; h.scfg.spaceTol = spaceTol; h.integrateAllomorph = !!integrateAllomorph;
+	}
+
+	// test hook: hand kept paths on in the reference's own (history-dependent) container order instead of insertion order
+	void korc_set_faithful_order(void* hp, int on)
+	{
+		auto& h = *(OracleHandle*)hp;
+		h.bcfg.faithfulOrder = !!on;
+		h.persistent = PersistentContainers{};
 	}
 
 	// test hook: container selection limits (defaults 128, 512, 128)
@@ -181,7 +190,7 @@ extern "C"
 		Writer w{ out, out + cap };
 		try
 		{
-			auto res = analyzeOne(h, h.counters, (const char16_t*)text, len, topN, match, !!openEnding);
+			auto res = analyzeOne(h, h.counters, &h.persistent, (const char16_t*)text, len, topN, match, !!openEnding);
 			writeResults(w, res);
 		}
 		catch (const std::exception& e) { fprintf(stderr, "korc_analyze: %s\n", e.what()); return 0; }
@@ -202,7 +211,7 @@ extern "C"
 			{
 				const uint32_t i = next.fetch_add(1);
 				if (i >= n) break;
-				auto res = analyzeOne(h, cnts[tid], (const char16_t*)texts + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), topN, match, false);
+				auto res = analyzeOne(h, cnts[tid], nullptr, (const char16_t*)texts + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), topN, match, false);
 				local += res[0].first.size();
 			}
 			tokens += local;

@@ -30,6 +30,7 @@ class OracleKiwi:
         L.korc_close.argtypes = [C.c_void_p]
         L.korc_set_config.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.korc_dump_dict.restype = C.c_size_t
+        L.korc_set_faithful_order.argtypes = [C.c_void_p, C.c_int]
         L.korc_set_container_limits.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.korc_lm_next.restype = C.c_float
         L.korc_lm_next.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32]
@@ -62,6 +63,11 @@ class OracleKiwi:
 
     def set_config(self, cut_off=8.0, space_penalty=7.0, typo_cost_weight=6.0, max_unk=6, max_unk_j=0xFFFFFFFF, space_tol=0, integrate_allomorph=True):
         self.lib.korc_set_config(self.h, cut_off, space_penalty, typo_cost_weight, max_unk, max_unk_j, space_tol, int(integrate_allomorph))
+
+    def set_faithful_order(self, on=True):
+        """Test hook: hand kept paths on in the reference's own container order (persistent std::unordered_set / _map, as its
+        thread_local containers) instead of insertion order; resets the persistent state."""
+        self.lib.korc_set_faithful_order(self.h, int(on))
 
     def set_container_limits(self, small_max=128, medium_max=512, bucket_cap=128):
         """Test hook: number of incoming paths up to which the small / medium container is used, and the per-bucket key cap."""

@@ -14,7 +14,10 @@
 // on equal scores -- and every score is the reference's; results can differ from a given reference run only where two
 // paths tie exactly.
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <unordered_map>
+#include <unordered_set>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +35,11 @@ namespace korc
 		// container selection by number of incoming paths and the per-bucket key cap (BestPathContainer.hpp:275-277, 363-367);
 		// tests shrink them to drive the medium / large containers on small lattices
 		uint32_t smallMax = 128, mediumMax = 512, bucketCap = 128;
+		// `faithfulOrder`: the large top-1 container and the top-N container are the reference's own -- std::unordered_set / std::unordered_map
+		// + std heap algorithms of this libstdc++, PERSISTENT across calls like the reference's thread_local ones -- so that the order in
+		// which kept paths are handed on is the reference's as long as both sides analyse the same texts in the same sequence from a
+		// fresh state.  Off (default): insertion order, the order the device implements.
+		bool faithfulOrder = false;
 		bool openEnding = false, splitComplex = false, splitSaisiot = false, mergeSaisiot = false;
 	};
 
@@ -49,6 +57,42 @@ namespace korc
 		uint32_t wid = 0;
 		uint16_t ownFormId = 0;
 		uint8_t combineSocket = 0;
+	};
+
+	struct WPathSetHash
+	{
+		size_t operator()(const WPath& p) const   // Hash<WordLL<LmState>> (BestPathContainer.hpp:69-86) with Hash<KnLMState> / Hash<SbgState>
+		{
+			size_t r = (size_t)(int64_t)p.lmNode;
+			if (useHist) for (int i = 0; i < 8; ++i) r = (size_t)p.hist[i] ^ ((r << 3) | (r >> 61));
+			return ((uint16_t)p.prevRootId | ((uint16_t)p.spState << 8)) ^ ((r << 3) | (r >> 61));
+		}
+		bool useHist = false;
+	};
+	struct WPathSetEq
+	{
+		bool operator()(const WPath& a, const WPath& b) const
+		{
+			if (a.prevRootId != b.prevRootId || a.spState != b.spState || a.lmNode != b.lmNode) return false;
+			if (!useHist) return true;
+			if (a.histPos != b.histPos) return false;
+			for (int i = 0; i < 8; ++i) if (a.hist[i] != b.hist[i]) return false;
+			return true;
+		}
+		bool useHist = false;
+	};
+	struct TopNKey { int32_t lm; uint8_t rootId, sp; bool operator==(const TopNKey& o) const { return lm == o.lm && rootId == o.rootId && sp == o.sp; } };
+	struct TopNKeyHash   // Hash<PathHash<LmState>> (BestPathContainer.hpp:113-121), Knlm state
+	{
+		size_t operator()(const TopNKey& k) const { size_t r = (size_t)(int64_t)k.lm; return ((uint16_t)k.rootId | ((uint16_t)k.sp << 8)) ^ ((r << 3) | (r >> 61)); }
+	};
+	// what the reference keeps in thread_local storage: never shrunk, so their bucket counts carry the history of the thread
+	struct PersistentContainers
+	{
+		std::unordered_set<WPath, WPathSetHash, WPathSetEq> large{ 0, WPathSetHash{}, WPathSetEq{} };
+		std::unordered_map<TopNKey, std::pair<uint32_t, uint32_t>, TopNKeyHash> topIndex;
+		std::vector<WPath> topValues;
+		bool histInit = false;
 	};
 
 	class BestPathSearch
@@ -217,11 +261,54 @@ namespace korc
 		std::vector<WPath> lset;     // mode 2 (large): distinct keys in insertion order
 
 		std::vector<WPath> titems;   // mode 3 (top-N): every inserted path of the current candidate, in insertion order
+		PersistentContainers* pc = nullptr;   // faithfulOrder only
 
-		void contClear() { for (auto& b : bucket) b.clear(); lset.clear(); titems.clear(); }
+		void contClear()
+		{
+			for (auto& b : bucket) b.clear();
+			lset.clear(); titems.clear();
+			if (pc) { pc->large.clear(); pc->topIndex.clear(); pc->topValues.clear(); }
+		}
 		void contInsert(int mode, const WPath& np)
 		{
+			if (mode == 3 && pc && !S.present())
+			{
+				// BestPathConatiner<topN>::insert (BestPathContainer.hpp:167-203), verbatim semantics
+				const size_t topN = cfg.topN;
+				auto ins = pc->topIndex.emplace(TopNKey{ np.lmNode, np.prevRootId, np.spState }, std::make_pair((uint32_t)pc->topValues.size(), 1u));
+				auto greater = [](const WPath& a, const WPath& b) { return a.accScore > b.accScore; };
+				if (ins.second)
+				{
+					pc->topValues.push_back(np);
+					pc->topValues.resize(pc->topValues.size() + topN - 1);
+				}
+				else
+				{
+					auto first = pc->topValues.begin() + ins.first->second.first;
+					auto last = first + ins.first->second.second;
+					if ((size_t)(last - first) < topN)
+					{
+						*last = np;
+						std::push_heap(first, last + 1, greater);
+						++ins.first->second.second;
+					}
+					else if (np.accScore > first->accScore)
+					{
+						std::pop_heap(first, last, greater);
+						*(last - 1) = np;
+						std::push_heap(first, last, greater);
+					}
+				}
+				return;
+			}
 			if (mode == 3) { titems.push_back(np); return; }
+			if (mode == 2 && pc)
+			{
+				// BestPathConatiner<top1>::insert (BestPathContainer.hpp:238-257)
+				auto ins = pc->large.emplace(np);
+				if (!ins.second && np.accScore > ins.first->accScore) const_cast<WPath&>(*ins.first) = np;
+				return;
+			}
 			if (mode == 2)
 			{
 				// the reference's large container is a thread_local std::unordered_set that is never shrunk: its iteration order
@@ -260,6 +347,12 @@ namespace korc
 		}
 		template<class Fn> void contEach(int mode, Fn&& fn)
 		{
+			if (mode == 3 && pc && !S.present())
+			{
+				for (auto& kv : pc->topIndex) for (uint32_t i = 0; i < kv.second.second; ++i) fn(pc->topValues[kv.second.first + i]);
+				return;
+			}
+			if (mode == 2 && pc) { for (auto& p : pc->large) fn(p); return; }
 			if (mode == 3)
 			{
 				// keep a path iff fewer than N paths of its key beat it (higher score, or equal score and inserted earlier)
@@ -560,8 +653,18 @@ namespace korc
 		}
 
 	public:
-		BestPathSearch(const ModelView& m, const BestPathConfig& c, Counters& k, const SbgView& sbg = SbgView{}) : M(m), S(sbg), cfg(c), cnt(k)
+		BestPathSearch(const ModelView& m, const BestPathConfig& c, Counters& k, const SbgView& sbg = SbgView{}, PersistentContainers* persistent = nullptr) : M(m), S(sbg), cfg(c), cnt(k)
 		{
+			if (c.faithfulOrder && persistent)
+			{
+				pc = persistent;
+				if (!pc->histInit)
+				{
+					WPathSetHash hh; hh.useHist = S.present(); WPathSetEq ee; ee.useHist = S.present();
+					pc->large = std::unordered_set<WPath, WPathSetHash, WPathSetEq>{ 0, hh, ee };
+					pc->histInit = true;
+				}
+			}
 			// TagSequenceScorer (src/TagUtils.cpp:49-62), weight 5
 			for (auto& v : leftBoundary) v = 0;
 			leftBoundary[T_NNP] = leftBoundary[T_NP] = leftBoundary[T_IC] = -1; leftBoundary[T_SB] = -3;

@@ -99,6 +99,14 @@ def test_top_n_matches_reference_up_to_exact_ties(oracle, reference, small_model
     assert shape_diff <= 0.01 * len(texts)
 
 
+def _faithful(kind, top_n):
+    """tests/faithful_check.py in a fresh process (fresh thread_local containers on the reference side)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(HERE, "faithful_check.py"), kind, str(top_n)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_skipbigram_state_step_matches_reference(small_sbg_model):
     """SbgState::next (Knlm step, validity gate, 8 discounted + 8 compensated terms, scalar logSumExp, history ring) of the
     restatement against the real reference, bit for bit, over random word sequences."""
@@ -124,16 +132,23 @@ def test_skipbigram_state_step_matches_reference(small_sbg_model):
 
 def test_skipbigram_analyses_match_reference(small_sbg_model):
     """Whole analyses under the SkipBigram model.  With the history ring in the LM state, nodes of these lattices collect
-    hundreds of distinct paths, i.e. the reference runs its LARGE container (a thread_local std::unordered_set whose iteration
-    order depends on what the thread analysed before) feeding capacity-limited medium containers.  Every text that stays
-    within the small / medium containers must match exactly; texts that use the large one must match in the vast majority."""
+    hundreds of distinct paths, i.e. the reference runs its LARGE container -- a thread_local std::unordered_set whose iteration
+    order depends on what the thread analysed before -- feeding capacity-limited medium containers.  In its reference-faithful
+    mode (the same std containers, persistent, same sequence of texts from a fresh state on both sides) the oracle must agree
+    EXACTLY; in the default insertion-order mode every text that stays within the small / medium containers must agree."""
     import oraclelib
     import refbridge
     if not refbridge.available():
         pytest.skip("oracle/_ref not built")
     sm, path = small_sbg_model
-    orc, ref = oraclelib.OracleKiwi(path), refbridge.RefKiwi(path)
     texts = synthetic(sm, 300, 191, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 150, 192) + [t for t in EDGE_TEXTS if t.strip()]
+
+    def norm(res):
+        return [([astuple(t) for t in a[0]], a[1]) for a in res]
+
+    _faithful("small-sbg", 1)
+
+    orc, ref = oraclelib.OracleKiwi(path), refbridge.RefKiwi(path)
     prev = orc.counters()
     n_large = bad_large = 0
     for s in texts:
@@ -141,11 +156,22 @@ def test_skipbigram_analyses_match_reference(small_sbg_model):
         c = orc.counters()
         large = c["nodesOver512"] > prev["nodesOver512"]
         prev = c
-        y = ref.analyze(s)
-        same = [([astuple(t) for t in a[0]], a[1]) for a in x] == [([astuple(t) for t in a[0]], a[1]) for a in y]
+        same = norm(x) == norm(ref.analyze(s))
         if large:
             n_large += 1
             bad_large += not same
         else:
             assert same, s
     assert bad_large <= max(2, n_large // 20), (bad_large, n_large)
+
+
+@pytest.mark.parametrize("top_n", [2, 3, 4])
+def test_top_n_reference_faithful_order_is_exact(small_model, top_n):
+    """top-N with the oracle in its reference-faithful mode: the reference's own containers (std::unordered_map + std heap
+    algorithms, persistent like its thread_local ones), the same texts in the same sequence from a fresh state on both sides --
+    analyses, their order and fp32 scores must be identical, ties included.  This pins WHICH paths the top-N search keeps; the
+    default (insertion-order) mode, which the device implements, differs from it only in the hand-on order."""
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    _faithful("small", top_n)
