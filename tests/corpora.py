@@ -58,3 +58,35 @@ def dictionary_mix(sm, n, seed):
                 words.insert(pos, e)
         out.append(" ".join(words))
     return out
+
+
+_FUZZ_FRAGS = ["http://a.b/c?d=1", "https://www.example.com/path", "user@mail.com", "@handle", "#tag", "#한글태그", "010-1234-5678", "1,234.5", "3.14",
+               "2024-09-24", "12:30", "AB-123", "a.b.c", "e.g.", "U.S.A.", "Mr.", "...", "!?", "~~", "(", ")", "[", "]", "{", "}", "'", '"', "‘", "’", "“", "”",
+               "「", "」", "·", "…", "ㅋㅋㅋ", "ㅠㅠ", "😀", "👍🏽", "👨‍👩‍👧", "🇰🇷", "‍", "️", "①", "Ⅳ", "㈜", "㎏", "ＡＢＣ", "１２３", "日本語", "中文", "русский",
+               "العربية", "ελληνικά", "\t", "\n", "\r\n", "  ", "　", "\xa0", "A", "z", "0", "9", "-", "_", "+", "=", "*", "&", "%", "$", "₩", "@", "#", ".",
+               ",", ";", ":", "/", "\\", "|", "^", "`", "<", ">", "ᄀ", "ᅡ", "ᆨ", "가", "힣", "\ud800", "\udc00", "\ud83d", "\ude00x"]
+
+
+def fuzzed(sm, n, seed):
+    """Random mixtures of dictionary words, pattern-like fragments (URLs, e-mail, hashtags, mentions, serials, numbers), symbols,
+    emoji sequences, other scripts, jamo, lone surrogates and random code points: stresses normalisation, character typing, the
+    pattern recognisers, chunking and the special-character nodes of the lattice."""
+    import random
+    rng = random.Random(seed)
+    words = [w for t in dictionary_mix(sm, 200, seed + 1) for w in t.split()]
+    out = []
+    for _ in range(n):
+        parts = []
+        for _ in range(rng.randint(1, 12)):
+            c = rng.random()
+            if c < 0.45:
+                parts.append(rng.choice(words))
+            elif c < 0.85:
+                parts.append(rng.choice(_FUZZ_FRAGS))
+            else:
+                parts.append("".join(chr(rng.choice([rng.randint(0x20, 0x7e), rng.randint(0xac00, 0xd7a3), rng.randint(0x1100, 0x11ff),
+                                                     rng.randint(0x2000, 0x2bff), rng.randint(0x3000, 0x33ff)])) for _ in range(rng.randint(1, 4))))
+            if rng.random() < 0.6:
+                parts.append(" ")
+        out.append("".join(parts))
+    return out

@@ -8,7 +8,7 @@ from dataclasses import astuple
 import numpy as np
 import pytest
 
-from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+from corpora import EDGE_TEXTS, dictionary_mix, fuzzed, synthetic
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +40,19 @@ def test_tokens_bit_exact_vs_oracle(engine, oracle, small_model, kind):
     got = engine.analyze_batch(texts).to_python()
     for s, y in zip(texts, got):
         assert _norm(oracle.analyze(s)) == _norm(y), s
+
+
+def test_fuzzed_texts_bit_exact_vs_oracle(engine, oracle, small_model):
+    """Fuzzed inputs (URLs, e-mail, hashtags, emoji sequences, other scripts, jamo, lone surrogates, random code points): device
+    lattices and analyses against the oracle (which the CPU suite checks against the real reference on the same generator)."""
+    sm, _ = small_model
+    texts = fuzzed(sm, 1500, 221)
+    got = engine.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(oracle.analyze(s)) == _norm(y), repr(s)
+    for s in texts[:150]:
+        if s.strip():
+            assert engine.split(s) == oracle.split(s), repr(s)
 
 
 def test_golden_vectors_from_reference(engine):

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+from corpora import EDGE_TEXTS, dictionary_mix, fuzzed, synthetic
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -97,6 +97,15 @@ def test_top_n_matches_reference_up_to_exact_ties(oracle, reference, small_model
             shape_diff += 1
     assert exact >= 0.6 * len(texts)
     assert shape_diff <= 0.01 * len(texts)
+
+
+def test_fuzzed_texts_match_reference(oracle, reference, small_model):
+    """Fuzzed inputs (tests/corpora.py:fuzzed): lattices and analyses of the restatement -- whose text preparation is the product's
+    own host code -- against the real reference."""
+    sm, _ = small_model
+    for s in fuzzed(sm, 700, 211):
+        assert oracle.split(s) == reference.split(s), repr(s)
+        assert [([astuple(t) for t in a[0]], a[1]) for a in oracle.analyze(s)] == [([astuple(t) for t in a[0]], a[1]) for a in reference.analyze(s)], repr(s)
 
 
 def _faithful(kind, top_n):
