@@ -108,6 +108,22 @@ def test_fuzzed_texts_match_reference(oracle, reference, small_model):
         assert [([astuple(t) for t in a[0]], a[1]) for a in oracle.analyze(s)] == [([astuple(t) for t in a[0]], a[1]) for a in reference.analyze(s)], repr(s)
 
 
+@pytest.mark.parametrize("name,kind", [("small_model_top3_sequence.json", "small"), ("small_sbg_model_sequence.json", "small-sbg")])
+def test_golden_sequences(small_model, small_sbg_model, name, kind):
+    """Committed outputs of the real reference for top-3 (Knlm) and for the SkipBigram model, generated as one sequence from a
+    fresh process (tools/make_golden.py): replayed in the same order by a fresh oracle handle in its reference-faithful mode they
+    must be reproduced exactly -- order of the analyses, tokens and every fp32 score.  Runs without oracle/_ref."""
+    import oraclelib
+    g = json.load(open(os.path.join(HERE, "golden", name), encoding="utf-8"))
+    path = (small_sbg_model if kind == "small-sbg" else small_model)[1]
+    orc = oraclelib.OracleKiwi(path)
+    orc.set_faithful_order(True)
+    for it in g["items"]:
+        res = orc.analyze(it["text"], top_n=g["top_n"])
+        got = [{"score": a[1], "tokens": [[t.form, t.tag, t.position, t.length, t.word_position, t.sent_position, t.sense_id, t.morph_id, t.score] for t in a[0]]} for a in res]
+        assert got == it["analyses"], it["text"]
+
+
 def _faithful(kind, top_n):
     """tests/faithful_check.py in a fresh process (fresh thread_local containers on the reference side)."""
     import subprocess
