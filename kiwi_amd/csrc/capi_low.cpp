@@ -3,9 +3,11 @@
 // (/root/reference/src/capi/kiwi_c.cpp:84, 95-114).
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include "../../include/kiwi_amd.h"
 #include "engine.hpp"
+#include "sbg_eval.hpp"
 
 using namespace kamd;
 
@@ -122,6 +124,26 @@ extern "C"
 	int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n)
 	{
 		return guarded([&]() { kamd::exactMathProbe(x, exp_out, log_out, n); return 0; }, -1);
+	}
+
+	// Host-side run of the SkipBigram step the search kernel uses (sbg_eval.hpp, shared source): one LmState::next on top of a
+	// Knlm log-likelihood the caller supplies.  No device involved; tests compare it with the reference's SbgState::next.
+	int kamd_debug_sbg_next(const char* raw_model_path, uint32_t* hist8, uint32_t* pos, uint32_t wid, float knlm_ll, float* ll_out)
+	{
+		return guarded([&]()
+		{
+			static std::mutex mu; static std::string cachedPath; static std::unique_ptr<FlatModel> cached;
+			std::lock_guard<std::mutex> lk{ mu };
+			if (!cached || cachedPath != raw_model_path) { cached.reset(new FlatModel); bakeModel(*cached, raw_model_path); cachedPath = raw_model_path; }
+			const SbgView sv = cached->sbgView();
+			if (!sv.present()) throw std::runtime_error{ "kamd_debug_sbg_next: the model has no SkipBigram tables" };
+			uint32_t ring[8]; for (int i = 0; i < 8; ++i) ring[i] = hist8[i];
+			uint32_t p = *pos & 7u;
+			*ll_out = sbgNext(sv, ring, p, wid, knlm_ll);
+			for (int i = 0; i < 8; ++i) hist8[i] = ring[i];
+			*pos = p;
+			return 0;
+		}, -1);
 	}
 
 	size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap)

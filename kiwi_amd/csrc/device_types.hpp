@@ -144,6 +144,20 @@ namespace kamd
 		uint32_t* beacon;              // developer aid (KAMD_TIMELINE builds): per-chunk timeline records, else null
 	};
 
+	// SkipBigram model on the device (reference src/SkipBigramModel.hpp:40-105) plus the history storage of the search:
+	// only the SkipBigram instantiation of the search kernel takes this view (Knlm-only models never see it).
+	struct SbgDev
+	{
+		const uint32_t* ptrs;          // [vocab + 1] into keys / comps
+		const uint32_t* keys;          // partner (history) word ids, sorted per `next` word
+		const float* comps;            // compensation per key
+		const float* discnts;          // [vocab]
+		const uint8_t* valid;          // [vocab]
+		uint32_t vocabSize; float logWindowSize;
+		uint32_t* hist;                // [state][8]: history ring of every search state, parallel to WorkView::states (ring position: DevState::pad0)
+		uint8_t* itemScratch;          // per lane group: SbgScratch (viterbi_kernel.hpp), rings of the work items of one batch
+	};
+
 	// LDS layout of the wave-per-chunk lattice build (byte offsets): n text units, node capacity, packed-match capacity
 	struct LatticeLds { uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, endPosMap, fullMask, zAt, mforms, mfrec, out, spaceErr, queue, total; };
 	// LDS-side capacities are the typical need (3 per text unit), not the worst-case HBM capacities: a chunk that outgrows

@@ -114,6 +114,7 @@ namespace kamd
 		// device
 		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags, dTextOff;
 		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
+		DevBuf dHist;   // SkipBigram models: history ring of every search state (8 x u32), parallel to dStates
 		DevBuf dPackBase, dPacks, dStateBase, dStates, dNodeStOff, dNodeStCnt, dReach, dTokenBase, dTokens, dResults, dOrder;
 		BatchView bv{}; WorkView wv{};
 		std::vector<DevChunkResult> hResults;
@@ -138,6 +139,7 @@ namespace kamd
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter;
+		SbgDev sbg{}; bool hasSbg = false; DevBuf sbgScratch;   // SkipBigram tables on the device + per-lane-group item scratch of its search kernel
 		// the engine owns ONE pair of streams, one work counter and one scratch arena: device work of concurrent callers (the C API
 		// is callable from many threads, reference capi threading contract) is serialised per engine; host preparation is not
 		std::recursive_mutex deviceMu;
@@ -155,8 +157,13 @@ namespace kamd
 	Engine::Engine(const std::string& path, int device) : impl(new Impl)
 	{
 		bakeModel(impl->model, path);
-		if (!impl->model.sbgPtrs.empty())
-			throw std::runtime_error{ "kiwi_amd: this raw model carries SkipBigram tables; SkipBigram scoring is not built on the device path yet (Knlm models only)" };
+		// SkipBigram scoring on the device (viterbi_kernel_sbg.hip) is written but has not been through the GPU parity suite yet:
+		// it has to be asked for, so that nobody gets unchecked analyses from a model that merely happens to carry the tables
+		if (!impl->model.sbgPtrs.empty() && !std::getenv("KAMD_EXPERIMENTAL_SBG"))
+			throw std::runtime_error{ "kiwi_amd: this raw model carries SkipBigram tables; SkipBigram scoring on the device is experimental "
+				"(not parity-checked on a GPU yet) and only enabled with KAMD_EXPERIMENTAL_SBG=1 -- Knlm models are the supported ones" };
+		if (!impl->model.sbgPtrs.empty() && impl->model.sbgWindow != 8)
+			throw std::runtime_error{ "kiwi_amd: SkipBigram window size must be 8 (the reference instantiates SbgState<8> only, src/SkipBigramModel.cpp)" };
 		int nDev = 0;
 		if (hipGetDeviceCount(&nDev) != hipSuccess || nDev == 0)
 			throw std::runtime_error{ "kiwi_amd: no HIP device visible -- the analyze path has no CPU fallback" };
@@ -190,6 +197,14 @@ namespace kamd
 		v.trie = impl->up(m.trie); v.trieKeys = impl->up(m.trieKeys); v.trieChild = impl->up(m.trieChild); v.trieRoot = impl->up(m.trieRoot);
 		v.lmNodes = impl->up(m.lmNodes); v.lmKeys = impl->up(m.lmKeys); v.lmValues = impl->up(m.lmValues); v.lmRoot = impl->up(m.lmRoot);
 		v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff);
+		if (!m.sbgPtrs.empty())
+		{
+			const SbgView sv = m.sbgView();
+			SbgDev& d = impl->sbg;
+			d.ptrs = impl->up(m.sbgPtrs); d.keys = impl->up(m.sbgKeys); d.comps = impl->up(m.sbgComps); d.discnts = impl->up(m.sbgDiscnts); d.valid = impl->up(m.sbgValid);
+			d.vocabSize = sv.vocabSize; d.logWindowSize = sv.logWindowSize; d.hist = nullptr; d.itemScratch = nullptr;
+			impl->hasSbg = true;
+		}
 		hipDeviceProp_t prop;
 		HIPCHECK(hipGetDeviceProperties(&prop, device));
 		impl->persistBlocks = (uint32_t)prop.multiProcessorCount * 12;   // one-wave persistent blocks: 3 waves per SIMD is the most the search kernel is built for
@@ -319,6 +334,7 @@ namespace kamd
 		b.dPacks.ensure((size_t)b.packBase[nC] * sizeof(CandStatic) + 16);
 		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
 		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
+		if (I.hasSbg) b.dHist.ensure(totStates * 32 + 32);
 		b.devBytes = 0;
 		for (const DevBuf* d : { &b.dChars, &b.dCls, &b.dScript, &b.dNsToPos, &b.dPosToNs, &b.dCflag, &b.dMask, &b.dMoff, &b.dMatchForm, &b.dNodes, &b.dTmpNodes, &b.dEndPosMap, &b.dTmpIdx,
 			&b.dPacks, &b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults }) b.devBytes += d->cap;
@@ -413,11 +429,13 @@ namespace kamd
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
 		HIPCHECK(hipMemsetAsync(b.dNNodes.p, 0, (size_t)nC * 4, sA));   // also clears the lattice kernels' hand-over flag
 		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
-		const uint32_t nGroups = 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
+		const uint32_t nGroups = I.hasSbg ? ((I.groupLanesForced && I.groupLanes == 64) ? 1u : 4u)      // (the SkipBigram kernel: 16-lane groups unless 64 is forced)
+			: 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
 		const uint32_t maxBlocks = std::min(I.persistBlocks, (maxWork + nGroups - 1) / nGroups);
 		I.bigScratch.ensure((size_t)maxBlocks * nGroups * sizeof(GroupScratch) * std::min(S, 2u));
 		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)sizeof(GroupScratch);
+		if (I.hasSbg) I.sbgScratch.ensure((size_t)maxBlocks * nGroups * sizeof(SbgScratch) * std::min(S, 2u));
 		const uint32_t ldsBytes = searchKernelLdsBytes(I.groupLanes);
 		for (uint32_t k = 0; k < S; ++k)
 		{
@@ -465,13 +483,22 @@ namespace kamd
 			// groups, 2 waves per SIMD measured best on 8192 x 40 jamo); with many chunks it is a throughput problem and narrower
 			// groups + a third wave per SIMD win (65536 x 40 jamo: 6.9 vs 9.3 ms).  KAMD_GROUP_LANES / KAMD_WPS override.
 			const bool many = cn >= 32768;
-			const int gl = I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
+			const int gl = I.hasSbg ? ((I.groupLanesForced && I.groupLanes == 64) ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
 			const int wps = I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
 			const uint32_t blocksK = std::min(I.persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
 			const uint32_t ldsK = searchKernelLdsBytes(gl);
 #define KAMD_LAUNCH(GG, WW) hipLaunchKernelGGL((k_best_path<GG, WW>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn)
-			if (wps == 3 && gl == 8) KAMD_LAUNCH(8, 3);
+			if (I.hasSbg)
+			{
+				// SkipBigram model: the search kernel with history rings (16-lane groups, or one chunk per wave when 64 is forced)
+				SbgDev sd = I.sbg;
+				sd.hist = b.dHist.as<uint32_t>();
+				sd.itemScratch = I.sbgScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(SbgScratch) : 0);
+				if (gl == 64) hipLaunchKernelGGL((sbgk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
+				else hipLaunchKernelGGL((sbgk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
+			}
+			else if (wps == 3 && gl == 8) KAMD_LAUNCH(8, 3);
 			else if (wps == 3 && gl == 16) KAMD_LAUNCH(16, 3);
 			else switch (gl)
 			{

@@ -42,9 +42,22 @@
 #include "device_types.hpp"
 #include "feature.hpp"
 #include "viterbi_kernel.hpp"
+// SkipBigram models (Knlm + skip-bigram mixture): this file is compiled a second time by viterbi_kernel_sbg.hip with KAMD_SBG
+// defined, into namespace kamd::sbgk.  Everything that exists only there is spelled SBG_ONLY(...) or sits under #ifdef KAMD_SBG,
+// so that without the macro the translation unit is, token for token, the Knlm kernel that was measured and profiled.
+#ifdef KAMD_SBG
+#include "sbg_eval.hpp"
+#define SBG_ONLY(...) __VA_ARGS__
+#else
+#define SBG_ONLY(...)
+#endif
 
 namespace kamd
 {
+#ifdef KAMD_SBG
+namespace sbgk
+{
+#endif
 	constexpr uint64_t KINVALID = ~0ull;
 // Inlining level of the node loop's stages (3 = everything inlined into the kernel: the lane-group context then lives in
 // registers).  The end-candidate stage (finishChunk) always stays a real function: inlined as well, the hipcc of ROCm 7.2
@@ -136,10 +149,12 @@ namespace kamd
 		static constexpr uint32_t LB = (64 / G) * SIZE;              // f32[2*T_MAX+1], shared by the groups
 		static constexpr uint32_t TOTAL = LB + 4 * (2 * T_MAX + 1);
 	};
+#ifndef KAMD_SBG
 	uint32_t searchKernelLdsBytes(int G)
 	{
 		switch (G) { case 4: return Lay<4>::TOTAL; case 8: return Lay<8>::TOTAL; case 16: return Lay<16>::TOTAL; case 32: return Lay<32>::TOTAL; default: return Lay<64>::TOTAL; }
 	}
+#endif
 
 	// candidate record as the scoring lanes see it (registers; 64 bytes in LDS)
 	struct Cand
@@ -197,13 +212,17 @@ namespace kamd
 		return h;
 	}
 	__device__ __forceinline__ void storeState(DevState* st, uint32_t i, int32_t lmNode, float acc, float typo, uint32_t wid, uint16_t leftFeat, uint8_t rootId, uint8_t sp,
-		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode)
+		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode SBG_ONLY(, uint32_t histPos = 0))
 	{
 		uint4* p = reinterpret_cast<uint4*>(st + i);
 		p[0] = make_uint4((uint32_t)lmNode, __float_as_uint(acc), (uint32_t)leftFeat | ((uint32_t)rootId << 16) | ((uint32_t)sp << 24),
 			(uint32_t)socket | ((uint32_t)prevFlags << 8) | ((uint32_t)ownKind << 24));
 		p[1] = make_uint4(__float_as_uint(typo), wid, parent, morph);
+#ifdef KAMD_SBG
+		p[2] = make_uint4(__float_as_uint(fcs), (uint32_t)nodeId | ((uint32_t)ownNode << 16), histPos, 0);   // DevState::pad0 = ring position
+#else
 		p[2] = make_uint4(__float_as_uint(fcs), (uint32_t)nodeId | ((uint32_t)ownNode << 16), 0, 0);
+#endif
 	}
 
 	// edge (node, wid) of the Knlm trie through the bucketed hash built at load time (flat_model.hpp LmSlot)
@@ -264,6 +283,71 @@ namespace kamd
 		}
 	}
 
+#ifdef KAMD_SBG
+	// ---- SkipBigram LM state beyond the Knlm node: ring of the last 8 valid word ids + write position (SbgState,
+	// src/SkipBigramModel.hpp:141-182).  Rings are only ever indexed with compile-time constants or select chains, so they
+	// stay in registers.
+	struct Ring { uint32_t h[8]; uint32_t pos; };
+	__device__ __forceinline__ Ring loadRing(const uint32_t* base, uint32_t pos)
+	{
+		const uint4 a = reinterpret_cast<const uint4*>(base)[0], b = reinterpret_cast<const uint4*>(base)[1];
+		Ring r; r.h[0] = a.x; r.h[1] = a.y; r.h[2] = a.z; r.h[3] = a.w; r.h[4] = b.x; r.h[5] = b.y; r.h[6] = b.z; r.h[7] = b.w; r.pos = pos;
+		return r;
+	}
+	__device__ __forceinline__ void storeRing(uint32_t* base, const Ring& r)
+	{
+		reinterpret_cast<uint4*>(base)[0] = make_uint4(r.h[0], r.h[1], r.h[2], r.h[3]);
+		reinterpret_cast<uint4*>(base)[1] = make_uint4(r.h[4], r.h[5], r.h[6], r.h[7]);
+	}
+	__device__ __forceinline__ uint32_t ringAt(const Ring& r, uint32_t i)
+	{
+		uint32_t v = r.h[0];
+#pragma unroll
+		for (uint32_t k = 1; k < 8; ++k) v = i == k ? r.h[k] : v;
+		return v;
+	}
+	// the k-th of the last four words fed, oldest first (SbgState::getLastHistory, SkipBigramModel.hpp:161-167)
+	__device__ __forceinline__ uint32_t ringLast4(const Ring& r, uint32_t k) { return ringAt(r, (r.pos + 4u + k) & 7u); }
+	// LM-state equality as the path containers see it: the whole ring and its position for top-1 (SbgState::operator==,
+	// SkipBigramModel.hpp:156-159); the last four words only for top-N (PathHash<SbgState>, src/SkipBigramModel.cpp:8-35)
+	__device__ __forceinline__ bool sameRing(const Ring& a, const Ring& b, bool last4)
+	{
+		bool eq = true;
+		if (last4)
+		{
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) eq = eq & (ringLast4(a, k) == ringLast4(b, k));
+		}
+		else
+		{
+			eq = a.pos == b.pos;
+#pragma unroll
+			for (uint32_t k = 0; k < 8; ++k) eq = eq & (a.h[k] == b.h[k]);
+		}
+		return eq;
+	}
+	// 32-bit digest over exactly what sameRing compares: unequal digests prove unequal rings, equal digests are re-checked on the rings
+	__device__ __forceinline__ uint32_t ringDigest(const Ring& r, bool last4)
+	{
+#ifdef KAMD_TEST_WEAK_DIGEST
+		return 0;      // test build: every pair of items with equal keys reaches the exact comparison / the collision hand-over
+#else
+		uint32_t d = last4 ? 0x51ED270Bu : r.pos;
+		if (last4)
+		{
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) { d = (d ^ ringLast4(r, k)) * 0x9E3779B1u; d ^= d >> 15; }
+		}
+		else
+		{
+#pragma unroll
+			for (uint32_t k = 0; k < 8; ++k) { d = (d ^ r.h[k]) * 0x9E3779B1u; d ^= d >> 15; }
+		}
+		return d;
+#endif
+	}
+#endif
+
 	__device__ __forceinline__ uint8_t hashSb(uint32_t type, uint32_t order)   // PathEvaluator.hpp:83-86
 	{
 		type &= 0xFF; order &= 0xFF;
@@ -313,7 +397,10 @@ namespace kamd
 			gl = o.gl; gshift = o.gshift; lds = o.lds; nodes = o.nodes; Gn = o.Gn; str = o.str; cls = o.cls; st = o.st; stCap = o.stCap; stTop = o.stTop;
 			nodeStOff = o.nodeStOff; nodeStCnt = o.nodeStCnt; nodeLive = o.nodeLive; uniq = o.uniq; nUniq = o.nUniq;
 			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; tl = o.tl;
+			SBG_ONLY(S = o.S; hist = o.hist; sscr = o.sscr;)
 		}
+		// SkipBigram: the model view, the chunk's state rings (parallel to st) and the lane group's item scratch
+		SBG_ONLY(const SbgDev* S; uint32_t* hist; SbgScratch* sscr;)
 		uint32_t gl, gshift, lds;       // lane in group, group's first lane, byte offset of the group's LDS slice
 		const DevNode* nodes; uint32_t Gn;
 		const uint16_t* str; const uint8_t* cls;
@@ -366,9 +453,9 @@ namespace kamd
 	}
 	template<int G>
 	__device__ __forceinline__ void putState(GroupCtx<G>& X, uint32_t i, int32_t lmNode, float acc, float typo, uint32_t wid, uint16_t leftFeat, uint8_t rootId, uint8_t sp,
-		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode)
+		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode SBG_ONLY(, uint32_t histPos = 0))
 	{
-		storeState(X.st, i, lmNode, acc, typo, wid, leftFeat, rootId, sp, socket, prevFlags, ownKind, parent, morph, fcs, nodeId, ownNode);
+		storeState(X.st, i, lmNode, acc, typo, wid, leftFeat, rootId, sp, socket, prevFlags, ownKind, parent, morph, fcs, nodeId, ownNode SBG_ONLY(, histPos));
 		if constexpr (Lay<G>::HCAP != 0)
 		{
 			if (i < Lay<G>::HCAP)
@@ -434,6 +521,10 @@ namespace kamd
 		const bool fast = (G == 16 || G == 8) && Qtot <= (uint32_t)G && mode == 0;
 #endif
 		uint64_t rKey = KINVALID; float rScore = 0, rFcs = 0, rTypo = 0;
+#ifdef KAMD_SBG
+		uint32_t rDigest = 0;      // digest of the item's history ring (the ring itself goes to X.sscr)
+		const bool last4 = X.P.topN > 1;   // what of the ring belongs to the container key (sameRing)
+#endif
 
 		// ---- scoring pass: one work item per lane -------------------------------------------------------
 		for (uint32_t qb = 0; qb < Qtot; qb += G)
@@ -443,6 +534,7 @@ namespace kamd
 			uint32_t k = 0;
 			if (valid) { while (k + 1 < nC && q >= X.candQOff(k + 1)) ++k; }
 			float cand = 0, firstChunk = 0; int32_t lmNode = 0; uint8_t rootKey = 0, sp = 0;
+			SBG_ONLY(Ring ring{};)
 			if (valid)
 			{
 				const Cand c = loadCand(X.candOff(k));
@@ -490,11 +582,13 @@ namespace kamd
 						else if (!ok) { valid = false; break; }
 					}
 					lmNode = ps.lmNode;
+					SBG_ONLY(ring = loadRing(X.hist + 8ull * (pBeg + p), X.st[pBeg + p].pad0);)
 					if (!(csock && single))
 					{
 						// prohibit <v> without <chunk> (PathEvaluator.hpp:604-608): static per candidate unless the word id was replaced above
 						if (widReplaced ? (M.morphs[firstWid].tag == T_P) : ((c.flags() & MF_FIRST_WID_IS_P) != 0)) { valid = false; break; }
 						float ll = lmProgress(M, lmNode, firstWid);
+						SBG_ONLY(ll = sbgNext(*X.S, ring.h, ring.pos, firstWid, ll);)
 						cand += ll; firstChunk += ll;
 						if (!single)
 						{
@@ -504,6 +598,7 @@ namespace kamd
 								const uint32_t wid = ch == 1 ? c.secondWid : M.chunkLm[c.chunkOff + ch];
 								if ((c.flags() & MF_ANY_REST_WID_IS_P) && M.morphs[wid].tag == T_P) { valid = false; break; }
 								ll = lmProgress(M, lmNode, wid);
+								SBG_ONLY(ll = sbgNext(*X.S, ring.h, ring.pos, wid, ll);)
 								cand += ll;
 							}
 							if (!valid) break;
@@ -527,7 +622,16 @@ namespace kamd
 				// key: LM node | new special state | previous root | candidate ; r is recoverable from q
 				const uint64_t key = valid ? ((uint64_t)(uint32_t)lmNode | ((uint64_t)sp << 32) | ((uint64_t)rootKey << 40) | ((uint64_t)k << 48)) : KINVALID;
 				rKey = key; rScore = cand; rFcs = firstChunk;
+#ifdef KAMD_SBG
+				// the LM state of the item beyond the Knlm node; the queues are filled on the register path too, which hands a
+				// batch over to the scanning path when two digests collide
+				rDigest = ringDigest(ring, last4);
+				if (valid) { storeRing(X.sscr->hist[q], ring); X.sscr->pos[q] = ring.pos; }
+				X.sscr->hash[q] = rDigest;
+				if (false) {}
+#else
 				if (fast) {}
+#endif
 				else if (big) { X.scratch->key[q] = key; X.scratch->score[q] = cand; X.scratch->fcs[q] = firstChunk; }
 				else { X.qKey()[q] = key; X.qScore()[q] = cand; X.qFcs()[q] = firstChunk; }
 			}
@@ -550,10 +654,20 @@ namespace kamd
 			const uint8_t stSocket = single ? c.socket() : 0;
 			const bool own = single && ownKind;
 			const uint16_t lf = own ? (uint16_t)(ownFeat | (c.leftFeat() & (LF_TAG_SSC | LF_PREV_ZSIOT))) : c.leftFeat();
+#ifdef KAMD_SBG
+			// the ring of item qw (top-1: the key's winner has, by key equality, the ring of every item of the key)
+			const Ring er = loadRing(X.sscr->hist[qw], X.sscr->pos[qw]);
+			storeRing(X.hist + 8ull * pos, er);
+#endif
 			putState<G>(X, pos, (int32_t)(uint32_t)wkey, wscore, wtypo, c.lastSeqId, lf, newRoot, (uint8_t)(wkey >> 32), stSocket, c.prevFlags(),
-				own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0);
+				own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0 SBG_ONLY(, er.pos));
 			stageState<G>(X, pos - E.nodeStart, wscore, newRoot, c.socket() != 0, stSocket != 0);
 		};
+#ifdef KAMD_SBG
+		// top-N: the container key leaves the previous root out (PathHash<SbgState>::operator==, src/SkipBigramModel.cpp:26-29)
+		const uint64_t keyMask = last4 ? ~(0xFFull << 40) : ~0ull;
+		bool scan = !fast;      // the register path hands its batch to the scanning path when ring digests collide
+#endif
 		if (fast)
 		{
 			if constexpr (G == 16 || G == 8)
@@ -564,9 +678,18 @@ namespace kamd
 				bool rep = rKey != KINVALID;
 				float best = rScore; uint32_t qw = q;
 				uint32_t beaten = 0;      // top-N: items of the same key that beat this one (higher score, or equal and earlier)
+#ifdef KAMD_SBG
+				uint32_t firstSame = q;   // earliest item whose key and ring digest equal this one's
+				const uint32_t hiMask = (uint32_t)(keyMask >> 32);
+#define KAMD_SAME_ITEM(N) ((((orl ^ rl) & (16u - G)) == 0)) & (ol == keyLo) & ((((oh ^ keyHi) & hiMask) == 0)) & (rowRor<N>(rDigest) == rDigest)
+#define KAMD_TRACK_FIRST firstSame = (same & (oi < firstSame)) ? oi : firstSame;
+#else
+#define KAMD_SAME_ITEM(N) ((((orl ^ rl) & (16u - G)) == 0)) & (ol == keyLo) & (oh == keyHi)
+#define KAMD_TRACK_FIRST
+#endif
 				// branch-free on purpose (bitwise logic on predicates + selects): 15 short dependent steps instead of 45 exec-mask branches
 #define KAMD_ROT_STEP(N) { const uint32_t orl = rowRor<N>(rl), oi = orl & (G - 1), ol = rowRorOld<N>(keyLo, 0xFFFFFFFFu), oh = rowRorOld<N>(keyHi, 0xFFFFFFFFu); const float os = rowRorF<N>(rScore); \
-				const bool same = ((((orl ^ rl) & (16u - G)) == 0)) & (ol == keyLo) & (oh == keyHi); \
+				const bool same = KAMD_SAME_ITEM(N); KAMD_TRACK_FIRST \
 				rep = rep & !(same & (oi < q)); \
 				const bool better = same & ((os > best) | ((os == best) & (oi < qw))); \
 				beaten += (same & ((os > rScore) | ((os == rScore) & (oi < q)))) ? 1u : 0u; \
@@ -574,7 +697,20 @@ namespace kamd
 				KAMD_ROT_STEP(1) KAMD_ROT_STEP(2) KAMD_ROT_STEP(3) KAMD_ROT_STEP(4) KAMD_ROT_STEP(5) KAMD_ROT_STEP(6) KAMD_ROT_STEP(7) KAMD_ROT_STEP(8)
 				KAMD_ROT_STEP(9) KAMD_ROT_STEP(10) KAMD_ROT_STEP(11) KAMD_ROT_STEP(12) KAMD_ROT_STEP(13) KAMD_ROT_STEP(14) KAMD_ROT_STEP(15)
 #undef KAMD_ROT_STEP
+#undef KAMD_SAME_ITEM
+#undef KAMD_TRACK_FIRST
 				TLMARK(X, 7)
+#ifdef KAMD_SBG
+				// the rotations compared digests: every item checks its ring against the earliest item of its digest class.
+				// All checks passing makes the classes exact (equality is transitive); a single mismatch sends the whole
+				// batch through the scanning path, which compares rings.
+				bool clash = false;
+				if (rKey != KINVALID && firstSame != q)
+					clash = !sameRing(loadRing(X.sscr->hist[q], X.sscr->pos[q]), loadRing(X.sscr->hist[firstSame], X.sscr->pos[firstSame]), last4);
+				scan = X.any(clash);
+				if (!scan)
+				{
+#endif
 				if (X.P.topN > 1)
 				{
 					// keep the N best of every key, each with its own values, in item order (top-N)
@@ -591,9 +727,14 @@ namespace kamd
 					else X.overflow = true;
 				}
 				X.stTop += __popcll(kbal);
+				SBG_ONLY(})
 			}
 		}
+#ifdef KAMD_SBG
+		if (scan)
+#else
 		else
+#endif
 		{
 			const int nBuckets = mode == 1 ? 4 : 1;
 			for (int b = 0; b < nBuckets; ++b)
@@ -610,6 +751,18 @@ namespace kamd
 						const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
 						rep = true;
 						float best = -INFINITY; bool haveBest = false;
+#ifdef KAMD_SBG
+						// does item j (key kj) belong to another container key than this item?  Packed key, then digest, then the rings
+						const Ring myRing = loadRing(X.sscr->hist[q], X.sscr->pos[q]); const uint32_t myDigest = X.sscr->hash[q];
+						auto otherKey = [&](uint32_t j, uint64_t kj) -> bool
+						{
+							if (((kj ^ key) & keyMask) != 0 || X.sscr->hash[j] != myDigest) return true;
+							return j != q && !sameRing(loadRing(X.sscr->hist[j], X.sscr->pos[j]), myRing, last4);
+						};
+#define KAMD_OTHER_KEY(j, kj) otherKey(j, kj)
+#else
+#define KAMD_OTHER_KEY(j, kj) kj != key
+#endif
 						if (X.P.topN > 1)
 						{
 							const float sq = big ? X.scratch->score[q] : X.qScore()[q];
@@ -617,7 +770,7 @@ namespace kamd
 							for (uint32_t j = lo; j < hi; ++j)
 							{
 								const uint64_t kj = big ? X.scratch->key[j] : X.qKey()[j];
-								if (kj != key || j == q) continue;
+								if (KAMD_OTHER_KEY(j, kj) || j == q) continue;
 								const float sj = big ? X.scratch->score[j] : X.qScore()[j];
 								if (sj > sq || (sj == sq && j < q)) ++beaten;
 							}
@@ -628,16 +781,24 @@ namespace kamd
 						for (uint32_t j = lo; j < hi; ++j)
 						{
 							const uint64_t kj = big ? X.scratch->key[j] : X.qKey()[j];
-							if (kj != key) continue;
+							if (KAMD_OTHER_KEY(j, kj)) continue;
 							if (j < q) { rep = false; break; }
 							const float sj = big ? X.scratch->score[j] : X.qScore()[j];
 							if (!haveBest || sj > best) { best = sj; qw = j; haveBest = true; }
 						}
 						}
+#undef KAMD_OTHER_KEY
 						if (rep && mode == 1)
 						{
 							// bucket = (h >> 8) & 3 of Hash<WordLL> (BestPathContainer.hpp:80-85, 323)
+#ifdef KAMD_SBG
+							// Hash<SbgState> (src/SkipBigramModel.hpp:186-201): the ring words chained onto the Knlm node
+							uint64_t lmv = (uint64_t)(int64_t)(int32_t)(uint32_t)key;
+#pragma unroll
+							for (int w = 0; w < 8; ++w) lmv = (uint64_t)myRing.h[w] ^ ((lmv << 3) | (lmv >> 61));
+#else
 							const uint64_t lmv = (uint64_t)(int64_t)(int32_t)(uint32_t)key;
+#endif
 							const uint64_t hh = (uint64_t)(((key >> 40) & 0xFF) | (((key >> 32) & 0xFF) << 8)) ^ ((lmv << 3) | (lmv >> 61));
 							rep = (int)((hh >> 8) & 3) == b;
 						}
@@ -702,8 +863,9 @@ namespace kamd
 					ns.parent = E.pBeg + p; ns.morph = newMorph; ns.wid = newMorph; ns.nodeId = (uint16_t)E.nodeIdx;
 					ns.leftFeat = ns.ownKind ? (uint16_t)((ns.leftFeat & (0x1FFF | LF_STR_SSC)) | (lfMorph & (LF_TAG_SSC | LF_PREV_ZSIOT))) : lfMorph;
 					ns.prevFlags = nm.prevFlags;
+					SBG_ONLY(storeRing(X.hist + 8ull * pos, loadRing(X.hist + 8ull * (E.pBeg + p), ns.pad0));)   // the LM state is handed on unchanged
 					putState<G>(X, pos, ns.lmNode, ns.accScore, ns.accTypoCost, ns.wid, ns.leftFeat, ns.rootId, ns.spState, ns.socket, ns.prevFlags, ns.ownKind,
-						ns.parent, ns.morph, ns.firstChunkScore, ns.nodeId, ns.ownNode);
+						ns.parent, ns.morph, ns.firstChunkScore, ns.nodeId, ns.ownNode SBG_ONLY(, ns.pad0));
 					stageState<G>(X, pos - E.nodeStart, ns.accScore, ns.rootId, newMorphSocket, ns.socket != 0);
 				}
 				else X.overflow = true;
@@ -938,6 +1100,7 @@ namespace kamd
 		TLMARK(X, 4)
 	}
 
+#ifndef KAMD_SBG    // (the end stage after the EOS transition does not depend on the LM type: one copy, in the Knlm translation unit)
 	// libstdc++'s std::sort restated for the end-node candidate list (the reference sorts it with an unstable
 	// std::sort, PathEvaluator.hpp:1359-1368; equal keys must land where introsort puts them).  Runs on one lane.
 	__device__ __forceinline__ bool endLess(const EndCand& a, const EndCand& b)
@@ -1101,6 +1264,7 @@ namespace kamd
 		return nTok;
 	}
 
+#endif
 	// End node, first half (PathEvaluator.hpp:1320-1358): EOS transition of every surviving path -> end-candidate list for k_finish_paths.
 	template<int G>
 	__device__ __noinline__ void finishChunk(GroupCtx<G>& X, uint32_t chunk, bool openEnding, DevChunkResult* res)
@@ -1134,6 +1298,7 @@ namespace kamd
 					{
 						int32_t ln = ps.lmNode;
 						first = lmProgress(M, ln, 1);
+						SBG_ONLY({ Ring er = loadRing(X.hist + 8ull * (pBeg + p), ps.pad0); first = sbgNext(*X.S, er.h, er.pos, 1u, first); })
 						c += first;
 						if (ps.spState & 1) c -= 2;
 						if (ps.spState & 2) c -= 2;
@@ -1164,6 +1329,7 @@ namespace kamd
 		}
 	}
 
+#ifndef KAMD_SBG
 	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418); one thread per chunk
 	__global__ void __launch_bounds__(64) k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount)
 	{
@@ -1206,6 +1372,7 @@ namespace kamd
 		}
 		res->status = status; res->nPaths = status == CS_OK ? nPaths : 0;
 	}
+#endif
 
 	template<int G>
 	__device__ INL3 void searchChunk(GroupCtx<G>& X, const BatchView& B, const WorkView& W, uint32_t chunk)
@@ -1219,6 +1386,7 @@ namespace kamd
 		X.nodes = W.nodes + nBase; X.Gn = W.nNodes[chunk];
 		X.str = B.chars + cOff; X.cls = B.cls + cOff;
 		X.st = W.states + W.stateBase[chunk]; X.stCap = (uint32_t)(W.stateBase[chunk + 1] - W.stateBase[chunk]); X.stTop = 0;
+		SBG_ONLY(X.hist = X.S->hist + 8ull * W.stateBase[chunk];)
 		X.nodeStOff = W.nodeStateOff + nBase; X.nodeStCnt = W.nodeStateCnt + nBase; X.nodeLive = W.tmpIdx + 2ull * nBase;
 		X.uniq = B.spStates + B.spOff[chunk]; X.nUniq = B.spOff[chunk + 1] - B.spOff[chunk];
 		X.overflow = false; X.pairOverflow = false;
@@ -1253,6 +1421,7 @@ namespace kamd
 		{
 			const MorphRec m0 = M.morphs[0];
 			putState<G>(X, 0, M.h.bosNode, 0.f, 0.f, 0, m0.feat, COMMON_ROOT, 0, 0, m0.prevFlags, 0, 0xFFFFFFFFu, 0, 0.f, 0, 0);
+			SBG_ONLY({ const Ring z{}; storeRing(X.hist, z); })   // SbgState(): empty ring, position 0
 			X.nodeStOff[0] = 0; X.nodeStCnt[0] = 1; X.nodeLive[0] = 1;
 			X.ringBeg()[0] = 0; X.ringEnd()[0] = 1; X.ringCum()[0] = 1;
 		}
@@ -1406,6 +1575,7 @@ namespace kamd
 			// originals passed by reference, every X.field and M.pointer access in the node loop became a scratch load)
 			const ModelView Mc = X.M; const SearchParams Pc = X.P;
 			GroupCtx<G> Y(X, Mc, Pc);
+			SBG_ONLY(const SbgDev Sc = *X.S; Y.S = &Sc;)
 			finishChunk<G>(Y, chunk, openEnding, res);
 		}
 #ifdef KAMD_TIMELINE
@@ -1417,7 +1587,7 @@ namespace kamd
 	// WPS = waves per SIMD the kernel is compiled for (register budget 512 / WPS): 2 is fastest when a batch is small enough
 	// to be latency-bound (c2: 8192 chunks), 3 (with a few spills) when there are chunks to fill the extra wave slots
 	template<int G, int WPS>
-	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork)
+	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S))
 	{
 		constexpr int NG = 64 / G;
 		const uint32_t lane = threadIdx.x;
@@ -1440,6 +1610,7 @@ namespace kamd
 		X.gl = lane % G; X.gshift = gid * G; X.lds = gid * Lay<G>::SIZE;
 		X.scratch = reinterpret_cast<GroupScratch*>(W.bigScratch) + ((size_t)blockIdx.x * NG + gid);
 		X.tl = nullptr;
+		SBG_ONLY(X.S = &S; X.hist = nullptr; X.sscr = reinterpret_cast<SbgScratch*>(S.itemScratch) + ((size_t)blockIdx.x * NG + gid);)
 
 		for (;;)
 		{
@@ -1451,6 +1622,11 @@ namespace kamd
 		}
 	}
 
+#ifdef KAMD_SBG
+	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, SbgDev);
+	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, SbgDev);
+}
+#else
 	template __global__ void k_best_path<4, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<8, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
@@ -1458,4 +1634,5 @@ namespace kamd
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+#endif
 }

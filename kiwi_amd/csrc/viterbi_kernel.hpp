@@ -17,12 +17,24 @@ namespace kamd
 	// scratch in HBM per lane group (items of oversized batches, end-node candidates)
 	struct GroupScratch { uint64_t key[BIGQ]; float score[BIGQ]; float fcs[BIGQ]; };
 
+	// SkipBigram models: LM state of every work item of a batch beyond the Knlm node -- history ring, ring position, and a
+	// 32-bit digest that is compared before the rings are
+	struct SbgScratch { uint32_t hist[BIGQ][8]; uint32_t pos[BIGQ]; uint32_t hash[BIGQ]; };
+
 	uint32_t searchKernelLdsBytes(int G);
 
 	// G = lanes per chunk (4, 8, 16, 32 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
 	// WPS = waves per SIMD the instantiation is compiled for (2, or 3 for G = 8 / 16).
 	template<int G, int WPS>
 	__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork);
+	// The same search for a SkipBigram model (Knlm + skip-bigram mixture, reference src/SkipBigramModel.hpp): the kernel source
+	// compiled a second time with KAMD_SBG defined (viterbi_kernel_sbg.hip), so that the Knlm kernels above stay exactly the
+	// code that was measured.  G = 16 or 64, WPS = 2.
+	namespace sbgk
+	{
+		template<int G, int WPS>
+		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, SbgDev S);
+	}
 	// End stage, one THREAD per chunk: restated std::sort of the end candidates, per-(root, state) selection and the
 	// back-trace into 24-byte tokens.  A separate launch so that 64 chunks share a wavefront in this strictly serial stage.
 	__global__ void k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount);

@@ -1,0 +1,92 @@
+"""GPU (-m gpu): the search kernel for SkipBigram models (kiwi_amd/csrc/viterbi_kernel_sbg.hip) against the CPU oracle, whose
+SkipBigram path is pinned to the real reference by tests/test_oracle_vs_ref.py.
+
+The device SkipBigram path is EXPERIMENTAL: it was written after the round's GPU budget was spent and has not run on a GPU
+yet.  The engine therefore refuses SkipBigram models unless KAMD_EXPERIMENTAL_SBG=1 is set, and the parity tests below are
+skipped without it -- `KAMD_EXPERIMENTAL_SBG=1 python -m pytest tests/test_gpu_sbg.py -m gpu` is the first thing to run on
+a GPU box.  Only the refusal itself is tested unconditionally."""
+import os
+from dataclasses import astuple
+
+import pytest
+
+from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+enabled = pytest.mark.skipif(not os.environ.get("KAMD_EXPERIMENTAL_SBG"), reason="device SkipBigram scoring is experimental: set KAMD_EXPERIMENTAL_SBG=1")
+
+
+def _norm(res):
+    return [([astuple(t) for t in a[0]], a[1]) for a in res]
+
+
+def test_skipbigram_model_is_refused_without_the_flag(small_sbg_model, monkeypatch):
+    from kiwi_amd.api import KiwiAmd
+    monkeypatch.delenv("KAMD_EXPERIMENTAL_SBG", raising=False)
+    with pytest.raises(RuntimeError, match="SkipBigram"):
+        KiwiAmd(small_sbg_model[1])
+
+
+def _texts(sm, seed):
+    return synthetic(sm, 300, seed, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 150, seed + 1) + EDGE_TEXTS
+
+
+@enabled
+@pytest.mark.parametrize("lanes", ["16", "64"])
+@pytest.mark.parametrize("top_n", [1, 2, 3])
+def test_skipbigram_tokens_bit_exact_vs_oracle(small_sbg_model, monkeypatch, lanes, top_n):
+    """Tokens, positions and fp32 scores under Knlm + skip-bigram mixture scoring: history rings in the LM state (container keys
+    compare the whole ring for top-1, the last four words and no root for top-N), glibc-exact exp / log on the device."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_sbg_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path)
+    texts = _texts(sm, 301)
+    got = dev.analyze_batch(texts, top_n=top_n).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (lanes, top_n, s)
+    dev.close()
+
+
+@enabled
+@pytest.mark.parametrize("lanes", ["16", "64"])
+def test_skipbigram_fallback_paths_with_small_capacities(small_sbg_model, monkeypatch, lanes):
+    """The `make smallcaps` build: LDS capacities of 4, container limits 3 / 8 / 2 on both sides (medium container: the bucket
+    hash chains the ring words), and a constant ring digest, so that every pair of items with equal packed keys reaches the
+    exact ring comparison and the register path hands colliding batches over to the scanning path."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_sbg_model
+    lib = os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip_smallcaps.so")
+    if not os.path.exists(lib):
+        pytest.skip("libkiwi_hip_smallcaps.so not built (make -C kiwi_amd/csrc smallcaps)")
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    monkeypatch.setenv("KAMD_CONTAINER_LIMITS", "3,8,2")
+    orc = oraclelib.OracleKiwi(path)
+    orc.set_container_limits(3, 8, 2)
+    dev = KiwiAmd(path, lib_path=lib)
+    texts = _texts(sm, 311)
+    for top_n in (1, 2):
+        got = dev.analyze_batch(texts, top_n=top_n).to_python()
+        for s, y in zip(texts, got):
+            assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (lanes, top_n, s)
+    dev.close()
+
+
+@enabled
+def test_skipbigram_golden_sequence_from_reference(small_sbg_model):
+    """The committed analyses of the real reference under the SkipBigram model (tests/golden/small_sbg_model_sequence.json, top-1):
+    where the reference's large container decided the order of equal-score paths the device may differ (top-N /
+    container order); everything else must be identical, so at least the scores of the best analysis are compared exactly."""
+    import json
+    from kiwi_amd.api import KiwiAmd
+    g = json.load(open(os.path.join(HERE, "golden", "small_sbg_model_sequence.json"), encoding="utf-8"))
+    dev = KiwiAmd(small_sbg_model[1])
+    texts = [it["text"] for it in g["items"]]
+    got = dev.analyze_batch(texts, top_n=g.get("top_n", 1)).to_python()
+    same = sum(1 for it, y in zip(g["items"], got) if y and y[0][1] == it["analyses"][0]["score"])
+    assert same >= 0.99 * len(texts), (same, len(texts))
+    dev.close()
