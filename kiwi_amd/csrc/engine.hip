@@ -432,9 +432,12 @@ namespace kamd
 		const uint32_t nGroups = I.hasSbg ? ((I.groupLanesForced && I.groupLanes == 64) ? 1u : 4u)      // (the SkipBigram kernel: 16-lane groups unless 64 is forced)
 			: 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
-		const uint32_t maxBlocks = std::min(I.persistBlocks, (maxWork + nGroups - 1) / nGroups);
-		I.bigScratch.ensure((size_t)maxBlocks * nGroups * sizeof(GroupScratch) * std::min(S, 2u));
-		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)sizeof(GroupScratch);
+		// (the SkipBigram kernel is built for 2 waves per SIMD and carries 1.8 MB of item scratch per lane group: 8 persistent blocks per CU)
+		const uint32_t persistBlocks = I.hasSbg ? I.persistBlocks / 12 * 8 : I.persistBlocks;
+		const uint32_t maxBlocks = std::min(persistBlocks, (maxWork + nGroups - 1) / nGroups);
+		const size_t groupScratchBytes = I.hasSbg ? sizeof(GroupScratchT<BIGQ_SBG>) : sizeof(GroupScratch);
+		I.bigScratch.ensure((size_t)maxBlocks * nGroups * groupScratchBytes * std::min(S, 2u));
+		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)groupScratchBytes;
 		if (I.hasSbg) I.sbgScratch.ensure((size_t)maxBlocks * nGroups * sizeof(SbgScratch) * std::min(S, 2u));
 		const uint32_t ldsBytes = searchKernelLdsBytes(I.groupLanes);
 		for (uint32_t k = 0; k < S; ++k)
@@ -476,7 +479,7 @@ namespace kamd
 			HIPCHECK(hipMemsetAsync(tlBuf.p, 0, (size_t)nC * 128, sB));
 			wv.beacon = tlBuf.as<uint32_t>(); gTimeline = tlBuf.p;
 #endif
-			wv.bigScratch = I.bigScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(GroupScratch) : 0);
+			wv.bigScratch = I.bigScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * groupScratchBytes : 0);
 			uint32_t* counter = I.counter.as<uint32_t>() + k;
 			const uint32_t* order = b.dOrder.as<uint32_t>() + c0;
 			// lane-group width / register budget: with few chunks the step is bound by the dependent chain of one chunk (16-lane
@@ -486,7 +489,7 @@ namespace kamd
 			const int gl = I.hasSbg ? ((I.groupLanesForced && I.groupLanes == 64) ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
 			const int wps = I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
-			const uint32_t blocksK = std::min(I.persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
+			const uint32_t blocksK = std::min(persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
 			const uint32_t ldsK = searchKernelLdsBytes(gl);
 #define KAMD_LAUNCH(GG, WW) hipLaunchKernelGGL((k_best_path<GG, WW>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn)
 			if (I.hasSbg)

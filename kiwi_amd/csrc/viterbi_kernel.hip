@@ -57,6 +57,9 @@ namespace kamd
 #ifdef KAMD_SBG
 namespace sbgk
 {
+	// (shadow the Knlm kernel's staging capacity and scratch record inside this namespace)
+	constexpr uint32_t BIGQ = BIGQ_SBG;
+	using GroupScratch = GroupScratchT<BIGQ_SBG>;
 #endif
 	constexpr uint64_t KINVALID = ~0ull;
 // Inlining level of the node loop's stages (3 = everything inlined into the kernel: the lane-group context then lives in
@@ -1026,8 +1029,17 @@ namespace sbgk
 		{
 			// general sizes: every path counts the socket-free paths of its root that lie more than cutOff above it; the verdicts
 			// are collected first (one bit per block of G paths in a lane-private mask) and applied after all counting is done
+#ifdef KAMD_SBG
+			// (with rings in the keys a node can gain more than 64 x G paths: the verdicts are parked in the states' spare dword,
+			// DevState::pad1, instead of a lane-private bit mask)
+#define KAMD_VERDICT_SET(i, blk) X.st[E.nodeStart + (i)].pad1 = 1u
+#define KAMD_VERDICT_GET(i, blk) (X.st[E.nodeStart + (i)].pad1 != 0)
+#else
 			if (cnt > 64u * G) { X.pairOverflow = true; return; }
 			uint64_t verdict = 0;
+#define KAMD_VERDICT_SET(i, blk) verdict |= 1ull << (blk)
+#define KAMD_VERDICT_GET(i, blk) ((verdict >> (blk)) & 1)
+#endif
 			for (uint32_t b = 0, blk = 0; b < cnt; b += G, ++blk)
 			{
 				const uint32_t i = b + X.gl;
@@ -1045,19 +1057,21 @@ namespace sbgk
 					else { const DevState* t = &X.st[E.nodeStart + j]; sj = t->accScore; slj = t->rootId == COMMON_ROOT ? 0 : t->rootId + 1u; dj = t->dead; mj = M.morphs[t->morph].socket != 0; }
 					if (!dj && !mj && slj == slot && lim < sj) ++above;
 				}
-				if (above >= P.topN) verdict |= 1ull << blk;
+				if (above >= P.topN) KAMD_VERDICT_SET(i, blk);
 			}
 			waveSync();
 			for (uint32_t b = 0, blk = 0; b < cnt; b += G, ++blk)
 			{
 				const uint32_t i = b + X.gl;
-				if (i < cnt && ((verdict >> blk) & 1))
+				if (i < cnt && KAMD_VERDICT_GET(i, blk))
 				{
 					if (staged) { X.stBits()[i] = X.stBits()[i] | SB_DEAD; markDead<G>(X, E.nodeStart + i); }
 					else markDead<G>(X, E.nodeStart + i);
 				}
 			}
 			waveSync();
+#undef KAMD_VERDICT_SET
+#undef KAMD_VERDICT_GET
 			TLMARK(X, 4)
 			return;
 		}

@@ -15,11 +15,16 @@ namespace kamd
 
 	struct EndCand { float score, fcs, typo; uint32_t parent; uint8_t rootId, sp; uint16_t pad; };
 	// scratch in HBM per lane group (items of oversized batches, end-node candidates)
-	struct GroupScratch { uint64_t key[BIGQ]; float score[BIGQ]; float fcs[BIGQ]; };
+	template<uint32_t Q> struct GroupScratchT { uint64_t key[Q]; float score[Q]; float fcs[Q]; };
+	using GroupScratch = GroupScratchT<BIGQ>;
 
 	// SkipBigram models: LM state of every work item of a batch beyond the Knlm node -- history ring, ring position, and a
 	// 32-bit digest that is compared before the rings are
-	struct SbgScratch { uint32_t hist[BIGQ][8]; uint32_t pos[BIGQ]; uint32_t hash[BIGQ]; };
+	// are.  With rings in the container keys far fewer paths coincide, so nodes collect thousands of incoming paths where the
+	// Knlm search sees tens (7271 live ones, 17682 slots counting pruned paths, on the small synthetic model): this kernel stages up
+	// to BIGQ_SBG items of one batch (1.8 MB of HBM scratch per lane group; compacting pruned paths out of the item list is future work).
+	constexpr uint32_t BIGQ_SBG = 32768;
+	struct SbgScratch { uint32_t hist[BIGQ_SBG][8]; uint32_t pos[BIGQ_SBG]; uint32_t hash[BIGQ_SBG]; };
 
 	uint32_t searchKernelLdsBytes(int G);
 

@@ -1,0 +1,156 @@
+// TEST INFRASTRUCTURE -- the lane scheduler behind tests/hipemu/include/hip/hip_runtime.h (read its header first).
+// One block at a time; every lane of the block is a ucontext fiber; a cross-lane operation is a rendezvous of the running lanes of
+// a convergence domain.  Also defines the dynamic-LDS arrays the kernels declare `extern __shared__`.
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace kamd
+{
+	// dynamic LDS of the product's kernels (lattice_kernels.hip, viterbi_kernel.hip and its SkipBigram compilation): blocks run one
+	// after another, so one buffer of the hardware's size per declaration is enough
+	alignas(16) uint8_t lSmem[160 * 1024];
+	alignas(16) uint8_t kSmem[160 * 1024];
+	namespace sbgk { alignas(16) uint8_t kSmem[160 * 1024]; }
+}
+
+namespace hipemu
+{
+	namespace
+	{
+		constexpr uint32_t MAXT = 1024;
+		constexpr size_t STACK = 512 * 1024;
+		struct Domain { uint32_t arrived = 0; uint64_t gen = 0; Op op = (Op)0; uint64_t active[2] = { 0, 0 }; };
+		struct Lane
+		{
+			ucontext_t uc; bool finished = true; LaneCtx ctx;
+			bool waiting = false; Op waitOp = (Op)0; uint32_t waitBase = 0, waitSize = 0; uint64_t waitGen = 0;
+		};
+		struct Block
+		{
+			std::vector<Lane> lanes; uint32_t n = 0, width = 64;
+			std::map<std::pair<uint32_t, uint32_t>, Domain> domains;     // (first lane, size)
+			uint64_t vals[2][MAXT];
+			uint64_t progress = 0;
+			const std::function<void()>* body = nullptr;
+			ucontext_t sched; int cur = -1;
+			const char* kernel = "";
+		};
+		Block* B = nullptr;
+		std::vector<char*> stacks;
+		std::mutex launchMu;
+
+		void trampoline()
+		{
+			(*B->body)();
+			Lane& l = B->lanes[B->cur];
+			l.finished = true; ++B->progress;
+			swapcontext(&l.uc, &B->sched);
+		}
+		uint32_t running(uint32_t base, uint32_t size, uint64_t* mask)
+		{
+			uint32_t c = 0; uint64_t m = 0;
+			for (uint32_t i = 0; i < size && base + i < B->n; ++i) if (!B->lanes[base + i].finished) { ++c; if (i < 64) m |= 1ull << i; }
+			if (mask) *mask = m;
+			return c;
+		}
+		const char* opName(Op o)
+		{
+			switch (o) { case OP_BALLOT: return "__ballot"; case OP_SHFL: return "__shfl"; case OP_SHFL_UP: return "__shfl_up"; case OP_SHFL_XOR: return "__shfl_xor";
+			case OP_DPP: return "dpp row_ror"; case OP_WAVE_BARRIER: return "wave_barrier"; case OP_SYNCTHREADS: return "__syncthreads"; default: return "?"; }
+		}
+		[[noreturn]] void die(const char* why)
+		{
+			std::fprintf(stderr, "hipemu: %s in kernel %s, block %u\n", why, B->kernel, B->lanes[0].ctx.bid.x);
+			for (uint32_t i = 0; i < B->n; ++i)
+			{
+				const Lane& l = B->lanes[i];
+				if (l.finished) continue;
+				std::fprintf(stderr, "  lane %3u: %s", i, l.waiting ? "waits at " : "runnable");
+				if (l.waiting) std::fprintf(stderr, "%s (domain %u+%u, generation %llu)", opName(l.waitOp), l.waitBase, l.waitSize, (unsigned long long)l.waitGen);
+				std::fprintf(stderr, "\n");
+			}
+			std::abort();
+		}
+	}
+
+	LaneCtx& ctx() { return B->lanes[B->cur].ctx; }
+	uint32_t width() { return B->width; }
+
+	const uint64_t* exchange(Op op, uint32_t domain, uint64_t mine, uint64_t* active, uint32_t* domainBase)
+	{
+		const uint32_t self = (uint32_t)B->cur;
+		const uint32_t size = domain ? domain : B->width;
+		const uint32_t base = self / size * size;
+		Domain& d = B->domains[{ base, size }];
+		Lane& l = B->lanes[self];
+		if (d.arrived == 0) d.op = op;
+		else if (d.op != op)
+		{
+			l.waiting = true; l.waitOp = op; l.waitBase = base; l.waitSize = size; l.waitGen = d.gen;
+			die("lanes of one convergence domain arrived at different cross-lane operations (divergent control flow around a cross-lane operation)");
+		}
+		const uint64_t g = d.gen;
+		B->vals[g & 1][self] = mine;
+		++d.arrived; ++B->progress;
+		l.waiting = true; l.waitOp = op; l.waitBase = base; l.waitSize = size; l.waitGen = g;
+		for (;;)
+		{
+			if (d.gen != g) break;                                   // completed by another lane
+			uint64_t mask;
+			if (d.arrived == running(base, size, &mask)) { d.active[g & 1] = mask; d.arrived = 0; ++d.gen; ++B->progress; break; }
+			swapcontext(&l.uc, &B->sched);
+		}
+		l.waiting = false;
+		*active = d.active[g & 1]; *domainBase = base;
+		return B->vals[g & 1];
+	}
+
+	void launch(const char* name, dim3 grid, dim3 block, size_t ldsBytes, const std::function<void()>& laneBody)
+	{
+		std::lock_guard<std::mutex> lk{ launchMu };
+		if (block.x > MAXT || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1 || ldsBytes > 160 * 1024) { std::fprintf(stderr, "hipemu: unsupported launch shape of %s\n", name); std::abort(); }
+		// convergence width: the lane-group width of k_best_path<G, ...>, else the wavefront
+		uint32_t width = 64;
+		const std::string nm{ name };
+		const size_t at = nm.find("k_best_path<");
+		if (at != std::string::npos) width = (uint32_t)std::atoi(nm.c_str() + at + 12);
+		if (width == 0 || width > 64 || (width & (width - 1))) { std::fprintf(stderr, "hipemu: cannot read the lane-group width out of '%s'\n", name); std::abort(); }
+		Block blk; blk.n = block.x; blk.width = width; blk.body = &laneBody; blk.kernel = name;
+		blk.lanes.resize(block.x);
+		while (stacks.size() < block.x) stacks.push_back((char*)std::malloc(STACK));
+		Block* outer = B;      // (a kernel never launches a kernel; kept for symmetry)
+		for (uint32_t b = 0; b < grid.x; ++b)
+		{
+			B = &blk;
+			blk.domains.clear(); blk.progress = 0;
+			for (uint32_t t = 0; t < block.x; ++t)
+			{
+				Lane& l = blk.lanes[t];
+				l.finished = false; l.waiting = false;
+				l.ctx.tid = dim3(t); l.ctx.bid = dim3(b); l.ctx.bdim = block; l.ctx.gdim = grid;
+				getcontext(&l.uc);
+				l.uc.uc_stack.ss_sp = stacks[t]; l.uc.uc_stack.ss_size = STACK; l.uc.uc_link = nullptr;
+				makecontext(&l.uc, trampoline, 0);
+			}
+			for (;;)
+			{
+				const uint64_t before = blk.progress;
+				bool any = false;
+				for (uint32_t t = 0; t < block.x; ++t)
+				{
+					if (blk.lanes[t].finished) continue;
+					any = true; blk.cur = (int)t;
+					swapcontext(&blk.sched, &blk.lanes[t].uc);
+				}
+				if (!any) break;
+				if (blk.progress == before) die("no lane can make progress (a cross-lane operation some lanes of the domain never reach)");
+			}
+		}
+		B = outer;
+	}
+}

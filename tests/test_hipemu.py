@@ -1,0 +1,157 @@
+"""CPU (not gpu): the product's HIP kernels EXECUTED on the host, lane by lane, by the test-only emulator of tests/hipemu
+(the product's sources compiled as C++ against a stand-in <hip/hip_runtime.h>: lanes are fibers, cross-lane operations are
+rendezvous of a convergence domain -- see tests/hipemu/include/hip/hip_runtime.h), called through the same C ABI and compared
+with the CPU oracle exactly like the GPU parity suite does.
+
+What this adds to `-m gpu`: the kernels' logic -- every lane-group instantiation, the fallback paths of the `smallcaps`
+configuration, top-N, and the SkipBigram kernel that has not seen a GPU yet -- is checked wherever the CPU suite runs, and a
+cross-lane operation in divergent control flow aborts with a lane-by-lane report instead of hanging a GPU.  What it cannot
+show: anything about timing, occupancy, the compiler's gfx950 code, or memory-model races.  The emulated library is never
+the product: only this file loads it (explicit lib_path); kiwi_amd/ has no reference to it."""
+import os
+import subprocess
+from dataclasses import astuple
+
+import pytest
+
+from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "hipemu")
+
+
+@pytest.fixture(scope="module")
+def emu_libs():
+    subprocess.check_call(["make", "-C", EMU, "-j8"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", EMU, "smallcaps", "-j8"], stdout=subprocess.DEVNULL)
+    return os.path.join(EMU, "_build", "libkiwi_hipemu.so"), os.path.join(EMU, "_build", "libkiwi_hipemu_smallcaps.so")
+
+
+def _norm(res):
+    return [([astuple(t) for t in a[0]], a[1]) for a in res]
+
+
+def _check(dev, orc, texts, top_ns=(1,)):
+    for top_n in top_ns:
+        got = dev.analyze_batch(texts, top_n=top_n).to_python()
+        for s, y in zip(texts, got):
+            assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (top_n, s)
+
+
+def test_the_product_library_is_not_the_emulator(emu_libs):
+    from kiwi_amd import api
+    assert "hipemu" not in api.LIB_PATH and os.path.basename(api.LIB_PATH) == "libkiwi_hip.so"
+    for root, _, files in os.walk(os.path.join(os.path.dirname(HERE), "kiwi_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", "Makefile")):
+                assert "hipemu" not in open(os.path.join(root, f), encoding="utf-8", errors="ignore").read(), f
+
+
+@pytest.mark.parametrize("lanes,wps", [("16", "2"), ("16", "3"), ("8", "3"), ("8", "2"), ("4", "2"), ("32", "2"), ("64", "2")])
+def test_emulated_knlm_kernels_match_oracle(emu_libs, oracle, small_model, monkeypatch, lanes, wps):
+    """Dictionary scan, lattice build (LDS and HBM variants), candidate expansion, best-path search in every lane-group
+    instantiation, end stage: tokens, positions and fp32 scores equal the oracle's, top-1 and top-2."""
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    if lanes in ("8", "16"):
+        monkeypatch.setenv("KAMD_WPS", wps)
+    n = 100 if lanes == "16" and wps == "2" else 40
+    texts = synthetic(sm, n, 521, min_jamo=5, max_jamo=120) + dictionary_mix(sm, n // 2, 522) + (EDGE_TEXTS if n == 100 else [])
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    _check(dev, oracle, texts, (1, 2))
+    if n == 100:
+        for s in texts[:60]:
+            if s.strip():
+                assert dev.split(s) == oracle.split(s), s
+    dev.close()
+
+
+@pytest.mark.parametrize("lanes", ["16", "8", "64"])
+def test_emulated_fallback_paths_with_small_capacities(emu_libs, small_model, monkeypatch, lanes):
+    """The `smallcaps` configuration (LDS capacities of 4) with the container limits cut to 3 / 8 / 2 on both sides:
+    medium / large containers, HBM work-item queue, HBM pruning path, far-back node lookup."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    monkeypatch.setenv("KAMD_CONTAINER_LIMITS", "3,8,2")
+    orc = oraclelib.OracleKiwi(path)
+    orc.set_container_limits(3, 8, 2)
+    dev = KiwiAmd(path, lib_path=emu_libs[1])
+    _check(dev, orc, synthetic(sm, 50, 531, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 25, 532), (1, 2))
+    dev.close()
+
+
+def test_emulated_lattice_hbm_kernel_and_rerun_ladder(emu_libs, oracle, small_model, monkeypatch):
+    """KAMD_LATTICE_LDS=0 sends every chunk to the thread-per-chunk lattice kernel; KAMD_TEST_TINY_ARENAS makes most chunks
+    climb the capacity ladder (re-runs with 4x / 16x / 64x arenas)."""
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    texts = synthetic(sm, 40, 541, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 20, 542)
+    monkeypatch.setenv("KAMD_LATTICE_LDS", "0")
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    _check(dev, oracle, texts)
+    dev.close()
+    monkeypatch.delenv("KAMD_LATTICE_LDS")
+    monkeypatch.setenv("KAMD_TEST_TINY_ARENAS", "1")
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    _check(dev, oracle, texts)
+    dev.close()
+
+
+@pytest.mark.parametrize("lanes,top_n", [("16", 1), ("16", 2), ("16", 3), ("64", 1), ("64", 2)])
+def test_emulated_skipbigram_kernel_matches_oracle(emu_libs, small_sbg_model, monkeypatch, lanes, top_n):
+    """The SkipBigram search kernel (viterbi_kernel_sbg.hip; gated on the device until it has passed tests/test_gpu_sbg.py on a
+    GPU): history rings in the LM state, ring-aware container keys (whole ring for top-1, last four words and no root for top-N),
+    glibc-exact exp / log -- against the oracle, which is pinned to the real reference's SkipBigram path.  Nodes of these lattices
+    carry up to thousands of incoming paths, so the large-container / HBM-queue path does most of the work here."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_sbg_model
+    monkeypatch.setenv("KAMD_EXPERIMENTAL_SBG", "1")
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    n = 40 if top_n == 1 else 60
+    texts = synthetic(sm, n, 551, min_jamo=5, max_jamo=70 if top_n == 1 else 120) + dictionary_mix(sm, n // 2, 552) + EDGE_TEXTS
+    _check(dev, orc, texts, (top_n,))
+    dev.close()
+
+
+@pytest.mark.parametrize("lanes", ["16", "64"])
+def test_emulated_skipbigram_fallback_paths(emu_libs, small_sbg_model, monkeypatch, lanes):
+    """SkipBigram kernel in the `smallcaps` configuration: tiny LDS capacities, container limits 3 / 8 / 2 on both sides (the medium
+    container's bucket hash chains the ring words), and a constant ring digest, so that every pair of items with equal packed
+    keys reaches the exact ring comparison and the register path hands colliding batches over to the scanning path."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_sbg_model
+    monkeypatch.setenv("KAMD_EXPERIMENTAL_SBG", "1")
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    monkeypatch.setenv("KAMD_CONTAINER_LIMITS", "3,8,2")
+    orc = oraclelib.OracleKiwi(path)
+    orc.set_container_limits(3, 8, 2)
+    dev = KiwiAmd(path, lib_path=emu_libs[1])
+    _check(dev, orc, synthetic(sm, 30, 561, min_jamo=5, max_jamo=70) + dictionary_mix(sm, 15, 562), (1, 2))
+    dev.close()
+
+
+def test_emulated_skipbigram_golden_sequence(emu_libs, small_sbg_model, monkeypatch):
+    """Emulated SkipBigram kernel against the committed outputs of the REAL reference (tests/golden/small_sbg_model_sequence.json).
+    The reference's large container hands equal-score paths on in a history-dependent order (top-N), so a tie may pick
+    another analysis; the best score of every text must still be the reference's, bit for bit."""
+    import json
+    from kiwi_amd.api import KiwiAmd
+    g = json.load(open(os.path.join(HERE, "golden", "small_sbg_model_sequence.json"), encoding="utf-8"))
+    monkeypatch.setenv("KAMD_EXPERIMENTAL_SBG", "1")
+    dev = KiwiAmd(small_sbg_model[1], lib_path=emu_libs[0])
+    items = [it for it in g["items"] if len(it["text"]) <= 60][:60]
+    got = dev.analyze_batch([it["text"] for it in items], top_n=g["top_n"]).to_python()
+    exact = 0
+    for it, y in zip(items, got):
+        assert y[0][1] == it["analyses"][0]["score"], it["text"]
+        toks = [[t.form, t.tag, t.position, t.length, t.word_position, t.sent_position, t.sense_id, t.morph_id, t.score] for t in y[0][0]]
+        exact += toks == it["analyses"][0]["tokens"]
+    assert exact >= 0.9 * len(items), (exact, len(items))
+    dev.close()
