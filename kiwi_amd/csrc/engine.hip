@@ -438,7 +438,13 @@ namespace kamd
 		const size_t groupScratchBytes = I.hasSbg ? sizeof(GroupScratchT<BIGQ_SBG>) : sizeof(GroupScratch);
 		I.bigScratch.ensure((size_t)maxBlocks * nGroups * groupScratchBytes * std::min(S, 2u));
 		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)groupScratchBytes;
-		if (I.hasSbg) I.sbgScratch.ensure((size_t)maxBlocks * nGroups * sizeof(SbgScratch) * std::min(S, 2u));
+		if (I.hasSbg)
+		{
+			// the kernel's key hash tables (SbgScratch::table) are handed over all-zero and left all-zero by every batch
+			const void* before = I.sbgScratch.p;
+			I.sbgScratch.ensure((size_t)maxBlocks * nGroups * sizeof(SbgScratch) * std::min(S, 2u));
+			if (I.sbgScratch.p != before) HIPCHECK(hipMemsetAsync(I.sbgScratch.p, 0, I.sbgScratch.cap, sA));
+		}
 		const uint32_t ldsBytes = searchKernelLdsBytes(I.groupLanes);
 		for (uint32_t k = 0; k < S; ++k)
 		{

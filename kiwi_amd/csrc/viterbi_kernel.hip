@@ -740,6 +740,43 @@ namespace sbgk
 #endif
 		{
 			const int nBuckets = mode == 1 ? 4 : 1;
+#ifdef KAMD_SBG
+			// top-1: representative and winner of every container key through a hash table in the group's HBM scratch (one slot
+			// per key, claimed by compare-and-swap, settled by atomic max) -- with rings in the keys a node gathers thousands of
+			// items per candidate, far too many for every item to scan its candidate's list.  top-N keeps the scan (its keys hold
+			// only the last four ring words, and the N-th-best pruning keeps those lists short).
+			const bool hashed = X.P.topN == 1;
+			constexpr uint32_t TMASK = 2 * BIGQ_SBG - 1;
+			if (hashed)
+			{
+				for (uint32_t qb = 0; qb < Qtot; qb += G)
+				{
+					const uint32_t q = qb + X.gl;
+					if (q >= Qtot) continue;
+					const uint64_t key = big ? X.scratch->key[q] : X.qKey()[q];
+					if (key == KINVALID) continue;
+					const Ring myRing = loadRing(X.sscr->hist[q], X.sscr->pos[q]); const uint32_t myDigest = X.sscr->hash[q];
+					uint32_t h = (uint32_t)key * 0x9E3779B1u ^ (uint32_t)(key >> 32) * 0x85EBCA77u ^ myDigest; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+					SbgSlot* e;
+					for (h &= TMASK; ; h = (h + 1) & TMASK)
+					{
+						e = &X.sscr->table[h];
+						uint32_t o = atomicCAS(&e->owner, 0u, q + 1u);
+						if (o == 0) break;                      // claimed a free slot: a new key
+						o -= 1;
+						if (o == q) break;
+						const uint64_t ko = big ? X.scratch->key[o] : X.qKey()[o];
+						if (ko == key && X.sscr->hash[o] == myDigest && sameRing(loadRing(X.sscr->hist[o], X.sscr->pos[o]), myRing, false)) break;
+					}
+					const uint32_t sb = __float_as_uint(big ? X.scratch->score[q] : X.qScore()[q]);
+					const uint32_t ord = (sb & 0x80000000u) ? ~sb : (sb | 0x80000000u);      // order-preserving image of the fp32 score
+					atomicMax(&e->firstInv, 0xFFFFFFFFu - q);
+					atomicMax(&e->best, ((unsigned long long)ord << 32) | (unsigned long long)(0xFFFFFFFFu - q));
+					X.sscr->slot[q] = h;
+				}
+				waveSync();
+			}
+#endif
 			for (int b = 0; b < nBuckets; ++b)
 			{
 				uint32_t emittedInBucket = 0;
@@ -779,6 +816,15 @@ namespace sbgk
 							}
 							rep = beaten < X.P.topN;      // qw stays q: every kept item is written with its own values
 						}
+#ifdef KAMD_SBG
+						else if (hashed)
+						{
+							// (atomic reads: the slot was settled by atomics of other lanes, a plain load could be served from a stale cache line)
+							SbgSlot* e = &X.sscr->table[X.sscr->slot[q]];
+							rep = (0xFFFFFFFFu - atomicMax(&e->firstInv, 0u)) == q;
+							qw = 0xFFFFFFFFu - (uint32_t)atomicMax(&e->best, 0ull);
+						}
+#endif
 						else
 						{
 						for (uint32_t j = lo; j < hi; ++j)
@@ -827,6 +873,22 @@ namespace sbgk
 					emittedInBucket += __popcll(bal);
 				}
 			}
+#ifdef KAMD_SBG
+			if (hashed)
+			{
+				// leave the table as it was found: every item frees the slot of its key
+				waveSync();
+				for (uint32_t qb = 0; qb < Qtot; qb += G)
+				{
+					const uint32_t q = qb + X.gl;
+					if (q >= Qtot) continue;
+					const uint64_t key = big ? X.scratch->key[q] : X.qKey()[q];
+					if (key == KINVALID) continue;
+					SbgSlot* e = &X.sscr->table[X.sscr->slot[q]];
+					atomicExch(&e->owner, 0u); atomicExch(&e->firstInv, 0u); atomicExch(&e->best, 0ull);
+				}
+			}
+#endif
 		}
 		X.overflow = X.any(X.overflow);
 		X.stageOverflow = X.any(X.stageOverflow);

@@ -24,7 +24,12 @@ namespace kamd
 	// Knlm search sees tens (7271 live ones, 17682 slots counting pruned paths, on the small synthetic model): this kernel stages up
 	// to BIGQ_SBG items of one batch (1.8 MB of HBM scratch per lane group; compacting pruned paths out of the item list is future work).
 	constexpr uint32_t BIGQ_SBG = 32768;
-	struct SbgScratch { uint32_t hist[BIGQ_SBG][8]; uint32_t pos[BIGQ_SBG]; uint32_t hash[BIGQ_SBG]; };
+	// Top-1 de-duplication of a staged batch by hashing instead of scanning (thousands of items per candidate): one slot per
+	// container key.  All-zero = free, which is how the engine hands the table over and how every batch leaves it.
+	struct SbgSlot { uint32_t owner;      // item that claimed the slot, + 1
+		uint32_t firstInv;                 // 0xFFFFFFFF - (earliest item of the key)            (atomicMax)
+		unsigned long long best; };        // orderable(score) << 32 | 0xFFFFFFFF - item: the key's winner, first on ties (atomicMax)
+	struct SbgScratch { uint32_t hist[BIGQ_SBG][8]; uint32_t pos[BIGQ_SBG]; uint32_t hash[BIGQ_SBG]; uint32_t slot[BIGQ_SBG]; SbgSlot table[2 * BIGQ_SBG]; };
 
 	uint32_t searchKernelLdsBytes(int G);
 

@@ -124,6 +124,8 @@ inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); r
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 template<class T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }      // lanes are fibers of one thread
 template<class T> inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
+template<class T> inline T atomicCAS(T* p, T cmp, T v) { const T o = *p; if (o == cmp) *p = v; return o; }
+template<class T> inline T atomicExch(T* p, T v) { const T o = *p; *p = v; return o; }
 template<class T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
 template<class T> inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
 inline unsigned long long wall_clock64() { return 0; }
