@@ -11,7 +11,8 @@ from corpora import EDGE_TEXTS, dictionary_mix, synthetic
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip.so")
+# KAMD_TEST_LIB: tests/test_hipemu.py re-runs this file on the CPU against the lane-emulated build of the same sources
+LIB = os.environ.get("KAMD_TEST_LIB") or os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip.so")
 MATCH_ALL_WITH_NORMALIZING = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 23) | (1 << 16)
 
 
@@ -251,7 +252,7 @@ def test_c_client_program(oracle, small_model, tmp_path):
     root = os.path.dirname(HERE)
     exe = str(tmp_path / "kiwi_client")
     subprocess.check_call(["gcc", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(HERE, "c_client", "client.c"),
-                           "-L" + os.path.join(root, "kiwi_amd"), "-lkiwi_hip", "-Wl,-rpath," + os.path.join(root, "kiwi_amd"), "-o", exe])
+                           LIB, "-Wl,-rpath," + os.path.dirname(LIB), "-o", exe])
     texts = [t for t in synthetic(sm, 200, 171, min_jamo=5, max_jamo=100) if "\n" not in t and "\r" not in t and t.strip()]
     corpus = tmp_path / "corpus.txt"
     corpus.write_text("\n".join(texts) + "\n", encoding="utf-8")
