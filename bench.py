@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def cpu_baseline(model_path, texts, budget_s=20.0):
+def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1):
     """Times the CPU path on this box's host cores on a bounded sample of the same workload.
     Uses the real reference TUs (oracle/_ref) when the prebuilt library travelled with the repo, else this
     repo's CPU oracle ("port").  Also returns the oracle's ALG_BYTES event counts on its sample."""
@@ -27,9 +27,11 @@ def cpu_baseline(model_path, texts, budget_s=20.0):
     import refbridge
     cores = os.cpu_count() or 1
     orc = oraclelib.OracleKiwi(model_path)
-    sample = texts[:2048]
+    # single-thread sample: 2048 sentences, fewer when the model is slow on the CPU (SkipBigram lattices: tens of sentences/s)
+    probe, _ = orc.analyze_batch(texts[:32], top_n=top_n, threads=1)
+    sample = texts[:int(min(2048, max(32, 32 / max(probe, 1e-6) * 4.0)))]
     orc.counters(reset=True)
-    sec1, _ = orc.analyze_batch(sample, threads=1)
+    sec1, _ = orc.analyze_batch(sample, top_n=top_n, threads=1)
     counts = orc.counters()
     alg = oraclelib.alg_bytes(counts)
     per_sentence = {k: v / len(sample) for k, v in alg.items()}
@@ -39,10 +41,10 @@ def cpu_baseline(model_path, texts, budget_s=20.0):
         kind, runner = "reference", ref
     else:
         kind, runner = "port", orc
-    s1, _ = runner.analyze_batch(sample, threads=1)
+    s1, _ = runner.analyze_batch(sample, top_n=top_n, threads=1)
     rate1 = len(sample) / s1
-    n_mt = int(min(len(texts), max(2048, rate1 * cores * budget_s / 4)))
-    smt, _ = runner.analyze_batch(texts[:n_mt], threads=cores)
+    n_mt = int(min(len(texts), max(min(2048, 4 * cores), rate1 * cores * budget_s / 4)))
+    smt, _ = runner.analyze_batch(texts[:n_mt], top_n=top_n, threads=cores)
     out["cpu_baseline"] = {"value": n_mt / smt, "unit": "sentences/s", "cores": cores, "kind": kind,
                            "sample": f"{n_mt} sentences of the same workload on {cores} threads; single thread: {rate1:.0f} sentences/s on {len(sample)}"}
     return out
@@ -73,7 +75,7 @@ def main():
     import torch
     from kiwi_amd import dist
     from kiwi_amd.api import KiwiAmd
-    from kiwi_amd.workloads import get_workload
+    from kiwi_amd.workloads import get_workload, workload_top_n
     rank, local_rank, world = dist.env_rank_world()
     if world > 1:
         dist.init("nccl", local_rank)
@@ -87,9 +89,13 @@ def main():
     n = len(texts)
     shard = dist.weak_shard(texts, rank)
 
+    top_n = workload_top_n(args.workload)
     eng = KiwiAmd(model_path, local_rank)
     batch = eng.stage(shard)
     info = batch.info()
+    if top_n > 1:
+        eng.run(batch)
+        eng.fetch(batch, top_n).close()     # a batch keeps the top-N of its last fetch: every run below searches with it
 
     def sync():
         torch.cuda.synchronize()
@@ -111,7 +117,7 @@ def main():
         kt[k] /= args.steps
 
     # sanity: the staged batch really was analysed (token count > 0, no failed chunk)
-    res = eng.fetch(batch)
+    res = eng.fetch(batch, top_n)
     n_tok = sum(res.lib.kamd_res_token_num(res.h, i, 0) for i in range(min(256, n)))
     assert n_tok > 0
     summary = dist.gather_counts([n, n_tok], device="cuda" if world > 1 else "cpu")   # the only result "gather": per-rank counts
@@ -121,7 +127,7 @@ def main():
         total_sent = n * world * args.steps
         value = total_sent / elapsed
         out = {
-            "metric": "sentences/sec on batched analyze() (dictionary scan + lattice + Viterbi/Knlm, top-1)",
+            "metric": "sentences/sec on batched analyze() (dictionary scan + lattice + Viterbi/%s, top-%d)" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "Knlm", top_n),
             "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32+f32", "data": "synthetic",
@@ -130,7 +136,7 @@ def main():
                        "kernel_ms": kt, "device_bytes": info["device_bytes"]},
         }
         if not args.no_cpu_baseline:
-            cb = cpu_baseline(model_path, texts)
+            cb = cpu_baseline(model_path, texts, top_n=top_n)
             per = cb["alg_bytes_per_sentence"]
             search_bytes = per["search"] * n
             achieved = search_bytes / (kt["search_ms"] * 1e-3) / 1e9

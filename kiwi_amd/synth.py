@@ -301,6 +301,8 @@ class SynthSpec:
 
 FULL_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
                       n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3)  # order 3: build_knlm packs an n-gram into 63 bits
+FULL_SBG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
+                          n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_sbg=True)   # FULL_SPEC + skip-bigram tables (32-bit keys)
 SMALL_SPEC = SynthSpec()
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
 

@@ -14,6 +14,8 @@ WORKLOADS = {
     # name: (spec name, n sentences, corpus kwargs, seed offset)  -- seeds follow BASELINE.md ("KIWI" + config index)
     "c2": ("full", 8192, dict(exact_jamo=40), 2),
     "c3": ("full", 65536, dict(min_jamo=5, max_jamo=200), 3),
+    # BASELINE config 3 proper: SkipBigram model, top-3 (device kernel experimental: needs KAMD_EXPERIMENTAL_SBG=1)
+    "c3-sbg": ("full-sbg", 65536, dict(min_jamo=5, max_jamo=200), 3),
     "small-c2": ("small", 8192, dict(exact_jamo=40), 2),
     # c2 at the batch size the north-star throughput target is quoted on (>= 64k sentences): the throughput regime
     "c2-64k": ("full", 65536, dict(exact_jamo=40), 12),
@@ -21,8 +23,8 @@ WORKLOADS = {
 
 
 def _spec(name):
-    from .synth import FULL_SPEC, SMALL_SPEC
-    return {"full": FULL_SPEC, "small": SMALL_SPEC}[name]
+    from .synth import FULL_SBG_SPEC, FULL_SPEC, SMALL_SPEC
+    return {"full": FULL_SPEC, "full-sbg": FULL_SBG_SPEC, "small": SMALL_SPEC}[name]
 
 
 def get_workload(name: str):
@@ -44,5 +46,10 @@ def get_workload(name: str):
     with open(corpus_path, encoding="utf-8") as f:
         texts = f.read().split("\n")
     assert len(texts) == n, (len(texts), n)
-    desc = f"{name}: {n} synthetic sentences ({kw}), synthetic '{spec_name}' model (kiwi_amd/synth.py), Knlm, top-1"
+    lm = "Knlm + SkipBigram, top-3" if spec_name.endswith("-sbg") else "Knlm, top-1"
+    desc = f"{name}: {n} synthetic sentences ({kw}), synthetic '{spec_name}' model (kiwi_amd/synth.py), {lm}"
     return model_path, texts, desc
+
+
+def workload_top_n(name: str) -> int:
+    return 3 if WORKLOADS[name][0].endswith("-sbg") else 1

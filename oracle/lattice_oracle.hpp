@@ -35,6 +35,8 @@ namespace korc
 		uint64_t inputUnits = 0, trieProbes = 0, trieProbeKeyBytes = 0, failHops = 0, candEmits = 0, otherNodes = 0;
 		uint64_t transitions = 0, candMorphs = 0, statesWritten = 0, lmProbes = 0, lmProbeKeyBytes = 0, lmRootProbes = 0, tokens = 0;
 		uint64_t maxPrevPaths = 0, nodesOver128 = 0, nodesOver512 = 0, lattNodes = 0;
+		// SkipBigram extra (SURVEY.md §8(d) "SBG extra"): evaluate() calls, key bytes of their 8 partner searches, hits; sbgModel = the model has the tables
+		uint64_t sbgEvals = 0, sbgProbeKeyBytes = 0, sbgHits = 0, sbgModel = 0;
 	};
 
 	struct SplitConfig { uint64_t match; uint32_t maxUnk, maxUnkJ, spaceTol; };

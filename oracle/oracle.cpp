@@ -235,10 +235,10 @@ extern "C"
 		return std::chrono::duration<double>(t1 - t0).count();
 	}
 
-	void korc_counters(void* hp, uint64_t* out17, int reset)
+	void korc_counters(void* hp, uint64_t* out21, int reset)
 	{
 		auto& h = *(OracleHandle*)hp;
-		std::memcpy(out17, &h.counters, sizeof(Counters));
+		std::memcpy(out21, &h.counters, sizeof(Counters));
 		if (reset) h.counters = Counters{};
 	}
 }

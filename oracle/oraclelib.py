@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 
 COUNTER_NAMES = ["inputUnits", "trieProbes", "trieProbeKeyBytes", "failHops", "candEmits", "otherNodes",
                  "transitions", "candMorphs", "statesWritten", "lmProbes", "lmProbeKeyBytes", "lmRootProbes", "tokens",
-                 "maxPrevPaths", "nodesOver128", "nodesOver512", "lattNodes"]
+                 "maxPrevPaths", "nodesOver128", "nodesOver512", "lattNodes", "sbgEvals", "sbgProbeKeyBytes", "sbgHits", "sbgModel"]
 
 
 def available() -> bool:
@@ -125,6 +125,9 @@ def alg_bytes(c: dict) -> dict:
     Returns the split used by bench.py: dictionary scan + lattice build ('lattice') and best-path search ('search')."""
     lattice = (2 * c["inputUnits"] + c["trieProbes"] * (12 + 4) + c["trieProbeKeyBytes"] + c["failHops"] * 8
                + c["candEmits"] * (16 + 24) + c["otherNodes"] * 24)
-    search = (c["transitions"] * 32 + c["candMorphs"] * 16 + c["statesWritten"] * 32
-              + c["lmProbes"] * (20 + 4) + c["lmProbeKeyBytes"] + c["lmRootProbes"] * 4 + c["tokens"] * 24)
+    state = 48 if c.get("sbgModel") else 32     # S: the SkipBigram state carries the 8-word history ring (SURVEY.md section 8(d))
+    search = (c["transitions"] * state + c["candMorphs"] * 16 + c["statesWritten"] * state
+              + c["lmProbes"] * (20 + 4) + c["lmProbeKeyBytes"] + c["lmRootProbes"] * 4 + c["tokens"] * 24
+              # "SBG extra": per evaluate() 8 B row pointers + 8 discounts + the key bytes of 8 partner searches + 4 B per hit
+              + c.get("sbgEvals", 0) * (8 + 8 * 4) + c.get("sbgProbeKeyBytes", 0) + c.get("sbgHits", 0) * 4)
     return {"lattice": lattice, "search": search, "total": lattice + search}

@@ -169,11 +169,13 @@ namespace korc
 					float arr[16];
 					for (int i = 0; i < 8; ++i) { arr[i] = ll; arr[8 + i] = -INFINITY; }
 					const uint32_t* kb = S.keys + S.ptrs[next]; const uint32_t* ke = S.keys + S.ptrs[next + 1];
+					cnt.sbgEvals++; cnt.sbgModel = 1;
+					cnt.sbgProbeKeyBytes += 8ull * 2 * log2c((uint32_t)(ke - kb)) * M.h.lmKeyBytes;
 					for (int i = 0; i < 8; ++i)
 					{
 						arr[i] = S.discnts[st.hist[i]] + ll;
 						const uint32_t* it = std::lower_bound(kb, ke, st.hist[i]);
-						if (it != ke && *it == st.hist[i]) arr[8 + i] = S.comps[S.ptrs[next] + (it - kb)];
+						if (it != ke && *it == st.hist[i]) { arr[8 + i] = S.comps[S.ptrs[next] + (it - kb)]; cnt.sbgHits++; }
 					}
 					const float mx = *std::max_element(arr, arr + 16);
 					float sum = 0;
