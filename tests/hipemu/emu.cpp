@@ -9,6 +9,17 @@
 #include <string>
 #include <vector>
 
+// Sanitizer builds (`make asan`): AddressSanitizer has to be told about every stack switch
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+extern "C" void __sanitizer_start_switch_fiber(void** fakeStackSave, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fakeStackSave, const void** bottomOld, size_t* sizeOld);
+extern "C" void __asan_poison_memory_region(void const volatile* addr, size_t size);
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+#endif
+#endif
+
 namespace kamd
 {
 	// dynamic LDS of the product's kernels (lattice_kernels.hip, viterbi_kernel.hip and its SkipBigram compilation): blocks run one
@@ -39,17 +50,34 @@ namespace hipemu
 			const std::function<void()>* body = nullptr;
 			ucontext_t sched; int cur = -1;
 			const char* kernel = "";
+			const void* schedStack = nullptr; size_t schedStackSize = 0;     // (AddressSanitizer builds: the launching thread's stack)
 		};
 		Block* B = nullptr;
 		std::vector<char*> stacks;
 		std::mutex launchMu;
 
+		// lane -> scheduler
+		void yieldToScheduler(Lane& l, bool dying)
+		{
+#ifdef HIPEMU_ASAN
+			void* fake = nullptr;
+			__sanitizer_start_switch_fiber(dying ? nullptr : &fake, B->schedStack, B->schedStackSize);
+#endif
+			swapcontext(&l.uc, &B->sched);
+#ifdef HIPEMU_ASAN
+			__sanitizer_finish_switch_fiber(fake, &B->schedStack, &B->schedStackSize);
+#endif
+			(void)dying;
+		}
 		void trampoline()
 		{
+#ifdef HIPEMU_ASAN
+			__sanitizer_finish_switch_fiber(nullptr, &B->schedStack, &B->schedStackSize);
+#endif
 			(*B->body)();
 			Lane& l = B->lanes[B->cur];
 			l.finished = true; ++B->progress;
-			swapcontext(&l.uc, &B->sched);
+			yieldToScheduler(l, true);
 		}
 		uint32_t running(uint32_t base, uint32_t size, uint64_t* mask)
 		{
@@ -103,7 +131,7 @@ namespace hipemu
 			if (d.gen != g) break;                                   // completed by another lane
 			uint64_t mask;
 			if (d.arrived == running(base, size, &mask)) { d.active[g & 1] = mask; d.arrived = 0; ++d.gen; ++B->progress; break; }
-			swapcontext(&l.uc, &B->sched);
+			yieldToScheduler(l, false);
 		}
 		l.waiting = false;
 		*active = d.active[g & 1]; *domainBase = base;
@@ -123,6 +151,14 @@ namespace hipemu
 		Block blk; blk.n = block.x; blk.width = width; blk.body = &laneBody; blk.kernel = name;
 		blk.lanes.resize(block.x);
 		while (stacks.size() < block.x) stacks.push_back((char*)std::malloc(STACK));
+#ifdef HIPEMU_ASAN
+		// dynamic LDS beyond what the launch asked for does not exist
+		for (uint8_t* a : { kamd::lSmem, kamd::kSmem, kamd::sbgk::kSmem })
+		{
+			__asan_unpoison_memory_region(a, 160 * 1024);
+			__asan_poison_memory_region(a + ((ldsBytes + 7) & ~(size_t)7), 160 * 1024 - ((ldsBytes + 7) & ~(size_t)7));
+		}
+#endif
 		Block* outer = B;      // (a kernel never launches a kernel; kept for symmetry)
 		for (uint32_t b = 0; b < grid.x; ++b)
 		{
@@ -145,7 +181,14 @@ namespace hipemu
 				{
 					if (blk.lanes[t].finished) continue;
 					any = true; blk.cur = (int)t;
+#ifdef HIPEMU_ASAN
+					void* fake = nullptr;
+					__sanitizer_start_switch_fiber(&fake, stacks[t], STACK);
+#endif
 					swapcontext(&blk.sched, &blk.lanes[t].uc);
+#ifdef HIPEMU_ASAN
+					__sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+#endif
 				}
 				if (!any) break;
 				if (blk.progress == before) die("no lane can make progress (a cross-lane operation some lanes of the domain never reach)");

@@ -165,3 +165,25 @@ def test_emulated_c_api_suite(emu_libs):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_capi.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("kind", ["knlm-tiny-arenas", "sbg"])
+def test_emulated_kernels_under_address_and_ub_sanitizers(kind):
+    """The emulated kernels compiled with AddressSanitizer + UndefinedBehaviorSanitizer (`make -C tests/hipemu asan`): an access
+    outside an HBM buffer or beyond the dynamic LDS a launch asked for -- which a GPU executes silently -- ends the run.  Knlm with
+    KAMD_TEST_TINY_ARENAS (most chunks first hit a capacity limit: the code that must stop BEFORE writing out of bounds), and the
+    SkipBigram kernel."""
+    import sys
+    subprocess.check_call(["make", "-C", EMU, "asan", "-j8"], stdout=subprocess.DEVNULL)
+    rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("no shared AddressSanitizer runtime next to the compiler")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    if kind == "sbg":
+        env["KAMD_EXPERIMENTAL_SBG"] = "1"
+    else:
+        env["KAMD_TEST_TINY_ARENAS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(EMU, "sanitizer_run.py"), os.path.join(EMU, "_build", "libkiwi_hipemu_asan.so"), "sbg" if kind == "sbg" else "knlm"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and "sanitizer run complete" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr.replace("WARNING: ASan doesn't fully support makecontext/swapcontext", ""), r.stderr[-3000:]
