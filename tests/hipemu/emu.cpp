@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 #include <ucontext.h>
 #include <cstdio>
-#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -18,6 +17,23 @@ extern "C" void __sanitizer_finish_switch_fiber(void* fakeStackSave, const void*
 extern "C" void __asan_poison_memory_region(void const volatile* addr, size_t size);
 extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
 #endif
+#endif
+
+// ThreadSanitizer builds (`make tsan`; this file itself is compiled WITHOUT the sanitizer, the kernels with it): every lane is a TSan
+// fiber, switched without implied synchronisation; a rendezvous is release (on arrival) + acquire (on leaving) on its domain; a kernel
+// launch is ordered after everything the launching thread did before and before everything it does afterwards.  Two lanes touching the
+// same LDS / HBM location with no rendezvous in between, at least one of them writing non-atomically, is then a reported data race --
+// the missing-barrier bug that on the GPU shows up as a rare wrong answer.
+#ifdef HIPEMU_TSAN
+extern "C" void* __tsan_get_current_fiber(void);
+extern "C" void* __tsan_create_fiber(unsigned flags);
+extern "C" void __tsan_destroy_fiber(void* fiber);
+extern "C" void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+extern "C" void __tsan_acquire(void* addr);
+extern "C" void __tsan_release(void* addr);
+#define TSAN_ONLY(...) __VA_ARGS__
+#else
+#define TSAN_ONLY(...)
 #endif
 
 namespace kamd
@@ -39,19 +55,23 @@ namespace hipemu
 		struct Lane
 		{
 			ucontext_t uc; bool finished = true; LaneCtx ctx;
+			void* tsanFiber = nullptr;
 			bool waiting = false; Op waitOp = (Op)0; uint32_t waitBase = 0, waitSize = 0; uint64_t waitGen = 0;
 		};
 		struct Block
 		{
 			std::vector<Lane> lanes; uint32_t n = 0, width = 64;
-			std::map<std::pair<uint32_t, uint32_t>, Domain> domains;     // (first lane, size)
+			Domain groupDom[MAXT];      // convergence domains of the kernel's width, by first lane / width (no allocation inside fibers)
+			Domain blockDom;            // __syncthreads
 			uint64_t vals[2][MAXT];
 			uint64_t progress = 0;
 			const std::function<void()>* body = nullptr;
 			ucontext_t sched; int cur = -1;
-			const char* kernel = "";
+			const char* kernel = ""; bool dropBarrier = false;
 			const void* schedStack = nullptr; size_t schedStackSize = 0;     // (AddressSanitizer builds: the launching thread's stack)
+			void* schedFiber = nullptr;                                       // (ThreadSanitizer builds)
 		};
+		char streamOrder;      // ThreadSanitizer builds: the sync object that stands for stream order (host -> kernel -> host)
 		Block* B = nullptr;
 		std::vector<char*> stacks;
 		std::mutex launchMu;
@@ -63,6 +83,7 @@ namespace hipemu
 			void* fake = nullptr;
 			__sanitizer_start_switch_fiber(dying ? nullptr : &fake, B->schedStack, B->schedStackSize);
 #endif
+			TSAN_ONLY(if (dying) __tsan_release(&streamOrder); __tsan_switch_to_fiber(B->schedFiber, 1 /* no implied synchronisation */);)
 			swapcontext(&l.uc, &B->sched);
 #ifdef HIPEMU_ASAN
 			__sanitizer_finish_switch_fiber(fake, &B->schedStack, &B->schedStackSize);
@@ -74,6 +95,7 @@ namespace hipemu
 #ifdef HIPEMU_ASAN
 			__sanitizer_finish_switch_fiber(nullptr, &B->schedStack, &B->schedStackSize);
 #endif
+			TSAN_ONLY(__tsan_acquire(&streamOrder);)
 			(*B->body)();
 			Lane& l = B->lanes[B->cur];
 			l.finished = true; ++B->progress;
@@ -108,13 +130,15 @@ namespace hipemu
 
 	LaneCtx& ctx() { return B->lanes[B->cur].ctx; }
 	uint32_t width() { return B->width; }
+	bool dropWaveBarrier() { return B->dropBarrier; }
 
 	const uint64_t* exchange(Op op, uint32_t domain, uint64_t mine, uint64_t* active, uint32_t* domainBase)
 	{
 		const uint32_t self = (uint32_t)B->cur;
 		const uint32_t size = domain ? domain : B->width;
 		const uint32_t base = self / size * size;
-		Domain& d = B->domains[{ base, size }];
+		if (size != B->width && size != B->n) die("unsupported rendezvous size");
+		Domain& d = (domain == 0) ? B->groupDom[base / size] : B->blockDom;
 		Lane& l = B->lanes[self];
 		if (d.arrived == 0) d.op = op;
 		else if (d.op != op)
@@ -123,6 +147,7 @@ namespace hipemu
 			die("lanes of one convergence domain arrived at different cross-lane operations (divergent control flow around a cross-lane operation)");
 		}
 		const uint64_t g = d.gen;
+		TSAN_ONLY(__tsan_release(&d);)
 		B->vals[g & 1][self] = mine;
 		++d.arrived; ++B->progress;
 		l.waiting = true; l.waitOp = op; l.waitBase = base; l.waitSize = size; l.waitGen = g;
@@ -134,6 +159,7 @@ namespace hipemu
 			yieldToScheduler(l, false);
 		}
 		l.waiting = false;
+		TSAN_ONLY(__tsan_acquire(&d);)
 		*active = d.active[g & 1]; *domainBase = base;
 		return B->vals[g & 1];
 	}
@@ -149,6 +175,7 @@ namespace hipemu
 		if (at != std::string::npos) width = (uint32_t)std::atoi(nm.c_str() + at + 12);
 		if (width == 0 || width > 64 || (width & (width - 1))) { std::fprintf(stderr, "hipemu: cannot read the lane-group width out of '%s'\n", name); std::abort(); }
 		Block blk; blk.n = block.x; blk.width = width; blk.body = &laneBody; blk.kernel = name;
+		if (const char* drop = std::getenv("HIPEMU_TEST_DROP_WAVE_BARRIER")) blk.dropBarrier = nm.find(drop) != std::string::npos;
 		blk.lanes.resize(block.x);
 		while (stacks.size() < block.x) stacks.push_back((char*)std::malloc(STACK));
 #ifdef HIPEMU_ASAN
@@ -159,16 +186,19 @@ namespace hipemu
 			__asan_poison_memory_region(a + ((ldsBytes + 7) & ~(size_t)7), 160 * 1024 - ((ldsBytes + 7) & ~(size_t)7));
 		}
 #endif
+		TSAN_ONLY(blk.schedFiber = __tsan_get_current_fiber(); __tsan_release(&streamOrder);)
 		Block* outer = B;      // (a kernel never launches a kernel; kept for symmetry)
 		for (uint32_t b = 0; b < grid.x; ++b)
 		{
 			B = &blk;
-			blk.domains.clear(); blk.progress = 0;
+			for (auto& d : blk.groupDom) d = Domain{};
+			blk.blockDom = Domain{}; blk.progress = 0;
 			for (uint32_t t = 0; t < block.x; ++t)
 			{
 				Lane& l = blk.lanes[t];
 				l.finished = false; l.waiting = false;
 				l.ctx.tid = dim3(t); l.ctx.bid = dim3(b); l.ctx.bdim = block; l.ctx.gdim = grid;
+				TSAN_ONLY(l.tsanFiber = __tsan_create_fiber(0);)
 				getcontext(&l.uc);
 				l.uc.uc_stack.ss_sp = stacks[t]; l.uc.uc_stack.ss_size = STACK; l.uc.uc_link = nullptr;
 				makecontext(&l.uc, trampoline, 0);
@@ -185,6 +215,7 @@ namespace hipemu
 					void* fake = nullptr;
 					__sanitizer_start_switch_fiber(&fake, stacks[t], STACK);
 #endif
+					TSAN_ONLY(__tsan_switch_to_fiber(blk.lanes[t].tsanFiber, 1);)
 					swapcontext(&blk.sched, &blk.lanes[t].uc);
 #ifdef HIPEMU_ASAN
 					__sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
@@ -193,7 +224,9 @@ namespace hipemu
 				if (!any) break;
 				if (blk.progress == before) die("no lane can make progress (a cross-lane operation some lanes of the domain never reach)");
 			}
+			TSAN_ONLY(for (uint32_t t = 0; t < block.x; ++t) __tsan_destroy_fiber(blk.lanes[t].tsanFiber);)
 		}
 		B = outer;
+		TSAN_ONLY(__tsan_acquire(&streamOrder);)
 	}
 }

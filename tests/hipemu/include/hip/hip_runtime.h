@@ -111,7 +111,10 @@ inline int hipemu_update_dpp(int old, int src, int ctrl, int rowMask, int bankMa
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-inline void hipemu_wave_barrier() { uint64_t a; uint32_t b; (void)hipemu::exchange(hipemu::OP_WAVE_BARRIER, 0, 0, &a, &b); }
+// HIPEMU_TEST_DROP_WAVE_BARRIER=<kernel name> turns the wave barrier of that kernel into nothing: the self-test of the race detector
+// (the ThreadSanitizer build must then report the races the barrier exists to prevent; tests/test_hipemu.py)
+namespace hipemu { bool dropWaveBarrier(); }
+inline void hipemu_wave_barrier() { if (hipemu::dropWaveBarrier()) return; uint64_t a; uint32_t b; (void)hipemu::exchange(hipemu::OP_WAVE_BARRIER, 0, 0, &a, &b); }
 #define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
 inline void __syncthreads() { uint64_t a; uint32_t b; (void)hipemu::exchange(hipemu::OP_SYNCTHREADS, blockDim.x, 0, &a, &b); }
 
@@ -122,12 +125,13 @@ inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v);
 inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
-template<class T> inline T atomicAdd(T* p, T v) { const T o = *p; *p = o + v; return o; }      // lanes are fibers of one thread
-template<class T> inline T atomicOr(T* p, T v) { const T o = *p; *p = o | v; return o; }
-template<class T> inline T atomicCAS(T* p, T cmp, T v) { const T o = *p; if (o == cmp) *p = v; return o; }
-template<class T> inline T atomicExch(T* p, T v) { const T o = *p; *p = v; return o; }
-template<class T> inline T atomicMax(T* p, T v) { const T o = *p; if (v > o) *p = v; return o; }
-template<class T> inline T atomicMin(T* p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+// device atomics: relaxed (as on the GPU they order nothing else), real atomics so that the ThreadSanitizer build sees them as such
+template<class T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template<class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template<class T> inline T atomicCAS(T* p, T cmp, T v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); return cmp; }
+template<class T> inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+template<class T> inline T atomicMax(T* p, T v) { T o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
+template<class T> inline T atomicMin(T* p, T v) { T o = __atomic_load_n(p, __ATOMIC_RELAXED); while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {} return o; }
 inline unsigned long long wall_clock64() { return 0; }
 inline unsigned long long clock64() { return 0; }
 using std::min;

@@ -187,3 +187,35 @@ def test_emulated_kernels_under_address_and_ub_sanitizers(kind):
                        env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "sanitizer run complete" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr.replace("WARNING: ASan doesn't fully support makecontext/swapcontext", ""), r.stderr[-3000:]
+
+
+def _tsan_run(kind, extra_env):
+    import sys
+    subprocess.check_call(["make", "-C", EMU, "tsan", "-j8"], stdout=subprocess.DEVNULL)
+    rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-print-file-name=libclang_rt.tsan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("no shared ThreadSanitizer runtime next to the compiler")
+    env = dict(os.environ, LD_PRELOAD=rt, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0", **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(EMU, "sanitizer_run.py"), os.path.join(EMU, "_build", "libkiwi_hipemu_tsan.so"), kind],
+                       env=env, capture_output=True, text=True)
+    if "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot run in this address-space layout")
+    return r
+
+
+@pytest.mark.parametrize("kind", ["knlm", "sbg"])
+def test_emulated_kernels_have_no_cross_lane_data_races(kind):
+    """The emulated kernels under ThreadSanitizer with every lane a TSan fiber (tests/hipemu/emu.cpp): two lanes touching one LDS /
+    HBM location, at least one writing non-atomically, with no rendezvous (ballot, shuffle, DPP, wave barrier, __syncthreads) in
+    between is a reported race -- i.e. every cross-lane hand-over in the kernels is fenced by construction, not by the luck of
+    lock-step execution."""
+    r = _tsan_run(kind, {"KAMD_EXPERIMENTAL_SBG": "1"} if kind == "sbg" else {})
+    assert r.returncode == 0 and "sanitizer run complete" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "ThreadSanitizer: data race" not in r.stderr, r.stderr[:6000]
+
+
+def test_race_detector_sees_a_dropped_wave_barrier():
+    """Self-test of the above: with the wave barriers of one kernel turned into nothing (HIPEMU_TEST_DROP_WAVE_BARRIER) the same run
+    must report races (what the kernel then computes, or whether it survives, does not matter)."""
+    r = _tsan_run("knlm", {"HIPEMU_TEST_DROP_WAVE_BARRIER": "k_build_lattice"})
+    assert "ThreadSanitizer: data race" in r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
