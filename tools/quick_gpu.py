@@ -3,12 +3,13 @@ import os, sys
 from dataclasses import astuple
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from kiwi_amd.synth import SynthModel, SMALL_SPEC
+from kiwi_amd.synth import SynthModel, SMALL_SPEC, SMALL_SBG_SPEC
 from kiwi_amd.api import KiwiAmd
 import oraclelib
 os.makedirs(os.path.join(ROOT, "_data"), exist_ok=True)
-path = os.path.join(ROOT, "_data", "small.raw")
-sm = SynthModel(SMALL_SPEC); sm.raw.save(path)
+sbg = bool(os.environ.get("KAMD_EXPERIMENTAL_SBG"))      # the SkipBigram model and its (gated) search kernel
+path = os.path.join(ROOT, "_data", "small-sbg.raw" if sbg else "small.raw")
+sm = SynthModel(SMALL_SBG_SPEC if sbg else SMALL_SPEC); sm.raw.save(path)
 o = oraclelib.OracleKiwi(path); k = KiwiAmd(path)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 corpus = sm.make_corpus(n, 77, min_jamo=5, max_jamo=120)
