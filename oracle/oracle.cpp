@@ -10,6 +10,7 @@
 #include <thread>
 #include <atomic>
 #include "viterbi_oracle.hpp"
+#include "typo_oracle.hpp"
 
 using namespace korc;
 
@@ -240,5 +241,44 @@ extern "C"
 		auto& h = *(OracleHandle*)hp;
 		std::memcpy(out21, &h.counters, sizeof(Counters));
 		if (reset) h.counters = Counters{};
+	}
+
+	// ---- typo graphs (typo_oracle.hpp); byte layouts as oracle/ref_bridge.cpp kref_typo_* ------------------------------------------------
+	struct TypoHandle { korc::typo::Rules rules; std::unique_ptr<korc::typo::Prepared> prepared; };
+	void* korc_typo_new(float continualCost, float lengtheningCost)
+	{
+		auto* h = new TypoHandle; h->rules.continualCost = continualCost; h->rules.lengtheningCost = lengtheningCost; return h;
+	}
+	void korc_typo_close(void* hp) { delete (TypoHandle*)hp; }
+	int korc_typo_add(void* hp, const uint16_t* orig, uint32_t nOrig, const uint16_t* err, uint32_t nErr, float cost, int cond, int dialect)
+	{
+		try { ((TypoHandle*)hp)->rules.add(std::u16string{ (const char16_t*)orig, nOrig }, std::u16string{ (const char16_t*)err, nErr }, cost, (uint8_t)cond, (uint16_t)dialect); return 0; }
+		catch (const std::exception&) { return -1; }
+	}
+	void korc_typo_add_entry(void* hp, const uint16_t* orig, uint32_t nOrig, const uint16_t* err, uint32_t nErr, float cost, int cond, int dialect)
+	{
+		((TypoHandle*)hp)->rules.addEntry(std::u16string{ (const char16_t*)orig, nOrig }, std::u16string{ (const char16_t*)err, nErr }, cost, (uint8_t)cond, (uint16_t)dialect);
+	}
+	void korc_typo_set_costs(void* hp, float continualCost, float lengtheningCost) { auto* h = (TypoHandle*)hp; h->rules.continualCost = continualCost; h->rules.lengtheningCost = lengtheningCost; }
+	void korc_typo_prepare(void* hp, int inverse) { auto* h = (TypoHandle*)hp; h->prepared.reset(new korc::typo::Prepared{ h->rules, inverse != 0 }); }
+	size_t korc_typo_graph(void* hp, const uint16_t* text, uint32_t len, int allowedDialect, int normCoda, uint8_t* out, size_t cap)
+	{
+		auto* h = (TypoHandle*)hp;
+		U16 norm; std::vector<uint32_t> pos;
+		normalizeWithPosition((const char16_t*)text, len, norm, pos);
+		if (normCoda) normalizeCoda(norm);
+		size_t maxIdx = 0;
+		const auto g = h->prepared->graph(std::u16string{ (const char16_t*)norm.data(), norm.size() }, (uint16_t)allowedDialect, maxIdx);
+		Writer w{ out, out + cap };
+		w.put<uint32_t>((uint32_t)norm.size()); for (auto c : norm) w.put<uint16_t>((uint16_t)c);
+		w.put<uint32_t>((uint32_t)g.size());
+		for (auto& n : g)
+		{
+			w.put<uint32_t>((uint32_t)n.form.size()); for (auto c : n.form) w.put<uint16_t>((uint16_t)c);
+			w.put<uint32_t>(n.endPos); w.put<float>(n.typoCost); w.put<uint32_t>(n.prevOffset); w.put<uint32_t>(n.siblingOffset);
+			w.put<uint8_t>(n.continualTypoIdx); w.put<uint16_t>(n.dialect);
+		}
+		w.put<uint32_t>((uint32_t)maxIdx);
+		return w.need;
 	}
 }

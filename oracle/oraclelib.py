@@ -131,3 +131,52 @@ def alg_bytes(c: dict) -> dict:
               # "SBG extra": per evaluate() 8 B row pointers + 8 discounts + the key bytes of 8 partner searches + 4 B per hit
               + c.get("sbgEvals", 0) * (8 + 8 * 4) + c.get("sbgProbeKeyBytes", 0) + c.get("sbgHits", 0) * 4)
     return {"lattice": lattice, "search": search, "total": lattice + search}
+
+
+class OracleTypo:
+    """typo_oracle.hpp: rule container -> prepare -> typo graph (same interface and byte layout as refbridge.RefTypo)."""
+
+    def __init__(self, continual=float("inf"), lengthening=float("inf")):
+        L = self.lib = C.CDLL(LIB_PATH)
+        L.korc_typo_new.restype = C.c_void_p
+        L.korc_typo_new.argtypes = [C.c_float, C.c_float]
+        L.korc_typo_close.argtypes = [C.c_void_p]
+        L.korc_typo_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_int]
+        L.korc_typo_add_entry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_int]
+        L.korc_typo_set_costs.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.korc_typo_prepare.argtypes = [C.c_void_p, C.c_int]
+        L.korc_typo_graph.restype = C.c_size_t
+        L.korc_typo_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        self.h = L.korc_typo_new(continual, lengthening)
+
+    @staticmethod
+    def _u16(s):
+        return np.frombuffer(s.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+
+    def add(self, orig, error, cost=1.0, cond=0, dialect=0):
+        o, e = self._u16(orig), self._u16(error)
+        if self.lib.korc_typo_add(self.h, o.ctypes.data, len(o), e.ctypes.data, len(e), cost, cond, dialect) != 0:
+            raise ValueError((orig, error))
+
+    def update_entries(self, entries, continual, lengthening):
+        """TypoTransformer::update with another transformer's entries, given in the iteration order of its map."""
+        for orig, err, cost, cond, dialect in entries:
+            o, e = self._u16(orig), self._u16(err)
+            self.lib.korc_typo_add_entry(self.h, o.ctypes.data, len(o), e.ctypes.data, len(e), cost, cond, dialect)
+        self.lib.korc_typo_set_costs(self.h, continual, lengthening)
+
+    def prepare(self, inverse=True):
+        self.lib.korc_typo_prepare(self.h, int(inverse))
+
+    def graph_bytes(self, text, allowed_dialect=0, norm_coda=True):
+        u = self._u16(text)
+        need = self.lib.korc_typo_graph(self.h, u.ctypes.data, len(u), allowed_dialect, int(norm_coda), None, 0)
+        buf = np.zeros(need, np.uint8)
+        self.lib.korc_typo_graph(self.h, u.ctypes.data, len(u), allowed_dialect, int(norm_coda), buf.ctypes.data, need)
+        return buf.tobytes()
+
+    def __del__(self):
+        try:
+            self.lib.korc_typo_close(self.h)
+        except Exception:
+            pass

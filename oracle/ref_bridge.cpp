@@ -479,4 +479,63 @@ extern "C"
 		if (tokensOut) *tokensOut = tokens.load();
 		return std::chrono::duration<double>(t1 - t0).count();
 	}
+
+	// ---- typo graphs: the reference's TypoTransformer / PreparedTypoTransformer, public API only --------
+	// A transformer is filled either rule by rule (TypoTransformer::addTypo: normalisation + jamo expansion inside) or by replaying,
+	// entry by entry, one of the built-in sets (TypoTransformer::update, which inserts in the iteration order of the source map).
+	struct TypoHandle { kiwi::TypoTransformer tt; std::unique_ptr<kiwi::PreparedTypoTransformer> ptt; };
+	void* kref_typo_new(float continualCost, float lengtheningCost)
+	{
+		auto* h = new TypoHandle;
+		h->tt.setContinualTypoCost(continualCost); h->tt.setLengtheningTypoCost(lengtheningCost);
+		return h;
+	}
+	void kref_typo_close(void* hp) { delete (TypoHandle*)hp; }
+	int kref_typo_add(void* hp, const uint16_t* orig, uint32_t nOrig, const uint16_t* err, uint32_t nErr, float cost, int cond, int dialect)
+	{
+		try { ((TypoHandle*)hp)->tt.addTypo(std::u16string{ (const char16_t*)orig, nOrig }, std::u16string{ (const char16_t*)err, nErr }, cost, (kiwi::CondVowel)cond, (kiwi::Dialect)dialect); return 0; }
+		catch (const std::exception&) { return -1; }
+	}
+	// the entries of a built-in set in the iteration order of its map: {u32 n; per entry: u32 nOrig, u16[], u32 nErr, u16[], f32 cost, u8 cond, u16 dialect}; f32 continual, f32 lengthening
+	size_t kref_typo_default_entries(int set, uint8_t* out, size_t cap)
+	{
+		const auto& tt = kiwi::getDefaultTypoSet((kiwi::DefaultTypoSet)set);
+		Writer w{ out, out + cap };
+		w.put<uint32_t>((uint32_t)tt.getTypos().size());
+		for (auto& p : tt.getTypos())
+		{
+			const auto& o = std::get<0>(p.first); const auto& e = std::get<1>(p.first);
+			w.put<uint32_t>((uint32_t)o.size()); for (auto c : o) w.put<uint16_t>((uint16_t)c);
+			w.put<uint32_t>((uint32_t)e.size()); for (auto c : e) w.put<uint16_t>((uint16_t)c);
+			w.put<float>(p.second); w.put<uint8_t>((uint8_t)std::get<2>(p.first)); w.put<uint16_t>((uint16_t)std::get<3>(p.first));
+		}
+		w.put<float>(tt.getContinualTypoCost()); w.put<float>(tt.getLengtheningTypoCost());
+		return w.need;
+	}
+	// update(built-in set): what a client does with `TypoTransformer tt; tt |= getDefaultTypoSet(set)`
+	void kref_typo_update_default(void* hp, int set) { ((TypoHandle*)hp)->tt.update(kiwi::getDefaultTypoSet((kiwi::DefaultTypoSet)set)); }
+	void kref_typo_prepare(void* hp, int inverse) { auto* h = (TypoHandle*)hp; h->ptt.reset(new kiwi::PreparedTypoTransformer{ h->tt, inverse != 0 }); }
+	// generateGraph over the normalised text (normalizeHangul; normalizeCoda when `normCoda`).
+	// {u32 normLen, u16[]; u32 nNodes; per node: u32 formLen, u16[], u32 endPos, f32 typoCost, u32 prevOffset, u32 siblingOffset, u8 continualTypoIdx, u16 dialect}; u32 maxContinualTypoIdx
+	size_t kref_typo_graph(void* hp, const uint16_t* text, uint32_t len, int allowedDialect, int normCoda, uint8_t* out, size_t cap)
+	{
+		using namespace kiwi;
+		auto* h = (TypoHandle*)hp;
+		KString norm = normalizeHangul(std::u16string{ (const char16_t*)text, len });
+		if (normCoda) normalizeCoda(norm.begin(), norm.end());
+		std::vector<TypoGraphNode> g;
+		size_t maxIdx = 0;
+		h->ptt->generateGraph(U16StringView{ norm.data(), norm.size() }, g, (Dialect)allowedDialect, nullptr, nullptr, &maxIdx);
+		Writer w{ out, out + cap };
+		w.put<uint32_t>((uint32_t)norm.size()); for (auto c : norm) w.put<uint16_t>((uint16_t)c);
+		w.put<uint32_t>((uint32_t)g.size());
+		for (auto& n : g)
+		{
+			w.put<uint32_t>((uint32_t)n.form.size()); for (auto c : n.form) w.put<uint16_t>((uint16_t)c);
+			w.put<uint32_t>(n.endPos); w.put<float>(n.typoCost); w.put<uint32_t>(n.prevOffset); w.put<uint32_t>(n.siblingOffset);
+			w.put<uint8_t>(n.continualTypoIdx); w.put<uint16_t>((uint16_t)n.dialect);
+		}
+		w.put<uint32_t>((uint32_t)maxIdx);
+		return w.need;
+	}
 }

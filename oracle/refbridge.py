@@ -151,3 +151,103 @@ class RefKiwi:
         ntok = C.c_uint64(0)
         sec = self.lib.kref_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(enc), top_n, match, threads, C.byref(ntok))
         return float(sec), int(ntok.value)
+
+
+# ---- typo graphs ---------------------------------------------------------------------------
+COND = {"none": 0, "any": 1, "vowel": 2, "vocalic": 3, "vocalic_h": 4, "non_vowel": 5, "non_vocalic": 6, "non_vocalic_h": 7, "applosive": 8, "continual": 9, "boundary": 10}
+DEFAULT_TYPO_SETS = {"without": 0, "basic": 1, "continual": 2, "basic_with_continual": 3, "lengthening": 4, "basic_with_continual_and_lengthening": 5, "dialect": 6}
+
+
+def _u16(s):
+    return np.frombuffer(s.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(LIB_PATH)
+    return _LIB
+
+
+def parse_typo_graph(buf):
+    """Byte layout shared by kref_typo_graph and the oracle's korc_typo_graph -> (normalised text, nodes, maxContinualTypoIdx);
+    node = (form, endPos, typoCost, prevOffset, siblingOffset, continualTypoIdx, dialect)."""
+    import struct
+    o = 0
+    n, = struct.unpack_from("<I", buf, o); o += 4
+    norm = bytes(buf[o:o + 2 * n]).decode("utf-16-le", errors="surrogatepass"); o += 2 * n
+    cnt, = struct.unpack_from("<I", buf, o); o += 4
+    nodes = []
+    for _ in range(cnt):
+        fl, = struct.unpack_from("<I", buf, o); o += 4
+        form = bytes(buf[o:o + 2 * fl]).decode("utf-16-le", errors="surrogatepass"); o += 2 * fl
+        end, cost, prev, sib, cti, dia = struct.unpack_from("<IfIIBH", buf, o); o += 19
+        nodes.append((form, end, cost, prev, sib, cti, dia))
+    mx, = struct.unpack_from("<I", buf, o)
+    return norm, nodes, mx
+
+
+def default_typo_entries(set_name):
+    """Entries of a built-in typo set in the iteration order of the reference's map: [(orig, error, cost, cond, dialect)], continual, lengthening."""
+    import struct
+    L = _lib()
+    L.kref_typo_default_entries.restype = C.c_size_t
+    L.kref_typo_default_entries.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+    need = L.kref_typo_default_entries(DEFAULT_TYPO_SETS[set_name], None, 0)
+    buf = np.zeros(need, np.uint8)
+    L.kref_typo_default_entries(DEFAULT_TYPO_SETS[set_name], buf.ctypes.data, need)
+    b = buf.tobytes(); o = 0
+    n, = struct.unpack_from("<I", b, o); o += 4
+    out = []
+    for _ in range(n):
+        no, = struct.unpack_from("<I", b, o); o += 4
+        orig = b[o:o + 2 * no].decode("utf-16-le", errors="surrogatepass"); o += 2 * no
+        ne, = struct.unpack_from("<I", b, o); o += 4
+        err = b[o:o + 2 * ne].decode("utf-16-le", errors="surrogatepass"); o += 2 * ne
+        cost, cond, dia = struct.unpack_from("<fBH", b, o); o += 7
+        out.append((orig, err, cost, cond, dia))
+    cont, leng = struct.unpack_from("<ff", b, o)
+    return out, cont, leng
+
+
+class RefTypo:
+    """The reference's TypoTransformer -> PreparedTypoTransformer -> generateGraph, public API only."""
+
+    def __init__(self, continual=float("inf"), lengthening=float("inf")):
+        L = self.lib = _lib()
+        L.kref_typo_new.restype = C.c_void_p
+        L.kref_typo_new.argtypes = [C.c_float, C.c_float]
+        L.kref_typo_close.argtypes = [C.c_void_p]
+        L.kref_typo_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_int]
+        L.kref_typo_update_default.argtypes = [C.c_void_p, C.c_int]
+        L.kref_typo_prepare.argtypes = [C.c_void_p, C.c_int]
+        L.kref_typo_graph.restype = C.c_size_t
+        L.kref_typo_graph.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        self.h = L.kref_typo_new(continual, lengthening)
+
+    def add(self, orig, error, cost=1.0, cond="none", dialect=0):
+        o, e = _u16(orig), _u16(error)
+        if self.lib.kref_typo_add(self.h, o.ctypes.data, len(o), e.ctypes.data, len(e), cost, COND[cond] if isinstance(cond, str) else cond, dialect) != 0:
+            raise ValueError((orig, error))
+
+    def update_default(self, set_name):
+        self.lib.kref_typo_update_default(self.h, DEFAULT_TYPO_SETS[set_name])
+
+    def prepare(self, inverse=True):
+        self.lib.kref_typo_prepare(self.h, int(inverse))
+
+    def graph(self, text, allowed_dialect=0, norm_coda=True):
+        u = _u16(text)
+        need = self.lib.kref_typo_graph(self.h, u.ctypes.data, len(u), allowed_dialect, int(norm_coda), None, 0)
+        buf = np.zeros(need, np.uint8)
+        self.lib.kref_typo_graph(self.h, u.ctypes.data, len(u), allowed_dialect, int(norm_coda), buf.ctypes.data, need)
+        return parse_typo_graph(buf.tobytes())
+
+    def __del__(self):
+        try:
+            self.lib.kref_typo_close(self.h)
+        except Exception:
+            pass

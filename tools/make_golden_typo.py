@@ -1,0 +1,32 @@
+"""Generates tests/golden/typo_graphs.json: typo graphs of the REAL reference (src/TypoTransformer.cpp through oracle/ref_bridge.cpp)
+for this repo's test rules (tests/typo_cases.py).  Run in the container that has /root/reference; the JSON is committed and replayed
+against oracle/typo_oracle.hpp by tests/test_typo_oracle.py::test_golden_typo_graphs."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import refbridge  # noqa: E402
+from typo_cases import INF, fill, texts  # noqa: E402
+
+cases = []
+for inverse, cont, leng, dia in ((True, INF, INF, 0), (True, 1.0, 0.25, 0xFFFF), (False, 1.0, INF, 8)):
+    ref = refbridge.RefTypo(cont, leng)
+    fill(ref, True)
+    ref.prepare(inverse)
+    items = []
+    for t in texts(40, 101):
+        u = refbridge._u16(t)
+        need = ref.lib.kref_typo_graph(ref.h, u.ctypes.data, len(u), dia, 1, None, 0)
+        buf = np.zeros(need, np.uint8)
+        ref.lib.kref_typo_graph(ref.h, u.ctypes.data, len(u), dia, 1, buf.ctypes.data, need)
+        items.append({"text": t, "graph": buf.tobytes().hex()})
+    cases.append({"inverse": inverse, "continual": None if cont == INF else cont, "lengthening": None if leng == INF else leng, "dialect": dia, "items": items})
+out = os.path.join(ROOT, "tests", "golden", "typo_graphs.json")
+json.dump({"rules": "tests/typo_cases.py RULES", "reference": "bab2min/Kiwi v0.23.1 src/TypoTransformer.cpp via oracle/ref_bridge.cpp (kref_typo_graph byte layout)", "cases": cases},
+          open(out, "w", encoding="utf-8"), ensure_ascii=True)
+print(sum(len(c["items"]) for c in cases), "graphs ->", out, os.path.getsize(out), "bytes")
