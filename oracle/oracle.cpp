@@ -11,6 +11,7 @@
 #include <atomic>
 #include "viterbi_oracle.hpp"
 #include "typo_oracle.hpp"
+#include "typo_lattice_oracle.hpp"
 
 using namespace korc;
 
@@ -35,8 +36,11 @@ namespace
 		void putStr(const U16& s) { put<uint32_t>((uint32_t)s.size()); for (auto c : s) put<uint16_t>(c); }
 	};
 
+	// a prepared typo transformer applied to an analysis (AnalyzeOption::typoTransformer / typoThreshold / allowedDialects)
+	struct TypoOpt { const korc::typo::Prepared* prepared = nullptr; float threshold = 2.5f; uint16_t dialect = 0; };
+
 	std::vector<TokenResult> analyzeOne(OracleHandle& h, Counters& cnt, PersistentContainers* persistent, const char16_t* text, uint32_t len, uint32_t topN, uint64_t match, bool openEnding,
-		std::vector<std::vector<LNode>>* latticesOut = nullptr)
+		std::vector<std::vector<LNode>>* latticesOut = nullptr, TypoOpt typo = {})
 	{
 		if (topN < 1 || topN > 4) throw std::runtime_error{ "oracle: top_n must be 1..4" };
 		PreparedText pt;
@@ -47,6 +51,7 @@ namespace
 		bc.splitComplex = match & M_SPLIT_COMPLEX; bc.splitSaisiot = match & M_SPLIT_SAISIOT; bc.mergeSaisiot = match & M_MERGE_SAISIOT;
 		bc.spaceTolerance = sc.spaceTol;
 		LatticeBuilder lb{ h.view, sc, cnt };
+		TypoLatticeBuilder tlb{ h.view, sc };
 		ResultBuilder rb{ h.model, topN, match, h.integrateAllomorph };
 		rb.begin(text, len, pt.position);
 		std::vector<LNode> nodes;
@@ -54,7 +59,9 @@ namespace
 		for (auto& ch : pt.chunks)
 		{
 			if (ch.empty) continue;
-			const bool ok = lb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.cls.data() + ch.startOffset, pt.script.data() + ch.startOffset,
+			const bool ok = typo.prepared
+				? tlb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset, *typo.prepared, typo.threshold, typo.dialect)
+				: lb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.cls.data() + ch.startOffset, pt.script.data() + ch.startOffset,
 				pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset);
 			if (latticesOut) latticesOut->push_back(nodes);
 			if (!ok) continue;
@@ -133,10 +140,17 @@ extern "C"
 		return ll;
 	}
 
+	struct TypoHandle { korc::typo::Rules rules; std::unique_ptr<korc::typo::Prepared> prepared; };
+	size_t korc_split_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap);
 	// same layout as kref_split (oracle/ref_bridge.cpp)
 	size_t korc_split(void* hp, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
 	{
+		return korc_split_typo(hp, nullptr, 2.5f, 0, text, len, match, out, cap);
+	}
+	size_t korc_split_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
+	{
 		auto& h = *(OracleHandle*)hp;
+		const korc::typo::Prepared* prepared = typoHp ? ((TypoHandle*)typoHp)->prepared.get() : nullptr;
 		Writer w{ out, out + cap };
 		try
 		{
@@ -145,11 +159,13 @@ extern "C"
 			SplitConfig sc = h.scfg; sc.match = match;
 			Counters cnt;
 			LatticeBuilder lb{ h.view, sc, cnt };
+			TypoLatticeBuilder tlb{ h.view, sc };
 			w.put<uint32_t>((uint32_t)pt.chunks.size());
 			std::vector<LNode> nodes;
 			for (auto& ch : pt.chunks)
 			{
 				if (ch.empty) { nodes.assign(2, LNode{}); }
+				else if (prepared) tlb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset, *prepared, typoThreshold, (uint16_t)allowedDialect);
 				else lb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.cls.data() + ch.startOffset, pt.script.data() + ch.startOffset,
 					pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset);
 				w.put<uint32_t>((uint32_t)nodes.size());
@@ -185,13 +201,20 @@ extern "C"
 		}
 	}
 
+	size_t korc_analyze_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap);
 	size_t korc_analyze(void* hp, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
+	{
+		return korc_analyze_typo(hp, nullptr, 2.5f, 0, text, len, topN, match, openEnding, out, cap);
+	}
+	size_t korc_analyze_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
 	{
 		auto& h = *(OracleHandle*)hp;
 		Writer w{ out, out + cap };
 		try
 		{
-			auto res = analyzeOne(h, h.counters, &h.persistent, (const char16_t*)text, len, topN, match, !!openEnding);
+			TypoOpt typo;
+			if (typoHp) { typo.prepared = ((TypoHandle*)typoHp)->prepared.get(); typo.threshold = typoThreshold; typo.dialect = (uint16_t)allowedDialect; }
+			auto res = analyzeOne(h, h.counters, &h.persistent, (const char16_t*)text, len, topN, match, !!openEnding, nullptr, typo);
 			writeResults(w, res);
 		}
 		catch (const std::exception& e) { fprintf(stderr, "korc_analyze: %s\n", e.what()); return 0; }
@@ -244,7 +267,6 @@ extern "C"
 	}
 
 	// ---- typo graphs (typo_oracle.hpp); byte layouts as oracle/ref_bridge.cpp kref_typo_* ------------------------------------------------
-	struct TypoHandle { korc::typo::Rules rules; std::unique_ptr<korc::typo::Prepared> prepared; };
 	void* korc_typo_new(float continualCost, float lengtheningCost)
 	{
 		auto* h = new TypoHandle; h->rules.continualCost = continualCost; h->rules.lengtheningCost = lengtheningCost; return h;

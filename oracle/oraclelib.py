@@ -91,6 +91,28 @@ class OracleKiwi:
             chunks.append((split_end, nodes))
         return chunks
 
+    def split_typo(self, typo, text: str, threshold=2.5, allowed_dialect=0, match: int = MATCH_ALL_WITH_NORMALIZING):
+        """Lattices over the typo graph of every chunk; `typo` is a prepared OracleTypo (typo_lattice_oracle.hpp)."""
+        self.lib.korc_split_typo.restype = C.c_size_t
+        self.lib.korc_split_typo.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t]
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        buf = self._call(lambda *a: self.lib.korc_split_typo(self.h, typo.h, threshold, allowed_dialect, u.ctypes.data, len(u), match, *a))
+        r = _Reader(buf)
+        chunks = []
+        for _ in range(r.get("I")):
+            n, split_end = r.get("II")
+            chunks.append((split_end, [r.get("IIIIiIIIf") for _ in range(n)]))
+        return chunks
+
+    def analyze_typo(self, typo, text: str, threshold=2.5, allowed_dialect=0, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING, open_ending=False):
+        self.lib.korc_analyze_typo.restype = C.c_size_t
+        self.lib.korc_analyze_typo.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        buf = self._call(lambda *a: self.lib.korc_analyze_typo(self.h, typo.h, threshold, allowed_dialect, u.ctypes.data, len(u), top_n, match, int(open_ending), *a))
+        if len(buf) == 0:
+            raise RuntimeError("korc_analyze_typo failed")
+        return parse_results(buf)
+
     def lm_progress(self, node: int, wid: int):
         n = C.c_int32(node)
         ll = self.lib.korc_lm_progress(self.h, C.byref(n), wid)

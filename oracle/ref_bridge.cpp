@@ -226,17 +226,20 @@ namespace kiwi
 		static const lm::ILangModel* lm(const Kiwi& k) { return k.langMdl.get(); }
 		static const std::array<size_t, 6>& specialMorphs(const Kiwi& k) { return k.specialMorphIds; }
 
-		static size_t split(const Kiwi& k, Vector<KGraphNode>& nodes, U16StringView str, size_t startOffset, Match m, const KiwiConfig& cfg)
+		static size_t split(const Kiwi& k, Vector<KGraphNode>& nodes, U16StringView str, size_t startOffset, Match m, const KiwiConfig& cfg,
+			const PreparedTypoTransformer* typo = nullptr, float typoThreshold = 2.5f, Dialect allowedDialect = Dialect::standard)
 		{
 			const PretokenizedSpanGroup::Span* pf = nullptr;
 			return (*reinterpret_cast<FnSplitByTrie>(k.dfSplitByTrie))(nodes, k.forms.data(), k.typoPtrs.data(), k.formTrie, str, startOffset,
-				m, Dialect::standard, cfg.maxUnkFormSize, cfg.maxUnkFormSizeFollowedByJClass, cfg.spaceTolerance,
-				nullptr, 2.5f, k.continualTypoCost, k.lengtheningTypoCost, pf, pf);
+				m, allowedDialect, cfg.maxUnkFormSize, cfg.maxUnkFormSizeFollowedByJClass, cfg.spaceTolerance,
+				typo, typoThreshold, k.continualTypoCost, k.lengtheningTypoCost, pf, pf);
 		}
 	};
 }
 
 using Acc = kiwi::BestPathFinder<kamd_ref::Access>;
+
+struct TypoHandle { kiwi::TypoTransformer tt; std::unique_ptr<kiwi::PreparedTypoTransformer> ptt; };
 
 struct RefHandle
 {
@@ -372,10 +375,17 @@ extern "C"
 	// Lattice of every chunk of `text` (already raw UTF-16; normalised inside exactly as Kiwi::analyze does,
 	// src/Kiwi.cpp:1028-1030,1095-1117).  Per chunk: {u32 nNodes, u32 splitEnd, nodes{u32 start,end,prev,sibling,
 	// i32 formId, u32 uformLen, u32 uformOff(in normalised str), u32 spaceErrors, f32 typoCost}[]} ; leading u32 nChunks.
+	size_t kref_split_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap);
 	size_t kref_split(void* hp, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
+	{
+		return kref_split_typo(hp, nullptr, 2.5f, 0, text, len, match, out, cap);
+	}
+	// ... with a prepared typo transformer (kref_typo_*): the lattice over the typo graph of every chunk (KTrie.cpp:873-895, 998-1464)
+	size_t kref_split_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
 	{
 		using namespace kiwi;
 		auto& kw = ((RefHandle*)hp)->kw;
+		const PreparedTypoTransformer* typo = typoHp ? ((TypoHandle*)typoHp)->ptt.get() : nullptr;
 		KString norm; Vector<uint32_t> pos;
 		normalizeHangulWithPosition((const char16_t*)text, (const char16_t*)text + len, std::back_inserter(norm), std::back_inserter(pos));
 		if (!!((Match)match & Match::normalizeCoda)) normalizeCoda(norm.begin(), norm.end());
@@ -388,7 +398,7 @@ extern "C"
 		while (splitEnd < norm.size())
 		{
 			nodes.clear();
-			splitEnd = Acc::split(kw, nodes, U16StringView{ norm.data() + splitEnd, norm.size() - splitEnd }, splitEnd, (Match)match, Acc::config(kw));
+			splitEnd = Acc::split(kw, nodes, U16StringView{ norm.data() + splitEnd, norm.size() - splitEnd }, splitEnd, (Match)match, Acc::config(kw), typo, typoThreshold, (Dialect)allowedDialect);
 			++nChunks;
 			w.put<uint32_t>((uint32_t)nodes.size());
 			w.put<uint32_t>((uint32_t)splitEnd);
@@ -427,7 +437,12 @@ extern "C"
 	}
 
 	// Kiwi::analyze (src/Kiwi.cpp:1014-1158) on one text.  Returns bytes needed.
+	size_t kref_analyze_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap);
 	size_t kref_analyze(void* hp, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
+	{
+		return kref_analyze_typo(hp, nullptr, 2.5f, 0, text, len, topN, match, openEnding, out, cap);
+	}
+	size_t kref_analyze_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
 	{
 		auto& kw = ((RefHandle*)hp)->kw;
 		Writer w{ out, out + cap };
@@ -435,6 +450,7 @@ extern "C"
 		{
 			kiwi::AnalyzeOption opt{ (kiwi::Match)match };
 			opt.openEnding = !!openEnding;
+			if (typoHp) { opt.typoTransformer = ((TypoHandle*)typoHp)->ptt.get(); opt.typoThreshold = typoThreshold; opt.allowedDialects = (kiwi::Dialect)allowedDialect; }
 			auto res = kw.analyze(std::u16string{ (const char16_t*)text, (const char16_t*)text + len }, topN, opt);
 			writeResults(w, res, kw);
 		}
@@ -483,7 +499,6 @@ extern "C"
 	// ---- typo graphs: the reference's TypoTransformer / PreparedTypoTransformer, public API only --------
 	// A transformer is filled either rule by rule (TypoTransformer::addTypo: normalisation + jamo expansion inside) or by replaying,
 	// entry by entry, one of the built-in sets (TypoTransformer::update, which inserts in the iteration order of the source map).
-	struct TypoHandle { kiwi::TypoTransformer tt; std::unique_ptr<kiwi::PreparedTypoTransformer> ptt; };
 	void* kref_typo_new(float continualCost, float lengtheningCost)
 	{
 		auto* h = new TypoHandle;

@@ -1,8 +1,10 @@
 """SURVEY.md section 8 row a4, first half: the typo graph (TypoTransformer rule container -> prepare() -> generateGraph).
 oracle/typo_oracle.hpp is a CPU restatement; here it is pinned, byte for byte, to the REAL reference translation unit
 (src/TypoTransformer.cpp through oracle/ref_bridge.cpp), to the reference's own known-answer test, and to committed graphs
-generated from the reference (tests/golden/typo_graphs.json).  The lattice search over such graphs (the second half of a4,
-a5's per-branch search states) is not built yet."""
+generated from the reference (tests/golden/typo_graphs.json).  Second half: the lattice built OVER such a graph
+(oracle/typo_lattice_oracle.hpp: per-branch search states, typo costs, continual-typo positions) and the whole analysis with a typo
+transformer -- lattices, tokens, fp32 scores and typo costs equal the reference's (kref_split_typo / kref_analyze_typo) on misspelt
+texts.  Lengthening typos are not restated; nothing of this is on the device yet."""
 import json
 import os
 
@@ -87,3 +89,54 @@ def test_golden_typo_graphs():
         orc.prepare(case["inverse"])
         for it in case["items"]:
             assert orc.graph_bytes(it["text"], case["dialect"], True).hex() == it["graph"], (case["inverse"], it["text"])
+
+
+def _norm(res):
+    from dataclasses import astuple
+    return [([astuple(t) for t in a[0]], a[1]) for a in res]
+
+
+@pytest.mark.parametrize("name,threshold,carry", [("basic", 2.5, False), ("basic", 6.0, False), ("continual", 2.5, True), ("basic_with_continual", 2.5, True),
+                                                   ("basic_with_continual", 1.2, True), ("dialect", 2.5, False)])
+def test_typo_lattices_and_analyses_equal_reference(small_model, name, threshold, carry):
+    """Misspelt texts of the synthetic model (confusable vowels, codas carried over to the next syllable) through Kiwi::analyze with a
+    typo transformer, reference vs oracle: the lattice of every chunk (nodes, links, typo costs) and the analyses (tokens, positions,
+    fp32 scores, per-token typo costs)."""
+    import random
+    import oraclelib
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+    from typo_cases import misspell
+    sm, path = small_model
+    ref, orc = refbridge.RefKiwi(path), oraclelib.OracleKiwi(path)
+    ents, cont, leng = refbridge.default_typo_entries(name)
+    rt = refbridge.RefTypo(); rt.update_default(name); rt.prepare(True)
+    ot = oraclelib.OracleTypo(); ot.update_entries(ents, cont, leng); ot.prepare(True)
+    rnd = random.Random(5)
+    dia = 0xFFFF if name == "dialect" else 0
+    tt = [misspell(t, rnd, True, carry) for t in synthetic(sm, 70, 701, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 40, 702)] + EDGE_TEXTS
+    corrected = 0
+    for t in tt:
+        if not t.strip():
+            continue
+        assert ref.split_typo(rt, t, threshold, dia) == orc.split_typo(ot, t, threshold, dia), t
+        a = ref.analyze_typo(rt, t, threshold, dia)
+        assert _norm(a) == _norm(orc.analyze_typo(ot, t, threshold, dia)), t
+        corrected += any(x.typo_cost > 0 for x in a[0][0])
+    assert corrected >= (20 if name.startswith("basic") or carry else 1)
+
+
+def test_golden_typo_analyses(small_model):
+    """Analyses of the real reference with this repo's test rules on misspelt texts (tools/make_golden_typo.py), replayed without oracle/_ref."""
+    import oraclelib
+    g = json.load(open(os.path.join(HERE, "golden", "typo_analyses.json"), encoding="utf-8"))
+    orc = oraclelib.OracleKiwi(small_model[1])
+    ot = oraclelib.OracleTypo(g["continual"], INF)
+    fill(ot, False)
+    ot.prepare(True)
+    for it in g["items"]:
+        res = orc.analyze_typo(ot, it["text"], g["threshold"], 0)
+        got = [[t.form, t.tag, t.position, t.length, t.score, t.typo_cost] for t in res[0][0]]
+        assert got == it["tokens"] and res[0][1] == it["score"], it["text"]

@@ -31,3 +31,31 @@ def fill(transformer, as_names):
 def texts(n, seed):
     rnd = random.Random(seed)
     return HAND_TEXTS + ["".join(rnd.choice(SYLLABLES + "  ") for _ in range(rnd.randint(1, 60))) for _ in range(n)]
+
+
+CODA2ONSET = {1: 0, 4: 2, 7: 3, 8: 5, 16: 6, 17: 7, 19: 9, 22: 12, 23: 14, 24: 15, 25: 16, 26: 17, 27: 18}
+
+
+def misspell(text, rnd, vowels=True, carry=True):
+    """Injects the kinds of errors the built-in typo sets correct into a text of the synthetic model: confusable vowels (ㅐ/ㅔ, ㅚ/ㅙ)
+    and a coda written as the onset of the following vowel-initial syllable (연철, what the continual rules undo)."""
+    o = list(text)
+    if vowels:
+        for i, ch in enumerate(o):
+            c = ord(ch)
+            if 0xAC00 <= c < 0xD7A4 and rnd.random() < 0.15:
+                v = (c - 0xAC00) // 28 % 21
+                if v == 1: c += 4 * 28
+                elif v == 5: c -= 4 * 28
+                elif v == 11: c -= 1 * 28
+                o[i] = chr(c)
+    if carry:
+        for i in range(len(o) - 1):
+            a, b = ord(o[i]), ord(o[i + 1])
+            if 0xAC00 <= a < 0xD7A4 and 0xAC00 <= b < 0xD7A4 and rnd.random() < 0.5:
+                coda = (a - 0xAC00) % 28
+                onset = (b - 0xAC00) // 28 // 21
+                if coda in CODA2ONSET and onset == 11:
+                    o[i] = chr(a - coda)
+                    o[i + 1] = chr(b + (CODA2ONSET[coda] - 11) * 21 * 28)
+    return "".join(o)

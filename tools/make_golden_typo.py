@@ -30,3 +30,29 @@ out = os.path.join(ROOT, "tests", "golden", "typo_graphs.json")
 json.dump({"rules": "tests/typo_cases.py RULES", "reference": "bab2min/Kiwi v0.23.1 src/TypoTransformer.cpp via oracle/ref_bridge.cpp (kref_typo_graph byte layout)", "cases": cases},
           open(out, "w", encoding="utf-8"), ensure_ascii=True)
 print(sum(len(c["items"]) for c in cases), "graphs ->", out, os.path.getsize(out), "bytes")
+
+# ---- analyses with a typo transformer (own rules, continual cost 1) on misspelt texts of the small synthetic model
+import random  # noqa: E402
+sys.path.insert(0, ROOT)
+from corpora import dictionary_mix, synthetic  # noqa: E402
+from kiwi_amd.synth import SMALL_SPEC, SynthModel  # noqa: E402
+from typo_cases import misspell  # noqa: E402
+
+sm = SynthModel(SMALL_SPEC)
+os.makedirs(os.path.join(ROOT, "_data"), exist_ok=True)
+path = os.path.join(ROOT, "_data", "small.raw")
+sm.raw.save(path)
+ref = refbridge.RefKiwi(path)
+rt = refbridge.RefTypo(1.0, INF)
+fill(rt, True)
+rt.prepare(True)
+rnd = random.Random(9)
+items = []
+for t in synthetic(sm, 60, 801, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 30, 802):
+    t = misspell(t, rnd)
+    res = ref.analyze_typo(rt, t, 2.5, 0)
+    items.append({"text": t, "score": res[0][1], "tokens": [[x.form, x.tag, x.position, x.length, x.score, x.typo_cost] for x in res[0][0]]})
+out = os.path.join(ROOT, "tests", "golden", "typo_analyses.json")
+json.dump({"model": "kiwi_amd.synth.SMALL_SPEC", "rules": "tests/typo_cases.py RULES", "continual": 1.0, "threshold": 2.5,
+           "reference": "bab2min/Kiwi v0.23.1 TUs via oracle/ref_bridge.cpp (kref_analyze_typo)", "items": items}, open(out, "w", encoding="utf-8"), ensure_ascii=True)
+print(len(items), "analyses ->", out, sum(any(tok[5] > 0 for tok in it["tokens"]) for it in items), "with a corrected token")
