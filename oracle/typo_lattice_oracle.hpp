@@ -6,7 +6,8 @@
 // the typo, start-position offset (a correction may be longer or shorter than what it replaces), the unknown-form / special-character
 // bookkeeping positions, the last character and the continual-typo index the state started in.  Lattice positions are multiplied by
 // 2^posMultiplierBit so that the halves of a continual typo (a coda carried over to the next syllable) get positions of their own.
-// Lengthening typos (SearchState<true>) are not restated: a transformer with a finite lengthening cost is refused.
+// With a finite lengthening cost (SearchState<true>) a state also carries the trie nodes reached by skipping 1..8 syllables that merely
+// lengthen the preceding vowel ("아아아"); a form found through one of them starts that many positions earlier and costs cost * (3 + skipped).
 // Pinned against the real translation unit by tests/test_typo_oracle.py through kref_split_typo.
 #pragma once
 #include <deque>
@@ -25,14 +26,17 @@ namespace korc
 		std::vector<LNode> out;
 		std::vector<typo::GraphNode> graph;
 		uint32_t pmb = 0;
-		float typoThreshold = 2.5f;
+		float typoThreshold = 2.5f, lengtheningCost = INFINITY;
+		bool lengthening = false;
 		const PatternSpan* pat = nullptr; const PatternSpan* patEnd = nullptr;
 
 		struct SState
 		{
 			int32_t node = 0; float cost = 0; uint32_t minFormLen = 0; int32_t startPosOffset = 0;
 			uint32_t specialStart = 0, unkStart = 0, boundary = 0; uint32_t lastChr = 0; uint16_t startCti = 0;
+			std::vector<std::pair<uint32_t, int32_t>> lnodes;      // (syllables skipped, trie node): LengtheningTypoNodes<true>
 		};
+		struct Cand { uint32_t form; uint32_t lengthened; };
 
 		bool append(uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, float typoCost = 0)
 		{
@@ -118,12 +122,13 @@ namespace korc
 		}
 
 		// flushCandidates (KTrie.cpp:955-996)
-		void flush(std::vector<uint32_t>& cands, uint32_t endNs, int32_t startPosOffset, uint32_t unkStart, uint32_t boundary, float typoCost, uint32_t startCti, uint32_t endCti)
+		void flush(std::vector<Cand>& cands, uint32_t endNs, int32_t startPosOffset, uint32_t unkStart, uint32_t boundary, float typoCost, uint32_t startCti, uint32_t endCti)
 		{
-			for (uint32_t fi : cands)
+			for (const Cand& cd : cands)
 			{
+				const uint32_t fi = cd.form;
 				const FormRec& f = M.forms[fi];
-				const uint32_t nb = (uint32_t)((int64_t)endNs - (int64_t)(f.len - f.numSpaces) + startPosOffset), ne = endNs;
+				const uint32_t nb = (uint32_t)((int64_t)endNs - (int64_t)(f.len - f.numSpaces) - (int64_t)cd.lengthened + startPosOffset), ne = endNs;
 				if (startCti == 0 && !(f.flags & FF_FIRST_IS_CODA))
 				{
 					const bool hj = (f.flags & FF_HAS_JCLASS) || (f.flags & FF_IS_STAG);
@@ -135,7 +140,7 @@ namespace korc
 				{
 					const uint32_t b2 = startCti ? (nb << pmb) + startCti : nb << pmb;
 					const uint32_t e2 = endCti ? ((ne - 1) << pmb) + endCti : ne << pmb;
-					if (append(b2, e2, fi, 0, 0, typoCost)) out.back().spaceErrors = se;
+					if (append(b2, e2, fi, 0, 0, typoCost + (cd.lengthened ? lengtheningCost * (float)(3 + cd.lengthened) : 0.f))) out.back().spaceErrors = se;
 				}
 			}
 			cands.clear();
@@ -156,7 +161,8 @@ namespace korc
 			if (tn.typoCost > 0) startPosOffset += (int32_t)fsz - (int32_t)(tn.endPos - prevT.endPos);
 			int32_t curNode = st.node;      // -1 = none
 			const uint8_t scriptVS = 98;    // ScriptType::variation_selectors
-			std::vector<uint32_t> cands;
+			std::vector<Cand> cands;
+			auto lnodes = st.lnodes;
 			const uint32_t nNs = (uint32_t)nsToPos.size();
 			for (uint32_t j = 0; j < fsz; ++j)
 			{
@@ -211,9 +217,9 @@ namespace korc
 							}
 						}
 						if ((cfg.match & M_Z_CODA) && zc && isHangulCoda(ch) && (pos + 1 >= n || !isHangulSyllable(str[pos + 1])))
-							cands.push_back(kDefaultTagSize + (ch - 0x11A8) - 1);
+							cands.push_back(Cand{ kDefaultTagSize + (ch - 0x11A8) - 1u, 0 });
 						else if ((cfg.match & (M_SPLIT_SAISIOT | M_MERGE_SAISIOT)) && zs && ch == 0x11BA && pos + 1 < n && isHangulSyllable(str[pos + 1]))
-							cands.push_back(kDefaultTagSize + (0x11BA - 0x11A8) - 1);
+							cands.push_back(Cand{ kDefaultTagSize + (0x11BA - 0x11A8) - 1u, 0 });
 					}
 				}
 				else if (isSpace(c32))
@@ -235,6 +241,34 @@ namespace korc
 					}
 				}
 				if (c32 >= 0x10000) { ++j; prevChr = c32; continue; }
+				if (lengthening)      // KTrie.cpp:1215-1270
+				{
+					static const uint8_t lengtheningVowel[21] = { 0, 1, 0, 1, 4, 5, 4, 5, 8, 0, 1, 1, 8, 13, 4, 5, 20, 13, 18, 20, 20 };
+					const size_t prevSize = lnodes.size();
+					if (prevChr && prevChr < 0x10000 && isHangulSyllable((char16_t)prevChr) && (0xC544 <= ch && ch < 0xC790)
+						&& lengtheningVowel[((prevChr - 0xAC00) / 28) % 21] == ((ch - 0xAC00) / 28) % 21)
+					{
+						lnodes.emplace_back(1u, curNode);
+						for (size_t i = 0; i < prevSize; ++i) { const auto nd = lnodes[i]; if (nd.first < 8) lnodes.emplace_back(nd.first + 1, nd.second); }
+					}
+					size_t outIdx = 0;
+					for (size_t i = 0; i < prevSize; ++i)
+					{
+						auto nd = lnodes[i];
+						nd.second = trieNext((uint32_t)nd.second, ch);
+						lnodes[i] = nd;
+						if (nd.second < 0) continue;
+						if (std::find(lnodes.begin(), lnodes.begin() + outIdx, nd) != lnodes.begin() + outIdx) continue;
+						lnodes[outIdx++] = nd;
+					}
+					for (size_t i = prevSize; i < lnodes.size(); ++i)
+					{
+						const auto nd = lnodes[i];
+						if (std::find(lnodes.begin(), lnodes.begin() + outIdx, nd) != lnodes.begin() + outIdx) continue;
+						lnodes[outIdx++] = nd;
+					}
+					lnodes.resize(outIdx);
+				}
 				prevChr = c32;
 
 				if (minFormLen > 0 || tn.typoCost > 0) ++minFormLen;
@@ -259,13 +293,23 @@ namespace korc
 							if (v != TRIE_SUBMATCH)
 							{
 								if (M.forms[v].len < minFormLen) break;
-								cands.push_back((uint32_t)v);
+								cands.push_back(Cand{ (uint32_t)v, 0 });
+							}
+						}
+						for (auto& ln : lnodes)
+						{
+							const int32_t v = M.trie[ln.second].value;
+							if (v >= 0)
+							{
+								if (M.forms[v].len < minFormLen) continue;
+								cands.push_back(Cand{ (uint32_t)v, ln.first });
 							}
 						}
 					}
 				}
 				else
 				{
+					lnodes.clear();
 					if (typoCost == 0) curNode = 0;
 					else return;
 				}
@@ -289,14 +333,16 @@ namespace korc
 				{
 					curNode = 0; typoCost = 0; minFormLen = 0; startPosOffset = -1;
 					if (!cur.empty()) return;
+					lnodes.clear();
 				}
-				if (typoCost > 0 && M.trie[curNode].depth < minFormLen) {}      // early pruning
+				if (typoCost > 0 && M.trie[curNode].depth < minFormLen && lnodes.empty()) {}      // early pruning
 				else
 				{
 					SState ns; ns.node = curNode; ns.cost = typoCost; ns.minFormLen = minFormLen; ns.startPosOffset = startPosOffset;
 					ns.specialStart = specialStart; ns.unkStart = unkStart; ns.boundary = boundary; ns.lastChr = prevChr;
 					ns.startCti = tn.continualTypoIdx ? tn.continualTypoIdx : st.startCti;
-					cur.push_back(ns);
+					ns.lnodes = std::move(lnodes);
+					cur.push_back(std::move(ns));
 				}
 			}
 		}
@@ -308,7 +354,7 @@ namespace korc
 		bool build(std::vector<LNode>& ret, const char16_t* s, uint32_t len, const PatternSpan* patBegin, const PatternSpan* patEndIn, uint32_t startOffset,
 			const typo::Prepared& prepared, float threshold, uint16_t allowedDialect)
 		{
-			if (std::isfinite(prepared.lengthening())) throw std::runtime_error{ "typo lattice oracle: lengthening typos are not restated" };
+			lengtheningCost = prepared.lengthening(); lengthening = std::isfinite(lengtheningCost);
 			str = s; n = len; pat = patBegin; patEnd = patEndIn; typoThreshold = threshold;
 			nsToPos.clear(); posToNs.clear(); out.clear();
 			for (uint32_t i = 0; i < n; ++i)

@@ -4,7 +4,7 @@ oracle/typo_oracle.hpp is a CPU restatement; here it is pinned, byte for byte, t
 generated from the reference (tests/golden/typo_graphs.json).  Second half: the lattice built OVER such a graph
 (oracle/typo_lattice_oracle.hpp: per-branch search states, typo costs, continual-typo positions) and the whole analysis with a typo
 transformer -- lattices, tokens, fp32 scores and typo costs equal the reference's (kref_split_typo / kref_analyze_typo) on misspelt
-texts.  Lengthening typos are not restated; nothing of this is on the device yet."""
+texts -- including lengthening typos.  Nothing of this is on the device yet."""
 import json
 import os
 
@@ -97,7 +97,8 @@ def _norm(res):
 
 
 @pytest.mark.parametrize("name,threshold,carry", [("basic", 2.5, False), ("basic", 6.0, False), ("continual", 2.5, True), ("basic_with_continual", 2.5, True),
-                                                   ("basic_with_continual", 1.2, True), ("dialect", 2.5, False)])
+                                                   ("basic_with_continual", 1.2, True), ("dialect", 2.5, False), ("lengthening", 2.5, False),
+                                                   ("basic_with_continual_and_lengthening", 2.5, True), ("basic_with_continual_and_lengthening", 4.0, True)])
 def test_typo_lattices_and_analyses_equal_reference(small_model, name, threshold, carry):
     """Misspelt texts of the synthetic model (confusable vowels, codas carried over to the next syllable) through Kiwi::analyze with a
     typo transformer, reference vs oracle: the lattice of every chunk (nodes, links, typo costs) and the analyses (tokens, positions,
@@ -116,7 +117,7 @@ def test_typo_lattices_and_analyses_equal_reference(small_model, name, threshold
     ot = oraclelib.OracleTypo(); ot.update_entries(ents, cont, leng); ot.prepare(True)
     rnd = random.Random(5)
     dia = 0xFFFF if name == "dialect" else 0
-    tt = [misspell(t, rnd, True, carry) for t in synthetic(sm, 70, 701, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 40, 702)] + EDGE_TEXTS
+    tt = [misspell(t, rnd, True, carry, "lengthening" in name) for t in synthetic(sm, 70, 701, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 40, 702)] + EDGE_TEXTS
     corrected = 0
     for t in tt:
         if not t.strip():
@@ -125,7 +126,7 @@ def test_typo_lattices_and_analyses_equal_reference(small_model, name, threshold
         a = ref.analyze_typo(rt, t, threshold, dia)
         assert _norm(a) == _norm(orc.analyze_typo(ot, t, threshold, dia)), t
         corrected += any(x.typo_cost > 0 for x in a[0][0])
-    assert corrected >= (20 if name.startswith("basic") or carry else 1)
+    assert corrected >= (20 if name.startswith("basic") or carry or "lengthening" in name else 1)
 
 
 def test_golden_typo_analyses(small_model):

@@ -36,9 +36,13 @@ def texts(n, seed):
 CODA2ONSET = {1: 0, 4: 2, 7: 3, 8: 5, 16: 6, 17: 7, 19: 9, 22: 12, 23: 14, 24: 15, 25: 16, 26: 17, 27: 18}
 
 
-def misspell(text, rnd, vowels=True, carry=True):
-    """Injects the kinds of errors the built-in typo sets correct into a text of the synthetic model: confusable vowels (ㅐ/ㅔ, ㅚ/ㅙ)
-    and a coda written as the onset of the following vowel-initial syllable (연철, what the continual rules undo)."""
+LENGTHENING_VOWEL = [0, 1, 0, 1, 4, 5, 4, 5, 8, 0, 1, 1, 8, 13, 4, 5, 20, 13, 18, 20, 20]
+
+
+def misspell(text, rnd, vowels=True, carry=True, lengthen=False):
+    """Injects the kinds of errors the built-in typo sets correct into a text of the synthetic model: confusable vowels (ㅐ/ㅔ, ㅚ/ㅙ),
+    a coda written as the onset of the following vowel-initial syllable (연철, what the continual rules undo), and 1-3 syllables that
+    merely lengthen the vowel of an open syllable ("가아아", what the lengthening cost pays for)."""
     o = list(text)
     if vowels:
         for i, ch in enumerate(o):
@@ -58,4 +62,12 @@ def misspell(text, rnd, vowels=True, carry=True):
                 if coda in CODA2ONSET and onset == 11:
                     o[i] = chr(a - coda)
                     o[i + 1] = chr(b + (CODA2ONSET[coda] - 11) * 21 * 28)
+    if lengthen:
+        p = []
+        for ch in o:
+            p.append(ch)
+            c = ord(ch)
+            if 0xAC00 <= c < 0xD7A4 and (c - 0xAC00) % 28 == 0 and rnd.random() < 0.2:
+                p.append(chr(0xAC00 + (11 * 21 + LENGTHENING_VOWEL[(c - 0xAC00) // 28 % 21]) * 28) * rnd.randint(1, 3))
+        o = p
     return "".join(o)
