@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <algorithm>
 #include <functional>
 
@@ -161,12 +162,13 @@ inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hip
 inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)std::malloc(8); return hipSuccess; }
+inline double hipemu_now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)std::malloc(8); *(double*)*e = 0; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { *(double*)e = hipemu_now_ms(); return hipSuccess; }      // (everything before it has finished)
 inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*(double*)b - *(double*)a); return hipSuccess; }      // host wall clock of the emulated work
 
 // the kernel expression is evaluated by every lane (a call through the function the product names); arguments are read-only views
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
