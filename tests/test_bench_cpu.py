@@ -42,3 +42,40 @@ def test_bench_main_emits_the_contract_line(tmp_path):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in out["cpu_baseline"], k
     assert out["cpu_baseline"]["kind"] in ("reference", "port") and out["cpu_baseline"]["value"] > 0
+
+
+DRIVER2 = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+torch.cuda.synchronize = lambda *a, **k: None
+import kiwi_amd.dist as D
+_init, _mx, _gc = D.init, D.max_over_ranks, D.gather_counts
+D.init = lambda backend, device_index=None: _init("gloo")            # RCCL on the GPU box; gloo here
+D.max_over_ranks = lambda v, device="cpu": _mx(v, "cpu")
+D.gather_counts = lambda v, device="cpu": _gc(v, "cpu")
+import kiwi_amd.workloads as W
+orig = W.get_workload
+W.get_workload = lambda name: (lambda p, t, d: (p, t[:16], d))(*orig(name))
+import bench
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small-c2", "--no-cpu-baseline"]
+bench.main()
+'''
+
+
+def test_bench_main_with_two_ranks(tmp_path):
+    """The N > 1 flow of bench.py exactly as the driver launches it (torch.distributed.run, one process per rank): rank 0 prepares the
+    workload first, every rank analyses a same-sized shard, barrier + MAX over ranks of the time, one JSON line from rank 0 with the
+    whole-job rate.  gloo instead of RCCL, emulated kernels instead of a GPU."""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hipemu"), "-j8"], stdout=subprocess.DEVNULL)
+    drv = tmp_path / "bench_two_ranks.py"
+    drv.write_text(DRIVER2 % {"root": ROOT})
+    env = dict(os.environ, KAMD_LIB=os.path.join(HERE, "hipemu", "_build", "libkiwi_hipemu.so"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29633", str(drv)],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "shard2" and out["config"]["sentences_per_gpu"] == 16
+    assert abs(out["value"] - 16 * 2 * 2 / (out["ms_per_step"] * 2 / 1000.0)) < 1e-6 * out["value"] + 1e-9      # all ranks' sentences / max time
