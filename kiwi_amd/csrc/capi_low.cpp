@@ -8,6 +8,7 @@
 #include "../../include/kiwi_amd.h"
 #include "engine.hpp"
 #include "sbg_eval.hpp"
+#include "typo.hpp"
 
 using namespace kamd;
 
@@ -144,6 +145,65 @@ extern "C"
 			*pos = p;
 			return 0;
 		}, -1);
+	}
+
+	// ---- typo transformers (typo.hpp): host-side building block; analyze does not take them yet ---------------------------------------------
+	struct kamd_typo { TypoTransformer tt; std::unique_ptr<PreparedTypo> prepared; };
+	kamd_typo* kamd_typo_new(float continual_cost, float lengthening_cost)
+	{
+		return guarded([&]() { auto* t = new kamd_typo; t->tt.setContinualCost(continual_cost); t->tt.setLengtheningCost(lengthening_cost); return t; }, (kamd_typo*)nullptr);
+	}
+	void kamd_typo_close(kamd_typo* t) { delete t; }
+	int kamd_typo_add(kamd_typo* t, const uint16_t* orig, uint32_t n_orig, const uint16_t* error, uint32_t n_error, float cost, int left_cond, int dialect)
+	{
+		if (!t) return -2;
+		return guarded([&]() { t->tt.add(std::u16string{ (const char16_t*)orig, n_orig }, std::u16string{ (const char16_t*)error, n_error }, cost, (uint8_t)left_cond, (uint16_t)dialect); return 0; }, -1);
+	}
+	int kamd_typo_add_entry(kamd_typo* t, const uint16_t* orig, uint32_t n_orig, const uint16_t* error, uint32_t n_error, float cost, int left_cond, int dialect)
+	{
+		if (!t) return -2;
+		return guarded([&]() { t->tt.addEntry(std::u16string{ (const char16_t*)orig, n_orig }, std::u16string{ (const char16_t*)error, n_error }, cost, (uint8_t)left_cond, (uint16_t)dialect); return 0; }, -1);
+	}
+	int kamd_typo_set_costs(kamd_typo* t, float continual_cost, float lengthening_cost)
+	{
+		if (!t) return -2;
+		t->tt.setContinualCost(continual_cost); t->tt.setLengtheningCost(lengthening_cost);
+		return 0;
+	}
+	int kamd_typo_scale(kamd_typo* t, float scale)
+	{
+		if (!t) return -2;
+		return guarded([&]() { t->tt.scaleCost(scale); return 0; }, -1);
+	}
+	int kamd_typo_prepare(kamd_typo* t, int inverse)
+	{
+		if (!t) return -2;
+		return guarded([&]() { t->prepared.reset(new PreparedTypo{ t->tt, inverse != 0 }); return 0; }, -1);
+	}
+	size_t kamd_typo_graph(kamd_typo* t, const uint16_t* text, uint32_t len, int allowed_dialect, int normalize_coda, uint8_t* out, size_t cap)
+	{
+		if (!t || !t->prepared) { lastError = "typo transformer not prepared"; return 0; }
+		return guarded([&]()
+		{
+			U16 norm; std::vector<uint32_t> pos;
+			normalizeWithPosition((const char16_t*)text, len, norm, pos);
+			if (normalize_coda) normalizeCoda(norm);
+			std::vector<TypoGraphNode> g;
+			const size_t maxIdx = t->prepared->graph((const char16_t*)norm.data(), norm.size(), (uint16_t)allowed_dialect, g);
+			size_t need = 0; uint8_t* p = out;
+			auto put = [&](const void* v, size_t n) { need += n; if (p && need <= cap) { std::memcpy(p, v, n); p += n; } };
+			auto put32 = [&](uint32_t v) { put(&v, 4); };
+			put32((uint32_t)norm.size()); put(norm.data(), 2 * norm.size());
+			put32((uint32_t)g.size());
+			for (auto& n : g)
+			{
+				const std::u16string f = t->prepared->formOf(n, (const char16_t*)norm.data());
+				put32((uint32_t)f.size()); put(f.data(), 2 * f.size());
+				put32(n.endPos); put(&n.typoCost, 4); put32(n.prevOffset); put32(n.siblingOffset); put(&n.continualTypoIdx, 1); put(&n.dialect, 2);
+			}
+			put32((uint32_t)maxIdx);
+			return need;
+		}, (size_t)0);
 	}
 
 	size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap)

@@ -1,0 +1,96 @@
+// Typo correction, host side: the rule container, its preparation into a pattern automaton, and the typo
+// graph of a normalised chunk -- the input of the typo-aware lattice build.  Reference behaviour reproduced:
+//   TypoTransformer::addTypo / update / scaleCost        /root/reference/src/TypoTransformer.cpp:224-373
+//   PreparedTypoTransformer (prepare)                    src/TypoTransformer.cpp:375-486
+//   PreparedTypoTransformer::generateGraph               src/TypoTransformer.cpp:594-628, 811-1049
+// STATUS: building block.  The device kernels that build a lattice over such a graph are not written yet, so the analyze entry points
+// still refuse typo transformers (capi_kiwi.cpp); this module is exercised by tests/test_typo_product.py through kamd_typo_*.
+//
+// Layout for the device (flat arrays, uploaded as they are): the pattern automaton is a CSR trie like the form trie (node = edge range,
+// failure link, pattern id or "a shorter pattern ends here" mark; sorted u16 keys; children), patterns index a replacement table, every
+// replacement names a span of one UTF-16 pool.  Graph nodes are 28-byte records whose forms are spans of the chunk text or of that pool.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace kamd
+{
+	enum TypoCond : uint8_t { TC_NONE, TC_ANY, TC_VOWEL, TC_VOCALIC, TC_VOCALIC_H, TC_NON_VOWEL, TC_NON_VOCALIC, TC_NON_VOCALIC_H, TC_APPLOSIVE, TC_CONTINUAL, TC_BOUNDARY };   // CondVowel
+
+	class TypoTransformer
+	{
+	public:
+		struct Key
+		{
+			std::u16string orig, error; uint8_t cond; uint16_t dialect;
+			bool operator==(const Key& o) const { return orig == o.orig && error == o.error && cond == o.cond && dialect == o.dialect; }
+		};
+		// Hash<std::tuple<KString, KString, CondVowel, Dialect>> of the reference (include/kiwi/Types.h:499-518).  It has to be THIS hash over THIS
+		// container: prepare() walks the rules in the map's iteration order, which decides the order of a pattern's replacements.
+		struct KeyHash { size_t operator()(const Key& k) const; };
+		using Map = std::unordered_map<Key, float, KeyHash>;
+
+		void add(const std::u16string& orig, const std::u16string& error, float cost = 1.f, uint8_t cond = TC_NONE, uint16_t dialect = 0);   // addTypo: throws std::invalid_argument
+		void addEntry(const std::u16string& orig, const std::u16string& error, float cost, uint8_t cond, uint16_t dialect);                    // one entry of update()
+		void update(const TypoTransformer& o);
+		void scaleCost(float scale);
+		void setContinualCost(float c) { continualCost_ = c; }
+		void setLengtheningCost(float c) { lengtheningCost_ = c; }
+		float continualCost() const { return continualCost_; }
+		float lengtheningCost() const { return lengtheningCost_; }
+		const Map& rules() const { return typos_; }
+		bool empty() const { return typos_.empty() && !std::isfinite(continualCost_) && !std::isfinite(lengtheningCost_); }
+
+	private:
+		void addWithCond(const std::u16string& orig, const std::u16string& error, float cost, uint8_t cond, uint16_t dialect);
+		void addNormalized(const std::u16string& orig, const std::u16string& error, float cost, uint8_t cond, uint16_t dialect);
+		Map typos_;
+		float continualCost_ = INFINITY, lengtheningCost_ = INFINITY;
+	};
+
+	struct TypoGraphNode      // TypoGraphNode of the reference (include/kiwi/TypoTransformer.h:131-157), form as a span
+	{
+		uint32_t formOff;      // bit 31 set: offset into the prepared transformer's pool, else into the chunk text
+		uint32_t formLen;
+		uint32_t endPos;
+		float typoCost;
+		uint32_t prevOffset, siblingOffset;
+		uint8_t continualTypoIdx; uint8_t pad; uint16_t dialect;
+	};
+	static_assert(sizeof(TypoGraphNode) == 28, "TypoGraphNode");
+	constexpr uint32_t TYPO_FORM_IN_POOL = 0x80000000u;
+
+	class PreparedTypo
+	{
+	public:
+		struct TrieNode { uint32_t edgeOff; uint16_t numNexts, depth; int32_t fail; int32_t pattern; };   // pattern: id, -1 none, -2 a shorter pattern ends here
+		struct Pattern { uint32_t replOff, replCnt, patLength; };
+		struct Repl { uint32_t strOff, strLen; float cost; uint8_t cond; uint8_t pad; uint16_t dialect; };
+
+		PreparedTypo(const TypoTransformer& tt, bool inverse);
+		float continualCost() const { return continualCost_; }
+		float lengtheningCost() const { return lengtheningCost_; }
+		bool ready() const { return !repls_.empty(); }
+
+		// generateGraph over the normalised text str[0..n); returns max(continual typo index) + 1 over the match clusters (>= 0; 0 = none seen)
+		size_t graph(const char16_t* str, size_t n, uint16_t allowedDialect, std::vector<TypoGraphNode>& out) const;
+		std::u16string formOf(const TypoGraphNode& g, const char16_t* str) const;
+
+		// flat tables (device upload)
+		const std::vector<TrieNode>& trie() const { return trie_; }
+		const std::vector<uint16_t>& trieKeys() const { return keys_; }
+		const std::vector<uint32_t>& trieChildren() const { return children_; }
+		const std::vector<Pattern>& patterns() const { return pats_; }
+		const std::vector<Repl>& replacements() const { return repls_; }
+		const std::u16string& pool() const { return pool_; }
+
+	private:
+		int32_t step(int32_t node, char16_t c) const;
+		std::vector<TrieNode> trie_; std::vector<uint16_t> keys_; std::vector<uint32_t> children_;
+		std::vector<Pattern> pats_; std::vector<Repl> repls_; std::u16string pool_;
+		float continualCost_ = INFINITY, lengtheningCost_ = INFINITY;
+	};
+}
