@@ -82,6 +82,9 @@ int kamd_typo_set_costs(kamd_typo_h t, float continual_cost, float lengthening_c
 int kamd_typo_scale(kamd_typo_h t, float scale);
 int kamd_typo_prepare(kamd_typo_h t, int inverse);
 size_t kamd_typo_graph(kamd_typo_h t, const uint16_t* text, uint32_t len, int allowed_dialect, int normalize_coda, uint8_t* out, size_t cap);
+/* parity hook: the lattices the device builds OVER the typo graphs of a text's chunks (csrc/typo_lattice_kernel.hip), in the layout of kamd_dump_lattices;
+ * lengthening typos are refused; 0 + kamd_last_error() on failure */
+size_t kamd_typo_lattices(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);
 size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap);
 size_t kamd_dump_lattices(kamd_engine_h h, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);
 

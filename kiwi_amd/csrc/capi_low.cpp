@@ -206,6 +206,12 @@ extern "C"
 		}, (size_t)0);
 	}
 
+	size_t kamd_typo_lattices(kamd_engine_h h, kamd_typo* t, float threshold, int allowed_dialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
+	{
+		if (!h || !t || !t->prepared) { lastError = "invalid handle / typo transformer not prepared"; return 0; }
+		return guarded([&]() { auto d = h->e->dumpTypoLattices(*t->prepared, threshold, (uint16_t)allowed_dialect, (const char16_t*)text, len, match); if (d.size() <= cap) std::memcpy(out, d.data(), d.size()); return d.size(); }, (size_t)0);
+	}
+
 	size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap)
 	{
 		if (!h) return 0;

@@ -17,6 +17,7 @@
 #include "engine.hpp"
 #include "viterbi_kernel.hpp"
 #include "exact_math.hpp"
+#include "typo_lattice_kernel.hpp"
 
 namespace kamd
 {
@@ -819,6 +820,109 @@ namespace kamd
 				put32(nd.spaceErrors); put32(0);
 			}
 			++ri;
+		}
+		return out;
+	}
+
+	// Parity hook: typo graphs on the host (typo.cpp), the lattice over each of them by k_build_lattice_typo, dumped like dumpLattices.
+	std::vector<uint8_t> Engine::dumpTypoLattices(const PreparedTypo& typo, float threshold, uint16_t allowedDialect, const char16_t* text, size_t n, uint64_t match)
+	{
+		if (std::isfinite(typo.lengtheningCost())) throw std::runtime_error{ "typo lattices: lengthening typos are not handled by the kernel yet" };
+		PreparedText pt;
+		prepareText(pt, text, n, match, 0);
+		std::vector<TypoLatChunk> chunks; std::vector<uint32_t> chunkOf;
+		std::vector<TypoGraphNode> graph; std::vector<uint8_t> graphLast; std::vector<DevPattern> pats;
+		uint32_t nodeTop = 0, mapTop = 0, nsTop = 0, stateTop = 0;
+		std::vector<TypoGraphNode> g;
+		for (size_t ci = 0; ci < pt.chunks.size(); ++ci)
+		{
+			const ChunkDesc& d = pt.chunks[ci];
+			if (d.empty) continue;
+			const char16_t* str = (const char16_t*)pt.norm.data() + d.startOffset;
+			if (d.nChars > 20000) throw std::runtime_error{ "typo lattices: chunk too long" };
+			const size_t maxCti = typo.graph(str, d.nChars, allowedDialect, g);
+			TypoLatChunk c{};
+			c.charOff = d.startOffset; c.nChars = d.nChars; c.textOffset = d.startOffset;
+			c.patOff = (uint32_t)pats.size(); c.patCnt = d.patEnd - d.patBegin;
+			for (uint32_t k = d.patBegin; k < d.patEnd; ++k) pats.push_back(DevPattern{ pt.patterns[k].end, pt.patterns[k].length, pt.patterns[k].tag });
+			c.graphOff = (uint32_t)graph.size(); c.graphCnt = (uint32_t)g.size();
+			for (auto& gn : g)
+			{
+				// type / script of the node's last character as progressNode leaves it in prevChr (surrogate pairs merged; NUL = none)
+				uint32_t lastC = 0; bool any = false;
+				const std::u16string f = typo.formOf(gn, str);
+				for (size_t j = 0; j < f.size(); ++j)
+				{
+					uint32_t c32 = f[j];
+					if (isHighSurrogate(c32) && j + 1 < f.size()) { c32 = mergeSurrogate(c32, f[j + 1]); ++j; }
+					lastC = c32; any = true;
+				}
+				graphLast.push_back((any && lastC) ? identifySpecialChr(lastC) : (uint8_t)0xFF);
+				graphLast.push_back((any && lastC) ? chr2ScriptType(lastC) : (uint8_t)0);
+				graph.push_back(gn);
+			}
+			c.pmb = 0;
+			if (maxCti > 1) { size_t v = maxCti - 1; while (v > 0) { v >>= 1; ++c.pmb; } }
+			uint32_t nNs = 0;
+			for (uint32_t i = 0; i < d.nChars; ++i) if (!isSpace(str[i])) { ++nNs; if (isHighSurrogate(str[i]) && i + 1 < d.nChars) { ++nNs; ++i; } }
+			c.nNs = nNs;
+			c.nodeOff = nodeTop; c.nodeCap = 16 * d.nChars + 64; nodeTop += c.nodeCap;
+			c.mapOff = mapTop; c.mapLen = (nNs << c.pmb) + 1; mapTop += c.mapLen;
+			c.nsOff = nsTop; nsTop += d.nChars + 2;
+			c.stateOff = stateTop; c.stateCap = (uint32_t)g.size() * 16 + 64; stateTop += c.stateCap;
+			chunkOf.push_back((uint32_t)ci);
+			chunks.push_back(c);
+		}
+		std::vector<TypoLatNode> fin(nodeTop);
+		if (!chunks.empty())
+		{
+			std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+			HIPCHECK(hipSetDevice(impl->device));
+			hipStream_t s = impl->stream;
+			DevBuf dChars, dCls, dScript, dPats, dGraph, dGraphLast, dPool, dChunks, dNodes, dFinal, dMap, dNs, dPs, dStates, dSIdx, dScratch;
+			std::vector<uint16_t> chars(pt.norm.begin(), pt.norm.end()), pool(typo.pool().begin(), typo.pool().end());
+			if (pats.empty()) pats.push_back(DevPattern{ 0, 0, 0 });
+			if (pool.empty()) pool.push_back(0);
+			upload(dChars, chars, s); upload(dCls, pt.cls, s); upload(dScript, pt.script, s); upload(dPats, pats, s);
+			upload(dGraph, graph, s); upload(dGraphLast, graphLast, s); upload(dPool, pool, s); upload(dChunks, chunks, s);
+			dNodes.ensure((size_t)nodeTop * sizeof(TypoLatNode)); dFinal.ensure((size_t)nodeTop * sizeof(TypoLatNode)); dMap.ensure((size_t)mapTop * 8 + 16);
+			dNs.ensure((size_t)nsTop * 2 + 16); dPs.ensure((size_t)nsTop * 2 + 16); dStates.ensure((size_t)stateTop * sizeof(TypoState)); dSIdx.ensure(graph.size() * 8 + 16);
+			dScratch.ensure((size_t)nodeTop * 12 + 16);
+			TypoLatView v{};
+			v.chars = dChars.as<uint16_t>(); v.cls = dCls.as<uint8_t>(); v.script = dScript.as<uint8_t>(); v.patterns = dPats.as<DevPattern>();
+			v.graph = dGraph.as<TypoGraphNode>(); v.graphLast = dGraphLast.as<uint8_t>(); v.pool = dPool.as<uint16_t>(); v.chunks = dChunks.as<TypoLatChunk>();
+			v.nodes = dNodes.as<TypoLatNode>(); v.nodesFinal = dFinal.as<TypoLatNode>(); v.endPosMap = dMap.as<uint2>(); v.nsToPos = dNs.as<uint16_t>(); v.posToNs = dPs.as<uint16_t>();
+			v.states = dStates.as<TypoState>(); v.stateIdx = dSIdx.as<uint32_t>(); v.scratch = dScratch.as<uint32_t>();
+			v.threshold = threshold; v.maxUnk = config.maxUnkFormSize; v.maxUnkJ = config.maxUnkFormSizeFollowedByJClass; v.spaceTol = config.spaceTolerance; v.match = match;
+			launchTypoLattice(impl->dview, v, (uint32_t)chunks.size(), s);
+			HIPCHECK(hipGetLastError());
+			HIPCHECK(hipMemcpyAsync(chunks.data(), dChunks.p, chunks.size() * sizeof(TypoLatChunk), hipMemcpyDeviceToHost, s));
+			HIPCHECK(hipMemcpyAsync(fin.data(), dFinal.p, fin.size() * sizeof(TypoLatNode), hipMemcpyDeviceToHost, s));
+			HIPCHECK(hipStreamSynchronize(s));
+		}
+		std::vector<uint8_t> out;
+		auto put32 = [&](uint32_t v) { out.insert(out.end(), (uint8_t*)&v, (uint8_t*)&v + 4); };
+		put32((uint32_t)pt.chunks.size());
+		size_t ri = 0;
+		for (size_t c = 0; c < pt.chunks.size(); ++c)
+		{
+			const ChunkDesc& d = pt.chunks[c];
+			if (d.empty)
+			{
+				put32(2); put32(d.nextOffset);
+				for (int k = 0; k < 2; ++k) { put32(0); put32(0); put32(0); put32(0); put32(0xFFFFFFFFu); put32(0); put32(0); put32(0); put32(0); }
+				continue;
+			}
+			const TypoLatChunk& tc = chunks[ri++];
+			if (tc.status != CS_OK) throw std::runtime_error{ "typo lattices: device status " + std::to_string(tc.status) };
+			put32(tc.nOutFinal); put32(d.nextOffset);
+			for (uint32_t k = 0; k < tc.nOutFinal; ++k)
+			{
+				const TypoLatNode& nd = fin[tc.nodeOff + k];
+				put32(nd.startPos); put32(nd.endPos); put32(nd.prev); put32(nd.sibling); put32((uint32_t)nd.form);
+				put32(nd.uformLen); put32(nd.uformLen ? nd.uformOff : 0); put32(nd.spaceErrors);
+				uint32_t cost; std::memcpy(&cost, &nd.typoCost, 4); put32(cost);
+			}
 		}
 		return out;
 	}

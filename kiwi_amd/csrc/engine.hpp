@@ -52,5 +52,8 @@ namespace kamd
 
 		// debugging / parity hooks: lattice of every chunk of one text in the layout of oracle's korc_split
 		std::vector<uint8_t> dumpLattices(const char16_t* text, size_t n, uint64_t match);
+		// ... and the lattices built over the typo graphs a prepared transformer gives for the chunks (typo_lattice_kernel.hip); same layout.
+		// Parity hook of a building block: analyze does not take typo transformers yet.
+		std::vector<uint8_t> dumpTypoLattices(const class PreparedTypo& typo, float threshold, uint16_t allowedDialect, const char16_t* text, size_t n, uint64_t match);
 	};
 }

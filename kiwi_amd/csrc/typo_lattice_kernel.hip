@@ -1,0 +1,408 @@
+// HIP kernel: the morpheme lattice of a chunk built OVER ITS TYPO GRAPH -- Splitter::search /
+// progressNode / flushCandidates / insertUnkForm / hasFormAlready / removeUnconnected / writeResult of the reference
+// (/root/reference/src/KTrie.cpp:897-996, 998-1464, 240-299) in their general form: one search state per (typo-graph node, way of
+// reaching it), positions multiplied by 2^posMultiplierBit for the halves of continual typos.
+//
+// STATUS: first, unoptimised form and a building block -- one THREAD per chunk over HBM arrays (the shape of k_build_lattice_big), reached
+// only through the parity hook Engine::dumpTypoLattices / kamd_typo_lattices; the analyze path does not use it yet (the search kernel has
+// no typo-cost variant).  Lengthening typos are not handled (refused by the caller).  The typo graph itself comes from
+// the host (typo.cpp).  Checked against the CPU oracle through the lane emulator (tests/test_hipemu.py) -- it has not run on a GPU.
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+#include "feature.hpp"
+#include "typo.hpp"
+#include "typo_lattice_kernel.hpp"
+
+namespace kamd
+{
+	namespace
+	{
+		constexpr uint32_t NPOS = 0xFFFFFFFFu;
+		constexpr uint32_t MAXCAND = 96;
+
+		struct Ctx
+		{
+			const ModelView& M; const TypoLatView& V; TypoLatChunk& C;
+			const uint16_t* str; const uint8_t* cls; const uint8_t* script; uint32_t n, nNs, pmb;
+			const uint16_t* nsToPos; const uint16_t* posToNs;
+			uint2* endPosMap; TypoLatNode* out; uint32_t nOut;
+			const DevPattern* pat; const DevPattern* patEnd;
+			bool overflow;
+
+			__device__ bool append(uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, float typoCost = 0.f)
+			{
+				if (endPosMap[s].x == endPosMap[s].y) return false;
+				if (nOut >= C.nodeCap) { overflow = true; return false; }
+				const uint32_t id = nOut++;
+				TypoLatNode nn; nn.startPos = s; nn.endPos = e; nn.prev = id - endPosMap[s].x; nn.sibling = 0; nn.form = (int32_t)form; nn.uformLen = uLen; nn.uformOff = uOff; nn.spaceErrors = 0; nn.typoCost = typoCost;
+				out[id] = nn;
+				if (e >= C.mapLen) return true;
+				uint2 m = endPosMap[e];
+				if (m.x == m.y) { m.x = id; m.y = id + 1; }
+				else { out[m.y - 1].sibling = id - (m.y - 1); m.y = id + 1; }
+				endPosMap[e] = m;
+				return true;
+			}
+			__device__ uint32_t nodeLen(const TypoLatNode& g) const
+			{
+				if (g.uformLen) return g.uformLen;
+				const FormRec f = M.forms[g.form];
+				return f.len - f.numSpaces;
+			}
+			__device__ bool hasForm(uint32_t ms, uint32_t me) const
+			{
+				const uint2 m = endPosMap[me];
+				if (m.x == NPOS) return false;
+				for (uint32_t i = m.x < 1 ? 1 : m.x; i < m.y; ++i)
+				{
+					const TypoLatNode g = out[i];
+					if (g.endPos == me && g.endPos - (nodeLen(g) << pmb) == ms && g.typoCost == 0 && (g.form < 0 || (M.forms[g.form].flags & FF_HAS_ANY_FULL))) return true;
+				}
+				return false;
+			}
+			__device__ void trimmed(uint32_t off, uint32_t len, uint32_t& o, uint32_t& l) const
+			{
+				while (len && isSpace(str[off + len - 1])) --len;
+				o = off; l = len;
+			}
+			__device__ void insertUnk(uint32_t s, uint32_t e, bool hasJ)
+			{
+				if (s >= e || hasForm(s << pmb, e << pmb)) return;
+				uint32_t lastPos = out[nOut - 1].endPos;      // (a multiplied position against plain ones: as in the reference)
+				if (lastPos < e)
+				{
+					if (lastPos && isHangulCoda(str[nsToPos[lastPos]])) lastPos--;
+					if (lastPos != s && !hasForm(lastPos << pmb, e << pmb))
+					{
+						uint32_t o, l; trimmed(nsToPos[lastPos], nsToPos[e - 1] + 1 - nsToPos[lastPos], o, l);
+						append(lastPos << pmb, e << pmb, NOFORM, o, l);
+					}
+				}
+				const uint32_t limit = hasJ ? V.maxUnkJ : V.maxUnk;
+				if (e - s <= limit)
+				{
+					uint32_t o, l; trimmed(nsToPos[s], nsToPos[e - 1] + 1 - nsToPos[s], o, l);
+					append(s << pmb, e << pmb, NOFORM, o, l);
+				}
+			}
+			__device__ void unkPair(uint32_t boundary, uint32_t unkStart, uint32_t e, bool hasJ)
+			{
+				if (boundary < unkStart) insertUnk(boundary, e, hasJ);
+				insertUnk(unkStart, e, hasJ);
+			}
+			__device__ uint32_t spaceErrors(const FormRec& f, uint32_t b, uint32_t e) const
+			{
+				const uint16_t* fs = M.formChars + f.charOff;
+				uint32_t nErr = 0, off = 0;
+				for (uint32_t i = 1; i < e - b; ++i)
+				{
+					const bool hasSpace = nsToPos[b + i] - nsToPos[b + i - 1] > 1;
+					const uint16_t fc = (i + off < f.len) ? fs[i + off] : 0;
+					if (hasSpace && fc != u' ') ++nErr;
+					if (fc == u' ') ++off;
+				}
+				return nErr;
+			}
+			__device__ int32_t trieNext(uint32_t node, uint16_t c) const
+			{
+				if (node == 0) { const uint32_t r = M.trieRoot[c]; return r ? (int32_t)r : -1; }
+				const TrieNodeRec t = M.trie[node];
+				uint32_t lo = 0, hi = t.numNexts;
+				const uint16_t* kb = M.trieKeys + t.edgeOff;
+				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (kb[mid] < c) lo = mid + 1; else hi = mid; }
+				if (lo == t.numNexts || kb[lo] != c) return -1;
+				return (int32_t)M.trieChild[t.edgeOff + lo];
+			}
+			__device__ uint16_t formChar(const TypoGraphNode& g, uint32_t j) const
+			{
+				return (g.formOff & TYPO_FORM_IN_POOL) ? V.pool[(g.formOff & ~TYPO_FORM_IN_POOL) + j] : str[g.formOff + j];
+			}
+
+			__device__ void flush(uint32_t* cands, uint32_t& nCands, uint32_t endNs, int32_t startPosOffset, uint32_t unkStart, uint32_t boundary, float typoCost, uint32_t startCti, uint32_t endCti)
+			{
+				for (uint32_t k = 0; k < nCands; ++k)
+				{
+					const uint32_t fi = cands[k];
+					const FormRec f = M.forms[fi];
+					const uint32_t nb = (uint32_t)((int32_t)endNs - (int32_t)(f.len - f.numSpaces) + startPosOffset), ne = endNs;
+					if (startCti == 0 && !(f.flags & FF_FIRST_IS_CODA))
+					{
+						const bool hj = (f.flags & FF_HAS_JCLASS) || (f.flags & FF_IS_STAG);
+						if (boundary < nb) insertUnk(boundary, nb, hj);
+						insertUnk(unkStart, nb, hj);
+					}
+					const uint32_t se = spaceErrors(f, nb, ne);
+					if (se <= V.spaceTol)
+					{
+						const uint32_t b2 = startCti ? (nb << pmb) + startCti : nb << pmb;
+						const uint32_t e2 = endCti ? ((ne - 1) << pmb) + endCti : ne << pmb;
+						if (append(b2, e2, fi, 0, 0, typoCost)) out[nOut - 1].spaceErrors = se;
+					}
+				}
+				nCands = 0;
+			}
+
+			// progressNode: state `st` of graph node `prevT` continued through graph node `tn`; new states go to cur[0..nCur)
+			__device__ void progress(const TypoGraphNode& prevT, const TypoGraphNode& tn, uint32_t tnIdx, const TypoState st, TypoState* cur, uint32_t& nCur, uint32_t curCap)
+			{
+				float typoCost = st.cost + tn.typoCost;
+				if (typoCost > V.threshold) return;
+				uint8_t lastType = st.hasLast ? st.lastType : (uint8_t)T_UNKNOWN;
+				uint8_t lastScript = st.hasLast ? st.lastScript : (uint8_t)0;
+				uint8_t outType = st.lastType, outScript = st.lastScript, outHas = st.hasLast;      // what the last character of this node leaves behind
+				uint32_t specialStart = st.specialStart, unkStart = st.unkStart, boundary = st.boundary;
+				uint32_t minFormLen = st.minFormLen;
+				int32_t startPosOffset = st.startPosOffset;
+				const uint32_t fsz = tn.formLen;
+				if (tn.typoCost > 0) startPosOffset += (int32_t)fsz - (int32_t)(tn.endPos - prevT.endPos);
+				if (fsz) { outType = V.graphLast[2 * tnIdx]; outScript = V.graphLast[2 * tnIdx + 1]; outHas = outType != 0xFF; }
+				int32_t curNode = st.node;
+				const uint8_t scriptVS = 98;
+				uint32_t cands[MAXCAND]; uint32_t nCands = 0;
+				auto push = [&](uint32_t f) { if (nCands < MAXCAND) cands[nCands++] = f; else overflow = true; };
+				for (uint32_t j = 0; j < fsz; ++j)
+				{
+					const uint16_t ch = formChar(tn, j);
+					uint32_t c32 = ch;
+					if (isHighSurrogate(c32) && j + 1 < fsz) c32 = mergeSurrogate(c32, formChar(tn, j + 1));
+					const uint32_t pos = tn.endPos + j - fsz;
+					if (typoCost == 0)
+					{
+						const bool inPattern = pat != patEnd && pos >= pat->end - pat->length;
+						uint8_t type = cls[pos] & 0x3F, sct = script[pos];
+						if (lastType == T_SW && (c32 == 0x200d || (0x1f3fb <= c32 && c32 <= 0x1f3ff) || sct == scriptVS)) { type = lastType; sct = lastScript; }
+						const uint8_t curT = inPattern ? (uint8_t)T_UNKNOWN : type;
+						const bool symA = lastType == T_SL || lastType == T_SH || lastType == T_SW, symB = curT == T_SL || curT == T_SH || curT == T_SW;
+						const bool discont = (symA && symB) ? (lastScript != sct) : (lastType != curT);
+						if (discont || lastType == T_SSO || lastType == T_SSC)
+						{
+							if (lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
+							{
+								const bool sj = T_SF <= lastType && lastType <= T_SW;
+								unkPair(boundary, unkStart, specialStart, sj);
+								uint32_t o, l; trimmed(nsToPos[specialStart], pos - nsToPos[specialStart], o, l);
+								append(specialStart << pmb, (uint32_t)posToNs[pos] << pmb, lastType - 1u, o, l);
+							}
+							unkStart = specialStart;
+							specialStart = posToNs[pos];
+							if (T_SF <= lastType && lastType <= T_SW) boundary = specialStart;
+						}
+						else if (type == T_MAX) unkStart = specialStart;
+						lastType = curT; lastScript = sct;
+						if (c32 < 0x10000)
+						{
+							if (type == T_UNKNOWN)
+							{
+								unkPair(boundary, unkStart, posToNs[pos + 1], true);
+								boundary = specialStart = unkStart = posToNs[pos + 1];
+								continue;
+							}
+							bool zc = false, zs = false;
+							const uint32_t p = posToNs[pos];
+							if (p < nNs)
+							{
+								const uint2 m = endPosMap[p << pmb];
+								if (m.x != NPOS) for (uint32_t i = m.x; i < m.y; ++i)
+								{
+									const TypoLatNode g = out[i];
+									if (g.endPos != (p << pmb) || g.form < 0) continue;
+									const uint8_t ff = M.forms[g.form].flags;
+									zc = zc || (ff & FF_ZCODA_APPENDABLE); zs = zs || (ff & FF_ZSIOT_APPENDABLE);
+								}
+							}
+							if ((V.match & M_Z_CODA) && zc && isHangulCoda(ch) && (pos + 1 >= n || !isHangulSyllable(str[pos + 1]))) push(kDefaultTagSize + (ch - 0x11A8) - 1u);
+							else if ((V.match & (M_SPLIT_SAISIOT | M_MERGE_SAISIOT)) && zs && ch == 0x11BA && pos + 1 < n && isHangulSyllable(str[pos + 1])) push(kDefaultTagSize + (0x11BA - 0x11A8) - 1u);
+						}
+					}
+					else if (isSpace(c32))
+					{
+						boundary = specialStart = unkStart = posToNs[pos + 1];
+						continue;
+					}
+					if (tn.typoCost == 0 && pat != patEnd)
+					{
+						const uint32_t curEnd = pos + (c32 >= 0x10000 ? 2 : 1);
+						while (pat != patEnd && pat->end == curEnd)
+						{
+							const uint32_t ms = pat->end - pat->length;
+							const bool wj = T_W_URL <= pat->tag && pat->tag <= T_W_EMOJI;
+							unkPair(boundary, unkStart, posToNs[ms], wj);
+							append((uint32_t)posToNs[ms] << pmb, (uint32_t)posToNs[pat->end] << pmb, pat->tag - 1u, ms, pat->length);
+							++pat;
+						}
+					}
+					if (c32 >= 0x10000) { ++j; continue; }
+
+					if (minFormLen > 0 || tn.typoCost > 0) ++minFormLen;
+					int32_t nx = trieNext((uint32_t)curNode, ch);
+					while (nx < 0)
+					{
+						curNode = M.trie[curNode].fail;
+						if (curNode < 0) break;
+						nx = trieNext((uint32_t)curNode, ch);
+					}
+					if (nx >= 0)
+					{
+						curNode = nx;
+						if (tn.typoCost == 0 || j == fsz - 1)
+						{
+							if (typoCost > 0 && M.trie[curNode].depth < minFormLen) {}      // early pruning
+							else for (int32_t sm = curNode; sm >= 0; sm = M.trie[sm].fail)
+							{
+								const int32_t v = M.trie[sm].value;
+								if (v == TRIE_NONE) break;
+								if (v != TRIE_SUBMATCH)
+								{
+									if (M.forms[v].len < minFormLen) break;
+									push((uint32_t)v);
+								}
+							}
+						}
+					}
+					else
+					{
+						if (typoCost == 0) curNode = 0;
+						else return;
+					}
+					flush(cands, nCands, posToNs[tn.endPos + j + 1 - fsz], startPosOffset, unkStart, boundary, typoCost, st.startCti, tn.continualTypoIdx);
+				}
+				if (typoCost == 0 && lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
+				{
+					const bool sj = T_SF <= lastType && lastType <= T_SW;
+					unkPair(boundary, unkStart, specialStart, sj);
+					uint32_t o, l; trimmed(nsToPos[specialStart], tn.endPos - nsToPos[specialStart], o, l);
+					append(specialStart << pmb, (uint32_t)posToNs[tn.endPos] << pmb, lastType - 1u, o, l);
+					unkStart = specialStart;
+					if (sj) boundary = posToNs[tn.endPos];
+				}
+				if (curNode >= 0)
+				{
+					if (tn.continualTypoIdx)
+					{
+						curNode = 0; typoCost = 0; minFormLen = 0; startPosOffset = -1;
+						if (nCur) return;
+					}
+					if (typoCost > 0 && M.trie[curNode].depth < minFormLen) return;      // early pruning
+					if (nCur >= curCap) { overflow = true; return; }
+					TypoState ns; ns.node = curNode; ns.cost = typoCost; ns.minFormLen = minFormLen; ns.startPosOffset = startPosOffset;
+					ns.specialStart = specialStart; ns.unkStart = unkStart; ns.boundary = boundary;
+					ns.lastType = outType; ns.lastScript = outScript; ns.hasLast = outHas; ns.pad = 0;
+					ns.startCti = tn.continualTypoIdx ? tn.continualTypoIdx : st.startCti; ns.pad2 = 0;
+					cur[nCur++] = ns;
+				}
+			}
+		};
+	}
+
+	__global__ void __launch_bounds__(64) k_build_lattice_typo(ModelView M, TypoLatView V, uint32_t nChunks)
+	{
+		const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+		if (c >= nChunks) return;
+		TypoLatChunk& C = V.chunks[c];
+		Ctx X{ M, V, C };
+		X.str = V.chars + C.charOff; X.cls = V.cls + C.charOff; X.script = V.script + C.charOff; X.n = C.nChars; X.pmb = C.pmb;
+		uint16_t* nsToPos = V.nsToPos + C.nsOff; uint16_t* posToNs = V.posToNs + C.nsOff;
+		uint32_t nNs = 0;
+		for (uint32_t i = 0; i < X.n; ++i)
+		{
+			posToNs[i] = (uint16_t)nNs;
+			if (!isSpace(X.str[i]))
+			{
+				nsToPos[nNs++] = (uint16_t)i;
+				if (isHighSurrogate(X.str[i]) && i + 1 < X.n) { posToNs[i + 1] = (uint16_t)nNs; nsToPos[nNs++] = (uint16_t)(i + 1); ++i; }
+			}
+		}
+		posToNs[X.n] = (uint16_t)nNs;
+		X.nNs = nNs; X.nsToPos = nsToPos; X.posToNs = posToNs;
+		X.endPosMap = V.endPosMap + C.mapOff; X.out = V.nodes + C.nodeOff; X.nOut = 0; X.overflow = false;
+		X.pat = V.patterns + C.patOff; X.patEnd = X.pat + C.patCnt;
+		if (((nNs << X.pmb) + 1) > C.mapLen || nNs != C.nNs) { C.status = CS_ERR_NODE_OVERFLOW; return; }
+		for (uint32_t i = 0; i < C.mapLen; ++i) X.endPosMap[i] = make_uint2(NPOS, NPOS);
+		X.endPosMap[0] = make_uint2(0, 1);
+		{ TypoLatNode z{}; z.form = -1; X.out[X.nOut++] = z; }
+
+		// search (KTrie.cpp:1414-1452): states of graph node i are the contiguous run stateIdx[2i] .. +stateIdx[2i+1] of the chunk's arena
+		const TypoGraphNode* graph = V.graph + C.graphOff;
+		TypoState* states = V.states + C.stateOff;
+		uint32_t* sIdx = V.stateIdx + 2 * C.graphOff;
+		const uint32_t totEnd = nNs ? (uint32_t)nsToPos[nNs - 1] + 1 : 0;
+		uint32_t top = 0;
+		{ TypoState s0{}; states[top] = s0; sIdx[0] = 0; sIdx[1] = 1; ++top; }
+		for (uint32_t i = 1; i < C.graphCnt; ++i)
+		{
+			const TypoGraphNode tn = graph[i];
+			const uint32_t curBeg = top; uint32_t nCur = 0;
+			for (uint32_t p = tn.prevOffset ? i - tn.prevOffset : NPOS; p != NPOS; p = graph[p].siblingOffset ? p + graph[p].siblingOffset : NPOS)
+			{
+				const TypoGraphNode pt = graph[p];
+				for (uint32_t k = 0; k < sIdx[2 * p + 1]; ++k)
+					X.progress(pt, tn, C.graphOff + i, states[sIdx[2 * p] + k], states + curBeg, nCur, C.stateCap - curBeg);
+			}
+			sIdx[2 * i] = curBeg; sIdx[2 * i + 1] = nCur; top = curBeg + nCur;
+			if (tn.typoCost == 0 && tn.endPos == totEnd)
+				for (uint32_t k = 0; k < nCur; ++k) X.unkPair(states[curBeg + k].boundary, states[curBeg + k].unkStart, posToNs[totEnd], true);
+		}
+		X.append(nNs << X.pmb, (nNs << X.pmb) + 1, NOFORM, 0, 0);
+		X.out[X.nOut - 1].endPos = nNs << X.pmb;
+		if (X.overflow) { C.status = CS_ERR_NODE_OVERFLOW; return; }
+
+		// removeUnconnected (KTrie.cpp:240-299): reachable from the end node backwards; stable order by (connected, end position)
+		const uint32_t G = X.nOut;
+		uint32_t* conn = V.scratch + 3ull * C.nodeOff; uint32_t* sorted = conn + C.nodeCap; uint32_t* inv = sorted + C.nodeCap;
+		for (uint32_t i = 0; i < G; ++i) conn[i] = 0;
+		uint32_t qh = 0, qt = 0;
+		sorted[qt++] = G - 1; conn[G - 1] = 1;      // (`sorted` doubles as the BFS queue first)
+		while (qh < qt)
+		{
+			const uint32_t id = sorted[qh++];
+			const uint2 m = X.endPosMap[X.out[id].startPos];
+			if (m.x == NPOS) continue;
+			for (uint32_t i = m.x; i < m.y; ++i)
+			{
+				if (X.out[i].endPos != X.out[id].startPos || conn[i]) continue;
+				conn[i] = 1; sorted[qt++] = i;
+			}
+		}
+		uint32_t nConn = 0;
+		for (uint32_t i = 0; i < G; ++i) nConn += conn[i];
+		// stable sort of the connected nodes by end position: insertion sort over the original order (lattices are a few hundred nodes)
+		uint32_t k = 0;
+		for (uint32_t i = 0; i < G; ++i)
+		{
+			if (!conn[i]) continue;
+			uint32_t j = k++;
+			const uint32_t e = X.out[i].endPos;
+			while (j > 0 && X.out[sorted[j - 1]].endPos > e) { sorted[j] = sorted[j - 1]; --j; }
+			sorted[j] = i;
+		}
+		for (uint32_t i = 0; i < G; ++i) inv[i] = NPOS;
+		for (uint32_t i = 0; i < nConn; ++i) inv[sorted[i]] = i;
+		TypoLatNode* fin = V.nodesFinal + C.nodeOff;
+		for (uint32_t i = 0; i < nConn; ++i)
+		{
+			const uint32_t idx = sorted[i];
+			TypoLatNode nn = X.out[idx];
+			if (nn.prev) nn.prev = i - inv[idx - nn.prev];
+			if (nn.sibling)
+			{
+				const uint32_t ns = inv[idx + nn.sibling];
+				nn.sibling = ns == NPOS ? 0 : ns - i;
+			}
+			if (i >= 1 && i + 1 < nConn)      // writeResult (KTrie.cpp:1454-1464)
+			{
+				nn.startPos = (uint32_t)nsToPos[nn.startPos >> X.pmb] + C.textOffset;
+				nn.endPos = (uint32_t)nsToPos[((nn.endPos + (1u << X.pmb) - 1) >> X.pmb) - 1] + 1 + C.textOffset;
+				if (nn.uformLen) nn.uformOff += C.textOffset;
+			}
+			else if (i + 1 == nConn) { nn.startPos = nn.endPos = C.textOffset + X.n; }
+			fin[i] = nn;
+		}
+		C.nOutFinal = nConn;
+		C.status = CS_OK;
+	}
+
+	void launchTypoLattice(const ModelView& M, const TypoLatView& V, uint32_t nChunks, hipStream_t stream)
+	{
+		hipLaunchKernelGGL(k_build_lattice_typo, dim3((nChunks + 63) / 64), dim3(64), 0, stream, M, V, nChunks);
+	}
+}

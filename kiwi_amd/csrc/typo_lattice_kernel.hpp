@@ -1,0 +1,46 @@
+// Launch-side declarations of the typo-lattice kernel (typo_lattice_kernel.hip): plain device pointers, one record per chunk.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+#include "typo.hpp"
+
+namespace kamd
+{
+	struct TypoLatChunk
+	{
+		uint32_t charOff, nChars;      // chunk text inside chars / cls / script
+		uint32_t patOff, patCnt;       // pattern spans of the chunk (chunk-relative)
+		uint32_t graphOff, graphCnt;   // its typo graph
+		uint32_t pmb;                  // posMultiplierBit = ceil(log2(max continual-typo index)) (KTrie.cpp:860-891)
+		uint32_t nNs;                  // non-space positions (the kernel recounts and compares)
+		uint32_t nodeOff, nodeCap;     // build-order and final node regions (same offsets), 3 x nodeCap words of scratch
+		uint32_t mapOff, mapLen;       // endPosMap: ((nNs << pmb) + 1) entries
+		uint32_t nsOff;                // nsToPos / posToNs: nChars + 2 entries each
+		uint32_t stateOff, stateCap;   // search-state arena
+		uint32_t textOffset;           // offset of the chunk in the normalised text (added to final positions)
+		uint32_t nOutFinal, status;    // out: number of connected nodes, ChunkStatus
+	};
+	// lattice node in the layout of the parity dumps (oracle korc_split / reference kref_split): positions are text offsets when final
+	struct TypoLatNode { uint32_t startPos, endPos, prev, sibling; int32_t form; uint32_t uformLen, uformOff, spaceErrors; float typoCost; };
+	// SearchState<false> (KTrie.cpp:671-707); the last character is kept as its type / script (what the next node derives from it)
+	struct TypoState
+	{
+		int32_t node; float cost; uint32_t minFormLen; int32_t startPosOffset;
+		uint32_t specialStart, unkStart, boundary;
+		uint8_t lastType, lastScript, hasLast, pad; uint16_t startCti, pad2;
+	};
+	struct TypoLatView
+	{
+		const uint16_t* chars; const uint8_t* cls; const uint8_t* script; const DevPattern* patterns;
+		const TypoGraphNode* graph;
+		const uint8_t* graphLast;      // per graph node: {type, script} of its last character (type 0xFF: the character is NUL = "none"); host-computed
+		const uint16_t* pool;          // replacement strings of the prepared transformer
+		TypoLatChunk* chunks;
+		TypoLatNode* nodes; TypoLatNode* nodesFinal;
+		uint2* endPosMap; uint16_t* nsToPos; uint16_t* posToNs;
+		TypoState* states; uint32_t* stateIdx;      // per graph node: {first state, count}
+		uint32_t* scratch;
+		float threshold; uint32_t maxUnk, maxUnkJ, spaceTol; uint64_t match;
+	};
+	void launchTypoLattice(const ModelView& M, const TypoLatView& V, uint32_t nChunks, hipStream_t stream);
+}

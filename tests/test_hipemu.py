@@ -219,3 +219,58 @@ def test_race_detector_sees_a_dropped_wave_barrier():
     must report races (what the kernel then computes, or whether it survives, does not matter)."""
     r = _tsan_run("knlm", {"HIPEMU_TEST_DROP_WAVE_BARRIER": "k_build_lattice"})
     assert "ThreadSanitizer: data race" in r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def _typo_lattices(dev, typo, text, threshold, dialect=0):
+    import ctypes as C
+    import numpy as np
+    import oraclelib
+    L = dev.lib
+    L.kamd_typo_lattices.restype = C.c_size_t
+    L.kamd_typo_lattices.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_size_t]
+    u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+    need = L.kamd_typo_lattices(dev.h, typo.h, threshold, dialect, u.ctypes.data, len(u), oraclelib.MATCH_ALL_WITH_NORMALIZING, None, 0)
+    assert need, L.kamd_last_error()
+    buf = np.zeros(need, np.uint8)
+    L.kamd_typo_lattices(dev.h, typo.h, threshold, dialect, u.ctypes.data, len(u), oraclelib.MATCH_ALL_WITH_NORMALIZING, buf.ctypes.data, need)
+    r = oraclelib._Reader(buf.tobytes())
+    chunks = []
+    for _ in range(r.get("I")):
+        n, split_end = r.get("II")
+        chunks.append((split_end, [r.get("IIIIiIIIf") for _ in range(n)]))
+    return chunks
+
+
+@pytest.mark.parametrize("rules,threshold", [("own", 2.5), ("own-continual", 2.5), ("own-continual", 1.2)])
+def test_emulated_typo_lattice_kernel_matches_oracle(emu_libs, small_model, rules, threshold):
+    """k_build_lattice_typo (typo graph from the product's host module, multi-state lattice build on the device) against the oracle's
+    lattice over a typo graph -- which is pinned to the real reference by tests/test_typo_oracle.py -- on misspelt texts: nodes, links,
+    positions, typo costs.  A building block: the analyze path does not use it yet."""
+    import random
+    import oraclelib
+    import test_typo_product
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import COND, INF, RULES, misspell
+    sm, path = small_model
+    cont = 1.0 if "continual" in rules else INF
+    test_typo_product.LIB = emu_libs[0]
+    prod = test_typo_product.ProductTypo(cont, INF)
+    orc_t = oraclelib.OracleTypo(cont, INF)
+    for origs, errs, cost, cond, dia in RULES:
+        for o in origs:
+            for e in errs:
+                assert prod.add(o, e, cost, COND[cond], dia) == 0
+                orc_t.add(o, e, cost, COND[cond], dia)
+    prod.prepare(True); orc_t.prepare(True)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    orc = oraclelib.OracleKiwi(path)
+    rnd = random.Random(3)
+    n_typo_nodes = 0
+    for t in [misspell(t, rnd, True, "continual" in rules) for t in synthetic(sm, 60, 571, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 30, 572)] + EDGE_TEXTS:
+        if not t.strip():
+            continue
+        want = orc.split_typo(orc_t, t, threshold)
+        assert _typo_lattices(dev, prod, t, threshold) == want, t
+        n_typo_nodes += sum(1 for c in want for nd in c[1] if nd[8] > 0)
+    assert n_typo_nodes > 50
+    dev.close(); prod.close()
