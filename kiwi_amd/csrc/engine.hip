@@ -116,6 +116,11 @@ namespace kamd
 		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags, dTextOff;
 		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
 		DevBuf dHist;   // SkipBigram models: history ring of every search state (8 x u32), parallel to dStates
+		// typo correction (EXPERIMENTAL, KAMD_EXPERIMENTAL_TYPO): the transformer the batch is analysed with, the typo graph of every chunk and the
+		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
+		TypoOption typo;
+		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo;
+		TypoLatView tv{};
 		DevBuf dPackBase, dPacks, dStateBase, dStates, dNodeStOff, dNodeStCnt, dReach, dTokenBase, dTokens, dResults, dOrder;
 		BatchView bv{}; WorkView wv{};
 		std::vector<DevChunkResult> hResults;
@@ -290,6 +295,7 @@ namespace kamd
 			b.patOff[c + 1] = b.patOff[c] + (d.patEnd - d.patBegin);
 			b.spOff[c + 1] = b.spOff[c] + (uint32_t)r.sp.size();
 			uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
+			if (b.typo.typo) ncap = std::min<uint64_t>(2 * ncap, 0xFFE0);      // lattices over typo graphs come out about twice as large
 			if (tinyArenas)   // test hook (KAMD_TEST_TINY_ARENAS): regions far too small at scale 1, so that the overflow -> re-run ladder is exercised
 			{
 				mcap = (n / 2 + 8) * sc; ncap = std::min<uint64_t>((n / 2 + 8) * sc, 0xFFE0); scap = (n + 16) * sc; tcap = (n / 4 + 4) * sc;
@@ -356,6 +362,62 @@ namespace kamd
 		w.tokenBase = b.dTokenBase.as<uint64_t>(); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
 		w.bigScratch = nullptr; w.bigScratchBytes = 0;   // bound at launch
 		b.subBatches = 0;
+		if (b.typo.typo)
+		{
+			// typo graphs on the host (typo.cpp), one record per chunk for k_build_lattice_typo (engine mode)
+			const PreparedTypo& T = *b.typo.typo;
+			std::vector<TypoLatChunk> tch(nC); std::vector<TypoGraphNode> graph; std::vector<uint8_t> glast; std::vector<TypoGraphNode> g;
+			uint64_t mapTop = 0, nsTop = 0, stateTop = 0;
+			for (size_t c = 0; c < nC; ++c)
+			{
+				const auto& r = b.refs[c];
+				const PreparedText& pt = b.prep[r.text];
+				const ChunkDesc& d = pt.chunks[r.chunk];
+				const char16_t* str = (const char16_t*)pt.norm.data() + d.startOffset;
+				const size_t maxCti = T.graph(str, d.nChars, b.typo.allowedDialect, g);
+				TypoLatChunk& t = tch[c];
+				t = TypoLatChunk{};
+				t.charOff = b.charOff[c]; t.nChars = d.nChars; t.textOffset = d.startOffset; t.chunkId = (uint32_t)c;
+				t.patOff = b.patOff[c]; t.patCnt = b.patOff[c + 1] - b.patOff[c];
+				t.graphOff = (uint32_t)graph.size(); t.graphCnt = (uint32_t)g.size();
+				for (auto& gn : g)
+				{
+					uint32_t lastC = 0; bool any = false;
+					const std::u16string f = T.formOf(gn, str);
+					for (size_t j = 0; j < f.size(); ++j)
+					{
+						uint32_t c32 = f[j];
+						if (isHighSurrogate(c32) && j + 1 < f.size()) { c32 = mergeSurrogate(c32, f[j + 1]); ++j; }
+						lastC = c32; any = true;
+					}
+					glast.push_back((any && lastC) ? identifySpecialChr(lastC) : (uint8_t)0xFF);
+					glast.push_back((any && lastC) ? chr2ScriptType(lastC) : (uint8_t)0);
+					graph.push_back(gn);
+				}
+				if (maxCti > 1) { size_t v = maxCti - 1; while (v > 0) { v >>= 1; ++t.pmb; } }
+				for (uint32_t i = 0; i < d.nChars; ++i) if (!isSpace(str[i])) { ++t.nNs; if (isHighSurrogate(str[i]) && i + 1 < d.nChars) { ++t.nNs; ++i; } }
+				t.nodeOff = b.nodeBase[c]; t.nodeCap = b.nodeBase[c + 1] - b.nodeBase[c]; t.packCap = b.packBase[c + 1] - b.packBase[c];
+				t.mapOff = (uint32_t)mapTop; t.mapLen = (t.nNs << t.pmb) + 1; mapTop += t.mapLen;
+				t.nsOff = (uint32_t)nsTop; nsTop += d.nChars + 2;
+				t.stateOff = (uint32_t)stateTop; t.stateCap = (uint32_t)std::min<uint64_t>((g.size() * 16 + 64) * sc, 0x7FFFFFFF); stateTop += t.stateCap;
+				if (mapTop > 0xFFFFFFF0ull || stateTop > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit typo scratch offsets: split the batch" };
+			}
+			std::vector<uint16_t> pool(T.pool().begin(), T.pool().end());
+			if (pool.empty()) pool.push_back(0);
+			if (graph.empty()) graph.push_back(TypoGraphNode{});
+			if (glast.empty()) glast.assign(2, 0);
+			upload(b.dTypoGraph, graph, s); upload(b.dTypoLast, glast, s); upload(b.dTypoPool, pool, s); upload(b.dTypoChunks, tch, s);
+			b.dTypoTmp.ensure(totNodes * sizeof(TypoLatNode) + 64); b.dTypoMap.ensure(mapTop * 8 + 64); b.dTypoNs.ensure(nsTop * 2 + 64); b.dTypoPs.ensure(nsTop * 2 + 64);
+			b.dTypoStates.ensure(stateTop * sizeof(TypoState) + 64); b.dTypoSIdx.ensure(graph.size() * 8 + 64); b.dTypoScratch.ensure(totNodes * 12 + 64);
+			b.dNodeTypo.ensure(totNodes * 4 + 64);
+			TypoLatView& v = b.tv;
+			v = TypoLatView{};
+			v.chars = bv.chars; v.cls = bv.cls; v.script = bv.script; v.patterns = bv.patterns;
+			v.graph = b.dTypoGraph.as<TypoGraphNode>(); v.graphLast = b.dTypoLast.as<uint8_t>(); v.pool = b.dTypoPool.as<uint16_t>(); v.chunks = b.dTypoChunks.as<TypoLatChunk>();
+			v.nodes = b.dTypoTmp.as<TypoLatNode>(); v.nodesFinal = nullptr; v.endPosMap = b.dTypoMap.as<uint2>(); v.nsToPos = b.dTypoNs.as<uint16_t>(); v.posToNs = b.dTypoPs.as<uint16_t>();
+			v.states = b.dTypoStates.as<TypoState>(); v.stateIdx = b.dTypoSIdx.as<uint32_t>(); v.scratch = b.dTypoScratch.as<uint32_t>();
+			v.devNodes = w.nodes; v.nodeTypo = b.dNodeTypo.as<float>(); v.nNodes = w.nNodes; v.results = w.results;
+		}
 		HIPCHECK(hipStreamSynchronize(s));
 		b.ran = false;
 	}
@@ -430,7 +492,7 @@ namespace kamd
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
 		HIPCHECK(hipMemsetAsync(b.dNNodes.p, 0, (size_t)nC * 4, sA));   // also clears the lattice kernels' hand-over flag
 		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
-		const uint32_t nGroups = I.hasSbg ? ((I.groupLanesForced && I.groupLanes == 64) ? 1u : 4u)      // (the SkipBigram kernel: 16-lane groups unless 64 is forced)
+		const uint32_t nGroups = (I.hasSbg || b.typo.typo) ? ((I.groupLanesForced && I.groupLanes == 64) ? 1u : 4u)      // (the SkipBigram kernel: 16-lane groups unless 64 is forced)
 			: 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
 		// (the SkipBigram kernel is built for 2 waves per SIMD and carries 1.8 MB of item scratch per lane group: 8 persistent blocks per CU)
@@ -452,6 +514,17 @@ namespace kamd
 			const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S), cn = c1 - c0;
 			hipEvent_t* e = &I.evs[6 * (size_t)k];
 			HIPCHECK(hipEventRecord(e[0], sA));
+			if (b.typo.typo)
+			{
+				// typo correction: the lattice of every chunk over its typo graph (thread per chunk; the dictionary scan happens inside, per search state)
+				TypoLatView tv = b.tv;
+				tv.chunks += c0;
+				tv.threshold = b.typo.threshold; tv.maxUnk = sp.maxUnk; tv.maxUnkJ = sp.maxUnkJ; tv.spaceTol = sp.spaceTol; tv.match = sp.match;
+				HIPCHECK(hipEventRecord(e[1], sA));
+				launchTypoLattice(I.dview, tv, cn, sA);
+			}
+			else
+			{
 			hipLaunchKernelGGL(k_dict_scan, dim3((cn + 3) / 4), dim3(256), 0, sA, I.dview, b.bv, b.wv, c0, cn);
 			HIPCHECK(hipEventRecord(e[1], sA));
 			// wave-per-chunk build with the chunk's working set in LDS.  The dynamic LDS size of a launch is uniform, so the
@@ -471,6 +544,7 @@ namespace kamd
 					i = j;
 				}
 				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget);
+			}
 			}
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn);
 			HIPCHECK(hipEventRecord(e[2], sA));
@@ -493,8 +567,8 @@ namespace kamd
 			// groups, 2 waves per SIMD measured best on 8192 x 40 jamo); with many chunks it is a throughput problem and narrower
 			// groups + a third wave per SIMD win (65536 x 40 jamo: 6.9 vs 9.3 ms).  KAMD_GROUP_LANES / KAMD_WPS override.
 			const bool many = cn >= 32768;
-			const int gl = I.hasSbg ? ((I.groupLanesForced && I.groupLanes == 64) ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
-			const int wps = I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
+			const int gl = (I.hasSbg || b.typo.typo) ? ((I.groupLanesForced && I.groupLanes == 64) ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
+			const int wps = b.typo.typo ? 2 : I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
 			const uint32_t blocksK = std::min(persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
 			const uint32_t ldsK = searchKernelLdsBytes(gl);
@@ -507,6 +581,13 @@ namespace kamd
 				sd.itemScratch = I.sbgScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(SbgScratch) : 0);
 				if (gl == 64) hipLaunchKernelGGL((sbgk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
 				else hipLaunchKernelGGL((sbgk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
+			}
+			else if (b.typo.typo)
+			{
+				// lattice nodes with typo costs: the search kernel compiled with KAMD_TYPO (16-lane groups, or one chunk per wave when 64 is forced)
+				const float* nodeTypo = b.dNodeTypo.as<float>();
+				if (gl == 64) hipLaunchKernelGGL((typok::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, nodeTypo);
+				else hipLaunchKernelGGL((typok::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, nodeTypo);
 			}
 			else if (wps == 3 && gl == 8) KAMD_LAUNCH(8, 3);
 			else if (wps == 3 && gl == 16) KAMD_LAUNCH(16, 3);
@@ -644,8 +725,16 @@ namespace kamd
 		std::sort(out.begin(), out.end(), [](const PathResult& a, const PathResult& b2) { return a.score > b2.score; });   // PathEvaluator.hpp:1414-1417
 	}
 
-	std::shared_ptr<StagedBatch> Engine::stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads)
+	std::shared_ptr<StagedBatch> Engine::stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads, TypoOption typo)
 	{
+		if (typo.typo)
+		{
+			// typo correction on the device is written and identical to the oracle under lane emulation, but has not run on a GPU yet
+			if (!std::getenv("KAMD_EXPERIMENTAL_TYPO")) throw std::runtime_error{ "kiwi_amd: typo correction on the device is experimental (not parity-checked on a GPU yet) and only enabled with KAMD_EXPERIMENTAL_TYPO=1" };
+			if (std::isfinite(typo.typo->lengtheningCost())) throw std::runtime_error{ "kiwi_amd: lengthening typos are not handled on the device yet" };
+			if (impl->hasSbg) throw std::runtime_error{ "kiwi_amd: typo correction with a SkipBigram model is not built" };
+			if (!typo.typo->ready()) typo.typo = nullptr;      // an empty transformer corrects nothing
+		}
 		HostTimer tm{ "stage" };
 		auto b = std::make_shared<StagedBatch>();
 		b->match = match;
@@ -667,6 +756,7 @@ namespace kamd
 		}
 		tm.lap("text preparation");
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		b->typo = typo;
 		layoutAndUpload(*impl, *b, makeParams(config, match));
 		tm.lap("layout + device buffers + upload");
 		return b;
@@ -686,7 +776,7 @@ namespace kamd
 		std::vector<std::vector<PathResult>>& out)
 	{
 		StagedBatch b;
-		b.match = parent.match; b.capScale = capScale; b.topN = parent.topN;
+		b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo;
 		b.prep.swap(parent.prep);   // borrow
 		b.refs = std::move(refs);
 		try
@@ -767,10 +857,10 @@ namespace kamd
 	}
 
 	std::vector<std::vector<TokenResult>> Engine::analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
-		size_t topN, uint64_t match, bool openEnding, int hostThreads)
+		size_t topN, uint64_t match, bool openEnding, int hostThreads, TypoOption typo)
 	{
 		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
-		auto b = stage(texts, match, openEnding, hostThreads);
+		auto b = stage(texts, match, openEnding, hostThreads, typo);
 		b->topN = (uint32_t)topN;
 		run(*b);
 		return fetch(*b, topN);

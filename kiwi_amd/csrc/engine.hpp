@@ -23,6 +23,9 @@ namespace kamd
 	struct KernelTimes { float scanMs = 0, latticeMs = 0, searchMs = 0, finishMs = 0; uint32_t searchLaunches = 1; };   // sums over the sub-batches of one run
 
 	struct StagedBatch;   // chunks of one round resident in HBM
+	class PreparedTypo;
+	// a prepared typo transformer applied to an analysis (AnalyzeOption::typoTransformer / typoThreshold / allowedDialects of the reference)
+	struct TypoOption { const PreparedTypo* typo = nullptr; float threshold = 2.5f; uint16_t allowedDialect = 0; };
 
 	class Engine
 	{
@@ -38,12 +41,12 @@ namespace kamd
 
 		// Full path: prepare -> kernels -> results, for a batch of raw UTF-16 texts.  Results are per text.
 		std::vector<std::vector<TokenResult>> analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
-			size_t topN, uint64_t match, bool openEnding, int hostThreads = 0);
+			size_t topN, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {});
 
 		// Staged path (benchmarks): stage() does host preparation + upload of every chunk of the texts (one round,
 		// the common case where no quote/bullet state crosses chunk boundaries); run() launches the three kernels on
 		// the resident batch and returns their event-timed durations; fetch() downloads and assembles results.
-		std::shared_ptr<StagedBatch> stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads = 0);
+		std::shared_ptr<StagedBatch> stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {});
 		KernelTimes run(StagedBatch& b);
 		std::vector<std::vector<TokenResult>> fetch(StagedBatch& b, size_t topN);
 		static size_t stagedChunks(const StagedBatch& b);
@@ -54,6 +57,6 @@ namespace kamd
 		std::vector<uint8_t> dumpLattices(const char16_t* text, size_t n, uint64_t match);
 		// ... and the lattices built over the typo graphs a prepared transformer gives for the chunks (typo_lattice_kernel.hip); same layout.
 		// Parity hook of a building block: analyze does not take typo transformers yet.
-		std::vector<uint8_t> dumpTypoLattices(const class PreparedTypo& typo, float threshold, uint16_t allowedDialect, const char16_t* text, size_t n, uint64_t match);
+		std::vector<uint8_t> dumpTypoLattices(const PreparedTypo& typo, float threshold, uint16_t allowedDialect, const char16_t* text, size_t n, uint64_t match);
 	};
 }

@@ -316,7 +316,9 @@ namespace kamd
 		X.nNs = nNs; X.nsToPos = nsToPos; X.posToNs = posToNs;
 		X.endPosMap = V.endPosMap + C.mapOff; X.out = V.nodes + C.nodeOff; X.nOut = 0; X.overflow = false;
 		X.pat = V.patterns + C.patOff; X.patEnd = X.pat + C.patCnt;
-		if (((nNs << X.pmb) + 1) > C.mapLen || nNs != C.nNs) { C.status = CS_ERR_NODE_OVERFLOW; return; }
+		auto fail = [&](uint32_t code) { C.status = code; if (V.results) V.results[C.chunkId].status = code; };
+		if (V.results && V.results[C.chunkId].status >= 16) { C.status = V.results[C.chunkId].status; return; }
+		if (((nNs << X.pmb) + 1) > C.mapLen || nNs != C.nNs) { fail(CS_ERR_TOO_LONG); return; }
 		for (uint32_t i = 0; i < C.mapLen; ++i) X.endPosMap[i] = make_uint2(NPOS, NPOS);
 		X.endPosMap[0] = make_uint2(0, 1);
 		{ TypoLatNode z{}; z.form = -1; X.out[X.nOut++] = z; }
@@ -344,7 +346,7 @@ namespace kamd
 		}
 		X.append(nNs << X.pmb, (nNs << X.pmb) + 1, NOFORM, 0, 0);
 		X.out[X.nOut - 1].endPos = nNs << X.pmb;
-		if (X.overflow) { C.status = CS_ERR_NODE_OVERFLOW; return; }
+		if (X.overflow || X.nOut + 1 >= C.nodeCap) { fail(CS_ERR_NODE_OVERFLOW); return; }
 
 		// removeUnconnected (KTrie.cpp:240-299): reachable from the end node backwards; stable order by (connected, end position)
 		const uint32_t G = X.nOut;
@@ -377,6 +379,79 @@ namespace kamd
 		}
 		for (uint32_t i = 0; i < G; ++i) inv[i] = NPOS;
 		for (uint32_t i = 0; i < nConn; ++i) inv[sorted[i]] = i;
+		if (V.devNodes)
+		{
+			// engine mode: the record the search kernel reads, with the predecessor-dependent facts of lattice_kernels.hip latticeEmitNode
+			DevNode* dn = V.devNodes + C.nodeOff; float* tc = V.nodeTypo + C.nodeOff;
+			if (nNs > 0xFFF0 || C.nodeCap > 0xFFF0 || nConn > 0xFFF0) { fail(CS_ERR_TOO_LONG); return; }
+			uint32_t packTop = 0;
+			for (uint32_t i = 0; i < nConn; ++i)
+			{
+				const uint32_t idx = sorted[i];
+				const TypoLatNode g = X.out[idx];
+				DevNode nn;
+				nn.form = g.form < 0 ? NOFORM : (uint32_t)g.form; nn.uformOff = (uint16_t)g.uformOff; nn.uformLen = (uint16_t)g.uformLen; nn.spaceErrors = (uint8_t)g.spaceErrors;
+				nn.nPrev = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0; nn.prev = 0; nn.sibling = 0;
+				uint8_t nf = 0;
+				if (i >= 1)
+				{
+					const uint32_t pidx = idx - g.prev;
+					const TypoLatNode pn = X.out[pidx];
+					const uint32_t startStr = (i + 1 == nConn) ? X.n : (uint32_t)nsToPos[g.startPos >> X.pmb];
+					const bool pnBos = pidx == 0;
+					const uint32_t pnEndStr = pnBos ? 0 : (uint32_t)nsToPos[((pn.endPos + (1u << X.pmb) - 1) >> X.pmb) - 1] + 1;
+					const bool spaceBefore = pnBos ? (C.textOffset + startStr > 0) : (pnEndStr < startStr);
+					bool lb = pnBos || spaceBefore;
+					if (!lb && pn.uformLen)
+					{
+						const uint32_t lp = pn.uformOff + pn.uformLen - 1;
+						const uint16_t ch = X.str[lp];
+						const uint8_t tag = (isLowSurrogate(ch) || isHighSurrogate(ch)) ? (uint8_t)T_SH : (uint8_t)(X.cls[lp] & 0x3F);
+						if (tag == T_SSC || ch == u'"' || ch == u'\'') lb = false;
+						else if (T_SF <= tag && tag <= T_SB) lb = true;
+					}
+					if (spaceBefore) nf |= NF_SPACE_BEFORE;
+					if (lb) nf |= NF_LEFT_BOUNDARY;
+					if (g.uformLen && X.str[g.uformOff + g.uformLen - 1] == u'.') nf |= NF_UFORM_ENDS_POINT;
+					uint32_t np = 0;      // connected nodes ending where this one starts
+					const uint2 m = X.endPosMap[g.startPos];
+					if (m.x != NPOS) for (uint32_t j = m.x; j < m.y; ++j) if (X.out[j].endPos == g.startPos && conn[j]) ++np;
+					nn.nPrev = (uint16_t)np;
+				}
+				if (g.form >= 0)
+				{
+					const FormRec f = M.forms[g.form];
+					nn.candCnt = f.candCnt; nn.fflags = f.flags; nn.flen = f.len;
+					if ((f.flags2 & FF2_ALL_PARTIAL) && g.typoCost == 0) nf |= NF_ALL_PARTIAL;      // (PathEvaluator.hpp:1275: only for nodes without a typo)
+				}
+				if (g.uformLen)
+				{
+					uint16_t of = featMask(X.str + g.uformOff, g.uformLen) & 0x1FFF;
+					const uint32_t lp = g.uformOff + g.uformLen - 1;
+					const uint16_t ch = X.str[lp];
+					const uint8_t tag = (isLowSurrogate(ch) || isHighSurrogate(ch)) ? (uint8_t)T_SH : (uint8_t)(X.cls[lp] & 0x3F);
+					if (tag == T_SSC) of |= LF_STR_SSC;
+					nn.ownFeat = of;
+				}
+				nn.nflags = nf;
+				if (g.prev) nn.prev = (uint16_t)(i - inv[idx - g.prev]);
+				if (g.sibling) { const uint32_t ns = inv[idx + g.sibling]; nn.sibling = ns == NPOS ? 0 : (uint16_t)(ns - i); }
+				if (i >= 1 && i + 1 < nConn)
+				{
+					nn.startPos = nsToPos[g.startPos >> X.pmb];
+					nn.endPos = (uint16_t)(nsToPos[((g.endPos + (1u << X.pmb) - 1) >> X.pmb) - 1] + 1);
+				}
+				else if (i + 1 == nConn) nn.startPos = nn.endPos = (uint16_t)X.n;
+				else nn.startPos = nn.endPos = 0;
+				nn.packOff = packTop; packTop += nn.candCnt;
+				dn[i] = nn; tc[i] = g.typoCost;
+			}
+			if (packTop > C.packCap) { fail(CS_ERR_NODE_OVERFLOW); return; }
+			V.nNodes[C.chunkId] = nConn;
+			C.nOutFinal = nConn; C.status = CS_OK;
+			if (nConn <= 2) V.results[C.chunkId].status = CS_NO_LATTICE;
+			return;
+		}
 		TypoLatNode* fin = V.nodesFinal + C.nodeOff;
 		for (uint32_t i = 0; i < nConn; ++i)
 		{

@@ -17,7 +17,8 @@ namespace kamd
 		uint32_t mapOff, mapLen;       // endPosMap: ((nNs << pmb) + 1) entries
 		uint32_t nsOff;                // nsToPos / posToNs: nChars + 2 entries each
 		uint32_t stateOff, stateCap;   // search-state arena
-		uint32_t textOffset;           // offset of the chunk in the normalised text (added to final positions)
+		uint32_t textOffset;           // offset of the chunk in the normalised text (added to final positions of the dump records)
+		uint32_t chunkId, packCap;     // engine mode: index of the chunk in the batch, capacity of its candidate-pack region
 		uint32_t nOutFinal, status;    // out: number of connected nodes, ChunkStatus
 	};
 	// lattice node in the layout of the parity dumps (oracle korc_split / reference kref_split): positions are text offsets when final
@@ -40,6 +41,9 @@ namespace kamd
 		uint2* endPosMap; uint16_t* nsToPos; uint16_t* posToNs;
 		TypoState* states; uint32_t* stateIdx;      // per graph node: {first state, count}
 		uint32_t* scratch;
+		// engine mode (all null in the parity hook): the search kernel's node records (chunk-relative positions, per-node facts as
+		// latticeEmitNode computes them), each node's typo cost beside them, node counts and chunk statuses of the batch
+		DevNode* devNodes; float* nodeTypo; uint32_t* nNodes; DevChunkResult* results;
 		float threshold; uint32_t maxUnk, maxUnkJ, spaceTol; uint64_t match;
 	};
 	void launchTypoLattice(const ModelView& M, const TypoLatView& V, uint32_t nChunks, hipStream_t stream);

@@ -51,9 +51,23 @@
 #else
 #define SBG_ONLY(...)
 #endif
+// Typo correction: a third compilation (viterbi_kernel_typo.hip, KAMD_TYPO, namespace kamd::typok) in which every lattice node carries a
+// typo cost (an array beside the node records): it discounts the node's candidates and accumulates on the paths (PathEvaluator.hpp:235, 371).
+#ifdef KAMD_TYPO
+#define TYPO_ONLY(...) __VA_ARGS__
+#else
+#define TYPO_ONLY(...)
+#endif
+#if defined(KAMD_SBG) || defined(KAMD_TYPO)
+#define KAMD_VARIANT 1      // not the Knlm translation unit: the pieces that exist once (end-stage kernel, LDS size helper) are left out
+#endif
 
 namespace kamd
 {
+#ifdef KAMD_TYPO
+namespace typok
+{
+#endif
 #ifdef KAMD_SBG
 namespace sbgk
 {
@@ -152,7 +166,7 @@ namespace sbgk
 		static constexpr uint32_t LB = (64 / G) * SIZE;              // f32[2*T_MAX+1], shared by the groups
 		static constexpr uint32_t TOTAL = LB + 4 * (2 * T_MAX + 1);
 	};
-#ifndef KAMD_SBG
+#ifndef KAMD_VARIANT
 	uint32_t searchKernelLdsBytes(int G)
 	{
 		switch (G) { case 4: return Lay<4>::TOTAL; case 8: return Lay<8>::TOTAL; case 16: return Lay<16>::TOTAL; case 32: return Lay<32>::TOTAL; default: return Lay<64>::TOTAL; }
@@ -401,9 +415,11 @@ namespace sbgk
 			nodeStOff = o.nodeStOff; nodeStCnt = o.nodeStCnt; nodeLive = o.nodeLive; uniq = o.uniq; nUniq = o.nUniq;
 			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; tl = o.tl;
 			SBG_ONLY(S = o.S; hist = o.hist; sscr = o.sscr;)
+			TYPO_ONLY(typoAll = o.typoAll; nodeTypo = o.nodeTypo;)
 		}
 		// SkipBigram: the model view, the chunk's state rings (parallel to st) and the lane group's item scratch
 		SBG_ONLY(const SbgDev* S; uint32_t* hist; SbgScratch* sscr;)
+		TYPO_ONLY(const float* typoAll; const float* nodeTypo;)      // typo cost of every node of the batch / of the chunk's nodes
 		uint32_t gl, gshift, lds;       // lane in group, group's first lane, byte offset of the group's LDS slice
 		const DevNode* nodes; uint32_t Gn;
 		const uint16_t* str; const uint8_t* cls;
@@ -432,7 +448,7 @@ namespace sbgk
 		__device__ __forceinline__ const LDS_AS float* lb() const { return ldsPtr<float>(Lay<G>::LB); }
 	};
 
-	struct NodeEnv { uint32_t pBeg, nP, nLive; uint32_t nodeIdx, nodeStart; uint8_t nflags, fflags; };
+	struct NodeEnv { uint32_t pBeg, nP, nLive; uint32_t nodeIdx, nodeStart; uint8_t nflags, fflags; TYPO_ONLY(float typoCost;) };
 
 	template<int G>
 	__device__ __forceinline__ Hot getHot(const GroupCtx<G>& X, uint32_t i)
@@ -650,7 +666,11 @@ namespace sbgk
 			const uint32_t local = qw - c.qOff;
 			uint32_t parent = pBeg + local, r = 0;
 			if (c.R != 1) { parent = pBeg + local / c.R; r = local % c.R; }
+#ifdef KAMD_TYPO
+			const float wtypo = (haveTypo ? parentTypo : getTypo<G>(X, parent)) + E.typoCost;      // accTypoCost + node->typoCost (PathEvaluator.hpp:235)
+#else
 			const float wtypo = (haveTypo ? parentTypo : getTypo<G>(X, parent)) + 0.f;
+#endif
 			const bool single = c.single();
 			const uint8_t rootKey = (uint8_t)(wkey >> 40);
 			const uint8_t newRoot = (c.quoteOrBullet() && rootKey == COMMON_ROOT) ? (uint8_t)r : rootKey;
@@ -1176,7 +1196,7 @@ namespace sbgk
 		TLMARK(X, 4)
 	}
 
-#ifndef KAMD_SBG    // (the end stage after the EOS transition does not depend on the LM type: one copy, in the Knlm translation unit)
+#ifndef KAMD_VARIANT    // (the end stage after the EOS transition does not depend on the LM type: one copy, in the Knlm translation unit)
 	// libstdc++'s std::sort restated for the end-node candidate list (the reference sorts it with an unstable
 	// std::sort, PathEvaluator.hpp:1359-1368; equal keys must land where introsort puts them).  Runs on one lane.
 	__device__ __forceinline__ bool endLess(const EndCand& a, const EndCand& b)
@@ -1405,7 +1425,7 @@ namespace sbgk
 		}
 	}
 
-#ifndef KAMD_SBG
+#ifndef KAMD_VARIANT
 	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418); one thread per chunk
 	__global__ void __launch_bounds__(64) k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount)
 	{
@@ -1463,6 +1483,7 @@ namespace sbgk
 		X.str = B.chars + cOff; X.cls = B.cls + cOff;
 		X.st = W.states + W.stateBase[chunk]; X.stCap = (uint32_t)(W.stateBase[chunk + 1] - W.stateBase[chunk]); X.stTop = 0;
 		SBG_ONLY(X.hist = X.S->hist + 8ull * W.stateBase[chunk];)
+		TYPO_ONLY(X.nodeTypo = X.typoAll + nBase;)
 		X.nodeStOff = W.nodeStateOff + nBase; X.nodeStCnt = W.nodeStateCnt + nBase; X.nodeLive = W.tmpIdx + 2ull * nBase;
 		X.uniq = B.spStates + B.spOff[chunk]; X.nUniq = B.spOff[chunk + 1] - B.spOff[chunk];
 		X.overflow = false; X.pairOverflow = false;
@@ -1533,7 +1554,12 @@ namespace sbgk
 			X.stageOverflow = false;
 			float ws = 0;
 			if (!node.uformLen && node.form != NOFORM && node.flen && node.spaceErrors) ws = -P.spacePenalty * (float)node.spaceErrors;
+#ifdef KAMD_TYPO
+			E.typoCost = X.nodeTypo[i];
+			const float baseDiscount = ws + (-E.typoCost * P.typoCostWeight);
+#else
 			const float baseDiscount = ws + (-0.f * P.typoCostWeight);   // whitespaceDiscount + typoDiscount (PathEvaluator.hpp:366-371)
+#endif
 
 			TLMARK(X, 0)
 			const uint8_t ownKind = node.uformLen ? 1 : 0; const uint16_t ownFeat = node.ownFeat;
@@ -1663,7 +1689,7 @@ namespace sbgk
 	// WPS = waves per SIMD the kernel is compiled for (register budget 512 / WPS): 2 is fastest when a batch is small enough
 	// to be latency-bound (c2: 8192 chunks), 3 (with a few spills) when there are chunks to fill the extra wave slots
 	template<int G, int WPS>
-	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S))
+	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S) TYPO_ONLY(, const float* nodeTypoAll))
 	{
 		constexpr int NG = 64 / G;
 		const uint32_t lane = threadIdx.x;
@@ -1687,6 +1713,7 @@ namespace sbgk
 		X.scratch = reinterpret_cast<GroupScratch*>(W.bigScratch) + ((size_t)blockIdx.x * NG + gid);
 		X.tl = nullptr;
 		SBG_ONLY(X.S = &S; X.hist = nullptr; X.sscr = reinterpret_cast<SbgScratch*>(S.itemScratch) + ((size_t)blockIdx.x * NG + gid);)
+		TYPO_ONLY(X.typoAll = nodeTypoAll; X.nodeTypo = nullptr;)
 
 		for (;;)
 		{
@@ -1698,9 +1725,13 @@ namespace sbgk
 		}
 	}
 
-#ifdef KAMD_SBG
+#if defined(KAMD_SBG)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, SbgDev);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, SbgDev);
+}
+#elif defined(KAMD_TYPO)
+	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
+	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
 }
 #else
 	template __global__ void k_best_path<4, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);

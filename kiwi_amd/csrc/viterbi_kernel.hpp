@@ -45,6 +45,13 @@ namespace kamd
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, SbgDev S);
 	}
+	// ... and for lattices built over typo graphs (viterbi_kernel_typo.hip, KAMD_TYPO): nodeTypo = the typo cost of every node of the batch,
+	// parallel to WorkView::nodes.  G = 16 or 64, WPS = 2; Knlm scoring.
+	namespace typok
+	{
+		template<int G, int WPS>
+		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, const float* nodeTypo);
+	}
 	// End stage, one THREAD per chunk: restated std::sort of the end candidates, per-(root, state) selection and the
 	// back-trace into 24-byte tokens.  A separate launch so that 64 chunks share a wavefront in this strictly serial stage.
 	__global__ void k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount);

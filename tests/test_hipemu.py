@@ -274,3 +274,78 @@ def test_emulated_typo_lattice_kernel_matches_oracle(emu_libs, small_model, rule
         n_typo_nodes += sum(1 for c in want for nd in c[1] if nd[8] > 0)
     assert n_typo_nodes > 50
     dev.close(); prod.close()
+
+
+def _analyze_typo(dev, typo, texts, threshold, top_n=1, dialect=0):
+    import ctypes as C
+    import numpy as np
+    import oraclelib
+    from kiwi_amd.api import Results
+    L = dev.lib
+    L.kamd_analyze_batch_typo.restype = C.c_void_p
+    L.kamd_analyze_batch_typo.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+    enc = [np.frombuffer(t.encode("utf-16-le", errors="surrogatepass"), np.uint16) for t in texts]
+    offs = np.zeros(len(enc) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    flat = np.concatenate(enc) if enc else np.zeros(0, np.uint16)
+    r = L.kamd_analyze_batch_typo(dev.h, typo.h, threshold, dialect, flat.ctypes.data, offs.ctypes.data, len(texts), top_n, oraclelib.MATCH_ALL_WITH_NORMALIZING, 0, 0)
+    if not r:
+        raise RuntimeError(L.kamd_last_error().decode())
+    return Results(L, r).to_python()
+
+
+def _typo_pair(lib, continual):
+    import oraclelib
+    import test_typo_product
+    from typo_cases import COND, INF, RULES
+    test_typo_product.LIB = lib
+    prod = test_typo_product.ProductTypo(continual, INF)
+    orc_t = oraclelib.OracleTypo(continual, INF)
+    for origs, errs, cost, cond, dia in RULES:
+        for o in origs:
+            for e in errs:
+                assert prod.add(o, e, cost, COND[cond], dia) == 0
+                orc_t.add(o, e, cost, COND[cond], dia)
+    prod.prepare(True); orc_t.prepare(True)
+    return prod, orc_t
+
+
+@pytest.mark.parametrize("continual,threshold,top_n,lanes,tiny", [(float("inf"), 2.5, 1, "16", False), (1.0, 2.5, 1, "16", False), (1.0, 1.2, 3, "16", False),
+                                                                   (1.0, 2.5, 1, "64", False), (1.0, 2.5, 2, "16", True)])
+def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch, continual, threshold, top_n, lanes, tiny):
+    """The whole typo-correcting analysis on the (emulated) device -- typo graphs from the host module, k_build_lattice_typo, the search kernel
+    compiled with node typo costs (viterbi_kernel_typo.hip), end stage, host post-processing -- against the oracle (pinned to the real
+    reference): tokens, positions, fp32 scores, per-token typo costs; also through the capacity ladder.  Gated on the device
+    (KAMD_EXPERIMENTAL_TYPO) until it has run on a GPU."""
+    import random
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import misspell
+    sm, path = small_model
+    monkeypatch.setenv("KAMD_EXPERIMENTAL_TYPO", "1")
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    if tiny:
+        monkeypatch.setenv("KAMD_TEST_TINY_ARENAS", "1")
+    prod, orc_t = _typo_pair(emu_libs[0], continual)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    orc = oraclelib.OracleKiwi(path)
+    rnd = random.Random(7)
+    texts = [misspell(t, rnd, True, continual == 1.0) for t in synthetic(sm, 50, 581, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 25, 582)] + EDGE_TEXTS
+    got = _analyze_typo(dev, prod, texts, threshold, top_n)
+    corrected = 0
+    for t, y in zip(texts, got):
+        want = orc.analyze_typo(orc_t, t, threshold, 0, top_n=top_n)
+        assert _norm(want) == _norm(y), t
+        corrected += any(x.typo_cost > 0 for x in want[0][0])
+    assert corrected >= 5
+    dev.close(); prod.close()
+
+
+def test_typo_analysis_is_refused_without_the_flag(emu_libs, small_model, monkeypatch):
+    from kiwi_amd.api import KiwiAmd
+    monkeypatch.delenv("KAMD_EXPERIMENTAL_TYPO", raising=False)
+    prod, _ = _typo_pair(emu_libs[0], 1.0)
+    dev = KiwiAmd(small_model[1], lib_path=emu_libs[0])
+    with pytest.raises(RuntimeError, match="experimental"):
+        _analyze_typo(dev, prod, ["가나다"], 2.5)
+    dev.close(); prod.close()
