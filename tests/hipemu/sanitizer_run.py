@@ -1,5 +1,6 @@
 """Run by tests/test_hipemu.py in a subprocess with a sanitizer runtime preloaded: a small corpus through the sanitizer build of the
-emulated library (Knlm with KAMD_TEST_TINY_ARENAS, i.e. with most chunks hitting a capacity limit first; then the SkipBigram kernel).
+emulated library (Knlm with KAMD_TEST_TINY_ARENAS, i.e. with most chunks hitting a capacity limit first; the SkipBigram kernel; the
+typo-correcting analysis).
 Any report of the sanitizer ends the process with a non-zero status."""
 import os
 import sys
@@ -8,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))      # (test_hipemu imports the oracle wrappers at module level; nothing of the oracle runs here)
 from corpora import EDGE_TEXTS, dictionary_mix, synthetic   # noqa: E402
 from kiwi_amd.api import KiwiAmd                              # noqa: E402
 from kiwi_amd.synth import SMALL_SBG_SPEC, SMALL_SPEC, SynthModel   # noqa: E402
@@ -19,6 +21,27 @@ if not os.path.exists(path):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     sm.raw.save(path)
 dev = KiwiAmd(path, lib_path=lib)
+if kind == "typo":
+    # the typo-correcting analysis (typo lattice kernel, search with node typo costs) on misspelt texts
+    import random
+    import test_hipemu
+    from typo_cases import misspell
+    import test_typo_product
+    from typo_cases import COND, INF, RULES
+    test_typo_product.LIB = lib
+    prod = test_typo_product.ProductTypo(1.0, INF)
+    for origs, errs, cost, cond, dia in RULES:
+        for o in origs:
+            for e in errs:
+                assert prod.add(o, e, cost, COND[cond], dia) == 0
+    prod.prepare(True)
+    rnd = random.Random(3)
+    texts = [misspell(t, rnd, True, True) for t in synthetic(sm, 12, 611, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 6, 612)]
+    for top_n in (1, 2):
+        assert len(test_hipemu._analyze_typo(dev, prod, texts, 2.5, top_n)) == len(texts)
+    dev.close(); prod.close()
+    print("sanitizer run complete:", kind, len(texts), "texts")
+    sys.exit(0)
 n = 8 if kind == "sbg" else 14
 texts = synthetic(sm, n, 601, min_jamo=5, max_jamo=50 if kind == "sbg" else 80) + dictionary_mix(sm, n // 2, 602) + (EDGE_TEXTS if kind != "sbg" else [])
 for top_n in (1, 2):

@@ -1,0 +1,65 @@
+"""GPU (-m gpu): typo correction on the device (kiwi_amd/csrc/typo.cpp on the host, typo_lattice_kernel.hip, viterbi_kernel_typo.hip) against
+the CPU oracle, whose typo path is pinned to the real reference by tests/test_typo_oracle.py.
+
+EXPERIMENTAL, like the SkipBigram kernel: written after the round's GPU budget was spent, identical to the oracle under lane emulation
+(tests/test_hipemu.py), never run on hardware.  The engine refuses typo transformers unless KAMD_EXPERIMENTAL_TYPO=1, and the parity
+tests below are skipped without it; `KAMD_EXPERIMENTAL_TYPO=1 python -m pytest tests/test_gpu_typo.py -m gpu` is what to run on a GPU box."""
+import os
+import random
+
+import pytest
+
+from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+from test_hipemu import _analyze_typo, _norm, _typo_lattices, _typo_pair
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip.so")
+enabled = pytest.mark.skipif(not os.environ.get("KAMD_EXPERIMENTAL_TYPO"), reason="typo correction on the device is experimental: set KAMD_EXPERIMENTAL_TYPO=1")
+
+
+def test_typo_transformer_is_refused_without_the_flag(small_model, monkeypatch):
+    from kiwi_amd.api import KiwiAmd
+    monkeypatch.delenv("KAMD_EXPERIMENTAL_TYPO", raising=False)
+    prod, _ = _typo_pair(LIB, 1.0)
+    dev = KiwiAmd(small_model[1])
+    with pytest.raises(RuntimeError, match="experimental"):
+        _analyze_typo(dev, prod, ["가나다"], 2.5)
+    dev.close(); prod.close()
+
+
+@enabled
+@pytest.mark.parametrize("continual,threshold,top_n,lanes", [(float("inf"), 2.5, 1, "16"), (1.0, 2.5, 1, "16"), (1.0, 1.2, 3, "16"), (1.0, 2.5, 2, "64")])
+def test_typo_analyses_bit_exact_vs_oracle(small_model, monkeypatch, continual, threshold, top_n, lanes):
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import misspell
+    sm, path = small_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    prod, orc_t = _typo_pair(LIB, continual)
+    dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
+    rnd = random.Random(11)
+    texts = [misspell(t, rnd, True, continual == 1.0) for t in synthetic(sm, 400, 591, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 200, 592)] + EDGE_TEXTS
+    got = _analyze_typo(dev, prod, texts, threshold, top_n)
+    for t, y in zip(texts, got):
+        assert _norm(orc.analyze_typo(orc_t, t, threshold, 0, top_n=top_n)) == _norm(y), t
+    for t in texts[:100]:
+        if t.strip():
+            assert _typo_lattices(dev, prod, t, threshold) == orc.split_typo(orc_t, t, threshold), t
+    dev.close(); prod.close()
+
+
+@enabled
+def test_typo_analyses_through_the_capacity_ladder(small_model, monkeypatch):
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import misspell
+    sm, path = small_model
+    monkeypatch.setenv("KAMD_TEST_TINY_ARENAS", "1")
+    prod, orc_t = _typo_pair(LIB, 1.0)
+    dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
+    rnd = random.Random(13)
+    texts = [misspell(t, rnd) for t in synthetic(sm, 150, 593, min_jamo=5, max_jamo=120)]
+    for t, y in zip(texts, _analyze_typo(dev, prod, texts, 2.5)):
+        assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0)) == _norm(y), t
+    dev.close(); prod.close()
