@@ -84,11 +84,11 @@ int kamd_typo_prepare(kamd_typo_h t, int inverse);
 size_t kamd_typo_graph(kamd_typo_h t, const uint16_t* text, uint32_t len, int allowed_dialect, int normalize_coda, uint8_t* out, size_t cap);
 /* EXPERIMENTAL (needs KAMD_EXPERIMENTAL_TYPO=1 in the environment; identical to the CPU oracle under lane emulation, not yet run on a GPU):
  * kamd_analyze_batch with a prepared typo transformer -- AnalyzeOption::typoTransformer / typoThreshold / allowedDialects of the reference.
- * Lengthening typos and SkipBigram models are refused. */
+ * SkipBigram models are refused. */
 kamd_results_h kamd_analyze_batch_typo(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts,
                                        uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
 /* parity hook: the lattices the device builds OVER the typo graphs of a text's chunks (csrc/typo_lattice_kernel.hip), in the layout of kamd_dump_lattices;
- * lengthening typos are refused; 0 + kamd_last_error() on failure */
+ * 0 + kamd_last_error() on failure */
 size_t kamd_typo_lattices(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);
 size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap);
 size_t kamd_dump_lattices(kamd_engine_h h, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);

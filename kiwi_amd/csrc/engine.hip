@@ -519,6 +519,7 @@ namespace kamd
 				// typo correction: the lattice of every chunk over its typo graph (thread per chunk; the dictionary scan happens inside, per search state)
 				TypoLatView tv = b.tv;
 				tv.chunks += c0;
+				tv.lengtheningCost = b.typo.typo->lengtheningCost();
 				tv.threshold = b.typo.threshold; tv.maxUnk = sp.maxUnk; tv.maxUnkJ = sp.maxUnkJ; tv.spaceTol = sp.spaceTol; tv.match = sp.match;
 				HIPCHECK(hipEventRecord(e[1], sA));
 				launchTypoLattice(I.dview, tv, cn, sA);
@@ -731,9 +732,8 @@ namespace kamd
 		{
 			// typo correction on the device is written and identical to the oracle under lane emulation, but has not run on a GPU yet
 			if (!std::getenv("KAMD_EXPERIMENTAL_TYPO")) throw std::runtime_error{ "kiwi_amd: typo correction on the device is experimental (not parity-checked on a GPU yet) and only enabled with KAMD_EXPERIMENTAL_TYPO=1" };
-			if (std::isfinite(typo.typo->lengtheningCost())) throw std::runtime_error{ "kiwi_amd: lengthening typos are not handled on the device yet" };
 			if (impl->hasSbg) throw std::runtime_error{ "kiwi_amd: typo correction with a SkipBigram model is not built" };
-			if (!typo.typo->ready()) typo.typo = nullptr;      // an empty transformer corrects nothing
+			if (impl->model.forms.size() >= (1u << 24)) throw std::runtime_error{ "kiwi_amd: typo correction supports up to 2^24 forms" };
 		}
 		HostTimer tm{ "stage" };
 		auto b = std::make_shared<StagedBatch>();
@@ -917,7 +917,6 @@ namespace kamd
 	// Parity hook: typo graphs on the host (typo.cpp), the lattice over each of them by k_build_lattice_typo, dumped like dumpLattices.
 	std::vector<uint8_t> Engine::dumpTypoLattices(const PreparedTypo& typo, float threshold, uint16_t allowedDialect, const char16_t* text, size_t n, uint64_t match)
 	{
-		if (std::isfinite(typo.lengtheningCost())) throw std::runtime_error{ "typo lattices: lengthening typos are not handled by the kernel yet" };
 		PreparedText pt;
 		prepareText(pt, text, n, match, 0);
 		std::vector<TypoLatChunk> chunks; std::vector<uint32_t> chunkOf;
@@ -983,6 +982,7 @@ namespace kamd
 			v.graph = dGraph.as<TypoGraphNode>(); v.graphLast = dGraphLast.as<uint8_t>(); v.pool = dPool.as<uint16_t>(); v.chunks = dChunks.as<TypoLatChunk>();
 			v.nodes = dNodes.as<TypoLatNode>(); v.nodesFinal = dFinal.as<TypoLatNode>(); v.endPosMap = dMap.as<uint2>(); v.nsToPos = dNs.as<uint16_t>(); v.posToNs = dPs.as<uint16_t>();
 			v.states = dStates.as<TypoState>(); v.stateIdx = dSIdx.as<uint32_t>(); v.scratch = dScratch.as<uint32_t>();
+			v.lengtheningCost = typo.lengtheningCost();
 			v.threshold = threshold; v.maxUnk = config.maxUnkFormSize; v.maxUnkJ = config.maxUnkFormSizeFollowedByJClass; v.spaceTol = config.spaceTolerance; v.match = match;
 			launchTypoLattice(impl->dview, v, (uint32_t)chunks.size(), s);
 			HIPCHECK(hipGetLastError());

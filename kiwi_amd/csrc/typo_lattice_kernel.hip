@@ -3,10 +3,10 @@
 // (/root/reference/src/KTrie.cpp:897-996, 998-1464, 240-299) in their general form: one search state per (typo-graph node, way of
 // reaching it), positions multiplied by 2^posMultiplierBit for the halves of continual typos.
 //
-// STATUS: first, unoptimised form and a building block -- one THREAD per chunk over HBM arrays (the shape of k_build_lattice_big), reached
-// only through the parity hook Engine::dumpTypoLattices / kamd_typo_lattices; the analyze path does not use it yet (the search kernel has
-// no typo-cost variant).  Lengthening typos are not handled (refused by the caller).  The typo graph itself comes from
-// the host (typo.cpp).  Checked against the CPU oracle through the lane emulator (tests/test_hipemu.py) -- it has not run on a GPU.
+// STATUS: first, unoptimised form -- one THREAD per chunk over HBM arrays (the shape of k_build_lattice_big).  Two outputs: the dump records of
+// the parity hook (Engine::dumpTypoLattices / kamd_typo_lattices), or, in engine mode, the search kernel's DevNode records plus a typo cost
+// per node (experimental analyze path, KAMD_EXPERIMENTAL_TYPO).  The typo graph itself comes from
+// the host (typo.cpp).  Its parity has so far been checked in the CPU test suite only -- it has not run on a GPU.
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
 #include "feature.hpp"
@@ -118,13 +118,14 @@ namespace kamd
 				return (g.formOff & TYPO_FORM_IN_POOL) ? V.pool[(g.formOff & ~TYPO_FORM_IN_POOL) + j] : str[g.formOff + j];
 			}
 
+			// candidates: form id in the low 24 bits, syllables skipped as lengthening in the high 8
 			__device__ void flush(uint32_t* cands, uint32_t& nCands, uint32_t endNs, int32_t startPosOffset, uint32_t unkStart, uint32_t boundary, float typoCost, uint32_t startCti, uint32_t endCti)
 			{
 				for (uint32_t k = 0; k < nCands; ++k)
 				{
-					const uint32_t fi = cands[k];
+					const uint32_t fi = cands[k] & 0xFFFFFFu, lengthened = cands[k] >> 24;
 					const FormRec f = M.forms[fi];
-					const uint32_t nb = (uint32_t)((int32_t)endNs - (int32_t)(f.len - f.numSpaces) + startPosOffset), ne = endNs;
+					const uint32_t nb = (uint32_t)((int32_t)endNs - (int32_t)(f.len - f.numSpaces) - (int32_t)lengthened + startPosOffset), ne = endNs;
 					if (startCti == 0 && !(f.flags & FF_FIRST_IS_CODA))
 					{
 						const bool hj = (f.flags & FF_HAS_JCLASS) || (f.flags & FF_IS_STAG);
@@ -136,7 +137,7 @@ namespace kamd
 					{
 						const uint32_t b2 = startCti ? (nb << pmb) + startCti : nb << pmb;
 						const uint32_t e2 = endCti ? ((ne - 1) << pmb) + endCti : ne << pmb;
-						if (append(b2, e2, fi, 0, 0, typoCost)) out[nOut - 1].spaceErrors = se;
+						if (append(b2, e2, fi, 0, 0, typoCost + (lengthened ? V.lengtheningCost * (float)(3 + lengthened) : 0.f))) out[nOut - 1].spaceErrors = se;
 					}
 				}
 				nCands = 0;
@@ -159,7 +160,11 @@ namespace kamd
 				int32_t curNode = st.node;
 				const uint8_t scriptVS = 98;
 				uint32_t cands[MAXCAND]; uint32_t nCands = 0;
-				auto push = [&](uint32_t f) { if (nCands < MAXCAND) cands[nCands++] = f; else overflow = true; };
+				auto push = [&](uint32_t f) { if (nCands < MAXCAND) cands[nCands++] = f; else overflow = true; };      // (form ids stay below 2^24: checked by the engine)
+				const bool lengthening = V.lengtheningCost < INFINITY;
+				uint32_t prevChr = st.lastChr;
+				uint8_t lsz[kTypoLengthNodes]; int32_t lnd[kTypoLengthNodes]; uint32_t nL = st.nL;
+				for (uint32_t k = 0; k < nL; ++k) { lsz[k] = st.lsize[k]; lnd[k] = st.lnode[k]; }
 				for (uint32_t j = 0; j < fsz; ++j)
 				{
 					const uint16_t ch = formChar(tn, j);
@@ -195,6 +200,7 @@ namespace kamd
 							{
 								unkPair(boundary, unkStart, posToNs[pos + 1], true);
 								boundary = specialStart = unkStart = posToNs[pos + 1];
+								prevChr = c32;
 								continue;
 							}
 							bool zc = false, zs = false;
@@ -217,6 +223,7 @@ namespace kamd
 					else if (isSpace(c32))
 					{
 						boundary = specialStart = unkStart = posToNs[pos + 1];
+						prevChr = c32;
 						continue;
 					}
 					if (tn.typoCost == 0 && pat != patEnd)
@@ -231,7 +238,30 @@ namespace kamd
 							++pat;
 						}
 					}
-					if (c32 >= 0x10000) { ++j; continue; }
+					if (c32 >= 0x10000) { ++j; prevChr = c32; continue; }
+					if (lengthening)      // KTrie.cpp:1215-1270
+					{
+						const uint8_t lengtheningVowel[21] = { 0, 1, 0, 1, 4, 5, 4, 5, 8, 0, 1, 1, 8, 13, 4, 5, 20, 13, 18, 20, 20 };
+						const uint32_t prevSize = nL;
+						if (prevChr && prevChr < 0x10000 && isHangulSyllable((uint16_t)prevChr) && (0xC544 <= ch && ch < 0xC790)
+							&& lengtheningVowel[((prevChr - 0xAC00) / 28) % 21] == ((ch - 0xAC00) / 28) % 21)
+						{
+							if (nL < kTypoLengthNodes) { lsz[nL] = 1; lnd[nL] = curNode; ++nL; } else overflow = true;
+							for (uint32_t k = 0; k < prevSize; ++k) if (lsz[k] < 8) { if (nL < kTypoLengthNodes) { lsz[nL] = (uint8_t)(lsz[k] + 1); lnd[nL] = lnd[k]; ++nL; } else overflow = true; }
+						}
+						uint32_t outIdx = 0;
+						for (uint32_t k = 0; k < nL; ++k)
+						{
+							uint8_t sz = lsz[k]; int32_t nd = lnd[k];
+							if (k < prevSize) { nd = trieNext((uint32_t)nd, ch); lnd[k] = nd; if (nd < 0) continue; }
+							bool dup = false;
+							for (uint32_t q = 0; q < outIdx; ++q) dup = dup || (lsz[q] == sz && lnd[q] == nd);
+							if (dup) continue;
+							lsz[outIdx] = sz; lnd[outIdx] = nd; ++outIdx;
+						}
+						nL = outIdx;
+					}
+					prevChr = c32;
 
 					if (minFormLen > 0 || tn.typoCost > 0) ++minFormLen;
 					int32_t nx = trieNext((uint32_t)curNode, ch);
@@ -257,10 +287,16 @@ namespace kamd
 									push((uint32_t)v);
 								}
 							}
+							for (uint32_t k = 0; k < nL; ++k)
+							{
+								const int32_t v = M.trie[lnd[k]].value;
+								if (v >= 0 && M.forms[v].len >= minFormLen) push((uint32_t)v | ((uint32_t)lsz[k] << 24));
+							}
 						}
 					}
 					else
 					{
+						nL = 0;
 						if (typoCost == 0) curNode = 0;
 						else return;
 					}
@@ -281,13 +317,16 @@ namespace kamd
 					{
 						curNode = 0; typoCost = 0; minFormLen = 0; startPosOffset = -1;
 						if (nCur) return;
+						nL = 0;
 					}
-					if (typoCost > 0 && M.trie[curNode].depth < minFormLen) return;      // early pruning
+					if (typoCost > 0 && M.trie[curNode].depth < minFormLen && nL == 0) return;      // early pruning
 					if (nCur >= curCap) { overflow = true; return; }
 					TypoState ns; ns.node = curNode; ns.cost = typoCost; ns.minFormLen = minFormLen; ns.startPosOffset = startPosOffset;
 					ns.specialStart = specialStart; ns.unkStart = unkStart; ns.boundary = boundary;
 					ns.lastType = outType; ns.lastScript = outScript; ns.hasLast = outHas; ns.pad = 0;
 					ns.startCti = tn.continualTypoIdx ? tn.continualTypoIdx : st.startCti; ns.pad2 = 0;
+					ns.lastChr = prevChr; ns.nL = nL;
+					for (uint32_t k = 0; k < nL; ++k) { ns.lsize[k] = lsz[k]; ns.lnode[k] = lnd[k]; }
 					cur[nCur++] = ns;
 				}
 			}

@@ -21,14 +21,18 @@ namespace kamd
 		uint32_t chunkId, packCap;     // engine mode: index of the chunk in the batch, capacity of its candidate-pack region
 		uint32_t nOutFinal, status;    // out: number of connected nodes, ChunkStatus
 	};
-	// lattice node in the layout of the parity dumps (oracle korc_split / reference kref_split): positions are text offsets when final
+	// lattice node in the layout of the parity dumps (kamd_dump_lattices; the reference bridge writes the same): positions are text offsets when final
 	struct TypoLatNode { uint32_t startPos, endPos, prev, sibling; int32_t form; uint32_t uformLen, uformOff, spaceErrors; float typoCost; };
-	// SearchState<false> (KTrie.cpp:671-707); the last character is kept as its type / script (what the next node derives from it)
+	// SearchState (KTrie.cpp:671-707); of the last character its type / script travel along (what the next node derives from it; the host
+	// computes them per graph node) and, for lengthening typos, the character itself; lsize / lnode = LengtheningTypoNodes<true>
+	constexpr uint32_t kTypoLengthNodes = 64;
 	struct TypoState
 	{
 		int32_t node; float cost; uint32_t minFormLen; int32_t startPosOffset;
 		uint32_t specialStart, unkStart, boundary;
 		uint8_t lastType, lastScript, hasLast, pad; uint16_t startCti, pad2;
+		uint32_t lastChr, nL;
+		uint8_t lsize[kTypoLengthNodes]; int32_t lnode[kTypoLengthNodes];
 	};
 	struct TypoLatView
 	{
@@ -45,6 +49,7 @@ namespace kamd
 		// latticeEmitNode computes them), each node's typo cost beside them, node counts and chunk statuses of the batch
 		DevNode* devNodes; float* nodeTypo; uint32_t* nNodes; DevChunkResult* results;
 		float threshold; uint32_t maxUnk, maxUnkJ, spaceTol; uint64_t match;
+		float lengtheningCost;         // INFINITY: no lengthening typos (PreparedTypoTransformer::getLengtheningTypoCost)
 	};
 	void launchTypoLattice(const ModelView& M, const TypoLatView& V, uint32_t nChunks, hipStream_t stream);
 }

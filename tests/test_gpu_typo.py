@@ -29,17 +29,18 @@ def test_typo_transformer_is_refused_without_the_flag(small_model, monkeypatch):
 
 
 @enabled
-@pytest.mark.parametrize("continual,threshold,top_n,lanes", [(float("inf"), 2.5, 1, "16"), (1.0, 2.5, 1, "16"), (1.0, 1.2, 3, "16"), (1.0, 2.5, 2, "64")])
-def test_typo_analyses_bit_exact_vs_oracle(small_model, monkeypatch, continual, threshold, top_n, lanes):
+@pytest.mark.parametrize("continual,threshold,top_n,lanes,lengthening", [(float("inf"), 2.5, 1, "16", float("inf")), (1.0, 2.5, 1, "16", float("inf")), (1.0, 1.2, 3, "16", float("inf")),
+                                                                         (1.0, 2.5, 2, "64", float("inf")), (1.0, 2.5, 1, "16", 0.25)])
+def test_typo_analyses_bit_exact_vs_oracle(small_model, monkeypatch, continual, threshold, top_n, lanes, lengthening):
     import oraclelib
     from kiwi_amd.api import KiwiAmd
     from typo_cases import misspell
     sm, path = small_model
     monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
-    prod, orc_t = _typo_pair(LIB, continual)
+    prod, orc_t = _typo_pair(LIB, continual, lengthening)
     dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
     rnd = random.Random(11)
-    texts = [misspell(t, rnd, True, continual == 1.0) for t in synthetic(sm, 400, 591, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 200, 592)] + EDGE_TEXTS
+    texts = [misspell(t, rnd, True, continual == 1.0, lengthening < 1e9) for t in synthetic(sm, 400, 591, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 200, 592)] + EDGE_TEXTS
     got = _analyze_typo(dev, prod, texts, threshold, top_n)
     for t, y in zip(texts, got):
         assert _norm(orc.analyze_typo(orc_t, t, threshold, 0, top_n=top_n)) == _norm(y), t

@@ -296,13 +296,13 @@ def _analyze_typo(dev, typo, texts, threshold, top_n=1, dialect=0):
     return Results(L, r).to_python()
 
 
-def _typo_pair(lib, continual):
+def _typo_pair(lib, continual, lengthening=float("inf")):
     import oraclelib
     import test_typo_product
-    from typo_cases import COND, INF, RULES
+    from typo_cases import COND, RULES
     test_typo_product.LIB = lib
-    prod = test_typo_product.ProductTypo(continual, INF)
-    orc_t = oraclelib.OracleTypo(continual, INF)
+    prod = test_typo_product.ProductTypo(continual, lengthening)
+    orc_t = oraclelib.OracleTypo(continual, lengthening)
     for origs, errs, cost, cond, dia in RULES:
         for o in origs:
             for e in errs:
@@ -312,12 +312,13 @@ def _typo_pair(lib, continual):
     return prod, orc_t
 
 
-@pytest.mark.parametrize("continual,threshold,top_n,lanes,tiny", [(float("inf"), 2.5, 1, "16", False), (1.0, 2.5, 1, "16", False), (1.0, 1.2, 3, "16", False),
-                                                                   (1.0, 2.5, 1, "64", False), (1.0, 2.5, 2, "16", True)])
-def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch, continual, threshold, top_n, lanes, tiny):
+@pytest.mark.parametrize("continual,threshold,top_n,lanes,tiny,lengthening", [(float("inf"), 2.5, 1, "16", False, float("inf")), (1.0, 2.5, 1, "16", False, float("inf")),
+                                                                               (1.0, 1.2, 3, "16", False, float("inf")), (1.0, 2.5, 1, "64", False, float("inf")),
+                                                                               (1.0, 2.5, 2, "16", True, float("inf")), (1.0, 2.5, 1, "16", False, 0.25), (float("inf"), 4.0, 2, "64", False, 0.25)])
+def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch, continual, threshold, top_n, lanes, tiny, lengthening):
     """The whole typo-correcting analysis on the (emulated) device -- typo graphs from the host module, k_build_lattice_typo, the search kernel
     compiled with node typo costs (viterbi_kernel_typo.hip), end stage, host post-processing -- against the oracle (pinned to the real
-    reference): tokens, positions, fp32 scores, per-token typo costs; also through the capacity ladder.  Gated on the device
+    reference): tokens, positions, fp32 scores, per-token typo costs; continual and lengthening typos; also through the capacity ladder.  Gated on the device
     (KAMD_EXPERIMENTAL_TYPO) until it has run on a GPU."""
     import random
     import oraclelib
@@ -328,11 +329,11 @@ def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch,
     monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
     if tiny:
         monkeypatch.setenv("KAMD_TEST_TINY_ARENAS", "1")
-    prod, orc_t = _typo_pair(emu_libs[0], continual)
+    prod, orc_t = _typo_pair(emu_libs[0], continual, lengthening)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     orc = oraclelib.OracleKiwi(path)
     rnd = random.Random(7)
-    texts = [misspell(t, rnd, True, continual == 1.0) for t in synthetic(sm, 50, 581, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 25, 582)] + EDGE_TEXTS
+    texts = [misspell(t, rnd, True, continual == 1.0, lengthening < 1e9) for t in synthetic(sm, 50, 581, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 25, 582)] + EDGE_TEXTS
     got = _analyze_typo(dev, prod, texts, threshold, top_n)
     corrected = 0
     for t, y in zip(texts, got):
