@@ -7,8 +7,8 @@
  * Differences a caller can observe:
  *   - kiwi_init's model_path names a raw-model container (or a directory holding `kiwi_amd.raw`);
  *     on-disk sj.morph / sj.knlm loaders are a "next" row.
- *   - top_n > 4, blocklist, pretokenized spans, typo transformers and non-standard dialects are refused with
- *     NULL/KIWIERR_FAIL + kiwi_error() instead of being silently ignored.
+ *   - top_n > 4, blocklist, pretokenized spans and non-standard dialects are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
+ *     being silently ignored; a typo transformer is accepted only with KAMD_EXPERIMENTAL_TYPO=1 (experimental device path).
  */
 #ifndef KIWI_CAPI_SUBSET_H
 #define KIWI_CAPI_SUBSET_H
@@ -27,6 +27,7 @@ typedef struct kiwi_s* kiwi_h;                       /* capi.h:29 */
 typedef struct kiwi_res* kiwi_res_h;                 /* capi.h:31 */
 typedef struct kiwi_morphset* kiwi_morphset_h;       /* capi.h:36 */
 typedef struct kiwi_pretokenized* kiwi_pretokenized_h; /* capi.h:37 */
+typedef struct kiwi_typo* kiwi_typo_h;                   /* capi.h:35 */
 typedef struct kiwi_prepared_typo* kiwi_prepared_typo_h; /* capi.h:38 */
 typedef unsigned short kchar16_t;                    /* capi.h:39 */
 
@@ -94,6 +95,21 @@ float kiwi_res_score(kiwi_res_h result, int index, int num);                    
 float kiwi_res_typo_cost(kiwi_res_h result, int index, int num);                                 /* capi.h:927 */
 int kiwi_res_close(kiwi_res_h result);                                                           /* capi.h:937 */
 const char* kiwi_get_script_name(uint8_t script);                                                /* capi.h:1417 */
+/* typo transformers.  Building and preparing one is complete; ANALYSING with one (option.typo_transformer) is experimental on the device and needs
+ * KAMD_EXPERIMENTAL_TYPO=1 in the environment, otherwise kiwi_analyze* return NULL / KIWIERR_FAIL with a message.  kiwi_typo_get_default / _get_basic
+ * return NULL: the built-in sets are rule tables of the reference and are not shipped. */
+kiwi_typo_h kiwi_typo_init(void);                                                                /* capi.h:469 */
+kiwi_typo_h kiwi_typo_get_basic(void);                                                           /* capi.h:480 */
+kiwi_typo_h kiwi_typo_get_default(int kiwi_typo_set);                                            /* capi.h:501 */
+int kiwi_typo_add(kiwi_typo_h handle, const char** orig, int orig_size, const char** error, int error_size, float cost, int condition); /* capi.h:510 */
+kiwi_typo_h kiwi_typo_copy(kiwi_typo_h handle);                                                  /* capi.h:519 */
+int kiwi_typo_update(kiwi_typo_h handle, kiwi_typo_h src);                                       /* capi.h:530 */
+int kiwi_typo_scale_cost(kiwi_typo_h handle, float scale);                                       /* capi.h:539 */
+int kiwi_typo_set_continual_typo_cost(kiwi_typo_h handle, float threshold);                      /* capi.h:550 */
+int kiwi_typo_set_lengthening_typo_cost(kiwi_typo_h handle, float threshold);                    /* capi.h:561 */
+int kiwi_typo_close(kiwi_typo_h handle);                                                         /* capi.h:570 */
+kiwi_prepared_typo_h kiwi_typo_prepare(kiwi_typo_h handle);                                      /* capi.h:580 */
+int kiwi_prepared_typo_close(kiwi_prepared_typo_h handle);                                       /* capi.h:588 */
 
 #ifdef __cplusplus
 }

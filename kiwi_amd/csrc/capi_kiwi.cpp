@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 #include "../../include/kiwi_capi.h"
 #include "engine.hpp"
+#include "typo.hpp"
 
 using namespace kamd;
 
@@ -18,6 +19,9 @@ struct kiwi_s
 	int numThreads = 0;
 	int batchSize = 65536;
 };
+
+struct kiwi_typo { kamd::TypoTransformer tt; };                       // capi.h:35
+struct kiwi_prepared_typo { kamd::PreparedTypo p; };                  // capi.h:38
 
 struct kiwi_res
 {
@@ -89,12 +93,14 @@ namespace
 	void checkOption(const kiwi_analyze_option_t& o, kiwi_pretokenized_h pt)
 	{
 		if (o.blocklist) throw std::invalid_argument{ "kiwi_amd: blocklist is not supported on the device path yet" };
-		if (o.typo_transformer) throw std::invalid_argument{ "kiwi_amd: typo transformers are not supported on the device path yet" };
 		if (o.allowed_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported on the device path yet" };
 		if (pt) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
 		if ((uint32_t)o.match_options & (3u << 8)) throw std::invalid_argument{ "`oovChrModel` option is set but the character-level noun model is not loaded." };
 		if ((uint32_t)o.match_options & (1u << 30)) throw std::invalid_argument{ "kiwi_amd: useOldSplitter is not supported" };
 	}
+
+	// AnalyzeOption::typoTransformer / typoThreshold (the engine gates the experimental path behind KAMD_EXPERIMENTAL_TYPO)
+	TypoOption typoOf(const kiwi_analyze_option_t& o);
 
 	kiwi_res* makeRes(std::vector<TokenResult>&& r)
 	{
@@ -134,7 +140,7 @@ namespace
 			if (texts.empty()) break;
 			std::vector<std::pair<const char16_t*, size_t>> views;
 			for (auto& t : texts) views.emplace_back(t.data(), t.size());
-			auto res = h->engine->analyzeBatch(views, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads);
+			auto res = h->engine->analyzeBatch(views, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt));
 			for (auto& r : res) (*receiver)(receiverIdx++, makeRes(std::move(r)), ud);   // in input order; the receiver owns the result
 		}
 		return readerIdx;
@@ -146,8 +152,61 @@ namespace
 	}
 }
 
+namespace
+{
+	TypoOption typoOf(const kiwi_analyze_option_t& o)
+	{
+		TypoOption t;
+		if (o.typo_transformer) { t.typo = &o.typo_transformer->p; t.threshold = o.typo_threshold; t.allowedDialect = 0; }
+		return t;
+	}
+}
+
 extern "C"
 {
+	// ---- typo transformers (capi.h:459-588; src/capi/kiwi_c.cpp:540-715).  The analysis with one is EXPERIMENTAL on the device.
+	kiwi_typo_h kiwi_typo_init() { try { return new kiwi_typo; } catch (const std::exception& e) { setError(e); return nullptr; } }
+	kiwi_typo_h kiwi_typo_get_basic() { return kiwi_typo_get_default(1); }
+	kiwi_typo_h kiwi_typo_get_default(int)
+	{
+		// the built-in sets are rule tables of the reference (src/TypoTransformer.cpp:1058-1254), i.e. its data: not shipped here
+		setError(std::runtime_error{ "kiwi_amd: the built-in typo sets are not shipped with this library; build the set with kiwi_typo_add" });
+		return nullptr;
+	}
+	int kiwi_typo_add(kiwi_typo_h h, const char** orig, int orig_size, const char** error, int error_size, float cost, int condition)
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		try
+		{
+			std::vector<std::u16string> origs, errors;
+			for (int i = 0; i < orig_size; ++i) origs.push_back(utf8To16(orig[i], std::strlen(orig[i])));
+			for (int i = 0; i < error_size; ++i) errors.push_back(utf8To16(error[i], std::strlen(error[i])));
+			for (auto& o : origs) for (auto& e : errors) h->tt.add(o, e, cost, (uint8_t)condition, 0);
+			return 0;
+		}
+		catch (const std::exception& e) { setError(e); return -1; }
+	}
+	kiwi_typo_h kiwi_typo_copy(kiwi_typo_h h) { if (!h) return nullptr; try { return new kiwi_typo{ *h }; } catch (const std::exception& e) { setError(e); return nullptr; } }
+	int kiwi_typo_update(kiwi_typo_h h, kiwi_typo_h src)
+	{
+		if (!h || !src) return KIWIERR_INVALID_HANDLE;
+		try { h->tt.update(src->tt); return 0; } catch (const std::exception& e) { setError(e); return -1; }
+	}
+	int kiwi_typo_scale_cost(kiwi_typo_h h, float scale)
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		try { h->tt.scaleCost(scale); return 0; } catch (const std::exception& e) { setError(e); return -1; }
+	}
+	int kiwi_typo_set_continual_typo_cost(kiwi_typo_h h, float threshold) { if (!h) return KIWIERR_INVALID_HANDLE; h->tt.setContinualCost(threshold); return 0; }
+	int kiwi_typo_set_lengthening_typo_cost(kiwi_typo_h h, float threshold) { if (!h) return KIWIERR_INVALID_HANDLE; h->tt.setLengtheningCost(threshold); return 0; }
+	int kiwi_typo_close(kiwi_typo_h h) { if (!h) return KIWIERR_INVALID_HANDLE; delete h; return 0; }
+	kiwi_prepared_typo_h kiwi_typo_prepare(kiwi_typo_h h)
+	{
+		if (!h) return nullptr;
+		try { return new kiwi_prepared_typo{ kamd::PreparedTypo{ h->tt, true } }; } catch (const std::exception& e) { setError(e); return nullptr; }
+	}
+	int kiwi_prepared_typo_close(kiwi_prepared_typo_h h) { if (!h) return KIWIERR_INVALID_HANDLE; delete h; return 0; }
+
 	const char* kiwi_version(void) { return "0.23.1+kiwi_amd"; }
 	const char* kiwi_error(void) { return hasError ? currentError.c_str() : nullptr; }
 	void kiwi_clear_error(void) { hasError = false; currentError.clear(); }
@@ -222,7 +281,7 @@ extern "C"
 			checkOption(opt, pt);
 			size_t n = 0; while (text[n]) ++n;
 			std::vector<std::pair<const char16_t*, size_t>> v{ { (const char16_t*)text, n } };
-			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1);
+			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
 			return makeRes(std::move(res[0]));
 		}
 		catch (const std::exception& e) { setError(e); return nullptr; }
@@ -236,7 +295,7 @@ extern "C"
 			checkOption(opt, pt);
 			const std::u16string u = utf8To16(text, std::strlen(text));
 			std::vector<std::pair<const char16_t*, size_t>> v{ { u.data(), u.size() } };
-			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1);
+			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
 			return makeRes(std::move(res[0]));
 		}
 		catch (const std::exception& e) { setError(e); return nullptr; }

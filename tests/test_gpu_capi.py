@@ -272,3 +272,66 @@ def test_c_client_program(oracle, small_model, tmp_path):
         else:
             got.append((int(f[0]), f[1], int(f[3]), int(f[4]), f[5]))
     assert got == want
+
+
+@pytest.mark.skipif(not os.environ.get("KAMD_EXPERIMENTAL_TYPO"), reason="typo correction on the device is experimental: set KAMD_EXPERIMENTAL_TYPO=1")
+def test_typo_transformer_through_the_c_api(capi, kiwi, small_model):
+    """kiwi_typo_init / _add / _copy / _update / _scale_cost / _set_*_cost / _prepare and kiwi_analyze with option.typo_transformer, as a client of the
+    reference would call them (capi.h:459-588, 662-698), against the oracle with the same rules: tokens, scores, kiwi_res_typo_cost."""
+    import random
+    import oraclelib
+    from typo_cases import COND, RULES, misspell
+    sm, path = small_model
+    L = capi
+    L.kiwi_typo_init.restype = C.c_void_p
+    L.kiwi_typo_copy.restype = C.c_void_p
+    L.kiwi_typo_copy.argtypes = [C.c_void_p]
+    L.kiwi_typo_get_default.restype = C.c_void_p
+    L.kiwi_typo_add.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_float, C.c_int]
+    L.kiwi_typo_update.argtypes = [C.c_void_p, C.c_void_p]
+    L.kiwi_typo_scale_cost.argtypes = [C.c_void_p, C.c_float]
+    L.kiwi_typo_set_continual_typo_cost.argtypes = [C.c_void_p, C.c_float]
+    L.kiwi_typo_set_lengthening_typo_cost.argtypes = [C.c_void_p, C.c_float]
+    L.kiwi_typo_close.argtypes = [C.c_void_p]
+    L.kiwi_typo_prepare.restype = C.c_void_p
+    L.kiwi_typo_prepare.argtypes = [C.c_void_p]
+    L.kiwi_prepared_typo_close.argtypes = [C.c_void_p]
+    L.kiwi_res_typo_cost.restype = C.c_float
+    L.kiwi_res_typo_cost.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    assert not L.kiwi_typo_get_default(1) and b"not shipped" in L.kiwi_error()
+    part, whole = L.kiwi_typo_init(), L.kiwi_typo_init()
+    orc_t = oraclelib.OracleTypo(1.0, 0.25)
+    for origs, errs, cost, cond, dia in RULES:
+        if dia:
+            continue          # (the C API's kiwi_typo_add has no dialect argument)
+        o = (C.c_char_p * len(origs))(*[x.encode() for x in origs])
+        e = (C.c_char_p * len(errs))(*[x.encode() for x in errs])
+        assert L.kiwi_typo_add(part, o, len(origs), e, len(errs), cost / 2, COND[cond]) == 0      # half the cost here, doubled by scale_cost below
+        for a in origs:
+            for b in errs:
+                orc_t.add(a, b, cost, COND[cond], 0)
+    assert L.kiwi_typo_scale_cost(part, 2.0) == 0 and L.kiwi_typo_scale_cost(part, -1.0) == -1
+    assert L.kiwi_typo_update(whole, part) == 0
+    copy = L.kiwi_typo_copy(whole)
+    assert L.kiwi_typo_set_continual_typo_cost(copy, 1.0) == 0 and L.kiwi_typo_set_lengthening_typo_cost(copy, 0.25) == 0
+    prepared = L.kiwi_typo_prepare(copy)
+    assert prepared
+    orc_t.prepare(True)
+    orc = oraclelib.OracleKiwi(path)
+    rnd = random.Random(21)
+    opt = Option(MATCH_ALL_WITH_NORMALIZING, None, 0, 0, 3.0, prepared, 2.5)
+    corrected = 0
+    for t in [misspell(x, rnd, True, True, True) for x in synthetic(sm, 60, 181, min_jamo=5, max_jamo=80)]:
+        r = L.kiwi_analyze(kiwi, t.encode("utf-8"), 1, opt, None)
+        assert r, L.kiwi_error()
+        want = orc.analyze_typo(orc_t, t, 2.5, 0)
+        toks = want[0][0]
+        assert L.kiwi_res_word_num(r, 0) == len(toks) and L.kiwi_res_prob(r, 0) == want[0][1], t
+        for k, tok in enumerate(toks):
+            assert L.kiwi_res_form(r, 0, k).decode("utf-8") == tok.form and L.kiwi_res_typo_cost(r, 0, k) == tok.typo_cost, (t, k)
+            corrected += tok.typo_cost > 0
+        L.kiwi_res_close(r)
+    assert corrected > 10
+    L.kiwi_prepared_typo_close(prepared)
+    for h in (part, whole, copy):
+        assert L.kiwi_typo_close(h) == 0

@@ -161,7 +161,7 @@ def test_emulated_c_api_suite(emu_libs):
     """The drop-in boundary on the CPU: tests/test_gpu_capi.py (Kiwi's own C API bound with ctypes, reader / receiver protocol,
     8 concurrent callers on one handle, a gcc-built C client) re-run against the emulated build of the same sources."""
     import sys
-    env = dict(os.environ, KAMD_TEST_LIB=emu_libs[0])
+    env = dict(os.environ, KAMD_TEST_LIB=emu_libs[0], KAMD_EXPERIMENTAL_TYPO="1")      # (so that the typo-transformer test of that file runs too)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_capi.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
