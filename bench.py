@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1):
+def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None):
     """Times the CPU path on this box's host cores on a bounded sample of the same workload.
     Uses the real reference TUs (oracle/_ref) when the prebuilt library travelled with the repo, else this
     repo's CPU oracle ("port").  Also returns the oracle's ALG_BYTES event counts on its sample."""
@@ -27,24 +27,32 @@ def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1):
     import refbridge
     cores = os.cpu_count() or 1
     orc = oraclelib.OracleKiwi(model_path)
+    orc_typo = ref_typo = None
+    thr = 2.5
+    if typo is not None:      # the same rules on both CPU sides
+        from kiwi_amd.workloads import fill_typo_rules
+        cont, leng, thr = typo
+        orc_typo = oraclelib.OracleTypo(cont, leng); fill_typo_rules(orc_typo); orc_typo.prepare(True)
+        if refbridge.available():
+            ref_typo = refbridge.RefTypo(cont, leng); fill_typo_rules(ref_typo, cond_by_name=True); ref_typo.prepare(True)
     # single-thread sample: 2048 sentences, fewer when the model is slow on the CPU (SkipBigram lattices: tens of sentences/s)
-    probe, _ = orc.analyze_batch(texts[:32], top_n=top_n, threads=1)
+    probe, _ = orc.analyze_batch(texts[:32], top_n=top_n, threads=1, typo=orc_typo, typo_threshold=thr)
     sample = texts[:int(min(2048, max(32, 32 / max(probe, 1e-6) * 4.0)))]
     orc.counters(reset=True)
-    sec1, _ = orc.analyze_batch(sample, top_n=top_n, threads=1)
+    sec1, _ = orc.analyze_batch(sample, top_n=top_n, threads=1, typo=orc_typo, typo_threshold=thr)
     counts = orc.counters()
     alg = oraclelib.alg_bytes(counts)
     per_sentence = {k: v / len(sample) for k, v in alg.items()}
     out = {"alg_bytes_per_sentence": per_sentence, "alg_sample": len(sample)}
     if refbridge.available():
         ref = refbridge.RefKiwi(model_path)
-        kind, runner = "reference", ref
+        kind, runner, rtypo = "reference", ref, ref_typo
     else:
-        kind, runner = "port", orc
-    s1, _ = runner.analyze_batch(sample, top_n=top_n, threads=1)
+        kind, runner, rtypo = "port", orc, orc_typo
+    s1, _ = runner.analyze_batch(sample, top_n=top_n, threads=1, typo=rtypo, typo_threshold=thr)
     rate1 = len(sample) / s1
     n_mt = int(min(len(texts), max(min(2048, 4 * cores), rate1 * cores * budget_s / 4)))
-    smt, _ = runner.analyze_batch(texts[:n_mt], top_n=top_n, threads=cores)
+    smt, _ = runner.analyze_batch(texts[:n_mt], top_n=top_n, threads=cores, typo=rtypo, typo_threshold=thr)
     out["cpu_baseline"] = {"value": n_mt / smt, "unit": "sentences/s", "cores": cores, "kind": kind,
                            "sample": f"{n_mt} sentences of the same workload on {cores} threads; single thread: {rate1:.0f} sentences/s on {len(sample)}"}
     return out
@@ -75,7 +83,7 @@ def main():
     import torch
     from kiwi_amd import dist
     from kiwi_amd.api import KiwiAmd
-    from kiwi_amd.workloads import get_workload, workload_top_n
+    from kiwi_amd.workloads import fill_typo_rules, get_workload, workload_top_n, workload_typo
     rank, local_rank, world = dist.env_rank_world()
     if world > 1:
         dist.init("nccl", local_rank)
@@ -91,7 +99,13 @@ def main():
 
     top_n = workload_top_n(args.workload)
     eng = KiwiAmd(model_path, local_rank)
-    batch = eng.stage(shard)
+    typo_cfg, typo = workload_typo(args.workload), None
+    if typo_cfg is not None:
+        from kiwi_amd.api import Typo
+        typo = Typo(eng.lib, typo_cfg[0], typo_cfg[1])
+        fill_typo_rules(typo)
+        typo.prepare(True)
+    batch = eng.stage(shard) if typo is None else eng.stage(shard, typo=typo, typo_threshold=typo_cfg[2])
     info = batch.info()
     if top_n > 1:
         eng.run(batch)
@@ -127,7 +141,7 @@ def main():
         total_sent = n * world * args.steps
         value = total_sent / elapsed
         out = {
-            "metric": "sentences/sec on batched analyze() (dictionary scan + lattice + Viterbi/%s, top-%d)" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "Knlm", top_n),
+            "metric": "sentences/sec on batched analyze() (dictionary scan + lattice + Viterbi/%s, top-%d)" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "Knlm, typo correction" if typo is not None else "Knlm", top_n),
             "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32+f32", "data": "synthetic",
@@ -136,7 +150,7 @@ def main():
                        "kernel_ms": kt, "device_bytes": info["device_bytes"]},
         }
         if not args.no_cpu_baseline:
-            cb = cpu_baseline(model_path, texts, top_n=top_n)
+            cb = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg)
             per = cb["alg_bytes_per_sentence"]
             search_bytes = per["search"] * n
             achieved = search_bytes / (kt["search_ms"] * 1e-3) / 1e9
@@ -147,6 +161,8 @@ def main():
         print(json.dumps(out))
     res.close()
     batch.close()
+    if typo is not None:
+        typo.close()
     eng.close()
     if world > 1:
         torch.distributed.destroy_process_group()

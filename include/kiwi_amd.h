@@ -87,6 +87,9 @@ size_t kamd_typo_graph(kamd_typo_h t, const uint16_t* text, uint32_t len, int al
  * SkipBigram models are refused. */
 kamd_results_h kamd_analyze_batch_typo(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts,
                                        uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
+/* ... and kamd_stage with one (the transformer must outlive the batch): kamd_run / kamd_fetch as usual */
+kamd_batch_h kamd_stage_typo(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts,
+                             uint64_t match_options, int open_ending, int host_threads);
 /* parity hook: the lattices the device builds OVER the typo graphs of a text's chunks (csrc/typo_lattice_kernel.hip), in the layout of kamd_dump_lattices;
  * 0 + kamd_last_error() on failure */
 size_t kamd_typo_lattices(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);

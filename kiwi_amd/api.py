@@ -194,9 +194,15 @@ class KiwiAmd:
     def analyze(self, text, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False):
         return self.analyze_batch([text], top_n, match, open_ending, 1).to_python()[0]
 
-    def stage(self, texts, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Batch:
+    def stage(self, texts, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0, typo=None, typo_threshold=2.5) -> Batch:
+        """typo: a prepared `Typo` (experimental device path, KAMD_EXPERIMENTAL_TYPO=1); it must outlive the batch."""
         flat, offs = pack_texts(texts)
-        b = self.lib.kamd_stage(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), match, int(open_ending), host_threads)
+        if typo is None:
+            b = self.lib.kamd_stage(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), match, int(open_ending), host_threads)
+        else:
+            self.lib.kamd_stage_typo.restype = C.c_void_p
+            self.lib.kamd_stage_typo.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+            b = self.lib.kamd_stage_typo(self.h, typo.h, typo_threshold, 0, flat.ctypes.data, offs.ctypes.data, len(texts), match, int(open_ending), host_threads)
         if not b:
             raise self._err("kamd_stage")
         return Batch(self.lib, b)
@@ -244,3 +250,32 @@ class KiwiAmd:
                 o += 36
             chunks.append((se, nodes))
         return chunks
+
+
+class Typo:
+    """A typo transformer of the low-level ABI (kamd_typo_*): rules added one by one, then prepared for analysis."""
+
+    def __init__(self, lib, continual=float("inf"), lengthening=float("inf")):
+        self.lib = lib
+        lib.kamd_typo_new.restype = C.c_void_p
+        lib.kamd_typo_new.argtypes = [C.c_float, C.c_float]
+        lib.kamd_typo_close.argtypes = [C.c_void_p]
+        lib.kamd_typo_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_int]
+        lib.kamd_typo_prepare.argtypes = [C.c_void_p, C.c_int]
+        self.h = lib.kamd_typo_new(continual, lengthening)
+
+    def add(self, orig, error, cost=1.0, cond=0, dialect=0):
+        o = np.frombuffer(orig.encode("utf-16-le"), np.uint16)
+        e = np.frombuffer(error.encode("utf-16-le"), np.uint16)
+        if self.lib.kamd_typo_add(self.h, o.ctypes.data, len(o), e.ctypes.data, len(e), cost, cond, dialect) != 0:
+            raise ValueError((orig, error))
+
+    def prepare(self, inverse=True):
+        if self.lib.kamd_typo_prepare(self.h, int(inverse)) != 0:
+            raise RuntimeError("kamd_typo_prepare")
+        return self
+
+    def close(self):
+        if self.h:
+            self.lib.kamd_typo_close(self.h)
+            self.h = None

@@ -211,6 +211,11 @@ extern "C"
 		if (!h || !t || !t->prepared) { lastError = "invalid handle / typo transformer not prepared"; return nullptr; }
 		return guarded([&]() { return pack(h->e->analyzeBatch(views(texts, offsets, n), topN, match, !!openEnding, hostThreads, TypoOption{ t->prepared.get(), threshold, (uint16_t)allowed_dialect })); }, (kamd_results*)nullptr);
 	}
+	kamd_batch_h kamd_stage_typo(kamd_engine_h h, kamd_typo* t, float threshold, int allowed_dialect, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint64_t match, int openEnding, int hostThreads)
+	{
+		if (!h || !t || !t->prepared) { lastError = "invalid handle / typo transformer not prepared"; return nullptr; }
+		return guarded([&]() { auto b = std::make_unique<kamd_batch>(); b->b = h->e->stage(views(texts, offsets, n), match, !!openEnding, hostThreads, TypoOption{ t->prepared.get(), threshold, (uint16_t)allowed_dialect }); return b.release(); }, (kamd_batch*)nullptr);
+	}
 	size_t kamd_typo_lattices(kamd_engine_h h, kamd_typo* t, float threshold, int allowed_dialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
 	{
 		if (!h || !t || !t->prepared) { lastError = "invalid handle / typo transformer not prepared"; return 0; }

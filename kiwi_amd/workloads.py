@@ -10,6 +10,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA = os.path.join(ROOT, "_data")
 
+SEED_C5 = 0x4B495749 + 5
 WORKLOADS = {
     # name: (spec name, n sentences, corpus kwargs, seed offset)  -- seeds follow BASELINE.md ("KIWI" + config index)
     "c2": ("full", 8192, dict(exact_jamo=40), 2),
@@ -17,9 +18,74 @@ WORKLOADS = {
     # BASELINE config 3 proper: SkipBigram model, top-3 (device kernel experimental: needs KAMD_EXPERIMENTAL_SBG=1)
     "c3-sbg": ("full-sbg", 65536, dict(min_jamo=5, max_jamo=200), 3),
     "small-c2": ("small", 8192, dict(exact_jamo=40), 2),
+    # BASELINE config 5: the c2 corpus misspelt (confusable vowels, carried-over codas), analysed with a typo transformer (TYPO_RULES, continual cost 1,
+    # typoCostWeight 6, threshold 2.5); device path experimental: needs KAMD_EXPERIMENTAL_TYPO=1
+    "c5": ("full", 8192, dict(exact_jamo=40), 2),
     # c2 at the batch size the north-star throughput target is quoted on (>= 64k sentences): the throughput regime
     "c2-64k": ("full", 65536, dict(exact_jamo=40), 12),
 }
+
+
+INF = float("inf")
+COND = {"none": 0, "any": 1, "vowel": 2, "vocalic": 3, "vocalic_h": 4, "non_vowel": 5, "non_vocalic": 6, "non_vocalic_h": 7, "applosive": 8, "continual": 9, "boundary": 10}
+# This repo's own typo rules (the reference's built-in sets are its data and are not shipped): (origs, errors, cost, left condition, dialect bits)
+TYPO_RULES = [
+    (["ㅐ", "ㅔ"], ["ㅐ", "ㅔ"], 1.0, "none", 0), (["ㅚ", "ㅙ"], ["ㅞ", "ㅐ"], 1.5, "none", 0), (["ㅟ", "ㅢ"], ["ㅣ"], 1.0, "none", 0),
+    (["위", "의"], ["이"], INF, "none", 0), (["위", "의"], ["이"], 1.0, "any", 0), (["자", "쟈"], ["자", "쟈"], 1.0, "none", 0),
+    (["ᆻ어"], ["ᆺ어", "ᆺ서"], 1.0, "none", 0), (["ᆫᄒ"], ["ᆫᄒ", "ᆭᄋ"], 2.0, "none", 0), (["ᄒ"], ["ᄋ"], 0.5, "vowel", 0),
+    (["ᄒ", "ᄀ"], ["ᄏ", "ᄁ"], 1.0, "applosive", 0), (["ᆨᄋ"], ["ᄀ"], 1.0, "continual", 0), (["ᆫᄋ"], ["ᄂ"], 1.0, "continual", 0),
+    (["ᆯᄋ"], ["ᄅ"], 1.0, "continual", 0), (["시어"], ["셔"], 0.25, "boundary", 8), (["지어"], ["져"], 0.25, "boundary", 0),
+    (["안"], ["않"], 1.5, "none", 0), (["돼"], ["되"], 1.0, "none", 0), (["던"], ["든"], 1.0, "none", 16),
+]
+CODA2ONSET = {1: 0, 4: 2, 7: 3, 8: 5, 16: 6, 17: 7, 19: 9, 22: 12, 23: 14, 24: 15, 25: 16, 26: 17, 27: 18}
+LENGTHENING_VOWEL = [0, 1, 0, 1, 4, 5, 4, 5, 8, 0, 1, 1, 8, 13, 4, 5, 20, 13, 18, 20, 20]
+
+
+def misspell(text, rnd, vowels=True, carry=True, lengthen=False):
+    """Injects the kinds of errors typo transformers correct into a text of the synthetic model: confusable vowels (ㅐ/ㅔ, ㅚ/ㅙ), a coda
+    written as the onset of the following vowel-initial syllable (연철, what continual rules undo), and 1-3 syllables that merely lengthen
+    the vowel of an open syllable ("가아아", what the lengthening cost pays for)."""
+    o = list(text)
+    if vowels:
+        for i, ch in enumerate(o):
+            c = ord(ch)
+            if 0xAC00 <= c < 0xD7A4 and rnd.random() < 0.15:
+                v = (c - 0xAC00) // 28 % 21
+                if v == 1: c += 4 * 28
+                elif v == 5: c -= 4 * 28
+                elif v == 11: c -= 1 * 28
+                o[i] = chr(c)
+    if carry:
+        for i in range(len(o) - 1):
+            a, b = ord(o[i]), ord(o[i + 1])
+            if 0xAC00 <= a < 0xD7A4 and 0xAC00 <= b < 0xD7A4 and rnd.random() < 0.5:
+                coda = (a - 0xAC00) % 28
+                onset = (b - 0xAC00) // 28 // 21
+                if coda in CODA2ONSET and onset == 11:
+                    o[i] = chr(a - coda)
+                    o[i + 1] = chr(b + (CODA2ONSET[coda] - 11) * 21 * 28)
+    if lengthen:
+        p = []
+        for ch in o:
+            p.append(ch)
+            c = ord(ch)
+            if 0xAC00 <= c < 0xD7A4 and (c - 0xAC00) % 28 == 0 and rnd.random() < 0.2:
+                p.append(chr(0xAC00 + (11 * 21 + LENGTHENING_VOWEL[(c - 0xAC00) // 28 % 21]) * 28) * rnd.randint(1, 3))
+        o = p
+    return "".join(o)
+
+
+def fill_typo_rules(transformer, cond_by_name=False):
+    """TYPO_RULES through `transformer.add(orig, error, cost, cond, dialect)`."""
+    for origs, errs, cost, cond, dia in TYPO_RULES:
+        for o in origs:
+            for e in errs:
+                transformer.add(o, e, cost, cond if cond_by_name else COND[cond], dia)
+
+
+def workload_typo(name: str):
+    """None, or (continual cost, lengthening cost, threshold) of the transformer the workload is analysed with (rules: TYPO_RULES)."""
+    return (1.0, INF, 2.5) if name == "c5" else None
 
 
 def _spec(name):
@@ -43,6 +109,12 @@ def get_workload(name: str):
             texts = sm.make_corpus(wn, SEED_BASE + widx, **wkw)
             with open(os.path.join(DATA, f"{wname}.corpus.txt"), "w", encoding="utf-8") as f:
                 f.write("\n".join(texts))
+    if name == "c5":      # the c2 corpus, misspelt deterministically
+        import random
+        _, texts, _ = get_workload("c2")
+        rnd = random.Random(SEED_C5)
+        texts = [misspell(t, rnd) for t in texts]
+        return model_path, texts, f"c5: {n} synthetic sentences (c2 corpus misspelt: confusable vowels, carried-over codas), synthetic '{spec_name}' model (kiwi_amd/synth.py), Knlm, top-1, typo transformer (kiwi_amd.workloads.TYPO_RULES, continual cost 1, threshold 2.5)"
     with open(corpus_path, encoding="utf-8") as f:
         texts = f.read().split("\n")
     assert len(texts) == n, (len(texts), n)

@@ -222,9 +222,16 @@ extern "C"
 	}
 
 	// CPU baseline ("port" kind): batch over `threads` workers; returns wall seconds
+	double korc_analyze_batch_typo(void* hp, void* typoHp, float typoThreshold, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut);
 	double korc_analyze_batch(void* hp, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut)
 	{
+		return korc_analyze_batch_typo(hp, nullptr, 2.5f, texts, offsets, n, topN, match, threads, tokensOut);
+	}
+	double korc_analyze_batch_typo(void* hp, void* typoHp, float typoThreshold, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut)
+	{
 		auto& h = *(OracleHandle*)hp;
+		TypoOpt typo;
+		if (typoHp) { typo.prepared = ((TypoHandle*)typoHp)->prepared.get(); typo.threshold = typoThreshold; }
 		std::atomic<uint32_t> next{ 0 };
 		std::atomic<uint64_t> tokens{ 0 };
 		std::vector<Counters> cnts(std::max(threads, 1));
@@ -235,7 +242,7 @@ extern "C"
 			{
 				const uint32_t i = next.fetch_add(1);
 				if (i >= n) break;
-				auto res = analyzeOne(h, cnts[tid], nullptr, (const char16_t*)texts + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), topN, match, false);
+				auto res = analyzeOne(h, cnts[tid], nullptr, (const char16_t*)texts + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), topN, match, false, nullptr, typo);
 				local += res[0].first.size();
 			}
 			tokens += local;

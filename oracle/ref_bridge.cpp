@@ -465,7 +465,12 @@ extern "C"
 	// CPU baseline: the reference analysing a batch with `threads` worker threads, like
 	// Kiwi::analyze(topN, reader, receiver) does with its pool (include/kiwi/Kiwi.h:402-454).
 	// texts are concatenated UTF-16 with offsets[n+1]. Returns wall seconds; *tokensOut = total top-1 tokens.
+	double kref_analyze_batch_typo(void* hp, void* typoHp, float typoThreshold, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut);
 	double kref_analyze_batch(void* hp, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut)
+	{
+		return kref_analyze_batch_typo(hp, nullptr, 2.5f, texts, offsets, n, topN, match, threads, tokensOut);
+	}
+	double kref_analyze_batch_typo(void* hp, void* typoHp, float typoThreshold, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut)
 	{
 		auto& kw = ((RefHandle*)hp)->kw;
 		std::atomic<uint32_t> next{ 0 };
@@ -473,6 +478,7 @@ extern "C"
 		auto work = [&]()
 		{
 			kiwi::AnalyzeOption opt{ (kiwi::Match)match };
+			if (typoHp) { opt.typoTransformer = ((TypoHandle*)typoHp)->ptt.get(); opt.typoThreshold = typoThreshold; }
 			uint64_t local = 0;
 			for (;;)
 			{

@@ -163,13 +163,16 @@ class RefKiwi:
     def dump_dict(self) -> bytes:
         return bytes(self._call(lambda *a: self.lib.kref_dump_dict(self.h, *a)))
 
-    def analyze_batch(self, texts: list, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, threads=1):
+    def analyze_batch(self, texts: list, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, threads=1, typo=None, typo_threshold=2.5):
+        """typo: a prepared OracleTypo / RefTypo -> the batch is analysed with it."""
         enc = [np.frombuffer(t.encode("utf-16-le", errors="surrogatepass"), np.uint16) for t in texts]
         offs = np.zeros(len(enc) + 1, np.uint64)
         offs[1:] = np.cumsum([len(e) for e in enc])
         flat = np.concatenate(enc) if enc else np.zeros(0, np.uint16)
         ntok = C.c_uint64(0)
-        sec = self.lib.kref_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(enc), top_n, match, threads, C.byref(ntok))
+        self.lib.kref_analyze_batch_typo.restype = C.c_double
+        self.lib.kref_analyze_batch_typo.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+        sec = self.lib.kref_analyze_batch_typo(self.h, typo.h if typo is not None else None, typo_threshold, flat.ctypes.data, offs.ctypes.data, len(enc), top_n, match, threads, C.byref(ntok))
         return float(sec), int(ntok.value)
 
 

@@ -36,3 +36,4 @@ timeout 600 python -m pytest tests/test_gpu_sbg.py -m gpu -x -q > $OUT/pytest_gp
 timeout 900 python bench.py --workload c3-sbg --steps 3 --warmup 1 > $OUT/bench_c3_sbg.json 2> $OUT/bench_c3_sbg.err; cut -c1-600 $OUT/bench_c3_sbg.json
 # 4. typo correction on the device (same status as the SkipBigram kernel: identical to the oracle under lane emulation, first time on hardware)
 KAMD_EXPERIMENTAL_TYPO=1 timeout 600 python -m pytest tests/test_gpu_typo.py -m gpu -x -q > $OUT/pytest_gpu_typo.txt 2>&1; tail -3 $OUT/pytest_gpu_typo.txt
+KAMD_EXPERIMENTAL_TYPO=1 timeout 600 python bench.py --workload c5 --steps 5 --warmup 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; cut -c1-600 $OUT/bench_c5.json
