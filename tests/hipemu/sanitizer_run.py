@@ -42,8 +42,8 @@ if kind == "typo":
     dev.close(); prod.close()
     print("sanitizer run complete:", kind, len(texts), "texts")
     sys.exit(0)
-n = 8 if kind == "sbg" else 14
-texts = synthetic(sm, n, 601, min_jamo=5, max_jamo=50 if kind == "sbg" else 80) + dictionary_mix(sm, n // 2, 602) + (EDGE_TEXTS if kind != "sbg" else [])
+n = 8 if kind == "sbg" else 9
+texts = synthetic(sm, n, 601, min_jamo=5, max_jamo=50 if kind == "sbg" else 60) + dictionary_mix(sm, n // 2, 602) + (EDGE_TEXTS if kind != "sbg" else [])
 for top_n in (1, 2):
     res = dev.analyze_batch(texts, top_n=top_n).to_python()
     assert len(res) == len(texts)
