@@ -68,9 +68,8 @@ int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32
 /* developer probe, HOST side, no device: one SkipBigram LM step (reference SbgState::nextImpl, src/SkipBigramModel.hpp:169-182) on top of
  * the Knlm log-likelihood `knlm_ll`, by the code the search kernel shares (csrc/sbg_eval.hpp); hist8 / pos are updated in place */
 int kamd_debug_sbg_next(const char* raw_model_path, uint32_t* hist8, uint32_t* pos, uint32_t wid, float knlm_ll, float* ll_out);
-/* Typo transformers, host side only so far (csrc/typo.hpp): rule container (reference TypoTransformer::addTypo / update / scaleCost), preparation
- * (TypoTransformer::prepare) and the typo graph of a text (PreparedTypoTransformer::generateGraph).  The analyze calls do NOT take a
- * transformer yet -- the kernels that build a lattice over such a graph are a later round; kamd_typo_graph dumps the graph for tests:
+/* Typo transformers (csrc/typo.hpp): rule container (reference TypoTransformer::addTypo / update / scaleCost), preparation
+ * (TypoTransformer::prepare) and the typo graph of a text (PreparedTypoTransformer::generateGraph).  kamd_analyze_batch_typo / kamd_stage_typo analyse with a prepared one; kamd_typo_graph dumps the graph for tests:
  * {u32 normLen, u16[]; u32 nNodes; per node: u32 formLen, u16[], u32 endPos, f32 typoCost, u32 prevOffset, u32 siblingOffset, u8 continualTypoIdx, u16 dialect}; u32 maxContinualTypoIdx.
  * left_cond: CondVowel value (0 none, 1 any, 2 vowel, 8 applosive, 9 continual, 10 boundary); dialect: Dialect bit mask. */
 typedef struct kamd_typo* kamd_typo_h;
@@ -82,8 +81,7 @@ int kamd_typo_set_costs(kamd_typo_h t, float continual_cost, float lengthening_c
 int kamd_typo_scale(kamd_typo_h t, float scale);
 int kamd_typo_prepare(kamd_typo_h t, int inverse);
 size_t kamd_typo_graph(kamd_typo_h t, const uint16_t* text, uint32_t len, int allowed_dialect, int normalize_coda, uint8_t* out, size_t cap);
-/* EXPERIMENTAL (needs KAMD_EXPERIMENTAL_TYPO=1 in the environment; identical to the CPU oracle under lane emulation, not yet run on a GPU):
- * kamd_analyze_batch with a prepared typo transformer -- AnalyzeOption::typoTransformer / typoThreshold / allowedDialects of the reference.
+/* kamd_analyze_batch with a prepared typo transformer -- AnalyzeOption::typoTransformer / typoThreshold / allowedDialects of the reference.
  * SkipBigram models are refused. */
 kamd_results_h kamd_analyze_batch_typo(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts,
                                        uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);

@@ -8,7 +8,7 @@
  *   - kiwi_init's model_path names a raw-model container (or a directory holding `kiwi_amd.raw`);
  *     on-disk sj.morph / sj.knlm loaders are a "next" row.
  *   - top_n > 4, blocklist, pretokenized spans and non-standard dialects are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
- *     being silently ignored; a typo transformer is accepted only with KAMD_EXPERIMENTAL_TYPO=1 (experimental device path).
+ *     being silently ignored.
  */
 #ifndef KIWI_CAPI_SUBSET_H
 #define KIWI_CAPI_SUBSET_H
@@ -95,9 +95,8 @@ float kiwi_res_score(kiwi_res_h result, int index, int num);                    
 float kiwi_res_typo_cost(kiwi_res_h result, int index, int num);                                 /* capi.h:927 */
 int kiwi_res_close(kiwi_res_h result);                                                           /* capi.h:937 */
 const char* kiwi_get_script_name(uint8_t script);                                                /* capi.h:1417 */
-/* typo transformers.  Building and preparing one is complete; ANALYSING with one (option.typo_transformer) is experimental on the device and needs
- * KAMD_EXPERIMENTAL_TYPO=1 in the environment, otherwise kiwi_analyze* return NULL / KIWIERR_FAIL with a message.  kiwi_typo_get_default / _get_basic
- * return NULL: the built-in sets are rule tables of the reference and are not shipped. */
+/* typo transformers (rule container, preparation, option.typo_transformer / typo_threshold of kiwi_analyze*): parity-checked on the MI355X against the
+ * oracle and the real reference (tests/test_gpu_typo.py, tests/test_gpu_capi.py). */
 kiwi_typo_h kiwi_typo_init(void);                                                                /* capi.h:469 */
 kiwi_typo_h kiwi_typo_get_basic(void);                                                           /* capi.h:480 */
 kiwi_typo_h kiwi_typo_get_default(int kiwi_typo_set);                                            /* capi.h:501 */

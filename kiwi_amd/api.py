@@ -195,7 +195,7 @@ class KiwiAmd:
         return self.analyze_batch([text], top_n, match, open_ending, 1).to_python()[0]
 
     def stage(self, texts, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0, typo=None, typo_threshold=2.5) -> Batch:
-        """typo: a prepared `Typo` (experimental device path, KAMD_EXPERIMENTAL_TYPO=1); it must outlive the batch."""
+        """typo: a prepared `Typo` (kamd_stage_typo); it must outlive the batch."""
         flat, offs = pack_texts(texts)
         if typo is None:
             b = self.lib.kamd_stage(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), match, int(open_ending), host_threads)

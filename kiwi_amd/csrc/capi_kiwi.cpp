@@ -99,7 +99,7 @@ namespace
 		if ((uint32_t)o.match_options & (1u << 30)) throw std::invalid_argument{ "kiwi_amd: useOldSplitter is not supported" };
 	}
 
-	// AnalyzeOption::typoTransformer / typoThreshold (the engine gates the experimental path behind KAMD_EXPERIMENTAL_TYPO)
+	// AnalyzeOption::typoTransformer / typoThreshold
 	TypoOption typoOf(const kiwi_analyze_option_t& o);
 
 	kiwi_res* makeRes(std::vector<TokenResult>&& r)
@@ -164,7 +164,7 @@ namespace
 
 extern "C"
 {
-	// ---- typo transformers (capi.h:459-588; src/capi/kiwi_c.cpp:540-715).  The analysis with one is EXPERIMENTAL on the device.
+	// ---- typo transformers (capi.h:459-588; src/capi/kiwi_c.cpp:540-715).
 	kiwi_typo_h kiwi_typo_init() { try { return new kiwi_typo; } catch (const std::exception& e) { setError(e); return nullptr; } }
 	kiwi_typo_h kiwi_typo_get_basic() { return kiwi_typo_get_default(1); }
 	kiwi_typo_h kiwi_typo_get_default(int)

@@ -116,7 +116,7 @@ namespace kamd
 		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags, dTextOff;
 		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
 		DevBuf dHist;   // SkipBigram models: history ring of every search state (8 x u32), parallel to dStates
-		// typo correction (EXPERIMENTAL, KAMD_EXPERIMENTAL_TYPO): the transformer the batch is analysed with, the typo graph of every chunk and the
+		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
 		TypoOption typo;
 		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo;
@@ -163,11 +163,6 @@ namespace kamd
 	Engine::Engine(const std::string& path, int device) : impl(new Impl)
 	{
 		bakeModel(impl->model, path);
-		// SkipBigram scoring on the device (viterbi_kernel_sbg.hip) is written but has not been through the GPU parity suite yet:
-		// it has to be asked for, so that nobody gets unchecked analyses from a model that merely happens to carry the tables
-		if (!impl->model.sbgPtrs.empty() && !std::getenv("KAMD_EXPERIMENTAL_SBG"))
-			throw std::runtime_error{ "kiwi_amd: this raw model carries SkipBigram tables; SkipBigram scoring on the device is experimental "
-				"(not parity-checked on a GPU yet) and only enabled with KAMD_EXPERIMENTAL_SBG=1 -- Knlm models are the supported ones" };
 		if (!impl->model.sbgPtrs.empty() && impl->model.sbgWindow != 8)
 			throw std::runtime_error{ "kiwi_amd: SkipBigram window size must be 8 (the reference instantiates SbgState<8> only, src/SkipBigramModel.cpp)" };
 		int nDev = 0;
@@ -730,8 +725,6 @@ namespace kamd
 	{
 		if (typo.typo)
 		{
-			// typo correction on the device is written and identical to the oracle under lane emulation, but has not run on a GPU yet
-			if (!std::getenv("KAMD_EXPERIMENTAL_TYPO")) throw std::runtime_error{ "kiwi_amd: typo correction on the device is experimental (not parity-checked on a GPU yet) and only enabled with KAMD_EXPERIMENTAL_TYPO=1" };
 			if (impl->hasSbg) throw std::runtime_error{ "kiwi_amd: typo correction with a SkipBigram model is not built" };
 			if (impl->model.forms.size() >= (1u << 24)) throw std::runtime_error{ "kiwi_amd: typo correction supports up to 2^24 forms" };
 		}

@@ -5,7 +5,7 @@
 //
 // STATUS: first, unoptimised form -- one THREAD per chunk over HBM arrays (the shape of k_build_lattice_big).  Two outputs: the dump records of
 // the parity hook (Engine::dumpTypoLattices / kamd_typo_lattices), or, in engine mode, the search kernel's DevNode records plus a typo cost
-// per node (experimental analyze path, KAMD_EXPERIMENTAL_TYPO).  The typo graph itself comes from
+// per node.  The typo graph itself comes from
 // the host (typo.cpp).  Its parity has so far been checked in the CPU test suite only -- it has not run on a GPU.
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"

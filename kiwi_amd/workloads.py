@@ -15,11 +15,11 @@ WORKLOADS = {
     # name: (spec name, n sentences, corpus kwargs, seed offset)  -- seeds follow BASELINE.md ("KIWI" + config index)
     "c2": ("full", 8192, dict(exact_jamo=40), 2),
     "c3": ("full", 65536, dict(min_jamo=5, max_jamo=200), 3),
-    # BASELINE config 3 proper: SkipBigram model, top-3 (device kernel experimental: needs KAMD_EXPERIMENTAL_SBG=1)
+    # BASELINE config 3 proper: SkipBigram model, top-3
     "c3-sbg": ("full-sbg", 65536, dict(min_jamo=5, max_jamo=200), 3),
     "small-c2": ("small", 8192, dict(exact_jamo=40), 2),
     # BASELINE config 5: the c2 corpus misspelt (confusable vowels, carried-over codas), analysed with a typo transformer (TYPO_RULES, continual cost 1,
-    # typoCostWeight 6, threshold 2.5); device path experimental: needs KAMD_EXPERIMENTAL_TYPO=1
+    # typoCostWeight 6, threshold 2.5)
     "c5": ("full", 8192, dict(exact_jamo=40), 2),
     # c2 at the batch size the north-star throughput target is quoted on (>= 64k sentences): the throughput regime
     "c2-64k": ("full", 65536, dict(exact_jamo=40), 12),

@@ -274,7 +274,6 @@ def test_c_client_program(oracle, small_model, tmp_path):
     assert got == want
 
 
-@pytest.mark.skipif(not os.environ.get("KAMD_EXPERIMENTAL_TYPO"), reason="typo correction on the device is experimental: set KAMD_EXPERIMENTAL_TYPO=1")
 def test_typo_transformer_through_the_c_api(capi, kiwi, small_model):
     """kiwi_typo_init / _add / _copy / _update / _scale_cost / _set_*_cost / _prepare and kiwi_analyze with option.typo_transformer, as a client of the
     reference would call them (capi.h:459-588, 662-698), against the oracle with the same rules: tokens, scores, kiwi_res_typo_cost."""

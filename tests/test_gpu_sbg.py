@@ -1,10 +1,7 @@
 """GPU (-m gpu): the search kernel for SkipBigram models (kiwi_amd/csrc/viterbi_kernel_sbg.hip) against the CPU oracle, whose
 SkipBigram path is pinned to the real reference by tests/test_oracle_vs_ref.py.
 
-The device SkipBigram path is EXPERIMENTAL: it was written after the round's GPU budget was spent and has not run on a GPU
-yet.  The engine therefore refuses SkipBigram models unless KAMD_EXPERIMENTAL_SBG=1 is set, and the parity tests below are
-skipped without it -- `KAMD_EXPERIMENTAL_SBG=1 python -m pytest tests/test_gpu_sbg.py -m gpu` is the first thing to run on
-a GPU box.  Only the refusal itself is tested unconditionally."""
+First run on an MI355X in round 2 (profiles/r02_a_*): all green at first contact; the experimental gate is gone."""
 import os
 from dataclasses import astuple
 
@@ -14,25 +11,16 @@ from corpora import EDGE_TEXTS, dictionary_mix, synthetic
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-enabled = pytest.mark.skipif(not os.environ.get("KAMD_EXPERIMENTAL_SBG"), reason="device SkipBigram scoring is experimental: set KAMD_EXPERIMENTAL_SBG=1")
 
 
 def _norm(res):
     return [([astuple(t) for t in a[0]], a[1]) for a in res]
 
 
-def test_skipbigram_model_is_refused_without_the_flag(small_sbg_model, monkeypatch):
-    from kiwi_amd.api import KiwiAmd
-    monkeypatch.delenv("KAMD_EXPERIMENTAL_SBG", raising=False)
-    with pytest.raises(RuntimeError, match="SkipBigram"):
-        KiwiAmd(small_sbg_model[1])
-
-
 def _texts(sm, seed):
     return synthetic(sm, 300, seed, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 150, seed + 1) + EDGE_TEXTS
 
 
-@enabled
 @pytest.mark.parametrize("lanes", ["16", "64"])
 @pytest.mark.parametrize("top_n", [1, 2, 3])
 def test_skipbigram_tokens_bit_exact_vs_oracle(small_sbg_model, monkeypatch, lanes, top_n):
@@ -51,7 +39,6 @@ def test_skipbigram_tokens_bit_exact_vs_oracle(small_sbg_model, monkeypatch, lan
     dev.close()
 
 
-@enabled
 @pytest.mark.parametrize("lanes", ["16", "64"])
 def test_skipbigram_fallback_paths_with_small_capacities(small_sbg_model, monkeypatch, lanes):
     """The `make smallcaps` build: LDS capacities of 4, container limits 3 / 8 / 2 on both sides (medium container: the bucket
@@ -76,7 +63,6 @@ def test_skipbigram_fallback_paths_with_small_capacities(small_sbg_model, monkey
     dev.close()
 
 
-@enabled
 def test_skipbigram_golden_sequence_from_reference(small_sbg_model):
     """The committed analyses of the real reference under the SkipBigram model (tests/golden/small_sbg_model_sequence.json, top-1):
     where the reference's large container decided the order of equal-score paths the device may differ (top-N /

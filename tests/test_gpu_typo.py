@@ -1,9 +1,7 @@
 """GPU (-m gpu): typo correction on the device (kiwi_amd/csrc/typo.cpp on the host, typo_lattice_kernel.hip, viterbi_kernel_typo.hip) against
 the CPU oracle, whose typo path is pinned to the real reference by tests/test_typo_oracle.py.
 
-EXPERIMENTAL, like the SkipBigram kernel: written after the round's GPU budget was spent, identical to the oracle under lane emulation
-(tests/test_hipemu.py), never run on hardware.  The engine refuses typo transformers unless KAMD_EXPERIMENTAL_TYPO=1, and the parity
-tests below are skipped without it; `KAMD_EXPERIMENTAL_TYPO=1 python -m pytest tests/test_gpu_typo.py -m gpu` is what to run on a GPU box."""
+First run on an MI355X in round 2 (profiles/r02_a_*): all green at first contact; the experimental gate is gone."""
 import os
 import random
 
@@ -15,20 +13,8 @@ from test_hipemu import _analyze_typo, _norm, _typo_lattices, _typo_pair
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip.so")
-enabled = pytest.mark.skipif(not os.environ.get("KAMD_EXPERIMENTAL_TYPO"), reason="typo correction on the device is experimental: set KAMD_EXPERIMENTAL_TYPO=1")
 
 
-def test_typo_transformer_is_refused_without_the_flag(small_model, monkeypatch):
-    from kiwi_amd.api import KiwiAmd
-    monkeypatch.delenv("KAMD_EXPERIMENTAL_TYPO", raising=False)
-    prod, _ = _typo_pair(LIB, 1.0)
-    dev = KiwiAmd(small_model[1])
-    with pytest.raises(RuntimeError, match="experimental"):
-        _analyze_typo(dev, prod, ["가나다"], 2.5)
-    dev.close(); prod.close()
-
-
-@enabled
 @pytest.mark.parametrize("continual,threshold,top_n,lanes,lengthening", [(float("inf"), 2.5, 1, "16", float("inf")), (1.0, 2.5, 1, "16", float("inf")), (1.0, 1.2, 3, "16", float("inf")),
                                                                          (1.0, 2.5, 2, "64", float("inf")), (1.0, 2.5, 1, "16", 0.25)])
 def test_typo_analyses_bit_exact_vs_oracle(small_model, monkeypatch, continual, threshold, top_n, lanes, lengthening):
@@ -50,7 +36,6 @@ def test_typo_analyses_bit_exact_vs_oracle(small_model, monkeypatch, continual, 
     dev.close(); prod.close()
 
 
-@enabled
 def test_typo_analyses_through_the_capacity_ladder(small_model, monkeypatch):
     import oraclelib
     from kiwi_amd.api import KiwiAmd

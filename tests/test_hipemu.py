@@ -318,8 +318,7 @@ def _typo_pair(lib, continual, lengthening=float("inf")):
 def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch, continual, threshold, top_n, lanes, tiny, lengthening):
     """The whole typo-correcting analysis on the (emulated) device -- typo graphs from the host module, k_build_lattice_typo, the search kernel
     compiled with node typo costs (viterbi_kernel_typo.hip), end stage, host post-processing -- against the oracle (pinned to the real
-    reference): tokens, positions, fp32 scores, per-token typo costs; continual and lengthening typos; also through the capacity ladder.  Gated on the device
-    (KAMD_EXPERIMENTAL_TYPO) until it has run on a GPU."""
+    reference): tokens, positions, fp32 scores, per-token typo costs; continual and lengthening typos; also through the capacity ladder."""
     import random
     import oraclelib
     from kiwi_amd.api import KiwiAmd
@@ -343,12 +342,3 @@ def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch,
     assert corrected >= 5
     dev.close(); prod.close()
 
-
-def test_typo_analysis_is_refused_without_the_flag(emu_libs, small_model, monkeypatch):
-    from kiwi_amd.api import KiwiAmd
-    monkeypatch.delenv("KAMD_EXPERIMENTAL_TYPO", raising=False)
-    prod, _ = _typo_pair(emu_libs[0], 1.0)
-    dev = KiwiAmd(small_model[1], lib_path=emu_libs[0])
-    with pytest.raises(RuntimeError, match="experimental"):
-        _analyze_typo(dev, prod, ["가나다"], 2.5)
-    dev.close(); prod.close()
