@@ -29,7 +29,7 @@ typedef struct
 	uint32_t typo_form_id, paired_token, sub_sent_position;
 	uint16_t dialect; uint16_t form_len;
 	int32_t morph_id;
-	uint64_t form_off;   /* offset of the UTF-16 form in kamd_res_forms() */
+	uint64_t form_off;   /* offset of the NUL-terminated UTF-16 form in kamd_res_forms(r, text) */
 } kamd_token_t;
 
 /* returns NULL on failure; kamd_last_error() (thread local) tells why.  device < 0: current/first device */
@@ -59,7 +59,10 @@ uint32_t kamd_res_size(kamd_results_h r, uint32_t text);                       /
 float kamd_res_prob(kamd_results_h r, uint32_t text, uint32_t index);
 uint32_t kamd_res_token_num(kamd_results_h r, uint32_t text, uint32_t index);
 const kamd_token_t* kamd_res_tokens(kamd_results_h r, uint32_t text, uint32_t index);
-const uint16_t* kamd_res_forms(kamd_results_h r);
+/* form pool the tokens of `text` index with form_off (results are stored in flat segments of consecutive texts; each has its own pool) */
+const uint16_t* kamd_res_forms(kamd_results_h r, uint32_t text);
+/* bytes the device -> host copy of this batch moved (chunk summaries + the path headers and token records actually produced) */
+uint64_t kamd_res_d2h_bytes(kamd_results_h r);
 void kamd_res_close(kamd_results_h r);
 
 /* test hooks: baked dictionary dump and the lattices of one text, in the byte layouts of oracle/ref_bridge.cpp */

@@ -78,7 +78,9 @@ def load_library(lib_path=None):
     L.kamd_res_tokens.restype = C.c_void_p
     L.kamd_res_tokens.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.kamd_res_forms.restype = C.c_void_p
-    L.kamd_res_forms.argtypes = [C.c_void_p]
+    L.kamd_res_forms.argtypes = [C.c_void_p, C.c_uint32]
+    L.kamd_res_d2h_bytes.restype = C.c_uint64
+    L.kamd_res_d2h_bytes.argtypes = [C.c_void_p]
     L.kamd_res_close.argtypes = [C.c_void_p]
     L.kamd_dump_dict.restype = C.c_size_t
     L.kamd_dump_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -128,8 +130,8 @@ class Results:
     def to_python(self):
         """[(tokens, score)] per analysis, per text -- same shape as refbridge.parse_results."""
         out = []
-        forms_p = self.lib.kamd_res_forms(self.h)
         for t in range(self.n_texts()):
+            forms_p = self.lib.kamd_res_forms(self.h, t)
             res = []
             for i in range(self.lib.kamd_res_size(self.h, t)):
                 arr = self.token_array(t, i)

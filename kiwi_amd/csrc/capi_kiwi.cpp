@@ -1,6 +1,7 @@
 // Kiwi-compatible C API (include/kiwi_capi.h) on top of kamd::Engine: the drop-in boundary for
 // Kiwi::analyze.  Conventions follow /root/reference/src/capi/kiwi_c.cpp: handles are heap objects owned by the
 // caller, nothing throws across the boundary, failures are recorded in a thread-local slot read by kiwi_error().
+#include <cstddef>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -23,14 +24,23 @@ struct kiwi_s
 struct kiwi_typo { kamd::TypoTransformer tt; };                       // capi.h:35
 struct kiwi_prepared_typo { kamd::PreparedTypo p; };                  // capi.h:38
 
+// One text's analyses, flat (its slice of a batch's ResultSegment): token records whose first 44 bytes are kiwi_token_info_t -- the
+// reference hands out a pointer into its TokenInfo the same way (kiwi_c.cpp:1097) -- and one pool of NUL-terminated UTF-16 forms.
+// UTF-8 forms and UTF-16 tag names are materialised on first request, as the reference's ResultBuffer does (kiwi_c.cpp:20-23).
 struct kiwi_res
 {
-	std::vector<TokenResult> res;
-	// the C struct is layout-compatible with the tail of the reference's TokenInfo (kiwi_c.cpp:1097); here it is materialised
-	std::vector<std::vector<kiwi_token_info_t>> info;
-	std::map<std::pair<int, int>, std::string> formBuf, tagBuf;
+	std::vector<uint32_t> anaTok{ 0 };
+	std::vector<float> scores;
+	std::vector<FlatToken> toks;
+	std::vector<char16_t> forms;
+	std::map<std::pair<int, int>, std::string> formBuf;
 	std::map<std::pair<int, int>, std::u16string> tagBufW;
+	size_t size() const { return scores.size(); }
+	size_t tokens(int index) const { return anaTok[index + 1] - anaTok[index]; }
+	const FlatToken& tok(int index, int num) const { return toks[anaTok[index] + num]; }
 };
+static_assert(offsetof(FlatToken, dialect) == offsetof(kiwi_token_info_t, dialect) && offsetof(FlatToken, score) == offsetof(kiwi_token_info_t, score)
+	&& offsetof(FlatToken, subSentPosition) == offsetof(kiwi_token_info_t, sub_sent_position) && offsetof(FlatToken, tag) == offsetof(kiwi_token_info_t, tag), "FlatToken starts with kiwi_token_info_t");
 
 namespace
 {
@@ -102,20 +112,23 @@ namespace
 	// AnalyzeOption::typoTransformer / typoThreshold
 	TypoOption typoOf(const kiwi_analyze_option_t& o);
 
-	kiwi_res* makeRes(std::vector<TokenResult>&& r)
+	kiwi_res* makeRes(const BatchResults& br, size_t text)
 	{
 		auto res = std::make_unique<kiwi_res>();
-		res->res = std::move(r);
-		res->info.resize(res->res.size());
-		for (size_t i = 0; i < res->res.size(); ++i)
+		size_t local;
+		const ResultSegment& seg = br.locate(text, local);
+		const uint32_t a0 = seg.textAna[local], a1 = seg.textAna[local + 1];
+		if (a1 > a0)
 		{
-			for (auto& t : res->res[i].first)
+			const uint32_t t0 = seg.anaTok[a0], t1 = seg.anaTok[a1];
+			res->scores.assign(seg.anaScore.begin() + a0, seg.anaScore.begin() + a1);
+			for (uint32_t a = a0; a < a1; ++a) res->anaTok.push_back(seg.anaTok[a + 1] - t0);
+			res->toks.assign(seg.toks.begin() + t0, seg.toks.begin() + t1);
+			if (t1 > t0)
 			{
-				kiwi_token_info_t o{};
-				o.chr_position = t.position; o.word_position = t.wordPosition; o.sent_position = t.sentPosition; o.line_number = t.lineNumber;
-				o.length = t.length; o.tag = t.tag; o.sense_id = t.senseId; o.score = t.score; o.typo_cost = t.typoCost; o.typo_form_id = t.typoFormId;
-				o.paired_token = t.pairedToken; o.sub_sent_position = t.subSentPosition; o.dialect = t.dialect;
-				res->info[i].push_back(o);
+				const uint64_t f0 = seg.toks[t0].formOff, f1 = seg.toks[t1 - 1].formOff + seg.toks[t1 - 1].formLen + 1;
+				res->forms.assign(seg.forms.begin() + f0, seg.forms.begin() + f1);
+				for (auto& t : res->toks) t.formOff -= f0;
 			}
 		}
 		return res.release();
@@ -141,14 +154,14 @@ namespace
 			std::vector<std::pair<const char16_t*, size_t>> views;
 			for (auto& t : texts) views.emplace_back(t.data(), t.size());
 			auto res = h->engine->analyzeBatch(views, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt));
-			for (auto& r : res) (*receiver)(receiverIdx++, makeRes(std::move(r)), ud);   // in input order; the receiver owns the result
+			for (size_t i = 0; i < texts.size(); ++i) (*receiver)(receiverIdx++, makeRes(res, i), ud);   // in input order; the receiver owns the result
 		}
 		return readerIdx;
 	}
 
 	bool validIdx(kiwi_res_h r, int index, int num)
 	{
-		return index >= 0 && (size_t)index < r->res.size() && num >= 0 && (size_t)num < r->res[index].first.size();
+		return index >= 0 && (size_t)index < r->size() && num >= 0 && (size_t)num < r->tokens(index);
 	}
 }
 
@@ -282,7 +295,7 @@ extern "C"
 			size_t n = 0; while (text[n]) ++n;
 			std::vector<std::pair<const char16_t*, size_t>> v{ { (const char16_t*)text, n } };
 			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
-			return makeRes(std::move(res[0]));
+			return makeRes(res, 0);
 		}
 		catch (const std::exception& e) { setError(e); return nullptr; }
 	}
@@ -296,7 +309,7 @@ extern "C"
 			const std::u16string u = utf8To16(text, std::strlen(text));
 			std::vector<std::pair<const char16_t*, size_t>> v{ { u.data(), u.size() } };
 			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
-			return makeRes(std::move(res[0]));
+			return makeRes(res, 0);
 		}
 		catch (const std::exception& e) { setError(e); return nullptr; }
 	}
@@ -338,43 +351,43 @@ extern "C"
 	const char* kiwi_tag_to_string(kiwi_h, uint8_t tag) { return tagToString(tag); }
 	const char* kiwi_get_script_name(uint8_t script) { return scriptName(script); }
 
-	int kiwi_res_size(kiwi_res_h r) { return r ? (int)r->res.size() : KIWIERR_INVALID_HANDLE; }
-	float kiwi_res_prob(kiwi_res_h r, int index) { return (r && index >= 0 && (size_t)index < r->res.size()) ? r->res[index].second : 0.f; }
+	int kiwi_res_size(kiwi_res_h r) { return r ? (int)r->size() : KIWIERR_INVALID_HANDLE; }
+	float kiwi_res_prob(kiwi_res_h r, int index) { return (r && index >= 0 && (size_t)index < r->size()) ? r->scores[index] : 0.f; }
 	int kiwi_res_word_num(kiwi_res_h r, int index)
 	{
 		if (!r) return KIWIERR_INVALID_HANDLE;
-		if (index < 0 || (size_t)index >= r->res.size()) return KIWIERR_INVALID_INDEX;
-		return (int)r->res[index].first.size();
+		if (index < 0 || (size_t)index >= r->size()) return KIWIERR_INVALID_INDEX;
+		return (int)r->tokens(index);
 	}
-	const kiwi_token_info_t* kiwi_res_token_info(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? &r->info[index][num] : nullptr; }
+	const kiwi_token_info_t* kiwi_res_token_info(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? reinterpret_cast<const kiwi_token_info_t*>(&r->tok(index, num)) : nullptr; }
 	int kiwi_res_morpheme_id(kiwi_res_h r, int index, int num, kiwi_h h)
 	{
 		if (!r || !h) return KIWIERR_INVALID_HANDLE;
 		if (!validIdx(r, index, num)) return KIWIERR_INVALID_INDEX;
-		return r->res[index].first[num].morph;
+		return r->tok(index, num).morph;
 	}
-	const kchar16_t* kiwi_res_form_w(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? (const kchar16_t*)r->res[index].first[num].str.c_str() : nullptr; }
+	const kchar16_t* kiwi_res_form_w(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? (const kchar16_t*)(r->forms.data() + r->tok(index, num).formOff) : nullptr; }
 	const kchar16_t* kiwi_res_tag_w(kiwi_res_h r, int index, int num)
 	{
 		if (!r || !validIdx(r, index, num)) return nullptr;
 		auto& s = r->tagBufW[{ index, num }];
-		if (s.empty()) for (const char* p = tagToString(r->res[index].first[num].tag); *p; ++p) s.push_back((char16_t)*p);
+		if (s.empty()) for (const char* p = tagToString(r->tok(index, num).tag); *p; ++p) s.push_back((char16_t)*p);
 		return (const kchar16_t*)s.c_str();
 	}
 	const char* kiwi_res_form(kiwi_res_h r, int index, int num)
 	{
 		if (!r || !validIdx(r, index, num)) return nullptr;
 		auto it = r->formBuf.find({ index, num });
-		if (it == r->formBuf.end()) it = r->formBuf.emplace(std::make_pair(index, num), utf16To8(r->res[index].first[num].str)).first;
+		if (it == r->formBuf.end()) it = r->formBuf.emplace(std::make_pair(index, num), utf16To8(std::u16string{ r->forms.data() + r->tok(index, num).formOff, r->tok(index, num).formLen })).first;
 		return it->second.c_str();
 	}
-	const char* kiwi_res_tag(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? tagToString(r->res[index].first[num].tag) : nullptr; }
-	int kiwi_res_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->res[index].first[num].position; }
-	int kiwi_res_length(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->res[index].first[num].length; }
-	int kiwi_res_word_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->res[index].first[num].wordPosition; }
-	int kiwi_res_sent_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->res[index].first[num].sentPosition; }
-	float kiwi_res_score(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? r->res[index].first[num].score : 0.f; }
-	float kiwi_res_typo_cost(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? r->res[index].first[num].typoCost : 0.f; }
+	const char* kiwi_res_tag(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? tagToString(r->tok(index, num).tag) : nullptr; }
+	int kiwi_res_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->tok(index, num).position; }
+	int kiwi_res_length(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->tok(index, num).length; }
+	int kiwi_res_word_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->tok(index, num).wordPosition; }
+	int kiwi_res_sent_position(kiwi_res_h r, int index, int num) { return !r ? KIWIERR_INVALID_HANDLE : !validIdx(r, index, num) ? KIWIERR_INVALID_INDEX : (int)r->tok(index, num).sentPosition; }
+	float kiwi_res_score(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? r->tok(index, num).score : 0.f; }
+	float kiwi_res_typo_cost(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? r->tok(index, num).typoCost : 0.f; }
 	int kiwi_res_close(kiwi_res_h r)
 	{
 		if (!r) return KIWIERR_INVALID_HANDLE;

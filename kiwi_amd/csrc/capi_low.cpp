@@ -1,6 +1,7 @@
 // Low-level C ABI (include/kiwi_amd.h) over kamd::Engine.  Error convention mirrors the reference's C API:
 // nothing throws across the boundary; failures return NULL / negative and leave a thread-local message
 // (/root/reference/src/capi/kiwi_c.cpp:84, 95-114).
+#include <cstddef>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -14,12 +15,9 @@ using namespace kamd;
 
 struct kamd_engine { std::unique_ptr<Engine> e; };
 struct kamd_batch { std::shared_ptr<StagedBatch> b; };
-struct kamd_results
-{
-	std::vector<std::vector<std::vector<kamd_token_t>>> toks;   // [text][analysis][token]
-	std::vector<std::vector<float>> scores;
-	std::vector<uint16_t> forms;
-};
+struct kamd_results { BatchResults r; };   // flat segments; the accessors below index into them
+static_assert(sizeof(kamd_token_t) == sizeof(FlatToken) && offsetof(kamd_token_t, form_off) == offsetof(FlatToken, formOff) && offsetof(kamd_token_t, morph_id) == offsetof(FlatToken, morph),
+	"kamd_token_t is the layout of kamd::FlatToken");
 
 namespace kamd { void exactMathProbe(const float* x, float* e, float* l, uint32_t n); }
 
@@ -41,29 +39,17 @@ namespace
 		return v;
 	}
 
-	kamd_results* pack(std::vector<std::vector<TokenResult>>&& res)
+	kamd_results* pack(BatchResults&& res) { return new kamd_results{ std::move(res) }; }
+
+	// analysis `i` of text `t`: segment + global analysis index, or null
+	const ResultSegment* ana(kamd_results_h r, uint32_t t, uint32_t i, uint32_t& a)
 	{
-		auto r = std::make_unique<kamd_results>();
-		r->toks.resize(res.size()); r->scores.resize(res.size());
-		for (size_t t = 0; t < res.size(); ++t)
-		{
-			for (auto& a : res[t])
-			{
-				r->scores[t].push_back(a.second);
-				r->toks[t].emplace_back();
-				for (auto& tk : a.first)
-				{
-					kamd_token_t o{};
-					o.position = tk.position; o.word_position = tk.wordPosition; o.sent_position = tk.sentPosition; o.line_number = tk.lineNumber;
-					o.length = tk.length; o.tag = tk.tag; o.sense_or_script = tk.senseId; o.score = tk.score; o.typo_cost = tk.typoCost;
-					o.typo_form_id = tk.typoFormId; o.paired_token = tk.pairedToken; o.sub_sent_position = tk.subSentPosition; o.dialect = tk.dialect;
-					o.morph_id = tk.morph; o.form_len = (uint16_t)tk.str.size(); o.form_off = r->forms.size();
-					r->forms.insert(r->forms.end(), tk.str.begin(), tk.str.end());
-					r->toks[t].back().push_back(o);
-				}
-			}
-		}
-		return r.release();
+		if (!r || t >= r->r.nTexts) return nullptr;
+		size_t local;
+		const ResultSegment& seg = r->r.locate(t, local);
+		if (i >= seg.textAna[local + 1] - seg.textAna[local]) return nullptr;
+		a = seg.textAna[local] + i;
+		return &seg;
 	}
 }
 
@@ -114,12 +100,27 @@ extern "C"
 	}
 	void kamd_batch_close(kamd_batch_h b) { delete b; }
 
-	uint32_t kamd_res_texts(kamd_results_h r) { return r ? (uint32_t)r->toks.size() : 0; }
-	uint32_t kamd_res_size(kamd_results_h r, uint32_t t) { return (r && t < r->toks.size()) ? (uint32_t)r->toks[t].size() : 0; }
-	float kamd_res_prob(kamd_results_h r, uint32_t t, uint32_t i) { return (r && t < r->scores.size() && i < r->scores[t].size()) ? r->scores[t][i] : 0.f; }
-	uint32_t kamd_res_token_num(kamd_results_h r, uint32_t t, uint32_t i) { return (r && t < r->toks.size() && i < r->toks[t].size()) ? (uint32_t)r->toks[t][i].size() : 0; }
-	const kamd_token_t* kamd_res_tokens(kamd_results_h r, uint32_t t, uint32_t i) { return (r && t < r->toks.size() && i < r->toks[t].size()) ? r->toks[t][i].data() : nullptr; }
-	const uint16_t* kamd_res_forms(kamd_results_h r) { return r ? r->forms.data() : nullptr; }
+	uint32_t kamd_res_texts(kamd_results_h r) { return r ? (uint32_t)r->r.nTexts : 0; }
+	uint32_t kamd_res_size(kamd_results_h r, uint32_t t)
+	{
+		if (!r || t >= r->r.nTexts) return 0;
+		size_t local; const ResultSegment& seg = r->r.locate(t, local);
+		return seg.textAna[local + 1] - seg.textAna[local];
+	}
+	float kamd_res_prob(kamd_results_h r, uint32_t t, uint32_t i) { uint32_t a; const ResultSegment* s = ana(r, t, i, a); return s ? s->anaScore[a] : 0.f; }
+	uint32_t kamd_res_token_num(kamd_results_h r, uint32_t t, uint32_t i) { uint32_t a; const ResultSegment* s = ana(r, t, i, a); return s ? s->anaTok[a + 1] - s->anaTok[a] : 0; }
+	const kamd_token_t* kamd_res_tokens(kamd_results_h r, uint32_t t, uint32_t i)
+	{
+		uint32_t a; const ResultSegment* s = ana(r, t, i, a);
+		return (s && s->anaTok[a + 1] > s->anaTok[a]) ? reinterpret_cast<const kamd_token_t*>(s->toks.data() + s->anaTok[a]) : nullptr;
+	}
+	const uint16_t* kamd_res_forms(kamd_results_h r, uint32_t t)
+	{
+		if (!r || t >= r->r.nTexts) return nullptr;
+		size_t local; const ResultSegment& seg = r->r.locate(t, local);
+		return reinterpret_cast<const uint16_t*>(seg.forms.data());
+	}
+	uint64_t kamd_res_d2h_bytes(kamd_results_h r) { return r ? r->r.d2hBytes : 0; }
 	void kamd_res_close(kamd_results_h r) { delete r; }
 
 	int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n)

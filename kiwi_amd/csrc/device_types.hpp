@@ -69,11 +69,14 @@ namespace kamd
 	};
 	static_assert(sizeof(DevToken) == 24, "DevToken");
 
-	constexpr uint32_t kMaxPathsPerChunk = 16;
-	struct DevPathHeader { float score; uint32_t tokOff; uint16_t nTokens; uint8_t prevState, curState; };
+	// The end stage writes what the host needs -- path headers and token records -- COMPACTLY into two batch-wide output arrays
+	// (WorkView::outPaths / outTokens, ranges handed out by wave-aggregated atomics on WorkView::outCounters), so that the D2H copy is
+	// sum(tokens) x 24 B instead of the token arenas at capacity, and a chunk may return any number of paths.
+	struct DevPathHeader { float score; uint32_t tokOff; uint16_t nTokens; uint8_t prevState, curState; };   // tokOff: relative to the chunk's first output token
 	// nEnd/endOff: end-node candidates of the chunk, left by k_best_path in the unused tail of the chunk's state arena
-	// (entry index endOff, 24-byte records) for k_finish_paths
-	struct DevChunkResult { uint32_t nPaths; uint32_t status; DevPathHeader paths[kMaxPathsPerChunk]; uint32_t nEnd, endOff; };
+	// (entry index endOff, 24-byte records) for k_finish_paths; pathOff/tokOff: the chunk's ranges in the output arrays
+	struct DevChunkResult { uint32_t nPaths, status, nEnd, endOff, pathOff, tokOff, nTok, pad; };
+	static_assert(sizeof(DevChunkResult) == 32, "DevChunkResult");
 
 	enum ChunkStatus : uint32_t
 	{
@@ -91,7 +94,7 @@ namespace kamd
 		uint32_t smallMax, mediumMax, bucketCap;   // container selection by incoming paths (128, 512) and per-bucket key cap (128): BestPathContainer.hpp:275-277
 		uint32_t topN;                 // paths kept per (candidate, key): 1..kMaxTopN (BestPathContainer.hpp:151-222 for N > 1)
 	};
-	constexpr uint32_t kMaxTopN = 4;      // the end stage hands on ceil(2N / groups) <= kMaxPathsPerChunk paths
+	constexpr uint32_t kMaxTopN = 4;
 
 	struct BatchView
 	{
@@ -139,6 +142,10 @@ namespace kamd
 		const uint64_t* tokenBase;     // [nChunks+1]
 		DevToken* tokens;
 		DevChunkResult* results;       // [c]
+		DevPathHeader* outPaths;       // compact output of the end stage: path headers of all chunks ...
+		DevToken* outTokens;           // ... and their token records (D2H copies exactly what was produced)
+		uint32_t* outCounters;         // [0] path headers handed out, [1] token records handed out
+		uint32_t outPathCap, outTokCap;
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
 		uint32_t bigScratchBytes;      // per wave
 		uint32_t* beacon;              // developer aid (KAMD_TIMELINE builds): per-chunk timeline records, else null

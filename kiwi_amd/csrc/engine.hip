@@ -15,6 +15,7 @@
 #include <stdexcept>
 #include <thread>
 #include "engine.hpp"
+#include "hostpool.hpp"
 #include "viterbi_kernel.hpp"
 #include "exact_math.hpp"
 #include "typo_lattice_kernel.hpp"
@@ -38,55 +39,79 @@ namespace kamd
 		// for 8192 sentences), and hipMalloc/hipFree of those per batch cost more than the kernels.  Bounded, per process.
 		struct DevBlockCache
 		{
-			std::mutex mu; std::vector<std::pair<void*, size_t>> blocks; size_t bytes = 0;
+			struct Block { void* p; size_t cap; int device; };      // device -1: pinned host memory
+			std::mutex mu; std::vector<Block> blocks; size_t bytes = 0;
 			static constexpr size_t kMaxBlocks = 256, kMaxBytes = 64ull << 30;
-			void* take(size_t n, size_t& capOut)
+			static void release(const Block& b) { if (b.device < 0) (void)hipHostFree(b.p); else (void)hipFree(b.p); }   // (hipFree takes a pointer of any device)
+			void* take(size_t n, size_t& capOut, int device)
 			{
 				std::lock_guard<std::mutex> g{ mu };
 				size_t best = blocks.size();
 				for (size_t i = 0; i < blocks.size(); ++i)
-					if (blocks[i].second >= n && blocks[i].second <= 2 * n + (1u << 20) && (best == blocks.size() || blocks[i].second < blocks[best].second)) best = i;
+					if (blocks[i].device == device && blocks[i].cap >= n && blocks[i].cap <= 2 * n + (1u << 20) && (best == blocks.size() || blocks[i].cap < blocks[best].cap)) best = i;
 				if (best == blocks.size()) return nullptr;
-				void* p = blocks[best].first; capOut = blocks[best].second; bytes -= capOut;
+				void* p = blocks[best].p; capOut = blocks[best].cap; bytes -= capOut;
 				blocks.erase(blocks.begin() + best);
 				return p;
 			}
-			void give(void* p, size_t cap)
+			void give(void* p, size_t cap, int device)
 			{
 				{
 					std::lock_guard<std::mutex> g{ mu };
-					if (blocks.size() < kMaxBlocks && bytes + cap <= kMaxBytes) { blocks.emplace_back(p, cap); bytes += cap; return; }
+					if (blocks.size() < kMaxBlocks && bytes + cap <= kMaxBytes) { blocks.push_back(Block{ p, cap, device }); bytes += cap; return; }
 				}
-				(void)hipFree(p);
+				release(Block{ p, cap, device });
 			}
 			void trim()
 			{
 				std::lock_guard<std::mutex> g{ mu };
-				for (auto& b : blocks) (void)hipFree(b.first);
+				for (auto& b : blocks) release(b);
 				blocks.clear(); bytes = 0;
 			}
 		};
 		DevBlockCache& devCache() { static DevBlockCache c; return c; }
+		int currentDevice() { int d = 0; (void)hipGetDevice(&d); return d; }
 
 		struct DevBuf
 		{
-			void* p = nullptr; size_t cap = 0;
+			void* p = nullptr; size_t cap = 0; int device = 0;
 			DevBuf() = default;
 			DevBuf(const DevBuf&) = delete;
 			DevBuf& operator=(const DevBuf&) = delete;
-			~DevBuf() { if (p) devCache().give(p, cap); }
+			~DevBuf() { release(); }
+			void release() { if (p) devCache().give(p, cap, device); p = nullptr; cap = 0; }
 			void ensure(size_t n)
 			{
 				if (n <= cap) return;
-				if (p) devCache().give(p, cap);
-				p = nullptr; cap = 0;
+				release();
+				device = currentDevice();      // (the engine binds its device to the calling thread before any allocation)
 				const size_t want = n + n / 8 + 256;
-				p = devCache().take(want, cap);
+				p = devCache().take(want, cap, device);
 				if (!p) { HIPCHECK(hipMalloc(&p, want)); cap = want; }
 				// developer aid: KAMD_POISON=1 fills every (re)acquired block with 0xCD, so that a read of memory no kernel has written
 				// yet shows up the same way on every run (fresh and recycled blocks otherwise hold arbitrary bytes)
 				static const bool poison = std::getenv("KAMD_POISON") != nullptr;
 				if (poison) { HIPCHECK(hipMemset(p, 0xCD, cap)); HIPCHECK(hipDeviceSynchronize()); }   // (the engine's streams do not wait for the null stream)
+			}
+			template<class T> T* as() const { return reinterpret_cast<T*>(p); }
+		};
+
+		// pinned host staging memory (H2D of a batch's inputs, D2H of its compact outputs), recycled like the device blocks
+		struct PinBuf
+		{
+			void* p = nullptr; size_t cap = 0;
+			PinBuf() = default;
+			PinBuf(const PinBuf&) = delete;
+			PinBuf& operator=(const PinBuf&) = delete;
+			~PinBuf() { if (p) devCache().give(p, cap, -1); }
+			void ensure(size_t n)
+			{
+				if (n <= cap) return;
+				if (p) devCache().give(p, cap, -1);
+				p = nullptr; cap = 0;
+				const size_t want = n + n / 4 + 4096;
+				p = devCache().take(want, cap, -1);
+				if (!p) { HIPCHECK(hipHostMalloc(&p, want, 0)); cap = want; }
 			}
 			template<class T> T* as() const { return reinterpret_cast<T*>(p); }
 		};
@@ -103,8 +128,9 @@ namespace kamd
 
 	struct StagedBatch
 	{
-		std::vector<U16> raw;
+		U16 rawFlat; std::vector<uint64_t> rawOff;   // the raw texts (result assembly reads them: word positions, line breaks)
 		std::vector<PreparedText> prep;
+		int hostThreads = 0;
 		std::vector<ChunkRef> refs;
 		uint64_t match = 0;
 		uint32_t capScale = 1;
@@ -113,18 +139,20 @@ namespace kamd
 		std::vector<uint32_t> charOff, patOff, spOff, matchBase, nodeBase, packBase;
 		std::vector<uint64_t> stateBase, tokenBase;
 		// device
-		DevBuf dChars, dCls, dScript, dCharOff, dPatOff, dPatterns, dSpOff, dSp, dFlags, dTextOff;
-		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchBase, dMatchForm, dNodeBase, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
+		PinBuf hIn; DevBuf dIn;   // the batch's input block (layoutAndUpload)
+		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchForm, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
 		DevBuf dHist;   // SkipBigram models: history ring of every search state (8 x u32), parallel to dStates
 		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
 		TypoOption typo;
 		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo;
 		TypoLatView tv{};
-		DevBuf dPackBase, dPacks, dStateBase, dStates, dNodeStOff, dNodeStCnt, dReach, dTokenBase, dTokens, dResults, dOrder;
+		DevBuf dPacks, dStates, dNodeStOff, dNodeStCnt, dReach, dTokens, dResults, dOrder;
+		DevBuf dOutPaths, dOutTokens, dOutCounters; uint32_t outPathCap = 0, outTokCap = 0;   // compact outputs of the end stage
+		PinBuf hOut, hOut2;       // D2H landing zones: counters + chunk results; then the path headers and token records that were produced
+		uint64_t outBytes = 0;    // bytes the last download copied
 		BatchView bv{}; WorkView wv{};
-		std::vector<DevChunkResult> hResults;
-		std::vector<DevToken> hTokens;
+		const DevChunkResult* hResults = nullptr; const DevPathHeader* hPaths = nullptr; const DevToken* hTokens = nullptr;   // inside hOut
 		bool ran = false;
 		uint32_t subBatches = 0;
 		uint32_t topN = 1;            // the search of the last run() kept this many paths per key
@@ -227,6 +255,9 @@ namespace kamd
 			(void)hipSetDevice(impl->device);
 			(void)hipDeviceSynchronize();
 			for (auto& e : impl->evs) if (e) (void)hipEventDestroy(e);
+			// the engine's own blocks go back to the cache first, then the cache is emptied: nothing stays allocated after the last engine
+			impl->modelBufs.clear();
+			impl->bigScratch.release(); impl->counter.release(); impl->sbgScratch.release();
 			devCache().trim();
 			if (impl->stream) (void)hipStreamDestroy(impl->stream);
 			if (impl->stream2) (void)hipStreamDestroy(impl->stream2);
@@ -244,41 +275,15 @@ namespace kamd
 			explicit HostTimer(const char* w) : what(w) {}
 			void lap(const char* name) { if (!on) return; const auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[host] %s: %s %.2f ms\n", what, name, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
 		};
-		void parallelFor(size_t n, int threads, const std::function<void(size_t)>& fn)
-		{
-			if (threads <= 0) threads = (int)std::min(48u, std::max(1u, std::thread::hardware_concurrency()));   // spawned per call: keep the spawn cost small
-			threads = (int)std::min<size_t>(threads, std::max<size_t>(1, n / 64));
-			if (threads <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-			std::atomic<size_t> next{ 0 };
-			std::exception_ptr err; std::atomic<bool> failed{ false };
-			auto work = [&]()
-			{
-				try
-				{
-					for (;;)
-					{
-						const size_t i = next.fetch_add(64);
-						if (i >= n || failed) break;
-						for (size_t k = i; k < std::min(n, i + 64); ++k) fn(k);
-					}
-				}
-				catch (...) { if (!failed.exchange(true)) err = std::current_exception(); }
-			};
-			std::vector<std::thread> ts;
-			for (int t = 0; t < threads; ++t) ts.emplace_back(work);
-			for (auto& t : ts) t.join();
-			if (err) std::rethrow_exception(err);
-		}
 	}
 
-	// Lays a set of chunks out in HBM.
+	// Lays a set of chunks out in HBM.  Everything the kernels read about the batch -- text, character classes, scripts, patterns, special
+	// states, flags and the region offsets -- is assembled in ONE pinned host block and uploaded with ONE copy.
 	static void layoutAndUpload(Engine::Impl& I, StagedBatch& b, const SearchParams&)
 	{
 		const size_t nC = b.refs.size();
 		b.charOff.assign(nC + 1, 0); b.patOff.assign(nC + 1, 0); b.spOff.assign(nC + 1, 0);
 		b.matchBase.assign(nC + 1, 0); b.nodeBase.assign(nC + 1, 0); b.packBase.assign(nC + 1, 0); b.stateBase.assign(nC + 1, 0); b.tokenBase.assign(nC + 1, 0);
-		std::vector<uint8_t> flags(nC), sp;
-		std::vector<uint32_t> textOff(nC);
 		const uint64_t sc = b.capScale;
 		const bool tinyArenas = std::getenv("KAMD_TEST_TINY_ARENAS") != nullptr;
 		for (size_t c = 0; c < nC; ++c)
@@ -302,30 +307,45 @@ namespace kamd
 			b.packBase[c + 1] = b.packBase[c] + (uint32_t)(3 * ncap);
 			b.stateBase[c + 1] = b.stateBase[c] + scap;
 			b.tokenBase[c + 1] = b.tokenBase[c] + tcap;
-			flags[c] = r.openEnding ? 1 : 0;
-			textOff[c] = d.startOffset;
-			sp.insert(sp.end(), r.sp.begin(), r.sp.end());
 		}
 		const size_t totChars = b.charOff[nC];
-		std::vector<uint16_t> chars(totChars); std::vector<uint8_t> cls(totChars), script(totChars);
-		std::vector<DevPattern> pats(b.patOff[nC]);
-		b.units = 0;
-		for (size_t c = 0; c < nC; ++c)
+		// the input block: sections at 256-byte boundaries, same layout on the host (pinned) and on the device
+		size_t top = 0;
+		auto take = [&](size_t bytes) { const size_t at = top; top = (top + std::max<size_t>(bytes, 16) + 255) & ~(size_t)255; return at; };
+		const size_t oChars = take(2 * totChars), oCls = take(totChars), oScript = take(totChars);
+		const size_t oCharOff = take(4 * (nC + 1)), oPatOff = take(4 * (nC + 1)), oPats = take(sizeof(DevPattern) * (size_t)b.patOff[nC]);
+		const size_t oSpOff = take(4 * (nC + 1)), oSp = take(b.spOff[nC]), oFlags = take(nC), oTextOff = take(4 * nC);
+		const size_t oMatchBase = take(4 * (nC + 1)), oNodeBase = take(4 * (nC + 1)), oPackBase = take(4 * (nC + 1)), oStateBase = take(8 * (nC + 1)), oTokenBase = take(8 * (nC + 1));
+		b.hIn.ensure(top); b.dIn.ensure(top);
+		uint8_t* H = b.hIn.as<uint8_t>();
+		std::memcpy(H + oCharOff, b.charOff.data(), 4 * (nC + 1)); std::memcpy(H + oPatOff, b.patOff.data(), 4 * (nC + 1)); std::memcpy(H + oSpOff, b.spOff.data(), 4 * (nC + 1));
+		std::memcpy(H + oMatchBase, b.matchBase.data(), 4 * (nC + 1)); std::memcpy(H + oNodeBase, b.nodeBase.data(), 4 * (nC + 1)); std::memcpy(H + oPackBase, b.packBase.data(), 4 * (nC + 1));
+		std::memcpy(H + oStateBase, b.stateBase.data(), 8 * (nC + 1)); std::memcpy(H + oTokenBase, b.tokenBase.data(), 8 * (nC + 1));
+		std::atomic<uint64_t> units{ 0 };
+		HostPool::instance().run(nC, 512, b.hostThreads, [&](size_t c0, size_t c1, int)
 		{
-			const auto& r = b.refs[c];
-			const PreparedText& pt = b.prep[r.text];
-			const ChunkDesc& d = pt.chunks[r.chunk];
-			std::memcpy(chars.data() + b.charOff[c], pt.norm.data() + d.startOffset, 2 * (size_t)d.nChars);
-			std::memcpy(cls.data() + b.charOff[c], pt.cls.data() + d.startOffset, d.nChars);
-			std::memcpy(script.data() + b.charOff[c], pt.script.data() + d.startOffset, d.nChars);
-			for (uint32_t k = d.patBegin; k < d.patEnd; ++k) pats[b.patOff[c] + (k - d.patBegin)] = DevPattern{ pt.patterns[k].end, pt.patterns[k].length, pt.patterns[k].tag };
-			for (uint32_t k = 0; k < d.nChars; ++k) if (!isSpace(pt.norm[d.startOffset + k])) ++b.units;
-		}
+			uint64_t u = 0;
+			for (size_t c = c0; c < c1; ++c)
+			{
+				const auto& r = b.refs[c];
+				const PreparedText& pt = b.prep[r.text];
+				const ChunkDesc& d = pt.chunks[r.chunk];
+				std::memcpy(H + oChars + 2 * (size_t)b.charOff[c], pt.norm.data() + d.startOffset, 2 * (size_t)d.nChars);
+				std::memcpy(H + oCls + b.charOff[c], pt.cls.data() + d.startOffset, d.nChars);
+				std::memcpy(H + oScript + b.charOff[c], pt.script.data() + d.startOffset, d.nChars);
+				DevPattern* pats = reinterpret_cast<DevPattern*>(H + oPats) + b.patOff[c];
+				for (uint32_t k = d.patBegin; k < d.patEnd; ++k) pats[k - d.patBegin] = DevPattern{ pt.patterns[k].end, pt.patterns[k].length, pt.patterns[k].tag };
+				for (uint32_t k = 0; k < d.nChars; ++k) if (!isSpace(pt.norm[d.startOffset + k])) ++u;
+				if (!r.sp.empty()) std::memcpy(H + oSp + b.spOff[c], r.sp.data(), r.sp.size());
+				H[oFlags + c] = r.openEnding ? 1 : 0;
+				reinterpret_cast<uint32_t*>(H + oTextOff)[c] = d.startOffset;
+			}
+			units += u;
+		});
+		b.units = units;
 		hipStream_t s = I.stream;
-		upload(b.dChars, chars, s); upload(b.dCls, cls, s); upload(b.dScript, script, s);
-		upload(b.dCharOff, b.charOff, s); upload(b.dPatOff, b.patOff, s); upload(b.dPatterns, pats, s);
-		upload(b.dSpOff, b.spOff, s); upload(b.dSp, sp, s); upload(b.dFlags, flags, s); upload(b.dTextOff, textOff, s);
-		upload(b.dMatchBase, b.matchBase, s); upload(b.dNodeBase, b.nodeBase, s); upload(b.dPackBase, b.packBase, s); upload(b.dStateBase, b.stateBase, s); upload(b.dTokenBase, b.tokenBase, s);
+		if (top) HIPCHECK(hipMemcpyAsync(b.dIn.p, H, top, hipMemcpyHostToDevice, s));
+		uint8_t* D = b.dIn.as<uint8_t>();
 		const size_t perChar = totChars + nC + 16;
 		const size_t totNodes = b.nodeBase[nC], totMatch = b.matchBase[nC];
 		const uint64_t totStates = b.stateBase[nC], totTokens = b.tokenBase[nC];
@@ -337,24 +357,29 @@ namespace kamd
 		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
 		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
 		if (I.hasSbg) b.dHist.ensure(totStates * 32 + 32);
+		// compact outputs of the end stage: as many token records as the arenas could hold, 16 path headers per chunk (x capacity scale)
+		b.outTokCap = (uint32_t)std::min<uint64_t>(totTokens, 0xFFFFFFF0ull); b.outPathCap = (uint32_t)std::min<uint64_t>((uint64_t)nC * 16 * sc, 0xFFFFFFF0ull);
+		b.dOutTokens.ensure((size_t)b.outTokCap * sizeof(DevToken) + 16); b.dOutPaths.ensure((size_t)b.outPathCap * sizeof(DevPathHeader) + 16); b.dOutCounters.ensure(64);
 		b.devBytes = 0;
-		for (const DevBuf* d : { &b.dChars, &b.dCls, &b.dScript, &b.dNsToPos, &b.dPosToNs, &b.dCflag, &b.dMask, &b.dMoff, &b.dMatchForm, &b.dNodes, &b.dTmpNodes, &b.dEndPosMap, &b.dTmpIdx,
+		for (const DevBuf* d : { &b.dIn, &b.dOutTokens, &b.dOutPaths, &b.dNsToPos, &b.dPosToNs, &b.dCflag, &b.dMask, &b.dMoff, &b.dMatchForm, &b.dNodes, &b.dTmpNodes, &b.dEndPosMap, &b.dTmpIdx,
 			&b.dPacks, &b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults }) b.devBytes += d->cap;
 
 		BatchView& bv = b.bv;
-		bv.nChunks = (uint32_t)nC; bv.chars = b.dChars.as<uint16_t>(); bv.cls = b.dCls.as<uint8_t>(); bv.script = b.dScript.as<uint8_t>();
-		bv.charOff = b.dCharOff.as<uint32_t>(); bv.patOff = b.dPatOff.as<uint32_t>(); bv.patterns = b.dPatterns.as<DevPattern>();
-		bv.spOff = b.dSpOff.as<uint32_t>(); bv.spStates = b.dSp.as<uint8_t>(); bv.chunkFlags = b.dFlags.as<uint8_t>(); bv.textOffset = b.dTextOff.as<uint32_t>();
+		bv.nChunks = (uint32_t)nC; bv.chars = (const uint16_t*)(D + oChars); bv.cls = D + oCls; bv.script = D + oScript;
+		bv.charOff = (const uint32_t*)(D + oCharOff); bv.patOff = (const uint32_t*)(D + oPatOff); bv.patterns = (const DevPattern*)(D + oPats);
+		bv.spOff = (const uint32_t*)(D + oSpOff); bv.spStates = D + oSp; bv.chunkFlags = D + oFlags; bv.textOffset = (const uint32_t*)(D + oTextOff);
 		WorkView& w = b.wv;
 		w.nsToPos = b.dNsToPos.as<uint16_t>(); w.posToNs = b.dPosToNs.as<uint16_t>(); w.cflag = b.dCflag.as<uint8_t>();
 		w.matchMask = b.dMask.as<uint64_t>(); w.matchOff = b.dMoff.as<uint32_t>(); w.nNs = b.dNNs.as<uint32_t>();
-		w.matchBase = b.dMatchBase.as<uint32_t>(); w.matchForm = b.dMatchForm.as<uint32_t>();
-		w.nodeBase = b.dNodeBase.as<uint32_t>(); w.nodes = b.dNodes.as<DevNode>(); w.tmpNodes = b.dTmpNodes.as<DevNode>();
+		w.matchBase = (const uint32_t*)(D + oMatchBase); w.matchForm = b.dMatchForm.as<uint32_t>();
+		w.nodeBase = (const uint32_t*)(D + oNodeBase); w.nodes = b.dNodes.as<DevNode>(); w.tmpNodes = b.dTmpNodes.as<DevNode>();
 		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.fullMask = b.dFullMask.as<uint64_t>(); w.zAt = b.dZAt.as<uint8_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>();
-		w.packBase = b.dPackBase.as<uint32_t>(); w.packs = b.dPacks.as<CandStatic>();
-		w.stateBase = b.dStateBase.as<uint64_t>(); w.states = b.dStates.as<DevState>();
+		w.packBase = (const uint32_t*)(D + oPackBase); w.packs = b.dPacks.as<CandStatic>();
+		w.stateBase = (const uint64_t*)(D + oStateBase); w.states = b.dStates.as<DevState>();
 		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();
-		w.tokenBase = b.dTokenBase.as<uint64_t>(); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
+		w.tokenBase = (const uint64_t*)(D + oTokenBase); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
+		w.outTokens = b.dOutTokens.as<DevToken>(); w.outPaths = b.dOutPaths.as<DevPathHeader>(); w.outCounters = b.dOutCounters.as<uint32_t>();
+		w.outTokCap = b.outTokCap; w.outPathCap = b.outPathCap;
 		w.bigScratch = nullptr; w.bigScratchBytes = 0;   // bound at launch
 		b.subBatches = 0;
 		if (b.typo.typo)
@@ -412,6 +437,7 @@ namespace kamd
 			v.nodes = b.dTypoTmp.as<TypoLatNode>(); v.nodesFinal = nullptr; v.endPosMap = b.dTypoMap.as<uint2>(); v.nsToPos = b.dTypoNs.as<uint16_t>(); v.posToNs = b.dTypoPs.as<uint16_t>();
 			v.states = b.dTypoStates.as<TypoState>(); v.stateIdx = b.dTypoSIdx.as<uint32_t>(); v.scratch = b.dTypoScratch.as<uint32_t>();
 			v.devNodes = w.nodes; v.nodeTypo = b.dNodeTypo.as<float>(); v.nNodes = w.nNodes; v.results = w.results;
+			HIPCHECK(hipStreamSynchronize(s));      // the host vectors above are the sources of asynchronous copies: they must outlive them
 		}
 		HIPCHECK(hipStreamSynchronize(s));
 		b.ran = false;
@@ -484,6 +510,7 @@ namespace kamd
 		const size_t nEv = 6 * (size_t)S + 2;
 		while (I.evs.size() < nEv) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); I.evs.push_back(e); }
 		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), sA));
+		HIPCHECK(hipMemsetAsync(b.dOutCounters.p, 0, 64, sA));
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
 		HIPCHECK(hipMemsetAsync(b.dNNodes.p, 0, (size_t)nC * 4, sA));   // also clears the lattice kernels' hand-over flag
 		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
@@ -685,15 +712,30 @@ namespace kamd
 		return t;
 	}
 
+	// D2H of what the end stage produced: 32 B per chunk and the two counters first, then exactly the path headers and token
+	// records that were written (pinned landing zone; the token arenas at capacity stay on the device).
 	static void download(Engine::Impl& I, StagedBatch& b)
 	{
 		const size_t nC = b.refs.size();
-		b.hResults.resize(nC);
-		b.hTokens.resize(b.tokenBase[nC]);
+		b.hResults = nullptr; b.hPaths = nullptr; b.hTokens = nullptr;
 		if (!nC) return;
-		HIPCHECK(hipMemcpyAsync(b.hResults.data(), b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost, I.stream));
-		HIPCHECK(hipMemcpyAsync(b.hTokens.data(), b.dTokens.p, b.hTokens.size() * sizeof(DevToken), hipMemcpyDeviceToHost, I.stream));
+		const size_t oRes = 64, resBytes = (nC * sizeof(DevChunkResult) + 255) & ~(size_t)255;
+		b.hOut.ensure(oRes + resBytes);
+		uint8_t* H = b.hOut.as<uint8_t>();
+		HIPCHECK(hipMemcpyAsync(H, b.dOutCounters.p, 8, hipMemcpyDeviceToHost, I.stream));
+		HIPCHECK(hipMemcpyAsync(H + oRes, b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost, I.stream));
 		HIPCHECK(hipStreamSynchronize(I.stream));
+		const uint32_t nPaths = std::min(reinterpret_cast<const uint32_t*>(H)[0], b.outPathCap), nTok = std::min(reinterpret_cast<const uint32_t*>(H)[1], b.outTokCap);
+		const size_t oTok = ((size_t)nPaths * sizeof(DevPathHeader) + 255) & ~(size_t)255;
+		b.hOut2.ensure(oTok + (size_t)nTok * sizeof(DevToken) + 16);
+		uint8_t* H2 = b.hOut2.as<uint8_t>();
+		if (nPaths) HIPCHECK(hipMemcpyAsync(H2, b.dOutPaths.p, (size_t)nPaths * sizeof(DevPathHeader), hipMemcpyDeviceToHost, I.stream));
+		if (nTok) HIPCHECK(hipMemcpyAsync(H2 + oTok, b.dOutTokens.p, (size_t)nTok * sizeof(DevToken), hipMemcpyDeviceToHost, I.stream));
+		HIPCHECK(hipStreamSynchronize(I.stream));
+		b.hResults = reinterpret_cast<const DevChunkResult*>(H + oRes);
+		b.hPaths = reinterpret_cast<const DevPathHeader*>(H2);
+		b.hTokens = reinterpret_cast<const DevToken*>(H2 + oTok);
+		b.outBytes = 8 + nC * sizeof(DevChunkResult) + (size_t)nPaths * sizeof(DevPathHeader) + (size_t)nTok * sizeof(DevToken);
 	}
 
 	static void chunkPaths(std::vector<PathResult>& out, const FlatModel& m, const StagedBatch& b, size_t c)
@@ -706,9 +748,10 @@ namespace kamd
 		for (uint32_t p = 0; p < r.nPaths; ++p)
 		{
 			PathResult pr;
-			pr.score = r.paths[p].score; pr.prevState = r.paths[p].prevState; pr.curState = r.paths[p].curState;
-			const DevToken* tk = b.hTokens.data() + b.tokenBase[c] + r.paths[p].tokOff;
-			for (uint32_t k = 0; k < r.paths[p].nTokens; ++k)
+			const DevPathHeader& ph = b.hPaths[r.pathOff + p];
+			pr.score = ph.score; pr.prevState = ph.prevState; pr.curState = ph.curState;
+			const DevToken* tk = b.hTokens + r.tokOff + ph.tokOff;
+			for (uint32_t k = 0; k < ph.nTokens; ++k)
 			{
 				PathTok t;
 				t.morph = tk[k].morph; t.begin = tk[k].begin + so; t.end = tk[k].end + so; t.wordScore = tk[k].wordScore; t.typoCost = tk[k].typoCost;
@@ -731,11 +774,17 @@ namespace kamd
 		HostTimer tm{ "stage" };
 		auto b = std::make_shared<StagedBatch>();
 		b->match = match;
-		b->raw.resize(texts.size()); b->prep.resize(texts.size());
-		parallelFor(texts.size(), hostThreads, [&](size_t i)
+		b->hostThreads = hostThreads;
+		b->prep.resize(texts.size()); b->rawOff.assign(texts.size() + 1, 0);
+		for (size_t i = 0; i < texts.size(); ++i) b->rawOff[i + 1] = b->rawOff[i] + texts[i].second;
+		b->rawFlat.resize(b->rawOff.back());
+		HostPool::instance().run(texts.size(), 64, hostThreads, [&](size_t i0, size_t i1, int)
 		{
-			b->raw[i].assign(texts[i].first, texts[i].second);
-			prepareText(b->prep[i], texts[i].first, texts[i].second, match, (uint32_t)i);
+			for (size_t i = i0; i < i1; ++i)
+			{
+				if (texts[i].second) std::memcpy(&b->rawFlat[b->rawOff[i]], texts[i].first, 2 * texts[i].second);
+				prepareText(b->prep[i], texts[i].first, texts[i].second, match, (uint32_t)i);
+			}
 		});
 		for (size_t i = 0; i < texts.size(); ++i)
 		{
@@ -749,6 +798,7 @@ namespace kamd
 		}
 		tm.lap("text preparation");
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		HIPCHECK(hipSetDevice(impl->device));      // the device is bound per thread: callers come from any thread
 		b->typo = typo;
 		layoutAndUpload(*impl, *b, makeParams(config, match));
 		tm.lap("layout + device buffers + upload");
@@ -758,6 +808,7 @@ namespace kamd
 	KernelTimes Engine::run(StagedBatch& b)
 	{
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		HIPCHECK(hipSetDevice(impl->device));
 		return launchAll(*impl, b, makeParams(config, b.match, b.topN));
 	}
 	size_t Engine::stagedChunks(const StagedBatch& b) { return b.refs.size(); }
@@ -769,7 +820,7 @@ namespace kamd
 		std::vector<std::vector<PathResult>>& out)
 	{
 		StagedBatch b;
-		b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo;
+		b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo; b.hostThreads = 1;
 		b.prep.swap(parent.prep);   // borrow
 		b.refs = std::move(refs);
 		try
@@ -797,27 +848,31 @@ namespace kamd
 		b.prep.swap(parent.prep);
 	}
 
-	std::vector<std::vector<TokenResult>> Engine::fetch(StagedBatch& b, size_t topN)
+	BatchResults Engine::fetch(StagedBatch& b, size_t topN)
 	{
 		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		HIPCHECK(hipSetDevice(impl->device));
 		if (!b.ran || b.topN != (uint32_t)topN) { b.topN = (uint32_t)topN; run(b); }
 		HostTimer tm{ "fetch" };
 		download(*impl, b);
 		tm.lap("download");
 		const size_t nT = b.prep.size();
-		std::vector<std::vector<TokenResult>> ret(nT);
+		BatchResults ret;
+		ret.nTexts = nT; ret.d2hBytes = b.outBytes;
+		ret.segs.resize((nT + BatchResults::kSegTexts - 1) / BatchResults::kSegTexts);
 		// chunk index of each text inside refs
 		std::vector<size_t> firstRef(nT + 1, 0);
 		for (auto& r : b.refs) firstRef[r.text + 1]++;
 		for (size_t i = 0; i < nT; ++i) firstRef[i + 1] += firstRef[i];
-		// texts are independent: post-process them on host threads; a text whose chunk must be searched again (other start
-		// states than the speculative {0}, or a scratch overflow) needs the device and is finished afterwards, one by one
-		auto doText = [&](size_t i, bool mayRerun) -> bool
+		// texts are independent: post-process them on the host workers, one segment of consecutive texts per task; a text whose chunk
+		// must be searched again (other start states than the speculative {0}, or a scratch overflow) needs the device and is finished
+		// afterwards, one by one
+		auto doText = [&](size_t i, bool mayRerun, ResultSegment& seg, std::vector<PathResult>& paths) -> bool
 		{
-			std::vector<PathResult> paths;
+			const char16_t* raw = b.rawFlat.data() + b.rawOff[i]; const size_t rawLen = (size_t)(b.rawOff[i + 1] - b.rawOff[i]);
 			ResultBuilder rb{ impl->model, topN, b.match, config.integrateAllomorph };
-			rb.begin(b.raw[i].data(), b.raw[i].size(), b.prep[i].position);
+			rb.begin(raw, rawLen, b.prep[i].position);
 			for (size_t c = firstRef[i]; c < firstRef[i + 1]; ++c)
 			{
 				// special states actually carried into this chunk (Kiwi.cpp:1122-1140) vs. the ones it was searched with
@@ -839,17 +894,35 @@ namespace kamd
 				chunkPaths(paths, impl->model, b, c);
 				rb.insertPaths(paths);
 			}
-			ret[i] = rb.finish(b.raw[i].data(), b.raw[i].size());
+			seg.appendText(rb.finish(raw, rawLen));
 			return true;
 		};
 		std::vector<uint8_t> again(nT, 0);
-		parallelFor(nT, 0, [&](size_t i) { if (!doText(i, false)) again[i] = 1; });
-		for (size_t i = 0; i < nT; ++i) if (again[i]) doText(i, true);
+		const int postThreads = std::getenv("KAMD_POST_THREADS") ? std::atoi(std::getenv("KAMD_POST_THREADS")) : b.hostThreads;
+		HostPool::instance().run(ret.segs.size(), 1, postThreads, [&](size_t s0, size_t s1, int)
+		{
+			std::vector<PathResult> paths;
+			for (size_t sIdx = s0; sIdx < s1; ++sIdx)
+			{
+				ResultSegment& seg = ret.segs[sIdx];
+				const size_t t0 = sIdx * BatchResults::kSegTexts, t1 = std::min(nT, t0 + BatchResults::kSegTexts);
+				seg.toks.reserve(32 * (t1 - t0)); seg.forms.reserve(128 * (t1 - t0));
+				for (size_t i = t0; i < t1; ++i)
+					if (!doText(i, false, seg, paths)) { again[i] = 1; seg.appendText({}); }
+			}
+		});
+		// (the nested run above must not be re-entered: runRefs uses the device and the pool from this thread only)
+		std::vector<PathResult> paths;
+		for (size_t i = 0; i < nT; ++i) if (again[i])
+		{
+			ret.overrides.emplace_back(i, ResultSegment{});
+			doText(i, true, ret.overrides.back().second, paths);
+		}
 		tm.lap("post-processing");
 		return ret;
 	}
 
-	std::vector<std::vector<TokenResult>> Engine::analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
+	BatchResults Engine::analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
 		size_t topN, uint64_t match, bool openEnding, int hostThreads, TypoOption typo)
 	{
 		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };

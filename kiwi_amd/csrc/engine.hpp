@@ -3,6 +3,7 @@
 // (/root/reference/include/kiwi/Kiwi.h:402-454).  Host code prepares chunks (textprep), the kernels build
 // lattices and search them, host code stitches chunk results into token lists (post).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -23,6 +24,29 @@ namespace kamd
 	struct KernelTimes { float scanMs = 0, latticeMs = 0, searchMs = 0, finishMs = 0; uint32_t searchLaunches = 1; };   // sums over the sub-batches of one run
 
 	struct StagedBatch;   // chunks of one round resident in HBM
+
+	// Results of a batch: flat segments of kSegTexts consecutive texts each (post.hpp ResultSegment), filled in parallel by the host
+	// workers; a text whose chunks had to be searched again on the device (other start states than the speculative ones, scratch
+	// overflow) is finished afterwards and kept as a one-text override.
+	struct BatchResults
+	{
+		static constexpr size_t kSegTexts = 128;
+		size_t nTexts = 0;
+		std::vector<ResultSegment> segs;
+		std::vector<std::pair<size_t, ResultSegment>> overrides;     // sorted by text
+		// segment and local text index of text t
+		const ResultSegment& locate(size_t t, size_t& local) const
+		{
+			if (!overrides.empty())
+			{
+				auto it = std::lower_bound(overrides.begin(), overrides.end(), t, [](const std::pair<size_t, ResultSegment>& a, size_t v) { return a.first < v; });
+				if (it != overrides.end() && it->first == t) { local = 0; return it->second; }
+			}
+			local = t % kSegTexts;
+			return segs[t / kSegTexts];
+		}
+		uint64_t d2hBytes = 0;     // bytes the device -> host copy of this batch moved
+	};
 	class PreparedTypo;
 	// a prepared typo transformer applied to an analysis (AnalyzeOption::typoTransformer / typoThreshold / allowedDialects of the reference)
 	struct TypoOption { const PreparedTypo* typo = nullptr; float threshold = 2.5f; uint16_t allowedDialect = 0; };
@@ -40,7 +64,7 @@ namespace kamd
 		const FlatModel& model() const;
 
 		// Full path: prepare -> kernels -> results, for a batch of raw UTF-16 texts.  Results are per text.
-		std::vector<std::vector<TokenResult>> analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
+		BatchResults analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
 			size_t topN, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {});
 
 		// Staged path (benchmarks): stage() does host preparation + upload of every chunk of the texts (one round,
@@ -48,7 +72,7 @@ namespace kamd
 		// the resident batch and returns their event-timed durations; fetch() downloads and assembles results.
 		std::shared_ptr<StagedBatch> stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {});
 		KernelTimes run(StagedBatch& b);
-		std::vector<std::vector<TokenResult>> fetch(StagedBatch& b, size_t topN);
+		BatchResults fetch(StagedBatch& b, size_t topN);
 		static size_t stagedChunks(const StagedBatch& b);
 		static uint64_t stagedUnits(const StagedBatch& b);     // non-space normalised units ("jamo")
 		static uint64_t stagedDeviceBytes(const StagedBatch& b);

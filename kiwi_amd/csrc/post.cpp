@@ -242,6 +242,27 @@ namespace kamd
 		}
 	}
 
+	void ResultSegment::appendText(const std::vector<TokenResult>& analyses)
+	{
+		for (const auto& a : analyses)
+		{
+			for (const Token& t : a.first)
+			{
+				FlatToken o{};
+				o.position = t.position; o.wordPosition = t.wordPosition; o.sentPosition = t.sentPosition; o.lineNumber = t.lineNumber;
+				o.length = t.length; o.tag = t.tag; o.senseOrScript = t.senseId; o.score = t.score; o.typoCost = t.typoCost;
+				o.typoFormId = t.typoFormId; o.pairedToken = t.pairedToken; o.subSentPosition = t.subSentPosition; o.dialect = t.dialect;
+				o.morph = t.morph; o.formLen = (uint16_t)t.str.size(); o.formOff = forms.size();
+				forms.insert(forms.end(), t.str.begin(), t.str.end());
+				forms.push_back(0);
+				toks.push_back(o);
+			}
+			anaScore.push_back(a.second);
+			anaTok.push_back((uint32_t)toks.size());
+		}
+		textAna.push_back((uint32_t)anaScore.size());
+	}
+
 	void ResultBuilder::begin(const char16_t* raw, size_t n, const std::vector<uint32_t>& pt)
 	{
 		ret.clear(); spStatesByRet.clear();

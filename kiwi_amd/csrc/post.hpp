@@ -39,6 +39,32 @@ namespace kamd
 	};
 	struct PathResult { std::vector<PathTok> path; float score = 0; uint8_t prevState = 0, curState = 0; };
 
+	// Packed token record as the C ABI hands it out (include/kiwi_amd.h kamd_token_t; its first 44 bytes are the reference's
+	// kiwi_token_info_t, include/kiwi/capi.h:43-61, so that kiwi_res_token_info can return a pointer into it).
+	struct FlatToken
+	{
+		uint32_t position, wordPosition, sentPosition, lineNumber;
+		uint16_t length; uint8_t tag; uint8_t senseOrScript;
+		float score, typoCost;
+		uint32_t typoFormId, pairedToken, subSentPosition;
+		uint16_t dialect; uint16_t formLen;
+		int32_t morph;
+		uint64_t formOff;      // offset of the NUL-terminated UTF-16 form in the segment's `forms`
+	};
+	static_assert(sizeof(FlatToken) == 56, "FlatToken");
+
+	// Results of a run of consecutive texts, flat: analyses of text t are textAna[t] .. textAna[t+1], tokens of analysis a are
+	// anaTok[a] .. anaTok[a+1].  One segment is filled by one host worker, without per-token allocations.
+	struct ResultSegment
+	{
+		std::vector<uint32_t> textAna{ 0 }, anaTok{ 0 };
+		std::vector<float> anaScore;
+		std::vector<FlatToken> toks;
+		std::vector<char16_t> forms;
+		size_t texts() const { return textAna.size() - 1; }
+		void appendText(const std::vector<TokenResult>& analyses);
+	};
+
 	class ResultBuilder
 	{
 		const FlatModel& mdl;

@@ -1429,44 +1429,92 @@ namespace sbgk
 	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418); one thread per chunk
 	__global__ void __launch_bounds__(64) k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount)
 	{
+		// (no early return: every lane of the wave takes part in the prefix sums that hand out the output ranges)
+		const uint32_t lane = threadIdx.x & 63u;
 		const uint32_t t = blockIdx.x * 64 + threadIdx.x;
-		if (t >= chunkCount) return;
-		const uint32_t chunk = chunkBegin + t;
+		const uint32_t chunk = chunkBegin + (t < chunkCount ? t : 0u);
 		DevChunkResult* res = &W.results[chunk];
-		if (res->status != CS_OK) return;
-		const uint32_t nEnd = res->nEnd;
-		const uint32_t nBase = W.nodeBase[chunk];
-		const uint32_t Gn = W.nNodes[chunk];
-		DevState* st = W.states + W.stateBase[chunk];
-		EndCand* endBuf = reinterpret_cast<EndCand*>(st + res->endOff);
-		uint32_t* chain = reinterpret_cast<uint32_t*>(endBuf + nEnd);
-		const uint8_t* uniq = B.spStates + B.spOff[chunk];
-		uint32_t status = CS_OK; uint32_t nPaths = 0;
-		sortEndCands(endBuf, (int)nEnd);
-		uint32_t numUniq = 0;
-		for (uint32_t a = 0; a < nEnd; ++a)
+		const bool active = t < chunkCount && res->status == CS_OK;
+		uint32_t nEnd = 0, nBase = 0, Gn = 0, perGroup = 0, nSel = 0;
+		DevState* st = nullptr; EndCand* endBuf = nullptr; uint32_t* chain = nullptr; const uint8_t* uniq = nullptr;
+		if (active)
 		{
-			bool seen = false;
-			for (uint32_t b = 0; b < a && !seen; ++b) seen = endBuf[b].rootId == endBuf[a].rootId && endBuf[b].sp == endBuf[a].sp;
-			if (!seen) ++numUniq;
+			nEnd = res->nEnd; nBase = W.nodeBase[chunk]; Gn = W.nNodes[chunk];
+			st = W.states + W.stateBase[chunk];
+			endBuf = reinterpret_cast<EndCand*>(st + res->endOff);
+			chain = reinterpret_cast<uint32_t*>(endBuf + nEnd);
+			uniq = B.spStates + B.spOff[chunk];
+			sortEndCands(endBuf, (int)nEnd);
+			uint32_t numUniq = 0;
+			for (uint32_t a = 0; a < nEnd; ++a)
+			{
+				bool seen = false;
+				for (uint32_t b = 0; b < a && !seen; ++b) seen = endBuf[b].rootId == endBuf[a].rootId && endBuf[b].sp == endBuf[a].sp;
+				if (!seen) ++numUniq;
+			}
+			perGroup = numUniq ? (2 * P.topN + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq)
+			// paths this chunk hands on: the first perGroup candidates of every (root, state) group
+			for (uint32_t a = 0, startIdx = 0; a < nEnd; ++a)
+			{
+				if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
+				if (a - startIdx < perGroup) ++nSel;
+			}
 		}
-		const uint32_t perGroup = numUniq ? (2 * P.topN + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq)
-		DevToken* tok = W.tokens + W.tokenBase[chunk];
-		const uint32_t tokCap = (uint32_t)(W.tokenBase[chunk + 1] - W.tokenBase[chunk]);
-		uint32_t tokTop = 0, startIdx = 0;
-		for (uint32_t a = 0; a < nEnd && status == CS_OK; ++a)
+		// output range of the path headers: wave prefix sum + one atomic per wave
+		uint32_t status = CS_OK;
+		uint32_t pathOff;
 		{
-			if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
-			if (a - startIdx >= perGroup) continue;
-			if (nPaths >= kMaxPathsPerChunk) { status = CS_ERR_PATH_OVERFLOW; break; }
-			const int nt = backTrace(M, P, W.nodes + nBase, st, endBuf[a].parent, tok + tokTop, tokCap - tokTop, chain, Gn);
-			if (nt < 0) { status = CS_ERR_TOKEN_OVERFLOW; break; }
-			DevPathHeader& ph = res->paths[nPaths++];
-			ph.score = endBuf[a].score; ph.tokOff = tokTop; ph.nTokens = (uint16_t)nt;
-			ph.prevState = uniq[endBuf[a].rootId]; ph.curState = endBuf[a].sp;
-			tokTop += (uint32_t)nt;
+			uint32_t incl = nSel;
+			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+			const uint32_t total = __shfl(incl, 63, 64);
+			uint32_t base = 0;
+			if (lane == 0 && total) base = atomicAdd(&W.outCounters[0], total);
+			base = __shfl(base, 0, 64);
+			pathOff = base + incl - nSel;
+			if (active && pathOff + nSel > W.outPathCap) status = CS_ERR_PATH_OVERFLOW;
 		}
-		res->status = status; res->nPaths = status == CS_OK ? nPaths : 0;
+		DevToken* tok = nullptr; uint32_t tokTop = 0, nPaths = 0;
+		if (active && status == CS_OK)
+		{
+			tok = W.tokens + W.tokenBase[chunk];
+			const uint32_t tokCap = (uint32_t)(W.tokenBase[chunk + 1] - W.tokenBase[chunk]);
+			for (uint32_t a = 0, startIdx = 0; a < nEnd; ++a)
+			{
+				if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
+				if (a - startIdx >= perGroup) continue;
+				const int nt = backTrace(M, P, W.nodes + nBase, st, endBuf[a].parent, tok + tokTop, tokCap - tokTop, chain, Gn);
+				if (nt < 0) { status = CS_ERR_TOKEN_OVERFLOW; break; }
+				DevPathHeader ph;
+				ph.score = endBuf[a].score; ph.tokOff = tokTop; ph.nTokens = (uint16_t)nt;
+				ph.prevState = uniq[endBuf[a].rootId]; ph.curState = endBuf[a].sp;
+				W.outPaths[pathOff + nPaths++] = ph;
+				tokTop += (uint32_t)nt;
+			}
+			if (status != CS_OK) tokTop = 0;
+		}
+		// output range of the token records, then the copy out of the chunk's arena
+		uint32_t tokOff;
+		{
+			uint32_t incl = tokTop;
+			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+			const uint32_t total = __shfl(incl, 63, 64);
+			uint32_t base = 0;
+			if (lane == 0 && total) base = atomicAdd(&W.outCounters[1], total);
+			base = __shfl(base, 0, 64);
+			tokOff = base + incl - tokTop;
+			if (active && status == CS_OK && tokOff + tokTop > W.outTokCap) status = CS_ERR_TOKEN_OVERFLOW;
+		}
+		if (active && status == CS_OK)
+		{
+			const uint2* src = reinterpret_cast<const uint2*>(tok);            // 24-byte records, 8-byte aligned
+			uint2* dst = reinterpret_cast<uint2*>(W.outTokens + tokOff);
+			for (uint32_t i = 0; i < 3 * tokTop; ++i) dst[i] = src[i];
+		}
+		if (t < chunkCount && res->status == CS_OK)
+		{
+			res->status = status; res->nPaths = status == CS_OK ? nPaths : 0;
+			res->pathOff = pathOff; res->tokOff = tokOff; res->nTok = status == CS_OK ? tokTop : 0;
+		}
 	}
 #endif
 

@@ -154,6 +154,9 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::memset(p, 0, sizeof(*p)); std::strcpy(p->name, "hipemu (CPU lanes)"); p->multiProcessorCount = 1; p->totalGlobalMem = 1ull << 34; return hipSuccess; }
 template<class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+template<class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { *p = (T*)std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
