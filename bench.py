@@ -130,6 +130,28 @@ def main():
     for k in kt:
         kt[k] /= args.steps
 
+    # End to end: UTF-16 strings resident on the host -> kamd_analyze_batch (host text preparation, H2D, kernels,
+    # D2H, result assembly) -> packed token records resident on the host.  Timed through the C ABI on an already packed buffer.
+    e2e = None
+    if typo is None:
+        from kiwi_amd.api import pack_texts
+        flat, offs = pack_texts(shard)
+        e2e_steps = max(3, min(args.steps, 10))
+        for _ in range(2):
+            eng.analyze_packed(flat, offs, top_n).close()
+        sync()
+        te = time.perf_counter()
+        d2h = 0
+        for _ in range(e2e_steps):
+            r = eng.analyze_packed(flat, offs, top_n)
+            d2h = r.d2h_bytes()
+            r.close()
+        sync()
+        e2e_elapsed = dist.max_over_ranks(time.perf_counter() - te, device="cuda" if world > 1 else "cpu")
+        e2e = {"value": n * world * e2e_steps / e2e_elapsed, "unit": "sentences/s", "ms_per_batch": 1000.0 * e2e_elapsed / e2e_steps, "steps": e2e_steps,
+               "region": "host UTF-16 strings -> kamd_analyze_batch -> host token records (text preparation, H2D, kernels, D2H, result assembly)",
+               "h2d_bytes_per_batch": int(flat.nbytes), "d2h_bytes_per_batch": d2h}
+
     # sanity: the staged batch really was analysed (token count > 0, no failed chunk)
     res = eng.fetch(batch, top_n)
     n_tok = sum(res.lib.kamd_res_token_num(res.h, i, 0) for i in range(min(256, n)))
@@ -141,7 +163,7 @@ def main():
         total_sent = n * world * args.steps
         value = total_sent / elapsed
         out = {
-            "metric": "sentences/sec on batched analyze() (dictionary scan + lattice + Viterbi/%s, top-%d)" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "Knlm, typo correction" if typo is not None else "Knlm", top_n),
+            "metric": "sentences/sec on batched analyze(), device kernels with inputs resident in HBM (dictionary scan + lattice + Viterbi/%s, top-%d); host-to-host rate: see e2e" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "Knlm, typo correction" if typo is not None else "Knlm", top_n),
             "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32+f32", "data": "synthetic",
@@ -158,6 +180,10 @@ def main():
                                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, "k_best_path"),
                                "alg_bytes_per_sentence": per, "all_kernels_achieved": per["total"] * n / ((kt["scan_ms"] + kt["lattice_ms"] + kt["search_ms"] + kt["finish_ms"]) * 1e-3) / 1e9}
             out["cpu_baseline"] = cb["cpu_baseline"]
+            if e2e is not None:
+                e2e["vs_cpu_baseline"] = e2e["value"] / cb["cpu_baseline"]["value"]
+        if e2e is not None:
+            out["e2e"] = e2e
         print(json.dumps(out))
     res.close()
     batch.close()

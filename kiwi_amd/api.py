@@ -120,6 +120,9 @@ class Results:
     def n_texts(self):
         return self.lib.kamd_res_texts(self.h)
 
+    def d2h_bytes(self):
+        return int(self.lib.kamd_res_d2h_bytes(self.h))
+
     def token_array(self, text, index=0):
         n = self.lib.kamd_res_token_num(self.h, text, index)
         if not n:
@@ -189,6 +192,14 @@ class KiwiAmd:
     def analyze_batch(self, texts, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Results:
         flat, offs = pack_texts(texts)
         r = self.lib.kamd_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), top_n, match, int(open_ending), host_threads)
+        if not r:
+            raise self._err("kamd_analyze_batch")
+        return Results(self.lib, r)
+
+    def analyze_packed(self, flat, offs, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Results:
+        """The C-ABI call itself on an already packed batch (`pack_texts`): UTF-16 strings resident on the host in, packed token
+        records resident on the host out -- the end-to-end region of SURVEY.md section 8(d)."""
+        r = self.lib.kamd_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(offs) - 1, top_n, match, int(open_ending), host_threads)
         if not r:
             raise self._err("kamd_analyze_batch")
         return Results(self.lib, r)

@@ -129,7 +129,9 @@ namespace kamd
 	struct StagedBatch
 	{
 		U16 rawFlat; std::vector<uint64_t> rawOff;   // the raw texts (result assembly reads them: word positions, line breaks)
-		std::vector<PreparedText> prep;
+		std::vector<PrepBlock> prepBlocks;            // flat storage of the prepared texts, kPrepBlock consecutive texts per block
+		std::vector<PreparedView> prep;               // per text: views into its block
+		static constexpr size_t kPrepBlock = 64;
 		int hostThreads = 0;
 		std::vector<ChunkRef> refs;
 		uint64_t match = 0;
@@ -328,7 +330,7 @@ namespace kamd
 			for (size_t c = c0; c < c1; ++c)
 			{
 				const auto& r = b.refs[c];
-				const PreparedText& pt = b.prep[r.text];
+				const PreparedView& pt = b.prep[r.text];
 				const ChunkDesc& d = pt.chunks[r.chunk];
 				std::memcpy(H + oChars + 2 * (size_t)b.charOff[c], pt.norm.data() + d.startOffset, 2 * (size_t)d.nChars);
 				std::memcpy(H + oCls + b.charOff[c], pt.cls.data() + d.startOffset, d.nChars);
@@ -391,7 +393,7 @@ namespace kamd
 			for (size_t c = 0; c < nC; ++c)
 			{
 				const auto& r = b.refs[c];
-				const PreparedText& pt = b.prep[r.text];
+				const PreparedView& pt = b.prep[r.text];
 				const ChunkDesc& d = pt.chunks[r.chunk];
 				const char16_t* str = (const char16_t*)pt.norm.data() + d.startOffset;
 				const size_t maxCti = T.graph(str, d.nChars, b.typo.allowedDialect, g);
@@ -743,7 +745,7 @@ namespace kamd
 		out.clear();
 		const DevChunkResult& r = b.hResults[c];
 		const auto& ref = b.refs[c];
-		const PreparedText& pt = b.prep[ref.text];
+		const PreparedView& pt = b.prep[ref.text];
 		const uint32_t so = pt.chunks[ref.chunk].startOffset;
 		for (uint32_t p = 0; p < r.nPaths; ++p)
 		{
@@ -751,12 +753,13 @@ namespace kamd
 			const DevPathHeader& ph = b.hPaths[r.pathOff + p];
 			pr.score = ph.score; pr.prevState = ph.prevState; pr.curState = ph.curState;
 			const DevToken* tk = b.hTokens + r.tokOff + ph.tokOff;
+			pr.path.reserve(ph.nTokens);
 			for (uint32_t k = 0; k < ph.nTokens; ++k)
 			{
 				PathTok t;
 				t.morph = tk[k].morph; t.begin = tk[k].begin + so; t.end = tk[k].end + so; t.wordScore = tk[k].wordScore; t.typoCost = tk[k].typoCost;
 				if (tk[k].ownKind == 2) t.str = m.formStr(tk[k].ownA);
-				else if (tk[k].ownKind) t.str = pt.norm.substr(so + tk[k].ownA, tk[k].ownLen);
+				else if (tk[k].ownKind) t.str = pt.normSubstr(so + tk[k].ownA, tk[k].ownLen);
 				pr.path.push_back(std::move(t));
 			}
 			out.push_back(std::move(pr));
@@ -776,15 +779,22 @@ namespace kamd
 		b->match = match;
 		b->hostThreads = hostThreads;
 		b->prep.resize(texts.size()); b->rawOff.assign(texts.size() + 1, 0);
+		b->prepBlocks.resize((texts.size() + StagedBatch::kPrepBlock - 1) / StagedBatch::kPrepBlock);
 		for (size_t i = 0; i < texts.size(); ++i) b->rawOff[i + 1] = b->rawOff[i] + texts[i].second;
 		b->rawFlat.resize(b->rawOff.back());
-		HostPool::instance().run(texts.size(), 64, hostThreads, [&](size_t i0, size_t i1, int)
+		HostPool::instance().run(texts.size(), StagedBatch::kPrepBlock, hostThreads, [&](size_t i0, size_t i1, int)
 		{
+			PrepBlock& blk = b->prepBlocks[i0 / StagedBatch::kPrepBlock];
+			size_t units = 0;
+			for (size_t i = i0; i < i1; ++i) units += texts[i].second;
+			blk.norm.reserve(units + units / 2 + 16); blk.position.reserve(units + (i1 - i0) + 16); blk.cls.reserve(units + units / 2 + 16); blk.script.reserve(units + units / 2 + 16);
+			blk.chunks.reserve(2 * (i1 - i0)); blk.idx.reserve(i1 - i0);
 			for (size_t i = i0; i < i1; ++i)
 			{
 				if (texts[i].second) std::memcpy(&b->rawFlat[b->rawOff[i]], texts[i].first, 2 * texts[i].second);
-				prepareText(b->prep[i], texts[i].first, texts[i].second, match, (uint32_t)i);
+				blk.append(texts[i].first, texts[i].second, match, (uint32_t)i);
 			}
+			for (size_t i = i0; i < i1; ++i) b->prep[i] = blk.view(i - i0);
 		});
 		for (size_t i = 0; i < texts.size(); ++i)
 		{
@@ -872,7 +882,7 @@ namespace kamd
 		{
 			const char16_t* raw = b.rawFlat.data() + b.rawOff[i]; const size_t rawLen = (size_t)(b.rawOff[i + 1] - b.rawOff[i]);
 			ResultBuilder rb{ impl->model, topN, b.match, config.integrateAllomorph };
-			rb.begin(raw, rawLen, b.prep[i].position);
+			rb.begin(raw, rawLen, b.prep[i].position.data(), b.prep[i].position.size());
 			for (size_t c = firstRef[i]; c < firstRef[i + 1]; ++c)
 			{
 				// special states actually carried into this chunk (Kiwi.cpp:1122-1140) vs. the ones it was searched with
@@ -950,7 +960,7 @@ namespace kamd
 		}
 		std::vector<uint8_t> out;
 		auto put32 = [&](uint32_t v) { out.insert(out.end(), (uint8_t*)&v, (uint8_t*)&v + 4); };
-		const PreparedText& pt = b->prep[0];
+		const PreparedView& pt = b->prep[0];
 		put32((uint32_t)pt.chunks.size());
 		size_t ri = 0;
 		for (size_t c = 0; c < pt.chunks.size(); ++c)

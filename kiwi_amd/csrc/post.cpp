@@ -263,10 +263,10 @@ namespace kamd
 		textAna.push_back((uint32_t)anaScore.size());
 	}
 
-	void ResultBuilder::begin(const char16_t* raw, size_t n, const std::vector<uint32_t>& pt)
+	void ResultBuilder::begin(const char16_t* raw, size_t n, const uint32_t* pt, size_t ptLen)
 	{
 		ret.clear(); spStatesByRet.clear();
-		positionTable = &pt;
+		positionTable = pt; positionLen = ptLen;
 		// getWordPositions (Kiwi.cpp:465-487)
 		wordPositions.resize(n);
 		uint32_t position = 0; bool contSpace = false;
@@ -314,7 +314,7 @@ namespace kamd
 
 		uint32_t spStateCnt[256] = { 0 };
 		size_t valid = 0;
-		const auto& pt = *positionTable;
+		const uint32_t* ptBegin = positionTable; const uint32_t* ptEnd = positionTable + positionLen;
 		for (size_t i = 0; i < ret.size(); ++i)
 		{
 			if (!(parentMap[i] < pathes.size() && spStateCnt[pathes[parentMap[i]].curState] < topN)) continue;
@@ -322,6 +322,7 @@ namespace kamd
 			const PathResult& r = pathes[parentMap[i]];
 			auto& rarr = ret[valid].first;
 			const size_t firstNew = rarr.size();
+			rarr.reserve(rarr.size() + r.path.size());
 			int32_t prevMorph = -1;
 			for (auto& s : r.path)
 			{
@@ -341,8 +342,8 @@ namespace kamd
 				rarr.emplace_back();
 				Token& tk = rarr.back();
 				tk.str = std::move(joined); tk.tag = mr.tag; tk.morph = (int32_t)s.morph;
-				const size_t b = (std::upper_bound(pt.begin(), pt.end(), s.begin) - pt.begin()) - 1;
-				const size_t e = std::lower_bound(pt.begin(), pt.end(), s.end) - pt.begin();
+				const size_t b = (std::upper_bound(ptBegin, ptEnd, s.begin) - ptBegin) - 1;
+				const size_t e = std::lower_bound(ptBegin, ptEnd, s.end) - ptBegin;
 				tk.position = (uint32_t)b; tk.length = (uint16_t)(e - b);
 				tk.score = s.wordScore; tk.typoCost = s.typoCost; tk.typoFormId = s.typoFormId;
 				tk.senseId = mr.senseId;

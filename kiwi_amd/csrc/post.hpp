@@ -70,13 +70,13 @@ namespace kamd
 		const FlatModel& mdl;
 		std::vector<TokenResult> ret;
 		std::vector<uint8_t> spStatesByRet;
-		const std::vector<uint32_t>* positionTable = nullptr;
+		const uint32_t* positionTable = nullptr; size_t positionLen = 0;
 		std::vector<uint16_t> wordPositions;
 		size_t topN; uint64_t match; bool integrateAllomorph;
 	public:
 		ResultBuilder(const FlatModel& m, size_t _topN, uint64_t _match, bool _integrateAllomorph)
 			: mdl(m), topN(_topN), match(_match), integrateAllomorph(_integrateAllomorph) {}
-		void begin(const char16_t* raw, size_t n, const std::vector<uint32_t>& positionTable);
+		void begin(const char16_t* raw, size_t n, const uint32_t* positionTable, size_t positionLen);
 		const std::vector<uint8_t>& spStates() const { return spStatesByRet; }
 		void insertPaths(const std::vector<PathResult>& paths);
 		std::vector<TokenResult> finish(const char16_t* raw, size_t n);

@@ -264,14 +264,14 @@ namespace kamd
 		return { 0, T_UNKNOWN };
 	}
 
-	void normalizeWithPosition(const char16_t* s, size_t n, U16& out, std::vector<uint32_t>& pos)
+	// appends the normalised form of s[0, n) to `out` and its position table (offsets relative to the text's first unit) to `pos`
+	static void appendNormalized(const char16_t* s, size_t n, U16& out, std::vector<uint32_t>& pos)
 	{
-		out.clear(); pos.clear();
-		out.reserve(n + n / 2); pos.reserve(n + 1);
+		const size_t base = out.size();
 		for (size_t i = 0; i < n; ++i)
 		{
 			char16_t c = s[i];
-			pos.push_back((uint32_t)out.size());
+			pos.push_back((uint32_t)(out.size() - base));
 			if (c == 0xB42C) c = 0xB410;
 			if (0xAC00 <= c && c < 0xD7A4)
 			{
@@ -281,17 +281,26 @@ namespace kamd
 			}
 			else out.push_back(c);
 		}
-		pos.push_back((uint32_t)out.size());
+		pos.push_back((uint32_t)(out.size() - base));
 	}
 
-	void normalizeCoda(U16& s) // src/StrUtils.h:637-703: "받침 + 같은 초성체" -> merged
+	void normalizeWithPosition(const char16_t* s, size_t n, U16& out, std::vector<uint32_t>& pos)
+	{
+		out.clear(); pos.clear();
+		out.reserve(n + n / 2); pos.reserve(n + 1);
+		appendNormalized(s, n, out, pos);
+	}
+
+	void normalizeCoda(U16& s) { if (!s.empty()) normalizeCoda(&s[0], s.size()); }
+
+	void normalizeCoda(char16_t* s, size_t n) // src/StrUtils.h:637-703: "받침 + 같은 초성체" -> merged
 	{
 		static const char16_t toOnset[27] = { 0x3131, 0x3131, 0x3145, 0x3134, 0x3148, 0x314E, 0x3137, 0x3139, 0x3131, 0x3141, 0x3142, 0x3145, 0x314C, 0x314D,
 			0x314E, 0x3141, 0x3142, 0x3145, 0x3145, 0x3145, 0x3147, 0x3148, 0x314A, 0x314B, 0x314C, 0x314D, 0x314E };
 		static const char16_t conv[27] = { 0, 0x11A8, 0x11A8, 0, 0x11AB, 0x11AB, 0, 0, 0x11AF, 0x11AF, 0x11AF, 0x11AF, 0x11AF, 0x11AF, 0x11AF,
 			0, 0, 0x11B8, 0, 0x11BA, 0, 0, 0, 0, 0, 0, 0 };
 		char16_t before = 0;
-		for (size_t i = 0; i < s.size(); ++i)
+		for (size_t i = 0; i < n; ++i)
 		{
 			if (0x11A8 <= before && before <= 0x11C2)
 			{
@@ -304,48 +313,91 @@ namespace kamd
 
 	void prepareText(PreparedText& o, const char16_t* raw, size_t n, uint64_t mo, uint32_t textId)
 	{
-		normalizeWithPosition(raw, n, o.norm, o.position);
-		if (mo & M_NORMALIZE_CODA) normalizeCoda(o.norm);
-		const size_t L = o.norm.size();
-		o.cls.assign(L, 0); o.script.assign(L, 0);
+		PrepBlock blk;
+		blk.append(raw, n, mo, textId);
+		o.norm = std::move(blk.norm); o.position = std::move(blk.position); o.cls = std::move(blk.cls); o.script = std::move(blk.script);
+		o.chunks = std::move(blk.chunks); o.patterns = std::move(blk.patterns);
+	}
+
+	namespace
+	{
+		// Per-character facts of the preparation loop as tables: type and script of every ASCII character and of the two Hangul blocks the
+		// normalised text consists of, and which characters can START a pattern at all -- matchPattern's recognisers begin with a digit
+		// (ASCII or full-width), an ASCII letter, '#', '@', an e-mail account character or an emoji base; everything else (Hangul above all)
+		// is rejected without running them.  Built once from the very functions they stand for.
+		struct PrepTables
+		{
+			uint8_t cls[128], script[128]; bool canStart[128];
+			uint8_t hangulSyllableScript, hangulJamoScript;
+			PrepTables()
+			{
+				for (uint32_t c = 0; c < 128; ++c)
+				{
+					cls[c] = identifySpecialChr(c); script[c] = chr2ScriptType(c);
+					canStart[c] = isDigit(c) || isAlpha(c) || c == '#' || c == '@' || csEmailAccount(c) || findRange(kEmoji1, c) || findRange(kEmoji2, c);
+				}
+				hangulSyllableScript = chr2ScriptType(0xAC00); hangulJamoScript = chr2ScriptType(0x11A8);
+			}
+		};
+		const PrepTables& prepTables() { static const PrepTables t; return t; }
+	}
+
+	void PrepBlock::append(const char16_t* raw, size_t n, uint64_t mo, uint32_t textId)
+	{
+		const PrepTables& T = prepTables();
+		Idx x{};
+		x.normOff = norm.size(); x.posOff = position.size(); x.chunkOff = chunks.size(); x.patOff = patterns.size();
+		appendNormalized(raw, n, norm, position);
+		const size_t L = norm.size() - x.normOff;
+		char16_t* nrm = L ? &norm[x.normOff] : nullptr;
+		if (mo & M_NORMALIZE_CODA) normalizeCoda(nrm, L);
+		cls.resize(x.normOff + L); script.resize(x.normOff + L);
+		uint8_t* ocls = cls.data() + x.normOff; uint8_t* oscript = script.data() + x.normOff;
 		for (size_t i = 0; i < L; ++i)
 		{
-			uint32_t c = o.norm[i];
+			uint32_t c = nrm[i];
+			if (c < 128) { ocls[i] = T.cls[c]; oscript[i] = T.script[c]; continue; }                                  // (no emoji starts below U+0080 is flagged here: see below)
+			if (0xAC00 <= c && c < 0xD7A4) { ocls[i] = T_MAX; oscript[i] = T.hangulSyllableScript; continue; }
+			if (0x11A8 <= c && c <= 0x11C2) { ocls[i] = T_MAX; oscript[i] = T.hangulJamoScript; continue; }
 			uint32_t c1 = 0;
 			size_t nx = i + 1;
-			if (isHighSurrogate(c) && i + 1 < L) { c = mergeSurrogate(c, o.norm[i + 1]); nx = i + 2; }
+			if (isHighSurrogate(c) && i + 1 < L) { c = mergeSurrogate(c, nrm[i + 1]); nx = i + 2; }
 			if (nx < L)
 			{
-				c1 = o.norm[nx];
-				if (isHighSurrogate(c1) && nx + 1 < L) c1 = mergeSurrogate(c1, o.norm[nx + 1]);
+				c1 = nrm[nx];
+				if (isHighSurrogate(c1) && nx + 1 < L) c1 = mergeSurrogate(c1, nrm[nx + 1]);
 			}
-			o.cls[i] = identifySpecialChr(c);
-			o.script[i] = chr2ScriptType(c);
-			if (c >= 0x80 && isEmoji(c, c1)) o.cls[i] |= 0x80;
+			ocls[i] = identifySpecialChr(c);
+			oscript[i] = chr2ScriptType(c);
+			if (c >= 0x80 && isEmoji(c, c1)) ocls[i] |= 0x80;
 		}
-		o.chunks.clear(); o.patterns.clear();
 		size_t splitEnd = 0;
 		while (splitEnd < L)
 		{
-			const char16_t* str = o.norm.data() + splitEnd;
+			const char16_t* str = nrm + splitEnd;
 			const size_t sz = L - splitEnd;
 			ChunkDesc ch{};
-			ch.textId = textId; ch.startOffset = (uint32_t)splitEnd; ch.patBegin = (uint32_t)o.patterns.size();
+			ch.textId = textId; ch.startOffset = (uint32_t)splitEnd; ch.patBegin = (uint32_t)(patterns.size() - x.patOff);
 			size_t k = 0, contNonSpace = 0;
 			uint8_t lastType = T_UNKNOWN;
 			bool anyNonSpace = false;
+			const uint8_t* ccls = ocls + splitEnd;
 			for (; k < sz; ++k)
 			{
-				auto pm = matchPattern(k ? str[k - 1] : u' ', str + k, str + sz, mo);
-				if (pm.second != T_UNKNOWN)
+				const char16_t c0 = str[k];
+				if (c0 < 128 ? T.canStart[c0] : ((ccls[k] & 0x80) || (0xff10 <= c0 && c0 <= 0xff19)))
 				{
-					o.patterns.push_back(PatternSpan{ (uint32_t)(k + pm.first), (uint32_t)pm.first, pm.second });
-					k += pm.first - 1;
-					continue;
+					auto pm = matchPattern(k ? str[k - 1] : u' ', str + k, str + sz, mo);
+					if (pm.second != T_UNKNOWN)
+					{
+						patterns.push_back(PatternSpan{ (uint32_t)(k + pm.first), (uint32_t)pm.first, pm.second });
+						k += pm.first - 1;
+						continue;
+					}
 				}
-				uint32_t c32 = str[k];
+				uint32_t c32 = c0;
 				if (isHighSurrogate(c32) && k + 1 < sz) c32 = mergeSurrogate(c32, str[k + 1]);
-				const uint8_t t = identifySpecialChr(c32);
+				const uint8_t t = ccls[k] & 0x7F;                      // == identifySpecialChr(c32): typed above, surrogate pairs merged at their first unit
 				if (t == T_UNKNOWN) contNonSpace = 0; else ++contNonSpace;
 				if (t == T_UNKNOWN && k >= (lastType == T_SF ? 4u : 4096u))
 				{
@@ -357,21 +409,23 @@ namespace kamd
 			}
 			if (k > sz) k = sz;
 			for (size_t i = 0; i < k; ++i) if (!isSpace(str[i])) { anyNonSpace = true; break; }
-			std::sort(o.patterns.begin() + ch.patBegin, o.patterns.end(), [](const PatternSpan& a, const PatternSpan& b)
+			std::sort(patterns.begin() + x.patOff + ch.patBegin, patterns.end(), [](const PatternSpan& a, const PatternSpan& b)
 			{
 				if (a.end != b.end) return a.end < b.end;
 				if (a.length != b.length) return a.length < b.length;
 				return a.tag < b.tag;
 			});
-			ch.patEnd = (uint32_t)o.patterns.size();
+			ch.patEnd = (uint32_t)(patterns.size() - x.patOff);
 			ch.nChars = (uint32_t)k;
 			ch.empty = !anyNonSpace;
 			size_t stop = k;
 			if (ch.empty) while (stop < sz && isSpace(str[stop])) ++stop;   // KTrie.cpp:1505-1506
 			ch.nextOffset = (uint32_t)(splitEnd + stop);
-			o.chunks.push_back(ch);
+			chunks.push_back(ch);
 			if (stop == 0) throw std::runtime_error{ "prepareText: chunker made no progress" };
 			splitEnd += stop;
 		}
+		x.normLen = L; x.posLen = position.size() - x.posOff; x.nChunks = chunks.size() - x.chunkOff; x.nPat = patterns.size() - x.patOff;
+		idx.push_back(x);
 	}
 }

@@ -53,7 +53,7 @@ namespace
 		LatticeBuilder lb{ h.view, sc, cnt };
 		TypoLatticeBuilder tlb{ h.view, sc };
 		ResultBuilder rb{ h.model, topN, match, h.integrateAllomorph };
-		rb.begin(text, len, pt.position);
+		rb.begin(text, len, pt.position.data(), pt.position.size());
 		std::vector<LNode> nodes;
 		std::vector<PathResult> paths;
 		for (auto& ch : pt.chunks)

@@ -17,7 +17,9 @@ def _norm(res):
     return [([astuple(t) for t in a[0]], a[1]) for a in res]
 
 
-def _texts(sm, seed):
+def _texts(sm, seed, small=False):
+    if small:      # the small-capacity build sends every batch through the staged (HBM scratch) path: minutes per hundred long texts
+        return synthetic(sm, 60, seed, min_jamo=5, max_jamo=70) + dictionary_mix(sm, 40, seed + 1) + EDGE_TEXTS[:40]
     return synthetic(sm, 300, seed, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 150, seed + 1) + EDGE_TEXTS
 
 
@@ -55,7 +57,7 @@ def test_skipbigram_fallback_paths_with_small_capacities(small_sbg_model, monkey
     orc = oraclelib.OracleKiwi(path)
     orc.set_container_limits(3, 8, 2)
     dev = KiwiAmd(path, lib_path=lib)
-    texts = _texts(sm, 311)
+    texts = _texts(sm, 311, small=True)
     for top_n in (1, 2):
         got = dev.analyze_batch(texts, top_n=top_n).to_python()
         for s, y in zip(texts, got):
