@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--limit", type=int, default=0, help="diagnostics: only the first N sentences of the workload (named in config.workload)")
     args = ap.parse_args()
 
     import torch
@@ -93,6 +94,9 @@ def main():
     model_path, texts, desc = get_workload(args.workload)
     if world > 1 and rank == 0:
         dist.barrier()
+    if args.limit and args.limit < len(texts):
+        texts = texts[:args.limit]
+        desc += f" [first {args.limit} sentences only]"
     # weak scaling: every rank analyses a same-sized shard; rotate so shards differ
     n = len(texts)
     shard = dist.weak_shard(texts, rank)
