@@ -78,6 +78,7 @@ int kamd_debug_sbg_next(const char* raw_model_path, uint32_t* hist8, uint32_t* p
 typedef struct kamd_typo* kamd_typo_h;
 kamd_typo_h kamd_typo_new(float continual_cost, float lengthening_cost);     /* INFINITY = that kind of typo is off */
 void kamd_typo_close(kamd_typo_h t);
+kamd_typo_h kamd_typo_default(int default_typo_set);   /* a copy of one of Kiwi's built-in sets (reference DefaultTypoSet 0..6, capi.h:485-491); NULL + error otherwise */
 int kamd_typo_add(kamd_typo_h t, const uint16_t* orig, uint32_t n_orig, const uint16_t* error, uint32_t n_error, float cost, int left_cond, int dialect);
 int kamd_typo_add_entry(kamd_typo_h t, const uint16_t* orig, uint32_t n_orig, const uint16_t* error, uint32_t n_error, float cost, int left_cond, int dialect);   /* an already expanded rule, as update() inserts it */
 int kamd_typo_set_costs(kamd_typo_h t, float continual_cost, float lengthening_cost);

@@ -6,7 +6,9 @@
  *
  * Differences a caller can observe:
  *   - kiwi_init's model_path names a raw-model container (or a directory holding `kiwi_amd.raw`);
- *     on-disk sj.morph / sj.knlm loaders are a "next" row.
+ *     on-disk sj.morph / sj.knlm loaders are a "next" row.  Its `options` are honoured as in the reference:
+ *     KIWI_BUILD_INTEGRATE_ALLOMORPH sets integrate_allomorph; the model type bits select Knlm (default, KNLM) or SkipBigram (LARGEST when
+ *     the container has the tables, SBG) and refuse CONG / CONG_GLOBAL; the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).
  *   - top_n > 4, blocklist, pretokenized spans and non-standard dialects are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
  *     being silently ignored.
  */
@@ -63,6 +65,15 @@ typedef int (*kiwi_reader_w_t)(int, kchar16_t*, void*); /* capi.h:105 */
 typedef int (*kiwi_receiver_t)(int, kiwi_res_h, void*); /* capi.h:144 */
 
 enum { KIWI_NUM_THREADS = 0x8001, KIWI_GPU_BATCH_SIZE = 0x9001 };   /* capi.h:222 (+ one extension option) */
+enum {                                               /* capi.h:158-171 */
+	KIWI_BUILD_INTEGRATE_ALLOMORPH = 1, KIWI_BUILD_LOAD_DEFAULT_DICT = 2, KIWI_BUILD_LOAD_TYPO_DICT = 4, KIWI_BUILD_LOAD_MULTI_DICT = 8, KIWI_BUILD_DEFAULT = 15,
+	KIWI_BUILD_MODEL_TYPE_DEFAULT = 0x0000, KIWI_BUILD_MODEL_TYPE_LARGEST = 0x0100, KIWI_BUILD_MODEL_TYPE_KNLM = 0x0200, KIWI_BUILD_MODEL_TYPE_SBG = 0x0300,
+	KIWI_BUILD_MODEL_TYPE_CONG = 0x0400, KIWI_BUILD_MODEL_TYPE_CONG_GLOBAL = 0x0500,
+};
+enum {                                               /* capi.h:485-491 */
+	KIWI_TYPO_WITHOUT_TYPO = 0, KIWI_TYPO_BASIC_TYPO_SET = 1, KIWI_TYPO_CONTINUAL_TYPO_SET = 2, KIWI_TYPO_BASIC_TYPO_SET_WITH_CONTINUAL = 3,
+	KIWI_TYPO_LENGTHENING_TYPO_SET = 4, KIWI_TYPO_BASIC_TYPO_SET_WITH_CONTINUAL_AND_LENGTHENING = 5, KIWI_TYPO_DIALECT = 6,
+};
 
 const char* kiwi_version(void);                      /* capi.h:238 */
 const char* kiwi_error(void);                        /* capi.h:245 */
@@ -72,6 +83,8 @@ void kiwi_set_global_config(kiwi_h handle, kiwi_config_t config);               
 kiwi_config_t kiwi_get_global_config(kiwi_h handle);                                             /* capi.h:615 */
 void kiwi_set_option(kiwi_h handle, int option, int value);                                      /* capi.h:623 */
 int kiwi_get_option(kiwi_h handle, int option);                                                  /* capi.h:636 */
+void kiwi_set_option_f(kiwi_h handle, int option, float value);                                  /* capi.h:644 */
+float kiwi_get_option_f(kiwi_h handle, int option);                                              /* capi.h:652 */
 kiwi_res_h kiwi_analyze_w(kiwi_h handle, const kchar16_t* text, int top_n, kiwi_analyze_option_t option, kiwi_pretokenized_h pretokenized); /* capi.h:684 */
 kiwi_res_h kiwi_analyze(kiwi_h handle, const char* text, int top_n, kiwi_analyze_option_t option, kiwi_pretokenized_h pretokenized);        /* capi.h:698 */
 int kiwi_analyze_mw(kiwi_h handle, kiwi_reader_w_t reader, kiwi_receiver_t receiver, void* user_data, int top_n, kiwi_analyze_option_t option); /* capi.h:711 */

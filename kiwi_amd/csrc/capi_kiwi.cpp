@@ -5,6 +5,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <sys/stat.h>
@@ -180,11 +181,19 @@ extern "C"
 	// ---- typo transformers (capi.h:459-588; src/capi/kiwi_c.cpp:540-715).
 	kiwi_typo_h kiwi_typo_init() { try { return new kiwi_typo; } catch (const std::exception& e) { setError(e); return nullptr; } }
 	kiwi_typo_h kiwi_typo_get_basic() { return kiwi_typo_get_default(1); }
-	kiwi_typo_h kiwi_typo_get_default(int)
+	kiwi_typo_h kiwi_typo_get_default(int set)
 	{
-		// the built-in sets are rule tables of the reference (src/TypoTransformer.cpp:1058-1254), i.e. its data: not shipped here
-		setError(std::runtime_error{ "kiwi_amd: the built-in typo sets are not shipped with this library; build the set with kiwi_typo_add" });
-		return nullptr;
+		// the handle of a built-in set lives for the process and must not be closed (capi.h:494-501; the reference returns the address of a static)
+		try
+		{
+			static kiwi_typo* sets[7] = {};
+			static std::mutex mu;
+			const TypoTransformer& tt = kamd::defaultTypoSet(set);      // throws for ids outside 0..6
+			std::lock_guard<std::mutex> g{ mu };
+			if (!sets[set]) sets[set] = new kiwi_typo{ tt };
+			return sets[set];
+		}
+		catch (const std::exception& e) { setError(e); return nullptr; }
 	}
 	int kiwi_typo_add(kiwi_typo_h h, const char** orig, int orig_size, const char** error, int error_size, float cost, int condition)
 	{
@@ -228,13 +237,25 @@ extern "C"
 	{
 		try
 		{
-			(void)options;
+			// options (capi.h:158-171; kiwi_c.cpp:717-736): bit 0 = integrateAllomorph (KiwiBuilder.cpp:2413); bits 1-3 ask for dictionaries that a raw
+			// container already has baked in (or not) -- they cannot change anything here; 0x0F00 = model type
+			if (options & ~0x0F0F) throw std::invalid_argument{ "kiwi_amd: unknown build option bits" };
+			Engine::LmMode lm;
+			switch (options & 0x0F00)
+			{
+			case 0x0000: case 0x0200: lm = Engine::LmMode::Knlm; break;   // default: with skip-bigram tables present the reference still picks knlm (KiwiBuilder.cpp:939-961)
+			case 0x0100: lm = Engine::LmMode::Auto; break;                  // largest: sbg when present
+			case 0x0300: lm = Engine::LmMode::Sbg; break;
+			case 0x0400: case 0x0500: throw std::invalid_argument{ "kiwi_amd: CoNgram models are not supported on the device path yet" };
+			default: throw std::invalid_argument{ "kiwi_amd: unknown model type" };
+			}
 			if (enabled_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported" };
 			std::string path = model_path ? model_path : "";
 			struct stat st;
 			if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) path += "/kiwi_amd.raw";
 			auto h = std::make_unique<kiwi_s>();
-			h->engine.reset(new Engine(path, -1));
+			h->engine.reset(new Engine(path, -1, lm));
+			h->engine->config.integrateAllomorph = !!(options & 1);
 			h->numThreads = num_threads < 0 ? 0 : (num_threads == 0 ? 1 : num_threads);
 			return h.release();
 		}
@@ -275,6 +296,19 @@ extern "C"
 		if (option == KIWI_NUM_THREADS) h->numThreads = value;
 		else if (option == KIWI_GPU_BATCH_SIZE && value > 0) h->batchSize = value;
 		else { currentError = "Invalid option value: " + std::to_string(option); hasError = true; }
+	}
+
+	// capi.h:644-652; kiwi_c.cpp:826-849: no float option exists any more (deprecated in favour of the global config) -- every id is invalid
+	void kiwi_set_option_f(kiwi_h h, int option, float)
+	{
+		if (!h) return;
+		currentError = "Invalid option value: " + std::to_string(option); hasError = true;
+	}
+	float kiwi_get_option_f(kiwi_h h, int option)
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		currentError = "Invalid option value: " + std::to_string(option); hasError = true;
+		return KIWIERR_INVALID_INDEX;
 	}
 
 	int kiwi_get_option(kiwi_h h, int option)

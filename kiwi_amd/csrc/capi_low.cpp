@@ -155,6 +155,11 @@ extern "C"
 		return guarded([&]() { auto* t = new kamd_typo; t->tt.setContinualCost(continual_cost); t->tt.setLengtheningCost(lengthening_cost); return t; }, (kamd_typo*)nullptr);
 	}
 	void kamd_typo_close(kamd_typo* t) { delete t; }
+	// a copy of one of Kiwi's built-in sets (DefaultTypoSet id 0..6): the caller owns it
+	kamd_typo* kamd_typo_default(int set)
+	{
+		return guarded([&]() { auto* t = new kamd_typo; t->tt = defaultTypoSet(set); return t; }, (kamd_typo*)nullptr);
+	}
 	int kamd_typo_add(kamd_typo* t, const uint16_t* orig, uint32_t n_orig, const uint16_t* error, uint32_t n_error, float cost, int left_cond, int dialect)
 	{
 		if (!t) return -2;

@@ -190,9 +190,11 @@ namespace kamd
 		}
 	};
 
-	Engine::Engine(const std::string& path, int device) : impl(new Impl)
+	Engine::Engine(const std::string& path, int device, LmMode lm) : impl(new Impl)
 	{
 		bakeModel(impl->model, path);
+		if (lm == LmMode::Sbg && impl->model.sbgPtrs.empty()) throw std::runtime_error{ "Cannot open required files for skipbigram model" };   // KiwiBuilder.cpp:1008-1013
+		if (lm == LmMode::Knlm) { impl->model.sbgPtrs.clear(); impl->model.sbgKeys.clear(); impl->model.sbgComps.clear(); impl->model.sbgDiscnts.clear(); impl->model.sbgValid.clear(); }
 		if (!impl->model.sbgPtrs.empty() && impl->model.sbgWindow != 8)
 			throw std::runtime_error{ "kiwi_amd: SkipBigram window size must be 8 (the reference instantiates SbgState<8> only, src/SkipBigramModel.cpp)" };
 		int nDev = 0;

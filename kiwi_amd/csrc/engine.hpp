@@ -59,7 +59,10 @@ namespace kamd
 		std::unique_ptr<Impl> impl;
 	public:
 		EngineConfig config;
-		explicit Engine(const std::string& rawModelPath, int device = -1);
+		// which language model of the container scores the search (reference ModelType, include/kiwi/Types.h:292-335): Auto = SkipBigram when the
+		// container carries its tables, else Knlm; Knlm = Knlm even then; Sbg = SkipBigram or an error
+		enum class LmMode { Auto, Knlm, Sbg };
+		explicit Engine(const std::string& rawModelPath, int device = -1, LmMode lm = LmMode::Auto);
 		~Engine();
 		const FlatModel& model() const;
 

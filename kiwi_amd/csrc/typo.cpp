@@ -126,6 +126,54 @@ namespace kamd
 		lengtheningCost_ = std::min(lengtheningCost_, o.lengtheningCost_);
 	}
 
+	TypoTransformer TypoTransformer::withDialect(uint16_t dialect) const
+	{
+		TypoTransformer ret;
+		for (auto& p : typos_) ret.typos_.emplace(Key{ p.first.orig, p.first.error, p.first.cond, dialect }, p.second);
+		ret.continualCost_ = continualCost_; ret.lengtheningCost_ = lengtheningCost_;
+		return ret;
+	}
+
+	namespace
+	{
+#include "typo_sets.inc"
+		template<size_t N> void addRows(TypoTransformer& t, const TypoDefRow(&rows)[N])
+		{
+			auto split = [](const char16_t* s) { std::vector<std::u16string> v(1); for (; *s; ++s) { if (*s == u'|') v.emplace_back(); else v.back().push_back(*s); } return v; };
+			for (const TypoDefRow& r : rows)
+				for (const auto& o : split(r.origs)) for (const auto& e : split(r.errors)) t.add(o, e, r.cost, r.cond, 0);      // TypoTransformer::addTypos (include/kiwi/TypoTransformer.h:309-321)
+		}
+		TypoTransformer unite(TypoTransformer a, const TypoTransformer& b) { a.update(b); return a; }      // operator| (TypoTransformer.h:396-401)
+	}
+
+	const TypoTransformer& defaultTypoSet(int set)
+	{
+		enum : uint16_t { D_GANGWON = 1 << 2, D_GYEONGSANG = 1 << 3, D_JEJU = 1 << 5, D_HAMGYEONG = 1 << 7 };      // Dialect (include/kiwi/Types.h:322-335)
+		static const TypoTransformer withoutTypo;
+		static const TypoTransformer basic = [] { TypoTransformer t; addRows(t, kTypoBasic); return t; }();
+		static const TypoTransformer continual = [] { TypoTransformer t; t.setContinualCost(1.f); addRows(t, kTypoContinual); return t; }();
+		static const TypoTransformer basicWithContinual = unite(basic, continual);
+		static const TypoTransformer lengthening = [] { TypoTransformer t; t.setLengtheningCost(0.25f); return t; }();
+		static const TypoTransformer basicWithContinualAndLengthening = unite(basicWithContinual, lengthening);
+		static const TypoTransformer dialect = []
+		{
+			TypoTransformer a, b, c, d;
+			addRows(a, kTypoDialectJeju); addRows(b, kTypoDialectHamgyeong); addRows(c, kTypoDialectNorthEast); addRows(d, kTypoDialectGyeongsang);
+			return unite(unite(unite(a.withDialect(D_JEJU), b.withDialect(D_HAMGYEONG)), c.withDialect(D_HAMGYEONG | D_GYEONGSANG | D_GANGWON)), d.withDialect(D_GYEONGSANG));
+		}();
+		switch (set)
+		{
+		case 0: return withoutTypo;
+		case 1: return basic;
+		case 2: return continual;
+		case 3: return basicWithContinual;
+		case 4: return lengthening;
+		case 5: return basicWithContinualAndLengthening;
+		case 6: return dialect;
+		default: throw std::invalid_argument{ "Invalid `DefaultTypoSet`" };
+		}
+	}
+
 	void TypoTransformer::scaleCost(float scale)
 	{
 		if (!std::isfinite(scale) || scale <= 0) throw std::invalid_argument{ "`scale` must be positive real." };

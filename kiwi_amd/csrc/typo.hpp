@@ -3,8 +3,7 @@
 //   TypoTransformer::addTypo / update / scaleCost        /root/reference/src/TypoTransformer.cpp:224-373
 //   PreparedTypoTransformer (prepare)                    src/TypoTransformer.cpp:375-486
 //   PreparedTypoTransformer::generateGraph               src/TypoTransformer.cpp:594-628, 811-1049
-// STATUS: building block.  The device kernels that build a lattice over such a graph are not written yet, so the analyze entry points
-// still refuse typo transformers (capi_kiwi.cpp); this module is exercised by tests/test_typo_product.py through kamd_typo_*.
+// The lattice over such a graph is built by typo_lattice_kernel.hip; tests: tests/test_typo_product.py (host), tests/test_gpu_typo.py (device).
 //
 // Layout for the device (flat arrays, uploaded as they are): the pattern automaton is a CSR trie like the form trie (node = edge range,
 // failure link, pattern id or "a shorter pattern ends here" mark; sorted u16 keys; children), patterns index a replacement table, every
@@ -37,6 +36,7 @@ namespace kamd
 		void addEntry(const std::u16string& orig, const std::u16string& error, float cost, uint8_t cond, uint16_t dialect);                    // one entry of update()
 		void update(const TypoTransformer& o);
 		void scaleCost(float scale);
+		TypoTransformer withDialect(uint16_t dialect) const;      // copyWithDialectOverriding (src/TypoTransformer.cpp:325-336)
 		void setContinualCost(float c) { continualCost_ = c; }
 		void setLengtheningCost(float c) { lengtheningCost_ = c; }
 		float continualCost() const { return continualCost_; }
@@ -50,6 +50,10 @@ namespace kamd
 		Map typos_;
 		float continualCost_ = INFINITY, lengtheningCost_ = INFINITY;
 	};
+
+	// Kiwi's built-in typo sets (reference getDefaultTypoSet, src/TypoTransformer.cpp:1058-1254; DefaultTypoSet ids 0..6 = capi.h:485-491):
+	// assembled once from the rule tables of typo_sets.inc; throws std::invalid_argument for any other id.  The objects live for the process.
+	const TypoTransformer& defaultTypoSet(int set);
 
 	struct TypoGraphNode      // TypoGraphNode of the reference (include/kiwi/TypoTransformer.h:131-157), form as a span
 	{

@@ -533,6 +533,8 @@ extern "C"
 		w.put<float>(tt.getContinualTypoCost()); w.put<float>(tt.getLengtheningTypoCost());
 		return w.need;
 	}
+	// a copy of a built-in set itself (what kiwi_typo_get_default hands to kiwi_typo_prepare)
+	void* kref_typo_from_default(int set) { auto* h = new TypoHandle; h->tt = kiwi::getDefaultTypoSet((kiwi::DefaultTypoSet)set); return h; }
 	// update(built-in set): what a client does with `TypoTransformer tt; tt |= getDefaultTypoSet(set)`
 	void kref_typo_update_default(void* hp, int set) { ((TypoHandle*)hp)->tt.update(kiwi::getDefaultTypoSet((kiwi::DefaultTypoSet)set)); }
 	void kref_typo_prepare(void* hp, int inverse) { auto* h = (TypoHandle*)hp; h->ptt.reset(new kiwi::PreparedTypoTransformer{ h->tt, inverse != 0 }); }

@@ -256,6 +256,16 @@ class RefTypo:
         if self.lib.kref_typo_add(self.h, o.ctypes.data, len(o), e.ctypes.data, len(e), cost, COND[cond] if isinstance(cond, str) else cond, dialect) != 0:
             raise ValueError((orig, error))
 
+    @classmethod
+    def from_default(cls, set_name):
+        """A copy of the built-in set itself (kiwi_typo_get_default)."""
+        self = cls()
+        self.lib.kref_typo_close(self.h)
+        self.lib.kref_typo_from_default.restype = C.c_void_p
+        self.lib.kref_typo_from_default.argtypes = [C.c_int]
+        self.h = self.lib.kref_typo_from_default(DEFAULT_TYPO_SETS[set_name])
+        return self
+
     def update_default(self, set_name):
         self.lib.kref_typo_update_default(self.h, DEFAULT_TYPO_SETS[set_name])
 

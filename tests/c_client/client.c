@@ -5,7 +5,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef KIWI_CLIENT_REFERENCE_HEADER
+#include <kiwi/capi.h>      /* the reference's own header: -I/root/reference/include */
+#else
 #include "kiwi_capi.h"
+#endif
 
 typedef struct { char** lines; int n; } corpus_t;
 
@@ -51,7 +55,7 @@ int main(int argc, char** argv)
 		c.lines[c.n++] = strdup(line);
 	}
 	fclose(f);
-	k = kiwi_init(argv[1], 0, 0, 0);
+	k = kiwi_init(argv[1], 0, KIWI_BUILD_DEFAULT, 0);
 	if (!k) { fprintf(stderr, "kiwi_init: %s\n", kiwi_error()); return 1; }
 	memset(&opt, 0, sizeof(opt));
 	opt.match_options = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 23) | (1 << 16);   /* KIWI_MATCH_ALL_WITH_NORMALIZING */

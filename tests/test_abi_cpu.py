@@ -43,3 +43,37 @@ def test_product_sources_do_not_reference_the_oracle():
                 continue
             text = open(os.path.join(dp, f), encoding="utf-8", errors="ignore").read()
             assert "oracle/" not in text.replace("oracle/ref_bridge.cpp", "").replace("oracle/_ref", "").replace("oracle's korc_split", "") or f in ("synth.py",), (dp, f)
+
+
+def test_c_client_compiles_against_the_reference_header(tmp_path):
+    """The drop-in claim at the source level: tests/c_client/client.c compiled against the REFERENCE's own include/kiwi/capi.h (not this
+    repo's header) links with the product library -- every function it uses exists with a declaration gcc accepts -- and, declaration
+    by declaration, this repo's header agrees with the reference's on every function both declare (same return and parameter types)."""
+    import re
+    import subprocess
+    ref_hdr = "/root/reference/include/kiwi/capi.h"
+    if not os.path.exists(ref_hdr):
+        pytest.skip("/root/reference is not present on this box")
+    _lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "client_refhdr")
+    subprocess.check_call(["gcc", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-Werror", "-DKIWI_CLIENT_REFERENCE_HEADER", "-I/root/reference/include",
+                           os.path.join(root, "tests", "c_client", "client.c"), api.LIB_PATH, "-o", exe])
+
+    def decls(path):
+        text = open(path, encoding="utf-8").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", " ", text)
+        text = re.sub(r"^\s*#[^\n]*", ";", text, flags=re.M)      # preprocessor lines end a declaration context
+        out = {}
+        for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(kiwi_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text):
+            ret = re.sub(r"\b(DECL_DLL|extern)\b", " ", m.group(1))
+            norm = lambda s: re.sub(r"\s+", " ", re.sub(r"\s*\*\s*", "* ", s)).strip()
+            params = [norm(re.sub(r"\b[a-z_][a-z0-9_]*$", "", p.strip())) if not p.strip().endswith("*") else norm(p) for p in m.group(3).split(",")]
+            out[m.group(2)] = (norm(ret), [p.replace("const char* *", "const char**") for p in params])
+        return out
+    mine, ref = decls(os.path.join(root, "include", "kiwi_capi.h")), decls(ref_hdr)
+    shared = sorted(set(mine) & set(ref))
+    assert len(shared) >= 45, shared
+    bad = [(n, mine[n], ref[n]) for n in shared if mine[n] != ref[n]]
+    assert not bad, bad

@@ -113,7 +113,7 @@ def from_oracle(res):
 
 @pytest.fixture(scope="module")
 def kiwi(capi, small_model):
-    k = capi.kiwi_init(small_model[1].encode(), 0, 0, 0)
+    k = capi.kiwi_init(small_model[1].encode(), 0, 15, 0)      # KIWI_BUILD_DEFAULT
     assert k, capi.kiwi_error()
     yield k
     assert capi.kiwi_close(k) == 0
@@ -244,15 +244,23 @@ def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
     assert not capi.kiwi_analyze(kiwi, s.encode(), 1, o, None)               # blocklists are a later row
 
 
-def test_c_client_program(oracle, small_model, tmp_path):
+@pytest.mark.parametrize("header", ["kiwi_capi.h", "reference capi.h"])
+def test_c_client_program(oracle, small_model, tmp_path, header):
     """a plain C program written against the C API header only is compiled with gcc, linked to the
-    library and run on a corpus; its printed tokens equal the oracle's."""
+    library and run on a corpus; its printed tokens equal the oracle's.  Once against this repo's header, once against the REFERENCE's
+    own include/kiwi/capi.h (the actual drop-in claim): that binary is built where /root/reference exists (tests/c_client/Makefile,
+    __graft_entry__.build()) and travels to the GPU box."""
     import subprocess
     sm, path = small_model
     root = os.path.dirname(HERE)
-    exe = str(tmp_path / "kiwi_client")
-    subprocess.check_call(["gcc", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(HERE, "c_client", "client.c"),
-                           LIB, "-Wl,-rpath," + os.path.dirname(LIB), "-o", exe])
+    if header == "kiwi_capi.h":
+        exe = str(tmp_path / "kiwi_client")
+        subprocess.check_call(["gcc", "-std=c99", "-D_GNU_SOURCE", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(HERE, "c_client", "client.c"),
+                               LIB, "-Wl,-rpath," + os.path.dirname(LIB), "-o", exe])
+    else:
+        exe = os.path.join(HERE, "c_client", "_build", "client_refhdr")
+        if not os.path.exists(exe):
+            pytest.skip("tests/c_client/_build/client_refhdr not built (needs /root/reference/include/kiwi/capi.h)")
     texts = [t for t in synthetic(sm, 200, 171, min_jamo=5, max_jamo=100) if "\n" not in t and "\r" not in t and t.strip()]
     corpus = tmp_path / "corpus.txt"
     corpus.write_text("\n".join(texts) + "\n", encoding="utf-8")
@@ -297,7 +305,7 @@ def test_typo_transformer_through_the_c_api(capi, kiwi, small_model):
     L.kiwi_prepared_typo_close.argtypes = [C.c_void_p]
     L.kiwi_res_typo_cost.restype = C.c_float
     L.kiwi_res_typo_cost.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    assert not L.kiwi_typo_get_default(1) and b"not shipped" in L.kiwi_error()
+    assert not L.kiwi_typo_get_default(7) and b"DefaultTypoSet" in L.kiwi_error()
     part, whole = L.kiwi_typo_init(), L.kiwi_typo_init()
     orc_t = oraclelib.OracleTypo(1.0, 0.25)
     for origs, errs, cost, cond, dia in RULES:
@@ -334,3 +342,27 @@ def test_typo_transformer_through_the_c_api(capi, kiwi, small_model):
     L.kiwi_prepared_typo_close(prepared)
     for h in (part, whole, copy):
         assert L.kiwi_typo_close(h) == 0
+    # the built-in sets (kiwi_typo_get_default; the reference's --typo configurations): against the REAL reference analysing with its own set
+    import refbridge
+    if refbridge.available():
+        ref = refbridge.RefKiwi(path)
+        for name, sid in (("basic", 1), ("basic_with_continual_and_lengthening", 5)):
+            builtin = L.kiwi_typo_get_default(sid)
+            assert builtin, L.kiwi_error()
+            assert builtin == (L.kiwi_typo_get_basic() if sid == 1 else L.kiwi_typo_get_default(sid))      # one static object per set
+            prepared = L.kiwi_typo_prepare(builtin)
+            rt = refbridge.RefTypo.from_default(name); rt.prepare(True)
+            opt = Option(MATCH_ALL_WITH_NORMALIZING, None, 0, 0, 3.0, prepared, 2.5)
+            corrected = 0
+            for t in [misspell(x, rnd, True, True, sid == 5) for x in synthetic(sm, 60, 183, min_jamo=5, max_jamo=80)]:
+                r = L.kiwi_analyze(kiwi, t.encode("utf-8"), 1, opt, None)
+                assert r, L.kiwi_error()
+                want = ref.analyze_typo(rt, t, 2.5, 0)
+                toks = want[0][0]
+                assert L.kiwi_res_word_num(r, 0) == len(toks) and L.kiwi_res_prob(r, 0) == want[0][1], (name, t)
+                for k, tok in enumerate(toks):
+                    assert L.kiwi_res_form(r, 0, k).decode("utf-8") == tok.form and L.kiwi_res_typo_cost(r, 0, k) == tok.typo_cost, (name, t, k)
+                    corrected += tok.typo_cost > 0
+                L.kiwi_res_close(r)
+            assert corrected > 5, name
+            L.kiwi_prepared_typo_close(prepared)

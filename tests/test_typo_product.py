@@ -1,6 +1,6 @@
-"""CPU (not gpu): the product's host-side typo module (kiwi_amd/csrc/typo.cpp through kamd_typo_*: rule container, prepare(), typo graph)
-against the oracle's -- and so, transitively and where oracle/_ref is present directly, against the real reference -- byte for byte.
-The module is a building block: the analyze calls do not take a typo transformer yet (no lattice kernel over typo graphs)."""
+"""CPU (not gpu): the product's host-side typo module (kiwi_amd/csrc/typo.cpp through kamd_typo_*: rule container, prepare(), typo graph, the
+shipped built-in sets) against the oracle's -- and so, transitively and where oracle/_ref is present directly, against the real reference --
+byte for byte.  The analysis with a transformer is tests/test_gpu_typo.py."""
 import ctypes as C
 import os
 
@@ -103,3 +103,26 @@ def test_product_builtin_sets_equal_reference(name):
     for t in texts(100, 53):
         assert _ref_bytes(ref, t, dia) == prod.graph_bytes(t, dia), (name, t)
     prod.close()
+
+
+@pytest.mark.parametrize("name", ["without", "basic", "continual", "basic_with_continual", "lengthening", "basic_with_continual_and_lengthening", "dialect"])
+def test_shipped_builtin_sets_equal_reference(name):
+    """kamd_typo_default / kiwi_typo_get_default: the sets assembled by the product from its own copy of the rule tables
+    (kiwi_amd/csrc/typo_sets.inc + typo.cpp defaultTypoSet) give the graphs of the reference's getDefaultTypoSet objects themselves."""
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    from test_typo_oracle import _ref_bytes
+    ref = refbridge.RefTypo.from_default(name); ref.prepare(True)
+    prod = ProductTypo()
+    prod.close()
+    prod.lib.kamd_typo_default.restype = C.c_void_p
+    prod.lib.kamd_typo_default.argtypes = [C.c_int]
+    prod.h = prod.lib.kamd_typo_default(refbridge.DEFAULT_TYPO_SETS[name])
+    assert prod.h
+    prod.prepare(True)
+    for dia in ((0, 0xFFFF, 8) if name == "dialect" else (0,)):
+        for t in texts(100, 57):
+            assert _ref_bytes(ref, t, dia) == prod.graph_bytes(t, dia), (name, dia, t)
+    prod.close()
+    assert not prod.lib.kamd_typo_default(7)
