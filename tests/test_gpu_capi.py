@@ -261,6 +261,8 @@ def test_c_client_program(oracle, small_model, tmp_path, header):
         exe = os.path.join(HERE, "c_client", "_build", "client_refhdr")
         if not os.path.exists(exe):
             pytest.skip("tests/c_client/_build/client_refhdr not built (needs /root/reference/include/kiwi/capi.h)")
+        if os.environ.get("KAMD_TEST_LIB"):
+            pytest.skip("the prebuilt binary is linked with the product library, not with the library under test")
     texts = [t for t in synthetic(sm, 200, 171, min_jamo=5, max_jamo=100) if "\n" not in t and "\r" not in t and t.strip()]
     corpus = tmp_path / "corpus.txt"
     corpus.write_text("\n".join(texts) + "\n", encoding="utf-8")
