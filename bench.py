@@ -58,6 +58,29 @@ def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None):
     return out
 
 
+def model_facts(workload):
+    """Facts of the synthetic model a workload runs on (SURVEY.md section 8(d) asks for order 4 / 2^20 n-gram nodes; the generator packs an n-gram
+    into 63 bits, which caps the 'full' model at order 3 -- stated here rather than implied)."""
+    import struct
+    from dataclasses import asdict
+    from kiwi_amd.container import read_container
+    from kiwi_amd.workloads import DATA, WORKLOADS, _spec
+    spec_name = WORKLOADS[workload][0]
+    sp = asdict(_spec(spec_name))
+    out = {"spec": spec_name, "knlm_order": sp.get("lm_order"), "dictionary_words": sp.get("n_words"), "skipbigram": bool(sp.get("use_sbg"))}
+    try:
+        _, sec = read_container(os.path.join(DATA, f"{spec_name}.raw"))
+        for name, a in sec.items():
+            if name.lower().startswith("knlm") and a.nbytes >= 96:
+                out["knlm_nodes"] = struct.unpack_from("<Q", a.tobytes()[:8])[0]
+                out["knlm_bytes"] = int(a.nbytes)
+            if "form" in name.lower() and "ptr" in name.lower():
+                out["forms"] = int(a.nbytes // 4 - 1)
+    except Exception:
+        pass
+    return out
+
+
 def measured_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, separate
     rocprofv3 --pmc runs of this same command; see profiles/README.md).  None when no measurement of this workload is on file."""
@@ -78,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank analyses a batch of the workload's size; strong: ONE corpus split over the ranks by index (text i -> rank i %% N)")
     ap.add_argument("--limit", type=int, default=0, help="diagnostics: only the first N sentences of the workload (named in config.workload)")
     args = ap.parse_args()
 
@@ -98,8 +123,10 @@ def main():
         texts = texts[:args.limit]
         desc += f" [first {args.limit} sentences only]"
     # weak scaling: every rank analyses a same-sized shard; rotate so shards differ
-    n = len(texts)
-    shard = dist.weak_shard(texts, rank)
+    strong = args.scaling == "strong" and world > 1
+    shard = [texts[i] for i in dist.shard_indices(len(texts), rank, world)] if strong else dist.weak_shard(texts, rank)
+    n = len(shard)
+    n_job = len(texts) if strong else n * world      # sentences the whole job analyses per step
 
     top_n = workload_top_n(args.workload)
     eng = KiwiAmd(model_path, local_rank)
@@ -152,7 +179,7 @@ def main():
             r.close()
         sync()
         e2e_elapsed = dist.max_over_ranks(time.perf_counter() - te, device="cuda" if world > 1 else "cpu")
-        e2e = {"value": n * world * e2e_steps / e2e_elapsed, "unit": "sentences/s", "ms_per_batch": 1000.0 * e2e_elapsed / e2e_steps, "steps": e2e_steps,
+        e2e = {"value": n_job * e2e_steps / e2e_elapsed, "unit": "sentences/s", "ms_per_batch": 1000.0 * e2e_elapsed / e2e_steps, "steps": e2e_steps,
                "region": "host UTF-16 strings -> kamd_analyze_batch -> host token records (text preparation, H2D, kernels, D2H, result assembly)",
                "h2d_bytes_per_batch": int(flat.nbytes), "d2h_bytes_per_batch": d2h}
 
@@ -163,16 +190,40 @@ def main():
     summary = dist.gather_counts([n, n_tok], device="cuda" if world > 1 else "cpu")   # the only result "gather": per-rank counts
     assert len(summary) == world
 
+    # The final result gather (the path's only exchange step): every rank packs its token records, the packed buffers are gathered on rank 0
+    # over the process group (RCCL over xGMI; device tensors) and merged -- in input order when the corpus was split by index.  Outside the timed
+    # regions above: `value` is device-resident by contract; the gather's own time is reported.
+    gather = None
+    if world > 1:
+        from kiwi_amd.api import Results
+        packed = res.pack()
+        sync()
+        tg = time.perf_counter()
+        parts = dist.gather_packed(packed, device="cuda")
+        merged_texts = 0
+        if rank == 0:
+            if strong:
+                m = Results.merge_strided(eng.lib, parts); merged_texts = m.n_texts(); m.close()
+            else:
+                for p in parts:
+                    m = Results.merge_strided(eng.lib, [p]); merged_texts += m.n_texts(); m.close()
+        sync()
+        gather = {"ms": 1000.0 * (time.perf_counter() - tg), "bytes_per_rank": int(packed.nbytes), "merged_texts": merged_texts,
+                  "what": "all-gather of packed sizes + gather of packed token records to rank 0 (kiwi_amd.dist.gather_packed) + merge" + (" in input order" if strong else "")}
+        if rank == 0:
+            assert merged_texts == n_job, (merged_texts, n_job)
+
     if rank == 0:
-        total_sent = n * world * args.steps
+        total_sent = n_job * args.steps
         value = total_sent / elapsed
         out = {
             "metric": "sentences/sec on batched analyze(), device kernels with inputs resident in HBM (dictionary scan + lattice + Viterbi/%s, top-%d); host-to-host rate: see e2e" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "Knlm, typo correction" if typo is not None else "Knlm", top_n),
             "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "int32+f32", "data": "synthetic",
             "config": {"workload": desc, "sentences_per_gpu": n, "chunks_per_gpu": info["chunks"], "jamo_per_gpu": info["units"],
                        "parallelism": f"shard{world}", "m_jamo_per_s": info["units"] * world * args.steps / elapsed / 1e6,
+                       "model": model_facts(args.workload),
                        "kernel_ms": kt, "device_bytes": info["device_bytes"]},
         }
         if not args.no_cpu_baseline:
@@ -188,6 +239,8 @@ def main():
                 e2e["vs_cpu_baseline"] = e2e["value"] / cb["cpu_baseline"]["value"]
         if e2e is not None:
             out["e2e"] = e2e
+        if gather is not None:
+            out["gather"] = gather
         print(json.dumps(out))
     res.close()
     batch.close()

@@ -64,6 +64,11 @@ const uint16_t* kamd_res_forms(kamd_results_h r, uint32_t text);
 /* bytes the device -> host copy of this batch moved (chunk summaries + the path headers and token records actually produced) */
 uint64_t kamd_res_d2h_bytes(kamd_results_h r);
 void kamd_res_close(kamd_results_h r);
+/* Multi-GPU result gather (one process per GPU; the path shards by independent texts): a rank packs its results into one
+ * position-independent buffer (returns the size needed; writes when cap suffices), ships it to the gathering rank (RCCL / gloo: kiwi_amd/dist.py),
+ * which merges the parts of an index-strided split (text g -> part g % n_parts) back into input order. */
+size_t kamd_res_pack(kamd_results_h r, uint8_t* out, size_t cap);
+kamd_results_h kamd_res_merge_strided(const uint8_t* const* parts, const size_t* sizes, uint32_t n_parts);
 
 /* test hooks: baked dictionary dump and the lattices of one text, in the byte layouts of oracle/ref_bridge.cpp */
 /* developer probe: exp_out[i] = expf, log_out[i] = logf of x[i] computed ON THE DEVICE by csrc/exact_math.hpp (bit-identical to glibc) */

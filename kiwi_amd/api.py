@@ -82,6 +82,10 @@ def load_library(lib_path=None):
     L.kamd_res_d2h_bytes.restype = C.c_uint64
     L.kamd_res_d2h_bytes.argtypes = [C.c_void_p]
     L.kamd_res_close.argtypes = [C.c_void_p]
+    L.kamd_res_pack.restype = C.c_size_t
+    L.kamd_res_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.kamd_res_merge_strided.restype = C.c_void_p
+    L.kamd_res_merge_strided.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.kamd_dump_dict.restype = C.c_size_t
     L.kamd_dump_dict.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.kamd_dump_lattices.restype = C.c_size_t
@@ -122,6 +126,25 @@ class Results:
 
     def d2h_bytes(self):
         return int(self.lib.kamd_res_d2h_bytes(self.h))
+
+    def pack(self) -> np.ndarray:
+        """The results as one position-independent byte buffer (kamd_res_pack): what a rank ships to the gathering rank."""
+        n = self.lib.kamd_res_pack(self.h, None, 0)
+        buf = np.zeros(n, np.uint8)
+        if self.lib.kamd_res_pack(self.h, buf.ctypes.data, n) != n:
+            raise RuntimeError("kamd_res_pack failed: " + self.lib.kamd_last_error().decode())
+        return buf
+
+    @classmethod
+    def merge_strided(cls, lib, parts):
+        """Packed results of an index-strided split (text g -> part g % len(parts)) merged back into input order."""
+        parts = [np.ascontiguousarray(p, np.uint8) for p in parts]
+        ptrs = (C.c_void_p * len(parts))(*[p.ctypes.data for p in parts])
+        sizes = (C.c_size_t * len(parts))(*[p.nbytes for p in parts])
+        h = lib.kamd_res_merge_strided(ptrs, sizes, len(parts))
+        if not h:
+            raise RuntimeError("kamd_res_merge_strided failed: " + lib.kamd_last_error().decode())
+        return cls(lib, h)
 
     def token_array(self, text, index=0):
         n = self.lib.kamd_res_token_num(self.h, text, index)

@@ -9,6 +9,8 @@
 #include <stdexcept>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
+#include <cstdlib>
 #include "../../include/kiwi_capi.h"
 #include "engine.hpp"
 #include "typo.hpp"
@@ -17,9 +19,12 @@ using namespace kamd;
 
 struct kiwi_s
 {
-	std::unique_ptr<Engine> engine;
+	std::unique_ptr<Engine> engine;                      // device 0: single-text calls, configuration
+	std::vector<std::unique_ptr<Engine>> replicas;       // devices 1 .. N-1 (every visible GPU, or KAMD_DEVICES of them): kiwi_analyze_m / _mw spread a batch over all
 	int numThreads = 0;
 	int batchSize = 65536;
+	Engine& device(size_t d) { return d == 0 ? *engine : *replicas[d - 1]; }
+	size_t devices() const { return 1 + replicas.size(); }
 };
 
 struct kiwi_typo { kamd::TypoTransformer tt; };                       // capi.h:35
@@ -154,8 +159,35 @@ namespace
 			if (texts.empty()) break;
 			std::vector<std::pair<const char16_t*, size_t>> views;
 			for (auto& t : texts) views.emplace_back(t.data(), t.size());
-			auto res = h->engine->analyzeBatch(views, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt));
-			for (size_t i = 0; i < texts.size(); ++i) (*receiver)(receiverIdx++, makeRes(res, i), ud);   // in input order; the receiver owns the result
+			// One host process drives every GPU (the reference's driver keeps a thread pool busy, include/kiwi/Kiwi.h:402-454): the batch is cut into
+			// contiguous parts of about equal text volume, part d is analysed by the engine of device d on its own thread, results are delivered in
+			// input order.  (Texts are independent: no exchange between the devices; each holds a replica of the model tables.)
+			const size_t nDev = std::min(h->devices(), std::max<size_t>(1, texts.size() / 64));
+			std::vector<size_t> cut(nDev + 1, 0);
+			{
+				size_t total = 0; for (auto& t : texts) total += t.size() + 8;
+				size_t acc = 0, d = 1;
+				for (size_t i = 0; i < texts.size() && d < nDev; ++i) { acc += texts[i].size() + 8; if (acc * nDev >= total * d) cut[d++] = i + 1; }
+				for (; d <= nDev; ++d) cut[d] = texts.size();
+			}
+			std::vector<BatchResults> parts(nDev);
+			std::vector<std::exception_ptr> errs(nDev);
+			auto work = [&](size_t d)
+			{
+				try
+				{
+					std::vector<std::pair<const char16_t*, size_t>> v(views.begin() + cut[d], views.begin() + cut[d + 1]);
+					parts[d] = h->device(d).analyzeBatch(v, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt));
+				}
+				catch (...) { errs[d] = std::current_exception(); }
+			};
+			std::vector<std::thread> workers;
+			for (size_t d = 1; d < nDev; ++d) workers.emplace_back(work, d);
+			work(0);
+			for (auto& w : workers) w.join();
+			for (auto& e : errs) if (e) std::rethrow_exception(e);
+			for (size_t d = 0; d < nDev; ++d)
+				for (size_t i = cut[d]; i < cut[d + 1]; ++i) (*receiver)(receiverIdx++, makeRes(parts[d], i - cut[d]), ud);   // in input order; the receiver owns the result
 		}
 		return readerIdx;
 	}
@@ -254,8 +286,12 @@ extern "C"
 			struct stat st;
 			if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) path += "/kiwi_amd.raw";
 			auto h = std::make_unique<kiwi_s>();
-			h->engine.reset(new Engine(path, -1, lm));
+			h->engine.reset(new Engine(path, 0, lm));
 			h->engine->config.integrateAllomorph = !!(options & 1);
+			// a replica of the device tables on every other visible GPU (KAMD_DEVICES=n limits it; 1 = single-GPU behaviour)
+			int nDev = Engine::visibleDevices();
+			if (const char* e = std::getenv("KAMD_DEVICES")) nDev = std::max(1, std::min(nDev, std::atoi(e)));
+			for (int d = 1; d < nDev; ++d) h->replicas.emplace_back(new Engine(*h->engine, d));
 			h->numThreads = num_threads < 0 ? 0 : (num_threads == 0 ? 1 : num_threads);
 			return h.release();
 		}
@@ -276,6 +312,7 @@ extern "C"
 		g.integrateAllomorph = !!c.integrate_allomorph; g.cutOffThreshold = c.cut_off_threshold; g.oovRuleScale = c.oov_rule_scale; g.oovRuleBias = c.oov_rule_bias;
 		g.spacePenalty = c.space_penalty; g.typoCostWeight = c.typo_cost_weight; g.maxUnkFormSize = c.max_unk_form_size;
 		g.maxUnkFormSizeFollowedByJClass = c.max_unk_form_size_followed_by_j_class; g.spaceTolerance = c.space_tolerance;
+		for (auto& r : h->replicas) r->config = g;
 	}
 
 	kiwi_config_t kiwi_get_global_config(kiwi_h h)

@@ -121,6 +121,111 @@ extern "C"
 		return reinterpret_cast<const uint16_t*>(seg.forms.data());
 	}
 	uint64_t kamd_res_d2h_bytes(kamd_results_h r) { return r ? r->r.d2hBytes : 0; }
+
+	// ---- packed, position-independent form of a batch's results: what a rank ships to the gathering rank -----
+	// {u32 magic 'KRES', u32 nTexts, u32 nAna, u32 pad, u64 nTok, u64 nFormUnits} u32 textAna[nTexts+1] u32 anaTok[nAna+1] f32 anaScore[nAna]
+	// kamd_token_t tok[nTok] (form_off into the one pool that follows) u16 forms[nFormUnits]; every section starts at a multiple of 8 bytes
+	size_t kamd_res_pack(kamd_results_h r, uint8_t* out, size_t cap)
+	{
+		if (!r) return 0;
+		return guarded([&]()
+		{
+			const BatchResults& R = r->r;
+			uint64_t nAna = 0, nTok = 0, nForms = 0;
+			for (size_t t = 0; t < R.nTexts; ++t)
+			{
+				size_t l; const ResultSegment& s = R.locate(t, l);
+				const uint32_t a0 = s.textAna[l], a1 = s.textAna[l + 1];
+				nAna += a1 - a0;
+				if (a1 > a0)
+				{
+					const uint32_t t0 = s.anaTok[a0], t1 = s.anaTok[a1];
+					nTok += t1 - t0;
+					if (t1 > t0) nForms += s.toks[t1 - 1].formOff + s.toks[t1 - 1].formLen + 1 - s.toks[t0].formOff;
+				}
+			}
+			auto pad8 = [](size_t n) { return (n + 7) & ~(size_t)7; };
+			const size_t oTextAna = 32, oAnaTok = pad8(oTextAna + 4 * (R.nTexts + 1)), oScore = pad8(oAnaTok + 4 * (nAna + 1)), oTok = pad8(oScore + 4 * nAna),
+				oForms = oTok + sizeof(FlatToken) * nTok, total = pad8(oForms + 2 * nForms);
+			if (!out || cap < total) return total;
+			std::memset(out, 0, total);
+			uint32_t* hd = reinterpret_cast<uint32_t*>(out);
+			hd[0] = 0x5345524Bu; hd[1] = (uint32_t)R.nTexts; hd[2] = (uint32_t)nAna; hd[3] = 0;
+			reinterpret_cast<uint64_t*>(out)[2] = nTok; reinterpret_cast<uint64_t*>(out)[3] = nForms;
+			uint32_t* textAna = reinterpret_cast<uint32_t*>(out + oTextAna); uint32_t* anaTok = reinterpret_cast<uint32_t*>(out + oAnaTok);
+			float* score = reinterpret_cast<float*>(out + oScore); FlatToken* tok = reinterpret_cast<FlatToken*>(out + oTok); char16_t* forms = reinterpret_cast<char16_t*>(out + oForms);
+			uint64_t a = 0, k = 0, f = 0;
+			textAna[0] = 0; anaTok[0] = 0;
+			for (size_t t = 0; t < R.nTexts; ++t)
+			{
+				size_t l; const ResultSegment& s = R.locate(t, l);
+				const uint32_t a0 = s.textAna[l], a1 = s.textAna[l + 1];
+				if (a1 > a0)
+				{
+					const uint32_t t0 = s.anaTok[a0], t1 = s.anaTok[a1];
+					const uint64_t f0 = t1 > t0 ? s.toks[t0].formOff : 0, f1 = t1 > t0 ? s.toks[t1 - 1].formOff + s.toks[t1 - 1].formLen + 1 : 0;
+					for (uint32_t i = a0; i < a1; ++i) { score[a] = s.anaScore[i]; anaTok[a + 1] = (uint32_t)(k + (s.anaTok[i + 1] - t0)); ++a; }
+					for (uint32_t i = t0; i < t1; ++i) { tok[k] = s.toks[i]; tok[k].formOff = s.toks[i].formOff - f0 + f; ++k; }
+					if (f1 > f0) std::memcpy(forms + f, s.forms.data() + f0, 2 * (f1 - f0));
+					f += f1 - f0;
+				}
+				textAna[t + 1] = (uint32_t)a;
+			}
+			return total;
+		}, (size_t)0);
+	}
+
+	// Results of one corpus that was sharded over `n_parts` ranks by index (text g -> part g % n_parts, local index g / n_parts: kiwi_amd.dist.shard_indices),
+	// every part packed by kamd_res_pack: merged back into input order.  The handle answers kamd_res_* like any other.
+	kamd_results_h kamd_res_merge_strided(const uint8_t* const* parts, const size_t* sizes, uint32_t n_parts)
+	{
+		return guarded([&]()
+		{
+			struct View { uint32_t nTexts, nAna; const uint32_t* textAna; const uint32_t* anaTok; const float* score; const FlatToken* tok; const char16_t* forms; };
+			auto pad8 = [](size_t n) { return (n + 7) & ~(size_t)7; };
+			std::vector<View> v(n_parts);
+			size_t total = 0;
+			for (uint32_t p = 0; p < n_parts; ++p)
+			{
+				const uint8_t* b = parts[p];
+				if (sizes[p] < 32 || reinterpret_cast<const uint32_t*>(b)[0] != 0x5345524Bu) throw std::runtime_error{ "kamd_res_merge_strided: not a packed result" };
+				View& w = v[p];
+				w.nTexts = reinterpret_cast<const uint32_t*>(b)[1]; w.nAna = reinterpret_cast<const uint32_t*>(b)[2];
+				const uint64_t nTok = reinterpret_cast<const uint64_t*>(b)[2], nForms = reinterpret_cast<const uint64_t*>(b)[3];
+				const size_t oTextAna = 32, oAnaTok = pad8(oTextAna + 4 * ((size_t)w.nTexts + 1)), oScore = pad8(oAnaTok + 4 * ((size_t)w.nAna + 1)), oTok = pad8(oScore + 4 * (size_t)w.nAna),
+					oForms = oTok + sizeof(FlatToken) * nTok;
+				if (pad8(oForms + 2 * nForms) > sizes[p]) throw std::runtime_error{ "kamd_res_merge_strided: truncated part" };
+				w.textAna = reinterpret_cast<const uint32_t*>(b + oTextAna); w.anaTok = reinterpret_cast<const uint32_t*>(b + oAnaTok); w.score = reinterpret_cast<const float*>(b + oScore);
+				w.tok = reinterpret_cast<const FlatToken*>(b + oTok); w.forms = reinterpret_cast<const char16_t*>(b + oForms);
+				total += w.nTexts;
+			}
+			for (uint32_t p = 0; p < n_parts; ++p) if (v[p].nTexts != (total + n_parts - 1 - p) / n_parts) throw std::runtime_error{ "kamd_res_merge_strided: parts are not an index-strided split" };
+			auto res = std::make_unique<kamd_results>();
+			BatchResults& R = res->r;
+			R.nTexts = total;
+			R.segs.resize((total + BatchResults::kSegTexts - 1) / BatchResults::kSegTexts);
+			for (size_t g = 0; g < total; ++g)
+			{
+				const View& w = v[g % n_parts]; const size_t l = g / n_parts;
+				ResultSegment& seg = R.segs[g / BatchResults::kSegTexts];
+				for (uint32_t a = w.textAna[l]; a < w.textAna[l + 1]; ++a)
+				{
+					for (uint32_t i = w.anaTok[a]; i < w.anaTok[a + 1]; ++i)
+					{
+						FlatToken t = w.tok[i];
+						const char16_t* fs = w.forms + t.formOff;
+						t.formOff = seg.forms.size();
+						seg.forms.insert(seg.forms.end(), fs, fs + t.formLen + 1);
+						seg.toks.push_back(t);
+					}
+					seg.anaScore.push_back(w.score[a]);
+					seg.anaTok.push_back((uint32_t)seg.toks.size());
+				}
+				seg.textAna.push_back((uint32_t)seg.anaScore.size());
+			}
+			return res.release();
+		}, (kamd_results*)nullptr);
+	}
 	void kamd_res_close(kamd_results_h r) { delete r; }
 
 	int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n)

@@ -163,7 +163,9 @@ namespace kamd
 
 	struct Engine::Impl
 	{
-		FlatModel model;
+		std::shared_ptr<FlatModel> modelOwner;   // the baked model is shared by the engines of one handle (one replica of the DEVICE tables per GPU)
+		FlatModel& model;
+		explicit Impl(std::shared_ptr<FlatModel> m) : modelOwner(std::move(m)), model(*modelOwner) {}
 		ModelView dview{};
 		std::vector<std::unique_ptr<DevBuf>> modelBufs;
 		hipStream_t stream = nullptr, stream2 = nullptr;   // lattice stages / search stage (sub-batches overlap)
@@ -190,13 +192,28 @@ namespace kamd
 		}
 	};
 
-	Engine::Engine(const std::string& path, int device, LmMode lm) : impl(new Impl)
+	int Engine::visibleDevices()
+	{
+		int n = 0;
+		if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+		return n;
+	}
+
+	Engine::Engine(const std::string& path, int device, LmMode lm) : impl(new Impl(std::make_shared<FlatModel>()))
 	{
 		bakeModel(impl->model, path);
 		if (lm == LmMode::Sbg && impl->model.sbgPtrs.empty()) throw std::runtime_error{ "Cannot open required files for skipbigram model" };   // KiwiBuilder.cpp:1008-1013
 		if (lm == LmMode::Knlm) { impl->model.sbgPtrs.clear(); impl->model.sbgKeys.clear(); impl->model.sbgComps.clear(); impl->model.sbgDiscnts.clear(); impl->model.sbgValid.clear(); }
 		if (!impl->model.sbgPtrs.empty() && impl->model.sbgWindow != 8)
 			throw std::runtime_error{ "kiwi_amd: SkipBigram window size must be 8 (the reference instantiates SbgState<8> only, src/SkipBigramModel.cpp)" };
+		openDevice(device);
+	}
+
+	// a replica on another GPU: same baked model on the host, its own device tables, streams and scratch
+	Engine::Engine(const Engine& other, int device) : impl(new Impl(other.impl->modelOwner)), config(other.config) { openDevice(device); }
+
+	void Engine::openDevice(int device)
+	{
 		int nDev = 0;
 		if (hipGetDeviceCount(&nDev) != hipSuccess || nDev == 0)
 			throw std::runtime_error{ "kiwi_amd: no HIP device visible -- the analyze path has no CPU fallback" };

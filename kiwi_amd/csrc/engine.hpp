@@ -57,12 +57,15 @@ namespace kamd
 		struct Impl;
 	private:
 		std::unique_ptr<Impl> impl;
+		void openDevice(int device);
 	public:
 		EngineConfig config;
 		// which language model of the container scores the search (reference ModelType, include/kiwi/Types.h:292-335): Auto = SkipBigram when the
 		// container carries its tables, else Knlm; Knlm = Knlm even then; Sbg = SkipBigram or an error
 		enum class LmMode { Auto, Knlm, Sbg };
 		explicit Engine(const std::string& rawModelPath, int device = -1, LmMode lm = LmMode::Auto);
+		Engine(const Engine& other, int device);      // replica of `other` on another GPU (shares the baked host model)
+		static int visibleDevices();
 		~Engine();
 		const FlatModel& model() const;
 

@@ -148,7 +148,7 @@ enum { hipStreamNonBlocking = 1 };
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; };
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { const char* e = std::getenv("HIPEMU_DEVICES"); *n = e ? std::max(1, std::atoi(e)) : 1; return hipSuccess; }      // (device ids are ignored: every "device" is the host)
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::memset(p, 0, sizeof(*p)); std::strcpy(p->name, "hipemu (CPU lanes)"); p->multiProcessorCount = 1; p->totalGlobalMem = 1ull << 34; return hipSuccess; }

@@ -50,15 +50,16 @@ sys.path.insert(0, %(root)r)
 import torch
 torch.cuda.synchronize = lambda *a, **k: None
 import kiwi_amd.dist as D
-_init, _mx, _gc = D.init, D.max_over_ranks, D.gather_counts
+_init, _mx, _gc, _gp = D.init, D.max_over_ranks, D.gather_counts, D.gather_packed
 D.init = lambda backend, device_index=None: _init("gloo")            # RCCL on the GPU box; gloo here
 D.max_over_ranks = lambda v, device="cpu": _mx(v, "cpu")
 D.gather_counts = lambda v, device="cpu": _gc(v, "cpu")
+D.gather_packed = lambda buf, device="cpu", dst=0: _gp(buf, "cpu", dst)
 import kiwi_amd.workloads as W
 orig = W.get_workload
 W.get_workload = lambda name: (lambda p, t, d: (p, t[:16], d))(*orig(name))
 import bench
-sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small-c2", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "small-c2", "--no-cpu-baseline"] + sys.argv[1:]
 bench.main()
 '''
 
@@ -79,3 +80,11 @@ def test_bench_main_with_two_ranks(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "shard2" and out["config"]["sentences_per_gpu"] == 16
     assert abs(out["value"] - 16 * 2 * 2 / (out["ms_per_step"] * 2 / 1000.0)) < 1e-6 * out["value"] + 1e-9      # all ranks' sentences / max time
+    assert out["gather"]["merged_texts"] == 32 and out["gather"]["bytes_per_rank"] > 1000      # the packed token records of both ranks arrived on rank 0
+    # strong scaling: ONE corpus split by index, the gathered records merged in input order
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29635", str(drv), "--scaling", "strong"],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["sentences_per_gpu"] == 8 and out["gather"]["merged_texts"] == 16
+    assert abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2 / 1000.0)) < 1e-6 * out["value"] + 1e-9

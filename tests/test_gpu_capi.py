@@ -296,6 +296,7 @@ def test_typo_transformer_through_the_c_api(capi, kiwi, small_model):
     L.kiwi_typo_copy.restype = C.c_void_p
     L.kiwi_typo_copy.argtypes = [C.c_void_p]
     L.kiwi_typo_get_default.restype = C.c_void_p
+    L.kiwi_typo_get_basic.restype = C.c_void_p
     L.kiwi_typo_add.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_float, C.c_int]
     L.kiwi_typo_update.argtypes = [C.c_void_p, C.c_void_p]
     L.kiwi_typo_scale_cost.argtypes = [C.c_void_p, C.c_float]

@@ -157,11 +157,14 @@ def test_emulated_skipbigram_golden_sequence(emu_libs, small_sbg_model, monkeypa
     dev.close()
 
 
-def test_emulated_c_api_suite(emu_libs):
+@pytest.mark.parametrize("devices", ["1", "2"])
+def test_emulated_c_api_suite(emu_libs, devices):
     """The drop-in boundary on the CPU: tests/test_gpu_capi.py (Kiwi's own C API bound with ctypes, reader / receiver protocol,
-    8 concurrent callers on one handle, a gcc-built C client) re-run against the emulated build of the same sources."""
+    8 concurrent callers on one handle, a gcc-built C client) re-run against the emulated build of the same sources.  With two
+    (emulated) devices visible kiwi_init builds an engine replica per device and kiwi_analyze_m / _mw spread every batch over both,
+    one host thread each, delivering in input order -- the one-process-drives-all-GPUs path behind the boundary."""
     import sys
-    env = dict(os.environ, KAMD_TEST_LIB=emu_libs[0], KAMD_EXPERIMENTAL_TYPO="1")      # (so that the typo-transformer test of that file runs too)
+    env = dict(os.environ, KAMD_TEST_LIB=emu_libs[0], HIPEMU_DEVICES=devices)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_capi.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
