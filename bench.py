@@ -168,7 +168,11 @@ def main():
         from kiwi_amd.api import pack_texts
         flat, offs = pack_texts(shard)
         e2e_steps = max(3, min(args.steps, 10))
-        for _ in range(2):
+        tw = time.perf_counter()
+        eng.analyze_packed(flat, offs, top_n).close()      # warm-up (device blocks, pinned buffers, host pool)
+        if time.perf_counter() - tw > 2.0:
+            e2e_steps = 1      # a slow workload (seconds per batch): one timed batch
+        else:
             eng.analyze_packed(flat, offs, top_n).close()
         sync()
         te = time.perf_counter()

@@ -535,7 +535,10 @@ namespace kamd
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
 		HIPCHECK(hipMemsetAsync(b.dNNodes.p, 0, (size_t)nC * 4, sA));   // also clears the lattice kernels' hand-over flag
 		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
-		const uint32_t nGroups = (I.hasSbg || b.typo.typo) ? ((I.groupLanesForced && I.groupLanes == 64) ? 1u : 4u)      // (the SkipBigram kernel: 16-lane groups unless 64 is forced)
+		// SkipBigram: one chunk per wave unless 16-lane groups are forced -- with history rings in the container keys a lattice node gathers
+		// thousands of work items, so a chunk's serial chain is items / lanes (MI355X, small model: 480 texts 0.7 s with 64 lanes, 7 s with 16)
+		const bool variant64 = I.hasSbg ? !(I.groupLanesForced && I.groupLanes == 16) : (I.groupLanesForced && I.groupLanes == 64);
+		const uint32_t nGroups = (I.hasSbg || b.typo.typo) ? (variant64 ? 1u : 4u)
 			: 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
 		// (the SkipBigram kernel is built for 2 waves per SIMD and carries 1.8 MB of item scratch per lane group: 8 persistent blocks per CU)
@@ -611,7 +614,7 @@ namespace kamd
 			// groups, 2 waves per SIMD measured best on 8192 x 40 jamo); with many chunks it is a throughput problem and narrower
 			// groups + a third wave per SIMD win (65536 x 40 jamo: 6.9 vs 9.3 ms).  KAMD_GROUP_LANES / KAMD_WPS override.
 			const bool many = cn >= 32768;
-			const int gl = (I.hasSbg || b.typo.typo) ? ((I.groupLanesForced && I.groupLanes == 64) ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
+			const int gl = (I.hasSbg || b.typo.typo) ? (variant64 ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
 			const int wps = b.typo.typo ? 2 : I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
 			const uint32_t blocksK = std::min(persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
