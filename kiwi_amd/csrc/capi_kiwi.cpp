@@ -282,9 +282,7 @@ extern "C"
 			default: throw std::invalid_argument{ "kiwi_amd: unknown model type" };
 			}
 			if (enabled_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported" };
-			std::string path = model_path ? model_path : "";
-			struct stat st;
-			if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode)) path += "/kiwi_amd.raw";
+			const std::string path = model_path ? model_path : "";      // a directory with sj.morph + sj.knlm (+ skipbigram.mdl) or kiwi_amd.raw, or a raw container file
 			auto h = std::make_unique<kiwi_s>();
 			h->engine.reset(new Engine(path, 0, lm));
 			h->engine->config.integrateAllomorph = !!(options & 1);

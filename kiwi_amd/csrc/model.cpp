@@ -4,6 +4,7 @@
 // reductions (:2478-2507), the form trie in creation order (include/kiwi/Trie.hpp:444-470) frozen into an
 // Aho-Corasick automaton (src/FrozenTrie.hpp:95-154), and the Knlm load-time expansion
 // (src/Knlm.hpp:1003-1167).  Everything is index based; nothing here is shared with oracle/_ref.
+#include <sys/stat.h>
 #include <algorithm>
 #include <cstring>
 #include <deque>
@@ -236,12 +237,112 @@ namespace kamd
 		}
 	}
 
+	namespace
+	{
+		// ---- the reference's on-disk model files ------------------------------------------------------------
+		// sj.morph = serializer::writeMany(os, toKey("KIWI"), forms, morphemes) (src/KiwiBuilder.cpp:923-937).  The serializer's format
+		// (src/serializer.hpp:212-350): fundamentals and enums raw little-endian, vectors and strings a u32 count followed by the elements,
+		// pairs member by member.  FormRaw = {form: u16 string, candidate: vector<u32>} (src/Form.cpp:71); MorphemeRaw = {kform u32, tag u8,
+		// vpPack u8, senseId u8, combineSocket u8, combined i32, userScore f32, chunks vector<u32>, chunkPositions vector<pair<u8,u8>>,
+		// lmMorphemeId u32, groupId u32, dialect u16, _reserved u16} (src/Form.cpp:36).  sj.knlm and skipbigram.mdl are memory images
+		// (include/kiwi/Knlm.h:9-15, src/SkipBigramModel.hpp:45-92) -- the layouts loadKnlm / the SkipBigram loader below already read.
+		struct ModelFiles
+		{
+			std::vector<uint32_t> meta, formPtr, formCandPtr, formCand, chunkIds;
+			std::vector<uint16_t> formChars;
+			std::vector<RawMorph> morph;
+			std::vector<uint8_t> chunkPos, knlm, sbg;
+		};
+
+		std::vector<uint8_t> readFile(const std::string& path, bool required)
+		{
+			FILE* f = std::fopen(path.c_str(), "rb");
+			if (!f) { if (required) throw std::runtime_error{ "cannot open model file: " + path }; return {}; }
+			std::fseek(f, 0, SEEK_END);
+			const long n = std::ftell(f);
+			std::fseek(f, 0, SEEK_SET);
+			std::vector<uint8_t> b((size_t)std::max(0l, n));
+			if (n > 0 && std::fread(b.data(), 1, (size_t)n, f) != (size_t)n) { std::fclose(f); throw std::runtime_error{ "short read: " + path }; }
+			std::fclose(f);
+			return b;
+		}
+
+		void loadModelDir(const std::string& dir, ModelFiles& o, RawModel& raw)
+		{
+			const std::vector<uint8_t> mb = readFile(dir + "/sj.morph", true);
+			const uint8_t* p = mb.data(); const uint8_t* end = p + mb.size();
+			auto need = [&](size_t n) { if ((size_t)(end - p) < n) throw std::runtime_error{ "sj.morph: truncated" }; };
+			auto get = [&](auto& v) { need(sizeof(v)); std::memcpy(&v, p, sizeof(v)); p += sizeof(v); };
+			need(4);
+			if (std::memcmp(p, "KIWI", 4) != 0) throw std::runtime_error{ "sj.morph: 'KIWI' is needed at the head of the file" };
+			p += 4;
+			uint32_t nForms; get(nForms);
+			o.formPtr.assign(1, 0); o.formCandPtr.assign(1, 0);
+			for (uint32_t i = 0; i < nForms; ++i)
+			{
+				uint32_t n; get(n); need(2 * (size_t)n);
+				const size_t at = o.formChars.size();
+				o.formChars.resize(at + n);
+				if (n) std::memcpy(&o.formChars[at], p, 2 * (size_t)n);
+				p += 2 * (size_t)n;
+				o.formPtr.push_back((uint32_t)o.formChars.size());
+				uint32_t c; get(c); need(4 * (size_t)c);
+				const size_t ca = o.formCand.size();
+				o.formCand.resize(ca + c);
+				if (c) std::memcpy(&o.formCand[ca], p, 4 * (size_t)c);
+				p += 4 * (size_t)c;
+				o.formCandPtr.push_back((uint32_t)o.formCand.size());
+			}
+			uint32_t nMorphs; get(nMorphs);
+			o.morph.assign(nMorphs, RawMorph{});
+			for (uint32_t i = 0; i < nMorphs; ++i)
+			{
+				RawMorph& r = o.morph[i];
+				get(r.kform); get(r.tag); get(r.vpPack); get(r.senseId); get(r.socket); get(r.combined); get(r.userScore);
+				uint32_t nc; get(nc); need(4 * (size_t)nc);
+				if (nc > 255) throw std::runtime_error{ "sj.morph: a morpheme with more than 255 chunks" };
+				r.chunkPtr = (uint32_t)o.chunkIds.size(); r.nChunks = (uint8_t)nc;
+				o.chunkIds.resize(o.chunkIds.size() + nc);
+				if (nc) std::memcpy(&o.chunkIds[r.chunkPtr], p, 4 * (size_t)nc);
+				p += 4 * (size_t)nc;
+				uint32_t np; get(np); need(2 * (size_t)np);
+				if (np != nc) throw std::runtime_error{ "sj.morph: chunkPositions.size() != chunks.size()" };
+				o.chunkPos.insert(o.chunkPos.end(), p, p + 2 * (size_t)np);
+				p += 2 * (size_t)np;
+				uint32_t groupId; uint16_t reserved;
+				get(r.lmId); get(groupId); get(r.dialect); get(reserved);
+				r.origId = 0; r.pad = 0;
+			}
+			if (p != end) throw std::runtime_error{ "sj.morph: trailing bytes" };
+			if (o.chunkIds.empty()) { o.chunkIds.push_back(0); o.chunkPos.assign(2, 0); }
+			if (o.formChars.empty()) o.formChars.push_back(0);
+			if (o.formCand.empty()) o.formCand.push_back(0);
+			o.knlm = readFile(dir + "/sj.knlm", true);
+			o.sbg = readFile(dir + "/skipbigram.mdl", false);
+			if (o.knlm.size() < sizeof(KnlmHeader)) throw std::runtime_error{ "sj.knlm: truncated header" };
+			KnlmHeader hd; std::memcpy(&hd, o.knlm.data(), sizeof(hd));
+			o.meta = { nForms, nMorphs, (uint32_t)hd.vocab_size, 0 };      // the language model's vocabulary size is the reference's langVocabSize
+			raw.meta = o.meta.data(); raw.formPtr = o.formPtr.data(); raw.formChars = o.formChars.data(); raw.formCandPtr = o.formCandPtr.data(); raw.formCand = o.formCand.data();
+			raw.morph = o.morph.data(); raw.chunkIds = o.chunkIds.data(); raw.chunkPos = o.chunkPos.data();
+			raw.knlm = o.knlm.data(); raw.knlmSize = o.knlm.size();
+			raw.sbg = o.sbg.empty() ? nullptr : o.sbg.data(); raw.sbgSize = o.sbg.size();
+		}
+	}
+
+	// `path`: a KAMDRAW1 container (kiwi_amd/synth.py), or a directory -- one that holds the reference's own model files sj.morph + sj.knlm
+	// (+ skipbigram.mdl), else one that holds kiwi_amd.raw
 	void bakeModel(FlatModel& m, const std::string& path)
 	{
 		Container file;
-		file.load(path);
+		ModelFiles files;
 		RawModel raw;
-		raw.bind(file);
+		struct stat st;
+		if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode))
+		{
+			if (stat((path + "/sj.morph").c_str(), &st) == 0) loadModelDir(path, files, raw);
+			else { file.load(path + "/kiwi_amd.raw"); raw.bind(file); }
+		}
+		else { file.load(path); raw.bind(file); }
 		const size_t nF = raw.nForms(), nM = raw.nMorphs();
 		if (nF < kDefaultFormSize) throw std::runtime_error{ "raw model: missing default forms" };
 

@@ -35,6 +35,7 @@
 #include "SortUtils.hpp"
 #include "PathEvaluator.h"
 #include "MathFunc.hpp"
+#include "serializer.hpp"
 
 #include "../kiwi_amd/csrc/container.hpp"
 #include "../kiwi_amd/csrc/raw_model.hpp"
@@ -108,11 +109,11 @@ namespace kiwi
 	template<>
 	struct BestPathFinder<kamd_ref::Access>
 	{
-		static Kiwi build(const kamd::RawModel& raw, ArchType arch)
+		// --- raw records -> FormRaw / MorphemeRaw (what KiwiBuilder holds before build()) ---
+		static void fromRaw(const kamd::RawModel& raw, Vector<FormRaw>& forms, Vector<MorphemeRaw>& morphemes)
 		{
-			// --- raw records -> FormRaw / MorphemeRaw (what KiwiBuilder holds before build()) ---
-			Vector<FormRaw> forms(raw.nForms());
-			Vector<MorphemeRaw> morphemes(raw.nMorphs());
+			forms.resize(raw.nForms());
+			morphemes.resize(raw.nMorphs());
 			for (size_t i = 0; i < raw.nForms(); ++i)
 			{
 				forms[i].form = KString{ (const char16_t*)raw.formChars + raw.formPtr[i], (const char16_t*)raw.formChars + raw.formPtr[i + 1] };
@@ -131,15 +132,36 @@ namespace kiwi
 					m.chunkPositions.emplace_back(raw.chunkPos[(r.chunkPtr + c) * 2], raw.chunkPos[(r.chunkPtr + c) * 2 + 1]);
 				}
 			}
+		}
 
-			utils::MemoryOwner mem{ raw.knlmSize };
-			std::memcpy(mem.get(), raw.knlm, raw.knlmSize);
+		static Kiwi build(const kamd::RawModel& raw, ArchType arch)
+		{
+			Vector<FormRaw> forms; Vector<MorphemeRaw> morphemes;
+			fromRaw(raw, forms, morphemes);
+			return build(forms, morphemes, raw.knlm, raw.knlmSize, raw.sbg, raw.sbgSize, arch);
+		}
+
+		// the on-disk model files of the reference: sj.morph through its own serializer (KiwiBuilder::loadMorphBin / saveMorphBin,
+		// src/KiwiBuilder.cpp:923-937: the "KIWI" key, the raw forms, the raw morphemes); sj.knlm and skipbigram.mdl are memory images
+		static void writeMorph(std::ostream& os, const Vector<FormRaw>& forms, const Vector<MorphemeRaw>& morphemes)
+		{
+			serializer::writeMany(os, serializer::toKey("KIWI"), forms, morphemes);
+		}
+		static void readMorph(std::istream& is, Vector<FormRaw>& forms, Vector<MorphemeRaw>& morphemes)
+		{
+			serializer::readMany(is, serializer::toKey("KIWI"), forms, morphemes);
+		}
+
+		static Kiwi build(const Vector<FormRaw>& forms, const Vector<MorphemeRaw>& morphemes, const uint8_t* knlm, size_t knlmSize, const uint8_t* sbg, size_t sbgSize, ArchType arch)
+		{
+			utils::MemoryOwner mem{ knlmSize };
+			std::memcpy(mem.get(), knlm, knlmSize);
 			std::shared_ptr<lm::ILangModel> langMdl;
-			if (raw.sbg)
+			if (sbg)
 			{
 				// SkipBigram on top of the same Knlm (KiwiBuilder.cpp: ModelType::sbg): SkipBigramModelBase::create (src/SkipBigramModel.cpp:99)
-				utils::MemoryOwner smem{ raw.sbgSize };
-				std::memcpy(smem.get(), raw.sbg, raw.sbgSize);
+				utils::MemoryOwner smem{ sbgSize };
+				std::memcpy(smem.get(), sbg, sbgSize);
 				langMdl = lm::SkipBigramModelBase::create(utils::MemoryObject{ std::move(mem) }, utils::MemoryObject{ std::move(smem) }, arch);
 			}
 			else langMdl = lm::KnLangModelBase::create(utils::MemoryObject{ std::move(mem) }, arch);
@@ -292,6 +314,49 @@ extern "C"
 		catch (const std::exception& e)
 		{
 			fprintf(stderr, "kref_open: %s\n", e.what());
+			return nullptr;
+		}
+	}
+
+	// The synthetic model written as the reference's own model FILES: sj.morph by the reference's serializer, sj.knlm / skipbigram.mdl as the
+	// memory images they are.  Returns 0 on success.
+	int kref_write_model_dir(const char* rawModelPath, const char* dir)
+	{
+		try
+		{
+			kamd::Container file; file.load(rawModelPath);
+			kamd::RawModel raw; raw.bind(file);
+			kiwi::Vector<kiwi::FormRaw> forms; kiwi::Vector<kiwi::MorphemeRaw> morphemes;
+			Acc::fromRaw(raw, forms, morphemes);
+			const std::string d = dir;
+			{ std::ofstream os{ d + "/sj.morph", std::ios::binary }; Acc::writeMorph(os, forms, morphemes); if (!os) return -2; }
+			{ std::ofstream os{ d + "/sj.knlm", std::ios::binary }; os.write((const char*)raw.knlm, (std::streamsize)raw.knlmSize); if (!os) return -2; }
+			if (raw.sbg) { std::ofstream os{ d + "/skipbigram.mdl", std::ios::binary }; os.write((const char*)raw.sbg, (std::streamsize)raw.sbgSize); if (!os) return -2; }
+			return 0;
+		}
+		catch (const std::exception& e) { fprintf(stderr, "kref_write_model_dir: %s\n", e.what()); return -1; }
+	}
+
+	// The reference loading those files: sj.morph through its serializer, the language model through KnLangModelBase / SkipBigramModelBase::create;
+	// useSbg: skipbigram.mdl as well (ModelType::sbg), else Knlm only (the reference's default when both files exist, KiwiBuilder.cpp:939-961)
+	void* kref_open_dir(const char* dir, int arch, int useSbg)
+	{
+		try
+		{
+			const std::string d = dir;
+			auto slurp = [](const std::string& p) { std::ifstream is{ p, std::ios::binary }; if (!is) throw std::runtime_error{ "cannot open " + p }; return std::vector<uint8_t>{ std::istreambuf_iterator<char>{ is }, std::istreambuf_iterator<char>{} }; };
+			kiwi::Vector<kiwi::FormRaw> forms; kiwi::Vector<kiwi::MorphemeRaw> morphemes;
+			{ std::ifstream is{ d + "/sj.morph", std::ios::binary }; if (!is) throw std::runtime_error{ "cannot open sj.morph" }; Acc::readMorph(is, forms, morphemes); }
+			const auto knlm = slurp(d + "/sj.knlm");
+			std::vector<uint8_t> sbg;
+			if (useSbg) sbg = slurp(d + "/skipbigram.mdl");
+			auto h = std::make_unique<RefHandle>();
+			h->kw = Acc::build(forms, morphemes, knlm.data(), knlm.size(), sbg.empty() ? nullptr : sbg.data(), sbg.size(), toArch(arch));
+			return h.release();
+		}
+		catch (const std::exception& e)
+		{
+			fprintf(stderr, "kref_open_dir: %s\n", e.what());
 			return nullptr;
 		}
 	}

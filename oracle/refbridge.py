@@ -73,10 +73,24 @@ def parse_results(buf) -> list:
     return out
 
 
+def write_model_dir(raw_model_path: str, out_dir: str):
+    """The synthetic model written as the reference's own model FILES: sj.morph by the reference's serializer (serializer::writeMany with
+    the "KIWI" key, src/KiwiBuilder.cpp:934-937), sj.knlm / skipbigram.mdl as the memory images they are."""
+    L = C.CDLL(LIB_PATH)
+    L.kref_write_model_dir.argtypes = [C.c_char_p, C.c_char_p]
+    os.makedirs(out_dir, exist_ok=True)
+    if L.kref_write_model_dir(raw_model_path.encode(), out_dir.encode()) != 0:
+        raise RuntimeError("kref_write_model_dir failed")
+
+
 class RefKiwi:
-    def __init__(self, raw_model_path: str, arch: int = 0):
+    def __init__(self, raw_model_path: str, arch: int = 0, model_dir_sbg=None):
+        """raw_model_path: a raw container; or, with model_dir_sbg = False / True, a DIRECTORY holding the reference's own model files,
+        loaded through the reference's serializer (Knlm only / with skipbigram.mdl)."""
         self.lib = C.CDLL(LIB_PATH)
         L = self.lib
+        L.kref_open_dir.restype = C.c_void_p
+        L.kref_open_dir.argtypes = [C.c_char_p, C.c_int, C.c_int]
         L.kref_open.restype = C.c_void_p
         L.kref_open.argtypes = [C.c_char_p, C.c_int]
         L.kref_close.argtypes = [C.c_void_p]
@@ -93,7 +107,7 @@ class RefKiwi:
         L.kref_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
         L.kref_analyze_batch.restype = C.c_double
         L.kref_analyze_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
-        self.h = L.kref_open(raw_model_path.encode(), arch)
+        self.h = L.kref_open(raw_model_path.encode(), arch) if model_dir_sbg is None else L.kref_open_dir(raw_model_path.encode(), arch, int(model_dir_sbg))
         if not self.h:
             raise RuntimeError("kref_open failed")
         self._buf = np.zeros(1 << 20, np.uint8)
