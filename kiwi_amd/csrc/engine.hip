@@ -648,7 +648,10 @@ namespace kamd
 			}
 #undef KAMD_LAUNCH
 			HIPCHECK(hipEventRecord(e[4], sB));
-			hipLaunchKernelGGL(k_finish_paths, dim3((cn + 63) / 64), dim3(64), 0, sB, I.dview, b.bv, wv, sp, c0, cn);
+			{
+				const uint32_t stride = cn <= 32768 ? 16u : 4u, perWave = 64 / stride;      // active lanes per wave: 4 up to 32k chunks, 16 beyond
+				hipLaunchKernelGGL(k_finish_paths, dim3((cn + perWave - 1) / perWave), dim3(64), 0, sB, I.dview, b.bv, wv, sp, c0, cn, stride);
+			}
 			HIPCHECK(hipEventRecord(e[5], sB));
 			if (getenv("KAMD_HANGDUMP"))
 			{

@@ -333,9 +333,13 @@ namespace kamd
 		};
 	}
 
-	__global__ void __launch_bounds__(64) k_build_lattice_typo(ModelView M, TypoLatView V, uint32_t nChunks)
+	// One THREAD per chunk, `stride` lanes apart: a strictly serial, branch-heavy replay runs at the speed of the SUM of its lanes' paths when 64
+	// chunks share a wavefront (lanes diverge at every branch).  With few active lanes per wave the chunks spread over all SIMDs instead
+	// (8192 chunks: 8192 one-lane waves resident at once) and a wave's time is one chunk's time.
+	__global__ void __launch_bounds__(64) k_build_lattice_typo(ModelView M, TypoLatView V, uint32_t nChunks, uint32_t stride)
 	{
-		const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+		if (threadIdx.x % stride) return;
+		const uint32_t c = blockIdx.x * (64 / stride) + threadIdx.x / stride;
 		if (c >= nChunks) return;
 		TypoLatChunk& C = V.chunks[c];
 		Ctx X{ M, V, C };
@@ -517,6 +521,9 @@ namespace kamd
 
 	void launchTypoLattice(const ModelView& M, const TypoLatView& V, uint32_t nChunks, hipStream_t stream)
 	{
-		hipLaunchKernelGGL(k_build_lattice_typo, dim3((nChunks + 63) / 64), dim3(64), 0, stream, M, V, nChunks);
+		// active lanes per wave: 1 up to 16k chunks, 4 up to 64k, 16 beyond (the machine holds 8192 waves)
+		const uint32_t stride = nChunks <= 16384 ? 64u : nChunks <= 65536 ? 16u : 4u;
+		const uint32_t perWave = 64 / stride;
+		hipLaunchKernelGGL(k_build_lattice_typo, dim3((nChunks + perWave - 1) / perWave), dim3(64), 0, stream, M, V, nChunks, stride);
 	}
 }

@@ -1427,11 +1427,14 @@ namespace sbgk
 
 #ifndef KAMD_VARIANT
 	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418); one thread per chunk
-	__global__ void __launch_bounds__(64) k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount)
+	// `stride`: lanes between two active threads of a wave (64 = one chunk per wave): the stage is serial and branchy per chunk, so chunks that
+	// share a wavefront run at the sum of their paths -- few active lanes per wave spread them over the SIMDs instead
+	__global__ void __launch_bounds__(64) k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t stride)
 	{
 		// (no early return: every lane of the wave takes part in the prefix sums that hand out the output ranges)
 		const uint32_t lane = threadIdx.x & 63u;
-		const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+		const bool mine = (threadIdx.x % stride) == 0;
+		const uint32_t t = mine ? blockIdx.x * (64 / stride) + threadIdx.x / stride : 0xFFFFFFFFu;
 		const uint32_t chunk = chunkBegin + (t < chunkCount ? t : 0u);
 		DevChunkResult* res = &W.results[chunk];
 		const bool active = t < chunkCount && res->status == CS_OK;
