@@ -158,6 +158,45 @@ namespace kamd
 		bool present() const { return vocabSize != 0; }
 	};
 
+	// CoNgram model, local (window 0) and quantised (reference src/CoNgramModel.cpp: ModelType::cong): a context trie -- same shape as the Knlm
+	// trie; an edge leads to a child context node (value > 0: relative offset) or to a leaf (value < 0: minus its context id); every node
+	// names the context id its history maps to -- plus two int8 embedding tables.  score(context c, word w) =
+	// float(sum_k ctx[c][k] * out[w][k]) * ctxScale[c] * outScale[w] + ctxBias[c]   (CoNgramModel.cpp:886-894; the reference stores the context
+	// row biased by +128 and subtracts 128 * sum(out[w]) again: the same integer).  Rows: dim x s8, then f32 scale, f32 bias (context) /
+	// f32 scale, 4 unused bytes (output): stride dim + 8.
+	struct CongNodeRec { uint32_t nextOff, numNexts; int32_t lower; uint32_t value; };
+	struct CongView
+	{
+		uint32_t dim = 0, stride = 0, nCtx = 0, vocabSize = 0;
+		const uint8_t* ctxEmb = nullptr; const uint8_t* outEmb = nullptr;
+		// host-side walk (oracle, bake); the device walks the edge hash that is uploaded in place of the Knlm one
+		const CongNodeRec* nodes = nullptr; const uint32_t* keys = nullptr; const int32_t* values = nullptr; const int32_t* root = nullptr;
+		bool present() const { return dim != 0; }
+	};
+	// the score of word `w` in context `c` (one fp32 conversion, two multiplications, one addition, in this order: CoNgramModel.cpp:886-894)
+	KAMD_HD float congScore(const CongView& C, uint32_t c, uint32_t w)
+	{
+		const int8_t* a = reinterpret_cast<const int8_t*>(C.ctxEmb + (size_t)c * C.stride);
+		const int8_t* b = reinterpret_cast<const int8_t*>(C.outEmb + (size_t)w * C.stride);
+		int32_t acc = 0;
+		for (uint32_t k = 0; k < C.dim; ++k) acc += (int32_t)a[k] * (int32_t)b[k];
+		float cs, os, bias;
+		__builtin_memcpy(&cs, a + C.dim, 4); __builtin_memcpy(&bias, a + C.dim + 4, 4); __builtin_memcpy(&os, b + C.dim, 4);
+		return (float)acc * cs * os + bias;
+	}
+
+	// the same with the output scale multiplied in first: the rounding of the reference's batched SSE4.1 kernel (src/archImpl/sse4_1.cpp:116)
+	KAMD_HD float congScoreOutputFirst(const CongView& C, uint32_t c, uint32_t w)
+	{
+		const int8_t* a = reinterpret_cast<const int8_t*>(C.ctxEmb + (size_t)c * C.stride);
+		const int8_t* b = reinterpret_cast<const int8_t*>(C.outEmb + (size_t)w * C.stride);
+		int32_t acc = 0;
+		for (uint32_t k = 0; k < C.dim; ++k) acc += (int32_t)a[k] * (int32_t)b[k];
+		float cs, os, bias;
+		__builtin_memcpy(&cs, a + C.dim, 4); __builtin_memcpy(&bias, a + C.dim + 4, 4); __builtin_memcpy(&os, b + C.dim, 4);
+		return (float)acc * os * cs + bias;
+	}
+
 	// Host-side owner.
 	struct FlatModel
 	{
@@ -184,6 +223,21 @@ namespace kamd
 		std::vector<LmRootRec> lmRoot2;
 		std::vector<LmBackoff> lmBackoff;
 		std::vector<uint32_t> sbgPtrs, sbgKeys; std::vector<float> sbgComps, sbgDiscnts; std::vector<uint8_t> sbgValid; uint32_t sbgWindow = 0;
+		// CoNgram (see CongView): host trie, the device lookup structures in the Knlm shapes (edge hash with the child's context id in the slot's
+		// `ll` bits, root table, per-node suffix link), embeddings
+		std::vector<CongNodeRec> congNodes; std::vector<uint32_t> congKeys; std::vector<int32_t> congValues, congRoot;
+		std::vector<LmSlot> congHash; uint32_t congHashMask = 0; std::vector<LmRootRec> congRoot2; std::vector<LmBackoff> congBackoff;
+		std::vector<uint8_t> congCtxEmb, congOutEmb; uint32_t congDim = 0, congCtx = 0;
+
+		CongView congView() const
+		{
+			CongView v;
+			if (!congDim) return v;
+			v.dim = congDim; v.stride = congDim + 8; v.nCtx = congCtx; v.vocabSize = (uint32_t)congRoot.size();
+			v.ctxEmb = congCtxEmb.data(); v.outEmb = congOutEmb.data();
+			v.nodes = congNodes.data(); v.keys = congKeys.data(); v.values = congValues.data(); v.root = congRoot.data();
+			return v;
+		}
 
 		SbgView sbgView() const
 		{

@@ -239,6 +239,189 @@ namespace kamd
 
 	namespace
 	{
+		// ---- CoNgram model blob (reference cong.mdl, loader src/CoNgramModel.cpp:425-789): local (window 0) use of an 8-bit model ------------
+		// header 64 B (include/kiwi/CoNgramModel.h:18-34) | node sizes, Stream VByte "0124" | keys, Stream VByte | values, Stream VByte "0124" |
+		// per context: dim x s8, fp16 scale, fp16 -bias [, 2 x fp16 when the model has a window] | per word: dim x s8, fp16 scale.
+		// Stream VByte (Lemire, Kurz, Rupp 2017): ceil(n/4) control bytes of four 2-bit length codes, then the significant bytes, little endian;
+		// codes 0..3 = 1, 2, 3, 4 bytes ("0124": 0, 1, 2, 4 bytes).
+		size_t svbDecode(const uint8_t* in, const uint8_t* end, uint32_t* out, size_t n, bool v0124)
+		{
+			static const uint8_t lenStd[4] = { 1, 2, 3, 4 }, len0124[4] = { 0, 1, 2, 4 };
+			const uint8_t* key = in; const uint8_t* data = in + (n + 3) / 4;
+			if (data > end) throw std::runtime_error{ "cong.mdl: truncated Stream VByte section" };
+			for (size_t i = 0; i < n; ++i)
+			{
+				const uint32_t code = (key[i / 4] >> ((i % 4) * 2)) & 3u;
+				const uint32_t nb = v0124 ? len0124[code] : lenStd[code];
+				if (data + nb > end) throw std::runtime_error{ "cong.mdl: truncated Stream VByte section" };
+				uint32_t v = 0;
+				for (uint32_t b = 0; b < nb; ++b) v |= (uint32_t)(*data++) << (8 * b);
+				out[i] = v;
+			}
+			return (size_t)(data - in);
+		}
+		float halfToFloat(uint16_t h)      // CoNgramModel.cpp:344-354 (normal numbers only, as there)
+		{
+			uint32_t u = (uint32_t)(h & 0x8000) << 16;
+			u |= ((uint32_t)(h & 0x7FFF) + 0x1C000) << 13;
+			float f; std::memcpy(&f, &u, 4);
+			return f;
+		}
+		bool congSearch(const FlatModel& m, const CongNodeRec& n, uint32_t key, int32_t& v)
+		{
+			const uint32_t* k = m.congKeys.data() + n.nextOff;
+			const uint32_t* it = std::lower_bound(k, k + n.numNexts, key);
+			if (it == k + n.numNexts || *it != key) return false;
+			v = m.congValues[n.nextOff + (it - k)];
+			return v != 0;
+		}
+
+		void loadCong(FlatModel& m, const uint8_t* blob, size_t size)
+		{
+			struct Header { uint64_t vocabSize, contextSize; uint16_t dim, flags; uint8_t keySize, windowSize, qbit, qgroup; uint64_t numNodes, nodeOffset, keyOffset, valueOffset, embOffset; };
+			static_assert(sizeof(Header) == 64, "CoNgramModelHeader");
+			if (size < sizeof(Header)) throw std::runtime_error{ "cong.mdl: truncated header" };
+			Header hd; std::memcpy(&hd, blob, sizeof(hd));
+			if (hd.qbit != 8) throw std::runtime_error{ "cong.mdl: only 8-bit embeddings are supported by this loader (4-bit grouped packing is not)" };
+			if (hd.flags != 0) throw std::runtime_error{ "cong.mdl: output bias / reordered vocabulary / trie frequencies are not supported by this loader" };
+			if (hd.keySize != 4 && hd.keySize != 2) throw std::runtime_error{ "cong.mdl: only 16- and 32-bit keys are supported by this loader" };
+			if (hd.dim == 0 || hd.dim % 4 || hd.numNodes < 1) throw std::runtime_error{ "cong.mdl: bad header" };
+			const uint8_t* end = blob + size;
+			const size_t nNodes = hd.numNodes;
+			std::vector<uint32_t> sizes(nNodes), keys(nNodes - 1), values(nNodes);
+			svbDecode(blob + hd.nodeOffset, end, sizes.data(), nNodes, true);
+			svbDecode(blob + hd.keyOffset, end, keys.data(), nNodes - 1, false);
+			svbDecode(blob + hd.valueOffset, end, values.data(), nNodes, true);
+			size_t nonLeaf = 0;
+			for (auto sz : sizes) nonLeaf += sz ? 1 : 0;
+			m.congNodes.assign(nonLeaf, CongNodeRec{});
+			m.congKeys = keys;
+			m.congValues.assign(nNodes - 1, 0);
+			m.congRoot.assign(hd.vocabSize, 0);
+			// pre-order node stream -> non-leaf node table + per-edge values (CoNgramModel.cpp:489-523)
+			struct Range { size_t node, cur, end; };
+			std::vector<Range> st;
+			size_t ni = 0, nextOff = 0;
+			for (size_t i = 0; i < nNodes; ++i)
+			{
+				if (sizes[i])
+				{
+					if (!st.empty()) m.congValues[st.back().cur] = (int32_t)(ni - st.back().node);
+					CongNodeRec& n = m.congNodes[ni];
+					n.value = values[i]; n.numNexts = sizes[i]; n.nextOff = (uint32_t)nextOff;
+					st.push_back(Range{ ni, nextOff, nextOff + sizes[i] });
+					nextOff += sizes[i];
+					++ni;
+				}
+				else
+				{
+					if (st.empty()) throw std::runtime_error{ "cong.mdl: malformed node stream" };
+					m.congValues[st.back().cur] = -(int32_t)values[i];
+					st.back().cur++;
+					while (st.back().cur == st.back().end)
+					{
+						st.pop_back();
+						if (st.empty()) break;
+						st.back().cur++;
+					}
+				}
+			}
+			for (uint32_t i = 0; i < m.congNodes[0].numNexts; ++i) if (keys[i] < hd.vocabSize) m.congRoot[keys[i]] = m.congValues[i];
+			// suffix links and inherited context ids, breadth first (CoNgramModel.cpp:547-568 with findLowerNode / findLowerValue, CoNgramModel.hpp:181-227)
+			std::deque<uint32_t> dq{ 0u };
+			while (!dq.empty())
+			{
+				const uint32_t p = dq.front(); dq.pop_front();
+				const CongNodeRec pn = m.congNodes[p];
+				for (uint32_t i = 0; i < pn.numNexts; ++i)
+				{
+					const int32_t v = m.congValues[pn.nextOff + i];
+					if (v <= 0) continue;
+					const uint32_t k = m.congKeys[pn.nextOff + i];
+					const uint32_t child = p + v;
+					// findLowerNode(p, k)
+					uint32_t node = p, lowerNode;
+					for (;;)
+					{
+						if (!m.congNodes[node].lower) { lowerNode = node; break; }
+						const uint32_t low = node + m.congNodes[node].lower;
+						int32_t found;
+						if (congSearch(m, m.congNodes[low], k, found) && found > 0) { lowerNode = low + found; break; }
+						node = low;
+					}
+					m.congNodes[child].lower = (int32_t)lowerNode - (int32_t)child;
+					if (m.congNodes[child].value == 0)
+					{
+						// findLowerValue(p, k)
+						uint32_t nd = p; uint32_t val = 0; bool done = false;
+						while (m.congNodes[nd].lower)
+						{
+							const uint32_t low = nd + m.congNodes[nd].lower;
+							int32_t found;
+							if (congSearch(m, m.congNodes[low], k, found)) { val = found >= 0 ? m.congNodes[low + found].value : (uint32_t)(-found); done = true; break; }
+							nd = low;
+						}
+						if (!done) val = m.congNodes[nd].value;
+						m.congNodes[child].value = val;
+					}
+					dq.push_back(child);
+				}
+			}
+			// embeddings
+			m.congDim = hd.dim; m.congCtx = (uint32_t)hd.contextSize;
+			const size_t stride = (size_t)hd.dim + 8;
+			m.congCtxEmb.assign(hd.contextSize * stride, 0); m.congOutEmb.assign(hd.vocabSize * stride, 0);
+			const uint8_t* e = blob + hd.embOffset;
+			const size_t ctxRec = (size_t)hd.dim + 2 + 2 + (hd.windowSize > 0 ? 4 : 0), outRec = (size_t)hd.dim + 2;
+			if (e + hd.contextSize * ctxRec + hd.vocabSize * outRec > end) throw std::runtime_error{ "cong.mdl: truncated embeddings" };
+			for (size_t i = 0; i < hd.contextSize; ++i, e += ctxRec)
+			{
+				uint8_t* o = &m.congCtxEmb[i * stride];
+				std::memcpy(o, e, hd.dim);
+				uint16_t hs, hb; std::memcpy(&hs, e + hd.dim, 2); std::memcpy(&hb, e + hd.dim + 2, 2);
+				const float scale = halfToFloat(hs), bias = -halfToFloat(hb);
+				std::memcpy(o + hd.dim, &scale, 4); std::memcpy(o + hd.dim + 4, &bias, 4);
+			}
+			for (size_t i = 0; i < hd.vocabSize; ++i, e += outRec)
+			{
+				uint8_t* o = &m.congOutEmb[i * stride];
+				std::memcpy(o, e, hd.dim);
+				uint16_t hs; std::memcpy(&hs, e + hd.dim, 2);
+				const float scale = halfToFloat(hs);
+				std::memcpy(o + hd.dim, &scale, 4);
+			}
+			// device lookup structures, in the shapes of the Knlm ones: edge hash (slot.ll carries the child's context id), root table, suffix links
+			auto asF = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
+			auto edgeCtx = [&](uint32_t node, int32_t v) { return v > 0 ? asF(m.congNodes[node + v].value) : asF(0u); };
+			m.congBackoff.resize(nonLeaf);
+			for (size_t i = 0; i < nonLeaf; ++i) m.congBackoff[i] = LmBackoff{ m.congNodes[i].lower, 0.f };
+			m.congRoot2.assign(hd.vocabSize, LmRootRec{ 0, 0.f });
+			for (uint32_t i = 0; i < m.congNodes[0].numNexts; ++i) if (keys[i] < hd.vocabSize) m.congRoot2[keys[i]] = LmRootRec{ m.congValues[i], edgeCtx(0, m.congValues[i]) };
+			const size_t nEdges = m.congKeys.size() - m.congNodes[0].numNexts;
+			size_t nBuckets = 1;
+			while (nBuckets * 2 < nEdges + 1) nBuckets <<= 1;
+			m.congHashMask = (uint32_t)(nBuckets - 1);
+			m.congHash.assign(nBuckets * 4, LmSlot{ LM_SLOT_EMPTY, LM_SLOT_EMPTY, 0, 0.f });
+			for (uint32_t nd = 1; nd < nonLeaf; ++nd)
+			{
+				const CongNodeRec& r = m.congNodes[nd];
+				for (uint32_t ei = 0; ei < r.numNexts; ++ei)
+				{
+					const uint32_t wid = m.congKeys[r.nextOff + ei];
+					const int32_t v = m.congValues[r.nextOff + ei];
+					uint32_t b = lmHashOf(nd, wid) & m.congHashMask;
+					for (;;)
+					{
+						LmSlot* s2 = &m.congHash[(size_t)b * 4];
+						int k = 0;
+						while (k < 4 && s2[k].node != LM_SLOT_EMPTY) ++k;
+						if (k < 4) { s2[k] = LmSlot{ nd, wid, v, edgeCtx(nd, v) }; break; }
+						b = (b + 1) & m.congHashMask;
+					}
+				}
+			}
+		}
+
 		// ---- the reference's on-disk model files ------------------------------------------------------------
 		// sj.morph = serializer::writeMany(os, toKey("KIWI"), forms, morphemes) (src/KiwiBuilder.cpp:923-937).  The serializer's format
 		// (src/serializer.hpp:212-350): fundamentals and enums raw little-endian, vectors and strings a u32 count followed by the elements,
@@ -664,6 +847,7 @@ namespace kamd
 		m.h.maxFormLen = maxLen;
 		if (maxLen > 64) throw std::runtime_error{ "dictionary form longer than 64 units: the trie-scan kernel's depth mask is 64 bits" };
 		loadKnlm(m, raw.knlm, raw.knlmSize);
+		if (raw.cong) loadCong(m, raw.cong, raw.congSize);
 		if (raw.sbg)
 		{
 			// SkipBigramModel blob, uncompressed + unquantised (reference src/SkipBigramModel.hpp:40-105): header{u64 vocabSize; u8 keySize,

@@ -36,6 +36,8 @@ namespace kamd
 		size_t knlmSize = 0;
 		const uint8_t* sbg = nullptr;   // optional SkipBigram blob (reference skipbigram.mdl layout)
 		size_t sbgSize = 0;
+		const uint8_t* cong = nullptr;  // optional CoNgram blob (reference cong.mdl layout)
+		size_t congSize = 0;
 
 		size_t nForms() const { return meta[0]; }
 		size_t nMorphs() const { return meta[1]; }
@@ -60,6 +62,7 @@ namespace kamd
 			auto s = c.get("knlm");
 			knlm = s.data; knlmSize = s.size;
 			if (c.has("sbg")) { auto g = c.get("sbg"); sbg = g.data; sbgSize = g.size; }
+			if (c.has("cong")) { auto g = c.get("cong"); cong = g.data; congSize = g.size; }
 		}
 	};
 }

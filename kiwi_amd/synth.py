@@ -126,6 +126,7 @@ class RawModel:
         self.vocab_size = 0
         self.knlm: bytes = b""
         self.sbg: bytes = b""          # optional: SkipBigramModel blob
+        self.cong: bytes = b""         # optional: CoNgram model blob (cong.mdl layout)
         self._init_defaults()
 
     # KiwiBuilder::initMorphemes (KiwiBuilder.cpp:1108-1131)
@@ -209,6 +210,7 @@ class RawModel:
             "chunk_pos": np.array(chunk_pos, "u1"),
             "knlm": np.frombuffer(self.knlm, "u1"),
             **({"sbg": np.frombuffer(self.sbg, "u1")} if self.sbg else {}),
+            **({"cong": np.frombuffer(self.cong, "u1")} if getattr(self, "cong", None) else {}),
         }
 
     def save(self, path: str):
@@ -296,6 +298,8 @@ class SynthSpec:
     lm_order: int = 3
     use_htx: bool = False
     use_sbg: bool = False        # also emit a SkipBigram model (reference skipbigram.mdl layout) over the same vocabulary
+    use_cong: bool = False       # also emit a local (window 0), 8-bit CoNgram model (reference cong.mdl layout) over the same vocabulary
+    cong_dim: int = 32
     seed: int = SEED_BASE
 
 
@@ -305,6 +309,9 @@ FULL_SBG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000
                           n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_sbg=True)   # FULL_SPEC + skip-bigram tables (32-bit keys)
 SMALL_SPEC = SynthSpec()
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
+SMALL_CONG_SPEC = SynthSpec(use_cong=True) # same lexicon as SMALL_SPEC + a local CoNgram model (the Knlm blob stays in the container: the dictionary bake needs a vocabulary size)
+FULL_CONG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
+                           n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_cong=True, cong_dim=64)
 
 
 class SynthModel:
@@ -666,6 +673,8 @@ class SynthModel:
         raw.knlm = build_knlm(sents, vocab, sp.lm_order, htx=htx)
         if sp.use_sbg:
             raw.sbg = build_sbg(sents, vocab, key_size=2 if vocab + 1 <= 0xFFFF else 4, seed=sp.seed + 2)
+        if sp.use_cong:
+            raw.cong = build_cong(sents, vocab, dim=sp.cong_dim, seed=sp.seed + 3)
 
     # -- text corpus -------------------------------------------------------------------------
     def make_corpus(self, n, seed, min_jamo=5, max_jamo=200, exact_jamo=None, oov_rate=0.03):
@@ -884,6 +893,115 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
     buf[gamma_off:gamma_off + gm_arr.nbytes] = gm_arr.tobytes()
     if htx_arr is not None:
         buf[htx_off:htx_off + htx_arr.nbytes] = htx_arr.tobytes()
+    return bytes(buf)
+
+
+def _svb_encode(values, v0124: bool) -> bytes:
+    """Stream VByte (Lemire / Kurz / Rupp 2017; the coding of the reference's cong.mdl node sizes, keys and values): ceil(n/4) control bytes of
+    four 2-bit length codes, then the significant bytes, little endian.  Standard codes 0..3 = 1, 2, 3, 4 bytes; '0124' codes = 0, 1, 2, 4 bytes."""
+    v = np.asarray(values, dtype=np.uint32)
+    n = len(v)
+    if v0124:
+        code = np.where(v == 0, 0, np.where(v < (1 << 8), 1, np.where(v < (1 << 16), 2, 3))).astype(np.uint8)
+        nbytes = np.array([0, 1, 2, 4], np.uint8)[code]
+    else:
+        code = np.where(v < (1 << 8), 0, np.where(v < (1 << 16), 1, np.where(v < (1 << 24), 2, 3))).astype(np.uint8)
+        nbytes = np.array([1, 2, 3, 4], np.uint8)[code]
+    pad = (-n) % 4
+    c4 = np.concatenate([code, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    ctrl = (c4[:, 0] | (c4[:, 1] << 2) | (c4[:, 2] << 4) | (c4[:, 3] << 6)).astype(np.uint8)
+    le = v.astype("<u4").view(np.uint8).reshape(-1, 4)
+    mask = np.arange(4)[None, :] < nbytes[:, None]
+    return ctrl.tobytes() + le[mask].tobytes()
+
+
+def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2) -> bytes:
+    """A synthetic *local* (window 0) CoNgram model in the reference's ``cong.mdl`` layout (reader: /root/reference/src/CoNgramModel.cpp:425-789;
+    header: include/kiwi/CoNgramModel.h:18-34): 8-bit embeddings (qbit 8), 32-bit keys (keySize 4), no optional sections (flags 0).
+
+    header 64 B | node sizes (Stream VByte 0124; pre-order stream, 0 = leaf) | keys (Stream VByte; per non-leaf node its sorted child keys) |
+    values (Stream VByte 0124; per node of the stream its context id, 0 = inherit from the longest suffix) |
+    per context: dim x int8, fp16 scale, fp16 (-bias) | per vocabulary word: dim x int8, fp16 scale.
+
+    The context trie holds the histories (token sequences of length <= max_ctx_len + 1 seen >= min_count times) of the LM training sentences;
+    every node is a context with its own embedding row.  Scores are not a trained model's: random embeddings scaled so that a transition costs
+    roughly -2 .. -12 like a log-probability -- the arithmetic (u8 x s8 dot product, hsum correction, two scales, bias) is what is exercised."""
+    rng = np.random.default_rng(seed)
+    flat = np.concatenate([np.asarray(s, dtype=np.int64) for s in sents])
+    lens = np.array([len(s) for s in sents], dtype=np.int64)
+    sid = np.repeat(np.arange(len(sents)), lens)
+    depth = max_ctx_len + 1
+    bits = max(1, int(vocab_size).bit_length())
+    assert bits * depth <= 63
+    children = {(): {}}                       # history tuple -> {next key: True}
+    n_tok = len(flat)
+    for n in range(1, depth + 1):
+        idx = np.arange(n_tok - n + 1)
+        idx = idx[sid[idx] == sid[idx + n - 1]]
+        code = np.zeros(len(idx), dtype=np.int64)
+        for k in range(n):
+            code = (code << bits) | flat[idx + k]
+        u, cnt = np.unique(code, return_counts=True)
+        u = u[cnt >= (1 if n == 1 else min_count)]
+        for c in u.tolist():
+            g = tuple((c >> (bits * (n - 1 - k))) & ((1 << bits) - 1) for k in range(n))
+            if g[:-1] in children:
+                children[g[:-1]][g[-1]] = True
+                children.setdefault(g, {})
+    node_sizes, keys_out, values = [], [], []
+    n_ctx = 1                                  # context 0: the empty / unknown context
+
+    def emit(h):
+        nonlocal n_ctx
+        ch = children[h]
+        node_sizes.append(len(ch))
+        if h and rng.random() < 0.85:
+            values.append(n_ctx); n_ctx += 1
+        else:
+            values.append(0)                   # the root, and a share of the inner nodes: the context of the longest suffix applies
+        ks = sorted(ch)
+        keys_out.extend(ks)
+        for k in ks:
+            g = h + (k,)
+            if children.get(g):
+                emit(g)
+            else:
+                node_sizes.append(0)
+                values.append(n_ctx); n_ctx += 1      # a leaf always names a context (its value is stored negated: must be non-zero)
+    import sys
+    sys.setrecursionlimit(10000)
+    emit(())
+    num_nodes = len(node_sizes)
+    assert len(keys_out) == num_nodes - 1 and n_ctx < (1 << 24)
+
+    def half(x):
+        return np.asarray(x, np.float16).view(np.uint16)
+    # value range: the reference's SSE4.1 / AVX2 kernels form the u8 x s8 dot product with pmaddubsw, which adds two products with SIGNED 16-bit
+    # SATURATION; |value| <= 63 keeps every pair sum below 2^15 (2 * 191 * 63), so that the exact integer dot product is also theirs
+    ctx_emb = rng.integers(-63, 64, size=(n_ctx, dim), dtype=np.int8)
+    ctx_scale = half(rng.uniform(0.008, 0.024, n_ctx))
+    ctx_negbias = half(rng.uniform(3.0, 9.0, n_ctx))                 # stored as -bias
+    out_emb = rng.integers(-63, 64, size=(vocab_size, dim), dtype=np.int8)
+    out_scale = half(rng.uniform(0.008, 0.024, vocab_size))
+    emb = bytearray()
+    for i in range(n_ctx):
+        emb += ctx_emb[i].tobytes() + ctx_scale[i].tobytes() + ctx_negbias[i].tobytes()
+    for i in range(vocab_size):
+        emb += out_emb[i].tobytes() + out_scale[i].tobytes()
+
+    def al(x):
+        return (x + 15) & ~15
+    node_b, key_b, val_b = _svb_encode(node_sizes, True), _svb_encode(keys_out, False), _svb_encode(values, True)
+    node_off = 64
+    key_off = al(node_off + len(node_b))
+    val_off = al(key_off + len(key_b))
+    emb_off = al(val_off + len(val_b))
+    buf = bytearray(al(emb_off + len(emb)))
+    struct.pack_into("<QQHHBBBBQQQQQ", buf, 0, vocab_size, n_ctx, dim, 0, 4, 0, 8, 0, num_nodes, node_off, key_off, val_off, emb_off)
+    buf[node_off:node_off + len(node_b)] = node_b
+    buf[key_off:key_off + len(key_b)] = key_b
+    buf[val_off:val_off + len(val_b)] = val_b
+    buf[emb_off:emb_off + len(emb)] = emb
     return bytes(buf)
 
 

@@ -20,6 +20,7 @@ struct OracleHandle
 	FlatModel model;
 	ModelView view;
 	SbgView sbg;          // present when the raw model carries SkipBigram tables
+	CongView cong;        // present when the raw model carries a CoNgram blob: the search is scored with it (the reference's default model type)
 	PersistentContainers persistent;   // faithfulOrder: what the reference keeps thread_local (single-threaded entry points only)
 	SplitConfig scfg{ 0, 6, 0xFFFFFFFFu, 0 };
 	BestPathConfig bcfg;
@@ -67,7 +68,7 @@ namespace
 			if (!ok) continue;
 			BestPathConfig bc2 = bc;
 			bc2.openEnding = openEnding && ch.nextOffset == pt.norm.size();
-			BestPathSearch bp{ h.view, bc2, cnt, h.sbg, persistent };
+			BestPathSearch bp{ h.view, bc2, cnt, h.sbg, persistent, h.cong };
 			bp.run(paths, pt.norm, pt.cls, nodes.data(), (uint32_t)nodes.size(), rb.spStates());
 			rb.insertPaths(paths);
 		}
@@ -85,6 +86,8 @@ extern "C"
 			bakeModel(h->model, rawModelPath);
 			h->view = h->model.view();
 			h->sbg = h->model.sbgView();
+			h->cong = h->model.congView();
+			if (h->cong.present()) h->sbg = SbgView{};
 			return h.release();
 		}
 		catch (const std::exception& e) { fprintf(stderr, "korc_open: %s\n", e.what()); return nullptr; }
@@ -118,6 +121,18 @@ extern "C"
 		auto d = dumpDict(((OracleHandle*)hp)->model);
 		if (d.size() <= cap) std::memcpy(out, d.data(), d.size());
 		return d.size();
+	}
+
+	// One CoNgram step (CoNgramState::next): node and context id in / out
+	float korc_cong_next(void* hp, int32_t* node, uint32_t* ctx, uint32_t wid)
+	{
+		auto& h = *(OracleHandle*)hp;
+		BestPathConfig bc; Counters c;
+		BestPathSearch bp{ h.view, bc, c, SbgView{}, nullptr, h.cong };
+		WPath st; st.lmNode = *node; st.ctx = *ctx;
+		const float ll = bp.lmNext(st, wid);
+		*node = st.lmNode; *ctx = st.ctx;
+		return ll;
 	}
 
 	float korc_lm_progress(void* hp, int32_t* node, uint32_t wid)

@@ -27,6 +27,9 @@
 #include <kiwi/Knlm.h>
 #include <kiwi/SkipBigramModel.h>
 #include "SkipBigramModel.hpp"
+#ifdef KREF_X86
+#include <kiwi/CoNgramModel.h>
+#endif
 #include <kiwi/Dataset.h>
 #include "ArchAvailable.h"
 #include "KTrie.h"
@@ -138,6 +141,11 @@ namespace kiwi
 		{
 			Vector<FormRaw> forms; Vector<MorphemeRaw> morphemes;
 			fromRaw(raw, forms, morphemes);
+#ifdef KREF_X86
+			// a container that carries a CoNgram blob is analysed with it (the reference's default model type): CoNgramModelBase::create with
+			// quantized = true exists for the SIMD architectures only (src/ArchAvailable.h:50-78), which is why this is the x86 build's job
+			if (raw.cong) return build(forms, morphemes, raw.cong, raw.congSize, nullptr, 0, arch, true);
+#endif
 			return build(forms, morphemes, raw.knlm, raw.knlmSize, raw.sbg, raw.sbgSize, arch);
 		}
 
@@ -152,11 +160,15 @@ namespace kiwi
 			serializer::readMany(is, serializer::toKey("KIWI"), forms, morphemes);
 		}
 
-		static Kiwi build(const Vector<FormRaw>& forms, const Vector<MorphemeRaw>& morphemes, const uint8_t* knlm, size_t knlmSize, const uint8_t* sbg, size_t sbgSize, ArchType arch)
+		static Kiwi build(const Vector<FormRaw>& forms, const Vector<MorphemeRaw>& morphemes, const uint8_t* knlm, size_t knlmSize, const uint8_t* sbg, size_t sbgSize, ArchType arch, bool cong = false)
 		{
 			utils::MemoryOwner mem{ knlmSize };
 			std::memcpy(mem.get(), knlm, knlmSize);
 			std::shared_ptr<lm::ILangModel> langMdl;
+#ifdef KREF_X86
+			if (cong) langMdl = lm::CoNgramModelBase::create(utils::MemoryObject{ std::move(mem) }, arch, false, true);   // local (window 0), quantised: ModelType::cong
+			else
+#endif
 			if (sbg)
 			{
 				// SkipBigram on top of the same Knlm (KiwiBuilder.cpp: ModelType::sbg): SkipBigramModelBase::create (src/SkipBigramModel.cpp:99)
@@ -294,6 +306,12 @@ namespace
 		{
 		case 1: return kiwi::ArchType::balanced;
 		case 2: return kiwi::ArchType::sse2;
+#ifdef KREF_X86
+		case 3: return kiwi::ArchType::sse4_1;
+		case 4: return kiwi::ArchType::avx2;
+		case 5: return kiwi::ArchType::avx512bw;
+		case 6: return kiwi::ArchType::avx512vnni;
+#endif
 		default: return kiwi::ArchType::none;
 		}
 	}
@@ -423,6 +441,16 @@ extern "C"
 		*node = (int32_t)n;
 		return ll;
 	}
+
+#ifdef KREF_X86
+	// One CoNgram state step through the reference (CoNgramModelBase::progressOneStep, src/CoNgramModel.cpp:922-927 -> progress()): node and context id in / out
+	float kref_cong_next(void* hp, int32_t* node, uint32_t* ctx, uint32_t wid)
+	{
+		auto* lm = dynamic_cast<const kiwi::lm::CoNgramModelBase*>(Acc::lm(((RefHandle*)hp)->kw));
+		if (!lm) return 0.f / 0.f;
+		return lm->progressOneStep(*node, *ctx, wid);
+	}
+#endif
 
 	// One SkipBigram state step through the reference (SbgState::nextImpl, src/SkipBigramModel.hpp:169-182); 16-bit vocabulary only.
 	float kref_sbg_next(void* hp, int32_t* node, uint32_t* pos, uint32_t* hist8, uint32_t wid)

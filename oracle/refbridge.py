@@ -17,6 +17,13 @@ MATCH_ALL = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1
 MATCH_ALL_WITH_NORMALIZING = MATCH_ALL | (1 << 16)
 
 
+LIB_X86_PATH = os.path.join(HERE, "_ref", "libkiwi_ref_x86.so")
+
+
+def x86_available() -> bool:
+    return os.path.exists(LIB_X86_PATH)
+
+
 def available() -> bool:
     return os.path.exists(LIB_PATH)
 
@@ -84,10 +91,12 @@ def write_model_dir(raw_model_path: str, out_dir: str):
 
 
 class RefKiwi:
-    def __init__(self, raw_model_path: str, arch: int = 0, model_dir_sbg=None):
+    def __init__(self, raw_model_path: str, arch: int = 0, model_dir_sbg=None, x86=False):
         """raw_model_path: a raw container; or, with model_dir_sbg = False / True, a DIRECTORY holding the reference's own model files,
-        loaded through the reference's serializer (Knlm only / with skipbigram.mdl)."""
-        self.lib = C.CDLL(LIB_PATH)
+        loaded through the reference's serializer (Knlm only / with skipbigram.mdl).
+        x86: the library built with every SIMD architecture and src/CoNgramModel.cpp (oracle/Makefile refx86): a container with a CoNgram blob is
+        analysed with it; arch 3 = sse4_1, 4 = avx2, 5 = avx512bw, 6 = avx512vnni (the quantised CoNgram path exists for those only)."""
+        self.lib = C.CDLL(LIB_X86_PATH if x86 else LIB_PATH)
         L = self.lib
         L.kref_open_dir.restype = C.c_void_p
         L.kref_open_dir.argtypes = [C.c_char_p, C.c_int, C.c_int]

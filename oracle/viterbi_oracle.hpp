@@ -47,6 +47,7 @@ namespace korc
 
 	struct WPath   // WordLL<KnLMState> (BestPathContainer.hpp:21-67)
 	{
+		uint32_t ctx = 0;              // CoNgram models: CoNgramState::contextIdx (the LM state proper is lmNode: CoNgramModel.hpp:470-473)
 		int32_t lmNode = 0;
 		// SkipBigram state on top of the Knlm node (SbgState, SkipBigramModel.hpp:141-182): ring of the last 8 valid word ids
 		uint32_t hist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; uint8_t histPos = 0;
@@ -99,6 +100,7 @@ namespace korc
 	{
 		const ModelView& M;
 		SbgView S;                       // absent (vocabSize == 0): plain Knlm scoring
+		CongView C;                      // present: CoNgram scoring (local, quantised) through the transposed evaluator
 		const BestPathConfig& cfg;
 		Counters& cnt;
 		const U16* norm = nullptr;   // normalised text
@@ -158,8 +160,68 @@ namespace korc
 
 		// LmState::next: Knlm alone, or SbgState::nextImpl (SkipBigramModel.hpp:169-182) + SkipBigramModel::evaluate (:113-139) with
 		// the scalar logSumExp of MathFunc.hpp:43-56 (ArchType::none / balanced): same operations, same order, fp32
+		// CoNgramModel::progressContextNodeVl (src/CoNgramModel.hpp:306-385): the context id the history + `next` maps to; moves `node`
+		bool congSearch(const CongNodeRec& nd, uint32_t key, int32_t& v) const
+		{
+			const uint32_t* k = C.keys + nd.nextOff;
+			const uint32_t* it = std::lower_bound(k, k + nd.numNexts, key);
+			if (it == k + nd.numNexts || *it != key) return false;
+			v = C.values[nd.nextOff + (it - k)];
+			return v != 0;
+		}
+		uint32_t congContext(int32_t& nodeIdx, uint32_t next) const
+		{
+			for (;;)
+			{
+				int32_t v;
+				const CongNodeRec* node = &C.nodes[nodeIdx];
+				if (nodeIdx != 0)
+				{
+					if (!congSearch(*node, next, v))
+					{
+						if (!node->lower) return 0;
+						nodeIdx += node->lower;
+						continue;
+					}
+				}
+				else
+				{
+					v = next < C.vocabSize ? C.root[next] : 0;
+					if (v == 0) return 0;
+				}
+				if (v > 0) { nodeIdx += v; return C.nodes[nodeIdx].value; }
+				while (node->lower)
+				{
+					node += node->lower;
+					int32_t lv;
+					if (node != C.nodes)
+					{
+						if (congSearch(*node, next, lv) && lv > 0) { nodeIdx = (int32_t)(node + lv - C.nodes); return (uint32_t)-v; }
+					}
+					else
+					{
+						lv = next < C.vocabSize ? C.root[next] : 0;
+						if (lv > 0) { nodeIdx = lv; return (uint32_t)-v; }
+					}
+				}
+				nodeIdx = 0;
+				return (uint32_t)-v;
+			}
+		}
+		// CoNgramModel::progress, window 0, quantised (src/CoNgramModel.cpp:869-908): the score in the CURRENT context, then the context moves on
+		// outputFirst: the batched path of the reference's SSE4.1 build multiplies the output scale in first (src/archImpl/sse4_1.cpp:116,
+		// scatteredGEMV_128: ((x * outputScale) * contextScale) + bias) where progress() and the baseline kernel (src/qgemm.hpp:73-80) multiply the
+		// context scale first -- one rounding apart
+		float congNext(WPath& st, uint32_t next, bool outputFirst = false) const
+		{
+			const float ll = outputFirst ? congScoreOutputFirst(C, st.ctx, next) : congScore(C, st.ctx, next);
+			st.ctx = congContext(st.lmNode, next);
+			return ll;
+		}
+
 		float lmNext(WPath& st, uint32_t next)
 		{
+			if (C.present()) return congNext(st, next);
 			float ll = lmProgress(st.lmNode, next);
 			if (!S.present()) return ll;
 			if (next < S.vocabSize && S.valid[next])
@@ -489,6 +551,251 @@ namespace korc
 			});
 		}
 
+		// MorphemeEvaluator<CoNgramState>::eval (src/CoNgramModel.cpp:18-318), the candidate side of the transposed PathEvaluator: all regular
+		// candidates first (their scores against every socket-free incoming path come from progressMatrix: per pair, the same arithmetic as
+		// progress()), then the left halves of split stems, then the right halves; one path container per candidate as in evalSingle.
+		void evalCong(int mode, std::vector<WPath>& outv, uint32_t nodeIdx, uint16_t ownFormId, const std::vector<uint32_t>& morphs, float ignoreCondScore, float nodeLevelDiscount)
+		{
+			const LNode* node = graph + nodeIdx;
+			struct Prev { const LNode* node; uint32_t idx; };
+			std::vector<Prev> regularPrev, combiningPrev;
+			const LNode* pfirst = node - node->prev;
+			for (const LNode* prev = node->prev ? pfirst : nullptr; prev; prev = prev->sibling ? prev + prev->sibling : nullptr)
+			{
+				const auto& pcs = cache[prev - graph];
+				for (uint32_t pi = 0; pi < pcs.size(); ++pi) (pcs[pi].combineSocket ? combiningPrev : regularPrev).push_back(Prev{ prev, pi });
+			}
+			std::vector<uint32_t> regular, combL, combR;
+			for (uint32_t mid : morphs)
+			{
+				const MorphRec& cm = M.morphs[mid];
+				const bool single = cm.flags & MF_SINGLE;
+				if (cm.socket) { (single ? combL : combR).push_back(mid); continue; }
+				const uint32_t firstWid = single ? cm.lmId : M.chunkLm[cm.chunkOff];
+				if (M.morphs[firstWid].tag == T_P) continue;
+				regular.push_back(mid);
+			}
+			auto ruleOf = [&](uint32_t morphId)
+			{
+				const MorphRec& cm = M.morphs[morphId];
+				Rule rule;
+				rule.special = cm.special;
+				rule.sbType = cm.tag == T_SB ? M.sbInfo[morphId] : 0;
+				rule.sbOrder = rule.sbType ? cm.senseId : 0;
+				rule.vowelE = cm.flags & MF_VOWEL_E; rule.infJ = cm.flags & MF_INF_J; rule.badPairOfL = cm.flags & MF_BAD_PAIR_OF_L;
+				rule.positiveE = isEClass(cm.tag) && node->form != NOFORM && (M.forms[node->form].flags & FF_STARTS_WITH_A);
+				rule.contractableE = cm.flags & MF_CONTRACTABLE_E;
+				rule.snEndsWithPoint = cm.tag == T_SN && node->uformLen && (*norm)[node->uformOff + node->uformLen - 1] == u'.';
+				rule.condP = cm.polar;
+				return rule;
+			};
+			// FormEvaluator (PathEvaluator.hpp:253-311): false = the path is excluded; may add ignoreCondScore to `score`
+			auto formOk = [&](const WPath& pp, const MorphRec& cm, float& score) -> bool
+			{
+				const MorphRec& pm = M.morphs[pp.morph];
+				uint16_t feat; bool sscLeft;
+				const MorphRec& wm = M.morphs[pp.wid];
+				if (pp.ownFormId)
+				{
+					uint32_t l; const uint16_t* sp = ownStr(pp.ownFormId, l);
+					feat = featMask(sp, l);
+					sscLeft = l && identifySpecialChr(sp[l - 1]) == T_SSC;
+				}
+				else if (!(wm.flags & MF_KFORM_EMPTY)) { feat = wm.feat; sscLeft = wm.flags & MF_ENDS_WITH_SSC; }
+				else if (pm.tag == T_UNKNOWN && pm.nChunks)
+				{
+					const MorphRec& lm = M.morphs[M.chunkMorph[pm.chunkOff + pm.nChunks - 1]];
+					feat = lm.feat; sscLeft = lm.flags & MF_ENDS_WITH_SSC;
+				}
+				else { feat = pm.feat; sscLeft = pm.flags & MF_ENDS_WITH_SSC; }
+				if (pm.tag == T_SSC || sscLeft) return true;
+				if (ignoreCondScore != 0) { score += featTest(feat, cm.vowel, cm.polar) ? 0 : ignoreCondScore; return true; }
+				return featTest(feat, cm.vowel, cm.polar);
+			};
+			// insertToPathContainer (PathEvaluator.hpp:193-251)
+			auto insertAll = [&](uint32_t morphId, const Rule& rule, const Prev& pr, const WPath& pp, const WPath& lmSt, float cand, float firstChunk)
+			{
+				cnt.transitions++;
+				auto insert = [&](uint8_t rootId)
+				{
+					uint8_t sp = pp.spState;
+					if (rootId != COMMON_ROOT) sp = uniqStates[rootId];
+					const float rs = rule(M.morphs[pp.wid], sp);
+					if (rule.special == 0) sp |= 1; else if (rule.special == 1) sp &= ~1; else if (rule.special == 3) sp |= 2; else if (rule.special == 4) sp &= ~2;
+					if (rule.sbType) sp = (uint8_t)((sp & 3) | (Rule::hashSb((uint8_t)rule.sbType, (uint8_t)(rule.sbOrder + 1)) << 2));
+					WPath np;
+					np.morph = morphId; np.accScore = (cand + rs) - 0.f; np.firstChunkScore = (firstChunk + rs) - 0.f;
+					np.accTypoCost = pp.accTypoCost + node->typoCost;
+					np.parentNode = (int32_t)(pr.node - graph); np.parentIdx = (int32_t)pr.idx;
+					np.lmNode = lmSt.lmNode; np.ctx = lmSt.ctx;
+					np.spState = sp;
+					np.rootId = pp.rootId; np.prevRootId = pp.rootId;
+					if (rootId != COMMON_ROOT) np.rootId = rootId;
+					contInsert(mode, np);
+				};
+				const bool quote = rule.special == 0 || rule.special == 1 || rule.special == 3 || rule.special == 4;
+				if ((rule.sbType || quote) && pp.rootId == COMMON_ROOT) for (uint8_t r = 0; r < uniqStates.size(); ++r) insert(r);
+				else insert(COMMON_ROOT);
+			};
+			auto writeOut = [&](uint32_t morphId)
+			{
+				const MorphRec& cm = M.morphs[morphId];
+				const bool single = cm.flags & MF_SINGLE;
+				contEach(mode, [&](const WPath& p)
+				{
+					outv.push_back(p);
+					WPath& q = outv.back();
+					q.wid = cm.lastSeqId;
+					if (single) { q.combineSocket = cm.socket; q.ownFormId = ownFormId; }
+				});
+			};
+			// Which kernel scores the (incoming path x regular candidate) matrix decides the rounding of every entry.  One path and one candidate:
+			// state.next() = progress().  Otherwise progressMatrixNoWindow (src/CoNgramModel.cpp:1495-1611) over the m UNIQUE context ids and the
+			// n UNIQUE first word ids: qgemm::scatteredGEMMOpt<sse4_1> (src/qgemm.hpp:157-205; pin = the reference's SSE4.1 build, the simplest
+			// dispatch): m <= 3 and n <= 3 -> baseline; n == 1 -> scatteredGEMV (specialised, output scale first) unless m == 8 (scatteredGEMV8x1:
+			// baseline there); everything else -> baseline.
+			bool outputFirst = false;
+			if (!(regularPrev.size() == 1 && regular.size() == 1) && !regularPrev.empty() && !regular.empty())
+			{
+				std::vector<uint32_t> uc, uw;
+				for (const Prev& pr : regularPrev) uc.push_back(cache[pr.node - graph][pr.idx].ctx);
+				for (uint32_t mid : regular) { const MorphRec& cm = M.morphs[mid]; uw.push_back((cm.flags & MF_SINGLE) ? cm.lmId : M.chunkLm[cm.chunkOff]); }
+				std::sort(uc.begin(), uc.end()); uc.erase(std::unique(uc.begin(), uc.end()), uc.end());
+				std::sort(uw.begin(), uw.end()); uw.erase(std::unique(uw.begin(), uw.end()), uw.end());
+				const size_t m = uc.size(), n = uw.size();
+				outputFirst = !(m <= 3 && n <= 3) && n == 1 && m != 8;
+			}
+			for (uint32_t mid : regular)
+			{
+				const MorphRec& cm = M.morphs[mid];
+				const bool single = cm.flags & MF_SINGLE;
+				const uint32_t firstWid = single ? cm.lmId : M.chunkLm[cm.chunkOff];
+				const uint32_t length = single ? 1u : cm.nChunks;
+				contClear();
+				cnt.candMorphs++;
+				const Rule rule = ruleOf(mid);
+				const float morphScore = cm.userScore + nodeLevelDiscount + leftBoundary[(hasLeftBoundary(node) ? T_MAX : 0) + clearIrregular(cm.tag)] * 5.f;
+				for (const Prev& pr : regularPrev)
+				{
+					const WPath& pp = cache[pr.node - graph][pr.idx];
+					WPath lmSt = pp;
+					const float ll = congNext(lmSt, firstWid, outputFirst);          // progressMatrix / next(): scores[prev][cur] and the moved-on state
+					float score = pp.accScore + morphScore + ll;
+					const float firstChunk = morphScore + ll;
+					if (!formOk(pp, cm, score)) continue;
+					if (M.morphs[pp.morph].tag == T_Z_SIOT && (!isNNClass(cm.tag) || pr.node->endPos < node->startPos)) continue;
+					bool bad = false;
+					for (uint32_t c = 1; c < length; ++c)
+					{
+						const uint32_t wid = M.chunkLm[cm.chunkOff + c];
+						if (M.morphs[wid].tag == T_P) { bad = true; break; }
+						score += congNext(lmSt, wid);
+					}
+					if (bad) continue;
+					insertAll(mid, rule, pr, pp, lmSt, score, firstChunk);
+				}
+				writeOut(mid);
+			}
+			for (uint32_t mid : combL)
+			{
+				const MorphRec& cm = M.morphs[mid];
+				contClear();
+				cnt.candMorphs++;
+				const Rule rule = ruleOf(mid);
+				const float morphScore = cm.userScore + nodeLevelDiscount + leftBoundary[(hasLeftBoundary(node) ? T_MAX : 0) + clearIrregular(cm.tag)] * 5.f;
+				for (const Prev& pr : regularPrev)
+				{
+					const WPath& pp = cache[pr.node - graph][pr.idx];
+					float score = pp.accScore + morphScore;
+					if (!formOk(pp, cm, score)) continue;
+					insertAll(mid, rule, pr, pp, pp, score, morphScore);
+				}
+				writeOut(mid);
+			}
+			for (uint32_t mid : combR)
+			{
+				const MorphRec& cm = M.morphs[mid];
+				const bool single = cm.flags & MF_SINGLE;
+				const uint32_t length = single ? 1u : cm.nChunks;
+				contClear();
+				cnt.candMorphs++;
+				const Rule rule = ruleOf(mid);
+				const float morphScore = cm.userScore + nodeLevelDiscount + leftBoundary[(hasLeftBoundary(node) ? T_MAX : 0) + clearIrregular(cm.tag)] * 5.f;
+				for (const Prev& pr : combiningPrev)
+				{
+					const WPath& pp = cache[pr.node - graph][pr.idx];
+					float score = pp.accScore + morphScore;
+					float firstChunk = 0;
+					if (pp.combineSocket != cm.socket || single) continue;
+					if (pr.node->endPos < node->startPos)
+					{
+						if (cfg.spaceTolerance > 0) score -= cfg.spacePenalty; else continue;
+					}
+					const uint32_t firstWid = M.morphs[M.morphs[pp.wid].combinedId].lmId;
+					if (!formOk(pp, cm, score)) continue;
+					WPath lmSt = pp;
+					score += (firstChunk = congNext(lmSt, firstWid));
+					firstChunk += morphScore;
+					bool bad = false;
+					for (uint32_t c = 1; c < length; ++c)
+					{
+						const uint32_t wid = M.chunkLm[cm.chunkOff + c];
+						if (M.morphs[wid].tag == T_P) { bad = true; break; }
+						score += congNext(lmSt, wid);
+					}
+					if (bad) continue;
+					insertAll(mid, rule, pr, pp, lmSt, score, firstChunk);
+				}
+				writeOut(mid);
+			}
+		}
+
+		// the transposed PathEvaluator::operator() (src/PathEvaluator.hpp:859-1035): candidate filter, z-coda / z-siot shortcuts FIRST, then the
+		// candidate evaluator above; pruning is the caller's (shared with the row-major evaluator)
+		void evaluateCongNode(std::vector<WPath>& nCache, uint32_t nodeIdx, uint16_t ownFormId, const uint32_t* cands, uint32_t nCands, float nodeLevelDiscount, int mode)
+		{
+			const LNode* node = graph + nodeIdx;
+			const LNode* pfirst = node - node->prev;
+			uint32_t zCoda = 0, zSiot = 0; bool hasZCoda = false, hasZSiot = false;
+			std::vector<uint32_t> valid;
+			for (uint32_t ci = 0; ci < nCands; ++ci)
+			{
+				const uint32_t mid = cands[ci];
+				const MorphRec& cm = M.morphs[mid];
+				if (cfg.splitComplex && (cm.flags & MF_HAS_COMPLEX)) continue;
+				if (cm.tag == T_Z_CODA) { zCoda = mid; hasZCoda = true; continue; }
+				if (cm.tag == T_Z_SIOT) { zSiot = mid; hasZSiot = true; continue; }
+				if (!(cm.flags & MF_SINGLE) && (cm.flags & MF_HA_CONTRACTION) && node->prev && (node - node->prev)->endPos < node->startPos) continue;
+				valid.push_back(mid);
+			}
+			auto shortcut = [&](uint32_t mid, bool coda)
+			{
+				const MorphRec& cm = M.morphs[mid];
+				for (const LNode* prev = node->prev ? pfirst : nullptr; prev; prev = prev->sibling ? prev + prev->sibling : nullptr)
+				{
+					const auto& pcs = cache[prev - graph];
+					for (uint32_t pi = 0; pi < pcs.size(); ++pi)
+					{
+						const uint8_t lastTag = M.morphs[pcs[pi].wid].tag;
+						if (coda ? (!isJClass(lastTag) && !isEClass(lastTag)) : !isNNClass(lastTag)) continue;
+						WPath np = pcs[pi];
+						np.accScore += cm.userScore * cfg.typoCostWeight;
+						np.accTypoCost -= cm.userScore;
+						np.parentNode = (int32_t)(prev - graph); np.parentIdx = (int32_t)pi;
+						np.morph = cm.lmId; np.wid = cm.lmId;
+						nCache.push_back(np);
+					}
+				}
+			};
+			for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
+			{
+				if (hasZCoda) shortcut(zCoda, true);
+				if (hasZSiot && (cfg.splitSaisiot || cfg.mergeSaisiot)) shortcut(zSiot, false);
+				evalCong(mode, nCache, nodeIdx, ownFormId, valid, ignoreCond ? -10.f : 0.f, nodeLevelDiscount);
+				if (!nCache.empty()) break;
+			}
+		}
+
 		void evaluate(uint32_t nodeIdx, uint16_t ownFormId, const uint32_t* cands, uint32_t nCands, float unkDiscount)
 		{
 			const LNode* node = graph + nodeIdx;
@@ -505,6 +812,8 @@ namespace korc
 			if (totalPrev > 512) cnt.nodesOver512++;
 			const int mode = cfg.topN > 1 ? 3 : totalPrev <= cfg.smallMax ? 0 : totalPrev <= cfg.mediumMax ? 1 : 2;
 
+			if (C.present()) evaluateCongNode(nCache, nodeIdx, ownFormId, cands, nCands, nodeLevelDiscount, mode);
+			else
 			for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
 			{
 				for (uint32_t ci = 0; ci < nCands; ++ci)
@@ -655,7 +964,7 @@ namespace korc
 		}
 
 	public:
-		BestPathSearch(const ModelView& m, const BestPathConfig& c, Counters& k, const SbgView& sbg = SbgView{}, PersistentContainers* persistent = nullptr) : M(m), S(sbg), cfg(c), cnt(k)
+		BestPathSearch(const ModelView& m, const BestPathConfig& c, Counters& k, const SbgView& sbg = SbgView{}, PersistentContainers* persistent = nullptr, const CongView& cong = CongView{}) : M(m), S(sbg), C(cong), cfg(c), cnt(k)
 		{
 			if (c.faithfulOrder && persistent)
 			{
@@ -686,7 +995,7 @@ namespace korc
 			uniqStates.erase(std::unique(uniqStates.begin(), uniqStates.end()), uniqStates.end());
 			if (prevSpStates.empty()) uniqStates.push_back(0);
 
-			WPath bos; bos.morph = 0; bos.lmNode = M.h.bosNode; bos.rootId = COMMON_ROOT;
+			WPath bos; bos.morph = 0; bos.lmNode = C.present() ? 0 : M.h.bosNode; bos.rootId = COMMON_ROOT;      // CoNgramState(): node 0, context 0
 			cache[0].push_back(bos);
 			reach[0] = 1;
 			const uint32_t unkCands[2] = { T_NNG + 1u, T_NNP + 1u }, unkLCands[1] = { T_NNP + 1u };
@@ -755,7 +1064,7 @@ namespace korc
 					}
 					WPath np;
 					np.accScore = c; np.firstChunkScore = first; np.accTypoCost = p.accTypoCost;
-					np.parentNode = (int32_t)(prev - g); np.parentIdx = (int32_t)pi; np.lmNode = lmSt.lmNode;
+					np.parentNode = (int32_t)(prev - g); np.parentIdx = (int32_t)pi; np.lmNode = lmSt.lmNode; np.ctx = lmSt.ctx;
 					if (p.rootId == COMMON_ROOT)
 					{
 						for (size_t r = 0; r < uniqStates.size(); ++r) { np.spState = uniqStates[r]; np.rootId = (uint8_t)r; cand.push_back(np); }

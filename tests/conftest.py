@@ -37,6 +37,18 @@ def small_sbg_model():
 
 
 @pytest.fixture(scope="session")
+def small_cong_model():
+    """The small synthetic model plus a local, 8-bit CoNgram model in the reference's cong.mdl layout (kiwi_amd/synth.py SMALL_CONG_SPEC)."""
+    from kiwi_amd.synth import SynthModel, SMALL_CONG_SPEC
+    d = os.path.join(ROOT, "_data")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "small-cong.raw")
+    sm = SynthModel(SMALL_CONG_SPEC)
+    sm.raw.save(path)
+    return sm, path
+
+
+@pytest.fixture(scope="session")
 def oracle(small_model):
     import subprocess
     import oraclelib
