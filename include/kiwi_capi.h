@@ -7,8 +7,9 @@
  * Differences a caller can observe:
  *   - kiwi_init's model_path names a raw-model container (or a directory holding `kiwi_amd.raw`);
  *     on-disk sj.morph / sj.knlm loaders are a "next" row.  Its `options` are honoured as in the reference:
- *     KIWI_BUILD_INTEGRATE_ALLOMORPH sets integrate_allomorph; the model type bits select Knlm (default, KNLM) or SkipBigram (LARGEST when
- *     the container has the tables, SBG) and refuse CONG / CONG_GLOBAL; the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).
+ *     KIWI_BUILD_INTEGRATE_ALLOMORPH sets integrate_allomorph; the model type bits select a CoNgram model (default / LARGEST when the
+ *     container has one, CONG; local scoring), Knlm (default otherwise, KNLM) or SkipBigram (LARGEST when the container has the tables, SBG)
+ *     and refuse CONG_GLOBAL; the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).
  *   - top_n > 4, blocklist, pretokenized spans and non-standard dialects are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
  *     being silently ignored.
  */

@@ -272,19 +272,25 @@ extern "C"
 			// options (capi.h:158-171; kiwi_c.cpp:717-736): bit 0 = integrateAllomorph (KiwiBuilder.cpp:2413); bits 1-3 ask for dictionaries that a raw
 			// container already has baked in (or not) -- they cannot change anything here; 0x0F00 = model type
 			if (options & ~0x0F0F) throw std::invalid_argument{ "kiwi_amd: unknown build option bits" };
-			Engine::LmMode lm;
+			Engine::LmMode lm; bool knlmUnlessCong = false;
 			switch (options & 0x0F00)
 			{
-			case 0x0000: case 0x0200: lm = Engine::LmMode::Knlm; break;   // default: with skip-bigram tables present the reference still picks knlm (KiwiBuilder.cpp:939-961)
-			case 0x0100: lm = Engine::LmMode::Auto; break;                  // largest: sbg when present
+			// default / largest: the reference looks for cong.mdl first (-> cong / congGlobal), then skipbigram.mdl (-> knlm / sbg), then sj.knlm
+			// (KiwiBuilder.cpp:939-961); here: a CoNgram blob when the container has one (local scoring: the global variant is not built),
+			// else Knlm by default and SkipBigram for `largest`
+			case 0x0000: lm = Engine::LmMode::Auto; knlmUnlessCong = true; break;
+			case 0x0100: lm = Engine::LmMode::Auto; break;
+			case 0x0200: lm = Engine::LmMode::Knlm; break;
 			case 0x0300: lm = Engine::LmMode::Sbg; break;
-			case 0x0400: case 0x0500: throw std::invalid_argument{ "kiwi_amd: CoNgram models are not supported on the device path yet" };
+			case 0x0400: lm = Engine::LmMode::Cong; break;
+			case 0x0500: throw std::invalid_argument{ "kiwi_amd: CoNgram models with distant-token (global) scoring are not supported on the device path yet" };
 			default: throw std::invalid_argument{ "kiwi_amd: unknown model type" };
 			}
 			if (enabled_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported" };
 			const std::string path = model_path ? model_path : "";      // a directory with sj.morph + sj.knlm (+ skipbigram.mdl) or kiwi_amd.raw, or a raw container file
 			auto h = std::make_unique<kiwi_s>();
 			h->engine.reset(new Engine(path, 0, lm));
+			if (knlmUnlessCong && !h->engine->usesCong() && h->engine->usesSbg()) h->engine.reset(new Engine(path, 0, Engine::LmMode::Knlm));
 			h->engine->config.integrateAllomorph = !!(options & 1);
 			// a replica of the device tables on every other visible GPU (KAMD_DEVICES=n limits it; 1 = single-GPU behaviour)
 			int nDev = Engine::visibleDevices();

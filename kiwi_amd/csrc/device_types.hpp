@@ -165,6 +165,9 @@ namespace kamd
 		uint8_t* itemScratch;          // per lane group: SbgScratch (viterbi_kernel.hpp), rings of the work items of one batch
 	};
 
+	// CoNgram model on the device (flat_model.hpp CongView): embedding rows of dim x s8 + f32 scale + f32 bias (context) / f32 scale + 4 unused bytes (output)
+	struct CongDev { const uint8_t* ctxEmb; const uint8_t* outEmb; uint32_t dim, stride; };
+
 	// LDS layout of the wave-per-chunk lattice build (byte offsets): n text units, node capacity, packed-match capacity
 	struct LatticeLds { uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, endPosMap, fullMask, zAt, mforms, mfrec, out, spaceErr, queue, total; };
 	// LDS-side capacities are the typical need (3 per text unit), not the worst-case HBM capacities: a chunk that outgrows

@@ -25,7 +25,7 @@ namespace kamd
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
 	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
-	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
+	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
 
 	namespace
 	{
@@ -177,6 +177,7 @@ namespace kamd
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter;
+		CongDev cong{}; bool hasCong = false;   // CoNgram model: the context trie is uploaded where the Knlm tables would be (ModelView::lmHash / lmRoot2 / lmBackoff)
 		SbgDev sbg{}; bool hasSbg = false; DevBuf sbgScratch;   // SkipBigram tables on the device + per-lane-group item scratch of its search kernel
 		// the engine owns ONE pair of streams, one work counter and one scratch arena: device work of concurrent callers (the C API
 		// is callable from many threads, reference capi threading contract) is serialised per engine; host preparation is not
@@ -203,6 +204,9 @@ namespace kamd
 	{
 		bakeModel(impl->model, path);
 		if (lm == LmMode::Sbg && impl->model.sbgPtrs.empty()) throw std::runtime_error{ "Cannot open required files for skipbigram model" };   // KiwiBuilder.cpp:1008-1013
+		if (lm == LmMode::Cong && !impl->model.congDim) throw std::runtime_error{ "Cannot open ConG model file 'cong.mdl'" };      // KiwiBuilder.cpp:1018-1023
+		if (lm == LmMode::Knlm || lm == LmMode::Sbg) { impl->model.congDim = 0; }
+		if (impl->model.congDim) { impl->model.sbgPtrs.clear(); impl->model.sbgKeys.clear(); impl->model.sbgComps.clear(); impl->model.sbgDiscnts.clear(); impl->model.sbgValid.clear(); }
 		if (lm == LmMode::Knlm) { impl->model.sbgPtrs.clear(); impl->model.sbgKeys.clear(); impl->model.sbgComps.clear(); impl->model.sbgDiscnts.clear(); impl->model.sbgValid.clear(); }
 		if (!impl->model.sbgPtrs.empty() && impl->model.sbgWindow != 8)
 			throw std::runtime_error{ "kiwi_amd: SkipBigram window size must be 8 (the reference instantiates SbgState<8> only, src/SkipBigramModel.cpp)" };
@@ -246,7 +250,16 @@ namespace kamd
 		v.sbInfo = impl->up(m.sbInfo); v.morphPath = impl->up(m.morphPath);
 		v.trie = impl->up(m.trie); v.trieKeys = impl->up(m.trieKeys); v.trieChild = impl->up(m.trieChild); v.trieRoot = impl->up(m.trieRoot);
 		v.lmNodes = impl->up(m.lmNodes); v.lmKeys = impl->up(m.lmKeys); v.lmValues = impl->up(m.lmValues); v.lmRoot = impl->up(m.lmRoot);
-		v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff);
+		if (m.congDim)
+		{
+			// CoNgram: the search walks the CONTEXT trie through the same lookup structures (edge hash with the child's context id in the slot,
+			// root table, suffix links); the initial state is the root with context 0 (CoNgramState())
+			v.lmHash = impl->up(m.congHash); v.lmHashMask = m.congHashMask; v.lmRoot2 = impl->up(m.congRoot2); v.lmBackoff = impl->up(m.congBackoff);
+			v.h.bosNode = 0;
+			impl->cong = CongDev{ impl->up(m.congCtxEmb), impl->up(m.congOutEmb), m.congDim, m.congDim + 8 };
+			impl->hasCong = true;
+		}
+		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
 		if (!m.sbgPtrs.empty())
 		{
 			const SbgView sv = m.sbgView();
@@ -286,6 +299,8 @@ namespace kamd
 	}
 
 	const FlatModel& Engine::model() const { return impl->model; }
+	bool Engine::usesCong() const { return impl->hasCong; }
+	bool Engine::usesSbg() const { return impl->hasSbg; }
 
 	namespace
 	{
@@ -538,13 +553,13 @@ namespace kamd
 		// SkipBigram: one chunk per wave unless 16-lane groups are forced -- with history rings in the container keys a lattice node gathers
 		// thousands of work items, so a chunk's serial chain is items / lanes (MI355X, small model: 480 texts 0.7 s with 64 lanes, 7 s with 16)
 		const bool variant64 = I.hasSbg ? !(I.groupLanesForced && I.groupLanes == 16) : (I.groupLanesForced && I.groupLanes == 64);
-		const uint32_t nGroups = (I.hasSbg || b.typo.typo) ? (variant64 ? 1u : 4u)
+		const uint32_t nGroups = (I.hasSbg || b.typo.typo || I.hasCong) ? (variant64 ? 1u : 4u)
 			: 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
 		// (the SkipBigram kernel is built for 2 waves per SIMD and carries 1.8 MB of item scratch per lane group: 8 persistent blocks per CU)
 		const uint32_t persistBlocks = I.hasSbg ? I.persistBlocks / 12 * 8 : I.persistBlocks;
 		const uint32_t maxBlocks = std::min(persistBlocks, (maxWork + nGroups - 1) / nGroups);
-		const size_t groupScratchBytes = I.hasSbg ? sizeof(GroupScratchT<BIGQ_SBG>) : sizeof(GroupScratch);
+		const size_t groupScratchBytes = I.hasSbg ? sizeof(GroupScratchT<BIGQ_SBG>) : I.hasCong ? sizeof(GroupScratchCong<BIGQ>) : sizeof(GroupScratch);
 		I.bigScratch.ensure((size_t)maxBlocks * nGroups * groupScratchBytes * std::min(S, 2u));
 		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)groupScratchBytes;
 		if (I.hasSbg)
@@ -593,7 +608,7 @@ namespace kamd
 				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget);
 			}
 			}
-			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn);
+			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u);
 			HIPCHECK(hipEventRecord(e[2], sA));
 			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));
 			HIPCHECK(hipEventRecord(e[3], sB));
@@ -614,7 +629,7 @@ namespace kamd
 			// groups, 2 waves per SIMD measured best on 8192 x 40 jamo); with many chunks it is a throughput problem and narrower
 			// groups + a third wave per SIMD win (65536 x 40 jamo: 6.9 vs 9.3 ms).  KAMD_GROUP_LANES / KAMD_WPS override.
 			const bool many = cn >= 32768;
-			const int gl = (I.hasSbg || b.typo.typo) ? (variant64 ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
+			const int gl = (I.hasSbg || b.typo.typo || I.hasCong) ? (variant64 ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
 			const int wps = b.typo.typo ? 2 : I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
 			const uint32_t blocksK = std::min(persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
@@ -628,6 +643,14 @@ namespace kamd
 				sd.itemScratch = I.sbgScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(SbgScratch) : 0);
 				if (gl == 64) hipLaunchKernelGGL((sbgk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
 				else hipLaunchKernelGGL((sbgk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
+			}
+			else if (I.hasCong)
+			{
+				// CoNgram model: the search kernel compiled with KAMD_CONG (16-lane groups, or one chunk per wave when 64 is forced); its LDS
+				// slices also stage the context id of every work item
+				const uint32_t ldsC = ldsK + (64u / (uint32_t)gl) * 4u * QCAP;
+				if (gl == 64) hipLaunchKernelGGL((congk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsC, sB, I.dview, b.bv, wv, sp, counter, order, cn, I.cong);
+				else hipLaunchKernelGGL((congk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsC, sB, I.dview, b.bv, wv, sp, counter, order, cn, I.cong);
 			}
 			else if (b.typo.typo)
 			{
@@ -797,6 +820,7 @@ namespace kamd
 		if (typo.typo)
 		{
 			if (impl->hasSbg) throw std::runtime_error{ "kiwi_amd: typo correction with a SkipBigram model is not built" };
+			if (impl->hasCong) throw std::runtime_error{ "kiwi_amd: typo correction with a CoNgram model is not built" };
 			if (impl->model.forms.size() >= (1u << 24)) throw std::runtime_error{ "kiwi_amd: typo correction supports up to 2^24 forms" };
 		}
 		HostTimer tm{ "stage" };

@@ -62,10 +62,11 @@ namespace kamd
 		EngineConfig config;
 		// which language model of the container scores the search (reference ModelType, include/kiwi/Types.h:292-335): Auto = SkipBigram when the
 		// container carries its tables, else Knlm; Knlm = Knlm even then; Sbg = SkipBigram or an error
-		enum class LmMode { Auto, Knlm, Sbg };
+		enum class LmMode { Auto, Knlm, Sbg, Cong };      // Auto: CoNgram when the container has a blob, else SkipBigram when it has tables, else Knlm
 		explicit Engine(const std::string& rawModelPath, int device = -1, LmMode lm = LmMode::Auto);
 		Engine(const Engine& other, int device);      // replica of `other` on another GPU (shares the baked host model)
 		static int visibleDevices();
+		bool usesCong() const; bool usesSbg() const;      // which language model scores the search
 		~Engine();
 		const FlatModel& model() const;
 

@@ -676,7 +676,10 @@ namespace kamd
 
 	// Static candidate records per lattice node (one block per chunk, one thread per node): resolves
 	// form -> candidate list -> morpheme record -> first LM id once, off the search kernel's dependent-load chain.
-	__global__ void __launch_bounds__(64) k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount)
+	// transposedOrder (CoNgram models): a node's records in the order the reference's transposed evaluator takes the candidates -- z-coda and
+	// z-siot shortcuts first, then the regular candidates, then the left halves of split stems, then the right halves (src/PathEvaluator.hpp:
+	// 884-915 + MorphemeEvaluator<CoNgramState>, src/CoNgramModel.cpp:86-135), each class in dictionary order
+	__global__ void __launch_bounds__(64) k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder)
 	{
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t chunk = chunkBegin + blockIdx.x;
@@ -700,7 +703,27 @@ namespace kamd
 				// 4th word: LM id of the second chunk of a chunked candidate (saves the search a dependent chunk-table load)
 				const uint32_t secondWid = (!(flags & MF_SINGLE) && (o.m1.w & 0xFF) >= 2) ? M.chunkLm[o.m0.z + 1] : 0;
 				o.x = Quad{ mid, firstWid, sbType, secondWid };
-				packs[nd.packOff + k] = o;
+				uint32_t at = k;
+				if (transposedOrder)
+				{
+					auto cls = [&](uint32_t m2) -> uint32_t
+					{
+						const MorphRec r = M.morphs[m2];
+						if (r.tag == T_Z_CODA) return 0;
+						if (r.tag == T_Z_SIOT) return 1;
+						if (!r.socket) return 2;
+						return (r.flags & MF_SINGLE) ? 3 : 4;
+					};
+					const uint32_t mine = cls(mid);
+					at = 0;
+					for (uint32_t j = 0; j < nd.candCnt; ++j)
+					{
+						if (j == k) continue;
+						const uint32_t other = cls(M.formCand[candOff + j]);
+						if (other < mine || (other == mine && j < k)) ++at;
+					}
+				}
+				packs[nd.packOff + at] = o;
 			}
 		}
 	}

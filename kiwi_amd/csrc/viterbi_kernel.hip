@@ -58,7 +58,20 @@
 #else
 #define TYPO_ONLY(...)
 #endif
-#if defined(KAMD_SBG) || defined(KAMD_TYPO)
+// CoNgram models (local, quantised; reference src/CoNgramModel.cpp): a fourth compilation (viterbi_kernel_cong.hip, KAMD_CONG, namespace kamd::congk).
+// The LM state is the context-trie node plus the context id of the history (DevState::pad0); a transition is scored by an int8 dot product of
+// two embedding rows; candidates are evaluated in the order of the reference's transposed evaluator (MorphemeEvaluator<CoNgramState>).
+#ifdef KAMD_CONG
+#define CONG_ONLY(...) __VA_ARGS__
+#else
+#define CONG_ONLY(...)
+#endif
+#if defined(KAMD_SBG) || defined(KAMD_CONG)
+#define STATE_EXTRA(...) __VA_ARGS__      // the state's spare dword carries part of the LM state (ring position / context id)
+#else
+#define STATE_EXTRA(...)
+#endif
+#if defined(KAMD_SBG) || defined(KAMD_TYPO) || defined(KAMD_CONG)
 #define KAMD_VARIANT 1      // not the Knlm translation unit: the pieces that exist once (end-stage kernel, LDS size helper) are left out
 #endif
 
@@ -67,6 +80,12 @@ namespace kamd
 #ifdef KAMD_TYPO
 namespace typok
 {
+#endif
+#ifdef KAMD_CONG
+namespace congk
+{
+	// (the big queue of this namespace also carries the context id of every work item)
+	using GroupScratch = GroupScratchCong<BIGQ>;
 #endif
 #ifdef KAMD_SBG
 namespace sbgk
@@ -142,7 +161,12 @@ namespace sbgk
 		static constexpr uint32_t KEY = 0;                          // u64[QCAP]
 		static constexpr uint32_t SCORE = KEY + 8 * QCAP;           // f32[QCAP]
 		static constexpr uint32_t FCS = SCORE + 4 * QCAP;
+#ifdef KAMD_CONG
+		static constexpr uint32_t CTXQ = FCS + 4 * QCAP;           // u32[QCAP]: context id of every staged work item
+		static constexpr uint32_t CAND = CTXQ + 4 * QCAP;          // 64-byte packed candidate records [MAXC]
+#else
 		static constexpr uint32_t CAND = FCS + 4 * QCAP;           // 64-byte packed candidate records [MAXC]
+#endif
 		static constexpr uint32_t STSCORE = CAND + 64 * MAXC;       // f32[SCAP]
 		static constexpr uint32_t STBITS = STSCORE + 4 * SCAP;      // u8[SCAP]
 		static constexpr uint32_t RBEG = STBITS + SCAP;             // u32[RING]
@@ -229,14 +253,14 @@ namespace sbgk
 		return h;
 	}
 	__device__ __forceinline__ void storeState(DevState* st, uint32_t i, int32_t lmNode, float acc, float typo, uint32_t wid, uint16_t leftFeat, uint8_t rootId, uint8_t sp,
-		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode SBG_ONLY(, uint32_t histPos = 0))
+		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode STATE_EXTRA(, uint32_t histPos = 0))
 	{
 		uint4* p = reinterpret_cast<uint4*>(st + i);
 		p[0] = make_uint4((uint32_t)lmNode, __float_as_uint(acc), (uint32_t)leftFeat | ((uint32_t)rootId << 16) | ((uint32_t)sp << 24),
 			(uint32_t)socket | ((uint32_t)prevFlags << 8) | ((uint32_t)ownKind << 24));
 		p[1] = make_uint4(__float_as_uint(typo), wid, parent, morph);
-#ifdef KAMD_SBG
-		p[2] = make_uint4(__float_as_uint(fcs), (uint32_t)nodeId | ((uint32_t)ownNode << 16), histPos, 0);   // DevState::pad0 = ring position
+#if defined(KAMD_SBG) || defined(KAMD_CONG)
+		p[2] = make_uint4(__float_as_uint(fcs), (uint32_t)nodeId | ((uint32_t)ownNode << 16), histPos, 0);   // DevState::pad0 = ring position / context id
 #else
 		p[2] = make_uint4(__float_as_uint(fcs), (uint32_t)nodeId | ((uint32_t)ownNode << 16), 0, 0);
 #endif
@@ -299,6 +323,69 @@ namespace sbgk
 			return acc + ll;
 		}
 	}
+
+#ifdef KAMD_CONG
+	__device__ __forceinline__ int32_t dot4s8(uint32_t a, uint32_t b, int32_t acc)
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		return __builtin_amdgcn_sdot4((int)a, (int)b, acc, false);      // v_dot4_i32_i8
+#else
+		for (int k = 0; k < 4; ++k) acc += (int32_t)(int8_t)(a >> (8 * k)) * (int32_t)(int8_t)(b >> (8 * k));
+		return acc;
+#endif
+	}
+	// CoNgramModel::progress, window 0, quantised (src/CoNgramModel.cpp:869-908): the score of `next` in the CURRENT context, then the context
+	// moves on (progressContextNodeVl, src/CoNgramModel.hpp:306-385, over the edge hash: slot.value > 0 child offset with the child's context id in
+	// the slot's ll bits, < 0 minus the context id of a leaf).  outputFirst: the rounding of the reference's batched SSE4.1 kernel
+	// (src/archImpl/sse4_1.cpp:116: ((x * outputScale) * contextScale) + bias) instead of progress()'s ((x * contextScale) * outputScale) + bias.
+	__device__ INL3 float congStep(const ModelView& M, const CongDev& CG, int32_t& node, uint32_t& ctx, uint32_t next, bool outputFirst)
+	{
+		const uint32_t* a = reinterpret_cast<const uint32_t*>(CG.ctxEmb + (size_t)ctx * CG.stride);
+		const uint32_t* b = reinterpret_cast<const uint32_t*>(CG.outEmb + (size_t)next * CG.stride);
+		const LmRootRec rootRec = M.lmRoot2[next];
+		const uint32_t nw = CG.dim >> 2;
+		int32_t acc = 0;
+		for (uint32_t k = 0; k < nw; ++k) acc = dot4s8(a[k], b[k], acc);
+		const float cs = __uint_as_float(a[nw]), bias = __uint_as_float(a[nw + 1]), os = __uint_as_float(b[nw]);
+		const float x = (float)acc;
+		const float ll = outputFirst ? x * os * cs + bias : x * cs * os + bias;
+		// context walk
+		for (;;)
+		{
+			int32_t v; float cbits;
+			if (node == 0)
+			{
+				v = rootRec.value; cbits = rootRec.ll;
+				if (v == 0) { ctx = 0; return ll; }
+			}
+			else
+			{
+				const LmBackoff bo = M.lmBackoff[node];
+				if (!lmLookup(M, (uint32_t)node, next, v, cbits))
+				{
+					if (!bo.lower) { ctx = 0; return ll; }
+					node += bo.lower;
+					continue;
+				}
+			}
+			if (v > 0) { node += v; ctx = __float_as_uint(cbits); return ll; }
+			// leaf: its own context id; the new node is the longest suffix context that continues with `next`
+			ctx = (uint32_t)-v;
+			int32_t cur = node;
+			for (;;)
+			{
+				const int32_t lower = M.lmBackoff[cur].lower;
+				if (!lower) break;
+				cur += lower;
+				int32_t lv; float l2;
+				if (cur == 0) { lv = rootRec.value; if (lv > 0) { node = lv; return ll; } }
+				else if (lmLookup(M, (uint32_t)cur, next, lv, l2) && lv > 0) { node = cur + lv; return ll; }
+			}
+			node = 0;
+			return ll;
+		}
+	}
+#endif
 
 #ifdef KAMD_SBG
 	// ---- SkipBigram LM state beyond the Knlm node: ring of the last 8 valid word ids + write position (SbgState,
@@ -416,10 +503,13 @@ namespace sbgk
 			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; tl = o.tl;
 			SBG_ONLY(S = o.S; hist = o.hist; sscr = o.sscr;)
 			TYPO_ONLY(typoAll = o.typoAll; nodeTypo = o.nodeTypo;)
+			CONG_ONLY(CG = o.CG; outFirst = o.outFirst;)
 		}
 		// SkipBigram: the model view, the chunk's state rings (parallel to st) and the lane group's item scratch
 		SBG_ONLY(const SbgDev* S; uint32_t* hist; SbgScratch* sscr;)
 		TYPO_ONLY(const float* typoAll; const float* nodeTypo;)      // typo cost of every node of the batch / of the chunk's nodes
+		CONG_ONLY(const CongDev* CG; bool outFirst;)                 // embedding tables; which kernel of the reference rounds the regular candidates' scores at this node
+		CONG_ONLY(__device__ __forceinline__ LDS_AS uint32_t* qCtx() const { return ldsPtr<uint32_t>(lds + Lay<G>::CTXQ); })
 		uint32_t gl, gshift, lds;       // lane in group, group's first lane, byte offset of the group's LDS slice
 		const DevNode* nodes; uint32_t Gn;
 		const uint16_t* str; const uint8_t* cls;
@@ -472,9 +562,9 @@ namespace sbgk
 	}
 	template<int G>
 	__device__ __forceinline__ void putState(GroupCtx<G>& X, uint32_t i, int32_t lmNode, float acc, float typo, uint32_t wid, uint16_t leftFeat, uint8_t rootId, uint8_t sp,
-		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode SBG_ONLY(, uint32_t histPos = 0))
+		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode STATE_EXTRA(, uint32_t histPos = 0))
 	{
-		storeState(X.st, i, lmNode, acc, typo, wid, leftFeat, rootId, sp, socket, prevFlags, ownKind, parent, morph, fcs, nodeId, ownNode SBG_ONLY(, histPos));
+		storeState(X.st, i, lmNode, acc, typo, wid, leftFeat, rootId, sp, socket, prevFlags, ownKind, parent, morph, fcs, nodeId, ownNode STATE_EXTRA(, histPos));
 		if constexpr (Lay<G>::HCAP != 0)
 		{
 			if (i < Lay<G>::HCAP)
@@ -540,6 +630,7 @@ namespace sbgk
 		const bool fast = (G == 16 || G == 8) && Qtot <= (uint32_t)G && mode == 0;
 #endif
 		uint64_t rKey = KINVALID; float rScore = 0, rFcs = 0, rTypo = 0;
+		CONG_ONLY(uint32_t rCtx = 0;)      // context id of the item's new LM state
 #ifdef KAMD_SBG
 		uint32_t rDigest = 0;      // digest of the item's history ring (the ring itself goes to X.sscr)
 		const bool last4 = X.P.topN > 1;   // what of the ring belongs to the container key (sameRing)
@@ -554,6 +645,7 @@ namespace sbgk
 			if (valid) { while (k + 1 < nC && q >= X.candQOff(k + 1)) ++k; }
 			float cand = 0, firstChunk = 0; int32_t lmNode = 0; uint8_t rootKey = 0, sp = 0;
 			SBG_ONLY(Ring ring{};)
+			CONG_ONLY(uint32_t ctx = 0; float icDeferred = 0;)
 			if (valid)
 			{
 				const Cand c = loadCand(X.candOff(k));
@@ -568,7 +660,17 @@ namespace sbgk
 				do
 				{
 					if (ps.dead()) { valid = false; break; }
+#ifdef KAMD_CONG
+					// the candidate evaluator of the transposed search tests the sai-siot rule for regular candidates only (CoNgramModel.cpp:170-176)
+					if (!csock && (ps.leftFeat() & LF_PREV_ZSIOT) && (!isNNClass(ctag) || spaceBefore)) { valid = false; break; }
+					// ... pairs the right half of a split stem with paths that end in a left half ONLY, each with the combined word of ITS path
+					// (CoNgramModel.cpp:262-283): no carried-over word id here
+					if (csock && !single && !ps.socket()) { valid = false; break; }
+					// ... and pairs everything else with socket-free paths only
+					if (!(csock && !single) && ps.socket()) { valid = false; break; }
+#else
 					if ((ps.leftFeat() & LF_PREV_ZSIOT) && (!isNNClass(ctag) || spaceBefore)) { valid = false; break; }
+#endif
 					cand = ps.accScore + c.additional;
 					firstChunk = c.additional;
 					if (ps.socket())
@@ -579,7 +681,12 @@ namespace sbgk
 							if (X.P.spaceTol > 0) cand -= X.P.spacePenalty; else { valid = false; break; }
 						}
 					}
+#ifdef KAMD_CONG
+					if (csock && !single) { firstWid = M.morphs[M.morphs[X.st[pBeg + p].wid].combinedId].lmId; widReplaced = true; }
+					if (false)
+#else
 					if (csock && !single)
+#endif
 					{
 						// the reference keeps the combined word id of the latest matching split stem for all later predecessors
 						// (PathEvaluator.hpp:578-591: `firstWid` is assigned inside the loop and never reset)
@@ -597,18 +704,30 @@ namespace sbgk
 					if (!(ps.leftFeat() & (LF_STR_SSC | LF_TAG_SSC)))
 					{
 						const bool ok = featTest(ps.leftFeat() & 0x1FFF, c.vowel(), c.polar());
+#ifdef KAMD_CONG
+						// a regular candidate gets the penalty AFTER its first LM score: ((acc + morphScore) + ll) + ignoreCondScore (CoNgramModel.cpp:163-168)
+						if (ignoreCondScore != 0) { if (!csock) icDeferred = ok ? 0 : ignoreCondScore; else cand += ok ? 0 : ignoreCondScore; }
+#else
 						if (ignoreCondScore != 0) cand += ok ? 0 : ignoreCondScore;
+#endif
 						else if (!ok) { valid = false; break; }
 					}
 					lmNode = ps.lmNode;
 					SBG_ONLY(ring = loadRing(X.hist + 8ull * (pBeg + p), X.st[pBeg + p].pad0);)
+					CONG_ONLY(ctx = X.st[pBeg + p].pad0;)
 					if (!(csock && single))
 					{
 						// prohibit <v> without <chunk> (PathEvaluator.hpp:604-608): static per candidate unless the word id was replaced above
 						if (widReplaced ? (M.morphs[firstWid].tag == T_P) : ((c.flags() & MF_FIRST_WID_IS_P) != 0)) { valid = false; break; }
+#ifdef KAMD_CONG
+						float ll = congStep(M, *X.CG, lmNode, ctx, firstWid, X.outFirst && !csock);
+						cand += ll; firstChunk += ll;
+						cand += icDeferred;
+#else
 						float ll = lmProgress(M, lmNode, firstWid);
 						SBG_ONLY(ll = sbgNext(*X.S, ring.h, ring.pos, firstWid, ll);)
 						cand += ll; firstChunk += ll;
+#endif
 						if (!single)
 						{
 							const uint32_t nCh = c.nChunks();
@@ -616,8 +735,12 @@ namespace sbgk
 							{
 								const uint32_t wid = ch == 1 ? c.secondWid : M.chunkLm[c.chunkOff + ch];
 								if ((c.flags() & MF_ANY_REST_WID_IS_P) && M.morphs[wid].tag == T_P) { valid = false; break; }
+#ifdef KAMD_CONG
+								ll = congStep(M, *X.CG, lmNode, ctx, wid, false);
+#else
 								ll = lmProgress(M, lmNode, wid);
 								SBG_ONLY(ll = sbgNext(*X.S, ring.h, ring.pos, wid, ll);)
+#endif
 								cand += ll;
 							}
 							if (!valid) break;
@@ -641,6 +764,7 @@ namespace sbgk
 				// key: LM node | new special state | previous root | candidate ; r is recoverable from q
 				const uint64_t key = valid ? ((uint64_t)(uint32_t)lmNode | ((uint64_t)sp << 32) | ((uint64_t)rootKey << 40) | ((uint64_t)k << 48)) : KINVALID;
 				rKey = key; rScore = cand; rFcs = firstChunk;
+				CONG_ONLY(rCtx = ctx; if (!fast) { if (big) X.scratch->ctx[q] = ctx; else X.qCtx()[q] = ctx; })
 #ifdef KAMD_SBG
 				// the LM state of the item beyond the Knlm node; the queues are filled on the register path too, which hands a
 				// batch over to the scanning path when two digests collide
@@ -660,7 +784,7 @@ namespace sbgk
 
 		// ---- emission pass: representatives in container iteration order, each carrying its key's winner ----
 		// writes the state of key `wkey` (winner item qw of candidate k) at arena slot pos
-		auto emitState = [&](uint32_t k, uint32_t qw, uint64_t wkey, float wscore, float wfcs, uint32_t pos, bool haveTypo, float parentTypo)
+		auto emitState = [&](uint32_t k, uint32_t qw, uint64_t wkey, float wscore, float wfcs, uint32_t pos, bool haveTypo, float parentTypo CONG_ONLY(, uint32_t wctx))
 		{
 			const Cand c = loadCand(X.candOff(k));
 			const uint32_t local = qw - c.qOff;
@@ -683,7 +807,7 @@ namespace sbgk
 			storeRing(X.hist + 8ull * pos, er);
 #endif
 			putState<G>(X, pos, (int32_t)(uint32_t)wkey, wscore, wtypo, c.lastSeqId, lf, newRoot, (uint8_t)(wkey >> 32), stSocket, c.prevFlags(),
-				own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0 SBG_ONLY(, er.pos));
+				own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0 SBG_ONLY(, er.pos) CONG_ONLY(, wctx));
 			stageState<G>(X, pos - E.nodeStart, wscore, newRoot, c.socket() != 0, stSocket != 0);
 		};
 #ifdef KAMD_SBG
@@ -742,11 +866,12 @@ namespace sbgk
 				}
 				const float wfcs = X.bcast(rFcs, (int)qw);
 				const float wtyp = X.bcast(rTypo, (int)qw);
+				CONG_ONLY(const uint32_t wctx = X.bcast(rCtx, (int)qw);)
 				const uint64_t kbal = X.ballot(rep);
 				if (rep)
 				{
 					const uint32_t pos = X.stTop + X.prefix(kbal);
-					if (pos < X.stCap) emitState((uint32_t)(rKey >> 48), qw, rKey, best, wfcs, pos, true, wtyp);
+					if (pos < X.stCap) emitState((uint32_t)(rKey >> 48), qw, rKey, best, wfcs, pos, true, wtyp CONG_ONLY(, wctx));
 					else X.overflow = true;
 				}
 				X.stTop += __popcll(kbal);
@@ -865,6 +990,10 @@ namespace sbgk
 							uint64_t lmv = (uint64_t)(int64_t)(int32_t)(uint32_t)key;
 #pragma unroll
 							for (int w = 0; w < 8; ++w) lmv = (uint64_t)myRing.h[w] ^ ((lmv << 3) | (lmv >> 61));
+#elif defined(KAMD_CONG)
+							// Hash<CoNgramState<0>> = Hash<uint32_t>(node) (src/CoNgramModel.hpp:505-541)
+							const uint64_t nv = (uint64_t)(uint32_t)key;
+							const uint64_t lmv = (nv * 2305843009213693951ull) ^ ((nv << 33) | (nv >> 31));
 #else
 							const uint64_t lmv = (uint64_t)(int64_t)(int32_t)(uint32_t)key;
 #endif
@@ -885,7 +1014,8 @@ namespace sbgk
 							const uint64_t wkey = big ? X.scratch->key[qw] : X.qKey()[qw];
 							const float wscore = big ? X.scratch->score[qw] : X.qScore()[qw];
 							const float wfcs = big ? X.scratch->fcs[qw] : X.qFcs()[qw];
-							emitState(k, qw, wkey, wscore, wfcs, pos, false, 0.f);
+							CONG_ONLY(const uint32_t wctx = big ? X.scratch->ctx[qw] : X.qCtx()[qw];)
+							emitState(k, qw, wkey, wscore, wfcs, pos, false, 0.f CONG_ONLY(, wctx));
 						}
 						else X.overflow = true;
 					}
@@ -950,7 +1080,7 @@ namespace sbgk
 					ns.prevFlags = nm.prevFlags;
 					SBG_ONLY(storeRing(X.hist + 8ull * pos, loadRing(X.hist + 8ull * (E.pBeg + p), ns.pad0));)   // the LM state is handed on unchanged
 					putState<G>(X, pos, ns.lmNode, ns.accScore, ns.accTypoCost, ns.wid, ns.leftFeat, ns.rootId, ns.spState, ns.socket, ns.prevFlags, ns.ownKind,
-						ns.parent, ns.morph, ns.firstChunkScore, ns.nodeId, ns.ownNode SBG_ONLY(, ns.pad0));
+						ns.parent, ns.morph, ns.firstChunkScore, ns.nodeId, ns.ownNode STATE_EXTRA(, ns.pad0));
 					stageState<G>(X, pos - E.nodeStart, ns.accScore, ns.rootId, newMorphSocket, ns.socket != 0);
 				}
 				else X.overflow = true;
@@ -975,6 +1105,65 @@ namespace sbgk
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		enum { K_NONE = 0, K_SKIP = 1, K_Z = 2, K_REG = 3 };
 		constexpr int MAXC = Lay<G>::MAXC;
+#ifdef KAMD_CONG
+		// Which kernel of the reference scores the (socket-free incoming path x regular candidate) matrix of this evaluation decides the rounding of
+		// its entries (congStep).  One path and one candidate: progress().  Otherwise progressMatrixNoWindow over the m UNIQUE context ids and the n
+		// UNIQUE first word ids -> qgemm::scatteredGEMMOpt<sse4_1> (src/qgemm.hpp:157-205): the specialised scatteredGEMV (output scale first) iff
+		// n == 1, m >= 4 and m != 8; the baseline kernel (context scale first, like progress()) in every other case.
+		{
+			X.outFirst = false;
+			uint32_t nReg = 0, refWid = 0xFFFFFFFFu; bool oneWid = true;
+			for (uint32_t cb = 0; cb < nCands; cb += G)
+			{
+				const uint32_t idx = cb + X.gl;
+				bool reg = false; uint32_t fw = 0;
+				if (idx < nCands)
+				{
+					const uint4* cs = reinterpret_cast<const uint4*>(cands + idx);
+					const uint4 m1 = cs[1], mx = cs[2];
+					const uint32_t flags = m1.y & 0xFFFF; const uint8_t tag = (uint8_t)m1.z, sock = (uint8_t)(m1.z >> 24);
+					const bool skip = (P.splitComplex && (flags & MF_HAS_COMPLEX)) || tag == T_Z_CODA || tag == T_Z_SIOT
+						|| (!(flags & MF_SINGLE) && (flags & MF_HA_CONTRACTION) && E.nodeIdx && spaceBefore);
+					reg = !skip && !sock && !(flags & MF_FIRST_WID_IS_P);
+					fw = mx.y;
+				}
+				const uint64_t bal = X.ballot(reg);
+				if (bal)
+				{
+					const uint32_t f0 = X.bcast(fw, __ffsll((unsigned long long)bal) - 1);
+					if (refWid == 0xFFFFFFFFu) refWid = f0;
+					if (X.any(reg && fw != refWid)) oneWid = false;
+					nReg += __popcll(bal);
+				}
+			}
+			if (nReg && oneWid && E.nP >= 4)
+			{
+				uint32_t m = 0;
+				for (uint32_t pb = 0; pb < E.nP; pb += G)
+				{
+					const uint32_t p = pb + X.gl;
+					bool isNew = false;
+					if (p < E.nP)
+					{
+						const Hot h = getHot<G>(X, E.pBeg + p);
+						if (!h.dead() && !h.socket())
+						{
+							const uint32_t cx = X.st[E.pBeg + p].pad0;
+							isNew = true;
+							for (uint32_t j = 0; j < p; ++j)
+							{
+								const Hot hj = getHot<G>(X, E.pBeg + j);
+								if (hj.dead() || hj.socket()) continue;
+								if (X.st[E.pBeg + j].pad0 == cx) { isNew = false; break; }
+							}
+						}
+					}
+					m += __popcll(X.ballot(isNew));
+				}
+				X.outFirst = m >= 4 && m != 8;
+			}
+		}
+#endif
 
 		for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
 		{
@@ -1393,7 +1582,12 @@ namespace sbgk
 					if (!openEnding)
 					{
 						int32_t ln = ps.lmNode;
+#ifdef KAMD_CONG
+						uint32_t ectx = ps.pad0;
+						first = congStep(M, *X.CG, ln, ectx, 1u, false);
+#else
 						first = lmProgress(M, ln, 1);
+#endif
 						SBG_ONLY({ Ring er = loadRing(X.hist + 8ull * (pBeg + p), ps.pad0); first = sbgNext(*X.S, er.h, er.pos, 1u, first); })
 						c += first;
 						if (ps.spState & 1) c -= 2;
@@ -1729,6 +1923,7 @@ namespace sbgk
 			const ModelView Mc = X.M; const SearchParams Pc = X.P;
 			GroupCtx<G> Y(X, Mc, Pc);
 			SBG_ONLY(const SbgDev Sc = *X.S; Y.S = &Sc;)
+			CONG_ONLY(const CongDev Cc = *X.CG; Y.CG = &Cc;)
 			finishChunk<G>(Y, chunk, openEnding, res);
 		}
 #ifdef KAMD_TIMELINE
@@ -1740,7 +1935,7 @@ namespace sbgk
 	// WPS = waves per SIMD the kernel is compiled for (register budget 512 / WPS): 2 is fastest when a batch is small enough
 	// to be latency-bound (c2: 8192 chunks), 3 (with a few spills) when there are chunks to fill the extra wave slots
 	template<int G, int WPS>
-	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S) TYPO_ONLY(, const float* nodeTypoAll))
+	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S) TYPO_ONLY(, const float* nodeTypoAll) CONG_ONLY(, CongDev CGv))
 	{
 		constexpr int NG = 64 / G;
 		const uint32_t lane = threadIdx.x;
@@ -1765,6 +1960,7 @@ namespace sbgk
 		X.tl = nullptr;
 		SBG_ONLY(X.S = &S; X.hist = nullptr; X.sscr = reinterpret_cast<SbgScratch*>(S.itemScratch) + ((size_t)blockIdx.x * NG + gid);)
 		TYPO_ONLY(X.typoAll = nodeTypoAll; X.nodeTypo = nullptr;)
+		CONG_ONLY(X.CG = &CGv; X.outFirst = false;)
 
 		for (;;)
 		{
@@ -1783,6 +1979,10 @@ namespace sbgk
 #elif defined(KAMD_TYPO)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
+}
+#elif defined(KAMD_CONG)
+	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev);
+	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev);
 }
 #else
 	template __global__ void k_best_path<4, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);

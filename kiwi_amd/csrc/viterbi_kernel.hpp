@@ -17,6 +17,7 @@ namespace kamd
 	// scratch in HBM per lane group (items of oversized batches, end-node candidates)
 	template<uint32_t Q> struct GroupScratchT { uint64_t key[Q]; float score[Q]; float fcs[Q]; };
 	using GroupScratch = GroupScratchT<BIGQ>;
+	template<uint32_t Q> struct GroupScratchCong { uint64_t key[Q]; float score[Q]; float fcs[Q]; uint32_t ctx[Q]; };   // CoNgram search: + the context id of every item
 
 	// SkipBigram models: LM state of every work item of a batch beyond the Knlm node -- history ring, ring position, and a
 	// 32-bit digest that is compared before the rings are
@@ -51,6 +52,13 @@ namespace kamd
 	{
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, const float* nodeTypo);
+	}
+	// ... and for CoNgram models (viterbi_kernel_cong.hip, KAMD_CONG): the context trie sits where the Knlm trie does in ModelView (edge hash, root
+	// table, suffix links), CG names the embedding tables.  G = 16 or 64, WPS = 2.
+	namespace congk
+	{
+		template<int G, int WPS>
+		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, CongDev CG);
 	}
 	// End stage, one THREAD per chunk: restated std::sort of the end candidates, per-(root, state) selection and the
 	// back-trace into 24-byte tokens.  A separate launch so that 64 chunks share a wavefront in this strictly serial stage.

@@ -390,7 +390,14 @@ namespace korc
 				return;
 			}
 			size_t h;
-			if (!S.present()) h = keyHash(Key{ np.lmNode, np.prevRootId, np.spState });
+			if (C.present())
+			{
+				// Hash<CoNgramState<0>> = Hash<uint32_t>(node) (src/CoNgramModel.hpp:505-541), then Hash<WordLL>'s mix
+				const size_t v = (size_t)(uint32_t)np.lmNode;
+				const size_t r = (v * (size_t)2305843009213693951ull) ^ ((v << 33) | (v >> 31));
+				h = ((uint16_t)np.prevRootId | ((uint16_t)np.spState << 8)) ^ ((r << 3) | (r >> 61));
+			}
+			else if (!S.present()) h = keyHash(Key{ np.lmNode, np.prevRootId, np.spState });
 			else
 			{
 				// Hash<SbgState> (SkipBigramModel.hpp:187-201): Knlm hash folded with the 8 history words, then Hash<WordLL>'s mix

@@ -345,3 +345,38 @@ def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch,
     assert corrected >= 5
     dev.close(); prod.close()
 
+
+
+@pytest.mark.parametrize("lanes,top_n", [("16", 1), ("64", 1), ("16", 2), ("16", 3)])
+def test_emulated_cong_kernels_match_oracle(emu_libs, small_cong_model, monkeypatch, lanes, top_n):
+    """The search kernel compiled for CoNgram models (viterbi_kernel_cong.hip: context trie + int8 embedding dot product, candidates in the
+    transposed evaluator's order, the reference kernel's rounding per node) against the oracle, whose CoNgram path is pinned to the REAL
+    src/CoNgramModel.cpp (tests/test_cong_oracle.py): tokens, positions, fp32 scores."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_cong_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    texts = synthetic(sm, 80, 911, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 40, 912) + EDGE_TEXTS
+    got = dev.analyze_batch(texts, top_n=top_n).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (lanes, top_n, s)
+    dev.close()
+
+
+def test_emulated_cong_fallback_paths_with_small_capacities(emu_libs, small_cong_model, monkeypatch):
+    """The small-capacity build (LDS queues of 4, container limits 3 / 8 / 2 on both sides): medium / large containers with the CoNgram
+    state hash, HBM work-item queues carrying context ids."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_cong_model
+    monkeypatch.setenv("KAMD_CONTAINER_LIMITS", "3,8,2")
+    orc = oraclelib.OracleKiwi(path)
+    orc.set_container_limits(3, 8, 2)
+    dev = KiwiAmd(path, lib_path=emu_libs[1])
+    texts = synthetic(sm, 50, 913, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 25, 914)
+    got = dev.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s)) == _norm(y), s
+    dev.close()
