@@ -221,7 +221,7 @@ def main():
         total_sent = n_job * args.steps
         value = total_sent / elapsed
         out = {
-            "metric": "sentences/sec on batched analyze(), device kernels with inputs resident in HBM (dictionary scan + lattice + Viterbi/%s, top-%d); host-to-host rate: see e2e" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "Knlm, typo correction" if typo is not None else "Knlm", top_n),
+            "metric": "sentences/sec on batched analyze(), device kernels with inputs resident in HBM (dictionary scan + lattice + Viterbi/%s, top-%d); host-to-host rate: see e2e" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "CoNgram (local, 8-bit)" if "cong" in args.workload else "Knlm, typo correction" if typo is not None else "Knlm", top_n),
             "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "int32+f32", "data": "synthetic",

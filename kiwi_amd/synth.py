@@ -677,13 +677,16 @@ class SynthModel:
             raw.cong = build_cong(sents, vocab, dim=sp.cong_dim, seed=sp.seed + 3)
 
     # -- text corpus -------------------------------------------------------------------------
-    def make_corpus(self, n, seed, min_jamo=5, max_jamo=200, exact_jamo=None, oov_rate=0.03):
+    def make_corpus(self, n, seed, min_jamo=5, max_jamo=200, exact_jamo=None, oov_rate=0.03, lognormal=None):
         """Synthetic sentences (composed Hangul text). Length is measured in non-space
         normalised units ("jamo")."""
         rng = np.random.default_rng(seed)
         out = []
         for _ in range(n):
-            target = exact_jamo or int(rng.integers(min_jamo, max_jamo + 1))
+            if lognormal is not None:      # (median, sigma): lengths ~ log-normal, clipped to [min_jamo, max_jamo] (SURVEY.md section 8(d), config 4)
+                target = int(min(max_jamo, max(min_jamo, round(float(rng.lognormal(np.log(lognormal[0]), lognormal[1]))))))
+            else:
+                target = exact_jamo or int(rng.integers(min_jamo, max_jamo + 1))
             words, total = [], 0
             while total < target - 1:
                 _, surf = self.sample_sentence(rng, n_eojeol=int(rng.integers(1, 4)))

@@ -21,6 +21,10 @@ WORKLOADS = {
     # BASELINE config 5: the c2 corpus misspelt (confusable vowels, carried-over codas), analysed with a typo transformer (TYPO_RULES, continual cost 1,
     # typoCostWeight 6, threshold 2.5)
     "c5": ("full", 8192, dict(exact_jamo=40), 2),
+    # BASELINE config 4's model type and length distribution on one GPU: CoNgram model (local, 8-bit, dim 64), sentence lengths log-normal
+    # (median 60 jamo, sigma 0.6, clipped to 5..400); 131072 sentences = one GPU's share of the 1M-sentence corpus on 8 GPUs
+    "c4-cong": ("full-cong", 131072, dict(min_jamo=5, max_jamo=400, lognormal=(60, 0.6)), 4),
+    "small-cong-c2": ("small-cong", 8192, dict(exact_jamo=40), 2),
     # c2 at the batch size the north-star throughput target is quoted on (>= 64k sentences): the throughput regime
     "c2-64k": ("full", 65536, dict(exact_jamo=40), 12),
 }
@@ -89,8 +93,8 @@ def workload_typo(name: str):
 
 
 def _spec(name):
-    from .synth import FULL_SBG_SPEC, FULL_SPEC, SMALL_SPEC
-    return {"full": FULL_SPEC, "full-sbg": FULL_SBG_SPEC, "small": SMALL_SPEC}[name]
+    from .synth import FULL_CONG_SPEC, FULL_SBG_SPEC, FULL_SPEC, SMALL_CONG_SPEC, SMALL_SPEC
+    return {"full": FULL_SPEC, "full-sbg": FULL_SBG_SPEC, "small": SMALL_SPEC, "full-cong": FULL_CONG_SPEC, "small-cong": SMALL_CONG_SPEC}[name]
 
 
 def get_workload(name: str):
@@ -118,7 +122,7 @@ def get_workload(name: str):
     with open(corpus_path, encoding="utf-8") as f:
         texts = f.read().split("\n")
     assert len(texts) == n, (len(texts), n)
-    lm = "Knlm + SkipBigram, top-3" if spec_name.endswith("-sbg") else "Knlm, top-1"
+    lm = "Knlm + SkipBigram, top-3" if spec_name.endswith("-sbg") else "CoNgram (local, 8-bit), top-1" if spec_name.endswith("-cong") else "Knlm, top-1"
     desc = f"{name}: {n} synthetic sentences ({kw}), synthetic '{spec_name}' model (kiwi_amd/synth.py), {lm}"
     return model_path, texts, desc
 

@@ -37,6 +37,10 @@ namespace korc
 		uint64_t maxPrevPaths = 0, nodesOver128 = 0, nodesOver512 = 0, lattNodes = 0;
 		// SkipBigram extra (SURVEY.md §8(d) "SBG extra"): evaluate() calls, key bytes of their 8 partner searches, hits; sbgModel = the model has the tables
 		uint64_t sbgEvals = 0, sbgProbeKeyBytes = 0, sbgHits = 0, sbgModel = 0;
+		// CoNgram (SURVEY.md §8(d) "CoNgram"): embedding rows gathered -- per candidate evaluation the UNIQUE context / output rows of its score
+		// matrix, one pair per later chunk step --, scores written, context-trie probes (non-root levels visited) with their key bytes, root
+		// probes; congDim = the embedding dimension (0: not a CoNgram model)
+		uint64_t congCtxRows = 0, congOutRows = 0, congScores = 0, congProbes = 0, congProbeKeyBytes = 0, congRootProbes = 0, congDim = 0;
 	};
 
 	struct SplitConfig { uint64_t match; uint32_t maxUnk, maxUnkJ, spaceTol; };

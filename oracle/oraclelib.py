@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 
 COUNTER_NAMES = ["inputUnits", "trieProbes", "trieProbeKeyBytes", "failHops", "candEmits", "otherNodes",
                  "transitions", "candMorphs", "statesWritten", "lmProbes", "lmProbeKeyBytes", "lmRootProbes", "tokens",
-                 "maxPrevPaths", "nodesOver128", "nodesOver512", "lattNodes", "sbgEvals", "sbgProbeKeyBytes", "sbgHits", "sbgModel"]
+                 "maxPrevPaths", "nodesOver128", "nodesOver512", "lattNodes", "sbgEvals", "sbgProbeKeyBytes", "sbgHits", "sbgModel",
+                 "congCtxRows", "congOutRows", "congScores", "congProbes", "congProbeKeyBytes", "congRootProbes", "congDim"]
 
 
 def available() -> bool:
@@ -155,6 +156,10 @@ def alg_bytes(c: dict) -> dict:
               + c["lmProbes"] * (20 + 4) + c["lmProbeKeyBytes"] + c["lmRootProbes"] * 4 + c["tokens"] * 24
               # "SBG extra": per evaluate() 8 B row pointers + 8 discounts + the key bytes of 8 partner searches + 4 B per hit
               + c.get("sbgEvals", 0) * (8 + 8 * 4) + c.get("sbgProbeKeyBytes", 0) + c.get("sbgHits", 0) * 4)
+    dim = c.get("congDim", 0)
+    if dim:     # "CoNgram": unique context rows dim + 16 B, unique output rows dim + 8 B, 4 B per score, context-trie probe = Knlm probe with a 16-byte node
+        search += (c["congCtxRows"] * (dim + 16) + c["congOutRows"] * (dim + 8) + c["congScores"] * 4
+                   + c["congProbes"] * (16 + 4) + c["congProbeKeyBytes"] + c["congRootProbes"] * 4)
     return {"lattice": lattice, "search": search, "total": lattice + search}
 
 

@@ -163,6 +163,7 @@ namespace korc
 		// CoNgramModel::progressContextNodeVl (src/CoNgramModel.hpp:306-385): the context id the history + `next` maps to; moves `node`
 		bool congSearch(const CongNodeRec& nd, uint32_t key, int32_t& v) const
 		{
+			cnt.congProbes++; cnt.congProbeKeyBytes += 2 * log2c(nd.numNexts) * 4;
 			const uint32_t* k = C.keys + nd.nextOff;
 			const uint32_t* it = std::lower_bound(k, k + nd.numNexts, key);
 			if (it == k + nd.numNexts || *it != key) return false;
@@ -186,6 +187,7 @@ namespace korc
 				}
 				else
 				{
+					cnt.congRootProbes++;
 					v = next < C.vocabSize ? C.root[next] : 0;
 					if (v == 0) return 0;
 				}
@@ -212,8 +214,9 @@ namespace korc
 		// outputFirst: the batched path of the reference's SSE4.1 build multiplies the output scale in first (src/archImpl/sse4_1.cpp:116,
 		// scatteredGEMV_128: ((x * outputScale) * contextScale) + bias) where progress() and the baseline kernel (src/qgemm.hpp:73-80) multiply the
 		// context scale first -- one rounding apart
-		float congNext(WPath& st, uint32_t next, bool outputFirst = false) const
+		float congNext(WPath& st, uint32_t next, bool outputFirst = false, bool countRows = true) const
 		{
+			if (countRows) { cnt.congCtxRows++; cnt.congOutRows++; cnt.congScores++; }
 			const float ll = outputFirst ? congScoreOutputFirst(C, st.ctx, next) : congScore(C, st.ctx, next);
 			st.ctx = congContext(st.lmNode, next);
 			return ll;
@@ -662,7 +665,8 @@ namespace korc
 			// dispatch): m <= 3 and n <= 3 -> baseline; n == 1 -> scatteredGEMV (specialised, output scale first) unless m == 8 (scatteredGEMV8x1:
 			// baseline there); everything else -> baseline.
 			bool outputFirst = false;
-			if (!(regularPrev.size() == 1 && regular.size() == 1) && !regularPrev.empty() && !regular.empty())
+			cnt.congDim = C.dim;
+			if (!regularPrev.empty() && !regular.empty())
 			{
 				std::vector<uint32_t> uc, uw;
 				for (const Prev& pr : regularPrev) uc.push_back(cache[pr.node - graph][pr.idx].ctx);
@@ -670,7 +674,8 @@ namespace korc
 				std::sort(uc.begin(), uc.end()); uc.erase(std::unique(uc.begin(), uc.end()), uc.end());
 				std::sort(uw.begin(), uw.end()); uw.erase(std::unique(uw.begin(), uw.end()), uw.end());
 				const size_t m = uc.size(), n = uw.size();
-				outputFirst = !(m <= 3 && n <= 3) && n == 1 && m != 8;
+				cnt.congCtxRows += m; cnt.congOutRows += n; cnt.congScores += regularPrev.size() * regular.size();
+				outputFirst = !(regularPrev.size() == 1 && regular.size() == 1) && !(m <= 3 && n <= 3) && n == 1 && m != 8;
 			}
 			for (uint32_t mid : regular)
 			{
@@ -686,7 +691,7 @@ namespace korc
 				{
 					const WPath& pp = cache[pr.node - graph][pr.idx];
 					WPath lmSt = pp;
-					const float ll = congNext(lmSt, firstWid, outputFirst);          // progressMatrix / next(): scores[prev][cur] and the moved-on state
+					const float ll = congNext(lmSt, firstWid, outputFirst, false);   // progressMatrix / next(): scores[prev][cur] and the moved-on state
 					float score = pp.accScore + morphScore + ll;
 					const float firstChunk = morphScore + ll;
 					if (!formOk(pp, cm, score)) continue;

@@ -52,3 +52,18 @@ def test_c3_4k_sentences_bit_exact_vs_oracle_and_reference(full):
     _check(dev, orc, c3[:4096])
     if ref is not None:
         _check(dev, ref, c3[:4096])
+
+
+def test_c4_cong_4k_sentences_bit_exact_vs_oracle_and_reference():
+    """BASELINE config 4's model type on the benchmarked 'full-cong' model (bench.py --workload c4-cong): device vs the CPU oracle and, where the
+    prebuilt x86 reference library travelled, vs the REAL src/CoNgramModel.cpp (SSE4.1 build)."""
+    import oraclelib
+    import refbridge
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+    path, c4, _ = get_workload("c4-cong")
+    dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
+    _check(dev, orc, c4[:4096])
+    if refbridge.x86_available():
+        _check(dev, refbridge.RefKiwi(path, arch=3, x86=True), c4[:4096])
+    dev.close()
