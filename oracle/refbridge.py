@@ -11,13 +11,17 @@ from dataclasses import dataclass
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_ref", "libkiwi_ref.so")
+# Two builds of the same reference sources (oracle/Makefile): `ref` (scalar architectures only) and `refx86` (every SIMD architecture +
+# src/CoNgramModel.cpp).  ONE of them is loaded per process -- the x86 build where it exists, it contains the other: their C++ statics are
+# STB_GNU_UNIQUE symbols, which the dynamic linker unifies process-wide, so the second library would silently run on the first one's dispatch tables.
+LIB_PLAIN_PATH = os.path.join(HERE, "_ref", "libkiwi_ref.so")
 
 MATCH_ALL = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 23)
 MATCH_ALL_WITH_NORMALIZING = MATCH_ALL | (1 << 16)
 
 
 LIB_X86_PATH = os.path.join(HERE, "_ref", "libkiwi_ref_x86.so")
+LIB_PATH = LIB_X86_PATH if os.path.exists(LIB_X86_PATH) else LIB_PLAIN_PATH
 
 
 def x86_available() -> bool:
@@ -96,7 +100,9 @@ class RefKiwi:
         loaded through the reference's serializer (Knlm only / with skipbigram.mdl).
         x86: the library built with every SIMD architecture and src/CoNgramModel.cpp (oracle/Makefile refx86): a container with a CoNgram blob is
         analysed with it; arch 3 = sse4_1, 4 = avx2, 5 = avx512bw, 6 = avx512vnni (the quantised CoNgram path exists for those only)."""
-        self.lib = C.CDLL(LIB_X86_PATH if x86 else LIB_PATH)
+        if x86 and not x86_available():
+            raise RuntimeError("oracle/_ref/libkiwi_ref_x86.so is not built")
+        self.lib = C.CDLL(LIB_PATH)
         L = self.lib
         L.kref_open_dir.restype = C.c_void_p
         L.kref_open_dir.argtypes = [C.c_char_p, C.c_int, C.c_int]
