@@ -160,6 +160,11 @@ def main():
     elapsed = dist.max_over_ranks(elapsed, device="cuda" if world > 1 else "cpu")
     for k in kt:
         kt[k] /= args.steps
+    # every chunk of the timed launches must have been searched to the end: a chunk that overflowed its scratch returns early (kamd_fetch
+    # would search it again with larger capacities) and a step that skipped work is not a measurement
+    failed = eng.failed_chunks(batch)
+    if failed:
+        raise SystemExit(f"bench.py: {failed} of {info['chunks']} chunks overflowed their device scratch in the timed launches: the timing is invalid")
 
     # End to end: UTF-16 strings resident on the host -> kamd_analyze_batch (host text preparation, H2D, kernels,
     # D2H, result assembly) -> packed token records resident on the host.  Timed through the C ABI on an already packed buffer.
@@ -228,7 +233,7 @@ def main():
             "config": {"workload": desc, "sentences_per_gpu": n, "chunks_per_gpu": info["chunks"], "jamo_per_gpu": info["units"],
                        "parallelism": f"shard{world}", "m_jamo_per_s": info["units"] * world * args.steps / elapsed / 1e6,
                        "model": model_facts(args.workload),
-                       "kernel_ms": kt, "device_bytes": info["device_bytes"]},
+                       "kernel_ms": kt, "device_bytes": info["device_bytes"], "failed_chunks": failed},
         }
         if not args.no_cpu_baseline:
             cb = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg)

@@ -52,6 +52,9 @@ int kamd_run(kamd_engine_h h, kamd_batch_h b, float* ms_out);
 kamd_results_h kamd_fetch(kamd_engine_h h, kamd_batch_h b, uint32_t top_n);
 /* info[0]=chunks, [1]=non-space normalised units ("jamo"), [2]=device bytes of the staged batch */
 int kamd_batch_info(kamd_batch_h b, uint64_t* info3);
+/* chunks of the last kamd_run that ended in a device scratch overflow (kamd_fetch searches those again with larger capacities);
+   0 = the run measured by kamd_run did all of the batch's work; < 0 on error */
+int kamd_batch_failed(kamd_engine_h h, kamd_batch_h b);
 void kamd_batch_close(kamd_batch_h b);
 
 uint32_t kamd_res_texts(kamd_results_h r);

@@ -98,6 +98,11 @@ extern "C"
 		info[0] = Engine::stagedChunks(*b->b); info[1] = Engine::stagedUnits(*b->b); info[2] = Engine::stagedDeviceBytes(*b->b);
 		return 0;
 	}
+	int kamd_batch_failed(kamd_engine_h h, kamd_batch_h b)
+	{
+		if (!h || !b) return -2;
+		return guarded([&]() { return (int)h->e->failedChunks(*b->b); }, -1);
+	}
 	void kamd_batch_close(kamd_batch_h b) { delete b; }
 
 	uint32_t kamd_res_texts(kamd_results_h r) { return r ? (uint32_t)r->r.nTexts : 0; }

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <stdexcept>
@@ -331,6 +332,8 @@ namespace kamd
 			b.patOff[c + 1] = b.patOff[c] + (d.patEnd - d.patBegin);
 			b.spOff[c + 1] = b.spOff[c] + (uint32_t)r.sp.size();
 			uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
+			// SkipBigram states carry their history ring in the container key: far fewer paths merge, a node keeps hundreds to thousands of them
+			if (I.hasSbg) scap *= 8;
 			if (b.typo.typo) ncap = std::min<uint64_t>(2 * ncap, 0xFFE0);      // lattices over typo graphs come out about twice as large
 			if (tinyArenas)   // test hook (KAMD_TEST_TINY_ARENAS): regions far too small at scale 1, so that the overflow -> re-run ladder is exercised
 			{
@@ -874,37 +877,76 @@ namespace kamd
 	uint64_t Engine::stagedUnits(const StagedBatch& b) { return b.units; }
 	uint64_t Engine::stagedDeviceBytes(const StagedBatch& b) { return b.devBytes; }
 
-	// Runs an explicit list of chunks (used for re-runs with larger capacities or non-default special states).
+	// Runs an explicit list of chunks (re-runs with larger capacities or non-default special states).  Chunks that overflow again go
+	// up the capacity ladder TOGETHER (one launch per rung, not one per chunk); a rung is cut into slices of bounded device memory.
 	static void runRefs(Engine& E, Engine::Impl& I, StagedBatch& parent, std::vector<ChunkRef> refs, uint32_t capScale,
 		std::vector<std::vector<PathResult>>& out)
 	{
-		StagedBatch b;
-		b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo; b.hostThreads = 1;
-		b.prep.swap(parent.prep);   // borrow
-		b.refs = std::move(refs);
-		try
+		out.clear(); out.resize(refs.size());
+		const SearchParams sp = makeParams(E.config, parent.match, parent.topN);
+		// ~ (48 n + 256) states of ~ 100 B per chunk and capacity step: 12 GB per slice
+		const uint64_t sliceBudget = 120000000ull;
+		size_t r0 = 0;
+		while (r0 < refs.size())
 		{
-			const SearchParams sp = makeParams(E.config, b.match, b.topN);
-			layoutAndUpload(I, b, sp);
-			launchAll(I, b, sp);
-			download(I, b);
-			out.resize(b.refs.size());
-			for (size_t c = 0; c < b.refs.size(); ++c)
+			uint64_t w = 0; size_t r1 = r0;
+			while (r1 < refs.size())
 			{
-				if (b.hResults[c].status >= 16)
-				{
-					if (capScale >= 64) throw std::runtime_error{ "analyze: device scratch overflow (status " + std::to_string(b.hResults[c].status) + ") even at 64x capacity" };
-					std::vector<std::vector<PathResult>> one;
-					b.prep.swap(parent.prep);
-					runRefs(E, I, parent, { b.refs[c] }, capScale * 4, one);
-					b.prep.swap(parent.prep);
-					out[c] = std::move(one[0]);
-				}
-				else chunkPaths(out[c], I.model, b, c);
+				const uint64_t cw = (48ull * parent.prep[refs[r1].text].chunks[refs[r1].chunk].nChars + 256) * capScale * (I.hasSbg ? 8 : 1);
+				if (r1 > r0 && w + cw > sliceBudget) break;
+				w += cw; ++r1;
 			}
+			StagedBatch b;
+			b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo; b.hostThreads = 1;
+			b.refs.assign(refs.begin() + r0, refs.begin() + r1);
+			std::vector<size_t> failing;
+			b.prep.swap(parent.prep);   // borrow the prepared texts for the duration of the launch
+			try
+			{
+				layoutAndUpload(I, b, sp);
+				launchAll(I, b, sp);
+				download(I, b);
+				for (size_t c = 0; c < b.refs.size(); ++c)
+				{
+					if (b.hResults[c].status >= 16)
+					{
+						if (capScale >= 64) throw std::runtime_error{ "analyze: device scratch overflow (status " + std::to_string(b.hResults[c].status) + ") even at 64x capacity" };
+						failing.push_back(c);
+					}
+					else chunkPaths(out[r0 + c], I.model, b, c);
+				}
+			}
+			catch (...) { b.prep.swap(parent.prep); throw; }
+			b.prep.swap(parent.prep);
+			if (!failing.empty())
+			{
+				std::vector<ChunkRef> again; again.reserve(failing.size());
+				for (size_t c : failing) again.push_back(b.refs[c]);
+				std::vector<std::vector<PathResult>> sub;
+				runRefs(E, I, parent, std::move(again), capScale * 4, sub);
+				for (size_t k = 0; k < failing.size(); ++k) out[r0 + failing[k]] = std::move(sub[k]);
+			}
+			r0 = r1;
 		}
-		catch (...) { b.prep.swap(parent.prep); throw; }
-		b.prep.swap(parent.prep);
+	}
+
+	uint32_t Engine::failedChunks(StagedBatch& b)
+	{
+		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		HIPCHECK(hipSetDevice(impl->device));
+		const size_t nC = b.refs.size();
+		if (!nC || !b.ran) return 0;
+		std::vector<DevChunkResult> res(nC);
+		HIPCHECK(hipMemcpy(res.data(), b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost));
+		uint32_t n = 0;
+		for (auto& r : res) n += r.status >= 16;
+		if (n && std::getenv("KAMD_HOST_TIMING"))   // developer aid: which overflow
+		{
+			std::map<uint32_t, uint32_t> hist;
+			for (auto& r : res) hist[r.status]++;
+			for (auto& h : hist) fprintf(stderr, "[host] chunk status %u: %u chunks\n", h.first, h.second);
+		}
+		return n;
 	}
 
 	BatchResults Engine::fetch(StagedBatch& b, size_t topN)
@@ -924,6 +966,15 @@ namespace kamd
 		std::vector<size_t> firstRef(nT + 1, 0);
 		for (auto& r : b.refs) firstRef[r.text + 1]++;
 		for (size_t i = 0; i < nT; ++i) firstRef[i + 1] += firstRef[i];
+		// chunks whose scratch overflowed go up the capacity ladder together, before the per-text pass
+		std::vector<size_t> overIdx(b.refs.size(), SIZE_MAX);
+		std::vector<std::vector<PathResult>> overPaths;
+		{
+			std::vector<ChunkRef> over;
+			for (size_t c = 0; c < b.refs.size(); ++c) if (b.hResults[c].status >= 16) { overIdx[c] = over.size(); over.push_back(b.refs[c]); }
+			if (!over.empty()) runRefs(*this, *impl, b, std::move(over), b.capScale * 4, overPaths);
+			tm.lap("overflow re-runs");
+		}
 		// texts are independent: post-process them on the host workers, one segment of consecutive texts per task; a text whose chunk
 		// must be searched again (other start states than the speculative {0}, or a scratch overflow) needs the device and is finished
 		// afterwards, one by one
@@ -940,6 +991,11 @@ namespace kamd
 				uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
 				if (uniq.empty()) uniq.push_back(0);
 				const uint32_t st = b.hResults[c].status;
+				if (st >= 16 && uniq == b.refs[c].sp)
+				{
+					if (!overPaths[overIdx[c]].empty()) rb.insertPaths(overPaths[overIdx[c]]);
+					continue;
+				}
 				if (st >= 16 || uniq != b.refs[c].sp)
 				{
 					if (!mayRerun) return false;

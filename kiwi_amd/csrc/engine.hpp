@@ -83,6 +83,8 @@ namespace kamd
 		static size_t stagedChunks(const StagedBatch& b);
 		static uint64_t stagedUnits(const StagedBatch& b);     // non-space normalised units ("jamo")
 		static uint64_t stagedDeviceBytes(const StagedBatch& b);
+		// chunks whose last run ended in a scratch overflow (fetch() searches those again with larger capacities)
+		uint32_t failedChunks(StagedBatch& b);
 
 		// debugging / parity hooks: lattice of every chunk of one text in the layout of oracle's korc_split
 		std::vector<uint8_t> dumpLattices(const char16_t* text, size_t n, uint64_t match);
