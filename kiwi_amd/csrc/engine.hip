@@ -148,7 +148,7 @@ namespace kamd
 		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
 		TypoOption typo;
-		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo;
+		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder;
 		TypoLatView tv{};
 		DevBuf dPacks, dStates, dNodeStOff, dNodeStCnt, dReach, dTokens, dResults, dOrder;
 		DevBuf dOutPaths, dOutTokens, dOutCounters; uint32_t outPathCap = 0, outTokCap = 0;   // compact outputs of the end stage
@@ -159,6 +159,7 @@ namespace kamd
 		bool ran = false;
 		uint32_t subBatches = 0;
 		uint32_t topN = 1;            // the search of the last run() kept this many paths per key
+		std::vector<uint32_t> typoNeed, typoOrder;   // typo lattices: LDS need of every chunk, chunks by descending need inside each sub-batch (= dTypoOrder)
 		std::vector<uint32_t> order;   // host copy of dOrder (work order: longest chunk first inside each sub-batch)
 	};
 
@@ -458,6 +459,7 @@ namespace kamd
 				t.nodeOff = b.nodeBase[c]; t.nodeCap = b.nodeBase[c + 1] - b.nodeBase[c]; t.packCap = b.packBase[c + 1] - b.packBase[c];
 				t.mapOff = (uint32_t)mapTop; t.mapLen = (t.nNs << t.pmb) + 1; mapTop += t.mapLen;
 				t.nsOff = (uint32_t)nsTop; nsTop += d.nChars + 2;
+				t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.nodeCap).total;
 				t.stateOff = (uint32_t)stateTop; t.stateCap = (uint32_t)std::min<uint64_t>((g.size() * 16 + 64) * sc, 0x7FFFFFFF); stateTop += t.stateCap;
 				if (mapTop > 0xFFFFFFF0ull || stateTop > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit typo scratch offsets: split the batch" };
 			}
@@ -465,6 +467,7 @@ namespace kamd
 			if (pool.empty()) pool.push_back(0);
 			if (graph.empty()) graph.push_back(TypoGraphNode{});
 			if (glast.empty()) glast.assign(2, 0);
+			b.typoNeed.resize(nC); for (size_t c = 0; c < nC; ++c) b.typoNeed[c] = tch[c].ldsNeed;
 			upload(b.dTypoGraph, graph, s); upload(b.dTypoLast, glast, s); upload(b.dTypoPool, pool, s); upload(b.dTypoChunks, tch, s);
 			b.dTypoTmp.ensure(totNodes * sizeof(TypoLatNode) + 64); b.dTypoMap.ensure(mapTop * 8 + 64); b.dTypoNs.ensure(nsTop * 2 + 64); b.dTypoPs.ensure(nsTop * 2 + 64);
 			b.dTypoStates.ensure(stateTop * sizeof(TypoState) + 64); b.dTypoSIdx.ensure(graph.size() * 8 + 64); b.dTypoScratch.ensure(totNodes * 12 + 64);
@@ -545,6 +548,18 @@ namespace kamd
 			upload(b.dOrder, order, sA);
 			b.order = order;
 			b.subBatches = S;
+			if (b.typo.typo)
+			{
+				// typo lattices, wave-per-chunk kernel: largest LDS need first inside each sub-batch (one launch per size class)
+				b.typoOrder.resize(nC);
+				std::iota(b.typoOrder.begin(), b.typoOrder.end(), 0u);
+				for (uint32_t k = 0; k < S; ++k)
+				{
+					const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S);
+					std::stable_sort(b.typoOrder.begin() + c0, b.typoOrder.begin() + c1, [&](uint32_t a, uint32_t c) { return b.typoNeed[a] > b.typoNeed[c]; });
+				}
+				upload(b.dTypoOrder, b.typoOrder, sA);
+			}
 		}
 		const size_t nEv = 6 * (size_t)S + 2;
 		while (I.evs.size() < nEv) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); I.evs.push_back(e); }
@@ -582,11 +597,25 @@ namespace kamd
 			{
 				// typo correction: the lattice of every chunk over its typo graph (thread per chunk; the dictionary scan happens inside, per search state)
 				TypoLatView tv = b.tv;
-				tv.chunks += c0;
 				tv.lengtheningCost = b.typo.typo->lengtheningCost();
 				tv.threshold = b.typo.threshold; tv.maxUnk = sp.maxUnk; tv.maxUnkJ = sp.maxUnkJ; tv.spaceTol = sp.spaceTol; tv.match = sp.match;
 				HIPCHECK(hipEventRecord(e[1], sA));
-				launchTypoLattice(I.dview, tv, cn, sA);
+				// wave-per-chunk kernel with the chunk's working set in LDS, one launch per LDS size class (as for the plain lattice below); what
+				// is over the budget or outgrows its LDS copy is left to the thread-per-chunk kernel (returns at once otherwise)
+				{
+					uint32_t i = c0;
+					while (i < c1 && b.typoNeed[b.typoOrder[i]] > I.latticeLdsBudget) ++i;
+					while (i < c1)
+					{
+						const uint32_t need = b.typoNeed[b.typoOrder[i]];
+						uint32_t j = i + 1;
+						while (j < c1 && (uint64_t)b.typoNeed[b.typoOrder[j]] * 4 >= (uint64_t)need * 3) ++j;
+						launchTypoLatticeLds(I.dview, tv, b.dTypoOrder.as<uint32_t>() + i, j - i, need, sA);
+						i = j;
+					}
+				}
+				tv.chunks += c0;
+				launchTypoLatticeRest(I.dview, tv, cn, I.latticeLdsBudget, sA);
 			}
 			else
 			{
@@ -762,6 +791,16 @@ namespace kamd
 		}
 		t.searchLaunches = S;
 		b.ran = true;
+		if (b.typo.typo && std::getenv("KAMD_HOST_TIMING"))      // developer aid: how the typo lattices were built
+		{
+			std::vector<TypoLatChunk> tch(nC);
+			HIPCHECK(hipMemcpy(tch.data(), b.dTypoChunks.p, nC * sizeof(TypoLatChunk), hipMemcpyDeviceToHost));
+			uint64_t need = 0, big = 0, over = 0, nodes = 0, cap = 0; uint32_t maxNeed = 0;
+			for (auto& c : tch) { need += c.ldsNeed; maxNeed = std::max(maxNeed, c.ldsNeed); over += c.ldsNeed > I.latticeLdsBudget; nodes += c.nOutFinal; cap += typoLdsNodeCap(c.nChars, c.nodeCap); }
+			for (auto& c : tch) big += c.pad;
+			fprintf(stderr, "[host] typo lattices: LDS need avg %.0f max %u B, %llu chunks over the budget, %llu outgrew their LDS copy; connected nodes avg %.1f of LDS capacity avg %.1f\n",
+				(double)need / nC, maxNeed, (unsigned long long)over, (unsigned long long)big, (double)nodes / nC, (double)cap / nC);
+		}
 		return t;
 	}
 

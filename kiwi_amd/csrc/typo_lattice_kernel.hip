@@ -8,6 +8,8 @@
 // per node.  The typo graph itself comes from
 // the host (typo.cpp).  Its parity has so far been checked in the CPU test suite only -- it has not run on a GPU.
 #include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdlib>
 #include "device_types.hpp"
 #include "feature.hpp"
 #include "typo.hpp"
@@ -18,47 +20,114 @@ namespace kamd
 	namespace
 	{
 		constexpr uint32_t NPOS = 0xFFFFFFFFu;
-		constexpr uint32_t MAXCAND = 96;
+		constexpr uint32_t MAXCAND = kTypoMaxCand;
 
-		struct Ctx
+		// LDS = false: every working array in HBM (thread per chunk).  LDS = true: the wave-per-chunk kernel -- text, index maps, node list
+		// (TypoLdsNode), end-position index (first | (last + 1) << 16 per multiplied position) in LDS; hasFormAlready and the z-coda / z-siot
+		// look-ups answered from per-end-position summaries (fullMask: lengths of the qualifying nodes ending there, zAt: their form flags)
+		// instead of scans over the node list, as in lattice_kernels.hip.
+		template<bool LDS>
+		struct CtxT
 		{
 			const ModelView& M; const TypoLatView& V; TypoLatChunk& C;
 			const uint16_t* str; const uint8_t* cls; const uint8_t* script; uint32_t n, nNs, pmb;
 			const uint16_t* nsToPos; const uint16_t* posToNs;
-			uint2* endPosMap; TypoLatNode* out; uint32_t nOut;
+			uint2* endPosMap; TypoLatNode* out;                                                     // HBM variant
+			uint32_t* epm; TypoLdsNode* lout; uint64_t* fullMask; uint8_t* zAt; uint32_t* candBuf;   // LDS variant
+			uint32_t ldsCap, lastEnd; bool outgrown;
+			uint32_t nOut;
 			const DevPattern* pat; const DevPattern* patEnd;
 			bool overflow;
 
-			__device__ bool append(uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, float typoCost = 0.f)
+			// fp: the form's record when the caller holds it (null: read here if needed)
+			__device__ bool append(uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, float typoCost = 0.f, const FormRec* fp = nullptr)
 			{
-				if (endPosMap[s].x == endPosMap[s].y) return false;
-				if (nOut >= C.nodeCap) { overflow = true; return false; }
-				const uint32_t id = nOut++;
-				TypoLatNode nn; nn.startPos = s; nn.endPos = e; nn.prev = id - endPosMap[s].x; nn.sibling = 0; nn.form = (int32_t)form; nn.uformLen = uLen; nn.uformOff = uOff; nn.spaceErrors = 0; nn.typoCost = typoCost;
-				out[id] = nn;
-				if (e >= C.mapLen) return true;
-				uint2 m = endPosMap[e];
-				if (m.x == m.y) { m.x = id; m.y = id + 1; }
-				else { out[m.y - 1].sibling = id - (m.y - 1); m.y = id + 1; }
-				endPosMap[e] = m;
-				return true;
+				if constexpr (LDS)
+				{
+					const uint32_t ms = epm[s];
+					if ((ms & 0xFFFF) == (ms >> 16)) return false;
+					if (nOut >= ldsCap) { outgrown = true; return false; }
+					const uint32_t id = nOut++;
+					TypoLdsNode nn; nn.form = form; nn.startPos = (uint16_t)s; nn.endPos = (uint16_t)e; nn.prev = (uint16_t)(id - (ms & 0xFFFF)); nn.sibling = 0;
+					nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.typoCost = typoCost; nn.spaceErrors = 0; nn.pad[0] = nn.pad[1] = nn.pad[2] = 0;
+					lout[id] = nn;
+					lastEnd = e;
+					if (e >= C.mapLen) return true;
+					if ((e & ((1u << pmb) - 1)) == 0)      // only whole positions are ever asked about (insertUnk, the z-coda test)
+					{
+						uint8_t fl = 0; uint32_t flen = 0;
+						if (form != NOFORM)
+						{
+							if (fp) { fl = fp->flags; flen = fp->len - fp->numSpaces; }
+							else { const FormRec f = M.forms[form]; fl = f.flags; flen = f.len - f.numSpaces; }
+							zAt[e >> pmb] |= fl & 3;
+						}
+						const uint32_t lenKey = uLen ? uLen : flen;
+						if (typoCost == 0 && (form == NOFORM || (fl & FF_HAS_ANY_FULL)) && lenKey >= 1 && lenKey <= 64) fullMask[e >> pmb] |= 1ull << (lenKey - 1);
+					}
+					const uint32_t me = epm[e];
+					if ((me & 0xFFFF) == (me >> 16)) epm[e] = id | ((id + 1) << 16);
+					else
+					{
+						const uint32_t last = (me >> 16) - 1;
+						lout[last].sibling = (uint16_t)(id - last);
+						epm[e] = (me & 0xFFFF) | ((id + 1) << 16);
+					}
+					return true;
+				}
+				else
+				{
+					if (endPosMap[s].x == endPosMap[s].y) return false;
+					if (nOut >= C.nodeCap) { overflow = true; return false; }
+					const uint32_t id = nOut++;
+					TypoLatNode nn; nn.startPos = s; nn.endPos = e; nn.prev = id - endPosMap[s].x; nn.sibling = 0; nn.form = (int32_t)form; nn.uformLen = uLen; nn.uformOff = uOff; nn.spaceErrors = 0; nn.typoCost = typoCost;
+					out[id] = nn;
+					if (e >= C.mapLen) return true;
+					uint2 m = endPosMap[e];
+					if (m.x == m.y) { m.x = id; m.y = id + 1; }
+					else { out[m.y - 1].sibling = id - (m.y - 1); m.y = id + 1; }
+					endPosMap[e] = m;
+					return true;
+				}
 			}
+			__device__ void setLastSpaceErrors(uint32_t se) { if constexpr (LDS) lout[nOut - 1].spaceErrors = (uint8_t)se; else out[nOut - 1].spaceErrors = se; }
+			__device__ uint32_t lastNodeEnd() const { if constexpr (LDS) return lastEnd; else return out[nOut - 1].endPos; }
 			__device__ uint32_t nodeLen(const TypoLatNode& g) const
 			{
 				if (g.uformLen) return g.uformLen;
 				const FormRec f = M.forms[g.form];
 				return f.len - f.numSpaces;
 			}
-			__device__ bool hasForm(uint32_t ms, uint32_t me) const
+			__device__ bool hasForm(uint32_t ms, uint32_t me) const      // both whole positions, multiplied
 			{
-				const uint2 m = endPosMap[me];
-				if (m.x == NPOS) return false;
-				for (uint32_t i = m.x < 1 ? 1 : m.x; i < m.y; ++i)
+				if constexpr (LDS)
 				{
-					const TypoLatNode g = out[i];
-					if (g.endPos == me && g.endPos - (nodeLen(g) << pmb) == ms && g.typoCost == 0 && (g.form < 0 || (M.forms[g.form].flags & FF_HAS_ANY_FULL))) return true;
+					const uint32_t len = (me - ms) >> pmb;
+					if (len <= 64) return (fullMask[me >> pmb] >> (len - 1)) & 1;
+					const uint32_t m = epm[me];
+					uint32_t a = m & 0xFFFF; const uint32_t b = m >> 16;
+					if (a < 1) a = 1;
+					for (uint32_t i = a; i < b; ++i)
+					{
+						const TypoLdsNode g = lout[i];
+						if (g.endPos != me || g.typoCost != 0) continue;
+						uint32_t l = g.uformLen; bool full = g.form == NOFORM;
+						if (!l || !full) { const FormRec f = M.forms[g.form]; if (!l) l = f.len - f.numSpaces; full = full || (f.flags & FF_HAS_ANY_FULL); }
+						if (full && g.endPos - (l << pmb) == ms) return true;
+					}
+					return false;
 				}
-				return false;
+				else
+				{
+					const uint2 m = endPosMap[me];
+					if (m.x == NPOS) return false;
+					for (uint32_t i = m.x < 1 ? 1 : m.x; i < m.y; ++i)
+					{
+						const TypoLatNode g = out[i];
+						if (g.endPos == me && g.endPos - (nodeLen(g) << pmb) == ms && g.typoCost == 0 && (g.form < 0 || (M.forms[g.form].flags & FF_HAS_ANY_FULL))) return true;
+					}
+					return false;
+				}
 			}
 			__device__ void trimmed(uint32_t off, uint32_t len, uint32_t& o, uint32_t& l) const
 			{
@@ -68,7 +137,7 @@ namespace kamd
 			__device__ void insertUnk(uint32_t s, uint32_t e, bool hasJ)
 			{
 				if (s >= e || hasForm(s << pmb, e << pmb)) return;
-				uint32_t lastPos = out[nOut - 1].endPos;      // (a multiplied position against plain ones: as in the reference)
+				uint32_t lastPos = lastNodeEnd();      // (a multiplied position against plain ones: as in the reference)
 				if (lastPos < e)
 				{
 					if (lastPos && isHangulCoda(str[nsToPos[lastPos]])) lastPos--;
@@ -92,8 +161,13 @@ namespace kamd
 			}
 			__device__ uint32_t spaceErrors(const FormRec& f, uint32_t b, uint32_t e) const
 			{
-				const uint16_t* fs = M.formChars + f.charOff;
 				uint32_t nErr = 0, off = 0;
+				if (!f.numSpaces)      // a form without spaces: every gap inside the span is an error; the form's characters are not needed
+				{
+					for (uint32_t i = 1; i < e - b; ++i) nErr += (nsToPos[b + i] - nsToPos[b + i - 1] > 1) ? 1u : 0u;
+					return nErr;
+				}
+				const uint16_t* fs = M.formChars + f.charOff;
 				for (uint32_t i = 1; i < e - b; ++i)
 				{
 					const bool hasSpace = nsToPos[b + i] - nsToPos[b + i - 1] > 1;
@@ -137,15 +211,19 @@ namespace kamd
 					{
 						const uint32_t b2 = startCti ? (nb << pmb) + startCti : nb << pmb;
 						const uint32_t e2 = endCti ? ((ne - 1) << pmb) + endCti : ne << pmb;
-						if (append(b2, e2, fi, 0, 0, typoCost + (lengthened ? V.lengtheningCost * (float)(3 + lengthened) : 0.f))) out[nOut - 1].spaceErrors = se;
+						if (append(b2, e2, fi, 0, 0, typoCost + (lengthened ? V.lengtheningCost * (float)(3 + lengthened) : 0.f), &f)) setLastSpaceErrors(se);
 					}
 				}
 				nCands = 0;
 			}
 
 			// progressNode: state `st` of graph node `prevT` continued through graph node `tn`; new states go to cur[0..nCur)
-			__device__ void progress(const TypoGraphNode& prevT, const TypoGraphNode& tn, uint32_t tnIdx, const TypoState st, TypoState* cur, uint32_t& nCur, uint32_t curCap)
+			__device__ void progress(const TypoGraphNode& prevT, const TypoGraphNode& tn, uint32_t tnIdx, const TypoState& stRef, TypoState* cur, uint32_t& nCur, uint32_t curCap)
 			{
+				// (the state's fixed part only: its lengthening lists are read entry by entry, nL of them)
+				struct Head { int32_t node; float cost; uint32_t minFormLen; int32_t startPosOffset; uint32_t specialStart, unkStart, boundary; uint8_t lastType, lastScript, hasLast, pad; uint16_t startCti, pad2; uint32_t lastChr, nL; };
+				static_assert(sizeof(Head) == offsetof(TypoState, lsize), "TypoState head");
+				const Head st = *reinterpret_cast<const Head*>(&stRef);
 				float typoCost = st.cost + tn.typoCost;
 				if (typoCost > V.threshold) return;
 				uint8_t lastType = st.hasLast ? st.lastType : (uint8_t)T_UNKNOWN;
@@ -159,12 +237,12 @@ namespace kamd
 				if (fsz) { outType = V.graphLast[2 * tnIdx]; outScript = V.graphLast[2 * tnIdx + 1]; outHas = outType != 0xFF; }
 				int32_t curNode = st.node;
 				const uint8_t scriptVS = 98;
-				uint32_t cands[MAXCAND]; uint32_t nCands = 0;
+				uint32_t candsLocal[LDS ? 1 : MAXCAND]; uint32_t* cands = LDS ? candBuf : candsLocal; uint32_t nCands = 0;
 				auto push = [&](uint32_t f) { if (nCands < MAXCAND) cands[nCands++] = f; else overflow = true; };      // (form ids stay below 2^24: checked by the engine)
 				const bool lengthening = V.lengtheningCost < INFINITY;
 				uint32_t prevChr = st.lastChr;
 				uint8_t lsz[kTypoLengthNodes]; int32_t lnd[kTypoLengthNodes]; uint32_t nL = st.nL;
-				for (uint32_t k = 0; k < nL; ++k) { lsz[k] = st.lsize[k]; lnd[k] = st.lnode[k]; }
+				for (uint32_t k = 0; k < nL; ++k) { lsz[k] = stRef.lsize[k]; lnd[k] = stRef.lnode[k]; }
 				for (uint32_t j = 0; j < fsz; ++j)
 				{
 					const uint16_t ch = formChar(tn, j);
@@ -207,13 +285,17 @@ namespace kamd
 							const uint32_t p = posToNs[pos];
 							if (p < nNs)
 							{
-								const uint2 m = endPosMap[p << pmb];
-								if (m.x != NPOS) for (uint32_t i = m.x; i < m.y; ++i)
+								if constexpr (LDS) { const uint8_t zb = zAt[p]; zc = zb & FF_ZCODA_APPENDABLE; zs = zb & FF_ZSIOT_APPENDABLE; }
+								else
 								{
-									const TypoLatNode g = out[i];
-									if (g.endPos != (p << pmb) || g.form < 0) continue;
-									const uint8_t ff = M.forms[g.form].flags;
-									zc = zc || (ff & FF_ZCODA_APPENDABLE); zs = zs || (ff & FF_ZSIOT_APPENDABLE);
+									const uint2 m = endPosMap[p << pmb];
+									if (m.x != NPOS) for (uint32_t i = m.x; i < m.y; ++i)
+									{
+										const TypoLatNode g = out[i];
+										if (g.endPos != (p << pmb) || g.form < 0) continue;
+										const uint8_t ff = M.forms[g.form].flags;
+										zc = zc || (ff & FF_ZCODA_APPENDABLE); zs = zs || (ff & FF_ZSIOT_APPENDABLE);
+									}
 								}
 							}
 							if ((V.match & M_Z_CODA) && zc && isHangulCoda(ch) && (pos + 1 >= n || !isHangulSyllable(str[pos + 1]))) push(kDefaultTagSize + (ch - 0x11A8) - 1u);
@@ -321,13 +403,14 @@ namespace kamd
 					}
 					if (typoCost > 0 && M.trie[curNode].depth < minFormLen && nL == 0) return;      // early pruning
 					if (nCur >= curCap) { overflow = true; return; }
-					TypoState ns; ns.node = curNode; ns.cost = typoCost; ns.minFormLen = minFormLen; ns.startPosOffset = startPosOffset;
+					Head ns; ns.node = curNode; ns.cost = typoCost; ns.minFormLen = minFormLen; ns.startPosOffset = startPosOffset;
 					ns.specialStart = specialStart; ns.unkStart = unkStart; ns.boundary = boundary;
 					ns.lastType = outType; ns.lastScript = outScript; ns.hasLast = outHas; ns.pad = 0;
 					ns.startCti = tn.continualTypoIdx ? tn.continualTypoIdx : st.startCti; ns.pad2 = 0;
 					ns.lastChr = prevChr; ns.nL = nL;
-					for (uint32_t k = 0; k < nL; ++k) { ns.lsize[k] = lsz[k]; ns.lnode[k] = lnd[k]; }
-					cur[nCur++] = ns;
+					TypoState& dst = cur[nCur++];
+					*reinterpret_cast<Head*>(&dst) = ns;
+					for (uint32_t k = 0; k < nL; ++k) { dst.lsize[k] = lsz[k]; dst.lnode[k] = lnd[k]; }
 				}
 			}
 		};
@@ -336,13 +419,15 @@ namespace kamd
 	// One THREAD per chunk, `stride` lanes apart: a strictly serial, branch-heavy replay runs at the speed of the SUM of its lanes' paths when 64
 	// chunks share a wavefront (lanes diverge at every branch).  With few active lanes per wave the chunks spread over all SIMDs instead
 	// (8192 chunks: 8192 one-lane waves resident at once) and a wave's time is one chunk's time.
-	__global__ void __launch_bounds__(64) k_build_lattice_typo(ModelView M, TypoLatView V, uint32_t nChunks, uint32_t stride)
+	__global__ void __launch_bounds__(64) k_build_lattice_typo(ModelView M, TypoLatView V, uint32_t nChunks, uint32_t stride, uint32_t ldsBudget)
 	{
 		if (threadIdx.x % stride) return;
 		const uint32_t c = blockIdx.x * (64 / stride) + threadIdx.x / stride;
 		if (c >= nChunks) return;
 		TypoLatChunk& C = V.chunks[c];
-		Ctx X{ M, V, C };
+		if (ldsBudget && C.ldsNeed <= ldsBudget && C.status != kTypoLdsNeedsBig) return;      // done by the wave-per-chunk kernel
+		C.pad = C.status == kTypoLdsNeedsBig ? 1u : 0u;      // (developer statistics: this chunk outgrew its LDS copy)
+		CtxT<false> X{ M, V, C };
 		X.str = V.chars + C.charOff; X.cls = V.cls + C.charOff; X.script = V.script + C.charOff; X.n = C.nChars; X.pmb = C.pmb;
 		uint16_t* nsToPos = V.nsToPos + C.nsOff; uint16_t* posToNs = V.posToNs + C.nsOff;
 		uint32_t nNs = 0;
@@ -519,11 +604,251 @@ namespace kamd
 		C.status = CS_OK;
 	}
 
-	void launchTypoLattice(const ModelView& M, const TypoLatView& V, uint32_t nChunks, hipStream_t stream)
+	// dynamic LDS of the wave-per-chunk variant
+	extern __shared__ __align__(16) uint8_t tSmem[];
+
+	// One WAVE per chunk (engine mode).  The search over the typo graph is the same strictly sequential replay (lane 0), but every access to
+	// the chunk's own data is an LDS access instead of a dependent HBM round trip; search states and the typo graph stay in HBM (read once per
+	// step).  The final reorder and the per-node facts run one node per lane.  A chunk whose node list outgrows its LDS copy is handed to
+	// the thread-per-chunk kernel (TypoLatChunk::status = kTypoLdsNeedsBig).
+	template<int WPS>
+	__global__ void __launch_bounds__(64, WPS) k_build_lattice_typo_lds(ModelView M, TypoLatView V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
+	{
+		if (blockIdx.x >= chunkCount) return;
+		const uint32_t lane = threadIdx.x;
+		TypoLatChunk& C = V.chunks[chunkList[blockIdx.x]];
+		if (V.results[C.chunkId].status >= 16) { if (lane == 0) C.status = V.results[C.chunkId].status; return; }
+		const uint32_t n = C.nChars, pmb = C.pmb;
+		const TypoLds lay = typoLdsLayout(n, C.nNs, pmb, C.nodeCap);
+		if (lay.total > ldsBytes || C.mapLen > 0xFFF0 || C.nodeCap > 0xFFF0 || C.mapLen != (C.nNs << pmb) + 1) { if (lane == 0) C.status = kTypoLdsNeedsBig; return; }
+		uint16_t* str = reinterpret_cast<uint16_t*>(tSmem + lay.str); uint8_t* cls = tSmem + lay.cls; uint8_t* script = tSmem + lay.script;
+		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(tSmem + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(tSmem + lay.posToNs);
+		uint32_t* epm = reinterpret_cast<uint32_t*>(tSmem + lay.epm); uint64_t* fullMask = reinterpret_cast<uint64_t*>(tSmem + lay.fullMask); uint8_t* zAt = tSmem + lay.zAt;
+		TypoLdsNode* lout = reinterpret_cast<TypoLdsNode*>(tSmem + lay.nodes);
+		{
+			const uint16_t* gstr = V.chars + C.charOff; const uint8_t* gcls = V.cls + C.charOff; const uint8_t* gscript = V.script + C.charOff;
+			for (uint32_t i = lane; i < n; i += 64) { str[i] = gstr[i]; cls[i] = gcls[i]; script[i] = gscript[i]; }
+			for (uint32_t i = lane; i < C.mapLen; i += 64) epm[i] = 0;      // first == last + 1 - 1 ... : lo == hi, empty
+			for (uint32_t i = lane; i <= C.nNs; i += 64) { fullMask[i] = 0; zAt[i] = 0; }
+		}
+		waveSync();
+		CtxT<true> X{ M, V, C };
+		X.str = str; X.cls = cls; X.script = script; X.n = n; X.pmb = pmb; X.nsToPos = nsToPos; X.posToNs = posToNs;
+		X.endPosMap = nullptr; X.out = nullptr; X.epm = epm; X.lout = lout; X.fullMask = fullMask; X.zAt = zAt; X.candBuf = reinterpret_cast<uint32_t*>(tSmem + lay.cands);
+		X.ldsCap = lay.nodeCap; X.lastEnd = 0; X.outgrown = false; X.nOut = 0; X.overflow = false;
+		X.pat = V.patterns + C.patOff; X.patEnd = X.pat + C.patCnt;
+		uint16_t* inv = reinterpret_cast<uint16_t*>(tSmem + lay.queue);      // BFS queue first, then old -> new index
+		uint16_t* conn = reinterpret_cast<uint16_t*>(tSmem + lay.conn);      // connected flags, then candidate counts by new index
+		uint32_t err = 0, G = 0, nConn = 0;
+		if (lane == 0)
+		{
+			uint32_t nNs = 0;
+			for (uint32_t i = 0; i < n; ++i)
+			{
+				posToNs[i] = (uint16_t)nNs;
+				if (!isSpace(str[i]))
+				{
+					nsToPos[nNs++] = (uint16_t)i;
+					if (isHighSurrogate(str[i]) && i + 1 < n) { posToNs[i + 1] = (uint16_t)nNs; nsToPos[nNs++] = (uint16_t)(i + 1); ++i; }
+				}
+			}
+			posToNs[n] = (uint16_t)nNs;
+			X.nNs = nNs;
+			if (nNs != C.nNs) err = CS_ERR_TOO_LONG;
+			else
+			{
+				epm[0] = 0 | (1u << 16);
+				{ TypoLdsNode z{}; z.form = NOFORM; lout[X.nOut++] = z; }
+				// search (KTrie.cpp:1414-1452): states of graph node i are the contiguous run stateIdx[2i] .. +stateIdx[2i+1] of the chunk's arena
+				const TypoGraphNode* graph = V.graph + C.graphOff;
+				TypoState* states = V.states + C.stateOff;
+				uint32_t* sIdx = V.stateIdx + 2 * C.graphOff;
+				const uint32_t totEnd = nNs ? (uint32_t)nsToPos[nNs - 1] + 1 : 0;
+				uint32_t top = 0;
+				{ TypoState s0{}; states[top] = s0; sIdx[0] = 0; sIdx[1] = 1; ++top; }
+				for (uint32_t i = 1; i < C.graphCnt; ++i)
+				{
+					const TypoGraphNode tn = graph[i];
+					const uint32_t curBeg = top; uint32_t nCur = 0;
+					for (uint32_t p = tn.prevOffset ? i - tn.prevOffset : NPOS; p != NPOS; p = graph[p].siblingOffset ? p + graph[p].siblingOffset : NPOS)
+					{
+						const TypoGraphNode pt = graph[p];
+						for (uint32_t k = 0; k < sIdx[2 * p + 1]; ++k)
+							X.progress(pt, tn, C.graphOff + i, states[sIdx[2 * p] + k], states + curBeg, nCur, C.stateCap - curBeg);
+					}
+					sIdx[2 * i] = curBeg; sIdx[2 * i + 1] = nCur; top = curBeg + nCur;
+					if (tn.typoCost == 0 && tn.endPos == totEnd)
+						for (uint32_t k = 0; k < nCur; ++k) X.unkPair(states[curBeg + k].boundary, states[curBeg + k].unkStart, posToNs[totEnd], true);
+				}
+				X.append(nNs << pmb, (nNs << pmb) + 1, NOFORM, 0, 0);
+				lout[X.nOut - 1].endPos = (uint16_t)(nNs << pmb);
+				if (X.outgrown || (X.nOut + 1 >= lay.nodeCap && lay.nodeCap < C.nodeCap)) err = kTypoLdsNeedsBig;
+				else if (X.overflow || X.nOut + 1 >= C.nodeCap) err = CS_ERR_NODE_OVERFLOW;
+				else
+				{
+					// removeUnconnected (KTrie.cpp:240-299): reachable from the end node backwards; new index = nodes grouped by end position
+					// ascending, original order inside a group (the sibling chain of an end position enumerates exactly its nodes in index order;
+					// the end-of-input node is on no chain and sorts last)
+					G = X.nOut;
+					for (uint32_t i = 0; i < G; ++i) conn[i] = 0;
+					uint32_t qh = 0, qt = 0;
+					inv[qt++] = (uint16_t)(G - 1); conn[G - 1] = 1;
+					while (qh < qt)
+					{
+						const uint32_t id = inv[qh++];
+						const uint32_t sp = lout[id].startPos;
+						const uint32_t me = epm[sp];
+						for (uint32_t i = me & 0xFFFF; i < (me >> 16); ++i)
+						{
+							if (lout[i].endPos != sp || conn[i]) continue;
+							conn[i] = 1; inv[qt++] = (uint16_t)i;
+						}
+					}
+					for (uint32_t e = 0; e < C.mapLen; ++e)
+					{
+						const uint32_t me = epm[e];
+						uint32_t chainConn = 0;
+						if ((me & 0xFFFF) != (me >> 16))
+						{
+							for (uint32_t i = me & 0xFFFF;;)
+							{
+								if (i != G - 1)
+								{
+									if (conn[i]) { inv[i] = (uint16_t)nConn++; ++chainConn; }
+									else inv[i] = (uint16_t)0xFFFF;
+								}
+								const uint32_t sib = lout[i].sibling;
+								if (!sib) break;
+								i += sib;
+							}
+						}
+						epm[e] = chainConn;      // from here on: number of connected nodes ending at e
+					}
+					inv[G - 1] = (uint16_t)nConn++;
+					if (nNs > 0xFFF0 || nConn > 0xFFF0) err = CS_ERR_TOO_LONG;
+				}
+			}
+		}
+		waveSync();
+		err = __shfl(err, 0); G = __shfl(G, 0); nConn = __shfl(nConn, 0);
+		if (err)
+		{
+			if (lane == 0) { C.status = err; if (err != kTypoLdsNeedsBig) V.results[C.chunkId].status = err; }
+			return;
+		}
+		// ---- final records, one node per lane (the facts of lattice_kernels.hip latticeEmitNode); candidate-record offsets by a wave scan ----
+		DevNode* dn = V.devNodes + C.nodeOff; float* tc = V.nodeTypo + C.nodeOff;
+		uint16_t* cc = conn;
+		waveSync();
+		for (uint32_t base = 0; base < G; base += 64)
+		{
+			const uint32_t idx = base + lane;
+			uint32_t cnt = 0xFFFFFFFFu, ni = 0xFFFF;
+			if (idx < G) ni = inv[idx];
+			if (ni != 0xFFFF)
+			{
+				const TypoLdsNode g = lout[idx];
+				DevNode nn;
+				nn.form = g.form; nn.uformOff = g.uformOff; nn.uformLen = g.uformLen; nn.spaceErrors = g.spaceErrors;
+				nn.nPrev = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0; nn.prev = 0; nn.sibling = 0;
+				uint8_t nf = 0;
+				if (ni >= 1)
+				{
+					const uint32_t pidx = idx - g.prev;
+					const TypoLdsNode pn = lout[pidx];
+					const uint32_t startStr = (ni + 1 == nConn) ? n : (uint32_t)nsToPos[g.startPos >> pmb];
+					const bool pnBos = pidx == 0;
+					const uint32_t pnEndStr = pnBos ? 0 : (uint32_t)nsToPos[((pn.endPos + (1u << pmb) - 1) >> pmb) - 1] + 1;
+					const bool spaceBefore = pnBos ? (C.textOffset + startStr > 0) : (pnEndStr < startStr);
+					bool lb = pnBos || spaceBefore;
+					if (!lb && pn.uformLen)
+					{
+						const uint32_t lp = pn.uformOff + pn.uformLen - 1;
+						const uint16_t ch = str[lp];
+						const uint8_t tag = (isLowSurrogate(ch) || isHighSurrogate(ch)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
+						if (tag == T_SSC || ch == u'"' || ch == u'\'') lb = false;
+						else if (T_SF <= tag && tag <= T_SB) lb = true;
+					}
+					if (spaceBefore) nf |= NF_SPACE_BEFORE;
+					if (lb) nf |= NF_LEFT_BOUNDARY;
+					if (g.uformLen && str[g.uformOff + g.uformLen - 1] == u'.') nf |= NF_UFORM_ENDS_POINT;
+					nn.nPrev = (uint16_t)epm[g.startPos];
+				}
+				if (g.form != NOFORM)
+				{
+					const FormRec f = M.forms[g.form];
+					nn.candCnt = f.candCnt; nn.fflags = f.flags; nn.flen = f.len;
+					if ((f.flags2 & FF2_ALL_PARTIAL) && g.typoCost == 0) nf |= NF_ALL_PARTIAL;      // (PathEvaluator.hpp:1275: only for nodes without a typo)
+				}
+				if (g.uformLen)
+				{
+					uint16_t of = featMask(str + g.uformOff, g.uformLen) & 0x1FFF;
+					const uint32_t lp = g.uformOff + g.uformLen - 1;
+					const uint16_t ch = str[lp];
+					const uint8_t tag = (isLowSurrogate(ch) || isHighSurrogate(ch)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
+					if (tag == T_SSC) of |= LF_STR_SSC;
+					nn.ownFeat = of;
+				}
+				nn.nflags = nf;
+				if (g.prev) nn.prev = (uint16_t)(ni - inv[idx - g.prev]);
+				if (g.sibling) { const uint32_t ns = inv[idx + g.sibling]; nn.sibling = ns == 0xFFFF ? 0 : (uint16_t)(ns - ni); }
+				if (ni >= 1 && ni + 1 < nConn)
+				{
+					nn.startPos = nsToPos[g.startPos >> pmb];
+					nn.endPos = (uint16_t)(nsToPos[((g.endPos + (1u << pmb) - 1) >> pmb) - 1] + 1);
+				}
+				else if (ni + 1 == nConn) nn.startPos = nn.endPos = (uint16_t)n;
+				else nn.startPos = nn.endPos = 0;
+				nn.packOff = 0;
+				dn[ni] = nn; tc[ni] = g.typoCost;
+				cnt = nn.candCnt;
+			}
+			// (cc aliases the connected flags: all lanes of this round have read theirs above through inv)
+			if (cnt != 0xFFFFFFFFu) cc[ni] = (uint16_t)cnt;
+		}
+		waveSync();
+		uint32_t packTop = 0;
+		for (uint32_t base = 0; base < nConn; base += 64)
+		{
+			const uint32_t i = base + lane;
+			const uint32_t c = i < nConn ? (uint32_t)cc[i] : 0u;
+			uint32_t incl = c;
+			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+			if (i < nConn) dn[i].packOff = packTop + incl - c;
+			packTop += __shfl(incl, 63);
+		}
+		if (lane == 0)
+		{
+			if (packTop > C.packCap) { C.status = CS_ERR_NODE_OVERFLOW; V.results[C.chunkId].status = CS_ERR_NODE_OVERFLOW; }
+			else
+			{
+				V.nNodes[C.chunkId] = nConn;
+				C.nOutFinal = nConn; C.status = CS_OK;
+				if (nConn <= 2) V.results[C.chunkId].status = CS_NO_LATTICE;
+			}
+		}
+	}
+
+	static uint32_t strideFor(uint32_t nChunks)
 	{
 		// active lanes per wave: 1 up to 16k chunks, 4 up to 64k, 16 beyond (the machine holds 8192 waves)
-		const uint32_t stride = nChunks <= 16384 ? 64u : nChunks <= 65536 ? 16u : 4u;
-		const uint32_t perWave = 64 / stride;
-		hipLaunchKernelGGL(k_build_lattice_typo, dim3((nChunks + perWave - 1) / perWave), dim3(64), 0, stream, M, V, nChunks, stride);
+		return nChunks <= 16384 ? 64u : nChunks <= 65536 ? 16u : 4u;
+	}
+	void launchTypoLattice(const ModelView& M, const TypoLatView& V, uint32_t nChunks, hipStream_t stream)
+	{
+		const uint32_t stride = strideFor(nChunks), perWave = 64 / stride;
+		hipLaunchKernelGGL(k_build_lattice_typo, dim3((nChunks + perWave - 1) / perWave), dim3(64), 0, stream, M, V, nChunks, stride, 0u);
+	}
+	void launchTypoLatticeRest(const ModelView& M, const TypoLatView& V, uint32_t nChunks, uint32_t ldsBudget, hipStream_t stream)
+	{
+		const uint32_t stride = strideFor(nChunks), perWave = 64 / stride;
+		hipLaunchKernelGGL(k_build_lattice_typo, dim3((nChunks + perWave - 1) / perWave), dim3(64), 0, stream, M, V, nChunks, stride, ldsBudget);
+	}
+	void launchTypoLatticeLds(const ModelView& M, const TypoLatView& V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, hipStream_t stream)
+	{
+		// register budget: 4 waves per SIMD without spills (128 VGPRs), or 5 with a few (KAMD_TYPO_LATTICE_WPS=5; the LDS need of a 40-unit chunk allows 5)
+		static const int wps = std::getenv("KAMD_TYPO_LATTICE_WPS") ? std::atoi(std::getenv("KAMD_TYPO_LATTICE_WPS")) : 4;
+		if (wps >= 5) hipLaunchKernelGGL(k_build_lattice_typo_lds<5>, dim3(chunkCount), dim3(64), ldsBytes, stream, M, V, chunkList, chunkCount, ldsBytes);
+		else hipLaunchKernelGGL(k_build_lattice_typo_lds<4>, dim3(chunkCount), dim3(64), ldsBytes, stream, M, V, chunkList, chunkCount, ldsBytes);
 	}
 }

@@ -20,6 +20,7 @@ namespace kamd
 		uint32_t textOffset;           // offset of the chunk in the normalised text (added to final positions of the dump records)
 		uint32_t chunkId, packCap;     // engine mode: index of the chunk in the batch, capacity of its candidate-pack region
 		uint32_t nOutFinal, status;    // out: number of connected nodes, ChunkStatus
+		uint32_t ldsNeed, pad;         // engine mode: dynamic LDS the wave-per-chunk kernel needs for this chunk (typoLdsLayout().total)
 	};
 	// lattice node in the layout of the parity dumps (kamd_dump_lattices; the reference bridge writes the same): positions are text offsets when final
 	struct TypoLatNode { uint32_t startPos, endPos, prev, sibling; int32_t form; uint32_t uformLen, uformOff, spaceErrors; float typoCost; };
@@ -52,4 +53,37 @@ namespace kamd
 		float lengtheningCost;         // INFINITY: no lengthening typos (PreparedTypoTransformer::getLengtheningTypoCost)
 	};
 	void launchTypoLattice(const ModelView& M, const TypoLatView& V, uint32_t nChunks, hipStream_t stream);
+
+	// ---- wave-per-chunk variant (engine mode): the chunk's text, index maps, node list and end-position index live in the wave's LDS ----
+	constexpr uint32_t kTypoLdsNeedsBig = 0xFFFFu;      // TypoLatChunk::status: left to the thread-per-chunk kernel
+	constexpr uint32_t kTypoMaxCand = 96;               // dictionary candidates of one input position
+	// node of the build in LDS (24 bytes; positions are multiplied positions < 65536)
+	struct TypoLdsNode { uint32_t form; uint16_t startPos, endPos, prev, sibling, uformOff, uformLen; float typoCost; uint8_t spaceErrors, pad[3]; };
+	struct TypoLds { uint32_t str, cls, script, nsToPos, posToNs, epm, fullMask, zAt, cands, nodes, queue, conn, nodeCap, total; };
+	__host__ __device__ inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap) { const uint32_t c = 4 * nChars + 48; return c < nodeCap ? c : nodeCap; }
+	__host__ __device__ inline TypoLds typoLdsLayout(uint32_t nChars, uint32_t nNs, uint32_t pmb, uint32_t nodeCap)
+	{
+		TypoLds l; uint32_t top = 0;
+		auto take = [&](uint32_t bytes, uint32_t align) { top = (top + align - 1) / align * align; const uint32_t o = top; top += bytes; return o; };
+		const uint32_t mapLen = (nNs << pmb) + 1;
+		l.nodeCap = typoLdsNodeCap(nChars, nodeCap);
+		l.fullMask = take(8 * (nNs + 1), 8);
+		l.nodes = take(24 * l.nodeCap, 8);
+		l.epm = take(4 * mapLen, 4);
+		l.cands = take(4 * kTypoMaxCand, 4);
+		l.str = take(2 * nChars, 2);
+		l.nsToPos = take(2 * (nChars + 2), 2);
+		l.posToNs = take(2 * (nChars + 2), 2);
+		l.queue = take(2 * l.nodeCap, 2);
+		l.conn = take(2 * l.nodeCap, 2);
+		l.cls = take(nChars, 1);
+		l.script = take(nChars, 1);
+		l.zAt = take(nNs + 1, 1);
+		l.total = (top + 15) / 16 * 16;
+		return l;
+	}
+	// chunkList: chunk indices into V.chunks, all with ldsNeed <= ldsBytes (the launch's dynamic LDS size)
+	void launchTypoLatticeLds(const ModelView& M, const TypoLatView& V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, hipStream_t stream);
+	// the thread-per-chunk kernel over all chunks; ldsBudget > 0: chunks with ldsNeed <= ldsBudget that the LDS kernel finished are skipped
+	void launchTypoLatticeRest(const ModelView& M, const TypoLatView& V, uint32_t nChunks, uint32_t ldsBudget, hipStream_t stream);
 }
