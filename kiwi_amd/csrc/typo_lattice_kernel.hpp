@@ -60,7 +60,12 @@ namespace kamd
 	// node of the build in LDS (24 bytes; positions are multiplied positions < 65536)
 	struct TypoLdsNode { uint32_t form; uint16_t startPos, endPos, prev, sibling, uformOff, uformLen; float typoCost; uint8_t spaceErrors, pad[3]; };
 	struct TypoLds { uint32_t str, cls, script, nsToPos, posToNs, epm, fullMask, zAt, cands, nodes, queue, conn, nodeCap, total; };
+#ifdef KAMD_TEST_SMALL_CAPS
+	// test build (make smallcaps): most chunks outgrow their LDS node list and are handed to the thread-per-chunk kernel
+	__host__ __device__ inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap) { const uint32_t c = nChars / 2 + 4; return c < nodeCap ? c : nodeCap; }
+#else
 	__host__ __device__ inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap) { const uint32_t c = 4 * nChars + 48; return c < nodeCap ? c : nodeCap; }
+#endif
 	__host__ __device__ inline TypoLds typoLdsLayout(uint32_t nChars, uint32_t nNs, uint32_t pmb, uint32_t nodeCap)
 	{
 		TypoLds l; uint32_t top = 0;

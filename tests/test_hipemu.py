@@ -330,7 +330,8 @@ def _typo_pair(lib, continual, lengthening=float("inf")):
 
 @pytest.mark.parametrize("continual,threshold,top_n,lanes,tiny,lengthening", [(float("inf"), 2.5, 1, "16", False, float("inf")), (1.0, 2.5, 1, "16", False, float("inf")),
                                                                                (1.0, 1.2, 3, "16", False, float("inf")), (1.0, 2.5, 1, "64", False, float("inf")),
-                                                                               (1.0, 2.5, 2, "16", True, float("inf")), (1.0, 2.5, 1, "16", False, 0.25), (float("inf"), 4.0, 2, "64", False, 0.25)])
+                                                                               (1.0, 2.5, 2, "16", True, float("inf")), (1.0, 2.5, 1, "16", False, 0.25), (float("inf"), 4.0, 2, "64", False, 0.25),
+                                                                               (1.0, 2.5, 1, "16", "smallcaps", 0.25), (1.0, 2.5, 1, "16", "budget", float("inf"))])
 def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch, continual, threshold, top_n, lanes, tiny, lengthening):
     """The whole typo-correcting analysis on the (emulated) device -- typo graphs from the host module, k_build_lattice_typo, the search kernel
     compiled with node typo costs (viterbi_kernel_typo.hip), end stage, host post-processing -- against the oracle (pinned to the real
@@ -342,10 +343,15 @@ def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch,
     sm, path = small_model
     monkeypatch.setenv("KAMD_EXPERIMENTAL_TYPO", "1")
     monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
-    if tiny:
+    lib = emu_libs[0]
+    if tiny is True:
         monkeypatch.setenv("KAMD_TEST_TINY_ARENAS", "1")
-    prod, orc_t = _typo_pair(emu_libs[0], continual, lengthening)
-    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    elif tiny == "smallcaps":      # LDS node lists far too small: the wave-per-chunk lattice kernel hands most chunks to the thread-per-chunk one
+        lib = emu_libs[1]
+    elif tiny == "budget":         # an LDS budget only the shortest chunks fit
+        monkeypatch.setenv("KAMD_LATTICE_LDS", "3000")
+    prod, orc_t = _typo_pair(lib, continual, lengthening)
+    dev = KiwiAmd(path, lib_path=lib)
     orc = oraclelib.OracleKiwi(path)
     rnd = random.Random(7)
     texts = [misspell(t, rnd, True, continual == 1.0, lengthening < 1e9) for t in synthetic(sm, 50, 581, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 25, 582)] + EDGE_TEXTS
