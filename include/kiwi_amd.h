@@ -52,9 +52,10 @@ int kamd_run(kamd_engine_h h, kamd_batch_h b, float* ms_out);
 kamd_results_h kamd_fetch(kamd_engine_h h, kamd_batch_h b, uint32_t top_n);
 /* info[0]=chunks, [1]=non-space normalised units ("jamo"), [2]=device bytes of the staged batch */
 int kamd_batch_info(kamd_batch_h b, uint64_t* info3);
-/* chunks of the last kamd_run that ended in a device scratch overflow (kamd_fetch searches those again with larger capacities);
-   0 = the run measured by kamd_run did all of the batch's work; < 0 on error */
-int kamd_batch_failed(kamd_engine_h h, kamd_batch_h b);
+/* kamd_run searches every chunk to the end: chunks that outgrow their device scratch in the first pass are searched again, together, with
+   larger capacities before it returns.  Returns how many chunks of the last kamd_run that were (< 0: error); *ms_out (optional) = the wall
+   time of those extra passes, which kamd_run's ms_out[4] (first pass only) does not contain */
+int kamd_batch_reruns(kamd_batch_h b, float* ms_out);
 void kamd_batch_close(kamd_batch_h b);
 
 uint32_t kamd_res_texts(kamd_results_h r);

@@ -66,8 +66,8 @@ def load_library(lib_path=None):
     L.kamd_fetch.restype = C.c_void_p
     L.kamd_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.kamd_batch_info.argtypes = [C.c_void_p, C.c_void_p]
-    L.kamd_batch_failed.argtypes = [C.c_void_p, C.c_void_p]
-    L.kamd_batch_failed.restype = C.c_int
+    L.kamd_batch_reruns.argtypes = [C.c_void_p, C.c_void_p]
+    L.kamd_batch_reruns.restype = C.c_int
     L.kamd_batch_close.argtypes = [C.c_void_p]
     L.kamd_res_texts.restype = C.c_uint32
     L.kamd_res_texts.argtypes = [C.c_void_p]
@@ -251,12 +251,13 @@ class KiwiAmd:
             raise self._err("kamd_run")
         return {"scan_ms": float(ms[0]), "lattice_ms": float(ms[1]), "search_ms": float(ms[2]), "finish_ms": float(ms[3])}
 
-    def failed_chunks(self, batch: Batch) -> int:
-        """Chunks of the last run() that ended in a scratch overflow (fetch() searches them again with larger capacities)."""
-        n = self.lib.kamd_batch_failed(self.h, batch.h)
+    def reruns(self, batch: Batch):
+        """(chunks of the last run() that outgrew their scratch and were searched again inside it, wall ms of those passes)."""
+        ms = C.c_float(0)
+        n = self.lib.kamd_batch_reruns(batch.h, C.byref(ms))
         if n < 0:
-            raise self._err("kamd_batch_failed")
-        return n
+            raise self._err("kamd_batch_reruns")
+        return n, float(ms.value)
 
     def fetch(self, batch: Batch, top_n=1) -> Results:
         r = self.lib.kamd_fetch(self.h, batch.h, top_n)

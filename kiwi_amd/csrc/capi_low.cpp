@@ -98,10 +98,10 @@ extern "C"
 		info[0] = Engine::stagedChunks(*b->b); info[1] = Engine::stagedUnits(*b->b); info[2] = Engine::stagedDeviceBytes(*b->b);
 		return 0;
 	}
-	int kamd_batch_failed(kamd_engine_h h, kamd_batch_h b)
+	int kamd_batch_reruns(kamd_batch_h b, float* ms)
 	{
-		if (!h || !b) return -2;
-		return guarded([&]() { return (int)h->e->failedChunks(*b->b); }, -1);
+		if (!b) return -2;
+		return (int)Engine::rerunChunks(*b->b, ms);
 	}
 	void kamd_batch_close(kamd_batch_h b) { delete b; }
 

@@ -159,6 +159,8 @@ namespace kamd
 		bool ran = false;
 		uint32_t subBatches = 0;
 		uint32_t topN = 1;            // the search of the last run() kept this many paths per key
+		// chunks of the last run that overflowed and were searched again with larger capacities: index into overPaths per chunk (SIZE_MAX: none)
+		std::vector<size_t> overIdx; std::vector<std::vector<PathResult>> overPaths; uint32_t rerunChunks = 0; float rerunMs = 0;
 		std::vector<uint32_t> typoNeed, typoOrder;   // typo lattices: LDS need of every chunk, chunks by descending need inside each sub-batch (= dTypoOrder)
 		std::vector<uint32_t> order;   // host copy of dOrder (work order: longest chunk first inside each sub-batch)
 	};
@@ -906,11 +908,39 @@ namespace kamd
 		return b;
 	}
 
+	static void runRefs(Engine& E, Engine::Impl& I, StagedBatch& parent, std::vector<ChunkRef> refs, uint32_t capScale, std::vector<std::vector<PathResult>>& out);
+
+	// One pass of all kernels over the batch, then -- if any chunk outgrew its scratch regions -- those chunks again, together, with larger
+	// capacities (the ladder of runRefs): after run() every chunk of the batch has been searched to the end.
 	KernelTimes Engine::run(StagedBatch& b)
 	{
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		HIPCHECK(hipSetDevice(impl->device));
-		return launchAll(*impl, b, makeParams(config, b.match, b.topN));
+		KernelTimes t = launchAll(*impl, b, makeParams(config, b.match, b.topN));
+		b.overIdx.clear(); b.overPaths.clear(); b.rerunChunks = 0; b.rerunMs = 0;
+		const size_t nC = b.refs.size();
+		uint32_t nOver = 0;
+		if (nC) HIPCHECK(hipMemcpy(&nOver, b.dOutCounters.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost));
+		if (nOver)
+		{
+			const auto t0 = std::chrono::steady_clock::now();
+			std::vector<DevChunkResult> res(nC);
+			HIPCHECK(hipMemcpy(res.data(), b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost));
+			if (std::getenv("KAMD_HOST_TIMING"))   // developer aid: which overflow
+			{
+				std::map<uint32_t, uint32_t> hist;
+				for (auto& r : res) hist[r.status]++;
+				for (auto& h : hist) fprintf(stderr, "[host] chunk status %u: %u chunks\n", h.first, h.second);
+			}
+			b.overIdx.assign(nC, SIZE_MAX);
+			std::vector<ChunkRef> over;
+			for (size_t c = 0; c < nC; ++c) if (res[c].status >= 16) { b.overIdx[c] = over.size(); over.push_back(b.refs[c]); }
+			b.rerunChunks = (uint32_t)over.size();
+			if (!over.empty()) runRefs(*this, *impl, b, std::move(over), b.capScale * 4, b.overPaths);
+			b.rerunMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		}
+		t.rerunChunks = b.rerunChunks; t.rerunMs = b.rerunMs;
+		return t;
 	}
 	size_t Engine::stagedChunks(const StagedBatch& b) { return b.refs.size(); }
 	uint64_t Engine::stagedUnits(const StagedBatch& b) { return b.units; }
@@ -969,24 +999,7 @@ namespace kamd
 		}
 	}
 
-	uint32_t Engine::failedChunks(StagedBatch& b)
-	{
-		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
-		HIPCHECK(hipSetDevice(impl->device));
-		const size_t nC = b.refs.size();
-		if (!nC || !b.ran) return 0;
-		std::vector<DevChunkResult> res(nC);
-		HIPCHECK(hipMemcpy(res.data(), b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost));
-		uint32_t n = 0;
-		for (auto& r : res) n += r.status >= 16;
-		if (n && std::getenv("KAMD_HOST_TIMING"))   // developer aid: which overflow
-		{
-			std::map<uint32_t, uint32_t> hist;
-			for (auto& r : res) hist[r.status]++;
-			for (auto& h : hist) fprintf(stderr, "[host] chunk status %u: %u chunks\n", h.first, h.second);
-		}
-		return n;
-	}
+	uint32_t Engine::rerunChunks(const StagedBatch& b, float* ms) { if (ms) *ms = b.rerunMs; return b.rerunChunks; }
 
 	BatchResults Engine::fetch(StagedBatch& b, size_t topN)
 	{
@@ -1005,15 +1018,8 @@ namespace kamd
 		std::vector<size_t> firstRef(nT + 1, 0);
 		for (auto& r : b.refs) firstRef[r.text + 1]++;
 		for (size_t i = 0; i < nT; ++i) firstRef[i + 1] += firstRef[i];
-		// chunks whose scratch overflowed go up the capacity ladder together, before the per-text pass
-		std::vector<size_t> overIdx(b.refs.size(), SIZE_MAX);
-		std::vector<std::vector<PathResult>> overPaths;
-		{
-			std::vector<ChunkRef> over;
-			for (size_t c = 0; c < b.refs.size(); ++c) if (b.hResults[c].status >= 16) { overIdx[c] = over.size(); over.push_back(b.refs[c]); }
-			if (!over.empty()) runRefs(*this, *impl, b, std::move(over), b.capScale * 4, overPaths);
-			tm.lap("overflow re-runs");
-		}
+		// (chunks whose scratch overflowed were searched again inside run(): b.overIdx / b.overPaths)
+		const std::vector<size_t>& overIdx = b.overIdx; const std::vector<std::vector<PathResult>>& overPaths = b.overPaths;
 		// texts are independent: post-process them on the host workers, one segment of consecutive texts per task; a text whose chunk
 		// must be searched again (other start states than the speculative {0}, or a scratch overflow) needs the device and is finished
 		// afterwards, one by one
@@ -1030,7 +1036,7 @@ namespace kamd
 				uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
 				if (uniq.empty()) uniq.push_back(0);
 				const uint32_t st = b.hResults[c].status;
-				if (st >= 16 && uniq == b.refs[c].sp)
+				if (st >= 16 && uniq == b.refs[c].sp && c < overIdx.size() && overIdx[c] != SIZE_MAX)
 				{
 					if (!overPaths[overIdx[c]].empty()) rb.insertPaths(overPaths[overIdx[c]]);
 					continue;

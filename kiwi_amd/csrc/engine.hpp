@@ -21,7 +21,8 @@ namespace kamd
 		uint32_t maxUnkFormSize = 6, maxUnkFormSizeFollowedByJClass = 0xFFFFFFFFu, spaceTolerance = 0;
 	};
 
-	struct KernelTimes { float scanMs = 0, latticeMs = 0, searchMs = 0, finishMs = 0; uint32_t searchLaunches = 1; };   // sums over the sub-batches of one run
+	struct KernelTimes { float scanMs = 0, latticeMs = 0, searchMs = 0, finishMs = 0; uint32_t searchLaunches = 1;   // sums over the sub-batches of one run
+		uint32_t rerunChunks = 0; float rerunMs = 0; };   // chunks that overflowed their scratch and were searched again inside the run (wall time of that)
 
 	struct StagedBatch;   // chunks of one round resident in HBM
 
@@ -83,8 +84,8 @@ namespace kamd
 		static size_t stagedChunks(const StagedBatch& b);
 		static uint64_t stagedUnits(const StagedBatch& b);     // non-space normalised units ("jamo")
 		static uint64_t stagedDeviceBytes(const StagedBatch& b);
-		// chunks whose last run ended in a scratch overflow (fetch() searches those again with larger capacities)
-		uint32_t failedChunks(StagedBatch& b);
+		// chunks of the last run() that overflowed their scratch in the first pass and were searched again inside run(), and the wall time of that
+		static uint32_t rerunChunks(const StagedBatch& b, float* ms);
 
 		// debugging / parity hooks: lattice of every chunk of one text in the layout of oracle's korc_split
 		std::vector<uint8_t> dumpLattices(const char16_t* text, size_t n, uint64_t match);

@@ -1712,6 +1712,12 @@ namespace sbgk
 			res->status = status; res->nPaths = status == CS_OK ? nPaths : 0;
 			res->pathOff = pathOff; res->tokOff = tokOff; res->nTok = status == CS_OK ? tokTop : 0;
 		}
+		// chunks of the batch that ended in a scratch overflow (the host searches them again with larger capacities): one counter, so that
+		// a run without any costs the host four bytes of D2H instead of the status array
+		{
+			const unsigned long long bad = __ballot(mine && t < chunkCount && res->status >= 16);
+			if (lane == 0 && bad) atomicAdd(&W.outCounters[2], (uint32_t)__popcll(bad));
+		}
 	}
 #endif
 
