@@ -149,8 +149,7 @@ def main():
     batch = eng.stage(shard) if typo is None else eng.stage(shard, typo=typo, typo_threshold=typo_cfg[2])
     info = batch.info()
     if top_n > 1:
-        eng.run(batch)
-        eng.fetch(batch, top_n).close()     # a batch keeps the top-N of its last fetch: every run below searches with it
+        eng.fetch(batch, top_n).close()     # (runs the batch with this N) a batch keeps the top-N of its last fetch: every run below searches with it
 
     def sync():
         torch.cuda.synchronize()

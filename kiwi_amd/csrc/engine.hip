@@ -88,7 +88,13 @@ namespace kamd
 				device = currentDevice();      // (the engine binds its device to the calling thread before any allocation)
 				const size_t want = n + n / 8 + 256;
 				p = devCache().take(want, cap, device);
-				if (!p) { HIPCHECK(hipMalloc(&p, want)); cap = want; }
+				if (!p)
+				{
+					hipError_t e = hipMalloc(&p, want);
+					if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); devCache().trim(); e = hipMalloc(&p, want); }      // recycled blocks of other sizes are in the way
+					if (e != hipSuccess) { p = nullptr; (void)hipGetLastError(); throw std::runtime_error{ std::string{ "HIP error in hipMalloc(" } + std::to_string(want) + " bytes): " + hipGetErrorString(e) }; }
+					cap = want;
+				}
 				// developer aid: KAMD_POISON=1 fills every (re)acquired block with 0xCD, so that a read of memory no kernel has written
 				// yet shows up the same way on every run (fresh and recycled blocks otherwise hold arbitrary bytes)
 				static const bool poison = std::getenv("KAMD_POISON") != nullptr;

@@ -169,6 +169,7 @@ namespace kamd
 		const ModelView* M; const SearchParams* P;
 		const uint16_t* str; const uint16_t* nsToPos; const uint16_t* posToNs;
 		NodeT* out; uint32_t* endPosMap; uint64_t* fullMask; uint8_t* zAt; uint32_t nOut, cap; bool overflow;
+		uint32_t lastEnd = 0;   // end position of the most recently appended node (what insertUnkForm asks for), kept out of the node list
 		__device__ __forceinline__ void setSpaceErrors(uint32_t id, uint8_t v) { if constexpr (sizeof(NodeT) == sizeof(DevNode)) out[id].spaceErrors = v; else spaceErr[id] = v; }
 		__device__ __forceinline__ DevNode full(uint32_t id) const
 		{
@@ -199,6 +200,7 @@ namespace kamd
 		if constexpr (sizeof(typename LC::Node) == sizeof(DevNode)) { nn.spaceErrors = 0; nn.nflags = 0; nn.nPrev = 0; nn.packOff = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0; }
 		else L.spaceErr[id] = 0;
 		L.out[id] = nn;
+		L.lastEnd = e;
 		if (e >= nMap) return true;
 		if (qual && lenKey >= 1 && lenKey <= 64) L.fullMask[e] |= 1ull << (lenKey - 1);
 		if (zbits) L.zAt[e] |= zbits;
@@ -249,7 +251,7 @@ namespace kamd
 	__device__ void latInsertUnk(LC& L, uint32_t s, uint32_t e, bool hasJ, uint32_t nMap)   // Splitter::insertUnkForm (KTrie.cpp:921-953)
 	{
 		if (s >= e || latHasForm(L, s, e)) return;
-		uint32_t lastPos = L.out[L.nOut - 1].endPos;
+		uint32_t lastPos = L.lastEnd;
 		if (lastPos < e)
 		{
 			if (lastPos && isHangulCoda(L.str[L.nsToPos[lastPos]])) lastPos--;
@@ -278,7 +280,7 @@ namespace kamd
 	struct LatticeMem
 	{
 		const uint16_t* str; const uint8_t* cls; const uint8_t* script; const uint8_t* cflag;
-		const uint64_t* mask; const uint32_t* moff; const uint32_t* mforms; const uint2* mfrec;   // mfrec: {charOff, len | numSpaces << 8 | flags << 16} of every packed match, or null
+		const uint64_t* mask; const uint32_t* moff; const uint32_t* mforms; const uint2* mfrec;   // mfrec: {start | space errors << 16, form flags | valid << 8} of every packed match, or null
 		uint16_t* queue; uint16_t* connOrd;
 	};
 
@@ -362,10 +364,27 @@ namespace kamd
 			for (uint32_t k = zcand ? m0 - 1 : m0; k != m1; ++k)
 			{
 				const bool isZ = zcand && k == m0 - 1;
+				if (!isZ && mfrec)
+				{
+					// wave-per-chunk variant: the match's facts were computed by the staging pass
+					const uint2 r = mfrec[k];
+					if (!(r.y & 0x100)) continue;
+					const uint32_t nb = r.x & 0xFFFF, ne = endNs, se = r.x >> 16; const uint8_t fl = (uint8_t)r.y;
+					if (nb < resetNs) continue;
+					if (!(fl & FF_FIRST_IS_CODA))
+					{
+						const bool hj = (fl & FF_HAS_JCLASS) || (fl & FF_IS_STAG);
+						if (boundary < nb) latInsertUnk(L, boundary, nb, hj, nMap);
+						latInsertUnk(L, unkStart, nb, hj, nMap);
+					}
+					if (se <= P.spaceTol)
+					{
+						if (latAppend(L, nb, ne, mforms[k], 0, 0, nMap, (fl & FF_HAS_ANY_FULL) != 0, ne - nb, fl & 3)) L.setSpaceErrors(L.nOut - 1, (uint8_t)(se > 255 ? 255 : se));
+					}
+					continue;
+				}
 				const uint32_t fi = isZ ? zform : mforms[k];
-				FormRec f;
-				if (isZ || !mfrec) f = M.forms[fi];
-				else { const uint2 r = mfrec[k]; f.charOff = r.x; f.len = (uint8_t)r.y; f.numSpaces = (uint8_t)(r.y >> 8); f.flags = (uint8_t)(r.y >> 16); f.candOff = 0; f.candCnt = 0; f.flags2 = 0; f.vowelPolar = 0; f.formHash = 0; }
+				const FormRec f = M.forms[fi];
 				const uint32_t flen = f.len - f.numSpaces;
 				if (flen > endNs) continue;
 				const uint32_t nb = endNs - flen, ne = endNs;
@@ -569,10 +588,35 @@ namespace kamd
 			const uint32_t mTot = gmoff[nNs] + __popcll(gmask[nNs]);
 			const uint32_t* gforms = W.matchForm + mBase;
 			if (mTot > latticeLdsCap(n, mCap)) { if (lane == 0) W.nNodes[chunk] = kLatticeNeedsBig; return; }    // wave-uniform
+			waveSync();
+			// one packed match per lane: everything the replay needs of it that does not depend on the lattice built so far -- start position,
+			// space errors of the span (countSpaceErrors, KTrie.cpp:316-328), form flags -- so that the serial loop reads one 8-byte record
 			for (uint32_t k = lane; k < mTot; k += 64)
 			{
 				const uint32_t fi = gforms[k]; const FormRec f = M.forms[fi];
-				mforms[k] = fi; mfrec[k] = make_uint2(f.charOff, (uint32_t)f.len | ((uint32_t)f.numSpaces << 8) | ((uint32_t)f.flags << 16));
+				mforms[k] = fi;
+				uint32_t lo = 0, hi = nNs;      // end position of match k: the last e with moff[e] <= k
+				while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (moff[mid] <= k) lo = mid; else hi = mid - 1; }
+				const uint32_t endNs = lo, flen = f.len - f.numSpaces;
+				uint32_t nb = 0, se = 0, valid = 0;
+				if (flen <= endNs)
+				{
+					valid = 1; nb = endNs - flen;
+					uint32_t off = 0;
+					if (!f.numSpaces) { for (uint32_t i = 1; i < flen; ++i) se += (nsToPos[nb + i] - nsToPos[nb + i - 1] > 1) ? 1u : 0u; }
+					else
+					{
+						const uint16_t* fs = M.formChars + f.charOff;
+						for (uint32_t i = 1; i < flen; ++i)
+						{
+							const bool hasSpace = nsToPos[nb + i] - nsToPos[nb + i - 1] > 1;
+							const uint16_t fc = (i + off < f.len) ? fs[i + off] : 0;
+							if (hasSpace && fc != u' ') ++se;
+							if (fc == u' ') ++off;
+						}
+					}
+				}
+				mfrec[k] = make_uint2(nb | ((se > 0xFFFFu ? 0xFFFFu : se) << 16), (uint32_t)f.flags | (valid << 8));
 			}
 		}
 		LatticeCtxT<BuildNode16> L;

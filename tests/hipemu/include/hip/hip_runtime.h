@@ -140,7 +140,7 @@ using std::max;
 
 // ---- runtime API (synchronous: every launch has finished when the call returns) ------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 typedef struct hipemuStream* hipStream_t;
 typedef struct hipemuEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
@@ -152,9 +152,9 @@ inline hipError_t hipGetDeviceCount(int* n) { const char* e = std::getenv("HIPEM
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::memset(p, 0, sizeof(*p)); std::strcpy(p->name, "hipemu (CPU lanes)"); p->multiProcessorCount = 1; p->totalGlobalMem = 1ull << 34; return hipSuccess; }
-template<class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
+template<class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-template<class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { *p = (T*)std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorInvalidValue; }
+template<class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { *p = (T*)std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
