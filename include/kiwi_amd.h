@@ -101,6 +101,17 @@ kamd_results_h kamd_analyze_batch_typo(kamd_engine_h h, kamd_typo_h t, float thr
 /* ... and kamd_stage with one (the transformer must outlive the batch): kamd_run / kamd_fetch as usual */
 kamd_batch_h kamd_stage_typo(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts,
                              uint64_t match_options, int open_ending, int host_threads);
+/* Morpheme sets -- AnalyzeOption::blocklist of the reference (include/kiwi/Kiwi.h AnalyzeOption, src/capi/kiwi_c.cpp:851-864, 1779-1826): candidates
+ * whose combined morpheme or one of whose chunks is in the set are left out of the search (src/PathEvaluator.hpp:385, 892).
+ * kamd_morphset_add: Kiwi::findMorphemes(form, tag) -- every morpheme of the dictionary form `form` with POS tag id `tag` (< 0 or 0: any), irregularity
+ * ignored; returns how many were added (0: no such form), < 0 on error.  The set must outlive the calls that use it. */
+typedef struct kamd_morphset* kamd_morphset_h;
+kamd_morphset_h kamd_morphset_new(kamd_engine_h h);
+int kamd_morphset_add(kamd_morphset_h m, const uint16_t* form, uint32_t len, int tag);
+void kamd_morphset_close(kamd_morphset_h m);
+/* kamd_analyze_batch with the per-call options of the reference's AnalyzeOption: a prepared typo transformer (or NULL) and a blocklist (or NULL) */
+kamd_results_h kamd_analyze_batch_opt(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, kamd_morphset_h blocklist,
+                                      const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts, uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
 /* parity hook: the lattices the device builds OVER the typo graphs of a text's chunks (csrc/typo_lattice_kernel.hip), in the layout of kamd_dump_lattices;
  * 0 + kamd_last_error() on failure */
 size_t kamd_typo_lattices(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);

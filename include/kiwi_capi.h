@@ -5,12 +5,13 @@
  * long as it stays inside this subset (anything else is simply not exported: link error, not silent change).
  *
  * Differences a caller can observe:
- *   - kiwi_init's model_path names a raw-model container (or a directory holding `kiwi_amd.raw`);
- *     on-disk sj.morph / sj.knlm loaders are a "next" row.  Its `options` are honoured as in the reference:
+ *   - kiwi_init's model_path names a directory holding the reference's own model files (sj.morph + sj.knlm, optionally skipbigram.mdl;
+ *     cong.mdl is read from raw containers only), or a raw-model container (or a directory holding `kiwi_amd.raw`).  Its `options` are honoured as in the reference:
  *     KIWI_BUILD_INTEGRATE_ALLOMORPH sets integrate_allomorph; the model type bits select a CoNgram model (default / LARGEST when the
  *     container has one, CONG; local scoring), Knlm (default otherwise, KNLM) or SkipBigram (LARGEST when the container has the tables, SBG)
  *     and refuse CONG_GLOBAL; the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).
- *   - top_n > 4, blocklist, pretokenized spans and non-standard dialects are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
+ *   - option.blocklist (morpheme sets: kiwi_new_morphset / kiwi_morphset_add / _add_w / _close) is honoured;
+ *     top_n > 4, pretokenized spans and non-standard dialects are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
  *     being silently ignored.
  */
 #ifndef KIWI_CAPI_SUBSET_H
@@ -109,6 +110,11 @@ float kiwi_res_score(kiwi_res_h result, int index, int num);                    
 float kiwi_res_typo_cost(kiwi_res_h result, int index, int num);                                 /* capi.h:927 */
 int kiwi_res_close(kiwi_res_h result);                                                           /* capi.h:937 */
 const char* kiwi_get_script_name(uint8_t script);                                                /* capi.h:1417 */
+/* morpheme sets: kiwi_analyze_option_t::blocklist (candidates whose morpheme -- or a chunk of it -- is in the set are left out of the search) */
+kiwi_morphset_h kiwi_new_morphset(kiwi_h handle);                                                /* capi.h:660 */
+int kiwi_morphset_add(kiwi_morphset_h handle, const char* form, const char* tag);                /* capi.h:1243 */
+int kiwi_morphset_add_w(kiwi_morphset_h handle, const kchar16_t* form, const char* tag);         /* capi.h:1253 */
+int kiwi_morphset_close(kiwi_morphset_h handle);                                                 /* capi.h:1263 */
 /* typo transformers (rule container, preparation, option.typo_transformer / typo_threshold of kiwi_analyze*): parity-checked on the MI355X against the
  * oracle and the real reference (tests/test_gpu_typo.py, tests/test_gpu_capi.py). */
 kiwi_typo_h kiwi_typo_init(void);                                                                /* capi.h:469 */

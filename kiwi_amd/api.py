@@ -176,6 +176,19 @@ class Results:
         return out
 
 
+class MorphSet:
+    def __init__(self, lib, handle):
+        self.lib, self.h = lib, handle
+
+    def close(self):
+        if self.h:
+            self.lib.kamd_morphset_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Batch:
     def __init__(self, lib, handle):
         self.lib, self.h = lib, handle
@@ -219,6 +232,38 @@ class KiwiAmd:
         r = self.lib.kamd_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), top_n, match, int(open_ending), host_threads)
         if not r:
             raise self._err("kamd_analyze_batch")
+        return Results(self.lib, r)
+
+    def morphset(self, items):
+        """A morpheme set for `blocklist=`: items = [(form, tag id or -1)], each added like kiwi_morphset_add (Kiwi::findMorphemes).
+        Returns (handle object, morphemes found per item); keep the object alive while it is in use."""
+        L = self.lib
+        L.kamd_morphset_new.restype = C.c_void_p
+        L.kamd_morphset_new.argtypes = [C.c_void_p]
+        L.kamd_morphset_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        L.kamd_morphset_close.argtypes = [C.c_void_p]
+        ms = MorphSet(L, L.kamd_morphset_new(self.h))
+        if not ms.h:
+            raise self._err("kamd_morphset_new")
+        found = []
+        for form, tag in items:
+            u = np.frombuffer(form.encode("utf-16-le"), np.uint16)
+            n = L.kamd_morphset_add(ms.h, u.ctypes.data, len(u), tag)
+            if n < 0:
+                raise self._err("kamd_morphset_add")
+            found.append(n)
+        return ms, found
+
+    def analyze_batch_opt(self, texts, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0, typo=None, typo_threshold=2.5, blocklist=None) -> Results:
+        """kamd_analyze_batch_opt: the per-call options of the reference's AnalyzeOption (prepared typo transformer, blocklist)."""
+        L = self.lib
+        L.kamd_analyze_batch_opt.restype = C.c_void_p
+        L.kamd_analyze_batch_opt.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+        flat, offs = pack_texts(texts)
+        r = L.kamd_analyze_batch_opt(self.h, typo.h if typo is not None else None, typo_threshold, 0, blocklist.h if blocklist is not None else None,
+                                     flat.ctypes.data, offs.ctypes.data, len(texts), top_n, match, int(open_ending), host_threads)
+        if not r:
+            raise self._err("kamd_analyze_batch_opt")
         return Results(self.lib, r)
 
     def analyze_packed(self, flat, offs, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Results:

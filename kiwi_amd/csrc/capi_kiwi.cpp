@@ -28,6 +28,7 @@ struct kiwi_s
 };
 
 struct kiwi_typo { kamd::TypoTransformer tt; };                       // capi.h:35
+struct kiwi_morphset { kiwi_h owner; std::vector<uint32_t> ids, bits; };   // capi.h:36 (src/capi/kiwi_c.cpp: a set of Morpheme pointers; here ids + the bit set the kernels test)
 struct kiwi_prepared_typo { kamd::PreparedTypo p; };                  // capi.h:38
 
 // One text's analyses, flat (its slice of a batch's ResultSegment): token records whose first 44 bytes are kiwi_token_info_t -- the
@@ -64,6 +65,18 @@ namespace
 			switch (t & 0x7F) { case T_VV: return "VV-I"; case T_VA: return "VA-I"; case T_VX: return "VX-I"; case T_XSA: return "XSA-I"; default: return "@"; }
 		}
 		return t < sizeof(tagNames) / sizeof(tagNames[0]) ? tagNames[t] : "@";
+	}
+
+	uint8_t parseTag(const char* pos)   // parse_tag (src/capi/kiwi_c.cpp:86-93) + toPOSTag (src/StrUtils.h:552-633)
+	{
+		std::string u;
+		for (const char* p = pos; *p; ++p) u.push_back((char)std::toupper((unsigned char)*p));
+		for (uint8_t t = 1; t < T_P; ++t) if (u == tagNames[t]) return t;
+		if (u == "NF" || u == "NV" || u == "NA" || u == "UNK" || u == "UN" || u == "^") return T_UNKNOWN;
+		if (u == "V" || u == "A") return T_P;
+		if (u == "VV-I") return T_VV | 0x80; if (u == "VA-I") return T_VA | 0x80; if (u == "VX-I") return T_VX | 0x80; if (u == "XSA-I") return T_XSA | 0x80;
+		if (u == "VV-R") return T_VV; if (u == "VA-R") return T_VA; if (u == "VX-R") return T_VX; if (u == "XSA-R") return T_XSA;
+		throw std::invalid_argument{ std::string{ "Unknown POSTag : " } + pos };
 	}
 
 	std::u16string utf8To16(const char* s, size_t n)   // src/StrUtils.h:228-303 (strict decoder, throws on malformed input)
@@ -108,7 +121,6 @@ namespace
 
 	void checkOption(const kiwi_analyze_option_t& o, kiwi_pretokenized_h pt)
 	{
-		if (o.blocklist) throw std::invalid_argument{ "kiwi_amd: blocklist is not supported on the device path yet" };
 		if (o.allowed_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported on the device path yet" };
 		if (pt) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
 		if ((uint32_t)o.match_options & (3u << 8)) throw std::invalid_argument{ "`oovChrModel` option is set but the character-level noun model is not loaded." };
@@ -204,12 +216,47 @@ namespace
 	{
 		TypoOption t;
 		if (o.typo_transformer) { t.typo = &o.typo_transformer->p; t.threshold = o.typo_threshold; t.allowedDialect = 0; }
+		if (o.blocklist && !o.blocklist->ids.empty()) t.blocked = &o.blocklist->bits;      // AnalyzeOption::blocklist (src/capi/kiwi_c.cpp:870)
 		return t;
 	}
 }
 
 extern "C"
 {
+	// ---- morpheme sets: the blocklist of kiwi_analyze_option_t (capi.h:655-664, 1243-1263; src/capi/kiwi_c.cpp:851-864, 1779-1826)
+	kiwi_morphset_h kiwi_new_morphset(kiwi_h h)
+	{
+		if (!h) return nullptr;
+		try { auto* m = new kiwi_morphset; m->owner = h; return m; }
+		catch (const std::exception& e) { setError(e); return nullptr; }
+	}
+	static int morphsetAdd(kiwi_morphset_h m, const std::u16string& form, const char* tag)
+	{
+		const uint8_t t = tag ? parseTag(tag) : (uint8_t)T_UNKNOWN;
+		const auto found = kamd::findMorphemes(m->owner->engine->model(), form.data(), form.size(), t);
+		m->ids.insert(m->ids.end(), found.begin(), found.end());
+		m->bits = kamd::blockBitsOf(m->owner->engine->model(), m->ids);
+		return (int)found.size();
+	}
+	int kiwi_morphset_add(kiwi_morphset_h m, const char* form, const char* tag)
+	{
+		if (!m) return KIWIERR_INVALID_HANDLE;
+		try { return morphsetAdd(m, utf8To16(form, std::strlen(form)), tag); }
+		catch (const std::exception& e) { setError(e); return KIWIERR_FAIL; }
+	}
+	int kiwi_morphset_add_w(kiwi_morphset_h m, const kchar16_t* form, const char* tag)
+	{
+		if (!m) return KIWIERR_INVALID_HANDLE;
+		try { size_t n = 0; while (form[n]) ++n; return morphsetAdd(m, std::u16string{ (const char16_t*)form, n }, tag); }
+		catch (const std::exception& e) { setError(e); return KIWIERR_FAIL; }
+	}
+	int kiwi_morphset_close(kiwi_morphset_h m)
+	{
+		if (!m) return KIWIERR_INVALID_HANDLE;
+		delete m;
+		return 0;
+	}
+
 	// ---- typo transformers (capi.h:459-588; src/capi/kiwi_c.cpp:540-715).
 	kiwi_typo_h kiwi_typo_init() { try { return new kiwi_typo; } catch (const std::exception& e) { setError(e); return nullptr; } }
 	kiwi_typo_h kiwi_typo_get_basic() { return kiwi_typo_get_default(1); }

@@ -338,6 +338,39 @@ extern "C"
 		return guarded([&]() { auto d = h->e->dumpTypoLattices(*t->prepared, threshold, (uint16_t)allowed_dialect, (const char16_t*)text, len, match); if (d.size() <= cap) std::memcpy(out, d.data(), d.size()); return d.size(); }, (size_t)0);
 	}
 
+	// ---- morpheme sets (AnalyzeOption::blocklist)
+	struct kamd_morphset_impl { kamd_engine_h owner; std::vector<uint32_t> ids; std::vector<uint32_t> bits; };
+	kamd_morphset_h kamd_morphset_new(kamd_engine_h h)
+	{
+		if (!h) { lastError = "invalid handle"; return nullptr; }
+		return guarded([&]() { auto m = std::make_unique<kamd_morphset_impl>(); m->owner = h; return reinterpret_cast<kamd_morphset_h>(m.release()); }, (kamd_morphset_h)nullptr);
+	}
+	int kamd_morphset_add(kamd_morphset_h mh, const uint16_t* form, uint32_t len, int tag)
+	{
+		auto* m = reinterpret_cast<kamd_morphset_impl*>(mh);
+		if (!m || !form) return -2;
+		return guarded([&]()
+		{
+			const auto found = findMorphemes(m->owner->e->model(), (const char16_t*)form, len, (uint8_t)(tag < 0 ? 0 : tag));
+			m->ids.insert(m->ids.end(), found.begin(), found.end());
+			m->bits = blockBitsOf(m->owner->e->model(), m->ids);
+			return (int)found.size();
+		}, -1);
+	}
+	void kamd_morphset_close(kamd_morphset_h mh) { delete reinterpret_cast<kamd_morphset_impl*>(mh); }
+	kamd_results_h kamd_analyze_batch_opt(kamd_engine_h h, kamd_typo* t, float threshold, int allowed_dialect, kamd_morphset_h blocklist, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int openEnding, int hostThreads)
+	{
+		if (!h || (t && !t->prepared)) { lastError = "invalid handle / typo transformer not prepared"; return nullptr; }
+		auto* m = reinterpret_cast<kamd_morphset_impl*>(blocklist);
+		if (m && m->owner != h) { lastError = "the morpheme set belongs to another engine"; return nullptr; }
+		return guarded([&]()
+		{
+			TypoOption o; if (t) { o.typo = t->prepared.get(); o.threshold = threshold; o.allowedDialect = (uint16_t)allowed_dialect; }
+			if (m && !m->ids.empty()) o.blocked = &m->bits;
+			return pack(h->e->analyzeBatch(views(texts, offsets, n), topN, match, !!openEnding, hostThreads, o));
+		}, (kamd_results*)nullptr);
+	}
+
 	size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap)
 	{
 		if (!h) return 0;

@@ -144,7 +144,8 @@ namespace kamd
 		DevChunkResult* results;       // [c]
 		DevPathHeader* outPaths;       // compact output of the end stage: path headers of all chunks ...
 		DevToken* outTokens;           // ... and their token records (D2H copies exactly what was produced)
-		uint32_t* outCounters;         // [0] path headers handed out, [1] token records handed out
+		uint32_t* outCounters;         // [0] path headers handed out, [1] token records handed out, [2] chunks that ended in a scratch overflow
+		const uint32_t* blockBits;     // AnalyzeOption::blocklist as one bit per morpheme id (null: none): k_expand_cands drops those candidates
 		uint32_t outPathCap, outTokCap;
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
 		uint32_t bigScratchBytes;      // per wave

@@ -154,7 +154,7 @@ namespace kamd
 		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
 		TypoOption typo;
-		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder;
+		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder, dBlockBits;
 		TypoLatView tv{};
 		DevBuf dPacks, dStates, dNodeStOff, dNodeStCnt, dReach, dTokens, dResults, dOrder;
 		DevBuf dOutPaths, dOutTokens, dOutCounters; uint32_t outPathCap = 0, outTokCap = 0;   // compact outputs of the end stage
@@ -428,6 +428,13 @@ namespace kamd
 		w.tokenBase = (const uint64_t*)(D + oTokenBase); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
 		w.outTokens = b.dOutTokens.as<DevToken>(); w.outPaths = b.dOutPaths.as<DevPathHeader>(); w.outCounters = b.dOutCounters.as<uint32_t>();
 		w.outTokCap = b.outTokCap; w.outPathCap = b.outPathCap;
+		w.blockBits = nullptr;
+		if (b.typo.blocked && !b.typo.blocked->empty())
+		{
+			if (b.typo.blocked->size() != (I.model.morphs.size() + 31) / 32) throw std::invalid_argument{ "kiwi_amd: blocklist bit set does not belong to this model" };
+			upload(b.dBlockBits, *b.typo.blocked, s);
+			w.blockBits = b.dBlockBits.as<uint32_t>();
+		}
 		w.bigScratch = nullptr; w.bigScratchBytes = 0;   // bound at launch
 		b.subBatches = 0;
 		if (b.typo.typo)

@@ -50,7 +50,9 @@ namespace kamd
 	};
 	class PreparedTypo;
 	// a prepared typo transformer applied to an analysis (AnalyzeOption::typoTransformer / typoThreshold / allowedDialects of the reference)
-	struct TypoOption { const PreparedTypo* typo = nullptr; float threshold = 2.5f; uint16_t allowedDialect = 0; };
+	struct TypoOption { const PreparedTypo* typo = nullptr; float threshold = 2.5f; uint16_t allowedDialect = 0;
+		// AnalyzeOption::blocklist: one bit per morpheme id (flat_model.hpp blockBitsOf), null = none; must outlive the batch
+		const std::vector<uint32_t>* blocked = nullptr; };
 
 	class Engine
 	{

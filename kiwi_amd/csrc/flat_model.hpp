@@ -272,4 +272,10 @@ namespace kamd
 	void bakeModel(FlatModel& out, const std::string& rawModelPath);
 	// serialises the baked dictionary in the layout of oracle/ref_bridge.cpp:kref_dump_dict (tests compare both)
 	std::vector<uint8_t> dumpDict(const FlatModel& m);
+	// Kiwi::findMorphemes (src/Kiwi.cpp:1281-1297, findForm src/KTrie.cpp:2172-2192): the morphemes of the dictionary form spelled `s` (raw text: it is
+	// normalised like the reference's normalizeHangul) whose tag, irregularity aside, is `tag` (0 = any tag); halves of split stems are not returned
+	std::vector<uint32_t> findMorphemes(const FlatModel& m, const char16_t* s, size_t n, uint8_t tag);
+	// Morpheme::hasMorpheme over a set of morpheme ids (include/kiwi/Form.h:187-196), for every morpheme at once: bit m is set iff the set holds
+	// m's combined morpheme or one of its chunks -- what the candidate loops test a blocklist with (src/PathEvaluator.hpp:385, 892)
+	std::vector<uint32_t> blockBitsOf(const FlatModel& m, const std::vector<uint32_t>& ids);
 }

@@ -730,14 +730,20 @@ namespace kamd
 		if (W.results[chunk].status != CS_OK) return;
 		const uint32_t nBase = W.nodeBase[chunk], G = W.nNodes[chunk];
 		CandStatic* packs = W.packs + W.packBase[chunk];
+		const uint32_t* blk = W.blockBits;
+		auto blocked = [&](uint32_t m2) -> bool { return blk && ((blk[m2 >> 5] >> (m2 & 31)) & 1); };
 		for (uint32_t i = 1 + threadIdx.x; i + 1 < G; i += blockDim.x)
 		{
 			const DevNode nd = W.nodes[nBase + i];
 			if (nd.form == NOFORM) continue;
 			const uint32_t candOff = M.forms[nd.form].candOff;
+			uint32_t kept = 0;
 			for (uint32_t k = 0; k < nd.candCnt; ++k)
 			{
 				const uint32_t mid = M.formCand[candOff + k];
+				// a candidate on the blocklist is not a candidate (src/PathEvaluator.hpp:385, 892): it gets no record, the node's list shrinks
+				if (blocked(mid)) continue;
+				++kept;
 				const uint4* mr = reinterpret_cast<const uint4*>(M.morphs + mid);
 				CandStatic o; const uint4 r0 = mr[0], r1 = mr[1];
 				o.m0 = Quad{ r0.x, r0.y, r0.z, r0.w }; o.m1 = Quad{ r1.x, r1.y, r1.z, r1.w };
@@ -747,7 +753,7 @@ namespace kamd
 				// 4th word: LM id of the second chunk of a chunked candidate (saves the search a dependent chunk-table load)
 				const uint32_t secondWid = (!(flags & MF_SINGLE) && (o.m1.w & 0xFF) >= 2) ? M.chunkLm[o.m0.z + 1] : 0;
 				o.x = Quad{ mid, firstWid, sbType, secondWid };
-				uint32_t at = k;
+				uint32_t at = 0;
 				if (transposedOrder)
 				{
 					auto cls = [&](uint32_t m2) -> uint32_t
@@ -759,16 +765,20 @@ namespace kamd
 						return (r.flags & MF_SINGLE) ? 3 : 4;
 					};
 					const uint32_t mine = cls(mid);
-					at = 0;
 					for (uint32_t j = 0; j < nd.candCnt; ++j)
 					{
 						if (j == k) continue;
-						const uint32_t other = cls(M.formCand[candOff + j]);
+						const uint32_t mj = M.formCand[candOff + j];
+						if (blocked(mj)) continue;
+						const uint32_t other = cls(mj);
 						if (other < mine || (other == mine && j < k)) ++at;
 					}
 				}
+				else if (blk) { for (uint32_t j = 0; j < k; ++j) if (!blocked(M.formCand[candOff + j])) ++at; }
+				else at = k;
 				packs[nd.packOff + at] = o;
 			}
+			if (kept != nd.candCnt) W.nodes[nBase + i].candCnt = (uint16_t)kept;
 		}
 	}
 }

@@ -874,6 +874,62 @@ namespace kamd
 		if (vocab > m.lmRoot.size()) throw std::runtime_error{ "raw model: vocab larger than LM vocab" };
 	}
 
+	std::vector<uint32_t> findMorphemes(const FlatModel& m, const char16_t* s, size_t n, uint8_t tag)
+	{
+		std::vector<uint32_t> ret;
+		// normalizeHangul (src/StrUtils.h:494-521): syllable with coda -> open syllable + coda jamo
+		std::u16string nrm;
+		for (size_t i = 0; i < n; ++i)
+		{
+			char16_t c = s[i];
+			if (c == 0xB42C) c = 0xB410;
+			if (0xAC00 <= c && c < 0xD7A4)
+			{
+				const int coda = (c - 0xAC00) % 28;
+				nrm.push_back((char16_t)(c - coda));
+				if (coda) nrm.push_back((char16_t)(coda + 0x11A7));
+			}
+			else nrm.push_back(c);
+		}
+		uint32_t node = 0;
+		for (size_t i = 0; i < nrm.size(); ++i)
+		{
+			const uint16_t c = (uint16_t)nrm[i];
+			if (node == 0) { node = m.trieRoot[c]; if (!node) return ret; continue; }
+			const TrieNodeRec& t = m.trie[node];
+			const uint16_t* kb = m.trieKeys.data() + t.edgeOff;
+			const uint16_t* it = std::lower_bound(kb, kb + t.numNexts, c);
+			if (it == kb + t.numNexts || *it != c) return ret;
+			node = m.trieChild[t.edgeOff + (it - kb)];
+		}
+		if (node == 0 || m.trie[node].value < 0) return ret;      // no form ends here (or only a submatch does)
+		const FormRec& f = m.forms[m.trie[node].value];
+		for (uint32_t k = 0; k < f.candCnt; ++k)
+		{
+			const uint32_t mid = m.formCand[f.candOff + k];
+			const MorphRec& r = m.morphs[mid];
+			if (r.socket || (tag && (r.tag & 0x7F) != (tag & 0x7F))) continue;
+			ret.push_back(mid);
+		}
+		return ret;
+	}
+
+	std::vector<uint32_t> blockBitsOf(const FlatModel& m, const std::vector<uint32_t>& ids)
+	{
+		const size_t nM = m.morphs.size();
+		std::vector<uint32_t> raw((nM + 31) / 32, 0), eff((nM + 31) / 32, 0);
+		for (uint32_t id : ids) if (id < nM) raw[id >> 5] |= 1u << (id & 31);
+		auto has = [&](uint32_t id) { return id < nM && ((raw[id >> 5] >> (id & 31)) & 1); };
+		for (size_t i = 0; i < nM; ++i)
+		{
+			const MorphRec& r = m.morphs[i];
+			bool b = r.combinedId >= 0 && has((uint32_t)r.combinedId);
+			for (uint32_t k = 0; k < r.nChunks && !b; ++k) b = has(m.chunkMorph[r.chunkOff + k]);
+			if (b) eff[i >> 5] |= 1u << (i & 31);
+		}
+		return eff;
+	}
+
 	std::vector<uint8_t> dumpDict(const FlatModel& m)
 	{
 		std::vector<uint8_t> out;

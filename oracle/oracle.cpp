@@ -26,6 +26,7 @@ struct OracleHandle
 	BestPathConfig bcfg;
 	bool integrateAllomorph = true;
 	Counters counters;
+	std::vector<uint32_t> blockIds, blockBits;      // AnalyzeOption::blocklist of the following analyses (korc_blocklist_*)
 };
 
 namespace
@@ -107,6 +108,22 @@ extern "C"
 		auto& h = *(OracleHandle*)hp;
 		h.bcfg.faithfulOrder = !!on;
 		h.persistent = PersistentContainers{};
+	}
+
+	// AnalyzeOption::blocklist for every analysis that follows: kiwi_morphset_add (src/capi/kiwi_c.cpp:1779-1794) = Kiwi::findMorphemes(form, tag)
+	void korc_blocklist_clear(void* hp)
+	{
+		auto& h = *(OracleHandle*)hp;
+		h.blockIds.clear(); h.blockBits.clear(); h.bcfg.blockBits = nullptr;
+	}
+	int korc_blocklist_add(void* hp, const uint16_t* form, uint32_t len, int tag)
+	{
+		auto& h = *(OracleHandle*)hp;
+		const auto found = findMorphemes(h.model, (const char16_t*)form, len, (uint8_t)(tag < 0 ? 0 : tag));
+		h.blockIds.insert(h.blockIds.end(), found.begin(), found.end());
+		h.blockBits = blockBitsOf(h.model, h.blockIds);
+		h.bcfg.blockBits = h.blockIds.empty() ? nullptr : h.blockBits.data();
+		return (int)found.size();
 	}
 
 	// test hook: container selection limits (defaults 128, 512, 128)

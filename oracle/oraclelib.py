@@ -140,6 +140,17 @@ class OracleKiwi:
         sec = self.lib.korc_analyze_batch_typo(self.h, typo.h if typo is not None else None, typo_threshold, flat.ctypes.data, offs.ctypes.data, len(enc), top_n, match, threads, C.byref(ntok))
         return float(sec), int(ntok.value)
 
+    def set_blocklist(self, items):
+        """AnalyzeOption::blocklist of the analyses that follow: items = [(form, tag id or -1)]; returns the morphemes found per item."""
+        self.lib.korc_blocklist_clear.argtypes = [C.c_void_p]
+        self.lib.korc_blocklist_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        self.lib.korc_blocklist_clear(self.h)
+        out = []
+        for form, tag in items:
+            u = np.frombuffer(form.encode("utf-16-le"), np.uint16)
+            out.append(self.lib.korc_blocklist_add(self.h, u.ctypes.data, len(u), tag))
+        return out
+
     def counters(self, reset=False) -> dict:
         arr = np.zeros(len(COUNTER_NAMES), np.uint64)
         self.lib.korc_counters(self.h, arr.ctypes.data, int(reset))

@@ -280,6 +280,7 @@ struct RefHandle
 	kamd::Container file;
 	kamd::RawModel raw;
 	kiwi::Kiwi kw;
+	std::unordered_set<const kiwi::Morpheme*> blocklist;      // AnalyzeOption::blocklist of the following analyses (kref_blocklist_*)
 };
 
 namespace
@@ -531,6 +532,21 @@ extern "C"
 
 	// Kiwi::analyze (src/Kiwi.cpp:1014-1158) on one text.  Returns bytes needed.
 	size_t kref_analyze_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap);
+	// the blocklist of the following kref_analyze* calls, filled the way kiwi_morphset_add does it (src/capi/kiwi_c.cpp:1779-1794): the reference's own
+	// Kiwi::findMorphemes(form, tag) -> set of Morpheme pointers
+	void kref_blocklist_clear(void* hp) { ((RefHandle*)hp)->blocklist.clear(); }
+	int kref_blocklist_add(void* hp, const uint16_t* form, uint32_t len, int tag)
+	{
+		auto& h = *(RefHandle*)hp;
+		try
+		{
+			auto found = h.kw.findMorphemes(std::u16string{ (const char16_t*)form, (const char16_t*)form + len }, tag < 0 ? kiwi::POSTag::unknown : (kiwi::POSTag)tag);
+			h.blocklist.insert(found.begin(), found.end());
+			return (int)found.size();
+		}
+		catch (const std::exception& e) { fprintf(stderr, "kref_blocklist_add: %s\n", e.what()); return -1; }
+	}
+
 	size_t kref_analyze(void* hp, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
 	{
 		return kref_analyze_typo(hp, nullptr, 2.5f, 0, text, len, topN, match, openEnding, out, cap);
@@ -544,6 +560,7 @@ extern "C"
 			kiwi::AnalyzeOption opt{ (kiwi::Match)match };
 			opt.openEnding = !!openEnding;
 			if (typoHp) { opt.typoTransformer = ((TypoHandle*)typoHp)->ptt.get(); opt.typoThreshold = typoThreshold; opt.allowedDialects = (kiwi::Dialect)allowedDialect; }
+			if (!((RefHandle*)hp)->blocklist.empty()) opt.blocklist = &((RefHandle*)hp)->blocklist;
 			auto res = kw.analyze(std::u16string{ (const char16_t*)text, (const char16_t*)text + len }, topN, opt);
 			writeResults(w, res, kw);
 		}

@@ -132,6 +132,18 @@ class RefKiwi:
             self.lib.kref_close(self.h)
             self.h = None
 
+    def set_blocklist(self, items):
+        """AnalyzeOption::blocklist of the analyses that follow: items = [(form, tag id or -1)], added like kiwi_morphset_add does
+        (Kiwi::findMorphemes); returns the number of morphemes found per item.  [] clears it."""
+        self.lib.kref_blocklist_clear.argtypes = [C.c_void_p]
+        self.lib.kref_blocklist_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+        self.lib.kref_blocklist_clear(self.h)
+        out = []
+        for form, tag in items:
+            u = np.frombuffer(form.encode("utf-16-le"), np.uint16)
+            out.append(self.lib.kref_blocklist_add(self.h, u.ctypes.data, len(u), tag))
+        return out
+
     def _call(self, fn, *args):
         while True:
             need = fn(*args, self._buf.ctypes.data, self._buf.nbytes)

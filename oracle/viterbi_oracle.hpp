@@ -35,6 +35,8 @@ namespace korc
 		// container selection by number of incoming paths and the per-bucket key cap (BestPathContainer.hpp:275-277, 363-367);
 		// tests shrink them to drive the medium / large containers on small lattices
 		uint32_t smallMax = 128, mediumMax = 512, bucketCap = 128;
+		// AnalyzeOption::blocklist as one bit per morpheme id, Morpheme::hasMorpheme already applied (flat_model.hpp blockBitsOf); null = none
+		const uint32_t* blockBits = nullptr;
 		// `faithfulOrder`: the large top-1 container and the top-N container are the reference's own -- std::unordered_set / std::unordered_map
 		// + std heap algorithms of this libstdc++, PERSISTENT across calls like the reference's thread_local ones -- so that the order in
 		// which kept paths are handed on is the reference's as long as both sides analyse the same texts in the same sequence from a
@@ -810,6 +812,14 @@ namespace korc
 
 		void evaluate(uint32_t nodeIdx, uint16_t ownFormId, const uint32_t* cands, uint32_t nCands, float unkDiscount)
 		{
+			// `if (blocklist && curMorph->hasMorpheme(*blocklist)) continue;` is the first statement of both candidate loops
+			// (src/PathEvaluator.hpp:385, 892): a blocked candidate is not a candidate
+			std::vector<uint32_t> kept;
+			if (cfg.blockBits)
+			{
+				for (uint32_t k = 0; k < nCands; ++k) if (!((cfg.blockBits[cands[k] >> 5] >> (cands[k] & 31)) & 1)) kept.push_back(cands[k]);
+				cands = kept.data(); nCands = (uint32_t)kept.size();
+			}
 			const LNode* node = graph + nodeIdx;
 			auto& nCache = cache[nodeIdx];
 			float wsDiscount = 0;

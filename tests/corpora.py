@@ -90,3 +90,16 @@ def fuzzed(sm, n, seed):
                 parts.append(" ")
         out.append("".join(parts))
     return out
+
+
+def pick_blocklist(analyzer, texts, k, any_tag_every=4):
+    """A blocklist for `texts`: the k dictionary morphemes that occur most often in their (unconstrained) analyses by `analyzer`, as
+    [(form, tag id or -1)] for kiwi_morphset_add -- every `any_tag_every`-th item without a tag (= every morpheme of that form)."""
+    from collections import Counter
+    cnt = Counter()
+    for t in texts:
+        for tok in analyzer.analyze(t)[0][0]:
+            if tok.morph_id and 1 <= (tok.tag & 0x7F) <= 20 or 39 <= (tok.tag & 0x7F) <= 52:      # content words, particles, endings
+                cnt[(tok.form, tok.tag & 0x7F)] += 1
+    items = [it for it, _ in sorted(cnt.items(), key=lambda kv: (-kv[1], kv[0]))[:k]]
+    return [(f, -1 if i % any_tag_every == any_tag_every - 1 else t) for i, (f, t) in enumerate(items)]

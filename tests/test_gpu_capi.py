@@ -240,8 +240,8 @@ def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
     assert not capi.kiwi_analyze(kiwi, s.encode(), 9, opt(), None)          # top_n beyond the device limit: refused, not ignored
     assert capi.kiwi_error()
     o = opt()
-    o.blocklist = 1
-    assert not capi.kiwi_analyze(kiwi, s.encode(), 1, o, None)               # blocklists are a later row
+    o.allowed_dialects = 2
+    assert not capi.kiwi_analyze(kiwi, s.encode(), 1, o, None) and b"dialect" in capi.kiwi_error()      # dialect masks are a later row
 
 
 @pytest.mark.parametrize("header", ["kiwi_capi.h", "reference capi.h"])
@@ -369,3 +369,71 @@ def test_typo_transformer_through_the_c_api(capi, kiwi, small_model):
                 L.kiwi_res_close(r)
             assert corrected > 5, name
             L.kiwi_prepared_typo_close(prepared)
+
+
+def test_blocklist_through_the_c_api(capi, kiwi, oracle, small_model):
+    """kiwi_new_morphset / kiwi_morphset_add / _add_w / _close and kiwi_analyze* with option.blocklist, as a client of the reference calls them
+    (capi.h:655-664, 1243-1263), against the oracle with the same list (pinned to the real reference on the CPU): tokens, positions, scores."""
+    from corpora import pick_blocklist
+    sm, path = small_model
+    L = capi
+    L.kiwi_new_morphset.restype = C.c_void_p
+    L.kiwi_new_morphset.argtypes = [C.c_void_p]
+    L.kiwi_morphset_add.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.kiwi_morphset_add_w.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+    L.kiwi_morphset_close.argtypes = [C.c_void_p]
+    texts = synthetic(sm, 120, 941, min_jamo=5, max_jamo=100)
+    items = pick_blocklist(oracle, texts, 16)
+    ms = L.kiwi_new_morphset(kiwi)
+    assert ms
+    try:
+        want_found = oracle.set_blocklist(items)
+        for n, ((form, tag), wf) in enumerate(zip(items, want_found)):
+            tag_s = None if tag < 0 else L.kiwi_tag_to_string(kiwi, tag)
+            if n % 2:
+                u = np.frombuffer((form + "\0").encode("utf-16-le"), np.uint16).copy()
+                got = L.kiwi_morphset_add_w(ms, u.ctypes.data, tag_s)
+            else:
+                got = L.kiwi_morphset_add(ms, form.encode("utf-8"), tag_s.lower() if tag_s else None)      # (tags are case-insensitive)
+            assert got == wf, (form, tag)
+        assert L.kiwi_morphset_add(ms, "없는형태".encode("utf-8"), b"NNG") == 0
+        assert L.kiwi_morphset_add(ms, texts[0][:1].encode("utf-8"), b"NOTATAG") < 0 and b"Unknown POSTag" in L.kiwi_error()
+        o = Option(MATCH_ALL_WITH_NORMALIZING, ms, 0, 0, 0.0, None, 0.0)
+        changed = 0
+        for t in texts:
+            r = L.kiwi_analyze(kiwi, t.encode("utf-8"), 2, o, None)
+            assert r, L.kiwi_error()
+            assert read_result(L, kiwi, r) == from_oracle(oracle.analyze(t, top_n=2)), t
+            L.kiwi_res_close(r)
+        # through the batch driver as well, and unconstrained again without the option
+        got = {}
+        enc = [t.encode("utf-8") for t in texts]
+
+        def reader(idx, buf, ud):
+            if idx >= len(enc):
+                return 0
+            if not buf:
+                return len(enc[idx])
+            C.memmove(buf, enc[idx], len(enc[idx]))
+            return 0
+
+        def receiver(idx, res, ud):
+            got[idx] = read_result(L, kiwi, res)
+            L.kiwi_res_close(res)
+            return 0
+
+        rd, rc = READER(reader), RECEIVER(receiver)
+        assert L.kiwi_analyze_m(kiwi, rd, rc, None, 1, o) == len(texts)
+        for i, t in enumerate(texts):
+            assert got[i] == from_oracle(oracle.analyze(t)), t
+        oracle.set_blocklist([])
+        for t in texts[:40]:
+            r = L.kiwi_analyze(kiwi, t.encode("utf-8"), 1, opt(), None)
+            res = read_result(L, kiwi, r)
+            L.kiwi_res_close(r)
+            assert res == from_oracle(oracle.analyze(t)), t
+            changed += res != got[texts.index(t)]
+        assert changed >= 10
+    finally:
+        oracle.set_blocklist([])
+        assert L.kiwi_morphset_close(ms) == 0

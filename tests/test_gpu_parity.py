@@ -226,3 +226,27 @@ def test_top_n_bit_exact_vs_oracle(engine, oracle, small_model, top_n):
 def test_top_n_beyond_the_device_limit_is_refused_loudly(engine):
     with pytest.raises(RuntimeError):
         engine.analyze_batch(["가나다"], top_n=5)
+
+
+@pytest.mark.parametrize("model", ["knlm", "cong"])
+def test_blocklist_bit_exact_vs_oracle(small_model, small_cong_model, model):
+    """AnalyzeOption::blocklist (kamd_morphset_* + kamd_analyze_batch_opt): blocked candidates dropped by k_expand_cands -- device vs the oracle,
+    whose blocklist path equals the real reference's (tests/test_oracle_vs_ref.py::test_blocklist_matches_reference)."""
+    import oraclelib
+    from corpora import pick_blocklist
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model if model == "knlm" else small_cong_model
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path)
+    texts = synthetic(sm, 600, 951, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 300, 952) + EDGE_TEXTS
+    items = pick_blocklist(orc, texts[:300], 32)
+    ms, found = dev.morphset(items)
+    assert found == orc.set_blocklist(items)
+    for top_n in (1, 2):
+        got = dev.analyze_batch_opt(texts, top_n=top_n, blocklist=ms).to_python()
+        for s, y in zip(texts, got):
+            assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (model, top_n, s)
+    orc.set_blocklist([])
+    plain = dev.analyze_batch(texts).to_python()
+    assert sum(_norm(orc.analyze(s)) != _norm(y) for s, y in zip(texts[:50], plain[:50])) == 0
+    ms.close(); dev.close()

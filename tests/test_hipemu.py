@@ -398,3 +398,31 @@ def test_emulated_cong_fallback_paths_with_small_capacities(emu_libs, small_cong
     for s, y in zip(texts, got):
         assert _norm(orc.analyze(s)) == _norm(y), s
     dev.close()
+
+
+@pytest.mark.parametrize("model,top_n", [("knlm", 1), ("knlm", 2), ("cong", 1), ("sbg", 1)])
+def test_emulated_blocklist_matches_oracle(emu_libs, small_model, small_cong_model, small_sbg_model, model, top_n):
+    """AnalyzeOption::blocklist on the (emulated) device -- kamd_morphset_add = Kiwi::findMorphemes, one bit per morpheme with Morpheme::hasMorpheme
+    folded in, k_expand_cands dropping blocked candidates from a node's list (also in the transposed CoNgram order) -- against the oracle,
+    whose blocklist path is pinned to the real reference (tests/test_oracle_vs_ref.py::test_blocklist_matches_reference)."""
+    import oraclelib
+    from corpora import pick_blocklist
+    from kiwi_amd.api import KiwiAmd
+    sm, path = {"knlm": small_model, "cong": small_cong_model, "sbg": small_sbg_model}[model]
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    texts = synthetic(sm, 60, 931, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 30, 932) + EDGE_TEXTS[:20]
+    items = pick_blocklist(orc, texts, 20) + [("없는형태", 1)]
+    ms, found = dev.morphset(items)
+    assert found == orc.set_blocklist(items) and found[-1] == 0
+    got = dev.analyze_batch_opt(texts, top_n=top_n, blocklist=ms).to_python()
+    changed = 0
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (model, top_n, s)
+    plain = dev.analyze_batch(texts, top_n=top_n).to_python()      # the list is per call: the next call without it is unconstrained again
+    orc.set_blocklist([])
+    for s, y, z in zip(texts, plain, got):
+        assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), s
+        changed += _norm(y) != _norm(z)
+    assert changed >= 20
+    ms.close(); dev.close()

@@ -200,3 +200,26 @@ def test_top_n_reference_faithful_order_is_exact(small_model, top_n):
     if not refbridge.available():
         pytest.skip("oracle/_ref not built")
     _faithful("small", top_n)
+
+
+def test_blocklist_matches_reference(oracle, reference, small_model):
+    """AnalyzeOption::blocklist: Kiwi::findMorphemes + Morpheme::hasMorpheme + the `continue` of the candidate loops (src/Kiwi.cpp:1281-1297,
+    include/kiwi/Form.h:187-196, src/PathEvaluator.hpp:385) -- the oracle's restatement against the real reference: the same morphemes found per
+    item, the same analyses (tokens, positions, fp32 scores) with the list in force, and different ones than without it."""
+    from corpora import pick_blocklist
+    sm, _ = small_model
+    texts = synthetic(sm, 400, 911, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 150, 912)
+    items = pick_blocklist(oracle, texts, 24) + [("없는형태", 1), ("", -1)]
+    try:
+        found_o, found_r = oracle.set_blocklist(items), reference.set_blocklist(items)
+        assert found_o == found_r and sum(found_o) >= 24 and found_o[-2:] == [0, 0]
+        changed = 0
+        for t in texts:
+            assert oracle.analyze(t) == reference.analyze(t), t
+        oracle.set_blocklist([]); reference.set_blocklist([])
+        for t in texts[:100]:
+            oracle.set_blocklist([]); a0 = oracle.analyze(t)
+            oracle.set_blocklist(items); changed += a0 != oracle.analyze(t)
+        assert changed >= 50
+    finally:
+        oracle.set_blocklist([]); reference.set_blocklist([])
