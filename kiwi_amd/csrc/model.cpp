@@ -434,7 +434,7 @@ namespace kamd
 			std::vector<uint32_t> meta, formPtr, formCandPtr, formCand, chunkIds;
 			std::vector<uint16_t> formChars;
 			std::vector<RawMorph> morph;
-			std::vector<uint8_t> chunkPos, knlm, sbg;
+			std::vector<uint8_t> chunkPos, knlm, sbg, cong;
 		};
 
 		std::vector<uint8_t> readFile(const std::string& path, bool required)
@@ -500,15 +500,30 @@ namespace kamd
 			if (o.chunkIds.empty()) { o.chunkIds.push_back(0); o.chunkPos.assign(2, 0); }
 			if (o.formChars.empty()) o.formChars.push_back(0);
 			if (o.formCand.empty()) o.formCand.push_back(0);
-			o.knlm = readFile(dir + "/sj.knlm", true);
-			o.sbg = readFile(dir + "/skipbigram.mdl", false);
-			if (o.knlm.size() < sizeof(KnlmHeader)) throw std::runtime_error{ "sj.knlm: truncated header" };
-			KnlmHeader hd; std::memcpy(&hd, o.knlm.data(), sizeof(hd));
-			o.meta = { nForms, nMorphs, (uint32_t)hd.vocab_size, 0 };      // the language model's vocabulary size is the reference's langVocabSize
+			// language model files (KiwiBuilder.cpp:939-1031): cong.mdl alone is a complete model (models/cong/base ships no sj.knlm); else sj.knlm,
+			// optionally with skipbigram.mdl
+			o.cong = readFile(dir + "/cong.mdl", false);
+			o.knlm = readFile(dir + "/sj.knlm", o.cong.empty());
+			o.sbg = o.knlm.empty() ? std::vector<uint8_t>{} : readFile(dir + "/skipbigram.mdl", false);
+			uint32_t vocab = 0;
+			if (!o.knlm.empty())
+			{
+				if (o.knlm.size() < sizeof(KnlmHeader)) throw std::runtime_error{ "sj.knlm: truncated header" };
+				KnlmHeader hd; std::memcpy(&hd, o.knlm.data(), sizeof(hd));
+				vocab = (uint32_t)hd.vocab_size;      // the language model's vocabulary size is the reference's langVocabSize
+			}
+			else
+			{
+				if (o.cong.size() < 8) throw std::runtime_error{ "cong.mdl: truncated header" };
+				uint64_t v; std::memcpy(&v, o.cong.data(), 8); vocab = (uint32_t)v;      // CoNgramModelHeader::vocabSize
+			}
+			o.meta = { nForms, nMorphs, vocab, 0 };
 			raw.meta = o.meta.data(); raw.formPtr = o.formPtr.data(); raw.formChars = o.formChars.data(); raw.formCandPtr = o.formCandPtr.data(); raw.formCand = o.formCand.data();
 			raw.morph = o.morph.data(); raw.chunkIds = o.chunkIds.data(); raw.chunkPos = o.chunkPos.data();
 			raw.knlm = o.knlm.data(); raw.knlmSize = o.knlm.size();
+			raw.knlm = o.knlm.empty() ? nullptr : o.knlm.data();
 			raw.sbg = o.sbg.empty() ? nullptr : o.sbg.data(); raw.sbgSize = o.sbg.size();
+			raw.cong = o.cong.empty() ? nullptr : o.cong.data(); raw.congSize = o.cong.size();
 		}
 	}
 
@@ -846,7 +861,8 @@ namespace kamd
 		m.h.nTrieNodes = (uint32_t)nT; m.h.nTrieEdges = (uint32_t)m.trieKeys.size();
 		m.h.maxFormLen = maxLen;
 		if (maxLen > 64) throw std::runtime_error{ "dictionary form longer than 64 units: the trie-scan kernel's depth mask is 64 bits" };
-		loadKnlm(m, raw.knlm, raw.knlmSize);
+		if (raw.knlm) loadKnlm(m, raw.knlm, raw.knlmSize);
+		else if (!raw.cong) throw std::runtime_error{ "Cannot find any valid model files" };      // KiwiBuilder.cpp:984-990
 		if (raw.cong) loadCong(m, raw.cong, raw.congSize);
 		if (raw.sbg)
 		{
@@ -871,7 +887,7 @@ namespace kamd
 			if ((size_t)(p - raw.sbg) > raw.sbgSize) throw std::runtime_error{ "raw model: truncated SkipBigram blob" };
 			m.sbgWindow = window;
 		}
-		if (vocab > m.lmRoot.size()) throw std::runtime_error{ "raw model: vocab larger than LM vocab" };
+		if (raw.knlm && vocab > m.lmRoot.size()) throw std::runtime_error{ "raw model: vocab larger than LM vocab" };
 	}
 
 	std::vector<uint32_t> findMorphemes(const FlatModel& m, const char16_t* s, size_t n, uint8_t tag)

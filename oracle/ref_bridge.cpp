@@ -351,13 +351,14 @@ extern "C"
 			{ std::ofstream os{ d + "/sj.morph", std::ios::binary }; Acc::writeMorph(os, forms, morphemes); if (!os) return -2; }
 			{ std::ofstream os{ d + "/sj.knlm", std::ios::binary }; os.write((const char*)raw.knlm, (std::streamsize)raw.knlmSize); if (!os) return -2; }
 			if (raw.sbg) { std::ofstream os{ d + "/skipbigram.mdl", std::ios::binary }; os.write((const char*)raw.sbg, (std::streamsize)raw.sbgSize); if (!os) return -2; }
+			if (raw.cong) { std::ofstream os{ d + "/cong.mdl", std::ios::binary }; os.write((const char*)raw.cong, (std::streamsize)raw.congSize); if (!os) return -2; }
 			return 0;
 		}
 		catch (const std::exception& e) { fprintf(stderr, "kref_write_model_dir: %s\n", e.what()); return -1; }
 	}
 
 	// The reference loading those files: sj.morph through its serializer, the language model through KnLangModelBase / SkipBigramModelBase::create;
-	// useSbg: skipbigram.mdl as well (ModelType::sbg), else Knlm only (the reference's default when both files exist, KiwiBuilder.cpp:939-961)
+	// useSbg: 1 = skipbigram.mdl as well (ModelType::sbg), 2 = cong.mdl (ModelType::cong), else Knlm only (KiwiBuilder.cpp:939-961)
 	void* kref_open_dir(const char* dir, int arch, int useSbg)
 	{
 		try
@@ -366,10 +367,16 @@ extern "C"
 			auto slurp = [](const std::string& p) { std::ifstream is{ p, std::ios::binary }; if (!is) throw std::runtime_error{ "cannot open " + p }; return std::vector<uint8_t>{ std::istreambuf_iterator<char>{ is }, std::istreambuf_iterator<char>{} }; };
 			kiwi::Vector<kiwi::FormRaw> forms; kiwi::Vector<kiwi::MorphemeRaw> morphemes;
 			{ std::ifstream is{ d + "/sj.morph", std::ios::binary }; if (!is) throw std::runtime_error{ "cannot open sj.morph" }; Acc::readMorph(is, forms, morphemes); }
+			auto h = std::make_unique<RefHandle>();
+			if (useSbg == 2)      // ModelType::cong: cong.mdl alone (KiwiBuilder.cpp:1018-1031); the quantised path needs a SIMD architecture
+			{
+				const auto cong = slurp(d + "/cong.mdl");
+				h->kw = Acc::build(forms, morphemes, cong.data(), cong.size(), nullptr, 0, toArch(arch), true);
+				return h.release();
+			}
 			const auto knlm = slurp(d + "/sj.knlm");
 			std::vector<uint8_t> sbg;
 			if (useSbg) sbg = slurp(d + "/skipbigram.mdl");
-			auto h = std::make_unique<RefHandle>();
 			h->kw = Acc::build(forms, morphemes, knlm.data(), knlm.size(), sbg.empty() ? nullptr : sbg.data(), sbg.size(), toArch(arch));
 			return h.release();
 		}

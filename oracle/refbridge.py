@@ -96,7 +96,7 @@ def write_model_dir(raw_model_path: str, out_dir: str):
 
 class RefKiwi:
     def __init__(self, raw_model_path: str, arch: int = 0, model_dir_sbg=None, x86=False):
-        """raw_model_path: a raw container; or, with model_dir_sbg = False / True, a DIRECTORY holding the reference's own model files,
+        """raw_model_path: a raw container; or, with model_dir_sbg = False / True / 2 (= cong.mdl, CoNgram), a DIRECTORY holding the reference's own model files,
         loaded through the reference's serializer (Knlm only / with skipbigram.mdl).
         x86: the library built with every SIMD architecture and src/CoNgramModel.cpp (oracle/Makefile refx86): a container with a CoNgram blob is
         analysed with it; arch 3 = sse4_1, 4 = avx2, 5 = avx512bw, 6 = avx512vnni (the quantised CoNgram path exists for those only)."""

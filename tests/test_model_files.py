@@ -81,16 +81,56 @@ def test_directory_loader_equals_container_and_reference(small_model, small_sbg_
     a.close(); b.close()
 
 
-@pytest.mark.gpu
-def test_kiwi_init_on_a_model_directory(small_model):
-    """kiwi_init(directory with sj.morph + sj.knlm) on the device, against the reference loading the same files."""
+def _cong_dir(raw_path):
+    """A directory like the reference's models/cong/base: sj.morph + cong.mdl and NO sj.knlm."""
+    import shutil
+    d = _model_dir(raw_path, "small-cong-src")
+    out = os.path.join(ROOT, "_data", "small-cong.files")
+    if os.path.exists(os.path.join(d, "cong.mdl")):
+        os.makedirs(out, exist_ok=True)
+        for f in ("sj.morph", "cong.mdl"):
+            shutil.copyfile(os.path.join(d, f), os.path.join(out, f))
+    if not os.path.exists(os.path.join(out, "cong.mdl")):
+        pytest.skip("no model files (oracle/_ref not built)")
+    return out
+
+
+def test_cong_directory_loader_equals_container_and_reference(small_cong_model):
+    """kamd_open(directory with sj.morph + cong.mdl, no sj.knlm -- the layout of the reference's models/cong/base): same baked dictionary as the
+    container, CoNgram scoring selected, analyses equal the reference's SSE4.1 build loading the same two files (KiwiBuilder.cpp:939-1031)."""
     import refbridge
-    if not refbridge.available():
+    if not refbridge.x86_available():
+        pytest.skip("oracle/_ref/libkiwi_ref_x86.so not built")
+    from kiwi_amd.api import KiwiAmd
+    emu = os.path.join(HERE, "hipemu", "_build", "libkiwi_hipemu.so")
+    if not os.path.exists(emu):
+        pytest.skip("emulated library not built")
+    sm, path = small_cong_model
+    d = _cong_dir(path)
+    assert sorted(os.listdir(d)) == ["cong.mdl", "sj.morph"]
+    a, b = KiwiAmd(path, lib_path=emu), KiwiAmd(d, lib_path=emu)
+    assert a.dump_dict() == b.dump_dict()
+    ref = refbridge.RefKiwi(d, arch=3, model_dir_sbg=2, x86=True)
+    texts = synthetic(sm, 40, 721, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 20, 722)
+    got = b.analyze_batch(texts).to_python()
+    want = a.analyze_batch(texts).to_python()
+    for s, y, w in zip(texts, got, want):
+        assert _norm(ref.analyze(s)) == _norm(y) == _norm(w), s
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["knlm", "cong"])
+def test_kiwi_init_on_a_model_directory(small_model, small_cong_model, kind):
+    """kiwi_init(directory with sj.morph + sj.knlm, or with sj.morph + cong.mdl like the reference's models/cong/base) on the device, against
+    the reference loading the same files."""
+    import refbridge
+    if not refbridge.available() or (kind == "cong" and not refbridge.x86_available()):
         pytest.skip("oracle/_ref not built")
     import ctypes as C
     from test_gpu_capi import LIB, Option, MATCH_ALL_WITH_NORMALIZING
-    sm, path = small_model
-    d = _model_dir(path, "small")
+    sm, path = small_model if kind == "knlm" else small_cong_model
+    d = _model_dir(path, "small") if kind == "knlm" else _cong_dir(path)
     L = C.CDLL(LIB)
     L.kiwi_init.restype = C.c_void_p
     L.kiwi_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
@@ -106,7 +146,7 @@ def test_kiwi_init_on_a_model_directory(small_model):
     L.kiwi_error.restype = C.c_char_p
     k = L.kiwi_init(d.encode(), 0, 15, 0)
     assert k, L.kiwi_error()
-    ref = refbridge.RefKiwi(d, model_dir_sbg=False)
+    ref = refbridge.RefKiwi(d, model_dir_sbg=False) if kind == "knlm" else refbridge.RefKiwi(d, arch=3, model_dir_sbg=2, x86=True)
     opt = Option(MATCH_ALL_WITH_NORMALIZING, None, 0, 0, 3.0, None, 2.5)
     for s in synthetic(sm, 60, 713, min_jamo=5, max_jamo=80):
         r = L.kiwi_analyze(k, s.encode("utf-8"), 1, opt, None)
