@@ -11,7 +11,8 @@
  *     container has one, CONG; local scoring), Knlm (default otherwise, KNLM) or SkipBigram (LARGEST when the container has the tables, SBG)
  *     and refuse CONG_GLOBAL; the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).
  *   - option.blocklist (morpheme sets: kiwi_new_morphset / kiwi_morphset_add / _add_w / _close) is honoured;
- *     top_n > 4, pretokenized spans and non-standard dialects are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
+ *     option.allowed_dialects / dialect_cost are accepted: they only concern dialect morphemes, which no model loaded here has (kiwi_init
+ *     refuses enabled_dialects != 0); top_n > 4 and pretokenized spans are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
  *     being silently ignored.
  */
 #ifndef KIWI_CAPI_SUBSET_H

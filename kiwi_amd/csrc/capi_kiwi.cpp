@@ -121,7 +121,9 @@ namespace
 
 	void checkOption(const kiwi_analyze_option_t& o, kiwi_pretokenized_h pt)
 	{
-		if (o.allowed_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported on the device path yet" };
+		// allowed_dialects / dialect_cost: the candidate loops skip a morpheme whose dialect is neither standard nor allowed and charge dialect_cost for an
+		// allowed one (src/PathEvaluator.hpp:231, 386, 893).  Every model this library loads holds standard-dialect morphemes only (kiwi_init refuses
+		// enabled_dialects != 0, the bake refuses dialect morphemes), so both options are accepted and -- exactly as in the reference -- change nothing.
 		if (pt) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
 		if ((uint32_t)o.match_options & (3u << 8)) throw std::invalid_argument{ "`oovChrModel` option is set but the character-level noun model is not loaded." };
 		if ((uint32_t)o.match_options & (1u << 30)) throw std::invalid_argument{ "kiwi_amd: useOldSplitter is not supported" };

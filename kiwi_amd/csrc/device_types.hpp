@@ -94,7 +94,7 @@ namespace kamd
 		uint32_t smallMax, mediumMax, bucketCap;   // container selection by incoming paths (128, 512) and per-bucket key cap (128): BestPathContainer.hpp:275-277
 		uint32_t topN;                 // paths kept per (candidate, key): 1..kMaxTopN (BestPathContainer.hpp:151-222 for N > 1)
 	};
-	constexpr uint32_t kMaxTopN = 4;
+	constexpr uint32_t kMaxTopN = 16;
 
 	struct BatchView
 	{

@@ -287,7 +287,7 @@ namespace kamd
 			if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) { impl->groupLanes = v; impl->groupLanesForced = true; }
 			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16, 32 or 64" };
 		}
-		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3 || v == 4) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2, 3 or 4" }; }
+		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2 or 3" }; }
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
 		impl->counter.ensure(256);
 	}
@@ -590,7 +590,7 @@ namespace kamd
 			: 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
 		// (the SkipBigram kernel is built for 2 waves per SIMD and carries 1.8 MB of item scratch per lane group: 8 persistent blocks per CU)
-		const uint32_t persistBlocks = I.hasSbg ? I.persistBlocks / 12 * 8 : I.wpsForced == 4 ? I.persistBlocks / 3 * 4 : I.persistBlocks;      // (I.persistBlocks: 3 waves per SIMD)
+		const uint32_t persistBlocks = I.hasSbg ? I.persistBlocks / 12 * 8 : I.persistBlocks;
 		const uint32_t maxBlocks = std::min(persistBlocks, (maxWork + nGroups - 1) / nGroups);
 		const size_t groupScratchBytes = I.hasSbg ? sizeof(GroupScratchT<BIGQ_SBG>) : I.hasCong ? sizeof(GroupScratchCong<BIGQ>) : sizeof(GroupScratch);
 		I.bigScratch.ensure((size_t)maxBlocks * nGroups * groupScratchBytes * std::min(S, 2u));
@@ -706,8 +706,6 @@ namespace kamd
 				if (gl == 64) hipLaunchKernelGGL((typok::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, nodeTypo);
 				else hipLaunchKernelGGL((typok::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, nodeTypo);
 			}
-			else if (wps == 4 && gl == 8) KAMD_LAUNCH(8, 4);
-			else if (wps == 4 && gl == 16) KAMD_LAUNCH(16, 4);
 			else if (wps == 3 && gl == 8) KAMD_LAUNCH(8, 3);
 			else if (wps == 3 && gl == 16) KAMD_LAUNCH(16, 3);
 			else switch (gl)

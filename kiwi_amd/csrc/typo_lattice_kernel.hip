@@ -22,6 +22,8 @@ namespace kamd
 		constexpr uint32_t NPOS = 0xFFFFFFFFu;
 		constexpr uint32_t MAXCAND = kTypoMaxCand;
 
+		// Every method is force-inlined: a context that is passed to a real call lives in scratch memory (every member access a scratch load) and its
+		// LDS pointers degrade to flat accesses; inlined, it stays in registers and the LDS arrays are addressed with ds_read / ds_write.
 		// LDS = false: every working array in HBM (thread per chunk).  LDS = true: the wave-per-chunk kernel -- text, index maps, node list
 		// (TypoLdsNode), end-position index (first | (last + 1) << 16 per multiplied position) in LDS; hasFormAlready and the z-coda / z-siot
 		// look-ups answered from per-end-position summaries (fullMask: lengths of the qualifying nodes ending there, zAt: their form flags)
@@ -40,7 +42,7 @@ namespace kamd
 			bool overflow;
 
 			// fp: the form's record when the caller holds it (null: read here if needed)
-			__device__ bool append(uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, float typoCost = 0.f, const FormRec* fp = nullptr)
+			__device__ __forceinline__ bool append(uint32_t s, uint32_t e, uint32_t form, uint32_t uOff, uint32_t uLen, float typoCost = 0.f, const FormRec* fp = nullptr)
 			{
 				if constexpr (LDS)
 				{
@@ -90,15 +92,15 @@ namespace kamd
 					return true;
 				}
 			}
-			__device__ void setLastSpaceErrors(uint32_t se) { if constexpr (LDS) lout[nOut - 1].spaceErrors = (uint8_t)se; else out[nOut - 1].spaceErrors = se; }
-			__device__ uint32_t lastNodeEnd() const { if constexpr (LDS) return lastEnd; else return out[nOut - 1].endPos; }
-			__device__ uint32_t nodeLen(const TypoLatNode& g) const
+			__device__ __forceinline__ void setLastSpaceErrors(uint32_t se) { if constexpr (LDS) lout[nOut - 1].spaceErrors = (uint8_t)se; else out[nOut - 1].spaceErrors = se; }
+			__device__ __forceinline__ uint32_t lastNodeEnd() const { if constexpr (LDS) return lastEnd; else return out[nOut - 1].endPos; }
+			__device__ __forceinline__ uint32_t nodeLen(const TypoLatNode& g) const
 			{
 				if (g.uformLen) return g.uformLen;
 				const FormRec f = M.forms[g.form];
 				return f.len - f.numSpaces;
 			}
-			__device__ bool hasForm(uint32_t ms, uint32_t me) const      // both whole positions, multiplied
+			__device__ __forceinline__ bool hasForm(uint32_t ms, uint32_t me) const      // both whole positions, multiplied
 			{
 				if constexpr (LDS)
 				{
@@ -129,12 +131,12 @@ namespace kamd
 					return false;
 				}
 			}
-			__device__ void trimmed(uint32_t off, uint32_t len, uint32_t& o, uint32_t& l) const
+			__device__ __forceinline__ void trimmed(uint32_t off, uint32_t len, uint32_t& o, uint32_t& l) const
 			{
 				while (len && isSpace(str[off + len - 1])) --len;
 				o = off; l = len;
 			}
-			__device__ void insertUnk(uint32_t s, uint32_t e, bool hasJ)
+			__device__ __forceinline__ void insertUnk(uint32_t s, uint32_t e, bool hasJ)
 			{
 				if (s >= e || hasForm(s << pmb, e << pmb)) return;
 				uint32_t lastPos = lastNodeEnd();      // (a multiplied position against plain ones: as in the reference)
@@ -154,12 +156,12 @@ namespace kamd
 					append(s << pmb, e << pmb, NOFORM, o, l);
 				}
 			}
-			__device__ void unkPair(uint32_t boundary, uint32_t unkStart, uint32_t e, bool hasJ)
+			__device__ __forceinline__ void unkPair(uint32_t boundary, uint32_t unkStart, uint32_t e, bool hasJ)
 			{
 				if (boundary < unkStart) insertUnk(boundary, e, hasJ);
 				insertUnk(unkStart, e, hasJ);
 			}
-			__device__ uint32_t spaceErrors(const FormRec& f, uint32_t b, uint32_t e) const
+			__device__ __forceinline__ uint32_t spaceErrors(const FormRec& f, uint32_t b, uint32_t e) const
 			{
 				uint32_t nErr = 0, off = 0;
 				if (!f.numSpaces)      // a form without spaces: every gap inside the span is an error; the form's characters are not needed
@@ -177,7 +179,7 @@ namespace kamd
 				}
 				return nErr;
 			}
-			__device__ int32_t trieNext(uint32_t node, uint16_t c) const
+			__device__ __forceinline__ int32_t trieNext(uint32_t node, uint16_t c) const
 			{
 				if (node == 0) { const uint32_t r = M.trieRoot[c]; return r ? (int32_t)r : -1; }
 				const TrieNodeRec t = M.trie[node];
@@ -187,13 +189,13 @@ namespace kamd
 				if (lo == t.numNexts || kb[lo] != c) return -1;
 				return (int32_t)M.trieChild[t.edgeOff + lo];
 			}
-			__device__ uint16_t formChar(const TypoGraphNode& g, uint32_t j) const
+			__device__ __forceinline__ uint16_t formChar(const TypoGraphNode& g, uint32_t j) const
 			{
 				return (g.formOff & TYPO_FORM_IN_POOL) ? V.pool[(g.formOff & ~TYPO_FORM_IN_POOL) + j] : str[g.formOff + j];
 			}
 
 			// candidates: form id in the low 24 bits, syllables skipped as lengthening in the high 8
-			__device__ void flush(uint32_t* cands, uint32_t& nCands, uint32_t endNs, int32_t startPosOffset, uint32_t unkStart, uint32_t boundary, float typoCost, uint32_t startCti, uint32_t endCti)
+			__device__ __forceinline__ void flush(uint32_t* cands, uint32_t& nCands, uint32_t endNs, int32_t startPosOffset, uint32_t unkStart, uint32_t boundary, float typoCost, uint32_t startCti, uint32_t endCti)
 			{
 				for (uint32_t k = 0; k < nCands; ++k)
 				{
@@ -218,7 +220,7 @@ namespace kamd
 			}
 
 			// progressNode: state `st` of graph node `prevT` continued through graph node `tn`; new states go to cur[0..nCur)
-			__device__ void progress(const TypoGraphNode& prevT, const TypoGraphNode& tn, uint32_t tnIdx, const TypoState& stRef, TypoState* cur, uint32_t& nCur, uint32_t curCap)
+			__device__ __forceinline__ void progress(const TypoGraphNode& prevT, const TypoGraphNode& tn, uint32_t tnIdx, const TypoState& stRef, TypoState* cur, uint32_t& nCur, uint32_t curCap)
 			{
 				// (the state's fixed part only: its lengthening lists are read entry by entry, nL of them)
 				struct Head { int32_t node; float cost; uint32_t minFormLen; int32_t startPosOffset; uint32_t specialStart, unkStart, boundary; uint8_t lastType, lastScript, hasLast, pad; uint16_t startCti, pad2; uint32_t lastChr, nL; };
@@ -237,7 +239,8 @@ namespace kamd
 				if (fsz) { outType = V.graphLast[2 * tnIdx]; outScript = V.graphLast[2 * tnIdx + 1]; outHas = outType != 0xFF; }
 				int32_t curNode = st.node;
 				const uint8_t scriptVS = 98;
-				uint32_t candsLocal[LDS ? 1 : MAXCAND]; uint32_t* cands = LDS ? candBuf : candsLocal; uint32_t nCands = 0;
+				uint32_t candsLocal[LDS ? 1 : MAXCAND]; uint32_t* cands; uint32_t nCands = 0;
+				if constexpr (LDS) cands = candBuf; else cands = candsLocal;      // (no select between address spaces: the LDS buffer stays an LDS pointer)
 				auto push = [&](uint32_t f) { if (nCands < MAXCAND) cands[nCands++] = f; else overflow = true; };      // (form ids stay below 2^24: checked by the engine)
 				const bool lengthening = V.lengtheningCost < INFINITY;
 				uint32_t prevChr = st.lastChr;
@@ -611,8 +614,7 @@ namespace kamd
 	// the chunk's own data is an LDS access instead of a dependent HBM round trip; search states and the typo graph stay in HBM (read once per
 	// step).  The final reorder and the per-node facts run one node per lane.  A chunk whose node list outgrows its LDS copy is handed to
 	// the thread-per-chunk kernel (TypoLatChunk::status = kTypoLdsNeedsBig).
-	template<int WPS>
-	__global__ void __launch_bounds__(64, WPS) k_build_lattice_typo_lds(ModelView M, TypoLatView V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
+	__global__ void __launch_bounds__(64) k_build_lattice_typo_lds(ModelView M, TypoLatView V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
 	{
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t lane = threadIdx.x;
@@ -846,9 +848,6 @@ namespace kamd
 	}
 	void launchTypoLatticeLds(const ModelView& M, const TypoLatView& V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, hipStream_t stream)
 	{
-		// register budget: 4 waves per SIMD without spills (128 VGPRs), or 5 with a few (KAMD_TYPO_LATTICE_WPS=5; the LDS need of a 40-unit chunk allows 5)
-		static const int wps = std::getenv("KAMD_TYPO_LATTICE_WPS") ? std::atoi(std::getenv("KAMD_TYPO_LATTICE_WPS")) : 4;
-		if (wps >= 5) hipLaunchKernelGGL(k_build_lattice_typo_lds<5>, dim3(chunkCount), dim3(64), ldsBytes, stream, M, V, chunkList, chunkCount, ldsBytes);
-		else hipLaunchKernelGGL(k_build_lattice_typo_lds<4>, dim3(chunkCount), dim3(64), ldsBytes, stream, M, V, chunkList, chunkCount, ldsBytes);
+		hipLaunchKernelGGL(k_build_lattice_typo_lds, dim3(chunkCount), dim3(64), ldsBytes, stream, M, V, chunkList, chunkCount, ldsBytes);
 	}
 }

@@ -1998,7 +1998,5 @@ namespace sbgk
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
-	template __global__ void k_best_path<8, 4>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
-	template __global__ void k_best_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 #endif
 }

@@ -44,7 +44,7 @@ namespace
 	std::vector<TokenResult> analyzeOne(OracleHandle& h, Counters& cnt, PersistentContainers* persistent, const char16_t* text, uint32_t len, uint32_t topN, uint64_t match, bool openEnding,
 		std::vector<std::vector<LNode>>* latticesOut = nullptr, TypoOpt typo = {})
 	{
-		if (topN < 1 || topN > 4) throw std::runtime_error{ "oracle: top_n must be 1..4" };
+		if (topN < 1 || topN > 16) throw std::runtime_error{ "oracle: top_n must be 1..16" };
 		PreparedText pt;
 		prepareText(pt, text, len, match, 0);
 		SplitConfig sc = h.scfg; sc.match = match;

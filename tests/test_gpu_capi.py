@@ -237,11 +237,15 @@ def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
         cfg.cut_off_threshold = 8.0
         capi.kiwi_set_global_config(kiwi, cfg)
         oracle.set_config()
-    assert not capi.kiwi_analyze(kiwi, s.encode(), 9, opt(), None)          # top_n beyond the device limit: refused, not ignored
+    assert not capi.kiwi_analyze(kiwi, s.encode(), 17, opt(), None)         # top_n beyond the device limit (16): refused, not ignored
     assert capi.kiwi_error()
+    # allowed_dialects / dialect_cost only ever concern dialect morphemes; a model built without enabled dialects has none: accepted, no effect
     o = opt()
-    o.allowed_dialects = 2
-    assert not capi.kiwi_analyze(kiwi, s.encode(), 1, o, None) and b"dialect" in capi.kiwi_error()      # dialect masks are a later row
+    o.allowed_dialects, o.dialect_cost = 0x7FFF, 3.0
+    r = capi.kiwi_analyze(kiwi, s.encode(), 1, o, None)
+    assert r and read_result(capi, kiwi, r) == from_oracle(oracle.analyze(s))
+    capi.kiwi_res_close(r)
+    assert not capi.kiwi_init(b"/nonexistent", 0, 15, 1) and capi.kiwi_error()      # enabled dialects at build time: refused (no dialect.dict loader)
 
 
 @pytest.mark.parametrize("header", ["kiwi_capi.h", "reference capi.h"])

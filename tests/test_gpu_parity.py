@@ -212,7 +212,7 @@ def test_empty_and_degenerate_batches(engine):
     assert [len(x[0][0]) for x in r] == [0, 0, 0]
 
 
-@pytest.mark.parametrize("top_n", [2, 3, 4])
+@pytest.mark.parametrize("top_n", [2, 3, 4, 8, 16])
 def test_top_n_bit_exact_vs_oracle(engine, oracle, small_model, top_n):
     """top-N: the N best paths per key, N-th-best pruning, 2N end candidates -- same analyses, order and fp32 scores as the
     oracle (its hand-on order: DESIGN.md, top-N)."""
@@ -225,7 +225,7 @@ def test_top_n_bit_exact_vs_oracle(engine, oracle, small_model, top_n):
 
 def test_top_n_beyond_the_device_limit_is_refused_loudly(engine):
     with pytest.raises(RuntimeError):
-        engine.analyze_batch(["가나다"], top_n=5)
+        engine.analyze_batch(["가나다"], top_n=17)
 
 
 @pytest.mark.parametrize("model", ["knlm", "cong"])

@@ -71,7 +71,7 @@ def test_golden_vectors(oracle):
         assert abs(got[0][1] - item["score"]) == 0, item["text"]
 
 
-@pytest.mark.parametrize("top_n", [2, 3])
+@pytest.mark.parametrize("top_n", [2, 3, 6])
 def test_top_n_matches_reference_up_to_exact_ties(oracle, reference, small_model, top_n):
     """top-N: the reference hands paths on in the bucket order of a thread_local std::unordered_map that is never shrunk
     (BestPathContainer.hpp:151-222), i.e. in an order that depends on what the thread analysed before; the oracle hands them on
@@ -95,7 +95,7 @@ def test_top_n_matches_reference_up_to_exact_ties(oracle, reference, small_model
             exact += 1
         elif shape(x) != shape(y):
             shape_diff += 1
-    assert exact >= 0.6 * len(texts)
+    assert exact >= (0.6 if top_n <= 3 else 0.1) * len(texts)      # (the more analyses are asked for, the more of them sit in exact ties: 13 % identical at N = 6)
     assert shape_diff <= 0.01 * len(texts)
 
 
@@ -190,7 +190,7 @@ def test_skipbigram_analyses_match_reference(small_sbg_model):
     assert bad_large <= max(2, n_large // 20), (bad_large, n_large)
 
 
-@pytest.mark.parametrize("top_n", [2, 3, 4])
+@pytest.mark.parametrize("top_n", [2, 3, 4, 8])
 def test_top_n_reference_faithful_order_is_exact(small_model, top_n):
     """top-N with the oracle in its reference-faithful mode: the reference's own containers (std::unordered_map + std heap
     algorithms, persistent like its thread_local ones), the same texts in the same sequence from a fresh state on both sides --
