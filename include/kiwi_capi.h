@@ -12,7 +12,7 @@
  *     and refuse CONG_GLOBAL; the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).
  *   - option.blocklist (morpheme sets: kiwi_new_morphset / kiwi_morphset_add / _add_w / _close) is honoured;
  *     option.allowed_dialects / dialect_cost are accepted: they only concern dialect morphemes, which no model loaded here has (kiwi_init
- *     refuses enabled_dialects != 0); top_n > 4 and pretokenized spans are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
+ *     refuses enabled_dialects != 0); top_n > 16 and pretokenized spans are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
  *     being silently ignored.
  */
 #ifndef KIWI_CAPI_SUBSET_H

@@ -266,10 +266,16 @@ class KiwiAmd:
             raise self._err("kamd_analyze_batch_opt")
         return Results(self.lib, r)
 
-    def analyze_packed(self, flat, offs, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Results:
+    def analyze_packed(self, flat, offs, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0, typo=None, typo_threshold=2.5) -> Results:
         """The C-ABI call itself on an already packed batch (`pack_texts`): UTF-16 strings resident on the host in, packed token
-        records resident on the host out -- the end-to-end region of SURVEY.md section 8(d)."""
-        r = self.lib.kamd_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(offs) - 1, top_n, match, int(open_ending), host_threads)
+        records resident on the host out -- the end-to-end region of SURVEY.md section 8(d).  typo: a prepared `Typo` (kamd_analyze_batch_opt)."""
+        if typo is None:
+            r = self.lib.kamd_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(offs) - 1, top_n, match, int(open_ending), host_threads)
+        else:
+            L = self.lib
+            L.kamd_analyze_batch_opt.restype = C.c_void_p
+            L.kamd_analyze_batch_opt.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+            r = L.kamd_analyze_batch_opt(self.h, typo.h, typo_threshold, 0, None, flat.ctypes.data, offs.ctypes.data, len(offs) - 1, top_n, match, int(open_ending), host_threads)
         if not r:
             raise self._err("kamd_analyze_batch")
         return Results(self.lib, r)

@@ -441,43 +441,61 @@ namespace kamd
 		{
 			// typo graphs on the host (typo.cpp), one record per chunk for k_build_lattice_typo (engine mode)
 			const PreparedTypo& T = *b.typo.typo;
-			std::vector<TypoLatChunk> tch(nC); std::vector<TypoGraphNode> graph; std::vector<uint8_t> glast; std::vector<TypoGraphNode> g;
-			uint64_t mapTop = 0, nsTop = 0, stateTop = 0;
+			std::vector<TypoLatChunk> tch(nC); std::vector<TypoGraphNode> graph; std::vector<uint8_t> glast;
+			// graphs of kGraphBlock consecutive chunks per host task (each task appends to its own vectors), then one pass that lays the
+			// per-chunk regions out and concatenates
+			constexpr size_t kGraphBlock = 32;
+			const size_t nBlocks = (nC + kGraphBlock - 1) / kGraphBlock;
+			std::vector<std::vector<TypoGraphNode>> bGraph(nBlocks); std::vector<std::vector<uint8_t>> bLast(nBlocks);
+			HostPool::instance().run(nBlocks, 1, b.hostThreads, [&](size_t b0, size_t b1, int)
+			{
+				std::vector<TypoGraphNode> g;
+				for (size_t bi = b0; bi < b1; ++bi)
+				for (size_t c = bi * kGraphBlock, ce = std::min(nC, c + kGraphBlock); c < ce; ++c)
+				{
+					const auto& r = b.refs[c];
+					const PreparedView& pt = b.prep[r.text];
+					const ChunkDesc& d = pt.chunks[r.chunk];
+					const char16_t* str = (const char16_t*)pt.norm.data() + d.startOffset;
+					const size_t maxCti = T.graph(str, d.nChars, b.typo.allowedDialect, g);
+					TypoLatChunk& t = tch[c];
+					t = TypoLatChunk{};
+					t.charOff = b.charOff[c]; t.nChars = d.nChars; t.textOffset = d.startOffset; t.chunkId = (uint32_t)c;
+					t.patOff = b.patOff[c]; t.patCnt = b.patOff[c + 1] - b.patOff[c];
+					t.graphCnt = (uint32_t)g.size();
+					for (auto& gn : g)
+					{
+						uint32_t lastC = 0; bool any = false;
+						const std::u16string f = T.formOf(gn, str);
+						for (size_t j = 0; j < f.size(); ++j)
+						{
+							uint32_t c32 = f[j];
+							if (isHighSurrogate(c32) && j + 1 < f.size()) { c32 = mergeSurrogate(c32, f[j + 1]); ++j; }
+							lastC = c32; any = true;
+						}
+						bLast[bi].push_back((any && lastC) ? identifySpecialChr(lastC) : (uint8_t)0xFF);
+						bLast[bi].push_back((any && lastC) ? chr2ScriptType(lastC) : (uint8_t)0);
+						bGraph[bi].push_back(gn);
+					}
+					if (maxCti > 1) { size_t v = maxCti - 1; while (v > 0) { v >>= 1; ++t.pmb; } }
+					for (uint32_t i = 0; i < d.nChars; ++i) if (!isSpace(str[i])) { ++t.nNs; if (isHighSurrogate(str[i]) && i + 1 < d.nChars) { ++t.nNs; ++i; } }
+					t.nodeOff = b.nodeBase[c]; t.nodeCap = b.nodeBase[c + 1] - b.nodeBase[c]; t.packCap = b.packBase[c + 1] - b.packBase[c];
+					t.mapLen = (t.nNs << t.pmb) + 1;
+					t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.nodeCap).total;
+				}
+			});
+			uint64_t mapTop = 0, nsTop = 0, stateTop = 0, graphTop = 0;
 			for (size_t c = 0; c < nC; ++c)
 			{
-				const auto& r = b.refs[c];
-				const PreparedView& pt = b.prep[r.text];
-				const ChunkDesc& d = pt.chunks[r.chunk];
-				const char16_t* str = (const char16_t*)pt.norm.data() + d.startOffset;
-				const size_t maxCti = T.graph(str, d.nChars, b.typo.allowedDialect, g);
 				TypoLatChunk& t = tch[c];
-				t = TypoLatChunk{};
-				t.charOff = b.charOff[c]; t.nChars = d.nChars; t.textOffset = d.startOffset; t.chunkId = (uint32_t)c;
-				t.patOff = b.patOff[c]; t.patCnt = b.patOff[c + 1] - b.patOff[c];
-				t.graphOff = (uint32_t)graph.size(); t.graphCnt = (uint32_t)g.size();
-				for (auto& gn : g)
-				{
-					uint32_t lastC = 0; bool any = false;
-					const std::u16string f = T.formOf(gn, str);
-					for (size_t j = 0; j < f.size(); ++j)
-					{
-						uint32_t c32 = f[j];
-						if (isHighSurrogate(c32) && j + 1 < f.size()) { c32 = mergeSurrogate(c32, f[j + 1]); ++j; }
-						lastC = c32; any = true;
-					}
-					glast.push_back((any && lastC) ? identifySpecialChr(lastC) : (uint8_t)0xFF);
-					glast.push_back((any && lastC) ? chr2ScriptType(lastC) : (uint8_t)0);
-					graph.push_back(gn);
-				}
-				if (maxCti > 1) { size_t v = maxCti - 1; while (v > 0) { v >>= 1; ++t.pmb; } }
-				for (uint32_t i = 0; i < d.nChars; ++i) if (!isSpace(str[i])) { ++t.nNs; if (isHighSurrogate(str[i]) && i + 1 < d.nChars) { ++t.nNs; ++i; } }
-				t.nodeOff = b.nodeBase[c]; t.nodeCap = b.nodeBase[c + 1] - b.nodeBase[c]; t.packCap = b.packBase[c + 1] - b.packBase[c];
-				t.mapOff = (uint32_t)mapTop; t.mapLen = (t.nNs << t.pmb) + 1; mapTop += t.mapLen;
-				t.nsOff = (uint32_t)nsTop; nsTop += d.nChars + 2;
-				t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.nodeCap).total;
-				t.stateOff = (uint32_t)stateTop; t.stateCap = (uint32_t)std::min<uint64_t>((g.size() * 16 + 64) * sc, 0x7FFFFFFF); stateTop += t.stateCap;
-				if (mapTop > 0xFFFFFFF0ull || stateTop > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit typo scratch offsets: split the batch" };
+				t.graphOff = (uint32_t)graphTop; graphTop += t.graphCnt;
+				t.mapOff = (uint32_t)mapTop; mapTop += t.mapLen;
+				t.nsOff = (uint32_t)nsTop; nsTop += t.nChars + 2;
+				t.stateOff = (uint32_t)stateTop; t.stateCap = (uint32_t)std::min<uint64_t>(((uint64_t)t.graphCnt * 16 + 64) * sc, 0x7FFFFFFF); stateTop += t.stateCap;
+				if (mapTop > 0xFFFFFFF0ull || stateTop > 0xFFFFFFF0ull || graphTop > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit typo scratch offsets: split the batch" };
 			}
+			graph.reserve(graphTop); glast.reserve(2 * graphTop);
+			for (size_t bi = 0; bi < nBlocks; ++bi) { graph.insert(graph.end(), bGraph[bi].begin(), bGraph[bi].end()); glast.insert(glast.end(), bLast[bi].begin(), bLast[bi].end()); }
 			std::vector<uint16_t> pool(T.pool().begin(), T.pool().end());
 			if (pool.empty()) pool.push_back(0);
 			if (graph.empty()) graph.push_back(TypoGraphNode{});
