@@ -709,6 +709,14 @@ namespace kamd
 				if (gl == 64) hipLaunchKernelGGL((sbgk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
 				else hipLaunchKernelGGL((sbgk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
 			}
+			else if (I.hasCong && b.typo.typo)
+			{
+				// typo correction with a CoNgram model: both additions (viterbi_kernel_cong_typo.hip)
+				const float* nodeTypo = b.dNodeTypo.as<float>();
+				const uint32_t ldsC = ldsK + (64u / (uint32_t)gl) * 4u * QCAP;
+				if (gl == 64) hipLaunchKernelGGL((typok::congk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsC, sB, I.dview, b.bv, wv, sp, counter, order, cn, nodeTypo, I.cong);
+				else hipLaunchKernelGGL((typok::congk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsC, sB, I.dview, b.bv, wv, sp, counter, order, cn, nodeTypo, I.cong);
+			}
 			else if (I.hasCong)
 			{
 				// CoNgram model: the search kernel compiled with KAMD_CONG (16-lane groups, or one chunk per wave when 64 is forced); its LDS
@@ -895,7 +903,6 @@ namespace kamd
 		if (typo.typo)
 		{
 			if (impl->hasSbg) throw std::runtime_error{ "kiwi_amd: typo correction with a SkipBigram model is not built" };
-			if (impl->hasCong) throw std::runtime_error{ "kiwi_amd: typo correction with a CoNgram model is not built" };
 			if (impl->model.forms.size() >= (1u << 24)) throw std::runtime_error{ "kiwi_amd: typo correction supports up to 2^24 forms" };
 		}
 		HostTimer tm{ "stage" };

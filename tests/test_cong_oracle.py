@@ -70,3 +70,26 @@ def test_the_pin_is_the_sse41_build(cong_pair):
         assert abs(a[0][1] - b[0][1]) < 1e-2 * max(1.0, abs(a[0][1]))
         differ += _norm(a) != _norm(b)
     assert differ > 0
+
+
+@pytest.mark.parametrize("name,threshold,carry", [("basic_with_continual", 2.5, True), ("basic_with_continual_and_lengthening", 4.0, True)])
+def test_typo_correction_with_a_cong_model_equals_reference(cong_pair, name, threshold, carry):
+    """The reference's default model type together with its --typo configurations: Kiwi::analyze with a typo transformer on a CoNgram model,
+    SSE4.1 build of the real reference vs the oracle -- tokens, positions, fp32 scores, per-token typo costs."""
+    import oraclelib
+    import refbridge
+    from typo_cases import misspell
+    sm, ref, orc, _ = cong_pair
+    ents, cont, leng = refbridge.default_typo_entries(name)
+    rt = refbridge.RefTypo(); rt.update_default(name); rt.prepare(True)
+    ot = oraclelib.OracleTypo(); ot.update_entries(ents, cont, leng); ot.prepare(True)
+    rnd = random.Random(15)
+    tt = [misspell(t, rnd, True, carry, "lengthening" in name) for t in synthetic(sm, 70, 731, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 40, 732)] + EDGE_TEXTS[:30]
+    corrected = 0
+    for t in tt:
+        if not t.strip():
+            continue
+        a = ref.analyze_typo(rt, t, threshold, 0)
+        assert _norm(a) == _norm(orc.analyze_typo(ot, t, threshold, 0)), t
+        corrected += any(x.typo_cost > 0 for x in a[0][0])
+    assert corrected >= 15

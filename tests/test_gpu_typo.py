@@ -49,3 +49,27 @@ def test_typo_analyses_through_the_capacity_ladder(small_model, monkeypatch):
     for t, y in zip(texts, _analyze_typo(dev, prod, texts, 2.5)):
         assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0)) == _norm(y), t
     dev.close(); prod.close()
+
+
+@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("16", 1, 1.0, float("inf")), ("64", 2, 1.0, 0.25)])
+def test_typo_correction_with_a_cong_model(small_cong_model, monkeypatch, lanes, top_n, continual, lengthening):
+    """The reference's default model type with typo correction: viterbi_kernel_cong_typo.hip (CoNgram scoring + node typo costs) on the MI355X
+    against the oracle (pinned for this combination to the reference's SSE4.1 build) and, where it travelled, the real reference itself."""
+    import oraclelib
+    import refbridge
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import misspell
+    sm, path = small_cong_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    prod, orc_t = _typo_pair(LIB, continual, lengthening)
+    dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
+    rnd = random.Random(19)
+    texts = [misspell(t, rnd, True, continual == 1.0, lengthening < 1e9) for t in synthetic(sm, 400, 751, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 200, 752)] + EDGE_TEXTS
+    got = _analyze_typo(dev, prod, texts, 2.5, top_n)
+    corrected = 0
+    for t, y in zip(texts, got):
+        want = orc.analyze_typo(orc_t, t, 2.5, 0, top_n=top_n)
+        assert _norm(want) == _norm(y), t
+        corrected += any(x.typo_cost > 0 for x in want[0][0])
+    assert corrected >= 50
+    dev.close(); prod.close()

@@ -426,3 +426,29 @@ def test_emulated_blocklist_matches_oracle(emu_libs, small_model, small_cong_mod
         changed += _norm(y) != _norm(z)
     assert changed >= 20
     ms.close(); dev.close()
+
+
+@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("16", 1, 1.0, float("inf")), ("64", 1, 1.0, 0.25), ("16", 2, float("inf"), float("inf"))])
+def test_emulated_typo_correction_with_a_cong_model(emu_libs, small_cong_model, monkeypatch, lanes, top_n, continual, lengthening):
+    """Typo correction on a CoNgram model (the reference's default model type with its --typo configurations): the fifth compilation of the search
+    kernel (viterbi_kernel_cong_typo.hip: CoNgram scoring + node typo costs) over the typo lattices, against the oracle -- pinned for this
+    combination to the real reference's SSE4.1 build (tests/test_cong_oracle.py::test_typo_correction_with_a_cong_model_equals_reference)."""
+    import random
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import misspell
+    sm, path = small_cong_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    prod, orc_t = _typo_pair(emu_libs[0], continual, lengthening)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    orc = oraclelib.OracleKiwi(path)
+    rnd = random.Random(17)
+    texts = [misspell(t, rnd, True, continual == 1.0, lengthening < 1e9) for t in synthetic(sm, 50, 741, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 25, 742)] + EDGE_TEXTS[:20]
+    got = _analyze_typo(dev, prod, texts, 2.5, top_n)
+    corrected = 0
+    for t, y in zip(texts, got):
+        want = orc.analyze_typo(orc_t, t, 2.5, 0, top_n=top_n)
+        assert _norm(want) == _norm(y), t
+        corrected += any(x.typo_cost > 0 for x in want[0][0])
+    assert corrected >= 5
+    dev.close(); prod.close()
