@@ -215,6 +215,35 @@ namespace kamd
 		return true;
 	}
 
+	// latAppend for the run of candidates that all END at the same position e < nMap (flushCandidates): that position's index entry, length mask and
+	// flag bits are carried in registers by the caller (loaded before the run, written back after it) instead of being read, modified and written
+	// in LDS / HBM for every candidate -- the compiler cannot keep them itself (it cannot prove that the node writes do not alias them)
+	template<class LC>
+	__device__ __forceinline__ bool latAppendAt(LC& L, uint32_t s, uint32_t e, uint32_t form, bool qual, uint32_t lenKey, uint8_t zbits, uint32_t& epmE, uint64_t& fmE, uint8_t& zE)
+	{
+		const uint32_t ms = L.endPosMap[s];
+		if ((ms & 0xFFFF) == (ms >> 16)) return false;
+		if (L.nOut >= L.cap) { L.overflow = true; return false; }
+		const uint32_t id = L.nOut++;
+		typename LC::Node nn;
+		nn.form = form; nn.startPos = (uint16_t)s; nn.endPos = (uint16_t)e; nn.prev = (uint16_t)(id - (ms & 0xFFFF)); nn.sibling = 0;
+		nn.uformOff = 0; nn.uformLen = 0;
+		if constexpr (sizeof(typename LC::Node) == sizeof(DevNode)) { nn.spaceErrors = 0; nn.nflags = 0; nn.nPrev = 0; nn.packOff = 0; nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0; }
+		else L.spaceErr[id] = 0;
+		L.out[id] = nn;
+		L.lastEnd = e;
+		if (qual && lenKey >= 1 && lenKey <= 64) fmE |= 1ull << (lenKey - 1);
+		zE |= zbits;
+		if ((epmE & 0xFFFF) == (epmE >> 16)) epmE = id | ((id + 1) << 16);
+		else
+		{
+			const uint32_t last = (epmE >> 16) - 1;
+			L.out[last].sibling = (uint16_t)(id - last);
+			epmE = (epmE & 0xFFFF) | ((id + 1) << 16);
+		}
+		return true;
+	}
+
 	template<class LC>
 	__device__ __forceinline__ uint32_t latNodeLen(const LC& L, const typename LC::Node& g)
 	{
@@ -361,13 +390,18 @@ namespace kamd
 			// flushCandidates (KTrie.cpp:955-996) over [z-coda shortcut] + the packed dictionary matches ending here
 			const uint32_t endNs = L.posToNs[j + 1];
 			const uint32_t m0 = moff[endNs], m1 = m0 + __popcll(mask[endNs]);
-			for (uint32_t k = zcand ? m0 - 1 : m0; k != m1; ++k)
+			const uint32_t kFirst = zcand ? m0 - 1 : m0;
+			if (kFirst == m1) continue;
+			// every candidate of this run ends at endNs: that position's index entry / length mask / flag bits stay in registers (latAppendAt)
+			uint32_t epmE = L.endPosMap[endNs]; uint64_t fmE = L.fullMask[endNs]; uint8_t zE = L.zAt[endNs];
+			const uint32_t epm0 = epmE; const uint64_t fm0 = fmE; const uint8_t z0 = zE;
+			for (uint32_t k = kFirst; k != m1; ++k)
 			{
 				const bool isZ = zcand && k == m0 - 1;
 				if (!isZ && mfrec)
 				{
 					// wave-per-chunk variant: the match's facts were computed by the staging pass
-					const uint2 r = mfrec[k];
+					const uint2 r = mfrec[k]; const uint32_t fiK = mforms[k];      // (two independent reads: one round trip)
 					if (!(r.y & 0x100)) continue;
 					const uint32_t nb = r.x & 0xFFFF, ne = endNs, se = r.x >> 16; const uint8_t fl = (uint8_t)r.y;
 					if (nb < resetNs) continue;
@@ -379,7 +413,7 @@ namespace kamd
 					}
 					if (se <= P.spaceTol)
 					{
-						if (latAppend(L, nb, ne, mforms[k], 0, 0, nMap, (fl & FF_HAS_ANY_FULL) != 0, ne - nb, fl & 3)) L.setSpaceErrors(L.nOut - 1, (uint8_t)(se > 255 ? 255 : se));
+						if (latAppendAt(L, nb, ne, fiK, (fl & FF_HAS_ANY_FULL) != 0, ne - nb, fl & 3, epmE, fmE, zE)) L.setSpaceErrors(L.nOut - 1, (uint8_t)(se > 255 ? 255 : se));
 					}
 					continue;
 				}
@@ -415,9 +449,12 @@ namespace kamd
 				}
 				if (se <= P.spaceTol)
 				{
-					if (latAppend(L, nb, ne, fi, 0, 0, nMap, (f.flags & FF_HAS_ANY_FULL) != 0, flen, f.flags & 3)) L.setSpaceErrors(L.nOut - 1, (uint8_t)(se > 255 ? 255 : se));
+					if (latAppendAt(L, nb, ne, fi, (f.flags & FF_HAS_ANY_FULL) != 0, flen, f.flags & 3, epmE, fmE, zE)) L.setSpaceErrors(L.nOut - 1, (uint8_t)(se > 255 ? 255 : se));
 				}
 			}
+			if (epmE != epm0) L.endPosMap[endNs] = epmE;
+			if (fmE != fm0) L.fullMask[endNs] = fmE;
+			if (zE != z0) L.zAt[endNs] = zE;
 		}
 		if (lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
 		{
