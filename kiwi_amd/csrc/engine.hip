@@ -667,7 +667,8 @@ namespace kamd
 					const uint32_t need = needOf(b.order[i]);
 					uint32_t j = i + 1;
 					while (j < c1 && (uint64_t)needOf(b.order[j]) * 4 >= (uint64_t)need * 3) ++j;      // <= 25 % of a class's LDS unused
-					hipLaunchKernelGGL(k_build_lattice, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need);
+					static const uint32_t dbgStop = std::getenv("KAMD_LATTICE_STOP") ? (uint32_t)std::atoi(std::getenv("KAMD_LATTICE_STOP")) : 0u;      // EXPERIMENT
+					hipLaunchKernelGGL(k_build_lattice, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24));
 					i = j;
 				}
 				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget);

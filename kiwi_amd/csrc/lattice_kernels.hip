@@ -407,9 +407,17 @@ namespace kamd
 					if (nb < resetNs) continue;
 					if (!(fl & FF_FIRST_IS_CODA))
 					{
-						const bool hj = (fl & FF_HAS_JCLASS) || (fl & FF_IS_STAG);
-						if (boundary < nb) latInsertUnk(L, boundary, nb, hj, nMap);
-						latInsertUnk(L, unkStart, nb, hj, nMap);
+						// insertUnkForm(s, nb) returns at once when s >= nb or a form already covers [s, nb): both tests of the two calls read the same
+						// length mask -- one read decides the common case (nothing to insert); a call that does run may append, so the second is then made in full
+						const uint64_t fmNb = L.fullMask[nb];
+						const bool skipB = !(boundary < nb) || (nb - boundary <= 64 && ((fmNb >> (nb - boundary - 1)) & 1));
+						const bool skipU = unkStart >= nb || (nb - unkStart <= 64 && ((fmNb >> (nb - unkStart - 1)) & 1));
+						if (!skipB || !skipU)
+						{
+							const bool hj = (fl & FF_HAS_JCLASS) || (fl & FF_IS_STAG);
+							if (!skipB) latInsertUnk(L, boundary, nb, hj, nMap);
+							if (!skipB || !skipU) latInsertUnk(L, unkStart, nb, hj, nMap);
+						}
 					}
 					if (se <= P.spaceTol)
 					{
@@ -604,6 +612,7 @@ namespace kamd
 		const uint32_t nNs = W.nNs[chunk];
 		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
 		const uint32_t mBase = W.matchBase[chunk], mCap = W.matchBase[chunk + 1] - mBase;
+		const uint32_t dbgStop = ldsBytes >> 24; ldsBytes &= 0xFFFFFFu;      // EXPERIMENT (KAMD_LATTICE_STOP): leave after phase 1 / 2 / 3, results void
 		const LatticeLds lay = latticeLdsLayout(n, cap, mCap);
 		if (lay.total > ldsBytes) return;                      // k_build_lattice_big takes it
 		const uint32_t nMap = nNs + 1;
@@ -666,6 +675,7 @@ namespace kamd
 		waveSync();
 		LatticeMem Q{ str, cls, script, cflag, mask, moff, mforms, mfrec, reinterpret_cast<uint16_t*>(lSmem + lay.queue), reinterpret_cast<uint16_t*>(lSmem + lay.queue) + ldsCap };
 		uint32_t nConn = 0, G = 0, err = 0;
+		if (dbgStop == 1) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
 		if (lane == 0)
 		{
 			L.endPosMap[0] = 0 | (1u << 16);
@@ -673,9 +683,11 @@ namespace kamd
 			L.out[0] = bos; L.spaceErr[0] = 0; L.nOut = 1;
 			latticeSerialBuild(M, B, P, L, Q, chunk, n, nNs, nMap);
 			if (L.overflow || L.nOut + 1 >= ldsCap) err = ldsCap < cap ? 0xFFFFu : (uint32_t)CS_ERR_NODE_OVERFLOW;   // 0xFFFF: outgrew the LDS copy only
+			else if (dbgStop == 2) { G = L.nOut; }
 			else { G = L.nOut; nConn = latticeConnect(L, Q, ldsCap, nNs); }
 		}
 		waveSync();
+		if (dbgStop == 2 || dbgStop == 3) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
 		err = __shfl(err, 0); G = __shfl(G, 0); nConn = __shfl(nConn, 0);
 		if (err) { if (lane == 0) { if (err == 0xFFFFu) W.nNodes[chunk] = kLatticeNeedsBig; else W.results[chunk].status = err; } return; }
 
