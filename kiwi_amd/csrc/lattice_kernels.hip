@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
 #include "feature.hpp"
+#include "lattice_connect.hpp"
 
 namespace kamd
 {
@@ -683,13 +684,14 @@ namespace kamd
 			L.out[0] = bos; L.spaceErr[0] = 0; L.nOut = 1;
 			latticeSerialBuild(M, B, P, L, Q, chunk, n, nNs, nMap);
 			if (L.overflow || L.nOut + 1 >= ldsCap) err = ldsCap < cap ? 0xFFFFu : (uint32_t)CS_ERR_NODE_OVERFLOW;   // 0xFFFF: outgrew the LDS copy only
-			else if (dbgStop == 2) { G = L.nOut; }
-			else { G = L.nOut; nConn = latticeConnect(L, Q, ldsCap, nNs); }
+			else G = L.nOut;
 		}
 		waveSync();
-		if (dbgStop == 2 || dbgStop == 3) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
-		err = __shfl(err, 0); G = __shfl(G, 0); nConn = __shfl(nConn, 0);
+		err = __shfl(err, 0); G = __shfl(G, 0);
 		if (err) { if (lane == 0) { if (err == 0xFFFFu) W.nNodes[chunk] = kLatticeNeedsBig; else W.results[chunk].status = err; } return; }
+		if (dbgStop == 2) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
+		nConn = latticeConnectWave(L.out, L.endPosMap, Q.queue, Q.connOrd, reinterpret_cast<uint32_t*>(L.fullMask), G, nNs + 1, lane);
+		if (dbgStop == 3) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
 
 		// ---- final records, one node per lane; candidate-record offsets by a wave scan over the new order ----
 		DevNode* fin = W.nodes + nBase;

@@ -14,6 +14,7 @@
 #include "feature.hpp"
 #include "typo.hpp"
 #include "typo_lattice_kernel.hpp"
+#include "lattice_connect.hpp"
 
 namespace kamd
 {
@@ -622,7 +623,7 @@ namespace kamd
 		if (V.results[C.chunkId].status >= 16) { if (lane == 0) C.status = V.results[C.chunkId].status; return; }
 		const uint32_t n = C.nChars, pmb = C.pmb;
 		const TypoLds lay = typoLdsLayout(n, C.nNs, pmb, C.nodeCap);
-		if (lay.total > ldsBytes || C.mapLen > 0xFFF0 || C.nodeCap > 0xFFF0 || C.mapLen != (C.nNs << pmb) + 1) { if (lane == 0) C.status = kTypoLdsNeedsBig; return; }
+		if (lay.total > ldsBytes || C.mapLen > 0xFFF0 || C.nodeCap > 0xFFF0 || C.mapLen != (C.nNs << pmb) + 1 || C.mapLen > 64 * (C.nNs + 1)) { if (lane == 0) C.status = kTypoLdsNeedsBig; return; }
 		uint16_t* str = reinterpret_cast<uint16_t*>(tSmem + lay.str); uint8_t* cls = tSmem + lay.cls; uint8_t* script = tSmem + lay.script;
 		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(tSmem + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(tSmem + lay.posToNs);
 		uint32_t* epm = reinterpret_cast<uint32_t*>(tSmem + lay.epm); uint64_t* fullMask = reinterpret_cast<uint64_t*>(tSmem + lay.fullMask); uint8_t* zAt = tSmem + lay.zAt;
@@ -686,53 +687,18 @@ namespace kamd
 				lout[X.nOut - 1].endPos = (uint16_t)(nNs << pmb);
 				if (X.outgrown || (X.nOut + 1 >= lay.nodeCap && lay.nodeCap < C.nodeCap)) err = kTypoLdsNeedsBig;
 				else if (X.overflow || X.nOut + 1 >= C.nodeCap) err = CS_ERR_NODE_OVERFLOW;
-				else
-				{
-					// removeUnconnected (KTrie.cpp:240-299): reachable from the end node backwards; new index = nodes grouped by end position
-					// ascending, original order inside a group (the sibling chain of an end position enumerates exactly its nodes in index order;
-					// the end-of-input node is on no chain and sorts last)
-					G = X.nOut;
-					for (uint32_t i = 0; i < G; ++i) conn[i] = 0;
-					uint32_t qh = 0, qt = 0;
-					inv[qt++] = (uint16_t)(G - 1); conn[G - 1] = 1;
-					while (qh < qt)
-					{
-						const uint32_t id = inv[qh++];
-						const uint32_t sp = lout[id].startPos;
-						const uint32_t me = epm[sp];
-						for (uint32_t i = me & 0xFFFF; i < (me >> 16); ++i)
-						{
-							if (lout[i].endPos != sp || conn[i]) continue;
-							conn[i] = 1; inv[qt++] = (uint16_t)i;
-						}
-					}
-					for (uint32_t e = 0; e < C.mapLen; ++e)
-					{
-						const uint32_t me = epm[e];
-						uint32_t chainConn = 0;
-						if ((me & 0xFFFF) != (me >> 16))
-						{
-							for (uint32_t i = me & 0xFFFF;;)
-							{
-								if (i != G - 1)
-								{
-									if (conn[i]) { inv[i] = (uint16_t)nConn++; ++chainConn; }
-									else inv[i] = (uint16_t)0xFFFF;
-								}
-								const uint32_t sib = lout[i].sibling;
-								if (!sib) break;
-								i += sib;
-							}
-						}
-						epm[e] = chainConn;      // from here on: number of connected nodes ending at e
-					}
-					inv[G - 1] = (uint16_t)nConn++;
-					if (nNs > 0xFFF0 || nConn > 0xFFF0) err = CS_ERR_TOO_LONG;
-				}
+				else G = X.nOut;
 			}
 		}
 		waveSync();
-		err = __shfl(err, 0); G = __shfl(G, 0); nConn = __shfl(nConn, 0);
+		err = __shfl(err, 0); G = __shfl(G, 0);
+		if (!err)
+		{
+			// removeUnconnected (KTrie.cpp:240-299), all lanes: reachability by a downward sweep over the positions, new index = nodes grouped by end
+			// position ascending, original order inside a group (lattice_connect.hpp); the length masks of the build serve as its flag bits
+			nConn = latticeConnectWave(lout, epm, inv, conn, reinterpret_cast<uint32_t*>(fullMask), G, C.mapLen, lane);
+			if (C.nNs > 0xFFF0 || nConn > 0xFFF0) err = CS_ERR_TOO_LONG;
+		}
 		if (err)
 		{
 			if (lane == 0) { C.status = err; if (err != kTypoLdsNeedsBig) V.results[C.chunkId].status = err; }
