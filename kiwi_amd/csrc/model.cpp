@@ -115,23 +115,77 @@ namespace kamd
 			if (size < sizeof(KnlmHeader)) throw std::runtime_error{ "knlm: truncated header" };
 			KnlmHeader hd;
 			std::memcpy(&hd, blob, sizeof(hd));
-			if (hd.quantized) throw std::runtime_error{ "knlm: quantised/compressed language models are not supported by this loader yet" };
 			if (hd.htx_offset) throw std::runtime_error{ "knlm: history-transformed language models are not supported by this loader yet" };
 			if (hd.key_size != 2 && hd.key_size != 4) throw std::runtime_error{ "knlm: unsupported key size" };
 			const size_t nNodes = hd.num_nodes;
+			const uint32_t qbits = hd.quantized & 0x1F; const bool compressed = (hd.quantized & 0x80) != 0;      // Knlm.hpp:1008-1009
+			if (qbits > 16) throw std::runtime_error{ "16+ bits quantization not supported." };
 			auto keyAt = [&](uint64_t off, size_t i) -> uint32_t
 			{
 				if (hd.key_size == 2) { uint16_t v; std::memcpy(&v, blob + off + 2 * i, 2); return v; }
 				uint32_t v; std::memcpy(&v, blob + off + 4 * i, 4); return v;
 			};
+			// node sizes: plain keys, or -- compressed -- the variable-length code qe::QCode<0, 2, 8, 16> (src/QEncoder.hpp): two header bits per value
+			// name its class {0 bits: 0, 2 bits: 1..4, 8 bits: 5..260, 16 bits: 261..}, the bodies form one LSB-first bit stream of 64-bit words that
+			// starts right behind the header bytes (Knlm.hpp:1016-1023; the reference decodes into 16-bit slots: 16-bit keys only)
+			std::vector<uint32_t> nodeSize(nNodes);
+			if (compressed)
+			{
+				if (hd.key_size != 2) throw std::runtime_error{ "knlm: compressed node sizes need 16-bit keys" };
+				const uint8_t* qh = blob + hd.node_offset;
+				const uint8_t* qb = qh + (nNodes + 3) / 4;
+				if (qb > blob + size) throw std::runtime_error{ "knlm: truncated node section" };
+				static const uint32_t qBits[4] = { 0, 2, 8, 16 }, qBias[4] = { 0, 1, 5, 261 };
+				uint64_t bitPos = 0;
+				for (size_t i = 0; i < nNodes; ++i)
+				{
+					const uint32_t q = (qh[i / 4] >> (2 * (i % 4))) & 3;
+					uint32_t e = 0;
+					if (qBits[q])
+					{
+						if (qb + (bitPos + qBits[q] + 7) / 8 > blob + size) throw std::runtime_error{ "knlm: truncated node section" };
+						for (uint32_t k = 0; k < qBits[q]; ++k) e |= (uint32_t)((qb[(bitPos + k) >> 3] >> ((bitPos + k) & 7)) & 1) << k;
+						bitPos += qBits[q];
+					}
+					nodeSize[i] = e + qBias[q];
+				}
+			}
+			else for (size_t i = 0; i < nNodes; ++i) nodeSize[i] = keyAt(hd.node_offset, i);
 			size_t nonLeaf = 0, leaf = 0;
-			for (size_t i = 0; i < nNodes; ++i) (keyAt(hd.node_offset, i) ? nonLeaf : leaf)++;
+			for (size_t i = 0; i < nNodes; ++i) (nodeSize[i] ? nonLeaf : leaf)++;
 			const size_t nKeys = (hd.ll_offset - hd.key_offset) / hd.key_size;
 			m.lmKeys.resize(nNodes ? nNodes - 1 : 0);
 			if (nKeys < m.lmKeys.size()) throw std::runtime_error{ "knlm: key section too small" };
 			for (size_t i = 0; i < m.lmKeys.size(); ++i) m.lmKeys[i] = keyAt(hd.key_offset, i);
-			const float* ll = (const float*)(blob + hd.ll_offset);
-			const float* gamma = (const float*)(blob + hd.gamma_offset);
+			// log-likelihoods and back-off weights: floats, or -- quantised -- fixed-width codes into two tables of 2^bits floats at qtable_offset
+			// (lm::FixedLengthEncoder<bits, uint32_t>, src/BitEncoder.hpp: a plain LSB-first bit stream; one stream for the non-leaf then the leaf
+			// log-likelihoods, one for the back-off weights; Knlm.hpp:398-455, 1036-1061)
+			std::vector<float> llV(nonLeaf + leaf), gammaV(nonLeaf);
+			if (qbits)
+			{
+				const size_t tab = (size_t)1 << qbits;
+				if (hd.qtable_offset + 8 * tab > size) throw std::runtime_error{ "knlm: truncated quantisation tables" };
+				const float* llTable = (const float*)(blob + hd.qtable_offset);
+				const float* gammaTable = llTable + tab;
+				auto code = [&](uint64_t off, uint64_t limit, size_t i) -> uint32_t
+				{
+					const uint64_t bp = (uint64_t)i * qbits;
+					if (off + (bp + qbits + 7) / 8 > limit) throw std::runtime_error{ "knlm: truncated quantised section" };
+					uint32_t v = 0;
+					for (uint32_t k = 0; k < qbits; ++k) v |= (uint32_t)((blob[off + ((bp + k) >> 3)] >> ((bp + k) & 7)) & 1) << k;
+					return v;
+				};
+				for (size_t i = 0; i < nonLeaf + leaf; ++i) llV[i] = llTable[code(hd.ll_offset, hd.gamma_offset, i)];
+				for (size_t i = 0; i < nonLeaf; ++i) gammaV[i] = gammaTable[code(hd.gamma_offset, hd.qtable_offset, i)];
+			}
+			else
+			{
+				if (hd.ll_offset + 4 * (nonLeaf + leaf) > size || hd.gamma_offset + 4 * nonLeaf > size) throw std::runtime_error{ "knlm: truncated float sections" };
+				std::memcpy(llV.data(), blob + hd.ll_offset, 4 * (nonLeaf + leaf));
+				std::memcpy(gammaV.data(), blob + hd.gamma_offset, 4 * nonLeaf);
+			}
+			const float* ll = llV.data();
+			const float* gamma = gammaV.data();
 			const float* leafLl = ll + nonLeaf;
 
 			m.lmNodes.assign(nonLeaf, LmNodeRec{});
@@ -143,7 +197,7 @@ namespace kamd
 			size_t ni = 0, li = 0, nextOff = 0;
 			for (size_t i = 0; i < nNodes; ++i)
 			{
-				const uint32_t sz = keyAt(hd.node_offset, i);
+				const uint32_t sz = nodeSize[i];
 				if (sz)
 				{
 					if (!st.empty()) m.lmValues[st.back().cur] = (int32_t)(ni - st.back().node);

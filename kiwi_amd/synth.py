@@ -297,6 +297,8 @@ class SynthSpec:
     lm_sentences: int = 20000
     lm_order: int = 3
     use_htx: bool = False
+    knlm_qbits: int = 0          # > 0: the Knlm blob is quantised to that many bits (reference KnLangModelHeader::quantized, Knlm.hpp:398-455, 1036-1061)
+    knlm_compress: bool = False  # node sizes in the variable-length code qe::QCode<0, 2, 8, 16> (quantized |= 0x80; 16-bit keys only)
     use_sbg: bool = False        # also emit a SkipBigram model (reference skipbigram.mdl layout) over the same vocabulary
     use_cong: bool = False       # also emit a local (window 0), 8-bit CoNgram model (reference cong.mdl layout) over the same vocabulary
     cong_dim: int = 32
@@ -308,6 +310,8 @@ FULL_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_
 FULL_SBG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
                           n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_sbg=True)   # FULL_SPEC + skip-bigram tables (32-bit keys)
 SMALL_SPEC = SynthSpec()
+SMALL_Q8_SPEC = SynthSpec(knlm_qbits=8, knlm_compress=True)   # SMALL_SPEC with the Knlm file as the reference ships it: 8-bit quantised, node sizes compressed
+SMALL_Q5_SPEC = SynthSpec(knlm_qbits=5)                       # ... and a bit width that exercises the generic fixed-length bit stream
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
 SMALL_CONG_SPEC = SynthSpec(use_cong=True) # same lexicon as SMALL_SPEC + a local CoNgram model (the Knlm blob stays in the container: the dictionary bake needs a vocabulary size)
 FULL_CONG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
@@ -671,6 +675,8 @@ class SynthModel:
         if sp.use_htx:
             htx = np.array([(raw.morphs[i].tag & 0x7F) + vocab for i in range(vocab)], dtype=np.int64)
         raw.knlm = build_knlm(sents, vocab, sp.lm_order, htx=htx)
+        if sp.knlm_qbits or sp.knlm_compress:
+            raw.knlm = quantize_knlm(raw.knlm, sp.knlm_qbits, sp.knlm_compress)
         if sp.use_sbg:
             raw.sbg = build_sbg(sents, vocab, key_size=2 if vocab + 1 <= 0xFFFF else 4, seed=sp.seed + 2)
         if sp.use_cong:
@@ -717,6 +723,97 @@ class SynthModel:
 
 
 # ---------------------------------------------------------------------------------------------
+def _pack_bits(codes, bits) -> bytes:
+    """lm::FixedLengthEncoder<bits, uint32_t> (src/BitEncoder.hpp): value k occupies bits [k*bits, (k+1)*bits) of an LSB-first bit stream."""
+    codes = np.asarray(codes, np.uint32)
+    if bits == 8:
+        return codes.astype(np.uint8).tobytes()
+    b = ((codes[:, None] >> np.arange(bits, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(-1)
+    out = np.packbits(b, bitorder="little").tobytes()
+    return out + b"\0" * ((-len(out)) % 4)      # (whole 32-bit packets)
+
+
+def _qcode_encode(sizes):
+    """qe::QCode<0, 2, 8, 16> (src/QEncoder.hpp:13-45, 92-135): two header bits per value name its class {0: the value 0, 1: 1..4 in 2 bits,
+    2: 5..260 in 8 bits, 3: 261.. in 16 bits}; the bodies form one LSB-first bit stream of 64-bit words right behind the header bytes."""
+    sizes = np.asarray(sizes, np.int64)
+    q = (sizes >= 1).astype(np.int64) + (sizes >= 5) + (sizes >= 261)
+    assert sizes.max() < 261 + 65536
+    n = len(sizes)
+    qp = np.concatenate([q, np.zeros((-n) % 4, np.int64)]).reshape(-1, 4)
+    header = (qp[:, 0] | (qp[:, 1] << 2) | (qp[:, 2] << 4) | (qp[:, 3] << 6)).astype(np.uint8).tobytes()
+    nbits = np.array([0, 2, 8, 16])[q]
+    bias = np.array([0, 1, 5, 261])[q]
+    e = sizes - bias
+    bits = []
+    for v, b in zip(e.tolist(), nbits.tolist()):
+        bits.extend((v >> k) & 1 for k in range(b))
+    body = np.packbits(np.array(bits, np.uint8), bitorder="little").tobytes() if bits else b""
+    body += b"\0" * ((-len(body)) % 8 + 8)      # whole 64-bit words and one to spare (the reference's decoder may read a word ahead)
+    return header + body
+
+
+def quantize_knlm(blob: bytes, bits: int, compress: bool) -> bytes:
+    """Re-writes an unquantised Knlm blob the way KnLangModelBase::build does with quantize = bits / compress (Knlm.hpp:688-790): log-likelihoods
+    and back-off weights as `bits`-bit codes into two tables of 2^bits floats, node sizes optionally QCode-compressed."""
+    (num_nodes, node_off, key_off, ll_off, gamma_off, qtable_off, htx_off, unk_id, bos_id, eos_id, vocab_size,
+     order, key_size, diff_size, quantized, extra) = struct.unpack_from("<11Q4BI", blob, 0)
+    assert quantized == 0
+    kdt = "<u2" if key_size == 2 else "<u4"
+    sizes = np.frombuffer(blob, kdt, num_nodes, node_off)
+    n_nonleaf = int((sizes != 0).sum()); n_leaf = num_nodes - n_nonleaf
+    keys = np.frombuffer(blob, kdt, num_nodes - 1, key_off)
+    ll = np.frombuffer(blob, "<f4", num_nodes, ll_off)
+    gamma = np.frombuffer(blob, "<f4", n_nonleaf, gamma_off)
+    htx = None if not htx_off else np.frombuffer(blob, kdt, vocab_size, htx_off)
+
+    def table_and_codes(x):
+        if not bits:
+            return None, None
+        tab = np.quantile(x, np.linspace(0, 1, 1 << bits)).astype("<f4")
+        tab = np.unique(tab)
+        tab = np.concatenate([tab, np.full((1 << bits) - len(tab), tab[-1], "<f4")]).astype("<f4")
+        idx = np.clip(np.searchsorted(tab, x), 1, len(tab) - 1)
+        idx = np.where(np.abs(tab[idx - 1] - x) <= np.abs(tab[idx] - x), idx - 1, idx)
+        return tab, idx.astype(np.uint32)
+    ll_tab, ll_codes = table_and_codes(np.minimum(ll, np.float32(-1e-6)))      # (a table entry of +0 would turn a leaf's value into a child offset)
+    gm_tab, gm_codes = table_and_codes(gamma)
+    if bits:
+        assert (ll_tab[ll_codes[n_nonleaf:]] < 0).all()      # leaf values are told apart from child offsets by their sign
+    node_bytes = _qcode_encode(sizes) if compress else sizes.astype(kdt).tobytes()
+    if compress:
+        assert key_size == 2, "the reference decodes compressed node sizes into 16-bit slots"
+    ll_bytes = _pack_bits(ll_codes, bits) if bits else ll.astype("<f4").tobytes()
+    gm_bytes = _pack_bits(gm_codes, bits) if bits else gamma.astype("<f4").tobytes()
+
+    def al(x):
+        return (x + 15) & ~15
+    off = 96
+    node_o = off; off = al(off + len(node_bytes))
+    key_o = off; off = al(off + keys.nbytes)
+    ll_o = off; off = al(off + len(ll_bytes))
+    gm_o = off; off = al(off + len(gm_bytes))
+    qt_o = off
+    if bits:
+        off = al(off + 8 * (1 << bits))
+    htx_o = 0
+    if htx is not None:
+        htx_o = off; off = al(off + htx.nbytes)
+    buf = bytearray(off)
+    struct.pack_into("<11Q4BI", buf, 0, num_nodes, node_o, key_o, ll_o, gm_o, qt_o if bits else off if htx is None else qt_o, htx_o,
+                     unk_id, bos_id, eos_id, vocab_size, order, key_size, diff_size, (bits & 0x1F) | (0x80 if compress else 0), 0)
+    buf[node_o:node_o + len(node_bytes)] = node_bytes
+    buf[key_o:key_o + keys.nbytes] = keys.tobytes()
+    buf[ll_o:ll_o + len(ll_bytes)] = ll_bytes
+    buf[gm_o:gm_o + len(gm_bytes)] = gm_bytes
+    if bits:
+        buf[qt_o:qt_o + 4 * (1 << bits)] = ll_tab.tobytes()
+        buf[qt_o + 4 * (1 << bits):qt_o + 8 * (1 << bits)] = gm_tab.tobytes()
+    if htx is not None:
+        buf[htx_o:htx_o + htx.nbytes] = htx.tobytes()
+    return bytes(buf)
+
+
 def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_id=0, eos_id=1) -> bytes:
     """Interpolated Kneser-Ney estimate serialised in the reference's uncompressed,
     unquantised ``sj.knlm`` layout (reader: /root/reference/src/Knlm.hpp:1003-1167; header:

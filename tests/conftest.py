@@ -36,6 +36,20 @@ def small_sbg_model():
     return sm, path
 
 
+@pytest.fixture(scope="session", params=["q8c", "q5"])
+def small_quantised_model(request):
+    """The small synthetic model with its Knlm blob as the reference's builder writes it: 8-bit quantised with compressed node sizes (q8c), or
+    5-bit quantised (q5: the generic fixed-length bit stream) -- kiwi_amd/synth.py quantize_knlm."""
+    from kiwi_amd.synth import SynthModel, SMALL_Q8_SPEC, SMALL_Q5_SPEC
+    d = os.path.join(ROOT, "_data")
+    os.makedirs(d, exist_ok=True)
+    name, spec = {"q8c": ("small-q8", SMALL_Q8_SPEC), "q5": ("small-q5", SMALL_Q5_SPEC)}[request.param]
+    path = os.path.join(d, name + ".raw")
+    sm = SynthModel(spec)
+    sm.raw.save(path)
+    return sm, path, name
+
+
 @pytest.fixture(scope="session")
 def small_cong_model():
     """The small synthetic model plus a local, 8-bit CoNgram model in the reference's cong.mdl layout (kiwi_amd/synth.py SMALL_CONG_SPEC)."""

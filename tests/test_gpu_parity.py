@@ -250,3 +250,16 @@ def test_blocklist_bit_exact_vs_oracle(small_model, small_cong_model, model):
     plain = dev.analyze_batch(texts).to_python()
     assert sum(_norm(orc.analyze(s)) != _norm(y) for s, y in zip(texts[:50], plain[:50])) == 0
     ms.close(); dev.close()
+
+
+def test_quantised_knlm_bit_exact_vs_oracle(small_quantised_model):
+    """A model whose sj.knlm is quantised / compressed as the reference's builder writes it: device vs oracle (= the real reference on that blob)."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path, _ = small_quantised_model
+    orc, dev = oraclelib.OracleKiwi(path), KiwiAmd(path)
+    texts = synthetic(sm, 800, 981, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 400, 982) + EDGE_TEXTS
+    got = dev.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s)) == _norm(y), s
+    dev.close()

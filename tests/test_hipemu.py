@@ -452,3 +452,15 @@ def test_emulated_typo_correction_with_a_cong_model(emu_libs, small_cong_model, 
         corrected += any(x.typo_cost > 0 for x in want[0][0])
     assert corrected >= 5
     dev.close(); prod.close()
+
+
+def test_emulated_kernels_on_a_quantised_knlm(emu_libs, small_quantised_model):
+    """The device path on a model whose Knlm file is quantised / compressed (loader: kiwi_amd/csrc/model.cpp loadKnlm) against the oracle, which
+    equals the real reference reading the same blob (tests/test_oracle_vs_ref.py::test_quantised_knlm_matches_reference)."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path, _ = small_quantised_model
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    _check(dev, orc, synthetic(sm, 60, 971, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 30, 972), top_ns=(1, 2))
+    dev.close()

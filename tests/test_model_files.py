@@ -81,6 +81,27 @@ def test_directory_loader_equals_container_and_reference(small_model, small_sbg_
     a.close(); b.close()
 
 
+def test_quantised_knlm_file_in_a_model_directory(small_quantised_model):
+    """A directory whose sj.knlm is quantised / compressed: the product's directory loader against the reference's own loading of the same files."""
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    from kiwi_amd.api import KiwiAmd
+    emu = os.path.join(HERE, "hipemu", "_build", "libkiwi_hipemu.so")
+    if not os.path.exists(emu):
+        pytest.skip("emulated library not built")
+    sm, path, name = small_quantised_model
+    d = _model_dir(path, name)
+    import struct
+    assert struct.unpack_from("<B", open(os.path.join(d, "sj.knlm"), "rb").read(), 91)[0] != 0      # KnLangModelHeader::quantized
+    dev = KiwiAmd(d, lib_path=emu)
+    ref = refbridge.RefKiwi(d, model_dir_sbg=False)
+    texts = synthetic(sm, 40, 723, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 20, 724)
+    for s, y in zip(texts, dev.analyze_batch(texts).to_python()):
+        assert _norm(ref.analyze(s)) == _norm(y), s
+    dev.close()
+
+
 def _cong_dir(raw_path):
     """A directory like the reference's models/cong/base: sj.morph + cong.mdl and NO sj.knlm."""
     import shutil

@@ -223,3 +223,28 @@ def test_blocklist_matches_reference(oracle, reference, small_model):
         assert changed >= 50
     finally:
         oracle.set_blocklist([]); reference.set_blocklist([])
+
+
+def test_quantised_knlm_matches_reference(small_quantised_model):
+    """sj.knlm as the reference's builder writes it -- log-likelihoods / back-off weights as n-bit codes into two float tables, node sizes in the
+    variable-length QCode (Knlm.hpp:398-455, 1003-1061; src/BitEncoder.hpp, src/QEncoder.hpp): this repo's loader (shared by oracle and product)
+    against KnLangModelBase::create of the real reference on the same blob -- LM steps on random probes, lattices, analyses."""
+    import random
+    import oraclelib
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    sm, path, _ = small_quantised_model
+    orc, ref = oraclelib.OracleKiwi(path), refbridge.RefKiwi(path)
+    rnd = random.Random(3)
+    vocab = sm.raw.vocab_size
+    node_o = node_r = 0
+    for i in range(4000):
+        wid = rnd.randrange(0, vocab) if rnd.random() < 0.6 else rnd.randrange(0, 300)
+        a, b = orc.lm_progress(node_o, wid), ref.lm_progress(node_r, wid)
+        assert a[0] == b[0], (i, wid)
+        node_o, node_r = a[1], b[1]
+        if i % 9 == 8:
+            node_o = node_r = 0
+    for s in synthetic(sm, 300, 961, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 150, 962):
+        assert ref.analyze(s) == orc.analyze(s), s
