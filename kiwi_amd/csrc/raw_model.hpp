@@ -59,8 +59,7 @@ namespace kamd
 			if (n != nMorphs()) throw std::runtime_error{ "raw model: morph size" };
 			chunkIds = c.ptr<uint32_t>("chunk_ids");
 			chunkPos = c.ptr<uint8_t>("chunk_pos");
-			auto s = c.get("knlm");
-			knlm = s.data; knlmSize = s.size;
+			if (c.has("knlm")) { auto s = c.get("knlm"); knlm = s.data; knlmSize = s.size; }      // (a CoNgram-only model has none, like the reference's models/cong/base)
 			if (c.has("sbg")) { auto g = c.get("sbg"); sbg = g.data; sbgSize = g.size; }
 			if (c.has("cong")) { auto g = c.get("cong"); cong = g.data; congSize = g.size; }
 		}

@@ -208,7 +208,7 @@ class RawModel:
             "morph": rec,
             "chunk_ids": np.array(chunk_ids, "<u4"),
             "chunk_pos": np.array(chunk_pos, "u1"),
-            "knlm": np.frombuffer(self.knlm, "u1"),
+            **({"knlm": np.frombuffer(self.knlm, "u1")} if self.knlm else {}),
             **({"sbg": np.frombuffer(self.sbg, "u1")} if self.sbg else {}),
             **({"cong": np.frombuffer(self.cong, "u1")} if getattr(self, "cong", None) else {}),
         }
@@ -302,6 +302,7 @@ class SynthSpec:
     use_sbg: bool = False        # also emit a SkipBigram model (reference skipbigram.mdl layout) over the same vocabulary
     use_cong: bool = False       # also emit a local (window 0), 8-bit CoNgram model (reference cong.mdl layout) over the same vocabulary
     cong_dim: int = 32
+    cong_only: bool = False      # with use_cong: no Knlm blob in the container (the layout of the reference's models/cong/base: sj.morph + cong.mdl)
     seed: int = SEED_BASE
 
 
@@ -315,7 +316,7 @@ SMALL_Q5_SPEC = SynthSpec(knlm_qbits=5)                       # ... and a bit wi
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
 SMALL_CONG_SPEC = SynthSpec(use_cong=True) # same lexicon as SMALL_SPEC + a local CoNgram model (the Knlm blob stays in the container: the dictionary bake needs a vocabulary size)
 FULL_CONG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
-                           n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_cong=True, cong_dim=64)
+                           n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_cong=True, cong_dim=64, cong_only=True)
 
 
 class SynthModel:
@@ -681,6 +682,8 @@ class SynthModel:
             raw.sbg = build_sbg(sents, vocab, key_size=2 if vocab + 1 <= 0xFFFF else 4, seed=sp.seed + 2)
         if sp.use_cong:
             raw.cong = build_cong(sents, vocab, dim=sp.cong_dim, seed=sp.seed + 3)
+            if sp.cong_only:
+                raw.knlm = b""
 
     # -- text corpus -------------------------------------------------------------------------
     def make_corpus(self, n, seed, min_jamo=5, max_jamo=200, exact_jamo=None, oov_rate=0.03, lognormal=None):

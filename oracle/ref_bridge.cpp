@@ -349,7 +349,7 @@ extern "C"
 			Acc::fromRaw(raw, forms, morphemes);
 			const std::string d = dir;
 			{ std::ofstream os{ d + "/sj.morph", std::ios::binary }; Acc::writeMorph(os, forms, morphemes); if (!os) return -2; }
-			{ std::ofstream os{ d + "/sj.knlm", std::ios::binary }; os.write((const char*)raw.knlm, (std::streamsize)raw.knlmSize); if (!os) return -2; }
+			if (raw.knlm) { std::ofstream os{ d + "/sj.knlm", std::ios::binary }; os.write((const char*)raw.knlm, (std::streamsize)raw.knlmSize); if (!os) return -2; }
 			if (raw.sbg) { std::ofstream os{ d + "/skipbigram.mdl", std::ios::binary }; os.write((const char*)raw.sbg, (std::streamsize)raw.sbgSize); if (!os) return -2; }
 			if (raw.cong) { std::ofstream os{ d + "/cong.mdl", std::ios::binary }; os.write((const char*)raw.cong, (std::streamsize)raw.congSize); if (!os) return -2; }
 			return 0;
