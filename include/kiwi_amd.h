@@ -114,6 +114,9 @@ kamd_results_h kamd_analyze_batch_opt(kamd_engine_h h, kamd_typo_h t, float thre
                                       const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts, uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
 /* parity hook: the lattices the device builds OVER the typo graphs of a text's chunks (csrc/typo_lattice_kernel.hip), in the layout of kamd_dump_lattices;
  * 0 + kamd_last_error() on failure */
+/* parity hook of the device typo-graph kernel (the analyze path generates typo graphs on the GPU): kamd_typo_graph's layout + two bytes per
+ * node (type, script of the last character of its form); use_device 0 = the same from the host module */
+size_t kamd_typo_graph_device(kamd_engine_h h, kamd_typo_h t, const uint16_t* text, uint32_t len, int allowed_dialect, int normalize_coda, int use_device, uint8_t* out, size_t cap);
 size_t kamd_typo_lattices(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);
 size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap);
 size_t kamd_dump_lattices(kamd_engine_h h, const uint16_t* text, uint32_t len, uint64_t match_options, uint8_t* out, size_t cap);

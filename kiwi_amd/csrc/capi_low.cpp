@@ -332,6 +332,11 @@ extern "C"
 		if (!h || !t || !t->prepared) { lastError = "invalid handle / typo transformer not prepared"; return nullptr; }
 		return guarded([&]() { auto b = std::make_unique<kamd_batch>(); b->b = h->e->stage(views(texts, offsets, n), match, !!openEnding, hostThreads, TypoOption{ t->prepared.get(), threshold, (uint16_t)allowed_dialect }); return b.release(); }, (kamd_batch*)nullptr);
 	}
+	size_t kamd_typo_graph_device(kamd_engine_h h, kamd_typo* t, const uint16_t* text, uint32_t len, int allowed_dialect, int normalize_coda, int use_device, uint8_t* out, size_t cap)
+	{
+		if (!h || !t || !t->prepared) { lastError = "invalid handle / typo transformer not prepared"; return 0; }
+		return guarded([&]() { auto d = h->e->dumpTypoGraph(*t->prepared, (uint16_t)allowed_dialect, (const char16_t*)text, len, normalize_coda != 0, use_device != 0); if (out && d.size() <= cap) std::memcpy(out, d.data(), d.size()); return d.size(); }, (size_t)0);
+	}
 	size_t kamd_typo_lattices(kamd_engine_h h, kamd_typo* t, float threshold, int allowed_dialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap)
 	{
 		if (!h || !t || !t->prepared) { lastError = "invalid handle / typo transformer not prepared"; return 0; }

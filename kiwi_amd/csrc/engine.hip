@@ -20,6 +20,7 @@
 #include "viterbi_kernel.hpp"
 #include "exact_math.hpp"
 #include "typo_lattice_kernel.hpp"
+#include "typo_graph_kernel.hpp"
 
 namespace kamd
 {
@@ -129,6 +130,28 @@ namespace kamd
 			if (!v.empty()) HIPCHECK(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
 		}
 
+		// the prepared typo transformer's flat tables on the device (typo_graph_kernel.hpp); the sources are members of the PreparedTypo, which
+		// the caller keeps alive for the batch
+		struct TypoGraphDev
+		{
+			DevBuf trie, keys, children, pats, repls, replLast, pool;
+			TypoGraphTables tables{};
+		};
+		void uploadTypoTables(TypoGraphDev& d, const PreparedTypo& T, hipStream_t s)
+		{
+			upload(d.trie, T.trie(), s); upload(d.keys, T.trieKeys(), s); upload(d.children, T.trieChildren(), s);
+			upload(d.pats, T.patterns(), s); upload(d.repls, T.replacements(), s); upload(d.replLast, T.replLast(), s);
+			const std::u16string& pool = T.pool();
+			d.pool.ensure(2 * (pool.size() + 1) + 16);
+			HIPCHECK(hipMemcpyAsync(d.pool.p, pool.c_str(), 2 * (pool.size() + 1), hipMemcpyHostToDevice, s));      // (with the terminating NUL: an empty replacement at the end of the pool reads it)
+			TypoGraphTables& t = d.tables;
+			t.trie = d.trie.as<PreparedTypo::TrieNode>(); t.keys = d.keys.as<uint16_t>(); t.children = d.children.as<uint32_t>();
+			t.pats = d.pats.as<PreparedTypo::Pattern>(); t.repls = d.repls.as<PreparedTypo::Repl>(); t.replLast = d.replLast.as<uint8_t>(); t.pool = d.pool.as<uint16_t>();
+			t.continualCost = T.continualCost(); t.continualOn = std::isfinite(T.continualCost()) ? 1 : 0;
+			t.entryNode = T.entryNode();
+			t.hiType = identifySpecialChr(0xD800); t.hiScript = chr2ScriptType(0xD800); t.loType = identifySpecialChr(0xDC00); t.loScript = chr2ScriptType(0xDC00);
+		}
+
 	}
 
 	struct ChunkRef { uint32_t text, chunk; std::vector<uint8_t> sp; bool openEnding; };
@@ -154,6 +177,7 @@ namespace kamd
 		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
 		TypoOption typo;
+		TypoGraphDev typoDev;
 		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder, dBlockBits;
 		TypoLatView tv{};
 		DevBuf dPacks, dStates, dNodeStOff, dNodeStCnt, dReach, dTokens, dResults, dOrder;
@@ -439,76 +463,84 @@ namespace kamd
 		b.subBatches = 0;
 		if (b.typo.typo)
 		{
-			// typo graphs on the host (typo.cpp), one record per chunk for k_build_lattice_typo (engine mode)
+			// typo graphs on the DEVICE (typo_graph_kernel.hip; row f3): a count pass over the text block that is already on its way, the counts
+			// come back (the state arenas and the LDS size classes of the lattice build are laid out from them), then the write pass into exactly
+			// sized regions.  The host keeps PreparedTypo::graph for the parity hooks only.
 			const PreparedTypo& T = *b.typo.typo;
-			std::vector<TypoLatChunk> tch(nC); std::vector<TypoGraphNode> graph; std::vector<uint8_t> glast;
-			// graphs of kGraphBlock consecutive chunks per host task (each task appends to its own vectors), then one pass that lays the
-			// per-chunk regions out and concatenates
-			constexpr size_t kGraphBlock = 32;
-			const size_t nBlocks = (nC + kGraphBlock - 1) / kGraphBlock;
-			std::vector<std::vector<TypoGraphNode>> bGraph(nBlocks); std::vector<std::vector<uint8_t>> bLast(nBlocks);
-			HostPool::instance().run(nBlocks, 1, b.hostThreads, [&](size_t b0, size_t b1, int)
+			if (T.maxCtiBound() > kTypoMaxContinual + 1) throw std::runtime_error{ "kiwi_amd: a typo pattern with more than 32 distinct continual replacements is not supported" };
+			std::vector<TypoLatChunk> tch(nC); std::vector<TypoGraphChunk> gch(nC);
+			HostPool::instance().run(nC, 256, b.hostThreads, [&](size_t c0, size_t c1, int)
 			{
-				std::vector<TypoGraphNode> g;
-				for (size_t bi = b0; bi < b1; ++bi)
-				for (size_t c = bi * kGraphBlock, ce = std::min(nC, c + kGraphBlock); c < ce; ++c)
+				for (size_t c = c0; c < c1; ++c)
 				{
 					const auto& r = b.refs[c];
 					const PreparedView& pt = b.prep[r.text];
 					const ChunkDesc& d = pt.chunks[r.chunk];
 					const char16_t* str = (const char16_t*)pt.norm.data() + d.startOffset;
-					const size_t maxCti = T.graph(str, d.nChars, b.typo.allowedDialect, g);
 					TypoLatChunk& t = tch[c];
 					t = TypoLatChunk{};
 					t.charOff = b.charOff[c]; t.nChars = d.nChars; t.textOffset = d.startOffset; t.chunkId = (uint32_t)c;
 					t.patOff = b.patOff[c]; t.patCnt = b.patOff[c + 1] - b.patOff[c];
-					t.graphCnt = (uint32_t)g.size();
-					for (auto& gn : g)
-					{
-						uint32_t lastC = 0; bool any = false;
-						const std::u16string f = T.formOf(gn, str);
-						for (size_t j = 0; j < f.size(); ++j)
-						{
-							uint32_t c32 = f[j];
-							if (isHighSurrogate(c32) && j + 1 < f.size()) { c32 = mergeSurrogate(c32, f[j + 1]); ++j; }
-							lastC = c32; any = true;
-						}
-						bLast[bi].push_back((any && lastC) ? identifySpecialChr(lastC) : (uint8_t)0xFF);
-						bLast[bi].push_back((any && lastC) ? chr2ScriptType(lastC) : (uint8_t)0);
-						bGraph[bi].push_back(gn);
-					}
-					if (maxCti > 1) { size_t v = maxCti - 1; while (v > 0) { v >>= 1; ++t.pmb; } }
 					for (uint32_t i = 0; i < d.nChars; ++i) if (!isSpace(str[i])) { ++t.nNs; if (isHighSurrogate(str[i]) && i + 1 < d.nChars) { ++t.nNs; ++i; } }
 					t.nodeOff = b.nodeBase[c]; t.nodeCap = b.nodeBase[c + 1] - b.nodeBase[c]; t.packCap = b.packBase[c + 1] - b.packBase[c];
-					t.mapLen = (t.nNs << t.pmb) + 1;
-					t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.nodeCap).total;
 				}
 			});
+			TypoGraphDev& gd = b.typoDev;      // (the lattice build reads replacement strings from the pool uploaded here: it lives as long as the batch)
+			uploadTypoTables(gd, T, s);
+			uint64_t scrTop = 0;
+			for (size_t c = 0; c < nC; ++c)
+			{
+				gch[c] = TypoGraphChunk{ tch[c].charOff, tch[c].nChars, 0, 0, (uint32_t)scrTop, T.scratchCapFor(tch[c].nChars, 0) };
+				scrTop += gch[c].scrCap;
+				if (scrTop > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit typo scratch offsets: split the batch" };
+			}
+			std::vector<TypoGraphOut> gout(nC);
+			DevBuf dGch, dGout, dMatches, dBp, dEpm, dRev, dCnt, dTemp;
+			TypoGraphView gv{};
+			gv.chars = bv.chars; gv.cls = bv.cls; gv.script = bv.script; gv.allowedDialect = b.typo.allowedDialect;
+			upload(dGch, gch, s); dGout.ensure(nC * sizeof(TypoGraphOut) + 16);
+			dMatches.ensure(scrTop * 8 + 16); dBp.ensure(scrTop * 4 + 16); dEpm.ensure(scrTop * 8 + 16);
+			gv.chunks = dGch.as<TypoGraphChunk>(); gv.out = dGout.as<TypoGraphOut>(); gv.matches = dMatches.as<uint2>(); gv.bp = dBp.as<uint32_t>(); gv.epm = dEpm.as<uint2>();
+			launchTypoGraph(gd.tables, gv, (uint32_t)nC, true, s);
+			HIPCHECK(hipGetLastError());
+			HIPCHECK(hipMemcpyAsync(gout.data(), dGout.p, nC * sizeof(TypoGraphOut), hipMemcpyDeviceToHost, s));
+			HIPCHECK(hipStreamSynchronize(s));
 			uint64_t mapTop = 0, nsTop = 0, stateTop = 0, graphTop = 0;
+			scrTop = 0;
 			for (size_t c = 0; c < nC; ++c)
 			{
 				TypoLatChunk& t = tch[c];
+				if (gout[c].status) throw std::runtime_error{ "kiwi_amd: typo graph kernel status " + std::to_string(gout[c].status) + (gout[c].status == 3 ? " (a typo pattern with an explicit NUL)" : "") };
+				t.graphCnt = gout[c].graphCnt;
+				if (gout[c].maxCti > 1) { size_t v = gout[c].maxCti - 1; while (v > 0) { v >>= 1; ++t.pmb; } }
+				t.mapLen = (t.nNs << t.pmb) + 1;
+				t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.nodeCap).total;
 				t.graphOff = (uint32_t)graphTop; graphTop += t.graphCnt;
 				t.mapOff = (uint32_t)mapTop; mapTop += t.mapLen;
 				t.nsOff = (uint32_t)nsTop; nsTop += t.nChars + 2;
 				t.stateOff = (uint32_t)stateTop; t.stateCap = (uint32_t)std::min<uint64_t>(((uint64_t)t.graphCnt * 16 + 64) * sc, 0x7FFFFFFF); stateTop += t.stateCap;
-				if (mapTop > 0xFFFFFFF0ull || stateTop > 0xFFFFFFF0ull || graphTop > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit typo scratch offsets: split the batch" };
+				gch[c].graphOff = t.graphOff; gch[c].graphCap = t.graphCnt; gch[c].scrOff = (uint32_t)scrTop; gch[c].scrCap = T.scratchCapFor(t.nChars, t.graphCnt);
+				scrTop += gch[c].scrCap;
+				if (mapTop > 0xFFFFFFF0ull || stateTop > 0xFFFFFFF0ull || graphTop > 0xFFFFFFF0ull || scrTop > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit typo scratch offsets: split the batch" };
 			}
-			graph.reserve(graphTop); glast.reserve(2 * graphTop);
-			for (size_t bi = 0; bi < nBlocks; ++bi) { graph.insert(graph.end(), bGraph[bi].begin(), bGraph[bi].end()); glast.insert(glast.end(), bLast[bi].begin(), bLast[bi].end()); }
-			std::vector<uint16_t> pool(T.pool().begin(), T.pool().end());
-			if (pool.empty()) pool.push_back(0);
-			if (graph.empty()) graph.push_back(TypoGraphNode{});
-			if (glast.empty()) glast.assign(2, 0);
 			b.typoNeed.resize(nC); for (size_t c = 0; c < nC; ++c) b.typoNeed[c] = tch[c].ldsNeed;
-			upload(b.dTypoGraph, graph, s); upload(b.dTypoLast, glast, s); upload(b.dTypoPool, pool, s); upload(b.dTypoChunks, tch, s);
+			const size_t graphSize = std::max<uint64_t>(graphTop, 1);
+			b.dTypoGraph.ensure(graphSize * sizeof(TypoGraphNode) + 64); b.dTypoLast.ensure(graphSize * 2 + 64);
+			dTemp.ensure(graphSize * sizeof(TypoGraphNode) + 64);
+			dMatches.ensure(scrTop * 8 + 16); dBp.ensure(scrTop * 4 + 16); dEpm.ensure(scrTop * 8 + 16); dRev.ensure(scrTop * 4 + 16); dCnt.ensure(scrTop * 4 + 16);
+			upload(dGch, gch, s);
+			gv.chunks = dGch.as<TypoGraphChunk>(); gv.matches = dMatches.as<uint2>(); gv.bp = dBp.as<uint32_t>(); gv.epm = dEpm.as<uint2>(); gv.rev = dRev.as<uint32_t>(); gv.cnt = dCnt.as<uint32_t>();
+			gv.graph = b.dTypoGraph.as<TypoGraphNode>(); gv.graphLast = b.dTypoLast.as<uint8_t>(); gv.temp = dTemp.as<TypoGraphNode>();
+			launchTypoGraph(gd.tables, gv, (uint32_t)nC, false, s);
+			HIPCHECK(hipGetLastError());
+			upload(b.dTypoChunks, tch, s);
 			b.dTypoTmp.ensure(totNodes * sizeof(TypoLatNode) + 64); b.dTypoMap.ensure(mapTop * 8 + 64); b.dTypoNs.ensure(nsTop * 2 + 64); b.dTypoPs.ensure(nsTop * 2 + 64);
-			b.dTypoStates.ensure(stateTop * sizeof(TypoState) + 64); b.dTypoSIdx.ensure(graph.size() * 8 + 64); b.dTypoScratch.ensure(totNodes * 12 + 64);
+			b.dTypoStates.ensure(stateTop * sizeof(TypoState) + 64); b.dTypoSIdx.ensure(graphSize * 8 + 64); b.dTypoScratch.ensure(totNodes * 12 + 64);
 			b.dNodeTypo.ensure(totNodes * 4 + 64);
 			TypoLatView& v = b.tv;
 			v = TypoLatView{};
 			v.chars = bv.chars; v.cls = bv.cls; v.script = bv.script; v.patterns = bv.patterns;
-			v.graph = b.dTypoGraph.as<TypoGraphNode>(); v.graphLast = b.dTypoLast.as<uint8_t>(); v.pool = b.dTypoPool.as<uint16_t>(); v.chunks = b.dTypoChunks.as<TypoLatChunk>();
+			v.graph = b.dTypoGraph.as<TypoGraphNode>(); v.graphLast = b.dTypoLast.as<uint8_t>(); v.pool = gd.tables.pool; v.chunks = b.dTypoChunks.as<TypoLatChunk>();
 			v.nodes = b.dTypoTmp.as<TypoLatNode>(); v.nodesFinal = nullptr; v.endPosMap = b.dTypoMap.as<uint2>(); v.nsToPos = b.dTypoNs.as<uint16_t>(); v.posToNs = b.dTypoPs.as<uint16_t>();
 			v.states = b.dTypoStates.as<TypoState>(); v.stateIdx = b.dTypoSIdx.as<uint32_t>(); v.scratch = b.dTypoScratch.as<uint32_t>();
 			v.devNodes = w.nodes; v.nodeTypo = b.dNodeTypo.as<float>(); v.nNodes = w.nNodes; v.results = w.results;
@@ -1177,6 +1209,76 @@ namespace kamd
 			++ri;
 		}
 		return out;
+	}
+
+	// Parity hook of typo_graph_kernel.hip: the typo graph of a whole text (normalised, taken as one chunk) in the layout of kamd_typo_graph, followed
+	// by two bytes per node ({type, script} of the last character of its form); useDevice: from the kernel's two passes, else from the host module.
+	std::vector<uint8_t> Engine::dumpTypoGraph(const PreparedTypo& typo, uint16_t allowedDialect, const char16_t* text, size_t n, bool normCoda, bool useDevice)
+	{
+		PreparedText pt;
+		prepareText(pt, text, n, normCoda ? (uint64_t)M_NORMALIZE_CODA : 0, 0);
+		const uint32_t L = (uint32_t)pt.norm.size();
+		std::vector<TypoGraphNode> g; std::vector<uint8_t> last; size_t maxIdx = 0;
+		if (!useDevice)
+		{
+			maxIdx = typo.graph((const char16_t*)pt.norm.data(), L, allowedDialect, g);
+			last.resize(2 * g.size());
+			for (size_t i = 0; i < g.size(); ++i) typo.lastOf(g[i], (const char16_t*)pt.norm.data(), &last[2 * i]);
+		}
+		else
+		{
+			std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+			HIPCHECK(hipSetDevice(impl->device));
+			hipStream_t s = impl->stream;
+			std::vector<uint16_t> chars(pt.norm.begin(), pt.norm.end());
+			DevBuf dChars, dCls, dScript, dGch, dGout, dMatches, dBp, dEpm, dRev, dCnt, dTemp, dGraph, dLast;
+			TypoGraphDev gd;
+			uploadTypoTables(gd, typo, s);
+			upload(dChars, chars, s); upload(dCls, pt.cls, s); upload(dScript, pt.script, s);
+			std::vector<TypoGraphChunk> gch(1, TypoGraphChunk{ 0, L, 0, 0, 0, typo.scratchCapFor(L, 0) });
+			upload(dGch, gch, s); dGout.ensure(64);
+			dMatches.ensure((size_t)gch[0].scrCap * 8 + 16); dBp.ensure((size_t)gch[0].scrCap * 4 + 16); dEpm.ensure((size_t)gch[0].scrCap * 8 + 16);
+			TypoGraphView gv{};
+			gv.chars = dChars.as<uint16_t>(); gv.cls = dCls.as<uint8_t>(); gv.script = dScript.as<uint8_t>(); gv.allowedDialect = allowedDialect;
+			gv.chunks = dGch.as<TypoGraphChunk>(); gv.out = dGout.as<TypoGraphOut>(); gv.matches = dMatches.as<uint2>(); gv.bp = dBp.as<uint32_t>(); gv.epm = dEpm.as<uint2>();
+			launchTypoGraph(gd.tables, gv, 1, true, s);
+			HIPCHECK(hipGetLastError());
+			TypoGraphOut out{};
+			HIPCHECK(hipMemcpyAsync(&out, dGout.p, sizeof(out), hipMemcpyDeviceToHost, s));
+			HIPCHECK(hipStreamSynchronize(s));
+			if (out.status) throw std::runtime_error{ "typo graph kernel (count pass): status " + std::to_string(out.status) };
+			const uint32_t cnt = out.graphCnt;
+			gch[0].graphCap = cnt; gch[0].scrCap = typo.scratchCapFor(L, cnt);
+			upload(dGch, gch, s);
+			const size_t sc = gch[0].scrCap;
+			dMatches.ensure(sc * 8 + 16); dBp.ensure(sc * 4 + 16); dEpm.ensure(sc * 8 + 16); dRev.ensure(sc * 4 + 16); dCnt.ensure(sc * 4 + 16);
+			dTemp.ensure((size_t)cnt * sizeof(TypoGraphNode) + 64); dGraph.ensure((size_t)cnt * sizeof(TypoGraphNode) + 64); dLast.ensure((size_t)cnt * 2 + 64);
+			gv.chunks = dGch.as<TypoGraphChunk>(); gv.matches = dMatches.as<uint2>(); gv.bp = dBp.as<uint32_t>(); gv.epm = dEpm.as<uint2>(); gv.rev = dRev.as<uint32_t>(); gv.cnt = dCnt.as<uint32_t>();
+			gv.temp = dTemp.as<TypoGraphNode>(); gv.graph = dGraph.as<TypoGraphNode>(); gv.graphLast = dLast.as<uint8_t>();
+			launchTypoGraph(gd.tables, gv, 1, false, s);
+			HIPCHECK(hipGetLastError());
+			g.resize(cnt); last.resize(2 * (size_t)cnt);
+			TypoGraphOut out2{};
+			HIPCHECK(hipMemcpyAsync(&out2, dGout.p, sizeof(out2), hipMemcpyDeviceToHost, s));
+			if (cnt) { HIPCHECK(hipMemcpyAsync(g.data(), dGraph.p, (size_t)cnt * sizeof(TypoGraphNode), hipMemcpyDeviceToHost, s)); HIPCHECK(hipMemcpyAsync(last.data(), dLast.p, 2 * (size_t)cnt, hipMemcpyDeviceToHost, s)); }
+			HIPCHECK(hipStreamSynchronize(s));
+			if (out2.status || out2.graphCnt != cnt || out2.maxCti != out.maxCti) throw std::runtime_error{ "typo graph kernel (write pass): status " + std::to_string(out2.status) + ", the two passes disagree" };
+			maxIdx = out.maxCti;
+		}
+		std::vector<uint8_t> o;
+		auto put = [&](const void* v, size_t nb) { const uint8_t* q = (const uint8_t*)v; o.insert(o.end(), q, q + nb); };
+		auto put32 = [&](uint32_t v) { put(&v, 4); };
+		put32(L); put(pt.norm.data(), 2 * (size_t)L);
+		put32((uint32_t)g.size());
+		for (auto& nd : g)
+		{
+			const std::u16string f = typo.formOf(nd, (const char16_t*)pt.norm.data());
+			put32((uint32_t)f.size()); put(f.data(), 2 * f.size());
+			put32(nd.endPos); put(&nd.typoCost, 4); put32(nd.prevOffset); put32(nd.siblingOffset); put(&nd.continualTypoIdx, 1); put(&nd.dialect, 2);
+		}
+		put32((uint32_t)maxIdx);
+		put(last.data(), last.size());
+		return o;
 	}
 
 	// Parity hook: typo graphs on the host (typo.cpp), the lattice over each of them by k_build_lattice_typo, dumped like dumpLattices.

@@ -94,5 +94,8 @@ namespace kamd
 		// ... and the lattices built over the typo graphs a prepared transformer gives for the chunks (typo_lattice_kernel.hip); same layout.
 		// Parity hook of a building block: analyze does not take typo transformers yet.
 		std::vector<uint8_t> dumpTypoLattices(const PreparedTypo& typo, float threshold, uint16_t allowedDialect, const char16_t* text, size_t n, uint64_t match);
+		// ... and the typo graph itself, from the device kernel the analyze path uses (typo_graph_kernel.hip) or from the host module: layout of
+		// kamd_typo_graph + two bytes per node (type and script of the last character of its form)
+		std::vector<uint8_t> dumpTypoGraph(const PreparedTypo& typo, uint16_t allowedDialect, const char16_t* text, size_t n, bool normCoda, bool useDevice);
 	};
 }

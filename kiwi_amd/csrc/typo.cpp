@@ -4,6 +4,8 @@
 #include <numeric>
 #include <stdexcept>
 #include "typo.hpp"
+#include "hostutil.hpp"
+#include "textprep.hpp"
 
 namespace kamd
 {
@@ -29,30 +31,7 @@ namespace kamd
 			}
 			return o;
 		}
-		// FeatureTestor::isMatched(begin, end, CondVowel) (src/FeatureTestor.cpp:6-60) on the prefix [0, n) of s
-		bool leftCondMatched(const char16_t* s, size_t n, uint8_t cond)
-		{
-			if (cond == TC_NONE) return true;
-			if (n == 0) return false;
-			if (cond == TC_ANY) return true;
-			const char16_t l = s[n - 1];
-			if (cond == TC_APPLOSIVE)
-			{
-				switch (l) { case 0x11A8: case 0x11A9: case 0x11AA: case 0x11AE: case 0x11B8: case 0x11B9: case 0x11BA: case 0x11BB: case 0x11BD: case 0x11BE: case 0x11BF: case 0x11C0: case 0x11C1: return true; default: return false; }
-			}
-			if (!(0xAC00 <= l && l <= 0xD7A4) && !(0x11A8 <= l && l <= 0x11C2)) return true;
-			const bool coda = 0x11A8 <= l && l <= 0x11C2;
-			switch (cond)
-			{
-			case TC_VOCALIC_H: if (l == 0x11C2) return true; [[fallthrough]];
-			case TC_VOCALIC: if (l == 0x11AF) return true; [[fallthrough]];
-			case TC_VOWEL: return !coda;
-			case TC_NON_VOCALIC_H: if (l == 0x11C2) return false; [[fallthrough]];
-			case TC_NON_VOCALIC: if (l == 0x11AF) return false; [[fallthrough]];
-			case TC_NON_VOWEL: return !(0xAC00 <= l && l <= 0xD7A4);
-			default: return false;
-			}
-		}
+		inline bool leftCondMatched(const char16_t* s, size_t n, uint8_t cond) { return typoLeftCondMatched((const uint16_t*)s, n, cond); }
 	}
 
 	size_t TypoTransformer::KeyHash::operator()(const Key& k) const
@@ -262,6 +241,62 @@ namespace kamd
 			if (v == 0 || trie_[v].pattern >= 0) continue;
 			for (int f = trie_[v].fail; f > 0; f = trie_[f].fail) if (trie_[f].pattern >= 0) { trie_[v].pattern = -2; break; }
 		}
+		// what the device graph kernel needs beside the tables: the last-character facts of every replacement string, and its capacity bounds
+		auto lastOfStr = [](const char16_t* f, size_t n, uint8_t out[2])
+		{
+			uint32_t lastC = 0; bool any = false;
+			for (size_t j = 0; j < n; ++j)
+			{
+				uint32_t c32 = f[j];
+				if (isHighSurrogate(c32) && j + 1 < n) { c32 = mergeSurrogate(c32, f[j + 1]); ++j; }
+				lastC = c32; any = true;
+			}
+			out[0] = (any && lastC) ? identifySpecialChr(lastC) : (uint8_t)0xFF;
+			out[1] = (any && lastC) ? chr2ScriptType(lastC) : (uint8_t)0;
+		};
+		replLast_.assign(6 * repls_.size(), 0);
+		for (size_t i = 0; i < repls_.size(); ++i)
+		{
+			const char16_t* f = pool_.data() + repls_[i].strOff; const size_t n = repls_[i].strLen;
+			lastOfStr(f, n, &replLast_[6 * i]); lastOfStr(f, n ? 1 : 0, &replLast_[6 * i + 2]); lastOfStr(f + (n ? 1 : 0), n ? n - 1 : 0, &replLast_[6 * i + 4]);
+		}
+		for (size_t v = 0; v < trie_.size(); ++v)
+		{
+			uint32_t per = 0;
+			for (int32_t sub = (int32_t)v; sub >= 0; sub = trie_[sub].fail)
+			{
+				if (trie_[sub].pattern == -1) break;
+				if (trie_[sub].pattern < 0) continue;
+				++per;
+			}
+			matchesPerEnd_ = std::max(matchesPerEnd_, per);
+		}
+		for (auto& p : pats_)
+		{
+			std::vector<char16_t> firsts;
+			for (uint32_t ri = 0; ri < p.replCnt; ++ri)
+			{
+				const Repl& r = repls_[p.replOff + ri];
+				if (r.cond != TC_CONTINUAL && r.cond != TC_BOUNDARY) continue;
+				const char16_t c = pool_[r.strOff];      // (as graph() reads it: the unit at strOff even of an empty replacement)
+				if (std::find(firsts.begin(), firsts.end(), c) == firsts.end()) firsts.push_back(c);
+			}
+			maxCtiBound_ = std::max<uint32_t>(maxCtiBound_, (uint32_t)firsts.size() + 1);
+		}
+	}
+
+	void PreparedTypo::lastOf(const TypoGraphNode& gn, const char16_t* str, uint8_t out[2]) const
+	{
+		uint32_t lastC = 0; bool any = false;
+		const std::u16string f = formOf(gn, str);
+		for (size_t j = 0; j < f.size(); ++j)
+		{
+			uint32_t c32 = f[j];
+			if (isHighSurrogate(c32) && j + 1 < f.size()) { c32 = mergeSurrogate(c32, f[j + 1]); ++j; }
+			lastC = c32; any = true;
+		}
+		out[0] = (any && lastC) ? identifySpecialChr(lastC) : (uint8_t)0xFF;
+		out[1] = (any && lastC) ? chr2ScriptType(lastC) : (uint8_t)0;
 	}
 
 	int32_t PreparedTypo::step(int32_t node, char16_t c) const

@@ -83,6 +83,21 @@ namespace kamd
 		size_t graph(const char16_t* str, size_t n, uint16_t allowedDialect, std::vector<TypoGraphNode>& out) const;
 		std::u16string formOf(const TypoGraphNode& g, const char16_t* str) const;
 
+		// {type, script} of the last character of a graph node's form as the lattice build wants them (type 0xFF: empty form or NUL = "none"):
+		// identifySpecialChr / chr2ScriptType of the last code point, surrogate pairs merged inside the form
+		void lastOf(const TypoGraphNode& g, const char16_t* str, uint8_t out[2]) const;
+
+		// bounds the device graph kernel (typo_graph_kernel.hip) sizes its working regions with: patterns that can end at ONE text position
+		// (the longest chain of pattern-bearing suffixes in the automaton), and max(continual typo index) + 1 over any cluster
+		uint32_t matchesPerEndBound() const { return matchesPerEnd_; }
+		uint32_t maxCtiBound() const { return maxCtiBound_; }
+		// entries of the small per-chunk working arrays: a cluster's matches + break points, the end-position index (nChars + 2), and in the
+		// write pass one slot per graph node
+		uint32_t scratchCapFor(uint32_t nChars, uint32_t graphCnt) const { const uint32_t a = nChars * matchesPerEnd_ + 4, b = nChars + 4; const uint32_t m = a > b ? a : b; return m > graphCnt ? m : graphCnt; }
+		int32_t entryNode() const { return step(0, 0); }
+		// per replacement 6 bytes: {type, script} of the last character of the whole string, of its first unit alone, of the string without its first unit
+		const std::vector<uint8_t>& replLast() const { return replLast_; }
+
 		// flat tables (device upload)
 		const std::vector<TrieNode>& trie() const { return trie_; }
 		const std::vector<uint16_t>& trieKeys() const { return keys_; }
@@ -95,6 +110,37 @@ namespace kamd
 		int32_t step(int32_t node, char16_t c) const;
 		std::vector<TrieNode> trie_; std::vector<uint16_t> keys_; std::vector<uint32_t> children_;
 		std::vector<Pattern> pats_; std::vector<Repl> repls_; std::u16string pool_;
+		std::vector<uint8_t> replLast_; uint32_t matchesPerEnd_ = 0, maxCtiBound_ = 1;
 		float continualCost_ = INFINITY, lengtheningCost_ = INFINITY;
 	};
+
+	// FeatureTestor::isMatched(begin, end, CondVowel) (src/FeatureTestor.cpp:6-60) on the prefix [0, n) of s -- host and device
+#if defined(__HIPCC__) || defined(__HIP__)
+#define KAMD_TYPO_HD __host__ __device__ inline
+#else
+#define KAMD_TYPO_HD inline
+#endif
+	KAMD_TYPO_HD bool typoLeftCondMatched(const uint16_t* s, size_t n, uint8_t cond)
+	{
+		if (cond == TC_NONE) return true;
+		if (n == 0) return false;
+		if (cond == TC_ANY) return true;
+		const uint16_t l = s[n - 1];
+		if (cond == TC_APPLOSIVE)
+		{
+			switch (l) { case 0x11A8: case 0x11A9: case 0x11AA: case 0x11AE: case 0x11B8: case 0x11B9: case 0x11BA: case 0x11BB: case 0x11BD: case 0x11BE: case 0x11BF: case 0x11C0: case 0x11C1: return true; default: return false; }
+		}
+		if (!(0xAC00 <= l && l <= 0xD7A4) && !(0x11A8 <= l && l <= 0x11C2)) return true;
+		const bool coda = 0x11A8 <= l && l <= 0x11C2;
+		switch (cond)
+		{
+		case TC_VOCALIC_H: if (l == 0x11C2) return true; [[fallthrough]];
+		case TC_VOCALIC: if (l == 0x11AF) return true; [[fallthrough]];
+		case TC_VOWEL: return !coda;
+		case TC_NON_VOCALIC_H: if (l == 0x11C2) return false; [[fallthrough]];
+		case TC_NON_VOCALIC: if (l == 0x11AF) return false; [[fallthrough]];
+		case TC_NON_VOWEL: return !(0xAC00 <= l && l <= 0xD7A4);
+		default: return false;
+		}
+	}
 }

@@ -73,3 +73,11 @@ def test_typo_correction_with_a_cong_model(small_cong_model, monkeypatch, lanes,
         corrected += any(x.typo_cost > 0 for x in want[0][0])
     assert corrected >= 50
     dev.close(); prod.close()
+
+
+def test_device_typo_graphs_equal_the_host_module(small_model):
+    """k_typo_graph (typo_graph_kernel.hip: the graphs the analyze path builds its lattices over, count pass + write pass) against the host
+    module's graphs -- byte-identical to the real reference's (tests/test_typo_product.py) -- for the repo's own rules in both directions,
+    every built-in set, dialect masks; node records, links, continual indices and the last-character facts the lattice build reads."""
+    from test_hipemu import check_device_typo_graphs
+    check_device_typo_graphs(LIB, small_model[1], n_random=400)

@@ -464,3 +464,74 @@ def test_emulated_kernels_on_a_quantised_knlm(emu_libs, small_quantised_model):
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     _check(dev, orc, synthetic(sm, 60, 971, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 30, 972), top_ns=(1, 2))
     dev.close()
+
+
+def _graph_bytes(dev, typo, text, dialect, norm_coda, use_device):
+    import ctypes as C
+    import numpy as np
+    L = dev.lib
+    L.kamd_typo_graph_device.restype = C.c_size_t
+    L.kamd_typo_graph_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+    need = L.kamd_typo_graph_device(dev.h, typo.h, u.ctypes.data, len(u), dialect, int(norm_coda), int(use_device), None, 0)
+    assert need, dev.last_error() if hasattr(dev, "last_error") else "kamd_typo_graph_device failed"
+    buf = np.zeros(need, np.uint8)
+    assert L.kamd_typo_graph_device(dev.h, typo.h, u.ctypes.data, len(u), dialect, int(norm_coda), int(use_device), buf.ctypes.data, need) == need
+    return buf.tobytes()
+
+
+def check_device_typo_graphs(lib, model_path, n_random=150):
+    """Shared with tests/test_gpu_typo.py: the typo graphs of k_typo_graph (count pass + write pass; the graphs the analyze path uses) equal the
+    host module's -- which tests/test_typo_product.py pins to the real reference byte for byte -- node for node, links, costs, continual
+    indices, dialects, and the type / script of every node's last character, for this repo's own rule set (both directions, with and without
+    continual typos, dialect masks) and every built-in set, on texts dense in the patterns, misspelt sentences, supplementary-plane
+    characters and empty input."""
+    import ctypes as C
+    import random
+    import test_typo_product
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import COND, INF, RULES, misspell, texts
+    test_typo_product.LIB = lib
+    dev = KiwiAmd(model_path, lib_path=lib)
+    rnd = random.Random(11)
+    corpus = texts(n_random, 77) + ["😀안돼 𠀀됬어 😀", "a😀", "\ud83d", "됬\ud83d어", " ", "가" * 70, "됬어요 " * 12]
+    corpus += [misspell(t, rnd, True, True) for t in texts(30, 78)]
+    n_nodes = n_pool = 0
+    cases = []
+    for inverse in (True, False):
+        for cont in (INF, 1.0):
+            prod = test_typo_product.ProductTypo(cont, 0.25 if cont != INF else INF)
+            for origs, errs, cost, cond, dia in RULES:
+                for o in origs:
+                    for e in errs:
+                        assert prod.add(o, e, cost, COND[cond], dia) == 0
+            prod.prepare(inverse)
+            cases.append((prod, (0, 8, 0xFFFF)))
+    prod0 = test_typo_product.ProductTypo()
+    prod0.lib.kamd_typo_default.restype = C.c_void_p
+    prod0.lib.kamd_typo_default.argtypes = [C.c_int]
+    for k in range(7):
+        p = test_typo_product.ProductTypo(); p.close()
+        p.h = prod0.lib.kamd_typo_default(k)
+        assert p.h
+        p.prepare(True)
+        cases.append((p, (0xFFFF,) if k == 6 else (0,)))
+    prod0.close()
+    for prod, dialects in cases:
+        for dia in dialects:
+            for t in corpus:
+                for nc in (True, False) if len(t) < 12 else (True,):
+                    host = _graph_bytes(dev, prod, t, dia, nc, False)
+                    assert _graph_bytes(dev, prod, t, dia, nc, True) == host, (dia, nc, t)
+                    n_nodes += 1
+        # ... and the hook's host side is kamd_typo_graph itself plus the last-character bytes
+        t = corpus[1]
+        base = prod.graph_bytes(t, dialects[0], True)
+        assert _graph_bytes(dev, prod, t, dialects[0], True, False)[:len(base)] == base
+        prod.close()
+    assert n_nodes > 1000
+    dev.close()
+
+
+def test_emulated_typo_graph_kernel_matches_host_module(emu_libs, small_model):
+    check_device_typo_graphs(emu_libs[0], small_model[1])
