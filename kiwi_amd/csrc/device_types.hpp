@@ -167,7 +167,7 @@ namespace kamd
 	};
 
 	// CoNgram model on the device (flat_model.hpp CongView): embedding rows of dim x s8 + f32 scale + f32 bias (context) / f32 scale + 4 unused bytes (output)
-	struct CongDev { const uint8_t* ctxEmb; const uint8_t* outEmb; uint32_t dim, stride; };
+	struct CongDev { const uint8_t* ctxEmb; const uint8_t* outEmb; uint32_t dim, stride; uint32_t vlTMax, vlBits; };      // vlTMax / vlBits: CongView (variable-length trie keys; 0xFFFFFFFF = none)
 
 	// LDS layout of the wave-per-chunk lattice build (byte offsets): n text units, node capacity, packed-match capacity
 	struct LatticeLds { uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, endPosMap, fullMask, zAt, mforms, mfrec, out, spaceErr, queue, total; };

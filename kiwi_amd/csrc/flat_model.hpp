@@ -171,6 +171,10 @@ namespace kamd
 		const uint8_t* ctxEmb = nullptr; const uint8_t* outEmb = nullptr;
 		// host-side walk (oracle, bake); the device walks the edge hash that is uploaded in place of the Knlm one
 		const CongNodeRec* nodes = nullptr; const uint32_t* keys = nullptr; const int32_t* values = nullptr; const int32_t* root = nullptr;
+		uint32_t rootSize = 0;
+		// variable-length keys (cong.mdl keySize 3): a word id >= vlTMax is spelt as the two trie keys vlTMax + (r >> vlBits) and
+		// vlTMax + (1 << vlBits) + (r & mask), r = id - vlTMax (CoNgramModel::progressContextNode, src/CoNgramModel.hpp:271-300); 0xFFFFFFFF = no such ids
+		uint32_t vlTMax = 0xFFFFFFFFu, vlBits = 0;
 		bool present() const { return dim != 0; }
 	};
 	// the score of word `w` in context `c` (one fp32 conversion, two multiplications, one addition, in this order: CoNgramModel.cpp:886-894)
@@ -227,13 +231,13 @@ namespace kamd
 		// `ll` bits, root table, per-node suffix link), embeddings
 		std::vector<CongNodeRec> congNodes; std::vector<uint32_t> congKeys; std::vector<int32_t> congValues, congRoot;
 		std::vector<LmSlot> congHash; uint32_t congHashMask = 0; std::vector<LmRootRec> congRoot2; std::vector<LmBackoff> congBackoff;
-		std::vector<uint8_t> congCtxEmb, congOutEmb; uint32_t congDim = 0, congCtx = 0;
+		std::vector<uint8_t> congCtxEmb, congOutEmb; uint32_t congDim = 0, congCtx = 0, congVocab = 0, congVlTMax = 0xFFFFFFFFu, congVlBits = 0;
 
 		CongView congView() const
 		{
 			CongView v;
 			if (!congDim) return v;
-			v.dim = congDim; v.stride = congDim + 8; v.nCtx = congCtx; v.vocabSize = (uint32_t)congRoot.size();
+			v.dim = congDim; v.stride = congDim + 8; v.nCtx = congCtx; v.vocabSize = congVocab; v.rootSize = (uint32_t)congRoot.size(); v.vlTMax = congVlTMax; v.vlBits = congVlBits;
 			v.ctxEmb = congCtxEmb.data(); v.outEmb = congOutEmb.data();
 			v.nodes = congNodes.data(); v.keys = congKeys.data(); v.values = congValues.data(); v.root = congRoot.data();
 			return v;

@@ -336,10 +336,13 @@ namespace kamd
 			static_assert(sizeof(Header) == 64, "CoNgramModelHeader");
 			if (size < sizeof(Header)) throw std::runtime_error{ "cong.mdl: truncated header" };
 			Header hd; std::memcpy(&hd, blob, sizeof(hd));
-			if (hd.qbit != 8) throw std::runtime_error{ "cong.mdl: only 8-bit embeddings are supported by this loader (4-bit grouped packing is not)" };
-			if (hd.flags != 0) throw std::runtime_error{ "cong.mdl: output bias / reordered vocabulary / trie frequencies are not supported by this loader" };
-			if (hd.keySize != 4 && hd.keySize != 2) throw std::runtime_error{ "cong.mdl: only 16- and 32-bit keys are supported by this loader" };
+			if (hd.qbit != 8 && !(hd.qbit == 4 && (hd.qgroup == 4 || hd.qgroup == 8 || hd.qgroup == 16) && hd.dim % 16 == 0)) throw std::runtime_error{ "cong.mdl: unsupported embedding packing (8-bit, or 4-bit in groups of 4 / 8 / 16, are)" };
+			if (hd.flags != 0) throw std::runtime_error{ "cong.mdl: output bias / reordered vocabulary / trie frequencies (the sections of a character model) are not supported by this loader" };
+			if (hd.keySize != 4 && hd.keySize != 3 && hd.keySize != 2) throw std::runtime_error{ "cong.mdl: only 16-bit, variable-length 16-bit and 32-bit keys are supported by this loader" };
 			if (hd.dim == 0 || hd.dim % 4 || hd.numNodes < 1) throw std::runtime_error{ "cong.mdl: bad header" };
+			// keySize 3: 16-bit trie keys, a token id >= 63488 is spelt as two of them (CoNgramModel::progressContextNode, src/CoNgramModel.hpp:271-300)
+			m.congVlTMax = hd.keySize == 3 ? 65536u - 2048u : 0xFFFFFFFFu; m.congVlBits = hd.keySize == 3 ? 10u : 0u;
+			const size_t rootSize = std::max<size_t>(hd.vocabSize, hd.keySize == 3 ? 65536u : 0u);
 			const uint8_t* end = blob + size;
 			const size_t nNodes = hd.numNodes;
 			std::vector<uint32_t> sizes(nNodes), keys(nNodes - 1), values(nNodes);
@@ -351,7 +354,7 @@ namespace kamd
 			m.congNodes.assign(nonLeaf, CongNodeRec{});
 			m.congKeys = keys;
 			m.congValues.assign(nNodes - 1, 0);
-			m.congRoot.assign(hd.vocabSize, 0);
+			m.congRoot.assign(rootSize, 0);
 			// pre-order node stream -> non-leaf node table + per-edge values (CoNgramModel.cpp:489-523)
 			struct Range { size_t node, cur, end; };
 			std::vector<Range> st;
@@ -380,7 +383,7 @@ namespace kamd
 					}
 				}
 			}
-			for (uint32_t i = 0; i < m.congNodes[0].numNexts; ++i) if (keys[i] < hd.vocabSize) m.congRoot[keys[i]] = m.congValues[i];
+			for (uint32_t i = 0; i < m.congNodes[0].numNexts; ++i) if (keys[i] < rootSize) m.congRoot[keys[i]] = m.congValues[i];
 			// suffix links and inherited context ids, breadth first (CoNgramModel.cpp:547-568 with findLowerNode / findLowerValue, CoNgramModel.hpp:181-227)
 			std::deque<uint32_t> dq{ 0u };
 			while (!dq.empty())
@@ -422,35 +425,61 @@ namespace kamd
 				}
 			}
 			// embeddings
-			m.congDim = hd.dim; m.congCtx = (uint32_t)hd.contextSize;
+			m.congDim = hd.dim; m.congCtx = (uint32_t)hd.contextSize; m.congVocab = (uint32_t)hd.vocabSize;
 			const size_t stride = (size_t)hd.dim + 8;
 			m.congCtxEmb.assign(hd.contextSize * stride, 0); m.congOutEmb.assign(hd.vocabSize * stride, 0);
 			const uint8_t* e = blob + hd.embOffset;
-			const size_t ctxRec = (size_t)hd.dim + 2 + 2 + (hd.windowSize > 0 ? 4 : 0), outRec = (size_t)hd.dim + 2;
+			// a row: qbit 8 = dim x s8 + fp16 scale; qbit 4 = dim / 2 bytes of nibble pairs + fp16 global scale + dim / qgroup local bytes, requantised to
+			// s8 at load time as the reference does (requantizePackedInts, src/CoNgramModel.cpp:378-400)
+			const size_t rowRec = hd.qbit == 8 ? (size_t)hd.dim + 2 : (size_t)hd.dim / 2 + 2 + hd.dim / hd.qgroup;
+			const size_t ctxRec = rowRec + 2 + (hd.windowSize > 0 ? 4 : 0), outRec = rowRec;      // (a file of the global model carries confidence + valid-token sum per context: skipped, CoNgramModel.cpp:655-658)
 			if (e + hd.contextSize * ctxRec + hd.vocabSize * outRec > end) throw std::runtime_error{ "cong.mdl: truncated embeddings" };
+			auto readRow = [&](const uint8_t* src, uint8_t* o)      // -> the row's s8 values and its fp32 scale at o[dim]
+			{
+				float scale;
+				if (hd.qbit == 8)
+				{
+					std::memcpy(o, src, hd.dim);
+					uint16_t hs; std::memcpy(&hs, src + hd.dim, 2);
+					scale = halfToFloat(hs);
+				}
+				else
+				{
+					// requantizePackedU4 as the reference's SSE4.1 build computes it (src/archImpl/sse4_1.cpp:480-573; the pin of the CoNgram oracle): value =
+					// mulhrs((nibble - zeroPoint) * localScale +- 4, 32768 / 9) -- a rounded division by 9 where the scalar version (archImpl/none.cpp:22-57)
+					// truncates; zeroPoint = (local >> 6) + 6, localScale = (local & 63) + 9; scale = global / 8
+					uint16_t hs; std::memcpy(&hs, src + hd.dim / 2, 2);
+					const uint8_t* local = src + hd.dim / 2 + 2;
+					for (uint32_t i = 0; i < hd.dim; ++i)
+					{
+						const uint8_t packed = src[i / 2];
+						const int32_t nib = (i & 1) ? (packed >> 4) : (packed & 0x0F);
+						const uint8_t l = local[i / hd.qgroup];
+						int32_t v = (nib - (int32_t)((l >> 6) + 6)) * (int32_t)((l & 0x3F) + 9);
+						v += v > 0 ? 4 : v < 0 ? -4 : 0;
+						const int32_t q = (((v * (32768 / 9)) >> 14) + 1) >> 1;      // _mm_mulhrs_epi16
+						o[i] = (uint8_t)(int8_t)q;
+					}
+					scale = halfToFloat(hs) / 8;
+				}
+				std::memcpy(o + hd.dim, &scale, 4);
+			};
 			for (size_t i = 0; i < hd.contextSize; ++i, e += ctxRec)
 			{
 				uint8_t* o = &m.congCtxEmb[i * stride];
-				std::memcpy(o, e, hd.dim);
-				uint16_t hs, hb; std::memcpy(&hs, e + hd.dim, 2); std::memcpy(&hb, e + hd.dim + 2, 2);
-				const float scale = halfToFloat(hs), bias = -halfToFloat(hb);
-				std::memcpy(o + hd.dim, &scale, 4); std::memcpy(o + hd.dim + 4, &bias, 4);
+				readRow(e, o);
+				uint16_t hb; std::memcpy(&hb, e + rowRec, 2);
+				const float bias = -halfToFloat(hb);
+				std::memcpy(o + hd.dim + 4, &bias, 4);
 			}
-			for (size_t i = 0; i < hd.vocabSize; ++i, e += outRec)
-			{
-				uint8_t* o = &m.congOutEmb[i * stride];
-				std::memcpy(o, e, hd.dim);
-				uint16_t hs; std::memcpy(&hs, e + hd.dim, 2);
-				const float scale = halfToFloat(hs);
-				std::memcpy(o + hd.dim, &scale, 4);
-			}
+			for (size_t i = 0; i < hd.vocabSize; ++i, e += outRec) readRow(e, &m.congOutEmb[i * stride]);
 			// device lookup structures, in the shapes of the Knlm ones: edge hash (slot.ll carries the child's context id), root table, suffix links
 			auto asF = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
 			auto edgeCtx = [&](uint32_t node, int32_t v) { return v > 0 ? asF(m.congNodes[node + v].value) : asF(0u); };
 			m.congBackoff.resize(nonLeaf);
 			for (size_t i = 0; i < nonLeaf; ++i) m.congBackoff[i] = LmBackoff{ m.congNodes[i].lower, 0.f };
-			m.congRoot2.assign(hd.vocabSize, LmRootRec{ 0, 0.f });
-			for (uint32_t i = 0; i < m.congNodes[0].numNexts; ++i) if (keys[i] < hd.vocabSize) m.congRoot2[keys[i]] = LmRootRec{ m.congValues[i], edgeCtx(0, m.congValues[i]) };
+			m.congRoot2.assign(rootSize, LmRootRec{ 0, 0.f });
+			for (uint32_t i = 0; i < m.congNodes[0].numNexts; ++i) if (keys[i] < rootSize) m.congRoot2[keys[i]] = LmRootRec{ m.congValues[i], edgeCtx(0, m.congValues[i]) };
 			const size_t nEdges = m.congKeys.size() - m.congNodes[0].numNexts;
 			size_t nBuckets = 1;
 			while (nBuckets * 2 < nEdges + 1) nBuckets <<= 1;

@@ -338,39 +338,30 @@ namespace sbgk
 	// moves on (progressContextNodeVl, src/CoNgramModel.hpp:306-385, over the edge hash: slot.value > 0 child offset with the child's context id in
 	// the slot's ll bits, < 0 minus the context id of a leaf).  outputFirst: the rounding of the reference's batched SSE4.1 kernel
 	// (src/archImpl/sse4_1.cpp:116: ((x * outputScale) * contextScale) + bias) instead of progress()'s ((x * contextScale) * outputScale) + bias.
-	__device__ INL3 float congStep(const ModelView& M, const CongDev& CG, int32_t& node, uint32_t& ctx, uint32_t next, bool outputFirst)
+	// progressContextNodeVl (src/CoNgramModel.hpp:306-385) over the edge hash: the context id `key` leads to from `node` (a miss at the root: context 0,
+	// stay at the root; a leaf names its own context and the walk re-anchors at the longest suffix that continues with `key`); rootRec = M.lmRoot2[key]
+	__device__ __forceinline__ uint32_t congWalk(const ModelView& M, int32_t& node, uint32_t key, const LmRootRec rootRec)
 	{
-		const uint32_t* a = reinterpret_cast<const uint32_t*>(CG.ctxEmb + (size_t)ctx * CG.stride);
-		const uint32_t* b = reinterpret_cast<const uint32_t*>(CG.outEmb + (size_t)next * CG.stride);
-		const LmRootRec rootRec = M.lmRoot2[next];
-		const uint32_t nw = CG.dim >> 2;
-		int32_t acc = 0;
-		for (uint32_t k = 0; k < nw; ++k) acc = dot4s8(a[k], b[k], acc);
-		const float cs = __uint_as_float(a[nw]), bias = __uint_as_float(a[nw + 1]), os = __uint_as_float(b[nw]);
-		const float x = (float)acc;
-		const float ll = outputFirst ? x * os * cs + bias : x * cs * os + bias;
-		// context walk
 		for (;;)
 		{
 			int32_t v; float cbits;
 			if (node == 0)
 			{
 				v = rootRec.value; cbits = rootRec.ll;
-				if (v == 0) { ctx = 0; return ll; }
+				if (v == 0) return 0;
 			}
 			else
 			{
 				const LmBackoff bo = M.lmBackoff[node];
-				if (!lmLookup(M, (uint32_t)node, next, v, cbits))
+				if (!lmLookup(M, (uint32_t)node, key, v, cbits))
 				{
-					if (!bo.lower) { ctx = 0; return ll; }
+					if (!bo.lower) return 0;
 					node += bo.lower;
 					continue;
 				}
 			}
-			if (v > 0) { node += v; ctx = __float_as_uint(cbits); return ll; }
-			// leaf: its own context id; the new node is the longest suffix context that continues with `next`
-			ctx = (uint32_t)-v;
+			if (v > 0) { node += v; return __float_as_uint(cbits); }
+			// leaf: its own context id; the new node is the longest suffix context that continues with `key`
 			int32_t cur = node;
 			for (;;)
 			{
@@ -378,12 +369,33 @@ namespace sbgk
 				if (!lower) break;
 				cur += lower;
 				int32_t lv; float l2;
-				if (cur == 0) { lv = rootRec.value; if (lv > 0) { node = lv; return ll; } }
-				else if (lmLookup(M, (uint32_t)cur, next, lv, l2) && lv > 0) { node = cur + lv; return ll; }
+				if (cur == 0) { lv = rootRec.value; if (lv > 0) { node = lv; return (uint32_t)-v; } }
+				else if (lmLookup(M, (uint32_t)cur, key, lv, l2) && lv > 0) { node = cur + lv; return (uint32_t)-v; }
 			}
 			node = 0;
-			return ll;
+			return (uint32_t)-v;
 		}
+	}
+	__device__ INL3 float congStep(const ModelView& M, const CongDev& CG, int32_t& node, uint32_t& ctx, uint32_t next, bool outputFirst)
+	{
+		const uint32_t* a = reinterpret_cast<const uint32_t*>(CG.ctxEmb + (size_t)ctx * CG.stride);
+		const uint32_t* b = reinterpret_cast<const uint32_t*>(CG.outEmb + (size_t)next * CG.stride);
+		const LmRootRec rootRec = M.lmRoot2[next];      // (fetched with the rows; a two-key id below reads its own)
+		const uint32_t nw = CG.dim >> 2;
+		int32_t acc = 0;
+		for (uint32_t k = 0; k < nw; ++k) acc = dot4s8(a[k], b[k], acc);
+		const float cs = __uint_as_float(a[nw]), bias = __uint_as_float(a[nw + 1]), os = __uint_as_float(b[nw]);
+		const float x = (float)acc;
+		const float ll = outputFirst ? x * os * cs + bias : x * cs * os + bias;
+		if (next < CG.vlTMax) ctx = congWalk(M, node, next, rootRec);
+		else
+		{
+			// variable-length keys (cong.mdl keySize 3; CoNgramModel::progressContextNode, src/CoNgramModel.hpp:271-300): two steps, the first context id is dropped
+			const uint32_t r = next - CG.vlTMax, k1 = CG.vlTMax + (r >> CG.vlBits), k2 = CG.vlTMax + (1u << CG.vlBits) + (r & ((1u << CG.vlBits) - 1));
+			congWalk(M, node, k1, M.lmRoot2[k1]);
+			ctx = congWalk(M, node, k2, M.lmRoot2[k2]);
+		}
+		return ll;
 	}
 #endif
 

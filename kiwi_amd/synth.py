@@ -303,6 +303,11 @@ class SynthSpec:
     use_cong: bool = False       # also emit a local (window 0), 8-bit CoNgram model (reference cong.mdl layout) over the same vocabulary
     cong_dim: int = 32
     cong_only: bool = False      # with use_cong: no Knlm blob in the container (the layout of the reference's models/cong/base: sj.morph + cong.mdl)
+    cong_key_size: int = 4       # CoNgramModelHeader::keySize: 2 / 4 = 16- / 32-bit trie keys, 3 = 16-bit keys with ids >= 63488 spelt as two "surrogate" keys (src/CoNgramModel.hpp:271-300)
+    cong_qbit: int = 8           # 4: embeddings packed two per byte with one 8-bit local scale / zero point per cong_qgroup values (src/CoNgramModel.cpp:378-400)
+    cong_qgroup: int = 0
+    cong_window: int = 0         # > 0: the file also carries the sections of the global model (confidences, distant embeddings, mask), as the reference's builder always writes them
+    lm_id_offset: int = 0        # > 0: LM ids of the ordinary morphemes start that much higher (ids beyond 63488 exercise the two-key spelling of keySize 3)
     seed: int = SEED_BASE
 
 
@@ -314,6 +319,8 @@ SMALL_SPEC = SynthSpec()
 SMALL_Q8_SPEC = SynthSpec(knlm_qbits=8, knlm_compress=True)   # SMALL_SPEC with the Knlm file as the reference ships it: 8-bit quantised, node sizes compressed
 SMALL_Q5_SPEC = SynthSpec(knlm_qbits=5)                       # ... and a bit width that exercises the generic fixed-length bit stream
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
+# the CoNgram file the way the reference's builder writes it for a large vocabulary: 4-bit grouped embeddings, variable-length 16-bit keys, window sections
+SMALL_CONG_VL4_SPEC = SynthSpec(use_cong=True, cong_only=True, cong_key_size=3, cong_qbit=4, cong_qgroup=8, cong_window=7, lm_id_offset=62000)
 SMALL_CONG_SPEC = SynthSpec(use_cong=True) # same lexicon as SMALL_SPEC + a local CoNgram model (the Knlm blob stays in the container: the dictionary bake needs a vocabulary size)
 FULL_CONG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
                            n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_cong=True, cong_dim=64, cong_only=True)
@@ -666,6 +673,13 @@ class SynthModel:
                 m.lm_id = i                       # KiwiBuilder.cpp:1641
             elif m.lm_id == 0 and i > 0:
                 m.lm_id = i                       # KiwiBuilder.cpp:906-921
+        if sp.lm_id_offset:
+            # test models only: the ids of everything after the default morphemes move up (the reference reads lmMorphemeId as a free field)
+            for i, m in enumerate(raw.morphs):
+                if m.lm_id >= DEFAULT_FORM_SIZE + 8:
+                    m.lm_id += sp.lm_id_offset
+            vocab += sp.lm_id_offset
+            raw.vocab_size = vocab
         rng = np.random.default_rng(sp.seed + 1)
         sents = []
         sf_id = SF + 1
@@ -681,7 +695,7 @@ class SynthModel:
         if sp.use_sbg:
             raw.sbg = build_sbg(sents, vocab, key_size=2 if vocab + 1 <= 0xFFFF else 4, seed=sp.seed + 2)
         if sp.use_cong:
-            raw.cong = build_cong(sents, vocab, dim=sp.cong_dim, seed=sp.seed + 3)
+            raw.cong = build_cong(sents, vocab, dim=sp.cong_dim, seed=sp.seed + 3, key_size=sp.cong_key_size, qbit=sp.cong_qbit, qgroup=sp.cong_qgroup, window=sp.cong_window)
             if sp.cong_only:
                 raw.knlm = b""
 
@@ -1018,7 +1032,36 @@ def _svb_encode(values, v0124: bool) -> bytes:
     return ctrl.tobytes() + le[mask].tobytes()
 
 
-def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2) -> bytes:
+def _cong_vl_keys(tok, key_size):
+    """The trie keys a token id is spelt with (CoNgramModel::progressContextNode, src/CoNgramModel.hpp:271-300): itself, or for keySize 3 and
+    ids >= 63488 two 16-bit "surrogate" keys (63488 + high 10 bits, 63488 + 1024 + low 10 bits)."""
+    if key_size != 3 or tok < 63488:
+        return (tok,)
+    r = tok - 63488
+    return (63488 + (r >> 10), 63488 + 1024 + (r & 1023))
+
+
+def _pack_u4_row(vals, qgroup, rng):
+    """One embedding row in the 4-bit grouped packing (reader: requantizePackedInts qbit 4, src/CoNgramModel.cpp:388-395; unpacking
+    src/archImpl/none.cpp:22-57 / sse4_1.cpp:480-573): dim/2 bytes of nibble pairs (low nibble first), fp16 global scale, dim/qgroup local bytes
+    (bits 0-5: scale - 9, bits 6-7: zero point - 6).  `vals` are the target values; what is stored is their nearest representable code."""
+    dim = len(vals)
+    ng = dim // qgroup
+    local = np.zeros(ng, np.uint8)
+    nib = np.zeros(dim, np.uint8)
+    for g in range(ng):
+        v = vals[g * qgroup:(g + 1) * qgroup].astype(np.int64)
+        zp = int(rng.integers(6, 10))
+        span = max(int(np.abs(v).max()), 1)
+        sc = int(min(63, max(9, round(span * 9 / 7))))      # (nibble - zp) in about -9 .. 9; value = that * sc / 9, |value| <= 63
+        q = np.clip(np.round(v * 9 / sc).astype(np.int64) + zp, 0, 15)
+        nib[g * qgroup:(g + 1) * qgroup] = q
+        local[g] = ((zp - 6) << 6) | (sc - 9)
+    packed = (nib[0::2] | (nib[1::2] << 4)).astype(np.uint8)
+    return packed, local
+
+
+def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2, key_size=4, qbit=8, qgroup=0, window=0) -> bytes:
     """A synthetic *local* (window 0) CoNgram model in the reference's ``cong.mdl`` layout (reader: /root/reference/src/CoNgramModel.cpp:425-789;
     header: include/kiwi/CoNgramModel.h:18-34): 8-bit embeddings (qbit 8), 32-bit keys (keySize 4), no optional sections (flags 0).
 
@@ -1036,8 +1079,10 @@ def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2) ->
     depth = max_ctx_len + 1
     bits = max(1, int(vocab_size).bit_length())
     assert bits * depth <= 63
-    children = {(): {}}                       # history tuple -> {next key: True}
+    children = {(): {}}                       # history tuple (of trie KEYS) -> {next key: True}
     n_tok = len(flat)
+    assert key_size in (2, 3, 4) and (key_size != 2 or vocab_size <= 0xFFFF) and (key_size != 3 or vocab_size <= 63488 + (1 << 20))
+    assert qbit == 8 or (qbit == 4 and qgroup in (4, 8, 16) and dim % 16 == 0)
     for n in range(1, depth + 1):
         idx = np.arange(n_tok - n + 1)
         idx = idx[sid[idx] == sid[idx + n - 1]]
@@ -1047,10 +1092,14 @@ def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2) ->
         u, cnt = np.unique(code, return_counts=True)
         u = u[cnt >= (1 if n == 1 else min_count)]
         for c in u.tolist():
-            g = tuple((c >> (bits * (n - 1 - k))) & ((1 << bits) - 1) for k in range(n))
-            if g[:-1] in children:
-                children[g[:-1]][g[-1]] = True
-                children.setdefault(g, {})
+            toks = tuple((c >> (bits * (n - 1 - k))) & ((1 << bits) - 1) for k in range(n))
+            hist = tuple(k for t in toks[:-1] for k in _cong_vl_keys(t, key_size))
+            if hist not in children:
+                continue
+            for k in _cong_vl_keys(toks[-1], key_size):      # (a two-key token adds an inner node for its first key)
+                children[hist][k] = True
+                hist = hist + (k,)
+                children.setdefault(hist, {})
     node_sizes, keys_out, values = [], [], []
     n_ctx = 1                                  # context 0: the empty / unknown context
 
@@ -1058,7 +1107,7 @@ def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2) ->
         nonlocal n_ctx
         ch = children[h]
         node_sizes.append(len(ch))
-        if h and rng.random() < 0.85:
+        if h and rng.random() < 0.85 and not (key_size == 3 and 63488 <= h[-1] < 63488 + 1024):      # (the node of a first "surrogate" key is no context)
             values.append(n_ctx); n_ctx += 1
         else:
             values.append(0)                   # the root, and a share of the inner nodes: the context of the longest suffix applies
@@ -1087,11 +1136,24 @@ def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2) ->
     out_emb = rng.integers(-63, 64, size=(vocab_size, dim), dtype=np.int8)
     out_scale = half(rng.uniform(0.008, 0.024, vocab_size))
     emb = bytearray()
-    for i in range(n_ctx):
-        emb += ctx_emb[i].tobytes() + ctx_scale[i].tobytes() + ctx_negbias[i].tobytes()
-    for i in range(vocab_size):
-        emb += out_emb[i].tobytes() + out_scale[i].tobytes()
 
+    def row(vals, scale16):
+        if qbit == 8:
+            return vals.tobytes() + scale16.tobytes()
+        packed, local = _pack_u4_row(vals, qgroup, rng)
+        # qbit 4: the reader's scale is globalScale / 8 (src/archImpl/sse4_1.cpp:572) -- the stored fp16 is 8 x the wanted scale
+        return packed.tobytes() + half(np.float32(np.float16(scale16.view(np.float16)) * np.float16(8))).tobytes() + local.tobytes()
+    for i in range(n_ctx):
+        emb += row(ctx_emb[i], ctx_scale[i]) + ctx_negbias[i].tobytes()
+        if window:
+            emb += half(rng.uniform(-1.0, 1.0)).tobytes() + half(rng.uniform(0.0, 1.0)).tobytes()      # confidence, valid-token sum (global model only)
+    for i in range(vocab_size):
+        emb += row(out_emb[i], out_scale[i])
+    if window:
+        for i in range(vocab_size):          # distant embeddings: row, fp16 -bias, fp16 confidence
+            emb += row(out_emb[(i * 7 + 3) % vocab_size], out_scale[i]) + half(rng.uniform(3.0, 9.0)).tobytes() + half(rng.uniform(-1.0, 1.0)).tobytes()
+        emb += half(rng.uniform(-1.0, 1.0, window)).tobytes()      # position confidences
+        emb += rng.integers(0, 256, (vocab_size + 7) // 8, dtype=np.uint8).tobytes()      # distant-token mask
     def al(x):
         return (x + 15) & ~15
     node_b, key_b, val_b = _svb_encode(node_sizes, True), _svb_encode(keys_out, False), _svb_encode(values, True)
@@ -1100,7 +1162,7 @@ def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2) ->
     val_off = al(key_off + len(key_b))
     emb_off = al(val_off + len(val_b))
     buf = bytearray(al(emb_off + len(emb)))
-    struct.pack_into("<QQHHBBBBQQQQQ", buf, 0, vocab_size, n_ctx, dim, 0, 4, 0, 8, 0, num_nodes, node_off, key_off, val_off, emb_off)
+    struct.pack_into("<QQHHBBBBQQQQQ", buf, 0, vocab_size, n_ctx, dim, 0, key_size, window, qbit, qgroup, num_nodes, node_off, key_off, val_off, emb_off)
     buf[node_off:node_off + len(node_b)] = node_b
     buf[key_off:key_off + len(key_b)] = key_b
     buf[val_off:val_off + len(val_b)] = val_b

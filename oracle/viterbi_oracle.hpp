@@ -172,7 +172,16 @@ namespace korc
 			v = C.values[nd.nextOff + (it - k)];
 			return v != 0;
 		}
+		// CoNgramModel::progressContextNode (src/CoNgramModel.hpp:271-300): with variable-length keys (cong.mdl keySize 3) a word id >= tMax takes two
+		// steps through the trie, the first one's context id is dropped
 		uint32_t congContext(int32_t& nodeIdx, uint32_t next) const
+		{
+			if (next < C.vlTMax) return congContextVl(nodeIdx, next);
+			const uint32_t r = next - C.vlTMax;
+			congContextVl(nodeIdx, C.vlTMax + (r >> C.vlBits));
+			return congContextVl(nodeIdx, C.vlTMax + (1u << C.vlBits) + (r & ((1u << C.vlBits) - 1)));
+		}
+		uint32_t congContextVl(int32_t& nodeIdx, uint32_t next) const
 		{
 			for (;;)
 			{
@@ -190,7 +199,7 @@ namespace korc
 				else
 				{
 					cnt.congRootProbes++;
-					v = next < C.vocabSize ? C.root[next] : 0;
+					v = next < C.rootSize ? C.root[next] : 0;
 					if (v == 0) return 0;
 				}
 				if (v > 0) { nodeIdx += v; return C.nodes[nodeIdx].value; }
@@ -204,7 +213,7 @@ namespace korc
 					}
 					else
 					{
-						lv = next < C.vocabSize ? C.root[next] : 0;
+						lv = next < C.rootSize ? C.root[next] : 0;
 						if (lv > 0) { nodeIdx = lv; return (uint32_t)-v; }
 					}
 				}
