@@ -290,7 +290,7 @@ namespace kamd
 			// root table, suffix links); the initial state is the root with context 0 (CoNgramState())
 			v.lmHash = impl->up(m.congHash); v.lmHashMask = m.congHashMask; v.lmRoot2 = impl->up(m.congRoot2); v.lmBackoff = impl->up(m.congBackoff);
 			v.h.bosNode = 0;
-			impl->cong = CongDev{ impl->up(m.congCtxEmb), impl->up(m.congOutEmb), m.congDim, m.congDim + 8 };
+			impl->cong = CongDev{ impl->up(m.congCtxEmb), impl->up(m.congOutEmb), m.congDim, m.congDim + 8, m.congVlTMax, m.congVlBits };
 			impl->hasCong = true;
 		}
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }

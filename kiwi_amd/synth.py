@@ -307,7 +307,6 @@ class SynthSpec:
     cong_qbit: int = 8           # 4: embeddings packed two per byte with one 8-bit local scale / zero point per cong_qgroup values (src/CoNgramModel.cpp:378-400)
     cong_qgroup: int = 0
     cong_window: int = 0         # > 0: the file also carries the sections of the global model (confidences, distant embeddings, mask), as the reference's builder always writes them
-    lm_id_offset: int = 0        # > 0: LM ids of the ordinary morphemes start that much higher (ids beyond 63488 exercise the two-key spelling of keySize 3)
     seed: int = SEED_BASE
 
 
@@ -320,7 +319,7 @@ SMALL_Q8_SPEC = SynthSpec(knlm_qbits=8, knlm_compress=True)   # SMALL_SPEC with 
 SMALL_Q5_SPEC = SynthSpec(knlm_qbits=5)                       # ... and a bit width that exercises the generic fixed-length bit stream
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
 # the CoNgram file the way the reference's builder writes it for a large vocabulary: 4-bit grouped embeddings, variable-length 16-bit keys, window sections
-SMALL_CONG_VL4_SPEC = SynthSpec(use_cong=True, cong_only=True, cong_key_size=3, cong_qbit=4, cong_qgroup=8, cong_window=7, lm_id_offset=62000)
+MID_CONG_VL4_SPEC = SynthSpec(n_words=66000, use_cong=True, cong_only=True, cong_key_size=3, cong_qbit=4, cong_qgroup=8, cong_window=7)   # (> 65536 morphemes: an LM id is a morpheme id, and the reference sizes its root table by the vocabulary while indexing it with 16-bit keys)
 SMALL_CONG_SPEC = SynthSpec(use_cong=True) # same lexicon as SMALL_SPEC + a local CoNgram model (the Knlm blob stays in the container: the dictionary bake needs a vocabulary size)
 FULL_CONG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
                            n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_cong=True, cong_dim=64, cong_only=True)
@@ -673,13 +672,6 @@ class SynthModel:
                 m.lm_id = i                       # KiwiBuilder.cpp:1641
             elif m.lm_id == 0 and i > 0:
                 m.lm_id = i                       # KiwiBuilder.cpp:906-921
-        if sp.lm_id_offset:
-            # test models only: the ids of everything after the default morphemes move up (the reference reads lmMorphemeId as a free field)
-            for i, m in enumerate(raw.morphs):
-                if m.lm_id >= DEFAULT_FORM_SIZE + 8:
-                    m.lm_id += sp.lm_id_offset
-            vocab += sp.lm_id_offset
-            raw.vocab_size = vocab
         rng = np.random.default_rng(sp.seed + 1)
         sents = []
         sf_id = SF + 1

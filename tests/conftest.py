@@ -63,6 +63,19 @@ def small_cong_model():
 
 
 @pytest.fixture(scope="session")
+def mid_cong_vl4_model():
+    """A 66 000-word lexicon with a CoNgram-only model file as the reference's builder writes one for a large vocabulary (kiwi_amd/synth.py
+    MID_CONG_VL4_SPEC): 4-bit grouped embeddings, variable-length 16-bit trie keys (LM ids beyond 63488), the global model's sections present."""
+    from kiwi_amd.synth import SynthModel, MID_CONG_VL4_SPEC
+    d = os.path.join(ROOT, "_data")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "mid-cong-vl4.raw")
+    sm = SynthModel(MID_CONG_VL4_SPEC)
+    sm.raw.save(path)
+    return sm, path
+
+
+@pytest.fixture(scope="session")
 def oracle(small_model):
     import subprocess
     import oraclelib

@@ -30,6 +30,44 @@ def cong_pair(small_cong_model):
     return sm, refbridge.RefKiwi(path, arch=3, x86=True), oraclelib.OracleKiwi(path), path
 
 
+@pytest.fixture(scope="module")
+def cong_vl4_pair(mid_cong_vl4_model):
+    import oraclelib
+    import refbridge
+    if not refbridge.x86_available():
+        pytest.skip("oracle/_ref/libkiwi_ref_x86.so not built (make -C oracle refx86; needs /root/reference)")
+    sm, path = mid_cong_vl4_model
+    return sm, refbridge.RefKiwi(path, arch=3, x86=True), oraclelib.OracleKiwi(path), path
+
+
+def test_cong_file_as_the_builder_writes_it_for_a_large_vocabulary(cong_vl4_pair):
+    """cong.mdl with keySize 3 (a word id >= 63488 is two 16-bit trie keys: CoNgramModel::progressContextNode), qbit 4 (nibble pairs + local
+    scale / zero point per group, requantised to int8 at load time by requantizePackedU4 -- the SSE4.1 build's rounding) and the sections of the
+    global model present (skipped in local mode): LM steps over random walks incl. ids on both sides of the two-key boundary, then whole analyses."""
+    sm, ref, orc, _ = cong_vl4_pair
+    ref.lib.kref_cong_next.restype = C.c_float
+    ref.lib.kref_cong_next.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_uint32]
+    orc.lib.korc_cong_next.restype = C.c_float
+    orc.lib.korc_cong_next.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.c_uint32]
+    rnd = random.Random(6)
+    vocab = sm.raw.vocab_size
+    assert vocab > 63488 + 1024
+    seen_big = 0
+    for _ in range(1500):
+        n1, c1, n2, c2 = C.c_int32(0), C.c_uint32(0), C.c_int32(0), C.c_uint32(0)
+        for _ in range(8):
+            r = rnd.random()
+            w = rnd.randrange(60000, vocab) if r < 0.6 else rnd.randrange(63400, 63600) if r < 0.7 else rnd.randrange(0, 200)
+            a = ref.lib.kref_cong_next(ref.h, C.byref(n1), C.byref(c1), w)
+            b = orc.lib.korc_cong_next(orc.h, C.byref(n2), C.byref(c2), w)
+            assert (a, n1.value, c1.value) == (b, n2.value, c2.value), w
+            seen_big += w >= 63488 and c1.value != 0
+    assert seen_big > 200
+    texts = synthetic(sm, 500, 841, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 300, 842) + EDGE_TEXTS + fuzzed(sm, 200, 843)
+    for t in texts:
+        assert _norm(ref.analyze(t)) == _norm(orc.analyze(t)), repr(t)
+
+
 def test_cong_lm_steps_equal_reference(cong_pair):
     """CoNgramModel::progress (score in the current context, then progressContextNode) over random walks: log-likelihood bits, node, context id."""
     sm, ref, orc, _ = cong_pair

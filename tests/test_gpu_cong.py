@@ -97,3 +97,22 @@ def test_kiwi_init_selects_the_cong_model(small_cong_model):
             L.kiwi_res_close(r)
         L.kiwi_close(k)
     assert not L.kiwi_init(path.encode(), 0, 15 | 0x0500, 0)
+
+
+def test_cong_file_as_the_reference_builder_writes_it(mid_cong_vl4_model):
+    """keySize 3 (two trie steps for LM ids >= 63488), 4-bit grouped embeddings, the global model's sections present (skipped): device vs oracle,
+    and vs the real reference's SSE4.1 build where it travelled."""
+    import oraclelib
+    import refbridge
+    from kiwi_amd.api import KiwiAmd
+    sm, path = mid_cong_vl4_model
+    orc = oraclelib.OracleKiwi(path)
+    ref = refbridge.RefKiwi(path, arch=3, x86=True) if refbridge.x86_available() else None
+    dev = KiwiAmd(path)
+    texts = synthetic(sm, 1500, 927, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 500, 928) + EDGE_TEXTS + fuzzed(sm, 300, 929)
+    got = dev.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s)) == _norm(y), s
+        if ref is not None:
+            assert _norm(ref.analyze(s)) == _norm(y), s
+    dev.close()

@@ -535,3 +535,21 @@ def check_device_typo_graphs(lib, model_path, n_random=150):
 
 def test_emulated_typo_graph_kernel_matches_host_module(emu_libs, small_model):
     check_device_typo_graphs(emu_libs[0], small_model[1])
+
+
+@pytest.mark.parametrize("lanes,top_n", [("16", 1), ("64", 2)])
+def test_emulated_cong_kernel_on_a_file_as_the_reference_builder_writes_it(emu_libs, mid_cong_vl4_model, monkeypatch, lanes, top_n):
+    """cong.mdl with variable-length 16-bit keys (keySize 3: LM ids >= 63488 take two trie steps in congStep), 4-bit grouped embeddings
+    (requantised to int8 by the loader) and the global model's sections present: the emulated search kernel against the oracle, which
+    tests/test_cong_oracle.py pins to the real reference on the same file."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = mid_cong_vl4_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    texts = synthetic(sm, 70, 915, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 30, 916) + EDGE_TEXTS[:20]
+    got = dev.analyze_batch(texts, top_n=top_n).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (lanes, top_n, s)
+    dev.close()
