@@ -294,6 +294,7 @@ namespace kamd
 			impl->hasCong = true;
 		}
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
+		v.lmHtxNode = (m.congDim || m.lmHtxNode.empty()) ? nullptr : impl->up(m.lmHtxNode);      // history-transformed Knlm only
 		if (!m.sbgPtrs.empty())
 		{
 			const SbgView sv = m.sbgView();

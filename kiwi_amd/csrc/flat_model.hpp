@@ -142,6 +142,9 @@ namespace kamd
 		const LmRootRec* lmRoot2;     // [vocab]
 		const LmBackoff* lmBackoff;   // [nLmNodes]
 		const void* unkPacks;         // device only: CandStatic[2] for the unknown-noun candidates NNG, NNP (PathEvaluator.hpp:1204-1206)
+		// history-transformed Knlm (KnLangModelHeader::htx_offset; the reference's builder writes one by default): per word the root's child for its
+		// TRANSFORMED id (a node index, 0 = none) -- where a walk lands when no context continues with the word (Knlm.cpp:61-70, 116-126); null = plain model
+		const int32_t* lmHtxNode;
 	};
 
 	// SkipBigram tables (reference src/SkipBigramModel.hpp:40-105), kept apart from ModelView: only the CPU restatement uses
@@ -226,6 +229,7 @@ namespace kamd
 		std::vector<LmSlot> lmHash; uint32_t lmHashMask = 0;
 		std::vector<LmRootRec> lmRoot2;
 		std::vector<LmBackoff> lmBackoff;
+		std::vector<uint32_t> lmHtx; std::vector<int32_t> lmHtxNode;      // history transformer [vocab] and what the walks need of it (ModelView::lmHtxNode)
 		std::vector<uint32_t> sbgPtrs, sbgKeys; std::vector<float> sbgComps, sbgDiscnts; std::vector<uint8_t> sbgValid; uint32_t sbgWindow = 0;
 		// CoNgram (see CongView): host trie, the device lookup structures in the Knlm shapes (edge hash with the child's context id in the slot's
 		// `ll` bits, root table, per-node suffix link), embeddings
@@ -263,6 +267,7 @@ namespace kamd
 			v.trie = trie.data(); v.trieKeys = trieKeys.data(); v.trieChild = trieChild.data(); v.trieRoot = trieRoot.data();
 			v.lmNodes = lmNodes.data(); v.lmKeys = lmKeys.data(); v.lmValues = lmValues.data(); v.lmRoot = lmRoot.data();
 			v.lmHash = lmHash.data(); v.lmHashMask = lmHashMask; v.lmRoot2 = lmRoot2.data(); v.lmBackoff = lmBackoff.data();
+			v.lmHtxNode = lmHtxNode.empty() ? nullptr : lmHtxNode.data();
 			return v;
 		}
 

@@ -72,10 +72,13 @@ namespace kamd
 			{
 				int32_t v;
 				const LmNodeRec* n = &m.lmNodes[node];
+				// a history-transformed model (Knlm.cpp:61-70, 116-126): when no context continues with `next`, the new state is the root's child for the
+				// TRANSFORMED id (the oldest token of a trie path is stored transformed, src/count.hpp:148-240)
+				auto htxRoot = [&](uint32_t w) -> int32_t { if (m.lmHtx.empty()) return 0; const uint32_t t = m.lmHtx[w]; return t < m.lmRoot.size() ? m.lmRoot[t] : 0; };
 				if (node == 0)
 				{
 					v = m.lmRoot[next];
-					if (v == 0) return acc + m.h.unkLl;
+					if (v == 0) { node = htxRoot(next); return acc + m.h.unkLl; }
 				}
 				else if (!lmSearch(m, *n, next, v))
 				{
@@ -91,7 +94,7 @@ namespace kamd
 					int32_t lv;
 					if (lmSearch(m, m.lmNodes[cur], next, lv) && lv > 0) { node = cur + lv; return acc + lmValueAsFloat(v); }
 				}
-				node = 0;
+				node = htxRoot(next);
 				return acc + lmValueAsFloat(v);
 			}
 		}
@@ -105,7 +108,11 @@ namespace kamd
 				v = m.lmRoot[next];
 				if (v == 0) return m.h.unkLl;
 			}
-			else if (!lmSearch(m, n, next, v)) return n.gamma + lmGetLL(m, node + n.lower, next);
+			else if (!lmSearch(m, n, next, v))
+			{
+				if (!n.lower) throw std::runtime_error{ "knlm: the start context of a history-transformed model does not hold the unknown word (the reference's loader recurses forever on such a file)" };
+				return n.gamma + lmGetLL(m, node + n.lower, next);
+			}
 			if (v > 0) return m.lmNodes[node + v].ll;
 			return lmValueAsFloat(v);
 		}
@@ -115,7 +122,6 @@ namespace kamd
 			if (size < sizeof(KnlmHeader)) throw std::runtime_error{ "knlm: truncated header" };
 			KnlmHeader hd;
 			std::memcpy(&hd, blob, sizeof(hd));
-			if (hd.htx_offset) throw std::runtime_error{ "knlm: history-transformed language models are not supported by this loader yet" };
 			if (hd.key_size != 2 && hd.key_size != 4) throw std::runtime_error{ "knlm: unsupported key size" };
 			const size_t nNodes = hd.num_nodes;
 			const uint32_t qbits = hd.quantized & 0x1F; const bool compressed = (hd.quantized & 0x80) != 0;      // Knlm.hpp:1008-1009
@@ -188,9 +194,18 @@ namespace kamd
 			const float* gamma = gammaV.data();
 			const float* leafLl = ll + nonLeaf;
 
+			// history transformer (Knlm.hpp:1070-1076): [vocab] keys; the root's direct table then spans the transformed ids too
+			m.lmHtx.clear(); m.lmHtxNode.clear();
+			size_t rootSize = hd.vocab_size;
+			if (hd.htx_offset)
+			{
+				if (hd.htx_offset + (size_t)hd.key_size * hd.vocab_size > size) throw std::runtime_error{ "knlm: truncated history transformer" };
+				m.lmHtx.resize(hd.vocab_size);
+				for (size_t i = 0; i < hd.vocab_size; ++i) { m.lmHtx[i] = keyAt(hd.htx_offset, i); rootSize = std::max<size_t>(rootSize, (size_t)m.lmHtx[i] + 1); }
+			}
 			m.lmNodes.assign(nonLeaf, LmNodeRec{});
 			m.lmValues.assign(nNodes - 1, 0);
-			m.lmRoot.assign(hd.vocab_size, 0);
+			m.lmRoot.assign(rootSize, 0);
 			// pre-order node stream -> non-leaf node table + per-edge values (Knlm.hpp:1089-1122)
 			struct Range { size_t node, cur, end; };
 			std::vector<Range> st;
@@ -221,14 +236,25 @@ namespace kamd
 					++li;
 				}
 			}
-			for (uint32_t i = 0; i < m.lmNodes[0].numNexts; ++i) m.lmRoot[m.lmKeys[i]] = m.lmValues[i];
+			for (uint32_t i = 0; i < m.lmNodes[0].numNexts; ++i) if (m.lmKeys[i] < rootSize) m.lmRoot[m.lmKeys[i]] = m.lmValues[i];
 
 			m.h.nLmNodes = (uint32_t)nonLeaf;
 			m.h.nLmEdges = (uint32_t)m.lmKeys.size();
 			m.h.lmOrder = hd.order;
 			m.h.lmKeyBytes = hd.key_size;
 			m.h.unkLl = 0;
-			m.h.unkLl = lmGetLL(m, 0, (uint32_t)hd.unk_id);   // Knlm.hpp:1147
+			if (!m.lmHtx.empty())
+			{
+				// Knlm.hpp:1138-1145: the unknown word's score is read in the state after <s> (links and unk_ll still zero), the start state is entered
+				// through the TRANSFORMED <s>
+				int32_t nd = 0;
+				lmProgressHost(m, nd, (uint32_t)hd.bos_id);
+				m.h.unkLl = lmGetLL(m, nd, (uint32_t)hd.unk_id);
+				int32_t bos0 = 0;
+				lmProgressHost(m, bos0, m.lmHtx[hd.bos_id]);
+				m.h.bosNode = bos0;
+			}
+			else m.h.unkLl = lmGetLL(m, 0, (uint32_t)hd.unk_id);   // Knlm.hpp:1147
 			// suffix ("lower") links by BFS (Knlm.hpp:38-63, 1153-1166)
 			std::deque<uint32_t> dq{ 0u };
 			while (!dq.empty())
@@ -239,12 +265,13 @@ namespace kamd
 				{
 					const int32_t v = m.lmValues[pn.nextOff + i];
 					if (v <= 0) continue;
-					const uint32_t k = m.lmKeys[pn.nextOff + i];
+					uint32_t k = m.lmKeys[pn.nextOff + i];
 					const uint32_t child = p + v;
 					uint32_t node = p;
 					while (m.lmNodes[node].lower)
 					{
 						const uint32_t low = node + m.lmNodes[node].lower;
+						if (low == 0 && !m.lmHtx.empty()) k = k < m.lmHtx.size() ? m.lmHtx[k] : 0;      // findLowerNode, Knlm.hpp:43-46: the root's children are keyed by transformed ids
 						int32_t found;
 						if (lmSearch(m, m.lmNodes[low], k, found)) { node = low + found; goto done; }
 						node = low;
@@ -257,9 +284,14 @@ namespace kamd
 			// device lookup structures: edge hash, root table with the child's ll, per-node back-off record
 			m.lmBackoff.resize(nonLeaf);
 			for (size_t i = 0; i < nonLeaf; ++i) m.lmBackoff[i] = LmBackoff{ m.lmNodes[i].lower, m.lmNodes[i].gamma };
-			m.lmRoot2.assign(hd.vocab_size, LmRootRec{ 0, 0.f });
+			m.lmRoot2.assign(rootSize, LmRootRec{ 0, 0.f });
+			if (!m.lmHtx.empty())
+			{
+				m.lmHtxNode.assign(rootSize, 0);
+				for (size_t w = 0; w < m.lmHtx.size(); ++w) { const uint32_t t = m.lmHtx[w]; m.lmHtxNode[w] = t < rootSize ? m.lmRoot[t] : 0; }
+			}
 			auto edgeLl = [&](uint32_t node, int32_t v) { return v > 0 ? m.lmNodes[node + v].ll : lmValueAsFloat(v); };
-			for (uint32_t i = 0; i < m.lmNodes[0].numNexts; ++i) m.lmRoot2[m.lmKeys[i]] = LmRootRec{ m.lmValues[i], edgeLl(0, m.lmValues[i]) };
+			for (uint32_t i = 0; i < m.lmNodes[0].numNexts; ++i) if (m.lmKeys[i] < rootSize) m.lmRoot2[m.lmKeys[i]] = LmRootRec{ m.lmValues[i], edgeLl(0, m.lmValues[i]) };
 			{
 				const size_t nEdges = m.lmKeys.size() - m.lmNodes[0].numNexts;
 				size_t nBuckets = 1;
@@ -285,9 +317,12 @@ namespace kamd
 					}
 				}
 			}
-			int32_t bos = 0;
-			lmProgressHost(m, bos, (uint32_t)hd.bos_id);  // Knlm.hpp:1148-1149 (links are still zero there too)
-			m.h.bosNode = bos;
+			if (m.lmHtx.empty())
+			{
+				int32_t bos = 0;
+				lmProgressHost(m, bos, (uint32_t)hd.bos_id);  // Knlm.hpp:1148-1149 (links are still zero there too)
+				m.h.bosNode = bos;
+			}
 		}
 	}
 

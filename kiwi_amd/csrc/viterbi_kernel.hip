@@ -299,7 +299,7 @@ namespace sbgk
 			if (node == 0)
 			{
 				const LmRootRec r = rootRec;
-				if (r.value == 0) return acc + M.h.unkLl;
+				if (r.value == 0) { if (M.lmHtxNode) node = M.lmHtxNode[next]; return acc + M.h.unkLl; }      // (history-transformed model, Knlm.cpp:61-70)
 				v = r.value; ll = r.ll;
 			}
 			else
@@ -319,7 +319,7 @@ namespace sbgk
 				if (cur == 0) { lv = rootRec.value; if (lv > 0) { node = lv; return acc + ll; } }
 				else if (lmLookup(M, (uint32_t)cur, next, lv, l2) && lv > 0) { node = cur + lv; return acc + ll; }
 			}
-			node = 0;
+			node = M.lmHtxNode ? M.lmHtxNode[next] : 0;      // (history-transformed model: the root's child for the transformed id, Knlm.cpp:116-126)
 			return acc + ll;
 		}
 	}

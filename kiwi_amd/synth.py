@@ -317,6 +317,8 @@ FULL_SBG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000
 SMALL_SPEC = SynthSpec()
 SMALL_Q8_SPEC = SynthSpec(knlm_qbits=8, knlm_compress=True)   # SMALL_SPEC with the Knlm file as the reference ships it: 8-bit quantised, node sizes compressed
 SMALL_Q5_SPEC = SynthSpec(knlm_qbits=5)                       # ... and a bit width that exercises the generic fixed-length bit stream
+SMALL_HTX_SPEC = SynthSpec(use_htx=True)                       # SMALL_SPEC with a history-transformed Knlm (tag histories: what the reference's builder writes by default)
+SMALL_HTX_Q8_SPEC = SynthSpec(use_htx=True, knlm_qbits=8, knlm_compress=True)   # ... and quantised / compressed on top: the shape of a shipped sj.knlm
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
 # the CoNgram file the way the reference's builder writes it for a large vocabulary: 4-bit grouped embeddings, variable-length 16-bit keys, window sections
 MID_CONG_VL4_SPEC = SynthSpec(n_words=66000, use_cong=True, cong_only=True, cong_key_size=3, cong_qbit=4, cong_qgroup=8, cong_window=7)   # (> 65536 morphemes: an LM id is a morpheme id, and the reference sizes its root table by the vocabulary while indexing it with 16-bit keys)
@@ -826,8 +828,15 @@ def quantize_knlm(blob: bytes, bits: int, compress: bool) -> bytes:
 def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_id=0, eos_id=1) -> bytes:
     """Interpolated Kneser-Ney estimate serialised in the reference's uncompressed,
     unquantised ``sj.knlm`` layout (reader: /root/reference/src/Knlm.hpp:1003-1167; header:
-    include/kiwi/Knlm.h:9-15).  History transforms (``htx``) are not generated here."""
-    assert htx is None, "history-transformed synthetic LMs are not generated yet"
+    include/kiwi/Knlm.h:9-15).
+
+    ``htx`` (history transformer; the reference's builder uses one by default: useLmTagHistory, src/KiwiBuilder.cpp:1167-1174, ids = tag + vocab):
+    the OLDEST token of a trie path is stored transformed, the rest raw (utils::countNgrams, src/count.hpp:148-240: the first edge from the root is
+    makeNext(historyTx(w)), later ones makeNext(w)), so the key of an n-gram (w1 .. wn), n >= 2, is (htx[w1], w2, .., wn); unigrams stay raw."""
+    if htx is not None:
+        # the reference's loader reads the unknown word's score in the context of <s> BEFORE the suffix links exist (Knlm.hpp:1138-1141): the
+        # bigram (<s>, <unk>) has to be in the model
+        sents = list(sents) + [[bos_id, unk_id, eos_id]] * 3
     flat = np.concatenate([np.asarray(s, dtype=np.int64) for s in sents])
     lens = np.array([len(s) for s in sents], dtype=np.int64)
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
@@ -843,12 +852,22 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
         idx = np.arange(n_tok - n + 1)
         ok = sid[idx] == sid[idx + n - 1]
         idx = idx[ok]
-        cols = [hist[idx + k] for k in range(n - 1)] + [flat[idx + n - 1]]
+        cols = [flat[idx + k] for k in range(n)]
+        if htx is not None and n >= 2:
+            cols[0] = hist[idx]
         code = np.zeros(len(idx), dtype=np.int64)
         for c in cols:
             code = (code << bits) | c
         u, cnt = np.unique(code, return_counts=True)
         grams[n] = (u, cnt.astype(np.float64))
+
+    def lead_tx(code, n):
+        """key of the n-gram whose tokens `code` packs raw: its first token transformed when the model has a history transformer (n >= 2)"""
+        if htx is None or n < 2:
+            return code
+        sh = bits * (n - 1)
+        top = (code >> sh) & ((1 << bits) - 1)
+        return (code & ((1 << sh) - 1)) | (htx[top].astype(np.int64) << sh)
 
     def split(code, n):
         cols = []
@@ -861,7 +880,7 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
     for n in range(order - 1, 0, -1):
         hi, _ = grams[n + 1]
         # suffix of an (n+1)-gram in *mixed* key space: history part transformed, last raw
-        suffix = hi & ((1 << (bits * n)) - 1)
+        suffix = lead_tx(hi & ((1 << (bits * n)) - 1), n)
         u, c = np.unique(suffix, return_counts=True)
         cc = np.zeros(len(grams[n][0]))
         pos = np.searchsorted(grams[n][0], u)
@@ -890,7 +909,7 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
         n1 = np.bincount(inv)
         g = discount * n1 / tot
         # lower-order probability of the same word in the shortened context
-        low_key = keys & ((1 << (bits * (n - 1))) - 1)
+        low_key = lead_tx(keys & ((1 << (bits * (n - 1))) - 1), n - 1)
         if n - 1 == 1:
             lp_pos = np.searchsorted(grams[1][0], low_key)
             lower = prob[1][np.minimum(lp_pos, len(prob[1]) - 1)]
@@ -935,7 +954,7 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
     # nodes (Knlm.hpp:38-63)
     for ctx in sorted(list(nodes_children), key=len, reverse=True):
         for s in range(1, len(ctx)):
-            suf = tuple(ctx[s:])
+            suf = tuple(ctx[s:]) if htx is None else (int(htx[ctx[s]]),) + tuple(ctx[s + 1:])
             if suf not in nodes_children:
                 nodes_children[suf] = {}
                 for d in range(1, len(suf) + 1):

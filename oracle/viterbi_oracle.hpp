@@ -139,7 +139,8 @@ namespace korc
 				{
 					cnt.lmRootProbes++;
 					v = M.lmRoot[next];
-					if (v == 0) return acc + M.h.unkLl;
+					// history-transformed model (Knlm.cpp:61-70): an unseen word still moves the state to the root's child for its transformed id
+					if (v == 0) { node = M.lmHtxNode ? M.lmHtxNode[next] : 0; return acc + M.h.unkLl; }
 				}
 				else
 				{
@@ -155,7 +156,7 @@ namespace korc
 					cnt.lmProbes++;
 					if (lmSearch(M.lmNodes[cur], next, lv) && lv > 0) { node = cur + lv; return acc + asFloat(v); }
 				}
-				node = 0;
+				node = M.lmHtxNode ? M.lmHtxNode[next] : 0;      // (Knlm.cpp:116-126)
 				return acc + asFloat(v);
 			}
 		}

@@ -36,14 +36,15 @@ def small_sbg_model():
     return sm, path
 
 
-@pytest.fixture(scope="session", params=["q8c", "q5"])
+@pytest.fixture(scope="session", params=["q8c", "q5", "htx", "htx-q8c"])
 def small_quantised_model(request):
     """The small synthetic model with its Knlm blob as the reference's builder writes it: 8-bit quantised with compressed node sizes (q8c), or
-    5-bit quantised (q5: the generic fixed-length bit stream) -- kiwi_amd/synth.py quantize_knlm."""
-    from kiwi_amd.synth import SynthModel, SMALL_Q8_SPEC, SMALL_Q5_SPEC
+    5-bit quantised (q5: the generic fixed-length bit stream) -- kiwi_amd/synth.py quantize_knlm; htx: with a history transformer (tag
+    histories: the oldest token of a trie path is stored as tag + vocab), what the reference's builder writes by default; htx-q8c: both."""
+    from kiwi_amd.synth import SynthModel, SMALL_Q8_SPEC, SMALL_Q5_SPEC, SMALL_HTX_SPEC, SMALL_HTX_Q8_SPEC
     d = os.path.join(ROOT, "_data")
     os.makedirs(d, exist_ok=True)
-    name, spec = {"q8c": ("small-q8", SMALL_Q8_SPEC), "q5": ("small-q5", SMALL_Q5_SPEC)}[request.param]
+    name, spec = {"q8c": ("small-q8", SMALL_Q8_SPEC), "q5": ("small-q5", SMALL_Q5_SPEC), "htx": ("small-htx", SMALL_HTX_SPEC), "htx-q8c": ("small-htx-q8", SMALL_HTX_Q8_SPEC)}[request.param]
     path = os.path.join(d, name + ".raw")
     sm = SynthModel(spec)
     sm.raw.save(path)

@@ -82,7 +82,7 @@ def test_directory_loader_equals_container_and_reference(small_model, small_sbg_
 
 
 def test_quantised_knlm_file_in_a_model_directory(small_quantised_model):
-    """A directory whose sj.knlm is quantised / compressed: the product's directory loader against the reference's own loading of the same files."""
+    """A directory whose sj.knlm is quantised / compressed and / or history-transformed (what the reference's builder writes by default): the product's directory loader against the reference's own loading of the same files."""
     import refbridge
     if not refbridge.available():
         pytest.skip("oracle/_ref not built")
@@ -93,7 +93,9 @@ def test_quantised_knlm_file_in_a_model_directory(small_quantised_model):
     sm, path, name = small_quantised_model
     d = _model_dir(path, name)
     import struct
-    assert struct.unpack_from("<B", open(os.path.join(d, "sj.knlm"), "rb").read(), 91)[0] != 0      # KnLangModelHeader::quantized
+    blob = open(os.path.join(d, "sj.knlm"), "rb").read()
+    assert (struct.unpack_from("<B", blob, 91)[0] != 0) == ("q" in name)      # KnLangModelHeader::quantized
+    assert (struct.unpack_from("<Q", blob, 48)[0] != 0) == ("htx" in name)     # KnLangModelHeader::htx_offset
     dev = KiwiAmd(d, lib_path=emu)
     ref = refbridge.RefKiwi(d, model_dir_sbg=False)
     texts = synthetic(sm, 40, 723, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 20, 724)
