@@ -204,6 +204,103 @@ namespace kamd
 		return (float)acc * os * cs + bias;
 	}
 
+	// Character-level CoNgram model for unknown-form scoring (reference nounchr.mdl; Match::oovChrModel, src/UnkFormScorer.cpp:53-66): the local quantised
+	// CoNgram step over a trie with BYTE keys -- a (reordered) token id >= 192 is spelt as two bytes, 192 + (r >> 5) and 224 + (r & 31)
+	// (CoNgramModel::progressContextNode, src/CoNgramModel.hpp:271-300, VlKeyType = uint8_t) --, an output bias per token, and the token reordering.
+	// One source for the host (bake: per-form scores), the oracle and the device kernel (k_unk_chr).
+	struct ChrView
+	{
+		uint32_t dim = 0, stride = 0, nCtx = 0, vocab = 0;
+		const uint8_t* ctxEmb = nullptr;      // nCtx rows: dim x s8, f32 scale, f32 bias
+		const uint8_t* outEmb = nullptr;      // vocab rows: dim x s8, f32 scale, f32 output bias
+		const CongNodeRec* nodes = nullptr; const uint8_t* keys = nullptr; const int32_t* values = nullptr;
+		const int32_t* root = nullptr;        // [256]
+		const uint16_t* inv = nullptr;        // [vocab]: token -> key space (hasReorderedVocab), or null
+		int32_t bosNode = 0; uint32_t bosCtx = 0;      // the state after <s> (UnkFormScorer's constructor)
+		bool present() const { return dim != 0; }
+	};
+	KAMD_HD bool chrSearch(const ChrView& C, const CongNodeRec& nd, uint32_t key, int32_t& v)
+	{
+		uint32_t lo = 0, hi = nd.numNexts;
+		const uint8_t* k = C.keys + nd.nextOff;
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (k[mid] < key) lo = mid + 1; else hi = mid; }
+		if (lo == nd.numNexts || k[lo] != key) return false;
+		v = C.values[nd.nextOff + lo];
+		return v != 0;
+	}
+	// progressContextNodeVl (src/CoNgramModel.hpp:306-385) with byte keys
+	KAMD_HD uint32_t chrContextVl(const ChrView& C, int32_t& nodeIdx, uint32_t key)
+	{
+		for (;;)
+		{
+			int32_t v;
+			const CongNodeRec* node = &C.nodes[nodeIdx];
+			if (nodeIdx != 0)
+			{
+				if (!chrSearch(C, *node, key, v))
+				{
+					if (!node->lower) return 0;
+					nodeIdx += node->lower;
+					continue;
+				}
+			}
+			else
+			{
+				v = C.root[key & 255];
+				if (v == 0) return 0;
+			}
+			if (v > 0) { nodeIdx += v; return C.nodes[nodeIdx].value; }
+			while (node->lower)
+			{
+				node += node->lower;
+				int32_t lv;
+				if (node != C.nodes)
+				{
+					if (chrSearch(C, *node, key, lv) && lv > 0) { nodeIdx = (int32_t)(node + lv - C.nodes); return (uint32_t)-v; }
+				}
+				else
+				{
+					lv = C.root[key & 255];
+					if (lv > 0) { nodeIdx = lv; return (uint32_t)-v; }
+				}
+			}
+			nodeIdx = 0;
+			return (uint32_t)-v;
+		}
+	}
+	// CoNgramModel::progressOneStep -> progress(), window 0, quantised (src/CoNgramModel.cpp:869-908): score of `tok` in the current context (one
+	// fp32 conversion, two multiplications, the context bias, then the output bias), then the context moves on; ctx = the UNPACKED context id
+	// (the trie's values carry a frequency in their top byte: CoNgramModel::unpackContextId)
+	KAMD_HD float chrProgress(const ChrView& C, int32_t& node, uint32_t& ctx, uint32_t tok)
+	{
+		const int8_t* a = reinterpret_cast<const int8_t*>(C.ctxEmb + (size_t)ctx * C.stride);
+		const int8_t* b = reinterpret_cast<const int8_t*>(C.outEmb + (size_t)tok * C.stride);
+		int32_t acc = 0;
+		for (uint32_t k = 0; k < C.dim; ++k) acc += (int32_t)a[k] * (int32_t)b[k];
+		float cs, os, bias, obias;
+		__builtin_memcpy(&cs, a + C.dim, 4); __builtin_memcpy(&bias, a + C.dim + 4, 4); __builtin_memcpy(&os, b + C.dim, 4); __builtin_memcpy(&obias, b + C.dim + 4, 4);
+		float ll = (float)acc * cs * os + bias;
+		ll += obias;
+		uint32_t key = C.inv ? C.inv[tok] : tok;
+		uint32_t c;
+		if (key < 192) c = chrContextVl(C, node, key);
+		else { const uint32_t r = key - 192; chrContextVl(C, node, 192 + (r >> 5)); c = chrContextVl(C, node, 224 + (r & 31)); }
+		ctx = c & 0x00FFFFFFu;
+		return ll;
+	}
+	// ChrTokenizer::encodeOne (src/Dataset.cpp:805-847) of one UTF-16 unit whose identifySpecialChr type is `type`
+	KAMD_HD uint32_t chrToken(uint32_t c, uint8_t type)
+	{
+		if (0xAC00 <= c && c < 0xD7A4) return 10 + (c - 0xAC00) / 28;
+		if (0x11A8 <= c && c <= 0x11C2) return 10 + 399 + (c - 0x11A8);
+		if (0x21 <= c && c < 0x7F) return 10 + 399 + 27 + (c - 0x21);
+		switch (type)
+		{
+		case T_SF: return 1; case T_SP: return 2; case T_SS: return 3; case T_SSO: return 4; case T_SSC: return 5; case T_SE: return 6; case T_SO: return 7; case T_SH: return 9;
+		default: return 8;
+		}
+	}
+
 	// Host-side owner.
 	struct FlatModel
 	{
@@ -235,6 +332,11 @@ namespace kamd
 		// `ll` bits, root table, per-node suffix link), embeddings
 		std::vector<CongNodeRec> congNodes; std::vector<uint32_t> congKeys; std::vector<int32_t> congValues, congRoot;
 		std::vector<LmSlot> congHash; uint32_t congHashMask = 0; std::vector<LmRootRec> congRoot2; std::vector<LmBackoff> congBackoff;
+		// character model of Match::oovChrModel (ChrView) and, per form, the sum of its steps over the form's own string incl. </s> (what a dictionary
+		// node's unknown-noun reading is scored with; the analyze-time bias is subtracted where it is used)
+		std::vector<CongNodeRec> chrNodes; std::vector<uint8_t> chrKeys; std::vector<int32_t> chrValues, chrRoot; std::vector<uint16_t> chrInv;
+		std::vector<uint8_t> chrCtxEmb, chrOutEmb; uint32_t chrDim = 0, chrCtx = 0, chrVocab = 0; int32_t chrBosNode = 0; uint32_t chrBosCtx = 0;
+		std::vector<float> formUnkChr;
 		std::vector<uint8_t> congCtxEmb, congOutEmb; uint32_t congDim = 0, congCtx = 0, congVocab = 0, congVlTMax = 0xFFFFFFFFu, congVlBits = 0;
 
 		CongView congView() const
@@ -244,6 +346,16 @@ namespace kamd
 			v.dim = congDim; v.stride = congDim + 8; v.nCtx = congCtx; v.vocabSize = congVocab; v.rootSize = (uint32_t)congRoot.size(); v.vlTMax = congVlTMax; v.vlBits = congVlBits;
 			v.ctxEmb = congCtxEmb.data(); v.outEmb = congOutEmb.data();
 			v.nodes = congNodes.data(); v.keys = congKeys.data(); v.values = congValues.data(); v.root = congRoot.data();
+			return v;
+		}
+
+		ChrView chrView() const
+		{
+			ChrView v;
+			if (!chrDim) return v;
+			v.dim = chrDim; v.stride = chrDim + 8; v.nCtx = chrCtx; v.vocab = chrVocab;
+			v.ctxEmb = chrCtxEmb.data(); v.outEmb = chrOutEmb.data(); v.nodes = chrNodes.data(); v.keys = chrKeys.data(); v.values = chrValues.data(); v.root = chrRoot.data();
+			v.inv = chrInv.empty() ? nullptr : chrInv.data(); v.bosNode = chrBosNode; v.bosCtx = chrBosCtx;
 			return v;
 		}
 

@@ -555,6 +555,149 @@ namespace kamd
 			std::vector<uint8_t> chunkPos, knlm, sbg, cong;
 		};
 
+		// ---- character-level CoNgram model (reference nounchr.mdl; writer src/CoNgramModel.cpp:2087-2400, reader :425-789 with VlKeyType = uint8_t) ----
+		// header | node sizes, one BYTE per node of the pre-order stream | keys, bytes | values, Stream VByte "0124" | [flag 4] one frequency byte per node
+		// (16-byte aligned behind the values) | per context: row, fp16 -bias | per token: row | [flag 1] one bias code per token + fp16 minimum
+		// (bias = code * -min / 255 + min) | [flag 2] u16 per token: its id in the trie's key space | [flag 4] fp16 entropy per context (not used here)
+		void loadChr(FlatModel& m, const uint8_t* blob, size_t size)
+		{
+			struct Header { uint64_t vocabSize, contextSize; uint16_t dim, flags; uint8_t keySize, windowSize, qbit, qgroup; uint64_t numNodes, nodeOffset, keyOffset, valueOffset, embOffset; };
+			if (size < sizeof(Header)) throw std::runtime_error{ "nounchr.mdl: truncated header" };
+			Header hd; std::memcpy(&hd, blob, sizeof(hd));
+			if (hd.keySize != 1) throw std::runtime_error{ "nounchr.mdl: a character model has 8-bit keys (keySize 1)" };
+			if (hd.qbit != 8 || hd.windowSize != 0) throw std::runtime_error{ "nounchr.mdl: only 8-bit embeddings without a window are supported by this loader" };
+			if (hd.dim == 0 || hd.dim % 4 || hd.numNodes < 1 || hd.vocabSize > 65535) throw std::runtime_error{ "nounchr.mdl: bad header" };
+			const uint8_t* end = blob + size;
+			const size_t nNodes = hd.numNodes;
+			if (hd.nodeOffset + nNodes > size || hd.keyOffset + nNodes - 1 > size) throw std::runtime_error{ "nounchr.mdl: truncated trie" };
+			std::vector<uint32_t> values(nNodes);
+			const size_t valBytes = svbDecode(blob + hd.valueOffset, end, values.data(), nNodes, true);
+			if (hd.flags & 4) for (auto& v : values) v &= 0x00FFFFFFu;      // (the reference packs the frequency byte on top; only unknown-form modes 2 / 3 read it)
+			(void)valBytes;
+			const uint8_t* sizes = blob + hd.nodeOffset; const uint8_t* keys = blob + hd.keyOffset;
+			size_t nonLeaf = 0;
+			for (size_t i = 0; i < nNodes; ++i) nonLeaf += sizes[i] ? 1 : 0;
+			m.chrNodes.assign(nonLeaf, CongNodeRec{});
+			m.chrKeys.assign(keys, keys + (nNodes - 1));
+			m.chrValues.assign(nNodes - 1, 0);
+			m.chrRoot.assign(256, 0);
+			struct Range { size_t node, cur, end; };
+			std::vector<Range> st;
+			size_t ni = 0, nextOff = 0;
+			for (size_t i = 0; i < nNodes; ++i)
+			{
+				if (sizes[i])
+				{
+					if (!st.empty()) m.chrValues[st.back().cur] = (int32_t)(ni - st.back().node);
+					CongNodeRec& n = m.chrNodes[ni];
+					n.value = values[i]; n.numNexts = sizes[i]; n.nextOff = (uint32_t)nextOff;
+					st.push_back(Range{ ni, nextOff, nextOff + sizes[i] });
+					nextOff += sizes[i];
+					++ni;
+				}
+				else
+				{
+					if (st.empty()) throw std::runtime_error{ "nounchr.mdl: malformed node stream" };
+					m.chrValues[st.back().cur] = -(int32_t)values[i];
+					st.back().cur++;
+					while (st.back().cur == st.back().end)
+					{
+						st.pop_back();
+						if (st.empty()) break;
+						st.back().cur++;
+					}
+				}
+			}
+			for (uint32_t i = 0; i < m.chrNodes[0].numNexts; ++i) m.chrRoot[m.chrKeys[i]] = m.chrValues[i];
+			m.chrDim = hd.dim; m.chrCtx = (uint32_t)hd.contextSize; m.chrVocab = (uint32_t)hd.vocabSize;
+			ChrView C = m.chrView();      // (host walk over the tables filled so far; embeddings follow)
+			// suffix links and inherited context ids, breadth first (CoNgramModel.cpp:547-568; findLowerNode / findLowerValue, CoNgramModel.hpp:181-227)
+			std::deque<uint32_t> dq{ 0u };
+			while (!dq.empty())
+			{
+				const uint32_t p = dq.front(); dq.pop_front();
+				const CongNodeRec pn = m.chrNodes[p];
+				for (uint32_t i = 0; i < pn.numNexts; ++i)
+				{
+					const int32_t v = m.chrValues[pn.nextOff + i];
+					if (v <= 0) continue;
+					const uint32_t k = m.chrKeys[pn.nextOff + i];
+					const uint32_t child = p + v;
+					uint32_t node = p, lowerNode;
+					for (;;)
+					{
+						if (!m.chrNodes[node].lower) { lowerNode = node; break; }
+						const uint32_t low = node + m.chrNodes[node].lower;
+						int32_t found;
+						if (chrSearch(C, m.chrNodes[low], k, found) && found > 0) { lowerNode = low + found; break; }
+						node = low;
+					}
+					m.chrNodes[child].lower = (int32_t)lowerNode - (int32_t)child;
+					if (m.chrNodes[child].value == 0)
+					{
+						uint32_t nd = p; uint32_t val = 0; bool done = false;
+						while (m.chrNodes[nd].lower)
+						{
+							const uint32_t low = nd + m.chrNodes[nd].lower;
+							int32_t found;
+							if (chrSearch(C, m.chrNodes[low], k, found)) { val = found >= 0 ? m.chrNodes[low + found].value : (uint32_t)(-found); done = true; break; }
+							nd = low;
+						}
+						if (!done) val = m.chrNodes[nd].value;
+						m.chrNodes[child].value = val;
+					}
+					dq.push_back(child);
+				}
+			}
+			const size_t stride = (size_t)hd.dim + 8;
+			m.chrCtxEmb.assign(hd.contextSize * stride, 0); m.chrOutEmb.assign(hd.vocabSize * stride, 0);
+			const uint8_t* e = blob + hd.embOffset;
+			const size_t ctxRec = (size_t)hd.dim + 4, outRec = (size_t)hd.dim + 2;
+			size_t need = hd.contextSize * ctxRec + hd.vocabSize * outRec;
+			if (hd.flags & 1) need += hd.vocabSize + 2;
+			if (hd.flags & 2) need += 2 * hd.vocabSize;
+			if (e + need > end) throw std::runtime_error{ "nounchr.mdl: truncated embeddings" };
+			for (size_t i = 0; i < hd.contextSize; ++i, e += ctxRec)
+			{
+				uint8_t* o = &m.chrCtxEmb[i * stride];
+				std::memcpy(o, e, hd.dim);
+				uint16_t hs, hb; std::memcpy(&hs, e + hd.dim, 2); std::memcpy(&hb, e + hd.dim + 2, 2);
+				const float scale = halfToFloat(hs), bias = -halfToFloat(hb);
+				std::memcpy(o + hd.dim, &scale, 4); std::memcpy(o + hd.dim + 4, &bias, 4);
+			}
+			for (size_t i = 0; i < hd.vocabSize; ++i, e += outRec)
+			{
+				uint8_t* o = &m.chrOutEmb[i * stride];
+				std::memcpy(o, e, hd.dim);
+				uint16_t hs; std::memcpy(&hs, e + hd.dim, 2);
+				const float scale = halfToFloat(hs);
+				std::memcpy(o + hd.dim, &scale, 4);
+			}
+			if (hd.flags & 1)
+			{
+				uint16_t hm; std::memcpy(&hm, e + hd.vocabSize, 2);
+				const float minVal = halfToFloat(hm);
+				for (size_t i = 0; i < hd.vocabSize; ++i)
+				{
+					const float b = (float)e[i] * (-minVal) / 255.f + minVal;      // CoNgramModel.cpp:764-772
+					std::memcpy(&m.chrOutEmb[i * stride + hd.dim + 4], &b, 4);
+				}
+				e += hd.vocabSize + 2;
+			}
+			m.chrInv.clear();
+			if (hd.flags & 2)
+			{
+				m.chrInv.resize(hd.vocabSize);
+				std::memcpy(m.chrInv.data(), e, 2 * hd.vocabSize);
+				e += 2 * hd.vocabSize;
+			}
+			// the state after <s> (UnkFormScorer::UnkFormScorer, src/UnkFormScorer.cpp:22-25)
+			C = m.chrView();
+			int32_t node = 0; uint32_t ctx = 0;
+			chrProgress(C, node, ctx, 0);
+			m.chrBosNode = node; m.chrBosCtx = ctx;
+		}
+
 		std::vector<uint8_t> readFile(const std::string& path, bool required)
 		{
 			FILE* f = std::fopen(path.c_str(), "rb");

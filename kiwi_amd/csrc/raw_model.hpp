@@ -38,6 +38,8 @@ namespace kamd
 		size_t sbgSize = 0;
 		const uint8_t* cong = nullptr;  // optional CoNgram blob (reference cong.mdl layout)
 		size_t congSize = 0;
+		const uint8_t* nounchr = nullptr;  // optional character-level CoNgram blob (reference nounchr.mdl layout)
+		size_t nounchrSize = 0;
 
 		size_t nForms() const { return meta[0]; }
 		size_t nMorphs() const { return meta[1]; }
@@ -62,6 +64,7 @@ namespace kamd
 			if (c.has("knlm")) { auto s = c.get("knlm"); knlm = s.data; knlmSize = s.size; }      // (a CoNgram-only model has none, like the reference's models/cong/base)
 			if (c.has("sbg")) { auto g = c.get("sbg"); sbg = g.data; sbgSize = g.size; }
 			if (c.has("cong")) { auto g = c.get("cong"); cong = g.data; congSize = g.size; }
+			if (c.has("nounchr")) { auto g = c.get("nounchr"); nounchr = g.data; nounchrSize = g.size; }
 		}
 	};
 }

@@ -127,6 +127,7 @@ class RawModel:
         self.knlm: bytes = b""
         self.sbg: bytes = b""          # optional: SkipBigramModel blob
         self.cong: bytes = b""         # optional: CoNgram model blob (cong.mdl layout)
+        self.nounchr: bytes = b""      # optional: character-level CoNgram model for unknown-form scoring (nounchr.mdl layout)
         self._init_defaults()
 
     # KiwiBuilder::initMorphemes (KiwiBuilder.cpp:1108-1131)
@@ -211,6 +212,7 @@ class RawModel:
             **({"knlm": np.frombuffer(self.knlm, "u1")} if self.knlm else {}),
             **({"sbg": np.frombuffer(self.sbg, "u1")} if self.sbg else {}),
             **({"cong": np.frombuffer(self.cong, "u1")} if getattr(self, "cong", None) else {}),
+            **({"nounchr": np.frombuffer(self.nounchr, "u1")} if getattr(self, "nounchr", None) else {}),
         }
 
     def save(self, path: str):
@@ -306,6 +308,7 @@ class SynthSpec:
     cong_key_size: int = 4       # CoNgramModelHeader::keySize: 2 / 4 = 16- / 32-bit trie keys, 3 = 16-bit keys with ids >= 63488 spelt as two "surrogate" keys (src/CoNgramModel.hpp:271-300)
     cong_qbit: int = 8           # 4: embeddings packed two per byte with one 8-bit local scale / zero point per cong_qgroup values (src/CoNgramModel.cpp:378-400)
     cong_qgroup: int = 0
+    use_nounchr: bool = False    # also emit a character-level CoNgram model (reference nounchr.mdl: Match::oovChrModel scores unknown forms with it, src/UnkFormScorer.cpp)
     cong_window: int = 0         # > 0: the file also carries the sections of the global model (confidences, distant embeddings, mask), as the reference's builder always writes them
     seed: int = SEED_BASE
 
@@ -319,6 +322,7 @@ SMALL_Q8_SPEC = SynthSpec(knlm_qbits=8, knlm_compress=True)   # SMALL_SPEC with 
 SMALL_Q5_SPEC = SynthSpec(knlm_qbits=5)                       # ... and a bit width that exercises the generic fixed-length bit stream
 SMALL_HTX_SPEC = SynthSpec(use_htx=True)                       # SMALL_SPEC with a history-transformed Knlm (tag histories: what the reference's builder writes by default)
 SMALL_HTX_Q8_SPEC = SynthSpec(use_htx=True, knlm_qbits=8, knlm_compress=True)   # ... and quantised / compressed on top: the shape of a shipped sj.knlm
+SMALL_CONG_CHR_SPEC = SynthSpec(use_cong=True, use_nounchr=True)   # SMALL_CONG_SPEC + the character model of Match::oovChrModel (the reference loads it quantised with CoNgram model types only)
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
 # the CoNgram file the way the reference's builder writes it for a large vocabulary: 4-bit grouped embeddings, variable-length 16-bit keys, window sections
 MID_CONG_VL4_SPEC = SynthSpec(n_words=66000, use_cong=True, cong_only=True, cong_key_size=3, cong_qbit=4, cong_qgroup=8, cong_window=7)   # (> 65536 morphemes: an LM id is a morpheme id, and the reference sizes its root table by the vocabulary while indexing it with 16-bit keys)
@@ -692,6 +696,8 @@ class SynthModel:
             raw.cong = build_cong(sents, vocab, dim=sp.cong_dim, seed=sp.seed + 3, key_size=sp.cong_key_size, qbit=sp.cong_qbit, qgroup=sp.cong_qgroup, window=sp.cong_window)
             if sp.cong_only:
                 raw.knlm = b""
+        if sp.use_nounchr:
+            raw.nounchr = build_nounchr([f for f in raw.forms[DEFAULT_FORM_SIZE:] if f], seed=sp.seed + 4)
 
     # -- text corpus -------------------------------------------------------------------------
     def make_corpus(self, n, seed, min_jamo=5, max_jamo=200, exact_jamo=None, oov_rate=0.03, lognormal=None):
@@ -1177,6 +1183,130 @@ def build_cong(sents, vocab_size, dim=32, max_ctx_len=2, seed=0, min_count=2, ke
     buf[node_off:node_off + len(node_b)] = node_b
     buf[key_off:key_off + len(key_b)] = key_b
     buf[val_off:val_off + len(val_b)] = val_b
+    buf[emb_off:emb_off + len(emb)] = emb
+    return bytes(buf)
+
+
+CHR_VOCAB = 530      # ChrTokenizer::Token::max (include/kiwi/Dataset.h:144-153)
+
+
+def chr_token(c: int, special_type) -> int:
+    """ChrTokenizer::encodeOne (src/Dataset.cpp:805-847) of one UTF-16 unit; special_type(c) = identifySpecialChr as a POSTag name."""
+    if 0xAC00 <= c < 0xD7A4:
+        return 10 + (c - 0xAC00) // 28
+    if 0x11A8 <= c <= 0x11C2:
+        return 10 + 399 + (c - 0x11A8)
+    if 0x21 <= c < 0x7F:
+        return 10 + 399 + 27 + (c - 0x21)
+    return {"sf": 1, "sp": 2, "ss": 3, "sso": 4, "ssc": 5, "se": 6, "so": 7, "sh": 9}.get(special_type(c), 8)
+
+
+def build_nounchr(forms, dim=32, max_ctx_len=2, seed=0) -> bytes:
+    """A synthetic character-level CoNgram model in the layout of the reference's ``nounchr.mdl`` (writer: src/CoNgramModel.cpp:2087-2400, reader
+    :425-789): keySize 1 -- the trie's keys are BYTES, a (reordered) token id >= 192 is spelt as two of them (192 + high 5 bits, 224 + low 5 bits:
+    CoNgramModel::progressContextNode, src/CoNgramModel.hpp:271-300) --, node sizes and keys as plain bytes, values Stream VByte, and all three
+    optional sections (flags 7): one frequency byte per trie node behind the values, an 8-bit output bias + its fp16 minimum, the token
+    reordering (u16 per token), an fp16 entropy per context.  Trained on nothing: the trie holds the character n-grams of the dictionary's own
+    forms, embeddings / biases are random in the range of log-probabilities."""
+    rng = np.random.default_rng(seed)
+    V = CHR_VOCAB
+    inv = np.arange(V)
+    inv[1:] = 1 + rng.permutation(V - 1)          # token -> context key space (0 = BOS / EOS stays)
+
+    def keys_of(tok):
+        k = int(inv[tok])
+        if k < 192:
+            return (k,)
+        r = k - 192
+        return (192 + (r >> 5), 224 + (r & 31))
+
+    def toks(form):
+        out = []
+        for ch in form:
+            c = ord(ch)
+            if 0xAC00 <= c < 0xD7A4:
+                coda = (c - 0xAC00) % 28
+                out.append(10 + (c - coda - 0xAC00) // 28)
+                if coda:
+                    out.append(10 + 399 + coda - 1)
+            elif 0x21 <= c < 0x7F:
+                out.append(10 + 399 + 27 + c - 0x21)
+            else:
+                out.append(8)
+        return out
+    children = {(): {}}
+    for f in forms:
+        t = [0] + toks(f) + [0]
+        for i in range(len(t)):
+            for n in range(1, max_ctx_len + 2):
+                if i + n > len(t):
+                    break
+                hist = tuple(k for x in t[i:i + n - 1] for k in keys_of(x))
+                if hist not in children:
+                    break
+                for k in keys_of(t[i + n - 1]):
+                    children[hist][k] = True
+                    hist = hist + (k,)
+                    children.setdefault(hist, {})
+    node_sizes, keys_out, values, freqs = [], [], [], []
+    n_ctx = 1
+
+    def emit(h):
+        nonlocal n_ctx
+        ch = children[h]
+        assert len(ch) < 256
+        node_sizes.append(len(ch))
+        freqs.append(int(rng.integers(0, 200)))
+        if h and rng.random() < 0.85 and not (192 <= h[-1] < 224):      # (the node of a first "surrogate" byte is no context)
+            values.append(n_ctx); n_ctx += 1
+        else:
+            values.append(0)
+        ks = sorted(ch)
+        keys_out.extend(ks)
+        for k in ks:
+            g = h + (k,)
+            if children.get(g):
+                emit(g)
+            else:
+                node_sizes.append(0)
+                freqs.append(int(rng.integers(0, 200)))
+                values.append(n_ctx); n_ctx += 1
+    import sys
+    sys.setrecursionlimit(10000)
+    emit(())
+    num_nodes = len(node_sizes)
+    assert len(keys_out) == num_nodes - 1 and n_ctx < (1 << 24)
+
+    def half(x):
+        return np.asarray(x, np.float16).view(np.uint16)
+    ctx_emb = rng.integers(-63, 64, size=(n_ctx, dim), dtype=np.int8)
+    ctx_scale = half(rng.uniform(0.008, 0.024, n_ctx))
+    ctx_negbias = half(rng.uniform(2.0, 6.0, n_ctx))
+    out_emb = rng.integers(-63, 64, size=(V, dim), dtype=np.int8)
+    out_scale = half(rng.uniform(0.008, 0.024, V))
+    emb = bytearray()
+    for i in range(n_ctx):
+        emb += ctx_emb[i].tobytes() + ctx_scale[i].tobytes() + ctx_negbias[i].tobytes()
+    for i in range(V):
+        emb += out_emb[i].tobytes() + out_scale[i].tobytes()
+    emb += rng.integers(0, 256, V, dtype=np.uint8).tobytes() + half(-3.5).tobytes()      # output bias codes, their minimum (maximum 0)
+    emb += inv.astype("<u2").tobytes()
+    emb += half(rng.uniform(0.0, 4.0, n_ctx)).tobytes()                                     # context entropies
+
+    def al(x):
+        return (x + 15) & ~15
+    node_b, key_b, val_b = bytes(node_sizes), bytes(keys_out), _svb_encode(values, True)
+    node_off = 64
+    key_off = al(node_off + len(node_b))
+    val_off = al(key_off + len(key_b))
+    freq_off = al(val_off + len(val_b))
+    emb_off = al(freq_off + num_nodes)
+    buf = bytearray(al(emb_off + len(emb)))
+    struct.pack_into("<QQHHBBBBQQQQQ", buf, 0, V, n_ctx, dim, 7, 1, 0, 8, 0, num_nodes, node_off, key_off, val_off, emb_off)
+    buf[node_off:node_off + len(node_b)] = node_b
+    buf[key_off:key_off + len(key_b)] = key_b
+    buf[val_off:val_off + len(val_b)] = val_b
+    buf[freq_off:freq_off + num_nodes] = bytes(freqs)
     buf[emb_off:emb_off + len(emb)] = emb
     return bytes(buf)
 
