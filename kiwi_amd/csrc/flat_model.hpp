@@ -399,4 +399,6 @@ namespace kamd
 	// Morpheme::hasMorpheme over a set of morpheme ids (include/kiwi/Form.h:187-196), for every morpheme at once: bit m is set iff the set holds
 	// m's combined morpheme or one of its chunks -- what the candidate loops test a blocklist with (src/PathEvaluator.hpp:385, 892)
 	std::vector<uint32_t> blockBitsOf(const FlatModel& m, const std::vector<uint32_t>& ids);
+	// UnkFormScorer::chrBasedScore without the final bias (src/UnkFormScorer.cpp:53-66) on the host: the bake's per-form table, the oracle
+	float chrScoreHost(const ChrView& C, const uint16_t* s, size_t n);
 }

@@ -552,7 +552,7 @@ namespace kamd
 			std::vector<uint32_t> meta, formPtr, formCandPtr, formCand, chunkIds;
 			std::vector<uint16_t> formChars;
 			std::vector<RawMorph> morph;
-			std::vector<uint8_t> chunkPos, knlm, sbg, cong;
+			std::vector<uint8_t> chunkPos, knlm, sbg, cong, nounchr;
 		};
 
 		// ---- character-level CoNgram model (reference nounchr.mdl; writer src/CoNgramModel.cpp:2087-2400, reader :425-789 with VlKeyType = uint8_t) ----
@@ -572,8 +572,15 @@ namespace kamd
 			if (hd.nodeOffset + nNodes > size || hd.keyOffset + nNodes - 1 > size) throw std::runtime_error{ "nounchr.mdl: truncated trie" };
 			std::vector<uint32_t> values(nNodes);
 			const size_t valBytes = svbDecode(blob + hd.valueOffset, end, values.data(), nNodes, true);
-			if (hd.flags & 4) for (auto& v : values) v &= 0x00FFFFFFu;      // (the reference packs the frequency byte on top; only unknown-form modes 2 / 3 read it)
-			(void)valBytes;
+			if (hd.flags & 4)
+			{
+				// one frequency byte per node, 16-byte aligned behind the values, packed on top of the context id as the reference does (clamped to 127,
+				// CoNgramModel.cpp:467-479): "no context of its own" (value == 0, inherit from the suffix) is tested on the PACKED value there, so a
+				// node with context 0 and a non-zero frequency keeps context 0; chrProgress unpacks (CoNgramModel::unpackContextId)
+				const size_t fo = hd.valueOffset + (valBytes + 15) / 16 * 16;
+				if (fo + nNodes > size) throw std::runtime_error{ "nounchr.mdl: truncated trie frequencies" };
+				for (size_t i = 0; i < nNodes; ++i) values[i] = (values[i] & 0x00FFFFFFu) | ((uint32_t)std::min<uint8_t>(blob[fo + i], 127) << 24);
+			}
 			const uint8_t* sizes = blob + hd.nodeOffset; const uint8_t* keys = blob + hd.keyOffset;
 			size_t nonLeaf = 0;
 			for (size_t i = 0; i < nNodes; ++i) nonLeaf += sizes[i] ? 1 : 0;
@@ -785,11 +792,23 @@ namespace kamd
 			raw.knlm = o.knlm.empty() ? nullptr : o.knlm.data();
 			raw.sbg = o.sbg.empty() ? nullptr : o.sbg.data(); raw.sbgSize = o.sbg.size();
 			raw.cong = o.cong.empty() ? nullptr : o.cong.data(); raw.congSize = o.cong.size();
+			// the character model of Match::oovChrModel (KiwiBuilder.cpp:1094-1100): optional
+			o.nounchr = readFile(dir + "/nounchr.mdl", false);
+			raw.nounchr = o.nounchr.empty() ? nullptr : o.nounchr.data(); raw.nounchrSize = o.nounchr.size();
 		}
 	}
 
 	// `path`: a KAMDRAW1 container (kiwi_amd/synth.py), or a directory -- one that holds the reference's own model files sj.morph + sj.knlm
 	// (+ skipbigram.mdl), else one that holds kiwi_amd.raw
+	float chrScoreHost(const ChrView& C, const uint16_t* s, size_t n)
+	{
+		int32_t node = C.bosNode; uint32_t ctx = C.bosCtx;
+		float score = 0;
+		for (size_t i = 0; i < n; ++i) score += chrProgress(C, node, ctx, chrToken(s[i], identifySpecialChr(s[i])));
+		score += chrProgress(C, node, ctx, 0);
+		return score;
+	}
+
 	void bakeModel(FlatModel& m, const std::string& path)
 	{
 		Container file;
@@ -1125,6 +1144,19 @@ namespace kamd
 		if (raw.knlm) loadKnlm(m, raw.knlm, raw.knlmSize);
 		else if (!raw.cong) throw std::runtime_error{ "Cannot find any valid model files" };      // KiwiBuilder.cpp:984-990
 		if (raw.cong) loadCong(m, raw.cong, raw.congSize);
+		if (raw.nounchr)
+		{
+			// the reference loads nounchr.mdl QUANTISED only next to a CoNgram model (KiwiBuilder.cpp:1096-1099: fp32 through Eigen otherwise); the
+			// quantised scorer is what is restated here, so the character model is kept for CoNgram models only
+			if (raw.cong)
+			{
+				loadChr(m, raw.nounchr, raw.nounchrSize);
+				// per form: the steps over its own string and </s> (UnkFormScorer::chrBasedScore before the bias, src/UnkFormScorer.cpp:53-66)
+				const ChrView C = m.chrView();
+				m.formUnkChr.assign(nF, 0.f);
+				for (size_t f = 0; f < nF; ++f) m.formUnkChr[f] = chrScoreHost(C, m.formChars.data() + m.forms[f].charOff, m.forms[f].len);
+			}
+		}
 		if (raw.sbg)
 		{
 			// SkipBigramModel blob, uncompressed + unquantised (reference src/SkipBigramModel.hpp:40-105): header{u64 vocabSize; u8 keySize,

@@ -25,6 +25,7 @@ struct OracleHandle
 	SplitConfig scfg{ 0, 6, 0xFFFFFFFFu, 0 };
 	BestPathConfig bcfg;
 	bool integrateAllomorph = true;
+	float oovChrBias = 0;      // KiwiConfig::oovChrBias
 	Counters counters;
 	std::vector<uint32_t> blockIds, blockBits;      // AnalyzeOption::blocklist of the following analyses (korc_blocklist_*)
 };
@@ -52,6 +53,14 @@ namespace
 		bc.topN = topN;
 		bc.splitComplex = match & M_SPLIT_COMPLEX; bc.splitSaisiot = match & M_SPLIT_SAISIOT; bc.mergeSaisiot = match & M_MERGE_SAISIOT;
 		bc.spaceTolerance = sc.spaceTol;
+		// Match::oovMask (include/kiwi/PatternMatcher.h:20-24): 1 = the character model scores unknown forms; 2 / 3 (with substring frequencies) are not restated
+		const kamd::ChrView chrV = h.model.chrView();
+		if ((match >> 8) & 3)
+		{
+			if (!chrV.present()) throw std::runtime_error{ "`oovChrModel` option is set but the character-level noun model is not loaded." };      // Kiwi.cpp:1032-1035
+			if (((match >> 8) & 3) > 1) throw std::runtime_error{ "oracle: oovChrFreqModel / oovChrFreqBranchModel are not restated" };
+			bc.chr = &chrV; bc.oovChrBias = h.oovChrBias;
+		}
 		LatticeBuilder lb{ h.view, sc, cnt };
 		TypoLatticeBuilder tlb{ h.view, sc };
 		ResultBuilder rb{ h.model, topN, match, h.integrateAllomorph };
@@ -171,6 +180,16 @@ extern "C"
 		*node = st.lmNode; *pos = st.histPos; for (int i = 0; i < 8; ++i) hist8[i] = st.hist[i];
 		return ll;
 	}
+
+	// UnkFormScorer::chrBasedScore of a (normalised) string with bias 0; NaN when the model has no character model
+	float korc_unk_chr_score(void* hp, const uint16_t* s, uint32_t len)
+	{
+		auto& h = *(OracleHandle*)hp;
+		const kamd::ChrView C = h.model.chrView();
+		if (!C.present()) return 0.f / 0.f;
+		return kamd::chrScoreHost(C, s, len);
+	}
+	void korc_set_oov_chr_bias(void* hp, float bias) { ((OracleHandle*)hp)->oovChrBias = bias; }
 
 	struct TypoHandle { korc::typo::Rules rules; std::unique_ptr<korc::typo::Prepared> prepared; };
 	size_t korc_split_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap);

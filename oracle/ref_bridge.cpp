@@ -39,6 +39,7 @@
 #include "PathEvaluator.h"
 #include "MathFunc.hpp"
 #include "serializer.hpp"
+#include "UnkFormScorer.h"
 
 #include "../kiwi_amd/csrc/container.hpp"
 #include "../kiwi_amd/csrc/raw_model.hpp"
@@ -53,9 +54,11 @@ namespace kiwi
 		template float logSumExp<ArchType::balanced>(const float* arr, size_t size);
 		template float logSumExp<ArchType::sse2>(const float* arr, size_t size);
 	}
-	// src/Dataset.cpp:805 (needs Eigen-dependent headers); only used by the optional OOV
-	// character model which the bridge never enables.
+#ifndef KREF_X86
+	// src/Dataset.cpp:805 (needs Eigen-dependent headers); only used by the optional OOV character model, which only the x86 build of the bridge
+	// enables -- that build compiles the real src/Dataset.cpp over the Eigen stand-in
 	size_t ChrTokenizer::encodeOne(char32_t) const { throw std::runtime_error{ "ChrTokenizer unavailable in ref bridge" }; }
+#endif
 }
 
 namespace kamd_ref { struct Access; }
@@ -137,6 +140,20 @@ namespace kiwi
 			}
 		}
 
+#ifdef KREF_X86
+		static void attachChr(Kiwi& k, const uint8_t* blob, size_t size, ArchType arch)
+		{
+			utils::MemoryOwner mem{ size };
+			std::memcpy(mem.get(), blob, size);
+			k.nounChrMdl = lm::CoNgramModelBase::create(utils::MemoryObject{ std::move(mem) }, arch, false, true);
+		}
+		static float unkChrScore(const Kiwi& k, const char16_t* s, size_t n)
+		{
+			UnkFormScorer sc{ 0.f, 0.f, k.nounChrMdl.get(), 0.f, nullptr };
+			return sc(U16StringView{ s, n });
+		}
+		static bool hasChr(const Kiwi& k) { return !!k.nounChrMdl; }
+#endif
 		static Kiwi build(const kamd::RawModel& raw, ArchType arch)
 		{
 			Vector<FormRaw> forms; Vector<MorphemeRaw> morphemes;
@@ -144,7 +161,13 @@ namespace kiwi
 #ifdef KREF_X86
 			// a container that carries a CoNgram blob is analysed with it (the reference's default model type): CoNgramModelBase::create with
 			// quantized = true exists for the SIMD architectures only (src/ArchAvailable.h:50-78), which is why this is the x86 build's job
-			if (raw.cong) return build(forms, morphemes, raw.cong, raw.congSize, nullptr, 0, arch, true);
+			if (raw.cong)
+			{
+				Kiwi k = build(forms, morphemes, raw.cong, raw.congSize, nullptr, 0, arch, true);
+				// the character model of Match::oovChrModel next to a CoNgram model: loaded quantised (KiwiBuilder.cpp:1094-1100)
+				if (raw.nounchr) attachChr(k, raw.nounchr, raw.nounchrSize, arch);
+				return k;
+			}
 #endif
 			return build(forms, morphemes, raw.knlm, raw.knlmSize, raw.sbg, raw.sbgSize, arch);
 		}
@@ -458,6 +481,17 @@ extern "C"
 		if (!lm) return 0.f / 0.f;
 		return lm->progressOneStep(*node, *ctx, wid);
 	}
+#endif
+
+#ifdef KREF_X86
+	// UnkFormScorer::chrBasedScore (src/UnkFormScorer.cpp:53-66) of a normalised string through the reference's own scorer, bias 0
+	float kref_unk_chr_score(void* hp, const uint16_t* s, uint32_t len)
+	{
+		auto& kw = ((RefHandle*)hp)->kw;
+		if (!Acc::hasChr(kw)) return 0.f / 0.f;
+		return Acc::unkChrScore(kw, (const char16_t*)s, len);
+	}
+	void kref_set_oov_chr_bias(void* hp, float bias) { Acc::config(((RefHandle*)hp)->kw).oovChrBias = bias; }
 #endif
 
 	// One SkipBigram state step through the reference (SbgState::nextImpl, src/SkipBigramModel.hpp:169-182); 16-bit vocabulary only.

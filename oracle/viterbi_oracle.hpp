@@ -30,6 +30,8 @@ namespace korc
 	struct BestPathConfig
 	{
 		float cutOff = 8, spacePenalty = 7, typoCostWeight = 6, oovRuleScale = 4, oovRuleBias = 4;
+		// Match::oovChrModel: unknown forms are scored by the character model instead of the length rule (UnkFormScorer::operator(), src/UnkFormScorer.h:40-58)
+		const kamd::ChrView* chr = nullptr; float oovChrBias = 0;
 		uint32_t spaceTolerance = 0;
 		uint32_t topN = 1;
 		// container selection by number of incoming paths and the per-bucket key cap (BestPathContainer.hpp:275-277, 363-367);
@@ -907,6 +909,13 @@ namespace korc
 		}
 
 		float unkScore(uint32_t len, bool emojiStart) const { return (emojiStart ? -10.f : 0.f) - (len * cfg.oovRuleScale + cfg.oovRuleBias); }
+		// UnkFormScorer::operator(): chrBasedScore (src/UnkFormScorer.cpp:53-66: one model step per UTF-16 unit, </s>, minus the bias) when the
+		// character model is in use, else ruleBasedScore (:27-51)
+		float unkScoreOf(const uint16_t* s, uint32_t len, bool emojiStart) const
+		{
+			if (cfg.chr) { float sc = kamd::chrScoreHost(*cfg.chr, s, len); sc -= cfg.oovChrBias; return sc; }
+			return unkScore(len, emojiStart);
+		}
 
 		bool disconnected(std::vector<uint8_t>& reach, uint32_t scanStart) const   // PathEvaluator.hpp:1159-1176
 		{
@@ -1056,7 +1065,7 @@ namespace korc
 						ownFormId = (uint16_t)ownForms.size();
 						const uint16_t* fs = M.formChars + f.charOff;
 						const bool emo = f.len && fs[0] >= 0x80 && isEmoji(fs[0], f.len > 1 ? fs[1] : 0);
-						evaluate(i, ownFormId, unkLCands, 1, unkScore(f.len, emo));
+						evaluate(i, ownFormId, unkLCands, 1, unkScoreOf(fs, f.len, emo));
 					}
 					bool any = false;
 					for (auto& p : cache[i]) if (!p.combineSocket) { any = true; break; }
@@ -1065,10 +1074,10 @@ namespace korc
 					{
 						ownForms.push_back({ 0, OwnForm{ node->startPos, node->endPos - node->startPos } });
 						ownFormId = (uint16_t)ownForms.size();
-						evaluate(i, ownFormId, unkCands, 2, unkScore(node->endPos - node->startPos, emojiAt(node->startPos)));
+						evaluate(i, ownFormId, unkCands, 2, unkScoreOf((const uint16_t*)norm->data() + node->startPos, node->endPos - node->startPos, emojiAt(node->startPos)));
 					}
 				}
-				else evaluate(i, ownFormId, unkCands, 2, unkScore(node->uformLen, emojiAt(node->uformOff)));
+				else evaluate(i, ownFormId, unkCands, 2, unkScoreOf((const uint16_t*)norm->data() + node->uformOff, node->uformLen, emojiAt(node->uformOff)));
 				cnt.statesWritten += cache[i].size();
 				if (getenv("KORC_DEBUG")) { fprintf(stderr, "node %u:", i); for (auto& p : cache[i]) fprintf(stderr, " [m%u w%u lm%d s%.9g par(%d,%d) r%u]", p.morph, p.wid, p.lmNode, p.accScore, p.parentNode, p.parentIdx, p.rootId); fprintf(stderr, "\n"); }
 			}

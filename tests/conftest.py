@@ -77,6 +77,18 @@ def mid_cong_vl4_model():
 
 
 @pytest.fixture(scope="session")
+def small_cong_chr_model():
+    """SMALL_CONG_SPEC plus the character model of Match::oovChrModel (nounchr.mdl layout; kiwi_amd/synth.py SMALL_CONG_CHR_SPEC)."""
+    from kiwi_amd.synth import SynthModel, SMALL_CONG_CHR_SPEC
+    d = os.path.join(ROOT, "_data")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "small-cong-chr.raw")
+    sm = SynthModel(SMALL_CONG_CHR_SPEC)
+    sm.raw.save(path)
+    return sm, path
+
+
+@pytest.fixture(scope="session")
 def oracle(small_model):
     import subprocess
     import oraclelib

@@ -1,0 +1,72 @@
+"""CPU: unknown-form scoring with the character model (Match::oovChrModel) -- oracle side.  The REAL
+src/UnkFormScorer.cpp + src/CoNgramModel.cpp (SSE4.1 build, the pin of the CoNgram oracle: oracle/_ref/libkiwi_ref_x86.so) load a synthetic
+nounchr.mdl in the reference's own layout (kiwi_amd/synth.py build_nounchr: 8-bit keys with two-byte spellings, trie frequencies, output
+bias, reordered vocabulary) and pin this repo's restatement (kiwi_amd/csrc/flat_model.hpp chrProgress / chrToken, model.cpp loadChr /
+chrScoreHost, oracle/viterbi_oracle.hpp unkScoreOf): the score of single strings and whole analyses, bit for bit."""
+import ctypes as C
+import os
+import random
+from dataclasses import astuple
+
+import numpy as np
+import pytest
+
+from corpora import EDGE_TEXTS, dictionary_mix, fuzzed, synthetic
+
+OOV_CHR_MODEL = 1 << 8      # Match::oovChrModel (include/kiwi/PatternMatcher.h:21)
+
+
+def _norm(res):
+    return [([astuple(t) for t in a[0]], a[1]) for a in res]
+
+
+@pytest.fixture(scope="module")
+def chr_pair(small_cong_chr_model):
+    import oraclelib
+    import refbridge
+    if not refbridge.x86_available():
+        pytest.skip("oracle/_ref/libkiwi_ref_x86.so not built (make -C oracle refx86; needs /root/reference)")
+    sm, path = small_cong_chr_model
+    ref, orc = refbridge.RefKiwi(path, arch=3, x86=True), oraclelib.OracleKiwi(path)
+    for L, name in ((ref.lib, "kref"), (orc.lib, "korc")):
+        f = getattr(L, name + "_unk_chr_score"); f.restype = C.c_float; f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        g = getattr(L, name + "_set_oov_chr_bias"); g.argtypes = [C.c_void_p, C.c_float]
+    return sm, ref, orc
+
+
+def _score(L, name, h, s):
+    u = np.frombuffer(s.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+    return getattr(L, name + "_unk_chr_score")(h, u.ctypes.data, len(u))
+
+
+def test_chr_scores_of_strings_equal_reference(chr_pair):
+    sm, ref, orc = chr_pair
+    rnd = random.Random(9)
+    alphabet = "가각나난다닫라마바사아자차카타파하해했어요은는이를ᆫᆯᆷᆸᆼabcXYZ019.,!?()[]'\"~-… 　\t😀𠀀ㄱㅏ한漢あ"
+    strings = [f for f in sm.raw.forms[100:700] if f] + ["".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 14))) for _ in range(1500)] + ["", "\ud83d", "a\udc00b"]
+    seen = set()
+    for s in strings:
+        # the scorer sees NORMALISED text: codas split off (the generator's forms are composed Hangul)
+        n = "".join(chr(ord(c) - (ord(c) - 0xAC00) % 28) + (chr(0x11A7 + (ord(c) - 0xAC00) % 28) if (ord(c) - 0xAC00) % 28 else "") if 0xAC00 <= ord(c) < 0xD7A4 else c for c in s)
+        a, b = _score(ref.lib, "kref", ref.h, n), _score(orc.lib, "korc", orc.h, n)
+        assert a == b, (n, a, b)
+        seen.add(a)
+    assert len(seen) > 1000
+
+
+@pytest.mark.parametrize("bias", [0.0, 2.5])
+def test_analyses_with_the_character_model_equal_reference(chr_pair, bias):
+    sm, ref, orc = chr_pair
+    import refbridge
+    match = refbridge.MATCH_ALL_WITH_NORMALIZING | OOV_CHR_MODEL
+    ref.lib.kref_set_oov_chr_bias(ref.h, bias); orc.lib.korc_set_oov_chr_bias(orc.h, bias)
+    try:
+        texts = synthetic(sm, 500, 851, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 300, 852) + EDGE_TEXTS + fuzzed(sm, 300, 853)
+        differ = 0
+        for t in texts:
+            a = ref.analyze(t, match=match)
+            assert _norm(a) == _norm(orc.analyze(t, match=match)), repr(t)
+            differ += _norm(a) != _norm(ref.analyze(t))
+        assert differ > 50      # (the option changes analyses: the comparison is not vacuous)
+    finally:
+        ref.lib.kref_set_oov_chr_bias(ref.h, 0.0); orc.lib.korc_set_oov_chr_bias(orc.h, 0.0)
