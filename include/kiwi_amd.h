@@ -40,6 +40,9 @@ const char* kamd_last_error(void);
 /* KiwiConfig fields used on this path (include/kiwi/Kiwi.h:150-167) */
 int kamd_set_config(kamd_engine_h h, float cut_off_threshold, float space_penalty, float typo_cost_weight,
 	uint32_t max_unk_form_size, uint32_t max_unk_form_size_followed_by_jclass, uint32_t space_tolerance, int integrate_allomorph);
+/* KiwiConfig::oovChrBias: subtracted from the character model's score of an unknown form when match_options carry Match::oovChrModel (1 << 8);
+ * that option needs a model with the character model (nounchr.mdl next to cong.mdl / the raw container's `nounchr` section) */
+int kamd_set_oov_chr_bias(kamd_engine_h h, float bias);
 
 /* texts: concatenated UTF-16; offsets[n+1].  top_n in 1..4 (null + error otherwise); analyses beyond the best differ from a given reference run only in exact ties (top-N). */
 kamd_results_h kamd_analyze_batch(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n,

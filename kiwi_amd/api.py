@@ -227,6 +227,10 @@ class KiwiAmd:
     def set_config(self, cut_off=8.0, space_penalty=7.0, typo_cost_weight=6.0, max_unk=6, max_unk_j=0xFFFFFFFF, space_tol=0, integrate_allomorph=True):
         self.lib.kamd_set_config(self.h, cut_off, space_penalty, typo_cost_weight, max_unk, max_unk_j, space_tol, int(integrate_allomorph))
 
+    def set_oov_chr_bias(self, bias: float):
+        self.lib.kamd_set_oov_chr_bias.argtypes = [C.c_void_p, C.c_float]
+        self.lib.kamd_set_oov_chr_bias(self.h, bias)
+
     def analyze_batch(self, texts, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Results:
         flat, offs = pack_texts(texts)
         r = self.lib.kamd_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), top_n, match, int(open_ending), host_threads)

@@ -125,7 +125,8 @@ namespace
 		// allowed one (src/PathEvaluator.hpp:231, 386, 893).  Every model this library loads holds standard-dialect morphemes only (kiwi_init refuses
 		// enabled_dialects != 0, the bake refuses dialect morphemes), so both options are accepted and -- exactly as in the reference -- change nothing.
 		if (pt) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
-		if ((uint32_t)o.match_options & (3u << 8)) throw std::invalid_argument{ "`oovChrModel` option is set but the character-level noun model is not loaded." };
+		// Match::oovChrModel (bits 8-9): the engine checks that the model carries the character model (nounchr.mdl next to a CoNgram model) and refuses
+		// with the reference's own message otherwise; the two frequency-based modes are not built
 		if ((uint32_t)o.match_options & (1u << 30)) throw std::invalid_argument{ "kiwi_amd: useOldSplitter is not supported" };
 	}
 
@@ -362,7 +363,7 @@ extern "C"
 	{
 		if (!h) return;
 		auto& g = h->engine->config;
-		g.integrateAllomorph = !!c.integrate_allomorph; g.cutOffThreshold = c.cut_off_threshold; g.oovRuleScale = c.oov_rule_scale; g.oovRuleBias = c.oov_rule_bias;
+		g.integrateAllomorph = !!c.integrate_allomorph; g.cutOffThreshold = c.cut_off_threshold; g.oovRuleScale = c.oov_rule_scale; g.oovRuleBias = c.oov_rule_bias; g.oovChrBias = c.oov_chr_bias;
 		g.spacePenalty = c.space_penalty; g.typoCostWeight = c.typo_cost_weight; g.maxUnkFormSize = c.max_unk_form_size;
 		g.maxUnkFormSizeFollowedByJClass = c.max_unk_form_size_followed_by_j_class; g.spaceTolerance = c.space_tolerance;
 		for (auto& r : h->replicas) r->config = g;
@@ -373,8 +374,8 @@ extern "C"
 		kiwi_config_t c{};
 		if (!h) return c;
 		const auto& g = h->engine->config;
-		c.integrate_allomorph = g.integrateAllomorph; c.cut_off_threshold = g.cutOffThreshold; c.oov_rule_scale = g.oovRuleScale; c.oov_rule_bias = g.oovRuleBias;
-		c.oov_chr_bias = 0; c.oov_global_weight = 35; c.oov_local_weight = 3; c.oov_global_min_freq = 4;
+		c.integrate_allomorph = g.integrateAllomorph; c.cut_off_threshold = g.cutOffThreshold; c.oov_rule_scale = g.oovRuleScale; c.oov_rule_bias = g.oovRuleBias; c.oov_chr_bias = g.oovChrBias;
+		c.oov_global_weight = 35; c.oov_local_weight = 3; c.oov_global_min_freq = 4;
 		c.space_penalty = g.spacePenalty; c.typo_cost_weight = g.typoCostWeight; c.max_unk_form_size = g.maxUnkFormSize;
 		c.max_unk_form_size_followed_by_j_class = g.maxUnkFormSizeFollowedByJClass; c.space_tolerance = g.spaceTolerance;
 		return c;

@@ -71,6 +71,13 @@ extern "C"
 		return 0;
 	}
 
+	int kamd_set_oov_chr_bias(kamd_engine_h h, float bias)
+	{
+		if (!h) return -2;
+		h->e->config.oovChrBias = bias;
+		return 0;
+	}
+
 	kamd_results_h kamd_analyze_batch(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int openEnding, int hostThreads)
 	{
 		if (!h) { lastError = "invalid handle"; return nullptr; }

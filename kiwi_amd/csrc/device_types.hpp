@@ -93,6 +93,7 @@ namespace kamd
 		uint32_t splitComplex, splitSaisiot, mergeSaisiot;
 		uint32_t smallMax, mediumMax, bucketCap;   // container selection by incoming paths (128, 512) and per-bucket key cap (128): BestPathContainer.hpp:275-277
 		uint32_t topN;                 // paths kept per (candidate, key): 1..kMaxTopN (BestPathContainer.hpp:151-222 for N > 1)
+		float oovChrBias;              // KiwiConfig::oovChrBias: subtracted from the character model's score of an unknown form (Match::oovChrModel)
 	};
 	constexpr uint32_t kMaxTopN = 16;
 
@@ -145,6 +146,9 @@ namespace kamd
 		DevPathHeader* outPaths;       // compact output of the end stage: path headers of all chunks ...
 		DevToken* outTokens;           // ... and their token records (D2H copies exactly what was produced)
 		uint32_t* outCounters;         // [0] path headers handed out, [1] token records handed out, [2] chunks that ended in a scratch overflow
+		// Match::oovChrModel (null: unknown forms are scored by the length rule): per node, same offsets as nodes, the character model's score of
+		// the node's unknown form -- its own string of a formless node, else its text span (k_unk_chr; UnkFormScorer::chrBasedScore before the bias)
+		float* unkChr;
 		const uint32_t* blockBits;     // AnalyzeOption::blocklist as one bit per morpheme id (null: none): k_expand_cands drops those candidates
 		uint32_t outPathCap, outTokCap;
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs

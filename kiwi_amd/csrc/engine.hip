@@ -28,6 +28,7 @@ namespace kamd
 	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
+	__global__ void k_unk_chr(ModelView M, BatchView B, WorkView W, ChrView C, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
 
 	namespace
 	{
@@ -178,7 +179,7 @@ namespace kamd
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
 		TypoOption typo;
 		TypoGraphDev typoDev;
-		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder, dBlockBits;
+		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder, dBlockBits, dUnkChr;
 		TypoLatView tv{};
 		DevBuf dPacks, dStates, dNodeStOff, dNodeStCnt, dReach, dTokens, dResults, dOrder;
 		DevBuf dOutPaths, dOutTokens, dOutCounters; uint32_t outPathCap = 0, outTokCap = 0;   // compact outputs of the end stage
@@ -211,6 +212,7 @@ namespace kamd
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter;
+		ChrView chr{};      // character model of Match::oovChrModel on the device (absent: dim 0)
 		CongDev cong{}; bool hasCong = false;   // CoNgram model: the context trie is uploaded where the Knlm tables would be (ModelView::lmHash / lmRoot2 / lmBackoff)
 		SbgDev sbg{}; bool hasSbg = false; DevBuf sbgScratch;   // SkipBigram tables on the device + per-lane-group item scratch of its search kernel
 		// the engine owns ONE pair of streams, one work counter and one scratch arena: device work of concurrent callers (the C API
@@ -295,6 +297,15 @@ namespace kamd
 		}
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
 		v.lmHtxNode = (m.congDim || m.lmHtxNode.empty()) ? nullptr : impl->up(m.lmHtxNode);      // history-transformed Knlm only
+		v.formUnkChr = nullptr;
+		if (m.chrDim)
+		{
+			ChrView c = m.chrView();
+			c.ctxEmb = impl->up(m.chrCtxEmb); c.outEmb = impl->up(m.chrOutEmb); c.nodes = impl->up(m.chrNodes); c.keys = impl->up(m.chrKeys); c.values = impl->up(m.chrValues);
+			c.root = impl->up(m.chrRoot); c.inv = m.chrInv.empty() ? nullptr : impl->up(m.chrInv);
+			impl->chr = c;
+			v.formUnkChr = impl->up(m.formUnkChr);
+		}
 		if (!m.sbgPtrs.empty())
 		{
 			const SbgView sv = m.sbgView();
@@ -454,6 +465,8 @@ namespace kamd
 		w.outTokens = b.dOutTokens.as<DevToken>(); w.outPaths = b.dOutPaths.as<DevPathHeader>(); w.outCounters = b.dOutCounters.as<uint32_t>();
 		w.outTokCap = b.outTokCap; w.outPathCap = b.outPathCap;
 		w.blockBits = nullptr;
+		w.unkChr = nullptr;
+		if ((b.match >> 8) & 3) { b.dUnkChr.ensure(totNodes * 4 + 16); w.unkChr = b.dUnkChr.as<float>(); }      // Match::oovChrModel (checked in stage())
 		if (b.typo.blocked && !b.typo.blocked->empty())
 		{
 			if (b.typo.blocked->size() != (I.model.morphs.size() + 31) / 32) throw std::invalid_argument{ "kiwi_amd: blocklist bit set does not belong to this model" };
@@ -572,7 +585,7 @@ namespace kamd
 	{
 		SearchParams p{};
 		p.match = match; p.cutOff = c.cutOffThreshold; p.spacePenalty = c.spacePenalty; p.typoCostWeight = c.typoCostWeight;
-		p.oovRuleScale = c.oovRuleScale; p.oovRuleBias = c.oovRuleBias;
+		p.oovRuleScale = c.oovRuleScale; p.oovRuleBias = c.oovRuleBias; p.oovChrBias = c.oovChrBias;
 		p.maxUnk = c.maxUnkFormSize; p.maxUnkJ = c.maxUnkFormSizeFollowedByJClass; p.spaceTol = c.spaceTolerance;
 		p.splitComplex = (match & M_SPLIT_COMPLEX) ? 1 : 0; p.splitSaisiot = (match & M_SPLIT_SAISIOT) ? 1 : 0; p.mergeSaisiot = (match & M_MERGE_SAISIOT) ? 1 : 0;
 		p.topN = topN;
@@ -708,6 +721,8 @@ namespace kamd
 			}
 			}
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u);
+			if (b.wv.unkChr)      // Match::oovChrModel: every node's unknown form scored by the character model, once, before the search
+				hipLaunchKernelGGL(k_unk_chr, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, I.chr, c0, cn, chrToken(0xD800, identifySpecialChr(0xD800)), chrToken(0xDC00, identifySpecialChr(0xDC00)));
 			HIPCHECK(hipEventRecord(e[2], sA));
 			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));
 			HIPCHECK(hipEventRecord(e[3], sB));
@@ -938,6 +953,13 @@ namespace kamd
 		{
 			if (impl->hasSbg) throw std::runtime_error{ "kiwi_amd: typo correction with a SkipBigram model is not built" };
 			if (impl->model.forms.size() >= (1u << 24)) throw std::runtime_error{ "kiwi_amd: typo correction supports up to 2^24 forms" };
+		}
+		if ((match >> 8) & 3)
+		{
+			// Match::oovMask (include/kiwi/PatternMatcher.h:20-24): 1 = unknown forms scored by the character model; 2 / 3 add substring frequencies
+			if (!impl->chr.present()) throw std::invalid_argument{ "`oovChrModel` option is set but the character-level noun model is not loaded." };      // Kiwi.cpp:1032-1035
+			if (((match >> 8) & 3) > 1) throw std::runtime_error{ "kiwi_amd: oovChrFreqModel / oovChrFreqBranchModel are not built (oovChrModel is)" };
+			if (typo.typo) throw std::runtime_error{ "kiwi_amd: the character model together with a typo transformer is not built" };
 		}
 		HostTimer tm{ "stage" };
 		auto b = std::make_shared<StagedBatch>();

@@ -17,7 +17,7 @@ namespace kamd
 	struct EngineConfig   // KiwiConfig (include/kiwi/Kiwi.h:150-167)
 	{
 		bool integrateAllomorph = true;
-		float cutOffThreshold = 8, oovRuleScale = 4, oovRuleBias = 4, spacePenalty = 7, typoCostWeight = 6;
+		float cutOffThreshold = 8, oovRuleScale = 4, oovRuleBias = 4, oovChrBias = 0, spacePenalty = 7, typoCostWeight = 6;
 		uint32_t maxUnkFormSize = 6, maxUnkFormSizeFollowedByJClass = 0xFFFFFFFFu, spaceTolerance = 0;
 	};
 

@@ -145,6 +145,8 @@ namespace kamd
 		// history-transformed Knlm (KnLangModelHeader::htx_offset; the reference's builder writes one by default): per word the root's child for its
 		// TRANSFORMED id (a node index, 0 = none) -- where a walk lands when no context continues with the word (Knlm.cpp:61-70, 116-126); null = plain model
 		const int32_t* lmHtxNode;
+		// character model present: per form the score of its own string (what a dictionary node's unknown proper-noun reading costs under Match::oovChrModel)
+		const float* formUnkChr;
 	};
 
 	// SkipBigram tables (reference src/SkipBigramModel.hpp:40-105), kept apart from ModelView: only the CPU restatement uses
@@ -380,6 +382,7 @@ namespace kamd
 			v.lmNodes = lmNodes.data(); v.lmKeys = lmKeys.data(); v.lmValues = lmValues.data(); v.lmRoot = lmRoot.data();
 			v.lmHash = lmHash.data(); v.lmHashMask = lmHashMask; v.lmRoot2 = lmRoot2.data(); v.lmBackoff = lmBackoff.data();
 			v.lmHtxNode = lmHtxNode.empty() ? nullptr : lmHtxNode.data();
+			v.formUnkChr = formUnkChr.empty() ? nullptr : formUnkChr.data();
 			return v;
 		}
 

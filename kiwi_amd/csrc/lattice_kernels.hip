@@ -832,4 +832,34 @@ namespace kamd
 			if (kept != nd.candCnt) W.nodes[nBase + i].candCnt = (uint16_t)kept;
 		}
 	}
+
+	// Match::oovChrModel (UnkFormScorer::chrBasedScore, src/UnkFormScorer.cpp:53-66): the character model's score of every
+	// lattice node's unknown form, once per node and off the search kernel's dependent chain -- a formless node's own string, else the node's
+	// text span (what the search uses when the node left the lattice disconnected).  One block per chunk, one node per thread: the local
+	// quantised CoNgram step (flat_model.hpp chrProgress: byte-keyed context trie + int8 dot product) per UTF-16 unit, then </s>; fp32 sum in
+	// that order.  hiTok / loTok: the tokens of a lone high / low surrogate unit (ChrTokenizer::encodeOne sees units, not code points).
+	__global__ void __launch_bounds__(64) k_unk_chr(ModelView M, BatchView B, WorkView W, ChrView C, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok)
+	{
+		if (blockIdx.x >= chunkCount) return;
+		const uint32_t chunk = chunkBegin + blockIdx.x;
+		if (W.results[chunk].status != CS_OK) return;
+		const uint32_t nBase = W.nodeBase[chunk], G = W.nNodes[chunk];
+		const uint32_t cOff = B.charOff[chunk];
+		const uint16_t* str = B.chars + cOff; const uint8_t* cls = B.cls + cOff;
+		for (uint32_t i = 1 + threadIdx.x; i + 1 < G; i += blockDim.x)
+		{
+			const DevNode nd = W.nodes[nBase + i];
+			const uint32_t off = nd.form == NOFORM ? nd.uformOff : nd.startPos, len = nd.form == NOFORM ? nd.uformLen : (uint32_t)(nd.endPos - nd.startPos);
+			int32_t node = C.bosNode; uint32_t ctx = C.bosCtx;
+			float score = 0;
+			for (uint32_t k = 0; k < len; ++k)
+			{
+				const uint16_t c = str[off + k];
+				const uint32_t tok = isHighSurrogate(c) ? hiTok : isLowSurrogate(c) ? loTok : chrToken(c, cls[off + k] & 0x7F);
+				score += chrProgress(C, node, ctx, tok);
+			}
+			score += chrProgress(C, node, ctx, 0);
+			W.unkChr[nBase + i] = score;
+		}
+	}
 }

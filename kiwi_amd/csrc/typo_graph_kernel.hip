@@ -4,7 +4,7 @@
 // unchanged segments between the break points plus one node per admissible replacement (two for the halves of a continual typo), then the
 // nodes in end-position order.  The host module (typo.cpp: PreparedTypo::graph, byte-identical to the reference's graphs) is the same
 // algorithm over std containers; this is its restatement over fixed per-chunk regions, checked against it node for node
-// (tests/test_hipemu.py, tests/test_gpu_typo.py through kamd_typo_graph_device).
+// (the CPU and GPU suites, through kamd_typo_graph_device).
 //
 // Shape: the build is sequential per chunk (every append asks what already ends at its start position; node ids are handed out in order), so
 // it runs on ONE lane per chunk with few active lanes per wave (`stride`, as k_finish_paths / k_build_lattice_typo): chunks spread over all

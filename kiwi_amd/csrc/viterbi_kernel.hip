@@ -1844,6 +1844,13 @@ namespace sbgk
 					{
 						const float emo = (X.cls[node.uformOff] & 0x80) ? -10.f : 0.f;
 						cl = unkPacks; clLds = Lay<G>::PCAP; clN = 2; ok = ownKind; of = ownFeat;
+						// UnkFormScorer::operator() (src/UnkFormScorer.h:40-58): the character model's score of the form (k_unk_chr) under Match::oovChrModel, else the length rule
+						// (CoNgram compilations only: the reference loads the character model quantised next to a CoNgram model, and so does the loader here --
+						// the Knlm / SkipBigram / typo kernels keep their code)
+#ifdef KAMD_CONG
+						if (W.unkChr) disc = baseDiscount + (W.unkChr[(uint32_t)(X.nodes - W.nodes) + i] - P.oovChrBias);
+						else
+#endif
 						disc = baseDiscount + (emo - ((float)node.uformLen * P.oovRuleScale + P.oovRuleBias));
 					}
 				}
@@ -1856,6 +1863,10 @@ namespace sbgk
 					of = featMask(fs, f.len) & 0x1FFF;
 					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
 					cl = unkPacks + 1; clLds = Lay<G>::PCAP + 1; clN = 1; ok = 2;
+#ifdef KAMD_CONG
+					if (W.unkChr) disc = baseDiscount + (M.formUnkChr[node.form] - P.oovChrBias);
+					else
+#endif
 					disc = baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias);
 				}
 				else
@@ -1899,6 +1910,10 @@ namespace sbgk
 					}
 					const float emo = (X.cls[node.startPos] & 0x80) ? -10.f : 0.f;
 					cl = unkPacks; clLds = Lay<G>::PCAP; clN = 2; ok = 3;
+#ifdef KAMD_CONG
+					if (W.unkChr) disc = baseDiscount + (W.unkChr[(uint32_t)(X.nodes - W.nodes) + i] - P.oovChrBias);
+					else
+#endif
 					disc = baseDiscount + (emo - ((float)len * P.oovRuleScale + P.oovRuleBias));
 				}
 				evaluateNode<G>(X, E, cl, clLds, clN, ok, of, disc);

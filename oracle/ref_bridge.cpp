@@ -375,6 +375,7 @@ extern "C"
 			if (raw.knlm) { std::ofstream os{ d + "/sj.knlm", std::ios::binary }; os.write((const char*)raw.knlm, (std::streamsize)raw.knlmSize); if (!os) return -2; }
 			if (raw.sbg) { std::ofstream os{ d + "/skipbigram.mdl", std::ios::binary }; os.write((const char*)raw.sbg, (std::streamsize)raw.sbgSize); if (!os) return -2; }
 			if (raw.cong) { std::ofstream os{ d + "/cong.mdl", std::ios::binary }; os.write((const char*)raw.cong, (std::streamsize)raw.congSize); if (!os) return -2; }
+			if (raw.nounchr) { std::ofstream os{ d + "/nounchr.mdl", std::ios::binary }; os.write((const char*)raw.nounchr, (std::streamsize)raw.nounchrSize); if (!os) return -2; }
 			return 0;
 		}
 		catch (const std::exception& e) { fprintf(stderr, "kref_write_model_dir: %s\n", e.what()); return -1; }
@@ -395,6 +396,13 @@ extern "C"
 			{
 				const auto cong = slurp(d + "/cong.mdl");
 				h->kw = Acc::build(forms, morphemes, cong.data(), cong.size(), nullptr, 0, toArch(arch), true);
+#ifdef KREF_X86
+				{
+					// the optional character model (KiwiBuilder.cpp:1094-1100)
+					std::ifstream is{ d + "/nounchr.mdl", std::ios::binary };
+					if (is) { const std::vector<uint8_t> chr{ std::istreambuf_iterator<char>{ is }, std::istreambuf_iterator<char>{} }; Acc::attachChr(h->kw, chr.data(), chr.size(), toArch(arch)); }
+				}
+#endif
 				return h.release();
 			}
 			const auto knlm = slurp(d + "/sj.knlm");

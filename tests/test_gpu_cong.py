@@ -116,3 +116,37 @@ def test_cong_file_as_the_reference_builder_writes_it(mid_cong_vl4_model):
         if ref is not None:
             assert _norm(ref.analyze(s)) == _norm(y), s
     dev.close()
+
+
+@pytest.mark.parametrize("lanes,top_n,bias", [("16", 1, 0.0), ("64", 2, 2.5)])
+def test_unknown_forms_scored_by_the_character_model(small_cong_chr_model, monkeypatch, lanes, top_n, bias):
+    """Match::oovChrModel (SURVEY.md section 8 row f4): k_unk_chr + the search kernel reading its scores, against the oracle and -- where it
+    travelled -- the real reference (UnkFormScorer + CoNgramModel, SSE4.1 build) on the same nounchr.mdl."""
+    import ctypes as C
+    import oraclelib
+    import refbridge
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_cong_chr_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
+    orc = oraclelib.OracleKiwi(path)
+    orc.lib.korc_set_oov_chr_bias.argtypes = [C.c_void_p, C.c_float]
+    orc.lib.korc_set_oov_chr_bias(orc.h, bias)
+    ref = None
+    if refbridge.x86_available() and top_n == 1:
+        ref = refbridge.RefKiwi(path, arch=3, x86=True)
+        ref.lib.kref_set_oov_chr_bias.argtypes = [C.c_void_p, C.c_float]
+        ref.lib.kref_set_oov_chr_bias(ref.h, bias)
+    dev = KiwiAmd(path)
+    dev.set_oov_chr_bias(bias)
+    texts = synthetic(sm, 1200, 931, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 500, 932) + EDGE_TEXTS + fuzzed(sm, 400, 933)
+    got = dev.analyze_batch(texts, top_n=top_n, match=match).to_python()
+    plain = dev.analyze_batch(texts, top_n=top_n).to_python()
+    differ = 0
+    for s, y, p in zip(texts, got, plain):
+        assert _norm(orc.analyze(s, top_n=top_n, match=match)) == _norm(y), (lanes, top_n, s)
+        if ref is not None:
+            assert _norm(ref.analyze(s, match=match)) == _norm(y), s
+        differ += _norm(y) != _norm(p)
+    assert differ > 100
+    dev.close()

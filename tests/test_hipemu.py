@@ -553,3 +553,38 @@ def test_emulated_cong_kernel_on_a_file_as_the_reference_builder_writes_it(emu_l
     for s, y in zip(texts, got):
         assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), (lanes, top_n, s)
     dev.close()
+
+
+@pytest.mark.parametrize("lanes,top_n,bias", [("16", 1, 0.0), ("64", 1, 2.5), ("16", 2, 2.5)])
+def test_emulated_unknown_forms_scored_by_the_character_model(emu_libs, small_cong_chr_model, monkeypatch, lanes, top_n, bias):
+    """Match::oovChrModel (row f4): k_unk_chr scores every node's unknown form with the character model (byte-keyed context trie, int8 dot
+    product, output bias), the search reads those scores / the per-form table instead of the length rule -- against the oracle, which
+    tests/test_chr_oracle.py pins to the real UnkFormScorer + CoNgramModel of the reference."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_cong_chr_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
+    orc = oraclelib.OracleKiwi(path)
+    orc.lib.korc_set_oov_chr_bias.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_float]
+    orc.lib.korc_set_oov_chr_bias(orc.h, bias)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    dev.set_oov_chr_bias(bias)
+    texts = synthetic(sm, 80, 917, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 40, 918) + EDGE_TEXTS
+    got = dev.analyze_batch(texts, top_n=top_n, match=match).to_python()
+    plain = dev.analyze_batch(texts, top_n=top_n).to_python()
+    differ = 0
+    for s, y, p in zip(texts, got, plain):
+        assert _norm(orc.analyze(s, top_n=top_n, match=match)) == _norm(y), (lanes, top_n, s)
+        differ += _norm(y) != _norm(p)
+    assert differ > 10
+    dev.close()
+
+
+def test_emulated_character_model_option_without_the_model_is_refused(emu_libs, small_cong_model):
+    from kiwi_amd.api import KiwiAmd
+    import oraclelib
+    dev = KiwiAmd(small_cong_model[1], lib_path=emu_libs[0])
+    with pytest.raises(Exception, match="character-level noun model is not loaded"):
+        dev.analyze_batch(["가나다"], match=oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8))
+    dev.close()

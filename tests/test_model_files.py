@@ -142,6 +142,32 @@ def test_cong_directory_loader_equals_container_and_reference(small_cong_model):
     a.close(); b.close()
 
 
+def test_directory_with_a_character_model(small_cong_chr_model):
+    """sj.morph + cong.mdl + nounchr.mdl (KiwiBuilder.cpp:1094-1100): the directory loader picks the character model up; analyses with
+    Match::oovChrModel equal the reference's SSE4.1 build loading the same three files."""
+    import shutil
+    import refbridge
+    if not refbridge.x86_available():
+        pytest.skip("oracle/_ref/libkiwi_ref_x86.so not built")
+    from kiwi_amd.api import KiwiAmd
+    emu = os.path.join(HERE, "hipemu", "_build", "libkiwi_hipemu.so")
+    if not os.path.exists(emu):
+        pytest.skip("emulated library not built")
+    sm, path = small_cong_chr_model
+    src = _model_dir(path, "small-cong-chr-src")
+    d = os.path.join(ROOT, "_data", "small-cong-chr.files")
+    os.makedirs(d, exist_ok=True)
+    for f in ("sj.morph", "cong.mdl", "nounchr.mdl"):
+        shutil.copyfile(os.path.join(src, f), os.path.join(d, f))
+    match = refbridge.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
+    dev = KiwiAmd(d, lib_path=emu)
+    ref = refbridge.RefKiwi(d, arch=3, model_dir_sbg=2, x86=True)
+    texts = synthetic(sm, 40, 725, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 20, 726)
+    for s, y in zip(texts, dev.analyze_batch(texts, match=match).to_python()):
+        assert _norm(ref.analyze(s, match=match)) == _norm(y), s
+    dev.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["knlm", "cong"])
 def test_kiwi_init_on_a_model_directory(small_model, small_cong_model, kind):
