@@ -480,7 +480,7 @@ def _graph_bytes(dev, typo, text, dialect, norm_coda, use_device):
     return buf.tobytes()
 
 
-def check_device_typo_graphs(lib, model_path, n_random=150):
+def check_device_typo_graphs(lib, model_path, n_random=80):
     """Shared with tests/test_gpu_typo.py: the typo graphs of k_typo_graph (count pass + write pass; the graphs the analyze path uses) equal the
     host module's -- which tests/test_typo_product.py pins to the real reference byte for byte -- node for node, links, costs, continual
     indices, dialects, and the type / script of every node's last character, for this repo's own rule set (both directions, with and without
@@ -529,7 +529,7 @@ def check_device_typo_graphs(lib, model_path, n_random=150):
         base = prod.graph_bytes(t, dialects[0], True)
         assert _graph_bytes(dev, prod, t, dialects[0], True, False)[:len(base)] == base
         prod.close()
-    assert n_nodes > 1000
+    assert n_nodes > 800
     dev.close()
 
 
@@ -555,7 +555,7 @@ def test_emulated_cong_kernel_on_a_file_as_the_reference_builder_writes_it(emu_l
     dev.close()
 
 
-@pytest.mark.parametrize("lanes,top_n,bias", [("16", 1, 0.0), ("64", 1, 2.5), ("16", 2, 2.5)])
+@pytest.mark.parametrize("lanes,top_n,bias", [("16", 1, 0.0), ("64", 2, 2.5)])
 def test_emulated_unknown_forms_scored_by_the_character_model(emu_libs, small_cong_chr_model, monkeypatch, lanes, top_n, bias):
     """Match::oovChrModel (row f4): k_unk_chr scores every node's unknown form with the character model (byte-keyed context trie, int8 dot
     product, output bias), the search reads those scores / the per-form table instead of the length rule -- against the oracle, which
@@ -570,7 +570,7 @@ def test_emulated_unknown_forms_scored_by_the_character_model(emu_libs, small_co
     orc.lib.korc_set_oov_chr_bias(orc.h, bias)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     dev.set_oov_chr_bias(bias)
-    texts = synthetic(sm, 80, 917, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 40, 918) + EDGE_TEXTS
+    texts = synthetic(sm, 50, 917, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 25, 918) + EDGE_TEXTS[:40]
     got = dev.analyze_batch(texts, top_n=top_n, match=match).to_python()
     plain = dev.analyze_batch(texts, top_n=top_n).to_python()
     differ = 0
