@@ -959,7 +959,6 @@ namespace kamd
 			// Match::oovMask (include/kiwi/PatternMatcher.h:20-24): 1 = unknown forms scored by the character model; 2 / 3 add substring frequencies
 			if (!impl->chr.present()) throw std::invalid_argument{ "`oovChrModel` option is set but the character-level noun model is not loaded." };      // Kiwi.cpp:1032-1035
 			if (((match >> 8) & 3) > 1) throw std::runtime_error{ "kiwi_amd: oovChrFreqModel / oovChrFreqBranchModel are not built (oovChrModel is)" };
-			if (typo.typo) throw std::runtime_error{ "kiwi_amd: the character model together with a typo transformer is not built" };
 		}
 		HostTimer tm{ "stage" };
 		auto b = std::make_shared<StagedBatch>();

@@ -70,3 +70,26 @@ def test_analyses_with_the_character_model_equal_reference(chr_pair, bias):
         assert differ > 50      # (the option changes analyses: the comparison is not vacuous)
     finally:
         ref.lib.kref_set_oov_chr_bias(ref.h, 0.0); orc.lib.korc_set_oov_chr_bias(orc.h, 0.0)
+
+
+def test_typo_correction_with_the_character_model_equals_reference(chr_pair):
+    """Match::oovChrModel together with a typo transformer (CoNgram model): the reference's SSE4.1 build vs the oracle."""
+    import oraclelib
+    import refbridge
+    from typo_cases import misspell
+    sm, ref, orc = chr_pair
+    match = refbridge.MATCH_ALL_WITH_NORMALIZING | OOV_CHR_MODEL
+    name = "basic_with_continual"
+    ents, cont, leng = refbridge.default_typo_entries(name)
+    rt = refbridge.RefTypo(); rt.update_default(name); rt.prepare(True)
+    ot = oraclelib.OracleTypo(); ot.update_entries(ents, cont, leng); ot.prepare(True)
+    rnd = random.Random(17)
+    tt = [misspell(t, rnd, True, True, False) for t in synthetic(sm, 70, 741, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 40, 742)] + EDGE_TEXTS[:30]
+    corrected = 0
+    for t in tt:
+        if not t.strip():
+            continue
+        a = ref.analyze_typo(rt, t, 2.5, 0, match=match)
+        assert _norm(a) == _norm(orc.analyze_typo(ot, t, 2.5, 0, match=match)), t
+        corrected += any(x.typo_cost > 0 for x in a[0][0])
+    assert corrected >= 10

@@ -293,7 +293,7 @@ def test_emulated_typo_lattice_kernel_matches_oracle(emu_libs, small_model, rule
     dev.close(); prod.close()
 
 
-def _analyze_typo(dev, typo, texts, threshold, top_n=1, dialect=0):
+def _analyze_typo(dev, typo, texts, threshold, top_n=1, dialect=0, match=None):
     import ctypes as C
     import numpy as np
     import oraclelib
@@ -305,7 +305,7 @@ def _analyze_typo(dev, typo, texts, threshold, top_n=1, dialect=0):
     offs = np.zeros(len(enc) + 1, np.uint64)
     offs[1:] = np.cumsum([len(e) for e in enc])
     flat = np.concatenate(enc) if enc else np.zeros(0, np.uint16)
-    r = L.kamd_analyze_batch_typo(dev.h, typo.h, threshold, dialect, flat.ctypes.data, offs.ctypes.data, len(texts), top_n, oraclelib.MATCH_ALL_WITH_NORMALIZING, 0, 0)
+    r = L.kamd_analyze_batch_typo(dev.h, typo.h, threshold, dialect, flat.ctypes.data, offs.ctypes.data, len(texts), top_n, oraclelib.MATCH_ALL_WITH_NORMALIZING if match is None else match, 0, 0)
     if not r:
         raise RuntimeError(L.kamd_last_error().decode())
     return Results(L, r).to_python()
@@ -588,3 +588,22 @@ def test_emulated_character_model_option_without_the_model_is_refused(emu_libs, 
     with pytest.raises(Exception, match="character-level noun model is not loaded"):
         dev.analyze_batch(["가나다"], match=oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8))
     dev.close()
+
+
+def test_emulated_typo_correction_with_the_character_model(emu_libs, small_cong_chr_model):
+    """Match::oovChrModel together with a typo transformer: k_unk_chr over the nodes of the typo lattices, the typo + CoNgram search kernel reading its scores."""
+    import random
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import misspell
+    sm, path = small_cong_chr_model
+    match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
+    prod, orc_t = _typo_pair(emu_libs[0], 1.0)
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    rnd = random.Random(19)
+    texts = [misspell(t, rnd, True, True) for t in synthetic(sm, 40, 919, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 20, 920)] + EDGE_TEXTS[:20]
+    got = _analyze_typo(dev, prod, texts, 2.5, match=match)
+    for t, y in zip(texts, got):
+        assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0, match=match)) == _norm(y), t
+    dev.close(); prod.close()
