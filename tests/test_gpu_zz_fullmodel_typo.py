@@ -1,0 +1,35 @@
+"""GPU (-m gpu): BASELINE config 5 on the benchmarked model itself -- the 'full' synthetic model, the c2 corpus misspelt, the typo transformer of
+`bench.py --workload c5` (kiwi_amd.workloads.TYPO_RULES, continual cost 1, threshold 2.5): typo graphs from k_typo_graph, lattices over them,
+the typo search kernel -- against the CPU oracle (pinned to the real reference's typo path by tests/test_typo_oracle.py), tokens, positions,
+fp32 scores and per-token typo costs.  (Sorted last on purpose: it is the one GPU test of the round that was written after the last GPU call.)"""
+import os
+
+import pytest
+
+from test_hipemu import _analyze_typo, _norm, _typo_pair
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip.so")
+
+
+def check_c5(lib, n):
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload, workload_typo
+    path, c5, _ = get_workload("c5")
+    cont, leng, threshold = workload_typo("c5")
+    prod, orc_t = _typo_pair(lib, cont, leng)
+    dev, orc = KiwiAmd(path, lib_path=lib), oraclelib.OracleKiwi(path)
+    texts = c5[:n]
+    got = _analyze_typo(dev, prod, texts, threshold)
+    bad = [t for t, y in zip(texts, got) if _norm(orc.analyze_typo(orc_t, t, threshold, 0)) != _norm(y)]
+    corrected = sum(any(tok.typo_cost > 0 for tok in y[0][0]) for y in got)
+    dev.close(); prod.close()
+    assert not bad, (len(bad), bad[:3])
+    assert corrected > n // 20
+    return corrected
+
+
+def test_c5_2k_sentences_bit_exact_vs_oracle():
+    check_c5(LIB, 2048)
