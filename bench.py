@@ -109,7 +109,7 @@ def measured_traffic(workload, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 100 for the headline workload c2 -- a 0.2 s timed region that a utilisation sampler can see --, 20 otherwise)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,6 +117,8 @@ def main():
                     help="weak (default): every rank analyses a batch of the workload's size; strong: ONE corpus split over the ranks by index (text i -> rank i %% N)")
     ap.add_argument("--limit", type=int, default=0, help="diagnostics: only the first N sentences of the workload (named in config.workload)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 100 if args.workload == "c2" else 20
 
     import torch
     from kiwi_amd import dist
