@@ -755,7 +755,14 @@ namespace kamd
 				SbgDev sd = I.sbg;
 				sd.hist = b.dHist.as<uint32_t>();
 				sd.itemScratch = I.sbgScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(SbgScratch) : 0);
-				if (gl == 64) hipLaunchKernelGGL((sbgk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
+				if (b.typo.typo)
+				{
+					// ... over lattices with typo costs: both additions (viterbi_kernel_sbg_typo.hip)
+					const float* nodeTypo = b.dNodeTypo.as<float>();
+					if (gl == 64) hipLaunchKernelGGL((typok::sbgk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd, nodeTypo);
+					else hipLaunchKernelGGL((typok::sbgk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd, nodeTypo);
+				}
+				else if (gl == 64) hipLaunchKernelGGL((sbgk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
 				else hipLaunchKernelGGL((sbgk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
 			}
 			else if (I.hasCong && b.typo.typo)
@@ -951,7 +958,6 @@ namespace kamd
 	{
 		if (typo.typo)
 		{
-			if (impl->hasSbg) throw std::runtime_error{ "kiwi_amd: typo correction with a SkipBigram model is not built" };
 			if (impl->model.forms.size() >= (1u << 24)) throw std::runtime_error{ "kiwi_amd: typo correction supports up to 2^24 forms" };
 		}
 		if ((match >> 8) & 3)

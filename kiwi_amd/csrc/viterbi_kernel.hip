@@ -2010,6 +2010,11 @@ namespace sbgk
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev);
 }
 }
+#elif defined(KAMD_TYPO) && defined(KAMD_SBG)
+	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, SbgDev, const float*);
+	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, SbgDev, const float*);
+}
+}
 #elif defined(KAMD_SBG)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, SbgDev);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, SbgDev);

@@ -66,6 +66,12 @@ namespace kamd
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, const float* nodeTypo, CongDev CG);
 	} }
+	// ... and for typo correction with a SkipBigram model (viterbi_kernel_sbg_typo.hip, KAMD_TYPO + KAMD_SBG)
+	namespace typok { namespace sbgk
+	{
+		template<int G, int WPS>
+		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, SbgDev S, const float* nodeTypo);
+	} }
 	// End stage, one THREAD per chunk: restated std::sort of the end candidates, per-(root, state) selection and the
 	// back-trace into 24-byte tokens.  A separate launch so that 64 chunks share a wavefront in this strictly serial stage.
 	__global__ void k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t stride);

@@ -33,3 +33,24 @@ def check_c5(lib, n):
 
 def test_c5_2k_sentences_bit_exact_vs_oracle():
     check_c5(LIB, 2048)
+
+
+@pytest.mark.parametrize("lanes", ["64", "16"])
+def test_typo_correction_with_a_skipbigram_model(small_sbg_model, monkeypatch, lanes):
+    """viterbi_kernel_sbg_typo.hip: the SkipBigram search kernel over lattices with typo costs, against the oracle (compared with the real
+    reference on this combination by tests/test_typo_oracle.py)."""
+    import random
+    import oraclelib
+    from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import misspell
+    sm, path = small_sbg_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    prod, orc_t = _typo_pair(LIB, 1.0)
+    dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
+    rnd = random.Random(25)
+    texts = [misspell(t, rnd, True, True) for t in synthetic(sm, 120, 941, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 60, 942)] + EDGE_TEXTS
+    got = _analyze_typo(dev, prod, texts, 2.5)
+    for t, y in zip(texts, got):
+        assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0)) == _norm(y), t
+    dev.close(); prod.close()

@@ -607,3 +607,24 @@ def test_emulated_typo_correction_with_the_character_model(emu_libs, small_cong_
     for t, y in zip(texts, got):
         assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0, match=match)) == _norm(y), t
     dev.close(); prod.close()
+
+
+@pytest.mark.parametrize("lanes", ["64", "16"])
+def test_emulated_typo_correction_with_a_skipbigram_model(emu_libs, small_sbg_model, monkeypatch, lanes):
+    """viterbi_kernel_sbg_typo.hip (history rings + node typo costs) against the oracle, which tests/test_typo_oracle.py compares with the real
+    reference on this combination."""
+    import random
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from typo_cases import misspell
+    sm, path = small_sbg_model
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    prod, orc_t = _typo_pair(emu_libs[0], 1.0)
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    rnd = random.Random(23)
+    texts = [misspell(t, rnd, True, True) for t in synthetic(sm, 24, 921, min_jamo=5, max_jamo=50) + dictionary_mix(sm, 12, 922)] + EDGE_TEXTS[:12]
+    got = _analyze_typo(dev, prod, texts, 2.5)
+    for t, y in zip(texts, got):
+        assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0)) == _norm(y), t
+    dev.close(); prod.close()

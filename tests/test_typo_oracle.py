@@ -141,3 +141,43 @@ def test_golden_typo_analyses(small_model):
         res = orc.analyze_typo(ot, it["text"], g["threshold"], 0)
         got = [[t.form, t.tag, t.position, t.length, t.score, t.typo_cost] for t in res[0][0]]
         assert got == it["tokens"] and res[0][1] == it["score"], it["text"]
+
+
+def test_typo_correction_with_a_skipbigram_model_equals_reference(small_sbg_model):
+    """The reference's typo transformers work with every model type: SkipBigram model + typo transformer, real reference vs oracle.  Texts whose
+    lattices stay within the small / medium containers must agree exactly; the large container hands tied paths on in a history-dependent order
+    (tests/test_oracle_vs_ref.py::test_skipbigram_analyses_match_reference), so there the best score is what is compared."""
+    import random
+    from dataclasses import astuple
+    import oraclelib
+    import refbridge
+    from corpora import dictionary_mix, synthetic
+    from typo_cases import misspell
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    sm, path = small_sbg_model
+    orc, ref = oraclelib.OracleKiwi(path), refbridge.RefKiwi(path)
+    name = "basic_with_continual"
+    ents, cont, leng = refbridge.default_typo_entries(name)
+    rt = refbridge.RefTypo(); rt.update_default(name); rt.prepare(True)
+    ot = oraclelib.OracleTypo(); ot.update_entries(ents, cont, leng); ot.prepare(True)
+    rnd = random.Random(21)
+    tt = [misspell(t, rnd, True, True, False) for t in synthetic(sm, 50, 751, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 30, 752)]
+
+    def norm(res):
+        return [([astuple(t) for t in a[0]], a[1]) for a in res]
+    prev = orc.counters()
+    exact = corrected = 0
+    for t in tt:
+        if not t.strip():
+            continue
+        a, b = ref.analyze_typo(rt, t, 2.5, 0), orc.analyze_typo(ot, t, 2.5, 0)
+        c = orc.counters()
+        large = c["nodesOver512"] > prev["nodesOver512"]
+        prev = c
+        assert a[0][1] == b[0][1], t
+        if not large:
+            assert norm(a) == norm(b), t
+            exact += 1
+        corrected += any(x.typo_cost > 0 for x in a[0][0])
+    assert exact >= 20 and corrected >= 5
