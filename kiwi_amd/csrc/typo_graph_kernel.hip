@@ -14,7 +14,9 @@
 // (generation on the worker pool, concatenation, one more upload), and host cores are what eight GPUs share.
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <cstdlib>
 #include "kchars.hpp"
+#include "device_types.hpp"
 #include "typo_graph_kernel.hpp"
 
 namespace kamd
@@ -236,105 +238,145 @@ namespace kamd
 		template<bool COUNT>
 		__global__ void __launch_bounds__(64) k_typo_graph(TypoGraphTables T, TypoGraphView V, uint32_t nChunks, uint32_t stride)
 		{
-			const bool mine = (threadIdx.x % stride) == 0;
-			const uint32_t c = mine ? blockIdx.x * (64 / stride) + threadIdx.x / stride : 0xFFFFFFFFu;
-			if (c >= nChunks) return;
+			// write pass with one chunk per wave (stride 64): the build itself runs on lane 0, the final ordering and the output copy on all 64 lanes
+			const bool wave = !COUNT && stride == 64;
+			const uint32_t lane = threadIdx.x;
+			const bool mine = (lane % stride) == 0;
+			const uint32_t c = wave ? blockIdx.x : mine ? blockIdx.x * (64 / stride) + lane / stride : 0xFFFFFFFFu;
+			if (c >= nChunks) return;      // (wave mode: the whole wave; else: the idle lanes)
 			const TypoGraphChunk C = V.chunks[c];
 			const uint32_t n = C.nChars;
-			if (C.scrCap < n + 2) { V.out[c] = TypoGraphOut{ 0, 0, 1 }; return; }
-			uint16_t* tlast = COUNT ? nullptr : reinterpret_cast<uint16_t*>(V.cnt + C.scrOff);      // (cnt is only needed by the final ordering: until then it holds the last-character facts)
-			GraphCtx<COUNT> G{ T, V.chars + C.charOff, V.cls + C.charOff, V.script + C.charOff, n, COUNT ? nullptr : V.temp + C.graphOff, tlast, V.epm + C.scrOff, C.graphCap, 0, 0, 1, false };
-			uint2* matches = V.matches + C.scrOff; uint32_t* bp = V.bp + C.scrOff;
-			uint32_t status = 0, maxCti = 0, nM = 0;
-			G.epm[0] = make_uint2(0, 0);
-			if constexpr (!COUNT)
+			uint32_t status = 0, maxCti = 0, nT = 0;
+			if (mine) do
 			{
-				if (!C.graphCap) { V.out[c] = TypoGraphOut{ 0, 0, 1 }; return; }
-				TypoGraphNode first{}; first.formOff = 0; first.formLen = 0; first.endPos = 0; first.typoCost = 0.f; first.prevOffset = 0; first.siblingOffset = 0;
-				first.continualTypoIdx = 0; first.pad = 0; first.dialect = 0;
-				G.temp[0] = first; G.tlast[0] = 0x00FF;
-			}
-			G.nTemp = 1;
-			int32_t node = T.entryNode;
-			if (node < 0) node = 0;
-			for (uint32_t i = 0; i <= n; ++i)      // (i == n: the text is over -- the pending cluster is closed through the same call site)
-			{
-				bool flush = false;
-				if (i < n)
+				if (C.scrCap < n + 2 || (!COUNT && !C.graphCap)) { status = 1; break; }
+				uint16_t* tlast = COUNT ? nullptr : reinterpret_cast<uint16_t*>(V.cnt + C.scrOff);      // (cnt is only needed by the final ordering: until then it holds the last-character facts)
+				GraphCtx<COUNT> G{ T, V.chars + C.charOff, V.cls + C.charOff, V.script + C.charOff, n, COUNT ? nullptr : V.temp + C.graphOff, tlast, V.epm + C.scrOff, C.graphCap, 0, 0, 1, false };
+				uint2* matches = V.matches + C.scrOff; uint32_t* bp = V.bp + C.scrOff;
+				uint32_t nM = 0;
+				G.epm[0] = make_uint2(0, 0);
+				if constexpr (!COUNT)
 				{
-					const uint16_t ch = G.str[i];
-					int32_t nx = tgStep(T, node, ch);
-					while (nx < 0)
+					TypoGraphNode first{}; first.formOff = 0; first.formLen = 0; first.endPos = 0; first.typoCost = 0.f; first.prevOffset = 0; first.siblingOffset = 0;
+					first.continualTypoIdx = 0; first.pad = 0; first.dialect = 0;
+					G.temp[0] = first; G.tlast[0] = 0x00FF;
+				}
+				G.nTemp = 1;
+				int32_t node = T.entryNode;
+				if (node < 0) node = 0;
+				for (uint32_t i = 0; i <= n; ++i)      // (i == n: the text is over -- the pending cluster is closed through the same call site)
+				{
+					bool flush = false;
+					if (i < n)
 					{
-						node = T.trie[node].fail;
-						if (node >= 0) nx = tgStep(T, node, ch);
-						else { node = 0; break; }
-					}
-					if (nx < 0) continue;
-					node = nx;
-					const int32_t pat = T.trie[node].pattern;
-					if (pat == -1) continue;
-					// a node that only carries the "a shorter pattern ends here" mark starts, in the reference's arithmetic, far beyond the text: it closes the pending cluster
-					if (nM)
-					{
-						if (pat < 0) flush = true;
-						else
+						const uint16_t ch = G.str[i];
+						int32_t nx = tgStep(T, node, ch);
+						while (nx < 0)
 						{
-							const uint32_t pl = T.pats[pat].patLength;
-							if (pl > i + 1) { status = 3; flush = true; }
-							else flush = matches[nM - 1].x < i + 1 - pl;
+							node = T.trie[node].fail;
+							if (node >= 0) nx = tgStep(T, node, ch);
+							else { node = 0; break; }
+						}
+						if (nx < 0) continue;
+						node = nx;
+						const int32_t pat = T.trie[node].pattern;
+						if (pat == -1) continue;
+						// a node that only carries the "a shorter pattern ends here" mark starts, in the reference's arithmetic, far beyond the text: it closes the pending cluster
+						if (nM)
+						{
+							if (pat < 0) flush = true;
+							else
+							{
+								const uint32_t pl = T.pats[pat].patLength;
+								if (pl > i + 1) { status = 3; flush = true; }
+								else flush = matches[nM - 1].x < i + 1 - pl;
+							}
 						}
 					}
+					else flush = nM != 0;
+					if (flush) { maxCti = insertBranch(G, matches, nM, bp, V.allowedDialect, maxCti, status); nM = 0; }
+					if (i == n) break;
+					const uint32_t endPos = i + 1;
+					for (int32_t sub = node; sub >= 0; sub = T.trie[sub].fail)
+					{
+						const int32_t sp = T.trie[sub].pattern;
+						if (sp == -1) break;
+						if (sp < 0) continue;
+						if (T.pats[sp].patLength > endPos) { status = 3; continue; }
+						if (nM + 2 >= C.scrCap) { G.overflow = true; break; }      // (the break points of the cluster: at most its matches + 1)
+						matches[nM++] = make_uint2(endPos, (uint32_t)sp);
+					}
 				}
-				else flush = nM != 0;
-				if (flush) { maxCti = insertBranch(G, matches, nM, bp, V.allowedDialect, maxCti, status); nM = 0; }
-				if (i == n) break;
-				const uint32_t endPos = i + 1;
-				for (int32_t sub = node; sub >= 0; sub = T.trie[sub].fail)
 				{
-					const int32_t sp = T.trie[sub].pattern;
-					if (sp == -1) break;
-					if (sp < 0) continue;
-					if (T.pats[sp].patLength > endPos) { status = 3; continue; }
-					if (nM + 2 >= C.scrCap) { G.overflow = true; break; }      // (the break points of the cluster: at most its matches + 1)
-					matches[nM++] = make_uint2(endPos, (uint32_t)sp);
+					const uint2 carry = G.epm[G.epmSize - 1];
+					G.epm[0] = carry; G.epmSize = 1;
+					G.append(G.last, n - G.last, G.last, n + 1, 0.f, COUNT ? (uint16_t)0 : G.lastOfText(G.last, n - G.last));
+					if constexpr (!COUNT) G.temp[G.nTemp - 1].endPos = n;      // (also when the append was refused: the reference sets the end of whatever node is last)
 				}
-			}
-			{
-				const uint2 carry = G.epm[G.epmSize - 1];
-				G.epm[0] = carry; G.epmSize = 1;
-				G.append(G.last, n - G.last, G.last, n + 1, 0.f, COUNT ? (uint16_t)0 : G.lastOfText(G.last, n - G.last));
-				if constexpr (!COUNT) G.temp[G.nTemp - 1].endPos = n;      // (also when the append was refused: the reference sets the end of whatever node is last)
-			}
-			if constexpr (COUNT) { V.out[c] = TypoGraphOut{ G.nTemp, maxCti, G.overflow ? 1u : status }; return; }
+				nT = G.nTemp;
+				if (G.overflow) status = 1;
+			} while (false);
+			if constexpr (COUNT) { if (mine) V.out[c] = TypoGraphOut{ nT, maxCti, status }; return; }
 			else
 			{
-			// the nodes in end-position order (std::stable_sort by endPos: counting sort), links re-based to the new indices
-			const uint32_t nT = G.nTemp;
-			if (nT > C.scrCap) { V.out[c] = TypoGraphOut{ nT, maxCti, 1 }; return; }
-			uint32_t* rev = V.rev + C.scrOff;
-			uint16_t* glast = reinterpret_cast<uint16_t*>(V.graphLast) + C.graphOff;
-			// (tlast shares cnt's region: move it out of the way first -- rev is free until the counting pass has run)
-			for (uint32_t i = 0; i < nT; ++i) rev[i] = G.tlast[i];
-			uint32_t* cnt = V.cnt + C.scrOff;
-			for (uint32_t i = 0; i <= n + 1; ++i) cnt[i] = 0;
-			for (uint32_t i = 0; i < nT; ++i) { const uint32_t e = G.temp[i].endPos; cnt[(e <= n ? e : n) + 1]++; }
-			for (uint32_t i = 1; i <= n + 1; ++i) cnt[i] += cnt[i - 1];
-			// bp is free now: bp[i] = last-character facts of temp node i, rev[i] = its new index
-			for (uint32_t i = 0; i < nT; ++i) bp[i] = rev[i];
-			for (uint32_t i = 0; i < nT; ++i) { const uint32_t e = G.temp[i].endPos; rev[i] = cnt[e <= n ? e : n]++; }
-			TypoGraphNode* out = V.graph + C.graphOff;
-			for (uint32_t i = 0; i < nT; ++i)
-			{
-				TypoGraphNode g = G.temp[i];
-				const uint32_t ni = rev[i];
-				g.prevOffset = ni - rev[g.prevOffset];
-				if (g.siblingOffset != 0) g.siblingOffset = rev[g.siblingOffset] - ni;
-				out[ni] = g;
-				glast[ni] = (uint16_t)bp[i];
-			}
-			if (G.overflow) status = 1;
-			V.out[c] = TypoGraphOut{ nT, maxCti, status };
+				if (wave) { waveSync(); nT = __shfl(nT, 0); status = __shfl(status, 0); maxCti = __shfl(maxCti, 0); }
+				if (status == 1 || nT > C.scrCap) { if (mine) V.out[c] = TypoGraphOut{ nT, maxCti, 1 }; return; }
+				// the nodes in end-position order (std::stable_sort by endPos), links re-based to the new indices
+				TypoGraphNode* temp = V.temp + C.graphOff; TypoGraphNode* out = V.graph + C.graphOff;
+				uint32_t* rev = V.rev + C.scrOff; uint32_t* cnt = V.cnt + C.scrOff; uint32_t* bp = V.bp + C.scrOff;
+				const uint16_t* tlast = reinterpret_cast<const uint16_t*>(cnt);
+				uint16_t* glast = reinterpret_cast<uint16_t*>(V.graphLast) + C.graphOff;
+				if (!wave)
+				{
+					// one lane: counting sort
+					for (uint32_t i = 0; i < nT; ++i) rev[i] = tlast[i];      // (tlast shares cnt's region: out of the way first)
+					for (uint32_t i = 0; i <= n + 1; ++i) cnt[i] = 0;
+					for (uint32_t i = 0; i < nT; ++i) { const uint32_t e = temp[i].endPos; cnt[(e <= n ? e : n) + 1]++; }
+					for (uint32_t i = 1; i <= n + 1; ++i) cnt[i] += cnt[i - 1];
+					for (uint32_t i = 0; i < nT; ++i) bp[i] = rev[i];
+					for (uint32_t i = 0; i < nT; ++i) { const uint32_t e = temp[i].endPos; rev[i] = cnt[e <= n ? e : n]++; }
+					for (uint32_t i = 0; i < nT; ++i)
+					{
+						TypoGraphNode g = temp[i];
+						const uint32_t ni = rev[i];
+						g.prevOffset = ni - rev[g.prevOffset];
+						if (g.siblingOffset != 0) g.siblingOffset = rev[g.siblingOffset] - ni;
+						out[ni] = g;
+						glast[ni] = (uint16_t)bp[i];
+					}
+				}
+				else
+				{
+					// 64 lanes: bp[i] = last-character facts, rev[i] = end position, cnt = histogram -> bucket starts, newIdx[i] = bucket start + number of
+					// earlier nodes with the same end (the stable order), then every lane copies its nodes
+					uint32_t* newIdx = reinterpret_cast<uint32_t*>(V.matches + C.scrOff);      // (the cluster's matches are history)
+					for (uint32_t i = lane; i < nT; i += 64) bp[i] = tlast[i];
+					waveSync();
+					for (uint32_t i = lane; i <= n + 1; i += 64) cnt[i] = 0;
+					waveSync();
+					for (uint32_t i = lane; i < nT; i += 64) { uint32_t e = temp[i].endPos; if (e > n) e = n; rev[i] = e; atomicAdd(&cnt[e + 1], 1u); }
+					waveSync();
+					if (lane == 0) for (uint32_t i = 1; i <= n + 1; ++i) cnt[i] += cnt[i - 1];
+					waveSync();
+					for (uint32_t i = lane; i < nT; i += 64)
+					{
+						const uint32_t e = rev[i];
+						uint32_t r = cnt[e];
+						for (uint32_t j = 0; j < i; ++j) r += rev[j] == e ? 1u : 0u;
+						newIdx[i] = r;
+					}
+					waveSync();
+					for (uint32_t i = lane; i < nT; i += 64)
+					{
+						TypoGraphNode g = temp[i];
+						const uint32_t ni = newIdx[i];
+						g.prevOffset = ni - newIdx[g.prevOffset];
+						if (g.siblingOffset != 0) g.siblingOffset = newIdx[g.siblingOffset] - ni;
+						out[ni] = g;
+						glast[ni] = (uint16_t)bp[i];
+					}
+				}
+				if (mine) V.out[c] = TypoGraphOut{ nT, maxCti, status };
 			}
 		}
 	}
@@ -343,7 +385,9 @@ namespace kamd
 	{
 		if (!nChunks) return;
 		// active lanes per wave: 1 up to 16k chunks, 4 up to 64k, 16 beyond (the machine holds 8192 waves)
-		const uint32_t stride = nChunks <= 16384 ? 64u : nChunks <= 65536 ? 16u : 4u, perWave = 64 / stride;
+		uint32_t stride = nChunks <= 16384 ? 64u : nChunks <= 65536 ? 16u : 4u;
+		if (const char* f = std::getenv("KAMD_TYPO_GRAPH_STRIDE")) { const int v = std::atoi(f); if (v == 4 || v == 16 || v == 64) stride = (uint32_t)v; }      // test hook: the several-chunks-per-wave path on small batches
+		const uint32_t perWave = 64 / stride;
 		if (countOnly) hipLaunchKernelGGL(k_typo_graph<true>, dim3((nChunks + perWave - 1) / perWave), dim3(64), 0, stream, T, V, nChunks, stride);
 		else hipLaunchKernelGGL(k_typo_graph<false>, dim3((nChunks + perWave - 1) / perWave), dim3(64), 0, stream, T, V, nChunks, stride);
 	}

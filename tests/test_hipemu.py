@@ -533,8 +533,11 @@ def check_device_typo_graphs(lib, model_path, n_random=80):
     dev.close()
 
 
-def test_emulated_typo_graph_kernel_matches_host_module(emu_libs, small_model):
-    check_device_typo_graphs(emu_libs[0], small_model[1])
+@pytest.mark.parametrize("stride", ["64", "16"])
+def test_emulated_typo_graph_kernel_matches_host_module(emu_libs, small_model, monkeypatch, stride):
+    """stride 64 = one chunk per wave (the ordering and the output copy on all lanes), 16 = four chunks per wave (one lane each)."""
+    monkeypatch.setenv("KAMD_TYPO_GRAPH_STRIDE", stride)
+    check_device_typo_graphs(emu_libs[0], small_model[1], n_random=80 if stride == "64" else 30)
 
 
 @pytest.mark.parametrize("lanes,top_n", [("16", 1), ("64", 2)])
