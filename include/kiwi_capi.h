@@ -116,6 +116,13 @@ kiwi_morphset_h kiwi_new_morphset(kiwi_h handle);                               
 int kiwi_morphset_add(kiwi_morphset_h handle, const char* form, const char* tag);                /* capi.h:1243 */
 int kiwi_morphset_add_w(kiwi_morphset_h handle, const kchar16_t* form, const char* tag);         /* capi.h:1253 */
 int kiwi_morphset_close(kiwi_morphset_h handle);                                                 /* capi.h:1263 */
+/* Pretokenized spans: the object can be built and closed; kiwi_analyze* accepts it as long as it holds no span (analysing with spans is refused loudly:
+ * the lattice kernels do not build span nodes yet) */
+kiwi_pretokenized_h kiwi_pt_init(void);                                                          /* capi.h:1351 */
+int kiwi_pt_add_span(kiwi_pretokenized_h handle, int begin, int end);                            /* capi.h:1367 */
+int kiwi_pt_add_token_to_span(kiwi_pretokenized_h handle, int span_id, const char* form, const char* tag, int begin, int end);          /* capi.h:1382 */
+int kiwi_pt_add_token_to_span_w(kiwi_pretokenized_h handle, int span_id, const kchar16_t* form, const char* tag, int begin, int end);   /* capi.h:1397 */
+int kiwi_pt_close(kiwi_pretokenized_h handle);                                                   /* capi.h:1405 */
 /* typo transformers (rule container, preparation, option.typo_transformer / typo_threshold of kiwi_analyze*): parity-checked on the MI355X against the
  * oracle and the real reference (tests/test_gpu_typo.py, tests/test_gpu_capi.py). */
 kiwi_typo_h kiwi_typo_init(void);                                                                /* capi.h:469 */

@@ -119,12 +119,24 @@ namespace
 		return ret;
 	}
 
+}
+// kiwi_pretokenized (src/capi/kiwi_c.cpp: a std::vector<PretokenizedSpan>): the object can be built and closed through the reference's entry points;
+// analysing WITH spans is refused loudly by checkOption below
+struct kiwi_pretokenized
+{
+	struct Token { std::u16string form; std::string tag; int begin, end; };
+	struct Span { int begin, end; std::vector<Token> tokens; };
+	std::vector<Span> spans;
+};
+namespace
+{
 	void checkOption(const kiwi_analyze_option_t& o, kiwi_pretokenized_h pt)
 	{
 		// allowed_dialects / dialect_cost: the candidate loops skip a morpheme whose dialect is neither standard nor allowed and charge dialect_cost for an
 		// allowed one (src/PathEvaluator.hpp:231, 386, 893).  Every model this library loads holds standard-dialect morphemes only (kiwi_init refuses
 		// enabled_dialects != 0, the bake refuses dialect morphemes), so both options are accepted and -- exactly as in the reference -- change nothing.
-		if (pt) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
+		// a pretokenized object without spans is no constraint (kiwi_pt_init + nothing added); spans themselves are not built on the device path yet
+		if (pt && !pt->spans.empty()) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
 		// Match::oovChrModel (bits 8-9): the engine checks that the model carries the character model (nounchr.mdl next to a CoNgram model) and refuses
 		// with the reference's own message otherwise; the two frequency-based modes are not built
 		if ((uint32_t)o.match_options & (1u << 30)) throw std::invalid_argument{ "kiwi_amd: useOldSplitter is not supported" };
@@ -253,6 +265,33 @@ extern "C"
 		try { size_t n = 0; while (form[n]) ++n; return morphsetAdd(m, std::u16string{ (const char16_t*)form, n }, tag); }
 		catch (const std::exception& e) { setError(e); return KIWIERR_FAIL; }
 	}
+	kiwi_pretokenized_h kiwi_pt_init() { return new (std::nothrow) kiwi_pretokenized; }      // capi.h:1351
+	int kiwi_pt_add_span(kiwi_pretokenized_h h, int begin, int end)                            // capi.h:1367: the id of the new span
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		try { h->spans.push_back(kiwi_pretokenized::Span{ begin, end, {} }); return (int)h->spans.size() - 1; }
+		catch (const std::exception& e) { setError(e); return KIWIERR_FAIL; }
+	}
+	int kiwi_pt_add_token_to_span_w(kiwi_pretokenized_h h, int span_id, const kchar16_t* form, const char* tag, int begin, int end)      // capi.h:1397
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		try
+		{
+			if (span_id < 0 || (size_t)span_id >= h->spans.size()) throw std::invalid_argument{ "invalid span_id: " + std::to_string(span_id) };
+			size_t n = 0; while (form[n]) ++n;
+			h->spans[(size_t)span_id].tokens.push_back(kiwi_pretokenized::Token{ std::u16string{ (const char16_t*)form, n }, tag ? tag : "", begin, end });
+			return 0;
+		}
+		catch (const std::exception& e) { setError(e); return KIWIERR_FAIL; }
+	}
+	int kiwi_pt_add_token_to_span(kiwi_pretokenized_h h, int span_id, const char* form, const char* tag, int begin, int end)               // capi.h:1382
+	{
+		if (!h) return KIWIERR_INVALID_HANDLE;
+		try { const std::u16string u = utf8To16(form, std::strlen(form)); return kiwi_pt_add_token_to_span_w(h, span_id, (const kchar16_t*)u.c_str(), tag, begin, end); }
+		catch (const std::exception& e) { setError(e); return KIWIERR_FAIL; }
+	}
+	int kiwi_pt_close(kiwi_pretokenized_h h) { if (!h) return KIWIERR_INVALID_HANDLE; delete h; return 0; }      // capi.h:1405
+
 	int kiwi_morphset_close(kiwi_morphset_h m)
 	{
 		if (!m) return KIWIERR_INVALID_HANDLE;

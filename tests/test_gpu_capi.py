@@ -246,6 +246,21 @@ def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
     assert r and read_result(capi, kiwi, r) == from_oracle(oracle.analyze(s))
     capi.kiwi_res_close(r)
     assert not capi.kiwi_init(b"/nonexistent", 0, 15, 1) and capi.kiwi_error()      # enabled dialects at build time: refused (no dialect.dict loader)
+    # pretokenized objects can be built and closed; without spans they constrain nothing, with a span the analysis is refused loudly
+    import ctypes as C
+    capi.kiwi_pt_init.restype = C.c_void_p
+    capi.kiwi_pt_add_span.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    capi.kiwi_pt_add_token_to_span.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    capi.kiwi_pt_close.argtypes = [C.c_void_p]
+    pt = capi.kiwi_pt_init()
+    assert pt
+    r = capi.kiwi_analyze(kiwi, s.encode(), 1, opt(), pt)
+    assert r and read_result(capi, kiwi, r) == from_oracle(oracle.analyze(s))
+    capi.kiwi_res_close(r)
+    assert capi.kiwi_pt_add_span(pt, 0, 3) == 0 and capi.kiwi_pt_add_token_to_span(pt, 0, "가나다".encode(), b"NNP", 0, 3) == 0
+    assert capi.kiwi_pt_add_token_to_span(pt, 5, "가".encode(), b"NNP", 0, 1) != 0
+    assert not capi.kiwi_analyze(kiwi, s.encode(), 1, opt(), pt) and b"pretokenized" in capi.kiwi_error()
+    assert capi.kiwi_pt_close(pt) == 0
 
 
 @pytest.mark.parametrize("header", ["kiwi_capi.h", "reference capi.h"])
