@@ -720,6 +720,17 @@ namespace kamd
 
 		void loadModelDir(const std::string& dir, ModelFiles& o, RawModel& raw)
 		{
+			// A model directory as Kiwi ships it also holds the build-time inputs of the reference's KiwiBuilder -- combiningRule.txt (REQUIRED there:
+			// rule-combined morphemes are generated from it at build time, src/KiwiBuilder.cpp:1080-1092, 2385-2640) and default / multi / typo .dict
+			// (:1035-1078).  This loader reads sj.morph and the language-model files only: analysing with such a directory would silently miss every
+			// rule-combined and dictionary entry.  Refused loudly instead, unless the caller asks for exactly that.
+			{
+				struct stat st;
+				if (stat((dir + "/combiningRule.txt").c_str(), &st) == 0 && !std::getenv("KAMD_ALLOW_UNEXPANDED_MODEL"))
+					throw std::runtime_error{ "kiwi_amd: this model directory holds combiningRule.txt: the reference expands rule-combined morphemes and loads its .dict "
+						"files at build time, which this library does not do yet -- analyses would differ from the reference's (tools/check_model_dir.py "
+						"describes the directory; KAMD_ALLOW_UNEXPANDED_MODEL=1 loads sj.morph + the language model alone)" };
+			}
 			const std::vector<uint8_t> mb = readFile(dir + "/sj.morph", true);
 			const uint8_t* p = mb.data(); const uint8_t* end = p + mb.size();
 			auto need = [&](size_t n) { if ((size_t)(end - p) < n) throw std::runtime_error{ "sj.morph: truncated" }; };

@@ -205,3 +205,27 @@ def test_kiwi_init_on_a_model_directory(small_model, small_cong_model, kind):
         assert [L.kiwi_res_form(r, 0, j).decode("utf-8") for j in range(len(want[0][0]))] == [t.form for t in want[0][0]], s
         L.kiwi_res_close(r)
     L.kiwi_close(k)
+
+
+def test_a_directory_with_the_builders_text_inputs_is_refused(small_model, tmp_path):
+    """A real Kiwi model directory also holds combiningRule.txt (+ .dict files), which the reference's KiwiBuilder consumes at build time and this
+    library does not: loading it is refused loudly (never a silently different dictionary), unless KAMD_ALLOW_UNEXPANDED_MODEL is set."""
+    import shutil
+    import subprocess
+    import sys
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref not built")
+    emu = os.path.join(HERE, "hipemu", "_build", "libkiwi_hipemu.so")
+    if not os.path.exists(emu):
+        pytest.skip("emulated library not built")
+    src = _model_dir(small_model[1], "small")
+    d = str(tmp_path / "real-like")
+    shutil.copytree(src, d)
+    open(os.path.join(d, "combiningRule.txt"), "w").write("# rules\n")
+    code = ("import sys; sys.path.insert(0, %r); from kiwi_amd.api import KiwiAmd\n"
+            "try:\n    KiwiAmd(%r, lib_path=%r); print('LOADED')\nexcept Exception as e:\n    print('REFUSED', 'combiningRule.txt' in str(e))\n") % (ROOT, d, emu)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k != "KAMD_ALLOW_UNEXPANDED_MODEL"}).stdout
+    assert "REFUSED True" in out, out
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, KAMD_ALLOW_UNEXPANDED_MODEL="1")).stdout
+    assert "LOADED" in out, out
