@@ -248,3 +248,26 @@ def test_quantised_knlm_matches_reference(small_quantised_model):
             node_o = node_r = 0
     for s in synthetic(sm, 300, 961, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 150, 962):
         assert ref.analyze(s) == orc.analyze(s), s
+
+
+@pytest.mark.parametrize("variant", ["htx-q6c", "cong-4bit-g4", "cong-4bit-g16-k2"])
+def test_more_model_file_variants_match_reference(variant, tmp_path):
+    """Other points of the format space than the fixtures cover, with other seeds: a history-transformed Knlm quantised to 6 bits with compressed node
+    sizes; cong.mdl with 4-bit embeddings in groups of 4 (32-bit keys, window sections) and in groups of 16 (16-bit keys) -- loader + oracle vs the real
+    reference (its SSE4.1 build for CoNgram) on whole analyses."""
+    import oraclelib
+    import refbridge
+    from kiwi_amd.synth import SynthModel, SynthSpec
+    cong = variant.startswith("cong")
+    if not (refbridge.x86_available() if cong else refbridge.available()):
+        pytest.skip("oracle/_ref not built")
+    spec = {"htx-q6c": SynthSpec(use_htx=True, knlm_qbits=6, knlm_compress=True, seed=101),
+            "cong-4bit-g4": SynthSpec(use_cong=True, cong_only=True, cong_qbit=4, cong_qgroup=4, cong_window=7, cong_key_size=4, seed=304),
+            "cong-4bit-g16-k2": SynthSpec(use_cong=True, cong_only=True, cong_qbit=4, cong_qgroup=16, cong_key_size=2, seed=401)}[variant]
+    sm = SynthModel(spec)
+    path = str(tmp_path / "m.raw")
+    sm.raw.save(path)
+    ref = refbridge.RefKiwi(path, arch=3, x86=True) if cong else refbridge.RefKiwi(path)
+    orc = oraclelib.OracleKiwi(path)
+    for s in synthetic(sm, 120, 7001, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 60, 7002):
+        assert ref.analyze(s) == orc.analyze(s), s
