@@ -12,15 +12,32 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))      # (test_hipemu imports the oracle wrappers at module level; nothing of the oracle runs here)
 from corpora import EDGE_TEXTS, dictionary_mix, synthetic   # noqa: E402
 from kiwi_amd.api import KiwiAmd                              # noqa: E402
-from kiwi_amd.synth import SMALL_SBG_SPEC, SMALL_SPEC, SynthModel   # noqa: E402
+from kiwi_amd.synth import SMALL_CONG_CHR_SPEC, SMALL_SBG_SPEC, SMALL_SPEC, SynthModel   # noqa: E402
 
 lib, kind = sys.argv[1], sys.argv[2]
-sm = SynthModel(SMALL_SBG_SPEC if kind == "sbg" else SMALL_SPEC)
-path = os.path.join(ROOT, "_data", "small-sbg.raw" if kind == "sbg" else "small.raw")
+sm = SynthModel(SMALL_SBG_SPEC if kind == "sbg" else SMALL_CONG_CHR_SPEC if kind == "chr" else SMALL_SPEC)
+path = os.path.join(ROOT, "_data", "small-sbg.raw" if kind == "sbg" else "small-cong-chr.raw" if kind == "chr" else "small.raw")
 if not os.path.exists(path):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     sm.raw.save(path)
 dev = KiwiAmd(path, lib_path=lib)
+if kind == "chr":
+    # Match::oovChrModel on a CoNgram model: k_unk_chr, the CoNgram search reading its scores -- plain and with a typo transformer (k_typo_graph,
+    # typo lattices, the typo + CoNgram search)
+    import random
+    import test_hipemu
+    from typo_cases import misspell
+    texts = synthetic(sm, 10, 621, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 5, 622) + EDGE_TEXTS[:25]
+    import oraclelib
+    match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
+    assert len(dev.analyze_batch(texts, match=match).to_python()) == len(texts)
+    prod, _ = test_hipemu._typo_pair(lib, 1.0)
+    rnd = random.Random(5)
+    tt = [misspell(t, rnd, True, True) for t in texts[:12]]
+    assert len(test_hipemu._analyze_typo(dev, prod, tt, 2.5, match=match)) == len(tt)
+    dev.close(); prod.close()
+    print("sanitizer run complete:", kind, len(texts), "texts")
+    sys.exit(0)
 if kind == "typo":
     # the typo-correcting analysis (typo lattice kernel, search with node typo costs) on misspelt texts
     import random
