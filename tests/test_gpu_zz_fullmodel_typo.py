@@ -54,3 +54,10 @@ def test_typo_correction_with_a_skipbigram_model(small_sbg_model, monkeypatch, l
     for t, y in zip(texts, got):
         assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0)) == _norm(y), t
     dev.close(); prod.close()
+
+
+def test_model_variant_goldens_from_the_real_reference():
+    """History-transformed quantised sj.knlm; CoNgram without / with Match::oovChrModel: the device against the committed outputs of the real
+    reference (tests/golden/model_variants_golden.json)."""
+    from test_hipemu import check_device_against_model_variant_goldens
+    check_device_against_model_variant_goldens(LIB)

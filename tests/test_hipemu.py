@@ -631,3 +631,26 @@ def test_emulated_typo_correction_with_a_skipbigram_model(emu_libs, small_sbg_mo
     for t, y in zip(texts, got):
         assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0)) == _norm(y), t
     dev.close(); prod.close()
+
+
+def check_device_against_model_variant_goldens(lib, names=("htx-q8c", "cong", "cong-oov-chr"), limit=None):
+    """Shared with tests/test_gpu_zz_fullmodel_typo.py: the device path against the committed outputs of the REAL reference for the round-2 model
+    variants (tests/golden/model_variants_golden.json, tools/make_golden_models.py): tokens, positions, morpheme ids, fp32 scores."""
+    import json
+    from kiwi_amd.api import KiwiAmd
+    from test_oracle_vs_ref import _golden_model
+    sets = json.load(open(os.path.join(HERE, "golden", "model_variants_golden.json"), encoding="utf-8"))["sets"]
+    for name in names:
+        g = sets[name]
+        items = g["items"][:limit] if limit else g["items"]
+        dev = KiwiAmd(_golden_model(name), lib_path=lib)
+        got = dev.analyze_batch([it["text"] for it in items], match=g["match"]).to_python()
+        for it, y in zip(items, got):
+            toks = [[t.form, t.tag, t.position, t.length, t.word_position, t.sent_position, t.sense_id, t.morph_id] for t in y[0][0]]
+            assert toks == it["tokens"], (name, it["text"])
+            assert y[0][1] == it["score"], (name, it["text"])
+        dev.close()
+
+
+def test_emulated_device_matches_the_model_variant_goldens(emu_libs):
+    check_device_against_model_variant_goldens(emu_libs[0], limit=70)

@@ -271,3 +271,27 @@ def test_more_model_file_variants_match_reference(variant, tmp_path):
     orc = oraclelib.OracleKiwi(path)
     for s in synthetic(sm, 120, 7001, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 60, 7002):
         assert ref.analyze(s) == orc.analyze(s), s
+
+
+def _golden_model(name):
+    from kiwi_amd.synth import SMALL_CONG_CHR_SPEC, SMALL_HTX_Q8_SPEC, SynthModel
+    spec, fname = {"htx-q8c": (SMALL_HTX_Q8_SPEC, "small-htx-q8.raw")}.get(name, (SMALL_CONG_CHR_SPEC, "small-cong-chr.raw"))
+    d = os.path.join(os.path.dirname(HERE), "_data")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, fname)
+    SynthModel(spec).raw.save(path)
+    return path
+
+
+@pytest.mark.parametrize("name", ["htx-q8c", "cong", "cong-oov-chr"])
+def test_golden_vectors_of_the_model_file_variants(name):
+    """tests/golden/model_variants_golden.json (tools/make_golden_models.py: the REAL reference on a history-transformed quantised sj.knlm, and on a
+    CoNgram model without / with Match::oovChrModel) against the oracle -- holds where oracle/_ref is absent too."""
+    import oraclelib
+    g = json.load(open(os.path.join(HERE, "golden", "model_variants_golden.json"), encoding="utf-8"))["sets"][name]
+    orc = oraclelib.OracleKiwi(_golden_model(name))
+    for item in g["items"]:
+        got = orc.analyze(item["text"], match=g["match"])
+        toks = [[t.form, t.tag, t.position, t.length, t.word_position, t.sent_position, t.sense_id, t.morph_id] for t in got[0][0]]
+        assert toks == item["tokens"], item["text"]
+        assert got[0][1] == item["score"], item["text"]
