@@ -15,8 +15,8 @@ from kiwi_amd.api import KiwiAmd                              # noqa: E402
 from kiwi_amd.synth import SMALL_CONG_CHR_SPEC, SMALL_SBG_SPEC, SMALL_SPEC, SynthModel   # noqa: E402
 
 lib, kind = sys.argv[1], sys.argv[2]
-sm = SynthModel(SMALL_SBG_SPEC if kind == "sbg" else SMALL_CONG_CHR_SPEC if kind == "chr" else SMALL_SPEC)
-path = os.path.join(ROOT, "_data", "small-sbg.raw" if kind == "sbg" else "small-cong-chr.raw" if kind == "chr" else "small.raw")
+sm = SynthModel(SMALL_SBG_SPEC if kind in ("sbg", "sbgtypo") else SMALL_CONG_CHR_SPEC if kind == "chr" else SMALL_SPEC)
+path = os.path.join(ROOT, "_data", "small-sbg.raw" if kind in ("sbg", "sbgtypo") else "small-cong-chr.raw" if kind == "chr" else "small.raw")
 if not os.path.exists(path):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     sm.raw.save(path)
@@ -38,7 +38,8 @@ if kind == "chr":
     dev.close(); prod.close()
     print("sanitizer run complete:", kind, len(texts), "texts")
     sys.exit(0)
-if kind == "typo":
+if kind in ("typo", "sbgtypo"):
+    # (sbgtypo: the same on a SkipBigram model -- viterbi_kernel_sbg_typo.hip)
     # the typo-correcting analysis (typo lattice kernel, search with node typo costs) on misspelt texts
     import random
     import test_hipemu
@@ -53,8 +54,8 @@ if kind == "typo":
                 assert prod.add(o, e, cost, COND[cond], dia) == 0
     prod.prepare(True)
     rnd = random.Random(3)
-    texts = [misspell(t, rnd, True, True) for t in synthetic(sm, 12, 611, min_jamo=5, max_jamo=60) + dictionary_mix(sm, 6, 612)]
-    for top_n in (1, 2):
+    texts = [misspell(t, rnd, True, True) for t in synthetic(sm, 12 if kind == "typo" else 6, 611, min_jamo=5, max_jamo=60 if kind == "typo" else 40) + dictionary_mix(sm, 6 if kind == "typo" else 3, 612)]
+    for top_n in (1, 2) if kind == "typo" else (1,):
         assert len(test_hipemu._analyze_typo(dev, prod, texts, 2.5, top_n)) == len(texts)
     dev.close(); prod.close()
     print("sanitizer run complete:", kind, len(texts), "texts")
