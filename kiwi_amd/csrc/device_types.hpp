@@ -33,6 +33,30 @@ namespace kamd
 	struct CandStatic { Quad m0, m1, x; };
 	constexpr uint32_t NOFORM = 0xFFFFFFFFu;
 
+	// ---- position program of the position-step search kernel (k_pos_path, viterbi_pos.inc), written once per batch by k_expand_pos ----
+	// Lattice nodes that END at the same position have all their predecessors complete and do not feed each other, so the search advances one
+	// END POSITION per step instead of one node.  Everything about such a step that is a function of the lattice alone is precomputed:
+	// one PosRec per (node, candidate that will be evaluated) -- statically skipped candidates are gone, the unknown-noun candidates of formless
+	// nodes and the extra proper-noun reading of all-partial forms (PathEvaluator.hpp:1277-1287) are ordinary records -- with every node-level
+	// term (discounts, left-boundary score, rule-scorer inputs, own-form facts) already folded in.
+	struct alignas(16) PosRec
+	{
+		uint32_t firstWid, secondWid, chunkOff, lastSeqId;      // LM ids fed first / second, chunk table offset, word id recorded on the path
+		uint32_t morph, flagsFeat, tagw, cntw;                  // morpheme id; MorphRec dwords 5..7 (device copy: path-side feat / prevFlags)
+		float additional;                                       // userScore + node-level discount + left-boundary tag score (PathEvaluator.hpp:366-383)
+		uint32_t nodeOwn;                                       // node index | own-form feature mask << 16
+		uint32_t bits;                                          // sbType | ruleBits << 8 | ownKind << 16 | node flags (NF_*) << 24
+		uint32_t rq;                                            // R (start states a quote / sentence-break candidate is tried under) | node's index inside its position << 8 | PR_* << 16
+	};
+	static_assert(sizeof(PosRec) == 48, "PosRec");
+	enum PosRecFlag : uint32_t { PR_PASS1 = 1u << 16,          // the all-partial form's extra unknown-noun reading (a second evaluation of the node)
+		PR_OUT_FIRST = 1u << 17 };                              // CoNgram: the evaluation's regular candidates share one first word (qgemm dispatch)
+	// one END position: nodes [firstNode, firstNode + nNodes), records [firstRec, firstRec + nRec) of the chunk.  Entry 0 of a chunk's table is
+	// its header: firstRec = number of positions (0: the chunk is left to the general kernel).
+	struct alignas(16) PosDesc { uint16_t firstNode; uint8_t nNodes; uint8_t flags; uint32_t firstRec; uint16_t nRec; uint16_t pad; uint32_t pad2; };      // pad: bit j = node j of the position has no dictionary form
+	static_assert(sizeof(PosDesc) == 16, "PosDesc");
+	enum PosFlag : uint8_t { POSF_SLOW = 1 };                     // something the position-step kernel does not do (z-coda / z-siot shortcut, > 16 records or nodes): hand over
+
 	// search state, 48 B = three 16-byte quads (reference: WordLL<KnLMState> 48 B, src/BestPathContainer.hpp:21-67).
 	// Quad 0 is everything a successor transition reads ("hot": one 16-byte load per work item); quads 1-2 are only
 	// needed when a state is created from its parent and by the back-trace.
@@ -151,6 +175,9 @@ namespace kamd
 		float* unkChr;
 		const uint32_t* blockBits;     // AnalyzeOption::blocklist as one bit per morpheme id (null: none): k_expand_cands drops those candidates
 		uint32_t outPathCap, outTokCap;
+		// position program (k_expand_pos -> k_pos_path): records at the chunk's packBase offset (same capacity as its candidate packs), position
+		// table and per-node predecessor ranges (first | last << 16) at its nodeBase offset; null = the position-step kernel is not used
+		PosRec* posRecs; PosDesc* posDesc; uint32_t* posPrev; uint32_t* posNodeRec;
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
 		uint32_t bigScratchBytes;      // per wave
 		uint32_t* beacon;              // developer aid (KAMD_TIMELINE builds): per-chunk timeline records, else null

@@ -28,6 +28,7 @@ namespace kamd
 	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
+	__global__ void k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr);
 	__global__ void k_unk_chr(ModelView M, BatchView B, WorkView W, ChrView C, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
 
 	namespace
@@ -182,6 +183,7 @@ namespace kamd
 		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder, dBlockBits, dUnkChr;
 		TypoLatView tv{};
 		DevBuf dPacks, dStates, dNodeStOff, dNodeStCnt, dReach, dTokens, dResults, dOrder;
+		DevBuf dPosRecs, dPosDesc, dPosPrev, dPosNodeRec;   // position program of k_pos_path (k_expand_pos)
 		DevBuf dOutPaths, dOutTokens, dOutCounters; uint32_t outPathCap = 0, outTokCap = 0;   // compact outputs of the end stage
 		PinBuf hOut, hOut2;       // D2H landing zones: counters + chunk results; then the path headers and token records that were produced
 		uint64_t outBytes = 0;    // bytes the last download copied
@@ -210,6 +212,7 @@ namespace kamd
 		uint32_t persistBlocks = 0;
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
+		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter;
 		ChrView chr{};      // character model of Match::oovChrModel on the device (absent: dim 0)
@@ -324,6 +327,7 @@ namespace kamd
 			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16, 32 or 64" };
 		}
 		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2 or 3" }; }
+		if (const char* pp = std::getenv("KAMD_POS_PATH")) impl->posPath = std::atoi(pp) != 0;
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
 		impl->counter.ensure(256);
 	}
@@ -440,13 +444,19 @@ namespace kamd
 		b.dPacks.ensure((size_t)b.packBase[nC] * sizeof(CandStatic) + 16);
 		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
 		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
+		const bool posPath = I.posPath && !I.hasSbg;
+		if (posPath)
+		{
+			b.dPosRecs.ensure((size_t)b.packBase[nC] * sizeof(PosRec) + 16); b.dPosDesc.ensure(totNodes * sizeof(PosDesc) + 16);
+			b.dPosPrev.ensure(totNodes * 4 + 16); b.dPosNodeRec.ensure(totNodes * 4 + 16);
+		}
 		if (I.hasSbg) b.dHist.ensure(totStates * 32 + 32);
 		// compact outputs of the end stage: as many token records as the arenas could hold, 16 path headers per chunk (x capacity scale)
 		b.outTokCap = (uint32_t)std::min<uint64_t>(totTokens, 0xFFFFFFF0ull); b.outPathCap = (uint32_t)std::min<uint64_t>((uint64_t)nC * 16 * sc, 0xFFFFFFF0ull);
 		b.dOutTokens.ensure((size_t)b.outTokCap * sizeof(DevToken) + 16); b.dOutPaths.ensure((size_t)b.outPathCap * sizeof(DevPathHeader) + 16); b.dOutCounters.ensure(64);
 		b.devBytes = 0;
 		for (const DevBuf* d : { &b.dIn, &b.dOutTokens, &b.dOutPaths, &b.dNsToPos, &b.dPosToNs, &b.dCflag, &b.dMask, &b.dMoff, &b.dMatchForm, &b.dNodes, &b.dTmpNodes, &b.dEndPosMap, &b.dTmpIdx,
-			&b.dPacks, &b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults }) b.devBytes += d->cap;
+			&b.dPacks, &b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults, &b.dPosRecs, &b.dPosDesc, &b.dPosPrev, &b.dPosNodeRec }) b.devBytes += d->cap;
 
 		BatchView& bv = b.bv;
 		bv.nChunks = (uint32_t)nC; bv.chars = (const uint16_t*)(D + oChars); bv.cls = D + oCls; bv.script = D + oScript;
@@ -464,6 +474,8 @@ namespace kamd
 		w.tokenBase = (const uint64_t*)(D + oTokenBase); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
 		w.outTokens = b.dOutTokens.as<DevToken>(); w.outPaths = b.dOutPaths.as<DevPathHeader>(); w.outCounters = b.dOutCounters.as<uint32_t>();
 		w.outTokCap = b.outTokCap; w.outPathCap = b.outPathCap;
+		w.posRecs = posPath ? b.dPosRecs.as<PosRec>() : nullptr; w.posDesc = posPath ? b.dPosDesc.as<PosDesc>() : nullptr;
+		w.posPrev = posPath ? b.dPosPrev.as<uint32_t>() : nullptr; w.posNodeRec = posPath ? b.dPosNodeRec.as<uint32_t>() : nullptr;
 		w.blockBits = nullptr;
 		w.unkChr = nullptr;
 		if ((b.match >> 8) & 3) { b.dUnkChr.ensure(totNodes * 4 + 16); w.unkChr = b.dUnkChr.as<float>(); }      // Match::oovChrModel (checked in stage())
@@ -723,6 +735,10 @@ namespace kamd
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u);
 			if (b.wv.unkChr)      // Match::oovChrModel: every node's unknown form scored by the character model, once, before the search
 				hipLaunchKernelGGL(k_unk_chr, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, I.chr, c0, cn, chrToken(0xD800, identifySpecialChr(0xD800)), chrToken(0xDC00, identifySpecialChr(0xDC00)));
+			// position-step search first (viterbi_pos.inc): top-1, 16-lane groups, not for SkipBigram models; what it cannot finish is resumed by the general kernel below
+			const bool usePos = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S == 1;
+			if (usePos)
+				hipLaunchKernelGGL(k_expand_pos, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, b.typo.typo ? b.dNodeTypo.as<float>() : (const float*)nullptr, (I.hasCong && b.wv.unkChr) ? 1u : 0u);
 			HIPCHECK(hipEventRecord(e[2], sA));
 			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));
 			HIPCHECK(hipEventRecord(e[3], sB));
@@ -736,6 +752,15 @@ namespace kamd
 			HIPCHECK(hipMemsetAsync(tlBuf.p, 0, (size_t)nC * 128, sB));
 			wv.beacon = tlBuf.as<uint32_t>(); gTimeline = tlBuf.p;
 #endif
+#ifndef KAMD_TIMELINE
+			static DevBuf posBeacon;      // developer aid (KAMD_POS_DEBUG builds): progress beacons of k_pos_path, 256 bytes per chunk, printed by KAMD_HANGDUMP
+			if (getenv("KAMD_POS_BEACON"))
+			{
+				posBeacon.ensure((size_t)nC * 256);
+				HIPCHECK(hipMemsetAsync(posBeacon.p, 0, (size_t)nC * 256, sB));
+				wv.beacon = posBeacon.as<uint32_t>();
+			}
+#endif
 			wv.bigScratch = I.bigScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * groupScratchBytes : 0);
 			uint32_t* counter = I.counter.as<uint32_t>() + k;
 			const uint32_t* order = b.dOrder.as<uint32_t>() + c0;
@@ -748,6 +773,19 @@ namespace kamd
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
 			const uint32_t blocksK = std::min(persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
 			const uint32_t ldsK = searchKernelLdsBytes(gl);
+			if (usePos)
+			{
+				const bool wide = cn >= 16384 && !(I.wpsForced == 2);      // many chunks: four waves per SIMD (a 128-VGPR build); few: the latency-bound regime
+				const uint32_t blocksP = (cn + 3) / 4;      // four chunks per one-wave block, no persistent loop (viterbi_pos.inc)
+				const float* nodeTypoP = b.typo.typo ? b.dNodeTypo.as<float>() : nullptr;
+#define KAMD_POS_LAUNCH(NS, ...) { if (wide) hipLaunchKernelGGL((NS k_pos_path<16, 4>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
+				else hipLaunchKernelGGL((NS k_pos_path<16, 2>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); }
+				if (I.hasCong && b.typo.typo) KAMD_POS_LAUNCH(typok::congk::, nodeTypoP, I.cong)
+				else if (I.hasCong) KAMD_POS_LAUNCH(congk::, I.cong)
+				else if (b.typo.typo) KAMD_POS_LAUNCH(typok::, nodeTypoP)
+				else KAMD_POS_LAUNCH(kamd::)
+#undef KAMD_POS_LAUNCH
+			}
 #define KAMD_LAUNCH(GG, WW) hipLaunchKernelGGL((k_best_path<GG, WW>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn)
 			if (I.hasSbg)
 			{
@@ -830,6 +868,28 @@ namespace kamd
 						if (!fin && shown < 24) { ++shown; fprintf(stderr, "  chunk %u text %u: status %u nPaths %u nEnd %u endOff %u nodes %u, node records written up to %u\n", c, (uint32_t)b.refs[c].text, res[c].status, res[c].nPaths, res[c].nEnd, res[c].endOff, nn[c], reached); }
 					}
 					fprintf(stderr, "[hangdump] finished chunks: %u / %u\n", done, nC);
+					if (wv.beacon)
+					{
+						std::vector<uint32_t> bc((size_t)nC * 64);
+						HIPCHECK(hipMemcpyAsync(bc.data(), wv.beacon, bc.size() * 4, hipMemcpyDeviceToHost, sC));
+						HIPCHECK(hipStreamSynchronize(sC));
+						uint32_t hist[16] = {}, shownB = 0;
+						for (uint32_t c = 0; c < nC; ++c)
+						{
+							const uint32_t* q = &bc[(size_t)c * 64];
+							++hist[q[0] & 15];
+							if (q[0] != 13 && q[0] != 11 && q[0] != 0 && shownB < 12)
+							{
+								++shownB;
+								fprintf(stderr, "  [pos beacon] chunk %u: stage %u args %u %u 0x%x beats %u\n    Q:", c, q[0], q[1], q[2], q[3], q[4]);
+								for (int l = 0; l < 16; ++l) fprintf(stderr, " %u", q[16 + l]);
+								fprintf(stderr, "\n    S:"); for (int l = 0; l < 16; ++l) fprintf(stderr, " %u", q[32 + l]);
+								fprintf(stderr, "\n    k|local<<8:"); for (int l = 0; l < 16; ++l) fprintf(stderr, " 0x%x", q[48 + l]);
+								fprintf(stderr, "\n");
+							}
+						}
+						fprintf(stderr, "[hangdump] pos beacon stages:"); for (int l = 0; l < 16; ++l) fprintf(stderr, " %d:%u", l, hist[l]); fprintf(stderr, "\n");
+					}
 					fflush(stderr);
 					_exit(7);
 				}
@@ -838,6 +898,24 @@ namespace kamd
 		HIPCHECK(hipGetLastError());
 		HIPCHECK(hipStreamSynchronize(sA));
 		HIPCHECK(hipStreamSynchronize(sB));
+		if (b.wv.posRecs && getenv("KAMD_POS_STATS"))
+		{
+			// developer aid: how many chunks the position-step kernel handed over before the end node, how far into their lattices it got, and why
+			std::vector<DevChunkResult> res(nC); std::vector<uint32_t> nn(nC);
+			HIPCHECK(hipMemcpy(res.data(), b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost));
+			HIPCHECK(hipMemcpy(nn.data(), b.dNNodes.p, nC * 4, hipMemcpyDeviceToHost));
+			double frac = 0; uint32_t early = 0, atStart = 0, seen = 0, why[16] = {};
+			for (uint32_t c = 0; c < nC; ++c)
+			{
+				const uint32_t at = res[c].pad & 0xFFFFFFu;
+				if (!at || !nn[c]) continue;
+				++seen;
+				if (at + 1 >= nn[c]) continue;
+				++early; frac += (double)at / nn[c]; atStart += at <= 1; ++why[(res[c].pad >> 24) & 15];
+			}
+			fprintf(stderr, "[pos] chunks %u (searched %u), handed over early %u (%.2f %%), of those from the start %u, mean hand-over point %.2f of the lattice; reasons: static %u, ring %u, container %u, record size %u, staging %u, retry %u, disconnected %u, no program %u\n",
+				nC, seen, early, seen ? 100.0 * early / seen : 0.0, atStart, early ? frac / early : 0.0, why[1], why[2], why[3], why[4], why[5], why[6], why[7], why[8]);
+		}
 #ifdef KAMD_TIMELINE
 		if (getenv("KAMD_TIMELINE_PRINT") && gTimeline)
 		{

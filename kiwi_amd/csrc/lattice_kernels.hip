@@ -833,6 +833,195 @@ namespace kamd
 		}
 	}
 
+	// ------------------------------------------------------------------------------------------------
+	// Position program of the position-step search kernel (k_pos_path, viterbi_pos.inc; device_types.hpp PosRec / PosDesc).
+	// The search sweeps the lattice one END POSITION at a time; what a step does is, apart from the incoming paths, a function of the lattice:
+	// which candidates are evaluated at all (PathEvaluator.hpp:385-446: complex morphemes under splitComplex, z-siot without the saisiot options,
+	// the "ha" contraction after a space are skipped), their node-level score terms (whitespace / typo discount, unknown-form score, left-boundary
+	// tag score: PathEvaluator.hpp:366-383, 1224-1318), the rule scorer's node-side inputs (:88-109), the own-form facts of the states they create.
+	// One wave per chunk, three passes of one node per lane, after k_expand_cands (and k_unk_chr): A counts records and positions, B completes the
+	// position table, C writes the records.  Memory-bound, off the search kernel's dependent chain.
+	__device__ __forceinline__ float leftBoundaryScore(uint32_t t)      // TagSequenceScorer (src/TagUtils.cpp:49-62) incl. the PA spill (include/kiwi/TagUtils.h:10-18)
+	{
+		if (t == 2 * T_MAX) return 5.f;
+		if (t < T_MAX) return (t == T_NNP || t == T_NP || t == T_IC) ? -1.f : (t == T_SB ? -3.f : 0.f);
+		const uint8_t r = (uint8_t)(t - T_MAX);
+		return (isEClass(r) || isJClass(r) || isSuffixTag(r) || r == T_VCP) ? -1.f : 0.f;
+	}
+	// 0 = not evaluated, 1 = a regular candidate, 2 = z-coda / z-siot shortcut (PathEvaluator.hpp:385-446)
+	__device__ __forceinline__ uint32_t posCandKind(const SearchParams& P, uint32_t flags, uint8_t tag, bool spaceBefore)
+	{
+		if (P.splitComplex && (flags & MF_HAS_COMPLEX)) return 0;
+		if (tag == T_Z_CODA || tag == T_Z_SIOT) return (tag == T_Z_SIOT && !(P.splitSaisiot || P.mergeSaisiot)) ? 0u : 2u;
+		if (!(flags & MF_SINGLE) && (flags & MF_HA_CONTRACTION) && spaceBefore) return 0;
+		return 1;
+	}
+	__global__ void __launch_bounds__(64) k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr)
+	{
+		if (blockIdx.x >= chunkCount) return;
+		const uint32_t lane = threadIdx.x;
+		const uint32_t chunk = chunkBegin + blockIdx.x;
+		const uint32_t nBase = W.nodeBase[chunk];
+		PosDesc* desc = W.posDesc + nBase;
+		if (lane == 0) { desc[0].firstNode = 0; desc[0].nNodes = 0; desc[0].flags = 0; desc[0].firstRec = 0; desc[0].nRec = 0; }      // no positions until the table is complete
+		if (W.results[chunk].status != CS_OK) return;
+		const uint32_t G = W.nNodes[chunk];
+		const uint32_t nUniq = B.spOff[chunk + 1] - B.spOff[chunk];
+		if (G <= 2 || G > 0xFFF0u || nUniq + 1 > 0x1Fu) return;
+		const DevNode* nodes = W.nodes + nBase;
+		const CandStatic* packs = W.packs + W.packBase[chunk];
+		const CandStatic* unkPacks = reinterpret_cast<const CandStatic*>(M.unkPacks);
+		PosRec* recs = W.posRecs + W.packBase[chunk];
+		const uint32_t recCap = W.packBase[chunk + 1] - W.packBase[chunk];
+		uint32_t* prev = W.posPrev + nBase; uint32_t* nodeRec = W.posNodeRec + nBase;
+		const uint8_t* cls = B.cls + B.charOff[chunk];
+
+		// ---- A: records per node, position of every node ----
+		uint32_t recTop = 0, posTop = 0;
+		for (uint32_t base = 1; base + 1 < G; base += 64)
+		{
+			const uint32_t i = base + lane;
+			const bool act = i + 1 < G;
+			uint32_t cnt = 0; bool slow = false, isFirst = false;
+			if (act)
+			{
+				const DevNode nd = nodes[i];
+				if (nd.form != NOFORM)
+				{
+					const bool spaceBefore = nd.nflags & NF_SPACE_BEFORE;
+					for (uint32_t k = 0; k < nd.candCnt; ++k)
+					{
+						const uint4 m1 = reinterpret_cast<const uint4*>(packs + nd.packOff + k)[1];
+						const uint32_t kind = posCandKind(P, m1.y & 0xFFFF, (uint8_t)m1.z, spaceBefore);
+						if (kind == 1) ++cnt; else if (kind == 2) slow = true;
+					}
+					if (!cnt) slow = true;      // nothing to evaluate: the reference then retries without conditions and falls back (PathEvaluator.hpp:468-473, 1286-1299)
+					if (nd.nflags & NF_ALL_PARTIAL) ++cnt;
+				}
+				else cnt = 2;
+				isFirst = i == 1 || nodes[i - 1].endPos != nd.endPos;
+				const uint32_t firstPrev = i - nd.prev;
+				prev[i] = firstPrev | ((firstPrev + nd.nPrev - 1) << 16);
+				// the nodes of one step must not feed each other: true for spans of the text (a predecessor ends where the node starts, before its end);
+				// a lattice over a typo graph may hold nodes of equal text end that do -- such a position is left to the general kernel
+				uint32_t j0 = i;
+				while (j0 > 1 && nodes[j0 - 1].endPos == nd.endPos) --j0;
+				if (firstPrev + nd.nPrev > j0) slow = true;
+			}
+			uint32_t incl = cnt;
+			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+			const uint64_t fb = __ballot(isFirst);
+			if (act) nodeRec[i] = (recTop + incl - cnt) | (slow ? 0x80000000u : 0u);
+			if (isFirst)
+			{
+				const uint32_t p = posTop + (uint32_t)__popcll(fb & ((2ull << lane) - 1));      // positions are numbered from 1
+				desc[p].firstNode = (uint16_t)i; desc[p].firstRec = recTop + incl - cnt;
+			}
+			recTop += __shfl(incl, 63);
+			posTop += (uint32_t)__popcll(fb);
+		}
+		if (recTop > recCap) return;      // (wave-uniform) the records do not fit the chunk's region: the general kernel takes the chunk
+		const uint32_t nPos = posTop;
+		if (lane == 0) { nodeRec[G - 1] = recTop; desc[nPos + 1].firstNode = (uint16_t)(G - 1); desc[nPos + 1].firstRec = recTop; }
+		waveSync();
+
+		// ---- B: extent of every position ----
+		for (uint32_t p = 1 + lane; p <= nPos; p += 64)
+		{
+			const uint32_t n0 = desc[p].firstNode, n1 = desc[p + 1].firstNode, r0 = desc[p].firstRec, r1 = desc[p + 1].firstRec;
+			bool slow = n1 - n0 > 16 || r1 - r0 > 16 || r1 == r0;
+			for (uint32_t j = n0; j < n1 && !slow; ++j) slow = (nodeRec[j] >> 31) != 0;
+			uint32_t formless = 0;      // bit j: node n0 + j has no dictionary form (the reference never sets its `reachable` flag itself, PathEvaluator.hpp:1300-1318)
+			for (uint32_t j = n0; j < n1 && j < n0 + 16; ++j) if (nodes[j].form == NOFORM) formless |= 1u << (j - n0);
+			desc[p].pad = (uint16_t)formless;
+			desc[p].nNodes = (uint8_t)(n1 - n0 > 255 ? 255 : n1 - n0); desc[p].flags = slow ? (uint8_t)POSF_SLOW : (uint8_t)0; desc[p].nRec = (uint16_t)(r1 - r0 > 0xFFFF ? 0xFFFF : r1 - r0);
+		}
+
+		// ---- C: the records ----
+		for (uint32_t i = 1 + lane; i + 1 < G; i += 64)
+		{
+			const DevNode nd = nodes[i];
+			uint32_t j0 = i;
+			while (j0 > 1 && nodes[j0 - 1].endPos == nd.endPos) --j0;
+			const uint32_t nl = i - j0;
+			if (nl >= 16) continue;      // (its position is marked slow)
+			PosRec* out = recs + (nodeRec[i] & 0x7FFFFFFFu);
+			float ws = 0;
+			if (!nd.uformLen && nd.form != NOFORM && nd.flen && nd.spaceErrors) ws = -P.spacePenalty * (float)nd.spaceErrors;
+			const float tc = nodeTypoAll ? nodeTypoAll[nBase + i] : 0.f;
+			const float baseDiscount = ws + (-tc * P.typoCostWeight);      // whitespaceDiscount + typoDiscount (PathEvaluator.hpp:366-371)
+			const bool spaceBefore = nd.nflags & NF_SPACE_BEFORE;
+			const uint8_t ownKind0 = nd.uformLen ? 1 : 0;
+			auto emit = [&](const CandStatic* cs, float disc, uint8_t ownKind, uint16_t ownFeat, uint32_t extra)
+			{
+				const uint4* q = reinterpret_cast<const uint4*>(cs);
+				const uint4 m0 = q[0], m1 = q[1], mx = q[2];
+				const uint8_t tag = (uint8_t)m1.z, special = (uint8_t)(m1.w >> 24);
+				const uint32_t sbType = mx.z;
+				const bool quote = special == 0 || special == 1 || special == 3 || special == 4;
+				const uint32_t R = ((sbType || quote) && nUniq > 1) ? nUniq : 1u;
+				PosRec r;
+				r.firstWid = mx.y; r.secondWid = mx.w; r.chunkOff = m0.z; r.lastSeqId = m0.y;
+				r.morph = mx.x; r.flagsFeat = m1.y; r.tagw = m1.z; r.cntw = m1.w;
+				r.additional = __uint_as_float(m0.w) + disc + leftBoundaryScore(((nd.nflags & NF_LEFT_BOUNDARY) ? T_MAX : 0) + clearIrregular(tag)) * 5.f;
+				const uint32_t ruleBits = ((isEClass(tag) && (nd.fflags & FF_STARTS_WITH_A)) ? 1u : 0u) | ((tag == T_SN && (nd.nflags & NF_UFORM_ENDS_POINT)) ? 2u : 0u);
+				r.nodeOwn = i | ((uint32_t)ownFeat << 16);
+				r.bits = (sbType & 0xFF) | (ruleBits << 8) | ((uint32_t)ownKind << 16) | ((uint32_t)nd.nflags << 24);
+				r.rq = R | (nl << 8) | extra;
+				*out++ = r;
+			};
+			// CoNgram: do the regular candidates of one evaluation share their first word?  (decides which of the reference's kernels rounds their scores)
+			auto sharedFirstWord = [&](const CandStatic* cl, uint32_t n) -> uint32_t
+			{
+				uint32_t nReg = 0, ref = 0; bool one = true;
+				for (uint32_t k = 0; k < n; ++k)
+				{
+					const uint4* q = reinterpret_cast<const uint4*>(cl + k);
+					const uint4 m1 = q[1], mx = q[2];
+					const uint32_t flags = m1.y & 0xFFFF; const uint8_t tag = (uint8_t)m1.z, sock = (uint8_t)(m1.z >> 24);
+					if (posCandKind(P, flags, tag, spaceBefore) != 1 || sock || (flags & MF_FIRST_WID_IS_P)) continue;
+					if (!nReg) ref = mx.y; else if (mx.y != ref) one = false;
+					++nReg;
+				}
+				return (nReg && one) ? (uint32_t)PR_OUT_FIRST : 0u;
+			};
+			if (nd.form != NOFORM)
+			{
+				const CandStatic* cl = packs + nd.packOff;
+				const uint32_t of0 = sharedFirstWord(cl, nd.candCnt);
+				for (uint32_t k = 0; k < nd.candCnt; ++k)
+				{
+					const uint4 m1 = reinterpret_cast<const uint4*>(cl + k)[1];
+					if (posCandKind(P, m1.y & 0xFFFF, (uint8_t)m1.z, spaceBefore) == 1) emit(cl + k, baseDiscount + 0.f, ownKind0, nd.ownFeat, of0);
+				}
+				if (nd.nflags & NF_ALL_PARTIAL)
+				{
+					// the form read as an unknown proper noun (PathEvaluator.hpp:1277-1287): own form = the dictionary form's string
+					const FormRec f = M.forms[nd.form];
+					uint16_t of = featMask(M.formChars + f.charOff, f.len) & 0x1FFF;
+					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
+					float disc;
+					if (useChr) disc = baseDiscount + (M.formUnkChr[nd.form] - P.oovChrBias);
+					else disc = baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias);
+					emit(unkPacks + 1, disc, 2, of, (uint32_t)PR_PASS1 | sharedFirstWord(unkPacks + 1, 1));
+				}
+			}
+			else
+			{
+				// unknown form: the two unknown-noun candidates (PathEvaluator.hpp:1204-1206, 1300-1318), scored by UnkFormScorer (src/UnkFormScorer.h:40-58)
+				const float emo = (cls[nd.uformOff] & 0x80) ? -10.f : 0.f;
+				float disc;
+				if (useChr) disc = baseDiscount + (W.unkChr[nBase + i] - P.oovChrBias);
+				else disc = baseDiscount + (emo - ((float)nd.uformLen * P.oovRuleScale + P.oovRuleBias));
+				const uint32_t of0 = sharedFirstWord(unkPacks, 2);
+				emit(unkPacks, disc, ownKind0, nd.ownFeat, of0);
+				emit(unkPacks + 1, disc, ownKind0, nd.ownFeat, of0);
+			}
+		}
+		waveSync();
+		if (lane == 0) desc[0].firstRec = nPos;
+	}
+
 	// Match::oovChrModel (UnkFormScorer::chrBasedScore, src/UnkFormScorer.cpp:53-66): the character model's score of every
 	// lattice node's unknown form, once per node and off the search kernel's dependent chain -- a formless node's own string, else the node's
 	// text span (what the search uses when the node left the lattice disconnected).  One block per chunk, one node per thread: the local

@@ -1631,6 +1631,8 @@ namespace sbgk
 		}
 	}
 
+#include "viterbi_pos.inc"
+
 #ifndef KAMD_VARIANT
 	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418); one thread per chunk
 	// `stride`: lanes between two active threads of a wave (64 = one chunk per wave): the stage is serial and branchy per chunk, so chunks that
@@ -1754,6 +1756,9 @@ namespace sbgk
 		const bool openEnding = B.chunkFlags[chunk] & 1;
 		uint8_t* reach = W.reach + nBase;
 		if (X.nUniq + 1 > SB_SLOT_MASK) { if (X.gl == 0) { res->status = CS_ERR_PATH_OVERFLOW; res->nPaths = 0; } return; }
+		// a chunk the position-step kernel (viterbi_pos.inc) worked on before: nodes [0, resume) are done -- their states, state ranges, live counts and
+		// reachable flags are in HBM -- and this kernel carries on at node `resume` (Gn - 1: only the end stage is left)
+		const uint32_t resume = res->pad & 0xFFFFFFu;      // (bits 24..31: why it was handed over, developer statistics)
 #ifdef KAMD_TIMELINE
 		unsigned long long* tl = W.beacon ? reinterpret_cast<unsigned long long*>(W.beacon) + 16ull * chunk : nullptr;
 		const unsigned long long tlClk0 = clock64();
@@ -1776,6 +1781,9 @@ namespace sbgk
 			for (uint32_t k = X.gl; k < 6; k += G) ldsStore4(X.lds + Lay<G>::PACKS + 16 * (3 * Lay<G>::PCAP + k), usrc[k]);
 			waveSync();
 		}
+		uint32_t cumLive = 1;    // live paths of nodes 0..i-1 (group-uniform)
+		if (!resume)
+		{
 		// start node (PathEvaluator.hpp:1224-1226)
 		if (X.gl == 0)
 		{
@@ -1787,12 +1795,36 @@ namespace sbgk
 		}
 		X.stTop = 1;
 		for (uint32_t k = X.gl; k < Gn; k += G) reach[k] = k == 0 ? 1 : 0;
+		}
+		else if (resume + 1 < Gn)
+		{
+			// the LDS ring of the last RING nodes, rebuilt from the HBM tables (running live totals from an arbitrary base: only differences inside the
+			// window are read, and a window that starts at node 0 starts at 0)
+			const uint32_t j0 = resume > RING ? resume - RING : 0u;
+			uint32_t cum = 0;
+			for (uint32_t j = j0; j < resume; ++j)
+			{
+				cum += X.nodeLive[j];
+				if (X.gl == 0) { const uint32_t o = X.nodeStOff[j]; X.ringBeg()[j & (RING - 1)] = o; X.ringEnd()[j & (RING - 1)] = o + X.nodeStCnt[j]; X.ringCum()[j & (RING - 1)] = cum; }
+			}
+			cumLive = cum;
+			if constexpr (Lay<G>::HCAP != 0)
+			{
+				// (one chunk per wave: the hot quads of the first HCAP states are read from their LDS copies)
+				const uint32_t nH = X.stTop < Lay<G>::HCAP ? X.stTop : Lay<G>::HCAP;
+				for (uint32_t k = X.gl; k < nH; k += G)
+				{
+					ldsStore4(X.lds + Lay<G>::HOT + 16 * k, *reinterpret_cast<const uint4*>(X.st + k));
+					ldsPtr<float>(X.lds + Lay<G>::HTYPO)[k] = X.st[k].accTypoCost;
+				}
+			}
+		}
+		if (resume) X.stTop = X.nodeStOff[resume - 1] + X.nodeStCnt[resume - 1];
 		waveSync();
 
 		const CandStatic* unkPacks = reinterpret_cast<const CandStatic*>(M.unkPacks);
 		const CandStatic* packs = W.packs + W.packBase[chunk];
-		uint32_t cumLive = 1;    // live paths of nodes 0..i-1 (group-uniform)
-		for (uint32_t i = 1; i + 1 < Gn; ++i)
+		for (uint32_t i = resume ? resume : 1u; i + 1 < Gn; ++i)
 		{
 			const DevNode node = getNode<G>(X, i);      // (prefetching it one node ahead cost 8 VGPRs and was slower at every batch size)
 			NodeEnv E;
@@ -2008,6 +2040,8 @@ namespace sbgk
 #if defined(KAMD_TYPO) && defined(KAMD_CONG)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev);
+	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
+	template __global__ void k_pos_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
 }
 }
 #elif defined(KAMD_TYPO) && defined(KAMD_SBG)
@@ -2022,10 +2056,14 @@ namespace sbgk
 #elif defined(KAMD_TYPO)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
+	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
+	template __global__ void k_pos_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
 }
 #elif defined(KAMD_CONG)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev);
+	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
+	template __global__ void k_pos_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
 }
 #else
 	template __global__ void k_best_path<4, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
@@ -2035,5 +2073,7 @@ namespace sbgk
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
+	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
+	template __global__ void k_pos_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
 #endif
 }

@@ -33,6 +33,7 @@ namespace kamd
 	struct SbgScratch { uint32_t hist[BIGQ_SBG][8]; uint32_t pos[BIGQ_SBG]; uint32_t hash[BIGQ_SBG]; uint32_t slot[BIGQ_SBG]; SbgSlot table[2 * BIGQ_SBG]; };
 
 	uint32_t searchKernelLdsBytes(int G);
+	constexpr uint32_t kPosKernelLdsBytes = 8192;      // dynamic LDS of k_pos_path (four lane groups: ring + staged new states)
 
 	// G = lanes per chunk (4, 8, 16, 32 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
 	// WPS = waves per SIMD the instantiation is compiled for (2, or 3 for G = 8 / 16).
@@ -72,6 +73,14 @@ namespace kamd
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, SbgDev S, const float* nodeTypo);
 	} }
+	// The position-step search (viterbi_pos.inc): the common case of the search above, one END POSITION of the lattice per step over the position
+	// program written by k_expand_pos; it leaves in DevChunkResult::pad the node k_best_path -- launched over all chunks afterwards -- carries on at
+	// (the end node: only the end stage is left).  G = 16 (one DPP row per chunk); every compilation of the search except the SkipBigram ones has it.
+	template<int G, int WPS>
+	__global__ void k_pos_path(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkOrder, uint32_t nWork);
+	namespace typok { template<int G, int WPS> __global__ void k_pos_path(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkOrder, uint32_t nWork, const float* nodeTypo); }
+	namespace congk { template<int G, int WPS> __global__ void k_pos_path(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkOrder, uint32_t nWork, CongDev CG); }
+	namespace typok { namespace congk { template<int G, int WPS> __global__ void k_pos_path(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkOrder, uint32_t nWork, const float* nodeTypo, CongDev CG); } }
 	// End stage, one THREAD per chunk: restated std::sort of the end candidates, per-(root, state) selection and the
 	// back-trace into 24-byte tokens.  A separate launch so that 64 chunks share a wavefront in this strictly serial stage.
 	__global__ void k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t stride);

@@ -3,6 +3,7 @@
 // host-side model baker and text preparation / result assembly code with the product (those are not the
 // hot path); the lattice construction and the best-path search are restated here independently of the
 // HIP kernels.  Output buffers use the same byte layout as oracle/ref_bridge.cpp so tests diff them directly.
+#include "timed_pool.hpp"
 #include <chrono>
 #include <cstdio>
 #include <memory>
@@ -273,6 +274,24 @@ extern "C"
 	}
 
 	// CPU baseline ("port" kind): batch over `threads` workers; returns wall seconds
+	// the batch timed soundly (timed_pool.hpp): persistent threads, one untimed warm-up pass, whole passes until >= minSeconds of wall
+	double korc_analyze_batch_timed(void* hp, void* typoHp, float typoThreshold, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, double minSeconds, uint32_t* passesOut, uint64_t* tokensOut)
+	{
+		auto& h = *(OracleHandle*)hp;
+		TypoOpt typo;
+		if (typoHp) { typo.prepared = ((TypoHandle*)typoHp)->prepared.get(); typo.threshold = typoThreshold; }
+		std::atomic<uint64_t> tokens{ 0 };
+		std::vector<Counters> cnts(std::max(threads, 1));
+		uint32_t passes = 0;
+		const double sec = timedpool::run(threads, n, minSeconds, &passes, [&](int tid, uint32_t i)
+		{
+			auto res = analyzeOne(h, cnts[tid], nullptr, (const char16_t*)texts + offsets[i], (uint32_t)(offsets[i + 1] - offsets[i]), topN, match, false, nullptr, typo);
+			tokens.fetch_add(res[0].first.size(), std::memory_order_relaxed);
+		});
+		if (passesOut) *passesOut = passes;
+		if (tokensOut) *tokensOut = tokens.load() / (passes + 1);
+		return sec;
+	}
 	double korc_analyze_batch_typo(void* hp, void* typoHp, float typoThreshold, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut);
 	double korc_analyze_batch(void* hp, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, uint64_t* tokensOut)
 	{

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <fstream>
 #include <thread>
+#include "timed_pool.hpp"
 #include <atomic>
 #include <numeric>
 
@@ -659,6 +660,25 @@ extern "C"
 		auto t1 = std::chrono::steady_clock::now();
 		if (tokensOut) *tokensOut = tokens.load();
 		return std::chrono::duration<double>(t1 - t0).count();
+	}
+
+	// The same batch, timed soundly (timed_pool.hpp): persistent threads, one untimed warm-up pass, whole passes until >= minSeconds of wall.
+	// Returns wall seconds of the timed passes; *passesOut = passes, *tokensOut = top-1 tokens of one pass.
+	double kref_analyze_batch_timed(void* hp, void* typoHp, float typoThreshold, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, double minSeconds, uint32_t* passesOut, uint64_t* tokensOut)
+	{
+		auto& kw = ((RefHandle*)hp)->kw;
+		std::atomic<uint64_t> tokens{ 0 };
+		kiwi::AnalyzeOption opt{ (kiwi::Match)match };
+		if (typoHp) { opt.typoTransformer = ((TypoHandle*)typoHp)->ptt.get(); opt.typoThreshold = typoThreshold; }
+		uint32_t passes = 0;
+		const double sec = timedpool::run(threads, n, minSeconds, &passes, [&](int, uint32_t i)
+		{
+			auto res = kw.analyze(std::u16string{ (const char16_t*)texts + offsets[i], (const char16_t*)texts + offsets[i + 1] }, topN, opt);
+			tokens.fetch_add(res[0].first.size(), std::memory_order_relaxed);
+		});
+		if (passesOut) *passesOut = passes;
+		if (tokensOut) *tokensOut = tokens.load() / (passes + 1);
+		return sec;
 	}
 
 	// ---- typo graphs: the reference's TypoTransformer / PreparedTypoTransformer, public API only --------

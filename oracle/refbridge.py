@@ -216,6 +216,20 @@ class RefKiwi:
         sec = self.lib.kref_analyze_batch_typo(self.h, typo.h if typo is not None else None, typo_threshold, flat.ctypes.data, offs.ctypes.data, len(enc), top_n, match, threads, C.byref(ntok))
         return float(sec), int(ntok.value)
 
+    def analyze_batch_timed(self, texts: list, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, threads=1, min_seconds=2.0, typo=None, typo_threshold=2.5):
+        """The batch timed soundly (timed_pool.hpp): persistent threads, one untimed warm-up pass, whole passes over `texts` until at least
+        `min_seconds` of wall time -> (seconds, passes, tokens of one pass)."""
+        enc = [np.frombuffer(t.encode("utf-16-le", errors="surrogatepass"), np.uint16) for t in texts]
+        offs = np.zeros(len(enc) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(e) for e in enc])
+        flat = np.concatenate(enc) if enc else np.zeros(0, np.uint16)
+        ntok = C.c_uint64(0); passes = C.c_uint32(0)
+        fn = self.lib.kref_analyze_batch_timed
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        sec = fn(self.h, typo.h if typo is not None else None, typo_threshold, flat.ctypes.data, offs.ctypes.data, len(enc), top_n, match, threads, min_seconds, C.byref(passes), C.byref(ntok))
+        return float(sec), int(passes.value), int(ntok.value)
+
 
 # ---- typo graphs (SURVEY.md section 8 row a4) ---------------------------------------------------------------------------
 COND = {"none": 0, "any": 1, "vowel": 2, "vocalic": 3, "vocalic_h": 4, "non_vowel": 5, "non_vocalic": 6, "non_vocalic_h": 7, "applosive": 8, "continual": 9, "boundary": 10}

@@ -846,10 +846,12 @@ namespace korc
 			if (totalPrev > 512) cnt.nodesOver512++;
 			const int mode = cfg.topN > 1 ? 3 : totalPrev <= cfg.smallMax ? 0 : totalPrev <= cfg.mediumMax ? 1 : 2;
 
+			int statIgnore = 0; uint32_t statZ = 0, statReg = 0, statR = 0; const size_t statBefore = nCache.size();
 			if (C.present()) evaluateCongNode(nCache, nodeIdx, ownFormId, cands, nCands, nodeLevelDiscount, mode);
 			else
 			for (int ignoreCond = 0; ignoreCond < 2; ++ignoreCond)
 			{
+				statIgnore = ignoreCond; statZ = statReg = statR = 0;
 				for (uint32_t ci = 0; ci < nCands; ++ci)
 				{
 					const uint32_t mid = cands[ci];
@@ -858,6 +860,7 @@ namespace korc
 					if (cm.tag == T_Z_CODA || cm.tag == T_Z_SIOT)
 					{
 						if (cm.tag == T_Z_SIOT && !(cfg.splitSaisiot || cfg.mergeSaisiot)) continue;
+						++statZ;
 						for (const LNode* prev = node->prev ? pfirst : nullptr; prev; prev = prev->sibling ? prev + prev->sibling : nullptr)
 						{
 							const auto& pc = cache[prev - graph];
@@ -876,10 +879,12 @@ namespace korc
 						continue;
 					}
 					if (!(cm.flags & MF_SINGLE) && (cm.flags & MF_HA_CONTRACTION) && node->prev && (node - node->prev)->endPos < node->startPos) continue;
+					{ ++statReg; const bool q_ = cm.special == 0 || cm.special == 1 || cm.special == 3 || cm.special == 4; statR += ((cm.tag == T_SB && M.sbInfo[mid]) || q_) ? (uint32_t)uniqStates.size() : 1u; }
 					evalSingle(mode, nCache, nodeIdx, ownFormId, mid, ignoreCond ? -10.f : 0.f, nodeLevelDiscount);
 				}
 				if (!nCache.empty()) break;
 			}
+			const size_t statMid = nCache.size();
 			// pruning threshold per root: the N-th best score (-inf while a root has fewer than N paths), PathEvaluator.hpp:475-503
 			const size_t N = cfg.topN;
 			std::vector<float> maxScores(1 + uniqStates.size(), -INFINITY);
@@ -906,7 +911,9 @@ namespace korc
 				valid++;
 			}
 			nCache.resize(valid);
+			if (statFile) fprintf(statFile, "E %u %u %u %zu %d %u %u %u %d %zu %zu %zu\n", statSent, nodeIdx, (unsigned)node->endPos, totalPrev, mode, statReg, statR, statZ, statIgnore, statBefore, statMid, valid);
 		}
+		FILE* statFile = getenv("KORC_STATS") ? fopen(getenv("KORC_STATS"), "a") : nullptr; uint32_t statSent = 0;
 
 		float unkScore(uint32_t len, bool emojiStart) const { return (emojiStart ? -10.f : 0.f) - (len * cfg.oovRuleScale + cfg.oovRuleBias); }
 		// UnkFormScorer::operator(): chrBasedScore (src/UnkFormScorer.cpp:53-66: one model step per UTF-16 unit, </s>, minus the bias) when the
@@ -1029,6 +1036,7 @@ namespace korc
 		void run(std::vector<PathResult>& ret, const U16& normText, const std::vector<uint8_t>& cls, const LNode* g, uint32_t gsize, const std::vector<uint8_t>& prevSpStates)
 		{
 			norm = &normText; graph = g; G = gsize;
+			{ static uint32_t sentCounter = 0; statSent = sentCounter++; }
 			cache.assign(G, {}); ownForms.clear();
 			std::vector<uint8_t> reach(G, 0);
 			uniqStates = prevSpStates;
@@ -1072,6 +1080,7 @@ namespace korc
 					reach[i] = any;
 					if (disconnected(reach, i + 1))
 					{
+						if (statFile) fprintf(statFile, "D %u %u\n", statSent, i);
 						ownForms.push_back({ 0, OwnForm{ node->startPos, node->endPos - node->startPos } });
 						ownFormId = (uint16_t)ownForms.size();
 						evaluate(i, ownFormId, unkCands, 2, unkScoreOf((const uint16_t*)norm->data() + node->startPos, node->endPos - node->startPos, emojiAt(node->startPos)));

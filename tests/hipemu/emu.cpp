@@ -174,8 +174,9 @@ namespace hipemu
 		// convergence width: the lane-group width of k_best_path<G, ...>, else the wavefront
 		uint32_t width = 64;
 		const std::string nm{ name };
-		const size_t at = nm.find("k_best_path<");
+		const size_t at = nm.find("k_best_path<"), atPos = nm.find("k_pos_path<");
 		if (at != std::string::npos) width = (uint32_t)std::atoi(nm.c_str() + at + 12);
+		else if (atPos != std::string::npos) width = (uint32_t)std::atoi(nm.c_str() + atPos + 11);
 		if (width == 0 || width > 64 || (width & (width - 1))) { std::fprintf(stderr, "hipemu: cannot read the lane-group width out of '%s'\n", name); std::abort(); }
 		Block blk; blk.n = block.x; blk.width = width; blk.body = &laneBody; blk.kernel = name;
 		if (const char* drop = std::getenv("HIPEMU_TEST_DROP_WAVE_BARRIER")) blk.dropBarrier = nm.find(drop) != std::string::npos;

@@ -123,6 +123,7 @@ inline void __syncthreads() { uint64_t a; uint32_t b; (void)hipemu::exchange(hip
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
