@@ -131,6 +131,8 @@ def measured_traffic(workload, kernel):
 def copy_bandwidth_gbs():
     """Measured device-to-device copy bandwidth (read + written bytes per second) of this GPU: what a purely streaming kernel achieves, beside the nominal peak."""
     import torch
+    if not torch.cuda.is_available():
+        return None
     n = 1 << 28
     a = torch.empty(n, dtype=torch.uint8, device="cuda"); b = torch.empty_like(a)
     for _ in range(2):

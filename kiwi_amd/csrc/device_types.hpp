@@ -50,10 +50,12 @@ namespace kamd
 	};
 	static_assert(sizeof(PosRec) == 48, "PosRec");
 	enum PosRecFlag : uint32_t { PR_PASS1 = 1u << 16,          // the all-partial form's extra unknown-noun reading (a second evaluation of the node)
-		PR_OUT_FIRST = 1u << 17 };                              // CoNgram: the evaluation's regular candidates share one first word (qgemm dispatch)
+		PR_OUT_FIRST = 1u << 17,
+		PR_Z = 1u << 18 };                                      // z-coda / z-siot shortcut: firstWid = the morpheme put on, secondWid = the shortcut's tag, chunkOff = path-side feat | prevFlags << 16 | socket << 24, additional = its score                              // CoNgram: the evaluation's regular candidates share one first word (qgemm dispatch)
 	// one END position: nodes [firstNode, firstNode + nNodes), records [firstRec, firstRec + nRec) of the chunk.  Entry 0 of a chunk's table is
-	// its header: firstRec = number of positions (0: the chunk is left to the general kernel).
-	struct alignas(16) PosDesc { uint16_t firstNode; uint8_t nNodes; uint8_t flags; uint32_t firstRec; uint16_t nRec; uint16_t pad; uint32_t pad2; };      // pad: bit j = node j of the position has no dictionary form
+	// its header: firstRec = number of positions (0: the chunk is left to the general kernel), nNodes != 0: no reachability propagation for this chunk,
+	// pad2 = the position the end node's predecessors end at.
+	struct alignas(16) PosDesc { uint16_t firstNode; uint8_t nNodes; uint8_t flags; uint32_t firstRec; uint16_t nRec; uint16_t pad; uint32_t pad2; };      // pad: bit j = node j of the position has no dictionary form; pad2 bit j: it has the extra unknown-noun reading (PR_PASS1 record)
 	static_assert(sizeof(PosDesc) == 16, "PosDesc");
 	enum PosFlag : uint8_t { POSF_SLOW = 1 };                     // something the position-step kernel does not do (z-coda / z-siot shortcut, > 16 records or nodes): hand over
 
@@ -176,8 +178,8 @@ namespace kamd
 		const uint32_t* blockBits;     // AnalyzeOption::blocklist as one bit per morpheme id (null: none): k_expand_cands drops those candidates
 		uint32_t outPathCap, outTokCap;
 		// position program (k_expand_pos -> k_pos_path): records at the chunk's packBase offset (same capacity as its candidate packs), position
-		// table and per-node predecessor ranges (first | last << 16) at its nodeBase offset; null = the position-step kernel is not used
-		PosRec* posRecs; PosDesc* posDesc; uint32_t* posPrev; uint32_t* posNodeRec;
+		// table, per-node predecessor ranges (first | (count - 1) << 16 | position of the predecessors << 24) and per-position start positions (four bytes) at its nodeBase offset; null = the position-step kernel is not used
+		PosRec* posRecs; PosDesc* posDesc; uint32_t* posPrev; uint32_t* posNodeRec; uint32_t* posMask;
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
 		uint32_t bigScratchBytes;      // per wave
 		uint32_t* beacon;              // developer aid (KAMD_TIMELINE builds): per-chunk timeline records, else null

@@ -893,7 +893,7 @@ namespace kamd
 					{
 						const uint4 m1 = reinterpret_cast<const uint4*>(packs + nd.packOff + k)[1];
 						const uint32_t kind = posCandKind(P, m1.y & 0xFFFF, (uint8_t)m1.z, spaceBefore);
-						if (kind == 1) ++cnt; else if (kind == 2) slow = true;
+						if (kind) ++cnt;      // a regular candidate, or the z-coda / z-siot shortcut (one item per incoming path)
 					}
 					if (!cnt) slow = true;      // nothing to evaluate: the reference then retries without conditions and falls back (PathEvaluator.hpp:468-473, 1286-1299)
 					if (nd.nflags & NF_ALL_PARTIAL) ++cnt;
@@ -901,7 +901,7 @@ namespace kamd
 				else cnt = 2;
 				isFirst = i == 1 || nodes[i - 1].endPos != nd.endPos;
 				const uint32_t firstPrev = i - nd.prev;
-				prev[i] = firstPrev | ((firstPrev + nd.nPrev - 1) << 16);
+				prev[i] = firstPrev;      // (completed in pass B': | (predecessor count - 1) << 16 | position of the predecessors << 24)
 				// the nodes of one step must not feed each other: true for spans of the text (a predecessor ends where the node starts, before its end);
 				// a lattice over a typo graph may hold nodes of equal text end that do -- such a position is left to the general kernel
 				uint32_t j0 = i;
@@ -911,31 +911,56 @@ namespace kamd
 			uint32_t incl = cnt;
 			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
 			const uint64_t fb = __ballot(isFirst);
-			if (act) nodeRec[i] = (recTop + incl - cnt) | (slow ? 0x80000000u : 0u);
-			if (isFirst)
-			{
-				const uint32_t p = posTop + (uint32_t)__popcll(fb & ((2ull << lane) - 1));      // positions are numbered from 1
-				desc[p].firstNode = (uint16_t)i; desc[p].firstRec = recTop + incl - cnt;
-			}
+			const uint32_t p = posTop + (uint32_t)__popcll(fb & ((2ull << lane) - 1));      // the node's position (numbered from 1; the start node is position 0)
+			// (record offset: 18 bits, position: 13 bits -- a chunk beyond either is left to the general kernel below)
+			if (act) nodeRec[i] = ((recTop + incl - cnt) & 0x3FFFFu) | ((p & 0x1FFFu) << 18) | (slow ? 0x80000000u : 0u);
+			if (isFirst) { desc[p].firstNode = (uint16_t)i; desc[p].firstRec = recTop + incl - cnt; }
 			recTop += __shfl(incl, 63);
 			posTop += (uint32_t)__popcll(fb);
 		}
-		if (recTop > recCap) return;      // (wave-uniform) the records do not fit the chunk's region: the general kernel takes the chunk
+		if (recTop > recCap || recTop >= 0x3FFFFu || posTop >= 0x1FFFu) return;      // (wave-uniform) the records do not fit the chunk's region / the packed fields: the general kernel takes the chunk
 		const uint32_t nPos = posTop;
-		if (lane == 0) { nodeRec[G - 1] = recTop; desc[nPos + 1].firstNode = (uint16_t)(G - 1); desc[nPos + 1].firstRec = recTop; }
+		if (lane == 0) { nodeRec[G - 1] = recTop; desc[nPos + 1].firstNode = (uint16_t)(G - 1); desc[nPos + 1].firstRec = recTop; nodeRec[0] = 0; }
 		waveSync();
+		// position of a node's predecessors (they all end where it starts): what the reachability propagation of the disconnected-lattice test runs over
+		auto startPosOf = [&](uint32_t node) -> uint32_t { const uint32_t fp = node - nodes[node].prev; return fp ? (nodeRec[fp] >> 18) & 0x1FFFu : 0u; };
 
 		// ---- B: extent of every position ----
 		for (uint32_t p = 1 + lane; p <= nPos; p += 64)
 		{
 			const uint32_t n0 = desc[p].firstNode, n1 = desc[p + 1].firstNode, r0 = desc[p].firstRec, r1 = desc[p + 1].firstRec;
 			bool slow = n1 - n0 > 16 || r1 - r0 > 16 || r1 == r0;
-			for (uint32_t j = n0; j < n1 && !slow; ++j) slow = (nodeRec[j] >> 31) != 0;
+			for (uint32_t j = n0; j < n1 && !slow; ++j) slow = (nodeRec[j] >> 31) != 0 || nodes[j].nPrev > 256;
+			// the distinct start positions of the position's nodes, four bytes (morphemes of a handful of lengths end at one place); more than four, or a
+			// chunk of more than 255 positions: no propagation for this chunk (header flag), the general kernel does its tests
+			uint32_t st4[4] = { 0, 0, 0, 0 }, nSt = 0; bool over = nPos > 255;
+			for (uint32_t j = n0; j < n1 && !over; ++j)
+			{
+				const uint32_t sp = startPosOf(j);
+				bool seen = false;
+				for (uint32_t t = 0; t < nSt; ++t) seen = seen || st4[t] == sp;
+				if (seen) continue;
+				if (nSt == 4) { over = true; break; }
+				st4[nSt++] = sp;
+			}
+			for (uint32_t t = nSt; t < 4; ++t) st4[t] = st4[0];
+			W.posMask[nBase + p] = over ? 0xFFFFFFFFu : (st4[0] | (st4[1] << 8) | (st4[2] << 16) | (st4[3] << 24));
+			if (over) desc[0].nNodes = 1;
 			uint32_t formless = 0;      // bit j: node n0 + j has no dictionary form (the reference never sets its `reachable` flag itself, PathEvaluator.hpp:1300-1318)
 			for (uint32_t j = n0; j < n1 && j < n0 + 16; ++j) if (nodes[j].form == NOFORM) formless |= 1u << (j - n0);
 			desc[p].pad = (uint16_t)formless;
+			uint32_t pass1 = 0;      // bit j: node n0 + j also gets the unknown proper-noun reading (a second evaluation with its own ignore-conditions retry)
+			for (uint32_t j = n0; j < n1 && j < n0 + 16; ++j) if (nodes[j].form != NOFORM && (nodes[j].nflags & NF_ALL_PARTIAL)) pass1 |= 1u << (j - n0);
+			desc[p].pad2 = pass1;
 			desc[p].nNodes = (uint8_t)(n1 - n0 > 255 ? 255 : n1 - n0); desc[p].flags = slow ? (uint8_t)POSF_SLOW : (uint8_t)0; desc[p].nRec = (uint16_t)(r1 - r0 > 0xFFFF ? 0xFFFF : r1 - r0);
 		}
+
+		for (uint32_t i = 1 + lane; i + 1 < G; i += 64)
+		{
+			const uint32_t sp = startPosOf(i), np1 = (uint32_t)nodes[i].nPrev - 1u;
+			prev[i] = (prev[i] & 0xFFFFu) | ((np1 > 255u ? 255u : np1) << 16) | ((sp > 255u ? 255u : sp) << 24);
+		}
+		if (lane == 0) desc[0].pad2 = startPosOf(G - 1);      // where the end node's predecessors end: reachable <=> the lattice is connected
 
 		// ---- C: the records ----
 		for (uint32_t i = 1 + lane; i + 1 < G; i += 64)
@@ -945,7 +970,7 @@ namespace kamd
 			while (j0 > 1 && nodes[j0 - 1].endPos == nd.endPos) --j0;
 			const uint32_t nl = i - j0;
 			if (nl >= 16) continue;      // (its position is marked slow)
-			PosRec* out = recs + (nodeRec[i] & 0x7FFFFFFFu);
+			PosRec* out = recs + (nodeRec[i] & 0x3FFFFu);
 			float ws = 0;
 			if (!nd.uformLen && nd.form != NOFORM && nd.flen && nd.spaceErrors) ws = -P.spacePenalty * (float)nd.spaceErrors;
 			const float tc = nodeTypoAll ? nodeTypoAll[nBase + i] : 0.f;
@@ -992,7 +1017,21 @@ namespace kamd
 				for (uint32_t k = 0; k < nd.candCnt; ++k)
 				{
 					const uint4 m1 = reinterpret_cast<const uint4*>(cl + k)[1];
-					if (posCandKind(P, m1.y & 0xFFFF, (uint8_t)m1.z, spaceBefore) == 1) emit(cl + k, baseDiscount + 0.f, ownKind0, nd.ownFeat, of0);
+					const uint32_t kind = posCandKind(P, m1.y & 0xFFFF, (uint8_t)m1.z, spaceBefore);
+					if (kind == 1) emit(cl + k, baseDiscount + 0.f, ownKind0, nd.ownFeat, of0);
+					else if (kind == 2)
+					{
+						// z-coda / z-siot shortcut (PathEvaluator.hpp:389-432): qualifying incoming paths are copied with the shortcut's morpheme put on; the
+						// record carries that morpheme (cm.lmId), the shortcut's tag and score, and what a path ending in the new morpheme exposes
+						const MorphRec cm = M.morphs[reinterpret_cast<const uint4*>(cl + k)[2].x];
+						const MorphRec nm = M.morphs[cm.lmId];
+						PosRec r;
+						r.firstWid = cm.lmId; r.secondWid = cm.tag; r.chunkOff = (uint32_t)nm.feat | ((uint32_t)nm.prevFlags << 16) | (nm.socket ? 1u << 24 : 0u); r.lastSeqId = 0;
+						r.morph = cm.lmId; r.flagsFeat = 0; r.tagw = 0; r.cntw = 0;
+						r.additional = cm.userScore;
+						r.nodeOwn = i; r.bits = (uint32_t)nd.nflags << 24; r.rq = 1u | (nl << 8) | (uint32_t)PR_Z;
+						*out++ = r;
+					}
 				}
 				if (nd.nflags & NF_ALL_PARTIAL)
 				{

@@ -1263,6 +1263,9 @@ namespace sbgk
 		// Nothing is moved: dead paths keep their slot (marked in LDS and HBM) and are skipped by every consumer.
 		TLMARK(X, 1)
 		const uint32_t cnt = X.stTop - E.nodeStart;
+#ifdef KAMD_POS_TRACE
+		if (X.gl == 0) fprintf(stderr, "  general node %u nodeStart %u cnt %u stageOverflow %d nP %u pBeg %u\n", E.nodeIdx, E.nodeStart, cnt, (int)X.stageOverflow, E.nP, E.pBeg);
+#endif
 		if (!cnt) return;
 		const bool staged = !X.stageOverflow;
 		const uint32_t nRootSlots = 1 + X.nUniq;
@@ -1820,6 +1823,9 @@ namespace sbgk
 			}
 		}
 		if (resume) X.stTop = X.nodeStOff[resume - 1] + X.nodeStCnt[resume - 1];
+#ifdef KAMD_POS_TRACE
+		if (X.gl == 0) fprintf(stderr, "general: chunk %u resume %u stTop %u Gn %u\n", chunk, resume, X.stTop, Gn);
+#endif
 		waveSync();
 
 		const CandStatic* unkPacks = reinterpret_cast<const CandStatic*>(M.unkPacks);

@@ -111,6 +111,23 @@ inline int hipemu_update_dpp(int old, int src, int ctrl, int rowMask, int bankMa
 	return hipemu::unpack<int>(v[from]);
 }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+// ds_permute_b32 (forward / "push" permute): every lane sends `data` to lane addr / 4 of its wavefront; a lane nobody writes to receives 0, of
+// several writers the highest lane wins
+inline int hipemu_ds_permute(int addr, int data)
+{
+	uint64_t active; uint32_t base;
+	const uint64_t* v = hipemu::exchange(hipemu::OP_SHFL, 0, ((uint64_t)(uint32_t)addr << 32) | (uint32_t)data, &active, &base);
+	const uint32_t self = threadIdx.x, wave = self & ~63u, w = hipemu::width();
+	int r = 0;
+	for (uint32_t i = 0; i < w; ++i)
+	{
+		if (!((active >> i) & 1)) continue;
+		const uint64_t pv = v[base + i];
+		if (wave + (((uint32_t)(pv >> 32) >> 2) & 63u) == self) r = (int)(uint32_t)pv;
+	}
+	return r;
+}
+#define __builtin_amdgcn_ds_permute(addr, data) hipemu_ds_permute((addr), (data))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 // HIPEMU_TEST_DROP_WAVE_BARRIER=<kernel name> turns the wave barrier of that kernel into nothing: the self-test of the race detector
 // (the ThreadSanitizer build must then report the races the barrier exists to prevent; tests/test_hipemu.py)
