@@ -57,6 +57,7 @@ namespace kamd
 	// pad2 = the position the end node's predecessors end at.
 	struct alignas(16) PosDesc { uint16_t firstNode; uint8_t nNodes; uint8_t flags; uint32_t firstRec; uint16_t nRec; uint16_t pad; uint32_t pad2; };      // pad: bit j = node j of the position has no dictionary form; pad2 bit j: it has the extra unknown-noun reading (PR_PASS1 record)
 	static_assert(sizeof(PosDesc) == 16, "PosDesc");
+	constexpr uint32_t kPosChunkDone = 0xFFFFFFu;      // DevChunkResult::pad of a chunk k_pos_path searched to the end
 	enum PosFlag : uint8_t { POSF_SLOW = 1 };                     // something the position-step kernel does not do (z-coda / z-siot shortcut, > 16 records or nodes): hand over
 
 	// search state, 48 B = three 16-byte quads (reference: WordLL<KnLMState> 48 B, src/BestPathContainer.hpp:21-67).
@@ -180,6 +181,7 @@ namespace kamd
 		// position program (k_expand_pos -> k_pos_path): records at the chunk's packBase offset (same capacity as its candidate packs), position
 		// table, per-node predecessor ranges (first | (count - 1) << 16 | position of the predecessors << 24) and per-position start positions (four bytes) at its nodeBase offset; null = the position-step kernel is not used
 		PosRec* posRecs; PosDesc* posDesc; uint32_t* posPrev; uint32_t* posNodeRec; uint32_t* posMask;
+		uint32_t* posHandOver;         // set by k_pos_path when it hands a chunk over (DevChunkResult::pad = the node to resume at, kPosChunkDone = nothing left): k_best_path returns at once while it is 0
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
 		uint32_t bigScratchBytes;      // per wave
 		uint32_t* beacon;              // developer aid (KAMD_TIMELINE builds): per-chunk timeline records, else null
@@ -233,6 +235,19 @@ namespace kamd
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	}
+	// The same separation of phases for data exchanged through LDS only: waits for the wave's LDS operations, not for its outstanding global loads /
+	// stores (a store's acknowledgement takes ~1 us; the position-step kernel exchanges everything a following step reads through LDS, and what it
+	// does re-read from HBM are earlier stores of the same wave, which its loads follow in order through the same L1)
+	__device__ inline __attribute__((always_inline)) void waveSyncLds()
+	{
+#if defined(__HIP_DEVICE_COMPILE__)
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
+#else
+		waveSync();
+#endif
 	}
 #endif
 }

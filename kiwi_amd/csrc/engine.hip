@@ -244,7 +244,15 @@ namespace kamd
 		bakeModel(impl->model, path);
 		if (lm == LmMode::Sbg && impl->model.sbgPtrs.empty()) throw std::runtime_error{ "Cannot open required files for skipbigram model" };   // KiwiBuilder.cpp:1008-1013
 		if (lm == LmMode::Cong && !impl->model.congDim) throw std::runtime_error{ "Cannot open ConG model file 'cong.mdl'" };      // KiwiBuilder.cpp:1018-1023
-		if (lm == LmMode::Knlm || lm == LmMode::Sbg) { impl->model.congDim = 0; }
+		// a model without a Knlm blob (the layout of models/cong/base: sj.morph + cong.mdl) cannot serve the Knlm / SkipBigram types: the reference
+		// fails to open sj.knlm there (KiwiBuilder.cpp:985-1001); searching with empty LM tables would read out of bounds
+		if ((lm == LmMode::Knlm || lm == LmMode::Sbg) && impl->model.lmNodes.empty()) throw std::runtime_error{ "Cannot open required file 'sj.knlm' for the requested model type" };
+		if (lm == LmMode::Knlm || lm == LmMode::Sbg)
+		{
+			impl->model.congDim = 0;
+			// ... and the character model is run quantised only next to a CoNgram model (the reference uses its fp32 scorer otherwise): not with these types
+			impl->model.chrDim = 0; impl->model.formUnkChr.clear();
+		}
 		if (impl->model.congDim) { impl->model.sbgPtrs.clear(); impl->model.sbgKeys.clear(); impl->model.sbgComps.clear(); impl->model.sbgDiscnts.clear(); impl->model.sbgValid.clear(); }
 		if (lm == LmMode::Knlm) { impl->model.sbgPtrs.clear(); impl->model.sbgKeys.clear(); impl->model.sbgComps.clear(); impl->model.sbgDiscnts.clear(); impl->model.sbgValid.clear(); }
 		if (!impl->model.sbgPtrs.empty() && impl->model.sbgWindow != 8)
@@ -301,6 +309,18 @@ namespace kamd
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
 		v.lmHtxNode = (m.congDim || m.lmHtxNode.empty()) ? nullptr : impl->up(m.lmHtxNode);      // history-transformed Knlm only
 		v.formUnkChr = nullptr;
+		v.lmChain = nullptr;
+		if (!m.congDim && !m.lmBackoff.empty())
+		{
+			std::vector<uint32_t> chain(2 * m.lmBackoff.size());
+			for (size_t n = 0; n < m.lmBackoff.size(); ++n)
+			{
+				const uint32_t l1 = n ? (uint32_t)((int64_t)n + m.lmBackoff[n].lower) : 0u;
+				const uint32_t l2 = l1 ? (uint32_t)((int64_t)l1 + m.lmBackoff[l1].lower) : 0u;
+				chain[2 * n] = l1; chain[2 * n + 1] = l2;
+			}
+			v.lmChain = impl->up(chain);
+		}
 		if (m.chrDim)
 		{
 			ChrView c = m.chrView();
@@ -476,6 +496,7 @@ namespace kamd
 		w.outTokCap = b.outTokCap; w.outPathCap = b.outPathCap;
 		w.posRecs = posPath ? b.dPosRecs.as<PosRec>() : nullptr; w.posDesc = posPath ? b.dPosDesc.as<PosDesc>() : nullptr;
 		w.posPrev = posPath ? b.dPosPrev.as<uint32_t>() : nullptr; w.posNodeRec = posPath ? b.dPosNodeRec.as<uint32_t>() : nullptr; w.posMask = posPath ? b.dPosMask.as<uint32_t>() : nullptr;
+		w.posHandOver = nullptr;
 		w.blockBits = nullptr;
 		w.unkChr = nullptr;
 		if ((b.match >> 8) & 3) { b.dUnkChr.ensure(totNodes * 4 + 16); w.unkChr = b.dUnkChr.as<float>(); }      // Match::oovChrModel (checked in stage())
@@ -614,6 +635,7 @@ namespace kamd
 #ifdef KAMD_TIMELINE
 	static void* gTimeline = nullptr;
 #endif
+	static DevBuf posBeacon;      // developer aid (KAMD_POS_DEBUG builds): progress beacons / phase timers of k_pos_path, 256 bytes per chunk (KAMD_POS_BEACON=1)
 	static KernelTimes launchAll(Engine::Impl& I, StagedBatch& b, const SearchParams& sp)
 	{
 		KernelTimes t;
@@ -746,6 +768,7 @@ namespace kamd
 			// consecutive searches may overlap at their tails: alternate between two scratch halves
 			WorkView wv = b.wv;
 			wv.beacon = nullptr;
+			wv.posHandOver = usePos ? I.counter.as<uint32_t>() + 48 + k : nullptr;      // (zeroed with the work counters above)
 #ifdef KAMD_TIMELINE
 			static DevBuf tlBuf;
 			tlBuf.ensure((size_t)nC * 128);
@@ -753,7 +776,6 @@ namespace kamd
 			wv.beacon = tlBuf.as<uint32_t>(); gTimeline = tlBuf.p;
 #endif
 #ifndef KAMD_TIMELINE
-			static DevBuf posBeacon;      // developer aid (KAMD_POS_DEBUG builds): progress beacons of k_pos_path, 256 bytes per chunk, printed by KAMD_HANGDUMP
 			if (getenv("KAMD_POS_BEACON"))
 			{
 				posBeacon.ensure((size_t)nC * 256);
@@ -767,7 +789,7 @@ namespace kamd
 			// lane-group width / register budget: with few chunks the step is bound by the dependent chain of one chunk (16-lane
 			// groups, 2 waves per SIMD measured best on 8192 x 40 jamo); with many chunks it is a throughput problem and narrower
 			// groups + a third wave per SIMD win (65536 x 40 jamo: 6.9 vs 9.3 ms).  KAMD_GROUP_LANES / KAMD_WPS override.
-			const bool many = cn >= 32768;
+			const bool many = cn >= 32768 && !usePos;      // (after the position-step kernel only a handful of chunks are left: what counts is one chunk's chain, not throughput)
 			const int gl = (I.hasSbg || b.typo.typo || I.hasCong) ? (variant64 ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
 			const int wps = b.typo.typo ? 2 : I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
@@ -775,10 +797,10 @@ namespace kamd
 			const uint32_t ldsK = searchKernelLdsBytes(gl);
 			if (usePos)
 			{
-				const bool wide = cn >= 16384 && !(I.wpsForced == 2);      // many chunks: four waves per SIMD (a 128-VGPR build); few: the latency-bound regime
+				const bool wide = cn >= 16384 && !(I.wpsForced == 2);      // many chunks: three waves per SIMD (what the kernel's LDS allows; a 168-VGPR build); few: the latency-bound regime
 				const uint32_t blocksP = (cn + 3) / 4;      // four chunks per one-wave block, no persistent loop (viterbi_pos.inc)
 				const float* nodeTypoP = b.typo.typo ? b.dNodeTypo.as<float>() : nullptr;
-#define KAMD_POS_LAUNCH(NS, ...) { if (wide) hipLaunchKernelGGL((NS k_pos_path<16, 4>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
+#define KAMD_POS_LAUNCH(NS, ...) { if (wide) hipLaunchKernelGGL((NS k_pos_path<16, 3>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
 				else hipLaunchKernelGGL((NS k_pos_path<16, 2>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); }
 				if (I.hasCong && b.typo.typo) KAMD_POS_LAUNCH(typok::congk::, nodeTypoP, I.cong)
 				else if (I.hasCong) KAMD_POS_LAUNCH(congk::, I.cong)
@@ -898,6 +920,19 @@ namespace kamd
 		HIPCHECK(hipGetLastError());
 		HIPCHECK(hipStreamSynchronize(sA));
 		HIPCHECK(hipStreamSynchronize(sB));
+		if (getenv("KAMD_POS_BEACON") && getenv("KAMD_POS_PHASES") && posBeacon.p)
+		{
+			// developer aid (KAMD_POS_DEBUG build): cycles per phase of a position step, averaged over the chunks' steps
+			std::vector<uint32_t> bc((size_t)nC * 64);
+			HIPCHECK(hipMemcpy(bc.data(), posBeacon.p, bc.size() * 4, hipMemcpyDeviceToHost));
+			double acc[14] = {}, steps = 0;
+			for (uint32_t c = 0; c < nC; ++c) { for (int k2 = 0; k2 < 14; ++k2) acc[k2] += bc[(size_t)c * 64 + 16 + k2]; steps += bc[(size_t)c * 64 + 31]; }
+			static const char* names[14] = { "loop/prefetch", "nodes+records", "round header+mapping", "record decode", "scoring after the LM step (rules, key)", "arg-max rotations", "emit", "end of rounds", "prune+counters", "retries+flags", "commit", "end stage", "wait for parent state + record", "LM step" };
+			double tot = 0; for (int k2 = 0; k2 < 14; ++k2) tot += acc[k2];
+			fprintf(stderr, "[pos phases] cycles per step (group-lane-0 clock; %0.f steps):", steps);
+			for (int k2 = 0; k2 < 14; ++k2) fprintf(stderr, " %s %.0f (%.0f%%);", names[k2], steps ? acc[k2] / steps : 0.0, tot ? 100.0 * acc[k2] / tot : 0.0);
+			fprintf(stderr, " total %.0f\n", steps ? tot / steps : 0.0);
+		}
 		if (b.wv.posRecs && getenv("KAMD_POS_STATS"))
 		{
 			// developer aid: how many chunks the position-step kernel handed over before the end node, how far into their lattices it got, and why
@@ -910,7 +945,7 @@ namespace kamd
 				const uint32_t at = res[c].pad & 0xFFFFFFu;
 				if (!at || !nn[c]) continue;
 				++seen;
-				if (at + 1 >= nn[c]) continue;
+				if (at == kPosChunkDone || at + 1 >= nn[c]) continue;
 				++early; frac += (double)at / nn[c]; atStart += at <= 1; ++why[(res[c].pad >> 24) & 15];
 			}
 			fprintf(stderr, "[pos] chunks %u (searched %u), handed over early %u (%.2f %%), of those from the start %u, mean hand-over point %.2f of the lattice; reasons: static %u, ring %u, container %u, record size %u, staging %u, retry %u, disconnected %u, no program %u\n",

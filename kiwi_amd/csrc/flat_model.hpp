@@ -147,6 +147,9 @@ namespace kamd
 		const int32_t* lmHtxNode;
 		// character model present: per form the score of its own string (what a dictionary node's unknown proper-noun reading costs under Match::oovChrModel)
 		const float* formUnkChr;
+		// device only (Knlm): per LM node the next two nodes of its back-off chain as absolute ids {node + lower, that node's lower node}; 0 = the root,
+		// where every chain ends.  A search state that carries this pair can probe all three contexts of its next transition at once (viterbi_pos.inc)
+		const uint32_t* lmChain;
 	};
 
 	// SkipBigram tables (reference src/SkipBigramModel.hpp:40-105), kept apart from ModelView: only the CPU restatement uses
@@ -383,6 +386,7 @@ namespace kamd
 			v.lmHash = lmHash.data(); v.lmHashMask = lmHashMask; v.lmRoot2 = lmRoot2.data(); v.lmBackoff = lmBackoff.data();
 			v.lmHtxNode = lmHtxNode.empty() ? nullptr : lmHtxNode.data();
 			v.formUnkChr = formUnkChr.empty() ? nullptr : formUnkChr.data();
+			v.lmChain = nullptr;
 			return v;
 		}
 

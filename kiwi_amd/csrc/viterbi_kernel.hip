@@ -287,9 +287,9 @@ namespace sbgk
 	}
 
 	// KnLangModel::progress (src/Knlm.cpp:44-130); float additions in the same order
-	__device__ INL3 float lmProgress(const ModelView& M, int32_t& node, uint32_t next)
+	__device__ INL3 float lmProgress(const ModelView& M, int32_t& node, uint32_t next, float acc0 = 0.f)
 	{
-		float acc = 0;
+		float acc = acc0;      // (back-off weights already collected by lmProgressChain, which hands a walk over half way; 0 otherwise)
 		// the unigram record of `next` does not depend on the walk: fetched together with the first bucket probe, because
 		// most walks (a context miss, then the root) would otherwise pay a second dependent round trip for it
 		const LmRootRec rootRec = M.lmRoot2[next];
@@ -323,6 +323,67 @@ namespace sbgk
 			return acc + ll;
 		}
 	}
+
+#ifndef KAMD_CONG
+	// KnLangModel::progress once more, for a state that carries the next two nodes of its back-off chain (ModelView::lmChain: n1, n2; 0 = root): the
+	// edge (node, next), the edge (n1, next), the unigram record and both back-off weights are requested TOGETHER, so the usual walk -- a miss in the
+	// context, then the shorter context, then the root -- costs one memory round trip instead of three.  What this cannot settle (a bucket that
+	// overflowed into its neighbour, a chain longer than three contexts, a leaf edge) goes on in lmProgress' own loop: same result, same additions in
+	// the same order.
+	__device__ INL3 float lmProgressChain(const ModelView& M, int32_t& node, uint32_t n1, uint32_t n2, uint32_t next)
+	{
+		const LmRootRec rootRec = M.lmRoot2[next];
+		const uint32_t n0 = (uint32_t)node;
+		float acc = 0, result = 0;
+		bool walk = n0 == 0;      // hand the rest to lmProgress' loop from `node` with `acc` (at the root the walk is the unigram record alone)
+		if (!walk)
+		{
+			const uint4* b0 = reinterpret_cast<const uint4*>(M.lmHash + (size_t)(lmHashOf(n0, next) & M.lmHashMask) * 4);
+			const uint4* b1 = reinterpret_cast<const uint4*>(M.lmHash + (size_t)(lmHashOf(n1, next) & M.lmHashMask) * 4);
+			const uint4 s0 = b0[0], s1 = b0[1], s2 = b0[2], s3 = b0[3];
+			const float g0 = M.lmBackoff[n0].gamma;
+			uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0, t3 = t0; float g1 = 0;
+			if (n1) { t0 = b1[0]; t1 = b1[1]; t2 = b1[2]; t3 = b1[3]; g1 = M.lmBackoff[n1].gamma; }
+			do
+			{
+				// context n0
+				{
+					const bool h0 = (s0.x == n0) & (s0.y == next), h1 = (s1.x == n0) & (s1.y == next), h2 = (s2.x == n0) & (s2.y == next), h3 = (s3.x == n0) & (s3.y == next);
+					if (h0 | h1 | h2 | h3)
+					{
+						const int32_t v = (int32_t)(h0 ? s0.z : h1 ? s1.z : h2 ? s2.z : s3.z);
+						if (v > 0) { node = (int32_t)n0 + v; result = acc + __uint_as_float(h0 ? s0.w : h1 ? s1.w : h2 ? s2.w : s3.w); }
+						else walk = true;      // (a leaf edge: the suffix search is the general walk's, which finds the edge again)
+						break;
+					}
+					if (s3.x != LM_SLOT_EMPTY) { walk = true; break; }      // (the bucket overflowed: the edge may sit in the next one)
+					acc += g0;
+				}
+				// context n1
+				if (n1)
+				{
+					const bool h0 = (t0.x == n1) & (t0.y == next), h1 = (t1.x == n1) & (t1.y == next), h2 = (t2.x == n1) & (t2.y == next), h3 = (t3.x == n1) & (t3.y == next);
+					if (h0 | h1 | h2 | h3)
+					{
+						const int32_t v = (int32_t)(h0 ? t0.z : h1 ? t1.z : h2 ? t2.z : t3.z);
+						if (v > 0) { node = (int32_t)n1 + v; result = acc + __uint_as_float(h0 ? t0.w : h1 ? t1.w : h2 ? t2.w : t3.w); }
+						else { node = (int32_t)n1; walk = true; }
+						break;
+					}
+					if (t3.x != LM_SLOT_EMPTY) { node = (int32_t)n1; walk = true; break; }
+					acc += g1;
+					if (n2) { node = (int32_t)n2; walk = true; break; }      // (a fourth context: carry on from it)
+				}
+				// the root
+				if (rootRec.value == 0) { node = M.lmHtxNode ? M.lmHtxNode[next] : 0; result = acc + M.h.unkLl; }
+				else if (rootRec.value > 0) { node = rootRec.value; result = acc + rootRec.ll; }
+				else { node = 0; walk = true; }      // (a leaf unigram: the general walk's last lines)
+			} while (0);
+		}
+		if (walk) result = lmProgress(M, node, next, acc);
+		return result;
+	}
+#endif
 
 #ifdef KAMD_CONG
 	__device__ __forceinline__ int32_t dot4s8(uint32_t a, uint32_t b, int32_t acc)
@@ -1762,6 +1823,7 @@ namespace sbgk
 		// a chunk the position-step kernel (viterbi_pos.inc) worked on before: nodes [0, resume) are done -- their states, state ranges, live counts and
 		// reachable flags are in HBM -- and this kernel carries on at node `resume` (Gn - 1: only the end stage is left)
 		const uint32_t resume = res->pad & 0xFFFFFFu;      // (bits 24..31: why it was handed over, developer statistics)
+		if (resume == kPosChunkDone) return;
 #ifdef KAMD_TIMELINE
 		unsigned long long* tl = W.beacon ? reinterpret_cast<unsigned long long*>(W.beacon) + 16ull * chunk : nullptr;
 		const unsigned long long tlClk0 = clock64();
@@ -2009,6 +2071,7 @@ namespace sbgk
 	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S) TYPO_ONLY(, const float* nodeTypoAll) CONG_ONLY(, CongDev CGv))
 	{
 		constexpr int NG = 64 / G;
+		if (W.posHandOver && *W.posHandOver == 0) return;      // the position-step kernel ran before and left nothing to do
 		const uint32_t lane = threadIdx.x;
 		// TagSequenceScorer tables (src/TagUtils.cpp:49-62): [0..T_MAX) without, [T_MAX..2*T_MAX) with a left boundary.
 		// Tag PA (== T_MAX) indexes one past a row in the reference (include/kiwi/TagUtils.h:10-18): row 0 spills into
@@ -2047,7 +2110,7 @@ namespace sbgk
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
-	template __global__ void k_pos_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
+	template __global__ void k_pos_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
 }
 }
 #elif defined(KAMD_TYPO) && defined(KAMD_SBG)
@@ -2063,13 +2126,13 @@ namespace sbgk
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
-	template __global__ void k_pos_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
+	template __global__ void k_pos_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
 }
 #elif defined(KAMD_CONG)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
-	template __global__ void k_pos_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
+	template __global__ void k_pos_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
 }
 #else
 	template __global__ void k_best_path<4, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
@@ -2080,6 +2143,6 @@ namespace sbgk
 	template __global__ void k_best_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_best_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
-	template __global__ void k_pos_path<16, 4>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
+	template __global__ void k_pos_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
 #endif
 }

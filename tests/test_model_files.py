@@ -229,3 +229,26 @@ def test_a_directory_with_the_builders_text_inputs_is_refused(small_model, tmp_p
     assert "REFUSED True" in out, out
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, KAMD_ALLOW_UNEXPANDED_MODEL="1")).stdout
     assert "LOADED" in out, out
+
+
+def test_knlm_model_type_is_refused_on_a_directory_without_sj_knlm(small_cong_model):
+    """kiwi_init(models/cong/base layout, KIWI_BUILD_MODEL_TYPE_KNLM): the reference cannot open sj.knlm there and fails; so does kiwi_init here --
+    NULL plus kiwi_error() -- instead of searching with empty LM tables."""
+    import ctypes as C
+    emu = os.path.join(HERE, "hipemu", "_build", "libkiwi_hipemu.so")
+    if not os.path.exists(emu):
+        pytest.skip("emulated library not built")
+    sm, path = small_cong_model
+    d = _cong_dir(path)
+    L = C.CDLL(emu)
+    L.kiwi_init.restype = C.c_void_p
+    L.kiwi_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+    L.kiwi_error.restype = C.c_char_p
+    L.kiwi_close.argtypes = [C.c_void_p]
+    for model_type in (0x0200, 0x0300):      # KIWI_BUILD_MODEL_TYPE_KNLM, _SBG
+        L.kiwi_clear_error()
+        assert not L.kiwi_init(d.encode(), 0, 15 | model_type, 0)
+        assert b"sj.knlm" in L.kiwi_error() or b"skipbigram" in L.kiwi_error().lower()
+    h = L.kiwi_init(d.encode(), 0, 15 | 0x0400, 0)      # KIWI_BUILD_MODEL_TYPE_CONG still opens
+    assert h
+    L.kiwi_close(h)

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 3, call f: position-step kernel with native z shortcut / second-reading retry / disconnected-lattice test, static prefetch, LDS node counters
-mkdir -p gpurun_out/r03_f; O=$PWD/gpurun_out/r03_f
+# round 3, call h: LDS ring of recent states, back-off chain probed at once, end stage in the kernel
+mkdir -p gpurun_out/r03_h; O=$PWD/gpurun_out/r03_h
 KAMD_LIB=$PWD/kiwi_amd/libkiwi_hip_posdebug.so KAMD_HANGDUMP=1 KAMD_POS_BEACON=1 KAMD_POS_STATS=1 timeout 120 python tools/quick_gpu.py 300 > $O/debug_small.txt 2>&1; echo "rc $?" >> $O/debug_small.txt
 tail -4 $O/debug_small.txt
 KAMD_POS_STATS=1 KAMD_HANGDUMP=1 timeout 120 python tools/pos_check.py c2 4000 > $O/check_c2.txt 2>&1; echo "rc $?" >> $O/check_c2.txt
