@@ -183,7 +183,7 @@ namespace kamd
 		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder, dBlockBits, dUnkChr;
 		TypoLatView tv{};
 		DevBuf dPacks, dStates, dNodeStOff, dNodeStCnt, dReach, dTokens, dResults, dOrder;
-		DevBuf dPosRecs, dPosDesc, dPosPrev, dPosNodeRec, dPosMask;   // position program of k_pos_path (k_expand_pos)
+		DevBuf dPosRecs, dPosDesc, dPosPrev, dPosNodeRec, dPosMask, dPosBig;   // position program of k_pos_path (k_expand_pos)
 		DevBuf dOutPaths, dOutTokens, dOutCounters; uint32_t outPathCap = 0, outTokCap = 0;   // compact outputs of the end stage
 		PinBuf hOut, hOut2;       // D2H landing zones: counters + chunk results; then the path headers and token records that were produced
 		uint64_t outBytes = 0;    // bytes the last download copied
@@ -468,7 +468,7 @@ namespace kamd
 		if (posPath)
 		{
 			b.dPosRecs.ensure((size_t)b.packBase[nC] * sizeof(PosRec) + 16); b.dPosDesc.ensure(totNodes * sizeof(PosDesc) + 16);
-			b.dPosPrev.ensure(totNodes * 4 + 16); b.dPosNodeRec.ensure(totNodes * 4 + 16); b.dPosMask.ensure(totNodes * 4 + 16);
+			b.dPosPrev.ensure(totNodes * 4 + 16); b.dPosNodeRec.ensure(totNodes * 4 + 16); b.dPosMask.ensure(totNodes * 4 + 16); b.dPosBig.ensure(((nC + 3) / 4 * 4) * (size_t)64 * 20 + 16);
 		}
 		if (I.hasSbg) b.dHist.ensure(totStates * 32 + 32);
 		// compact outputs of the end stage: as many token records as the arenas could hold, 16 path headers per chunk (x capacity scale)
@@ -476,7 +476,7 @@ namespace kamd
 		b.dOutTokens.ensure((size_t)b.outTokCap * sizeof(DevToken) + 16); b.dOutPaths.ensure((size_t)b.outPathCap * sizeof(DevPathHeader) + 16); b.dOutCounters.ensure(64);
 		b.devBytes = 0;
 		for (const DevBuf* d : { &b.dIn, &b.dOutTokens, &b.dOutPaths, &b.dNsToPos, &b.dPosToNs, &b.dCflag, &b.dMask, &b.dMoff, &b.dMatchForm, &b.dNodes, &b.dTmpNodes, &b.dEndPosMap, &b.dTmpIdx,
-			&b.dPacks, &b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults, &b.dPosRecs, &b.dPosDesc, &b.dPosPrev, &b.dPosNodeRec, &b.dPosMask }) b.devBytes += d->cap;
+			&b.dPacks, &b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults, &b.dPosRecs, &b.dPosDesc, &b.dPosPrev, &b.dPosNodeRec, &b.dPosMask, &b.dPosBig }) b.devBytes += d->cap;
 
 		BatchView& bv = b.bv;
 		bv.nChunks = (uint32_t)nC; bv.chars = (const uint16_t*)(D + oChars); bv.cls = D + oCls; bv.script = D + oScript;
@@ -495,7 +495,7 @@ namespace kamd
 		w.outTokens = b.dOutTokens.as<DevToken>(); w.outPaths = b.dOutPaths.as<DevPathHeader>(); w.outCounters = b.dOutCounters.as<uint32_t>();
 		w.outTokCap = b.outTokCap; w.outPathCap = b.outPathCap;
 		w.posRecs = posPath ? b.dPosRecs.as<PosRec>() : nullptr; w.posDesc = posPath ? b.dPosDesc.as<PosDesc>() : nullptr;
-		w.posPrev = posPath ? b.dPosPrev.as<uint32_t>() : nullptr; w.posNodeRec = posPath ? b.dPosNodeRec.as<uint32_t>() : nullptr; w.posMask = posPath ? b.dPosMask.as<uint32_t>() : nullptr;
+		w.posPrev = posPath ? b.dPosPrev.as<uint32_t>() : nullptr; w.posNodeRec = posPath ? b.dPosNodeRec.as<uint32_t>() : nullptr; w.posMask = posPath ? b.dPosMask.as<uint32_t>() : nullptr; w.posBig = posPath ? b.dPosBig.as<uint8_t>() : nullptr;
 		w.posHandOver = nullptr;
 		w.blockBits = nullptr;
 		w.unkChr = nullptr;

@@ -67,6 +67,7 @@ namespace hipemu
 			Domain groupDom[MAXT];      // convergence domains of the kernel's width, by first lane / width (no allocation inside fibers)
 			Domain blockDom;            // __syncthreads
 			uint64_t vals[2][MAXT];
+			uint64_t valsBlock[2][MAXT];      // payloads of block-wide rendezvous: a kernel may interleave them with group-wide ones, whose generations are independent
 			uint64_t progress = 0;
 			const std::function<void()>* body = nullptr;
 			ucontext_t sched; int cur = -1;
@@ -151,7 +152,7 @@ namespace hipemu
 		}
 		const uint64_t g = d.gen;
 		TSAN_ONLY(__tsan_release(&d);)
-		B->vals[g & 1][self] = mine;
+		(domain == 0 ? B->vals : B->valsBlock)[g & 1][self] = mine;
 		++d.arrived; ++B->progress;
 		l.waiting = true; l.waitOp = op; l.waitBase = base; l.waitSize = size; l.waitGen = g;
 		for (;;)
@@ -164,7 +165,7 @@ namespace hipemu
 		l.waiting = false;
 		TSAN_ONLY(__tsan_acquire(&d);)
 		*active = d.active[g & 1]; *domainBase = base;
-		return B->vals[g & 1];
+		return (domain == 0 ? B->vals : B->valsBlock)[g & 1];
 	}
 
 	void launch(const char* name, dim3 grid, dim3 block, size_t ldsBytes, const std::function<void()>& laneBody)

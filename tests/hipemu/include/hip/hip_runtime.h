@@ -19,6 +19,7 @@
 // timing is NOT detected, except that lanes really do run far apart between rendezvous points, so a missing barrier shows.
 #pragma once
 #define __HIPCC__ 1
+#define KAMD_HIPEMU 1      // (kernels that need a whole-wavefront operation beside their lane-group convergence width ask for hipemu_ballot64 / hipemu_shfl64)
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
@@ -128,6 +129,24 @@ inline int hipemu_ds_permute(int addr, int data)
 	return r;
 }
 #define __builtin_amdgcn_ds_permute(addr, data) hipemu_ds_permute((addr), (data))
+// whole-wavefront ballot / shuffle for kernels whose convergence width is a lane GROUP but which also have phases all 64 lanes run together
+// (k_pos_path: items of four chunks packed into one wavefront): a rendezvous of the block (one wavefront per block in those kernels)
+inline unsigned long long hipemu_ballot64(int pred)
+{
+	uint64_t active; uint32_t base;
+	const uint64_t* v = hipemu::exchange(hipemu::OP_BALLOT, blockDim.x, pred ? 1 : 0, &active, &base);
+	unsigned long long r = 0;
+	for (uint32_t i = 0; i < blockDim.x && i < 64; ++i) if (((active >> i) & 1) && v[base + i]) r |= 1ull << i;
+	return r;
+}
+template<class T> inline T hipemu_shfl64(T var, int srcLane)
+{
+	uint64_t active; uint32_t base;
+	const uint64_t* v = hipemu::exchange(hipemu::OP_SHFL, blockDim.x, hipemu::pack(var), &active, &base);
+	const uint32_t src = (uint32_t)srcLane & 63u;
+	if (src >= blockDim.x || !((active >> src) & 1)) return var;
+	return hipemu::unpack<T>(v[base + src]);
+}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 // HIPEMU_TEST_DROP_WAVE_BARRIER=<kernel name> turns the wave barrier of that kernel into nothing: the self-test of the race detector
 // (the ThreadSanitizer build must then report the races the barrier exists to prevent; tests/test_hipemu.py)

@@ -67,3 +67,39 @@ def test_c4_cong_4k_sentences_bit_exact_vs_oracle_and_reference():
     if refbridge.x86_available():
         _check(dev, refbridge.RefKiwi(path, arch=3, x86=True), c4[:4096])
     dev.close()
+
+
+def test_c2_64k_sample_bit_exact_vs_oracle_and_reference(full):
+    """The default bench workload (c2-64k: 65 536 x 40 jamo, the >= 64k-sentence regime of the north-star target): 4096 of its sentences analysed IN a
+    batch of 16 384 (so that the launch takes the many-chunk configuration of the position-step kernel), device vs oracle and real reference."""
+    from kiwi_amd.workloads import get_workload
+    dev, orc, ref, _, _ = full
+    _, c64, _ = get_workload("c2-64k")
+    batch = c64[:16384]
+    got = dev.analyze_batch(batch).to_python()
+    assert len(got) == len(batch)
+    sample = list(range(0, 16384, 4))
+    bad = [batch[i] for i in sample if _norm(orc.analyze(batch[i])) != _norm(got[i])]
+    assert not bad, (len(bad), bad[:3])
+    if ref is not None:
+        bad = [batch[i] for i in sample[:1024] if _norm(ref.analyze(batch[i])) != _norm(got[i])]
+        assert not bad, (len(bad), bad[:3])
+
+
+def test_position_step_and_general_kernel_agree_and_both_run(full, monkeypatch):
+    """The search runs as the position-step kernel (k_pos_path) with the general kernel (k_best_path) behind it; KAMD_POS_PATH=0 leaves the general
+    kernel alone.  Same analyses, same fp32 scores, from both -- on the benchmark corpus and on the mixed-length one -- and equal to the oracle."""
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+    dev, orc, _, c2, c3 = full
+    path, _, _ = get_workload("c2")
+    monkeypatch.setenv("KAMD_POS_PATH", "0")
+    gen = KiwiAmd(path)
+    monkeypatch.delenv("KAMD_POS_PATH")
+    texts = c2[:2048] + c3[:2048]
+    a = dev.analyze_batch(texts).to_python()
+    b = gen.analyze_batch(texts).to_python()
+    gen.close()
+    assert [_norm(x) for x in a] == [_norm(x) for x in b]
+    bad = [s for s, y in zip(texts[::8], a[::8]) if _norm(orc.analyze(s)) != _norm(y)]
+    assert not bad, (len(bad), bad[:3])
