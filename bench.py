@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--workload", default=None, help="default: c2-64k on one GPU (the >= 64k-sentence regime the north-star target is quoted on; c2 is measured beside it as config.also), "
                                                       "c4-cong on several (131 072 sentences per GPU = BASELINE config 4's 1M sentences at 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernels-only", action="store_true", help="profiler passes: only the warm-up and the timed region of the named workload (no CPU baseline, no side measurement, "
+                    "no C-API client, no end-to-end pass), so that per-kernel counters and statistics belong to this workload alone")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every rank analyses a batch of the workload's size; strong: ONE corpus split over the ranks by index (text i -> rank i %% N)")
     ap.add_argument("--limit", type=int, default=0, help="diagnostics: only the first N sentences of the workload (named in config.workload)")
@@ -288,13 +290,13 @@ def main():
     res.close()
     batch.close()      # (the end-to-end pass below stages its own batch: a large workload does not fit the device twice)
     also = None
-    if args.workload == "c2-64k" and world == 1 and not args.limit:
+    if args.workload == "c2-64k" and world == 1 and not args.limit and not args.kernels_only:
         also = side_measurement(eng, "c2")      # BASELINE configs[1] at its own batch size (8192 sentences: the latency-bound regime)
 
     # End to end: UTF-16 strings resident on the host -> kamd_analyze_batch (host text preparation, H2D, kernels,
     # D2H, result assembly) -> packed token records resident on the host.  Timed through the C ABI on an already packed buffer.
     e2e = None
-    if True:
+    if not args.kernels_only:
         tkw = {} if typo is None else {"typo": typo, "typo_threshold": typo_cfg[2]}
         from kiwi_amd.api import pack_texts
         flat, offs = pack_texts(shard)
@@ -331,7 +333,7 @@ def main():
                        "model": model_facts(args.workload),
                        "kernel_ms": kt, "device_bytes": info["device_bytes"], "rerun_chunks": rerun_chunks, "rerun_ms": rerun_ms},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not args.kernels_only:
             cb = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg, time_reference=world == 1)
             per = cb["alg_bytes_per_sentence"]
             search_bytes = per["search"] * n
@@ -348,7 +350,7 @@ def main():
                 also["roofline_frac"] = per["search"] * also["sentences"] / (also["kernel_ms"]["search_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS      # (same sentence shape: same algorithmic bytes per sentence)
         if also is not None:
             out["config"]["also"] = also
-        if world == 1 and typo is None and not args.limit:
+        if world == 1 and typo is None and not args.limit and not args.kernels_only:
             cr = capi_rate(model_path, args.workload, top_n)
             if cr is not None:
                 out["capi"] = cr

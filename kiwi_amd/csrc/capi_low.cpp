@@ -209,6 +209,12 @@ extern "C"
 				if (pad8(oForms + 2 * nForms) > sizes[p]) throw std::runtime_error{ "kamd_res_merge_strided: truncated part" };
 				w.textAna = reinterpret_cast<const uint32_t*>(b + oTextAna); w.anaTok = reinterpret_cast<const uint32_t*>(b + oAnaTok); w.score = reinterpret_cast<const float*>(b + oScore);
 				w.tok = reinterpret_cast<const FlatToken*>(b + oTok); w.forms = reinterpret_cast<const char16_t*>(b + oForms);
+				// the index tables come from another rank's buffer: every offset is checked before it is followed
+				bool ok = w.textAna[0] == 0 && w.textAna[w.nTexts] == w.nAna && w.anaTok[0] == 0 && w.anaTok[w.nAna] == nTok;
+				for (uint32_t i = 0; ok && i < w.nTexts; ++i) ok = w.textAna[i] <= w.textAna[i + 1];
+				for (uint32_t i = 0; ok && i < w.nAna; ++i) ok = w.anaTok[i] <= w.anaTok[i + 1];
+				for (uint64_t i = 0; ok && i < nTok; ++i) ok = w.tok[i].formOff <= nForms && (uint64_t)w.tok[i].formLen + 1 <= nForms - w.tok[i].formOff;
+				if (!ok) throw std::runtime_error{ "kamd_res_merge_strided: corrupt part (index tables out of range)" };
 				total += w.nTexts;
 			}
 			for (uint32_t p = 0; p < n_parts; ++p) if (v[p].nTexts != (total + n_parts - 1 - p) / n_parts) throw std::runtime_error{ "kamd_res_merge_strided: parts are not an index-strided split" };

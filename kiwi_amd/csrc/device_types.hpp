@@ -182,6 +182,7 @@ namespace kamd
 		// table, per-node predecessor ranges (first | (count - 1) << 16 | position of the predecessors << 24) and per-position start positions (four bytes) at its nodeBase offset; null = the position-step kernel is not used
 		PosRec* posRecs; PosDesc* posDesc; uint32_t* posPrev; uint32_t* posNodeRec; uint32_t* posMask;
 		uint8_t* posBig;               // k_pos_path: staging of the items of a record with more than 16 of them, 64 x 20 bytes per lane group (4 per block)
+		uint8_t* posScratch; uint32_t* posContCounter; uint32_t posContSlots;      // k_pos_path carrying a chunk on in the general search itself: item scratch slots (GroupScratch each), slots taken, number of slots
 		uint32_t* posHandOver;         // set by k_pos_path when it hands a chunk over (DevChunkResult::pad = the node to resume at, kPosChunkDone = nothing left): k_best_path returns at once while it is 0
 		uint8_t* bigScratch;           // fallback scratch for nodes with > 128 incoming (path, root) pairs
 		uint32_t bigScratchBytes;      // per wave

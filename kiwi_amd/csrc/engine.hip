@@ -214,7 +214,8 @@ namespace kamd
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
-		DevBuf bigScratch, counter;
+		DevBuf bigScratch, counter, posScratch;
+		uint32_t posContSlots = 64;      // chunks per launch that k_pos_path carries on in the general search itself (KAMD_POS_CONT=0: none, all left to k_best_path)
 		ChrView chr{};      // character model of Match::oovChrModel on the device (absent: dim 0)
 		CongDev cong{}; bool hasCong = false;   // CoNgram model: the context trie is uploaded where the Knlm tables would be (ModelView::lmHash / lmRoot2 / lmBackoff)
 		SbgDev sbg{}; bool hasSbg = false; DevBuf sbgScratch;   // SkipBigram tables on the device + per-lane-group item scratch of its search kernel
@@ -348,6 +349,7 @@ namespace kamd
 		}
 		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2 or 3" }; }
 		if (const char* pp = std::getenv("KAMD_POS_PATH")) impl->posPath = std::atoi(pp) != 0;
+		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
 		impl->counter.ensure(256);
 	}
@@ -361,7 +363,7 @@ namespace kamd
 			for (auto& e : impl->evs) if (e) (void)hipEventDestroy(e);
 			// the engine's own blocks go back to the cache first, then the cache is emptied: nothing stays allocated after the last engine
 			impl->modelBufs.clear();
-			impl->bigScratch.release(); impl->counter.release(); impl->sbgScratch.release();
+			impl->bigScratch.release(); impl->posScratch.release(); impl->counter.release(); impl->sbgScratch.release();
 			devCache().trim();
 			if (impl->stream) (void)hipStreamDestroy(impl->stream);
 			if (impl->stream2) (void)hipStreamDestroy(impl->stream2);
@@ -496,7 +498,7 @@ namespace kamd
 		w.outTokCap = b.outTokCap; w.outPathCap = b.outPathCap;
 		w.posRecs = posPath ? b.dPosRecs.as<PosRec>() : nullptr; w.posDesc = posPath ? b.dPosDesc.as<PosDesc>() : nullptr;
 		w.posPrev = posPath ? b.dPosPrev.as<uint32_t>() : nullptr; w.posNodeRec = posPath ? b.dPosNodeRec.as<uint32_t>() : nullptr; w.posMask = posPath ? b.dPosMask.as<uint32_t>() : nullptr; w.posBig = posPath ? b.dPosBig.as<uint8_t>() : nullptr;
-		w.posHandOver = nullptr;
+		w.posHandOver = nullptr; w.posScratch = nullptr; w.posContCounter = nullptr; w.posContSlots = 0;
 		w.blockBits = nullptr;
 		w.unkChr = nullptr;
 		if ((b.match >> 8) & 3) { b.dUnkChr.ensure(totNodes * 4 + 16); w.unkChr = b.dUnkChr.as<float>(); }      // Match::oovChrModel (checked in stage())
@@ -769,6 +771,11 @@ namespace kamd
 			WorkView wv = b.wv;
 			wv.beacon = nullptr;
 			wv.posHandOver = usePos ? I.counter.as<uint32_t>() + 48 + k : nullptr;      // (zeroed with the work counters above)
+			if (usePos && I.posContSlots)
+			{
+				I.posScratch.ensure((size_t)I.posContSlots * groupScratchBytes);
+				wv.posScratch = I.posScratch.as<uint8_t>(); wv.posContCounter = I.counter.as<uint32_t>() + 56 + (k & 7); wv.posContSlots = I.posContSlots;
+			}
 #ifdef KAMD_TIMELINE
 			static DevBuf tlBuf;
 			tlBuf.ensure((size_t)nC * 128);
@@ -939,17 +946,18 @@ namespace kamd
 			std::vector<DevChunkResult> res(nC); std::vector<uint32_t> nn(nC);
 			HIPCHECK(hipMemcpy(res.data(), b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost));
 			HIPCHECK(hipMemcpy(nn.data(), b.dNNodes.p, nC * 4, hipMemcpyDeviceToHost));
-			double frac = 0; uint32_t early = 0, atStart = 0, seen = 0, why[16] = {};
+			double frac = 0; uint32_t early = 0, carried = 0, atStart = 0, seen = 0, why[16] = {};
 			for (uint32_t c = 0; c < nC; ++c)
 			{
 				const uint32_t at = res[c].pad & 0xFFFFFFu;
 				if (!at || !nn[c]) continue;
 				++seen;
+				if (at == kPosChunkDone && (res[c].pad >> 24)) { ++carried; ++why[(res[c].pad >> 24) & 15]; continue; }
 				if (at == kPosChunkDone || at + 1 >= nn[c]) continue;
 				++early; frac += (double)at / nn[c]; atStart += at <= 1; ++why[(res[c].pad >> 24) & 15];
 			}
-			fprintf(stderr, "[pos] chunks %u (searched %u), handed over early %u (%.2f %%), of those from the start %u, mean hand-over point %.2f of the lattice; reasons: static %u, ring %u, container %u, record size %u, staging %u, retry %u, disconnected %u, no program %u\n",
-				nC, seen, early, seen ? 100.0 * early / seen : 0.0, atStart, early ? frac / early : 0.0, why[1], why[2], why[3], why[4], why[5], why[6], why[7], why[8]);
+			fprintf(stderr, "[pos] chunks %u (searched %u), carried on in the general search by the kernel itself %u, left to k_best_path %u (%.2f %%), of those from the start %u, mean hand-over point %.2f of the lattice; reasons: static %u, ring %u, container %u, record size %u, staging %u, retry %u, disconnected %u, no program %u\n",
+				nC, seen, carried, early, seen ? 100.0 * early / seen : 0.0, atStart, early ? frac / early : 0.0, why[1], why[2], why[3], why[4], why[5], why[6], why[7], why[8]);
 		}
 #ifdef KAMD_TIMELINE
 		if (getenv("KAMD_TIMELINE_PRINT") && gTimeline)

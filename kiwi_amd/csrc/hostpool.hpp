@@ -5,6 +5,8 @@
 // an 8k-sentence batch (fresh malloc arenas and first-touch page faults on every call).
 #pragma once
 #include <atomic>
+#include <cstdlib>
+#include <unistd.h>
 #include <condition_variable>
 #include <exception>
 #include <functional>
@@ -25,6 +27,7 @@ namespace kamd
 		uint64_t generation = 0;
 		int wanted = 0, running = 0;
 		bool stopping = false;
+		const pid_t owner = ::getpid();
 		std::exception_ptr error;
 		std::atomic<bool> failed{ false };
 
@@ -68,6 +71,7 @@ namespace kamd
 		}
 		~HostPool()
 		{
+			if (::getpid() != owner) { for (auto& t : threads) t.detach(); return; }      // (a forked child: the workers never existed here)
 			{ std::lock_guard<std::mutex> g{ mu }; stopping = true; }
 			cvWork.notify_all();
 			for (auto& t : threads) t.join();
@@ -83,7 +87,7 @@ namespace kamd
 			const size_t blocks = (n + block - 1) / block;
 			int helpers = (int)std::min<size_t>(threads.size(), blocks - 1);
 			if (maxThreads > 0) helpers = std::min(helpers, maxThreads - 1);
-			if (helpers <= 0) { fn(0, n, 0); return; }
+			if (helpers <= 0 || ::getpid() != owner) { fn(0, n, 0); return; }
 			std::lock_guard<std::mutex> serial{ runMu };
 			{
 				std::lock_guard<std::mutex> g{ mu };
@@ -98,11 +102,18 @@ namespace kamd
 			if (error) { auto e = error; error = nullptr; std::rethrow_exception(e); }
 		}
 
-		// the process-wide pool: hardware threads, at most 64 (beyond that the per-text stages of a batch are bound by memory, not cores)
+		// the process-wide pool: one thread per hardware thread (KAMD_HOST_THREADS overrides; the batch stages take their own `maxThreads` on top).
+		// A child process after fork() has none of the parent's threads: it runs its stages on the calling thread alone.
 		static HostPool& instance()
 		{
-			static HostPool pool{ (int)std::min(63u, std::max(1u, std::thread::hardware_concurrency()) - 1u) };
+			static HostPool pool{ defaultThreads() - 1 };
 			return pool;
+		}
+		static int defaultThreads()
+		{
+			unsigned n = std::max(1u, std::thread::hardware_concurrency());
+			if (const char* e = std::getenv("KAMD_HOST_THREADS")) { const long v = std::atol(e); if (v > 0) n = (unsigned)v; }
+			return (int)std::min(1024u, n);
 		}
 	};
 }

@@ -1695,8 +1695,6 @@ namespace sbgk
 		}
 	}
 
-#include "viterbi_pos.inc"
-
 #ifndef KAMD_VARIANT
 	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418); one thread per chunk
 	// `stride`: lanes between two active threads of a wave (64 = one chunk per wave): the stage is serial and branchy per chunk, so chunks that
@@ -1800,7 +1798,7 @@ namespace sbgk
 #endif
 
 	template<int G>
-	__device__ INL3 void searchChunk(GroupCtx<G>& X, const BatchView& B, const WorkView& W, uint32_t chunk)
+	__device__ INL3 void searchChunk(GroupCtx<G>& X, const BatchView& B, const WorkView& W, uint32_t chunk, uint32_t resumeAt = 0xFFFFFFFFu)
 	{
 		const ModelView& M = X.M;
 		const SearchParams& P = X.P;
@@ -1822,7 +1820,8 @@ namespace sbgk
 		if (X.nUniq + 1 > SB_SLOT_MASK) { if (X.gl == 0) { res->status = CS_ERR_PATH_OVERFLOW; res->nPaths = 0; } return; }
 		// a chunk the position-step kernel (viterbi_pos.inc) worked on before: nodes [0, resume) are done -- their states, state ranges, live counts and
 		// reachable flags are in HBM -- and this kernel carries on at node `resume` (Gn - 1: only the end stage is left)
-		const uint32_t resume = res->pad & 0xFFFFFFu;      // (bits 24..31: why it was handed over, developer statistics)
+		// (resumeAt: k_pos_path carrying on by itself; otherwise the node is in DevChunkResult::pad, bits 24..31 = why it was handed over, developer statistics)
+		const uint32_t resume = resumeAt != 0xFFFFFFFFu ? resumeAt : (res->pad & 0xFFFFFFu);
 		if (resume == kPosChunkDone) return;
 #ifdef KAMD_TIMELINE
 		unsigned long long* tl = W.beacon ? reinterpret_cast<unsigned long long*>(W.beacon) + 16ull * chunk : nullptr;
@@ -2064,6 +2063,8 @@ namespace sbgk
 #endif
 		TLMARK(X, 6)
 	}
+
+#include "viterbi_pos.inc"
 
 	// WPS = waves per SIMD the kernel is compiled for (register budget 512 / WPS): 2 is fastest when a batch is small enough
 	// to be latency-bound (c2: 8192 chunks), 3 (with a few spills) when there are chunks to fill the extra wave slots
