@@ -25,7 +25,7 @@
 namespace kamd
 {
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
-	__global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
+	template<int GW> __global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
 	__global__ void k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr);
@@ -210,6 +210,7 @@ namespace kamd
 		int subBatches = 0;   // 0 = automatic
 		int device = 0;
 		uint32_t persistBlocks = 0;
+		int latticeGroupForced = 0;      // KAMD_LATTICE_GROUP=16 / 64: lanes per chunk of k_build_lattice
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
@@ -350,6 +351,7 @@ namespace kamd
 		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2 or 3" }; }
 		if (const char* pp = std::getenv("KAMD_POS_PATH")) impl->posPath = std::atoi(pp) != 0;
 		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
+		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
 		impl->counter.ensure(256);
 	}
@@ -750,7 +752,13 @@ namespace kamd
 					uint32_t j = i + 1;
 					while (j < c1 && (uint64_t)needOf(b.order[j]) * 4 >= (uint64_t)need * 3) ++j;      // <= 25 % of a class's LDS unused
 					static const uint32_t dbgStop = std::getenv("KAMD_LATTICE_STOP") ? (uint32_t)std::atoi(std::getenv("KAMD_LATTICE_STOP")) : 0u;      // EXPERIMENT
-					hipLaunchKernelGGL(k_build_lattice, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24));
+					// one chunk per wavefront.  KAMD_LATTICE_GROUP=16 (EXPERIMENT) packs four: measured slower on the MI355X -- c2-64k 3.04 ms against
+					// 1.96 ms, c2 0.57 against 0.42 ms (profiles/r03_o_*): the four replays diverge, and a block with four working sets leaves a
+					// quarter of the wavefronts to hide their LDS chains
+					const uint32_t need16 = (need + 15u) & ~15u;
+					const bool four = I.latticeGroupForced == 16 && need16 * 4 <= 64 * 1024;
+					if (four) hipLaunchKernelGGL(k_build_lattice<16>, dim3((j - i + 3) / 4), dim3(64), need16 * 4, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need16 | (dbgStop << 24));
+					else hipLaunchKernelGGL(k_build_lattice<64>, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24));
 					i = j;
 				}
 				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget);
@@ -804,7 +812,7 @@ namespace kamd
 			const uint32_t ldsK = searchKernelLdsBytes(gl);
 			if (usePos)
 			{
-				const bool wide = cn >= 16384 && !(I.wpsForced == 2);      // many chunks: three waves per SIMD (what the kernel's LDS allows; a 168-VGPR build); few: the latency-bound regime
+				const bool wide = I.wpsForced ? I.wpsForced == 3 : cn >= 16384;      // many chunks: three waves per SIMD (what the kernel's LDS allows; a 168-VGPR build); few: the latency-bound regime (KAMD_WPS overrides)
 				const uint32_t blocksP = (cn + 3) / 4;      // four chunks per one-wave block, no persistent loop (viterbi_pos.inc)
 				const float* nodeTypoP = b.typo.typo ? b.dNodeTypo.as<float>() : nullptr;
 #define KAMD_POS_LAUNCH(NS, ...) { if (wide) hipLaunchKernelGGL((NS k_pos_path<16, 3>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \

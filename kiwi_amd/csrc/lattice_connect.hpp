@@ -6,7 +6,7 @@
 
 namespace kamd
 {
-	// All 64 lanes call it.  `out`: the build-order node list (fields startPos, sibling; node 0 = start node, node G - 1 = end node, which is on no
+	// All W lanes of the chunk's lane group call it (W = 64: one chunk per wavefront; 16: four).  `out`: the build-order node list (fields startPos, sibling; node 0 = start node, node G - 1 = end node, which is on no
 	// chain); endPosMap[p] = first | (last + 1) << 16 of the nodes ending at position p (0 .. nPos - 1), whose sibling links chain exactly those nodes in
 	// index order.  Returns the number of connected nodes; inv[i] = new index (0xFFFF: dropped); endPosMap[p] := connected nodes ending at p.
 	// Instead of a backward BFS with a queue and range scans (the ids between the first and the last node ending at a position include every node
@@ -15,11 +15,11 @@ namespace kamd
 	//   ends, and every edge leads to a strictly smaller position;  3. one position per lane: connected nodes on its chain, wave scan over the positions
 	//   (the first new index of a position is parked in inv[first node of its chain]);  4. one position per lane: new indices.
 	// flagBits: nPos bits of scratch (an array of the build that is no longer needed).
-	template<class NodeT>
+	template<int W = 64, class NodeT>
 	__device__ __forceinline__ uint32_t latticeConnectWave(NodeT* out, uint32_t* endPosMap, uint16_t* inv, uint16_t* conn, uint32_t* flagBits, uint32_t G, uint32_t nPos, uint32_t lane)
 	{
-		for (uint32_t i = lane; i < G; i += 64) conn[i] = 0;
-		for (uint32_t w = lane; w < (nPos + 31) / 32; w += 64) flagBits[w] = 0;
+		for (uint32_t i = lane; i < G; i += W) conn[i] = 0;
+		for (uint32_t w = lane; w < (nPos + 31) / 32; w += W) flagBits[w] = 0;
 		waveSync();
 		if (lane == 0)
 		{
@@ -41,7 +41,7 @@ namespace kamd
 		}
 		waveSync();
 		uint32_t total = 0;
-		for (uint32_t base = 0; base < nPos; base += 64)
+		for (uint32_t base = 0; base < nPos; base += W)
 		{
 			const uint32_t e = base + lane;
 			uint32_t c = 0, first = 0xFFFFFFFFu;
@@ -61,12 +61,12 @@ namespace kamd
 				}
 			}
 			uint32_t incl = c;
-			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+			for (uint32_t d = 1; d < W; d <<= 1) { const uint32_t v = __shfl_up(incl, d, W); if (lane >= d) incl += v; }
 			if (first != 0xFFFFFFFFu) inv[first] = (uint16_t)(total + incl - c);      // first new index of the nodes ending at e
-			total += __shfl(incl, 63);
+			total += __shfl(incl, W - 1, W);
 		}
 		waveSync();
-		for (uint32_t base = 0; base < nPos; base += 64)
+		for (uint32_t base = 0; base < nPos; base += W)
 		{
 			const uint32_t e = base + lane;
 			if (e >= nPos) continue;

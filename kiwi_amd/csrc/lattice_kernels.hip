@@ -599,46 +599,53 @@ namespace kamd
 	// dynamic LDS of the wave-per-chunk variant
 	extern __shared__ __align__(16) uint8_t lSmem[];
 
-	// One WAVE per chunk.  The build itself is sequential (lane 0), but every access of it is an LDS access instead of a
-	// dependent HBM round trip: the chunk's text, index maps, packed matches (+ their form records) are staged into LDS by
-	// all lanes first, the node list grows in LDS, and the final reorder / per-node fact computation runs one node per lane.
+	// One lane group of GW lanes per chunk (64: one chunk per wavefront; 16: four).  The build itself is sequential (the group's lane 0), but every
+	// access of it is an LDS access instead of a dependent HBM round trip: the chunk's text, index maps, packed matches (+ their form records) are
+	// staged into LDS by all lanes first, the node list grows in LDS, and the final reorder / per-node fact computation runs one node per lane.
 	// Chunks whose working set exceeds ldsBytes are left to k_build_lattice_big.
+	// GW = 16 (EXPERIMENT, KAMD_LATTICE_GROUP=16): the replay is branchy one-lane code -- 14 k scalar and 6 k vector instructions per 40-jamo chunk --
+	// and four chunks replayed by lanes 0 / 16 / 32 / 48 of one wavefront would share that wherever their control flow agrees.  Measured on the
+	// MI355X it is 1.5x SLOWER than one chunk per wavefront (engine.hip has the numbers): the replays rarely agree.  ldsBytes = ONE group's region.
+	template<int GW>
 	__global__ void __launch_bounds__(64) k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
 	{
-		if (blockIdx.x >= chunkCount) return;
-		const uint32_t lane = threadIdx.x;
-		const uint32_t chunk = chunkList[blockIdx.x];      // one launch per LDS size class: a slice of the longest-first work order
+		constexpr uint32_t NG = 64 / GW;
+		const uint32_t lane = threadIdx.x % GW, grp = threadIdx.x / GW;
+		const uint32_t wi = blockIdx.x * NG + grp;
+		const uint32_t dbgStop = ldsBytes >> 24; ldsBytes &= 0xFFFFFFu;      // EXPERIMENT (KAMD_LATTICE_STOP): leave after phase 1 / 2 / 3, results void
+		if (wi >= chunkCount) return;
+		const uint32_t chunk = chunkList[wi];      // one launch per LDS size class: a slice of the longest-first work order
+		uint8_t* const lS = lSmem + grp * ldsBytes;      // this group's region
 		if (W.results[chunk].status >= 16) return;
 		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
 		const uint32_t nNs = W.nNs[chunk];
 		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
 		const uint32_t mBase = W.matchBase[chunk], mCap = W.matchBase[chunk + 1] - mBase;
-		const uint32_t dbgStop = ldsBytes >> 24; ldsBytes &= 0xFFFFFFu;      // EXPERIMENT (KAMD_LATTICE_STOP): leave after phase 1 / 2 / 3, results void
 		const LatticeLds lay = latticeLdsLayout(n, cap, mCap);
 		if (lay.total > ldsBytes) return;                      // k_build_lattice_big takes it
 		const uint32_t nMap = nNs + 1;
 		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { if (lane == 0) W.results[chunk].status = CS_ERR_TOO_LONG; return; }
 
-		uint16_t* str = reinterpret_cast<uint16_t*>(lSmem + lay.str);
-		uint8_t* cls = lSmem + lay.cls; uint8_t* script = lSmem + lay.script; uint8_t* cflag = lSmem + lay.cflag;
-		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(lSmem + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(lSmem + lay.posToNs);
-		uint64_t* mask = reinterpret_cast<uint64_t*>(lSmem + lay.mask); uint32_t* moff = reinterpret_cast<uint32_t*>(lSmem + lay.moff);
-		uint32_t* mforms = reinterpret_cast<uint32_t*>(lSmem + lay.mforms); uint2* mfrec = reinterpret_cast<uint2*>(lSmem + lay.mfrec);
+		uint16_t* str = reinterpret_cast<uint16_t*>(lS + lay.str);
+		uint8_t* cls = lS + lay.cls; uint8_t* script = lS + lay.script; uint8_t* cflag = lS + lay.cflag;
+		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(lS + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(lS + lay.posToNs);
+		uint64_t* mask = reinterpret_cast<uint64_t*>(lS + lay.mask); uint32_t* moff = reinterpret_cast<uint32_t*>(lS + lay.moff);
+		uint32_t* mforms = reinterpret_cast<uint32_t*>(lS + lay.mforms); uint2* mfrec = reinterpret_cast<uint2*>(lS + lay.mfrec);
 		// ---- stage the chunk into LDS (all lanes, coalesced) ----
 		{
 			const uint16_t* gstr = B.chars + cOff; const uint8_t* gcls = B.cls + cOff; const uint8_t* gscript = B.script + cOff; const uint8_t* gcflag = W.cflag + cOff;
 			const uint16_t* gn2p = W.nsToPos + cOff + chunk; const uint16_t* gp2n = W.posToNs + cOff + chunk;
 			const uint64_t* gmask = W.matchMask + cOff + chunk; const uint32_t* gmoff = W.matchOff + cOff + chunk;
-			for (uint32_t i = lane; i < n; i += 64) { str[i] = gstr[i]; cls[i] = gcls[i]; script[i] = gscript[i]; cflag[i] = gcflag[i]; }
-			for (uint32_t i = lane; i <= n; i += 64) { posToNs[i] = gp2n[i]; if (i < nNs) nsToPos[i] = gn2p[i]; }
-			for (uint32_t i = lane; i <= nNs; i += 64) { mask[i] = gmask[i]; moff[i] = gmoff[i]; }
+			for (uint32_t i = lane; i < n; i += GW) { str[i] = gstr[i]; cls[i] = gcls[i]; script[i] = gscript[i]; cflag[i] = gcflag[i]; }
+			for (uint32_t i = lane; i <= n; i += GW) { posToNs[i] = gp2n[i]; if (i < nNs) nsToPos[i] = gn2p[i]; }
+			for (uint32_t i = lane; i <= nNs; i += GW) { mask[i] = gmask[i]; moff[i] = gmoff[i]; }
 			const uint32_t mTot = gmoff[nNs] + __popcll(gmask[nNs]);
 			const uint32_t* gforms = W.matchForm + mBase;
-			if (mTot > latticeLdsCap(n, mCap)) { if (lane == 0) W.nNodes[chunk] = kLatticeNeedsBig; return; }    // wave-uniform
+			if (mTot > latticeLdsCap(n, mCap)) { if (lane == 0) W.nNodes[chunk] = kLatticeNeedsBig; return; }    // group-uniform
 			waveSync();
 			// one packed match per lane: everything the replay needs of it that does not depend on the lattice built so far -- start position,
 			// space errors of the span (countSpaceErrors, KTrie.cpp:316-328), form flags -- so that the serial loop reads one 8-byte record
-			for (uint32_t k = lane; k < mTot; k += 64)
+			for (uint32_t k = lane; k < mTot; k += GW)
 			{
 				const uint32_t fi = gforms[k]; const FormRec f = M.forms[fi];
 				mforms[k] = fi;
@@ -668,13 +675,13 @@ namespace kamd
 		}
 		LatticeCtxT<BuildNode16> L;
 		L.M = &M; L.P = &P; L.str = str; L.nsToPos = nsToPos; L.posToNs = posToNs;
-		L.spaceErr = lSmem + lay.spaceErr;
-		L.out = reinterpret_cast<BuildNode16*>(lSmem + lay.out); L.endPosMap = reinterpret_cast<uint32_t*>(lSmem + lay.endPosMap);
-		L.fullMask = reinterpret_cast<uint64_t*>(lSmem + lay.fullMask); L.zAt = lSmem + lay.zAt; L.nOut = 0; L.cap = latticeLdsCap(n, cap); L.overflow = false;
+		L.spaceErr = lS + lay.spaceErr;
+		L.out = reinterpret_cast<BuildNode16*>(lS + lay.out); L.endPosMap = reinterpret_cast<uint32_t*>(lS + lay.endPosMap);
+		L.fullMask = reinterpret_cast<uint64_t*>(lS + lay.fullMask); L.zAt = lS + lay.zAt; L.nOut = 0; L.cap = latticeLdsCap(n, cap); L.overflow = false;
 		const uint32_t ldsCap = L.cap;
-		for (uint32_t i = lane; i < nMap; i += 64) { L.endPosMap[i] = 0; L.fullMask[i] = 0; L.zAt[i] = 0; }    // first == second : empty
+		for (uint32_t i = lane; i < nMap; i += GW) { L.endPosMap[i] = 0; L.fullMask[i] = 0; L.zAt[i] = 0; }    // first == second : empty
 		waveSync();
-		LatticeMem Q{ str, cls, script, cflag, mask, moff, mforms, mfrec, reinterpret_cast<uint16_t*>(lSmem + lay.queue), reinterpret_cast<uint16_t*>(lSmem + lay.queue) + ldsCap };
+		LatticeMem Q{ str, cls, script, cflag, mask, moff, mforms, mfrec, reinterpret_cast<uint16_t*>(lS + lay.queue), reinterpret_cast<uint16_t*>(lS + lay.queue) + ldsCap };
 		uint32_t nConn = 0, G = 0, err = 0;
 		if (dbgStop == 1) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
 		if (lane == 0)
@@ -687,10 +694,10 @@ namespace kamd
 			else G = L.nOut;
 		}
 		waveSync();
-		err = __shfl(err, 0); G = __shfl(G, 0);
+		err = __shfl(err, 0, GW); G = __shfl(G, 0, GW);
 		if (err) { if (lane == 0) { if (err == 0xFFFFu) W.nNodes[chunk] = kLatticeNeedsBig; else W.results[chunk].status = err; } return; }
 		if (dbgStop == 2) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
-		nConn = latticeConnectWave(L.out, L.endPosMap, Q.queue, Q.connOrd, reinterpret_cast<uint32_t*>(L.fullMask), G, nNs + 1, lane);
+		nConn = latticeConnectWave<GW>(L.out, L.endPosMap, Q.queue, Q.connOrd, reinterpret_cast<uint32_t*>(L.fullMask), G, nNs + 1, lane);
 		if (dbgStop == 3) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
 
 		// ---- final records, one node per lane; candidate-record offsets by a wave scan over the new order ----
@@ -699,7 +706,7 @@ namespace kamd
 		uint16_t* cc = Q.connOrd;                       // candidate count per NEW index (the connected flags are no longer needed)
 		const uint32_t textOff = B.textOffset[chunk];
 		waveSync();
-		for (uint32_t base = 0; base < G; base += 64)
+		for (uint32_t base = 0; base < G; base += GW)
 		{
 			const uint32_t idx = base + lane;
 			uint32_t cnt = 0xFFFFFFFFu;
@@ -708,14 +715,14 @@ namespace kamd
 		}
 		waveSync();
 		uint32_t packTop = 0;
-		for (uint32_t base = 0; base < nConn; base += 64)
+		for (uint32_t base = 0; base < nConn; base += GW)
 		{
 			const uint32_t i = base + lane;
 			const uint32_t c = i < nConn ? (uint32_t)cc[i] : 0u;
 			uint32_t incl = c;
-			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+			for (uint32_t d = 1; d < GW; d <<= 1) { const uint32_t v = __shfl_up(incl, d, GW); if (lane >= d) incl += v; }
 			if (i < nConn) fin[i].packOff = packTop + incl - c;
-			packTop += __shfl(incl, 63);
+			packTop += __shfl(incl, GW - 1, GW);
 		}
 		if (lane == 0)
 		{
@@ -724,6 +731,9 @@ namespace kamd
 			else { W.nNodes[chunk] = nConn; if (nConn <= 2) W.results[chunk].status = CS_NO_LATTICE; }
 		}
 	}
+
+	template __global__ void k_build_lattice<64>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, uint32_t);
+	template __global__ void k_build_lattice<16>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, uint32_t);
 
 	// One THREAD per chunk, all working arrays in HBM: for chunks whose working set does not fit the LDS budget of k_build_lattice.
 	__global__ void __launch_bounds__(64) k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes)

@@ -637,6 +637,9 @@ namespace sbgk
 	__device__ __forceinline__ void putState(GroupCtx<G>& X, uint32_t i, int32_t lmNode, float acc, float typo, uint32_t wid, uint16_t leftFeat, uint8_t rootId, uint8_t sp,
 		uint8_t socket, uint8_t prevFlags, uint8_t ownKind, uint32_t parent, uint32_t morph, float fcs, uint16_t nodeId, uint16_t ownNode STATE_EXTRA(, uint32_t histPos = 0))
 	{
+#ifdef KAMD_POS_TRACE
+		fprintf(stderr, "gput pos %u node %u parent %u score %.9g typo %g morph %u lm %d\n", i, (unsigned)nodeId, parent, (double)acc, (double)typo, morph, lmNode);
+#endif
 		storeState(X.st, i, lmNode, acc, typo, wid, leftFeat, rootId, sp, socket, prevFlags, ownKind, parent, morph, fcs, nodeId, ownNode STATE_EXTRA(, histPos));
 		if constexpr (Lay<G>::HCAP != 0)
 		{

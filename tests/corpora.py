@@ -103,3 +103,12 @@ def pick_blocklist(analyzer, texts, k, any_tag_every=4):
                 cnt[(tok.form, tok.tag & 0x7F)] += 1
     items = [it for it, _ in sorted(cnt.items(), key=lambda kv: (-kv[1], kv[0]))[:k]]
     return [(f, -1 if i % any_tag_every == any_tag_every - 1 else t) for i, (f, t) in enumerate(items)]
+
+
+def force_lanes(monkeypatch, lanes):
+    """KAMD_GROUP_LANES for a test's engine: a lane-group width forces the general search kernel k_best_path<lanes>; "pos" leaves the engine's own
+    choice in place -- top-1 searches then run the position-step kernel k_pos_path first (KAMD_WPS=3 selects its three-waves build)."""
+    if lanes == "pos":
+        monkeypatch.delenv("KAMD_GROUP_LANES", raising=False)
+    else:
+        monkeypatch.setenv("KAMD_GROUP_LANES", lanes)

@@ -172,12 +172,13 @@ namespace hipemu
 	{
 		std::lock_guard<std::mutex> lk{ launchMu };
 		if (block.x > MAXT || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1 || ldsBytes > 160 * 1024) { std::fprintf(stderr, "hipemu: unsupported launch shape of %s\n", name); std::abort(); }
-		// convergence width: the lane-group width of k_best_path<G, ...>, else the wavefront
+		// convergence width: the lane-group width of k_best_path<G, ...> / k_pos_path<G, ...> / k_build_lattice<G>, else the wavefront
 		uint32_t width = 64;
 		const std::string nm{ name };
-		const size_t at = nm.find("k_best_path<"), atPos = nm.find("k_pos_path<");
+		const size_t at = nm.find("k_best_path<"), atPos = nm.find("k_pos_path<"), atLat = nm.find("k_build_lattice<");
 		if (at != std::string::npos) width = (uint32_t)std::atoi(nm.c_str() + at + 12);
 		else if (atPos != std::string::npos) width = (uint32_t)std::atoi(nm.c_str() + atPos + 11);
+		else if (atLat != std::string::npos) width = (uint32_t)std::atoi(nm.c_str() + atLat + 16);
 		if (width == 0 || width > 64 || (width & (width - 1))) { std::fprintf(stderr, "hipemu: cannot read the lane-group width out of '%s'\n", name); std::abort(); }
 		Block blk; blk.n = block.x; blk.width = width; blk.body = &laneBody; blk.kernel = name;
 		if (const char* drop = std::getenv("HIPEMU_TEST_DROP_WAVE_BARRIER")) blk.dropBarrier = nm.find(drop) != std::string::npos;

@@ -6,7 +6,7 @@ from dataclasses import astuple
 
 import pytest
 
-from corpora import EDGE_TEXTS, dictionary_mix, fuzzed, synthetic
+from corpora import EDGE_TEXTS, dictionary_mix, force_lanes, fuzzed, synthetic
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -16,13 +16,12 @@ def _norm(res):
     return [([astuple(t) for t in a[0]], a[1]) for a in res]
 
 
-@pytest.mark.parametrize("lanes", ["16", "64"])
-@pytest.mark.parametrize("top_n", [1, 2])
+@pytest.mark.parametrize("lanes,top_n", [("pos", 1), ("16", 1), ("64", 1), ("16", 2), ("64", 2)])
 def test_cong_tokens_bit_exact_vs_oracle(small_cong_model, monkeypatch, lanes, top_n):
     import oraclelib
     from kiwi_amd.api import KiwiAmd
     sm, path = small_cong_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     orc = oraclelib.OracleKiwi(path)
     dev = KiwiAmd(path)
     texts = synthetic(sm, 1200, 921, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 500, 922) + EDGE_TEXTS + fuzzed(sm, 400, 923)
@@ -57,14 +56,14 @@ def test_cong_fallback_paths_with_small_capacities(small_cong_model, monkeypatch
     monkeypatch.setenv("KAMD_CONTAINER_LIMITS", "3,8,2")
     orc = oraclelib.OracleKiwi(path)
     orc.set_container_limits(3, 8, 2)
-    dev = KiwiAmd(path, lib_path=lib)
     texts = synthetic(sm, 300, 927, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 150, 928)
-    for lanes in ("16", "64"):
-        monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    for lanes in ("pos", "16", "64"):
+        force_lanes(monkeypatch, lanes)
+        dev = KiwiAmd(path, lib_path=lib)      # (the switch is read when an engine is opened)
         got = dev.analyze_batch(texts).to_python()
         for s, y in zip(texts, got):
             assert _norm(orc.analyze(s)) == _norm(y), (lanes, s)
-    dev.close()
+        dev.close()
 
 
 def test_kiwi_init_selects_the_cong_model(small_cong_model):
@@ -127,7 +126,7 @@ def test_unknown_forms_scored_by_the_character_model(small_cong_chr_model, monke
     import refbridge
     from kiwi_amd.api import KiwiAmd
     sm, path = small_cong_chr_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
     orc = oraclelib.OracleKiwi(path)
     orc.lib.korc_set_oov_chr_bias.argtypes = [C.c_void_p, C.c_float]

@@ -7,7 +7,7 @@ import random
 
 import pytest
 
-from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+from corpora import EDGE_TEXTS, dictionary_mix, force_lanes, synthetic
 from test_hipemu import _analyze_typo, _norm, _typo_lattices, _typo_pair
 
 pytestmark = pytest.mark.gpu
@@ -16,13 +16,14 @@ LIB = os.path.join(os.path.dirname(HERE), "kiwi_amd", "libkiwi_hip.so")
 
 
 @pytest.mark.parametrize("continual,threshold,top_n,lanes,lengthening", [(float("inf"), 2.5, 1, "16", float("inf")), (1.0, 2.5, 1, "16", float("inf")), (1.0, 1.2, 3, "16", float("inf")),
-                                                                         (1.0, 2.5, 2, "64", float("inf")), (1.0, 2.5, 1, "16", 0.25)])
+                                                                         (1.0, 2.5, 2, "64", float("inf")), (1.0, 2.5, 1, "16", 0.25),
+                                                                         (1.0, 2.5, 1, "pos", 0.25), (float("inf"), 2.5, 1, "pos", float("inf"))])
 def test_typo_analyses_bit_exact_vs_oracle(small_model, monkeypatch, continual, threshold, top_n, lanes, lengthening):
     import oraclelib
     from kiwi_amd.api import KiwiAmd
     from typo_cases import misspell
     sm, path = small_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     prod, orc_t = _typo_pair(LIB, continual, lengthening)
     dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
     rnd = random.Random(11)
@@ -51,7 +52,7 @@ def test_typo_analyses_through_the_capacity_ladder(small_model, monkeypatch):
     dev.close(); prod.close()
 
 
-@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("16", 1, 1.0, float("inf")), ("64", 2, 1.0, 0.25)])
+@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("pos", 1, 1.0, 0.25), ("16", 1, 1.0, float("inf")), ("64", 2, 1.0, 0.25)])
 def test_typo_correction_with_a_cong_model(small_cong_model, monkeypatch, lanes, top_n, continual, lengthening):
     """The reference's default model type with typo correction: viterbi_kernel_cong_typo.hip (CoNgram scoring + node typo costs) on the MI355X
     against the oracle (pinned for this combination to the reference's SSE4.1 build) and, where it travelled, the real reference itself."""
@@ -60,7 +61,7 @@ def test_typo_correction_with_a_cong_model(small_cong_model, monkeypatch, lanes,
     from kiwi_amd.api import KiwiAmd
     from typo_cases import misspell
     sm, path = small_cong_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     prod, orc_t = _typo_pair(LIB, continual, lengthening)
     dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
     rnd = random.Random(19)

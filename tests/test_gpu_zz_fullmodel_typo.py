@@ -41,11 +41,11 @@ def test_typo_correction_with_a_skipbigram_model(small_sbg_model, monkeypatch, l
     reference on this combination by tests/test_typo_oracle.py)."""
     import random
     import oraclelib
-    from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+    from corpora import EDGE_TEXTS, dictionary_mix, force_lanes, synthetic
     from kiwi_amd.api import KiwiAmd
     from typo_cases import misspell
     sm, path = small_sbg_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     prod, orc_t = _typo_pair(LIB, 1.0)
     dev, orc = KiwiAmd(path), oraclelib.OracleKiwi(path)
     rnd = random.Random(25)

@@ -14,7 +14,7 @@ from dataclasses import astuple
 
 import pytest
 
-from corpora import EDGE_TEXTS, dictionary_mix, synthetic
+from corpora import EDGE_TEXTS, dictionary_mix, force_lanes, synthetic
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU = os.path.join(HERE, "hipemu")
@@ -47,16 +47,16 @@ def test_the_product_library_is_not_the_emulator(emu_libs):
                 assert "hipemu" not in open(os.path.join(root, f), encoding="utf-8", errors="ignore").read(), f
 
 
-@pytest.mark.parametrize("lanes,wps", [("16", "2"), ("16", "3"), ("8", "3"), ("8", "2"), ("4", "2"), ("32", "2"), ("64", "2")])
+@pytest.mark.parametrize("lanes,wps", [("pos", "2"), ("pos", "3"), ("16", "2"), ("16", "3"), ("8", "3"), ("8", "2"), ("4", "2"), ("32", "2"), ("64", "2")])
 def test_emulated_knlm_kernels_match_oracle(emu_libs, oracle, small_model, monkeypatch, lanes, wps):
     """Dictionary scan, lattice build (LDS and HBM variants), candidate expansion, best-path search in every lane-group
     instantiation, end stage: tokens, positions and fp32 scores equal the oracle's, top-1 and top-2."""
     from kiwi_amd.api import KiwiAmd
     sm, path = small_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
-    if lanes in ("8", "16"):
+    force_lanes(monkeypatch, lanes)
+    if lanes in ("8", "16", "pos"):
         monkeypatch.setenv("KAMD_WPS", wps)
-    n = 100 if lanes == "16" and wps == "2" else 40
+    n = 100 if lanes in ("16", "pos") and wps == "2" else 40
     texts = synthetic(sm, n, 521, min_jamo=5, max_jamo=120) + dictionary_mix(sm, n // 2, 522) + (EDGE_TEXTS if n == 100 else [])
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     _check(dev, oracle, texts, (1, 2))
@@ -67,20 +67,39 @@ def test_emulated_knlm_kernels_match_oracle(emu_libs, oracle, small_model, monke
     dev.close()
 
 
-@pytest.mark.parametrize("lanes", ["16", "8", "64"])
+@pytest.mark.parametrize("lanes", ["pos", "16", "8", "64"])
 def test_emulated_fallback_paths_with_small_capacities(emu_libs, small_model, monkeypatch, lanes):
     """The `smallcaps` configuration (LDS capacities of 4) with the container limits cut to 3 / 8 / 2 on both sides:
     medium / large containers, HBM work-item queue, HBM pruning path, far-back node lookup."""
     import oraclelib
     from kiwi_amd.api import KiwiAmd
     sm, path = small_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     monkeypatch.setenv("KAMD_CONTAINER_LIMITS", "3,8,2")
     orc = oraclelib.OracleKiwi(path)
     orc.set_container_limits(3, 8, 2)
     dev = KiwiAmd(path, lib_path=emu_libs[1])
     _check(dev, orc, synthetic(sm, 50, 531, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 25, 532), (1, 2))
     dev.close()
+
+
+def test_emulated_lattice_build_with_four_chunks_per_wavefront(emu_libs, oracle, small_model, monkeypatch):
+    """k_build_lattice<16> (the engine's choice for batches of >= 32768 chunks; KAMD_LATTICE_GROUP=16 here): four chunks share a wavefront, each
+    replayed by lane 0 of its 16-lane group.  Lattices (split) and analyses against the oracle, mixed lengths, the edge texts, and a batch whose
+    size is not a multiple of four; KAMD_LATTICE_LDS=6000 leaves the longer chunks to the thread-per-chunk kernel in the same batch."""
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    texts = (synthetic(sm, 61, 543, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 30, 544) + EDGE_TEXTS)[:-1]
+    monkeypatch.setenv("KAMD_LATTICE_GROUP", "16")
+    for budget in (None, "6000"):
+        if budget:
+            monkeypatch.setenv("KAMD_LATTICE_LDS", budget)
+        dev = KiwiAmd(path, lib_path=emu_libs[0])
+        _check(dev, oracle, texts)
+        for t in texts[:40]:
+            if t.strip():
+                assert dev.split(t) == oracle.split(t), t
+        dev.close()
 
 
 def test_emulated_lattice_hbm_kernel_and_rerun_ladder(emu_libs, oracle, small_model, monkeypatch):
@@ -122,7 +141,7 @@ def test_emulated_skipbigram_kernel_matches_oracle(emu_libs, small_sbg_model, mo
     from kiwi_amd.api import KiwiAmd
     sm, path = small_sbg_model
     monkeypatch.setenv("KAMD_EXPERIMENTAL_SBG", "1")
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     orc = oraclelib.OracleKiwi(path)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     n = 40 if top_n == 1 else 60
@@ -140,7 +159,7 @@ def test_emulated_skipbigram_fallback_paths(emu_libs, small_sbg_model, monkeypat
     from kiwi_amd.api import KiwiAmd
     sm, path = small_sbg_model
     monkeypatch.setenv("KAMD_EXPERIMENTAL_SBG", "1")
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     monkeypatch.setenv("KAMD_CONTAINER_LIMITS", "3,8,2")
     orc = oraclelib.OracleKiwi(path)
     orc.set_container_limits(3, 8, 2)
@@ -330,7 +349,8 @@ def _typo_pair(lib, continual, lengthening=float("inf")):
 @pytest.mark.parametrize("continual,threshold,top_n,lanes,tiny,lengthening", [(float("inf"), 2.5, 1, "16", False, float("inf")), (1.0, 2.5, 1, "16", False, float("inf")),
                                                                                (1.0, 1.2, 3, "16", False, float("inf")), (1.0, 2.5, 1, "64", False, float("inf")),
                                                                                (1.0, 2.5, 2, "16", True, float("inf")), (1.0, 2.5, 1, "16", False, 0.25), (float("inf"), 4.0, 2, "64", False, 0.25),
-                                                                               (1.0, 2.5, 1, "16", "smallcaps", 0.25), (1.0, 2.5, 1, "16", "budget", float("inf"))])
+                                                                               (1.0, 2.5, 1, "16", "smallcaps", 0.25), (1.0, 2.5, 1, "16", "budget", float("inf")),
+                                                                               (1.0, 2.5, 1, "pos", False, 0.25), (float("inf"), 2.5, 1, "pos", False, float("inf")), (1.0, 2.5, 1, "pos", "smallcaps", 0.25)])
 def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch, continual, threshold, top_n, lanes, tiny, lengthening):
     """The whole typo-correcting analysis on the (emulated) device -- typo graphs from the host module, k_build_lattice_typo, the search kernel
     compiled with node typo costs (viterbi_kernel_typo.hip), end stage, host post-processing -- against the oracle (pinned to the real
@@ -341,7 +361,7 @@ def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch,
     from typo_cases import misspell
     sm, path = small_model
     monkeypatch.setenv("KAMD_EXPERIMENTAL_TYPO", "1")
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     lib = emu_libs[0]
     if tiny is True:
         monkeypatch.setenv("KAMD_TEST_TINY_ARENAS", "1")
@@ -365,7 +385,7 @@ def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch,
 
 
 
-@pytest.mark.parametrize("lanes,top_n", [("16", 1), ("64", 1), ("16", 2), ("16", 3)])
+@pytest.mark.parametrize("lanes,top_n", [("pos", 1), ("16", 1), ("64", 1), ("16", 2), ("16", 3)])
 def test_emulated_cong_kernels_match_oracle(emu_libs, small_cong_model, monkeypatch, lanes, top_n):
     """The search kernel compiled for CoNgram models (viterbi_kernel_cong.hip: context trie + int8 embedding dot product, candidates in the
     transposed evaluator's order, the reference kernel's rounding per node) against the oracle, whose CoNgram path is pinned to the REAL
@@ -373,7 +393,7 @@ def test_emulated_cong_kernels_match_oracle(emu_libs, small_cong_model, monkeypa
     import oraclelib
     from kiwi_amd.api import KiwiAmd
     sm, path = small_cong_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     orc = oraclelib.OracleKiwi(path)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     texts = synthetic(sm, 80, 911, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 40, 912) + EDGE_TEXTS
@@ -428,7 +448,7 @@ def test_emulated_blocklist_matches_oracle(emu_libs, small_model, small_cong_mod
     ms.close(); dev.close()
 
 
-@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("16", 1, 1.0, float("inf")), ("64", 1, 1.0, 0.25), ("16", 2, float("inf"), float("inf"))])
+@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("pos", 1, 1.0, 0.25), ("16", 1, 1.0, float("inf")), ("64", 1, 1.0, 0.25), ("16", 2, float("inf"), float("inf"))])
 def test_emulated_typo_correction_with_a_cong_model(emu_libs, small_cong_model, monkeypatch, lanes, top_n, continual, lengthening):
     """Typo correction on a CoNgram model (the reference's default model type with its --typo configurations): the fifth compilation of the search
     kernel (viterbi_kernel_cong_typo.hip: CoNgram scoring + node typo costs) over the typo lattices, against the oracle -- pinned for this
@@ -438,7 +458,7 @@ def test_emulated_typo_correction_with_a_cong_model(emu_libs, small_cong_model, 
     from kiwi_amd.api import KiwiAmd
     from typo_cases import misspell
     sm, path = small_cong_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     prod, orc_t = _typo_pair(emu_libs[0], continual, lengthening)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     orc = oraclelib.OracleKiwi(path)
@@ -548,7 +568,7 @@ def test_emulated_cong_kernel_on_a_file_as_the_reference_builder_writes_it(emu_l
     import oraclelib
     from kiwi_amd.api import KiwiAmd
     sm, path = mid_cong_vl4_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     orc = oraclelib.OracleKiwi(path)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     texts = synthetic(sm, 70, 915, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 30, 916) + EDGE_TEXTS[:20]
@@ -566,7 +586,7 @@ def test_emulated_unknown_forms_scored_by_the_character_model(emu_libs, small_co
     import oraclelib
     from kiwi_amd.api import KiwiAmd
     sm, path = small_cong_chr_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
     orc = oraclelib.OracleKiwi(path)
     orc.lib.korc_set_oov_chr_bias.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_float]
@@ -621,7 +641,7 @@ def test_emulated_typo_correction_with_a_skipbigram_model(emu_libs, small_sbg_mo
     from kiwi_amd.api import KiwiAmd
     from typo_cases import misspell
     sm, path = small_sbg_model
-    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    force_lanes(monkeypatch, lanes)
     prod, orc_t = _typo_pair(emu_libs[0], 1.0)
     orc = oraclelib.OracleKiwi(path)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
