@@ -295,7 +295,10 @@ namespace kamd
 			{
 				const size_t nEdges = m.lmKeys.size() - m.lmNodes[0].numNexts;
 				size_t nBuckets = 1;
-				while (nBuckets * 2 < nEdges + 1) nBuckets <<= 1;   // 4 slots per bucket => load factor <= 0.5
+				// 4 slots per bucket, at most one edge per two buckets on average: a bucket is full -- and a lookup that ends in it has to go on to the
+				// next one -- with probability < 0.2 % (Poisson, mean <= 0.5).  One such lane sends its whole wavefront through the general walk's loop,
+				// so the table is sized for that to be rare (at mean 2 it was 4 % of the lookups); 128 - 256 bytes of HBM per edge
+				while (nBuckets < 2 * (nEdges + 1)) nBuckets <<= 1;
 				m.lmHashMask = (uint32_t)(nBuckets - 1);
 				m.lmHash.assign(nBuckets * 4, LmSlot{ LM_SLOT_EMPTY, LM_SLOT_EMPTY, 0, 0.f });
 				for (uint32_t nd = 1; nd < nonLeaf; ++nd)

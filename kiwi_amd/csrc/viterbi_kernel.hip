@@ -39,6 +39,10 @@
 // top-N (1 < N <= kMaxTopN): the N best paths per key are kept (each with its own values), pruning uses the N-th best score
 // of a root, the end stage hands on ceil(2N / groups) candidates per group; kept paths are handed on in item order (top-N).
 #include <hip/hip_runtime.h>
+#ifdef KAMD_LMSTATS
+#include <atomic>
+#include <cstdio>
+#endif
 #include "device_types.hpp"
 #include "feature.hpp"
 #include "viterbi_kernel.hpp"
@@ -324,6 +328,15 @@ namespace sbgk
 		}
 	}
 
+	// developer statistics of the emulated build (make -C tests/hipemu EXTRA=-DKAMD_LMSTATS): which way lmProgressChain's calls go, printed at exit
+#ifdef KAMD_LMSTATS
+	struct LmStats { std::atomic<unsigned long long> c[16]; ~LmStats() { fprintf(stderr, "[lmstats] calls %llu root-start %llu hit0-child %llu hit0-leaf %llu ovf0 %llu hit1-child %llu hit1-leaf %llu ovf1 %llu n2 %llu root-unk %llu root-child %llu root-leaf %llu walk %llu\n",
+		c[0].load(), c[1].load(), c[2].load(), c[3].load(), c[4].load(), c[5].load(), c[6].load(), c[7].load(), c[8].load(), c[9].load(), c[10].load(), c[11].load(), c[12].load()); } };
+	static LmStats gLmStats;
+#define LMSTAT(k) gLmStats.c[k]++;
+#else
+#define LMSTAT(k) (void)0;
+#endif
 #ifndef KAMD_CONG
 	// KnLangModel::progress once more, for a state that carries the next two nodes of its back-off chain (ModelView::lmChain: n1, n2; 0 = root): the
 	// edge (node, next), the edge (n1, next), the unigram record and both back-off weights are requested TOGETHER, so the usual walk -- a miss in the
@@ -335,52 +348,64 @@ namespace sbgk
 		const LmRootRec rootRec = M.lmRoot2[next];
 		const uint32_t n0 = (uint32_t)node;
 		float acc = 0, result = 0;
-		bool walk = n0 == 0;      // hand the rest to lmProgress' loop from `node` with `acc` (at the root the walk is the unigram record alone)
-		if (!walk)
+		bool walk = false; LMSTAT(0)      // hand the rest to lmProgress' loop from `node` with `acc`
+		uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0, s2 = s0, s3 = s0, t0 = s0, t1 = s0, t2 = s0, t3 = s0; float g0 = 0, g1 = 0;
+		if (n0)
 		{
 			const uint4* b0 = reinterpret_cast<const uint4*>(M.lmHash + (size_t)(lmHashOf(n0, next) & M.lmHashMask) * 4);
 			const uint4* b1 = reinterpret_cast<const uint4*>(M.lmHash + (size_t)(lmHashOf(n1, next) & M.lmHashMask) * 4);
-			const uint4 s0 = b0[0], s1 = b0[1], s2 = b0[2], s3 = b0[3];
-			const float g0 = M.lmBackoff[n0].gamma;
-			uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0, t3 = t0; float g1 = 0;
+			s0 = b0[0]; s1 = b0[1]; s2 = b0[2]; s3 = b0[3];
+			g0 = M.lmBackoff[n0].gamma;
 			if (n1) { t0 = b1[0]; t1 = b1[1]; t2 = b1[2]; t3 = b1[3]; g1 = M.lmBackoff[n1].gamma; }
-			do
+		}
+		else { LMSTAT(1) }
+		do
+		{
+			// the edge (n1, next), if the shorter context has it (n1 == 0: no bucket was loaded, nothing matches)
+			const bool u0 = (t0.x == n1) & (t0.y == next), u1 = (t1.x == n1) & (t1.y == next), u2 = (t2.x == n1) & (t2.y == next), u3 = (t3.x == n1) & (t3.y == next);
+			const bool hit1 = (n1 != 0) & (u0 | u1 | u2 | u3);
+			const int32_t v1 = (int32_t)(u0 ? t0.z : u1 ? t1.z : u2 ? t2.z : t3.z);
+			const bool full1 = (n1 != 0) & (t3.x != LM_SLOT_EMPTY);      // (the bucket overflowed: the edge may sit in the next one)
+			if (n0)
 			{
 				// context n0
+				const bool h0 = (s0.x == n0) & (s0.y == next), h1 = (s1.x == n0) & (s1.y == next), h2 = (s2.x == n0) & (s2.y == next), h3 = (s3.x == n0) & (s3.y == next);
+				if (h0 | h1 | h2 | h3)
 				{
-					const bool h0 = (s0.x == n0) & (s0.y == next), h1 = (s1.x == n0) & (s1.y == next), h2 = (s2.x == n0) & (s2.y == next), h3 = (s3.x == n0) & (s3.y == next);
-					if (h0 | h1 | h2 | h3)
-					{
-						const int32_t v = (int32_t)(h0 ? s0.z : h1 ? s1.z : h2 ? s2.z : s3.z);
-						if (v > 0) { node = (int32_t)n0 + v; result = acc + __uint_as_float(h0 ? s0.w : h1 ? s1.w : h2 ? s2.w : s3.w); }
-						else walk = true;      // (a leaf edge: the suffix search is the general walk's, which finds the edge again)
-						break;
-					}
-					if (s3.x != LM_SLOT_EMPTY) { walk = true; break; }      // (the bucket overflowed: the edge may sit in the next one)
-					acc += g0;
+					const int32_t v = (int32_t)(h0 ? s0.z : h1 ? s1.z : h2 ? s2.z : s3.z);
+					result = acc + __uint_as_float(h0 ? s0.w : h1 ? s1.w : h2 ? s2.w : s3.w);
+					if (v > 0) { LMSTAT(2) node = (int32_t)n0 + v; break; }
+					// a leaf edge: the new state is the longest suffix context that continues with `next` (Knlm.cpp:96-128) -- n1, then n2, then the root.  The
+					// bucket of (n1, next) is here already; only a chain with a third context to ask goes through the general walk (which finds the edge again)
+					LMSTAT(3)
+					if (hit1 && v1 > 0) { node = (int32_t)n1 + v1; break; }
+					if ((n1 != 0) & ((!hit1 & full1) | (n2 != 0))) { walk = true; result = 0; break; }
+					if (rootRec.value > 0) node = rootRec.value;
+					else node = M.lmHtxNode ? M.lmHtxNode[next] : 0;
+					break;
 				}
+				if (s3.x != LM_SLOT_EMPTY) { LMSTAT(4) walk = true; break; }      // (the bucket overflowed: the edge may sit in the next one)
+				acc += g0;
 				// context n1
 				if (n1)
 				{
-					const bool h0 = (t0.x == n1) & (t0.y == next), h1 = (t1.x == n1) & (t1.y == next), h2 = (t2.x == n1) & (t2.y == next), h3 = (t3.x == n1) & (t3.y == next);
-					if (h0 | h1 | h2 | h3)
+					if (hit1)
 					{
-						const int32_t v = (int32_t)(h0 ? t0.z : h1 ? t1.z : h2 ? t2.z : t3.z);
-						if (v > 0) { node = (int32_t)n1 + v; result = acc + __uint_as_float(h0 ? t0.w : h1 ? t1.w : h2 ? t2.w : t3.w); }
-						else { node = (int32_t)n1; walk = true; }
+						if (v1 > 0) { LMSTAT(5) node = (int32_t)n1 + v1; result = acc + __uint_as_float(u0 ? t0.w : u1 ? t1.w : u2 ? t2.w : t3.w); }
+						else { LMSTAT(6) node = (int32_t)n1; walk = true; }
 						break;
 					}
-					if (t3.x != LM_SLOT_EMPTY) { node = (int32_t)n1; walk = true; break; }
+					if (full1) { LMSTAT(7) node = (int32_t)n1; walk = true; break; }
 					acc += g1;
-					if (n2) { node = (int32_t)n2; walk = true; break; }      // (a fourth context: carry on from it)
+					if (n2) { LMSTAT(8) node = (int32_t)n2; walk = true; break; }      // (a fourth context: carry on from it)
 				}
-				// the root
-				if (rootRec.value == 0) { node = M.lmHtxNode ? M.lmHtxNode[next] : 0; result = acc + M.h.unkLl; }
-				else if (rootRec.value > 0) { node = rootRec.value; result = acc + rootRec.ll; }
-				else { node = 0; walk = true; }      // (a leaf unigram: the general walk's last lines)
-			} while (0);
-		}
-		if (walk) result = lmProgress(M, node, next, acc);
+			}
+			// the root (a state at the root starts here: the unigram record is the whole walk)
+			if (rootRec.value == 0) { LMSTAT(9) node = M.lmHtxNode ? M.lmHtxNode[next] : 0; result = acc + M.h.unkLl; }
+			else if (rootRec.value > 0) { LMSTAT(10) node = rootRec.value; result = acc + rootRec.ll; }
+			else { LMSTAT(11) node = 0; walk = true; }      // (a leaf unigram: the general walk's last lines)
+		} while (0);
+		if (walk) { LMSTAT(12) result = lmProgress(M, node, next, acc); }
 		return result;
 	}
 #endif
