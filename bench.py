@@ -115,17 +115,20 @@ def model_facts(workload):
     return out
 
 
-def measured_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, separate
-    rocprofv3 --pmc runs of this same command; see profiles/README.md).  None when no measurement of this workload is on file."""
+def measured_traffic(workload, kernels):
+    """HBM bytes per launch of the named kernels together, from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE, separate
+    rocprofv3 --pmc runs of `bench.py --workload W --kernels-only`, tools/measure_round.sh; see profiles/README.md).  profiles/traffic.json
+    holds one entry per measured workload; None when this workload is not on file."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
     try:
         t = json.load(open(path))
-        if t.get("workload") == workload:
-            return t["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        entry = t.get(workload) if "kernels" not in t else (t if t.get("workload") == workload else None)
+        if entry is None:
+            return None
+        vals = [entry["kernels"][k]["hbm_bytes_per_launch"] for k in kernels if k in entry["kernels"]]
+        return float(sum(vals)) if vals else None
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def copy_bandwidth_gbs():
@@ -339,7 +342,7 @@ def main():
             search_bytes = per["search"] * n
             achieved = search_bytes / (kt["search_ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_pos_path + k_best_path (the search: position steps, then what they hand over and the end stage)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, "k_best_path"),
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, ("k_pos_path", "k_best_path")),
                                "measured_copy_GBs": copy_bandwidth_gbs() if world == 1 else None,
                                "alg_bytes_per_sentence": per, "all_kernels_achieved": per["total"] * n / ((kt["scan_ms"] + kt["lattice_ms"] + kt["search_ms"] + kt["finish_ms"]) * 1e-3) / 1e9}
             if "cpu_baseline" in cb:

@@ -103,3 +103,31 @@ def test_position_step_and_general_kernel_agree_and_both_run(full, monkeypatch):
     assert [_norm(x) for x in a] == [_norm(x) for x in b]
     bad = [s for s, y in zip(texts[::8], a[::8]) if _norm(orc.analyze(s)) != _norm(y)]
     assert not bad, (len(bad), bad[:3])
+
+
+def _packed(dev, texts, **kw):
+    r = dev.analyze_batch(texts, **kw)
+    a = r.pack()
+    r.close()
+    return a
+
+
+@pytest.mark.parametrize("workload,limit", [("c2-64k", 65536), ("c3", 65536), ("c4-cong", 32768)])
+def test_position_step_kernel_equals_general_kernel_on_whole_corpora(monkeypatch, workload, limit):
+    """Every sentence of the bench corpora -- 65 536 x 40 jamo, the mixed 5-200 jamo corpus, 32 768 of the CoNgram one -- through the position-step
+    kernel and through the general kernel alone (KAMD_POS_PATH=0): the packed token records (tokens, positions, fp32 scores) are the same bytes.
+    The general kernel is the one the oracle / reference comparisons above pin at sample size; this carries them over to the whole batch, to the
+    many-chunk launch configuration (three waves per SIMD) and to whatever the long sentences of c3 reach (steps of more states than the LDS ring)."""
+    import numpy as np
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+    path, texts, _ = get_workload(workload)
+    texts = texts[:limit]
+    pos = KiwiAmd(path)
+    a = _packed(pos, texts)
+    pos.close()
+    monkeypatch.setenv("KAMD_POS_PATH", "0")
+    gen = KiwiAmd(path)
+    b = _packed(gen, texts)
+    gen.close()
+    assert a.nbytes == b.nbytes and np.array_equal(a, b)

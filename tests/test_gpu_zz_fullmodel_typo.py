@@ -35,6 +35,27 @@ def test_c5_2k_sentences_bit_exact_vs_oracle():
     check_c5(LIB, 2048)
 
 
+def test_c5_position_step_kernel_equals_general_kernel_on_the_whole_corpus(monkeypatch):
+    """All 8192 misspelt sentences of c5 through the typo compilation of the position-step kernel and through the general kernel alone
+    (KAMD_POS_PATH=0): the same packed token records, typo costs included."""
+    import numpy as np
+    from kiwi_amd.api import KiwiAmd, Typo
+    from kiwi_amd.workloads import fill_typo_rules, get_workload, workload_typo
+    path, c5, _ = get_workload("c5")
+    cont, leng, threshold = workload_typo("c5")
+    out = []
+    for pos in ("1", "0"):
+        monkeypatch.setenv("KAMD_POS_PATH", pos)
+        dev = KiwiAmd(path, lib_path=LIB)
+        typo = Typo(dev.lib, cont, leng)
+        fill_typo_rules(typo)
+        typo.prepare(True)
+        r = dev.analyze_batch_opt(c5, typo=typo, typo_threshold=threshold)
+        out.append(r.pack()); r.close()
+        typo.close(); dev.close()
+    assert out[0].nbytes == out[1].nbytes and np.array_equal(out[0], out[1])
+
+
 @pytest.mark.parametrize("lanes", ["64", "16"])
 def test_typo_correction_with_a_skipbigram_model(small_sbg_model, monkeypatch, lanes):
     """viterbi_kernel_sbg_typo.hip: the SkipBigram search kernel over lattices with typo costs, against the oracle (compared with the real
