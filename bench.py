@@ -70,9 +70,13 @@ def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None, time_refe
     n_mt = int(min(len(texts), max(64 * cores, rate1 * min(cores, phys) * 1.0)))
     smt, pmt, _ = runner.analyze_batch_timed(texts[:n_mt], top_n=top_n, threads=cores, min_seconds=max(2.0, budget_s / 4), typo=rtypo, typo_threshold=thr)
     rate = n_mt * pmt / smt
+    # what the box lets this process use: the same thread count on register-only work (a container can see every logical CPU of the host and be
+    # scheduled on a fraction of them); the baseline cannot scale beyond it
+    usable = oraclelib.cpu_capacity(cores, 1.0)
     out["cpu_baseline"] = {"value": rate, "unit": "sentences/s", "cores": cores, "kind": kind,
-                           "threads": cores, "physical_cores": phys, "single_thread": rate1,
+                           "threads": cores, "physical_cores": phys, "usable_cores_measured": usable, "single_thread": rate1,
                            "scaling_efficiency_vs_physical_cores": rate / (rate1 * max(1, min(cores, phys))),
+                           "scaling_efficiency_vs_usable_cores": rate / (rate1 * max(1.0, min(usable, float(phys)))),
                            "sample": f"{pmt} timed passes over {n_mt} sentences of the same workload ({smt:.2f} s) on {cores} persistent threads after one untimed warm-up pass "
                                      f"(reference arch {arch_name}; texts handed out through one atomic counter, results dropped); single thread: {rate1:.0f} sentences/s ({p1} passes over {len(sample)})"}
     return out

@@ -44,7 +44,7 @@ int kamd_set_config(kamd_engine_h h, float cut_off_threshold, float space_penalt
  * that option needs a model with the character model (nounchr.mdl next to cong.mdl / the raw container's `nounchr` section) */
 int kamd_set_oov_chr_bias(kamd_engine_h h, float bias);
 
-/* texts: concatenated UTF-16; offsets[n+1].  top_n in 1..4 (null + error otherwise); analyses beyond the best differ from a given reference run only in exact ties (top-N). */
+/* texts: concatenated UTF-16; offsets[n+1].  top_n in 1..16 (null + error otherwise); analyses beyond the best differ from a given reference run only in exact ties (top-N). */
 kamd_results_h kamd_analyze_batch(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n,
 	uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
 

@@ -5,8 +5,8 @@
  * long as it stays inside this subset (anything else is simply not exported: link error, not silent change).
  *
  * Differences a caller can observe:
- *   - kiwi_init's model_path names a directory holding the reference's own model files (sj.morph + sj.knlm, optionally skipbigram.mdl;
- *     cong.mdl is read from raw containers only), or a raw-model container (or a directory holding `kiwi_amd.raw`).  Its `options` are honoured as in the reference:
+ *   - kiwi_init's model_path names a directory holding the reference's own model files (sj.morph + sj.knlm, optionally skipbigram.mdl; or
+ *     sj.morph + cong.mdl, optionally nounchr.mdl -- the layout of the reference's models/cong/base), or a raw-model container (or a directory holding `kiwi_amd.raw`).  Its `options` are honoured as in the reference:
  *     KIWI_BUILD_INTEGRATE_ALLOMORPH sets integrate_allomorph; the model type bits select a CoNgram model (default / LARGEST when the
  *     container has one, CONG; local scoring), Knlm (default otherwise, KNLM) or SkipBigram (LARGEST when the container has the tables, SBG)
  *     and refuse CONG_GLOBAL; the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).

@@ -273,6 +273,20 @@ extern "C"
 		return w.need;
 	}
 
+	// How many cores this process really gets: `threads` threads each run the same fixed amount of register-only integer work (no memory, no
+	// allocation, nothing shared); returns aggregate work per second relative to one thread doing it alone.  A container may see 256 logical CPUs
+	// and be scheduled on a fraction of them (CPU quota): the multi-thread baseline cannot scale beyond this number, whatever the code does.
+	double korc_cpu_capacity(int threads, double minSeconds)
+	{
+		auto spin = [](uint64_t seed) { uint64_t x = seed | 1; for (uint32_t i = 0; i < 20000000u; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; } return x; };
+		std::atomic<uint64_t> sink{ 0 };
+		uint32_t p1 = 0, pn = 0;
+		const double s1 = timedpool::run(1, 4, minSeconds / 2, &p1, [&](int, uint32_t i) { sink.fetch_xor(spin(i + 1), std::memory_order_relaxed); });
+		const double sn = timedpool::run(threads, 4u * (uint32_t)threads, minSeconds / 2, &pn, [&](int, uint32_t i) { sink.fetch_xor(spin(i + 1), std::memory_order_relaxed); });
+		const double r1 = 4.0 * p1 / s1, rn = 4.0 * threads * pn / sn;
+		return sink.load() == 0x1234567ull ? 0.0 : rn / r1;
+	}
+
 	// CPU baseline ("port" kind): batch over `threads` workers; returns wall seconds
 	// the batch timed soundly (timed_pool.hpp): persistent threads, one untimed warm-up pass, whole passes until >= minSeconds of wall
 	double korc_analyze_batch_timed(void* hp, void* typoHp, float typoThreshold, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int threads, double minSeconds, uint32_t* passesOut, uint64_t* tokensOut)

@@ -171,6 +171,14 @@ class OracleKiwi:
         return dict(zip(COUNTER_NAMES, (int(x) for x in arr)))
 
 
+def cpu_capacity(threads: int, min_seconds: float = 1.0) -> float:
+    """Cores this process really gets (korc_cpu_capacity): aggregate rate of `threads` threads of register-only work relative to one thread."""
+    lib = C.CDLL(LIB_PATH)
+    lib.korc_cpu_capacity.restype = C.c_double
+    lib.korc_cpu_capacity.argtypes = [C.c_int, C.c_double]
+    return float(lib.korc_cpu_capacity(threads, min_seconds))
+
+
 def alg_bytes(c: dict) -> dict:
     """ALG_BYTES v1: algorithmic bytes from oracle event counts, no cache credit.
     Returns the split used by bench.py: dictionary scan + lattice build ('lattice') and best-path search ('search')."""

@@ -20,6 +20,7 @@
 #include <thread>
 #include "timed_pool.hpp"
 #include <atomic>
+#include <malloc.h>
 #include <numeric>
 
 #include <kiwi/Kiwi.h>
@@ -670,6 +671,11 @@ extern "C"
 		std::atomic<uint64_t> tokens{ 0 };
 		kiwi::AnalyzeOption opt{ (kiwi::Match)match };
 		if (typoHp) { opt.typoTransformer = ((TypoHandle*)typoHp)->ptt.get(); opt.typoThreshold = typoThreshold; }
+		// The reference is built with mimalloc by default (KIWI_USE_MIMALLOC); this build of its translation units allocates through glibc, whose
+		// default policy maps and unmaps every large block -- at 256 threads the analyses then queue on the process's address-space lock instead of
+		// running (measured on the MI355X host: 6.7 % scaling efficiency).  Keep freed memory in the arenas, as mimalloc would: a fair baseline.
+		static const bool tuned = [] { mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 64 << 20); return true; }();
+		(void)tuned;
 		uint32_t passes = 0;
 		const double sec = timedpool::run(threads, n, minSeconds, &passes, [&](int, uint32_t i)
 		{
