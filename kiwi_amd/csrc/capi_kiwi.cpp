@@ -1,8 +1,11 @@
 // Kiwi-compatible C API (include/kiwi_capi.h) on top of kamd::Engine: the drop-in boundary for
 // Kiwi::analyze.  Conventions follow /root/reference/src/capi/kiwi_c.cpp: handles are heap objects owned by the
 // caller, nothing throws across the boundary, failures are recorded in a thread-local slot read by kiwi_error().
+#include <chrono>
 #include <cstddef>
+#include <cstdio>
 #include <cstring>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -34,17 +37,21 @@ struct kiwi_prepared_typo { kamd::PreparedTypo p; };                  // capi.h:
 // One text's analyses, flat (its slice of a batch's ResultSegment): token records whose first 44 bytes are kiwi_token_info_t -- the
 // reference hands out a pointer into its TokenInfo the same way (kiwi_c.cpp:1097) -- and one pool of NUL-terminated UTF-16 forms.
 // UTF-8 forms and UTF-16 tag names are materialised on first request, as the reference's ResultBuffer does (kiwi_c.cpp:20-23).
+// A result handed to the caller: a VIEW of one text's analyses inside the batch's flat result segments (post.hpp), which every result of the batch
+// keeps alive together -- no per-text copies of token records or form strings (the reference hands out a vector of its own per text,
+// src/capi/kiwi_c.cpp:45-60; a batch of 65 536 texts made 5 allocations and 4 copies per text here before).
 struct kiwi_res
 {
-	std::vector<uint32_t> anaTok{ 0 };
-	std::vector<float> scores;
-	std::vector<FlatToken> toks;
-	std::vector<char16_t> forms;
+	std::shared_ptr<const BatchResults> batch;
+	const ResultSegment* seg = nullptr;
+	uint32_t a0 = 0, nAna = 0;      // analyses [a0, a0 + nAna) of the segment
 	std::map<std::pair<int, int>, std::string> formBuf;
 	std::map<std::pair<int, int>, std::u16string> tagBufW;
-	size_t size() const { return scores.size(); }
-	size_t tokens(int index) const { return anaTok[index + 1] - anaTok[index]; }
-	const FlatToken& tok(int index, int num) const { return toks[anaTok[index] + num]; }
+	size_t size() const { return nAna; }
+	size_t tokens(int index) const { return seg->anaTok[a0 + index + 1] - seg->anaTok[a0 + index]; }
+	const FlatToken& tok(int index, int num) const { return seg->toks[seg->anaTok[a0 + index] + num]; }
+	float score(int index) const { return seg->anaScore[a0 + index]; }
+	const char16_t* form(int index, int num) const { return seg->forms.data() + tok(index, num).formOff; }      // NUL-terminated
 };
 static_assert(offsetof(FlatToken, dialect) == offsetof(kiwi_token_info_t, dialect) && offsetof(FlatToken, score) == offsetof(kiwi_token_info_t, score)
 	&& offsetof(FlatToken, subSentPosition) == offsetof(kiwi_token_info_t, sub_sent_position) && offsetof(FlatToken, tag) == offsetof(kiwi_token_info_t, tag), "FlatToken starts with kiwi_token_info_t");
@@ -145,66 +152,52 @@ namespace
 	// AnalyzeOption::typoTransformer / typoThreshold
 	TypoOption typoOf(const kiwi_analyze_option_t& o);
 
-	kiwi_res* makeRes(const BatchResults& br, size_t text)
+	kiwi_res* makeRes(const std::shared_ptr<const BatchResults>& br, size_t text)
 	{
 		auto res = std::make_unique<kiwi_res>();
 		size_t local;
-		const ResultSegment& seg = br.locate(text, local);
-		const uint32_t a0 = seg.textAna[local], a1 = seg.textAna[local + 1];
-		if (a1 > a0)
-		{
-			const uint32_t t0 = seg.anaTok[a0], t1 = seg.anaTok[a1];
-			res->scores.assign(seg.anaScore.begin() + a0, seg.anaScore.begin() + a1);
-			for (uint32_t a = a0; a < a1; ++a) res->anaTok.push_back(seg.anaTok[a + 1] - t0);
-			res->toks.assign(seg.toks.begin() + t0, seg.toks.begin() + t1);
-			if (t1 > t0)
-			{
-				const uint64_t f0 = seg.toks[t0].formOff, f1 = seg.toks[t1 - 1].formOff + seg.toks[t1 - 1].formLen + 1;
-				res->forms.assign(seg.forms.begin() + f0, seg.forms.begin() + f1);
-				for (auto& t : res->toks) t.formOff -= f0;
-			}
-		}
+		const ResultSegment& seg = br->locate(text, local);
+		res->batch = br; res->seg = &seg;
+		res->a0 = seg.textAna[local]; res->nAna = seg.textAna[local + 1] - seg.textAna[local];
 		return res.release();
 	}
 
+	// kiwi_analyze_m / _mw (src/capi/kiwi_c.cpp:914-960 over Kiwi::analyze(reader, receiver), include/kiwi/Kiwi.h:402-454): reader and receiver are the
+	// caller's functions and are called from the calling thread, in input order, like the reference does -- while the batch read before is on the
+	// device(s): batch k is analysed by a worker thread while the caller's thread delivers batch k - 1 and reads batch k + 1.
 	template<class ReadFn>
 	int analyzeMany(kiwi_h h, ReadFn&& readNext, kiwi_receiver_t receiver, void* ud, int topN, const kiwi_analyze_option_t& opt)
 	{
 		checkOption(opt, nullptr);
-		int readerIdx = 0, receiverIdx = 0;
-		bool done = false;
-		while (!done)
+		struct Job
 		{
 			std::vector<std::u16string> texts;
-			while ((int)texts.size() < h->batchSize)
-			{
-				std::u16string s;
-				if (!readNext(readerIdx, s)) { done = true; break; }
-				++readerIdx;
-				texts.push_back(std::move(s));
-			}
-			if (texts.empty()) break;
+			std::vector<size_t> cut;
+			std::vector<std::shared_ptr<const BatchResults>> parts;
+		};
+		auto analyse = [h, topN, &opt](Job& job)
+		{
 			std::vector<std::pair<const char16_t*, size_t>> views;
-			for (auto& t : texts) views.emplace_back(t.data(), t.size());
+			for (auto& t : job.texts) views.emplace_back(t.data(), t.size());
 			// One host process drives every GPU (the reference's driver keeps a thread pool busy, include/kiwi/Kiwi.h:402-454): the batch is cut into
 			// contiguous parts of about equal text volume, part d is analysed by the engine of device d on its own thread, results are delivered in
 			// input order.  (Texts are independent: no exchange between the devices; each holds a replica of the model tables.)
-			const size_t nDev = std::min(h->devices(), std::max<size_t>(1, texts.size() / 64));
-			std::vector<size_t> cut(nDev + 1, 0);
+			const size_t nDev = std::min(h->devices(), std::max<size_t>(1, job.texts.size() / 64));
+			job.cut.assign(nDev + 1, 0);
 			{
-				size_t total = 0; for (auto& t : texts) total += t.size() + 8;
+				size_t total = 0; for (auto& t : job.texts) total += t.size() + 8;
 				size_t acc = 0, d = 1;
-				for (size_t i = 0; i < texts.size() && d < nDev; ++i) { acc += texts[i].size() + 8; if (acc * nDev >= total * d) cut[d++] = i + 1; }
-				for (; d <= nDev; ++d) cut[d] = texts.size();
+				for (size_t i = 0; i < job.texts.size() && d < nDev; ++i) { acc += job.texts[i].size() + 8; if (acc * nDev >= total * d) job.cut[d++] = i + 1; }
+				for (; d <= nDev; ++d) job.cut[d] = job.texts.size();
 			}
-			std::vector<BatchResults> parts(nDev);
+			job.parts.assign(nDev, nullptr);
 			std::vector<std::exception_ptr> errs(nDev);
 			auto work = [&](size_t d)
 			{
 				try
 				{
-					std::vector<std::pair<const char16_t*, size_t>> v(views.begin() + cut[d], views.begin() + cut[d + 1]);
-					parts[d] = h->device(d).analyzeBatch(v, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt));
+					std::vector<std::pair<const char16_t*, size_t>> v(views.begin() + job.cut[d], views.begin() + job.cut[d + 1]);
+					job.parts[d] = std::make_shared<const BatchResults>(h->device(d).analyzeBatch(v, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt)));
 				}
 				catch (...) { errs[d] = std::current_exception(); }
 			};
@@ -213,9 +206,57 @@ namespace
 			work(0);
 			for (auto& w : workers) w.join();
 			for (auto& e : errs) if (e) std::rethrow_exception(e);
-			for (size_t d = 0; d < nDev; ++d)
-				for (size_t i = cut[d]; i < cut[d + 1]; ++i) (*receiver)(receiverIdx++, makeRes(parts[d], i - cut[d]), ud);   // in input order; the receiver owns the result
+		};
+		int readerIdx = 0, receiverIdx = 0;
+		auto deliver = [&](Job& job)
+		{
+			for (size_t d = 0; d + 1 < job.cut.size(); ++d)
+				for (size_t i = job.cut[d]; i < job.cut[d + 1]; ++i) (*receiver)(receiverIdx++, makeRes(job.parts[d], i - job.cut[d]), ud);   // in input order; the receiver owns the result
+		};
+		auto readBatch = [&](Job& job)
+		{
+			while ((int)job.texts.size() < h->batchSize)
+			{
+				std::u16string s;
+				if (!readNext(readerIdx, s)) return false;
+				++readerIdx;
+				job.texts.push_back(std::move(s));
+			}
+			return true;
+		};
+		std::unique_ptr<Job> running, finished;
+		std::future<void> pending;
+		bool more = true;
+		// developer aid (KAMD_CAPI_TIMING=1): where the calling thread's time goes
+		static const bool timing = std::getenv("KAMD_CAPI_TIMING") != nullptr;
+		double tRead = 0, tWait = 0, tDeliver = 0;
+		auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		try
+		{
+			while (more || running)
+			{
+				std::unique_ptr<Job> next;
+				const double t0 = clk();
+				if (more)
+				{
+					next = std::make_unique<Job>();
+					more = readBatch(*next);      // (overlaps the batch on the device)
+					if (next->texts.empty()) next.reset();
+				}
+				const double t1 = clk();
+				if (running) { pending.get(); finished = std::move(running); }
+				const double t2 = clk();
+				if (next) { running = std::move(next); Job* j = running.get(); pending = std::async(std::launch::async, [&analyse, j] { analyse(*j); }); }
+				if (finished) { deliver(*finished); finished.reset(); }      // (overlaps the next batch on the device)
+				tRead += t1 - t0; tWait += t2 - t1; tDeliver += clk() - t2;
+			}
 		}
+		catch (...)
+		{
+			if (pending.valid()) { try { pending.get(); } catch (...) {} }
+			throw;
+		}
+		if (timing) fprintf(stderr, "[kiwi_analyze_m] %d texts: reading %.1f ms, waiting for the device side %.1f ms, delivering %.1f ms\n", readerIdx, 1e3 * tRead, 1e3 * tWait, 1e3 * tDeliver);
 		return readerIdx;
 	}
 
@@ -459,7 +500,7 @@ extern "C"
 			size_t n = 0; while (text[n]) ++n;
 			std::vector<std::pair<const char16_t*, size_t>> v{ { (const char16_t*)text, n } };
 			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
-			return makeRes(res, 0);
+			return makeRes(std::make_shared<const BatchResults>(std::move(res)), 0);
 		}
 		catch (const std::exception& e) { setError(e); return nullptr; }
 	}
@@ -473,7 +514,7 @@ extern "C"
 			const std::u16string u = utf8To16(text, std::strlen(text));
 			std::vector<std::pair<const char16_t*, size_t>> v{ { u.data(), u.size() } };
 			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
-			return makeRes(res, 0);
+			return makeRes(std::make_shared<const BatchResults>(std::move(res)), 0);
 		}
 		catch (const std::exception& e) { setError(e); return nullptr; }
 	}
@@ -516,7 +557,7 @@ extern "C"
 	const char* kiwi_get_script_name(uint8_t script) { return scriptName(script); }
 
 	int kiwi_res_size(kiwi_res_h r) { return r ? (int)r->size() : KIWIERR_INVALID_HANDLE; }
-	float kiwi_res_prob(kiwi_res_h r, int index) { return (r && index >= 0 && (size_t)index < r->size()) ? r->scores[index] : 0.f; }
+	float kiwi_res_prob(kiwi_res_h r, int index) { return (r && index >= 0 && (size_t)index < r->size()) ? r->score(index) : 0.f; }
 	int kiwi_res_word_num(kiwi_res_h r, int index)
 	{
 		if (!r) return KIWIERR_INVALID_HANDLE;
@@ -530,7 +571,7 @@ extern "C"
 		if (!validIdx(r, index, num)) return KIWIERR_INVALID_INDEX;
 		return r->tok(index, num).morph;
 	}
-	const kchar16_t* kiwi_res_form_w(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? (const kchar16_t*)(r->forms.data() + r->tok(index, num).formOff) : nullptr; }
+	const kchar16_t* kiwi_res_form_w(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? (const kchar16_t*)r->form(index, num) : nullptr; }
 	const kchar16_t* kiwi_res_tag_w(kiwi_res_h r, int index, int num)
 	{
 		if (!r || !validIdx(r, index, num)) return nullptr;
@@ -542,7 +583,7 @@ extern "C"
 	{
 		if (!r || !validIdx(r, index, num)) return nullptr;
 		auto it = r->formBuf.find({ index, num });
-		if (it == r->formBuf.end()) it = r->formBuf.emplace(std::make_pair(index, num), utf16To8(std::u16string{ r->forms.data() + r->tok(index, num).formOff, r->tok(index, num).formLen })).first;
+		if (it == r->formBuf.end()) it = r->formBuf.emplace(std::make_pair(index, num), utf16To8(std::u16string{ r->form(index, num), r->tok(index, num).formLen })).first;
 		return it->second.c_str();
 	}
 	const char* kiwi_res_tag(kiwi_res_h r, int index, int num) { return (r && validIdx(r, index, num)) ? tagToString(r->tok(index, num).tag) : nullptr; }

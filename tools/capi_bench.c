@@ -52,7 +52,7 @@ int main(int argc, char** argv)
 		c.lines[c.n] = strdup(line); c.lens[c.n] = (int)len; ++c.n;
 	}
 	fclose(f);
-	k = kiwi_init(argv[1], 0, KIWI_BUILD_DEFAULT, 0);
+	k = kiwi_init(argv[1], -1, KIWI_BUILD_DEFAULT, 0);      /* num_threads -1: "as many as the machine has" (capi.h:594), what a throughput client asks for; 0 would keep every host stage on the calling thread */
 	if (!k) { fprintf(stderr, "kiwi_init: %s\n", kiwi_error()); return 1; }
 	memset(&opt, 0, sizeof(opt));
 	opt.match_options = (1 << 0) | (1 << 1) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 5) | (1 << 23) | (1 << 16);   /* KIWI_MATCH_ALL_WITH_NORMALIZING */
