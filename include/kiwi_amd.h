@@ -80,6 +80,9 @@ kamd_results_h kamd_res_merge_strided(const uint8_t* const* parts, const size_t*
 /* test hooks: baked dictionary dump and the lattices of one text, in the byte layouts of oracle/ref_bridge.cpp */
 /* developer probe: exp_out[i] = expf, log_out[i] = logf of x[i] computed ON THE DEVICE by csrc/exact_math.hpp (bit-identical to glibc) */
 int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n);
+/* developer probe, HOST side: the pattern recogniser of the text preparation (reference matchPattern, src/PatternMatcher.cpp:380) at text[0]:
+ * matched length | tag << 32, 0 = no pattern starts here.  `left` = the unit before text[0] (u' ' at the start) */
+uint64_t kamd_debug_match_pattern(uint16_t left, const uint16_t* text, uint32_t len, uint64_t match_options);
 /* developer probe, HOST side, no device: one SkipBigram LM step (reference SbgState::nextImpl, src/SkipBigramModel.hpp:169-182) on top of
  * the Knlm log-likelihood `knlm_ll`, by the code the search kernel shares (csrc/sbg_eval.hpp); hist8 / pos are updated in place */
 int kamd_debug_sbg_next(const char* raw_model_path, uint32_t* hist8, uint32_t* pos, uint32_t wid, float knlm_ll, float* ll_out);

@@ -246,6 +246,13 @@ extern "C"
 	}
 	void kamd_res_close(kamd_results_h r) { delete r; }
 
+	// developer probe, host side: the pattern recogniser of the text preparation at one position (textprep.cpp matchPattern): length | tag << 32
+	uint64_t kamd_debug_match_pattern(uint16_t left, const uint16_t* text, uint32_t len, uint64_t match_options)
+	{
+		const auto r = kamd::matchPattern((char16_t)left, (const char16_t*)text, (const char16_t*)text + len, match_options);
+		return (uint64_t)r.first | ((uint64_t)r.second << 32);
+	}
+
 	int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n)
 	{
 		return guarded([&]() { kamd::exactMathProbe(x, exp_out, log_out, n); return 0; }, -1);

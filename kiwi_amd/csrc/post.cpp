@@ -140,53 +140,102 @@ namespace kamd
 			return isJClass(t.tag) || isEClass(t.tag) || (isVerbClass(t.tag) && t.str.size() == 1 && t.str[0] == 0xD558) || t.tag == T_VCP || t.tag == T_SP;
 		}
 
+		// Sentence, sub-sentence, line and word numbers of the tokens of one analysis (what the reference's fillSentLineInfo leaves in them,
+		// src/Kiwi.cpp:325-415), as three passes over arrays instead of one loop over interleaved counters:
+		//   1. line of every token        -- a merge of the (sorted) newline offsets with the token positions;
+		//   2. sentence / sub-sentence    -- the boundary automaton: SentenceParser decides where a sentence ends; a bracketed span either hides its
+		//                                    inside from it (no sentence in there) or numbers the sentences inside as sub-sentences; a gap of more
+		//                                    than one line starts a sentence too.  A boundary may claim the symbol glued to the front of the token that
+		//                                    opens the next sentence: such late claims are collected and applied after the pass;
+		//   3. word index inside a sentence -- a running count of the changes of the tokens' original word index, restarted per sentence.
+		// Passes 1 and 3 are prefix scans; pass 2 carries the parser's state from token to token.
+		struct LateClaim { size_t token; uint32_t value; bool sentence; };
+
 		void fillSentLine(const FlatModel* m, std::vector<Token>& tokens, const std::vector<size_t>& newlines)
 		{
-			SentenceParser sp{ m };
-			uint32_t sentPos = 0, lastSentPos = 0, subSentPos = 0, accumSubSent = 1, accumWordPos = 0, lastWordPos = 0;
-			size_t nlPos = 0, lastNlPos = 0, nestedSentEnd = 0, nestedEnd = 0;
-			for (size_t i = 0; i < tokens.size(); ++i)
-			{
-				Token& t = tokens[i];
-				if (i >= nestedEnd && sp.next(t, nlPos, nestedSentEnd && i == nestedSentEnd))
-				{
-					const bool inc = i > 1
-						&& (tokens[i - 1].tag == T_SO || tokens[i - 1].tag == T_SW || tokens[i - 1].tag == T_SP || tokens[i - 1].tag == T_SE || tokens[i - 1].tag == T_SSO)
-						&& tokens[i - 1].endPos() == tokens[i].position
-						&& tokens[i - 1].position > tokens[i - 2].endPos();
-					if (nestedSentEnd)
-					{
-						subSentPos++; accumSubSent++;
-						if (inc) tokens[i - 1].subSentPosition = subSentPos;
-					}
-					else
-					{
-						sentPos++; accumSubSent = 1;
-						if (inc) { tokens[i - 1].sentPosition = sentPos; tokens[i - 1].wordPosition = 0; accumWordPos = 0; }
-					}
-				}
-				if (!nestedSentEnd && !nestedEnd && t.tag == T_SSO && t.pairedToken != (uint32_t)-1)
-				{
-					if (!hasSentences(m, &tokens[i], &tokens[t.pairedToken])) { nestedEnd = t.pairedToken; subSentPos = 0; }
-					else if ((t.pairedToken + 1 < tokens.size() && nestedRight(tokens[t.pairedToken + 1])) || (i > 0 && nestedLeft(tokens[i - 1])))
-					{
-						nestedSentEnd = t.pairedToken; subSentPos = accumSubSent;
-					}
-				}
-				else if (nestedSentEnd && i > nestedSentEnd) { nestedSentEnd = 0; subSentPos = 0; }
-				else if (nestedEnd && i >= nestedEnd) { nestedEnd = 0; subSentPos = 0; }
+			const size_t n = tokens.size();
+			if (!n) return;
+			std::vector<uint32_t> line(n), sent(n), sub(n);
 
-				while (nlPos < newlines.size() && newlines[nlPos] < t.position) nlPos++;
-				t.lineNumber = (uint32_t)nlPos;
-				if (nlPos > lastNlPos + 1 && sentPos == lastSentPos && !nestedSentEnd) sentPos++;
-				t.sentPosition = sentPos;
-				t.subSentPosition = (i == nestedSentEnd || i == tokens[nestedSentEnd].pairedToken) ? 0 : subSentPos;
-				if (sentPos != lastSentPos) { accumWordPos = 0; accumSubSent = 1; }
-				else if (t.wordPosition != lastWordPos) accumWordPos++;
-				lastWordPos = t.wordPosition;
-				t.wordPosition = accumWordPos;
-				lastSentPos = sentPos;
-				lastNlPos = nlPos;
+			// ---- 1: lines ----
+			{
+				size_t seen = 0;
+				for (size_t i = 0; i < n; ++i)
+				{
+					while (seen < newlines.size() && newlines[seen] < tokens[i].position) ++seen;
+					line[i] = (uint32_t)seen;
+				}
+			}
+
+			// ---- 2: sentences ----
+			enum class Span { None, Opaque, SubSentences };      // what an open bracket pair is to the sentence count
+			Span span = Span::None; size_t spanEnd = 0;          // its closing token
+			std::vector<LateClaim> claims;
+			{
+				SentenceParser parser{ m };
+				uint32_t curSent = 0, curSub = 0, subsSoFar = 1;      // subsSoFar: sub-sentence number the next bracketed span of this sentence starts at
+				auto gluedSymbolBefore = [&](size_t i)      // token i - 1 is a symbol written onto token i, with a gap before it: it opens the new sentence
+				{
+					if (i < 2) return false;
+					const Token& p = tokens[i - 1];
+					const bool symbol = p.tag == T_SO || p.tag == T_SW || p.tag == T_SP || p.tag == T_SE || p.tag == T_SSO;
+					return symbol && p.endPos() == tokens[i].position && p.position > tokens[i - 2].endPos();
+				};
+				for (size_t i = 0; i < n; ++i)
+				{
+					const Token& t = tokens[i];
+					const uint32_t sentBefore = curSent;
+					const bool hidden = span == Span::Opaque && i < spanEnd;
+					const bool closesSubs = span == Span::SubSentences && i == spanEnd;
+					if (!hidden && parser.next(t, i ? line[i - 1] : 0, closesSubs))
+					{
+						if (span == Span::SubSentences)
+						{
+							++curSub; ++subsSoFar;
+							if (gluedSymbolBefore(i)) claims.push_back({ i - 1, curSub, false });
+						}
+						else
+						{
+							++curSent; subsSoFar = 1;
+							if (gluedSymbolBefore(i)) claims.push_back({ i - 1, curSent, true });
+						}
+					}
+					if (span == Span::None)
+					{
+						if (t.tag == T_SSO && t.pairedToken != (uint32_t)-1)
+						{
+							const size_t close = t.pairedToken;
+							if (!hasSentences(m, &tokens[i], &tokens[close])) { span = Span::Opaque; spanEnd = close; curSub = 0; }
+							else if ((close + 1 < n && nestedRight(tokens[close + 1])) || (i > 0 && nestedLeft(tokens[i - 1]))) { span = Span::SubSentences; spanEnd = close; curSub = subsSoFar; }
+						}
+					}
+					else if ((span == Span::SubSentences && i > spanEnd) || (span == Span::Opaque && i >= spanEnd)) { span = Span::None; spanEnd = 0; curSub = 0; }
+
+					// (a span that closes at token 0 cannot exist, so "no span" and "span ending at 0" coincide as in the reference's counters)
+					const size_t subsEnd = span == Span::SubSentences ? spanEnd : 0;
+					if (line[i] > (i ? line[i - 1] : 0) + 1 && curSent == sentBefore && span != Span::SubSentences) ++curSent;      // an empty line in between
+					sent[i] = curSent;
+					sub[i] = (i == subsEnd || i == tokens[subsEnd].pairedToken) ? 0 : curSub;
+					if (curSent != (i ? sent[i - 1] : 0)) subsSoFar = 1;
+				}
+			}
+
+			// ---- 3: word indices, then everything into the tokens ----
+			{
+				uint32_t word = 0, lastOriginal = 0;
+				for (size_t i = 0; i < n; ++i)
+				{
+					Token& t = tokens[i];
+					if (sent[i] != (i ? sent[i - 1] : 0)) word = 0;
+					else if (t.wordPosition != lastOriginal) ++word;
+					lastOriginal = t.wordPosition;
+					t.wordPosition = word; t.sentPosition = sent[i]; t.subSentPosition = sub[i]; t.lineNumber = line[i];
+				}
+				for (const LateClaim& c : claims)
+				{
+					if (c.sentence) { tokens[c.token].sentPosition = c.value; tokens[c.token].wordPosition = 0; }
+					else tokens[c.token].subSentPosition = c.value;
+				}
 			}
 		}
 

@@ -1,5 +1,5 @@
-// Host-side text preparation (see textprep.hpp).  Pattern recognisers restate the regular
-// languages documented in /root/reference/src/PatternMatcher.cpp:53-364 as small hand-written scanners.
+// Host-side text preparation (see textprep.hpp).  The pattern recognisers accept the regular languages of
+// /root/reference/src/PatternMatcher.cpp:53-364 (URL, e-mail, mention, hashtag, number, serial, abbreviation, emoji), written over a small cursor type.
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
@@ -40,197 +40,182 @@ namespace kamd
 
 		using P = const char16_t*;
 
-		// domain-ish run ending in ".xx": returns end of the last accepted TLD-like position
-		template<class Set>
-		P scanDomain(P b, P last, P none, Set&& set)
+		// The recognisers below are written over a cursor with the four moves they are made of -- take one unit of a class, take a given unit, take
+		// a run of a class, take a literal -- so that each of them reads as the shape of the pattern it accepts (the reference states the same
+		// languages as hand-expanded scanners over iterators, src/PatternMatcher.cpp:53-364; what is matched, and how much, is the same to the unit).
+		struct Cursor
 		{
-			int state = 0;
-			P lastMatched = none;
-			for (; b != last && set(*b); ++b)
+			P at, end;
+			bool more() const { return at != end; }
+			size_t left() const { return (size_t)(end - at); }
+			template<class Cls> bool peek(Cls&& cls) const { return at != end && cls(*at); }
+			bool peekUnit(char16_t u) const { return at != end && *at == u; }
+			template<class Cls> bool one(Cls&& cls) { if (!peek(cls)) return false; ++at; return true; }
+			bool unit(char16_t u) { if (!peekUnit(u)) return false; ++at; return true; }
+			template<class Cls> size_t run(Cls&& cls) { const P from = at; while (peek(cls)) ++at; return (size_t)(at - from); }
+			bool literal(const char* ascii)
 			{
-				if (*b == '.') state = 1;
-				else if (isAlpha(*b))
-				{
-					if (state > 0) ++state;
-					if (state >= 3) lastMatched = b + 1;
-				}
-				else state = 0;
+				const size_t n = std::strlen(ascii);
+				if (left() < n) return false;
+				for (size_t i = 0; i < n; ++i) if (at[i] != (char16_t)ascii[i]) return false;
+				at += n;
+				return true;
 			}
-			return lastMatched;
+			// steps back over ONE trailing unit of the given set (a pattern never ends in its own punctuation)
+			void unlessEndsIn(const char16_t* set) { for (; *set; ++set) if (at[-1] == *set) { --at; return; } }
+		};
+
+		// The longest prefix of the run of `cls` at `from` that ends in a top-level-domain-like tail: a '.', then two or more letters with nothing but
+		// letters since the dot.  Null when the run has no such point.
+		template<class Cls>
+		P domainTail(P from, P end, Cls&& cls)
+		{
+			P best = nullptr;
+			int lettersSinceDot = -1;      // -1: no dot yet, or something other than letters after it
+			for (P p = from; p != end && cls(*p); ++p)
+			{
+				if (*p == u'.') lettersSinceDot = 0;
+				else if (!isAlpha(*p)) lettersSinceDot = -1;
+				else if (lettersSinceDot >= 0 && ++lettersSinceDot >= 2) best = p + 1;
+			}
+			return best;
 		}
 
+		// http(s)://host.tld[:port][/path]
 		size_t testUrl(P first, P last)
 		{
-			P b;
-			auto starts = [&](const char* lit) { size_t n = std::strlen(lit); if ((size_t)(last - first) < n) return false; for (size_t i = 0; i < n; ++i) if (first[i] != (char16_t)lit[i]) return false; b = first + n; return true; };
-			if (!starts("http://") && !starts("https://")) return 0;
-			if (b == last || !csDomain(*b)) return 0;
-			++b;
-			P m = scanDomain(b, last, first, csDomain);
-			if (m == first) return 0;
-			b = m;
-			if (b != last && *b == ':')
-			{
-				++b;
-				if (b == last || !isDigit(*b)) return 0;
-				while (b != last && isDigit(*b)) ++b;
-			}
-			if (b != last && *b == '/')
-			{
-				++b;
-				while (b != last && csPath(*b)) ++b;
-			}
-			else if (b != last && !csSpace(*b)) return 0;
-			if (b[-1] == u'.' || b[-1] == u':') --b;
-			return b - first;
+			Cursor c{ first, last };
+			if (!c.literal("http://") && !c.literal("https://")) return 0;
+			if (!c.one(csDomain)) return 0;
+			const P host = domainTail(c.at, last, csDomain);
+			if (!host) return 0;
+			c.at = host;
+			if (c.unit(u':') && !c.run(isDigit)) return 0;
+			if (c.unit(u'/')) c.run(csPath);
+			else if (c.more() && !csSpace(*c.at)) return 0;
+			c.unlessEndsIn(u".:");
+			return (size_t)(c.at - first);
 		}
 
+		// account@host.tld
 		size_t testEmail(P first, P last)
 		{
-			P b = first;
-			if (b == last || !csEmailAccount(*b)) return 0;
-			while (b != last && csEmailAccount(*b)) ++b;
-			if (b == last || *b != '@') return 0;
-			++b;
-			if (b == last || !csAlnumDotDash(*b)) return 0;
-			++b;
-			return scanDomain(b, last, first, csAlnumDotDash) - first;
+			Cursor c{ first, last };
+			if (!c.run(csEmailAccount) || !c.unit(u'@') || !c.one(csAlnumDotDash)) return 0;
+			const P tail = domainTail(c.at, last, csAlnumDotDash);
+			return tail ? (size_t)(tail - first) : 0;
 		}
 
+		// @name: a letter, then account characters; at least four units in all
 		size_t testMention(P first, P last)
 		{
-			P b = first;
-			if (b == last || *b != '@') return 0;
-			++b;
-			if (b == last || !isAlpha(*b)) return 0;
-			++b;
-			while (b != last && csEmailAccount(*b)) ++b;
-			if (b[-1] == u'.' || b[-1] == u'%' || b[-1] == u'+' || b[-1] == u'-') --b;
-			if (b - first <= 3) return 0;
-			return b - first;
+			Cursor c{ first, last };
+			if (!c.unit(u'@') || !c.one(isAlpha)) return 0;
+			c.run(csEmailAccount);
+			c.unlessEndsIn(u".%+-");
+			const size_t n = (size_t)(c.at - first);
+			return n > 3 ? n : 0;
 		}
 
+		// #tag
 		size_t testHashtag(P first, P last)
 		{
-			P b = first;
-			if (b == last || *b != '#') return 0;
-			++b;
-			if (b == last || !csHashtag(*b)) return 0;
-			while (b != last && csHashtag(*b)) ++b;
-			return b - first;
+			Cursor c{ first, last };
+			if (!c.unit(u'#') || !c.run(csHashtag)) return 0;
+			return (size_t)(c.at - first);
 		}
 
+		// digits[,ddd]*[.digits] -- not when a further '.' follows (that is a serial number); `left` is the unit before `first`
 		size_t testNumeric(char16_t left, P first, P last)
 		{
-			P b = first;
-			bool hasComma = false;
-			if (b == last || !isDigit(*b)) return 0;
-			while (b != last && isDigit(*b)) ++b;
-			while (b != last && *b == ',')
+			Cursor c{ first, last };
+			if (!c.run(isDigit)) return 0;
+			bool grouped = false;
+			while (c.unit(u','))
 			{
-				++b;
-				if (b + 2 >= last || !isDigit(b[0]) || !isDigit(b[1]) || !isDigit(b[2])) return b - 1 - first;
-				b += 3;
-				hasComma = true;
+				if (c.left() < 3 || !isDigit(c.at[0]) || !isDigit(c.at[1]) || !isDigit(c.at[2])) return (size_t)(c.at - 1 - first);      // the comma was punctuation
+				c.at += 3;
+				grouped = true;
 			}
-			if (b == last || isSpace(*b) || isHangulSyllable(*b)) return b - first;
-			if (*b == '.')
+			if (!c.more() || isSpace(*c.at) || isHangulSyllable(*c.at)) return (size_t)(c.at - first);
+			if (c.unit(u'.'))
 			{
-				++b;
-				if (!hasComma && !csAlnumDotDash(left) && (b == last || !csAlnumDotDash(*b))) return b - first;
-				if (b == last || !isDigit(*b)) return b - 1 - first;
-				while (b != last && isDigit(*b)) ++b;
+				const bool standsAlone = !grouped && !csAlnumDotDash(left) && !c.peek(csAlnumDotDash);      // "3." of an enumeration: the point belongs to it
+				if (standsAlone) return (size_t)(c.at - first);
+				if (!c.run(isDigit)) return (size_t)(c.at - 1 - first);      // the point was punctuation
 			}
-			if (b == last || *b != '.') return b - first;
-			return 0;
+			return c.peekUnit(u'.') ? 0 : (size_t)(c.at - first);
 		}
 
+		// number SEP number [SEP number]*, SEP one of : . - / (the same throughout), a single blank allowed after each; with '.' three numbers at least
 		size_t testSerial(P first, P last)
 		{
-			P b = first;
-			if (b == last || !isDigit(*b)) return 0;
-			while (b != last && isDigit(*b)) ++b;
-			if (b == last) return 0;
-			const char16_t sep = *b;
-			if (!(sep == ':' || sep == '.' || sep == '-' || sep == '/')) return 0;
-			++b;
-			if (b != last && *b == ' ') ++b;
-			if (b == last || !isDigit(*b)) return 0;
-			while (b != last && isDigit(*b)) ++b;
-			if (sep == '.' && (b == last || *b != sep)) return 0;
-			while (b != last && *b == sep)
+			Cursor c{ first, last };
+			if (!c.run(isDigit) || !c.more()) return 0;
+			const char16_t sep = *c.at;
+			if (sep != u':' && sep != u'.' && sep != u'-' && sep != u'/') return 0;
+			++c.at;
+			c.unit(u' ');
+			if (!c.run(isDigit)) return 0;
+			if (sep == u'.' && !c.peekUnit(sep)) return 0;
+			while (c.unit(sep))
 			{
-				++b;
-				if (b != last && *b == ' ') ++b;
-				if (b == last || !isDigit(*b)) break;
-				while (b != last && isDigit(*b)) ++b;
+				c.unit(u' ');
+				if (!c.run(isDigit)) break;
 			}
-			if (b[-1] == ' ') --b;
-			return b - first;
+			c.unlessEndsIn(u" ");
+			return (size_t)(c.at - first);
 		}
 
+		// an abbreviation: letters '.', either followed by a blank (short word) or continued as letters '.' letters '.' ... (each part at most five letters)
 		size_t testAbbr(P first, P last)
 		{
-			P b = first;
-			if (b == last || !isAlpha(*b)) return 0;
-			size_t l = 0;
-			while (b != last && isAlpha(*b)) ++b, ++l;
-			if (b == last || *b != '.') return 0;
-			++b;
-			if (b != last && *b == ' ')
+			Cursor c{ first, last };
+			size_t letters = c.run(isAlpha);
+			if (!letters || !c.unit(u'.')) return 0;
+			if (c.peekUnit(u' ')) return letters > (isUpper(*first) ? 5u : 3u) ? 0 : (size_t)(c.at - first);
+			if (letters > 5) return 0;
+			while (c.peek(isAlpha))
 			{
-				if (l > (isUpper(*first) ? 5u : 3u)) return 0;
-				return b - first;
+				letters = c.run(isAlpha);
+				if (letters > 5) return 0;
+				if (!c.unit(u'.')) return (size_t)(c.at - first);
 			}
-			if (l > 5) return 0;
-			while (b != last && isAlpha(*b))
-			{
-				l = 0;
-				while (b != last && isAlpha(*b)) ++b, ++l;
-				if (l > 5) return 0;
-				if (b != last && *b == '.') ++b;
-				else return b - first;
-			}
-			if (b[-1] == ' ') --b;
-			return b - first;
+			c.unlessEndsIn(u" ");
+			return (size_t)(c.at - first);
 		}
 
+		// one code point at p (a surrogate pair when it is whole), 0 at the end; `next` = where the following one starts
+		inline uint32_t codePointAt(P p, P end, bool pairNeedsBoth, P& next)
+		{
+			if (p >= end) { next = p; return 0; }
+			if (isHighSurrogate(*p) && (!pairNeedsBoth || p + 1 < end)) { next = p + 2; return mergeSurrogate(p[0], p[1]); }
+			next = p + 1;
+			return *p;
+		}
+
+		// emoji [variation selector | skin tone] [ZWJ emoji ...]
 		size_t testEmoji(P first, P last)
 		{
-			P b = first;
-			while (b + 1 < last)
+			P p = first;
+			while (p + 1 < last)
 			{
-				uint32_t c0, c1 = 0;
-				P b1 = b;
-				if (isHighSurrogate(*b1)) { c0 = mergeSurrogate(b1[0], b1[1]); b1 += 2; }
-				else c0 = *b1++;
-				P b2 = b1;
-				if (b2 < last)
+				P afterFirst, afterSecond;
+				const uint32_t c0 = codePointAt(p, last, false, afterFirst);
+				const uint32_t c1 = codePointAt(afterFirst, last, true, afterSecond);
+				const int kind = isEmoji(c0, c1);      // 1: c0 alone is an emoji; 2: only together with the selector / skin tone c1
+				if (kind == 1) p = afterFirst; else if (kind == 2) p = afterSecond; else break;
+				if (p == last) break;
+				if (0xfe00 <= *p && *p <= 0xfe0f) ++p;      // variation selector
+				else if (p + 1 < last && isHighSurrogate(*p))
 				{
-					if (isHighSurrogate(*b2) && b2 + 1 < last) { c1 = mergeSurrogate(b2[0], b2[1]); b2 += 2; }
-					else c1 = *b2++;
+					const uint32_t tone = mergeSurrogate(p[0], p[1]);
+					if (0x1f3fb <= tone && tone <= 0x1f3ff) p += 2;
 				}
-				const int r = isEmoji(c0, c1);
-				if (r == 1) b = b1; else if (r == 2) b = b2; else break;
-				if (b == last) return b - first;
-				if (0xfe00 <= *b && *b <= 0xfe0f)
-				{
-					++b;
-					if (b == last) return b - first;
-				}
-				else if (b + 1 < last && isHighSurrogate(b[0]))
-				{
-					const uint32_t m = mergeSurrogate(b[0], b[1]);
-					if (0x1f3fb <= m && m <= 0x1f3ff)
-					{
-						b += 2;
-						if (b == last) return b - first;
-					}
-				}
-				if (*b == 0x200d) { ++b; continue; }
-				break;
+				if (p == last || *p != 0x200d) break;
+				++p;      // zero-width joiner: another emoji may follow
 			}
-			return b - first;
+			return (size_t)(p - first);
 		}
 	}
 

@@ -24,6 +24,7 @@
 #include <numeric>
 
 #include <kiwi/Kiwi.h>
+#include <kiwi/PatternMatcher.h>
 #include <kiwi/Utils.h>
 #include <kiwi/Form.h>
 #include <kiwi/Knlm.h>
@@ -690,6 +691,13 @@ extern "C"
 	// ---- typo graphs: the reference's TypoTransformer / PreparedTypoTransformer, public API only --------
 	// A transformer is filled either rule by rule (TypoTransformer::addTypo: normalisation + jamo expansion inside) or by replaying,
 	// entry by entry, one of the built-in sets (TypoTransformer::update, which inserts in the iteration order of the source map).
+	// the reference's pattern recogniser at one position (src/PatternMatcher.cpp:380): length | tag << 32, 0 = no pattern
+	uint64_t kref_match_pattern(uint16_t left, const uint16_t* text, uint32_t len, uint64_t match)
+	{
+		const auto r = kiwi::matchPattern((char16_t)left, (const char16_t*)text, (const char16_t*)text + len, (kiwi::Match)match);
+		return (uint64_t)r.first | ((uint64_t)(uint8_t)r.second << 32);
+	}
+
 	void* kref_typo_new(float continualCost, float lengtheningCost)
 	{
 		auto* h = new TypoHandle;

@@ -339,3 +339,14 @@ class RefTypo:
             self.lib.kref_typo_close(self.h)
         except Exception:
             pass
+
+
+def match_pattern(left: str, text: str, match: int):
+    """The reference's matchPattern (src/PatternMatcher.cpp:380) at text[0], `left` = the UTF-16 unit before it: (matched length, tag)."""
+    import numpy as np
+    lib = _lib()
+    lib.kref_match_pattern.restype = C.c_uint64
+    lib.kref_match_pattern.argtypes = [C.c_uint16, C.c_void_p, C.c_uint32, C.c_uint64]
+    u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+    r = int(lib.kref_match_pattern(ord(left), u.ctypes.data, len(u), match))
+    return r & 0xFFFFFFFF, r >> 32
