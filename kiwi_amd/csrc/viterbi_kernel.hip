@@ -328,7 +328,7 @@ namespace sbgk
 		}
 	}
 
-	// developer statistics of the emulated build (make -C tests/hipemu EXTRA=-DKAMD_LMSTATS): which way lmProgressChain's calls go, printed at exit
+	// developer statistics of a host (lane-emulated) build with -DKAMD_LMSTATS: which way the calls of lmProgressChain go, printed at exit
 #ifdef KAMD_LMSTATS
 	struct LmStats { std::atomic<unsigned long long> c[16]; ~LmStats() { fprintf(stderr, "[lmstats] calls %llu root-start %llu hit0-child %llu hit0-leaf %llu ovf0 %llu hit1-child %llu hit1-leaf %llu ovf1 %llu n2 %llu root-unk %llu root-child %llu root-leaf %llu walk %llu\n",
 		c[0].load(), c[1].load(), c[2].load(), c[3].load(), c[4].load(), c[5].load(), c[6].load(), c[7].load(), c[8].load(), c[9].load(), c[10].load(), c[11].load(), c[12].load()); } };
