@@ -365,6 +365,18 @@ class Typo:
         lib.kamd_typo_prepare.argtypes = [C.c_void_p, C.c_int]
         self.h = lib.kamd_typo_new(continual, lengthening)
 
+    @classmethod
+    def from_default(cls, lib, default_typo_set: int):
+        """A copy of one of Kiwi's built-in typo sets (reference DefaultTypoSet 0..6: kamd_typo_default)."""
+        self = cls(lib)
+        lib.kamd_typo_close(self.h)
+        lib.kamd_typo_default.restype = C.c_void_p
+        lib.kamd_typo_default.argtypes = [C.c_int]
+        self.h = lib.kamd_typo_default(default_typo_set)
+        if not self.h:
+            raise ValueError(default_typo_set)
+        return self
+
     def add(self, orig, error, cost=1.0, cond=0, dialect=0):
         o = np.frombuffer(orig.encode("utf-16-le"), np.uint16)
         e = np.frombuffer(error.encode("utf-16-le"), np.uint16)

@@ -54,6 +54,23 @@ assert MORPH_DTYPE.itemsize == 32
 
 SEED_BASE = 0x4B495749  # "KIWI" 
 
+TAG_NAMES = ("UN", "NNG", "NNP", "NNB", "VV", "VA", "MAG", "NR", "NP", "VX", "MM", "MAJ", "IC", "XPN", "XSN", "XSV", "XSA", "XSM", "XR", "VCP", "VCN",
+             "SF", "SP", "SS", "SSO", "SSC", "SE", "SO", "SW", "SB", "SL", "SH", "SN", "W_URL", "W_EMAIL", "W_MENTION", "W_HASHTAG", "W_SERIAL", "W_EMOJI",
+             "JKS", "JKC", "JKG", "JKO", "JKB", "JKV", "JKQ", "JX", "JC", "EP", "EF", "EC", "ETN", "ETM", "Z_CODA", "Z_SIOT")
+
+
+def tag_id(name: str):
+    """Tag id of a tag as the reference prints it ("VV", "VV-I" = irregular, "VV-R" = marked regular); None when it is not a tag of the table."""
+    base, _, suffix = name.partition("-")
+    if base not in TAG_NAMES:
+        return None
+    return TAG_NAMES.index(base) | (IRREGULAR if suffix == "I" else 0)
+
+
+# compatibility jamo that stand for a coda (U+11A8 + index), in the order of the coda jamo block
+_COMPAT_CODA = (0x3131, 0x3132, 0x3133, 0x3134, 0x3135, 0x3136, 0x3137, 0x3139, 0x313A, 0x313B, 0x313C, 0x313D, 0x313E, 0x313F, 0x3140,
+                0x3141, 0x3142, 0x3144, 0x3145, 0x3146, 0x3147, 0x3148, 0x314A, 0x314B, 0x314C, 0x314D, 0x314E)
+
 
 def cv(onset: int, vowel: int) -> str:
     return chr(0xAC00 + (onset * 21 + vowel) * 28)
@@ -310,6 +327,7 @@ class SynthSpec:
     cong_qgroup: int = 0
     use_nounchr: bool = False    # also emit a character-level CoNgram model (reference nounchr.mdl: Match::oovChrModel scores unknown forms with it, src/UnkFormScorer.cpp)
     cong_window: int = 0         # > 0: the file also carries the sections of the global model (confidences, distant embeddings, mask), as the reference's builder always writes them
+    extra_words: tuple = ()      # ((form, tag name), ...): real-text dictionary entries added to the generated lexicon (the eval_data parity corpus, workloads.eval_model)
     seed: int = SEED_BASE
 
 
@@ -329,6 +347,12 @@ MID_CONG_VL4_SPEC = SynthSpec(n_words=66000, use_cong=True, cong_only=True, cong
 SMALL_CONG_SPEC = SynthSpec(use_cong=True) # same lexicon as SMALL_SPEC + a local CoNgram model (the Knlm blob stays in the container: the dictionary bake needs a vocabulary size)
 FULL_CONG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
                            n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_cong=True, cong_dim=64, cong_only=True)
+
+
+# grammatical class (of the sentence grammar below) a caller-given dictionary entry joins, by tag
+_CLASS_OF_TAG = {NNG: "noun", NNP: "noun", NNB: "noun", NP: "noun", NR: "noun", XR: "noun", VV: "verb", VX: "verb", VA: "adj", MAG: "adv", MAJ: "adv", IC: "adv",
+                 MM: "det", XPN: "xpn", XSN: "xsn", XSV: "xsv", XSA: "xsa", XSM: "xsm", VCP: "vcp", VCN: "vcn", JKS: "josa", JKC: "josa", JKG: "josa", JKO: "josa",
+                 JKB: "josa", JKV: "josa", JKQ: "josa", JX: "josa", JC: "josa", EP: "ep", EF: "ef", EC: "ec", ETN: "etn", ETM: "etm"}
 
 
 class SynthModel:
@@ -461,6 +485,21 @@ class SynthModel:
         for q in ("'", '"'):
             for tag in (SSO, SSC, SS):
                 raw.add_morph(q, tag)
+
+        # dictionary entries given by the caller (real text): a form is normalised as the dictionary holds it (syllable + split-out coda; a
+        # compatibility consonant such as the 'ㄴ' of the gold annotations is the coda jamo it stands for)
+        for form, tag_name in sp.extra_words:
+            tid = tag_id(tag_name)
+            cls = _CLASS_OF_TAG.get(tid & 0x7F)
+            if tid is None or cls is None:
+                continue
+            s = normalize_hangul("".join(chr(0x11A8 + _COMPAT_CODA.index(ord(ch))) if ord(ch) in _COMPAT_CODA else ch for ch in form))
+            if not s or " " in s:
+                continue
+            fid = raw.form_map.get(s)
+            if fid is not None and any(raw.morphs[m].tag == tid for m in raw.form_cands[fid]):
+                continue
+            lex.add(cls, raw.add_morph(s, tid, vowel=CV_VOWEL if is_coda(s[0]) else CV_NONE))
 
         base_end = len(raw.morphs)
 

@@ -97,6 +97,22 @@ def _spec(name):
     return {"full": FULL_SPEC, "full-sbg": FULL_SBG_SPEC, "small": SMALL_SPEC, "full-cong": FULL_CONG_SPEC, "small-cong": SMALL_CONG_SPEC}[name]
 
 
+def eval_model():
+    """The small synthetic model with the gold (form, tag) pairs of the reference's eval_data files as additional dictionary entries
+    (tests/golden/eval_data_lexicon.json, written by tools/make_golden_eval.py): real text then meets a lattice of real dictionary words; the language
+    model stays synthetic.  Returns (raw model path, number of entries the lexicon file holds)."""
+    import json
+    from dataclasses import replace
+    from .synth import SMALL_SPEC, SynthModel
+    lex_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "eval_data_lexicon.json")
+    entries = json.load(open(lex_path, encoding="utf-8"))["entries"]
+    os.makedirs(DATA, exist_ok=True)
+    path = os.path.join(DATA, "small-eval.raw")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(lex_path):
+        SynthModel(replace(SMALL_SPEC, extra_words=tuple((f, t) for f, t in entries))).raw.save(path)
+    return path, len(entries)
+
+
 def get_workload(name: str):
     """Returns (raw_model_path, list_of_texts, description)."""
     spec_name, n, kw, idx = WORKLOADS[name]
