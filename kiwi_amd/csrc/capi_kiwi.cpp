@@ -22,12 +22,27 @@ using namespace kamd;
 
 struct kiwi_s
 {
-	std::unique_ptr<Engine> engine;                      // device 0: single-text calls, configuration
-	std::vector<std::unique_ptr<Engine>> replicas;       // devices 1 .. N-1 (every visible GPU, or KAMD_DEVICES of them): kiwi_analyze_m / _mw spread a batch over all
+	std::unique_ptr<Engine> engine;                      // on the caller's current device at kiwi_init: single-text calls, configuration
+	// replicas of the device tables on the other visible GPUs (KAMD_DEVICES=n limits it; 1 = single-GPU behaviour): created by the first kiwi_analyze_m /
+	// _mw call, which spreads a batch over all of them -- a process that only calls kiwi_analyze, or one rank of a one-process-per-GPU job that did not
+	// narrow HIP_VISIBLE_DEVICES, allocates nothing on the other GPUs
+	std::vector<std::unique_ptr<Engine>> replicas;
+	std::mutex replicaMu; bool replicasMade = false;
 	int numThreads = 0;
 	int batchSize = 65536;
 	Engine& device(size_t d) { return d == 0 ? *engine : *replicas[d - 1]; }
 	size_t devices() const { return 1 + replicas.size(); }
+	void makeReplicas()
+	{
+		std::lock_guard<std::mutex> g{ replicaMu };
+		if (replicasMade) return;
+		int nDev = Engine::visibleDevices();
+		if (const char* e = std::getenv("KAMD_DEVICES")) nDev = std::max(1, std::min(nDev, std::atoi(e)));
+		const int own = engine->deviceIndex();
+		for (int d = 0; d < Engine::visibleDevices() && (int)replicas.size() + 1 < nDev; ++d) if (d != own) replicas.emplace_back(new Engine(*engine, d));
+		engine->bindThread();      // (opening a replica made its device the thread's current one)
+		replicasMade = true;
+	}
 };
 
 struct kiwi_typo { kamd::TypoTransformer tt; };                       // capi.h:35
@@ -169,6 +184,7 @@ namespace
 	int analyzeMany(kiwi_h h, ReadFn&& readNext, kiwi_receiver_t receiver, void* ud, int topN, const kiwi_analyze_option_t& opt)
 	{
 		checkOption(opt, nullptr);
+		h->makeReplicas();
 		struct Job
 		{
 			std::vector<std::u16string> texts;
@@ -419,13 +435,9 @@ extern "C"
 			if (enabled_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported" };
 			const std::string path = model_path ? model_path : "";      // a directory with sj.morph + sj.knlm (+ skipbigram.mdl) or kiwi_amd.raw, or a raw container file
 			auto h = std::make_unique<kiwi_s>();
-			h->engine.reset(new Engine(path, 0, lm));
-			if (knlmUnlessCong && !h->engine->usesCong() && h->engine->usesSbg()) h->engine.reset(new Engine(path, 0, Engine::LmMode::Knlm));
+			h->engine.reset(new Engine(path, -1, lm));      // (-1: the caller's current device)
+			if (knlmUnlessCong && !h->engine->usesCong() && h->engine->usesSbg()) h->engine.reset(new Engine(path, -1, Engine::LmMode::Knlm));
 			h->engine->config.integrateAllomorph = !!(options & 1);
-			// a replica of the device tables on every other visible GPU (KAMD_DEVICES=n limits it; 1 = single-GPU behaviour)
-			int nDev = Engine::visibleDevices();
-			if (const char* e = std::getenv("KAMD_DEVICES")) nDev = std::max(1, std::min(nDev, std::atoi(e)));
-			for (int d = 1; d < nDev; ++d) h->replicas.emplace_back(new Engine(*h->engine, d));
 			h->numThreads = num_threads < 0 ? 0 : (num_threads == 0 ? 1 : num_threads);
 			return h.release();
 		}

@@ -234,6 +234,8 @@ namespace kamd
 		}
 	};
 
+	int Engine::deviceIndex() const { return impl->device; }
+	void Engine::bindThread() const { (void)hipSetDevice(impl->device); }
 	int Engine::visibleDevices()
 	{
 		int n = 0;
@@ -270,7 +272,7 @@ namespace kamd
 		int nDev = 0;
 		if (hipGetDeviceCount(&nDev) != hipSuccess || nDev == 0)
 			throw std::runtime_error{ "kiwi_amd: no HIP device visible -- the analyze path has no CPU fallback" };
-		if (device < 0) device = 0;
+		if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;      // -1: the calling thread's current device (device 0 unless the caller chose another)
 		impl->device = device;
 		HIPCHECK(hipSetDevice(device));
 		HIPCHECK(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));

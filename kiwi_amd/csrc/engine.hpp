@@ -69,6 +69,8 @@ namespace kamd
 		explicit Engine(const std::string& rawModelPath, int device = -1, LmMode lm = LmMode::Auto);
 		Engine(const Engine& other, int device);      // replica of `other` on another GPU (shares the baked host model)
 		static int visibleDevices();
+		int deviceIndex() const;      // the HIP device this engine's tables and streams live on
+		void bindThread() const;      // makes that device the calling thread's current one
 		bool usesCong() const; bool usesSbg() const;      // which language model scores the search
 		~Engine();
 		const FlatModel& model() const;
