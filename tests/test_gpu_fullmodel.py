@@ -2,6 +2,7 @@
 (BASELINE config 2: 8192 x 40-jamo; config 3's corpus: mixed 5-200 jamo) -- device vs the real reference translation units
 (oracle/_ref, when the prebuilt library travelled) and vs the CPU oracle: tokens, positions and fp32 path scores, bit for bit.
 bench.py's numbers are for exactly these outputs."""
+import os
 from dataclasses import astuple
 
 import pytest
@@ -131,3 +132,46 @@ def test_position_step_kernel_equals_general_kernel_on_whole_corpora(monkeypatch
     b = _packed(gen, texts)
     gen.close()
     assert a.nbytes == b.nbytes and np.array_equal(a, b)
+
+
+def test_c3_sbg_2k_sentences_top3_vs_oracle_and_reference():
+    """BASELINE config 3 on its own model: the 'full-sbg' synthetic model (Knlm + SkipBigram), 2048 mixed 5-200 jamo sentences of its
+    lexicon (the c3 corpus), top-3 -- device vs the CPU oracle, analysis for analysis with fp32 scores, and vs the REAL reference where its
+    library travelled: identical score lists for every text; identical analyses except where exactly tied analyses come out in the reference's
+    hash-bucket order (tests/test_oracle_vs_ref.py::test_top_n_matches_reference_up_to_exact_ties states that rule).  The CPU sides run on a thread
+    pool (ctypes releases the GIL): SkipBigram lattices on this model take tens of milliseconds per sentence on one core."""
+    from concurrent.futures import ThreadPoolExecutor
+    import oraclelib
+    import refbridge
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+    from kiwi_amd.workloads import DATA
+    _, texts, _ = get_workload("c3")      # (the same mixed 5-200 jamo sentence generator as c3-sbg over the same lexicon; its corpus file travels anyway)
+    path = os.path.join(DATA, "full-sbg.raw")
+    if not os.path.exists(path):
+        path, _, _ = get_workload("c3-sbg")      # (generates the model: minutes)
+    texts = texts[:2048]
+    dev = KiwiAmd(path)
+    got = dev.analyze_batch(texts, top_n=3).to_python()
+    dev.close()
+    workers = max(4, min(64, (os.cpu_count() or 8) // 2))
+
+    def cpu_side(make):
+        import threading
+        local = threading.local()
+
+        def one(s):
+            if not hasattr(local, "k"):
+                local.k = make()
+            return local.k.analyze(s, top_n=3)
+        with ThreadPoolExecutor(workers) as ex:
+            return list(ex.map(one, texts))
+
+    want = cpu_side(lambda: oraclelib.OracleKiwi(path))
+    bad = [s for s, w, y in zip(texts, want, got) if _norm(w) != _norm(y)]
+    assert not bad, (len(bad), bad[:2])
+    if refbridge.available():
+        ref = cpu_side(lambda: refbridge.RefKiwi(path))
+        assert all([a[1] for a in r] == [a[1] for a in y] for r, y in zip(ref, got))
+        same = sum(_norm(r) == _norm(y) for r, y in zip(ref, got))
+        assert same >= 0.6 * len(texts), same
