@@ -169,6 +169,7 @@ namespace kamd
 		uint8_t* spaceErr;      // BuildNode16 only
 		const ModelView* M; const SearchParams* P;
 		const uint16_t* str; const uint16_t* nsToPos; const uint16_t* posToNs;
+		const uint8_t* cflag;      // per unit: bit 0 = not a space (k_dict_scan)
 		NodeT* out; uint32_t* endPosMap; uint64_t* fullMask; uint8_t* zAt; uint32_t nOut, cap; bool overflow;
 		uint32_t lastEnd = 0;   // end position of the most recently appended node (what insertUnkForm asks for), kept out of the node list
 		__device__ __forceinline__ void setSpaceErrors(uint32_t id, uint8_t v) { if constexpr (sizeof(NodeT) == sizeof(DevNode)) out[id].spaceErrors = v; else spaceErr[id] = v; }
@@ -273,7 +274,8 @@ namespace kamd
 	template<class LC>
 	__device__ __forceinline__ void latTrim(const LC& L, uint32_t off, uint32_t len, uint32_t& o, uint32_t& l)
 	{
-		while (len && isSpace(L.str[off + len - 1])) --len;
+		// (the space test is the dictionary scan's, one flag byte per unit: the 23-way character test inlined at every call was 40 % of this kernel's scalar code)
+		while (len && !(L.cflag[off + len - 1] & 1)) --len;
 		o = off; l = len;
 	}
 
@@ -674,7 +676,7 @@ namespace kamd
 			}
 		}
 		LatticeCtxT<BuildNode16> L;
-		L.M = &M; L.P = &P; L.str = str; L.nsToPos = nsToPos; L.posToNs = posToNs;
+		L.M = &M; L.P = &P; L.str = str; L.nsToPos = nsToPos; L.posToNs = posToNs; L.cflag = cflag;
 		L.spaceErr = lS + lay.spaceErr;
 		L.out = reinterpret_cast<BuildNode16*>(lS + lay.out); L.endPosMap = reinterpret_cast<uint32_t*>(lS + lay.endPosMap);
 		L.fullMask = reinterpret_cast<uint64_t*>(lS + lay.fullMask); L.zAt = lS + lay.zAt; L.nOut = 0; L.cap = latticeLdsCap(n, cap); L.overflow = false;
@@ -750,7 +752,7 @@ namespace kamd
 		const uint8_t* cls = B.cls + cOff;
 		LatticeCtx L;
 		L.spaceErr = nullptr;
-		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk;
+		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk; L.cflag = W.cflag + cOff;
 		L.out = W.tmpNodes + nBase; L.endPosMap = W.endPosMap + cOff + chunk; L.fullMask = W.fullMask + cOff + chunk; L.zAt = W.zAt + cOff + chunk; L.nOut = 0; L.cap = cap; L.overflow = false;
 		const uint32_t nMap = nNs + 1;
 		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { W.results[chunk].status = CS_ERR_TOO_LONG; return; }
