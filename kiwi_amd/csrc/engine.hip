@@ -772,7 +772,7 @@ namespace kamd
 			// position-step search first (viterbi_pos.inc): top-1, 16-lane groups, not for SkipBigram models; what it cannot finish is resumed by the general kernel below
 			const bool usePos = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S == 1;
 			if (usePos)
-				hipLaunchKernelGGL(k_expand_pos, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, b.typo.typo ? b.dNodeTypo.as<float>() : (const float*)nullptr, (I.hasCong && b.wv.unkChr) ? 1u : 0u);
+				hipLaunchKernelGGL(k_expand_pos, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, b.typo.typo ? b.dNodeTypo.as<float>() : (const float*)nullptr, ((I.hasCong && b.wv.unkChr) ? 1u : 0u) | (I.hasCong ? 2u : 0u));      // (bit 0: unknown forms scored by the character model; bit 1: a CoNgram model)
 			HIPCHECK(hipEventRecord(e[2], sA));
 			HIPCHECK(hipStreamWaitEvent(sB, e[2], 0));
 			HIPCHECK(hipEventRecord(e[3], sB));

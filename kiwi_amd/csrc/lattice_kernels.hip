@@ -169,7 +169,6 @@ namespace kamd
 		uint8_t* spaceErr;      // BuildNode16 only
 		const ModelView* M; const SearchParams* P;
 		const uint16_t* str; const uint16_t* nsToPos; const uint16_t* posToNs;
-		const uint8_t* cflag;      // per unit: bit 0 = not a space (k_dict_scan)
 		NodeT* out; uint32_t* endPosMap; uint64_t* fullMask; uint8_t* zAt; uint32_t nOut, cap; bool overflow;
 		uint32_t lastEnd = 0;   // end position of the most recently appended node (what insertUnkForm asks for), kept out of the node list
 		__device__ __forceinline__ void setSpaceErrors(uint32_t id, uint8_t v) { if constexpr (sizeof(NodeT) == sizeof(DevNode)) out[id].spaceErrors = v; else spaceErr[id] = v; }
@@ -274,8 +273,8 @@ namespace kamd
 	template<class LC>
 	__device__ __forceinline__ void latTrim(const LC& L, uint32_t off, uint32_t len, uint32_t& o, uint32_t& l)
 	{
-		// (the space test is the dictionary scan's, one flag byte per unit: the 23-way character test inlined at every call was 40 % of this kernel's scalar code)
-		while (len && !(L.cflag[off + len - 1] & 1)) --len;
+		// (NOT the dictionary scan's non-space flag: that one also counts the unit after a lone high surrogate as part of a pair)
+		while (len && isSpace(L.str[off + len - 1])) --len;
 		o = off; l = len;
 	}
 
@@ -676,7 +675,7 @@ namespace kamd
 			}
 		}
 		LatticeCtxT<BuildNode16> L;
-		L.M = &M; L.P = &P; L.str = str; L.nsToPos = nsToPos; L.posToNs = posToNs; L.cflag = cflag;
+		L.M = &M; L.P = &P; L.str = str; L.nsToPos = nsToPos; L.posToNs = posToNs;
 		L.spaceErr = lS + lay.spaceErr;
 		L.out = reinterpret_cast<BuildNode16*>(lS + lay.out); L.endPosMap = reinterpret_cast<uint32_t*>(lS + lay.endPosMap);
 		L.fullMask = reinterpret_cast<uint64_t*>(lS + lay.fullMask); L.zAt = lS + lay.zAt; L.nOut = 0; L.cap = latticeLdsCap(n, cap); L.overflow = false;
@@ -752,7 +751,7 @@ namespace kamd
 		const uint8_t* cls = B.cls + cOff;
 		LatticeCtx L;
 		L.spaceErr = nullptr;
-		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk; L.cflag = W.cflag + cOff;
+		L.M = &M; L.P = &P; L.str = str; L.nsToPos = W.nsToPos + cOff + chunk; L.posToNs = W.posToNs + cOff + chunk;
 		L.out = W.tmpNodes + nBase; L.endPosMap = W.endPosMap + cOff + chunk; L.fullMask = W.fullMask + cOff + chunk; L.zAt = W.zAt + cOff + chunk; L.nOut = 0; L.cap = cap; L.overflow = false;
 		const uint32_t nMap = nNs + 1;
 		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { W.results[chunk].status = CS_ERR_TOO_LONG; return; }
@@ -868,7 +867,7 @@ namespace kamd
 		if (!(flags & MF_SINGLE) && (flags & MF_HA_CONTRACTION) && spaceBefore) return 0;
 		return 1;
 	}
-	__global__ void __launch_bounds__(64) k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr)
+	__global__ void __launch_bounds__(64) k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr)      // useChr: bit 0 = unknown forms are scored by the character model, bit 1 = a CoNgram model
 	{
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t lane = threadIdx.x;
@@ -978,11 +977,10 @@ namespace kamd
 		for (uint32_t i = 1 + lane; i + 1 < G; i += 64)
 		{
 			const DevNode nd = nodes[i];
-			uint32_t j0 = i;
-			while (j0 > 1 && nodes[j0 - 1].endPos == nd.endPos) --j0;
-			const uint32_t nl = i - j0;
+			const uint32_t nr = nodeRec[i];
+			const uint32_t nl = i - desc[(nr >> 18) & 0x1FFFu].firstNode;      // the node's index inside its position (pass A numbered the positions)
 			if (nl >= 16) continue;      // (its position is marked slow)
-			PosRec* out = recs + (nodeRec[i] & 0x3FFFFu);
+			PosRec* out = recs + (nr & 0x3FFFFu);
 			float ws = 0;
 			if (!nd.uformLen && nd.form != NOFORM && nd.flen && nd.spaceErrors) ws = -P.spacePenalty * (float)nd.spaceErrors;
 			const float tc = nodeTypoAll ? nodeTypoAll[nBase + i] : 0.f;
@@ -1010,6 +1008,7 @@ namespace kamd
 			// CoNgram: do the regular candidates of one evaluation share their first word?  (decides which of the reference's kernels rounds their scores)
 			auto sharedFirstWord = [&](const CandStatic* cl, uint32_t n) -> uint32_t
 			{
+				if (!(useChr & 2u)) return 0u;      // (only the CoNgram kernels read the flag)
 				uint32_t nReg = 0, ref = 0; bool one = true;
 				for (uint32_t k = 0; k < n; ++k)
 				{
@@ -1052,7 +1051,7 @@ namespace kamd
 					uint16_t of = featMask(M.formChars + f.charOff, f.len) & 0x1FFF;
 					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
 					float disc;
-					if (useChr) disc = baseDiscount + (M.formUnkChr[nd.form] - P.oovChrBias);
+					if (useChr & 1u) disc = baseDiscount + (M.formUnkChr[nd.form] - P.oovChrBias);
 					else disc = baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias);
 					emit(unkPacks + 1, disc, 2, of, (uint32_t)PR_PASS1 | sharedFirstWord(unkPacks + 1, 1));
 				}
@@ -1062,7 +1061,7 @@ namespace kamd
 				// unknown form: the two unknown-noun candidates (PathEvaluator.hpp:1204-1206, 1300-1318), scored by UnkFormScorer (src/UnkFormScorer.h:40-58)
 				const float emo = (cls[nd.uformOff] & 0x80) ? -10.f : 0.f;
 				float disc;
-				if (useChr) disc = baseDiscount + (W.unkChr[nBase + i] - P.oovChrBias);
+				if (useChr & 1u) disc = baseDiscount + (W.unkChr[nBase + i] - P.oovChrBias);
 				else disc = baseDiscount + (emo - ((float)nd.uformLen * P.oovRuleScale + P.oovRuleBias));
 				const uint32_t of0 = sharedFirstWord(unkPacks, 2);
 				emit(unkPacks, disc, ownKind0, nd.ownFeat, of0);

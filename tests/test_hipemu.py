@@ -14,7 +14,7 @@ from dataclasses import astuple
 
 import pytest
 
-from corpora import EDGE_TEXTS, dictionary_mix, force_lanes, synthetic
+from corpora import EDGE_TEXTS, dictionary_mix, force_lanes, fuzzed, synthetic
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU = os.path.join(HERE, "hipemu")
@@ -57,7 +57,7 @@ def test_emulated_knlm_kernels_match_oracle(emu_libs, oracle, small_model, monke
     if lanes in ("8", "16", "pos"):
         monkeypatch.setenv("KAMD_WPS", wps)
     n = 100 if lanes in ("16", "pos") and wps == "2" else 40
-    texts = synthetic(sm, n, 521, min_jamo=5, max_jamo=120) + dictionary_mix(sm, n // 2, 522) + (EDGE_TEXTS if n == 100 else [])
+    texts = synthetic(sm, n, 521, min_jamo=5, max_jamo=120) + dictionary_mix(sm, n // 2, 522) + (EDGE_TEXTS + fuzzed(sm, 150, 523) if n == 100 else [])      # (fuzzed: lone surrogates, pattern fragments, other scripts)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     _check(dev, oracle, texts, (1, 2))
     if n == 100:
