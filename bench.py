@@ -74,7 +74,7 @@ def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None, time_refe
     # scheduled on a fraction of them); the baseline cannot scale beyond it
     usable = oraclelib.cpu_capacity(cores, 1.0)
     out["cpu_baseline"] = {"value": rate, "unit": "sentences/s", "cores": cores, "kind": kind,
-                           "threads": cores, "physical_cores": phys, "usable_cores_measured": usable, "single_thread": rate1,
+                           "threads": cores, "physical_cores": phys, "cpu_quota_cores": cpu_quota_cores(), "usable_cores_measured": usable, "single_thread": rate1,
                            "scaling_efficiency_vs_physical_cores": rate / (rate1 * max(1, min(cores, phys))),
                            "scaling_efficiency_vs_usable_cores": rate / (rate1 * max(1.0, min(usable, float(phys)))),
                            "sample": f"{pmt} timed passes over {n_mt} sentences of the same workload ({smt:.2f} s) on {cores} persistent threads after one untimed warm-up pass "
@@ -94,6 +94,21 @@ def physical_cores():
         return len(seen) or (os.cpu_count() or 1)
     except OSError:
         return os.cpu_count() or 1
+
+
+def cpu_quota_cores():
+    """CPU time this container may use, in cores (cgroup CFS quota, v2 cpu.max or v1 cfs_quota_us / cfs_period_us); None when unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
 
 
 def model_facts(workload):
