@@ -652,6 +652,8 @@ namespace kamd
 		// (many latency-bound waves) on a second stream.
 		// Measured on MI355X (c2): both stages are bound by the serial latency of ONE chunk, not by the chunk count, so
 		// splitting only adds launches (S=1: 4.5 ms, S=2: 6.4 ms, S=4: 9.9 ms per 8192 chunks).  Kept as an option only.
+		// Round 3, 65 536 chunks with the position-step kernel (throughput-bound stages): still slower -- c2-64k 7.04 / 7.59 / 7.74 / 8.47 ms per step
+		// for S = 1 / 2 / 4 / 8, c4-cong 46.3 / 49.8 / 69.3 ms: the overlapped kernels contend for the same wave slots and LDS.
 		uint32_t S = I.subBatches > 0 ? (uint32_t)I.subBatches : 1u;
 		S = std::min(S, std::min(nC, 16u));
 		if (b.subBatches != S)
@@ -770,7 +772,7 @@ namespace kamd
 			if (b.wv.unkChr)      // Match::oovChrModel: every node's unknown form scored by the character model, once, before the search
 				hipLaunchKernelGGL(k_unk_chr, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, I.chr, c0, cn, chrToken(0xD800, identifySpecialChr(0xD800)), chrToken(0xDC00, identifySpecialChr(0xDC00)));
 			// position-step search first (viterbi_pos.inc): top-1, 16-lane groups, not for SkipBigram models; what it cannot finish is resumed by the general kernel below
-			const bool usePos = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S == 1;
+			const bool usePos = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8;      // (per-sub-batch counters: 8 of each)
 			if (usePos)
 				hipLaunchKernelGGL(k_expand_pos, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, b.typo.typo ? b.dNodeTypo.as<float>() : (const float*)nullptr, ((I.hasCong && b.wv.unkChr) ? 1u : 0u) | (I.hasCong ? 2u : 0u));      // (bit 0: unknown forms scored by the character model; bit 1: a CoNgram model)
 			HIPCHECK(hipEventRecord(e[2], sA));
