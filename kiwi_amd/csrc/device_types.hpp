@@ -211,7 +211,9 @@ namespace kamd
 	// LDS-side capacities are the typical need (3 per text unit), not the worst-case HBM capacities: a chunk that outgrows
 	// them at run time is handed to the thread-per-chunk kernel (flag kLatticeNeedsBig in nNodes[chunk])
 	constexpr uint32_t kLatticeNeedsBig = 0xFFFFFFFEu;
-	KAMD_HD uint32_t latticeLdsCap(uint32_t n, uint32_t hbmCap) { const uint32_t c = 3 * n + 32; return c < hbmCap ? c : hbmCap; }
+	// (3 per unit up to 128 units, 2 per unit beyond: long chunks are the ones whose LDS copies limit the resident wavefronts -- MI355X, c4-cong: lattice
+	// stage 19.0 -> 17.x ms -- and they average fewer nodes per unit; short chunks gain nothing from smaller copies, c2-64k 1.99 ms either way)
+	KAMD_HD uint32_t latticeLdsCap(uint32_t n, uint32_t hbmCap) { const uint32_t c = n < 128 ? 3 * n + 32 : 2 * n + 160; return c < hbmCap ? c : hbmCap; }
 	KAMD_HD LatticeLds latticeLdsLayout(uint32_t n, uint32_t nodeCapHbm, uint32_t matchCapHbm)
 	{
 		const uint32_t nodeCap = latticeLdsCap(n, nodeCapHbm), matchCap = latticeLdsCap(n, matchCapHbm);

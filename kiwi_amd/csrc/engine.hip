@@ -216,7 +216,7 @@ namespace kamd
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter, posScratch;
-		uint32_t posContSlots = 64;      // chunks per launch that k_pos_path carries on in the general search itself (KAMD_POS_CONT=0: none, all left to k_best_path)
+		uint32_t posContSlots = 256;     // chunks per launch that k_pos_path carries on in the general search itself (KAMD_POS_CONT=0: none, all left to k_best_path)
 		ChrView chr{};      // character model of Match::oovChrModel on the device (absent: dim 0)
 		CongDev cong{}; bool hasCong = false;   // CoNgram model: the context trie is uploaded where the Knlm tables would be (ModelView::lmHash / lmRoot2 / lmBackoff)
 		SbgDev sbg{}; bool hasSbg = false; DevBuf sbgScratch;   // SkipBigram tables on the device + per-lane-group item scratch of its search kernel
