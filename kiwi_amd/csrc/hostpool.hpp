@@ -3,7 +3,11 @@
 // used at include/kiwi/Kiwi.h:402-454); here the per-text host work of a whole batch is cut into blocks that the workers pull
 // from an atomic counter.  The pool is created once per process and kept: threads spawned per call cost more than the work of
 // an 8k-sentence batch (fresh malloc arenas and first-touch page faults on every call).
+// Several callers may run at once -- one per GPU when kiwi_analyze_m drives every visible device from one process -- and SHARE the
+// workers: every call registers a job, a worker takes blocks from whichever registered job has some left (and room under its
+// thread limit), the caller works on its own job meanwhile and returns when the last of its blocks is done.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <unistd.h>
@@ -18,49 +22,67 @@ namespace kamd
 {
 	class HostPool
 	{
+		struct Job
+		{
+			const std::function<void(size_t, size_t, int)>* fn;      // (begin, end, worker id)
+			size_t total, grain, blocks;
+			int maxHelpers;                      // pool workers that may work on it at once (the caller is not counted)
+			std::atomic<size_t> next{ 0 };       // first item of the next block to hand out
+			std::atomic<size_t> done{ 0 };       // blocks finished
+			std::atomic<int> helpers{ 0 };
+			std::atomic<bool> failed{ false };
+			std::exception_ptr error;
+		};
 		std::vector<std::thread> threads;
-		std::mutex mu, runMu;
+		std::mutex mu;
 		std::condition_variable cvWork, cvDone;
-		const std::function<void(size_t, size_t, int)>* job = nullptr;   // (begin, end, worker id)
-		std::atomic<size_t> next{ 0 };
-		size_t total = 0, grain = 1;
-		uint64_t generation = 0;
-		int wanted = 0, running = 0;
+		std::vector<Job*> jobs;      // registered jobs (under mu)
+		size_t turn = 0;
 		bool stopping = false;
 		const pid_t owner = ::getpid();
-		std::exception_ptr error;
-		std::atomic<bool> failed{ false };
 
-		void drain(int id)
+		// blocks of `j` until none is left; true if this call finished the job's last block
+		bool drain(Job& j, int id)
 		{
-			try
+			bool last = false;
+			for (;;)
 			{
-				for (;;)
+				const size_t i = j.next.fetch_add(j.grain);
+				if (i >= j.total) break;
+				if (!j.failed.load(std::memory_order_relaxed))
 				{
-					const size_t i = next.fetch_add(grain);
-					if (i >= total || failed.load(std::memory_order_relaxed)) break;
-					(*job)(i, std::min(total, i + grain), id);
+					try { (*j.fn)(i, std::min(j.total, i + j.grain), id); }
+					catch (...) { if (!j.failed.exchange(true)) { std::lock_guard<std::mutex> g{ mu }; j.error = std::current_exception(); } }
 				}
+				if (j.done.fetch_add(1) + 1 == j.blocks) last = true;
 			}
-			catch (...)
-			{
-				if (!failed.exchange(true)) { std::lock_guard<std::mutex> g{ mu }; error = std::current_exception(); }
-			}
+			return last;
 		}
 
 		void workerMain(int id)
 		{
-			uint64_t seen = 0;
 			std::unique_lock<std::mutex> lk{ mu };
 			for (;;)
 			{
-				cvWork.wait(lk, [&] { return stopping || (generation != seen && id < wanted); });
-				if (stopping) return;
-				seen = generation;
+				Job* pick = nullptr;
+				for (size_t t = 0; t < jobs.size() && !pick; ++t)      // (round robin over the registered jobs: concurrent callers share the workers evenly)
+				{
+					Job* j = jobs[(turn + t) % jobs.size()];
+					if (j->next.load(std::memory_order_relaxed) < j->total && j->helpers.load(std::memory_order_relaxed) < j->maxHelpers) pick = j;
+				}
+				++turn;
+				if (!pick)
+				{
+					if (stopping) return;
+					cvWork.wait(lk);
+					continue;
+				}
+				pick->helpers.fetch_add(1);
 				lk.unlock();
-				drain(id + 1);
+				const bool last = drain(*pick, id + 1);
 				lk.lock();
-				if (--running == 0) cvDone.notify_all();
+				pick->helpers.fetch_sub(1);      // (under mu: the submitter waits for helpers == 0 before its Job goes out of scope)
+				if (last || pick->helpers.load() == 0) cvDone.notify_all();
 			}
 		}
 
@@ -79,7 +101,7 @@ namespace kamd
 		int size() const { return (int)threads.size() + 1; }
 
 		// Runs fn(begin, end, worker) over [0, n) in blocks of `block` items on up to `maxThreads` threads (the caller is one of
-		// them; worker ids are 0 .. size()-1).  Calls from several threads are serialised; an exception of any block is rethrown.
+		// them; worker ids are 0 .. size()-1, 0 = the caller).  Calls from several threads proceed side by side; an exception of any block is rethrown.
 		void run(size_t n, size_t block, int maxThreads, const std::function<void(size_t, size_t, int)>& fn)
 		{
 			if (!n) return;
@@ -88,18 +110,16 @@ namespace kamd
 			int helpers = (int)std::min<size_t>(threads.size(), blocks - 1);
 			if (maxThreads > 0) helpers = std::min(helpers, maxThreads - 1);
 			if (helpers <= 0 || ::getpid() != owner) { fn(0, n, 0); return; }
-			std::lock_guard<std::mutex> serial{ runMu };
-			{
-				std::lock_guard<std::mutex> g{ mu };
-				job = &fn; total = n; grain = block; next = 0; failed = false; error = nullptr;
-				wanted = helpers; running = helpers; ++generation;
-			}
+			Job j;
+			j.fn = &fn; j.total = n; j.grain = block; j.blocks = blocks; j.maxHelpers = helpers;
+			{ std::lock_guard<std::mutex> g{ mu }; jobs.push_back(&j); }
 			cvWork.notify_all();
-			drain(0);
+			drain(j, 0);
 			std::unique_lock<std::mutex> lk{ mu };
-			cvDone.wait(lk, [&] { return running == 0; });
-			job = nullptr;
-			if (error) { auto e = error; error = nullptr; std::rethrow_exception(e); }
+			cvDone.wait(lk, [&] { return j.done.load() == j.blocks && j.helpers.load() == 0; });
+			jobs.erase(std::find(jobs.begin(), jobs.end(), &j));
+			lk.unlock();
+			if (j.error) std::rethrow_exception(j.error);
 		}
 
 		// the process-wide pool: one thread per hardware thread (KAMD_HOST_THREADS overrides; the batch stages take their own `maxThreads` on top).
