@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include "../../include/kiwi_capi.h"
 #include "engine.hpp"
+#include "hostpool.hpp"
 #include "typo.hpp"
 
 using namespace kamd;
@@ -188,11 +189,14 @@ namespace
 		struct Job
 		{
 			std::vector<std::u16string> texts;
+			std::vector<std::string> utf8;      // kiwi_analyze_m: what the reader delivered; converted on the worker pool, not on the calling thread
 			std::vector<size_t> cut;
 			std::vector<std::shared_ptr<const BatchResults>> parts;
 		};
 		auto analyse = [h, topN, &opt](Job& job)
 		{
+			if (!job.utf8.empty())
+				HostPool::instance().run(job.utf8.size(), 512, h->numThreads, [&](size_t a, size_t b, int) { for (size_t i = a; i < b; ++i) job.texts[i] = utf8To16(job.utf8[i].data(), job.utf8[i].size()); });
 			std::vector<std::pair<const char16_t*, size_t>> views;
 			for (auto& t : job.texts) views.emplace_back(t.data(), t.size());
 			// One host process drives every GPU (the reference's driver keeps a thread pool busy, include/kiwi/Kiwi.h:402-454): the batch is cut into
@@ -233,10 +237,11 @@ namespace
 		{
 			while ((int)job.texts.size() < h->batchSize)
 			{
-				std::u16string s;
-				if (!readNext(readerIdx, s)) return false;
+				std::u16string s; std::string raw;
+				if (!readNext(readerIdx, s, raw)) return false;
 				++readerIdx;
 				job.texts.push_back(std::move(s));
+				if (!raw.empty()) job.utf8.push_back(std::move(raw));
 			}
 			return true;
 		};
@@ -536,7 +541,7 @@ extern "C"
 		if (!h) return KIWIERR_INVALID_HANDLE;
 		try
 		{
-			return analyzeMany(h, [&](int idx, std::u16string& out)
+			return analyzeMany(h, [&](int idx, std::u16string& out, std::string&)
 			{
 				out.resize((size_t)(*reader)(idx, nullptr, ud));
 				if (out.empty()) return false;
@@ -552,13 +557,11 @@ extern "C"
 		if (!h) return KIWIERR_INVALID_HANDLE;
 		try
 		{
-			return analyzeMany(h, [&](int idx, std::u16string& out)
+			return analyzeMany(h, [&](int idx, std::u16string&, std::string& raw)
 			{
-				std::string buf;
-				buf.resize((size_t)(*reader)(idx, nullptr, ud));
-				if (buf.empty()) return false;
-				(*reader)(idx, &buf[0], ud);
-				out = utf8To16(buf.data(), buf.size());
+				raw.resize((size_t)(*reader)(idx, nullptr, ud));
+				if (raw.empty()) return false;
+				(*reader)(idx, &raw[0], ud);      // (UTF-8 -> UTF-16 happens with the batch, on the worker pool)
 				return true;
 			}, receiver, ud, top_n, opt);
 		}
