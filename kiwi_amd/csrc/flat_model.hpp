@@ -183,7 +183,18 @@ namespace kamd
 		// variable-length keys (cong.mdl keySize 3): a word id >= vlTMax is spelt as the two trie keys vlTMax + (r >> vlBits) and
 		// vlTMax + (1 << vlBits) + (r & mask), r = id - vlTMax (CoNgramModel::progressContextNode, src/CoNgramModel.hpp:271-300); 0xFFFFFFFF = no such ids
 		uint32_t vlTMax = 0xFFFFFFFFu, vlBits = 0;
+		// the global model (ModelType::congGlobal; reference window 7): the sections a cong.mdl with windowSize > 0 carries on top.  A word whose bit is
+		// set in distMask ("valid distant token") is scored as a mixture over the context and the last `window` such words of the path
+		// (CoNgramModel::progress, src/CoNgramModel.cpp:802-868); window == 0: no such sections / local scoring asked for.
+		uint32_t window = 0;
+		uint32_t keyBytes = 4;                 // sizeof(KeyType) of the reference's instantiation (keySize 2 -> 2, else 4): Hash<CoNgramState> reads 8 bytes of history
+		const float* ctxConf = nullptr;        // [nCtx][2]: confidence, valid-token sum
+		const uint8_t* distEmb = nullptr;      // [vocab] rows like ctxEmb: dim x s8, f32 scale, f32 bias
+		const float* distConf = nullptr;       // [vocab]
+		const float* posConf = nullptr;        // [window + 1], [0] = 0
+		const uint8_t* distMask = nullptr;     // (vocab + 7) / 8 bytes
 		bool present() const { return dim != 0; }
+		KAMD_HD bool distant(uint32_t w) const { return window && (distMask[w >> 3] >> (w & 7) & 1); }
 	};
 	// the score of word `w` in context `c` (one fp32 conversion, two multiplications, one addition, in this order: CoNgramModel.cpp:886-894)
 	KAMD_HD float congScore(const CongView& C, uint32_t c, uint32_t w)
@@ -343,6 +354,9 @@ namespace kamd
 		std::vector<uint8_t> chrCtxEmb, chrOutEmb; uint32_t chrDim = 0, chrCtx = 0, chrVocab = 0; int32_t chrBosNode = 0; uint32_t chrBosCtx = 0;
 		std::vector<float> formUnkChr;
 		std::vector<uint8_t> congCtxEmb, congOutEmb; uint32_t congDim = 0, congCtx = 0, congVocab = 0, congVlTMax = 0xFFFFFFFFu, congVlBits = 0;
+		// sections of the global model (CongView::window ...); congGlobal: score with them (ModelType::congGlobal) -- set by whoever opens the model
+		std::vector<float> congCtxConf, congDistConf, congPosConf; std::vector<uint8_t> congDistEmb, congDistMask; uint32_t congWindow = 0, congKeyBytes = 4;
+		bool congGlobal = false;
 
 		CongView congView() const
 		{
@@ -351,6 +365,12 @@ namespace kamd
 			v.dim = congDim; v.stride = congDim + 8; v.nCtx = congCtx; v.vocabSize = congVocab; v.rootSize = (uint32_t)congRoot.size(); v.vlTMax = congVlTMax; v.vlBits = congVlBits;
 			v.ctxEmb = congCtxEmb.data(); v.outEmb = congOutEmb.data();
 			v.nodes = congNodes.data(); v.keys = congKeys.data(); v.values = congValues.data(); v.root = congRoot.data();
+			v.keyBytes = congKeyBytes;
+			if (congGlobal && congWindow)
+			{
+				v.window = congWindow; v.ctxConf = congCtxConf.data(); v.distEmb = congDistEmb.data(); v.distConf = congDistConf.data();
+				v.posConf = congPosConf.data(); v.distMask = congDistMask.data();
+			}
 			return v;
 		}
 

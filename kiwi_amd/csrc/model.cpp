@@ -470,8 +470,15 @@ namespace kamd
 			// a row: qbit 8 = dim x s8 + fp16 scale; qbit 4 = dim / 2 bytes of nibble pairs + fp16 global scale + dim / qgroup local bytes, requantised to
 			// s8 at load time as the reference does (requantizePackedInts, src/CoNgramModel.cpp:378-400)
 			const size_t rowRec = hd.qbit == 8 ? (size_t)hd.dim + 2 : (size_t)hd.dim / 2 + 2 + hd.dim / hd.qgroup;
-			const size_t ctxRec = rowRec + 2 + (hd.windowSize > 0 ? 4 : 0), outRec = rowRec;      // (a file of the global model carries confidence + valid-token sum per context: skipped, CoNgramModel.cpp:655-658)
-			if (e + hd.contextSize * ctxRec + hd.vocabSize * outRec > end) throw std::runtime_error{ "cong.mdl: truncated embeddings" };
+			// a file of the global model (windowSize 7; the reference's builder always writes one) carries on top: per context fp16 confidence + fp16 valid-token
+			// sum; after the output rows the distant rows (per word: row, fp16 -bias, fp16 confidence), windowSize fp16 position confidences and the
+			// distant-token mask (CoNgramModel.cpp:640-762)
+			if (hd.windowSize != 0 && hd.windowSize != 7) throw std::runtime_error{ "cong.mdl: unsupported window size (0 and 7 are)" };
+			const size_t ctxRec = rowRec + 2 + (hd.windowSize > 0 ? 4 : 0), outRec = rowRec, distRec = rowRec + 4;
+			const size_t globalBytes = hd.windowSize ? hd.vocabSize * distRec + 2 * (size_t)hd.windowSize + (hd.vocabSize + 7) / 8 : 0;
+			if (e + hd.contextSize * ctxRec + hd.vocabSize * outRec + globalBytes > end) throw std::runtime_error{ "cong.mdl: truncated embeddings" };
+			m.congWindow = hd.windowSize; m.congKeyBytes = hd.keySize == 2 ? 2 : 4;
+			if (hd.windowSize) m.congCtxConf.assign(hd.contextSize * 2, 0.f);
 			auto readRow = [&](const uint8_t* src, uint8_t* o)      // -> the row's s8 values and its fp32 scale at o[dim]
 			{
 				float scale;
@@ -509,8 +516,29 @@ namespace kamd
 				uint16_t hb; std::memcpy(&hb, e + rowRec, 2);
 				const float bias = -halfToFloat(hb);
 				std::memcpy(o + hd.dim + 4, &bias, 4);
+				if (hd.windowSize)
+				{
+					uint16_t hc, hv; std::memcpy(&hc, e + rowRec + 2, 2); std::memcpy(&hv, e + rowRec + 4, 2);
+					m.congCtxConf[i * 2] = halfToFloat(hc); m.congCtxConf[i * 2 + 1] = halfToFloat(hv);
+				}
 			}
 			for (size_t i = 0; i < hd.vocabSize; ++i, e += outRec) readRow(e, &m.congOutEmb[i * stride]);
+			if (hd.windowSize)
+			{
+				m.congDistEmb.assign(hd.vocabSize * stride, 0); m.congDistConf.assign(hd.vocabSize, 0.f);
+				for (size_t i = 0; i < hd.vocabSize; ++i, e += distRec)
+				{
+					uint8_t* o = &m.congDistEmb[i * stride];
+					readRow(e, o);
+					uint16_t hb, hc; std::memcpy(&hb, e + rowRec, 2); std::memcpy(&hc, e + rowRec + 2, 2);
+					const float bias = -halfToFloat(hb);
+					std::memcpy(o + hd.dim + 4, &bias, 4);
+					m.congDistConf[i] = halfToFloat(hc);
+				}
+				m.congPosConf.assign(hd.windowSize + 1, 0.f);
+				for (size_t i = 0; i < hd.windowSize; ++i, e += 2) { uint16_t h; std::memcpy(&h, e, 2); m.congPosConf[i + 1] = halfToFloat(h); }
+				m.congDistMask.assign(e, e + (hd.vocabSize + 7) / 8);
+			}
 			// device lookup structures, in the shapes of the Knlm ones: edge hash (slot.ll carries the child's context id), root table, suffix links
 			auto asF = [](uint32_t v) { float f; std::memcpy(&f, &v, 4); return f; };
 			auto edgeCtx = [&](uint32_t node, int32_t v) { return v > 0 ? asF(m.congNodes[node + v].value) : asF(0u); };

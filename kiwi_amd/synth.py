@@ -344,6 +344,9 @@ SMALL_CONG_CHR_SPEC = SynthSpec(use_cong=True, use_nounchr=True)   # SMALL_CONG_
 SMALL_SBG_SPEC = SynthSpec(use_sbg=True)   # same lexicon / Knlm as SMALL_SPEC (same seed) + skip-bigram tables
 # the CoNgram file the way the reference's builder writes it for a large vocabulary: 4-bit grouped embeddings, variable-length 16-bit keys, window sections
 MID_CONG_VL4_SPEC = SynthSpec(n_words=66000, use_cong=True, cong_only=True, cong_key_size=3, cong_qbit=4, cong_qgroup=8, cong_window=7)   # (> 65536 morphemes: an LM id is a morpheme id, and the reference sizes its root table by the vocabulary while indexing it with 16-bit keys)
+# the CoNgram file with the global model's sections (window 7): scored as ModelType::congGlobal where asked for; 32-bit and 16-bit ids (the reference's state hash reads 8 BYTES of history)
+SMALL_CONG_GLOBAL_SPEC = SynthSpec(use_cong=True, cong_window=7)
+SMALL_CONG_GLOBAL16_SPEC = SynthSpec(use_cong=True, cong_window=7, cong_key_size=2)
 SMALL_CONG_SPEC = SynthSpec(use_cong=True) # same lexicon as SMALL_SPEC + a local CoNgram model (the Knlm blob stays in the container: the dictionary bake needs a vocabulary size)
 FULL_CONG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
                            n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_cong=True, cong_dim=64, cong_only=True)

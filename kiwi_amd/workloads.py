@@ -97,19 +97,26 @@ def _spec(name):
     return {"full": FULL_SPEC, "full-sbg": FULL_SBG_SPEC, "small": SMALL_SPEC, "full-cong": FULL_CONG_SPEC, "small-cong": SMALL_CONG_SPEC}[name]
 
 
-def eval_model():
+# morphemes that the reference's shipped default.dict / typo.dict refer to as "original" morphemes (pre-analysed entries, allomorph definitions) beyond
+# those of the eval_data gold lexicon: the real KiwiBuilder refuses the files without them (tools/make_golden_built.py)
+EVAL_BUILDER_REQUIRED = (("으라", "EC"), ("ᆫ다", "EC"), ("편찮", "VA"), ("하찮", "VA"), ("시끄럽", "VA-I"))
+
+
+def eval_model(for_builder=False):
     """The small synthetic model with the gold (form, tag) pairs of the reference's eval_data files as additional dictionary entries
     (tests/golden/eval_data_lexicon.json, written by tools/make_golden_eval.py): real text then meets a lattice of real dictionary words; the language
-    model stays synthetic.  Returns (raw model path, number of entries the lexicon file holds)."""
+    model stays synthetic.  for_builder: plus EVAL_BUILDER_REQUIRED -- the input of the real KiwiBuilder run behind tests/golden/eval_built_model.raw.xz.
+    Returns (raw model path, number of entries the lexicon file holds)."""
     import json
     from dataclasses import replace
     from .synth import SMALL_SPEC, SynthModel
     lex_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "eval_data_lexicon.json")
     entries = json.load(open(lex_path, encoding="utf-8"))["entries"]
     os.makedirs(DATA, exist_ok=True)
-    path = os.path.join(DATA, "small-eval.raw")
+    path = os.path.join(DATA, "small-eval-builder.raw" if for_builder else "small-eval.raw")
     if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(lex_path):
-        SynthModel(replace(SMALL_SPEC, extra_words=tuple((f, t) for f, t in entries))).raw.save(path)
+        words = tuple((f, t) for f, t in entries) + (EVAL_BUILDER_REQUIRED if for_builder else ())
+        SynthModel(replace(SMALL_SPEC, extra_words=words)).raw.save(path)
     return path, len(entries)
 
 

@@ -41,6 +41,7 @@ namespace korc
 		// matrix, one pair per later chunk step --, scores written, context-trie probes (non-root levels visited) with their key bytes, root
 		// probes; congDim = the embedding dimension (0: not a CoNgram model)
 		uint64_t congCtxRows = 0, congOutRows = 0, congScores = 0, congProbes = 0, congProbeKeyBytes = 0, congRootProbes = 0, congDim = 0;
+		uint64_t congGlobalScores = 0;      // of congScores: mixtures over the history window (global model, valid distant tokens)
 	};
 
 	struct SplitConfig { uint64_t match; uint32_t maxUnk, maxUnkJ, spaceTol; };

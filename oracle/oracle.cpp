@@ -112,6 +112,16 @@ extern "C"
 		h.scfg.maxUnk = maxUnk; h.scfg.maxUnkJ = maxUnkJ; h.scfg.spaceTol = spaceTol; h.integrateAllomorph = !!integrateAllomorph;
 	}
 
+	// ModelType::congGlobal: score with the window sections of the CoNgram file (0 = ok, -1 = the model has none)
+	int korc_set_cong_global(void* hp, int on)
+	{
+		auto& h = *(OracleHandle*)hp;
+		if (on && !(h.model.congDim && h.model.congWindow)) return -1;
+		h.model.congGlobal = !!on;
+		h.cong = h.model.congView();
+		return 0;
+	}
+
 	// test hook: hand kept paths on in the reference's own (history-dependent) container order instead of insertion order
 	void korc_set_faithful_order(void* hp, int on)
 	{
@@ -159,6 +169,19 @@ extern "C"
 		WPath st; st.lmNode = *node; st.ctx = *ctx;
 		const float ll = bp.lmNext(st, wid);
 		*node = st.lmNode; *ctx = st.ctx;
+		return ll;
+	}
+	// the same with the global model's history (CoNgramState<7>::history, 8 words) in / out
+	float korc_cong_next_hist(void* hp, int32_t* node, uint32_t* ctx, uint32_t* hist8, uint32_t wid)
+	{
+		auto& h = *(OracleHandle*)hp;
+		BestPathConfig bc; Counters c;
+		BestPathSearch bp{ h.view, bc, c, SbgView{}, nullptr, h.cong };
+		WPath st; st.lmNode = *node; st.ctx = *ctx;
+		for (int i = 0; i < 8; ++i) st.hist[i] = hist8[i];
+		const float ll = bp.lmNext(st, wid);
+		*node = st.lmNode; *ctx = st.ctx;
+		for (int i = 0; i < 8; ++i) hist8[i] = st.hist[i];
 		return ll;
 	}
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 COUNTER_NAMES = ["inputUnits", "trieProbes", "trieProbeKeyBytes", "failHops", "candEmits", "otherNodes",
                  "transitions", "candMorphs", "statesWritten", "lmProbes", "lmProbeKeyBytes", "lmRootProbes", "tokens",
                  "maxPrevPaths", "nodesOver128", "nodesOver512", "lattNodes", "sbgEvals", "sbgProbeKeyBytes", "sbgHits", "sbgModel",
-                 "congCtxRows", "congOutRows", "congScores", "congProbes", "congProbeKeyBytes", "congRootProbes", "congDim"]
+                 "congCtxRows", "congOutRows", "congScores", "congProbes", "congProbeKeyBytes", "congRootProbes", "congDim", "congGlobalScores"]
 
 
 def available() -> bool:
@@ -45,6 +45,7 @@ class OracleKiwi:
         L.korc_analyze_batch.restype = C.c_double
         L.korc_analyze_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
         L.korc_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.korc_set_cong_global.argtypes = [C.c_void_p, C.c_int]
         self.h = L.korc_open(raw_model_path.encode())
         if not self.h:
             raise RuntimeError("korc_open failed")
@@ -64,6 +65,11 @@ class OracleKiwi:
 
     def set_config(self, cut_off=8.0, space_penalty=7.0, typo_cost_weight=6.0, max_unk=6, max_unk_j=0xFFFFFFFF, space_tol=0, integrate_allomorph=True):
         self.lib.korc_set_config(self.h, cut_off, space_penalty, typo_cost_weight, max_unk, max_unk_j, space_tol, int(integrate_allomorph))
+
+    def set_cong_global(self, on=True):
+        """Score with the sections of the global CoNgram model (ModelType::congGlobal) when the model file carries them (window 7)."""
+        if self.lib.korc_set_cong_global(self.h, int(on)) != 0:
+            raise RuntimeError("the model has no CoNgram window sections")
 
     def set_faithful_order(self, on=True):
         """Test hook: hand kept paths on in the reference's own container order (persistent std::unordered_set / _map, as its

@@ -157,6 +157,7 @@ namespace kiwi
 		}
 		static bool hasChr(const Kiwi& k) { return !!k.nounChrMdl; }
 #endif
+		static bool& congGlobalWanted() { static bool v = false; return v; }
 		static Kiwi build(const kamd::RawModel& raw, ArchType arch)
 		{
 			Vector<FormRaw> forms; Vector<MorphemeRaw> morphemes;
@@ -192,7 +193,8 @@ namespace kiwi
 			std::memcpy(mem.get(), knlm, knlmSize);
 			std::shared_ptr<lm::ILangModel> langMdl;
 #ifdef KREF_X86
-			if (cong) langMdl = lm::CoNgramModelBase::create(utils::MemoryObject{ std::move(mem) }, arch, false, true);   // local (window 0), quantised: ModelType::cong
+			// quantised; local (window 0: ModelType::cong) or, for kref_open_cong_global, with distant tokens (window 7: ModelType::congGlobal, KiwiBuilder.cpp:1018-1031)
+			if (cong) langMdl = lm::CoNgramModelBase::create(utils::MemoryObject{ std::move(mem) }, arch, congGlobalWanted(), true);
 			else
 #endif
 			if (sbg)
@@ -344,6 +346,26 @@ namespace
 	}
 }
 
+#ifdef KREF_X86
+// KiwiBuilder keeps its state private and befriends nobody this file could be; an explicit template instantiation may name private members
+// (the standard's access rules do not apply there), which is how its morpheme lists and buildCombinedMorphemes are reached -- unmodified sources.
+namespace kamd_ref
+{
+	template<class Tag, typename Tag::type M> struct Reach { friend typename Tag::type reach(Tag) { return M; } };
+	struct KbForms { using type = kiwi::Vector<kiwi::FormRaw> kiwi::KiwiBuilder::*; friend type reach(KbForms); };
+	struct KbMorphs { using type = kiwi::Vector<kiwi::MorphemeRaw> kiwi::KiwiBuilder::*; friend type reach(KbMorphs); };
+	struct KbCombine
+	{
+		using type = void (kiwi::KiwiBuilder::*)(kiwi::Vector<kiwi::FormRaw>&, kiwi::UnorderedMap<kiwi::KString, size_t>&, kiwi::Vector<kiwi::MorphemeRaw>&,
+			kiwi::UnorderedMap<size_t, kiwi::Vector<uint32_t>>&, kiwi::Map<int, int>*) const;
+		friend type reach(KbCombine);
+	};
+	template struct Reach<KbForms, &kiwi::KiwiBuilder::forms>;
+	template struct Reach<KbMorphs, &kiwi::KiwiBuilder::morphemes>;
+	template struct Reach<KbCombine, &kiwi::KiwiBuilder::buildCombinedMorphemes>;
+}
+#endif
+
 extern "C"
 {
 	void* kref_open(const char* rawModelPath, int arch)
@@ -362,6 +384,17 @@ extern "C"
 			return nullptr;
 		}
 	}
+
+#ifdef KREF_X86
+	// the same with the container's CoNgram blob loaded as the GLOBAL model (CoNgramModelBase::create(useDistantTokens = true): ModelType::congGlobal)
+	void* kref_open_cong_global(const char* rawModelPath, int arch)
+	{
+		Acc::congGlobalWanted() = true;
+		void* h = kref_open(rawModelPath, arch);
+		Acc::congGlobalWanted() = false;
+		return h;
+	}
+#endif
 
 	// The synthetic model written as the reference's own model FILES: sj.morph by the reference's serializer, sj.knlm / skipbigram.mdl as the
 	// memory images they are.  Returns 0 on success.
@@ -420,6 +453,105 @@ extern "C"
 			return nullptr;
 		}
 	}
+
+#ifdef KREF_X86
+	// The REAL builder, unmodified (src/KiwiBuilder.cpp is a translation unit of the x86 library): KiwiBuilder{ dir, ... } loads the directory as
+	// Kiwi ships it -- sj.morph, the language model, extract.mdl, combiningRule.txt and, per `options` (BuildOption bits), default.dict / typo.dict /
+	// multi.dict -- and build() bakes it (combined morphemes, dictionary entries).  Every other entry point of this bridge bakes with its own
+	// restatement of build() (Acc::build above, written while that file did not compile): this one is what pins the restatement.
+	// extract.mdl of the reference checkout is a git-LFS pointer; kref_write_empty_extract writes one with empty tables through the reference's serializer
+	// (the word detector it feeds is not on the analysis path).
+	int kref_write_empty_extract(const char* dir)
+	{
+		try
+		{
+			std::map<std::pair<kiwi::POSTag, bool>, std::map<char16_t, float>> posScore;
+			std::map<std::u16string, float> nounTailScore;
+			std::ofstream os{ std::string{ dir } + "/extract.mdl", std::ios::binary };
+			kiwi::serializer::writeMany(os, posScore, nounTailScore);
+			return os ? 0 : -2;
+		}
+		catch (const std::exception& e) { fprintf(stderr, "kref_write_empty_extract: %s\n", e.what()); return -1; }
+	}
+	// The state of the REAL builder after it has loaded `dir` (dictionaries per `options`) and generated the rule-combined morphemes
+	// (KiwiBuilder::buildCombinedMorphemes, the first step of build()), written as a raw-model container: forms + combined forms, every form's
+	// candidates followed by the combined ones build() would add to it, morphemes + combined morphemes; the language-model blobs and the vocabulary
+	// size are taken over from `lmRawPath`.  What build() does after that step is the bake this repo's loaders restate -- so a container exported
+	// here loads like any raw model, in the bridge, the oracle and the product.  Returns the number of combined morphemes, < 0 on failure.
+	int64_t kref_export_built_raw(const char* dir, int modelType, int options, const char* lmRawPath, const char* outPath)
+	{
+		try
+		{
+			using namespace kiwi;
+			KiwiBuilder kb{ std::string{ dir }, 1, (BuildOption)options, (ModelType)modelType };
+			const auto& forms = kb.*reach(kamd_ref::KbForms{});
+			const auto& morphemes = kb.*reach(kamd_ref::KbMorphs{});
+			Vector<FormRaw> cForms; Vector<MorphemeRaw> cMorphs;
+			UnorderedMap<KString, size_t> newFormMap; UnorderedMap<size_t, Vector<uint32_t>> newFormCands;
+			(kb.*reach(kamd_ref::KbCombine{}))(cForms, newFormMap, cMorphs, newFormCands, nullptr);
+
+			kamd::Container lmFile; lmFile.load(lmRawPath);
+			kamd::RawModel lmRaw; lmRaw.bind(lmFile);
+			std::vector<uint32_t> formPtr{ 0 }, candPtr{ 0 }, cands, chunkIds;
+			std::vector<uint16_t> chars; std::vector<uint8_t> chunkPos;
+			const size_t nF = forms.size() + cForms.size();
+			for (size_t i = 0; i < nF; ++i)
+			{
+				const FormRaw& f = i < forms.size() ? forms[i] : cForms[i - forms.size()];
+				chars.insert(chars.end(), f.form.begin(), f.form.end());
+				formPtr.push_back((uint32_t)chars.size());
+				cands.insert(cands.end(), f.candidate.begin(), f.candidate.end());
+				auto it = newFormCands.find(i);
+				if (it != newFormCands.end()) cands.insert(cands.end(), it->second.begin(), it->second.end());
+				candPtr.push_back((uint32_t)cands.size());
+			}
+			std::vector<kamd::RawMorph> recs;
+			const size_t nM = morphemes.size() + cMorphs.size();
+			for (size_t i = 0; i < nM; ++i)
+			{
+				const MorphemeRaw& m = i < morphemes.size() ? morphemes[i] : cMorphs[i - morphemes.size()];
+				kamd::RawMorph r{};
+				r.kform = m.kform; r.lmId = m.lmMorphemeId; r.origId = m.origMorphemeId; r.combined = m.combined; r.userScore = m.userScore;
+				r.chunkPtr = (uint32_t)chunkIds.size(); r.tag = (uint8_t)m.tag; r.vpPack = m.vpPack; r.senseId = m.senseId; r.socket = m.combineSocket;
+				r.dialect = (uint16_t)m.dialect; r.nChunks = (uint8_t)m.chunks.size();
+				if (m.chunks.size() > 255) throw std::runtime_error{ "a morpheme of more than 255 chunks" };
+				for (size_t c = 0; c < m.chunks.size(); ++c)
+				{
+					chunkIds.push_back(m.chunks[c]);
+					chunkPos.push_back((uint8_t)m.chunkPositions[c].first); chunkPos.push_back((uint8_t)m.chunkPositions[c].second);
+				}
+				recs.push_back(r);
+			}
+			const uint32_t meta[4] = { (uint32_t)nF, (uint32_t)nM, (uint32_t)lmRaw.vocabSize(), 0 };
+			kamd::ContainerWriter w;
+			w.add("meta", meta, sizeof(meta));
+			w.add("form_ptr", formPtr); w.add("form_chars", chars); w.add("form_cand_ptr", candPtr); w.add("form_cand", cands);
+			w.add("morph", recs); w.add("chunk_ids", chunkIds); w.add("chunk_pos", chunkPos);
+			if (lmRaw.knlm) w.add("knlm", lmRaw.knlm, lmRaw.knlmSize);
+			if (lmRaw.sbg) w.add("sbg", lmRaw.sbg, lmRaw.sbgSize);
+			if (lmRaw.cong) w.add("cong", lmRaw.cong, lmRaw.congSize);
+			if (lmRaw.nounchr) w.add("nounchr", lmRaw.nounchr, lmRaw.nounchrSize);
+			w.save(outPath, "KAMDRAW1");
+			return (int64_t)cMorphs.size();
+		}
+		catch (const std::exception& e) { fprintf(stderr, "kref_export_built_raw: %s\n", e.what()); return -1; }
+	}
+	void* kref_open_built(const char* dir, int modelType, int options)
+	{
+		try
+		{
+			auto h = std::make_unique<RefHandle>();
+			kiwi::KiwiBuilder kb{ std::string{ dir }, 1, (kiwi::BuildOption)options, (kiwi::ModelType)modelType };
+			h->kw = kb.build();
+			return h.release();
+		}
+		catch (const std::exception& e)
+		{
+			fprintf(stderr, "kref_open_built: %s\n", e.what());
+			return nullptr;
+		}
+	}
+#endif
 
 	void kref_close(void* h) { delete (RefHandle*)h; }
 

@@ -122,10 +122,29 @@ class RefKiwi:
         L.kref_analyze.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
         L.kref_analyze_batch.restype = C.c_double
         L.kref_analyze_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
-        self.h = L.kref_open(raw_model_path.encode(), arch) if model_dir_sbg is None else L.kref_open_dir(raw_model_path.encode(), arch, int(model_dir_sbg))
+        if model_dir_sbg == "cong_global":
+            # a raw container whose CoNgram blob carries the window sections, scored as ModelType::congGlobal (x86 library only)
+            L.kref_open_cong_global.restype = C.c_void_p
+            L.kref_open_cong_global.argtypes = [C.c_char_p, C.c_int]
+            self.h = L.kref_open_cong_global(raw_model_path.encode(), arch)
+        elif isinstance(model_dir_sbg, tuple) and model_dir_sbg[0] == "built":
+            # a directory as Kiwi ships it, loaded and baked by the REAL KiwiBuilder (x86 library only): ("built", ModelType, BuildOption bits)
+            L.kref_open_built.restype = C.c_void_p
+            L.kref_open_built.argtypes = [C.c_char_p, C.c_int, C.c_int]
+            self.h = L.kref_open_built(raw_model_path.encode(), int(model_dir_sbg[1]), int(model_dir_sbg[2]))
+        else:
+            self.h = L.kref_open(raw_model_path.encode(), arch) if model_dir_sbg is None else L.kref_open_dir(raw_model_path.encode(), arch, int(model_dir_sbg))
         if not self.h:
             raise RuntimeError("kref_open failed")
         self._buf = np.zeros(1 << 20, np.uint8)
+
+    @classmethod
+    def built(cls, model_dir: str, model_type: int = 2, options: int = 1):
+        """KiwiBuilder{ model_dir, 1, options, model_type }.build() of the reference itself (src/KiwiBuilder.cpp, unmodified): dictionaries per `options`
+        (BuildOption bits), the combining rules of the directory's combiningRule.txt."""
+        if not x86_available():
+            raise RuntimeError("oracle/_ref/libkiwi_ref_x86.so is not built")
+        return cls(model_dir, model_dir_sbg=("built", model_type, options))
 
     def close(self):
         if self.h:

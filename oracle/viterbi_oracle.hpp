@@ -24,6 +24,7 @@
 #include "lattice_oracle.hpp"
 #include "../kiwi_amd/csrc/feature.hpp"
 #include "../kiwi_amd/csrc/post.hpp"
+#include "../kiwi_amd/csrc/cong_global.hpp"
 
 namespace korc
 {
@@ -228,11 +229,21 @@ namespace korc
 		// outputFirst: the batched path of the reference's SSE4.1 build multiplies the output scale in first (src/archImpl/sse4_1.cpp:116,
 		// scatteredGEMV_128: ((x * outputScale) * contextScale) + bias) where progress() and the baseline kernel (src/qgemm.hpp:73-80) multiply the
 		// context scale first -- one rounding apart
-		float congNext(WPath& st, uint32_t next, bool outputFirst = false, bool countRows = true) const
+		// Global model (C.window == 7; src/CoNgramModel.cpp:802-868): a valid distant token is scored as a mixture over the context and the state's seven
+		// history words (csrc/cong_global.hpp), and every step pushes `next` (or 0) into the history.  `matrix`: the entry of progressMatrixWSort / WOSort
+		// (:1037-1466) instead of state.next() -- other roundings, see cong_global.hpp.
+		float congNext(WPath& st, uint32_t next, bool outputFirst = false, bool countRows = true, bool matrix = false) const
 		{
 			if (countRows) { cnt.congCtxRows++; cnt.congOutRows++; cnt.congScores++; }
-			const float ll = outputFirst ? congScoreOutputFirst(C, st.ctx, next) : congScore(C, st.ctx, next);
+			float ll;
+			if (C.window && C.distant(next))
+			{
+				cnt.congGlobalScores++;
+				ll = matrix ? congg::scoreMatrix(C, st.ctx, st.hist, next, outputFirst) : congg::scoreSingle(C, st.ctx, st.hist, next);
+			}
+			else ll = outputFirst ? congScoreOutputFirst(C, st.ctx, next) : congScore(C, st.ctx, next);
 			st.ctx = congContext(st.lmNode, next);
+			if (C.window) congg::pushHistory(C, st.hist, next);
 			return ll;
 		}
 
@@ -266,8 +277,10 @@ namespace korc
 			}
 			return ll;
 		}
-		static bool sameLm(const WPath& a, const WPath& b)   // LmState::operator== (Knlm node; + history ring and position for SBG)
+		bool sameLm(const WPath& a, const WPath& b) const   // LmState::operator== (Knlm node; + history ring and position for SBG)
 		{
+			// CoNgramState<7>::operator== (src/CoNgramModel.hpp:452-461): the node and history[3..6] -- not the newest word, not the three oldest
+			if (C.window) return a.lmNode == b.lmNode && a.hist[3] == b.hist[3] && a.hist[4] == b.hist[4] && a.hist[5] == b.hist[5] && a.hist[6] == b.hist[6];
 			if (a.lmNode != b.lmNode || a.histPos != b.histPos) return false;
 			for (int i = 0; i < 8; ++i) if (a.hist[i] != b.hist[i]) return false;
 			return true;
@@ -278,6 +291,7 @@ namespace korc
 		{
 			if (a.prevRootId != b.prevRootId && !S.present()) return false;    // the SBG PathHash::operator== does not compare rootId
 			if (a.spState != b.spState || a.lmNode != b.lmNode) return false;
+			if (C.window) return sameLm(a, b);
 			if (!S.present()) return true;
 			for (int i = 0; i < 4; ++i) if (a.hist[(a.histPos + 8 + i - 4) % 8] != b.hist[(b.histPos + 8 + i - 4) % 8]) return false;
 			return true;
@@ -411,7 +425,15 @@ namespace korc
 			{
 				// Hash<CoNgramState<0>> = Hash<uint32_t>(node) (src/CoNgramModel.hpp:505-541), then Hash<WordLL>'s mix
 				const size_t v = (size_t)(uint32_t)np.lmNode;
-				const size_t r = (v * (size_t)2305843009213693951ull) ^ ((v << 33) | (v >> 31));
+				size_t r = (v * (size_t)2305843009213693951ull) ^ ((v << 33) | (v >> 31));
+				if (C.window)
+				{
+					// Hash<CoNgramState<7>> (src/CoNgramModel.hpp:520-532): the last 8 BYTES of history[0..6] read as one word -- four 16-bit or two 32-bit ids
+					size_t hh = C.keyBytes == 2 ? ((size_t)(uint16_t)np.hist[3] | ((size_t)(uint16_t)np.hist[4] << 16) | ((size_t)(uint16_t)np.hist[5] << 32) | ((size_t)(uint16_t)np.hist[6] << 48))
+						: ((size_t)np.hist[5] | ((size_t)np.hist[6] << 32));
+					hh = (hh * (size_t)2305843009213693951ull) ^ ((hh << 31) | (hh >> 33));
+					r = hh ^ ((r << 3) | (r >> 61));
+				}
 				h = ((uint16_t)np.prevRootId | ((uint16_t)np.spState << 8)) ^ ((r << 3) | (r >> 61));
 			}
 			else if (!S.present()) h = keyHash(Key{ np.lmNode, np.prevRootId, np.spState });
@@ -423,8 +445,17 @@ namespace korc
 				h = ((uint16_t)np.prevRootId | ((uint16_t)np.spState << 8)) ^ ((r << 3) | (r >> 61));
 			}
 			auto& b = bucket[mode == 1 ? ((h >> 8) & 3) : 0];
-			for (auto& t : b)
+			// The SIMD builds look a state up through nst::findAll over the bucket's hash bytes (BestPathContainer.hpp:316-351), and the SSE2 / SSE4.1
+			// findAll masks its result with ((size_t)1 << size) - 1 (src/search.cpp:555-597) -- 0 for size == 64 on x86-64 (the shift count wraps).  Once a
+			// bucket holds 64 entries, entries 0..63 are therefore never found again, and with 128 none is: an equal state is APPENDED instead of merged.
+			// Reproduced for the global model, where equal states (node + history[3..6]) are not identical ones -- the survivor's other history words
+			// change later scores; with the local model an equal state is the same state, a dominated duplicate that changes nothing (and the device
+			// keeps merging there, as before).
+			size_t from = 0, to = b.size();
+			if (C.window && b.size() >= 64) { from = 64; if (b.size() >= 128) to = from; }
+			for (size_t bi = from; bi < to; ++bi)
 			{
+				WPath& t = b[bi];
 				if (t.prevRootId == np.prevRootId && t.spState == np.spState && sameLm(t, np))
 				{
 					if (np.accScore > t.accScore) { const uint8_t pr = t.prevRootId; t = np; t.prevRootId = pr; }
@@ -589,7 +620,7 @@ namespace korc
 				const auto& pcs = cache[prev - graph];
 				for (uint32_t pi = 0; pi < pcs.size(); ++pi) (pcs[pi].combineSocket ? combiningPrev : regularPrev).push_back(Prev{ prev, pi });
 			}
-			std::vector<uint32_t> regular, combL, combR;
+			std::vector<uint32_t> regular, regularDistant, combL, combR;
 			for (uint32_t mid : morphs)
 			{
 				const MorphRec& cm = M.morphs[mid];
@@ -597,8 +628,9 @@ namespace korc
 				if (cm.socket) { (single ? combL : combR).push_back(mid); continue; }
 				const uint32_t firstWid = single ? cm.lmId : M.chunkLm[cm.chunkOff];
 				if (M.morphs[firstWid].tag == T_P) continue;
-				regular.push_back(mid);
+				(C.window && C.distant(firstWid) ? regularDistant : regular).push_back(mid);
 			}
+			regular.insert(regular.end(), regularDistant.begin(), regularDistant.end());      // valid distant tokens last (src/CoNgramModel.cpp:105-124)
 			auto ruleOf = [&](uint32_t morphId)
 			{
 				const MorphRec& cm = M.morphs[morphId];
@@ -651,7 +683,7 @@ namespace korc
 					np.morph = morphId; np.accScore = (cand + rs) - 0.f; np.firstChunkScore = (firstChunk + rs) - 0.f;
 					np.accTypoCost = pp.accTypoCost + node->typoCost;
 					np.parentNode = (int32_t)(pr.node - graph); np.parentIdx = (int32_t)pr.idx;
-					np.lmNode = lmSt.lmNode; np.ctx = lmSt.ctx;
+					np.lmNode = lmSt.lmNode; np.ctx = lmSt.ctx; for (int hi = 0; hi < 8; ++hi) np.hist[hi] = lmSt.hist[hi];
 					np.spState = sp;
 					np.rootId = pp.rootId; np.prevRootId = pp.rootId;
 					if (rootId != COMMON_ROOT) np.rootId = rootId;
@@ -678,18 +710,29 @@ namespace korc
 			// n UNIQUE first word ids: qgemm::scatteredGEMMOpt<sse4_1> (src/qgemm.hpp:157-205; pin = the reference's SSE4.1 build, the simplest
 			// dispatch): m <= 3 and n <= 3 -> baseline; n == 1 -> scatteredGEMV (specialised, output scale first) unless m == 8 (scatteredGEMV8x1:
 			// baseline there); everything else -> baseline.
+			// Global model: progressMatrixWOSort for <= 16 paths and <= 16 candidates (:1470-1480) puts every path's context row, then EVERY non-empty history
+			// slot's distant row (no de-duplication) against every candidate's row: m = paths + slots, n = candidates; progressMatrixWSort otherwise:
+			// m = unique contexts + unique history words, n = unique first words.
 			bool outputFirst = false;
+			const bool matrix = !(regularPrev.size() == 1 && regular.size() == 1);
 			cnt.congDim = C.dim;
 			if (!regularPrev.empty() && !regular.empty())
 			{
-				std::vector<uint32_t> uc, uw;
+				std::vector<uint32_t> uc, uw, uh;
 				for (const Prev& pr : regularPrev) uc.push_back(cache[pr.node - graph][pr.idx].ctx);
 				for (uint32_t mid : regular) { const MorphRec& cm = M.morphs[mid]; uw.push_back((cm.flags & MF_SINGLE) ? cm.lmId : M.chunkLm[cm.chunkOff]); }
-				std::sort(uc.begin(), uc.end()); uc.erase(std::unique(uc.begin(), uc.end()), uc.end());
-				std::sort(uw.begin(), uw.end()); uw.erase(std::unique(uw.begin(), uw.end()), uw.end());
-				const size_t m = uc.size(), n = uw.size();
+				if (C.window) for (const Prev& pr : regularPrev) for (uint32_t k = 0; k < congg::WINDOW; ++k) { const uint32_t t = cache[pr.node - graph][pr.idx].hist[k]; if (t) uh.push_back(t); }
+				size_t m, n;
+				if (C.window && regularPrev.size() <= 16 && regular.size() <= 16) { m = regularPrev.size() + uh.size(); n = regular.size(); }
+				else
+				{
+					std::sort(uc.begin(), uc.end()); uc.erase(std::unique(uc.begin(), uc.end()), uc.end());
+					std::sort(uw.begin(), uw.end()); uw.erase(std::unique(uw.begin(), uw.end()), uw.end());
+					std::sort(uh.begin(), uh.end()); uh.erase(std::unique(uh.begin(), uh.end()), uh.end());
+					m = uc.size() + uh.size(); n = uw.size();
+				}
 				cnt.congCtxRows += m; cnt.congOutRows += n; cnt.congScores += regularPrev.size() * regular.size();
-				outputFirst = !(regularPrev.size() == 1 && regular.size() == 1) && !(m <= 3 && n <= 3) && n == 1 && m != 8;
+				outputFirst = matrix && !(m <= 3 && n <= 3) && n == 1 && m != 8;
 			}
 			for (uint32_t mid : regular)
 			{
@@ -705,7 +748,7 @@ namespace korc
 				{
 					const WPath& pp = cache[pr.node - graph][pr.idx];
 					WPath lmSt = pp;
-					const float ll = congNext(lmSt, firstWid, outputFirst, false);   // progressMatrix / next(): scores[prev][cur] and the moved-on state
+					const float ll = congNext(lmSt, firstWid, outputFirst, false, matrix);   // progressMatrix / next(): scores[prev][cur] and the moved-on state
 					float score = pp.accScore + morphScore + ll;
 					const float firstChunk = morphScore + ll;
 					if (!formOk(pp, cm, score)) continue;
@@ -1088,7 +1131,7 @@ namespace korc
 				}
 				else evaluate(i, ownFormId, unkCands, 2, unkScoreOf((const uint16_t*)norm->data() + node->uformOff, node->uformLen, emojiAt(node->uformOff)));
 				cnt.statesWritten += cache[i].size();
-				if (getenv("KORC_DEBUG")) { fprintf(stderr, "node %u:", i); for (auto& p : cache[i]) fprintf(stderr, " [m%u w%u lm%d s%.9g par(%d,%d) r%u]", p.morph, p.wid, p.lmNode, p.accScore, p.parentNode, p.parentIdx, p.rootId); fprintf(stderr, "\n"); }
+				if (getenv("KORC_DEBUG")) { fprintf(stderr, "node %u:", i); for (auto& p : cache[i]) fprintf(stderr, " [m%u w%u lm%d s%.9g par(%d,%d) r%u c%u h%u,%u,%u,%u,%u,%u,%u,%u]", p.morph, p.wid, p.lmNode, p.accScore, p.parentNode, p.parentIdx, p.rootId, p.ctx, p.hist[0], p.hist[1], p.hist[2], p.hist[3], p.hist[4], p.hist[5], p.hist[6], p.hist[7]); fprintf(stderr, "\n"); }
 			}
 
 			// end node (PathEvaluator.hpp:1320-1357)
@@ -1120,6 +1163,7 @@ namespace korc
 						for (size_t r = 0; r < uniqStates.size(); ++r) { np.spState = uniqStates[r]; np.rootId = (uint8_t)r; cand.push_back(np); }
 					}
 					else { np.spState = p.spState; np.rootId = p.rootId; cand.push_back(np); }
+					if (getenv("KORC_DEBUG")) fprintf(stderr, "end par(%d,%d) acc %.9g eos %.9g -> %.9g\n", np.parentNode, np.parentIdx, p.accScore, first, c);
 				}
 			}
 			std::sort(cand.begin(), cand.end(), [](const WPath& a, const WPath& b)

@@ -1,0 +1,177 @@
+"""A model as the REAL KiwiBuilder builds it (src/KiwiBuilder.cpp compiled unmodified into oracle/_ref/libkiwi_ref_x86.so): the small synthetic
+sj.morph / sj.knlm + the eval_data gold lexicon, then the reference's own shipped combiningRule.txt, default.dict (113 k entries) and typo.dict through
+loadDictionary / buildCombinedMorphemes / build -- exported after that step as a raw-model container (tests/golden/eval_built_model.raw.xz, 15 k
+rule-combined morphemes) together with what the built Kiwi itself answered on column 1 of the eval_data files (tests/golden/eval_built_*.json);
+both written by tools/make_golden_built.py in the build container.
+
+  * where /root/reference and the x86 reference build exist: the export is reproduced byte for byte, and the dictionary the reference bakes from the
+    container equals the one KiwiBuilder::build() baked from the directory -- the container route the parity tests use loses nothing of a real build;
+  * everywhere: the oracle and the product bake the same dictionary from the container, the oracle and the lane-emulated kernels answer what the built
+    Kiwi answered (typo files with the built-in set basicTypoSetWithContinual); `-m gpu`: tests/test_gpu_zzz_built_model.py, every line on the MI355X.
+
+What this covers beyond tests/test_eval_data.py: pre-combined and allomorph morphemes with chunks, combineSocket / combined links over 15 k rule
+products, pre-analysed multi-morpheme dictionary words, typo.dict's pre-analysed corrections.  The language model stays synthetic."""
+import json
+import lzma
+import os
+import struct
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FILES = ("web", "written", "web_with_typos", "web_with_cont_typos")
+TYPO_SET = 3      # DefaultTypoSet::basicTypoSetWithContinual
+MODEL_TYPE, OPTIONS = 2, 1 | 2 | 4
+
+
+def _golden(name):
+    return json.load(open(os.path.join(HERE, "golden", f"eval_built_{name}.json"), encoding="utf-8"))
+
+
+def _rows(tokens):
+    return [[t.form, t.tag, t.position, t.length, t.word_position, t.sent_position, t.line_number, t.score, t.typo_cost] for t in tokens]
+
+
+def built_model_path():
+    """tests/golden/eval_built_model.raw.xz unpacked under _data/ (kept between runs)."""
+    src = os.path.join(HERE, "golden", "eval_built_model.raw.xz")
+    dst = os.path.join(ROOT, "_data", "eval-built.raw")
+    if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        with lzma.open(src) as f, open(dst + ".tmp", "wb") as g:
+            g.write(f.read())
+        os.replace(dst + ".tmp", dst)
+    return dst
+
+
+def mask_unused(dump: bytes) -> bytes:
+    """A dictionary dump (layout: oracle/ref_bridge.cpp kref_dump_dict) with Morpheme::origMorphemeId zeroed: nothing on the analysis path reads it
+    (it serves KiwiBuilder's word extraction and the joiner), the product does not store it."""
+    b = bytearray(dump)
+    n_forms, n_morphs = struct.unpack_from("<II", b, 0)
+    o = 8
+    for _ in range(n_forms):
+        n, = struct.unpack_from("<I", b, o); o += 4 + 2 * n + 4 + 4 + 2
+        n, = struct.unpack_from("<I", b, o); o += 4 + 4 * n
+    for _ in range(n_morphs):
+        o += 4 + 7 + 4 + 4 + 4
+        b[o:o + 4] = b"\0\0\0\0"; o += 4 + 2
+        n, = struct.unpack_from("<I", b, o); o += 4 + 6 * n
+    assert len(b) - o < 4 * 64, "not the layout of kref_dump_dict"
+    return bytes(b)
+
+
+def check_device(lib_path, name, limit=None):
+    from kiwi_amd.api import KiwiAmd, Typo
+    g = _golden(name)
+    items = g["items"][:limit] if limit else g["items"]
+    path = built_model_path()
+    dev = KiwiAmd(path, lib_path=lib_path) if lib_path else KiwiAmd(path)
+    typo = None
+    if g["typo"]:
+        typo = Typo.from_default(dev.lib, TYPO_SET)
+        typo.prepare(True)
+    texts = [it["text"] for it in items]
+    res = dev.analyze_batch_opt(texts, typo=typo, typo_threshold=2.5) if typo is not None else dev.analyze_batch(texts)
+    got = res.to_python()
+    res.close()
+    for it, y in zip(items, got):
+        assert _rows(y[0][0]) == it["tokens"] and y[0][1] == it["score"], it["text"]
+    if typo is not None:
+        typo.close()
+    dev.close()
+    return len(items)
+
+
+def test_fixture_is_a_built_model():
+    import numpy as np
+    from kiwi_amd.container import read_container
+    from kiwi_amd.synth import MORPH_DTYPE
+    n = {name: len(_golden(name)["items"]) for name in FILES}
+    assert n == {"web": 158, "written": 33, "web_with_typos": 97, "web_with_cont_typos": 97}, n
+    kind, sec = read_container(built_model_path())
+    assert kind == b"KAMDRAW1"
+    morphs = np.frombuffer(sec["morph"].tobytes(), MORPH_DTYPE)
+    combined = int((morphs["combined"] != 0).sum())
+    with_chunks = int((morphs["n_chunks"] != 0).sum())
+    assert len(morphs) > 100000 and combined > 300 and with_chunks > 15000, (len(morphs), combined, with_chunks)
+    # the rules matter: the same texts on the model without them (tests/golden/eval_data_web.json) come out differently
+    plain = json.load(open(os.path.join(HERE, "golden", "eval_data_web.json"), encoding="utf-8"))["items"]
+    differ = sum(a["tokens"] != b["tokens"] for a, b in zip(plain, _golden("web")["items"]))
+    assert differ > 40, differ
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models/cong/base"), reason="needs the reference checkout (build container)")
+def test_real_kiwibuilder_build_is_what_the_container_holds(tmp_path):
+    import sys
+    import refbridge
+    if not refbridge.x86_available():
+        pytest.skip("oracle/_ref/libkiwi_ref_x86.so not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ctypes as C
+    import shutil
+    import make_golden_built as tool
+    from kiwi_amd.workloads import eval_model
+    raw, _ = eval_model(for_builder=True)
+    lib, d = tool.shipped_dir(raw)
+    try:
+        out = str(tmp_path / "export.raw")
+        lib.kref_export_built_raw.restype = C.c_int64
+        lib.kref_export_built_raw.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+        assert lib.kref_export_built_raw(d.encode(), MODEL_TYPE, OPTIONS, raw.encode(), out.encode()) > 10000
+        assert open(out, "rb").read() == open(built_model_path(), "rb").read()          # the committed fixture is this build
+        real = refbridge.RefKiwi.built(d, MODEL_TYPE, OPTIONS)                          # KiwiBuilder::build() itself
+        via_container = refbridge.RefKiwi(built_model_path())                          # the bridge's bake of the exported tables
+        assert real.dump_dict() == via_container.dump_dict()
+        for it in _golden("web")["items"][:40]:
+            a, b = real.analyze(it["text"]), via_container.analyze(it["text"])
+            assert _rows(a[0][0]) == _rows(b[0][0]) == it["tokens"] and a[0][1] == b[0][1] == it["score"], it["text"]
+    finally:
+        shutil.rmtree(d)
+
+
+def test_oracle_and_product_bake_the_reference_dictionary():
+    import subprocess
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    path = built_model_path()
+    emu = os.path.join(HERE, "hipemu")
+    subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
+    orc = oraclelib.OracleKiwi(path).dump_dict()
+    dev = KiwiAmd(path, lib_path=os.path.join(emu, "_build", "libkiwi_hipemu.so"))
+    prod = dev.dump_dict()
+    dev.close()
+    assert mask_unused(orc) == mask_unused(prod)
+    import refbridge
+    if refbridge.available():
+        ref = refbridge.RefKiwi(path).dump_dict()
+        a, b = mask_unused(ref), mask_unused(orc)
+        assert len(a) == len(b)
+        # the reference's sentinel form (last form record) carries uninitialised flag bits: compare around it (tests/test_oracle_vs_ref.py)
+        assert sum(x != y for x, y in zip(a, b)) <= 1
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_oracle_equals_the_built_reference(name):
+    import oraclelib
+    g = _golden(name)
+    orc = oraclelib.OracleKiwi(built_model_path())
+    typo = None
+    if g["typo"]:
+        import refbridge
+        if not refbridge.available():
+            pytest.skip("the built-in typo set is read out of oracle/_ref")
+        ents, cont, leng = refbridge.default_typo_entries("basic_with_continual")
+        typo = oraclelib.OracleTypo(); typo.update_entries(ents, cont, leng); typo.prepare(True)
+    for it in g["items"]:
+        got = orc.analyze_typo(typo, it["text"], 2.5, 0) if typo is not None else orc.analyze(it["text"])
+        assert _rows(got[0][0]) == it["tokens"] and got[0][1] == it["score"], it["text"]
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_emulated_device_equals_the_built_reference(name):
+    import subprocess
+    emu = os.path.join(HERE, "hipemu")
+    subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
+    assert check_device(os.path.join(emu, "_build", "libkiwi_hipemu.so"), name) >= 33            # every line
