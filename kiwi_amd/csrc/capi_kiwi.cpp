@@ -434,7 +434,7 @@ extern "C"
 			case 0x0200: lm = Engine::LmMode::Knlm; break;
 			case 0x0300: lm = Engine::LmMode::Sbg; break;
 			case 0x0400: lm = Engine::LmMode::Cong; break;
-			case 0x0500: throw std::invalid_argument{ "kiwi_amd: CoNgram models with distant-token (global) scoring are not supported on the device path yet" };
+			case 0x0500: throw std::invalid_argument{ "kiwi_amd: CoNgram models with distant-token (global, window 7) scoring are not supported on the device path yet (the oracle restates them: tests/test_cong_global.py)" };
 			default: throw std::invalid_argument{ "kiwi_amd: unknown model type" };
 			}
 			if (enabled_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported" };

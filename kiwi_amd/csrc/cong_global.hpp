@@ -102,33 +102,59 @@ namespace kamd
 			for (uint32_t k = 0; k < WINDOW; ++k) w[k + 1] = C.posConf[k + 1] + (hist[k] ? C.distConf[hist[k]] : -99999.f);
 		}
 
+		// logSoftmaxImpl<sse4_1, 8> (src/MathFunc.hpp:64-86): packets {0..3} and {4..7}, lane sums added horizontally (redsumf, SIMD.hpp:365-369)
+		KAMD_HD float packetSumExp8(const float* w, float mx)
+		{
+			float s[4];
+			for (int l = 0; l < 4; ++l) s[l] = (0.f + expfSimd(w[l] - mx)) + expfSimd(w[4 + l] - mx);
+			return (s[0] + s[2]) + (s[1] + s[3]);
+		}
+		KAMD_HD void logSoftmax8(float* w)
+		{
+			float mx = w[0];
+			for (int i = 1; i < 8; ++i) mx = fmaxSse(mx, w[i]);
+			const float sub = logfSimd(packetSumExp8(w, mx)) + mx;
+			for (int i = 0; i < 8; ++i) w[i] = w[i] - sub;
+		}
+		// logSumExpImpl<sse4_1, 8> (src/MathFunc.hpp:11-31): the same sum, libm's logarithm
+		KAMD_HD float logSumExp8(const float* w)
+		{
+			float mx = w[0];
+			for (int i = 1; i < 8; ++i) mx = fmaxSse(mx, w[i]);
+			return exact::logf_glibc(packetSumExp8(w, mx)) + mx;
+		}
+		// LogSoftmaxTransposed<arch, 8>::block / LogSumExpTransposed<arch, 8>::block (src/MathFunc.hpp:128-190, 245-291): one lane
+		KAMD_HD void logSoftmaxT8(float* w)
+		{
+			float m = fmaxSse(w[0], w[1]);
+			for (int i = 2; i < 8; ++i) m = fmaxSse(m, w[i]);
+			for (int i = 0; i < 8; ++i) w[i] = w[i] - m;
+			float s = expfSimd(w[0]);
+			for (int i = 1; i < 8; ++i) s = s + expfSimd(w[i]);
+			s = logfSimd(s);
+			for (int i = 0; i < 8; ++i) w[i] = w[i] - s;
+		}
+		KAMD_HD float logSumExpT8(const float* w)
+		{
+			float m = fmaxSse(w[0], w[1]);
+			for (int i = 2; i < 8; ++i) m = fmaxSse(m, w[i]);
+			float s = expfSimd(w[0] - m);
+			for (int i = 1; i < 8; ++i) s = s + expfSimd(w[i] - m);
+			return m + logfSimd(s);
+		}
+
 		// progress() for a valid distant token (src/CoNgramModel.cpp:812-841): scatteredGEMMOpt(8, 1) is the baseline kernel (qgemm.hpp:184-187)
 		KAMD_HD float scoreSingle(const CongView& C, uint32_t ctx, const uint32_t* hist, uint32_t next)
 		{
 			float w[8];
 			rawWeights(C, ctx, hist, w);
-			{
-				// logSoftmaxImpl<sse4_1, 8> (src/MathFunc.hpp:64-86): packets {0..3}, {4..7}
-				float mx = w[0];
-				for (int i = 1; i < 8; ++i) mx = fmaxSse(mx, w[i]);
-				float s[4];
-				for (int l = 0; l < 4; ++l) s[l] = (0.f + expfSimd(w[l] - mx)) + expfSimd(w[4 + l] - mx);
-				const float sum = (s[0] + s[2]) + (s[1] + s[3]);      // redsumf (SIMD.hpp:365-369)
-				const float sub = logfSimd(sum) + mx;
-				for (int i = 0; i < 8; ++i) w[i] = w[i] - sub;
-			}
+			logSoftmax8(w);
 			const uint8_t* out = C.outEmb + (size_t)next * C.stride;
 			w[0] = w[0] + rowScore(C.ctxEmb + (size_t)ctx * C.stride, out, C.dim, false);
 			for (uint32_t k = 0; k < WINDOW; ++k) w[k + 1] = w[k + 1] + rowScore(C.distEmb + (size_t)hist[k] * C.stride, out, C.dim, false);      // (an empty slot: distant row 0)
 			const float vts = C.ctxConf[2 * ctx + 1];
 			w[0] = w[0] - vts;
-			// logSumExpImpl<sse4_1, 8> (src/MathFunc.hpp:11-31): std::log of the horizontal sum
-			float mx = w[0];
-			for (int i = 1; i < 8; ++i) mx = fmaxSse(mx, w[i]);
-			float s[4];
-			for (int l = 0; l < 4; ++l) s[l] = (0.f + expfSimd(w[l] - mx)) + expfSimd(w[4 + l] - mx);
-			const float sum = (s[0] + s[2]) + (s[1] + s[3]);
-			return (exact::logf_glibc(sum) + mx) + vts;
+			return logSumExp8(w) + vts;
 		}
 
 		// one entry of progressMatrixWSort / WOSort for a valid distant token (src/CoNgramModel.cpp:1262-1296, 1420-1462); outputFirst: the rounding of the
@@ -137,27 +163,13 @@ namespace kamd
 		{
 			float w[8];
 			rawWeights(C, ctx, hist, w);
-			{
-				// LogSoftmaxTransposed<arch, 8>::block (src/MathFunc.hpp:128-190)
-				float m = fmaxSse(w[0], w[1]);
-				for (int i = 2; i < 8; ++i) m = fmaxSse(m, w[i]);
-				for (int i = 0; i < 8; ++i) w[i] = w[i] - m;
-				float s = expfSimd(w[0]);
-				for (int i = 1; i < 8; ++i) s = s + expfSimd(w[i]);
-				s = logfSimd(s);
-				for (int i = 0; i < 8; ++i) w[i] = w[i] - s;
-			}
+			logSoftmaxT8(w);
 			const float vts = C.ctxConf[2 * ctx + 1];
 			for (int i = 1; i < 8; ++i) w[i] = w[i] + vts;
 			const uint8_t* out = C.outEmb + (size_t)next * C.stride;
 			w[0] = w[0] + rowScore(C.ctxEmb + (size_t)ctx * C.stride, out, C.dim, outputFirst);
 			for (uint32_t k = 0; k < WINDOW; ++k) if (hist[k]) w[k + 1] = w[k + 1] + rowScore(C.distEmb + (size_t)hist[k] * C.stride, out, C.dim, outputFirst);
-			// LogSumExpTransposed<arch, 8>::block (src/MathFunc.hpp:245-291)
-			float m = fmaxSse(w[0], w[1]);
-			for (int i = 2; i < 8; ++i) m = fmaxSse(m, w[i]);
-			float s = expfSimd(w[0] - m);
-			for (int i = 1; i < 8; ++i) s = s + expfSimd(w[i] - m);
-			return m + logfSimd(s);
+			return logSumExpT8(w);
 		}
 
 		// the history after `next` (progress(): src/CoNgramModel.cpp:912-919; nextState: :1004-1013): slot 7 holds the newest word, the ring moves on only

@@ -112,6 +112,19 @@ extern "C"
 		h.scfg.maxUnk = maxUnk; h.scfg.maxUnkJ = maxUnkJ; h.scfg.spaceTol = spaceTol; h.integrateAllomorph = !!integrateAllomorph;
 	}
 
+	// probe of csrc/cong_global.hpp's four 8-term kernels (tests/test_cong_global.py, against the reference's own lm::logSoftmax / logSumExp / ...Transposed
+	// of its SSE4.1 build): which 0 = logSoftmax (in place), 1 = logSumExp, 2 / 3 = the transposed (per-lane) forms; returns the scalar result of 1 / 3
+	float korc_congg_math(int which, float* w8)
+	{
+		switch (which)
+		{
+		case 0: congg::logSoftmax8(w8); return 0;
+		case 1: return congg::logSumExp8(w8);
+		case 2: congg::logSoftmaxT8(w8); return 0;
+		default: return congg::logSumExpT8(w8);
+		}
+	}
+
 	// ModelType::congGlobal: score with the window sections of the CoNgram file (0 = ok, -1 = the model has none)
 	int korc_set_cong_global(void* hp, int on)
 	{

@@ -386,6 +386,28 @@ extern "C"
 	}
 
 #ifdef KREF_X86
+}
+// (instantiated by src/archImpl/sse4_1.cpp with its own ISA flags: not to be instantiated again by this translation unit)
+extern template float kiwi::lm::logSumExp<kiwi::ArchType::sse4_1>(const float*, size_t);
+extern template void kiwi::lm::logSoftmax<kiwi::ArchType::sse4_1>(float*, size_t);
+extern template void kiwi::lm::logSumExpTransposed<kiwi::ArchType::sse4_1>(float*, size_t, size_t, size_t);
+extern template void kiwi::lm::logSoftmaxTransposed<kiwi::ArchType::sse4_1>(float*, size_t, size_t, size_t);
+extern "C"
+{
+	// lm::logSoftmax / logSumExp / logSoftmaxTransposed / logSumExpTransposed of the SSE4.1 build (src/MathFunc.hpp, instantiated by src/archImpl/sse4_1.cpp)
+	// over 8 terms; the transposed forms run on lane 0 of a 32-wide batch like progressMatrix's score buffer.  which as korc_congg_math.
+	float kref_congg_math(int which, float* w8)
+	{
+		using kiwi::ArchType;
+		if (which == 0) { kiwi::lm::logSoftmax<ArchType::sse4_1>(w8, 8); return 0; }
+		if (which == 1) return kiwi::lm::logSumExp<ArchType::sse4_1>(w8, 8);
+		float buf[32 * 8] = { 0 };
+		for (int k = 0; k < 8; ++k) for (int l = 0; l < 4; ++l) buf[k * 32 + l] = w8[k];
+		if (which == 2) { kiwi::lm::logSoftmaxTransposed<ArchType::sse4_1>(buf, 8, 1, 32); for (int k = 0; k < 8; ++k) w8[k] = buf[k * 32]; return 0; }
+		kiwi::lm::logSumExpTransposed<ArchType::sse4_1>(buf, 8, 1, 32);
+		return buf[0];
+	}
+
 	// the same with the container's CoNgram blob loaded as the GLOBAL model (CoNgramModelBase::create(useDistantTokens = true): ModelType::congGlobal)
 	void* kref_open_cong_global(const char* rawModelPath, int arch)
 	{

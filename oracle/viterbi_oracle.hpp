@@ -353,6 +353,7 @@ namespace korc
 			return ((uint16_t)k.prevRoot | ((uint16_t)k.sp << 8)) ^ ((r << 3) | (r >> 61));
 		}
 		std::vector<WPath> bucket[4];
+		std::vector<uint8_t> bucketHash[4];      // low hash byte per entry (BucketedHashContainer::hashes), kept for the global CoNgram model's lookups
 		std::vector<WPath> lset;     // mode 2 (large): distinct keys in insertion order
 
 		std::vector<WPath> titems;   // mode 3 (top-N): every inserted path of the current candidate, in insertion order
@@ -361,6 +362,7 @@ namespace korc
 		void contClear()
 		{
 			for (auto& b : bucket) b.clear();
+			for (auto& b : bucketHash) b.clear();
 			lset.clear(); titems.clear();
 			if (pc) { pc->large.clear(); pc->topIndex.clear(); pc->topValues.clear(); }
 		}
@@ -445,24 +447,40 @@ namespace korc
 				h = ((uint16_t)np.prevRootId | ((uint16_t)np.spState << 8)) ^ ((r << 3) | (r >> 61));
 			}
 			auto& b = bucket[mode == 1 ? ((h >> 8) & 3) : 0];
-			// The SIMD builds look a state up through nst::findAll over the bucket's hash bytes (BestPathContainer.hpp:316-351), and the SSE2 / SSE4.1
-			// findAll masks its result with ((size_t)1 << size) - 1 (src/search.cpp:555-597) -- 0 for size == 64 on x86-64 (the shift count wraps).  Once a
-			// bucket holds 64 entries, entries 0..63 are therefore never found again, and with 128 none is: an equal state is APPENDED instead of merged.
-			// Reproduced for the global model, where equal states (node + history[3..6]) are not identical ones -- the survivor's other history words
-			// change later scores; with the local model an equal state is the same state, a dominated duplicate that changes nothing (and the device
-			// keeps merging there, as before).
-			size_t from = 0, to = b.size();
-			if (C.window && b.size() >= 64) { from = 64; if (b.size() >= 128) to = from; }
-			for (size_t bi = from; bi < to; ++bi)
+			if (C.window && b.size() >= 64)
 			{
-				WPath& t = b[bi];
+				// BucketedHashContainer::insertOptimized of the SIMD builds (BestPathContainer.hpp:316-384) once a bucket holds 64 entries -- two defects
+				// of the reference, reproduced because with the global model equal states (node + history[3..6]) are not identical ones and the survivor's
+				// other history words change later scores (with the local model an equal state is the same state: a dominated duplicate changes nothing,
+				// and device and oracle keep merging there):
+				//   * nst::findAll<sse2 / sse4_1> masks its result with ((size_t)1 << size) - 1 (src/search.cpp:555-597): 0 for size == 64, the shift count
+				//     wraps -- entries 0..63 are never candidates again, and with 128 entries none is;
+				//   * a candidate position j of the second half (hash byte of entry 64 + j equals the new one) is tested with value[j].equalTo(...) -- the
+				//     entry of the FIRST half -- and on success entry 64 + j is the one that is compared by score and overwritten (:341-350).
+				auto& hb = bucketHash[mode == 1 ? ((h >> 8) & 3) : 0];
+				const size_t n2 = b.size() - 64;
+				if (n2 < 64)
+					for (size_t bj = 0; bj < n2; ++bj)
+					{
+						if (hb[64 + bj] != (uint8_t)h) continue;
+						const WPath& probe = b[bj];
+						if (!(probe.prevRootId == np.prevRootId && probe.spState == np.spState && sameLm(probe, np))) continue;
+						WPath& t = b[64 + bj];
+						if (np.accScore > t.accScore) { const uint8_t pr = t.prevRootId; t = np; t.prevRootId = pr; }
+						return;
+					}
+				if (b.size() < (mode == 1 ? cfg.bucketCap : 128u)) { b.push_back(np); hb.push_back((uint8_t)h); }
+				return;
+			}
+			for (auto& t : b)
+			{
 				if (t.prevRootId == np.prevRootId && t.spState == np.spState && sameLm(t, np))
 				{
 					if (np.accScore > t.accScore) { const uint8_t pr = t.prevRootId; t = np; t.prevRootId = pr; }
 					return;
 				}
 			}
-			if (b.size() < (mode == 1 ? cfg.bucketCap : 128u)) b.push_back(np);   // the small container's own capacity is 128 as well
+			if (b.size() < (mode == 1 ? cfg.bucketCap : 128u)) { b.push_back(np); bucketHash[mode == 1 ? ((h >> 8) & 3) : 0].push_back((uint8_t)h); }
 		}
 		template<class Fn> void contEach(int mode, Fn&& fn)
 		{
