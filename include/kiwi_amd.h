@@ -80,6 +80,10 @@ kamd_results_h kamd_res_merge_strided(const uint8_t* const* parts, const size_t*
 /* test hooks: baked dictionary dump and the lattices of one text, in the byte layouts of oracle/ref_bridge.cpp */
 /* developer probe: exp_out[i] = expf, log_out[i] = logf of x[i] computed ON THE DEVICE by csrc/exact_math.hpp (bit-identical to glibc) */
 int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n);
+/* developer probe: the GLOBAL CoNgram model's score (reference CoNgramModel::progress / progressMatrix*, src/CoNgramModel.cpp:802-868, 1037-1466; csrc/cong_global.hpp)
+ * of next[i] after context id ctx[i] with the seven history words hist7[7 * i ..], computed ON THE DEVICE; flags[i] bit 0 = the progressMatrix* entry, bit 1 = output
+ * scale first.  The model must carry the window sections (cong.mdl windowSize 7).  The search does not use this model type yet (kiwi_init refuses CONG_GLOBAL). */
+int kamd_debug_cong_global(kamd_engine_h h, const uint32_t* ctx, const uint32_t* hist7, const uint32_t* next, const uint8_t* flags, float* out, uint32_t n);
 /* developer probe, HOST side: the pattern recogniser of the text preparation (reference matchPattern, src/PatternMatcher.cpp:380) at text[0]:
  * matched length | tag << 32, 0 = no pattern starts here.  `left` = the unit before text[0] (u' ' at the start) */
 uint64_t kamd_debug_match_pattern(uint16_t left, const uint16_t* text, uint32_t len, uint64_t match_options);

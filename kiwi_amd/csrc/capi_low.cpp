@@ -20,6 +20,7 @@ static_assert(sizeof(kamd_token_t) == sizeof(FlatToken) && offsetof(kamd_token_t
 	"kamd_token_t is the layout of kamd::FlatToken");
 
 namespace kamd { void exactMathProbe(const float* x, float* e, float* l, uint32_t n); }
+namespace kamd { void conggProbe(const FlatModel& m, const uint32_t* ctx, const uint32_t* hist, const uint32_t* next, const uint8_t* flags, float* out, uint32_t n); }
 
 namespace
 {
@@ -256,6 +257,12 @@ extern "C"
 	int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n)
 	{
 		return guarded([&]() { kamd::exactMathProbe(x, exp_out, log_out, n); return 0; }, -1);
+	}
+
+	int kamd_debug_cong_global(kamd_engine_h h, const uint32_t* ctx, const uint32_t* hist7, const uint32_t* next, const uint8_t* flags, float* out, uint32_t n)
+	{
+		if (!h) return -1;
+		return guarded([&]() { kamd::conggProbe(h->e->model(), ctx, hist7, next, flags, out, n); return 0; }, -1);
 	}
 
 	// Host-side run of the SkipBigram step the search kernel uses (sbg_eval.hpp, shared source): one LmState::next on top of a

@@ -19,7 +19,7 @@
 //
 // exp / log of the SIMD paths are the Cephes-style polynomials of src/SIMD.hpp:121-246 as the SSE2 / SSE4.1 operator set evaluates them -- per lane, multiply
 // and add rounded separately (maddf = addf(mulf), SIMD.hpp:295); the pin of the CoNgram oracle is the reference's SSE4.1 build.  Compiled with
-// -ffp-contract=off everywhere (csrc/Makefile, tests/hipemu/Makefile; the oracle's x86-64 baseline has no FMA to contract to).
+// -ffp-contract=off everywhere (csrc/Makefile and the lane emulator's; the oracle's x86-64 baseline has no FMA to contract to).
 #pragma once
 #include "flat_model.hpp"
 #include "exact_math.hpp"

@@ -19,6 +19,7 @@
 #include "hostpool.hpp"
 #include "viterbi_kernel.hpp"
 #include "exact_math.hpp"
+#include "cong_global.hpp"
 #include "typo_lattice_kernel.hpp"
 #include "typo_graph_kernel.hpp"
 
@@ -618,6 +619,39 @@ namespace kamd
 		HIPCHECK(hipGetLastError());
 		HIPCHECK(hipMemcpy(e, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 		HIPCHECK(hipMemcpy(l, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	}
+
+	// Probe of csrc/cong_global.hpp on the device (tests/test_cong_global.py): the score of `next[i]` after context ctx[i] and the seven history words hist[i][0..6]
+	// under the GLOBAL CoNgram model -- flags[i] bit 0: the progressMatrix* entry instead of state.next(), bit 1: output scale first -- and the local score for a
+	// word that is no valid distant token.  The first device piece of that model type (the search kernel does not use it yet): the arithmetic and the layout of
+	// the window sections in HBM, checked bit for bit against the host evaluation of the same header that the oracle pins to the real reference.
+	__global__ void k_congg_probe(CongView C, const uint32_t* ctx, const uint32_t* hist, const uint32_t* next, const uint8_t* flags, float* out, uint32_t n)
+	{
+		const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+		if (i >= n) return;
+		uint32_t h[7];
+		for (int k = 0; k < 7; ++k) h[k] = hist[7ull * i + k];
+		const bool matrix = flags[i] & 1, outFirst = flags[i] & 2;
+		if (C.distant(next[i])) out[i] = matrix ? congg::scoreMatrix(C, ctx[i], h, next[i], outFirst) : congg::scoreSingle(C, ctx[i], h, next[i]);
+		else out[i] = outFirst ? congScoreOutputFirst(C, ctx[i], next[i]) : congScore(C, ctx[i], next[i]);
+	}
+	void conggProbe(const FlatModel& m, const uint32_t* ctx, const uint32_t* hist, const uint32_t* next, const uint8_t* flags, float* out, uint32_t n)
+	{
+		if (!m.congDim || !m.congWindow) throw std::runtime_error{ "the model has no CoNgram window sections" };
+		DevBuf dCtxEmb, dOutEmb, dDistEmb, dCtxConf, dDistConf, dPosConf, dMask, dCtx, dHist, dNext, dFlags, dOut;
+		auto up = [](DevBuf& b, const void* p, size_t bytes) { b.ensure(bytes + 16); HIPCHECK(hipMemcpy(b.p, p, bytes, hipMemcpyHostToDevice)); };
+		up(dCtxEmb, m.congCtxEmb.data(), m.congCtxEmb.size()); up(dOutEmb, m.congOutEmb.data(), m.congOutEmb.size()); up(dDistEmb, m.congDistEmb.data(), m.congDistEmb.size());
+		up(dCtxConf, m.congCtxConf.data(), m.congCtxConf.size() * 4); up(dDistConf, m.congDistConf.data(), m.congDistConf.size() * 4);
+		up(dPosConf, m.congPosConf.data(), m.congPosConf.size() * 4); up(dMask, m.congDistMask.data(), m.congDistMask.size());
+		up(dCtx, ctx, (size_t)n * 4); up(dHist, hist, (size_t)n * 28); up(dNext, next, (size_t)n * 4); up(dFlags, flags, n);
+		dOut.ensure((size_t)n * 4 + 16);
+		CongView C;
+		C.dim = m.congDim; C.stride = m.congDim + 8; C.nCtx = m.congCtx; C.vocabSize = m.congVocab; C.window = m.congWindow; C.keyBytes = m.congKeyBytes;
+		C.ctxEmb = dCtxEmb.as<uint8_t>(); C.outEmb = dOutEmb.as<uint8_t>(); C.distEmb = dDistEmb.as<uint8_t>();
+		C.ctxConf = dCtxConf.as<float>(); C.distConf = dDistConf.as<float>(); C.posConf = dPosConf.as<float>(); C.distMask = dMask.as<uint8_t>();
+		hipLaunchKernelGGL(k_congg_probe, dim3((n + 63) / 64), dim3(64), 0, 0, C, dCtx.as<uint32_t>(), dHist.as<uint32_t>(), dNext.as<uint32_t>(), dFlags.as<uint8_t>(), dOut.as<float>(), n);
+		HIPCHECK(hipGetLastError());
+		HIPCHECK(hipMemcpy(out, dOut.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	}
 
 	static SearchParams makeParams(const EngineConfig& c, uint64_t match, uint32_t topN = 1)

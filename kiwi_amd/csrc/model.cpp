@@ -759,7 +759,8 @@ namespace kamd
 				struct stat st;
 				if (stat((dir + "/combiningRule.txt").c_str(), &st) == 0 && !std::getenv("KAMD_ALLOW_UNEXPANDED_MODEL"))
 					throw std::runtime_error{ "kiwi_amd: this model directory holds combiningRule.txt: the reference expands rule-combined morphemes and loads its .dict "
-						"files at build time, which this library does not do yet -- analyses would differ from the reference's (tools/check_model_dir.py "
+						"files at build time, which this library does not do itself -- analyses would differ from the reference's.  Let the reference's builder do that step: "
+						"tools/export_built.cpp (built against libkiwi) writes a container of this directory that kiwi_init loads.  (tools/check_model_dir.py "
 						"describes the directory; KAMD_ALLOW_UNEXPANDED_MODEL=1 loads sj.morph + the language model alone)" };
 			}
 			const std::vector<uint8_t> mb = readFile(dir + "/sj.morph", true);

@@ -125,6 +125,21 @@ extern "C"
 		}
 	}
 
+	// the host evaluation behind kamd_debug_cong_global's device probe: same arguments, the oracle's own model (congGlobal must be on)
+	int korc_congg_scores(void* hp, const uint32_t* ctx, const uint32_t* hist7, const uint32_t* next, const uint8_t* flags, float* out, uint32_t n)
+	{
+		auto& h = *(OracleHandle*)hp;
+		const CongView& C = h.cong;
+		if (!C.window) return -1;
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			const bool matrix = flags[i] & 1, outFirst = flags[i] & 2;
+			if (C.distant(next[i])) out[i] = matrix ? congg::scoreMatrix(C, ctx[i], hist7 + 7ull * i, next[i], outFirst) : congg::scoreSingle(C, ctx[i], hist7 + 7ull * i, next[i]);
+			else out[i] = outFirst ? congScoreOutputFirst(C, ctx[i], next[i]) : congScore(C, ctx[i], next[i]);
+		}
+		return 0;
+	}
+
 	// ModelType::congGlobal: score with the window sections of the CoNgram file (0 = ok, -1 = the model has none)
 	int korc_set_cong_global(void* hp, int on)
 	{

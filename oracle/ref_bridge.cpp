@@ -346,25 +346,6 @@ namespace
 	}
 }
 
-#ifdef KREF_X86
-// KiwiBuilder keeps its state private and befriends nobody this file could be; an explicit template instantiation may name private members
-// (the standard's access rules do not apply there), which is how its morpheme lists and buildCombinedMorphemes are reached -- unmodified sources.
-namespace kamd_ref
-{
-	template<class Tag, typename Tag::type M> struct Reach { friend typename Tag::type reach(Tag) { return M; } };
-	struct KbForms { using type = kiwi::Vector<kiwi::FormRaw> kiwi::KiwiBuilder::*; friend type reach(KbForms); };
-	struct KbMorphs { using type = kiwi::Vector<kiwi::MorphemeRaw> kiwi::KiwiBuilder::*; friend type reach(KbMorphs); };
-	struct KbCombine
-	{
-		using type = void (kiwi::KiwiBuilder::*)(kiwi::Vector<kiwi::FormRaw>&, kiwi::UnorderedMap<kiwi::KString, size_t>&, kiwi::Vector<kiwi::MorphemeRaw>&,
-			kiwi::UnorderedMap<size_t, kiwi::Vector<uint32_t>>&, kiwi::Map<int, int>*) const;
-		friend type reach(KbCombine);
-	};
-	template struct Reach<KbForms, &kiwi::KiwiBuilder::forms>;
-	template struct Reach<KbMorphs, &kiwi::KiwiBuilder::morphemes>;
-	template struct Reach<KbCombine, &kiwi::KiwiBuilder::buildCombinedMorphemes>;
-}
-#endif
 
 extern "C"
 {
@@ -495,69 +476,7 @@ extern "C"
 		}
 		catch (const std::exception& e) { fprintf(stderr, "kref_write_empty_extract: %s\n", e.what()); return -1; }
 	}
-	// The state of the REAL builder after it has loaded `dir` (dictionaries per `options`) and generated the rule-combined morphemes
-	// (KiwiBuilder::buildCombinedMorphemes, the first step of build()), written as a raw-model container: forms + combined forms, every form's
-	// candidates followed by the combined ones build() would add to it, morphemes + combined morphemes; the language-model blobs and the vocabulary
-	// size are taken over from `lmRawPath`.  What build() does after that step is the bake this repo's loaders restate -- so a container exported
-	// here loads like any raw model, in the bridge, the oracle and the product.  Returns the number of combined morphemes, < 0 on failure.
-	int64_t kref_export_built_raw(const char* dir, int modelType, int options, const char* lmRawPath, const char* outPath)
-	{
-		try
-		{
-			using namespace kiwi;
-			KiwiBuilder kb{ std::string{ dir }, 1, (BuildOption)options, (ModelType)modelType };
-			const auto& forms = kb.*reach(kamd_ref::KbForms{});
-			const auto& morphemes = kb.*reach(kamd_ref::KbMorphs{});
-			Vector<FormRaw> cForms; Vector<MorphemeRaw> cMorphs;
-			UnorderedMap<KString, size_t> newFormMap; UnorderedMap<size_t, Vector<uint32_t>> newFormCands;
-			(kb.*reach(kamd_ref::KbCombine{}))(cForms, newFormMap, cMorphs, newFormCands, nullptr);
-
-			kamd::Container lmFile; lmFile.load(lmRawPath);
-			kamd::RawModel lmRaw; lmRaw.bind(lmFile);
-			std::vector<uint32_t> formPtr{ 0 }, candPtr{ 0 }, cands, chunkIds;
-			std::vector<uint16_t> chars; std::vector<uint8_t> chunkPos;
-			const size_t nF = forms.size() + cForms.size();
-			for (size_t i = 0; i < nF; ++i)
-			{
-				const FormRaw& f = i < forms.size() ? forms[i] : cForms[i - forms.size()];
-				chars.insert(chars.end(), f.form.begin(), f.form.end());
-				formPtr.push_back((uint32_t)chars.size());
-				cands.insert(cands.end(), f.candidate.begin(), f.candidate.end());
-				auto it = newFormCands.find(i);
-				if (it != newFormCands.end()) cands.insert(cands.end(), it->second.begin(), it->second.end());
-				candPtr.push_back((uint32_t)cands.size());
-			}
-			std::vector<kamd::RawMorph> recs;
-			const size_t nM = morphemes.size() + cMorphs.size();
-			for (size_t i = 0; i < nM; ++i)
-			{
-				const MorphemeRaw& m = i < morphemes.size() ? morphemes[i] : cMorphs[i - morphemes.size()];
-				kamd::RawMorph r{};
-				r.kform = m.kform; r.lmId = m.lmMorphemeId; r.origId = m.origMorphemeId; r.combined = m.combined; r.userScore = m.userScore;
-				r.chunkPtr = (uint32_t)chunkIds.size(); r.tag = (uint8_t)m.tag; r.vpPack = m.vpPack; r.senseId = m.senseId; r.socket = m.combineSocket;
-				r.dialect = (uint16_t)m.dialect; r.nChunks = (uint8_t)m.chunks.size();
-				if (m.chunks.size() > 255) throw std::runtime_error{ "a morpheme of more than 255 chunks" };
-				for (size_t c = 0; c < m.chunks.size(); ++c)
-				{
-					chunkIds.push_back(m.chunks[c]);
-					chunkPos.push_back((uint8_t)m.chunkPositions[c].first); chunkPos.push_back((uint8_t)m.chunkPositions[c].second);
-				}
-				recs.push_back(r);
-			}
-			const uint32_t meta[4] = { (uint32_t)nF, (uint32_t)nM, (uint32_t)lmRaw.vocabSize(), 0 };
-			kamd::ContainerWriter w;
-			w.add("meta", meta, sizeof(meta));
-			w.add("form_ptr", formPtr); w.add("form_chars", chars); w.add("form_cand_ptr", candPtr); w.add("form_cand", cands);
-			w.add("morph", recs); w.add("chunk_ids", chunkIds); w.add("chunk_pos", chunkPos);
-			if (lmRaw.knlm) w.add("knlm", lmRaw.knlm, lmRaw.knlmSize);
-			if (lmRaw.sbg) w.add("sbg", lmRaw.sbg, lmRaw.sbgSize);
-			if (lmRaw.cong) w.add("cong", lmRaw.cong, lmRaw.congSize);
-			if (lmRaw.nounchr) w.add("nounchr", lmRaw.nounchr, lmRaw.nounchrSize);
-			w.save(outPath, "KAMDRAW1");
-			return (int64_t)cMorphs.size();
-		}
-		catch (const std::exception& e) { fprintf(stderr, "kref_export_built_raw: %s\n", e.what()); return -1; }
-	}
+	// (the export of the builder's tables after buildCombinedMorphemes is tools/export_built.cpp -- a program of its own, the one a Kiwi maintainer would build)
 	void* kref_open_built(const char* dir, int modelType, int options)
 	{
 		try

@@ -1,13 +1,13 @@
 """A model as the REAL KiwiBuilder builds it (src/KiwiBuilder.cpp compiled unmodified into oracle/_ref/libkiwi_ref_x86.so): the small synthetic
 sj.morph / sj.knlm + the eval_data gold lexicon, then the reference's own shipped combiningRule.txt, default.dict (113 k entries) and typo.dict through
-loadDictionary / buildCombinedMorphemes / build -- exported after that step as a raw-model container (tests/golden/eval_built_model.raw.xz, 15 k
+loadDictionary / buildCombinedMorphemes / build -- exported after that step by tools/export_built.cpp as a raw-model container (tests/golden/eval_built_model.raw.xz, 15 k
 rule-combined morphemes) together with what the built Kiwi itself answered on column 1 of the eval_data files (tests/golden/eval_built_*.json);
 both written by tools/make_golden_built.py in the build container.
 
   * where /root/reference and the x86 reference build exist: the export is reproduced byte for byte, and the dictionary the reference bakes from the
     container equals the one KiwiBuilder::build() baked from the directory -- the container route the parity tests use loses nothing of a real build;
   * everywhere: the oracle and the product bake the same dictionary from the container, the oracle and the lane-emulated kernels answer what the built
-    Kiwi answered (typo files with the built-in set basicTypoSetWithContinual); `-m gpu`: tests/test_gpu_zzz_built_model.py, every line on the MI355X.
+    Kiwi answered (typo files with the built-in set basicTypoSetWithContinual); `-m gpu`: tests/test_zz_gpu_built_model.py, every line on the MI355X.
 
 What this covers beyond tests/test_eval_data.py: pre-combined and allomorph morphemes with chunks, combineSocket / combined links over 15 k rule
 products, pre-analysed multi-morpheme dictionary words, typo.dict's pre-analysed corrections.  The language model stays synthetic."""
@@ -109,7 +109,6 @@ def test_real_kiwibuilder_build_is_what_the_container_holds(tmp_path):
     if not refbridge.x86_available():
         pytest.skip("oracle/_ref/libkiwi_ref_x86.so not built")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import ctypes as C
     import shutil
     import make_golden_built as tool
     from kiwi_amd.workloads import eval_model
@@ -117,9 +116,8 @@ def test_real_kiwibuilder_build_is_what_the_container_holds(tmp_path):
     lib, d = tool.shipped_dir(raw)
     try:
         out = str(tmp_path / "export.raw")
-        lib.kref_export_built_raw.restype = C.c_int64
-        lib.kref_export_built_raw.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
-        assert lib.kref_export_built_raw(d.encode(), MODEL_TYPE, OPTIONS, raw.encode(), out.encode()) > 10000
+        report = tool.export(d, out)                                                     # tools/export_built.cpp, the program a maintainer would run
+        assert "15272 rule-combined" in report and "135014 morphemes" in report, report
         assert open(out, "rb").read() == open(built_model_path(), "rb").read()          # the committed fixture is this build
         real = refbridge.RefKiwi.built(d, MODEL_TYPE, OPTIONS)                          # KiwiBuilder::build() itself
         via_container = refbridge.RefKiwi(built_model_path())                          # the bridge's bake of the exported tables

@@ -6,7 +6,9 @@ where the reference library is absent.  32-bit and 16-bit ids: the reference's s
 
 What the pin found in the reference and the oracle reproduces (without it 1 sentence in ~400 differs): once a bucket of the path container holds 64
 entries, nst::findAll<sse4_1> returns nothing for its first half (a shift count of 64), and candidates of the second half are compared with the entry of
-the FIRST half at the same offset (BestPathContainer.hpp:341-350).  The device path for this model type is not built: kiwi_init refuses CONG_GLOBAL."""
+the FIRST half at the same offset (BestPathContainer.hpp:341-350).  The device path for this model type is not built: kiwi_init refuses CONG_GLOBAL.  Its first
+piece is: kamd_debug_cong_global evaluates the same header on the device over the window sections in HBM (lane emulator here; `-m gpu`:
+tests/test_zzz_gpu_cong_global_probe.py on the MI355X)."""
 import json
 import os
 import struct
@@ -155,3 +157,47 @@ def test_the_sentence_that_needs_the_container_defects():
     got = _rows(_oracle(path).analyze(it["text"]))
     assert got == it["res"]
     assert [t[0] for t in got[0][0]][5:7] == ["소갸", "탸"] and abs(got[0][1] - (-89.72936248779297)) < 1e-6
+
+
+def probe_device_arithmetic(lib_path):
+    """kamd_debug_cong_global (the device evaluating csrc/cong_global.hpp over the window sections it uploaded) against the host evaluation of the same
+    header inside the oracle -- which the analyses above pin to the real reference: 24 000 random (context, history, next, kind) queries, bit for bit."""
+    import ctypes as C
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    n_ok = 0
+    for which in ("32", "16"):
+        sm, path = _model(which)
+        orc = _oracle(path)
+        dev = KiwiAmd(path, lib_path=lib_path) if lib_path else KiwiAmd(path)
+        L = dev.lib
+        L.kamd_debug_cong_global.argtypes = [C.c_void_p] * 6 + [C.c_uint32]
+        O = orc.lib
+        O.korc_congg_scores.argtypes = [C.c_void_p] * 6 + [C.c_uint32]
+        from kiwi_amd.container import read_container
+        blob = read_container(path)[1]["cong"]
+        vocab, n_ctx = struct.unpack_from("<QQ", blob.tobytes(), 0)
+        rng = np.random.default_rng(5)
+        n = 12000
+        ctx = rng.integers(0, n_ctx, n, dtype=np.uint32)
+        nxt = rng.integers(0, vocab, n, dtype=np.uint32)
+        hist = rng.integers(1, vocab, (n, 7), dtype=np.uint32)
+        hist[rng.random((n, 7)) < 0.35] = 0                      # empty slots
+        hist[: n // 10] = 0                                       # ... and whole empty histories
+        flags = rng.integers(0, 4, n, dtype=np.uint8)
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        assert L.kamd_debug_cong_global(dev.h, ctx.ctypes.data, hist.ctypes.data, nxt.ctypes.data, flags.ctypes.data, a.ctypes.data, n) == 0
+        assert O.korc_congg_scores(orc.h, ctx.ctypes.data, hist.ctypes.data, nxt.ctypes.data, flags.ctypes.data, b.ctypes.data, n) == 0
+        assert a.tobytes() == b.tobytes(), int((a.view(np.uint32) != b.view(np.uint32)).sum())
+        assert np.isfinite(a).all() and len(set(a.tolist())) > n // 2
+        dev.close()
+        n_ok += n
+    return n_ok
+
+
+def test_emulated_device_arithmetic_equals_the_oracle():
+    import subprocess
+    emu = os.path.join(HERE, "hipemu")
+    subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
+    assert probe_device_arithmetic(os.path.join(emu, "_build", "libkiwi_hipemu.so")) == 24000
+

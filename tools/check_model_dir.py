@@ -47,7 +47,9 @@ def main(d):
     if texts:
         print("build-time inputs of the reference's KiwiBuilder that this library does NOT consume:", ", ".join(texts))
         if "combiningRule.txt" in texts:
-            print("  -> kiwi_init refuses this directory (set KAMD_ALLOW_UNEXPANDED_MODEL=1 to analyse with sj.morph + the language model alone: "
+            print("  -> kiwi_init refuses this directory: export it with the reference's builder (tools/export_built.cpp, built against libkiwi) and load the "
+                  "container that writes;")
+            print("     (or set KAMD_ALLOW_UNEXPANDED_MODEL=1 to analyse with sj.morph + the language model alone: "
                   "rule-combined morphemes and dictionary entries will be missing, results differ from the reference's)")
 
 

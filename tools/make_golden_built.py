@@ -7,7 +7,7 @@ oracle/_ref/libkiwi_ref_x86.so) from a directory as Kiwi ships it --
     extract.mdl          empty tables, written through the reference's serializer (the word detector is not on the analysis path)
     combiningRule.txt, default.dict, typo.dict     the REAL files of /root/reference/models/cong/base (113 k dictionary entries, the combining rules)
 
--- exported after the builder's own buildCombinedMorphemes step as a raw-model container (kref_export_built_raw) into
+-- exported after the builder's own buildCombinedMorphemes step as a raw-model container (tools/export_built.cpp, the maintainer's exporter) into
 tests/golden/eval_built_model.raw.xz, and what the built Kiwi itself (KiwiBuilder::build) answers on column 1 of the eval_data files into
 tests/golden/eval_built_<file>.json (typo files with the built-in set basicTypoSetWithContinual).  Run in the build container."""
 import ctypes as C, json, lzma, os, shutil, sys, tempfile
@@ -35,6 +35,27 @@ def shipped_dir(raw_path):
     return lib, d
 
 
+def build_exporter():
+    """tools/export_built.cpp -- the exporter a Kiwi maintainer builds against libkiwi -- linked here against the reference objects of oracle/_ref
+    (every object but the bridge's).  Returns the path of the program."""
+    import glob, subprocess
+    objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "oracle", "_ref", "obj_x86", "*.o"))) if not o.endswith("ref_bridge.o")]
+    assert objs, "run `make -C oracle refx86` first"
+    exe = os.path.join(ROOT, "tools", "_build", "export_built")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    src = os.path.join(ROOT, "tools", "export_built.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(p) for p in [src] + objs):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-w", "-DKIWI_ARCH_X86_64", "-I" + os.path.join(ROOT, "oracle", "standin"), "-I/root/reference/include",
+                               "-I/root/reference/src", "-I" + ROOT, src] + objs + ["-pthread", "-o", exe])
+    return exe
+
+
+def export(d, out):
+    """export_built <directory> <out> <model type> <options> -> the program's report line."""
+    import subprocess
+    return subprocess.run([build_exporter(), d, out, str(MODEL_TYPE), str(OPTIONS)], check=True, capture_output=True, text=True).stdout.strip()
+
+
 def main():
     import refbridge
     from kiwi_amd.workloads import eval_model
@@ -42,13 +63,10 @@ def main():
     lib, d = shipped_dir(raw)
     try:
         out = os.path.join(tempfile.gettempdir(), "eval_built_model.raw")
-        lib.kref_export_built_raw.restype = C.c_int64
-        lib.kref_export_built_raw.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
-        n = lib.kref_export_built_raw(d.encode(), MODEL_TYPE, OPTIONS, raw.encode(), out.encode())
-        assert n > 0
+        print(export(d, out))
         with open(out, "rb") as f, lzma.open(os.path.join(GOLD, "eval_built_model.raw.xz"), "wb", preset=9) as g:
             g.write(f.read())
-        print(n, "rule-combined morphemes;", os.path.getsize(out), "bytes ->", os.path.getsize(os.path.join(GOLD, "eval_built_model.raw.xz")), "compressed")
+        print(os.path.getsize(out), "bytes ->", os.path.getsize(os.path.join(GOLD, "eval_built_model.raw.xz")), "compressed")
         built = refbridge.RefKiwi.built(d, MODEL_TYPE, OPTIONS)
         typo = refbridge.RefTypo.from_default("basic_with_continual")
         typo.prepare(True)
