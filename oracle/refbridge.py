@@ -98,6 +98,8 @@ class RefKiwi:
     def __init__(self, raw_model_path: str, arch: int = 0, model_dir_sbg=None, x86=False):
         """raw_model_path: a raw container; or, with model_dir_sbg = False / True / 2 (= cong.mdl, CoNgram), a DIRECTORY holding the reference's own model files,
         loaded through the reference's serializer (Knlm only / with skipbigram.mdl).
+        model_dir_sbg = "cong_global": a raw container whose CoNgram blob is loaded as the GLOBAL model (window 7); ("built", ModelType, BuildOption bits): a
+        directory as Kiwi ships it, loaded and built by the real KiwiBuilder (RefKiwi.built).
         x86: the library built with every SIMD architecture and src/CoNgramModel.cpp (oracle/Makefile refx86): a container with a CoNgram blob is
         analysed with it; arch 3 = sse4_1, 4 = avx2, 5 = avx512bw, 6 = avx512vnni (the quantised CoNgram path exists for those only)."""
         if x86 and not x86_available():
