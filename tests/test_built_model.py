@@ -173,3 +173,50 @@ def test_emulated_device_equals_the_built_reference(name):
     emu = os.path.join(HERE, "hipemu")
     subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
     assert check_device(os.path.join(emu, "_build", "libkiwi_hipemu.so"), name) >= 33            # every line
+
+
+@pytest.mark.parametrize("lanes", ["pos", "16", "64"])
+def test_emulated_kernel_variants_on_the_built_model(monkeypatch, lanes):
+    """The real dictionary through the search kernels one by one -- the position-step kernel ("pos"), the general kernel in groups of 16 and 64 lanes --:
+    top-1 and top-3 on the plain eval_data lines, typo correction top-1 and top-2 on the misspelt ones (built-in set basicTypoSetWithContinual entered
+    rule by rule in the same order on both sides: the order of the rules decides which of exactly tied paths is kept), all against the oracle."""
+    import subprocess
+    import oraclelib
+    import refbridge
+    import test_typo_product
+    from corpora import force_lanes
+    from kiwi_amd.api import KiwiAmd
+    from test_hipemu import _analyze_typo
+    if not refbridge.available():
+        pytest.skip("the built-in typo set is read out of oracle/_ref")
+    emu = os.path.join(HERE, "hipemu")
+    subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
+    lib = os.path.join(emu, "_build", "libkiwi_hipemu.so")
+    force_lanes(monkeypatch, lanes)
+    path = built_model_path()
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=lib)
+
+    def rows(res):
+        return [([(t.form, t.tag, t.position, t.length, t.score, t.typo_cost) for t in toks], sc) for toks, sc in res]
+    plain = [it["text"] for n in ("web", "written") for it in _golden(n)["items"]][::2]
+    for top_n in (1, 3):
+        for s, y in zip(plain, dev.analyze_batch(plain, top_n=top_n).to_python()):
+            assert rows(orc.analyze(s, top_n=top_n)) == rows(y), (top_n, s)
+    ents, cont, leng = refbridge.default_typo_entries("basic_with_continual")
+    test_typo_product.LIB = lib
+    prod = test_typo_product.ProductTypo(cont, leng)
+    ot = oraclelib.OracleTypo(cont, leng)
+    for orig, err, cost, cond, dialect in ents:
+        prod.add_entry(orig, err, cost, cond, dialect)
+    ot.update_entries(ents, cont, leng)
+    prod.prepare(True); ot.prepare(True)
+    misspelt = [it["text"] for it in _golden("web_with_typos")["items"]][::2]
+    corrected = 0
+    for top_n in (1, 2):
+        for s, y in zip(misspelt, _analyze_typo(dev, prod, misspelt, 2.5, top_n)):
+            want = orc.analyze_typo(ot, s, 2.5, 0, top_n=top_n)
+            assert rows(want) == rows(y), (top_n, s)
+            corrected += any(t.typo_cost > 0 for t in want[0][0])
+    assert corrected >= 20
+    dev.close(); prod.close()
