@@ -220,3 +220,53 @@ def test_emulated_kernel_variants_on_the_built_model(monkeypatch, lanes):
             corrected += any(t.typo_cost > 0 for t in want[0][0])
     assert corrected >= 20
     dev.close(); prod.close()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models/cong/base"), reason="needs the reference checkout (build container)")
+def test_built_cong_model_reference_oracle_and_emulated_device(tmp_path, monkeypatch):
+    """The same directory with a (synthetic, local) cong.mdl as its language model, the layout of the reference's models/cong/base: built by the real
+    KiwiBuilder as ModelType::cong on its SSE4.1 dispatch, exported by tools/export_built.cpp, analysed by the oracle and the lane-emulated CoNgram
+    kernels -- all three identical on the eval_data lines.  (The SkipBigram twin is not run: the synthetic skip-bigram tables let paths multiply on
+    462-character lines until reference, oracle and device arenas alike take minutes per line -- DESIGN.md section 8, state arenas.)"""
+    import json as _json
+    import shutil
+    import subprocess
+    import sys
+    from dataclasses import replace
+    import oraclelib
+    import refbridge
+    if not refbridge.x86_available():
+        pytest.skip("oracle/_ref/libkiwi_ref_x86.so not built")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden_built as tool
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.synth import SMALL_CONG_SPEC, SynthModel
+    from kiwi_amd.workloads import EVAL_BUILDER_REQUIRED
+    monkeypatch.setenv("KIWI_ARCH_TYPE", "sse4_1")      # the reference's own switch (src/ArchUtils.cpp:105-117); the CoNgram pin is its SSE4.1 arithmetic
+    entries = _json.load(open(os.path.join(HERE, "golden", "eval_data_lexicon.json"), encoding="utf-8"))["entries"]
+    raw = os.path.join(ROOT, "_data", "small-eval-builder-cong.raw")
+    if not os.path.exists(raw):
+        SynthModel(replace(SMALL_CONG_SPEC, extra_words=tuple((f, t) for f, t in entries) + EVAL_BUILDER_REQUIRED)).raw.save(raw)
+    lib, d = tool.shipped_dir(raw)
+    try:
+        assert "cong.mdl" in os.listdir(d)
+        out = str(tmp_path / "built_cong.raw")
+        monkeypatch.setattr(tool, "MODEL_TYPE", 4)      # ModelType::cong
+        assert "15272 rule-combined" in tool.export(d, out)
+        ref = refbridge.RefKiwi.built(d, 4, OPTIONS)
+        orc = oraclelib.OracleKiwi(out)
+        emu = os.path.join(HERE, "hipemu")
+        subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
+        dev = KiwiAmd(out, lib_path=os.path.join(emu, "_build", "libkiwi_hipemu.so"))
+
+        def rows(res):
+            return [([(t.form, t.tag, t.position, t.length, t.score) for t in toks], sc) for toks, sc in res]
+        texts = [it["text"] for n in ("web", "written") for it in _golden(n)["items"]][::3]
+        got = dev.analyze_batch(texts).to_python()
+        for s, y in zip(texts, got):
+            a = rows(ref.analyze(s))
+            assert a == rows(orc.analyze(s)) == rows(y), s
+        assert orc.counters()["congScores"] > 10000
+        dev.close()
+    finally:
+        shutil.rmtree(d)
