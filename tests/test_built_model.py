@@ -199,7 +199,7 @@ def test_emulated_kernel_variants_on_the_built_model(monkeypatch, lanes):
 
     def rows(res):
         return [([(t.form, t.tag, t.position, t.length, t.score, t.typo_cost) for t in toks], sc) for toks, sc in res]
-    plain = [it["text"] for n in ("web", "written") for it in _golden(n)["items"]][::2]
+    plain = [it["text"] for n in ("web", "written") for it in _golden(n)["items"]][::4]
     for top_n in (1, 3):
         for s, y in zip(plain, dev.analyze_batch(plain, top_n=top_n).to_python()):
             assert rows(orc.analyze(s, top_n=top_n)) == rows(y), (top_n, s)
@@ -211,14 +211,14 @@ def test_emulated_kernel_variants_on_the_built_model(monkeypatch, lanes):
         prod.add_entry(orig, err, cost, cond, dialect)
     ot.update_entries(ents, cont, leng)
     prod.prepare(True); ot.prepare(True)
-    misspelt = [it["text"] for it in _golden("web_with_typos")["items"]][::2]
+    misspelt = [it["text"] for it in _golden("web_with_typos")["items"]][::3]
     corrected = 0
     for top_n in (1, 2):
         for s, y in zip(misspelt, _analyze_typo(dev, prod, misspelt, 2.5, top_n)):
             want = orc.analyze_typo(ot, s, 2.5, 0, top_n=top_n)
             assert rows(want) == rows(y), (top_n, s)
             corrected += any(t.typo_cost > 0 for t in want[0][0])
-    assert corrected >= 20
+    assert corrected >= 12
     dev.close(); prod.close()
 
 
