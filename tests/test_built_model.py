@@ -270,3 +270,35 @@ def test_built_cong_model_reference_oracle_and_emulated_device(tmp_path, monkeyp
         dev.close()
     finally:
         shutil.rmtree(d)
+
+
+def test_match_options_on_the_built_model():
+    """open ending and the Match bits that change lattices or candidate sets (normalisation off, splitComplex, zCoda off, splitSaisiot, mergeSaisiot) on the
+    real dictionary: emulated device == oracle, and == the real reference analysing the same container where oracle/_ref is present."""
+    import subprocess
+    import oraclelib
+    import refbridge
+    from kiwi_amd.api import KiwiAmd
+    emu = os.path.join(HERE, "hipemu")
+    subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
+    path = built_model_path()
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=os.path.join(emu, "_build", "libkiwi_hipemu.so"))
+    ref = refbridge.RefKiwi(path) if refbridge.available() else None
+
+    def rows(res):
+        return [([(t.form, t.tag, t.position, t.length, t.score) for t in toks], sc) for toks, sc in res]
+    texts = [it["text"] for n in ("web", "written") for it in _golden(n)["items"]][::4]
+    M = oraclelib.MATCH_ALL_WITH_NORMALIZING
+    cases = [("open_ending", M, True), ("no normalisation", M & ~(1 << 16), False), ("splitComplex", M | (1 << 17), False), ("zCoda off", M & ~(1 << 23), False),
+             ("splitSaisiot", M | (1 << 19), False), ("mergeSaisiot", M | (1 << 21), False)]
+    base = [rows(orc.analyze(s)) for s in texts]
+    for name, match, open_ending in cases:
+        got = dev.analyze_batch(texts, match=match, open_ending=open_ending).to_python()
+        want = [rows(orc.analyze(s, match=match, open_ending=open_ending)) for s in texts]
+        assert [rows(y) for y in got] == want, name
+        if ref is not None:
+            assert [rows(ref.analyze(s, match=match, open_ending=open_ending)) for s in texts] == want, name
+        if name == "open_ending":      # (sanity: the option reaches the search; the Match bits need text the sample may not hold)
+            assert want != base, name
+    dev.close()
