@@ -302,3 +302,37 @@ def test_match_options_on_the_built_model():
         if name == "open_ending":      # (sanity: the option reaches the search; the Match bits need text the sample may not hold)
             assert want != base, name
     dev.close()
+
+
+def test_blocklist_on_the_built_model():
+    """AnalyzeOption::blocklist with frequent real morphemes (kiwi_morphset_add = Kiwi::findMorphemes over the built dictionary, pre-analysed and combined
+    morphemes included through Morpheme::hasMorpheme): emulated device == oracle for top-1 and top-2, == the real reference where oracle/_ref is present."""
+    import subprocess
+    import oraclelib
+    import refbridge
+    from corpora import pick_blocklist
+    from kiwi_amd.api import KiwiAmd
+    emu = os.path.join(HERE, "hipemu")
+    subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
+    path = built_model_path()
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=os.path.join(emu, "_build", "libkiwi_hipemu.so"))
+
+    def rows(res):
+        return [([(t.form, t.tag, t.position, t.length, t.score) for t in toks], sc) for toks, sc in res]
+    texts = [it["text"] for n in ("web", "written") for it in _golden(n)["items"]][::4]
+    base = [rows(orc.analyze(s)) for s in texts]
+    items = pick_blocklist(orc, texts, 25) + [("없는형태", 1)]
+    ms, found = dev.morphset(items)
+    assert found == orc.set_blocklist(items) and found[-1] == 0 and sum(found) >= 25
+    for top_n in (1, 2):
+        got = dev.analyze_batch_opt(texts, top_n=top_n, blocklist=ms).to_python()
+        want = [rows(orc.analyze(s, top_n=top_n)) for s in texts]
+        assert [rows(y) for y in got] == want, top_n
+        if top_n == 1:
+            assert sum(a != b for a, b in zip(want, base)) > len(texts) // 2      # the blocked morphemes were on most best paths
+            if refbridge.available():
+                ref = refbridge.RefKiwi(path)
+                assert ref.set_blocklist(items) == found
+                assert [rows(ref.analyze(s)) for s in texts] == want
+    dev.close()
