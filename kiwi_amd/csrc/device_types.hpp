@@ -229,6 +229,36 @@ namespace kamd
 		return l;
 	}
 
+	// ---- LDS layout of k_lattice_wave (lattice_wave.hip): the lattice build in which all 64 lanes work -- the chunk's appends ("ops", in the
+	// reference's order) are decided together by a fixpoint over the few order-dependent quantities instead of being replayed one by one.
+	// n text units, P = n + 2 positions, Mc packed matches, Kc ops (matches + special / space / pattern / tail / end ops), Nc final nodes.
+	struct LwLds
+	{
+		uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, mforms, mfrec;      // staged inputs + match digest (as k_build_lattice)
+		uint32_t ctlBU, ctlT, ctlRs;                                                        // per end position: boundary | unkStart << 16, time of its first match op, resetNs
+		uint32_t opNE, opBU, opFl, opSrc, decS, decT, grpList, miscForm, miscU;             // per op (time order, 1-based)
+		uint32_t grpOff, posA, posZ, fd, unkMinT, cntU, cntA, succ, base, firstU, cc, scal; // per position (cc: per final node; scal: a few wave-wide words)
+		uint32_t total, matchCap, opCap, miscCap, nodeCap;
+	};
+	KAMD_HD LwLds latticeWaveLayout(uint32_t n, uint32_t nodeCapHbm, uint32_t matchCapHbm)
+	{
+		LwLds l; uint32_t o = 0;
+		auto take = [&](uint32_t bytes) { const uint32_t at = o; o = (o + bytes + 15u) & ~15u; return at; };
+		const uint32_t P = n + 2;
+		l.matchCap = latticeLdsCap(n, matchCapHbm); l.miscCap = n / 2 + 12; l.opCap = l.matchCap + l.miscCap + 2; l.nodeCap = latticeLdsCap(n, nodeCapHbm);
+		l.str = take(2 * n); l.cls = take(n); l.script = take(n); l.cflag = take(n);
+		l.nsToPos = take(2 * P); l.posToNs = take(2 * P); l.mask = take(8 * P); l.moff = take(4 * P);
+		l.mforms = take(4 * l.matchCap); l.mfrec = take(8 * l.matchCap);
+		l.ctlBU = take(4 * P); l.ctlT = take(2 * P); l.ctlRs = take(2 * P);
+		l.opNE = take(4 * l.opCap); l.opBU = take(4 * l.opCap); l.opFl = take(2 * l.opCap); l.opSrc = take(2 * l.opCap);
+		l.decS = take(2 * l.opCap); l.decT = take(4 * l.opCap); l.grpList = take(2 * l.opCap);
+		l.miscForm = take(4 * l.miscCap); l.miscU = take(4 * l.miscCap);
+		l.grpOff = take(4 * (P + 1)); l.posA = take(4 * P); l.posZ = take(4 * P); l.fd = take(8 * P); l.unkMinT = take(2 * P); l.cntU = take(2 * P); l.cntA = take(4 * P);
+		l.succ = take(8 * P); l.base = take(2 * P); l.firstU = take(4 * P); l.cc = take(2 * l.nodeCap); l.scal = take(16);
+		l.total = o;
+		return l;
+	}
+
 #ifdef __HIPCC__
 	// Lanes of one wavefront exchange data through LDS / HBM between phases.  A memory fence alone orders one lane's own
 	// accesses; it does not stop the compiler from letting lanes that left a divergent loop early run ahead into the next

@@ -27,7 +27,8 @@ namespace kamd
 {
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
 	template<int GW> __global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
-	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes);
+	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes, uint32_t waveLayout);
+	__global__ void k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
 	__global__ void k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr);
 	__global__ void k_unk_chr(ModelView M, BatchView B, WorkView W, ChrView C, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
@@ -212,6 +213,7 @@ namespace kamd
 		int device = 0;
 		uint32_t persistBlocks = 0;
 		int latticeGroupForced = 0;      // KAMD_LATTICE_GROUP=16 / 64: lanes per chunk of k_build_lattice
+		bool latticeWave = true;         // k_lattice_wave (all lanes build the lattice); KAMD_LATTICE_WAVE=0: k_build_lattice's one-lane replay
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
@@ -355,6 +357,7 @@ namespace kamd
 		if (const char* pp = std::getenv("KAMD_POS_PATH")) impl->posPath = std::atoi(pp) != 0;
 		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
 		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
+		if (const char* lw = std::getenv("KAMD_LATTICE_WAVE")) impl->latticeWave = std::atoi(lw) != 0;
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
 		impl->counter.ensure(256);
 	}
@@ -781,7 +784,12 @@ namespace kamd
 			// mixed lengths does not run at the occupancy its longest chunk allows.  Chunks beyond the budget, and chunks that
 			// outgrow their LDS copy at run time, are picked up by the thread-per-chunk kernel (returns at once otherwise).
 			{
-				auto needOf = [&](uint32_t c) { return latticeLdsLayout(b.charOff[c + 1] - b.charOff[c], b.nodeBase[c + 1] - b.nodeBase[c], b.matchBase[c + 1] - b.matchBase[c]).total; };
+				const bool wave = I.latticeWave && I.latticeGroupForced == 0;
+				auto needOf = [&](uint32_t c)
+				{
+					const uint32_t nCh = b.charOff[c + 1] - b.charOff[c], nodeCap = b.nodeBase[c + 1] - b.nodeBase[c], matchCap = b.matchBase[c + 1] - b.matchBase[c];
+					return wave ? latticeWaveLayout(nCh, nodeCap, matchCap).total : latticeLdsLayout(nCh, nodeCap, matchCap).total;
+				};
 				uint32_t i = c0;
 				while (i < c1 && needOf(b.order[i]) > I.latticeLdsBudget) ++i;
 				while (i < c1)
@@ -795,11 +803,12 @@ namespace kamd
 					// quarter of the wavefronts to hide their LDS chains
 					const uint32_t need16 = (need + 15u) & ~15u;
 					const bool four = I.latticeGroupForced == 16 && need16 * 4 <= 64 * 1024;
-					if (four) hipLaunchKernelGGL(k_build_lattice<16>, dim3((j - i + 3) / 4), dim3(64), need16 * 4, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need16 | (dbgStop << 24));
+					if (wave) hipLaunchKernelGGL(k_lattice_wave, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need);
+					else if (four) hipLaunchKernelGGL(k_build_lattice<16>, dim3((j - i + 3) / 4), dim3(64), need16 * 4, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need16 | (dbgStop << 24));
 					else hipLaunchKernelGGL(k_build_lattice<64>, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24));
 					i = j;
 				}
-				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget);
+				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget, wave ? 1u : 0u);
 			}
 			}
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u);
@@ -985,6 +994,14 @@ namespace kamd
 			fprintf(stderr, "[pos phases] cycles per step (group-lane-0 clock; %0.f steps):", steps);
 			for (int k2 = 0; k2 < 14; ++k2) fprintf(stderr, " %s %.0f (%.0f%%);", names[k2], steps ? acc[k2] / steps : 0.0, tot ? 100.0 * acc[k2] / tot : 0.0);
 			fprintf(stderr, " total %.0f\n", steps ? tot / steps : 0.0);
+		}
+		if (getenv("KAMD_LATTICE_STATS"))
+		{
+			// developer aid: chunks k_lattice_wave built / handed over to the replay (by reason), fixpoint rounds per chunk
+			uint32_t c16[16] = {};
+			HIPCHECK(hipMemcpy(c16, b.dOutCounters.p, 64, hipMemcpyDeviceToHost));
+			fprintf(stderr, "[lattice wave] chunks %u: built %u (%.2f rounds each); handed over: matches %u, ops %u, long span / rounds %u, no end node %u, long node %u, no start %u\n",
+				(uint32_t)nC, c16[10], c16[10] ? (double)c16[11] / c16[10] : 0.0, c16[4], c16[5], c16[6], c16[7], c16[8], c16[9]);
 		}
 		if (b.wv.posRecs && getenv("KAMD_POS_STATS"))
 		{

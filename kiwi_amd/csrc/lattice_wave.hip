@@ -1,0 +1,609 @@
+// k_lattice_wave: the lattice of one chunk built by ALL 64 lanes of its wavefront (gfx950 / MI355X).
+//
+// The reference builds a chunk's lattice by a strictly sequential replay (Splitter::progressNode / flushCandidates / insertUnkForm /
+// appendNewNode, /root/reference/src/KTrie.cpp:15-43, 897-996, 1040-1137, 1350-1380, 1434-1450): every dictionary candidate, special-character
+// run, pattern span and space is one "op" that may insert unknown-form nodes in front of its start position and then append its own node,
+// and whether it does depends on what was appended before it.  k_build_lattice replays that on lane 0 (20 k instructions per 40-jamo chunk,
+// scalar-issue bound).  Here the ops of a chunk are laid out in the reference's order ("time") and DECIDED TOGETHER:
+//
+//   * what an op does depends on earlier ops only through four things -- is a position reachable (does a node end there yet), which
+//     (end, length) pairs already have a node (hasFormAlready), where the most recently appended node ended (insertUnkForm's extra bridge
+//     node), and the z-coda flags of the forms ending at a position;
+//   * unknown-form nodes ending at position q are only ever inserted by ops STARTING at q: lane q walks that short list in time order with the
+//     position's length mask in registers ("by-start pass");
+//   * a node an op appends for itself ends at the op's end position, and ops are in end-position order: lane T handles op T, publishes
+//     what it appends into per-position tables with LDS atomics and finds the end of the most recently appended node with a ballot ("by-time pass");
+//   * the two passes are iterated until nothing changes.  Every decision depends only on decisions of strictly earlier ops, so the fixpoint
+//     is unique and equals the sequential replay (by induction over time); a regular chunk converges in three rounds;
+//   * removeUnconnected (KTrie.cpp:240-299) keeps exactly the nodes that end at a position from which the end node is reachable and orders
+//     them by end position, insertion order inside one: the final index of a node is a prefix sum over positions plus its rank at its
+//     position -- no node list in build order, no renumbering pass.
+//
+// What this kernel does not do (spans longer than 64 positions, an op list that outgrows its LDS copy, an end node that cannot be appended)
+// it flags in nNodes[chunk] (kLatticeNeedsBig); k_build_lattice_big replays those chunks.  Memory-bound integer work: no MFMA.
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+#include "feature.hpp"
+
+namespace kamd
+{
+	extern __shared__ __align__(16) uint8_t lSmem[];
+
+	namespace lw
+	{
+		enum OpFlag : uint16_t
+		{
+			OF_HASUNK = 1, OF_CONDBU = 2,      // unknown-form attempts in front of the op; the boundary attempt is made when boundary < unkStart (else: boundary < start)
+			OF_LIMJ = 4, OF_HASAPP = 8, OF_SEOK = 16, OF_QUAL = 32, OF_ZBITS = 64 | 128, OF_VALID = 256, OF_ZSEL = 512 | 1024, OF_END = 2048,
+		};
+		constexpr uint32_t kMaxRounds = 16;
+
+		__device__ __forceinline__ uint32_t topBit(uint64_t m) { return 63u - (uint32_t)__builtin_clzll(m); }      // m != 0
+		__device__ __forceinline__ uint32_t trimmedLen(const uint16_t* str, uint32_t off, uint32_t len)
+		{
+			while (len && isSpace(str[off + len - 1])) --len;
+			return len;
+		}
+	}
+
+	// hands the chunk to k_build_lattice_big; outCounters[4 + reason] counts (developer statistics, KAMD_LATTICE_STATS)
+#define LW_HAND_OVER(reason) { if (lane == 0) { W.nNodes[chunk] = kLatticeNeedsBig; atomicAdd(&W.outCounters[4 + (reason)], 1u); } return; }
+	__global__ void __launch_bounds__(64) k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
+	{
+		using namespace lw;
+		const uint32_t lane = threadIdx.x;
+		if (blockIdx.x >= chunkCount) return;
+		const uint32_t chunk = chunkList[blockIdx.x];
+		if (W.results[chunk].status >= 16) return;
+		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
+		const uint32_t nNs = W.nNs[chunk];
+		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
+		const uint32_t mBase = W.matchBase[chunk], mCap = W.matchBase[chunk + 1] - mBase;
+		const LwLds lay = latticeWaveLayout(n, cap, mCap);
+		if (lay.total > ldsBytes) return;                      // k_build_lattice_big takes it
+		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { if (lane == 0) W.results[chunk].status = CS_ERR_TOO_LONG; return; }
+		uint8_t* const lS = lSmem;
+
+		uint16_t* str = reinterpret_cast<uint16_t*>(lS + lay.str);
+		uint8_t* cls = lS + lay.cls; uint8_t* script = lS + lay.script; uint8_t* cflag = lS + lay.cflag;
+		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(lS + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(lS + lay.posToNs);
+		uint64_t* mask = reinterpret_cast<uint64_t*>(lS + lay.mask); uint32_t* moff = reinterpret_cast<uint32_t*>(lS + lay.moff);
+		uint32_t* mforms = reinterpret_cast<uint32_t*>(lS + lay.mforms); uint2* mfrec = reinterpret_cast<uint2*>(lS + lay.mfrec);
+		uint32_t* ctlBU = reinterpret_cast<uint32_t*>(lS + lay.ctlBU); uint16_t* ctlT = reinterpret_cast<uint16_t*>(lS + lay.ctlT); uint16_t* ctlRs = reinterpret_cast<uint16_t*>(lS + lay.ctlRs);
+		uint32_t* opNE = reinterpret_cast<uint32_t*>(lS + lay.opNE); uint32_t* opBU = reinterpret_cast<uint32_t*>(lS + lay.opBU);
+		uint16_t* opFl = reinterpret_cast<uint16_t*>(lS + lay.opFl); uint16_t* opSrc = reinterpret_cast<uint16_t*>(lS + lay.opSrc);
+		uint16_t* decS = reinterpret_cast<uint16_t*>(lS + lay.decS); uint32_t* decT = reinterpret_cast<uint32_t*>(lS + lay.decT);
+		uint16_t* grpList = reinterpret_cast<uint16_t*>(lS + lay.grpList);
+		uint32_t* miscForm = reinterpret_cast<uint32_t*>(lS + lay.miscForm); uint32_t* miscU = reinterpret_cast<uint32_t*>(lS + lay.miscU);
+		uint32_t* grpOff = reinterpret_cast<uint32_t*>(lS + lay.grpOff); uint32_t* posA = reinterpret_cast<uint32_t*>(lS + lay.posA); uint32_t* posZ = reinterpret_cast<uint32_t*>(lS + lay.posZ);
+		uint64_t* fd = reinterpret_cast<uint64_t*>(lS + lay.fd); uint32_t* fdw = reinterpret_cast<uint32_t*>(lS + lay.fd);
+		uint16_t* unkMinT = reinterpret_cast<uint16_t*>(lS + lay.unkMinT); uint16_t* cntU = reinterpret_cast<uint16_t*>(lS + lay.cntU); uint32_t* cntA = reinterpret_cast<uint32_t*>(lS + lay.cntA);
+		uint64_t* succ = reinterpret_cast<uint64_t*>(lS + lay.succ); uint32_t* succw = reinterpret_cast<uint32_t*>(lS + lay.succ);
+		uint16_t* base = reinterpret_cast<uint16_t*>(lS + lay.base); uint32_t* firstU = reinterpret_cast<uint32_t*>(lS + lay.firstU);
+		uint16_t* cc = reinterpret_cast<uint16_t*>(lS + lay.cc); uint32_t* scal = reinterpret_cast<uint32_t*>(lS + lay.scal);
+		const uint32_t nPosAll = nNs + 2;      // positions 0 .. nNs, and nNs + 1 for the end node
+
+		// ---- 0. stage the chunk (all lanes, coalesced) and digest the packed matches, one per lane (as k_build_lattice) ----
+		uint32_t mTot;
+		{
+			const uint16_t* gstr = B.chars + cOff; const uint8_t* gcls = B.cls + cOff; const uint8_t* gscript = B.script + cOff; const uint8_t* gcflag = W.cflag + cOff;
+			const uint16_t* gn2p = W.nsToPos + cOff + chunk; const uint16_t* gp2n = W.posToNs + cOff + chunk;
+			const uint64_t* gmask = W.matchMask + cOff + chunk; const uint32_t* gmoff = W.matchOff + cOff + chunk;
+			for (uint32_t i = lane; i < n; i += 64) { str[i] = gstr[i]; cls[i] = gcls[i]; script[i] = gscript[i]; cflag[i] = gcflag[i]; }
+			for (uint32_t i = lane; i <= n; i += 64) { posToNs[i] = gp2n[i]; if (i < nNs) nsToPos[i] = gn2p[i]; }
+			for (uint32_t i = lane; i <= nNs; i += 64) { mask[i] = gmask[i]; moff[i] = gmoff[i]; }
+			for (uint32_t i = lane; i < nPosAll; i += 64) { ctlT[i] = 0; ctlRs[i] = 0; ctlBU[i] = 0; unkMinT[i] = 0xFFFF; cntU[i] = 0; cntA[i] = 0; grpOff[i] = 0; succ[i] = 0; firstU[i] = 0; }
+			if (lane == 0) { grpOff[nPosAll] = 0; scal[0] = 0; scal[1] = 0; }
+			mTot = gmoff[nNs] + __popcll(gmask[nNs]);
+			const uint32_t* gforms = W.matchForm + mBase;
+			if (mTot > lay.matchCap) LW_HAND_OVER(0)
+			waveSync();
+			for (uint32_t k = lane; k < mTot; k += 64)
+			{
+				const uint32_t fi = gforms[k]; const FormRec f = M.forms[fi];
+				mforms[k] = fi;
+				uint32_t lo = 0, hi = nNs;      // end position of match k: the last e with moff[e] <= k
+				while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (moff[mid] <= k) lo = mid; else hi = mid - 1; }
+				const uint32_t endNs = lo, flen = f.len - f.numSpaces;
+				uint32_t nb = 0, se = 0, valid = 0;
+				if (flen <= endNs)
+				{
+					// countSpaceErrors (KTrie.cpp:316-328)
+					valid = 1; nb = endNs - flen;
+					uint32_t off = 0;
+					if (!f.numSpaces) { for (uint32_t i = 1; i < flen; ++i) se += (nsToPos[nb + i] - nsToPos[nb + i - 1] > 1) ? 1u : 0u; }
+					else
+					{
+						const uint16_t* fs = M.formChars + f.charOff;
+						for (uint32_t i = 1; i < flen; ++i)
+						{
+							const bool hasSpace = nsToPos[nb + i] - nsToPos[nb + i - 1] > 1;
+							const uint16_t fc = (i + off < f.len) ? fs[i + off] : 0;
+							if (hasSpace && fc != u' ') ++se;
+							if (fc == u' ') ++off;
+						}
+					}
+				}
+				mfrec[k] = make_uint2(nb | ((se > 0xFFFFu ? 0xFFFFu : se) << 16), (uint32_t)f.flags | (valid << 8) | (endNs << 16));
+			}
+		}
+		waveSync();
+
+		// ---- 1. the character-type state machine of progressNode (KTrie.cpp:1040-1137, 1350-1380): a function of the text alone.  It decides the
+		// boundary / unknown-form start every op is made under and emits the ops that are not dictionary candidates, each at its place in time.
+		// (one lane: ~30 instructions per text unit)
+		if (lane == 0)
+		{
+			const DevPattern* pat = B.patterns + B.patOff[chunk];
+			const DevPattern* patEnd = B.patterns + B.patOff[chunk + 1];
+			uint8_t lastType = T_UNKNOWN, lastScript = 0;
+			uint32_t specialStart = 0, unkStart = 0, boundary = 0, resetNs = 0;
+			uint32_t T = 1, nMisc = 0; bool over = false;
+			const uint8_t scriptVS = 98;
+			auto emit = [&](uint32_t nb, uint32_t e, uint32_t fl, uint32_t form, uint32_t uOff, uint32_t uLen)
+			{
+				if (T >= lay.opCap || nMisc >= lay.miscCap) { over = true; return; }
+				opNE[T] = nb | (e << 16); opBU[T] = boundary | (unkStart << 16); opFl[T] = (uint16_t)fl; opSrc[T] = (uint16_t)(0x8000u | nMisc);
+				miscForm[nMisc] = form; miscU[nMisc] = uOff | (uLen << 16);
+				++nMisc; ++T;
+			};
+			for (uint32_t j = 0; j < n; ++j)
+			{
+				const uint16_t ch = str[j];
+				const bool pair = isHighSurrogate(ch) && j + 1 < n;
+				const uint32_t c32 = pair ? mergeSurrogate(ch, str[j + 1]) : ch;
+				const bool inPattern = pat != patEnd && j >= pat->end - pat->length;
+				uint8_t type = cls[j] & 0x3F, sct = script[j];
+				bool overridden = false;
+				if (lastType == T_SW && (c32 == 0x200d || (0x1f3fb <= c32 && c32 <= 0x1f3ff) || sct == scriptVS)) { overridden = type == T_UNKNOWN; type = lastType; sct = lastScript; }
+				const uint8_t curT = inPattern ? (uint8_t)T_UNKNOWN : type;
+				const bool symL = lastType == T_SL || lastType == T_SH || lastType == T_SW;
+				const bool symC = curT == T_SL || curT == T_SH || curT == T_SW;
+				const bool discont = (symL && symC) ? (lastScript != sct) : (lastType != curT);
+				if (discont || lastType == T_SSO || lastType == T_SSC)
+				{
+					if (lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
+					{
+						const bool sj = T_SF <= lastType && lastType <= T_SW;
+						const uint32_t o = nsToPos[specialStart], l = trimmedLen(str, o, j - o);
+						emit(specialStart, posToNs[j], OF_HASUNK | OF_CONDBU | (sj ? OF_LIMJ : 0) | OF_HASAPP | OF_SEOK | OF_VALID, lastType - 1u, o, l);
+					}
+					unkStart = specialStart;
+					specialStart = posToNs[j];
+					if (T_SF <= lastType && lastType <= T_SW) boundary = specialStart;
+				}
+				else if (type == T_MAX) unkStart = specialStart;
+				lastType = curT; lastScript = sct;
+
+				uint32_t zsel = 0, zform = 0;
+				if (!pair)
+				{
+					if (type == T_UNKNOWN)
+					{
+						emit(posToNs[j + 1], posToNs[j + 1], OF_HASUNK | OF_CONDBU | OF_LIMJ | OF_VALID, NOFORM, 0, 0);
+						boundary = specialStart = unkStart = posToNs[j + 1];
+						continue;
+					}
+					// a space-class unit promoted to a symbol was fed to the trie by the reference and reset the walk
+					if (overridden && (cflag[j] & 1)) resetNs = posToNs[j] + 1u;
+					// z-coda / saisiot shortcut (KTrie.cpp:1126-1135): the text side of the condition; the other side -- a form ending here allows it -- is the op's dynamic validity
+					if (posToNs[j] < nNs)
+					{
+						if ((P.match & M_Z_CODA) && isHangulCoda(ch) && (j + 1 >= n || !isHangulSyllable(str[j + 1]))) { zsel = 1; zform = kDefaultTagSize + (ch - 0x11A8) - 1; }
+						else if ((P.match & (M_SPLIT_SAISIOT | M_MERGE_SAISIOT)) && ch == 0x11BA && j + 1 < n && isHangulSyllable(str[j + 1])) { zsel = 2; zform = kDefaultTagSize + (0x11BA - 0x11A8) - 1; }
+					}
+				}
+				if (pat != patEnd)
+				{
+					const uint32_t curEnd = j + (pair ? 2 : 1);
+					while (pat != patEnd && pat->end == curEnd)
+					{
+						const uint32_t ms = pat->end - pat->length;
+						const bool wj = T_W_URL <= pat->tag && pat->tag <= T_W_EMOJI;
+						emit(posToNs[ms], posToNs[pat->end], OF_HASUNK | OF_CONDBU | (wj ? OF_LIMJ : 0) | OF_HASAPP | OF_SEOK | OF_VALID, pat->tag - 1u, ms, pat->length);
+						++pat;
+					}
+				}
+				if (pair) { ++j; continue; }
+				const uint32_t endNs = posToNs[j + 1];
+				if (zsel)
+				{
+					const FormRec f = M.forms[zform];
+					const uint32_t flen = f.len - f.numSpaces;
+					if (flen == 1 && flen <= endNs)
+					{
+						const bool hj = (f.flags & FF_HAS_JCLASS) || (f.flags & FF_IS_STAG);
+						uint32_t fl = OF_HASAPP | OF_SEOK | OF_VALID | (zsel << 9) | ((uint32_t)(f.flags & 3) << 6);
+						if (!(f.flags & FF_FIRST_IS_CODA)) fl |= OF_HASUNK | (hj ? OF_LIMJ : 0);
+						if (f.flags & FF_HAS_ANY_FULL) fl |= OF_QUAL;
+						emit(endNs - 1, endNs, fl, zform, 0, 0);
+					}
+					else if (flen <= endNs) over = true;      // (a z form of more than one unit: left to the replay)
+				}
+				ctlBU[endNs] = boundary | (unkStart << 16); ctlT[endNs] = (uint16_t)T; ctlRs[endNs] = (uint16_t)resetNs;
+				T += (uint32_t)__popcll(mask[endNs]);
+			}
+			if (lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
+			{
+				const bool sj = T_SF <= lastType && lastType <= T_SW;
+				const uint32_t o = nsToPos[specialStart], l = trimmedLen(str, o, n - o);
+				emit(specialStart, posToNs[n], OF_HASUNK | OF_CONDBU | (sj ? OF_LIMJ : 0) | OF_HASAPP | OF_SEOK | OF_VALID, lastType - 1u, o, l);
+				unkStart = specialStart;
+				if (sj) boundary = posToNs[n];
+			}
+			if (nNs && n == (uint32_t)nsToPos[nNs - 1] + 1) emit(posToNs[n], posToNs[n], OF_HASUNK | OF_CONDBU | OF_LIMJ | OF_VALID, NOFORM, 0, 0);
+			emit(nNs, nNs + 1, OF_HASAPP | OF_SEOK | OF_VALID | OF_END, NOFORM, 0, 0);
+			if (T > lay.opCap) over = true;
+			scal[0] = over ? 1u : 0u; scal[1] = T - 1;
+		}
+		waveSync();
+		if (scal[0]) LW_HAND_OVER(1)
+		const uint32_t K = scal[1];      // ops 1 .. K
+
+		// ---- 2. the dictionary candidates as ops, one per lane: time = the time of their end position's first candidate + rank in its list ----
+		for (uint32_t k = lane; k < mTot; k += 64)
+		{
+			const uint2 r = mfrec[k];
+			const uint32_t e = r.y >> 16, nb = r.x & 0xFFFF, se = r.x >> 16; const uint8_t fl = (uint8_t)r.y;
+			const uint32_t T = (uint32_t)ctlT[e] + (k - moff[e]);
+			const bool valid = (r.y & 0x100) && nb >= ctlRs[e];
+			const bool hj = (fl & FF_HAS_JCLASS) || (fl & FF_IS_STAG);
+			uint32_t of = OF_HASAPP | ((uint32_t)(fl & 3) << 6);
+			if (!(fl & FF_FIRST_IS_CODA)) of |= OF_HASUNK | (hj ? OF_LIMJ : 0);
+			if (se <= P.spaceTol) of |= OF_SEOK;
+			if (fl & FF_HAS_ANY_FULL) of |= OF_QUAL;
+			if (valid) of |= OF_VALID;
+			opNE[T] = nb | (e << 16); opBU[T] = ctlBU[e]; opFl[T] = (uint16_t)of; opSrc[T] = (uint16_t)k;
+		}
+		waveSync();
+
+		// ---- 3. ops grouped by START position (counting sort; the few ops of a position then ordered by time) ----
+		for (uint32_t T = 1 + lane; T <= K; T += 64) atomicAdd(&grpOff[(opNE[T] & 0xFFFF) + 1], 1u);
+		waveSync();
+		{
+			uint32_t run = 0;
+			for (uint32_t b0 = 0; b0 <= nPosAll; b0 += 64)
+			{
+				const uint32_t q = b0 + lane;
+				const uint32_t c = q <= nPosAll ? grpOff[q] : 0u;
+				uint32_t incl = c;
+				for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+				if (q <= nPosAll) grpOff[q] = run + incl;      // grpOff[q + 1] held the count of q: inclusive sum = first slot of position q
+				if (q < nPosAll) posA[q] = 0;                   // (scatter cursors)
+				run += __shfl(incl, 63);
+			}
+		}
+		waveSync();
+		for (uint32_t T = 1 + lane; T <= K; T += 64)
+		{
+			const uint32_t q = opNE[T] & 0xFFFF;
+			grpList[grpOff[q] + atomicAdd(&posA[q], 1u)] = (uint16_t)T;
+			decS[T] = (uint16_t)((1u << 4) | (((opFl[T] & OF_VALID) && !(opFl[T] & OF_ZSEL)) ? (1u << 5) : 0u));
+			decT[T] = 0xFFFFu << 16;
+		}
+		waveSync();
+		for (uint32_t q = lane; q < nPosAll; q += 64)
+		{
+			const uint32_t g0 = grpOff[q], g1 = grpOff[q + 1];
+			for (uint32_t i = g0 + 1; i < g1; ++i)
+			{
+				const uint16_t v = grpList[i]; uint32_t j = i;
+				while (j > g0 && grpList[j - 1] > v) { grpList[j] = grpList[j - 1]; --j; }
+				grpList[j] = v;
+			}
+		}
+		waveSync();
+
+		// ---- 4. the fixpoint ----
+		auto reachAt = [&](uint32_t x, uint32_t T) -> bool { return posA[x] < T || (uint32_t)unkMinT[x] < T; };      // a node ends at x before time T
+		uint32_t hazard = 0, nRounds = 0;
+		for (uint32_t round = 0;; ++round)
+		{
+			if (round >= kMaxRounds) { hazard = 1; break; }
+			nRounds = round + 1;
+			bool chg = false;
+			for (uint32_t q = lane; q < nPosAll; q += 64) { posA[q] = q ? 0xFFFFFFFFu : 0u; posZ[q] = 0; fd[q] = 0; }      // (the start node ends at position 0, at time 0)
+			waveSync();
+			// by-time pass: lane = op.  Its own node (needs its start reachable), the tables the other pass reads, the end of the most recently appended node
+			{
+				uint32_t carry = 0;
+				for (uint32_t b0 = 1; b0 <= K; b0 += 64)
+				{
+					const uint32_t T = b0 + lane; const bool act = T <= K;
+					uint32_t fl = 0, nb = 0, e = 0, s = 0;
+					if (act) { fl = opFl[T]; const uint32_t ne = opNE[T]; nb = ne & 0xFFFF; e = ne >> 16; s = decS[T]; }
+					const bool app = act && (fl & OF_HASAPP) && (fl & OF_SEOK) && ((s >> 5) & 1) && ((s >> 4) & 1);
+					const bool any = app || (s & 15u);
+					const uint32_t lastAfter = app ? e : nb;
+					const uint64_t m = __ballot(any);
+					const uint64_t lower = m & ((1ull << lane) - 1ull);
+					const uint32_t got = __shfl(lastAfter, lower ? (int)topBit(lower) : (int)lane);
+					const uint32_t lb = lower ? got : carry;
+					const uint32_t top = __shfl(lastAfter, m ? (int)topBit(m) : 0);
+					if (m) carry = top;
+					if (act)
+					{
+						const uint32_t nd = (app ? 1u : 0u) | (lb << 16);
+						if (decT[T] != nd) { chg = true; decT[T] = nd; }
+						if (app)
+						{
+							atomicMin(&posA[e], T);
+							const uint32_t len = e - nb;
+							if ((fl & OF_QUAL) && len >= 1 && len <= 64) atomicOr(&fdw[2 * e + ((len - 1) >> 5)], 1u << ((len - 1) & 31));
+							const uint32_t zb = (fl >> 6) & 3u;
+							if (zb) atomicOr(&posZ[e], zb);
+						}
+					}
+				}
+			}
+			waveSync();
+			// by-start pass: lane = position.  The unknown-form nodes ending there (insertUnkForm, KTrie.cpp:921-953), by the ops starting there, in time order
+			for (uint32_t b0 = 0; b0 < nPosAll; b0 += 64)
+			{
+				const uint32_t q = b0 + lane;
+				if (q >= nPosAll) continue;
+				const uint32_t g0 = grpOff[q], g1 = grpOff[q + 1];
+				uint64_t F = fd[q];
+				const uint32_t rmT = posA[q], zq = posZ[q];
+				uint32_t unkCnt = 0, firstUnkT = 0xFFFF;
+				for (uint32_t g = g0; g < g1; ++g)
+				{
+					const uint32_t T = grpList[g]; const uint32_t fl = opFl[T], bu = opBU[T];
+					const uint32_t b = bu & 0xFFFF, u = bu >> 16;
+					bool valid = (fl & OF_VALID) != 0;
+					const uint32_t zsel = (fl >> 9) & 3u;
+					if (zsel) valid = valid && (zq & zsel);
+					uint32_t um = 0; const uint32_t rank = unkCnt;
+					if (valid && (fl & OF_HASUNK))
+					{
+						const uint32_t lim = (fl & OF_LIMJ) ? P.maxUnkJ : P.maxUnk;
+						uint32_t le = decT[T] >> 16;      // where the most recently appended node ended when this op's turn came
+						const bool doB = (fl & OF_CONDBU) ? (b < u) : (b < q);
+						for (uint32_t a = doB ? 0u : 1u; a < 2; ++a)
+						{
+							const uint32_t s = a ? u : b;
+							if (s >= q) continue;
+							const uint32_t L = q - s;
+							if (L > 64) { hazard = 1; continue; }
+							if ((F >> (L - 1)) & 1) continue;
+							if (le < q)
+							{
+								// nothing ends at or beyond q yet: bridge from the end of the last node (not from a lone coda)
+								uint32_t lp = le;
+								if (lp && isHangulCoda(str[nsToPos[lp]])) --lp;
+								if (lp != s)
+								{
+									const uint32_t L2 = q - lp;
+									if (L2 > 64) hazard = 1;
+									else if (!((F >> (L2 - 1)) & 1) && reachAt(lp, T))
+									{
+										const uint32_t o = nsToPos[lp], l = trimmedLen(str, o, nsToPos[q - 1] + 1u - o);
+										if (l > 64) hazard = 1; else if (l) F |= 1ull << (l - 1);
+										um |= 1u << (2 * a); ++unkCnt; le = q;
+									}
+								}
+							}
+							if (L <= lim && reachAt(s, T))
+							{
+								const uint32_t o = nsToPos[s], l = trimmedLen(str, o, nsToPos[q - 1] + 1u - o);
+								if (l > 64) hazard = 1; else if (l) F |= 1ull << (l - 1);
+								um |= 2u << (2 * a); ++unkCnt; le = q;
+							}
+						}
+					}
+					if (um && firstUnkT == 0xFFFF) firstUnkT = T;
+					if (rank > 250) hazard = 1;
+					const bool rq = rmT < T || unkCnt > 0;
+					const uint32_t nd = um | (rq ? 16u : 0u) | (valid ? 32u : 0u) | ((rank & 0xFF) << 8);
+					if (decS[T] != nd) { chg = true; decS[T] = (uint16_t)nd; }
+				}
+				base[q] = (uint16_t)firstUnkT;      // (published after the pass: other lanes are still reading this round's unkMinT)
+				cntU[q] = (uint16_t)unkCnt;
+			}
+			waveSync();
+			for (uint32_t q = lane; q < nPosAll; q += 64) if (unkMinT[q] != base[q]) { chg = true; unkMinT[q] = base[q]; }
+			waveSync();
+			if (__ballot(hazard != 0)) { hazard = 1; break; }
+			if (!__ballot(chg)) break;
+		}
+		if (__ballot(hazard != 0)) LW_HAND_OVER(2)
+		// the end node must exist (else the reference renames whatever node came last: left to the replay)
+		if (!(decT[K] & 1u)) LW_HAND_OVER(3)
+		if (lane == 0) { atomicAdd(&W.outCounters[10], 1u); atomicAdd(&W.outCounters[11], nRounds); }
+
+		// ---- 5. rank of every appended node at its end position; successor masks; the first node of every position ----
+		{
+			uint32_t carryE = 0xFFFFFFFFu, carryCnt = 0;
+			for (uint32_t b0 = 1; b0 <= K; b0 += 64)
+			{
+				const uint32_t T = b0 + lane; const bool act = T <= K;
+				uint32_t nb = 0, e = 0xFFFFFFFEu; bool app = false;
+				if (act) { const uint32_t ne = opNE[T]; nb = ne & 0xFFFF; e = ne >> 16; app = decT[T] & 1u; }
+				const uint32_t ePrev = __shfl_up(e, 1);
+				const bool segStart = lane == 0 ? (e != carryE) : (e != ePrev);
+				const uint64_t sb = __ballot(segStart), am = __ballot(app);
+				const uint64_t below = (1ull << lane) - 1ull;
+				const uint64_t mine = sb & (below | (1ull << lane));      // segment starts at or below this lane
+				const uint32_t start = mine ? topBit(mine) : 0u;
+				uint32_t rank = (uint32_t)__popcll(am & below & ~((1ull << start) - 1ull));
+				if (!mine) rank += carryCnt;      // the segment began in an earlier block of 64 ops
+				if (act && app)
+				{
+					decT[T] = (decT[T] & 0xFFFF0001u) | (rank << 1);
+					if (!(opFl[T] & OF_END))
+					{
+						const uint32_t len = e - nb;
+						if (len < 1 || len > 64) hazard = 1; else atomicOr(&succw[2 * nb + ((len - 1) >> 5)], 1u << ((len - 1) & 31));
+						if (rank == 0) { const uint32_t src = opSrc[T]; firstU[e] = (src & 0x8000u) ? miscU[src & 0x7FFFu] : 0u; }
+					}
+					atomicAdd(&cntA[e], 1u);
+				}
+				// carry: the segment of the last lane
+				const uint32_t eLast = __shfl(e, 63);
+				const uint32_t startLast = sb ? topBit(sb) : 0u;
+				const uint32_t inLast = (uint32_t)__popcll(am & ~((1ull << startLast) - 1ull));
+				carryCnt = sb ? inLast : carryCnt + inLast;
+				carryE = eLast;
+			}
+		}
+		waveSync();
+		// unknown-form nodes: successor masks, and the first node of a position that no op ends at
+		for (uint32_t q = lane; q < nPosAll; q += 64)
+		{
+			const uint32_t g0 = grpOff[q], g1 = grpOff[q + 1];
+			bool first = cntA[q] == 0 && q != 0;
+			for (uint32_t g = g0; g < g1; ++g)
+			{
+				const uint32_t T = grpList[g]; const uint32_t s4 = decS[T] & 15u;
+				if (!s4) continue;
+				const uint32_t bu = opBU[T];
+				uint32_t lp = decT[T] >> 16;      // (a bridge node was made: the last node ended before q)
+				if ((s4 & 5u) && lp && isHangulCoda(str[nsToPos[lp]])) --lp;
+				for (uint32_t i = 0; i < 4; ++i)
+				{
+					if (!((s4 >> i) & 1)) continue;
+					const uint32_t s = (i & 1) ? ((i & 2) ? (bu >> 16) : (bu & 0xFFFF)) : lp;
+					const uint32_t len = q - s;
+					atomicOr(&succw[2 * s + ((len - 1) >> 5)], 1u << ((len - 1) & 31));
+					if (first) { const uint32_t o = nsToPos[s]; firstU[q] = o | (trimmedLen(str, o, nsToPos[q - 1] + 1u - o) << 16); first = false; }
+				}
+			}
+		}
+		waveSync();
+		if (__ballot(hazard != 0)) LW_HAND_OVER(4)
+
+		// ---- 6. removeUnconnected, part 1: from which positions is the end node reachable (sweep from the end; window of the next 64 positions) ----
+		uint16_t* keep = unkMinT;      // (no longer needed)
+		{
+			// lane 0: position by position, downwards; bit d - 1 of win = position q + d is kept
+			if (lane == 0)
+			{
+				uint64_t win = 0;      // (position nNs is kept by definition: the end node starts there and exists)
+				keep[nNs + 1] = 1;
+				for (uint32_t q = nNs + 1; q-- > 0;)
+				{
+					const bool k = q == nNs ? true : (succ[q] & win) != 0;
+					keep[q] = k ? 1 : 0;
+					win = (win << 1) | (k ? 1ull : 0ull);
+				}
+			}
+		}
+		waveSync();
+		if (!keep[0]) LW_HAND_OVER(5)      // (a lattice that does not reach back to the start node: left to the replay)
+		// part 2: first final index of every position
+		uint32_t nConn = 0;
+		for (uint32_t b0 = 0; b0 < nPosAll; b0 += 64)
+		{
+			const uint32_t q = b0 + lane;
+			uint32_t c = 0;
+			if (q < nPosAll && keep[q]) c = q == 0 ? 1u : cntA[q] + cntU[q];
+			uint32_t incl = c;
+			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+			if (q < nPosAll) base[q] = (uint16_t)(nConn + incl - c);
+			nConn += __shfl(incl, 63);
+		}
+		if (nConn + 1 >= cap || nConn > lay.nodeCap) { if (lane == 0) { if (nConn + 1 >= cap) W.results[chunk].status = CS_ERR_NODE_OVERFLOW; else W.nNodes[chunk] = kLatticeNeedsBig; } return; }
+		waveSync();
+
+		// ---- 7. the final records (removeUnconnected part 2 + the per-node facts the search kernel needs), one op per lane ----
+		DevNode* fin = W.nodes + nBase;
+		const uint32_t textOff = B.textOffset[chunk];
+		auto emitNode = [&](uint32_t ni, uint32_t s, uint32_t t, uint32_t form, uint32_t uOff, uint32_t uLen, uint32_t se, uint32_t rankAt, bool isEnd)
+		{
+			DevNode nn;
+			nn.form = form; nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = (uint8_t)(se > 255 ? 255 : se);
+			nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0; nn.packOff = 0;
+			const uint32_t startStr = isEnd ? n : (uint32_t)nsToPos[s];
+			const bool pnBos = s == 0;
+			const uint32_t pnEndStr = pnBos ? 0u : (uint32_t)nsToPos[s - 1] + 1u;
+			// the reference compares absolute text offsets; the start node's end is 0 (PathEvaluator.hpp:24-31, 436, 568)
+			const bool spaceBefore = pnBos ? (textOff + startStr > 0) : (pnEndStr < startStr);
+			bool lb = pnBos || spaceBefore;
+			const uint32_t pu = firstU[s];
+			if (!lb && (pu >> 16))
+			{
+				const uint32_t lp = (pu & 0xFFFF) + (pu >> 16) - 1;
+				const uint16_t c = str[lp];
+				const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
+				if (tag == T_SSC || c == u'"' || c == u'\'') lb = false;
+				else if (T_SF <= tag && tag <= T_SB) lb = true;
+			}
+			uint8_t nf = 0;
+			if (spaceBefore) nf |= NF_SPACE_BEFORE;
+			if (lb) nf |= NF_LEFT_BOUNDARY;
+			if (uLen && str[uOff + uLen - 1] == u'.') nf |= NF_UFORM_ENDS_POINT;
+			nn.nPrev = (uint16_t)(pnBos ? 1u : cntA[s] + cntU[s]);
+			if (form != NOFORM)
+			{
+				const FormRec f = M.forms[form];
+				nn.candCnt = f.candCnt; nn.fflags = f.flags; nn.flen = f.len;
+				if (f.flags2 & FF2_ALL_PARTIAL) nf |= NF_ALL_PARTIAL;
+			}
+			if (uLen)
+			{
+				uint16_t of = featMask(str + uOff, uLen) & 0x1FFF;
+				const uint32_t lp = uOff + uLen - 1;
+				const uint16_t c = str[lp];
+				const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
+				if (tag == T_SSC) of |= LF_STR_SSC;
+				nn.ownFeat = of;
+			}
+			nn.nflags = nf;
+			nn.prev = (uint16_t)(ni - base[s]);
+			nn.sibling = (!isEnd && rankAt + 1 < cntA[t] + cntU[t]) ? 1 : 0;
+			if (isEnd) nn.startPos = nn.endPos = (uint16_t)n;
+			else { nn.startPos = nsToPos[s]; nn.endPos = (uint16_t)(nsToPos[t - 1] + 1); }
+			fin[ni] = nn;
+			cc[ni] = nn.candCnt;
+		};
+		if (lane == 0)
+		{
+			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
+			fin[0] = bos; cc[0] = 0;
+		}
+		for (uint32_t T = 1 + lane; T <= K; T += 64)
+		{
+			const uint32_t ne = opNE[T], nb = ne & 0xFFFF, e = ne >> 16, fl = opFl[T], s4 = decS[T] & 15u, dt = decT[T];
+			if (s4 && keep[nb])
+			{
+				const uint32_t bu = opBU[T];
+				uint32_t lp = dt >> 16;
+				if ((s4 & 5u) && lp && isHangulCoda(str[nsToPos[lp]])) --lp;
+				uint32_t r = cntA[nb] + ((decS[T] >> 8) & 0xFFu);
+				for (uint32_t i = 0; i < 4; ++i)
+				{
+					if (!((s4 >> i) & 1)) continue;
+					const uint32_t s = (i & 1) ? ((i & 2) ? (bu >> 16) : (bu & 0xFFFF)) : lp;
+					const uint32_t o = nsToPos[s], l = trimmedLen(str, o, nsToPos[nb - 1] + 1u - o);
+					emitNode(base[nb] + r, s, nb, NOFORM, o, l, 0, r, false);
+					++r;
+				}
+			}
+			if ((dt & 1u) && keep[e])
+			{
+				const uint32_t rank = (dt >> 1) & 0x7FFFu, src = opSrc[T];
+				uint32_t form, uOff = 0, uLen = 0, se = 0;
+				if (src & 0x8000u) { form = miscForm[src & 0x7FFFu]; const uint32_t mu = miscU[src & 0x7FFFu]; uOff = mu & 0xFFFF; uLen = mu >> 16; }
+				else { form = mforms[src]; se = mfrec[src].x >> 16; }
+				emitNode(base[e] + rank, nb, e, form, uOff, uLen, se, rank, (fl & OF_END) != 0);
+			}
+		}
+		waveSync();
+		uint32_t packTop = 0;
+		for (uint32_t b0 = 0; b0 < nConn; b0 += 64)
+		{
+			const uint32_t i = b0 + lane;
+			const uint32_t c = i < nConn ? (uint32_t)cc[i] : 0u;
+			uint32_t incl = c;
+			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+			if (i < nConn) fin[i].packOff = packTop + incl - c;
+			packTop += __shfl(incl, 63);
+		}
+		if (lane == 0)
+		{
+			const uint32_t packCap = W.packBase[chunk + 1] - W.packBase[chunk];
+			if (packTop > packCap) W.results[chunk].status = CS_ERR_NODE_OVERFLOW;
+			else { W.nNodes[chunk] = nConn; if (nConn <= 2) W.results[chunk].status = CS_NO_LATTICE; }
+		}
+	}
+}

@@ -45,6 +45,14 @@ namespace korc
 	};
 
 	struct SplitConfig { uint64_t match; uint32_t maxUnk, maxUnkJ, spaceTol; };
+#ifdef KORC_HAZARD_STATS
+	// developer statistics (oracle/_build/liboracle_haz.so only): how often the lattice build meets the cases that make it order-dependent
+	struct HazStats { uint64_t chunks = 0, chunksHaz = 0, live = 0, h1enter = 0, h1act = 0, h2 = 0, h3 = 0, h4 = 0, ops = 0, appFailReach = 0, steps = 0, maxCand = 0; bool cur = false; };
+	inline HazStats& hazStats() { static HazStats h; return h; }
+#define KORC_HAZ(x) x
+#else
+#define KORC_HAZ(x)
+#endif
 
 	class LatticeBuilder
 	{
@@ -100,12 +108,15 @@ namespace korc
 		void insertUnk(uint32_t s, uint32_t e, bool hasJ)
 		{
 			if (s >= e || hasFormAlready(s, e)) return;
+			KORC_HAZ(hazStats().live++; if (e - s > 64) { hazStats().h3++; hazStats().cur = true; })
 			uint32_t lastPos = out.back().endPos;
 			if (lastPos < e)
 			{
+				KORC_HAZ(hazStats().h1enter++;)
 				if (lastPos && isHangulCoda(str[nsToPos[lastPos]])) lastPos--;
 				if (lastPos != s && !hasFormAlready(lastPos, e))
 				{
+					KORC_HAZ(hazStats().h1act++; hazStats().cur = true;)
 					uint32_t o, l; trimmed(nsToPos[lastPos], nsToPos[e - 1] + 1 - nsToPos[lastPos], o, l);
 					if (append(lastPos, e, NOFORM, o, l)) cnt.otherNodes++;
 				}
@@ -114,7 +125,9 @@ namespace korc
 			if (e - s <= limit)
 			{
 				uint32_t o, l; trimmed(nsToPos[s], nsToPos[e - 1] + 1 - nsToPos[s], o, l);
+				KORC_HAZ(if (l != e - s) { hazStats().h4++; hazStats().cur = true; })
 				if (append(s, e, NOFORM, o, l)) cnt.otherNodes++;
+				KORC_HAZ(else { hazStats().h2++; hazStats().cur = true; })
 			}
 		}
 
@@ -278,6 +291,7 @@ namespace korc
 
 				// flushCandidates (KTrie.cpp:955-996)
 				const uint32_t endNs = posToNs[j + 1];
+				KORC_HAZ(if (!cands.empty()) { hazStats().steps++; hazStats().ops += cands.size(); if (cands.size() > hazStats().maxCand) hazStats().maxCand = cands.size(); })
 				for (uint32_t fi : cands)
 				{
 					const FormRec& f = M.forms[fi];
@@ -292,6 +306,7 @@ namespace korc
 					if (se <= cfg.spaceTol)
 					{
 						if (append(nb, ne, fi, 0, 0)) { out.back().spaceErrors = se; cnt.candEmits++; }
+						KORC_HAZ(else hazStats().appFailReach++;)
 					}
 				}
 				cands.clear();
@@ -309,6 +324,7 @@ namespace korc
 			if (n == totEnd) unkPair(boundary, unkStart, posToNs[totEnd], true);
 			append(nNs, nNs + 1, NOFORM, 0, 0);
 			out.back().endPos = nNs;
+			KORC_HAZ(hazStats().chunks++; if (hazStats().cur) hazStats().chunksHaz++; hazStats().cur = false;)
 
 			// removeUnconnected (KTrie.cpp:240-299)
 			const uint32_t G = (uint32_t)out.size();

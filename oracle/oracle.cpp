@@ -446,3 +446,13 @@ extern "C"
 		return w.need;
 	}
 }
+
+#ifdef KORC_HAZARD_STATS
+extern "C" void korc_haz_stats(uint64_t* out12, int reset)
+{
+	auto& h = korc::hazStats();
+	const uint64_t v[12] = { h.chunks, h.chunksHaz, h.live, h.h1enter, h.h1act, h.h2, h.h3, h.h4, h.ops, h.appFailReach, h.steps, h.maxCand };
+	std::memcpy(out12, v, sizeof(v));
+	if (reset) h = korc::HazStats{};
+}
+#endif
