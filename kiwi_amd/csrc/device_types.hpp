@@ -234,7 +234,7 @@ namespace kamd
 	// n text units, P = n + 2 positions, Mc packed matches, Kc ops (matches + special / space / pattern / tail / end ops), Nc final nodes.
 	struct LwLds
 	{
-		uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, mforms, mfrec;      // staged inputs + match digest (as k_build_lattice)
+		uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, mforms, mse;        // staged inputs; form id and space errors of every packed match
 		uint32_t ctlBU, ctlT, ctlRs;                                                        // per end position: boundary | unkStart << 16, time of its first match op, resetNs
 		uint32_t opNE, opBU, opFl, opSrc, decS, decT, grpList, miscForm, miscU;             // per op (time order, 1-based)
 		uint32_t grpOff, posA, posZ, fd, unkMinT, cntU, cntA, succ, base, firstU, cc, scal; // per position (cc: per final node; scal: a few wave-wide words)
@@ -248,7 +248,7 @@ namespace kamd
 		l.matchCap = latticeLdsCap(n, matchCapHbm); l.miscCap = n / 2 + 12; l.opCap = l.matchCap + l.miscCap + 2; l.nodeCap = latticeLdsCap(n, nodeCapHbm);
 		l.str = take(2 * n); l.cls = take(n); l.script = take(n); l.cflag = take(n);
 		l.nsToPos = take(2 * P); l.posToNs = take(2 * P); l.mask = take(8 * P); l.moff = take(4 * P);
-		l.mforms = take(4 * l.matchCap); l.mfrec = take(8 * l.matchCap);
+		l.mforms = take(4 * l.matchCap); l.mse = take(l.matchCap);
 		l.ctlBU = take(4 * P); l.ctlT = take(2 * P); l.ctlRs = take(2 * P);
 		l.opNE = take(4 * l.opCap); l.opBU = take(4 * l.opCap); l.opFl = take(2 * l.opCap); l.opSrc = take(2 * l.opCap);
 		l.decS = take(2 * l.opCap); l.decT = take(4 * l.opCap); l.grpList = take(2 * l.opCap);

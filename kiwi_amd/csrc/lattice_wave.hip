@@ -55,6 +55,8 @@ namespace kamd
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t chunk = chunkList[blockIdx.x];
 		if (W.results[chunk].status >= 16) return;
+		const uint32_t dbgStop = ldsBytes >> 24; ldsBytes &= 0xFFFFFFu;      // EXPERIMENT (KAMD_LATTICE_STOP): leave after phase 1 .. 6, results void
+#define LW_STOP(k) if (dbgStop == (k)) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
 		const uint32_t cOff = B.charOff[chunk], n = B.charOff[chunk + 1] - cOff;
 		const uint32_t nNs = W.nNs[chunk];
 		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
@@ -68,7 +70,7 @@ namespace kamd
 		uint8_t* cls = lS + lay.cls; uint8_t* script = lS + lay.script; uint8_t* cflag = lS + lay.cflag;
 		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(lS + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(lS + lay.posToNs);
 		uint64_t* mask = reinterpret_cast<uint64_t*>(lS + lay.mask); uint32_t* moff = reinterpret_cast<uint32_t*>(lS + lay.moff);
-		uint32_t* mforms = reinterpret_cast<uint32_t*>(lS + lay.mforms); uint2* mfrec = reinterpret_cast<uint2*>(lS + lay.mfrec);
+		uint32_t* mforms = reinterpret_cast<uint32_t*>(lS + lay.mforms); uint8_t* mse = lS + lay.mse;
 		uint32_t* ctlBU = reinterpret_cast<uint32_t*>(lS + lay.ctlBU); uint16_t* ctlT = reinterpret_cast<uint16_t*>(lS + lay.ctlT); uint16_t* ctlRs = reinterpret_cast<uint16_t*>(lS + lay.ctlRs);
 		uint32_t* opNE = reinterpret_cast<uint32_t*>(lS + lay.opNE); uint32_t* opBU = reinterpret_cast<uint32_t*>(lS + lay.opBU);
 		uint16_t* opFl = reinterpret_cast<uint16_t*>(lS + lay.opFl); uint16_t* opSrc = reinterpret_cast<uint16_t*>(lS + lay.opSrc);
@@ -92,47 +94,151 @@ namespace kamd
 			for (uint32_t i = lane; i < n; i += 64) { str[i] = gstr[i]; cls[i] = gcls[i]; script[i] = gscript[i]; cflag[i] = gcflag[i]; }
 			for (uint32_t i = lane; i <= n; i += 64) { posToNs[i] = gp2n[i]; if (i < nNs) nsToPos[i] = gn2p[i]; }
 			for (uint32_t i = lane; i <= nNs; i += 64) { mask[i] = gmask[i]; moff[i] = gmoff[i]; }
-			for (uint32_t i = lane; i < nPosAll; i += 64) { ctlT[i] = 0; ctlRs[i] = 0; ctlBU[i] = 0; unkMinT[i] = 0xFFFF; cntU[i] = 0; cntA[i] = 0; grpOff[i] = 0; succ[i] = 0; firstU[i] = 0; }
+			for (uint32_t i = lane; i < nPosAll; i += 64) { ctlT[i] = 0; ctlRs[i] = 0; ctlBU[i] = 0; unkMinT[i] = 0xFFFF; cntU[i] = 0; cntA[i] = 0; grpOff[i] = 0; succ[i] = 0; firstU[i] = 0; posZ[i] = 0; base[i] = 0xFFFF; }
 			if (lane == 0) { grpOff[nPosAll] = 0; scal[0] = 0; scal[1] = 0; }
 			mTot = gmoff[nNs] + __popcll(gmask[nNs]);
 			const uint32_t* gforms = W.matchForm + mBase;
 			if (mTot > lay.matchCap) LW_HAND_OVER(0)
 			waveSync();
-			for (uint32_t k = lane; k < mTot; k += 64)
+			// end position of every packed match (its list is contiguous), and the number of gaps (spaces skipped by the non-space index) up to every position
+			uint16_t* endOf = grpList; uint16_t* gapPre = decS;      // (both arrays are free until the ops exist)
+			for (uint32_t e = lane; e <= nNs; e += 64) { const uint32_t m0 = moff[e], c = (uint32_t)__popcll(mask[e]); for (uint32_t i = 0; i < c; ++i) endOf[m0 + i] = (uint16_t)e; }
+			uint32_t run = 0;
+			for (uint32_t b0 = 0; b0 < nNs; b0 += 64)
 			{
-				const uint32_t fi = gforms[k]; const FormRec f = M.forms[fi];
-				mforms[k] = fi;
-				uint32_t lo = 0, hi = nNs;      // end position of match k: the last e with moff[e] <= k
-				while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (moff[mid] <= k) lo = mid; else hi = mid - 1; }
-				const uint32_t endNs = lo, flen = f.len - f.numSpaces;
-				uint32_t nb = 0, se = 0, valid = 0;
-				if (flen <= endNs)
-				{
-					// countSpaceErrors (KTrie.cpp:316-328)
-					valid = 1; nb = endNs - flen;
-					uint32_t off = 0;
-					if (!f.numSpaces) { for (uint32_t i = 1; i < flen; ++i) se += (nsToPos[nb + i] - nsToPos[nb + i - 1] > 1) ? 1u : 0u; }
-					else
-					{
-						const uint16_t* fs = M.formChars + f.charOff;
-						for (uint32_t i = 1; i < flen; ++i)
-						{
-							const bool hasSpace = nsToPos[nb + i] - nsToPos[nb + i - 1] > 1;
-							const uint16_t fc = (i + off < f.len) ? fs[i + off] : 0;
-							if (hasSpace && fc != u' ') ++se;
-							if (fc == u' ') ++off;
-						}
-					}
-				}
-				mfrec[k] = make_uint2(nb | ((se > 0xFFFFu ? 0xFFFFu : se) << 16), (uint32_t)f.flags | (valid << 8) | (endNs << 16));
+				const uint32_t i = b0 + lane;
+				const uint32_t g = (i > 0 && i < nNs && nsToPos[i] - nsToPos[i - 1] > 1) ? 1u : 0u;
+				uint32_t incl = g;
+				for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+				if (i < nNs) gapPre[i] = (uint16_t)(run + incl);
+				run += __shfl(incl, 63);
 			}
 		}
 		waveSync();
+		LW_STOP(1)
 
 		// ---- 1. the character-type state machine of progressNode (KTrie.cpp:1040-1137, 1350-1380): a function of the text alone.  It decides the
 		// boundary / unknown-form start every op is made under and emits the ops that are not dictionary candidates, each at its place in time.
-		// (one lane: ~30 instructions per text unit)
-		if (lane == 0)
+		// Text without patterns, surrogate pairs and emoji modifiers (the state then depends on the previous unit only): one unit per lane, the three
+		// running values -- start of the special run, unknown-form start, last boundary -- are "value at the most recent event", found with a ballot.
+		bool plain = B.patOff[chunk] == B.patOff[chunk + 1];
+		for (uint32_t b0 = 0; b0 < n; b0 += 64)
+		{
+			const uint32_t j = b0 + lane;
+			bool odd = false;
+			if (j < n) { const uint16_t c = str[j]; odd = isHighSurrogate(c) || isLowSurrogate(c) || c == 0x200d || script[j] == 98; }
+			if (__ballot(odd)) plain = false;
+		}
+		if (plain)
+		{
+			uint32_t tC = T_UNKNOWN, sC = 0, ssC = 0, bC = 0, uC = 0, Tbase = 1, miscBase = 0;
+			bool over = false;
+			auto lastEvent = [&](uint64_t ev, uint32_t val, uint32_t carry) -> uint32_t      // the value of the most recent event at or before this lane
+			{
+				const uint64_t m = ev & (((1ull << lane) - 1ull) | (1ull << lane));
+				const uint32_t got = __shfl(val, m ? (int)topBit(m) : (int)lane);
+				return m ? got : carry;
+			};
+			for (uint32_t b0 = 0; b0 < n; b0 += 64)
+			{
+				const uint32_t j = b0 + lane; const bool act = j < n;
+				const uint32_t t = act ? (uint32_t)(cls[j] & 0x3F) : (uint32_t)T_UNKNOWN, sc = act ? (uint32_t)script[j] : 0u;
+				const uint32_t tUp = __shfl_up(t, 1), sUp = __shfl_up(sc, 1);
+				const uint32_t tp = lane ? tUp : tC, sp = lane ? sUp : sC;
+				const bool symL = tp == T_SL || tp == T_SH || tp == T_SW, symC = t == T_SL || t == T_SH || t == T_SW;
+				const bool disc = act && (((symL && symC) ? (sp != sc) : (tp != t)) || tp == T_SSO || tp == T_SSC);
+				const bool spec = disc && tp != T_MAX && tp != T_UNKNOWN && tp != T_SS;
+				const bool sjp = T_SF <= tp && tp <= T_SW;
+				const bool isM = act && !disc && t == T_MAX, isS = act && t == T_UNKNOWN;
+				const uint32_t pj = act ? (uint32_t)posToNs[j] : 0u, pj1 = act ? (uint32_t)posToNs[j + 1] : 0u;
+				const uint32_t ss = lastEvent(__ballot(disc || isS), isS ? pj1 : pj, ssC);
+				const uint32_t ssUp = __shfl_up(ss, 1); const uint32_t ssPrev = lane ? ssUp : ssC;
+				const uint32_t bb = lastEvent(__ballot(isS || (disc && sjp)), isS ? pj1 : pj, bC);
+				const uint32_t bUp = __shfl_up(bb, 1); const uint32_t bPrev = lane ? bUp : bC;
+				const uint32_t uu = lastEvent(__ballot(isS || disc || isM), isS ? pj1 : ssPrev, uC);
+				const uint32_t uUp = __shfl_up(uu, 1); const uint32_t uPrev = lane ? uUp : uC;
+				// the z-coda / saisiot shortcut (KTrie.cpp:1126-1135), text side; the form's own facts come from the dictionary
+				uint32_t zsel = 0, zform = 0, zfl = 0;
+				const bool flush = act && !isS;
+				if (flush && pj < nNs)
+				{
+					const uint16_t ch = str[j];
+					if ((P.match & M_Z_CODA) && isHangulCoda(ch) && (j + 1 >= n || !isHangulSyllable(str[j + 1]))) { zsel = 1; zform = kDefaultTagSize + (ch - 0x11A8) - 1; }
+					else if ((P.match & (M_SPLIT_SAISIOT | M_MERGE_SAISIOT)) && ch == 0x11BA && j + 1 < n && isHangulSyllable(str[j + 1])) { zsel = 2; zform = kDefaultTagSize + (0x11BA - 0x11A8) - 1; }
+					if (zsel)
+					{
+						const FormRec f = M.forms[zform];
+						const uint32_t flen = f.len - f.numSpaces;
+						if (flen > pj1) zsel = 0;
+						else if (flen != 1) { over = true; zsel = 0; }
+						else
+						{
+							const bool hj = (f.flags & FF_HAS_JCLASS) || (f.flags & FF_IS_STAG);
+							zfl = OF_HASAPP | OF_SEOK | OF_VALID | (zsel << 9) | ((uint32_t)(f.flags & 3) << 6);
+							if (!(f.flags & FF_FIRST_IS_CODA)) zfl |= OF_HASUNK | (hj ? OF_LIMJ : 0);
+							if (f.flags & FF_HAS_ANY_FULL) zfl |= OF_QUAL;
+						}
+					}
+				}
+				const uint32_t nMiscMine = (spec ? 1u : 0u) + (isS ? 1u : 0u) + (zsel ? 1u : 0u);
+				const uint32_t nOpsMine = nMiscMine + (flush ? (uint32_t)__popcll(mask[pj1]) : 0u);
+				uint32_t inclT = nOpsMine, inclM = nMiscMine;
+				for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inclT, d), w = __shfl_up(inclM, d); if (lane >= d) { inclT += v; inclM += w; } }
+				uint32_t T = Tbase + inclT - nOpsMine, mi = miscBase + inclM - nMiscMine;
+				const uint32_t totT = __shfl(inclT, 63), totM = __shfl(inclM, 63);
+				if (Tbase + totT >= lay.opCap || miscBase + totM >= lay.miscCap) over = true;      // (uniform)
+				if (!over)
+				{
+					auto put = [&](uint32_t nb, uint32_t e, uint32_t bnd, uint32_t unk, uint32_t fl, uint32_t form, uint32_t uOff, uint32_t uLen)
+					{
+						opNE[T] = nb | (e << 16); opBU[T] = bnd | (unk << 16); opFl[T] = (uint16_t)fl; opSrc[T] = (uint16_t)(0x8000u | mi);
+						miscForm[mi] = form; miscU[mi] = uOff | (uLen << 16);
+						++T; ++mi;
+					};
+					if (spec)
+					{
+						const uint32_t o = nsToPos[ssPrev], l = trimmedLen(str, o, j - o);
+						put(ssPrev, pj, bPrev, uPrev, OF_HASUNK | OF_CONDBU | (sjp ? OF_LIMJ : 0) | OF_HASAPP | OF_SEOK | OF_VALID, tp - 1u, o, l);
+					}
+					// (the values a space's own attempts are made under: after the type change of this unit, before the space resets them)
+					if (isS) put(pj1, pj1, (disc && sjp) ? pj : bPrev, (disc || isM) ? ssPrev : uPrev, OF_HASUNK | OF_CONDBU | OF_LIMJ | OF_VALID, NOFORM, 0, 0);
+					if (flush)
+					{
+						if (zsel) put(pj1 - 1, pj1, bb, uu, zfl, zform, 0, 0);
+						ctlBU[pj1] = bb | (uu << 16); ctlT[pj1] = (uint16_t)T; ctlRs[pj1] = 0;
+					}
+				}
+				Tbase += totT; miscBase += totM;
+				tC = __shfl(t, 63); sC = __shfl(sc, 63); ssC = __shfl(ss, 63); bC = __shfl(bb, 63); uC = __shfl(uu, 63);
+				if (b0 + 64 > n) { const uint32_t last = (n - 1) & 63u; tC = __shfl(t, last); sC = __shfl(sc, last); }      // (the running values beyond the text repeat the last unit's: no events there)
+			}
+			over = __ballot(over) != 0;
+			if (lane == 0)
+			{
+				// after the last unit (KTrie.cpp:1350-1380, 1434-1450): the special run still open, the whole-tail unknown form, the end node
+				uint32_t T = Tbase, mi = miscBase, boundary = bC, unkStart = uC; const uint32_t specialStart = ssC, lastType = tC;
+				auto put = [&](uint32_t nb, uint32_t e, uint32_t fl, uint32_t form, uint32_t uOff, uint32_t uLen)
+				{
+					if (T >= lay.opCap || mi >= lay.miscCap) { over = true; return; }
+					opNE[T] = nb | (e << 16); opBU[T] = boundary | (unkStart << 16); opFl[T] = (uint16_t)fl; opSrc[T] = (uint16_t)(0x8000u | mi);
+					miscForm[mi] = form; miscU[mi] = uOff | (uLen << 16);
+					++T; ++mi;
+				};
+				if (lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
+				{
+					const bool sj = T_SF <= lastType && lastType <= T_SW;
+					const uint32_t o = nsToPos[specialStart], l = trimmedLen(str, o, n - o);
+					put(specialStart, posToNs[n], OF_HASUNK | OF_CONDBU | (sj ? OF_LIMJ : 0) | OF_HASAPP | OF_SEOK | OF_VALID, lastType - 1u, o, l);
+					unkStart = specialStart;
+					if (sj) boundary = posToNs[n];
+				}
+				if (nNs && n == (uint32_t)nsToPos[nNs - 1] + 1) put(posToNs[n], posToNs[n], OF_HASUNK | OF_CONDBU | OF_LIMJ | OF_VALID, NOFORM, 0, 0);
+				put(nNs, nNs + 1, OF_HASAPP | OF_SEOK | OF_VALID | OF_END, NOFORM, 0, 0);
+				scal[0] = over ? 1u : 0u; scal[1] = T - 1;
+			}
+		}
+		// any other text: the same machine unit by unit on one lane (~40 instructions per unit)
+		else if (lane == 0)
 		{
 			const DevPattern* pat = B.patterns + B.patOff[chunk];
 			const DevPattern* patEnd = B.patterns + B.patOff[chunk + 1];
@@ -239,21 +345,47 @@ namespace kamd
 		waveSync();
 		if (scal[0]) LW_HAND_OVER(1)
 		const uint32_t K = scal[1];      // ops 1 .. K
+		LW_STOP(2)
 
-		// ---- 2. the dictionary candidates as ops, one per lane: time = the time of their end position's first candidate + rank in its list ----
-		for (uint32_t k = lane; k < mTot; k += 64)
+		// ---- 2. the dictionary candidates as ops, one per lane: time = the time of their end position's first candidate + rank in its list;
+		// start position, space errors of the span (countSpaceErrors, KTrie.cpp:316-328) and form flags decide everything static about the op ----
 		{
-			const uint2 r = mfrec[k];
-			const uint32_t e = r.y >> 16, nb = r.x & 0xFFFF, se = r.x >> 16; const uint8_t fl = (uint8_t)r.y;
-			const uint32_t T = (uint32_t)ctlT[e] + (k - moff[e]);
-			const bool valid = (r.y & 0x100) && nb >= ctlRs[e];
-			const bool hj = (fl & FF_HAS_JCLASS) || (fl & FF_IS_STAG);
-			uint32_t of = OF_HASAPP | ((uint32_t)(fl & 3) << 6);
-			if (!(fl & FF_FIRST_IS_CODA)) of |= OF_HASUNK | (hj ? OF_LIMJ : 0);
-			if (se <= P.spaceTol) of |= OF_SEOK;
-			if (fl & FF_HAS_ANY_FULL) of |= OF_QUAL;
-			if (valid) of |= OF_VALID;
-			opNE[T] = nb | (e << 16); opBU[T] = ctlBU[e]; opFl[T] = (uint16_t)of; opSrc[T] = (uint16_t)k;
+			const uint32_t* gforms = W.matchForm + mBase;
+			const uint16_t* endOf = grpList; const uint16_t* gapPre = decS;
+			for (uint32_t k = lane; k < mTot; k += 64)
+			{
+				const uint32_t fi = gforms[k]; const FormRec f = M.forms[fi];
+				const uint32_t e = endOf[k], flen = f.len - f.numSpaces;
+				const uint32_t T = (uint32_t)ctlT[e] + (k - moff[e]);
+				uint32_t nb = 0, se = 0; bool valid = false;
+				if (flen <= e)
+				{
+					valid = true; nb = e - flen;
+					if (!f.numSpaces) { if (flen > 1) se = (uint32_t)gapPre[e - 1] - (uint32_t)gapPre[nb]; }      // every gap inside the span is an error
+					else
+					{
+						const uint16_t* fs = M.formChars + f.charOff;
+						uint32_t off = 0;
+						for (uint32_t i = 1; i < flen; ++i)
+						{
+							const bool hasSpace = nsToPos[nb + i] - nsToPos[nb + i - 1] > 1;
+							const uint16_t fc = (i + off < f.len) ? fs[i + off] : 0;
+							if (hasSpace && fc != u' ') ++se;
+							if (fc == u' ') ++off;
+						}
+					}
+				}
+				const uint8_t fl = f.flags;
+				const bool hj = (fl & FF_HAS_JCLASS) || (fl & FF_IS_STAG);
+				uint32_t of = OF_HASAPP | ((uint32_t)(fl & 3) << 6);
+				if (!(fl & FF_FIRST_IS_CODA)) of |= OF_HASUNK | (hj ? OF_LIMJ : 0);
+				if (se <= P.spaceTol) of |= OF_SEOK;
+				if (fl & FF_HAS_ANY_FULL) of |= OF_QUAL;
+				if (valid && nb >= ctlRs[e]) of |= OF_VALID;
+				opNE[T] = nb | (e << 16); opBU[T] = ctlBU[e]; opFl[T] = (uint16_t)of; opSrc[T] = (uint16_t)k;
+				mforms[k] = fi; mse[k] = (uint8_t)(se > 255 ? 255 : se);
+				if ((of & OF_VALID) && (of & OF_SEOK) && (fl & 3)) atomicOr(&posZ[e], (uint32_t)(fl & 3));      // first guess of the z-coda flags: every candidate appended
+			}
 		}
 		waveSync();
 
@@ -278,7 +410,8 @@ namespace kamd
 		{
 			const uint32_t q = opNE[T] & 0xFFFF;
 			grpList[grpOff[q] + atomicAdd(&posA[q], 1u)] = (uint16_t)T;
-			decS[T] = (uint16_t)((1u << 4) | (((opFl[T] & OF_VALID) && !(opFl[T] & OF_ZSEL)) ? (1u << 5) : 0u));
+			const uint32_t fl0 = opFl[T], zs0 = (fl0 >> 9) & 3u;
+			decS[T] = (uint16_t)((1u << 4) | (((fl0 & OF_VALID) && (!zs0 || (posZ[q] & zs0))) ? (1u << 5) : 0u));      // first guess: reachable; a z shortcut is valid if any candidate ending at its start allows it
 			decT[T] = 0xFFFFu << 16;
 		}
 		waveSync();
@@ -294,6 +427,7 @@ namespace kamd
 		}
 		waveSync();
 
+		LW_STOP(3)
 		// ---- 4. the fixpoint ----
 		auto reachAt = [&](uint32_t x, uint32_t T) -> bool { return posA[x] < T || (uint32_t)unkMinT[x] < T; };      // a node ends at x before time T
 		uint32_t hazard = 0, nRounds = 0;
@@ -324,7 +458,7 @@ namespace kamd
 					if (act)
 					{
 						const uint32_t nd = (app ? 1u : 0u) | (lb << 16);
-						if (decT[T] != nd) { chg = true; decT[T] = nd; }
+						decT[T] = nd;
 						if (app)
 						{
 							atomicMin(&posA[e], T);
@@ -337,70 +471,124 @@ namespace kamd
 				}
 			}
 			waveSync();
-			// by-start pass: lane = position.  The unknown-form nodes ending there (insertUnkForm, KTrie.cpp:921-953), by the ops starting there, in time order
-			for (uint32_t b0 = 0; b0 < nPosAll; b0 += 64)
+			// by-start pass: lane = op, in (start position, time) order.  The unknown-form nodes in front of it (insertUnkForm, KTrie.cpp:921-953).  What the
+			// ops of one start position share -- the position's length mask as it grows, the count of its unknown-form nodes -- are segmented scans over
+			// adjacent lanes: an attempt on a span is made by the first op that is allowed to, whichever op that is, so the OR of what every earlier op WOULD
+			// insert on the dictionary's mask alone equals the OR of what they did insert; only the bridge nodes (made when the last node ended before
+			// the position) depend on the order, and those are taken from the previous round
 			{
-				const uint32_t q = b0 + lane;
-				if (q >= nPosAll) continue;
-				const uint32_t g0 = grpOff[q], g1 = grpOff[q + 1];
-				uint64_t F = fd[q];
-				const uint32_t rmT = posA[q], zq = posZ[q];
-				uint32_t unkCnt = 0, firstUnkT = 0xFFFF;
-				for (uint32_t g = g0; g < g1; ++g)
+				uint32_t carryQ = 0xFFFFFFFFu, carryCnt = 0; uint64_t carryF = 0;
+				for (uint32_t b0 = 0; b0 < K; b0 += 64)
 				{
-					const uint32_t T = grpList[g]; const uint32_t fl = opFl[T], bu = opBU[T];
-					const uint32_t b = bu & 0xFFFF, u = bu >> 16;
+					const uint32_t g = b0 + lane; const bool act = g < K;
+					uint32_t T = 0, fl = 0, q = 0xFFFFFFFEu, b = 0, u = 0, lastB = 0xFFFF, prev = 0;
+					if (act) { T = grpList[g]; fl = opFl[T]; const uint32_t bu = opBU[T]; b = bu & 0xFFFF; u = bu >> 16; q = opNE[T] & 0xFFFF; lastB = decT[T] >> 16; prev = decS[T]; }
+					uint64_t Fdict = 0; uint32_t rmT = 0xFFFFFFFFu, zq = 0;
+					if (act) { Fdict = fd[q]; rmT = posA[q]; zq = posZ[q]; }
 					bool valid = (fl & OF_VALID) != 0;
 					const uint32_t zsel = (fl >> 9) & 3u;
 					if (zsel) valid = valid && (zq & zsel);
-					uint32_t um = 0; const uint32_t rank = unkCnt;
-					if (valid && (fl & OF_HASUNK))
+					const bool tries = act && valid && (fl & OF_HASUNK);
+					const uint32_t lim = (fl & OF_LIMJ) ? P.maxUnkJ : P.maxUnk;
+					const bool doB = (fl & OF_CONDBU) ? (b < u) : (b < q);
+					auto lenKeyOf = [&](uint32_t s0) -> uint32_t { const uint32_t o = nsToPos[s0], len = nsToPos[q - 1] + 1u - o; return plain ? len : trimmedLen(str, o, len); };
+					// the bridge start: the end of the last node, not a lone coda
+					uint32_t lp = lastB;
+					if (tries && lastB < q && lp && isHangulCoda(str[nsToPos[lp]])) --lp;
+					// what this op contributes to its position's mask, whatever the earlier ops of the position did
+					uint64_t contrib = 0;
+					if (tries)
 					{
-						const uint32_t lim = (fl & OF_LIMJ) ? P.maxUnkJ : P.maxUnk;
-						uint32_t le = decT[T] >> 16;      // where the most recently appended node ended when this op's turn came
-						const bool doB = (fl & OF_CONDBU) ? (b < u) : (b < q);
 						for (uint32_t a = doB ? 0u : 1u; a < 2; ++a)
 						{
-							const uint32_t s = a ? u : b;
-							if (s >= q) continue;
-							const uint32_t L = q - s;
+							const uint32_t s0 = a ? u : b;
+							if (s0 >= q) continue;
+							const uint32_t L = q - s0;
 							if (L > 64) { hazard = 1; continue; }
+							if (!((Fdict >> (L - 1)) & 1) && L <= lim && reachAt(s0, T)) { const uint32_t l = lenKeyOf(s0); if (l > 64) hazard = 1; else if (l) contrib |= 1ull << (l - 1); }
+						}
+						if ((prev & 5u) && lastB < q) { const uint32_t l = lenKeyOf(lp); if (l > 64) hazard = 1; else if (l) contrib |= 1ull << (l - 1); }
+					}
+					// segmented exclusive OR over the lanes of the same start position
+					const uint32_t qUp = __shfl_up(q, 1);
+					const bool segStart = lane == 0 ? (q != carryQ) : (q != qUp);
+					const uint64_t sb = __ballot(segStart);
+					const uint64_t mineSeg = sb & (((1ull << lane) - 1ull) | (1ull << lane));
+					const uint32_t start = mineSeg ? topBit(mineSeg) : 0u;      // first lane of this lane's segment (0: it began in an earlier block)
+					uint32_t lo = (uint32_t)contrib, hi = (uint32_t)(contrib >> 32);
+					for (uint32_t d = 1; d < 64; d <<= 1)
+					{
+						const uint32_t vl = __shfl_up(lo, d), vh = __shfl_up(hi, d);
+						if (lane >= d && lane - d >= start) { lo |= vl; hi |= vh; }
+					}
+					const uint32_t exLo = __shfl_up(lo, 1), exHi = __shfl_up(hi, 1);
+					uint64_t F = Fdict;
+					if (lane > start) F |= ((uint64_t)exHi << 32) | exLo;
+					if (!mineSeg) F |= carryF;
+					// the op itself, exactly as the reference makes its attempts, on the mask as it stands when its turn comes
+					uint32_t um = 0, own = 0;
+					if (tries)
+					{
+						uint32_t le = lastB;
+						for (uint32_t a = doB ? 0u : 1u; a < 2; ++a)
+						{
+							const uint32_t s0 = a ? u : b;
+							if (s0 >= q) continue;
+							const uint32_t L = q - s0;
+							if (L > 64) continue;
 							if ((F >> (L - 1)) & 1) continue;
-							if (le < q)
+							if (le < q && lp != s0)
 							{
-								// nothing ends at or beyond q yet: bridge from the end of the last node (not from a lone coda)
-								uint32_t lp = le;
-								if (lp && isHangulCoda(str[nsToPos[lp]])) --lp;
-								if (lp != s)
+								const uint32_t L2 = q - lp;
+								if (L2 > 64) hazard = 1;
+								else if (!((F >> (L2 - 1)) & 1) && reachAt(lp, T))
 								{
-									const uint32_t L2 = q - lp;
-									if (L2 > 64) hazard = 1;
-									else if (!((F >> (L2 - 1)) & 1) && reachAt(lp, T))
-									{
-										const uint32_t o = nsToPos[lp], l = trimmedLen(str, o, nsToPos[q - 1] + 1u - o);
-										if (l > 64) hazard = 1; else if (l) F |= 1ull << (l - 1);
-										um |= 1u << (2 * a); ++unkCnt; le = q;
-									}
+									const uint32_t l = lenKeyOf(lp);
+									if (l > 64) hazard = 1; else if (l) F |= 1ull << (l - 1);
+									um |= 1u << (2 * a); ++own; le = q;
 								}
 							}
-							if (L <= lim && reachAt(s, T))
+							if (L <= lim && reachAt(s0, T))
 							{
-								const uint32_t o = nsToPos[s], l = trimmedLen(str, o, nsToPos[q - 1] + 1u - o);
+								const uint32_t l = lenKeyOf(s0);
 								if (l > 64) hazard = 1; else if (l) F |= 1ull << (l - 1);
-								um |= 2u << (2 * a); ++unkCnt; le = q;
+								um |= 2u << (2 * a); ++own; le = q;
 							}
 						}
 					}
-					if (um && firstUnkT == 0xFFFF) firstUnkT = T;
-					if (rank > 250) hazard = 1;
-					const bool rq = rmT < T || unkCnt > 0;
-					const uint32_t nd = um | (rq ? 16u : 0u) | (valid ? 32u : 0u) | ((rank & 0xFF) << 8);
-					if (decS[T] != nd) { chg = true; decS[T] = (uint16_t)nd; }
+					// rank of its nodes among the position's unknown-form nodes: segmented exclusive sum
+					uint32_t incl = own;
+					for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d && lane - d >= start) incl += v; }
+					uint32_t rank = incl - own;
+					if (!mineSeg) rank += carryCnt;
+					if (act)
+					{
+						if (rank > 250) hazard = 1;
+						const bool rq = rmT < T || rank + own > 0;
+						const uint32_t nd = um | (rq ? 16u : 0u) | (valid ? 32u : 0u) | ((rank & 0xFF) << 8);
+#ifdef LW_DEBUG_ROUNDS
+						if (prev != nd && round >= 1) printf("round %u q %u T %u fl %x old %x new %x lastB %u rmT %u nb|e %x\n", round, q, T, fl, prev, nd, lastB, rmT, opNE[T]);
+#endif
+						if (prev != nd) { chg = true; decS[T] = (uint16_t)nd; }
+						if (own && rank == 0) base[q] = (uint16_t)T;      // the position's first unknown-form node (published after the pass: other lanes still read this round's unkMinT)
+					}
+					// the last lane of a segment knows the position's totals
+					bool segEnd = act && lane < 63 && ((sb >> (lane + 1)) & 1);      // (the lanes beyond the last op form a segment of their own)
+					if (act && lane == 63) segEnd = g + 1 >= K || (opNE[grpList[g + 1]] & 0xFFFFu) != q;
+					if (segEnd) { cntU[q] = (uint16_t)(rank + own); if (rank + own == 0) base[q] = 0xFFFF; }
+					// carry into the next block: the segment of lane 63
+					const uint64_t fullF = ((uint64_t)hi << 32) | lo;
+					const uint32_t cLo = __shfl((uint32_t)fullF, 63), cHi = __shfl((uint32_t)(fullF >> 32), 63), cCnt = __shfl(rank + own, 63), cQ = __shfl(q, 63);
+					const bool contSeg = sb == 0;      // no segment began in this block: lane 63 still continues the carried one
+					carryF = (contSeg ? carryF : 0ull) | ((uint64_t)cHi << 32) | cLo;
+					carryCnt = cCnt;      // (rank + own already includes the carried count when the segment continued)
+					carryQ = cQ;
 				}
-				base[q] = (uint16_t)firstUnkT;      // (published after the pass: other lanes are still reading this round's unkMinT)
-				cntU[q] = (uint16_t)unkCnt;
 			}
 			waveSync();
+#ifdef LW_DEBUG_ROUNDS
+			for (uint32_t q = lane; q < nPosAll; q += 64) if (unkMinT[q] != base[q] && round >= 1) printf("round %u q %u unkMinT %u -> %u\n", round, q, (unsigned)unkMinT[q], (unsigned)base[q]);
+#endif
 			for (uint32_t q = lane; q < nPosAll; q += 64) if (unkMinT[q] != base[q]) { chg = true; unkMinT[q] = base[q]; }
 			waveSync();
 			if (__ballot(hazard != 0)) { hazard = 1; break; }
@@ -411,6 +599,7 @@ namespace kamd
 		if (!(decT[K] & 1u)) LW_HAND_OVER(3)
 		if (lane == 0) { atomicAdd(&W.outCounters[10], 1u); atomicAdd(&W.outCounters[11], nRounds); }
 
+		LW_STOP(4)
 		// ---- 5. rank of every appended node at its end position; successor masks; the first node of every position ----
 		{
 			uint32_t carryE = 0xFFFFFFFFu, carryCnt = 0;
@@ -472,6 +661,7 @@ namespace kamd
 		waveSync();
 		if (__ballot(hazard != 0)) LW_HAND_OVER(4)
 
+		LW_STOP(5)
 		// ---- 6. removeUnconnected, part 1: from which positions is the end node reachable (sweep from the end; window of the next 64 positions) ----
 		uint16_t* keep = unkMinT;      // (no longer needed)
 		{
@@ -505,6 +695,7 @@ namespace kamd
 		if (nConn + 1 >= cap || nConn > lay.nodeCap) { if (lane == 0) { if (nConn + 1 >= cap) W.results[chunk].status = CS_ERR_NODE_OVERFLOW; else W.nNodes[chunk] = kLatticeNeedsBig; } return; }
 		waveSync();
 
+		LW_STOP(6)
 		// ---- 7. the final records (removeUnconnected part 2 + the per-node facts the search kernel needs), one op per lane ----
 		DevNode* fin = W.nodes + nBase;
 		const uint32_t textOff = B.textOffset[chunk];
@@ -584,7 +775,7 @@ namespace kamd
 				const uint32_t rank = (dt >> 1) & 0x7FFFu, src = opSrc[T];
 				uint32_t form, uOff = 0, uLen = 0, se = 0;
 				if (src & 0x8000u) { form = miscForm[src & 0x7FFFu]; const uint32_t mu = miscU[src & 0x7FFFu]; uOff = mu & 0xFFFF; uLen = mu >> 16; }
-				else { form = mforms[src]; se = mfrec[src].x >> 16; }
+				else { form = mforms[src]; se = mse[src]; }
 				emitNode(base[e] + rank, nb, e, form, uOff, uLen, se, rank, (fl & OF_END) != 0);
 			}
 		}
