@@ -211,6 +211,7 @@ namespace kamd
 	// LDS-side capacities are the typical need (3 per text unit), not the worst-case HBM capacities: a chunk that outgrows
 	// them at run time is handed to the thread-per-chunk kernel (flag kLatticeNeedsBig in nNodes[chunk])
 	constexpr uint32_t kLatticeNeedsBig = 0xFFFFFFFEu;
+	constexpr uint32_t kLatticeNeedsWide = 0xFFFFFFFDu;      // k_lattice_wave: the chunk's ops outgrew the LDS arrays of the first launch -- the wide launch takes it
 	// (3 per unit up to 128 units, 2 per unit beyond: long chunks are the ones whose LDS copies limit the resident wavefronts -- MI355X, c4-cong: lattice
 	// stage 19.0 -> 17.x ms -- and they average fewer nodes per unit; short chunks gain nothing from smaller copies, c2-64k 1.99 ms either way)
 	KAMD_HD uint32_t latticeLdsCap(uint32_t n, uint32_t hbmCap) { const uint32_t c = n < 128 ? 3 * n + 32 : 2 * n + 160; return c < hbmCap ? c : hbmCap; }
@@ -234,28 +235,39 @@ namespace kamd
 	// n text units, P = n + 2 positions, Mc packed matches, Kc ops (matches + special / space / pattern / tail / end ops), Nc final nodes.
 	struct LwLds
 	{
-		uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, mforms, mse;        // staged inputs; form id and space errors of every packed match
+		uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, mforms, mse, mfc;   // staged inputs; form id, space errors and form facts of every packed match
 		uint32_t ctlBU, ctlT, ctlRs;                                                        // per end position: boundary | unkStart << 16, time of its first match op, resetNs
-		uint32_t opNE, opBU, opFl, opSrc, decS, decT, grpList, miscForm, miscU;             // per op (time order, 1-based)
+		uint32_t opNE, opBU, opFl, opSrc, decS, decT, grpList, miscForm, miscU, miscFc;     // per op (time order, 1-based)
 		uint32_t grpOff, posA, posZ, fd, unkMinT, cntU, cntA, succ, base, firstU, cc, scal; // per position (cc: per final node; scal: a few wave-wide words)
 		uint32_t total, matchCap, opCap, miscCap, nodeCap;
 	};
-	KAMD_HD LwLds latticeWaveLayout(uint32_t n, uint32_t nodeCapHbm, uint32_t matchCapHbm)
+	// matchRatio16: LDS room for the packed matches, in sixteenths per text unit (the engine follows what its model's dictionary produces: a chunk that
+	// needs more is built by the second, `wide` launch -- 3 matches per unit and a miscellaneous op per unit).  Arrays that are only needed while the ops
+	// are made (the scan's masks, the per-position control words, script / cflag / posToNs) share their bytes with the arrays of the final phases.
+	constexpr uint32_t kLatticeWideRatio16 = 48, kLatticeWideBit = 0x8000u;      // (the bit marks the wide launch in the kernel's ratio argument)
+	KAMD_HD LwLds latticeWaveLayout(uint32_t n, uint32_t nodeCapHbm, uint32_t matchCapHbm, uint32_t matchRatio16)
 	{
 		LwLds l; uint32_t o = 0;
 		auto take = [&](uint32_t bytes) { const uint32_t at = o; o = (o + bytes + 15u) & ~15u; return at; };
 		const uint32_t P = n + 2;
-		l.matchCap = latticeLdsCap(n, matchCapHbm); l.miscCap = n / 2 + 12; l.opCap = l.matchCap + l.miscCap + 2; l.nodeCap = latticeLdsCap(n, nodeCapHbm);
-		l.str = take(2 * n); l.cls = take(n); l.script = take(n); l.cflag = take(n);
-		l.nsToPos = take(2 * P); l.posToNs = take(2 * P); l.mask = take(8 * P); l.moff = take(4 * P);
-		l.mforms = take(4 * l.matchCap); l.mse = take(l.matchCap);
-		l.ctlBU = take(4 * P); l.ctlT = take(2 * P); l.ctlRs = take(2 * P);
+		const bool wide = (matchRatio16 & kLatticeWideBit) != 0;
+		const uint32_t wantM = n * (matchRatio16 & 0x3FFFu) / 16 + 16;      // (bits 14 / 15 of the kernel's argument are flags)
+		l.matchCap = wantM < matchCapHbm ? wantM : matchCapHbm; l.miscCap = (wide ? n : n / 2) + 12; l.opCap = l.matchCap + l.miscCap + 2;
+		const uint32_t wantN = wide ? 2 * l.opCap : l.opCap + 16;
+		l.nodeCap = wantN < nodeCapHbm ? wantN : nodeCapHbm;
+		l.str = take(2 * n); l.cls = take(n); l.nsToPos = take(2 * P);
+		l.mforms = take(4 * l.matchCap); l.mse = take(l.matchCap); l.mfc = take(4 * l.matchCap);
 		l.opNE = take(4 * l.opCap); l.opBU = take(4 * l.opCap); l.opFl = take(2 * l.opCap); l.opSrc = take(2 * l.opCap);
 		l.decS = take(2 * l.opCap); l.decT = take(4 * l.opCap); l.grpList = take(2 * l.opCap);
-		l.miscForm = take(4 * l.miscCap); l.miscU = take(4 * l.miscCap);
-		l.grpOff = take(4 * (P + 1)); l.posA = take(4 * P); l.posZ = take(4 * P); l.fd = take(8 * P); l.unkMinT = take(2 * P); l.cntU = take(2 * P); l.cntA = take(4 * P);
-		l.succ = take(8 * P); l.base = take(2 * P); l.firstU = take(4 * P); l.cc = take(2 * l.nodeCap); l.scal = take(16);
-		l.total = o;
+		l.miscForm = take(4 * l.miscCap); l.miscU = take(4 * l.miscCap); l.miscFc = take(4 * l.miscCap);
+		l.grpOff = take(4 * (P + 1)); l.posA = take(4 * P); l.posZ = take(4 * P); l.fd = take(8 * P); l.unkMinT = take(2 * P); l.cntU = take(2 * P); l.base = take(2 * P);
+		l.scal = take(16);
+		const uint32_t shared = o;
+		l.script = take(n); l.cflag = take(n); l.posToNs = take(2 * P); l.mask = take(8 * P); l.moff = take(4 * P); l.ctlBU = take(4 * P); l.ctlT = take(2 * P); l.ctlRs = take(2 * P);
+		const uint32_t endEarly = o;
+		o = shared;
+		l.cntA = take(4 * P); l.succ = take(8 * P); l.firstU = take(4 * P); l.cc = take(4 * l.nodeCap);
+		l.total = o > endEarly ? o : endEarly;
 		return l;
 	}
 

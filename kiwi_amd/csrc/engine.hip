@@ -28,7 +28,7 @@ namespace kamd
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
 	template<int GW> __global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes, uint32_t waveLayout);
-	__global__ void k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
+	__global__ void k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, uint32_t matchRatio16);
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
 	__global__ void k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr);
 	__global__ void k_unk_chr(ModelView M, BatchView B, WorkView W, ChrView C, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
@@ -214,6 +214,9 @@ namespace kamd
 		uint32_t persistBlocks = 0;
 		int latticeGroupForced = 0;      // KAMD_LATTICE_GROUP=16 / 64: lanes per chunk of k_build_lattice
 		bool latticeWave = true;         // k_lattice_wave (all lanes build the lattice); KAMD_LATTICE_WAVE=0: k_build_lattice's one-lane replay
+		// LDS room of k_lattice_wave for packed matches, sixteenths per text unit: follows what the model's dictionary produced in the batches so far
+		// (read back with every batch's counters); the first batch assumes 3 per unit, a chunk beyond the room goes to the wide launch (KAMD_LATTICE_RATIO fixes it)
+		uint32_t latticeRatio16 = kLatticeWideRatio16; bool latticeRatioForced = false;
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
@@ -358,6 +361,7 @@ namespace kamd
 		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
 		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
 		if (const char* lw = std::getenv("KAMD_LATTICE_WAVE")) impl->latticeWave = std::atoi(lw) != 0;
+		if (const char* lr = std::getenv("KAMD_LATTICE_RATIO")) { impl->latticeRatio16 = (uint32_t)std::min(4096, std::max(4, std::atoi(lr))); impl->latticeRatioForced = true; }
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
 		impl->counter.ensure(256);
 	}
@@ -678,6 +682,7 @@ namespace kamd
 #ifdef KAMD_TIMELINE
 	static void* gTimeline = nullptr;
 #endif
+	static DevBuf lwProf;         // developer aid (make lwprof + KAMD_LATTICE_PROFILE=1): phase cycle sums of k_lattice_wave
 	static DevBuf posBeacon;      // developer aid (KAMD_POS_DEBUG builds): progress beacons / phase timers of k_pos_path, 256 bytes per chunk (KAMD_POS_BEACON=1)
 	static KernelTimes launchAll(Engine::Impl& I, StagedBatch& b, const SearchParams& sp)
 	{
@@ -785,10 +790,12 @@ namespace kamd
 			// outgrow their LDS copy at run time, are picked up by the thread-per-chunk kernel (returns at once otherwise).
 			{
 				const bool wave = I.latticeWave && I.latticeGroupForced == 0;
+				const uint32_t ratio16 = I.latticeRatio16 | (getenv("KAMD_LATTICE_STATS") ? 0x4000u : 0u);      // (bit 14: the kernel also counts developer statistics)
+				if (getenv("KAMD_LATTICE_PROFILE")) { lwProf.ensure((size_t)nC * 64); HIPCHECK(hipMemsetAsync(lwProf.p, 0, (size_t)nC * 64, sA)); b.wv.beacon = lwProf.as<uint32_t>(); }
 				auto needOf = [&](uint32_t c)
 				{
 					const uint32_t nCh = b.charOff[c + 1] - b.charOff[c], nodeCap = b.nodeBase[c + 1] - b.nodeBase[c], matchCap = b.matchBase[c + 1] - b.matchBase[c];
-					return wave ? latticeWaveLayout(nCh, nodeCap, matchCap).total : latticeLdsLayout(nCh, nodeCap, matchCap).total;
+					return wave ? latticeWaveLayout(nCh, nodeCap, matchCap, ratio16 & 0x3FFFu).total : latticeLdsLayout(nCh, nodeCap, matchCap).total;
 				};
 				uint32_t i = c0;
 				while (i < c1 && needOf(b.order[i]) > I.latticeLdsBudget) ++i;
@@ -803,12 +810,14 @@ namespace kamd
 					// quarter of the wavefronts to hide their LDS chains
 					const uint32_t need16 = (need + 15u) & ~15u;
 					const bool four = I.latticeGroupForced == 16 && need16 * 4 <= 64 * 1024;
-					if (wave) hipLaunchKernelGGL(k_lattice_wave, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24));
+					if (wave) hipLaunchKernelGGL(k_lattice_wave, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24), ratio16);
 					else if (four) hipLaunchKernelGGL(k_build_lattice<16>, dim3((j - i + 3) / 4), dim3(64), need16 * 4, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need16 | (dbgStop << 24));
 					else hipLaunchKernelGGL(k_build_lattice<64>, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24));
 					i = j;
 				}
-				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget, wave ? 1u : 0u);
+				// what outgrew the first launch's LDS arrays: the same kernel with room for 3 matches and one other op per text unit, all chunks of the sub-batch in one launch (the others leave at once)
+				if (wave && I.latticeLdsBudget) hipLaunchKernelGGL(k_lattice_wave, dim3(cn), dim3(64), I.latticeLdsBudget, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + c0, cn, I.latticeLdsBudget, kLatticeWideRatio16 | kLatticeWideBit | (ratio16 & 0x4000u));
+				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget, wave ? (ratio16 & 0x3FFFu) : 0u);
 			}
 			}
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u);
@@ -995,13 +1004,36 @@ namespace kamd
 			for (int k2 = 0; k2 < 14; ++k2) fprintf(stderr, " %s %.0f (%.0f%%);", names[k2], steps ? acc[k2] / steps : 0.0, tot ? 100.0 * acc[k2] / tot : 0.0);
 			fprintf(stderr, " total %.0f\n", steps ? tot / steps : 0.0);
 		}
+		if (I.latticeWave && !I.latticeRatioForced && !b.typo.typo && nC)
+		{
+			// k_lattice_wave's LDS room for the next batch: 1.25 x the most matches per text unit any chunk of this batch had (+ 1/8), more at once
+			// when chunks had to go to the wide launch for lack of room; never below 3/4 nor above 3 per unit
+			uint32_t c16[16] = {};
+			HIPCHECK(hipMemcpy(c16, b.dOutCounters.p, 64, hipMemcpyDeviceToHost));
+			uint32_t want = (c16[13] * 16u * 5u / 4u + 99u) / 100u + 2u;
+			if (c16[4] + c16[5] > nC / 256) want = std::max(want, I.latticeRatio16 * 3u / 2u);
+			I.latticeRatio16 = std::min(kLatticeWideRatio16, std::max(12u, want));
+		}
+		if (getenv("KAMD_LATTICE_PROFILE") && lwProf.p)
+		{
+			// developer aid (make lwprof): cycles per phase of k_lattice_wave, per wavefront
+			std::vector<uint32_t> rec((size_t)nC * 16);
+			HIPCHECK(hipMemcpy(rec.data(), lwProf.p, rec.size() * 4, hipMemcpyDeviceToHost));
+			double pr[13] = {}; uint32_t seen = 0;
+			for (uint32_t c = 0; c < nC; ++c) { if (!rec[(size_t)c * 16]) continue; ++seen; for (int k2 = 0; k2 < 13; ++k2) pr[k2] += rec[(size_t)c * 16 + k2]; }
+			static const char* names[13] = { "stage", "type pass", "match ops", "groups", "clear", "by-time", "by-start", "publish", "checks", "ranks", "sweep+prefix", "emit", "pack offsets" };
+			double tot = 0; for (int k2 = 0; k2 < 13; ++k2) tot += pr[k2];
+			fprintf(stderr, "[lattice profile] clock ticks per wavefront (%u chunks):", seen);
+			for (int k2 = 0; k2 < 13; ++k2) fprintf(stderr, " %s %.0f (%.0f%%);", names[k2], seen ? pr[k2] / seen : 0.0, tot ? 100.0 * pr[k2] / tot : 0.0);
+			fprintf(stderr, " total %.0f\n", seen ? tot / seen : 0.0);
+		}
 		if (getenv("KAMD_LATTICE_STATS"))
 		{
 			// developer aid: chunks k_lattice_wave built / handed over to the replay (by reason), fixpoint rounds per chunk
 			uint32_t c16[16] = {};
 			HIPCHECK(hipMemcpy(c16, b.dOutCounters.p, 64, hipMemcpyDeviceToHost));
-			fprintf(stderr, "[lattice wave] chunks %u: built %u (%.2f rounds each); handed over: matches %u, ops %u, long span / rounds %u, no end node %u, long node %u, no start %u\n",
-				(uint32_t)nC, c16[10], c16[10] ? (double)c16[11] / c16[10] : 0.0, c16[4], c16[5], c16[6], c16[7], c16[8], c16[9]);
+			fprintf(stderr, "[lattice wave] chunks %u: built %u (%.2f rounds each); handed over: matches %u, ops %u, long span / rounds %u, no end node %u, long node %u, no start %u; ops per text unit: mean %.2f, max %.2f (matches: max %.2f)\n",
+				(uint32_t)nC, c16[10], c16[10] ? (double)c16[11] / c16[10] : 0.0, c16[4], c16[5], c16[6], c16[7], c16[8], c16[9], c16[15] ? (double)c16[14] / c16[15] : 0.0, c16[12] / 100.0, c16[13] / 100.0);
 		}
 		if (b.wv.posRecs && getenv("KAMD_POS_STATS"))
 		{

@@ -737,7 +737,7 @@ namespace kamd
 	template __global__ void k_build_lattice<16>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, uint32_t);
 
 	// One THREAD per chunk, all working arrays in HBM: for chunks whose working set does not fit the LDS budget of k_build_lattice.
-	// waveLayout: the chunks within ldsBytes were built by k_lattice_wave (lattice_wave.hip), whose LDS need is latticeWaveLayout's
+	// waveLayout != 0: the chunks within ldsBytes were built by k_lattice_wave (lattice_wave.hip), whose LDS need is latticeWaveLayout's at that match ratio
 	__global__ void __launch_bounds__(64) k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes, uint32_t waveLayout)
 	{
 		const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
@@ -748,8 +748,8 @@ namespace kamd
 		const uint32_t nNs = W.nNs[chunk];
 		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
 		const uint32_t mCapB = W.matchBase[chunk + 1] - W.matchBase[chunk];
-		const uint32_t needB = waveLayout ? latticeWaveLayout(n, cap, mCapB).total : latticeLdsLayout(n, cap, mCapB).total;
-		if (needB <= ldsBytes && W.nNodes[chunk] != kLatticeNeedsBig) return;   // done by the wave-per-chunk kernel
+		const uint32_t needB = waveLayout ? latticeWaveLayout(n, cap, mCapB, waveLayout).total : latticeLdsLayout(n, cap, mCapB).total;
+		if (needB <= ldsBytes && W.nNodes[chunk] != kLatticeNeedsBig && W.nNodes[chunk] != kLatticeNeedsWide) return;   // done by the wave-per-chunk kernel
 		const uint16_t* str = B.chars + cOff;
 		const uint8_t* cls = B.cls + cOff;
 		LatticeCtx L;

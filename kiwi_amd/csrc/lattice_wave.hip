@@ -46,13 +46,22 @@ namespace kamd
 		}
 	}
 
+	// LW_PROFILE build (make lwprof): cycles per phase, one record of 16 words per chunk in WorkView::beacon
+#ifdef LW_PROFILE
+#define LW_T0() unsigned long long lwT = clock64(); uint32_t lwAcc[13] = {};
+#define LW_MARK(k) { const unsigned long long lwN = clock64(); lwAcc[(k)] += (uint32_t)(lwN - lwT); lwT = lwN; if ((k) == 12 && lane == 0 && W.beacon) for (int lwI = 0; lwI < 13; ++lwI) W.beacon[16 * (size_t)chunk + lwI] = lwAcc[lwI]; }
+#else
+#define LW_T0()
+#define LW_MARK(k)
+#endif
 	// hands the chunk to k_build_lattice_big; outCounters[4 + reason] counts (developer statistics, KAMD_LATTICE_STATS)
-#define LW_HAND_OVER(reason) { if (lane == 0) { W.nNodes[chunk] = kLatticeNeedsBig; atomicAdd(&W.outCounters[4 + (reason)], 1u); } return; }
-	__global__ void __launch_bounds__(64) k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
+#define LW_HAND_OVER(reason) { if (lane == 0) { W.nNodes[chunk] = (!wide && ((reason) == 0 || (reason) == 1 || (reason) == 6)) ? kLatticeNeedsWide : kLatticeNeedsBig; atomicAdd(&W.outCounters[(reason) == 6 ? 4 : 4 + (reason)], 1u); } return; }
+	__global__ void __launch_bounds__(64) k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, uint32_t matchRatio16)
 	{
 		using namespace lw;
 		const uint32_t lane = threadIdx.x;
 		if (blockIdx.x >= chunkCount) return;
+		LW_T0()
 		const uint32_t chunk = chunkList[blockIdx.x];
 		if (W.results[chunk].status >= 16) return;
 		const uint32_t dbgStop = ldsBytes >> 24; ldsBytes &= 0xFFFFFFu;      // EXPERIMENT (KAMD_LATTICE_STOP): leave after phase 1 .. 6, results void
@@ -61,8 +70,10 @@ namespace kamd
 		const uint32_t nNs = W.nNs[chunk];
 		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
 		const uint32_t mBase = W.matchBase[chunk], mCap = W.matchBase[chunk + 1] - mBase;
-		const LwLds lay = latticeWaveLayout(n, cap, mCap);
-		if (lay.total > ldsBytes) return;                      // k_build_lattice_big takes it
+		const bool wide = (matchRatio16 & kLatticeWideBit) != 0;      // the second launch: only the chunks the first one could not hold
+		if (wide && W.nNodes[chunk] != kLatticeNeedsWide) return;
+		const LwLds lay = latticeWaveLayout(n, cap, mCap, matchRatio16);
+		if (lay.total > ldsBytes) { if (wide && lane == 0) W.nNodes[chunk] = kLatticeNeedsBig; return; }      // the first launch leaves it to the wide one, that one to k_build_lattice_big
 		if (nNs > 0xFFF0 || cap > 0xFFF0 || cap < 4) { if (lane == 0) W.results[chunk].status = CS_ERR_TOO_LONG; return; }
 		uint8_t* const lS = lSmem;
 
@@ -70,19 +81,19 @@ namespace kamd
 		uint8_t* cls = lS + lay.cls; uint8_t* script = lS + lay.script; uint8_t* cflag = lS + lay.cflag;
 		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(lS + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(lS + lay.posToNs);
 		uint64_t* mask = reinterpret_cast<uint64_t*>(lS + lay.mask); uint32_t* moff = reinterpret_cast<uint32_t*>(lS + lay.moff);
-		uint32_t* mforms = reinterpret_cast<uint32_t*>(lS + lay.mforms); uint8_t* mse = lS + lay.mse;
+		uint32_t* mforms = reinterpret_cast<uint32_t*>(lS + lay.mforms); uint8_t* mse = lS + lay.mse; uint32_t* mfc = reinterpret_cast<uint32_t*>(lS + lay.mfc);
 		uint32_t* ctlBU = reinterpret_cast<uint32_t*>(lS + lay.ctlBU); uint16_t* ctlT = reinterpret_cast<uint16_t*>(lS + lay.ctlT); uint16_t* ctlRs = reinterpret_cast<uint16_t*>(lS + lay.ctlRs);
 		uint32_t* opNE = reinterpret_cast<uint32_t*>(lS + lay.opNE); uint32_t* opBU = reinterpret_cast<uint32_t*>(lS + lay.opBU);
 		uint16_t* opFl = reinterpret_cast<uint16_t*>(lS + lay.opFl); uint16_t* opSrc = reinterpret_cast<uint16_t*>(lS + lay.opSrc);
 		uint16_t* decS = reinterpret_cast<uint16_t*>(lS + lay.decS); uint32_t* decT = reinterpret_cast<uint32_t*>(lS + lay.decT);
 		uint16_t* grpList = reinterpret_cast<uint16_t*>(lS + lay.grpList);
-		uint32_t* miscForm = reinterpret_cast<uint32_t*>(lS + lay.miscForm); uint32_t* miscU = reinterpret_cast<uint32_t*>(lS + lay.miscU);
+		uint32_t* miscForm = reinterpret_cast<uint32_t*>(lS + lay.miscForm); uint32_t* miscU = reinterpret_cast<uint32_t*>(lS + lay.miscU); uint32_t* miscFc = reinterpret_cast<uint32_t*>(lS + lay.miscFc);
 		uint32_t* grpOff = reinterpret_cast<uint32_t*>(lS + lay.grpOff); uint32_t* posA = reinterpret_cast<uint32_t*>(lS + lay.posA); uint32_t* posZ = reinterpret_cast<uint32_t*>(lS + lay.posZ);
 		uint64_t* fd = reinterpret_cast<uint64_t*>(lS + lay.fd); uint32_t* fdw = reinterpret_cast<uint32_t*>(lS + lay.fd);
 		uint16_t* unkMinT = reinterpret_cast<uint16_t*>(lS + lay.unkMinT); uint16_t* cntU = reinterpret_cast<uint16_t*>(lS + lay.cntU); uint32_t* cntA = reinterpret_cast<uint32_t*>(lS + lay.cntA);
 		uint64_t* succ = reinterpret_cast<uint64_t*>(lS + lay.succ); uint32_t* succw = reinterpret_cast<uint32_t*>(lS + lay.succ);
 		uint16_t* base = reinterpret_cast<uint16_t*>(lS + lay.base); uint32_t* firstU = reinterpret_cast<uint32_t*>(lS + lay.firstU);
-		uint16_t* cc = reinterpret_cast<uint16_t*>(lS + lay.cc); uint32_t* scal = reinterpret_cast<uint32_t*>(lS + lay.scal);
+		uint32_t* cc = reinterpret_cast<uint32_t*>(lS + lay.cc); uint32_t* scal = reinterpret_cast<uint32_t*>(lS + lay.scal);
 		const uint32_t nPosAll = nNs + 2;      // positions 0 .. nNs, and nNs + 1 for the end node
 
 		// ---- 0. stage the chunk (all lanes, coalesced) and digest the packed matches, one per lane (as k_build_lattice) ----
@@ -94,7 +105,7 @@ namespace kamd
 			for (uint32_t i = lane; i < n; i += 64) { str[i] = gstr[i]; cls[i] = gcls[i]; script[i] = gscript[i]; cflag[i] = gcflag[i]; }
 			for (uint32_t i = lane; i <= n; i += 64) { posToNs[i] = gp2n[i]; if (i < nNs) nsToPos[i] = gn2p[i]; }
 			for (uint32_t i = lane; i <= nNs; i += 64) { mask[i] = gmask[i]; moff[i] = gmoff[i]; }
-			for (uint32_t i = lane; i < nPosAll; i += 64) { ctlT[i] = 0; ctlRs[i] = 0; ctlBU[i] = 0; unkMinT[i] = 0xFFFF; cntU[i] = 0; cntA[i] = 0; grpOff[i] = 0; succ[i] = 0; firstU[i] = 0; posZ[i] = 0; base[i] = 0xFFFF; }
+			for (uint32_t i = lane; i < nPosAll; i += 64) { ctlT[i] = 0; ctlRs[i] = 0; ctlBU[i] = 0; unkMinT[i] = 0xFFFF; cntU[i] = 0; grpOff[i] = 0; posZ[i] = 0; base[i] = 0xFFFF; }
 			if (lane == 0) { grpOff[nPosAll] = 0; scal[0] = 0; scal[1] = 0; }
 			mTot = gmoff[nNs] + __popcll(gmask[nNs]);
 			const uint32_t* gforms = W.matchForm + mBase;
@@ -115,6 +126,7 @@ namespace kamd
 			}
 		}
 		waveSync();
+		LW_MARK(0)
 		LW_STOP(1)
 
 		// ---- 1. the character-type state machine of progressNode (KTrie.cpp:1040-1137, 1350-1380): a function of the text alone.  It decides the
@@ -345,10 +357,12 @@ namespace kamd
 		waveSync();
 		if (scal[0]) LW_HAND_OVER(1)
 		const uint32_t K = scal[1];      // ops 1 .. K
+		LW_MARK(1)
 		LW_STOP(2)
 
 		// ---- 2. the dictionary candidates as ops, one per lane: time = the time of their end position's first candidate + rank in its list;
 		// start position, space errors of the span (countSpaceErrors, KTrie.cpp:316-328) and form flags decide everything static about the op ----
+		uint32_t hazardEarly = 0;
 		{
 			const uint32_t* gforms = W.matchForm + mBase;
 			const uint16_t* endOf = grpList; const uint16_t* gapPre = decS;
@@ -384,11 +398,15 @@ namespace kamd
 				if (valid && nb >= ctlRs[e]) of |= OF_VALID;
 				opNE[T] = nb | (e << 16); opBU[T] = ctlBU[e]; opFl[T] = (uint16_t)of; opSrc[T] = (uint16_t)k;
 				mforms[k] = fi; mse[k] = (uint8_t)(se > 255 ? 255 : se);
+				mfc[k] = (uint32_t)(f.candCnt & 0x7FFFu) | ((f.flags2 & FF2_ALL_PARTIAL) ? 0x8000u : 0u) | ((uint32_t)f.flags << 16) | ((uint32_t)f.len << 24);
+				if (f.candCnt > 0x7FFFu) hazardEarly = 1;
 				if ((of & OF_VALID) && (of & OF_SEOK) && (fl & 3)) atomicOr(&posZ[e], (uint32_t)(fl & 3));      // first guess of the z-coda flags: every candidate appended
 			}
 		}
 		waveSync();
 
+		if (__ballot(hazardEarly != 0)) LW_HAND_OVER(0)
+		LW_MARK(2)
 		// ---- 3. ops grouped by START position (counting sort; the few ops of a position then ordered by time) ----
 		for (uint32_t T = 1 + lane; T <= K; T += 64) atomicAdd(&grpOff[(opNE[T] & 0xFFFF) + 1], 1u);
 		waveSync();
@@ -427,6 +445,7 @@ namespace kamd
 		}
 		waveSync();
 
+		LW_MARK(3)
 		LW_STOP(3)
 		// ---- 4. the fixpoint ----
 		auto reachAt = [&](uint32_t x, uint32_t T) -> bool { return posA[x] < T || (uint32_t)unkMinT[x] < T; };      // a node ends at x before time T
@@ -438,6 +457,7 @@ namespace kamd
 			bool chg = false;
 			for (uint32_t q = lane; q < nPosAll; q += 64) { posA[q] = q ? 0xFFFFFFFFu : 0u; posZ[q] = 0; fd[q] = 0; }      // (the start node ends at position 0, at time 0)
 			waveSync();
+			LW_MARK(4)
 			// by-time pass: lane = op.  Its own node (needs its start reachable), the tables the other pass reads, the end of the most recently appended node
 			{
 				uint32_t carry = 0;
@@ -471,6 +491,7 @@ namespace kamd
 				}
 			}
 			waveSync();
+			LW_MARK(5)
 			// by-start pass: lane = op, in (start position, time) order.  The unknown-form nodes in front of it (insertUnkForm, KTrie.cpp:921-953).  What the
 			// ops of one start position share -- the position's length mask as it grows, the count of its unknown-form nodes -- are segmented scans over
 			// adjacent lanes: an attempt on a span is made by the first op that is allowed to, whichever op that is, so the OR of what every earlier op WOULD
@@ -586,21 +607,32 @@ namespace kamd
 				}
 			}
 			waveSync();
+			LW_MARK(6)
 #ifdef LW_DEBUG_ROUNDS
 			for (uint32_t q = lane; q < nPosAll; q += 64) if (unkMinT[q] != base[q] && round >= 1) printf("round %u q %u unkMinT %u -> %u\n", round, q, (unsigned)unkMinT[q], (unsigned)base[q]);
 #endif
 			for (uint32_t q = lane; q < nPosAll; q += 64) if (unkMinT[q] != base[q]) { chg = true; unkMinT[q] = base[q]; }
 			waveSync();
+			LW_MARK(7)
 			if (__ballot(hazard != 0)) { hazard = 1; break; }
 			if (!__ballot(chg)) break;
 		}
 		if (__ballot(hazard != 0)) LW_HAND_OVER(2)
 		// the end node must exist (else the reference renames whatever node came last: left to the replay)
 		if (!(decT[K] & 1u)) LW_HAND_OVER(3)
-		if (lane == 0) { atomicAdd(&W.outCounters[10], 1u); atomicAdd(&W.outCounters[11], nRounds); }
+		if (lane == 0)
+		{
+			// what the engine sizes the next batch's LDS arrays by: the most matches per text unit seen (an atomic only when it grows)
+			const uint32_t r100 = (mTot * 100u) / (n ? n : 1u);
+			if (r100 > W.outCounters[13]) atomicMax(&W.outCounters[13], r100);
+			if (matchRatio16 & 0x4000u) { atomicAdd(&W.outCounters[10], 1u); atomicAdd(&W.outCounters[11], nRounds); atomicMax(&W.outCounters[12], (K * 100u) / (n ? n : 1u)); atomicAdd(&W.outCounters[14], K); atomicAdd(&W.outCounters[15], n); }      // developer statistics
+		}
 
+		LW_MARK(8)
 		LW_STOP(4)
 		// ---- 5. rank of every appended node at its end position; successor masks; the first node of every position ----
+		for (uint32_t i = lane; i < nPosAll; i += 64) { cntA[i] = 0; succ[i] = 0; firstU[i] = 0; }      // (these arrays take over the bytes of the scan's masks and the control words)
+		waveSync();
 		{
 			uint32_t carryE = 0xFFFFFFFFu, carryCnt = 0;
 			for (uint32_t b0 = 1; b0 <= K; b0 += 64)
@@ -661,6 +693,7 @@ namespace kamd
 		waveSync();
 		if (__ballot(hazard != 0)) LW_HAND_OVER(4)
 
+		LW_MARK(9)
 		LW_STOP(5)
 		// ---- 6. removeUnconnected, part 1: from which positions is the end node reachable (sweep from the end; window of the next 64 positions) ----
 		uint16_t* keep = unkMinT;      // (no longer needed)
@@ -692,18 +725,50 @@ namespace kamd
 			if (q < nPosAll) base[q] = (uint16_t)(nConn + incl - c);
 			nConn += __shfl(incl, 63);
 		}
-		if (nConn + 1 >= cap || nConn > lay.nodeCap) { if (lane == 0) { if (nConn + 1 >= cap) W.results[chunk].status = CS_ERR_NODE_OVERFLOW; else W.nNodes[chunk] = kLatticeNeedsBig; } return; }
+		if (nConn + 1 >= cap) { if (lane == 0) W.results[chunk].status = CS_ERR_NODE_OVERFLOW; return; }
+		if (nConn > lay.nodeCap) LW_HAND_OVER(6)
 		waveSync();
 
+		LW_MARK(10)
 		LW_STOP(6)
-		// ---- 7. the final records (removeUnconnected part 2 + the per-node facts the search kernel needs), one op per lane ----
+		// ---- 7. the final records (removeUnconnected part 2 + the per-node facts the search kernel needs).  First the candidate count of every final
+		// node (the forms' facts were kept when the matches were digested), their prefix sum = the nodes' candidate-record offsets; then one op per
+		// lane builds its nodes whole and stores each once ----
 		DevNode* fin = W.nodes + nBase;
 		const uint32_t textOff = B.textOffset[chunk];
-		auto emitNode = [&](uint32_t ni, uint32_t s, uint32_t t, uint32_t form, uint32_t uOff, uint32_t uLen, uint32_t se, uint32_t rankAt, bool isEnd)
+		auto factsOf = [&](uint32_t form) -> uint32_t { const FormRec f = M.forms[form]; return (uint32_t)(f.candCnt & 0x7FFFu) | ((f.flags2 & FF2_ALL_PARTIAL) ? 0x8000u : 0u) | ((uint32_t)f.flags << 16) | ((uint32_t)f.len << 24); };
+		if (lane == 0) cc[0] = 0;
+		for (uint32_t T = 1 + lane; T <= K; T += 64)
+		{
+			const uint32_t ne = opNE[T], nb = ne & 0xFFFF, e = ne >> 16, ds = decS[T], s4 = ds & 15u, dt = decT[T];
+			if (s4 && keep[nb]) { uint32_t r = base[nb] + cntA[nb] + ((ds >> 8) & 0xFFu); for (uint32_t i = 0; i < 4; ++i) if ((s4 >> i) & 1) cc[r++] = 0; }
+			if ((dt & 1u) && keep[e])
+			{
+				const uint32_t src = opSrc[T];
+				uint32_t fc = 0;
+				if (!(src & 0x8000u)) fc = mfc[src];
+				else { const uint32_t form = miscForm[src & 0x7FFFu]; if (form != NOFORM) fc = factsOf(form); miscFc[src & 0x7FFFu] = fc; }
+				cc[base[e] + ((dt >> 1) & 0x7FFFu)] = fc & 0x7FFFu;
+			}
+		}
+		waveSync();
+		LW_MARK(11)
+		uint32_t packTop = 0;
+		for (uint32_t b0 = 0; b0 < nConn; b0 += 64)
+		{
+			const uint32_t i = b0 + lane;
+			const uint32_t c = i < nConn ? cc[i] : 0u;
+			uint32_t incl = c;
+			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+			if (i < nConn) cc[i] = packTop + incl - c;
+			packTop += __shfl(incl, 63);
+		}
+		waveSync();
+		auto emitNode = [&](uint32_t ni, uint32_t s, uint32_t t, uint32_t form, uint32_t fc, uint32_t uOff, uint32_t uLen, uint32_t se, uint32_t rankAt, bool isEnd)
 		{
 			DevNode nn;
 			nn.form = form; nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = (uint8_t)(se > 255 ? 255 : se);
-			nn.candCnt = 0; nn.fflags = 0; nn.flen = 0; nn.ownFeat = 0; nn.pad = 0; nn.packOff = 0;
+			nn.ownFeat = 0; nn.pad = 0; nn.packOff = cc[ni];
 			const uint32_t startStr = isEnd ? n : (uint32_t)nsToPos[s];
 			const bool pnBos = s == 0;
 			const uint32_t pnEndStr = pnBos ? 0u : (uint32_t)nsToPos[s - 1] + 1u;
@@ -723,16 +788,12 @@ namespace kamd
 			if (spaceBefore) nf |= NF_SPACE_BEFORE;
 			if (lb) nf |= NF_LEFT_BOUNDARY;
 			if (uLen && str[uOff + uLen - 1] == u'.') nf |= NF_UFORM_ENDS_POINT;
+			if (fc & 0x8000u) nf |= NF_ALL_PARTIAL;
 			nn.nPrev = (uint16_t)(pnBos ? 1u : cntA[s] + cntU[s]);
-			if (form != NOFORM)
-			{
-				const FormRec f = M.forms[form];
-				nn.candCnt = f.candCnt; nn.fflags = f.flags; nn.flen = f.len;
-				if (f.flags2 & FF2_ALL_PARTIAL) nf |= NF_ALL_PARTIAL;
-			}
+			nn.candCnt = (uint16_t)(fc & 0x7FFFu); nn.fflags = (uint8_t)(fc >> 16); nn.flen = (uint8_t)(fc >> 24);
 			if (uLen)
 			{
-				uint16_t of = featMask(str + uOff, uLen) & 0x1FFF;
+				uint16_t of = featMaskFast(str + uOff, uLen) & 0x1FFF;
 				const uint32_t lp = uOff + uLen - 1;
 				const uint16_t c = str[lp];
 				const uint8_t tag = (isLowSurrogate(c) || isHighSurrogate(c)) ? (uint8_t)T_SH : (uint8_t)(cls[lp] & 0x3F);
@@ -745,12 +806,11 @@ namespace kamd
 			if (isEnd) nn.startPos = nn.endPos = (uint16_t)n;
 			else { nn.startPos = nsToPos[s]; nn.endPos = (uint16_t)(nsToPos[t - 1] + 1); }
 			fin[ni] = nn;
-			cc[ni] = nn.candCnt;
 		};
 		if (lane == 0)
 		{
 			DevNode bos; bos.form = NOFORM; bos.startPos = bos.endPos = 0; bos.prev = bos.sibling = 0; bos.uformOff = bos.uformLen = 0; bos.spaceErrors = 0; bos.nflags = 0; bos.nPrev = 0; bos.packOff = 0; bos.candCnt = 0; bos.fflags = 0; bos.flen = 0; bos.ownFeat = 0; bos.pad = 0;
-			fin[0] = bos; cc[0] = 0;
+			fin[0] = bos;
 		}
 		for (uint32_t T = 1 + lane; T <= K; T += 64)
 		{
@@ -764,32 +824,22 @@ namespace kamd
 				for (uint32_t i = 0; i < 4; ++i)
 				{
 					if (!((s4 >> i) & 1)) continue;
-					const uint32_t s = (i & 1) ? ((i & 2) ? (bu >> 16) : (bu & 0xFFFF)) : lp;
-					const uint32_t o = nsToPos[s], l = trimmedLen(str, o, nsToPos[nb - 1] + 1u - o);
-					emitNode(base[nb] + r, s, nb, NOFORM, o, l, 0, r, false);
+					const uint32_t s0 = (i & 1) ? ((i & 2) ? (bu >> 16) : (bu & 0xFFFF)) : lp;
+					const uint32_t o = nsToPos[s0], len = nsToPos[nb - 1] + 1u - o, l = plain ? len : trimmedLen(str, o, len);
+					emitNode(base[nb] + r, s0, nb, NOFORM, 0, o, l, 0, r, false);
 					++r;
 				}
 			}
 			if ((dt & 1u) && keep[e])
 			{
 				const uint32_t rank = (dt >> 1) & 0x7FFFu, src = opSrc[T];
-				uint32_t form, uOff = 0, uLen = 0, se = 0;
-				if (src & 0x8000u) { form = miscForm[src & 0x7FFFu]; const uint32_t mu = miscU[src & 0x7FFFu]; uOff = mu & 0xFFFF; uLen = mu >> 16; }
-				else { form = mforms[src]; se = mse[src]; }
-				emitNode(base[e] + rank, nb, e, form, uOff, uLen, se, rank, (fl & OF_END) != 0);
+				uint32_t form, fc, uOff = 0, uLen = 0, se = 0;
+				if (src & 0x8000u) { form = miscForm[src & 0x7FFFu]; fc = miscFc[src & 0x7FFFu]; const uint32_t mu = miscU[src & 0x7FFFu]; uOff = mu & 0xFFFF; uLen = mu >> 16; }
+				else { form = mforms[src]; fc = mfc[src]; se = mse[src]; }
+				emitNode(base[e] + rank, nb, e, form, fc, uOff, uLen, se, rank, (fl & OF_END) != 0);
 			}
 		}
-		waveSync();
-		uint32_t packTop = 0;
-		for (uint32_t b0 = 0; b0 < nConn; b0 += 64)
-		{
-			const uint32_t i = b0 + lane;
-			const uint32_t c = i < nConn ? (uint32_t)cc[i] : 0u;
-			uint32_t incl = c;
-			for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-			if (i < nConn) fin[i].packOff = packTop + incl - c;
-			packTop += __shfl(incl, 63);
-		}
+		LW_MARK(12)
 		if (lane == 0)
 		{
 			const uint32_t packCap = W.packBase[chunk + 1] - W.packBase[chunk];
