@@ -172,7 +172,8 @@ namespace kamd
 		DevChunkResult* results;       // [c]
 		DevPathHeader* outPaths;       // compact output of the end stage: path headers of all chunks ...
 		DevToken* outTokens;           // ... and their token records (D2H copies exactly what was produced)
-		uint32_t* outCounters;         // [0] path headers handed out, [1] token records handed out, [2] chunks that ended in a scratch overflow
+		uint32_t* outCounters;         // [0] path headers handed out, [1] token records handed out, [2] chunks that ended in a scratch overflow, [3] entries of wideList, [4..15] k_lattice_wave's counters
+		uint32_t* wideList;            // [nChunks] chunks k_lattice_wave's first launch left to its wide launch
 		// Match::oovChrModel (null: unknown forms are scored by the length rule): per node, same offsets as nodes, the character model's score of
 		// the node's unknown form -- its own string of a formless node, else its text span (k_unk_chr; UnkFormScorer::chrBasedScore before the bias)
 		float* unkChr;

@@ -176,7 +176,7 @@ namespace kamd
 		std::vector<uint64_t> stateBase, tokenBase;
 		// device
 		PinBuf hIn; DevBuf dIn;   // the batch's input block (layoutAndUpload)
-		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchForm, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes;
+		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchForm, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes, dWideList;
 		DevBuf dHist;   // SkipBigram models: history ring of every search state (8 x u32), parallel to dStates
 		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
@@ -474,7 +474,7 @@ namespace kamd
 		b.dNsToPos.ensure(perChar * 2); b.dPosToNs.ensure(perChar * 2); b.dCflag.ensure(perChar); b.dMask.ensure(perChar * 8); b.dMoff.ensure(perChar * 4);
 		b.dNNs.ensure(nC * 4 + 16); b.dMatchForm.ensure(totMatch * 4 + 16);
 		b.dNodes.ensure(totNodes * sizeof(DevNode) + 16); b.dTmpNodes.ensure(totNodes * sizeof(DevNode) + 16);
-		b.dEndPosMap.ensure(perChar * 4); b.dFullMask.ensure(perChar * 8); b.dZAt.ensure(perChar); b.dTmpIdx.ensure(totNodes * 4 + 16); b.dNNodes.ensure(nC * 4 + 16);
+		b.dEndPosMap.ensure(perChar * 4); b.dFullMask.ensure(perChar * 8); b.dZAt.ensure(perChar); b.dTmpIdx.ensure(totNodes * 4 + 16); b.dNNodes.ensure(nC * 4 + 16); b.dWideList.ensure(nC * 4 + 16);
 		b.dPacks.ensure((size_t)b.packBase[nC] * sizeof(CandStatic) + 16);
 		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
 		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
@@ -501,7 +501,7 @@ namespace kamd
 		w.matchMask = b.dMask.as<uint64_t>(); w.matchOff = b.dMoff.as<uint32_t>(); w.nNs = b.dNNs.as<uint32_t>();
 		w.matchBase = (const uint32_t*)(D + oMatchBase); w.matchForm = b.dMatchForm.as<uint32_t>();
 		w.nodeBase = (const uint32_t*)(D + oNodeBase); w.nodes = b.dNodes.as<DevNode>(); w.tmpNodes = b.dTmpNodes.as<DevNode>();
-		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.fullMask = b.dFullMask.as<uint64_t>(); w.zAt = b.dZAt.as<uint8_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>();
+		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.fullMask = b.dFullMask.as<uint64_t>(); w.zAt = b.dZAt.as<uint8_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>(); w.wideList = b.dWideList.as<uint32_t>();
 		w.packBase = (const uint32_t*)(D + oPackBase); w.packs = b.dPacks.as<CandStatic>();
 		w.stateBase = (const uint64_t*)(D + oStateBase); w.states = b.dStates.as<DevState>();
 		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();
@@ -816,7 +816,7 @@ namespace kamd
 					i = j;
 				}
 				// what outgrew the first launch's LDS arrays: the same kernel with room for 3 matches and one other op per text unit, all chunks of the sub-batch in one launch (the others leave at once)
-				if (wave && I.latticeLdsBudget) hipLaunchKernelGGL(k_lattice_wave, dim3(cn), dim3(64), I.latticeLdsBudget, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + c0, cn, I.latticeLdsBudget, kLatticeWideRatio16 | kLatticeWideBit | (ratio16 & 0x4000u));
+				if (wave && I.latticeLdsBudget) hipLaunchKernelGGL(k_lattice_wave, dim3(std::min(cn, 1024u)), dim3(64), I.latticeLdsBudget, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + c0, std::min(cn, 1024u), I.latticeLdsBudget, kLatticeWideRatio16 | kLatticeWideBit | (ratio16 & 0x4000u));
 				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget, wave ? (ratio16 & 0x3FFFu) : 0u);
 			}
 			}

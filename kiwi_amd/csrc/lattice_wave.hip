@@ -55,14 +55,19 @@ namespace kamd
 #define LW_MARK(k)
 #endif
 	// hands the chunk to k_build_lattice_big; outCounters[4 + reason] counts (developer statistics, KAMD_LATTICE_STATS)
-#define LW_HAND_OVER(reason) { if (lane == 0) { W.nNodes[chunk] = (!wide && ((reason) == 0 || (reason) == 1 || (reason) == 6)) ? kLatticeNeedsWide : kLatticeNeedsBig; atomicAdd(&W.outCounters[(reason) == 6 ? 4 : 4 + (reason)], 1u); } return; }
+#define LW_HAND_OVER(reason) { if (lane == 0) { const bool toWide = !wide && ((reason) == 0 || (reason) == 1 || (reason) == 6); W.nNodes[chunk] = toWide ? kLatticeNeedsWide : kLatticeNeedsBig; \
+		if (toWide) W.wideList[atomicAdd(&W.outCounters[3], 1u)] = chunk; atomicAdd(&W.outCounters[(reason) == 6 ? 4 : 4 + (reason)], 1u); } return; }
 	__global__ void __launch_bounds__(64) k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, uint32_t matchRatio16)
 	{
 		using namespace lw;
 		const uint32_t lane = threadIdx.x;
+		// the second, `wide` launch: only the chunks the first one could not hold, from the list it left (one block per entry; chunkCount = the most
+		// entries this launch takes -- whatever is beyond stays flagged for k_build_lattice_big)
+		const bool wide = (matchRatio16 & kLatticeWideBit) != 0;
+		if (wide) chunkCount = W.outCounters[3] < chunkCount ? W.outCounters[3] : chunkCount;
 		if (blockIdx.x >= chunkCount) return;
 		LW_T0()
-		const uint32_t chunk = chunkList[blockIdx.x];
+		const uint32_t chunk = wide ? W.wideList[blockIdx.x] : chunkList[blockIdx.x];
 		if (W.results[chunk].status >= 16) return;
 		const uint32_t dbgStop = ldsBytes >> 24; ldsBytes &= 0xFFFFFFu;      // EXPERIMENT (KAMD_LATTICE_STOP): leave after phase 1 .. 6, results void
 #define LW_STOP(k) if (dbgStop == (k)) { if (lane == 0) W.results[chunk].status = CS_NO_LATTICE; return; }
@@ -70,7 +75,6 @@ namespace kamd
 		const uint32_t nNs = W.nNs[chunk];
 		const uint32_t nBase = W.nodeBase[chunk], cap = W.nodeBase[chunk + 1] - nBase;
 		const uint32_t mBase = W.matchBase[chunk], mCap = W.matchBase[chunk + 1] - mBase;
-		const bool wide = (matchRatio16 & kLatticeWideBit) != 0;      // the second launch: only the chunks the first one could not hold
 		if (wide && W.nNodes[chunk] != kLatticeNeedsWide) return;
 		const LwLds lay = latticeWaveLayout(n, cap, mCap, matchRatio16);
 		if (lay.total > ldsBytes) { if (wide && lane == 0) W.nNodes[chunk] = kLatticeNeedsBig; return; }      // the first launch leaves it to the wide one, that one to k_build_lattice_big
