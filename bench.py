@@ -170,13 +170,35 @@ def copy_bandwidth_gbs():
     return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def side_measurement(eng, workload, steps=20):
-    """Device-resident rate and per-kernel times of another workload on the same engine (config.also)."""
-    from kiwi_amd.workloads import get_workload
-    _, texts, desc = get_workload(workload)
-    batch = eng.stage(texts)
-    for _ in range(3):
-        eng.run(batch)
+def side_measurement(eng, workload, steps=20, limit=0, min_seconds=0.0):
+    """Device-resident rate, per-kernel times and roofline fraction of another workload (an entry of config.also).  eng: an engine on the workload's
+    model, or None -- then one is opened (and closed) here.  limit: only the first N sentences (named in the entry).  The algorithmic bytes per
+    sentence come from the oracle's event counters on a bounded sample of the same workload, as for the headline workload."""
+    from kiwi_amd.api import KiwiAmd, Typo
+    from kiwi_amd.workloads import fill_typo_rules, get_workload, workload_top_n, workload_typo
+    model_path, texts, desc = get_workload(workload)
+    if limit and limit < len(texts):
+        texts = texts[:limit]
+        desc += f" [first {limit} sentences only]"
+    own = eng is None
+    if own:
+        eng = KiwiAmd(model_path, 0)
+    top_n = workload_top_n(workload)
+    typo_cfg, typo = workload_typo(workload), None
+    if typo_cfg is not None:
+        typo = Typo(eng.lib, typo_cfg[0], typo_cfg[1]); fill_typo_rules(typo); typo.prepare(True)
+    batch = eng.stage(texts) if typo is None else eng.stage(texts, typo=typo, typo_threshold=typo_cfg[2])
+    if top_n > 1:
+        eng.fetch(batch, top_n).close()
+    t1 = time.perf_counter()
+    eng.run(batch)
+    one = time.perf_counter() - t1
+    if one > 1.0:
+        steps = 1      # (seconds per batch: one timed pass)
+    else:
+        for _ in range(2):
+            eng.run(batch)
+        steps = max(steps, int(min_seconds / max(one, 1e-6)) + 1) if min_seconds else steps
     kt = {"scan_ms": 0.0, "lattice_ms": 0.0, "search_ms": 0.0, "finish_ms": 0.0}
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -184,8 +206,23 @@ def side_measurement(eng, workload, steps=20):
         for k in kt:
             kt[k] += r[k]
     el = time.perf_counter() - t0
+    rerun_chunks, rerun_ms = eng.reruns(batch)
+    info = batch.info()
     batch.close()
-    return {"workload": desc, "value": len(texts) * steps / el, "unit": "sentences/s", "steps": steps, "ms_per_step": 1000.0 * el / steps, "kernel_ms": {k: v / steps for k, v in kt.items()}, "sentences": len(texts)}
+    if typo is not None:
+        typo.close()
+    if own:
+        eng.close()
+    out = {"workload": desc, "value": len(texts) * steps / el, "unit": "sentences/s", "steps": steps, "ms_per_step": 1000.0 * el / steps, "kernel_ms": {k: v / steps for k, v in kt.items()},
+           "sentences": len(texts), "top_n": top_n, "device_bytes": info["device_bytes"], "rerun_chunks": rerun_chunks}
+    try:
+        per = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg, time_reference=False)["alg_bytes_per_sentence"]
+        out["alg_bytes_per_sentence"] = per
+        out["roofline_frac"] = per["search"] * len(texts) / (out["kernel_ms"]["search_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        out["all_kernels_achieved"] = per["total"] * len(texts) / (sum(out["kernel_ms"].values()) * 1e-3) / 1e9
+    except Exception as e:      # (informative: never fail the bench line over it)
+        out["roofline_error"] = repr(e)[:200]
+    return out
 
 
 def capi_rate(model_path, workload, top_n, passes=5):
@@ -215,12 +252,13 @@ def main():
                     "no C-API client, no end-to-end pass), so that per-kernel counters and statistics belong to this workload alone")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every rank analyses a batch of the workload's size; strong: ONE corpus split over the ranks by index (text i -> rank i %% N)")
+    ap.add_argument("--no-side-models", action="store_true", help="config.also without the workloads that need another model loaded (c4-cong, c3-sbg)")
     ap.add_argument("--limit", type=int, default=0, help="diagnostics: only the first N sentences of the workload (named in config.workload)")
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "c2-64k" if args.gpus <= 1 else "c4-cong"
     if args.steps is None:
-        args.steps = 100 if args.workload == "c2" else 40 if args.workload == "c2-64k" else 20
+        args.steps = 400 if args.workload == "c2" else 200 if args.workload == "c2-64k" else 40      # a timed region of >= 1 s (a utilisation sampler sees it)
 
     import torch
     from kiwi_amd import dist
@@ -313,7 +351,12 @@ def main():
     batch.close()      # (the end-to-end pass below stages its own batch: a large workload does not fit the device twice)
     also = None
     if args.workload == "c2-64k" and world == 1 and not args.limit and not args.kernels_only:
-        also = side_measurement(eng, "c2")      # BASELINE configs[1] at its own batch size (8192 sentences: the latency-bound regime)
+        # the other BASELINE configurations beside the headline, each with its own roofline fraction: configs[1] at its own batch size (8192 sentences:
+        # the latency-bound regime), configs[4] (typo correction), configs[3]'s model and length mix on one GPU, configs[2] (SkipBigram, top-3: the
+        # synthetic tables do not prune like a real model -- seconds per batch, hence a bounded sample)
+        also = [side_measurement(eng, "c2", min_seconds=0.5), side_measurement(eng, "c5", min_seconds=0.5)]
+        if not args.no_side_models:
+            also += [side_measurement(None, "c4-cong", steps=10), side_measurement(None, "c3-sbg", steps=1, limit=4096)]
 
     # End to end: UTF-16 strings resident on the host -> kamd_analyze_batch (host text preparation, H2D, kernels,
     # D2H, result assembly) -> packed token records resident on the host.  Timed through the C ABI on an already packed buffer.
@@ -368,8 +411,6 @@ def main():
                 out["cpu_baseline"] = cb["cpu_baseline"]
                 if e2e is not None:
                     e2e["vs_cpu_baseline"] = e2e["value"] / cb["cpu_baseline"]["value"]
-            if also is not None:
-                also["roofline_frac"] = per["search"] * also["sentences"] / (also["kernel_ms"]["search_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS      # (same sentence shape: same algorithmic bytes per sentence)
         if also is not None:
             out["config"]["also"] = also
         if world == 1 and typo is None and not args.limit and not args.kernels_only:

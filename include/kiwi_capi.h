@@ -9,7 +9,12 @@
  *     sj.morph + cong.mdl, optionally nounchr.mdl -- the layout of the reference's models/cong/base), or a raw-model container (or a directory holding `kiwi_amd.raw`).  Its `options` are honoured as in the reference:
  *     KIWI_BUILD_INTEGRATE_ALLOMORPH sets integrate_allomorph; the model type bits select a CoNgram model (default / LARGEST when the
  *     container has one, CONG; local scoring), Knlm (default otherwise, KNLM) or SkipBigram (LARGEST when the container has the tables, SBG)
- *     and refuse CONG_GLOBAL; the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).
+ *     and refuse CONG_GLOBAL; LARGEST on a cong.mdl that carries distant-token (window) sections is refused too -- the reference resolves it to the
+ *     global scoring (KiwiBuilder.cpp:939-946), and a drop-in must not answer with another model's results; the LOAD_*_DICT bits are accepted
+ *     (a raw container's dictionary is baked).
+ *   - top_n > 1: the analyses and their scores are the reference's.  Among analyses whose scores are EXACTLY equal the order is this library's
+ *     own deterministic one (candidates in lattice order); the reference's order of such ties follows the iteration order of its per-morpheme hash
+ *     containers (src/BestPathContainer.hpp:279-483) and differs between its own builds.
  *   - option.blocklist (morpheme sets: kiwi_new_morphset / kiwi_morphset_add / _add_w / _close) is honoured;
  *     option.allowed_dialects / dialect_cost are accepted: they only concern dialect morphemes, which no model loaded here has (kiwi_init
  *     refuses enabled_dialects != 0); top_n > 16 and pretokenized spans are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of

@@ -40,8 +40,16 @@ struct kiwi_s
 		int nDev = Engine::visibleDevices();
 		if (const char* e = std::getenv("KAMD_DEVICES")) nDev = std::max(1, std::min(nDev, std::atoi(e)));
 		const int own = engine->deviceIndex();
-		for (int d = 0; d < Engine::visibleDevices() && (int)replicas.size() + 1 < nDev; ++d) if (d != own) replicas.emplace_back(new Engine(*engine, d));
+		// built aside and swapped in whole: a replica that fails to open (out of memory on one GPU) leaves the handle as it was -- no half set that the
+		// next call would extend with duplicates -- and the thread back on the handle's own device
+		std::vector<std::unique_ptr<Engine>> made;
+		try
+		{
+			for (int d = 0; d < Engine::visibleDevices() && (int)made.size() + 1 < nDev; ++d) if (d != own) made.emplace_back(new Engine(*engine, d));
+		}
+		catch (...) { engine->bindThread(); throw; }
 		engine->bindThread();      // (opening a replica made its device the thread's current one)
+		replicas.swap(made);
 		replicasMade = true;
 	}
 };
@@ -196,7 +204,10 @@ namespace
 		auto analyse = [h, topN, &opt](Job& job)
 		{
 			if (!job.utf8.empty())
+			{
 				HostPool::instance().run(job.utf8.size(), 512, h->numThreads, [&](size_t a, size_t b, int) { for (size_t i = a; i < b; ++i) job.texts[i] = utf8To16(job.utf8[i].data(), job.utf8[i].size()); });
+				std::vector<std::string>().swap(job.utf8);      // (the batch keeps one copy of its texts, not two, while it is on the device)
+			}
 			std::vector<std::pair<const char16_t*, size_t>> views;
 			for (auto& t : job.texts) views.emplace_back(t.data(), t.size());
 			// One host process drives every GPU (the reference's driver keeps a thread pool busy, include/kiwi/Kiwi.h:402-454): the batch is cut into
@@ -423,14 +434,14 @@ extern "C"
 			// options (capi.h:158-171; kiwi_c.cpp:717-736): bit 0 = integrateAllomorph (KiwiBuilder.cpp:2413); bits 1-3 ask for dictionaries that a raw
 			// container already has baked in (or not) -- they cannot change anything here; 0x0F00 = model type
 			if (options & ~0x0F0F) throw std::invalid_argument{ "kiwi_amd: unknown build option bits" };
-			Engine::LmMode lm; bool knlmUnlessCong = false;
+			Engine::LmMode lm; bool knlmUnlessCong = false, largest = false;
 			switch (options & 0x0F00)
 			{
 			// default / largest: the reference looks for cong.mdl first (-> cong / congGlobal), then skipbigram.mdl (-> knlm / sbg), then sj.knlm
 			// (KiwiBuilder.cpp:939-961); here: a CoNgram blob when the container has one (local scoring: the global variant is not built),
 			// else Knlm by default and SkipBigram for `largest`
 			case 0x0000: lm = Engine::LmMode::Auto; knlmUnlessCong = true; break;
-			case 0x0100: lm = Engine::LmMode::Auto; break;
+			case 0x0100: lm = Engine::LmMode::Auto; largest = true; break;
 			case 0x0200: lm = Engine::LmMode::Knlm; break;
 			case 0x0300: lm = Engine::LmMode::Sbg; break;
 			case 0x0400: lm = Engine::LmMode::Cong; break;
@@ -442,6 +453,9 @@ extern "C"
 			auto h = std::make_unique<kiwi_s>();
 			h->engine.reset(new Engine(path, -1, lm));      // (-1: the caller's current device)
 			if (knlmUnlessCong && !h->engine->usesCong() && h->engine->usesSbg()) h->engine.reset(new Engine(path, -1, Engine::LmMode::Knlm));
+			// LARGEST on a cong.mdl is the reference's congGlobal (KiwiBuilder.cpp:939-946): with distant-token sections in the file that is a different
+			// scoring from the local one built here -- refused rather than answered with another model's results
+			if (largest && h->engine->congWindow()) throw std::invalid_argument{ "kiwi_amd: KIWI_BUILD_MODEL_TYPE_LARGEST on a CoNgram model with distant-token sections means the global (window " + std::to_string(h->engine->congWindow()) + ") scoring, which the device path does not do yet; ask for KIWI_BUILD_MODEL_TYPE_CONG (local scoring) explicitly" };
 			h->engine->config.integrateAllomorph = !!(options & 1);
 			h->numThreads = num_threads < 0 ? 0 : (num_threads == 0 ? 1 : num_threads);
 			return h.release();

@@ -385,6 +385,7 @@ namespace kamd
 	const FlatModel& Engine::model() const { return impl->model; }
 	bool Engine::usesCong() const { return impl->hasCong; }
 	bool Engine::usesSbg() const { return impl->hasSbg; }
+	uint32_t Engine::congWindow() const { return impl->hasCong ? impl->model.congWindow : 0u; }
 
 	namespace
 	{
@@ -837,8 +838,10 @@ namespace kamd
 			wv.posHandOver = usePos ? I.counter.as<uint32_t>() + 48 + k : nullptr;      // (zeroed with the work counters above)
 			if (usePos && I.posContSlots)
 			{
-				I.posScratch.ensure((size_t)I.posContSlots * groupScratchBytes);
-				wv.posScratch = I.posScratch.as<uint8_t>(); wv.posContCounter = I.counter.as<uint32_t>() + 56 + (k & 7); wv.posContSlots = I.posContSlots;
+				// (consecutive sub-batches' searches may overlap at their tails: like bigScratch, the continuation slots alternate between two halves)
+				I.posScratch.ensure((size_t)I.posContSlots * groupScratchBytes * std::min(S, 2u));
+				wv.posScratch = I.posScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)I.posContSlots * groupScratchBytes : 0);
+				wv.posContCounter = I.counter.as<uint32_t>() + 56 + (k & 7); wv.posContSlots = I.posContSlots;
 			}
 #ifdef KAMD_TIMELINE
 			static DevBuf tlBuf;
@@ -847,7 +850,8 @@ namespace kamd
 			wv.beacon = tlBuf.as<uint32_t>(); gTimeline = tlBuf.p;
 #endif
 #ifndef KAMD_TIMELINE
-			if (getenv("KAMD_POS_BEACON"))
+			static const bool envPosBeacon = getenv("KAMD_POS_BEACON") != nullptr;      // (read once: this is the per-batch hot path)
+			if (envPosBeacon)
 			{
 				posBeacon.ensure((size_t)nC * 256);
 				HIPCHECK(hipMemsetAsync(posBeacon.p, 0, (size_t)nC * 256, sB));

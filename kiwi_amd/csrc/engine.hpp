@@ -72,6 +72,7 @@ namespace kamd
 		int deviceIndex() const;      // the HIP device this engine's tables and streams live on
 		void bindThread() const;      // makes that device the calling thread's current one
 		bool usesCong() const; bool usesSbg() const;      // which language model scores the search
+		uint32_t congWindow() const;                      // window size of the CoNgram model's distant-token sections (0: none, or not a CoNgram model)
 		~Engine();
 		const FlatModel& model() const;
 

@@ -6,6 +6,7 @@
 // (src/Knlm.hpp:1003-1167).  Everything is index based; nothing here is shared with oracle/_ref.
 #include <sys/stat.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -298,7 +299,11 @@ namespace kamd
 				// 4 slots per bucket, at most one edge per two buckets on average: a bucket is full -- and a lookup that ends in it has to go on to the
 				// next one -- with probability < 0.2 % (Poisson, mean <= 0.5).  One such lane sends its whole wavefront through the general walk's loop,
 				// so the table is sized for that to be rare (at mean 2 it was 4 % of the lookups); 128 - 256 bytes of HBM per edge
-				while (nBuckets < 2 * (nEdges + 1)) nBuckets <<= 1;
+				// (KAMD_LM_HASH_LOAD=<edges per bucket, 1..4>: a denser table for a model whose n-gram count makes 128 - 256 B per edge too much memory)
+				size_t perTwo = 1;
+				if (const char* e = std::getenv("KAMD_LM_HASH_LOAD")) perTwo = (size_t)std::min(8, std::max(1, 2 * std::atoi(e)));
+				while (nBuckets * perTwo < 2 * (nEdges + 1)) nBuckets <<= 1;
+				if (nBuckets > (size_t(1) << 32)) throw std::runtime_error{ "language model: the edge table would need more than 2^32 buckets (" + std::to_string(nEdges) + " edges)" };
 				m.lmHashMask = (uint32_t)(nBuckets - 1);
 				m.lmHash.assign(nBuckets * 4, LmSlot{ LM_SLOT_EMPTY, LM_SLOT_EMPTY, 0, 0.f });
 				for (uint32_t nd = 1; nd < nonLeaf; ++nd)

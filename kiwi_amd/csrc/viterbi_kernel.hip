@@ -1900,6 +1900,7 @@ namespace sbgk
 				if (X.gl == 0) { const uint32_t o = X.nodeStOff[j]; X.ringBeg()[j & (RING - 1)] = o; X.ringEnd()[j & (RING - 1)] = o + X.nodeStCnt[j]; X.ringCum()[j & (RING - 1)] = cum; }
 			}
 			cumLive = cum;
+			X.stTop = X.nodeStOff[resume - 1] + X.nodeStCnt[resume - 1];      // (before the hot-quad copy below, which is sized by it)
 			if constexpr (Lay<G>::HCAP != 0)
 			{
 				// (one chunk per wave: the hot quads of the first HCAP states are read from their LDS copies)

@@ -134,6 +134,35 @@ def test_position_step_kernel_equals_general_kernel_on_whole_corpora(monkeypatch
     assert a.nbytes == b.nbytes and np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("workload,limit", [("c2-64k", 65536), ("c3", 32768), ("c4-cong", 32768)])
+def test_all_lanes_lattice_kernel_equals_the_one_lane_replay_on_whole_corpora(monkeypatch, workload, limit):
+    """k_lattice_wave (round 4: the ops of a chunk decided together by a fixpoint, every lane at work) against k_build_lattice (the reference's
+    sequential replay on lane 0, the kernel the lattice dumps pin to the oracle and the real reference at sample size): every sentence of the bench
+    corpora, the packed token records -- what the search makes of the lattices, node order and per-node facts included -- are the same bytes; and
+    with LDS room for 3/4 match per text unit (KAMD_LATTICE_RATIO=12) the chunks that outgrow it are built by the wide launch, same bytes again."""
+    import numpy as np
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+    path, texts, _ = get_workload(workload)
+    texts = texts[:limit]
+    wave = KiwiAmd(path)
+    a = _packed(wave, texts)
+    wave.close()
+    monkeypatch.setenv("KAMD_LATTICE_RATIO", "12")
+    tight = KiwiAmd(path)
+    c = _packed(tight, texts[:8192])
+    a8 = None
+    tight.close()
+    monkeypatch.delenv("KAMD_LATTICE_RATIO")
+    monkeypatch.setenv("KAMD_LATTICE_WAVE", "0")
+    old = KiwiAmd(path)
+    b = _packed(old, texts)
+    b8 = _packed(old, texts[:8192])
+    old.close()
+    assert a.nbytes == b.nbytes and np.array_equal(a, b)
+    assert c.nbytes == b8.nbytes and np.array_equal(c, b8)
+
+
 def test_c3_sbg_2k_sentences_top3_vs_oracle_and_reference():
     """BASELINE config 3 on its own model: the 'full-sbg' synthetic model (Knlm + SkipBigram), 2048 mixed 5-200 jamo sentences of its
     lexicon (the c3 corpus), top-3 -- device vs the CPU oracle, analysis for analysis with fp32 scores, and vs the REAL reference where its

@@ -102,6 +102,28 @@ def test_emulated_lattice_build_with_four_chunks_per_wavefront(emu_libs, oracle,
         dev.close()
 
 
+def test_emulated_all_lanes_lattice_kernel(emu_libs, oracle, small_model, monkeypatch):
+    """k_lattice_wave (lattice_wave.hip; the engine's default): the lattice dumps and the analyses of mixed-length, dictionary-mix, edge and fuzzed
+    texts (surrogate pairs, emoji modifiers and pattern spans send a chunk through the one-lane character-type pass, everything else through the
+    one-unit-per-lane pass) equal the oracle's; with LDS room for a quarter match per text unit (KAMD_LATTICE_RATIO=4) every chunk outgrows the first
+    launch and is built by the wide one, with KAMD_LATTICE_LDS=3000 the longer chunks go to the thread-per-chunk replay; and the one-lane replay
+    kernel (KAMD_LATTICE_WAVE=0) still answers the same."""
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    texts = synthetic(sm, 60, 551, min_jamo=5, max_jamo=200) + dictionary_mix(sm, 30, 552) + EDGE_TEXTS + fuzzed(sm, 120, 553)
+    for env in ({}, {"KAMD_LATTICE_RATIO": "4"}, {"KAMD_LATTICE_LDS": "3000"}, {"KAMD_LATTICE_WAVE": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dev = KiwiAmd(path, lib_path=emu_libs[0])
+        _check(dev, oracle, texts[:120] if env else texts)
+        for t in (texts if not env else texts[::3]):
+            if t.strip():
+                assert dev.split(t) == oracle.split(t), (env, t)
+        dev.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_emulated_lattice_hbm_kernel_and_rerun_ladder(emu_libs, oracle, small_model, monkeypatch):
     """KAMD_LATTICE_LDS=0 sends every chunk to the thread-per-chunk lattice kernel; KAMD_TEST_TINY_ARENAS makes most chunks
     climb the capacity ladder (re-runs with 4x / 16x / 64x arenas)."""
