@@ -174,6 +174,7 @@ namespace kamd
 		DevToken* outTokens;           // ... and their token records (D2H copies exactly what was produced)
 		uint32_t* outCounters;         // [0] path headers handed out, [1] token records handed out, [2] chunks that ended in a scratch overflow, [3] entries of wideList, [4..15] k_lattice_wave's counters
 		uint32_t* wideList;            // [nChunks] chunks k_lattice_wave's first launch left to its wide launch
+		uint8_t* expanded;             // [nChunks] 1: k_lattice_wave wrote the chunk's candidate records and position program itself -- k_expand_cands / k_expand_pos skip it
 		// Match::oovChrModel (null: unknown forms are scored by the length rule): per node, same offsets as nodes, the character model's score of
 		// the node's unknown form -- its own string of a formless node, else its text span (k_unk_chr; UnkFormScorer::chrBasedScore before the bias)
 		float* unkChr;
@@ -239,7 +240,7 @@ namespace kamd
 		uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, mforms, mse, mfc;   // staged inputs; form id, space errors and form facts of every packed match
 		uint32_t ctlBU, ctlT, ctlRs;                                                        // per end position: boundary | unkStart << 16, time of its first match op, resetNs
 		uint32_t opNE, opBU, opFl, opSrc, decS, decT, grpList, miscForm, miscU, miscFc;     // per op (time order, 1-based)
-		uint32_t grpOff, posA, posZ, fd, unkMinT, cntU, cntA, succ, base, firstU, cc, scal; // per position (cc: per final node; scal: a few wave-wide words)
+		uint32_t grpOff, posA, posZ, fd, unkMinT, cntU, cntA, succ, base, firstU, cc, recOff, scal; // per position (cc: per final node; scal: a few wave-wide words)
 		uint32_t total, matchCap, opCap, miscCap, nodeCap;
 	};
 	// matchRatio16: LDS room for the packed matches, in sixteenths per text unit (the engine follows what its model's dictionary produces: a chunk that
@@ -267,7 +268,7 @@ namespace kamd
 		l.script = take(n); l.cflag = take(n); l.posToNs = take(2 * P); l.mask = take(8 * P); l.moff = take(4 * P); l.ctlBU = take(4 * P); l.ctlT = take(2 * P); l.ctlRs = take(2 * P);
 		const uint32_t endEarly = o;
 		o = shared;
-		l.cntA = take(4 * P); l.succ = take(8 * P); l.firstU = take(4 * P); l.cc = take(4 * l.nodeCap);
+		l.cntA = take(4 * P); l.succ = take(8 * P); l.firstU = take(4 * P); l.cc = take(4 * l.nodeCap); l.recOff = take(4 * l.nodeCap);
 		l.total = o > endEarly ? o : endEarly;
 		return l;
 	}

@@ -28,7 +28,7 @@ namespace kamd
 	__global__ void k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount);
 	template<int GW> __global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes, uint32_t waveLayout);
-	__global__ void k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, uint32_t matchRatio16);
+	__global__ void k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, uint32_t matchRatio16, uint32_t expandMode);
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
 	__global__ void k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr);
 	__global__ void k_unk_chr(ModelView M, BatchView B, WorkView W, ChrView C, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
@@ -176,7 +176,10 @@ namespace kamd
 		std::vector<uint64_t> stateBase, tokenBase;
 		// device
 		PinBuf hIn; DevBuf dIn;   // the batch's input block (layoutAndUpload)
-		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchForm, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes, dWideList;
+		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchForm, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes, dWideList, dExpanded;
+		// LDS size classes of the lattice kernel per sub-batch {first, end, bytes}, first = the chunks beyond the budget; made once per (batch, match ratio, kernel)
+		struct LatClass { uint32_t i, j, need; };
+		std::vector<std::vector<LatClass>> latClasses; std::vector<uint32_t> latSkip; uint32_t latClassesKey = 0xFFFFFFFFu;
 		DevBuf dHist;   // SkipBigram models: history ring of every search state (8 x u32), parallel to dStates
 		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
@@ -208,6 +211,8 @@ namespace kamd
 		ModelView dview{};
 		std::vector<std::unique_ptr<DevBuf>> modelBufs;
 		hipStream_t stream = nullptr, stream2 = nullptr;   // lattice stages / search stage (sub-batches overlap)
+		hipStream_t latStream[2] = { nullptr, nullptr };   // the lattice kernel's LDS size classes are launched round-robin over `stream` and these: their tails overlap
+		hipEvent_t latFork = nullptr, latJoin[2] = { nullptr, nullptr };
 		std::vector<hipEvent_t> evs;
 		int subBatches = 0;   // 0 = automatic
 		int device = 0;
@@ -218,6 +223,7 @@ namespace kamd
 		// (read back with every batch's counters); the first batch assumes 3 per unit, a chunk beyond the room goes to the wide launch (KAMD_LATTICE_RATIO fixes it)
 		uint32_t latticeRatio16 = kLatticeWideRatio16; bool latticeRatioForced = false;
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
+		uint32_t latticeWaveBudget = 128 * 1024; // ... and k_lattice_wave, which is allowed beyond the default 64 KB limit (a 400-unit chunk needs ~70 KB; the CU has 160 KB)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
@@ -283,6 +289,9 @@ namespace kamd
 		HIPCHECK(hipSetDevice(device));
 		HIPCHECK(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));
 		HIPCHECK(hipStreamCreateWithFlags(&impl->stream2, hipStreamNonBlocking));
+		for (auto& ls : impl->latStream) HIPCHECK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+		HIPCHECK(hipEventCreate(&impl->latFork)); for (auto& ev : impl->latJoin) HIPCHECK(hipEventCreate(&ev));
+
 		if (const char* sb = std::getenv("KAMD_SUBBATCHES")) impl->subBatches = std::atoi(sb);
 		const FlatModel& m = impl->model;
 		ModelView& v = impl->dview;
@@ -362,7 +371,8 @@ namespace kamd
 		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
 		if (const char* lw = std::getenv("KAMD_LATTICE_WAVE")) impl->latticeWave = std::atoi(lw) != 0;
 		if (const char* lr = std::getenv("KAMD_LATTICE_RATIO")) { impl->latticeRatio16 = (uint32_t)std::min(4096, std::max(4, std::atoi(lr))); impl->latticeRatioForced = true; }
-		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l)));
+		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) { impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l))); impl->latticeWaveBudget = (uint32_t)std::min(128 * 1024, std::max(0, std::atoi(l))); }
+		if (impl->latticeWaveBudget > 64 * 1024) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lattice_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)impl->latticeWaveBudget));
 		impl->counter.ensure(256);
 	}
 
@@ -379,6 +389,9 @@ namespace kamd
 			devCache().trim();
 			if (impl->stream) (void)hipStreamDestroy(impl->stream);
 			if (impl->stream2) (void)hipStreamDestroy(impl->stream2);
+			for (auto ls : impl->latStream) if (ls) (void)hipStreamDestroy(ls);
+			if (impl->latFork) (void)hipEventDestroy(impl->latFork);
+			for (auto ev : impl->latJoin) if (ev) (void)hipEventDestroy(ev);
 		}
 	}
 
@@ -475,7 +488,7 @@ namespace kamd
 		b.dNsToPos.ensure(perChar * 2); b.dPosToNs.ensure(perChar * 2); b.dCflag.ensure(perChar); b.dMask.ensure(perChar * 8); b.dMoff.ensure(perChar * 4);
 		b.dNNs.ensure(nC * 4 + 16); b.dMatchForm.ensure(totMatch * 4 + 16);
 		b.dNodes.ensure(totNodes * sizeof(DevNode) + 16); b.dTmpNodes.ensure(totNodes * sizeof(DevNode) + 16);
-		b.dEndPosMap.ensure(perChar * 4); b.dFullMask.ensure(perChar * 8); b.dZAt.ensure(perChar); b.dTmpIdx.ensure(totNodes * 4 + 16); b.dNNodes.ensure(nC * 4 + 16); b.dWideList.ensure(nC * 4 + 16);
+		b.dEndPosMap.ensure(perChar * 4); b.dFullMask.ensure(perChar * 8); b.dZAt.ensure(perChar); b.dTmpIdx.ensure(totNodes * 4 + 16); b.dNNodes.ensure(nC * 4 + 16); b.dWideList.ensure(nC * 4 + 16); b.dExpanded.ensure(nC + 16);
 		b.dPacks.ensure((size_t)b.packBase[nC] * sizeof(CandStatic) + 16);
 		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
 		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
@@ -502,7 +515,7 @@ namespace kamd
 		w.matchMask = b.dMask.as<uint64_t>(); w.matchOff = b.dMoff.as<uint32_t>(); w.nNs = b.dNNs.as<uint32_t>();
 		w.matchBase = (const uint32_t*)(D + oMatchBase); w.matchForm = b.dMatchForm.as<uint32_t>();
 		w.nodeBase = (const uint32_t*)(D + oNodeBase); w.nodes = b.dNodes.as<DevNode>(); w.tmpNodes = b.dTmpNodes.as<DevNode>();
-		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.fullMask = b.dFullMask.as<uint64_t>(); w.zAt = b.dZAt.as<uint8_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>(); w.wideList = b.dWideList.as<uint32_t>();
+		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.fullMask = b.dFullMask.as<uint64_t>(); w.zAt = b.dZAt.as<uint8_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>(); w.wideList = b.dWideList.as<uint32_t>(); w.expanded = b.dExpanded.as<uint8_t>();
 		w.packBase = (const uint32_t*)(D + oPackBase); w.packs = b.dPacks.as<CandStatic>();
 		w.stateBase = (const uint64_t*)(D + oStateBase); w.states = b.dStates.as<DevState>();
 		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();
@@ -731,6 +744,7 @@ namespace kamd
 		HIPCHECK(hipMemsetAsync(b.dOutCounters.p, 0, 64, sA));
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
 		HIPCHECK(hipMemsetAsync(b.dNNodes.p, 0, (size_t)nC * 4, sA));   // also clears the lattice kernels' hand-over flag
+		HIPCHECK(hipMemsetAsync(b.dExpanded.p, 0, nC, sA));
 		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
 		// SkipBigram: one chunk per wave unless 16-lane groups are forced -- with history rings in the container keys a lattice node gathers
 		// thousands of work items, so a chunk's serial chain is items / lanes (MI355X, small model: 480 texts 0.7 s with 64 lanes, 7 s with 16)
@@ -752,6 +766,40 @@ namespace kamd
 			if (I.sbgScratch.p != before) HIPCHECK(hipMemsetAsync(I.sbgScratch.p, 0, I.sbgScratch.cap, sA));
 		}
 		const uint32_t ldsBytes = searchKernelLdsBytes(I.groupLanes);
+		if (!b.typo.typo)
+		{
+			// the lattice kernel's LDS size classes: the work order (longest chunk first = largest LDS need first) of every sub-batch cut into classes of
+			// <= 25 % unused LDS, one launch each.  Made before anything is enqueued (between two launches it left the device idle for 0.45 ms at 65 536
+			// chunks) and kept with the batch while the match ratio stays what it was
+			const bool wave = I.latticeWave && I.latticeGroupForced == 0;
+			const uint32_t ratioKey = wave ? (I.latticeRatio16 & 0x3FFFu) : 0x10000u;
+			const uint32_t budget = wave ? I.latticeWaveBudget : I.latticeLdsBudget;
+			const uint32_t classesKey = ratioKey * 31u + budget / 16u;
+			if (b.latClassesKey != classesKey || b.latClasses.size() != S)
+			{
+				auto needOf = [&](uint32_t c)
+				{
+					const uint32_t nCh = b.charOff[c + 1] - b.charOff[c], nodeCap = b.nodeBase[c + 1] - b.nodeBase[c], matchCap = b.matchBase[c + 1] - b.matchBase[c];
+					return wave ? latticeWaveLayout(nCh, nodeCap, matchCap, ratioKey).total : latticeLdsLayout(nCh, nodeCap, matchCap).total;
+				};
+				b.latClasses.assign(S, {});
+				for (uint32_t k = 0; k < S; ++k)
+				{
+					const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S);
+					uint32_t i = c0;
+					while (i < c1 && needOf(b.order[i]) > budget) ++i;
+					while (i < c1)
+					{
+						const uint32_t need = needOf(b.order[i]);
+						uint32_t j = i + 1;
+						while (j < c1 && (uint64_t)needOf(b.order[j]) * 4 >= (uint64_t)need * 3) ++j;      // <= 25 % of a class's LDS unused
+						b.latClasses[k].push_back({ i, j, need });
+						i = j;
+					}
+				}
+				b.latClassesKey = classesKey;
+			}
+		}
 		for (uint32_t k = 0; k < S; ++k)
 		{
 			const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S), cn = c1 - c0;
@@ -792,33 +840,37 @@ namespace kamd
 			{
 				const bool wave = I.latticeWave && I.latticeGroupForced == 0;
 				const uint32_t ratio16 = I.latticeRatio16 | (getenv("KAMD_LATTICE_STATS") ? 0x4000u : 0u);      // (bit 14: the kernel also counts developer statistics)
+				// the candidate records and the position program written by the lattice kernel itself (no k_expand_cands / k_expand_pos pass over these chunks):
+				// for the position-step search without a blocklist and without character-model scores of unknown forms (k_unk_chr sits between the two);
+				// bit 1: a CoNgram model (records in the transposed evaluator's order).  KAMD_LATTICE_EXPAND=0: the two kernels do it
+				static const bool fuseExpand = !(getenv("KAMD_LATTICE_EXPAND") && std::atoi(getenv("KAMD_LATTICE_EXPAND")) == 0);
+				const bool posEarly = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8;
+				const uint32_t expandMode = (fuseExpand && posEarly && !b.wv.unkChr && !b.wv.blockBits) ? (1u | (I.hasCong ? 2u : 0u)) : 0u;
 				if (getenv("KAMD_LATTICE_PROFILE")) { lwProf.ensure((size_t)nC * 64); HIPCHECK(hipMemsetAsync(lwProf.p, 0, (size_t)nC * 64, sA)); b.wv.beacon = lwProf.as<uint32_t>(); }
-				auto needOf = [&](uint32_t c)
+				const uint32_t budget = wave ? I.latticeWaveBudget : I.latticeLdsBudget;
+				// the size classes of k_lattice_wave go round-robin over three streams (forked from and joined back into sA): a class ends when its slowest
+				// wavefront does, and the next class's wavefronts fill the machine meanwhile
+				uint32_t nClass = 0;
+				if (wave) { HIPCHECK(hipEventRecord(I.latFork, sA)); for (auto ls : I.latStream) HIPCHECK(hipStreamWaitEvent(ls, I.latFork, 0)); }
+				for (const auto& lc : b.latClasses[k])
 				{
-					const uint32_t nCh = b.charOff[c + 1] - b.charOff[c], nodeCap = b.nodeBase[c + 1] - b.nodeBase[c], matchCap = b.matchBase[c + 1] - b.matchBase[c];
-					return wave ? latticeWaveLayout(nCh, nodeCap, matchCap, ratio16 & 0x3FFFu).total : latticeLdsLayout(nCh, nodeCap, matchCap).total;
-				};
-				uint32_t i = c0;
-				while (i < c1 && needOf(b.order[i]) > I.latticeLdsBudget) ++i;
-				while (i < c1)
-				{
-					const uint32_t need = needOf(b.order[i]);
-					uint32_t j = i + 1;
-					while (j < c1 && (uint64_t)needOf(b.order[j]) * 4 >= (uint64_t)need * 3) ++j;      // <= 25 % of a class's LDS unused
+					const uint32_t i = lc.i, j = lc.j, need = lc.need;
 					static const uint32_t dbgStop = std::getenv("KAMD_LATTICE_STOP") ? (uint32_t)std::atoi(std::getenv("KAMD_LATTICE_STOP")) : 0u;      // EXPERIMENT
 					// one chunk per wavefront.  KAMD_LATTICE_GROUP=16 (EXPERIMENT) packs four: measured slower on the MI355X -- c2-64k 3.04 ms against
 					// 1.96 ms, c2 0.57 against 0.42 ms (profiles/r03_o_*): the four replays diverge, and a block with four working sets leaves a
 					// quarter of the wavefronts to hide their LDS chains
 					const uint32_t need16 = (need + 15u) & ~15u;
 					const bool four = I.latticeGroupForced == 16 && need16 * 4 <= 64 * 1024;
-					if (wave) hipLaunchKernelGGL(k_lattice_wave, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24), ratio16);
+					hipStream_t sL = wave ? (nClass % 3 == 0 ? sA : I.latStream[nClass % 3 - 1]) : sA;
+					++nClass;
+					if (wave) hipLaunchKernelGGL(k_lattice_wave, dim3(j - i), dim3(64), need, sL, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24), ratio16, expandMode);
 					else if (four) hipLaunchKernelGGL(k_build_lattice<16>, dim3((j - i + 3) / 4), dim3(64), need16 * 4, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need16 | (dbgStop << 24));
 					else hipLaunchKernelGGL(k_build_lattice<64>, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24));
-					i = j;
 				}
-				// what outgrew the first launch's LDS arrays: the same kernel with room for 3 matches and one other op per text unit, all chunks of the sub-batch in one launch (the others leave at once)
-				if (wave && I.latticeLdsBudget) hipLaunchKernelGGL(k_lattice_wave, dim3(std::min(cn, 1024u)), dim3(64), I.latticeLdsBudget, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + c0, std::min(cn, 1024u), I.latticeLdsBudget, kLatticeWideRatio16 | kLatticeWideBit | (ratio16 & 0x4000u));
-				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, I.latticeLdsBudget, wave ? (ratio16 & 0x3FFFu) : 0u);
+				if (wave) for (int t = 0; t < 2; ++t) { HIPCHECK(hipEventRecord(I.latJoin[t], I.latStream[t])); HIPCHECK(hipStreamWaitEvent(sA, I.latJoin[t], 0)); }
+				// what outgrew the first launch's LDS arrays: the same kernel with room for 3 matches and one other op per text unit, over the list the first launch left
+				if (wave && budget) hipLaunchKernelGGL(k_lattice_wave, dim3(std::min(cn, 1024u)), dim3(64), budget, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + c0, std::min(cn, 1024u), budget, kLatticeWideRatio16 | kLatticeWideBit | (ratio16 & 0x4000u), expandMode);
+				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, budget, wave ? (ratio16 & 0x3FFFu) : 0u);
 			}
 			}
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u);
@@ -1036,6 +1088,11 @@ namespace kamd
 			// developer aid: chunks k_lattice_wave built / handed over to the replay (by reason), fixpoint rounds per chunk
 			uint32_t c16[16] = {};
 			HIPCHECK(hipMemcpy(c16, b.dOutCounters.p, 64, hipMemcpyDeviceToHost));
+			std::vector<uint8_t> ex(nC); std::vector<PosDesc> pd;
+			HIPCHECK(hipMemcpy(ex.data(), b.dExpanded.p, nC, hipMemcpyDeviceToHost));
+			uint32_t nEx = 0, nProg = 0;
+			for (uint32_t c = 0; c < nC; ++c) if (ex[c]) { ++nEx; if (b.wv.posDesc) { PosDesc d; HIPCHECK(hipMemcpy(&d, b.wv.posDesc + b.nodeBase[c], sizeof(d), hipMemcpyDeviceToHost)); nProg += d.firstRec != 0; } }
+			fprintf(stderr, "[lattice wave] records written by the lattice kernel: %u chunks (%u with a position program)\n", nEx, nProg);
 			fprintf(stderr, "[lattice wave] chunks %u: built %u (%.2f rounds each); handed over: matches %u, ops %u, long span / rounds %u, no end node %u, long node %u, no start %u; ops per text unit: mean %.2f, max %.2f (matches: max %.2f)\n",
 				(uint32_t)nC, c16[10], c16[10] ? (double)c16[11] / c16[10] : 0.0, c16[4], c16[5], c16[6], c16[7], c16[8], c16[9], c16[15] ? (double)c16[14] / c16[15] : 0.0, c16[12] / 100.0, c16[13] / 100.0);
 		}

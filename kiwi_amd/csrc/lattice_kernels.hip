@@ -22,6 +22,7 @@
 #include "device_types.hpp"
 #include "feature.hpp"
 #include "lattice_connect.hpp"
+#include "lattice_expand.hpp"
 
 namespace kamd
 {
@@ -792,7 +793,7 @@ namespace kamd
 	{
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t chunk = chunkBegin + blockIdx.x;
-		if (W.results[chunk].status != CS_OK) return;
+		if (W.results[chunk].status != CS_OK || W.expanded[chunk]) return;      // (expanded: k_lattice_wave wrote the records itself)
 		const uint32_t nBase = W.nodeBase[chunk], G = W.nNodes[chunk];
 		CandStatic* packs = W.packs + W.packBase[chunk];
 		const uint32_t* blk = W.blockBits;
@@ -809,26 +810,11 @@ namespace kamd
 				// a candidate on the blocklist is not a candidate (src/PathEvaluator.hpp:385, 892): it gets no record, the node's list shrinks
 				if (blocked(mid)) continue;
 				++kept;
-				const uint4* mr = reinterpret_cast<const uint4*>(M.morphs + mid);
-				CandStatic o; const uint4 r0 = mr[0], r1 = mr[1];
-				o.m0 = Quad{ r0.x, r0.y, r0.z, r0.w }; o.m1 = Quad{ r1.x, r1.y, r1.z, r1.w };
-				const uint32_t flags = o.m1.y & 0xFFFF; const uint8_t tag = (uint8_t)o.m1.z;
-				const uint32_t firstWid = (flags & MF_SINGLE) ? o.m0.x : M.chunkLm[o.m0.z];
-				const uint32_t sbType = tag == T_SB ? M.sbInfo[mid] : 0;
-				// 4th word: LM id of the second chunk of a chunked candidate (saves the search a dependent chunk-table load)
-				const uint32_t secondWid = (!(flags & MF_SINGLE) && (o.m1.w & 0xFF) >= 2) ? M.chunkLm[o.m0.z + 1] : 0;
-				o.x = Quad{ mid, firstWid, sbType, secondWid };
+				const CandStatic o = candStaticOf(M, mid);
 				uint32_t at = 0;
 				if (transposedOrder)
 				{
-					auto cls = [&](uint32_t m2) -> uint32_t
-					{
-						const MorphRec r = M.morphs[m2];
-						if (r.tag == T_Z_CODA) return 0;
-						if (r.tag == T_Z_SIOT) return 1;
-						if (!r.socket) return 2;
-						return (r.flags & MF_SINGLE) ? 3 : 4;
-					};
+					auto cls = [&](uint32_t m2) -> uint32_t { const MorphRec r = M.morphs[m2]; return candClassOf(r.tag, r.socket, r.flags); };
 					const uint32_t mine = cls(mid);
 					for (uint32_t j = 0; j < nd.candCnt; ++j)
 					{
@@ -855,26 +841,12 @@ namespace kamd
 	// tag score: PathEvaluator.hpp:366-383, 1224-1318), the rule scorer's node-side inputs (:88-109), the own-form facts of the states they create.
 	// One wave per chunk, three passes of one node per lane, after k_expand_cands (and k_unk_chr): A counts records and positions, B completes the
 	// position table, C writes the records.  Memory-bound, off the search kernel's dependent chain.
-	__device__ __forceinline__ float leftBoundaryScore(uint32_t t)      // TagSequenceScorer (src/TagUtils.cpp:49-62) incl. the PA spill (include/kiwi/TagUtils.h:10-18)
-	{
-		if (t == 2 * T_MAX) return 5.f;
-		if (t < T_MAX) return (t == T_NNP || t == T_NP || t == T_IC) ? -1.f : (t == T_SB ? -3.f : 0.f);
-		const uint8_t r = (uint8_t)(t - T_MAX);
-		return (isEClass(r) || isJClass(r) || isSuffixTag(r) || r == T_VCP) ? -1.f : 0.f;
-	}
-	// 0 = not evaluated, 1 = a regular candidate, 2 = z-coda / z-siot shortcut (PathEvaluator.hpp:385-446)
-	__device__ __forceinline__ uint32_t posCandKind(const SearchParams& P, uint32_t flags, uint8_t tag, bool spaceBefore)
-	{
-		if (P.splitComplex && (flags & MF_HAS_COMPLEX)) return 0;
-		if (tag == T_Z_CODA || tag == T_Z_SIOT) return (tag == T_Z_SIOT && !(P.splitSaisiot || P.mergeSaisiot)) ? 0u : 2u;
-		if (!(flags & MF_SINGLE) && (flags & MF_HA_CONTRACTION) && spaceBefore) return 0;
-		return 1;
-	}
 	__global__ void __launch_bounds__(64) k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr)      // useChr: bit 0 = unknown forms are scored by the character model, bit 1 = a CoNgram model
 	{
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t lane = threadIdx.x;
 		const uint32_t chunk = chunkBegin + blockIdx.x;
+		if (W.expanded[chunk]) return;      // (k_lattice_wave wrote the position program itself)
 		const uint32_t nBase = W.nodeBase[chunk];
 		PosDesc* desc = W.posDesc + nBase;
 		if (lane == 0) { desc[0].firstNode = 0; desc[0].nNodes = 0; desc[0].flags = 0; desc[0].firstRec = 0; desc[0].nRec = 0; }      // no positions until the table is complete

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
 #include "feature.hpp"
+#include "lattice_expand.hpp"
 
 namespace kamd
 {
@@ -57,7 +58,7 @@ namespace kamd
 	// hands the chunk to k_build_lattice_big; outCounters[4 + reason] counts (developer statistics, KAMD_LATTICE_STATS)
 #define LW_HAND_OVER(reason) { if (lane == 0) { const bool toWide = !wide && ((reason) == 0 || (reason) == 1 || (reason) == 6); W.nNodes[chunk] = toWide ? kLatticeNeedsWide : kLatticeNeedsBig; \
 		if (toWide) W.wideList[atomicAdd(&W.outCounters[3], 1u)] = chunk; atomicAdd(&W.outCounters[(reason) == 6 ? 4 : 4 + (reason)], 1u); } return; }
-	__global__ void __launch_bounds__(64) k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, uint32_t matchRatio16)
+	__global__ void __launch_bounds__(64) k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, uint32_t matchRatio16, uint32_t expandMode)
 	{
 		using namespace lw;
 		const uint32_t lane = threadIdx.x;
@@ -97,7 +98,7 @@ namespace kamd
 		uint16_t* unkMinT = reinterpret_cast<uint16_t*>(lS + lay.unkMinT); uint16_t* cntU = reinterpret_cast<uint16_t*>(lS + lay.cntU); uint32_t* cntA = reinterpret_cast<uint32_t*>(lS + lay.cntA);
 		uint64_t* succ = reinterpret_cast<uint64_t*>(lS + lay.succ); uint32_t* succw = reinterpret_cast<uint32_t*>(lS + lay.succ);
 		uint16_t* base = reinterpret_cast<uint16_t*>(lS + lay.base); uint32_t* firstU = reinterpret_cast<uint32_t*>(lS + lay.firstU);
-		uint32_t* cc = reinterpret_cast<uint32_t*>(lS + lay.cc); uint32_t* scal = reinterpret_cast<uint32_t*>(lS + lay.scal);
+		uint32_t* cc = reinterpret_cast<uint32_t*>(lS + lay.cc); uint32_t* recOff = reinterpret_cast<uint32_t*>(lS + lay.recOff); uint32_t* scal = reinterpret_cast<uint32_t*>(lS + lay.scal);
 		const uint32_t nPosAll = nNs + 2;      // positions 0 .. nNs, and nNs + 1 for the end node
 
 		// ---- 0. stage the chunk (all lanes, coalesced) and digest the packed matches, one per lane (as k_build_lattice) ----
@@ -635,7 +636,8 @@ namespace kamd
 		LW_MARK(8)
 		LW_STOP(4)
 		// ---- 5. rank of every appended node at its end position; successor masks; the first node of every position ----
-		for (uint32_t i = lane; i < nPosAll; i += 64) { cntA[i] = 0; succ[i] = 0; firstU[i] = 0; }      // (these arrays take over the bytes of the scan's masks and the control words)
+		uint64_t* pred = fd; uint32_t* predw = fdw;      // (the dictionary masks are no longer needed: lengths of the nodes ENDING at a position, for the position program)
+		for (uint32_t i = lane; i < nPosAll; i += 64) { cntA[i] = 0; succ[i] = 0; firstU[i] = 0; pred[i] = 0; }      // (these arrays take over the bytes of the scan's masks and the control words)
 		waveSync();
 		{
 			uint32_t carryE = 0xFFFFFFFFu, carryCnt = 0;
@@ -658,7 +660,7 @@ namespace kamd
 					if (!(opFl[T] & OF_END))
 					{
 						const uint32_t len = e - nb;
-						if (len < 1 || len > 64) hazard = 1; else atomicOr(&succw[2 * nb + ((len - 1) >> 5)], 1u << ((len - 1) & 31));
+						if (len < 1 || len > 64) hazard = 1; else { atomicOr(&succw[2 * nb + ((len - 1) >> 5)], 1u << ((len - 1) & 31)); atomicOr(&predw[2 * e + ((len - 1) >> 5)], 1u << ((len - 1) & 31)); }
 						if (rank == 0) { const uint32_t src = opSrc[T]; firstU[e] = (src & 0x8000u) ? miscU[src & 0x7FFFu] : 0u; }
 					}
 					atomicAdd(&cntA[e], 1u);
@@ -689,7 +691,7 @@ namespace kamd
 					if (!((s4 >> i) & 1)) continue;
 					const uint32_t s = (i & 1) ? ((i & 2) ? (bu >> 16) : (bu & 0xFFFF)) : lp;
 					const uint32_t len = q - s;
-					atomicOr(&succw[2 * s + ((len - 1) >> 5)], 1u << ((len - 1) & 31));
+					atomicOr(&succw[2 * s + ((len - 1) >> 5)], 1u << ((len - 1) & 31)); atomicOr(&predw[2 * q + ((len - 1) >> 5)], 1u << ((len - 1) & 31));
 					if (first) { const uint32_t o = nsToPos[s]; firstU[q] = o | (trimmedLen(str, o, nsToPos[q - 1] + 1u - o) << 16); first = false; }
 				}
 			}
@@ -768,16 +770,144 @@ namespace kamd
 			packTop += __shfl(incl, 63);
 		}
 		waveSync();
+		// ---- 8. (expandMode bit 0) the candidate records and the position program of the position-step search, straight from the lattice in LDS
+		// -- what k_expand_cands and k_expand_pos (lattice_kernels.hip) make of the stored lattice in two more launches.  First every node's
+		// candidates: static records (reference order; CoNgram models: the transposed evaluator's class order) and how many of them are evaluated
+		// at all; the prefix sum is the nodes' record offsets; then the emission below writes a node's records with the node still in registers ----
+		const bool doExpand = (expandMode & 1u) != 0, transposed = (expandMode & 2u) != 0;
+		const uint32_t G = nConn;
+		const uint32_t nUniq = B.spOff[chunk + 1] - B.spOff[chunk];
+		CandStatic* packs = W.packs + W.packBase[chunk];
+		const CandStatic* unkPacks = reinterpret_cast<const CandStatic*>(M.unkPacks);
+		PosRec* recs = doExpand ? W.posRecs + W.packBase[chunk] : nullptr;
+		PosDesc* desc = doExpand ? W.posDesc + nBase : nullptr;
+		uint32_t* posSlow = grpOff; uint32_t* posPass1 = posA; uint32_t* posIdx = posZ;      // (free since the fixpoint ended)
+		bool posOk = doExpand && G > 2 && G <= 0xFFF0u && nUniq + 1 <= 0x1Fu;
+		uint32_t nPos = 0, recTop = 0;
+		auto spaceBeforeOf = [&](uint32_t s0, bool isEnd) -> bool
+		{
+			const uint32_t startStr = isEnd ? n : (uint32_t)nsToPos[s0];
+			return s0 == 0 ? (textOff + startStr > 0) : ((uint32_t)nsToPos[s0 - 1] + 1u < startStr);
+		};
+		if (doExpand)
+		{
+			if (lane == 0) { desc[0].firstNode = 0; desc[0].nNodes = 0; desc[0].flags = 0; desc[0].firstRec = 0; desc[0].nRec = 0; }      // no positions until the table is complete
+			for (uint32_t q = lane; q < nPosAll; q += 64) { posSlow[q] = 0; posPass1[q] = 0; }
+			if (lane == 0) recOff[0] = 0;
+			waveSync();
+			for (uint32_t T = 1 + lane; T <= K; T += 64)
+			{
+				const uint32_t ne = opNE[T], nb = ne & 0xFFFF, e = ne >> 16, fl = opFl[T], ds = decS[T], s4 = ds & 15u, dt = decT[T];
+				if (s4 && keep[nb])
+				{
+					// unknown forms: their two unknown-noun candidates each
+					uint32_t r = base[nb] + cntA[nb] + ((ds >> 8) & 0xFFu);
+					for (uint32_t i = 0; i < 4; ++i) if ((s4 >> i) & 1) recOff[r++] = 2;
+					const uint32_t bu = opBU[T];
+					uint32_t lp = dt >> 16;
+					if ((s4 & 5u) && lp && isHangulCoda(str[nsToPos[lp]])) --lp;
+					for (uint32_t i = 0; i < 4; ++i)
+					{
+						if (!((s4 >> i) & 1)) continue;
+						const uint32_t s0 = (i & 1) ? ((i & 2) ? (bu >> 16) : (bu & 0xFFFF)) : lp;
+						if (s0 && cntA[s0] + cntU[s0] > 256) atomicOr(&posSlow[nb], 1u);      // (more than 256 predecessors: the position is left to the general kernel)
+					}
+				}
+				if ((dt & 1u) && keep[e])
+				{
+					const uint32_t rank = (dt >> 1) & 0x7FFFu, src = opSrc[T], ni = base[e] + rank;
+					if (fl & OF_END) { recOff[ni] = 0; continue; }
+					uint32_t form, fc;
+					if (src & 0x8000u) { form = miscForm[src & 0x7FFFu]; fc = miscFc[src & 0x7FFFu]; } else { form = mforms[src]; fc = mfc[src]; }
+					if (nb && cntA[nb] + cntU[nb] > 256) atomicOr(&posSlow[e], 1u);
+					if (form == NOFORM) { recOff[ni] = 2; continue; }
+					const uint32_t candCnt = fc & 0x7FFFu, candOff = M.forms[form].candOff, pk = cc[ni];
+					const bool spaceBefore = spaceBeforeOf(nb, false);
+					uint32_t cnt = 0, classCnt[5] = { 0, 0, 0, 0, 0 };
+					if (transposed)
+						for (uint32_t k = 0; k < candCnt; ++k) { const MorphRec r = M.morphs[M.formCand[candOff + k]]; ++classCnt[candClassOf(r.tag, r.socket, r.flags)]; }
+					uint32_t classAt[5] = { 0, classCnt[0], classCnt[0] + classCnt[1], classCnt[0] + classCnt[1] + classCnt[2], classCnt[0] + classCnt[1] + classCnt[2] + classCnt[3] };
+					for (uint32_t k = 0; k < candCnt; ++k)
+					{
+						const CandStatic o = candStaticOf(M, M.formCand[candOff + k]);
+						const uint32_t flags = o.m1.y & 0xFFFF; const uint8_t tag = (uint8_t)o.m1.z;
+						const uint32_t at = transposed ? classAt[candClassOf(tag, o.m1.z >> 24, flags)]++ : k;
+						packs[pk + at] = o;
+						if (posCandKind(P, flags, tag, spaceBefore)) ++cnt;
+					}
+					if (cnt == 0) atomicOr(&posSlow[e], 1u);      // nothing to evaluate: the reference then retries without conditions and falls back (PathEvaluator.hpp:468-473, 1286-1299)
+					if ((fc & 0x8000u) && rank < 16) atomicOr(&posPass1[e], 1u << rank);
+					recOff[ni] = cnt + ((fc & 0x8000u) ? 1u : 0u);
+				}
+			}
+			waveSync();
+			for (uint32_t b0 = 0; b0 < G; b0 += 64)
+			{
+				const uint32_t i = b0 + lane;
+				const uint32_t c = i < G ? recOff[i] : 0u;
+				uint32_t incl = c;
+				for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+				if (i < G) recOff[i] = recTop + incl - c;
+				recTop += __shfl(incl, 63);
+			}
+			// the end positions that hold nodes, numbered from 1 (the start node is position 0; the end node is none)
+			for (uint32_t b0 = 0; b0 < nPosAll; b0 += 64)
+			{
+				const uint32_t q = b0 + lane;
+				const bool has = q >= 1 && q <= nNs && keep[q] && cntA[q] + cntU[q] > 0;
+				const uint64_t hb = __ballot(has);
+				if (q < nPosAll) posIdx[q] = has ? nPos + 1u + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull)) : 0u;
+				nPos += (uint32_t)__popcll(hb);
+			}
+			const uint32_t recCap = W.packBase[chunk + 1] - W.packBase[chunk];
+			if (recTop > recCap || recTop >= 0x3FFFFu || nPos >= 0x1FFFu) posOk = false;      // (uniform) the records do not fit the chunk's region / the packed fields: the general kernel takes the chunk
+			waveSync();
+			if (posOk)
+			{
+				uint32_t* posMask = W.posMask + nBase;
+				bool overAny = false;
+				for (uint32_t q = 1 + lane; q <= nNs; q += 64)
+				{
+					const uint32_t p = posIdx[q];
+					if (!p) continue;
+					const uint32_t n0 = base[q], nN = cntA[q] + cntU[q], r0 = recOff[n0], r1 = n0 + nN < G ? recOff[n0 + nN] : recTop;
+					const bool slow = nN > 16 || r1 - r0 > 16 || r1 == r0 || posSlow[q] != 0;
+					// the distinct start positions of the position's nodes, four bytes; more than four, or a chunk of more than 255 positions: no propagation for this chunk
+					uint32_t st4[4] = { 0, 0, 0, 0 }, nSt = 0; bool over = nPos > 255;
+					for (uint64_t m = pred[q]; m && !over; m &= m - 1)
+					{
+						const uint32_t len = (uint32_t)__ffsll((unsigned long long)m), sp = posIdx[q - len];
+						if (nSt == 4) { over = true; break; }
+						st4[nSt++] = sp;
+					}
+					for (uint32_t t = nSt; t < 4; ++t) st4[t] = st4[0];
+					posMask[p] = over ? 0xFFFFFFFFu : (st4[0] | (st4[1] << 8) | (st4[2] << 16) | (st4[3] << 24));
+					overAny = overAny || over;
+					// bit j: node j of the position has no dictionary form -- its unknown-form nodes, which follow the others
+					const uint32_t a = cntA[q], tot = nN < 16 ? nN : 16u;
+					const uint32_t formless = a < 16 ? (((1u << tot) - 1u) & ~((1u << a) - 1u)) : 0u;
+					PosDesc d;
+					d.firstNode = (uint16_t)n0; d.nNodes = (uint8_t)(nN > 255 ? 255 : nN); d.flags = slow ? (uint8_t)POSF_SLOW : (uint8_t)0;
+					d.firstRec = r0; d.nRec = (uint16_t)(r1 - r0 > 0xFFFF ? 0xFFFF : r1 - r0); d.pad = (uint16_t)formless; d.pad2 = posPass1[q];
+					desc[p] = d;
+				}
+				if (__ballot(overAny) && lane == 0) desc[0].nNodes = 1;
+				if (lane == 0)
+				{
+					PosDesc d; d.firstNode = (uint16_t)(G - 1); d.nNodes = 0; d.flags = 0; d.firstRec = recTop; d.nRec = 0; d.pad = 0; d.pad2 = 0;
+					desc[nPos + 1] = d;
+					desc[0].pad2 = posIdx[nNs];      // where the end node's predecessors end: reachable <=> the lattice is connected
+				}
+			}
+		}
 		auto emitNode = [&](uint32_t ni, uint32_t s, uint32_t t, uint32_t form, uint32_t fc, uint32_t uOff, uint32_t uLen, uint32_t se, uint32_t rankAt, bool isEnd)
 		{
 			DevNode nn;
 			nn.form = form; nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.spaceErrors = (uint8_t)(se > 255 ? 255 : se);
 			nn.ownFeat = 0; nn.pad = 0; nn.packOff = cc[ni];
-			const uint32_t startStr = isEnd ? n : (uint32_t)nsToPos[s];
 			const bool pnBos = s == 0;
-			const uint32_t pnEndStr = pnBos ? 0u : (uint32_t)nsToPos[s - 1] + 1u;
 			// the reference compares absolute text offsets; the start node's end is 0 (PathEvaluator.hpp:24-31, 436, 568)
-			const bool spaceBefore = pnBos ? (textOff + startStr > 0) : (pnEndStr < startStr);
+			const bool spaceBefore = spaceBeforeOf(s, isEnd);
 			bool lb = pnBos || spaceBefore;
 			const uint32_t pu = firstU[s];
 			if (!lb && (pu >> 16))
@@ -810,6 +940,94 @@ namespace kamd
 			if (isEnd) nn.startPos = nn.endPos = (uint16_t)n;
 			else { nn.startPos = nsToPos[s]; nn.endPos = (uint16_t)(nsToPos[t - 1] + 1); }
 			fin[ni] = nn;
+			if (!posOk || isEnd) return;
+			// the node's entry of the per-node predecessor table and its records (k_expand_pos pass B' and C; PathEvaluator.hpp:366-383, 1204-1318)
+			{
+				const uint32_t np1 = (uint32_t)nn.nPrev - 1u, sp = posIdx[s];
+				(W.posPrev + nBase)[ni] = base[s] | ((np1 > 255u ? 255u : np1) << 16) | ((sp > 255u ? 255u : sp) << 24);
+			}
+			const uint32_t nl = rankAt;      // the node's index inside its position
+			if (nl >= 16) return;          // (its position is marked slow)
+			PosRec* out = recs + recOff[ni];
+			float ws = 0;
+			if (!nn.uformLen && nn.form != NOFORM && nn.flen && nn.spaceErrors) ws = -P.spacePenalty * (float)nn.spaceErrors;
+			const float baseDiscount = ws + (-0.f * P.typoCostWeight);      // whitespaceDiscount + typoDiscount (no typo costs on this path)
+			const uint8_t ownKind0 = nn.uformLen ? 1 : 0;
+			auto emit = [&](const CandStatic* cs, float disc, uint8_t ownKind, uint16_t ownFeat, uint32_t extra)
+			{
+				const uint4* q4 = reinterpret_cast<const uint4*>(cs);
+				const uint4 m0 = q4[0], m1 = q4[1], mx = q4[2];
+				const uint8_t tag = (uint8_t)m1.z, special = (uint8_t)(m1.w >> 24);
+				const uint32_t sbType = mx.z;
+				const bool quote = special == 0 || special == 1 || special == 3 || special == 4;
+				const uint32_t R = ((sbType || quote) && nUniq > 1) ? nUniq : 1u;
+				PosRec r;
+				r.firstWid = mx.y; r.secondWid = mx.w; r.chunkOff = m0.z; r.lastSeqId = m0.y;
+				r.morph = mx.x; r.flagsFeat = m1.y; r.tagw = m1.z; r.cntw = m1.w;
+				r.additional = __uint_as_float(m0.w) + disc + leftBoundaryScore(((nn.nflags & NF_LEFT_BOUNDARY) ? T_MAX : 0) + clearIrregular(tag)) * 5.f;
+				const uint32_t ruleBits = ((isEClass(tag) && (nn.fflags & FF_STARTS_WITH_A)) ? 1u : 0u) | ((tag == T_SN && (nn.nflags & NF_UFORM_ENDS_POINT)) ? 2u : 0u);
+				r.nodeOwn = ni | ((uint32_t)ownFeat << 16);
+				r.bits = (sbType & 0xFF) | (ruleBits << 8) | ((uint32_t)ownKind << 16) | ((uint32_t)nn.nflags << 24);
+				r.rq = R | (nl << 8) | extra;
+				*out++ = r;
+			};
+			// CoNgram: do the regular candidates of one evaluation share their first word?  (decides which of the reference's kernels rounds their scores)
+			auto sharedFirstWord = [&](const CandStatic* cl, uint32_t nc) -> uint32_t
+			{
+				if (!transposed) return 0u;      // (only the CoNgram kernels read the flag)
+				uint32_t nReg = 0, ref = 0; bool one = true;
+				for (uint32_t k = 0; k < nc; ++k)
+				{
+					const uint4* q4 = reinterpret_cast<const uint4*>(cl + k);
+					const uint4 m1 = q4[1], mx = q4[2];
+					const uint32_t flags = m1.y & 0xFFFF; const uint8_t tag = (uint8_t)m1.z, sock = (uint8_t)(m1.z >> 24);
+					if (posCandKind(P, flags, tag, spaceBefore) != 1 || sock || (flags & MF_FIRST_WID_IS_P)) continue;
+					if (!nReg) ref = mx.y; else if (mx.y != ref) one = false;
+					++nReg;
+				}
+				return (nReg && one) ? (uint32_t)PR_OUT_FIRST : 0u;
+			};
+			if (nn.form != NOFORM)
+			{
+				const CandStatic* cl = packs + nn.packOff;      // (this lane's own stores of a moment ago)
+				const uint32_t of0 = sharedFirstWord(cl, nn.candCnt);
+				for (uint32_t k = 0; k < nn.candCnt; ++k)
+				{
+					const uint4 m1 = reinterpret_cast<const uint4*>(cl + k)[1];
+					const uint32_t kind = posCandKind(P, m1.y & 0xFFFF, (uint8_t)m1.z, spaceBefore);
+					if (kind == 1) emit(cl + k, baseDiscount + 0.f, ownKind0, nn.ownFeat, of0);
+					else if (kind == 2)
+					{
+						// z-coda / z-siot shortcut (PathEvaluator.hpp:389-432): the record carries the morpheme put on, the shortcut's tag and score, and what a path ending in the new morpheme exposes
+						const MorphRec cm = M.morphs[reinterpret_cast<const uint4*>(cl + k)[2].x];
+						const MorphRec nm = M.morphs[cm.lmId];
+						PosRec r;
+						r.firstWid = cm.lmId; r.secondWid = cm.tag; r.chunkOff = (uint32_t)nm.feat | ((uint32_t)nm.prevFlags << 16) | (nm.socket ? 1u << 24 : 0u); r.lastSeqId = 0;
+						r.morph = cm.lmId; r.flagsFeat = 0; r.tagw = 0; r.cntw = 0;
+						r.additional = cm.userScore;
+						r.nodeOwn = ni; r.bits = (uint32_t)nn.nflags << 24; r.rq = 1u | (nl << 8) | (uint32_t)PR_Z;
+						*out++ = r;
+					}
+				}
+				if (nn.nflags & NF_ALL_PARTIAL)
+				{
+					// the form read as an unknown proper noun (PathEvaluator.hpp:1277-1287): own form = the dictionary form's string
+					const FormRec f = M.forms[nn.form];
+					uint16_t of = featMaskFast(M.formChars + f.charOff, f.len) & 0x1FFF;
+					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
+					const float disc = baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias);
+					emit(unkPacks + 1, disc, 2, of, (uint32_t)PR_PASS1 | sharedFirstWord(unkPacks + 1, 1));
+				}
+			}
+			else
+			{
+				// unknown form: the two unknown-noun candidates (PathEvaluator.hpp:1204-1206, 1300-1318), scored by UnkFormScorer (src/UnkFormScorer.h:40-58)
+				const float emo = (cls[nn.uformOff] & 0x80) ? -10.f : 0.f;
+				const float disc = baseDiscount + (emo - ((float)nn.uformLen * P.oovRuleScale + P.oovRuleBias));
+				const uint32_t of0 = sharedFirstWord(unkPacks, 2);
+				emit(unkPacks, disc, ownKind0, nn.ownFeat, of0);
+				emit(unkPacks + 1, disc, ownKind0, nn.ownFeat, of0);
+			}
 		};
 		if (lane == 0)
 		{
@@ -842,6 +1060,11 @@ namespace kamd
 				else { form = mforms[src]; fc = mfc[src]; se = mse[src]; }
 				emitNode(base[e] + rank, nb, e, form, fc, uOff, uLen, se, rank, (fl & OF_END) != 0);
 			}
+		}
+		if (doExpand)
+		{
+			waveSync();
+			if (lane == 0) { if (posOk) desc[0].firstRec = nPos; W.expanded[chunk] = 1; }
 		}
 		LW_MARK(12)
 		if (lane == 0)
