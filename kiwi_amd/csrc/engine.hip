@@ -178,7 +178,7 @@ namespace kamd
 		PinBuf hIn; DevBuf dIn;   // the batch's input block (layoutAndUpload)
 		DevBuf dFullMask, dZAt, dNsToPos, dPosToNs, dCflag, dMask, dMoff, dNNs, dMatchForm, dNodes, dTmpNodes, dEndPosMap, dTmpIdx, dNNodes, dWideList, dExpanded;
 		// LDS size classes of the lattice kernel per sub-batch {first, end, bytes}, first = the chunks beyond the budget; made once per (batch, match ratio, kernel)
-		struct LatClass { uint32_t i, j, need; };
+		struct LatClass { uint32_t i, j, need, stream; };
 		std::vector<std::vector<LatClass>> latClasses; std::vector<uint32_t> latSkip; uint32_t latClassesKey = 0xFFFFFFFFu;
 		DevBuf dHist;   // SkipBigram models: history ring of every search state (8 x u32), parallel to dStates
 		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
@@ -211,8 +211,8 @@ namespace kamd
 		ModelView dview{};
 		std::vector<std::unique_ptr<DevBuf>> modelBufs;
 		hipStream_t stream = nullptr, stream2 = nullptr;   // lattice stages / search stage (sub-batches overlap)
-		hipStream_t latStream[2] = { nullptr, nullptr };   // the lattice kernel's LDS size classes are launched round-robin over `stream` and these: their tails overlap
-		hipEvent_t latFork = nullptr, latJoin[2] = { nullptr, nullptr };
+		hipStream_t latStream[3] = { nullptr, nullptr, nullptr };   // the lattice kernel's LDS size classes are launched round-robin over `stream` and these: their tails overlap
+		hipEvent_t latFork = nullptr, latJoin[3] = { nullptr, nullptr, nullptr };
 		std::vector<hipEvent_t> evs;
 		int subBatches = 0;   // 0 = automatic
 		int device = 0;
@@ -793,9 +793,16 @@ namespace kamd
 						const uint32_t need = needOf(b.order[i]);
 						uint32_t j = i + 1;
 						while (j < c1 && (uint64_t)needOf(b.order[j]) * 4 >= (uint64_t)need * 3) ++j;      // <= 25 % of a class's LDS unused
-						b.latClasses[k].push_back({ i, j, need });
+						b.latClasses[k].push_back({ i, j, need, 0u });
 						i = j;
 					}
+					// which of the four streams a class is launched on: largest first onto the least loaded (cost ~ chunks x LDS bytes: the classes are LDS-occupancy bound)
+					std::vector<size_t> byCost(b.latClasses[k].size());
+					std::iota(byCost.begin(), byCost.end(), (size_t)0);
+					auto cost = [&](size_t t) { const auto& c = b.latClasses[k][t]; return (uint64_t)(c.j - c.i) * c.need; };
+					std::stable_sort(byCost.begin(), byCost.end(), [&](size_t x, size_t y) { return cost(x) > cost(y); });
+					uint64_t load[4] = { 0, 0, 0, 0 };
+					for (size_t t : byCost) { const uint32_t st = (uint32_t)(std::min_element(load, load + 4) - load); b.latClasses[k][t].stream = st; load[st] += cost(t); }
 				}
 				b.latClassesKey = classesKey;
 			}
@@ -848,7 +855,7 @@ namespace kamd
 				const uint32_t expandMode = (fuseExpand && posEarly && !b.wv.unkChr && !b.wv.blockBits) ? (1u | (I.hasCong ? 2u : 0u)) : 0u;
 				if (getenv("KAMD_LATTICE_PROFILE")) { lwProf.ensure((size_t)nC * 64); HIPCHECK(hipMemsetAsync(lwProf.p, 0, (size_t)nC * 64, sA)); b.wv.beacon = lwProf.as<uint32_t>(); }
 				const uint32_t budget = wave ? I.latticeWaveBudget : I.latticeLdsBudget;
-				// the size classes of k_lattice_wave go round-robin over three streams (forked from and joined back into sA): a class ends when its slowest
+				// the size classes of k_lattice_wave go over four streams (forked from and joined back into sA; which one: decided with the classes): a class ends when its slowest
 				// wavefront does, and the next class's wavefronts fill the machine meanwhile
 				uint32_t nClass = 0;
 				if (wave) { HIPCHECK(hipEventRecord(I.latFork, sA)); for (auto ls : I.latStream) HIPCHECK(hipStreamWaitEvent(ls, I.latFork, 0)); }
@@ -861,13 +868,13 @@ namespace kamd
 					// quarter of the wavefronts to hide their LDS chains
 					const uint32_t need16 = (need + 15u) & ~15u;
 					const bool four = I.latticeGroupForced == 16 && need16 * 4 <= 64 * 1024;
-					hipStream_t sL = wave ? (nClass % 3 == 0 ? sA : I.latStream[nClass % 3 - 1]) : sA;
+					hipStream_t sL = (wave && lc.stream) ? I.latStream[lc.stream - 1] : sA;
 					++nClass;
 					if (wave) hipLaunchKernelGGL(k_lattice_wave, dim3(j - i), dim3(64), need, sL, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24), ratio16, expandMode);
 					else if (four) hipLaunchKernelGGL(k_build_lattice<16>, dim3((j - i + 3) / 4), dim3(64), need16 * 4, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need16 | (dbgStop << 24));
 					else hipLaunchKernelGGL(k_build_lattice<64>, dim3(j - i), dim3(64), need, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + i, j - i, need | (dbgStop << 24));
 				}
-				if (wave) for (int t = 0; t < 2; ++t) { HIPCHECK(hipEventRecord(I.latJoin[t], I.latStream[t])); HIPCHECK(hipStreamWaitEvent(sA, I.latJoin[t], 0)); }
+				if (wave) for (int t = 0; t < 3; ++t) { HIPCHECK(hipEventRecord(I.latJoin[t], I.latStream[t])); HIPCHECK(hipStreamWaitEvent(sA, I.latJoin[t], 0)); }
 				// what outgrew the first launch's LDS arrays: the same kernel with room for 3 matches and one other op per text unit, over the list the first launch left
 				if (wave && budget) hipLaunchKernelGGL(k_lattice_wave, dim3(std::min(cn, 1024u)), dim3(64), budget, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + c0, std::min(cn, 1024u), budget, kLatticeWideRatio16 | kLatticeWideBit | (ratio16 & 0x4000u), expandMode);
 				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, budget, wave ? (ratio16 & 0x3FFFu) : 0u);
