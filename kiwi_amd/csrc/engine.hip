@@ -226,6 +226,7 @@ namespace kamd
 		uint32_t latticeWaveBudget = 128 * 1024; // ... and k_lattice_wave, which is allowed beyond the default 64 KB limit (a 400-unit chunk needs ~70 KB; the CU has 160 KB)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
+		bool posPathForced = false;      // KAMD_POS_PATH=2: also for typo correction (slower there: see launchAll)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter, posScratch;
 		uint32_t posContSlots = 256;     // chunks per launch that k_pos_path carries on in the general search itself (KAMD_POS_CONT=0: none, all left to k_best_path)
@@ -366,7 +367,7 @@ namespace kamd
 			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16, 32 or 64" };
 		}
 		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2 or 3" }; }
-		if (const char* pp = std::getenv("KAMD_POS_PATH")) impl->posPath = std::atoi(pp) != 0;
+		if (const char* pp = std::getenv("KAMD_POS_PATH")) { impl->posPath = std::atoi(pp) != 0; impl->posPathForced = std::atoi(pp) == 2; }
 		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
 		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
 		if (const char* lw = std::getenv("KAMD_LATTICE_WAVE")) impl->latticeWave = std::atoi(lw) != 0;
@@ -851,7 +852,7 @@ namespace kamd
 				// for the position-step search without a blocklist and without character-model scores of unknown forms (k_unk_chr sits between the two);
 				// bit 1: a CoNgram model (records in the transposed evaluator's order).  KAMD_LATTICE_EXPAND=0: the two kernels do it
 				static const bool fuseExpand = !(getenv("KAMD_LATTICE_EXPAND") && std::atoi(getenv("KAMD_LATTICE_EXPAND")) == 0);
-				const bool posEarly = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8;
+				const bool posEarly = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8 && (!b.typo.typo || I.posPathForced);
 				const uint32_t expandMode = (fuseExpand && posEarly && !b.wv.unkChr && !b.wv.blockBits) ? (1u | (I.hasCong ? 2u : 0u)) : 0u;
 				if (getenv("KAMD_LATTICE_PROFILE")) { lwProf.ensure((size_t)nC * 64); HIPCHECK(hipMemsetAsync(lwProf.p, 0, (size_t)nC * 64, sA)); b.wv.beacon = lwProf.as<uint32_t>(); }
 				const uint32_t budget = wave ? I.latticeWaveBudget : I.latticeLdsBudget;
@@ -884,7 +885,9 @@ namespace kamd
 			if (b.wv.unkChr)      // Match::oovChrModel: every node's unknown form scored by the character model, once, before the search
 				hipLaunchKernelGGL(k_unk_chr, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, I.chr, c0, cn, chrToken(0xD800, identifySpecialChr(0xD800)), chrToken(0xDC00, identifySpecialChr(0xDC00)));
 			// position-step search first (viterbi_pos.inc): top-1, 16-lane groups, not for SkipBigram models; what it cannot finish is resumed by the general kernel below
-			const bool usePos = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8;      // (per-sub-batch counters: 8 of each)
+			// (not for typo correction unless asked for: the lattices over typo graphs hold positions the step kernel leaves to the general one -- MI355X, c5:
+			// search 3.97 ms with the position steps, 2.25 ms without, profiles/r04_j_c5_pos_path.txt; KAMD_POS_PATH=2 forces it, as the parity suites do)
+			const bool usePos = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8 && (!b.typo.typo || I.posPathForced);      // (per-sub-batch counters: 8 of each)
 			if (usePos)
 				hipLaunchKernelGGL(k_expand_pos, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, b.typo.typo ? b.dNodeTypo.as<float>() : (const float*)nullptr, ((I.hasCong && b.wv.unkChr) ? 1u : 0u) | (I.hasCong ? 2u : 0u));      // (bit 0: unknown forms scored by the character model; bit 1: a CoNgram model)
 			HIPCHECK(hipEventRecord(e[2], sA));

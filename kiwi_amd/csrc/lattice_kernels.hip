@@ -91,7 +91,12 @@ namespace kamd
 		for (uint32_t e = lane; e <= nNs; e += 64) mask[e] = 0;
 		waveSync();
 
-		// ---- 2. trie walk, pass 1: mark terminals ------------------------------------------------------
+		// ---- 2. trie walk, pass 1: mark terminals.  A start position's first three terminals are remembered (form, end position, depth) so that the
+		// second pass need not walk the trie again; a start with more of them -- or a form id beyond 24 bits -- is walked twice as before ----
+		constexpr uint32_t KEEP = 3;
+		uint32_t kForm[KEEP], kEnd[KEEP];      // (end position | depth << 16)
+		uint32_t nKept = 0; bool rewalk = false;
+		const bool oneBlock = nNs <= 64;      // (the remembered terminals belong to one start position per lane)
 		for (uint32_t base = 0; base < nNs; base += 64)
 		{
 			const uint32_t s = base + lane;
@@ -105,7 +110,16 @@ namespace kamd
 				node = trieChild(M, node, str[p]);
 				if (!node) break;
 				++depth;
-				if (M.trie[node].value >= 0) atomicOr((unsigned long long*)&mask[i + 1], 1ull << (depth - 1));
+				const int32_t v = M.trie[node].value;
+				if (v >= 0)
+				{
+					atomicOr((unsigned long long*)&mask[i + 1], 1ull << (depth - 1));
+					if (oneBlock)
+					{
+						if (nKept < KEEP && (uint32_t)v < (1u << 24) && depth < 64) { kForm[nKept] = (uint32_t)v; kEnd[nKept] = (i + 1) | (depth << 16); ++nKept; }
+						else rewalk = true;
+					}
+				}
 			}
 		}
 		waveSync();
@@ -135,6 +149,15 @@ namespace kamd
 
 		// ---- 4. pass 2: fill packed form lists, longest form first within an end position -------------
 		uint32_t* forms = W.matchForm + mBase;
+		if (oneBlock && !rewalk)
+		{
+			for (uint32_t t = 0; t < nKept; ++t)
+			{
+				const uint32_t e = kEnd[t] & 0xFFFFu, depth = kEnd[t] >> 16;
+				forms[moff[e] + (uint32_t)__popcll(mask[e] >> depth)] = kForm[t];      // forms longer than this one come first
+			}
+		}
+		else
 		for (uint32_t base = 0; base < nNs; base += 64)
 		{
 			const uint32_t s = base + lane;

@@ -110,5 +110,7 @@ def force_lanes(monkeypatch, lanes):
     choice in place -- top-1 searches then run the position-step kernel k_pos_path first (KAMD_WPS=3 selects its three-waves build)."""
     if lanes == "pos":
         monkeypatch.delenv("KAMD_GROUP_LANES", raising=False)
+        monkeypatch.setenv("KAMD_POS_PATH", "2")      # (also for typo correction, where the engine's own choice is the general kernel)
     else:
         monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+        monkeypatch.delenv("KAMD_POS_PATH", raising=False)

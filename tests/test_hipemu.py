@@ -275,7 +275,7 @@ def test_emulated_kernels_have_no_cross_lane_data_races(kind):
 def test_race_detector_sees_a_dropped_wave_barrier():
     """Self-test of the above: with the wave barriers of one kernel turned into nothing (HIPEMU_TEST_DROP_WAVE_BARRIER) the same run
     must report races (what the kernel then computes, or whether it survives, does not matter)."""
-    r = _tsan_run("knlm", {"HIPEMU_TEST_DROP_WAVE_BARRIER": "k_build_lattice"})
+    r = _tsan_run("knlm", {"HIPEMU_TEST_DROP_WAVE_BARRIER": "k_lattice_wave"})      # (the lattice kernel the engine runs by default: its phases exchange everything through LDS)
     assert "ThreadSanitizer: data race" in r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
 
 
