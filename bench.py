@@ -187,6 +187,8 @@ def side_measurement(eng, workload, steps=20, limit=0, min_seconds=0.0):
     typo_cfg, typo = workload_typo(workload), None
     if typo_cfg is not None:
         typo = Typo(eng.lib, typo_cfg[0], typo_cfg[1]); fill_typo_rules(typo); typo.prepare(True)
+    if len(texts) > 4096 and typo is None:
+        eng.analyze_batch(texts[:4096], top_n=top_n).close()      # (untimed sample batch: the engine's capacities follow what its model needs)
     batch = eng.stage(texts) if typo is None else eng.stage(texts, typo=typo, typo_threshold=typo_cfg[2])
     if top_n > 1:
         eng.fetch(batch, top_n).close()
@@ -290,6 +292,10 @@ def main():
         typo = Typo(eng.lib, typo_cfg[0], typo_cfg[1])
         fill_typo_rules(typo)
         typo.prepare(True)
+    # one untimed sample batch first: the engine sizes its LDS arrays and state arenas by what the model's dictionary and search produced in the batches
+    # before (matches per text unit, states per chunk) -- a fresh engine starts from worst-case capacities
+    if len(shard) > 4096 and typo is None:
+        eng.analyze_batch(shard[:4096], top_n=top_n).close()
     batch = eng.stage(shard) if typo is None else eng.stage(shard, typo=typo, typo_threshold=typo_cfg[2])
     info = batch.info()
     if top_n > 1:

@@ -222,6 +222,10 @@ namespace kamd
 		// LDS room of k_lattice_wave for packed matches, sixteenths per text unit: follows what the model's dictionary produced in the batches so far
 		// (read back with every batch's counters); the first batch assumes 3 per unit, a chunk beyond the room goes to the wide launch (KAMD_LATTICE_RATIO fixes it)
 		uint32_t latticeRatio16 = kLatticeWideRatio16; bool latticeRatioForced = false;
+		// state arenas: sixteenths of the worst-case capacity (48 states per text unit + 256; SkipBigram models x 8) a chunk's region gets.  Follows what the
+		// chunks of the batches so far needed (x 2, read from the downloaded per-chunk results); a batch in which a chunk ran out goes back to the full
+		// capacity (the capacity ladder inside run() has searched that chunk again meanwhile).  KAMD_STATE_SCALE=<sixteenths> fixes it
+		uint32_t stateScale16[2] = { 16, 0 }; bool stateScaleForced = false;      // [needed by top-1 batches, by top-N batches (0: none seen yet)]; a region gets the larger of the two (a batch is laid out before its top-N is known)
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
 		uint32_t latticeWaveBudget = 128 * 1024; // ... and k_lattice_wave, which is allowed beyond the default 64 KB limit (a 400-unit chunk needs ~70 KB; the CU has 160 KB)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
@@ -371,6 +375,7 @@ namespace kamd
 		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
 		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
 		if (const char* lw = std::getenv("KAMD_LATTICE_WAVE")) impl->latticeWave = std::atoi(lw) != 0;
+		if (const char* ss = std::getenv("KAMD_STATE_SCALE")) { impl->stateScale16[0] = impl->stateScale16[1] = (uint32_t)std::min(16, std::max(1, std::atoi(ss))); impl->stateScaleForced = true; }
 		if (const char* lr = std::getenv("KAMD_LATTICE_RATIO")) { impl->latticeRatio16 = (uint32_t)std::min(4096, std::max(4, std::atoi(lr))); impl->latticeRatioForced = true; }
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) { impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l))); impl->latticeWaveBudget = (uint32_t)std::min(128 * 1024, std::max(0, std::atoi(l))); }
 		if (impl->latticeWaveBudget > 64 * 1024) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lattice_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)impl->latticeWaveBudget));
@@ -432,6 +437,7 @@ namespace kamd
 			uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
 			// SkipBigram states carry their history ring in the container key: far fewer paths merge, a node keeps hundreds to thousands of them
 			if (I.hasSbg) scap *= 8;
+			if (sc == 1 && !tinyArenas) scap = std::max<uint64_t>(scap * std::max(I.stateScale16[0], I.stateScale16[1]) / 16, 64);      // (what the batches so far needed; a re-run at a higher rung takes the whole capacity)
 			if (b.typo.typo) ncap = std::min<uint64_t>(2 * ncap, 0xFFE0);      // lattices over typo graphs come out about twice as large
 			if (tinyArenas)   // test hook (KAMD_TEST_TINY_ARENAS): regions far too small at scale 1, so that the overflow -> re-run ladder is exercised
 			{
@@ -1396,6 +1402,20 @@ namespace kamd
 		HostTimer tm{ "fetch" };
 		download(*impl, b);
 		tm.lap("download");
+		if (!impl->stateScaleForced && b.capScale == 1 && b.refs.size() >= 64 && !std::getenv("KAMD_TEST_TINY_ARENAS"))
+		{
+			// how much of the worst-case state capacity the chunks of this batch used (states + the end candidates and the back-trace chain behind them)
+			uint64_t need16 = 1;
+			for (size_t c = 0; c < b.refs.size(); ++c)
+			{
+				const DevChunkResult& r = b.hResults[c];
+				if (r.status >= 16) continue;
+				const uint64_t full = (48ull * (b.charOff[c + 1] - b.charOff[c]) + 256) * (impl->hasSbg ? 8 : 1);
+				const uint64_t used = (uint64_t)r.endOff + r.nEnd / 2 + (b.nodeBase[c + 1] - b.nodeBase[c]) / 12 + 16;
+				need16 = std::max(need16, (used * 16 + full - 1) / full);
+			}
+			impl->stateScale16[b.topN > 1 ? 1 : 0] = b.rerunChunks ? 16u : (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, need16 * 2));
+		}
 		const size_t nT = b.prep.size();
 		BatchResults ret;
 		ret.nTexts = nT; ret.d2hBytes = b.outBytes;

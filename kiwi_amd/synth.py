@@ -248,13 +248,18 @@ class _Lex:
     def __init__(self):
         self.items: dict[str, list[int]] = {}
         self.cum: dict[str, np.ndarray] = {}
+        self.rare: set[int] = set()          # morphemes whose weight is scaled down (SynthSpec.homonym_skew)
 
     def add(self, cls: str, mid: int):
         self.items.setdefault(cls, []).append(mid)
 
-    def finalize(self):
+    def finalize(self, skew: float = 0.0):
         for k, v in self.items.items():
-            self.cum[k] = np.cumsum(_zipf_weights(len(v)))
+            w = _zipf_weights(len(v))
+            if skew > 0 and self.rare:
+                w = w * np.where(np.fromiter((m in self.rare for m in v), bool, len(v)), np.exp(-skew), 1.0)
+                w = w / w.sum()
+            self.cum[k] = np.cumsum(w)
 
     def sample(self, cls: str, rng) -> int:
         v = self.items[cls]
@@ -313,6 +318,14 @@ class SynthSpec:
     n_complex: int = 150
     n_spaced: int = 60           # forms containing a space
     homonym_rate: float = 0.12
+    # > 0: a homonym added to an existing surface form is sampled e^-skew times as often as its Zipf rank says (language-model corpus and test corpora
+    # alike).  Homonyms of one class at neighbouring ranks score within a fraction of a nat of each other, which a SkipBigram search -- whose paths do
+    # not merge for eight words -- turns into 2^k paths per node (86 x the states of the Knlm search on the 'full' lexicon, `_data/sbg_probe.py`); in a
+    # real model one reading of a homograph dominates in a given context
+    homonym_skew: float = 0.0
+    # > 0: that share of the nouns of the language-model corpus is replaced by the default NNG morpheme (an out-of-vocabulary noun as the search
+    # records it), a tenth of it by the default NNP one: the two unknown-noun readings of an unknown form then differ by ~ ln 10 instead of tying
+    lm_unk_rate: float = 0.0
     lm_sentences: int = 20000
     lm_order: int = 3
     use_htx: bool = False
@@ -334,7 +347,8 @@ class SynthSpec:
 FULL_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
                       n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3)  # order 3: build_knlm packs an n-gram into 63 bits
 FULL_SBG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
-                          n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_sbg=True)   # FULL_SPEC + skip-bigram tables (32-bit keys)
+                          n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_sbg=True,   # FULL_SPEC's lexicon + skip-bigram tables (32-bit keys)
+                          homonym_skew=4.0, lm_unk_rate=0.03)      # round 4: one reading of a homograph dominates, unknown NNG / NNP readings differ (a SkipBigram search needs both to prune: see the fields)
 SMALL_SPEC = SynthSpec()
 SMALL_Q8_SPEC = SynthSpec(knlm_qbits=8, knlm_compress=True)   # SMALL_SPEC with the Knlm file as the reference ships it: 8-bit quantised, node sizes compressed
 SMALL_Q5_SPEC = SynthSpec(knlm_qbits=5)                       # ... and a bit width that exercises the generic fixed-length bit stream
@@ -407,10 +421,13 @@ class SynthModel:
         existing: list[str] = []
         for _ in range(sp.n_words):
             tag = int(r.choice(open_tags, p=open_p))
+            homonym = False
             if existing and r.random() < sp.homonym_rate:
                 s = existing[int(r.integers(0, len(existing)))]
                 if any(raw.morphs[m].tag == tag for m in raw.form_cands[raw.form_map[s]]):
                     s = self._new_word()
+                else:
+                    homonym = True
             else:
                 s = self._new_word()
             kw = {}
@@ -421,6 +438,8 @@ class SynthModel:
             mid = raw.add_morph(s, tag, **kw)
             existing.append(s)
             lex.add(cls_of[tag], mid)
+            if homonym:
+                lex.rare.add(mid)
 
         # affixes
         for tag, n, cls in ((XPN, 6, "xpn"), (XSN, 14, "xsn"), (XSV, 4, "xsv"), (XSA, 4, "xsa"), (XSM, 3, "xsm")):
@@ -588,7 +607,7 @@ class SynthModel:
             self._add_combined(surf, [v, e], [(0, min(k + 1, len(surf))), (k, len(surf))], socket=0,
                                vowel=CV_NONE, score=float(np.float32(r.choice([0.0, -0.5, -1.0]))))
             self.contract[(v, e)] = [surf]
-        lex.finalize()
+        lex.finalize(sp.homonym_skew)
         self.base_end = base_end
 
     def _add_combined(self, surf, chunks, pos, socket, vowel, score):
@@ -723,9 +742,18 @@ class SynthModel:
         rng = np.random.default_rng(sp.seed + 1)
         sents = []
         sf_id = SF + 1
+        noun_ids = set(self.lex.items.get("noun", ())) if sp.lm_unk_rate > 0 else set()
+        urng = np.random.default_rng(sp.seed + 11)
         for _ in range(sp.lm_sentences):
             lm, _ = self.sample_sentence(rng)
-            sents.append([0] + [self._lmid(m) for m in lm] + [sf_id, 1])
+            ids = [self._lmid(m) for m in lm]
+            if noun_ids:
+                for k, m in enumerate(lm):
+                    if m in noun_ids:
+                        u = urng.random()
+                        if u < sp.lm_unk_rate:
+                            ids[k] = NNG + 1 if u < 0.9 * sp.lm_unk_rate else NNP + 1      # (default tag morphemes: id = tag + 1)
+            sents.append([0] + ids + [sf_id, 1])
         htx = None
         if sp.use_htx:
             htx = np.array([(raw.morphs[i].tag & 0x7F) + vocab for i in range(vocab)], dtype=np.int64)
