@@ -362,7 +362,7 @@ def main():
         # synthetic tables do not prune like a real model -- seconds per batch, hence a bounded sample)
         also = [side_measurement(eng, "c2", min_seconds=0.5), side_measurement(eng, "c5", min_seconds=0.5)]
         if not args.no_side_models:
-            also += [side_measurement(None, "c4-cong", steps=10), side_measurement(None, "c3-sbg", steps=1, limit=4096)]
+            also += [side_measurement(None, "c4-cong", steps=10), side_measurement(None, "c3-sbg", steps=1)]
 
     # End to end: UTF-16 strings resident on the host -> kamd_analyze_batch (host text preparation, H2D, kernels,
     # D2H, result assembly) -> packed token records resident on the host.  Timed through the C ABI on an already packed buffer.

@@ -1405,16 +1405,20 @@ namespace kamd
 		if (!impl->stateScaleForced && b.capScale == 1 && b.refs.size() >= 64 && !std::getenv("KAMD_TEST_TINY_ARENAS"))
 		{
 			// how much of the worst-case state capacity the chunks of this batch used (states + the end candidates and the back-trace chain behind them)
-			uint64_t need16 = 1;
+			// (the 99.9th percentile of the chunks, not the maximum: the few chunks beyond it climb the capacity ladder inside run())
+			uint32_t hist[18] = {}; size_t counted = 0;
 			for (size_t c = 0; c < b.refs.size(); ++c)
 			{
 				const DevChunkResult& r = b.hResults[c];
 				if (r.status >= 16) continue;
 				const uint64_t full = (48ull * (b.charOff[c + 1] - b.charOff[c]) + 256) * (impl->hasSbg ? 8 : 1);
 				const uint64_t used = (uint64_t)r.endOff + r.nEnd / 2 + (b.nodeBase[c + 1] - b.nodeBase[c]) / 12 + 16;
-				need16 = std::max(need16, (used * 16 + full - 1) / full);
+				++hist[std::min<uint64_t>(17, (used * 16 + full - 1) / full)]; ++counted;
 			}
+			uint64_t need16 = 1; size_t seen = 0;
+			for (uint32_t k = 0; k < 18; ++k) { seen += hist[k]; need16 = std::max<uint64_t>(1, k); if (seen * 1000 >= counted * 999) break; }
 			impl->stateScale16[b.topN > 1 ? 1 : 0] = b.rerunChunks ? 16u : (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, need16 * 2));
+			if (std::getenv("KAMD_LATTICE_STATS")) fprintf(stderr, "[state arenas] top-%u batch of %zu chunks: most used %llu/16 of the worst-case capacity, %u re-run -> scale %u/16 (top-1) %u/16 (top-N)\n", b.topN, b.refs.size(), (unsigned long long)need16, b.rerunChunks, impl->stateScale16[0], impl->stateScale16[1]);
 		}
 		const size_t nT = b.prep.size();
 		BatchResults ret;
