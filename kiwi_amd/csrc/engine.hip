@@ -1004,7 +1004,8 @@ namespace kamd
 #undef KAMD_LAUNCH
 			HIPCHECK(hipEventRecord(e[4], sB));
 			{
-				const uint32_t stride = cn <= 32768 ? 16u : 4u, perWave = 64 / stride;      // active lanes per wave: 4 up to 32k chunks, 16 beyond
+				static const uint32_t strideEnv = std::getenv("KAMD_FINISH_STRIDE") ? (uint32_t)std::atoi(std::getenv("KAMD_FINISH_STRIDE")) : 0u;      // EXPERIMENT
+				const uint32_t stride = (strideEnv == 1 || strideEnv == 2 || strideEnv == 4 || strideEnv == 8 || strideEnv == 16 || strideEnv == 32 || strideEnv == 64) ? strideEnv : cn <= 32768 ? 16u : 4u, perWave = 64 / stride;      // active lanes per wave: 4 up to 32k chunks, 16 beyond
 				hipLaunchKernelGGL(k_finish_paths, dim3((cn + perWave - 1) / perWave), dim3(64), 0, sB, I.dview, b.bv, wv, sp, c0, cn, stride);
 			}
 			HIPCHECK(hipEventRecord(e[5], sB));

@@ -1746,13 +1746,10 @@ namespace sbgk
 			chain = reinterpret_cast<uint32_t*>(endBuf + nEnd);
 			uniq = B.spStates + B.spOff[chunk];
 			sortEndCands(endBuf, (int)nEnd);
+			// distinct (root, state) groups: the sort above made every group contiguous (its key starts with root and state), so they are counted at
+			// their boundaries -- one pass instead of comparing every candidate with all earlier ones
 			uint32_t numUniq = 0;
-			for (uint32_t a = 0; a < nEnd; ++a)
-			{
-				bool seen = false;
-				for (uint32_t b = 0; b < a && !seen; ++b) seen = endBuf[b].rootId == endBuf[a].rootId && endBuf[b].sp == endBuf[a].sp;
-				if (!seen) ++numUniq;
-			}
+			for (uint32_t a = 0; a < nEnd; ++a) if (!a || endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp) ++numUniq;
 			perGroup = numUniq ? (2 * P.topN + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq)
 			// paths this chunk hands on: the first perGroup candidates of every (root, state) group
 			for (uint32_t a = 0, startIdx = 0; a < nEnd; ++a)
