@@ -19,8 +19,13 @@
 //     them by end position, insertion order inside one: the final index of a node is a prefix sum over positions plus its rank at its
 //     position -- no node list in build order, no renumbering pass.
 //
-// What this kernel does not do (spans longer than 64 positions, an op list that outgrows its LDS copy, an end node that cannot be appended)
-// it flags in nNodes[chunk] (kLatticeNeedsBig); k_build_lattice_big replays those chunks.  Memory-bound integer work: no MFMA.
+//   * the tail of the kernel writes what the search reads (the candidate records of every node and the per-position program: what
+//     k_expand_cands / k_expand_pos wrote in two more launches) while the lattice is still in LDS; W.expanded[chunk] tells those kernels to skip.
+//
+// Hand-over: a chunk whose ops or nodes outgrow the LDS room of this launch is flagged kLatticeNeedsWide and listed in W.wideList; the same
+// kernel runs over that list once more with the wide layout (kLatticeWideBit).  What no layout covers (spans longer than 64 positions, an
+// end node that cannot be appended, more rounds than kMaxRounds) is flagged kLatticeNeedsBig and replayed by k_build_lattice_big.
+// Memory-bound integer work: no MFMA.
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
 #include "feature.hpp"
