@@ -43,6 +43,9 @@ int kamd_set_config(kamd_engine_h h, float cut_off_threshold, float space_penalt
 /* KiwiConfig::oovChrBias: subtracted from the character model's score of an unknown form when match_options carry Match::oovChrModel (1 << 8);
  * that option needs a model with the character model (nounchr.mdl next to cong.mdl / the raw container's `nounchr` section) */
 int kamd_set_oov_chr_bias(kamd_engine_h h, float bias);
+/* KiwiConfig::oovGlobalWeight / oovLocalWeight / oovGlobalMinFreq (defaults 35 / 3 / 4): Match::oovChrFreqModel (2 << 8) and oovChrFreqBranchModel (3 << 8) mix the
+ * character model's score of an unknown form with how often its prefixes occur in the text under analysis (reference src/UnkFormScorer.cpp:68-121) */
+int kamd_set_oov_freq_params(kamd_engine_h h, float global_weight, float local_weight, float global_min_freq);
 
 /* texts: concatenated UTF-16; offsets[n+1].  top_n in 1..16 (null + error otherwise); analyses beyond the best differ from a given reference run only in exact ties (top-N). */
 kamd_results_h kamd_analyze_batch(kamd_engine_h h, const uint16_t* texts, const uint64_t* offsets, uint32_t n,
@@ -80,6 +83,8 @@ kamd_results_h kamd_res_merge_strided(const uint8_t* const* parts, const size_t*
 /* test hooks: baked dictionary dump and the lattices of one text, in the byte layouts of oracle/ref_bridge.cpp */
 /* developer probe: exp_out[i] = expf, log_out[i] = logf of x[i] computed ON THE DEVICE by csrc/exact_math.hpp (bit-identical to glibc) */
 int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n);
+/* developer probe: tanh_out[i] = tanhf of x[i] computed ON THE DEVICE by csrc/exact_math.hpp (bit-identical to glibc 2.35; the frequency-based unknown-form scores use it) */
+int kamd_debug_exact_tanh(const float* x, float* tanh_out, uint32_t n);
 /* developer probe: the GLOBAL CoNgram model's score (reference CoNgramModel::progress / progressMatrix*, src/CoNgramModel.cpp:802-868, 1037-1466; csrc/cong_global.hpp)
  * of next[i] after context id ctx[i] with the seven history words hist7[7 * i ..], computed ON THE DEVICE; flags[i] bit 0 = the progressMatrix* entry, bit 1 = output
  * scale first.  The model must carry the window sections (cong.mdl windowSize 7).  The search does not use this model type yet (kiwi_init refuses CONG_GLOBAL). */

@@ -231,6 +231,11 @@ class KiwiAmd:
         self.lib.kamd_set_oov_chr_bias.argtypes = [C.c_void_p, C.c_float]
         self.lib.kamd_set_oov_chr_bias(self.h, bias)
 
+    def set_oov_freq_params(self, global_weight: float = 35.0, local_weight: float = 3.0, global_min_freq: float = 4.0):
+        """KiwiConfig::oovGlobalWeight / oovLocalWeight / oovGlobalMinFreq (Match::oovChrFreqModel, 2 << 8 in `match`)."""
+        self.lib.kamd_set_oov_freq_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        self.lib.kamd_set_oov_freq_params(self.h, global_weight, local_weight, global_min_freq)
+
     def analyze_batch(self, texts, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0) -> Results:
         flat, offs = pack_texts(texts)
         r = self.lib.kamd_analyze_batch(self.h, flat.ctypes.data, offs.ctypes.data, len(texts), top_n, match, int(open_ending), host_threads)

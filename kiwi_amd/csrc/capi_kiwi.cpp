@@ -475,6 +475,7 @@ extern "C"
 		if (!h) return;
 		auto& g = h->engine->config;
 		g.integrateAllomorph = !!c.integrate_allomorph; g.cutOffThreshold = c.cut_off_threshold; g.oovRuleScale = c.oov_rule_scale; g.oovRuleBias = c.oov_rule_bias; g.oovChrBias = c.oov_chr_bias;
+		g.oovGlobalWeight = c.oov_global_weight; g.oovLocalWeight = c.oov_local_weight; g.oovGlobalMinFreq = c.oov_global_min_freq;
 		g.spacePenalty = c.space_penalty; g.typoCostWeight = c.typo_cost_weight; g.maxUnkFormSize = c.max_unk_form_size;
 		g.maxUnkFormSizeFollowedByJClass = c.max_unk_form_size_followed_by_j_class; g.spaceTolerance = c.space_tolerance;
 		for (auto& r : h->replicas) r->config = g;
@@ -486,7 +487,7 @@ extern "C"
 		if (!h) return c;
 		const auto& g = h->engine->config;
 		c.integrate_allomorph = g.integrateAllomorph; c.cut_off_threshold = g.cutOffThreshold; c.oov_rule_scale = g.oovRuleScale; c.oov_rule_bias = g.oovRuleBias; c.oov_chr_bias = g.oovChrBias;
-		c.oov_global_weight = 35; c.oov_local_weight = 3; c.oov_global_min_freq = 4;
+		c.oov_global_weight = g.oovGlobalWeight; c.oov_local_weight = g.oovLocalWeight; c.oov_global_min_freq = g.oovGlobalMinFreq;
 		c.space_penalty = g.spacePenalty; c.typo_cost_weight = g.typoCostWeight; c.max_unk_form_size = g.maxUnkFormSize;
 		c.max_unk_form_size_followed_by_j_class = g.maxUnkFormSizeFollowedByJClass; c.space_tolerance = g.spaceTolerance;
 		return c;

@@ -19,7 +19,7 @@ struct kamd_results { BatchResults r; };   // flat segments; the accessors below
 static_assert(sizeof(kamd_token_t) == sizeof(FlatToken) && offsetof(kamd_token_t, form_off) == offsetof(FlatToken, formOff) && offsetof(kamd_token_t, morph_id) == offsetof(FlatToken, morph),
 	"kamd_token_t is the layout of kamd::FlatToken");
 
-namespace kamd { void exactMathProbe(const float* x, float* e, float* l, uint32_t n); }
+namespace kamd { void exactMathProbe(const float* x, float* e, float* l, float* t, uint32_t n); }
 namespace kamd { void conggProbe(const FlatModel& m, const uint32_t* ctx, const uint32_t* hist, const uint32_t* next, const uint8_t* flags, float* out, uint32_t n); }
 
 namespace
@@ -76,6 +76,13 @@ extern "C"
 	{
 		if (!h) return -2;
 		h->e->config.oovChrBias = bias;
+		return 0;
+	}
+
+	int kamd_set_oov_freq_params(kamd_engine_h h, float global_weight, float local_weight, float global_min_freq)
+	{
+		if (!h) return -2;
+		h->e->config.oovGlobalWeight = global_weight; h->e->config.oovLocalWeight = local_weight; h->e->config.oovGlobalMinFreq = global_min_freq;
 		return 0;
 	}
 
@@ -256,7 +263,11 @@ extern "C"
 
 	int kamd_debug_exact_math(const float* x, float* exp_out, float* log_out, uint32_t n)
 	{
-		return guarded([&]() { kamd::exactMathProbe(x, exp_out, log_out, n); return 0; }, -1);
+		return guarded([&]() { kamd::exactMathProbe(x, exp_out, log_out, nullptr, n); return 0; }, -1);
+	}
+	int kamd_debug_exact_tanh(const float* x, float* tanh_out, uint32_t n)
+	{
+		return guarded([&]() { kamd::exactMathProbe(x, nullptr, nullptr, tanh_out, n); return 0; }, -1);
 	}
 
 	int kamd_debug_cong_global(kamd_engine_h h, const uint32_t* ctx, const uint32_t* hist7, const uint32_t* next, const uint8_t* flags, float* out, uint32_t n)

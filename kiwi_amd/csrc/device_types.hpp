@@ -121,6 +121,8 @@ namespace kamd
 		uint32_t smallMax, mediumMax, bucketCap;   // container selection by incoming paths (128, 512) and per-bucket key cap (128): BestPathContainer.hpp:275-277
 		uint32_t topN;                 // paths kept per (candidate, key): 1..kMaxTopN (BestPathContainer.hpp:151-222 for N > 1)
 		float oovChrBias;              // KiwiConfig::oovChrBias: subtracted from the character model's score of an unknown form (Match::oovChrModel)
+		// Match::oovChrFreqModel: KiwiConfig::oovGlobalWeight / oovLocalWeight / oovGlobalMinFreq, and the bias k_unk_chr_freq applies itself (oovChrBias is 0 then)
+		float oovGlobalWeight, oovLocalWeight, oovGlobalMinFreq, oovChrFreqBias;
 	};
 	constexpr uint32_t kMaxTopN = 16;
 
@@ -137,6 +139,9 @@ namespace kamd
 		const uint8_t* spStates;
 		const uint8_t* chunkFlags;     // bit0: openEnding applies to this chunk
 		const uint32_t* textOffset;    // [nChunks] offset of the chunk inside its normalised text (Kiwi.cpp:1095-1117 `splitEnd`)
+		// Match::oovChrFreqModel only (null otherwise): the FILTERED normalised text a chunk belongs to (Kiwi.cpp:1058-1086: special characters and spaces
+		// blanked) -- the whole text, not the chunk: substring frequencies are counted over it (chr_freq.hpp)
+		const uint16_t* filtChars; const uint32_t* filtOff; const uint32_t* filtLen;      // [nChunks] each
 	};
 
 	// Scratch + outputs.  All per-chunk regions are laid out by the host from the chunk lengths
@@ -178,6 +183,9 @@ namespace kamd
 		// Match::oovChrModel (null: unknown forms are scored by the length rule): per node, same offsets as nodes, the character model's score of
 		// the node's unknown form -- its own string of a formless node, else its text span (k_unk_chr; UnkFormScorer::chrBasedScore before the bias)
 		float* unkChr;
+		// Match::oovChrFreqModel (null otherwise): unkChr holds the FINAL scores (bias subtracted: the consumers see a bias of 0), and per node with a dictionary form
+		// the frequency-based score of that form's own string (replaces ModelView::formUnkChr, which cannot know the text)
+		float* unkChrForm;
 		const uint32_t* blockBits;     // AnalyzeOption::blocklist as one bit per morpheme id (null: none): k_expand_cands drops those candidates
 		uint32_t outPathCap, outTokCap;
 		// position program (k_expand_pos -> k_pos_path): records at the chunk's packBase offset (same capacity as its candidate packs), position

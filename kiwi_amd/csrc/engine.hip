@@ -20,6 +20,7 @@
 #include "viterbi_kernel.hpp"
 #include "exact_math.hpp"
 #include "cong_global.hpp"
+#include "chr_freq.hpp"
 #include "typo_lattice_kernel.hpp"
 #include "typo_graph_kernel.hpp"
 
@@ -32,6 +33,7 @@ namespace kamd
 	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
 	__global__ void k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr);
 	__global__ void k_unk_chr(ModelView M, BatchView B, WorkView W, ChrView C, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
+	__global__ void k_unk_chr_freq(ModelView M, BatchView B, WorkView W, ChrView C, ChrFreqParams Q, float chrBias, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
 
 	namespace
 	{
@@ -185,7 +187,7 @@ namespace kamd
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
 		TypoOption typo;
 		TypoGraphDev typoDev;
-		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder, dBlockBits, dUnkChr;
+		DevBuf dTypoGraph, dTypoLast, dTypoPool, dTypoChunks, dTypoTmp, dTypoMap, dTypoNs, dTypoPs, dTypoStates, dTypoSIdx, dTypoScratch, dNodeTypo, dTypoOrder, dBlockBits, dUnkChr, dUnkChrForm;
 		TypoLatView tv{};
 		DevBuf dPacks, dStates, dNodeStOff, dNodeStCnt, dReach, dTokens, dResults, dOrder;
 		DevBuf dPosRecs, dPosDesc, dPosPrev, dPosNodeRec, dPosMask, dPosBig;   // position program of k_pos_path (k_expand_pos)
@@ -272,7 +274,7 @@ namespace kamd
 		{
 			impl->model.congDim = 0;
 			// ... and the character model is run quantised only next to a CoNgram model (the reference uses its fp32 scorer otherwise): not with these types
-			impl->model.chrDim = 0; impl->model.formUnkChr.clear();
+			impl->model.chrDim = 0; impl->model.formUnkChr.clear(); impl->model.formChrTok.clear();
 		}
 		if (impl->model.congDim) { impl->model.sbgPtrs.clear(); impl->model.sbgKeys.clear(); impl->model.sbgComps.clear(); impl->model.sbgDiscnts.clear(); impl->model.sbgValid.clear(); }
 		if (lm == LmMode::Knlm) { impl->model.sbgPtrs.clear(); impl->model.sbgKeys.clear(); impl->model.sbgComps.clear(); impl->model.sbgDiscnts.clear(); impl->model.sbgValid.clear(); }
@@ -332,7 +334,7 @@ namespace kamd
 		}
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
 		v.lmHtxNode = (m.congDim || m.lmHtxNode.empty()) ? nullptr : impl->up(m.lmHtxNode);      // history-transformed Knlm only
-		v.formUnkChr = nullptr;
+		v.formUnkChr = nullptr; v.formChrTok = nullptr;
 		v.lmChain = nullptr;
 		if (!m.congDim && !m.lmBackoff.empty())
 		{
@@ -350,8 +352,9 @@ namespace kamd
 			ChrView c = m.chrView();
 			c.ctxEmb = impl->up(m.chrCtxEmb); c.outEmb = impl->up(m.chrOutEmb); c.nodes = impl->up(m.chrNodes); c.keys = impl->up(m.chrKeys); c.values = impl->up(m.chrValues);
 			c.root = impl->up(m.chrRoot); c.inv = m.chrInv.empty() ? nullptr : impl->up(m.chrInv);
+			c.depth = impl->up(m.chrDepth); c.freqTab = impl->up(m.chrFreqTab);
 			impl->chr = c;
-			v.formUnkChr = impl->up(m.formUnkChr);
+			v.formUnkChr = impl->up(m.formUnkChr); v.formChrTok = impl->up(m.formChrTok);
 		}
 		if (!m.sbgPtrs.empty())
 		{
@@ -458,6 +461,18 @@ namespace kamd
 		const size_t oChars = take(2 * totChars), oCls = take(totChars), oScript = take(totChars);
 		const size_t oCharOff = take(4 * (nC + 1)), oPatOff = take(4 * (nC + 1)), oPats = take(sizeof(DevPattern) * (size_t)b.patOff[nC]);
 		const size_t oSpOff = take(4 * (nC + 1)), oSp = take(b.spOff[nC]), oFlags = take(nC), oTextOff = take(4 * nC);
+		// Match::oovChrFreqModel: the filtered normalised texts of the batch, once per text, and where each chunk's text lies
+		const bool chrFreq = ((b.match >> 8) & 3) > 1;
+		std::vector<uint32_t> filtAt;
+		size_t totFilt = 0;
+		if (chrFreq)
+		{
+			filtAt.resize(b.prep.size() + 1);
+			for (size_t t = 0; t < b.prep.size(); ++t) { filtAt[t] = (uint32_t)totFilt; totFilt += b.prep[t].norm.size(); }
+			filtAt[b.prep.size()] = (uint32_t)totFilt;
+			if (totFilt > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit text offsets: split the batch" };
+		}
+		const size_t oFilt = take(2 * totFilt), oFiltOff = take(chrFreq ? 4 * nC : 0), oFiltLen = take(chrFreq ? 4 * nC : 0);
 		const size_t oMatchBase = take(4 * (nC + 1)), oNodeBase = take(4 * (nC + 1)), oPackBase = take(4 * (nC + 1)), oStateBase = take(8 * (nC + 1)), oTokenBase = take(8 * (nC + 1));
 		b.hIn.ensure(top); b.dIn.ensure(top);
 		uint8_t* H = b.hIn.as<uint8_t>();
@@ -482,9 +497,29 @@ namespace kamd
 				if (!r.sp.empty()) std::memcpy(H + oSp + b.spOff[c], r.sp.data(), r.sp.size());
 				H[oFlags + c] = r.openEnding ? 1 : 0;
 				reinterpret_cast<uint32_t*>(H + oTextOff)[c] = d.startOffset;
+				if (chrFreq) { reinterpret_cast<uint32_t*>(H + oFiltOff)[c] = filtAt[r.text]; reinterpret_cast<uint32_t*>(H + oFiltLen)[c] = (uint32_t)pt.norm.size(); }
 			}
 			units += u;
 		});
+		if (chrFreq)
+		{
+			// Kiwi.cpp:1064-1084: identifySpecialChr of every UTF-16 UNIT (a surrogate on its own, unlike `cls`, which types a pair at its first unit)
+			const uint8_t hiType = identifySpecialChr(0xD800), loType = identifySpecialChr(0xDC00);
+			HostPool::instance().run(b.prep.size(), 256, b.hostThreads, [&](size_t t0, size_t t1, int)
+			{
+				for (size_t t = t0; t < t1; ++t)
+				{
+					const PreparedView& pt = b.prep[t];
+					uint16_t* o = reinterpret_cast<uint16_t*>(H + oFilt) + filtAt[t];
+					for (size_t k = 0; k < pt.norm.size(); ++k)
+					{
+						const uint16_t c = (uint16_t)pt.norm[k];
+						const uint8_t type = isHighSurrogate(c) ? hiType : isLowSurrogate(c) ? loType : (uint8_t)(pt.cls[k] & 0x7F);
+						o[k] = chrFreqFiltered(type) ? (uint16_t)u' ' : c;
+					}
+				}
+			});
+		}
 		b.units = units;
 		hipStream_t s = I.stream;
 		if (top) HIPCHECK(hipMemcpyAsync(b.dIn.p, H, top, hipMemcpyHostToDevice, s));
@@ -517,6 +552,7 @@ namespace kamd
 		bv.nChunks = (uint32_t)nC; bv.chars = (const uint16_t*)(D + oChars); bv.cls = D + oCls; bv.script = D + oScript;
 		bv.charOff = (const uint32_t*)(D + oCharOff); bv.patOff = (const uint32_t*)(D + oPatOff); bv.patterns = (const DevPattern*)(D + oPats);
 		bv.spOff = (const uint32_t*)(D + oSpOff); bv.spStates = D + oSp; bv.chunkFlags = D + oFlags; bv.textOffset = (const uint32_t*)(D + oTextOff);
+		bv.filtChars = chrFreq ? (const uint16_t*)(D + oFilt) : nullptr; bv.filtOff = chrFreq ? (const uint32_t*)(D + oFiltOff) : nullptr; bv.filtLen = chrFreq ? (const uint32_t*)(D + oFiltLen) : nullptr;
 		WorkView& w = b.wv;
 		w.nsToPos = b.dNsToPos.as<uint16_t>(); w.posToNs = b.dPosToNs.as<uint16_t>(); w.cflag = b.dCflag.as<uint8_t>();
 		w.matchMask = b.dMask.as<uint64_t>(); w.matchOff = b.dMoff.as<uint32_t>(); w.nNs = b.dNNs.as<uint32_t>();
@@ -534,7 +570,9 @@ namespace kamd
 		w.posHandOver = nullptr; w.posScratch = nullptr; w.posContCounter = nullptr; w.posContSlots = 0;
 		w.blockBits = nullptr;
 		w.unkChr = nullptr;
+		w.unkChrForm = nullptr;
 		if ((b.match >> 8) & 3) { b.dUnkChr.ensure(totNodes * 4 + 16); w.unkChr = b.dUnkChr.as<float>(); }      // Match::oovChrModel (checked in stage())
+		if (((b.match >> 8) & 3) > 1) { b.dUnkChrForm.ensure(totNodes * 4 + 16); w.unkChrForm = b.dUnkChrForm.as<float>(); }      // Match::oovChrFreqModel / oovChrFreqBranchModel
 		if (b.typo.blocked && !b.typo.blocked->empty())
 		{
 			if (b.typo.blocked->size() != (I.model.morphs.size() + 31) / 32) throw std::invalid_argument{ "kiwi_amd: blocklist bit set does not belong to this model" };
@@ -632,21 +670,25 @@ namespace kamd
 		b.ran = false;
 	}
 
-	// Probe of csrc/exact_math.hpp on the device (tests/test_gpu_exact_math.py): y[i] = expf_glibc(x[i]), z[i] = logf_glibc(x[i])
-	__global__ void k_exact_math_probe(const float* x, float* e, float* l, uint32_t n)
+	// Probe of csrc/exact_math.hpp on the device (tests/test_exact_math.py): e[i] = expf_glibc(x[i]), l[i] = logf_glibc(x[i]), t[i] = tanhf_glibc(x[i]) (each where asked for)
+	__global__ void k_exact_math_probe(const float* x, float* e, float* l, float* t, uint32_t n)
 	{
 		const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-		if (i < n) { e[i] = exact::expf_glibc(x[i]); l[i] = exact::logf_glibc(x[i]); }
+		if (i >= n) return;
+		if (e) e[i] = exact::expf_glibc(x[i]);
+		if (l) l[i] = exact::logf_glibc(x[i]);
+		if (t) t[i] = exact::tanhf_glibc(x[i]);
 	}
-	void exactMathProbe(const float* x, float* e, float* l, uint32_t n)
+	void exactMathProbe(const float* x, float* e, float* l, float* t, uint32_t n)
 	{
-		DevBuf dx, de, dl;
-		dx.ensure((size_t)n * 4 + 16); de.ensure((size_t)n * 4 + 16); dl.ensure((size_t)n * 4 + 16);
+		DevBuf dx, de, dl, dt;
+		dx.ensure((size_t)n * 4 + 16); de.ensure((size_t)n * 4 + 16); dl.ensure((size_t)n * 4 + 16); dt.ensure((size_t)n * 4 + 16);
 		HIPCHECK(hipMemcpy(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
-		hipLaunchKernelGGL(k_exact_math_probe, dim3((n + 255) / 256), dim3(256), 0, 0, dx.as<float>(), de.as<float>(), dl.as<float>(), n);
+		hipLaunchKernelGGL(k_exact_math_probe, dim3((n + 255) / 256), dim3(256), 0, 0, dx.as<float>(), e ? de.as<float>() : (float*)nullptr, l ? dl.as<float>() : (float*)nullptr, t ? dt.as<float>() : (float*)nullptr, n);
 		HIPCHECK(hipGetLastError());
-		HIPCHECK(hipMemcpy(e, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-		HIPCHECK(hipMemcpy(l, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		if (e) HIPCHECK(hipMemcpy(e, de.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		if (l) HIPCHECK(hipMemcpy(l, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+		if (t) HIPCHECK(hipMemcpy(t, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	}
 
 	// Probe of csrc/cong_global.hpp on the device (tests/test_cong_global.py): the score of `next[i]` after context ctx[i] and the seven history words hist[i][0..6]
@@ -686,7 +728,9 @@ namespace kamd
 	{
 		SearchParams p{};
 		p.match = match; p.cutOff = c.cutOffThreshold; p.spacePenalty = c.spacePenalty; p.typoCostWeight = c.typoCostWeight;
-		p.oovRuleScale = c.oovRuleScale; p.oovRuleBias = c.oovRuleBias; p.oovChrBias = c.oovChrBias;
+		p.oovRuleScale = c.oovRuleScale; p.oovRuleBias = c.oovRuleBias;
+		p.oovGlobalWeight = c.oovGlobalWeight; p.oovLocalWeight = c.oovLocalWeight; p.oovGlobalMinFreq = c.oovGlobalMinFreq; p.oovChrFreqBias = c.oovChrBias;
+		p.oovChrBias = ((match >> 8) & 3) > 1 ? 0.f : c.oovChrBias;      // (the frequency-based scores arrive with the bias applied: WorkView::unkChrForm)
 		p.maxUnk = c.maxUnkFormSize; p.maxUnkJ = c.maxUnkFormSizeFollowedByJClass; p.spaceTol = c.spaceTolerance;
 		p.splitComplex = (match & M_SPLIT_COMPLEX) ? 1 : 0; p.splitSaisiot = (match & M_SPLIT_SAISIOT) ? 1 : 0; p.mergeSaisiot = (match & M_MERGE_SAISIOT) ? 1 : 0;
 		p.topN = topN;
@@ -888,7 +932,10 @@ namespace kamd
 			}
 			}
 			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u);
-			if (b.wv.unkChr)      // Match::oovChrModel: every node's unknown form scored by the character model, once, before the search
+			if (b.wv.unkChrForm)      // Match::oovChrFreqModel / oovChrFreqBranchModel: ... mixed with the substring frequencies of the text (chr_freq.hpp)
+				hipLaunchKernelGGL(k_unk_chr_freq, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, I.chr, ChrFreqParams{ sp.oovGlobalWeight, sp.oovLocalWeight, sp.oovGlobalMinFreq }, sp.oovChrFreqBias,
+					c0, cn, chrToken(0xD800, identifySpecialChr(0xD800)), chrToken(0xDC00, identifySpecialChr(0xDC00)));
+			else if (b.wv.unkChr)      // Match::oovChrModel: every node's unknown form scored by the character model, once, before the search
 				hipLaunchKernelGGL(k_unk_chr, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, I.chr, c0, cn, chrToken(0xD800, identifySpecialChr(0xD800)), chrToken(0xDC00, identifySpecialChr(0xDC00)));
 			// position-step search first (viterbi_pos.inc): top-1, 16-lane groups, not for SkipBigram models; what it cannot finish is resumed by the general kernel below
 			// (not for typo correction unless asked for: the lattices over typo graphs hold positions the step kernel leaves to the general one -- MI355X, c5:
@@ -1258,7 +1305,6 @@ namespace kamd
 		{
 			// Match::oovMask (include/kiwi/PatternMatcher.h:20-24): 1 = unknown forms scored by the character model; 2 / 3 add substring frequencies
 			if (!impl->chr.present()) throw std::invalid_argument{ "`oovChrModel` option is set but the character-level noun model is not loaded." };      // Kiwi.cpp:1032-1035
-			if (((match >> 8) & 3) > 1) throw std::runtime_error{ "kiwi_amd: oovChrFreqModel / oovChrFreqBranchModel are not built (oovChrModel is)" };
 		}
 		HostTimer tm{ "stage" };
 		auto b = std::make_shared<StagedBatch>();

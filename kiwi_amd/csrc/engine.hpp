@@ -19,6 +19,7 @@ namespace kamd
 		bool integrateAllomorph = true;
 		float cutOffThreshold = 8, oovRuleScale = 4, oovRuleBias = 4, oovChrBias = 0, spacePenalty = 7, typoCostWeight = 6;
 		uint32_t maxUnkFormSize = 6, maxUnkFormSizeFollowedByJClass = 0xFFFFFFFFu, spaceTolerance = 0;
+		float oovGlobalWeight = 35, oovLocalWeight = 3, oovGlobalMinFreq = 4;      // Match::oovChrFreqModel (include/kiwi/Kiwi.h:157-159)
 	};
 
 	struct KernelTimes { float scanMs = 0, latticeMs = 0, searchMs = 0, finishMs = 0; uint32_t searchLaunches = 1;   // sums over the sub-batches of one run

@@ -94,5 +94,100 @@ namespace kamd
 			y = y * r2 + (y0 + r);
 			return (float)y;
 		}
+
+		// expm1f (glibc 2.35 sysdeps/ieee754/flt-32/s_expm1f.c: the fdlibm algorithm in single precision) for finite x; the callers here
+		// (tanhf_glibc) pass |x| < 44.  Every operation is a single-precision one in the original's order (-ffp-contract=off).
+		KAMD_HD float expm1f_glibc(float x)
+		{
+			const float ln2_hi = u2f(0x3f317180u), ln2_lo = u2f(0x3717f7d1u), invln2 = u2f(0x3fb8aa3bu);
+			const float Q1 = u2f(0xbd088889u), Q2 = u2f(0x3ad00d01u), Q3 = u2f(0xb8a670cdu), Q4 = u2f(0x36867e54u), Q5 = u2f(0xb457edbbu);
+			uint32_t hx = f2u(x);
+			const bool neg = (hx & 0x80000000u) != 0;
+			hx &= 0x7fffffffu;
+			if (hx >= 0x4195b844u)      // |x| >= 27 ln2
+			{
+				if (hx >= 0x42b17218u)
+				{
+					if (hx > 0x7f800000u) return x + x;
+					if (hx == 0x7f800000u) return neg ? -1.0f : x;
+					if (x > u2f(0x42b17180u)) return u2f(0x7f800000u);
+				}
+				if (neg) return -1.0f;
+			}
+			float hi, lo, c = 0.f, t, e;
+			int32_t k;
+			if (hx > 0x3eb17218u)      // |x| > 0.5 ln2
+			{
+				if (hx < 0x3F851592u)      // and |x| < 1.5 ln2
+				{
+					if (!neg) { hi = x - ln2_hi; lo = ln2_lo; k = 1; }
+					else { hi = x + ln2_hi; lo = -ln2_lo; k = -1; }
+				}
+				else
+				{
+					k = (int32_t)(invln2 * x + (neg ? -0.5f : 0.5f));
+					t = (float)k;
+					hi = x - t * ln2_hi;
+					lo = t * ln2_lo;
+				}
+				x = hi - lo;
+				c = (hi - x) - lo;
+			}
+			else if (hx < 0x33000000u) return x;      // |x| < 2^-25
+			else k = 0;
+			const float hfx = 0.5f * x;
+			const float hxs = x * hfx;
+			const float r1 = 1.0f + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+			t = 3.0f - r1 * hfx;
+			e = hxs * ((r1 - t) / (6.0f - x * t));
+			if (k == 0) return x - (x * e - hxs);
+			e = (x * (e - c) - c);
+			e -= hxs;
+			if (k == -1) return 0.5f * (x - e) - 0.5f;
+			if (k == 1)
+			{
+				if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
+				return 1.0f + 2.0f * (x - e);
+			}
+			float y;
+			if (k <= -2 || k > 56)
+			{
+				y = 1.0f - (e - x);
+				y = u2f(f2u(y) + ((uint32_t)k << 23));
+				return y - 1.0f;
+			}
+			if (k < 23)
+			{
+				t = u2f(0x3f800000u - (0x1000000u >> k));      // 1 - 2^-k
+				y = t - (e - x);
+				y = u2f(f2u(y) + ((uint32_t)k << 23));
+			}
+			else
+			{
+				t = u2f((uint32_t)(0x7f - k) << 23);      // 2^-k
+				y = x - (e + t);
+				y += 1.0f;
+				y = u2f(f2u(y) + ((uint32_t)k << 23));
+			}
+			return y;
+		}
+
+		// tanhf (glibc 2.35 sysdeps/ieee754/flt-32/s_tanhf.c) for finite x
+		KAMD_HD float tanhf_glibc(float x)
+		{
+			const uint32_t jx = f2u(x), ix = jx & 0x7fffffffu;
+			if (ix >= 0x7f800000u) return (ix > 0x7f800000u) ? x + x : ((jx >> 31) ? -1.0f : 1.0f);
+			float z;
+			if (ix < 0x41b00000u)      // |x| < 22
+			{
+				if (ix == 0) return x;
+				if (ix < 0x24000000u) return x * (1.0f + x);
+				const float ax = u2f(ix);
+				if (ix >= 0x3f800000u) { const float t = expm1f_glibc(2.0f * ax); z = 1.0f - 2.0f / (t + 2.0f); }
+				else { const float t = expm1f_glibc(-2.0f * ax); z = -t / (t + 2.0f); }
+			}
+			else z = 1.0f;
+			return (jx >> 31) ? -z : z;
+		}
 	}
 }

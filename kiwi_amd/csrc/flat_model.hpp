@@ -147,6 +147,8 @@ namespace kamd
 		const int32_t* lmHtxNode;
 		// character model present: per form the score of its own string (what a dictionary node's unknown proper-noun reading costs under Match::oovChrModel)
 		const float* formUnkChr;
+		// ... and the character model's token of every unit of formChars (Match::oovChrFreqModel walks a dictionary form's string per node: chr_freq.hpp)
+		const uint16_t* formChrTok;
 		// device only (Knlm): per LM node the next two nodes of its back-off chain as absolute ids {node + lower, that node's lower node}; 0 = the root,
 		// where every chain ends.  A search state that carries this pair can probe all three contexts of its next transition at once (viterbi_pos.inc)
 		const uint32_t* lmChain;
@@ -233,6 +235,11 @@ namespace kamd
 		const int32_t* root = nullptr;        // [256]
 		const uint16_t* inv = nullptr;        // [vocab]: token -> key space (hasReorderedVocab), or null
 		int32_t bosNode = 0; uint32_t bosCtx = 0;      // the state after <s> (UnkFormScorer's constructor)
+		// Match::oovChrFreqModel (chr_freq.hpp): the trie values as the walk returns them carry a quantised frequency in their top byte
+		// (header flag hasTrieFrequency; CoNgramModel::getContextFrequency -> dequantizeFrequencyScale, src/CoNgramModel.hpp:34-39, 76-86: freqTab);
+		// depth[node] = tokens on the path from the root (CoNgramModel::getNodeDepth; assigned breadth first, src/CoNgramModel.cpp:551-572:
+		// the second byte of a two-byte spelling does not count)
+		const uint16_t* depth = nullptr; const float* freqTab = nullptr; uint32_t bosCtxPacked = 0; bool hasFreq = false;
 		bool present() const { return dim != 0; }
 	};
 	KAMD_HD bool chrSearch(const ChrView& C, const CongNodeRec& nd, uint32_t key, int32_t& v)
@@ -285,10 +292,11 @@ namespace kamd
 		}
 	}
 	// CoNgramModel::progressOneStep -> progress(), window 0, quantised (src/CoNgramModel.cpp:869-908): score of `tok` in the current context (one
-	// fp32 conversion, two multiplications, the context bias, then the output bias), then the context moves on; ctx = the UNPACKED context id
-	// (the trie's values carry a frequency in their top byte: CoNgramModel::unpackContextId)
-	KAMD_HD float chrProgress(const ChrView& C, int32_t& node, uint32_t& ctx, uint32_t tok)
+	// fp32 conversion, two multiplications, the context bias, then the output bias), then the context moves on.  chrProgressPacked keeps the context id as the
+	// trie holds it (a frequency in the top byte where the file has them); chrProgress: the UNPACKED id (CoNgramModel::unpackContextId)
+	KAMD_HD float chrProgressPacked(const ChrView& C, int32_t& node, uint32_t& packedCtx, uint32_t tok)
 	{
+		const uint32_t ctx = packedCtx & 0x00FFFFFFu;
 		const int8_t* a = reinterpret_cast<const int8_t*>(C.ctxEmb + (size_t)ctx * C.stride);
 		const int8_t* b = reinterpret_cast<const int8_t*>(C.outEmb + (size_t)tok * C.stride);
 		int32_t acc = 0;
@@ -301,7 +309,14 @@ namespace kamd
 		uint32_t c;
 		if (key < 192) c = chrContextVl(C, node, key);
 		else { const uint32_t r = key - 192; chrContextVl(C, node, 192 + (r >> 5)); c = chrContextVl(C, node, 224 + (r & 31)); }
-		ctx = c & 0x00FFFFFFu;
+		packedCtx = c;
+		return ll;
+	}
+	KAMD_HD float chrProgress(const ChrView& C, int32_t& node, uint32_t& ctx, uint32_t tok)
+	{
+		uint32_t packed = ctx;
+		const float ll = chrProgressPacked(C, node, packed, tok);
+		ctx = packed & 0x00FFFFFFu;
 		return ll;
 	}
 	// ChrTokenizer::encodeOne (src/Dataset.cpp:805-847) of one UTF-16 unit whose identifySpecialChr type is `type`
@@ -353,6 +368,9 @@ namespace kamd
 		std::vector<CongNodeRec> chrNodes; std::vector<uint8_t> chrKeys; std::vector<int32_t> chrValues, chrRoot; std::vector<uint16_t> chrInv;
 		std::vector<uint8_t> chrCtxEmb, chrOutEmb; uint32_t chrDim = 0, chrCtx = 0, chrVocab = 0; int32_t chrBosNode = 0; uint32_t chrBosCtx = 0;
 		std::vector<float> formUnkChr;
+		// Match::oovChrFreqModel: ChrView::depth / freqTab, and the character model's token of every unit of formChars (the frequency-based score of a
+		// dictionary form depends on the text, so the device walks the form's string itself)
+		std::vector<uint16_t> chrDepth, formChrTok; std::vector<float> chrFreqTab; uint32_t chrBosCtxPacked = 0; bool chrHasFreq = false;
 		std::vector<uint8_t> congCtxEmb, congOutEmb; uint32_t congDim = 0, congCtx = 0, congVocab = 0, congVlTMax = 0xFFFFFFFFu, congVlBits = 0;
 		// sections of the global model (CongView::window ...); congGlobal: score with them (ModelType::congGlobal) -- set by whoever opens the model
 		std::vector<float> congCtxConf, congDistConf, congPosConf; std::vector<uint8_t> congDistEmb, congDistMask; uint32_t congWindow = 0, congKeyBytes = 4;
@@ -381,6 +399,7 @@ namespace kamd
 			v.dim = chrDim; v.stride = chrDim + 8; v.nCtx = chrCtx; v.vocab = chrVocab;
 			v.ctxEmb = chrCtxEmb.data(); v.outEmb = chrOutEmb.data(); v.nodes = chrNodes.data(); v.keys = chrKeys.data(); v.values = chrValues.data(); v.root = chrRoot.data();
 			v.inv = chrInv.empty() ? nullptr : chrInv.data(); v.bosNode = chrBosNode; v.bosCtx = chrBosCtx;
+			v.depth = chrDepth.empty() ? nullptr : chrDepth.data(); v.freqTab = chrFreqTab.empty() ? nullptr : chrFreqTab.data(); v.bosCtxPacked = chrBosCtxPacked; v.hasFreq = chrHasFreq;
 			return v;
 		}
 
@@ -406,6 +425,7 @@ namespace kamd
 			v.lmHash = lmHash.data(); v.lmHashMask = lmHashMask; v.lmRoot2 = lmRoot2.data(); v.lmBackoff = lmBackoff.data();
 			v.lmHtxNode = lmHtxNode.empty() ? nullptr : lmHtxNode.data();
 			v.formUnkChr = formUnkChr.empty() ? nullptr : formUnkChr.data();
+			v.formChrTok = formChrTok.empty() ? nullptr : formChrTok.data();
 			v.lmChain = nullptr;
 			return v;
 		}

@@ -23,6 +23,7 @@
 #include "feature.hpp"
 #include "lattice_connect.hpp"
 #include "lattice_expand.hpp"
+#include "chr_freq.hpp"
 
 namespace kamd
 {
@@ -1049,7 +1050,7 @@ namespace kamd
 					uint16_t of = featMask(M.formChars + f.charOff, f.len) & 0x1FFF;
 					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
 					float disc;
-					if (useChr & 1u) disc = baseDiscount + (M.formUnkChr[nd.form] - P.oovChrBias);
+					if (useChr & 1u) disc = baseDiscount + ((W.unkChrForm ? W.unkChrForm[nBase + i] : M.formUnkChr[nd.form]) - P.oovChrBias);
 					else disc = baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias);
 					emit(unkPacks + 1, disc, 2, of, (uint32_t)PR_PASS1 | sharedFirstWord(unkPacks + 1, 1));
 				}
@@ -1097,6 +1098,52 @@ namespace kamd
 			}
 			score += chrProgress(C, node, ctx, 0);
 			W.unkChr[nBase + i] = score;
+		}
+	}
+	// Match::oovChrFreqModel / oovChrFreqBranchModel (row f4; UnkFormScorer::chrFreqBasedScore, src/UnkFormScorer.cpp:68-121; chr_freq.hpp): k_unk_chr with the
+	// substring frequencies of the text under analysis mixed in.  One block per chunk, one node per thread: the thread counts how often every prefix (<= 32 units)
+	// of its node's string occurs in the FILTERED text the chunk belongs to (one pass over that text; 16-bit counters in LDS, one column per thread), then walks
+	// the string through the character model.  W.unkChr[node]: a formless node's own string, else the node's text span -- as in k_unk_chr, but FINAL (bias
+	// subtracted; the early exit of :101 leaves without it).  W.unkChrForm[node]: the same for the own string of a node's dictionary form, which the
+	// frequency-free mode reads from a per-form table (ModelView::formUnkChr) and which here depends on the text; when that string is the text span the span's
+	// score is reused.  HBM-bound integer / fp32 work off the search kernel's dependent chain; no MFMA.
+	__global__ void __launch_bounds__(64) k_unk_chr_freq(ModelView M, BatchView B, WorkView W, ChrView C, ChrFreqParams Q, float chrBias, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok)
+	{
+		__shared__ uint16_t cnt[kSubstrMaxLen * 64];
+		if (blockIdx.x >= chunkCount) return;
+		const uint32_t chunk = chunkBegin + blockIdx.x;
+		if (W.results[chunk].status != CS_OK) return;
+		const uint32_t nBase = W.nodeBase[chunk], G = W.nNodes[chunk];
+		const uint32_t cOff = B.charOff[chunk];
+		const uint16_t* str = B.chars + cOff; const uint8_t* cls = B.cls + cOff;
+		const uint16_t* text = B.filtChars + B.filtOff[chunk]; const uint32_t textLen = B.filtLen[chunk];
+		uint16_t* myCnt = cnt + threadIdx.x;
+		for (uint32_t i = 1 + threadIdx.x; i + 1 < G; i += blockDim.x)
+		{
+			const DevNode nd = W.nodes[nBase + i];
+			const uint32_t off = nd.form == NOFORM ? nd.uformOff : nd.startPos, len = nd.form == NOFORM ? nd.uformLen : (uint32_t)(nd.endPos - nd.startPos);
+			bool biased;
+			substringCounts(text, textLen, str + off, len, myCnt, 64);
+			float score = chrFreqScore(C, Q, len, [&](uint32_t k) -> uint32_t
+			{
+				const uint16_t c = str[off + k];
+				return isHighSurrogate(c) ? hiTok : isLowSurrogate(c) ? loTok : chrToken(c, cls[off + k] & 0x7F);
+			}, myCnt, 64, biased);
+			if (biased) score -= chrBias;
+			W.unkChr[nBase + i] = score;
+			if (nd.form == NOFORM) continue;
+			const FormRec f = M.forms[nd.form];
+			const uint16_t* fs = M.formChars + f.charOff;
+			bool same = f.len == len;
+			for (uint32_t k = 0; same && k < len; ++k) same = fs[k] == str[off + k];
+			if (!same)
+			{
+				const uint16_t* ft = M.formChrTok + f.charOff;
+				substringCounts(text, textLen, fs, f.len, myCnt, 64);
+				score = chrFreqScore(C, Q, f.len, [&](uint32_t k) -> uint32_t { return ft[k]; }, myCnt, 64, biased);
+				if (biased) score -= chrBias;
+			}
+			W.unkChrForm[nBase + i] = score;
 		}
 	}
 }

@@ -6,6 +6,7 @@
 // (src/Knlm.hpp:1003-1167).  Everything is index based; nothing here is shared with oracle/_ref.
 #include <sys/stat.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -655,6 +656,9 @@ namespace kamd
 			m.chrDim = hd.dim; m.chrCtx = (uint32_t)hd.contextSize; m.chrVocab = (uint32_t)hd.vocabSize;
 			ChrView C = m.chrView();      // (host walk over the tables filled so far; embeddings follow)
 			// suffix links and inherited context ids, breadth first (CoNgramModel.cpp:547-568; findLowerNode / findLowerValue, CoNgramModel.hpp:181-227)
+			// ... and the depth of every node in TOKENS (CoNgramModel.cpp:551-572: the second byte of a two-byte spelling, key >= 224, does not count;
+			// CoNgramModel::getNodeDepth -- the frequency-based unknown-form score asks for it)
+			m.chrDepth.assign(nonLeaf, 0);
 			std::deque<uint32_t> dq{ 0u };
 			while (!dq.empty())
 			{
@@ -689,9 +693,14 @@ namespace kamd
 						if (!done) val = m.chrNodes[nd].value;
 						m.chrNodes[child].value = val;
 					}
+					m.chrDepth[child] = (uint16_t)(m.chrDepth[p] + (k >= 224 ? 0 : 1));
 					dq.push_back(child);
 				}
 			}
+			// CoNgramModel::getContextFrequency (CoNgramModel.hpp:76-86): dequantizeFrequencyScale of the byte on top of a trie value (:34-39; libm's powf, as there)
+			m.chrHasFreq = (hd.flags & 4) != 0;
+			m.chrFreqTab.assign(256, 0.f);
+			for (uint32_t q = 0; q < 256; ++q) m.chrFreqTab[q] = q <= 16 ? (float)q : powf(2.0f, ((float)q + 16) / 8.0f);
 			const size_t stride = (size_t)hd.dim + 8;
 			m.chrCtxEmb.assign(hd.contextSize * stride, 0); m.chrOutEmb.assign(hd.vocabSize * stride, 0);
 			const uint8_t* e = blob + hd.embOffset;
@@ -737,8 +746,8 @@ namespace kamd
 			// the state after <s> (UnkFormScorer::UnkFormScorer, src/UnkFormScorer.cpp:22-25)
 			C = m.chrView();
 			int32_t node = 0; uint32_t ctx = 0;
-			chrProgress(C, node, ctx, 0);
-			m.chrBosNode = node; m.chrBosCtx = ctx;
+			chrProgressPacked(C, node, ctx, 0);
+			m.chrBosNode = node; m.chrBosCtx = ctx & 0x00FFFFFFu; m.chrBosCtxPacked = ctx;
 		}
 
 		std::vector<uint8_t> readFile(const std::string& path, bool required)
@@ -1203,6 +1212,8 @@ namespace kamd
 				const ChrView C = m.chrView();
 				m.formUnkChr.assign(nF, 0.f);
 				for (size_t f = 0; f < nF; ++f) m.formUnkChr[f] = chrScoreHost(C, m.formChars.data() + m.forms[f].charOff, m.forms[f].len);
+				m.formChrTok.resize(m.formChars.size());
+				for (size_t i = 0; i < m.formChars.size(); ++i) m.formChrTok[i] = (uint16_t)chrToken(m.formChars[i], identifySpecialChr(m.formChars[i]));
 			}
 		}
 		if (raw.sbg)

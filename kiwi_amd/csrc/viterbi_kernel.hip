@@ -1989,7 +1989,7 @@ namespace sbgk
 					if (f.flags & FF_ENDS_WITH_SSC) of |= LF_STR_SSC;
 					cl = unkPacks + 1; clLds = Lay<G>::PCAP + 1; clN = 1; ok = 2;
 #ifdef KAMD_CONG
-					if (W.unkChr) disc = baseDiscount + (M.formUnkChr[node.form] - P.oovChrBias);
+					if (W.unkChr) disc = baseDiscount + ((W.unkChrForm ? W.unkChrForm[(uint32_t)(X.nodes - W.nodes) + i] : M.formUnkChr[node.form]) - P.oovChrBias);
 					else
 #endif
 					disc = baseDiscount + -((float)f.len * P.oovRuleScale + P.oovRuleBias);

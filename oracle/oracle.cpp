@@ -27,6 +27,7 @@ struct OracleHandle
 	BestPathConfig bcfg;
 	bool integrateAllomorph = true;
 	float oovChrBias = 0;      // KiwiConfig::oovChrBias
+	korc::ChrFreqConfig freq;  // KiwiConfig::oovGlobalWeight / oovLocalWeight / oovGlobalMinFreq
 	Counters counters;
 	std::vector<uint32_t> blockIds, blockBits;      // AnalyzeOption::blocklist of the following analyses (korc_blocklist_*)
 };
@@ -54,13 +55,20 @@ namespace
 		bc.topN = topN;
 		bc.splitComplex = match & M_SPLIT_COMPLEX; bc.splitSaisiot = match & M_SPLIT_SAISIOT; bc.mergeSaisiot = match & M_MERGE_SAISIOT;
 		bc.spaceTolerance = sc.spaceTol;
-		// Match::oovMask (include/kiwi/PatternMatcher.h:20-24): 1 = the character model scores unknown forms; 2 / 3 (with substring frequencies) are not restated
+		// Match::oovMask (include/kiwi/PatternMatcher.h:20-24): 1 = the character model scores unknown forms; 2 / 3: mixed with the substring counts of
+		// the filtered text (Kiwi.cpp:1058-1086, 1138; 3 -- "branch" -- evaluates the same expression: src/UnkFormScorer.cpp:118-121)
 		const kamd::ChrView chrV = h.model.chrView();
+		korc::SubstringCounts substr;
 		if ((match >> 8) & 3)
 		{
 			if (!chrV.present()) throw std::runtime_error{ "`oovChrModel` option is set but the character-level noun model is not loaded." };      // Kiwi.cpp:1032-1035
-			if (((match >> 8) & 3) > 1) throw std::runtime_error{ "oracle: oovChrFreqModel / oovChrFreqBranchModel are not restated" };
 			bc.chr = &chrV; bc.oovChrBias = h.oovChrBias;
+			if (((match >> 8) & 3) > 1)
+			{
+				const std::u16string filtered = korc::filteredText((const char16_t*)pt.norm.data(), pt.norm.size());
+				substr.build(filtered.data(), filtered.size());
+				bc.substr = &substr; bc.freq = h.freq;
+			}
 		}
 		LatticeBuilder lb{ h.view, sc, cnt };
 		TypoLatticeBuilder tlb{ h.view, sc };
@@ -242,6 +250,16 @@ extern "C"
 		return kamd::chrScoreHost(C, s, len);
 	}
 	void korc_set_oov_chr_bias(void* hp, float bias) { ((OracleHandle*)hp)->oovChrBias = bias; }
+	void korc_set_oov_freq_params(void* hp, float globalWeight, float localWeight, float globalMinFreq) { ((OracleHandle*)hp)->freq = korc::ChrFreqConfig{ globalWeight, localWeight, globalMinFreq }; }
+	// UnkFormScorer::chrFreqBasedScore of a (normalised) string against the substring counts of an (already filtered) text, bias 0
+	float korc_unk_chr_freq_score(void* hp, const uint16_t* text, uint32_t textLen, const uint16_t* s, uint32_t len)
+	{
+		auto& h = *(OracleHandle*)hp;
+		const kamd::ChrView C = h.model.chrView();
+		if (!C.present()) return 0.f / 0.f;
+		korc::SubstringCounts sc; sc.build((const char16_t*)text, textLen);
+		return korc::chrFreqScoreOracle(C, sc, h.freq, 0.f, s, len);
+	}
 
 	struct TypoHandle { korc::typo::Rules rules; std::unique_ptr<korc::typo::Prepared> prepared; };
 	size_t korc_split_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint64_t match, uint8_t* out, size_t cap);

@@ -43,6 +43,7 @@
 #include "MathFunc.hpp"
 #include "serializer.hpp"
 #include "UnkFormScorer.h"
+#include "SubstringCounter.hpp"
 
 #include "../kiwi_amd/csrc/container.hpp"
 #include "../kiwi_amd/csrc/raw_model.hpp"
@@ -153,6 +154,13 @@ namespace kiwi
 		static float unkChrScore(const Kiwi& k, const char16_t* s, size_t n)
 		{
 			UnkFormScorer sc{ 0.f, 0.f, k.nounChrMdl.get(), 0.f, nullptr };
+			return sc(U16StringView{ s, n });
+		}
+		static float unkChrFreqScore(const Kiwi& k, const char16_t* text, size_t textLen, const char16_t* s, size_t n)
+		{
+			const SubstringCounter counter{ text, textLen };
+			const KiwiConfig& c = k.globalConfig;
+			UnkFormScorer sc{ 0.f, 0.f, k.nounChrMdl.get(), 0.f, &counter, c.oovGlobalWeight, c.oovLocalWeight, c.oovGlobalMinFreq, false };
 			return sc(U16StringView{ s, n });
 		}
 		static bool hasChr(const Kiwi& k) { return !!k.nounChrMdl; }
@@ -576,6 +584,19 @@ extern "C"
 		return Acc::unkChrScore(kw, (const char16_t*)s, len);
 	}
 	void kref_set_oov_chr_bias(void* hp, float bias) { Acc::config(((RefHandle*)hp)->kw).oovChrBias = bias; }
+	void kref_set_oov_freq_params(void* hp, float globalWeight, float localWeight, float globalMinFreq)
+	{
+		auto& c = Acc::config(((RefHandle*)hp)->kw);
+		c.oovGlobalWeight = globalWeight; c.oovLocalWeight = localWeight; c.oovGlobalMinFreq = globalMinFreq;
+	}
+	// UnkFormScorer::chrFreqBasedScore (src/UnkFormScorer.cpp:68-116) of a normalised string through the reference's own scorer and its own SubstringCounter
+	// over an already filtered text, bias 0
+	float kref_unk_chr_freq_score(void* hp, const uint16_t* text, uint32_t textLen, const uint16_t* s, uint32_t len)
+	{
+		auto& kw = ((RefHandle*)hp)->kw;
+		if (!Acc::hasChr(kw)) return 0.f / 0.f;
+		return Acc::unkChrFreqScore(kw, (const char16_t*)text, textLen, (const char16_t*)s, len);
+	}
 #endif
 
 	// One SkipBigram state step through the reference (SbgState::nextImpl, src/SkipBigramModel.hpp:169-182); 16-bit vocabulary only.

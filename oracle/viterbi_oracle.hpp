@@ -25,6 +25,7 @@
 #include "../kiwi_amd/csrc/feature.hpp"
 #include "../kiwi_amd/csrc/post.hpp"
 #include "../kiwi_amd/csrc/cong_global.hpp"
+#include "unk_freq_oracle.hpp"
 
 namespace korc
 {
@@ -33,6 +34,8 @@ namespace korc
 		float cutOff = 8, spacePenalty = 7, typoCostWeight = 6, oovRuleScale = 4, oovRuleBias = 4;
 		// Match::oovChrModel: unknown forms are scored by the character model instead of the length rule (UnkFormScorer::operator(), src/UnkFormScorer.h:40-58)
 		const kamd::ChrView* chr = nullptr; float oovChrBias = 0;
+		// Match::oovChrFreqModel / oovChrFreqBranchModel: ... mixed with the substring counts of the (filtered) text under analysis (unk_freq_oracle.hpp)
+		const SubstringCounts* substr = nullptr; ChrFreqConfig freq;
 		uint32_t spaceTolerance = 0;
 		uint32_t topN = 1;
 		// container selection by number of incoming paths and the per-bucket key cap (BestPathContainer.hpp:275-277, 363-367);
@@ -981,6 +984,7 @@ namespace korc
 		// character model is in use, else ruleBasedScore (:27-51)
 		float unkScoreOf(const uint16_t* s, uint32_t len, bool emojiStart) const
 		{
+			if (cfg.chr && cfg.substr) return chrFreqScoreOracle(*cfg.chr, *cfg.substr, cfg.freq, cfg.oovChrBias, s, len);      // chrFreqBasedScore (src/UnkFormScorer.cpp:68-121)
 			if (cfg.chr) { float sc = kamd::chrScoreHost(*cfg.chr, s, len); sc -= cfg.oovChrBias; return sc; }
 			return unkScore(len, emojiStart);
 		}

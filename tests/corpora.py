@@ -1,5 +1,6 @@
 """Shared test inputs: synthetic sentences plus hand-written edge cases (patterns, brackets, quotes, numbers,
 multi-sentence texts, emoji, surrogates, empty / whitespace-only inputs)."""
+import random
 
 EDGE_TEXTS = [
     "가나다\x00", "abc\x00def 가\x00",      # U+0000 inside a text (the reference's own C test hands the terminator over as part of each line)
@@ -114,3 +115,18 @@ def force_lanes(monkeypatch, lanes):
     else:
         monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
         monkeypatch.delenv("KAMD_POS_PATH", raising=False)
+
+
+def repeated_unknown_texts(sm, n, seed):
+    """Texts in which unknown words recur (what Match::oovChrFreqModel is about): a few made-up words and dictionary words, repeated, between known text."""
+    rnd = random.Random(seed)
+    base = synthetic(sm, n, seed, min_jamo=5, max_jamo=60)
+    syll = "가나다라마바사아자차카타파하거너더러머버서어저고노도로모보소오조구누두루무부수우주"
+    out = []
+    for i, t in enumerate(base):
+        made = ["".join(rnd.choice(syll) for _ in range(rnd.randint(2, 5))) for _ in range(rnd.randint(1, 3))]
+        parts = t.split(" ")
+        for _ in range(rnd.randint(2, 8)):
+            parts.insert(rnd.randint(0, len(parts)), rnd.choice(made) + rnd.choice(["", "", "은", "를", "이"]))
+        out.append(" ".join(parts) + ("" if i % 4 else " " + t))
+    return out

@@ -11,9 +11,11 @@ from dataclasses import astuple
 import numpy as np
 import pytest
 
-from corpora import EDGE_TEXTS, dictionary_mix, fuzzed, synthetic
+from corpora import EDGE_TEXTS, dictionary_mix, fuzzed, repeated_unknown_texts, synthetic
 
 OOV_CHR_MODEL = 1 << 8      # Match::oovChrModel (include/kiwi/PatternMatcher.h:21)
+OOV_CHR_FREQ_MODEL = 2 << 8      # Match::oovChrFreqModel: ... mixed with the substring counts of the text under analysis (:22)
+OOV_CHR_FREQ_BRANCH_MODEL = 3 << 8      # Match::oovChrFreqBranchModel (:23; evaluates the same expression, src/UnkFormScorer.cpp:118-121)
 
 
 def _norm(res):
@@ -31,6 +33,8 @@ def chr_pair(small_cong_chr_model):
     for L, name in ((ref.lib, "kref"), (orc.lib, "korc")):
         f = getattr(L, name + "_unk_chr_score"); f.restype = C.c_float; f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         g = getattr(L, name + "_set_oov_chr_bias"); g.argtypes = [C.c_void_p, C.c_float]
+        f = getattr(L, name + "_unk_chr_freq_score"); f.restype = C.c_float; f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        g = getattr(L, name + "_set_oov_freq_params"); g.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
     return sm, ref, orc
 
 
@@ -93,3 +97,61 @@ def test_typo_correction_with_the_character_model_equals_reference(chr_pair):
         assert _norm(a) == _norm(orc.analyze_typo(ot, t, 2.5, 0, match=match)), t
         corrected += any(x.typo_cost > 0 for x in a[0][0])
     assert corrected >= 10
+
+
+def _split_codas(s):
+    return "".join(chr(ord(c) - (ord(c) - 0xAC00) % 28) + (chr(0x11A7 + (ord(c) - 0xAC00) % 28) if (ord(c) - 0xAC00) % 28 else "") if 0xAC00 <= ord(c) < 0xD7A4 else c for c in s)
+
+
+def _freq_score(L, name, h, text, s):
+    t = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+    u = np.frombuffer(s.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+    return getattr(L, name + "_unk_chr_freq_score")(h, t.ctypes.data, len(t), u.ctypes.data, len(u))
+
+
+@pytest.mark.parametrize("params", [(35.0, 3.0, 4.0), (60.0, 1.5, 1.0), (2.0, 8.0, 20.0)])
+def test_chr_freq_scores_of_strings_equal_reference(chr_pair, params):
+    """UnkFormScorer::chrFreqBasedScore (src/UnkFormScorer.cpp:68-116) with the reference's own SubstringCounter against the restatement
+    (oracle/unk_freq_oracle.hpp): strings that occur in the text once, several times, not at all; prefixes longer than the counter's 32 units
+    (the early exit of :101); other weights than the defaults."""
+    sm, ref, orc = chr_pair
+    ref.lib.kref_set_oov_freq_params(ref.h, *params); orc.lib.korc_set_oov_freq_params(orc.h, *params)
+    try:
+        rnd = random.Random(31)
+        words = [_split_codas(f) for f in sm.raw.forms[100:400] if f]
+        alphabet = "가나다라마바사아자차카타파한ᆯᆷabcXY019"
+        seen, mixed = set(), 0
+        for it in range(120):
+            pool = [rnd.choice(words) for _ in range(6)] + ["".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, 9))) for _ in range(4)]
+            if it % 10 == 0:
+                pool.append("".join(rnd.choice(alphabet) for _ in range(40)))      # longer than the counter's maximum length, repeated below
+            toks = [rnd.choice(pool) for _ in range(rnd.randint(5, 60))]
+            text = " ".join(toks) if it % 3 else "".join(t + rnd.choice(["", " ", "  "]) for t in toks)
+            for s in set(pool) | {"", rnd.choice(pool) + rnd.choice(pool), rnd.choice(pool)[:-1] or "a", "없는말" + rnd.choice(pool)}:
+                a, b = _freq_score(ref.lib, "kref", ref.h, text, s), _freq_score(orc.lib, "korc", orc.h, text, s)
+                assert a == b, (text, s, a, b)
+                seen.add(a)
+                mixed += a != _score(ref.lib, "kref", ref.h, s)
+        assert len(seen) > 500 and mixed > 300      # (the counts change the scores: the comparison is not vacuous)
+        assert -99999.0 in seen                     # (... and the early exit was taken)
+    finally:
+        ref.lib.kref_set_oov_freq_params(ref.h, 35.0, 3.0, 4.0); orc.lib.korc_set_oov_freq_params(orc.h, 35.0, 3.0, 4.0)
+
+
+@pytest.mark.parametrize("mode,bias", [(OOV_CHR_FREQ_MODEL, 0.0), (OOV_CHR_FREQ_MODEL, 2.5), (OOV_CHR_FREQ_BRANCH_MODEL, 0.0)])
+def test_analyses_with_the_frequency_based_scores_equal_reference(chr_pair, mode, bias):
+    """Whole analyses under Match::oovChrFreqModel / oovChrFreqBranchModel (Kiwi.cpp:1058-1086, 1138; PathEvaluator.hpp:1242-1252): the reference's SSE4.1 build vs the oracle."""
+    sm, ref, orc = chr_pair
+    import refbridge
+    match = refbridge.MATCH_ALL_WITH_NORMALIZING | mode
+    ref.lib.kref_set_oov_chr_bias(ref.h, bias); orc.lib.korc_set_oov_chr_bias(orc.h, bias)
+    try:
+        texts = repeated_unknown_texts(sm, 400, 861) + synthetic(sm, 150, 862, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 150, 863) + EDGE_TEXTS + fuzzed(sm, 200, 864)
+        differ = 0
+        for t in texts:
+            a = ref.analyze(t, match=match)
+            assert _norm(a) == _norm(orc.analyze(t, match=match)), repr(t)
+            differ += _norm(a) != _norm(ref.analyze(t, match=refbridge.MATCH_ALL_WITH_NORMALIZING | OOV_CHR_MODEL))
+        assert differ > 30      # (the counts change analyses against the frequency-free mode)
+    finally:
+        ref.lib.kref_set_oov_chr_bias(ref.h, 0.0); orc.lib.korc_set_oov_chr_bias(orc.h, 0.0)

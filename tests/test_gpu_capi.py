@@ -225,6 +225,13 @@ def test_concurrent_callers_on_one_handle(capi, kiwi, oracle, small_model):
 def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
     cfg = capi.kiwi_get_global_config(kiwi)
     assert cfg.cut_off_threshold == 8.0 and cfg.space_penalty == 7.0
+    assert (cfg.oov_global_weight, cfg.oov_local_weight, cfg.oov_global_min_freq) == (35.0, 3.0, 4.0)      # include/kiwi/Kiwi.h:157-159
+    cfg.oov_global_weight, cfg.oov_local_weight, cfg.oov_global_min_freq = 60.0, 1.5, 1.0
+    capi.kiwi_set_global_config(kiwi, cfg)
+    back = capi.kiwi_get_global_config(kiwi)
+    assert (back.oov_global_weight, back.oov_local_weight, back.oov_global_min_freq) == (60.0, 1.5, 1.0)
+    cfg.oov_global_weight, cfg.oov_local_weight, cfg.oov_global_min_freq = 35.0, 3.0, 4.0
+    capi.kiwi_set_global_config(kiwi, cfg)
     s = "가나다라 마바사"
     try:
         cfg.cut_off_threshold = 5.0

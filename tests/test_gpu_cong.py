@@ -149,3 +149,51 @@ def test_unknown_forms_scored_by_the_character_model(small_cong_chr_model, monke
         differ += _norm(y) != _norm(p)
     assert differ > 100
     dev.close()
+
+
+@pytest.mark.parametrize("lanes,top_n,mode,bias,params", [("16", 1, 2, 0.0, None), ("64", 1, 3, 2.5, (60.0, 1.5, 1.0)), ("64", 2, 2, 1.0, None)])
+def test_unknown_forms_scored_with_substring_frequencies(small_cong_chr_model, monkeypatch, lanes, top_n, mode, bias, params):
+    """Match::oovChrFreqModel / oovChrFreqBranchModel (SURVEY.md section 8 row f4): k_unk_chr_freq (substring counts of the filtered text + the character
+    model, tanhf / expf / logf restated from glibc: csrc/chr_freq.hpp, exact_math.hpp) + the search reading its per-node scores, against the oracle and --
+    where it travelled -- the real reference (UnkFormScorer + SubstringCounter + CoNgramModel, SSE4.1 build).  Long texts of many chunks count over the whole text."""
+    import ctypes as C
+    import oraclelib
+    import refbridge
+    from corpora import repeated_unknown_texts
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_cong_chr_model
+    force_lanes(monkeypatch, lanes)
+    match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (mode << 8)
+    orc = oraclelib.OracleKiwi(path)
+    orc.lib.korc_set_oov_chr_bias.argtypes = [C.c_void_p, C.c_float]
+    orc.lib.korc_set_oov_chr_bias(orc.h, bias)
+    orc.lib.korc_set_oov_freq_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    ref = None
+    if refbridge.x86_available() and top_n == 1:
+        ref = refbridge.RefKiwi(path, arch=3, x86=True)
+        ref.lib.kref_set_oov_chr_bias.argtypes = [C.c_void_p, C.c_float]
+        ref.lib.kref_set_oov_chr_bias(ref.h, bias)
+        ref.lib.kref_set_oov_freq_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    dev = KiwiAmd(path)
+    dev.set_oov_chr_bias(bias)
+    if params:
+        orc.lib.korc_set_oov_freq_params(orc.h, *params); dev.set_oov_freq_params(*params)
+        if ref is not None:
+            ref.lib.kref_set_oov_freq_params(ref.h, *params)
+    try:
+        texts = repeated_unknown_texts(sm, 1500, 941) + synthetic(sm, 300, 942, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 300, 943) + EDGE_TEXTS + fuzzed(sm, 300, 944)
+        texts += [". ".join(texts[k:k + 25]) + "." for k in range(0, 200, 25)]      # several chunks per text
+        texts += ["😀가나 😀가나 😀가나 ★다라★ ★다라★", "abc abc abc abcd abcd", "가" * 40 + " " + "가" * 40]
+        got = dev.analyze_batch(texts, top_n=top_n, match=match).to_python()
+        plain = dev.analyze_batch(texts, top_n=top_n, match=oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)).to_python()
+        differ = 0
+        for s, y, p in zip(texts, got, plain):
+            assert _norm(orc.analyze(s, top_n=top_n, match=match)) == _norm(y), (lanes, top_n, s)
+            if ref is not None:
+                assert _norm(ref.analyze(s, match=match)) == _norm(y), s
+            differ += _norm(y) != _norm(p)
+        assert differ > 100
+    finally:
+        if ref is not None:
+            ref.lib.kref_set_oov_freq_params(ref.h, 35.0, 3.0, 4.0); ref.lib.kref_set_oov_chr_bias(ref.h, 0.0)
+    dev.close()

@@ -626,6 +626,39 @@ def test_emulated_unknown_forms_scored_by_the_character_model(emu_libs, small_co
     dev.close()
 
 
+@pytest.mark.parametrize("lanes,top_n,mode,bias,params", [("16", 1, 2, 0.0, None), ("64", 2, 3, 2.5, (60.0, 1.5, 1.0))])
+def test_emulated_unknown_forms_scored_with_substring_frequencies(emu_libs, small_cong_chr_model, monkeypatch, lanes, top_n, mode, bias, params):
+    """Match::oovChrFreqModel / oovChrFreqBranchModel (row f4): k_unk_chr_freq counts the prefixes of every node's unknown form in the filtered text
+    (chr_freq.hpp) and mixes them into the character model's score with tanhf / expf / logf restated from glibc -- against the oracle (its own
+    substring table, libm), which tests/test_chr_oracle.py pins to the real UnkFormScorer + SubstringCounter of the reference.  Texts of several
+    chunks count over the WHOLE text."""
+    import ctypes as C
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from corpora import repeated_unknown_texts
+    sm, path = small_cong_chr_model
+    force_lanes(monkeypatch, lanes)
+    match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (mode << 8)
+    orc = oraclelib.OracleKiwi(path)
+    orc.lib.korc_set_oov_chr_bias.argtypes = [C.c_void_p, C.c_float]
+    orc.lib.korc_set_oov_chr_bias(orc.h, bias)
+    orc.lib.korc_set_oov_freq_params.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    dev.set_oov_chr_bias(bias)
+    if params:
+        orc.lib.korc_set_oov_freq_params(orc.h, *params); dev.set_oov_freq_params(*params)
+    texts = repeated_unknown_texts(sm, 60, 931) + synthetic(sm, 15, 932, min_jamo=5, max_jamo=100) + dictionary_mix(sm, 15, 933) + EDGE_TEXTS[:40]
+    texts += [". ".join(texts[:6]) + ".", "😀가나 😀가나 😀가나 ★다라★ ★다라★", "abc abc abc abcd abcd", "가" * 40 + " " + "가" * 40]
+    got = dev.analyze_batch(texts, top_n=top_n, match=match).to_python()
+    plain = dev.analyze_batch(texts, top_n=top_n, match=oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)).to_python()
+    differ = 0
+    for s, y, p in zip(texts, got, plain):
+        assert _norm(orc.analyze(s, top_n=top_n, match=match)) == _norm(y), (lanes, top_n, s)
+        differ += _norm(y) != _norm(p)
+    assert differ > 5
+    dev.close()
+
+
 def test_emulated_character_model_option_without_the_model_is_refused(emu_libs, small_cong_model):
     from kiwi_amd.api import KiwiAmd
     import oraclelib
