@@ -31,6 +31,10 @@ if kind == "chr":
     import oraclelib
     match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
     assert len(dev.analyze_batch(texts, match=match).to_python()) == len(texts)
+    # ... and Match::oovChrFreqModel: k_unk_chr_freq (substring counts over the filtered text, a column of LDS counters per lane); texts of several chunks
+    from corpora import repeated_unknown_texts
+    ft = repeated_unknown_texts(sm, 12, 623) + [". ".join(texts[:8]) + ".", "가" * 40 + " " + "가" * 40] + EDGE_TEXTS[:25]
+    assert len(dev.analyze_batch(ft, match=oraclelib.MATCH_ALL_WITH_NORMALIZING | (2 << 8)).to_python()) == len(ft)
     prod, _ = test_hipemu._typo_pair(lib, 1.0)
     rnd = random.Random(5)
     tt = [misspell(t, rnd, True, True) for t in texts[:12]]

@@ -76,19 +76,22 @@ def test_analyses_with_the_character_model_equal_reference(chr_pair, bias):
         ref.lib.kref_set_oov_chr_bias(ref.h, 0.0); orc.lib.korc_set_oov_chr_bias(orc.h, 0.0)
 
 
-def test_typo_correction_with_the_character_model_equals_reference(chr_pair):
-    """Match::oovChrModel together with a typo transformer (CoNgram model): the reference's SSE4.1 build vs the oracle."""
+@pytest.mark.parametrize("mode", [OOV_CHR_MODEL, OOV_CHR_FREQ_MODEL])
+def test_typo_correction_with_the_character_model_equals_reference(chr_pair, mode):
+    """Match::oovChrModel / oovChrFreqModel together with a typo transformer (CoNgram model): the reference's SSE4.1 build vs the oracle."""
     import oraclelib
     import refbridge
     from typo_cases import misspell
     sm, ref, orc = chr_pair
-    match = refbridge.MATCH_ALL_WITH_NORMALIZING | OOV_CHR_MODEL
+    match = refbridge.MATCH_ALL_WITH_NORMALIZING | mode
     name = "basic_with_continual"
     ents, cont, leng = refbridge.default_typo_entries(name)
     rt = refbridge.RefTypo(); rt.update_default(name); rt.prepare(True)
     ot = oraclelib.OracleTypo(); ot.update_entries(ents, cont, leng); ot.prepare(True)
     rnd = random.Random(17)
     tt = [misspell(t, rnd, True, True, False) for t in synthetic(sm, 70, 741, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 40, 742)] + EDGE_TEXTS[:30]
+    if mode != OOV_CHR_MODEL:
+        tt += [misspell(t, rnd, True, True, False) for t in repeated_unknown_texts(sm, 60, 743)]
     corrected = 0
     for t in tt:
         if not t.strip():

@@ -668,19 +668,23 @@ def test_emulated_character_model_option_without_the_model_is_refused(emu_libs, 
     dev.close()
 
 
-def test_emulated_typo_correction_with_the_character_model(emu_libs, small_cong_chr_model):
-    """Match::oovChrModel together with a typo transformer: k_unk_chr over the nodes of the typo lattices, the typo + CoNgram search kernel reading its scores."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_emulated_typo_correction_with_the_character_model(emu_libs, small_cong_chr_model, mode):
+    """Match::oovChrModel / oovChrFreqModel together with a typo transformer: k_unk_chr / k_unk_chr_freq over the nodes of the typo lattices, the typo + CoNgram search kernel reading its scores."""
     import random
     import oraclelib
     from kiwi_amd.api import KiwiAmd
     from typo_cases import misspell
     sm, path = small_cong_chr_model
-    match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (1 << 8)
+    match = oraclelib.MATCH_ALL_WITH_NORMALIZING | (mode << 8)
     prod, orc_t = _typo_pair(emu_libs[0], 1.0)
     orc = oraclelib.OracleKiwi(path)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     rnd = random.Random(19)
     texts = [misspell(t, rnd, True, True) for t in synthetic(sm, 40, 919, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 20, 920)] + EDGE_TEXTS[:20]
+    if mode == 2:
+        from corpora import repeated_unknown_texts
+        texts += [misspell(t, rnd, True, True) for t in repeated_unknown_texts(sm, 30, 923)]
     got = _analyze_typo(dev, prod, texts, 2.5, match=match)
     for t, y in zip(texts, got):
         assert _norm(orc.analyze_typo(orc_t, t, 2.5, 0, match=match)) == _norm(y), t
