@@ -17,14 +17,36 @@ namespace kamd
 	{
 		const uint32_t kb = S.ptrs[next], ke = S.ptrs[next + 1];
 		float a[16];
+		// std::lower_bound over the partners of `next` for all eight history words TOGETHER: the eight searches run over the same range, so they take the
+		// same number of halving steps and every step's eight probes are independent loads -- log2(partners) + 3 memory round trips for the whole mixture
+		// instead of eight searches one after the other (the search kernel is bound by exactly this chain: DESIGN.md, SkipBigram).  Invariant of a step:
+		// the answer lies in [base, base + len].
+		uint32_t base[8];
 #pragma unroll
-		for (int i = 0; i < 8; ++i)
+		for (int i = 0; i < 8; ++i) { base[i] = kb; a[i] = S.discnts[hist[i]] + ll; }
+		uint32_t len = ke - kb;
+		while (len > 1)
 		{
-			const uint32_t h = hist[i];
-			a[i] = S.discnts[h] + ll;
-			uint32_t lo = kb, hi = ke;      // std::lower_bound over the partners of `next`
-			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (S.keys[mid] < h) lo = mid + 1; else hi = mid; }
-			a[8 + i] = (lo < ke && S.keys[lo] == h) ? S.comps[lo] : -INFINITY;
+			const uint32_t half = len >> 1;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) base[i] += (S.keys[base[i] + half - 1] < hist[i]) ? half : 0u;
+			len -= half;
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) if (len == 1) base[i] += (S.keys[base[i]] < hist[i]) ? 1u : 0u;
+		// (key and compensation of the slot a search ended at are requested together, the compensation speculatively: one more round trip, not two)
+		if (ke > kb)
+		{
+			uint32_t fk[8]; float fc[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) { const uint32_t at = base[i] < ke ? base[i] : ke - 1; fk[i] = S.keys[at]; fc[i] = S.comps[at]; }
+#pragma unroll
+			for (int i = 0; i < 8; ++i) a[8 + i] = (base[i] < ke && fk[i] == hist[i]) ? fc[i] : -INFINITY;
+		}
+		else
+		{
+#pragma unroll
+			for (int i = 0; i < 8; ++i) a[8 + i] = -INFINITY;
 		}
 		float mx = a[0];
 #pragma unroll
