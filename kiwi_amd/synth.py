@@ -350,6 +350,7 @@ FULL_SBG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000
                           n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_sbg=True,   # FULL_SPEC's lexicon + skip-bigram tables (32-bit keys)
                           homonym_skew=4.0, lm_unk_rate=0.03)      # round 4: one reading of a homograph dominates, unknown NNG / NNP readings differ (a SkipBigram search needs both to prune: see the fields)
 SMALL_SPEC = SynthSpec()
+SMALL_ORDER4_SPEC = SynthSpec(lm_order=4, lm_sentences=60000)   # an order-4 Knlm (the reference's maximum, include/kiwi/Kiwi.h:611): contexts of three words, back-off chains one node longer than what a search state carries
 SMALL_Q8_SPEC = SynthSpec(knlm_qbits=8, knlm_compress=True)   # SMALL_SPEC with the Knlm file as the reference ships it: 8-bit quantised, node sizes compressed
 SMALL_Q5_SPEC = SynthSpec(knlm_qbits=5)                       # ... and a bit width that exercises the generic fixed-length bit stream
 SMALL_HTX_SPEC = SynthSpec(use_htx=True)                       # SMALL_SPEC with a history-transformed Knlm (tag histories: what the reference's builder writes by default)

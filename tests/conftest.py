@@ -25,6 +25,18 @@ def small_model(tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def small_order4_model():
+    """SMALL_SPEC's lexicon with an order-4 Knlm (kiwi_amd/synth.py SMALL_ORDER4_SPEC)."""
+    from kiwi_amd.synth import SynthModel, SMALL_ORDER4_SPEC
+    d = os.path.join(ROOT, "_data")
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "small-order4.raw")
+    sm = SynthModel(SMALL_ORDER4_SPEC)
+    sm.raw.save(path)
+    return sm, path
+
+
+@pytest.fixture(scope="session")
 def small_sbg_model():
     """The small synthetic model plus SkipBigram tables (same lexicon and Knlm; kiwi_amd/synth.py SMALL_SBG_SPEC)."""
     from kiwi_amd.synth import SynthModel, SMALL_SBG_SPEC

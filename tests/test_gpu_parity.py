@@ -223,6 +223,32 @@ def test_top_n_bit_exact_vs_oracle(engine, oracle, small_model, top_n):
         assert _norm(oracle.analyze(s, top_n=top_n)) == _norm(y), s
 
 
+@pytest.mark.parametrize("lanes", ["pos", "16", "64"])
+def test_order_4_knlm_bit_exact_vs_oracle_and_reference(small_order4_model, monkeypatch, lanes):
+    """An order-4 Knlm (order <= 4): contexts of three words, so a back-off chain is one node longer than the pair a search
+    state carries (ModelView::lmChain) and the one-round-trip probe hands its tail to the general walk -- position-step kernel, 16- and 64-lane general
+    kernels, top-1 and top-3, against the oracle and the real reference."""
+    import oraclelib
+    import refbridge
+    from corpora import force_lanes
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_order4_model
+    force_lanes(monkeypatch, lanes)
+    orc = oraclelib.OracleKiwi(path)
+    ref = refbridge.RefKiwi(path) if refbridge.available() else None
+    dev = KiwiAmd(path)
+    texts = synthetic(sm, 1500, 1101, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 500, 1102) + EDGE_TEXTS + fuzzed(sm, 300, 1103)
+    got = dev.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s)) == _norm(y), (lanes, s)
+        if ref is not None:
+            assert _norm(ref.analyze(s)) == _norm(y), (lanes, s)
+    got3 = dev.analyze_batch(texts[:600], top_n=3).to_python()
+    for s, y in zip(texts[:600], got3):
+        assert _norm(orc.analyze(s, top_n=3)) == _norm(y), (lanes, s)
+    dev.close()
+
+
 def test_top_n_beyond_the_device_limit_is_refused_loudly(engine):
     with pytest.raises(RuntimeError):
         engine.analyze_batch(["가나다"], top_n=17)

@@ -67,6 +67,26 @@ def test_emulated_knlm_kernels_match_oracle(emu_libs, oracle, small_model, monke
     dev.close()
 
 
+@pytest.mark.parametrize("lanes", ["pos", "16", "64"])
+def test_emulated_order_4_knlm(emu_libs, small_order4_model, monkeypatch, lanes):
+    """An order-4 Knlm (the reference's maximum): back-off chains one node longer than the pair a search state carries (ModelView::lmChain) -- the
+    one-round-trip probe of the position-step kernel hands the tail to the general walk.  Oracle == real reference on the same model first."""
+    import oraclelib
+    import refbridge
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_order4_model
+    force_lanes(monkeypatch, lanes)
+    orc = oraclelib.OracleKiwi(path)
+    texts = synthetic(sm, 120, 1111, min_jamo=5, max_jamo=120) + dictionary_mix(sm, 50, 1112) + EDGE_TEXTS[:60] + fuzzed(sm, 60, 1113)
+    if lanes == "pos" and refbridge.available():
+        ref = refbridge.RefKiwi(path)
+        for t in texts + synthetic(sm, 400, 1114, min_jamo=5, max_jamo=150):
+            assert _norm(ref.analyze(t)) == _norm(orc.analyze(t)), t
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    _check(dev, orc, texts, (1, 3))
+    dev.close()
+
+
 @pytest.mark.parametrize("lanes", ["pos", "16", "8", "64"])
 def test_emulated_fallback_paths_with_small_capacities(emu_libs, small_model, monkeypatch, lanes):
     """The `smallcaps` configuration (LDS capacities of 4) with the container limits cut to 3 / 8 / 2 on both sides:
