@@ -137,7 +137,7 @@ namespace kamd
 		const DevPattern* patterns;
 		const uint32_t* spOff;         // [nChunks+1] into spStates: sorted unique previous SpecialStates of the chunk
 		const uint8_t* spStates;
-		const uint8_t* chunkFlags;     // bit0: openEnding applies to this chunk
+		const uint8_t* chunkFlags;     // bit0: openEnding applies to this chunk; bit1: the only chunk of its text (a top-1 analysis needs its best path only: k_finish_paths)
 		const uint32_t* textOffset;    // [nChunks] offset of the chunk inside its normalised text (Kiwi.cpp:1095-1117 `splitEnd`)
 		// Match::oovChrFreqModel only (null otherwise): the FILTERED normalised text a chunk belongs to (Kiwi.cpp:1058-1086: special characters and spaces
 		// blanked) -- the whole text, not the chunk: substring frequencies are counted over it (chr_freq.hpp)

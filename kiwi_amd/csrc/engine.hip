@@ -160,7 +160,7 @@ namespace kamd
 
 	}
 
-	struct ChunkRef { uint32_t text, chunk; std::vector<uint8_t> sp; bool openEnding; };
+	struct ChunkRef { uint32_t text, chunk; std::vector<uint8_t> sp; bool openEnding; bool onlyChunk = false; };      // onlyChunk: the text has no other chunk to analyse
 
 	struct StagedBatch
 	{
@@ -495,7 +495,7 @@ namespace kamd
 				for (uint32_t k = d.patBegin; k < d.patEnd; ++k) pats[k - d.patBegin] = DevPattern{ pt.patterns[k].end, pt.patterns[k].length, pt.patterns[k].tag };
 				for (uint32_t k = 0; k < d.nChars; ++k) if (!isSpace(pt.norm[d.startOffset + k])) ++u;
 				if (!r.sp.empty()) std::memcpy(H + oSp + b.spOff[c], r.sp.data(), r.sp.size());
-				H[oFlags + c] = r.openEnding ? 1 : 0;
+				H[oFlags + c] = (r.openEnding ? 1 : 0) | (r.onlyChunk ? 2 : 0);
 				reinterpret_cast<uint32_t*>(H + oTextOff)[c] = d.startOffset;
 				if (chrFreq) { reinterpret_cast<uint32_t*>(H + oFiltOff)[c] = filtAt[r.text]; reinterpret_cast<uint32_t*>(H + oFiltLen)[c] = (uint32_t)pt.norm.size(); }
 			}
@@ -1331,11 +1331,13 @@ namespace kamd
 		for (size_t i = 0; i < texts.size(); ++i)
 		{
 			const auto& pt = b->prep[i];
+			size_t live = 0;
+			for (size_t c = 0; c < pt.chunks.size(); ++c) live += pt.chunks[c].empty ? 0 : 1;
 			for (size_t c = 0; c < pt.chunks.size(); ++c)
 			{
 				if (pt.chunks[c].empty) continue;
 				if (pt.chunks[c].nChars > 0xFFF0) throw std::runtime_error{ "chunk longer than 65520 units" };
-				b->refs.push_back(ChunkRef{ (uint32_t)i, (uint32_t)c, { 0 }, openEnding && pt.chunks[c].nextOffset == pt.norm.size() });
+				b->refs.push_back(ChunkRef{ (uint32_t)i, (uint32_t)c, { 0 }, openEnding && pt.chunks[c].nextOffset == pt.norm.size(), live == 1 });
 			}
 		}
 		tm.lap("text preparation");

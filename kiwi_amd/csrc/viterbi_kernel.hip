@@ -1736,7 +1736,7 @@ namespace sbgk
 		const uint32_t chunk = chunkBegin + (t < chunkCount ? t : 0u);
 		DevChunkResult* res = &W.results[chunk];
 		const bool active = t < chunkCount && res->status == CS_OK;
-		uint32_t nEnd = 0, nBase = 0, Gn = 0, perGroup = 0, nSel = 0;
+		uint32_t nEnd = 0, nBase = 0, Gn = 0, perGroup = 0, nSel = 0, bestOnly = 0xFFFFFFFFu;
 		DevState* st = nullptr; EndCand* endBuf = nullptr; uint32_t* chain = nullptr; const uint8_t* uniq = nullptr;
 		if (active)
 		{
@@ -1756,6 +1756,20 @@ namespace sbgk
 			{
 				if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
 				if (a - startIdx < perGroup) ++nSel;
+			}
+			// The only chunk of its text under top-1: of the 2 N paths the reference hands on (PathEvaluator.hpp:1359-1418) only the best one can become the
+			// analysis -- Kiwi::analyze sorts what insertPathIntoResults kept by score and cuts to N (Kiwi.cpp:1143-1158), and with no second chunk nothing
+			// is combined with the rest.  That is the first of the selected paths in the host's order: highest score, the earlier one of equal scores (its sort
+			// of these few paths is an insertion sort).  The groups' first candidates are their best ones, so it is the best of those.  One back-trace, one
+			// path and its tokens over PCIe instead of two.
+			if (P.topN == 1 && (B.chunkFlags[chunk] & 2) && nSel > 1)
+			{
+				for (uint32_t a = 0; a < nEnd; ++a)
+				{
+					if (a && endBuf[a].rootId == endBuf[a - 1].rootId && endBuf[a].sp == endBuf[a - 1].sp) continue;
+					if (bestOnly == 0xFFFFFFFFu || endBuf[a].score > endBuf[bestOnly].score) bestOnly = a;
+				}
+				nSel = 1;
 			}
 		}
 		// output range of the path headers: wave prefix sum + one atomic per wave
@@ -1780,6 +1794,7 @@ namespace sbgk
 			{
 				if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
 				if (a - startIdx >= perGroup) continue;
+				if (bestOnly != 0xFFFFFFFFu && a != bestOnly) continue;
 				const int nt = backTrace(M, P, W.nodes + nBase, st, endBuf[a].parent, tok + tokTop, tokCap - tokTop, chain, Gn);
 				if (nt < 0) { status = CS_ERR_TOKEN_OVERFLOW; break; }
 				DevPathHeader ph;
