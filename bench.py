@@ -70,14 +70,26 @@ def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None, time_refe
     n_mt = int(min(len(texts), max(64 * cores, rate1 * min(cores, phys) * 1.0)))
     smt, pmt, _ = runner.analyze_batch_timed(texts[:n_mt], top_n=top_n, threads=cores, min_seconds=max(2.0, budget_s / 4), typo=rtypo, typo_threshold=thr)
     rate = n_mt * pmt / smt
+    # Under a CFS quota far below the visible CPUs a thread per logical CPU is not the reference's best showing (its pool is sized by the caller:
+    # kiwi_init(num_threads)): the baseline is its BEST rate over {all logical CPUs, 4 x, 2 x, 1 x the quota}, every count reported.
+    by_threads = {cores: rate}
+    quota = cpu_quota_cores()
+    best_threads = cores
+    if quota and quota * 4 < cores:
+        for k in (4, 2, 1):
+            th = max(1, int(round(k * quota)))
+            s_k, p_k, _ = runner.analyze_batch_timed(texts[:n_mt], top_n=top_n, threads=th, min_seconds=2.0, typo=rtypo, typo_threshold=thr)
+            by_threads[th] = n_mt * p_k / s_k
+            if by_threads[th] > rate:
+                rate, best_threads, smt, pmt = by_threads[th], th, s_k, p_k
     # what the box lets this process use: the same thread count on register-only work (a container can see every logical CPU of the host and be
     # scheduled on a fraction of them); the baseline cannot scale beyond it
     usable = oraclelib.cpu_capacity(cores, 1.0)
-    out["cpu_baseline"] = {"value": rate, "unit": "sentences/s", "cores": cores, "kind": kind,
-                           "threads": cores, "physical_cores": phys, "cpu_quota_cores": cpu_quota_cores(), "usable_cores_measured": usable, "single_thread": rate1,
+    out["cpu_baseline"] = {"value": rate, "unit": "sentences/s", "cores": best_threads, "logical_cpus": cores, "kind": kind,
+                           "threads": best_threads, "rate_by_threads": {str(k): round(v, 1) for k, v in sorted(by_threads.items())}, "physical_cores": phys, "cpu_quota_cores": cpu_quota_cores(), "usable_cores_measured": usable, "single_thread": rate1,
                            "scaling_efficiency_vs_physical_cores": rate / (rate1 * max(1, min(cores, phys))),
                            "scaling_efficiency_vs_usable_cores": rate / (rate1 * max(1.0, min(usable, float(phys)))),
-                           "sample": f"{pmt} timed passes over {n_mt} sentences of the same workload ({smt:.2f} s) on {cores} persistent threads after one untimed warm-up pass "
+                           "sample": f"{pmt} timed passes over {n_mt} sentences of the same workload ({smt:.2f} s) on {best_threads} persistent threads (the best of the thread counts in rate_by_threads) after one untimed warm-up pass "
                                      f"(reference arch {arch_name}; texts handed out through one atomic counter, results dropped); single thread: {rate1:.0f} sentences/s ({p1} passes over {len(sample)})"}
     return out
 

@@ -458,6 +458,7 @@ extern "C"
 			if (largest && h->engine->congWindow()) throw std::invalid_argument{ "kiwi_amd: KIWI_BUILD_MODEL_TYPE_LARGEST on a CoNgram model with distant-token sections means the global (window " + std::to_string(h->engine->congWindow()) + ") scoring, which the device path does not do yet; ask for KIWI_BUILD_MODEL_TYPE_CONG (local scoring) explicitly" };
 			h->engine->config.integrateAllomorph = !!(options & 1);
 			h->numThreads = num_threads < 0 ? 0 : (num_threads == 0 ? 1 : num_threads);
+			if (const char* bs = std::getenv("KAMD_CAPI_BATCH")) { const int v = std::atoi(bs); if (v > 0) h->batchSize = v; }      // (developer knob; kiwi_set_option(KIWI_GPU_BATCH_SIZE) is the API)
 			return h.release();
 		}
 		catch (const std::exception& e) { setError(e); return nullptr; }

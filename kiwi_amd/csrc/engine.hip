@@ -160,7 +160,22 @@ namespace kamd
 
 	}
 
-	struct ChunkRef { uint32_t text, chunk; std::vector<uint8_t> sp; bool openEnding; bool onlyChunk = false; };      // onlyChunk: the text has no other chunk to analyse
+	// the sorted, distinct special states a chunk is searched under: almost always {0}.  Kept inline up to 14 of them -- one heap block per chunk was
+	// 65 536 allocations when a batch is staged and as many frees when it is released, on the calling thread (3 + 3 ms of a 29 ms end-to-end batch)
+	struct SpSet
+	{
+		uint8_t n = 0; uint8_t v[14] = {}; std::vector<uint8_t> big;
+		SpSet() = default;
+		SpSet(std::initializer_list<uint8_t> l) { assign(l.begin(), l.size()); }
+		void assign(const uint8_t* p, size_t k) { big.clear(); if (k <= sizeof(v)) { n = (uint8_t)k; if (k) std::memcpy(v, p, k); } else { n = 0xFF; big.assign(p, p + k); } }
+		SpSet& operator=(const std::vector<uint8_t>& o) { assign(o.data(), o.size()); return *this; }
+		size_t size() const { return n == 0xFF ? big.size() : n; }
+		bool empty() const { return size() == 0; }
+		const uint8_t* data() const { return n == 0xFF ? big.data() : v; }
+		bool operator==(const std::vector<uint8_t>& o) const { return o.size() == size() && (o.empty() || std::memcmp(o.data(), data(), o.size()) == 0); }
+		bool operator!=(const std::vector<uint8_t>& o) const { return !(*this == o); }
+	};
+	struct ChunkRef { uint32_t text, chunk; SpSet sp; bool openEnding; bool onlyChunk = false; };      // onlyChunk: the text has no other chunk to analyse
 
 	struct StagedBatch
 	{
@@ -754,6 +769,7 @@ namespace kamd
 		KernelTimes t;
 		const uint32_t nC = (uint32_t)b.refs.size();
 		if (!nC) return t;
+		HostTimer tm{ "launch" };
 		hipStream_t sA = I.stream, sB = I.stream2;
 		// Sub-batches: the lattice stages of sub-batch k+1 (few, long-running waves) overlap the search of sub-batch k
 		// (many latency-bound waves) on a second stream.
@@ -765,13 +781,21 @@ namespace kamd
 		S = std::min(S, std::min(nC, 16u));
 		if (b.subBatches != S)
 		{
-			// work order of the search kernel: longest chunks first inside each sub-batch
+			// work order of the search kernel: longest chunks first inside each sub-batch (a stable counting sort by length: this runs once per batch on the
+			// calling thread, between the upload and the first launch)
 			std::vector<uint32_t> order(nC);
-			std::iota(order.begin(), order.end(), 0u);
-			for (uint32_t k = 0; k < S; ++k)
 			{
-				const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S);
-				std::stable_sort(order.begin() + c0, order.begin() + c1, [&](uint32_t a, uint32_t c) { return b.charOff[a + 1] - b.charOff[a] > b.charOff[c + 1] - b.charOff[c]; });
+				uint32_t maxLen = 0;
+				for (uint32_t c = 0; c < nC; ++c) maxLen = std::max(maxLen, b.charOff[c + 1] - b.charOff[c]);
+				std::vector<uint32_t> at(maxLen + 2);
+				for (uint32_t k = 0; k < S; ++k)
+				{
+					const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S);
+					std::fill(at.begin(), at.end(), 0u);
+					for (uint32_t c = c0; c < c1; ++c) ++at[maxLen - (b.charOff[c + 1] - b.charOff[c]) + 1];      // bucket = maxLen - length: longest first
+					for (uint32_t l = 0; l <= maxLen; ++l) at[l + 1] += at[l];
+					for (uint32_t c = c0; c < c1; ++c) order[c0 + at[maxLen - (b.charOff[c + 1] - b.charOff[c])]++] = c;
+				}
 			}
 			upload(b.dOrder, order, sA);
 			b.order = order;
@@ -828,10 +852,15 @@ namespace kamd
 			const uint32_t classesKey = ratioKey * 31u + budget / 16u;
 			if (b.latClassesKey != classesKey || b.latClasses.size() != S)
 			{
+				// (the LDS need of a chunk is a function of its length -- its HBM capacities are -- : worked out once per length, not per chunk; a batch of
+				// 65 536 chunks asked this 200 000 times on the calling thread, 7 ms of a 29 ms end-to-end batch)
+				std::vector<uint32_t> needByLen;
 				auto needOf = [&](uint32_t c)
 				{
 					const uint32_t nCh = b.charOff[c + 1] - b.charOff[c], nodeCap = b.nodeBase[c + 1] - b.nodeBase[c], matchCap = b.matchBase[c + 1] - b.matchBase[c];
-					return wave ? latticeWaveLayout(nCh, nodeCap, matchCap, ratioKey).total : latticeLdsLayout(nCh, nodeCap, matchCap).total;
+					if (nCh >= needByLen.size()) needByLen.resize(nCh + 1, 0u);
+					if (!needByLen[nCh]) needByLen[nCh] = wave ? latticeWaveLayout(nCh, nodeCap, matchCap, ratioKey).total : latticeLdsLayout(nCh, nodeCap, matchCap).total;
+					return needByLen[nCh];
 				};
 				b.latClasses.assign(S, {});
 				for (uint32_t k = 0; k < S; ++k)
@@ -858,6 +887,7 @@ namespace kamd
 				b.latClassesKey = classesKey;
 			}
 		}
+		tm.lap("work order, size classes, scratch");
 		for (uint32_t k = 0; k < S; ++k)
 		{
 			const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S), cn = c1 - c0;
@@ -1109,8 +1139,10 @@ namespace kamd
 			}
 		}
 		HIPCHECK(hipGetLastError());
+		tm.lap("enqueueing the launches");
 		HIPCHECK(hipStreamSynchronize(sA));
 		HIPCHECK(hipStreamSynchronize(sB));
+		tm.lap("waiting for the kernels");
 		if (getenv("KAMD_POS_BEACON") && getenv("KAMD_POS_PHASES") && posBeacon.p)
 		{
 			// developer aid (KAMD_POS_DEBUG build): cycles per phase of a position step, averaged over the chunks' steps
@@ -1357,7 +1389,9 @@ namespace kamd
 	{
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		HIPCHECK(hipSetDevice(impl->device));
+		HostTimer tm{ "run" };
 		KernelTimes t = launchAll(*impl, b, makeParams(config, b.match, b.topN));
+		tm.lap("work order + launches + kernels");
 		b.overIdx.clear(); b.overPaths.clear(); b.rerunChunks = 0; b.rerunMs = 0;
 		const size_t nC = b.refs.size();
 		uint32_t nOver = 0;
@@ -1495,12 +1529,12 @@ namespace kamd
 				uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
 				if (uniq.empty()) uniq.push_back(0);
 				const uint32_t st = b.hResults[c].status;
-				if (st >= 16 && uniq == b.refs[c].sp && c < overIdx.size() && overIdx[c] != SIZE_MAX)
+				if (st >= 16 && b.refs[c].sp == uniq && c < overIdx.size() && overIdx[c] != SIZE_MAX)
 				{
 					if (!overPaths[overIdx[c]].empty()) rb.insertPaths(overPaths[overIdx[c]]);
 					continue;
 				}
-				if (st >= 16 || uniq != b.refs[c].sp)
+				if (st >= 16 || b.refs[c].sp != uniq)
 				{
 					if (!mayRerun) return false;
 					std::vector<std::vector<PathResult>> one;
@@ -1548,7 +1582,11 @@ namespace kamd
 		auto b = stage(texts, match, openEnding, hostThreads, typo);
 		b->topN = (uint32_t)topN;
 		run(*b);
-		return fetch(*b, topN);
+		BatchResults r = fetch(*b, topN);
+		HostTimer tm{ "batch" };
+		b.reset();
+		tm.lap("release of the staged batch");
+		return r;
 	}
 
 	std::vector<uint8_t> Engine::dumpLattices(const char16_t* text, size_t n, uint64_t match)
