@@ -5,7 +5,7 @@
 // The reference counts every substring of at most 32 units of the FILTERED text (Kiwi.cpp:1058-1086: special characters and spaces become ' ', and a
 // substring never spans a ' ') in a hash table (src/SubstringCounter.hpp) and looks the prefixes of a form up by content.  Here a form's counts come from one
 // pass over the filtered text: the longest common prefix of the form and the text at every position (substringCounts).  Device code (k_unk_chr_freq) and
-// the host side of the engine share this file; the oracle restates the scorer on its own (oracle/viterbi_oracle.hpp).
+// the host side of the engine share this file; the test oracle restates the scorer on its own, with libm and a content-keyed table.
 #pragma once
 #include "flat_model.hpp"
 #include "exact_math.hpp"
