@@ -212,6 +212,8 @@ namespace kamd
 		BatchView bv{}; WorkView wv{};
 		const DevChunkResult* hResults = nullptr; const DevPathHeader* hPaths = nullptr; const DevToken* hTokens = nullptr;   // inside hOut
 		bool ran = false;
+		hipEvent_t evDone = nullptr; bool launched = false; uint32_t launchS = 1;      // recorded behind the batch's last kernel (Engine::launch); Engine::finish waits for it
+		~StagedBatch() { if (evDone) (void)hipEventDestroy(evDone); }
 		uint32_t subBatches = 0;
 		uint32_t topN = 1;            // the search of the last run() kept this many paths per key
 		// chunks of the last run that overflowed and were searched again with larger capacities: index into overPaths per chunk (SIZE_MAX: none)
@@ -229,6 +231,12 @@ namespace kamd
 		std::vector<std::unique_ptr<DevBuf>> modelBufs;
 		hipStream_t stream = nullptr, stream2 = nullptr;   // lattice stages / search stage (sub-batches overlap)
 		hipStream_t latStream[3] = { nullptr, nullptr, nullptr };   // the lattice kernel's LDS size classes are launched round-robin over `stream` and these: their tails overlap
+		// Batches in flight (Engine::launch / finish: the host prepares the next part of a large batch while the kernels of the previous one run): uploads and
+		// downloads go over `streamCopy`, so that waiting for them never waits for kernels of another batch queued on `stream` / `stream2`; the kernels of two
+		// batches do NOT overlap -- the first launch of a batch waits for `lastDone`, the end of the batch launched before it (the engine's scratch
+		// blocks, work counters and timing events are shared) -- what overlaps is host work with device work.
+		hipStream_t streamCopy = nullptr;
+		hipEvent_t lastDone = nullptr, joinEv = nullptr; bool haveLast = false;
 		hipEvent_t latFork = nullptr, latJoin[3] = { nullptr, nullptr, nullptr };
 		std::vector<hipEvent_t> evs;
 		int subBatches = 0;   // 0 = automatic
@@ -312,6 +320,8 @@ namespace kamd
 		HIPCHECK(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));
 		HIPCHECK(hipStreamCreateWithFlags(&impl->stream2, hipStreamNonBlocking));
 		for (auto& ls : impl->latStream) HIPCHECK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+		HIPCHECK(hipStreamCreateWithFlags(&impl->streamCopy, hipStreamNonBlocking));
+		HIPCHECK(hipEventCreateWithFlags(&impl->lastDone, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&impl->joinEv, hipEventDisableTiming));
 		HIPCHECK(hipEventCreate(&impl->latFork)); for (auto& ev : impl->latJoin) HIPCHECK(hipEventCreate(&ev));
 
 		if (const char* sb = std::getenv("KAMD_SUBBATCHES")) impl->subBatches = std::atoi(sb);
@@ -414,6 +424,9 @@ namespace kamd
 			if (impl->stream) (void)hipStreamDestroy(impl->stream);
 			if (impl->stream2) (void)hipStreamDestroy(impl->stream2);
 			for (auto ls : impl->latStream) if (ls) (void)hipStreamDestroy(ls);
+			if (impl->streamCopy) (void)hipStreamDestroy(impl->streamCopy);
+			if (impl->lastDone) (void)hipEventDestroy(impl->lastDone);
+			if (impl->joinEv) (void)hipEventDestroy(impl->joinEv);
 			if (impl->latFork) (void)hipEventDestroy(impl->latFork);
 			for (auto ev : impl->latJoin) if (ev) (void)hipEventDestroy(ev);
 		}
@@ -536,7 +549,7 @@ namespace kamd
 			});
 		}
 		b.units = units;
-		hipStream_t s = I.stream;
+		hipStream_t s = I.streamCopy;      // (uploads, and the typo graph kernels over this batch's own buffers: never behind another batch's kernels)
 		if (top) HIPCHECK(hipMemcpyAsync(b.dIn.p, H, top, hipMemcpyHostToDevice, s));
 		uint8_t* D = b.dIn.as<uint8_t>();
 		const size_t perChar = totChars + nC + 16;
@@ -764,7 +777,9 @@ namespace kamd
 #endif
 	static DevBuf lwProf;         // developer aid (make lwprof + KAMD_LATTICE_PROFILE=1): phase cycle sums of k_lattice_wave
 	static DevBuf posBeacon;      // developer aid (KAMD_POS_DEBUG builds): progress beacons / phase timers of k_pos_path, 256 bytes per chunk (KAMD_POS_BEACON=1)
-	static KernelTimes launchAll(Engine::Impl& I, StagedBatch& b, const SearchParams& sp)
+	// wait = false: returns when everything is enqueued (Engine::launch); afterLaunch() is then the caller's business once the batch's `evDone` has fired
+	static void afterLaunch(Engine::Impl& I, StagedBatch& b, KernelTimes& t, bool timed);
+	static KernelTimes launchAll(Engine::Impl& I, StagedBatch& b, const SearchParams& sp, bool wait = true)
 	{
 		KernelTimes t;
 		const uint32_t nC = (uint32_t)b.refs.size();
@@ -797,7 +812,7 @@ namespace kamd
 					for (uint32_t c = c0; c < c1; ++c) order[c0 + at[maxLen - (b.charOff[c + 1] - b.charOff[c])]++] = c;
 				}
 			}
-			upload(b.dOrder, order, sA);
+			upload(b.dOrder, order, I.streamCopy);      // (not on the kernels' stream: behind a batch in flight a copy from pageable memory would hold the caller until that batch has finished)
 			b.order = order;
 			b.subBatches = S;
 			if (b.typo.typo)
@@ -810,11 +825,13 @@ namespace kamd
 					const uint32_t c0 = (uint32_t)((uint64_t)nC * k / S), c1 = (uint32_t)((uint64_t)nC * (k + 1) / S);
 					std::stable_sort(b.typoOrder.begin() + c0, b.typoOrder.begin() + c1, [&](uint32_t a, uint32_t c) { return b.typoNeed[a] > b.typoNeed[c]; });
 				}
-				upload(b.dTypoOrder, b.typoOrder, sA);
+				upload(b.dTypoOrder, b.typoOrder, I.streamCopy);
 			}
+			HIPCHECK(hipStreamSynchronize(I.streamCopy));
 		}
 		const size_t nEv = 6 * (size_t)S + 2;
 		while (I.evs.size() < nEv) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); I.evs.push_back(e); }
+		if (I.haveLast) HIPCHECK(hipStreamWaitEvent(sA, I.lastDone, 0));      // the kernels of two batches do not overlap (shared scratch, counters, events)
 		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), sA));
 		HIPCHECK(hipMemsetAsync(b.dOutCounters.p, 0, 64, sA));
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
@@ -1139,10 +1156,25 @@ namespace kamd
 			}
 		}
 		HIPCHECK(hipGetLastError());
+		// the end of the batch on the device: stream B behind everything stream A was given
+		HIPCHECK(hipEventRecord(I.joinEv, sA)); HIPCHECK(hipStreamWaitEvent(sB, I.joinEv, 0));
+		if (!b.evDone) HIPCHECK(hipEventCreateWithFlags(&b.evDone, hipEventDisableTiming));
+		HIPCHECK(hipEventRecord(b.evDone, sB)); HIPCHECK(hipEventRecord(I.lastDone, sB));
+		I.haveLast = true; b.launched = true; b.launchS = S;
 		tm.lap("enqueueing the launches");
+		if (!wait) return t;
 		HIPCHECK(hipStreamSynchronize(sA));
 		HIPCHECK(hipStreamSynchronize(sB));
 		tm.lap("waiting for the kernels");
+		afterLaunch(I, b, t, true);
+		return t;
+	}
+
+	// what follows the kernels of a batch on the host: developer read-outs, the lattice kernel's LDS room for the next batch, the stage timings
+	static void afterLaunch(Engine::Impl& I, StagedBatch& b, KernelTimes& t, bool timed)
+	{
+		const uint32_t nC = (uint32_t)b.refs.size();
+		const uint32_t S = b.launchS;
 		if (getenv("KAMD_POS_BEACON") && getenv("KAMD_POS_PHASES") && posBeacon.p)
 		{
 			// developer aid (KAMD_POS_DEBUG build): cycles per phase of a position step, averaged over the chunks' steps
@@ -1161,7 +1193,7 @@ namespace kamd
 			// k_lattice_wave's LDS room for the next batch: 1.25 x the most matches per text unit any chunk of this batch had (+ 1/8), more at once
 			// when chunks had to go to the wide launch for lack of room; never below 3/4 nor above 3 per unit
 			uint32_t c16[16] = {};
-			HIPCHECK(hipMemcpy(c16, b.dOutCounters.p, 64, hipMemcpyDeviceToHost));
+			HIPCHECK(hipMemcpyAsync(c16, b.dOutCounters.p, 64, hipMemcpyDeviceToHost, I.streamCopy)); HIPCHECK(hipStreamSynchronize(I.streamCopy));
 			uint32_t want = (c16[13] * 16u * 5u / 4u + 99u) / 100u + 2u;
 			if (c16[4] + c16[5] > nC / 256) want = std::max(want, I.latticeRatio16 * 3u / 2u);
 			I.latticeRatio16 = std::min(kLatticeWideRatio16, std::max(12u, want));
@@ -1249,7 +1281,7 @@ namespace kamd
 			stat(start, "chunk start offset"); stat(nodes, "node loop"); stat(fin, "end-candidate stage"); stat(perNode, "node loop / node");
 		}
 #endif
-		for (uint32_t k = 0; k < S; ++k)
+		for (uint32_t k = 0; timed && k < S; ++k)      // (the timing events are the engine's: only a batch that was waited for in launchAll reads them)
 		{
 			hipEvent_t* e = &I.evs[6 * (size_t)k];
 			float a = 0, l = 0, r = 0, f = 0;
@@ -1271,7 +1303,6 @@ namespace kamd
 			fprintf(stderr, "[host] typo lattices: LDS need avg %.0f max %u B, %llu chunks over the budget, %llu outgrew their LDS copy; connected nodes avg %.1f of LDS capacity avg %.1f\n",
 				(double)need / nC, maxNeed, (unsigned long long)over, (unsigned long long)big, (double)nodes / nC, (double)cap / nC);
 		}
-		return t;
 	}
 
 	// D2H of what the end stage produced: 32 B per chunk and the two counters first, then exactly the path headers and token
@@ -1284,16 +1315,16 @@ namespace kamd
 		const size_t oRes = 64, resBytes = (nC * sizeof(DevChunkResult) + 255) & ~(size_t)255;
 		b.hOut.ensure(oRes + resBytes);
 		uint8_t* H = b.hOut.as<uint8_t>();
-		HIPCHECK(hipMemcpyAsync(H, b.dOutCounters.p, 8, hipMemcpyDeviceToHost, I.stream));
-		HIPCHECK(hipMemcpyAsync(H + oRes, b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost, I.stream));
-		HIPCHECK(hipStreamSynchronize(I.stream));
+		HIPCHECK(hipMemcpyAsync(H, b.dOutCounters.p, 8, hipMemcpyDeviceToHost, I.streamCopy));
+		HIPCHECK(hipMemcpyAsync(H + oRes, b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost, I.streamCopy));
+		HIPCHECK(hipStreamSynchronize(I.streamCopy));
 		const uint32_t nPaths = std::min(reinterpret_cast<const uint32_t*>(H)[0], b.outPathCap), nTok = std::min(reinterpret_cast<const uint32_t*>(H)[1], b.outTokCap);
 		const size_t oTok = ((size_t)nPaths * sizeof(DevPathHeader) + 255) & ~(size_t)255;
 		b.hOut2.ensure(oTok + (size_t)nTok * sizeof(DevToken) + 16);
 		uint8_t* H2 = b.hOut2.as<uint8_t>();
-		if (nPaths) HIPCHECK(hipMemcpyAsync(H2, b.dOutPaths.p, (size_t)nPaths * sizeof(DevPathHeader), hipMemcpyDeviceToHost, I.stream));
-		if (nTok) HIPCHECK(hipMemcpyAsync(H2 + oTok, b.dOutTokens.p, (size_t)nTok * sizeof(DevToken), hipMemcpyDeviceToHost, I.stream));
-		HIPCHECK(hipStreamSynchronize(I.stream));
+		if (nPaths) HIPCHECK(hipMemcpyAsync(H2, b.dOutPaths.p, (size_t)nPaths * sizeof(DevPathHeader), hipMemcpyDeviceToHost, I.streamCopy));
+		if (nTok) HIPCHECK(hipMemcpyAsync(H2 + oTok, b.dOutTokens.p, (size_t)nTok * sizeof(DevToken), hipMemcpyDeviceToHost, I.streamCopy));
+		HIPCHECK(hipStreamSynchronize(I.streamCopy));
 		b.hResults = reinterpret_cast<const DevChunkResult*>(H + oRes);
 		b.hPaths = reinterpret_cast<const DevPathHeader*>(H2);
 		b.hTokens = reinterpret_cast<const DevToken*>(H2 + oTok);
@@ -1392,10 +1423,36 @@ namespace kamd
 		HostTimer tm{ "run" };
 		KernelTimes t = launchAll(*impl, b, makeParams(config, b.match, b.topN));
 		tm.lap("work order + launches + kernels");
+		rerunOverflows(b, t);
+		return t;
+	}
+
+	// The same in two halves, for a caller that has host work to do while the kernels run: launch() returns when everything is enqueued, finish() waits for
+	// the batch (not for batches launched after it) and searches again what outgrew its scratch regions.
+	void Engine::launch(StagedBatch& b)
+	{
+		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		HIPCHECK(hipSetDevice(impl->device));
+		launchAll(*impl, b, makeParams(config, b.match, b.topN), false);
+	}
+	void Engine::finish(StagedBatch& b)
+	{
+		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		HIPCHECK(hipSetDevice(impl->device));
+		HostTimer tm{ "finish" };
+		if (b.evDone) HIPCHECK(hipEventSynchronize(b.evDone));
+		tm.lap("waiting for the batch's kernels");
+		KernelTimes t;
+		afterLaunch(*impl, b, t, false);
+		rerunOverflows(b, t);
+	}
+
+	void Engine::rerunOverflows(StagedBatch& b, KernelTimes& t)
+	{
 		b.overIdx.clear(); b.overPaths.clear(); b.rerunChunks = 0; b.rerunMs = 0;
 		const size_t nC = b.refs.size();
 		uint32_t nOver = 0;
-		if (nC) HIPCHECK(hipMemcpy(&nOver, b.dOutCounters.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost));
+		if (nC) { HIPCHECK(hipMemcpyAsync(&nOver, b.dOutCounters.as<uint32_t>() + 2, 4, hipMemcpyDeviceToHost, impl->streamCopy)); HIPCHECK(hipStreamSynchronize(impl->streamCopy)); }      // (the batch's kernels are done; the copy stream never waits for another batch's)
 		if (nOver)
 		{
 			const auto t0 = std::chrono::steady_clock::now();
@@ -1415,7 +1472,6 @@ namespace kamd
 			b.rerunMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 		}
 		t.rerunChunks = b.rerunChunks; t.rerunMs = b.rerunMs;
-		return t;
 	}
 	size_t Engine::stagedChunks(const StagedBatch& b) { return b.refs.size(); }
 	uint64_t Engine::stagedUnits(const StagedBatch& b) { return b.units; }
@@ -1579,14 +1635,60 @@ namespace kamd
 		size_t topN, uint64_t match, bool openEnding, int hostThreads, TypoOption typo)
 	{
 		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
-		auto b = stage(texts, match, openEnding, hostThreads, typo);
-		b->topN = (uint32_t)topN;
-		run(*b);
-		BatchResults r = fetch(*b, topN);
-		HostTimer tm{ "batch" };
-		b.reset();
-		tm.lap("release of the staged batch");
-		return r;
+		// A large batch goes through in PARTS whose host stages overlap the kernels of their neighbours: while part k is searched on the device the host
+		// prepares and uploads part k + 1, and while part k + 1 is searched it downloads and assembles the results of part k (MI355X box with a 16-CPU
+		// quota, 65 536 sentences: text preparation 2.8 + upload 1.3 + kernels 5.3 + download 0.5 + result assembly 3.3 + release 1.0 ms one after the
+		// other = 14.2 ms; the kernels of the parts still run one part after the other).  Parts are cut at multiples of the result segment size, so the
+		// parts' segments concatenate into the batch's.  KAMD_BATCH_PARTS fixes the number (1: one piece).
+		const int forcedParts = [] { const char* e = std::getenv("KAMD_BATCH_PARTS"); return e ? std::atoi(e) : 0; }();
+		const size_t seg = BatchResults::kSegTexts;
+		size_t parts = forcedParts > 0 ? (size_t)forcedParts : std::min<size_t>(4, texts.size() / 16384);
+		parts = std::max<size_t>(1, std::min(parts, (texts.size() + seg - 1) / seg));
+		if (parts == 1)
+		{
+			auto b = stage(texts, match, openEnding, hostThreads, typo);
+			b->topN = (uint32_t)topN;
+			run(*b);
+			BatchResults r = fetch(*b, topN);
+			HostTimer tm{ "batch" };
+			b.reset();
+			tm.lap("release of the staged batch");
+			return r;
+		}
+		std::vector<size_t> cut(parts + 1, texts.size());
+		for (size_t k = 0; k < parts; ++k) cut[k] = std::min(texts.size(), (texts.size() * k / parts + seg - 1) / seg * seg);
+		std::vector<std::shared_ptr<StagedBatch>> staged(parts);
+		BatchResults all;
+		auto collect = [&](size_t k)
+		{
+			finish(*staged[k]);
+			BatchResults r = fetch(*staged[k], topN);
+			for (auto& sg : r.segs) all.segs.push_back(std::move(sg));
+			for (auto& o : r.overrides) all.overrides.emplace_back(o.first + cut[k], std::move(o.second));
+			all.nTexts += r.nTexts; all.d2hBytes += r.d2hBytes;
+			staged[k].reset();
+		};
+		size_t collected = 0;
+		try
+		{
+			for (size_t k = 0; k < parts; ++k)
+			{
+				std::vector<std::pair<const char16_t*, size_t>> part(texts.begin() + cut[k], texts.begin() + cut[k + 1]);
+				staged[k] = stage(part, match, openEnding, hostThreads, typo);
+				staged[k]->topN = (uint32_t)topN;
+				launch(*staged[k]);
+				if (k >= 1) { collect(collected); ++collected; }      // (part k - 1: its kernels ran while part k was prepared)
+			}
+			for (; collected < parts; ++collected) collect(collected);
+		}
+		catch (...)
+		{
+			// parts still in flight read their buffers: wait before anything is released
+			std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+			for (auto& sb : staged) if (sb && sb->launched && sb->evDone) (void)hipEventSynchronize(sb->evDone);
+			throw;
+		}
+		return all;
 	}
 
 	std::vector<uint8_t> Engine::dumpLattices(const char16_t* text, size_t n, uint64_t match)

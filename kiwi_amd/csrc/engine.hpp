@@ -86,6 +86,11 @@ namespace kamd
 		// the resident batch and returns their event-timed durations; fetch() downloads and assembles results.
 		std::shared_ptr<StagedBatch> stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {});
 		KernelTimes run(StagedBatch& b);
+		// run() in two halves: launch() enqueues the batch's kernels and returns, finish() waits for THIS batch and re-runs what overflowed -- the host
+		// prepares the next batch in between (analyzeBatch cuts a large batch into parts that way)
+		void launch(StagedBatch& b);
+		void finish(StagedBatch& b);
+		void rerunOverflows(StagedBatch& b, KernelTimes& t);      // (internal: the capacity ladder behind run() / finish())
 		BatchResults fetch(StagedBatch& b, size_t topN);
 		static size_t stagedChunks(const StagedBatch& b);
 		static uint64_t stagedUnits(const StagedBatch& b);     // non-space normalised units ("jamo")

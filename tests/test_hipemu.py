@@ -67,6 +67,30 @@ def test_emulated_knlm_kernels_match_oracle(emu_libs, oracle, small_model, monke
     dev.close()
 
 
+@pytest.mark.parametrize("tiny", [False, True])
+def test_emulated_batch_in_parts(emu_libs, oracle, small_model, monkeypatch, tiny):
+    """Engine::analyzeBatch cuts a large batch into parts whose host stages overlap the kernels of their neighbours (Engine::launch / finish): the parts'
+    result segments concatenate into the batch's -- same packed bytes as the batch in one piece, texts of several chunks (other start states: re-searched
+    while later parts are in flight) and, with tiny arenas, the capacity ladder inside a part included."""
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_model
+    if tiny:
+        monkeypatch.setenv("KAMD_TEST_TINY_ARENAS", "1")
+    texts = synthetic(sm, 300, 1201, min_jamo=5, max_jamo=120) + EDGE_TEXTS + dictionary_mix(sm, 100, 1202)
+    texts += [". ".join(texts[k:k + 6]) + '." \'' + texts[k + 7] + "'" for k in range(0, 120, 8)]      # several chunks per text, quotes carried across them
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    monkeypatch.setenv("KAMD_BATCH_PARTS", "1")
+    whole = dev.analyze_batch(texts, top_n=2)
+    one = whole.to_python(); packed_one = whole.pack()
+    monkeypatch.setenv("KAMD_BATCH_PARTS", "3")
+    parts = dev.analyze_batch(texts, top_n=2)
+    assert bytes(parts.pack()) == bytes(packed_one)
+    for s, y in zip(texts, parts.to_python()):
+        assert _norm(oracle.analyze(s, top_n=2)) == _norm(y), s
+    assert len(one) == len(texts)
+    dev.close()
+
+
 @pytest.mark.parametrize("lanes", ["pos", "16", "64"])
 def test_emulated_order_4_knlm(emu_libs, small_order4_model, monkeypatch, lanes):
     """An order-4 Knlm (the reference's maximum): back-off chains one node longer than the pair a search state carries (ModelView::lmChain) -- the
