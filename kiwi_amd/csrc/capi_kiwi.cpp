@@ -244,9 +244,15 @@ namespace
 			for (size_t d = 0; d + 1 < job.cut.size(); ++d)
 				for (size_t i = job.cut[d]; i < job.cut[d + 1]; ++i) (*receiver)(receiverIdx++, makeRes(job.parts[d], i - job.cut[d]), ud);   // in input order; the receiver owns the result
 		};
+		// The first batches are short -- 8 192 lines, then twice as many each time up to the batch size: the device side starts after a fraction of the
+		// reading instead of after all of it, and the last batch's results are delivered while little is left to do (an input of one batch size was
+		// read, analysed and delivered strictly one after the other).
+		int batchNo = 0;
 		auto readBatch = [&](Job& job)
 		{
-			while ((int)job.texts.size() < h->batchSize)
+			const int want = (int)std::min<long long>(h->batchSize, 8192ll << std::min(batchNo, 20));
+			++batchNo;
+			while ((int)job.texts.size() < want)
 			{
 				std::u16string s; std::string raw;
 				if (!readNext(readerIdx, s, raw)) return false;

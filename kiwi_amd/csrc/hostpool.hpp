@@ -123,7 +123,7 @@ namespace kamd
 			if (j.error) std::rethrow_exception(j.error);
 		}
 
-		// the process-wide pool: one thread per hardware thread, at most four per CPU of a CFS quota (KAMD_HOST_THREADS overrides; the batch stages take their own `maxThreads` on top).
+		// the process-wide pool: one thread per hardware thread, at most two per CPU of a CFS quota (KAMD_HOST_THREADS overrides; the batch stages take their own `maxThreads` on top).
 		// A child process after fork() has none of the parent's threads: it runs its stages on the calling thread alone.
 		static HostPool& instance()
 		{
@@ -133,12 +133,13 @@ namespace kamd
 		static int defaultThreads()
 		{
 			unsigned n = std::max(1u, std::thread::hardware_concurrency());
-			// A container can see every logical CPU of its host and be scheduled on a fraction of them (CFS quota).  Waking one worker per visible CPU
-			// then costs more than it brings -- MI355X box, 256 logical CPUs under a quota of 16: a 65 536-sentence batch end to end 22.3 ms with 256
-			// workers (stages of 2 - 3 ms stretched to 20 - 40 ms now and then), 16.6 ms with 64, 16.9 with 32, 22.1 with 16 (profiles/r04_r_*): four
-			// workers per CPU of the quota, so that a worker blocked in a page fault or on a lock does not idle its share.
+			// A container can see every logical CPU of its host and be scheduled on a fraction of them (CFS quota).  A worker per visible CPU then costs
+			// more than it brings, and what the workers burn beyond the work itself counts against the quota: once that is used up the whole process
+			// is stopped until the next period (cpu.stat nr_throttled: stages of 1 - 3 ms stretched to 20 - 40 ms a few times per second).  MI355X box,
+			// 256 logical CPUs under a quota of 16, a 65 536-sentence batch end to end: 22.3 ms with 256 workers, 16.6 - 19.5 with 64, 15.4 - 16.9 with 32,
+			// 22.1 with 16 (profiles/r04_r_*, r04_t_*): two workers per CPU of the quota.
 			const double quota = cpuQuota();
-			if (quota > 0) n = std::min(n, (unsigned)std::max(1.0, 4.0 * quota + 0.5));
+			if (quota > 0) n = std::min(n, (unsigned)std::max(1.0, 2.0 * quota + 0.5));
 			if (const char* e = std::getenv("KAMD_HOST_THREADS")) { const long v = std::atol(e); if (v > 0) n = (unsigned)v; }
 			return (int)std::min(1024u, n);
 		}
