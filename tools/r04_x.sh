@@ -1,0 +1,6 @@
+#!/bin/bash
+# round 4, final (after the record prefetch of the three-waves step kernel): the whole GPU suite and the default bench line on the round's last build
+mkdir -p gpurun_out/r04_x; O=$PWD/gpurun_out/r04_x
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > $O/pytest_gpu.txt 2>&1; echo "rc $?" >> $O/pytest_gpu.txt
+tail -12 $O/pytest_gpu.txt | cut -c1-200
+timeout 1200 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-400 $O/bench_default.json; tail -3 $O/bench_default.err
