@@ -163,6 +163,27 @@ def test_all_lanes_lattice_kernel_equals_the_one_lane_replay_on_whole_corpora(mo
     assert c.nbytes == b8.nbytes and np.array_equal(c, b8)
 
 
+@pytest.mark.parametrize("workload,limit", [("c2-64k", 65536), ("c3", 40000)])
+def test_batch_in_parts_equals_the_batch_in_one_piece(monkeypatch, workload, limit):
+    """Engine::analyzeBatch sends a large batch through in parts (the host prepares part k + 1 and assembles part k - 1 while part k is searched; launch /
+    finish, copy stream, per-batch done events): the packed records of the whole batch are the same bytes as with KAMD_BATCH_PARTS=1, at the scale where
+    the parts really are in flight together (the lane emulator, which runs a launch synchronously, checks the concatenation: tests/test_hipemu.py)."""
+    import numpy as np
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+    path, texts, _ = get_workload(workload)
+    texts = texts[:limit]
+    dev = KiwiAmd(path)
+    a = _packed(dev, texts)                       # the engine's own choice: four parts
+    monkeypatch.setenv("KAMD_BATCH_PARTS", "7")
+    c = _packed(dev, texts)
+    monkeypatch.setenv("KAMD_BATCH_PARTS", "1")
+    b = _packed(dev, texts)
+    dev.close()
+    assert a.nbytes == b.nbytes and np.array_equal(a, b)
+    assert c.nbytes == b.nbytes and np.array_equal(c, b)
+
+
 def test_c3_sbg_2k_sentences_top3_vs_oracle_and_reference():
     """BASELINE config 3 on its own model: the 'full-sbg' synthetic model (Knlm + SkipBigram), 2048 mixed 5-200 jamo sentences of its
     lexicon (the c3 corpus), top-3 -- device vs the CPU oracle, analysis for analysis with fp32 scores, and vs the REAL reference where its
