@@ -297,6 +297,10 @@ def main():
     n_job = len(texts) if strong else n * world      # sentences the whole job analyses per step
 
     top_n = workload_top_n(args.workload)
+    if world > 1 and "KAMD_HOST_THREADS" not in os.environ:
+        # one process per GPU on one host: the ranks share the container's CPUs -- each takes its share of the two-workers-per-quota-CPU pool
+        # (hostpool.hpp) instead of a whole one (N pools of that size used the quota up: CFS throttling, profiles/r04_t_cfs_throttling.txt)
+        os.environ["KAMD_HOST_THREADS"] = str(max(2, int(2 * (cpu_quota_cores() or os.cpu_count() or 2) / world)))
     eng = KiwiAmd(model_path, local_rank)
     typo_cfg, typo = workload_typo(args.workload), None
     if typo_cfg is not None:
