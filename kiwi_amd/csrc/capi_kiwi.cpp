@@ -110,9 +110,11 @@ namespace
 		throw std::invalid_argument{ std::string{ "Unknown POSTag : " } + pos };
 	}
 
-	std::u16string utf8To16(const char* s, size_t n)   // src/StrUtils.h:228-303 (strict decoder, throws on malformed input)
+	// UTF-8 -> UTF-16 into `out` (room for n units: a code point never takes more UTF-16 units than it took UTF-8 bytes); src/StrUtils.h:228-303 (strict
+	// decoder, throws on malformed input).  Returns the number of units written.
+	size_t utf8To16Into(const char* s, size_t n, char16_t* out)
 	{
-		std::u16string ret;
+		size_t k = 0;
 		for (size_t i = 0; i < n; ++i)
 		{
 			uint32_t code, b = (uint8_t)s[i];
@@ -128,10 +130,16 @@ namespace
 			else if ((b & 0xE0) == 0xC0) { code = (b & 0x1F) << 6; code |= cont(); }
 			else if ((b & 0x80) == 0) code = b;
 			else throw std::runtime_error{ "unicode error" };
-			if (code < 0x10000) ret.push_back((char16_t)code);
-			else if (code < 0x10FFFF) { code -= 0x10000; ret.push_back((char16_t)(0xD800 | (code >> 10))); ret.push_back((char16_t)(0xDC00 | (code & 0x3FF))); }
+			if (code < 0x10000) out[k++] = (char16_t)code;
+			else if (code < 0x10FFFF) { code -= 0x10000; out[k++] = (char16_t)(0xD800 | (code >> 10)); out[k++] = (char16_t)(0xDC00 | (code & 0x3FF)); }
 			else throw std::runtime_error{ "unicode error" };
 		}
+		return k;
+	}
+	std::u16string utf8To16(const char* s, size_t n)
+	{
+		std::u16string ret(n, u'\0');
+		ret.resize(n ? utf8To16Into(s, n, &ret[0]) : 0);
 		return ret;
 	}
 
@@ -194,32 +202,41 @@ namespace
 	{
 		checkOption(opt, nullptr);
 		h->makeReplicas();
+		// The lines of a batch back to back in ONE buffer (a string per line was two heap blocks per line on the calling thread, whose reading and
+		// delivering is what bounds kiwi_analyze_m): `raw8` as the UTF-8 reader delivered them, `w` as UTF-16 -- read directly (_mw), or converted on
+		// the worker pool into the slot at the line's byte offset (a line never has more UTF-16 units than UTF-8 bytes).
 		struct Job
 		{
-			std::vector<std::u16string> texts;
-			std::vector<std::string> utf8;      // kiwi_analyze_m: what the reader delivered; converted on the worker pool, not on the calling thread
+			std::string raw8; std::u16string w;
+			std::vector<size_t> off, len;      // line i: units [off[i], off[i] + len[i]) of w (and bytes [off[i], off[i + 1]) of raw8); off has one more entry
+			size_t count() const { return len.size(); }
 			std::vector<size_t> cut;
 			std::vector<std::shared_ptr<const BatchResults>> parts;
 		};
 		auto analyse = [h, topN, &opt](Job& job)
 		{
-			if (!job.utf8.empty())
+			if (!job.raw8.empty())
 			{
-				HostPool::instance().run(job.utf8.size(), 512, h->numThreads, [&](size_t a, size_t b, int) { for (size_t i = a; i < b; ++i) job.texts[i] = utf8To16(job.utf8[i].data(), job.utf8[i].size()); });
-				std::vector<std::string>().swap(job.utf8);      // (the batch keeps one copy of its texts, not two, while it is on the device)
+				job.w.resize(job.raw8.size());
+				HostPool::instance().run(job.count(), 512, h->numThreads, [&](size_t a, size_t b, int)
+				{
+					for (size_t i = a; i < b; ++i) job.len[i] = utf8To16Into(job.raw8.data() + job.off[i], job.off[i + 1] - job.off[i], &job.w[job.off[i]]);
+				});
+				std::string().swap(job.raw8);      // (the batch keeps one copy of its texts, not two, while it is on the device)
 			}
 			std::vector<std::pair<const char16_t*, size_t>> views;
-			for (auto& t : job.texts) views.emplace_back(t.data(), t.size());
+			views.reserve(job.count());
+			for (size_t i = 0; i < job.count(); ++i) views.emplace_back(job.w.data() + job.off[i], job.len[i]);
 			// One host process drives every GPU (the reference's driver keeps a thread pool busy, include/kiwi/Kiwi.h:402-454): the batch is cut into
 			// contiguous parts of about equal text volume, part d is analysed by the engine of device d on its own thread, results are delivered in
 			// input order.  (Texts are independent: no exchange between the devices; each holds a replica of the model tables.)
-			const size_t nDev = std::min(h->devices(), std::max<size_t>(1, job.texts.size() / 64));
+			const size_t nDev = std::min(h->devices(), std::max<size_t>(1, job.count() / 64));
 			job.cut.assign(nDev + 1, 0);
 			{
-				size_t total = 0; for (auto& t : job.texts) total += t.size() + 8;
+				size_t total = 0; for (size_t i = 0; i < job.count(); ++i) total += job.len[i] + 8;
 				size_t acc = 0, d = 1;
-				for (size_t i = 0; i < job.texts.size() && d < nDev; ++i) { acc += job.texts[i].size() + 8; if (acc * nDev >= total * d) job.cut[d++] = i + 1; }
-				for (; d <= nDev; ++d) job.cut[d] = job.texts.size();
+				for (size_t i = 0; i < job.count() && d < nDev; ++i) { acc += job.len[i] + 8; if (acc * nDev >= total * d) job.cut[d++] = i + 1; }
+				for (; d <= nDev; ++d) job.cut[d] = job.count();
 			}
 			job.parts.assign(nDev, nullptr);
 			std::vector<std::exception_ptr> errs(nDev);
@@ -252,13 +269,11 @@ namespace
 		{
 			const int want = (int)std::min<long long>(h->batchSize, 8192ll << std::min(batchNo, 20));
 			++batchNo;
-			while ((int)job.texts.size() < want)
+			if (job.off.empty()) job.off.push_back(0);
+			while ((int)job.count() < want)
 			{
-				std::u16string s; std::string raw;
-				if (!readNext(readerIdx, s, raw)) return false;
+				if (!readNext(readerIdx, job.raw8, job.w, job.off, job.len)) return false;
 				++readerIdx;
-				job.texts.push_back(std::move(s));
-				if (!raw.empty()) job.utf8.push_back(std::move(raw));
 			}
 			return true;
 		};
@@ -279,7 +294,7 @@ namespace
 				{
 					next = std::make_unique<Job>();
 					more = readBatch(*next);      // (overlaps the batch on the device)
-					if (next->texts.empty()) next.reset();
+					if (!next->count()) next.reset();
 				}
 				const double t1 = clk();
 				if (running) { pending.get(); finished = std::move(running); }
@@ -563,11 +578,13 @@ extern "C"
 		if (!h) return KIWIERR_INVALID_HANDLE;
 		try
 		{
-			return analyzeMany(h, [&](int idx, std::u16string& out, std::string&)
+			return analyzeMany(h, [&](int idx, std::string&, std::u16string& w, std::vector<size_t>& off, std::vector<size_t>& len)
 			{
-				out.resize((size_t)(*reader)(idx, nullptr, ud));
-				if (out.empty()) return false;
-				(*reader)(idx, (kchar16_t*)&out[0], ud);
+				const size_t n = (size_t)(*reader)(idx, nullptr, ud), at = w.size();
+				if (!n) return false;
+				w.resize(at + n);
+				(*reader)(idx, (kchar16_t*)&w[at], ud);
+				off.back() = at; off.push_back(at + n); len.push_back(n);
 				return true;
 			}, receiver, ud, top_n, opt);
 		}
@@ -579,11 +596,13 @@ extern "C"
 		if (!h) return KIWIERR_INVALID_HANDLE;
 		try
 		{
-			return analyzeMany(h, [&](int idx, std::u16string&, std::string& raw)
+			return analyzeMany(h, [&](int idx, std::string& raw8, std::u16string&, std::vector<size_t>& off, std::vector<size_t>& len)
 			{
-				raw.resize((size_t)(*reader)(idx, nullptr, ud));
-				if (raw.empty()) return false;
-				(*reader)(idx, &raw[0], ud);      // (UTF-8 -> UTF-16 happens with the batch, on the worker pool)
+				const size_t n = (size_t)(*reader)(idx, nullptr, ud), at = raw8.size();
+				if (!n) return false;
+				raw8.resize(at + n);
+				(*reader)(idx, &raw8[at], ud);      // (UTF-8 -> UTF-16 happens with the batch, on the worker pool)
+				off.back() = at; off.push_back(at + n); len.push_back(0);
 				return true;
 			}, receiver, ud, top_n, opt);
 		}
