@@ -64,8 +64,12 @@ struct kiwi_prepared_typo { kamd::PreparedTypo p; };                  // capi.h:
 // A result handed to the caller: a VIEW of one text's analyses inside the batch's flat result segments (post.hpp), which every result of the batch
 // keeps alive together -- no per-text copies of token records or form strings (the reference hands out a vector of its own per text,
 // src/capi/kiwi_c.cpp:45-60; a batch of 65 536 texts made 5 allocations and 4 copies per text here before).
+// Results of kiwi_analyze_m are handed to the receiver one handle per line; the handles of a delivered part live side by side in one block (ResSlab)
+// that goes when the last of them is closed -- a heap block per line and its release were 40 % of what delivering a line costs the calling thread.
+struct ResSlab { std::unique_ptr<unsigned char[]> mem; };
 struct kiwi_res
 {
+	std::shared_ptr<ResSlab> slab;      // set: this handle lies in the slab's block (kiwi_res_close destroys it in place)
 	std::shared_ptr<const BatchResults> batch;
 	const ResultSegment* seg = nullptr;
 	uint32_t a0 = 0, nAna = 0;      // analyses [a0, a0 + nAna) of the segment
@@ -184,14 +188,34 @@ namespace
 	// AnalyzeOption::typoTransformer / typoThreshold
 	TypoOption typoOf(const kiwi_analyze_option_t& o);
 
+	void fillRes(kiwi_res& res, const std::shared_ptr<const BatchResults>& br, size_t text)
+	{
+		size_t local;
+		const ResultSegment& seg = br->locate(text, local);
+		res.batch = br; res.seg = &seg;
+		res.a0 = seg.textAna[local]; res.nAna = seg.textAna[local + 1] - seg.textAna[local];
+	}
 	kiwi_res* makeRes(const std::shared_ptr<const BatchResults>& br, size_t text)
 	{
 		auto res = std::make_unique<kiwi_res>();
-		size_t local;
-		const ResultSegment& seg = br->locate(text, local);
-		res->batch = br; res->seg = &seg;
-		res->a0 = seg.textAna[local]; res->nAna = seg.textAna[local + 1] - seg.textAna[local];
+		fillRes(*res, br, text);
 		return res.release();
+	}
+	// the handles of texts [first, first + count) of `br`, constructed side by side in one block; handle i is at slabRes(slab, i)
+	std::shared_ptr<ResSlab> makeResSlab(size_t count)
+	{
+		auto slab = std::make_shared<ResSlab>();
+		slab->mem.reset(new unsigned char[count * sizeof(kiwi_res) + alignof(kiwi_res)]);
+		return slab;
+	}
+	kiwi_res* slabRes(const std::shared_ptr<ResSlab>& slab, size_t i, const std::shared_ptr<const BatchResults>& br, size_t text)
+	{
+		unsigned char* base = slab->mem.get();
+		base += (alignof(kiwi_res) - reinterpret_cast<uintptr_t>(base) % alignof(kiwi_res)) % alignof(kiwi_res);
+		kiwi_res* r = new (base + i * sizeof(kiwi_res)) kiwi_res{};
+		r->slab = slab;
+		fillRes(*r, br, text);
+		return r;
 	}
 
 	// kiwi_analyze_m / _mw (src/capi/kiwi_c.cpp:914-960 over Kiwi::analyze(reader, receiver), include/kiwi/Kiwi.h:402-454): reader and receiver are the
@@ -259,7 +283,13 @@ namespace
 		auto deliver = [&](Job& job)
 		{
 			for (size_t d = 0; d + 1 < job.cut.size(); ++d)
-				for (size_t i = job.cut[d]; i < job.cut[d + 1]; ++i) (*receiver)(receiverIdx++, makeRes(job.parts[d], i - job.cut[d]), ud);   // in input order; the receiver owns the result
+			{
+				// (handles are constructed one at a time, right before their delivery: a receiver that throws leaves no constructed-but-undelivered ones behind)
+				const size_t cnt = job.cut[d + 1] - job.cut[d];
+				if (!cnt) continue;
+				const auto slab = makeResSlab(cnt);
+				for (size_t i = 0; i < cnt; ++i) (*receiver)(receiverIdx++, slabRes(slab, i, job.parts[d], i), ud);   // in input order; the receiver owns the result
+			}
 		};
 		// The first batches are short -- 8 192 lines, then twice as many each time up to the batch size: the device side starts after a fraction of the
 		// reading instead of after all of it, and the last batch's results are delivered while little is left to do (an input of one batch size was
@@ -652,7 +682,12 @@ extern "C"
 	int kiwi_res_close(kiwi_res_h r)
 	{
 		if (!r) return KIWIERR_INVALID_HANDLE;
-		delete r;
+		if (r->slab)
+		{
+			const std::shared_ptr<ResSlab> keep = std::move(r->slab);      // (the block outlives the destructor call; it goes with the last handle)
+			r->~kiwi_res();
+		}
+		else delete r;
 		return 0;
 	}
 }
