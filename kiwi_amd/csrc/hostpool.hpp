@@ -143,6 +143,13 @@ namespace kamd
 			if (const char* e = std::getenv("KAMD_HOST_THREADS")) { const long v = std::atol(e); if (v > 0) n = (unsigned)v; }
 			return (int)std::min(1024u, n);
 		}
+		// the content of a cgroup v2 cpu.max file -- "<quota> <period>" in microseconds, or "max <period>" for no limit -- as CPUs; 0 = no limit / not understood
+		static double parseCpuMax(const char* text)
+		{
+			long long q = 0, p = 0;
+			if (std::sscanf(text, "%lld %lld", &q, &p) == 2 && q > 0 && p > 0) return (double)q / (double)p;
+			return 0;
+		}
 		// CPUs' worth of run time per period this process' control group may use (cgroup v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us); 0 = no limit known
 		static double cpuQuota()
 		{
@@ -156,12 +163,7 @@ namespace kamd
 				return k > 0;
 			};
 			char buf[128];
-			if (readAll("/sys/fs/cgroup/cpu.max", buf, sizeof(buf)))
-			{
-				long long q = 0, p = 0;
-				if (std::sscanf(buf, "%lld %lld", &q, &p) == 2 && q > 0 && p > 0) return (double)q / (double)p;
-				return 0;      // "max <period>": unlimited
-			}
+			if (readAll("/sys/fs/cgroup/cpu.max", buf, sizeof(buf))) return parseCpuMax(buf);
 			long long q = 0, p = 0;
 			if (readAll("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", buf, sizeof(buf))) q = std::atoll(buf);
 			if (readAll("/sys/fs/cgroup/cpu/cpu.cfs_period_us", buf, sizeof(buf))) p = std::atoll(buf);
