@@ -718,6 +718,38 @@ extern "C"
 		return w.need;
 	}
 
+	// Kiwi::analyze with pretokenized spans (src/Kiwi.cpp:785-946, 1043-1051; the argument of kiwi_analyze* that this repo's product still refuses): the
+	// reference's own answer, for golden vectors (tools/make_golden_pretokenized.py) and for the restatement to come.  spans: per span {begin, end, nTokens}
+	// (UTF-16 offsets into `text`), then per token {formOff, formLen (into `forms`), begin, end (relative to the span), tag, inferRegularity}.
+	size_t kref_analyze_pretokenized(void* hp, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, const uint32_t* spans, uint32_t nSpans, const uint16_t* forms, uint8_t* out, size_t cap)
+	{
+		auto& kw = ((RefHandle*)hp)->kw;
+		Writer w{ out, out + cap };
+		try
+		{
+			std::vector<kiwi::PretokenizedSpan> pt;
+			const uint32_t* p = spans;
+			for (uint32_t i = 0; i < nSpans; ++i)
+			{
+				kiwi::PretokenizedSpan sp{ p[0], p[1] };
+				const uint32_t nTok = p[2];
+				p += 3;
+				for (uint32_t t = 0; t < nTok; ++t, p += 6)
+					sp.tokenization.emplace_back(std::u16string{ (const char16_t*)forms + p[0], (const char16_t*)forms + p[0] + p[1] }, p[2], p[3], (kiwi::POSTag)p[4], (uint8_t)p[5]);
+				pt.push_back(std::move(sp));
+			}
+			kiwi::AnalyzeOption opt{ (kiwi::Match)match };
+			auto res = kw.analyze(std::u16string{ (const char16_t*)text, (const char16_t*)text + len }, topN, opt, pt);
+			writeResults(w, res, kw);
+		}
+		catch (const std::exception& e)
+		{
+			fprintf(stderr, "kref_analyze_pretokenized: %s\n", e.what());
+			return 0;
+		}
+		return w.need;
+	}
+
 	// CPU baseline: the reference analysing a batch with `threads` worker threads, like
 	// Kiwi::analyze(topN, reader, receiver) does with its pool (include/kiwi/Kiwi.h:402-454).
 	// texts are concatenated UTF-16 with offsets[n+1]. Returns wall seconds; *tokensOut = total top-1 tokens.

@@ -180,6 +180,24 @@ class RefKiwi:
         buf = self._call(lambda *a: self.lib.kref_analyze(self.h, u.ctypes.data, len(u), top_n, match, int(open_ending), *a))
         return parse_results(buf)
 
+    def analyze_pretokenized(self, text: str, spans, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING):
+        """Kiwi::analyze with pretokenized spans: spans = [(begin, end, [(form, begin, end, tag id, infer_regularity), ...]), ...], offsets in UTF-16 units
+        of `text` (a token's relative to its span).  The reference's own answer (this repo's product refuses the argument so far)."""
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        desc, forms = [], []
+        for b, e, toks in spans:
+            desc += [b, e, len(toks)]
+            for form, tb, te, tag, infer in toks:
+                f = np.frombuffer(form.encode("utf-16-le"), np.uint16)
+                desc += [sum(len(x) for x in forms), len(f), tb, te, tag, infer]
+                forms.append(f)
+        d = np.array(desc if desc else [0], np.uint32)
+        fl = np.concatenate(forms) if forms else np.zeros(1, np.uint16)
+        self.lib.kref_analyze_pretokenized.restype = C.c_size_t
+        self.lib.kref_analyze_pretokenized.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]
+        buf = self._call(lambda *a: self.lib.kref_analyze_pretokenized(self.h, u.ctypes.data, len(u), top_n, match, d.ctypes.data, len(spans), fl.ctypes.data, *a))
+        return parse_results(buf)
+
     def split(self, text: str, match: int = MATCH_ALL_WITH_NORMALIZING):
         u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
         buf = self._call(lambda *a: self.lib.kref_split(self.h, u.ctypes.data, len(u), match, *a))
