@@ -296,10 +296,10 @@ namespace kamd
 		}
 	}
 
-	void prepareText(PreparedText& o, const char16_t* raw, size_t n, uint64_t mo, uint32_t textId)
+	void prepareText(PreparedText& o, const char16_t* raw, size_t n, uint64_t mo, uint32_t textId, const std::pair<uint32_t, uint32_t>* spans, size_t nSpans)
 	{
 		PrepBlock blk;
-		blk.append(raw, n, mo, textId);
+		blk.append(raw, n, mo, textId, spans, nSpans);
 		o.norm = std::move(blk.norm); o.position = std::move(blk.position); o.cls = std::move(blk.cls); o.script = std::move(blk.script);
 		o.chunks = std::move(blk.chunks); o.patterns = std::move(blk.patterns);
 	}
@@ -327,8 +327,9 @@ namespace kamd
 		const PrepTables& prepTables() { static const PrepTables t; return t; }
 	}
 
-	void PrepBlock::append(const char16_t* raw, size_t n, uint64_t mo, uint32_t textId)
+	void PrepBlock::append(const char16_t* raw, size_t n, uint64_t mo, uint32_t textId, const std::pair<uint32_t, uint32_t>* spans, size_t nSpans)
 	{
+		size_t spanAt = 0;      // next pretokenized span (they are consumed in order, across the chunks of the text: KTrie.cpp:769, 788)
 		const PrepTables& T = prepTables();
 		Idx x{};
 		x.normOff = norm.size(); x.posOff = position.size(); x.chunkOff = chunks.size(); x.patOff = patterns.size();
@@ -369,6 +370,12 @@ namespace kamd
 			const uint8_t* ccls = ocls + splitEnd;
 			for (; k < sz; ++k)
 			{
+				if (spanAt < nSpans && spans[spanAt].first == splitEnd + k)      // a pretokenized span: stepped over whole (KTrie.cpp:782-790)
+				{
+					k += (size_t)(spans[spanAt].second - spans[spanAt].first) - 1;
+					++spanAt;
+					continue;
+				}
 				const char16_t c0 = str[k];
 				if (c0 < 128 ? T.canStart[c0] : ((ccls[k] & 0x80) || (0xff10 <= c0 && c0 <= 0xff19)))
 				{

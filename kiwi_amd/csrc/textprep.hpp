@@ -4,6 +4,7 @@
 //   Splitter::preparePattern /root/reference/src/KTrie.cpp:766-858
 //   matchPattern            /root/reference/src/PatternMatcher.cpp:366-384
 #pragma once
+#include <utility>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -44,7 +45,9 @@ namespace kamd
 	void normalizeCoda(U16& s);
 	void normalizeCoda(char16_t* s, size_t n);
 	// Fills everything in `out` for one raw text.
-	void prepareText(PreparedText& out, const char16_t* raw, size_t n, uint64_t matchOptions, uint32_t textId);
+	// spans: pretokenized spans as [begin, end) offsets into the NORMALISED text, ascending (Kiwi::analyze maps the caller's through the position table,
+	// src/Kiwi.cpp:817-818): the chunk cut steps over them (KTrie.cpp:782-790) -- no pattern starts inside one, no chunk ends inside one
+	void prepareText(PreparedText& out, const char16_t* raw, size_t n, uint64_t matchOptions, uint32_t textId, const std::pair<uint32_t, uint32_t>* spans = nullptr, size_t nSpans = 0);
 
 	// The batch path prepares runs of consecutive texts into ONE set of flat arrays (a block is filled by one host worker): six
 	// allocations per block instead of six per text, which is what the preparation of an 8k-sentence batch otherwise spends its time on.
@@ -67,7 +70,7 @@ namespace kamd
 		U16 norm; std::vector<uint32_t> position; std::vector<uint8_t> cls, script; std::vector<ChunkDesc> chunks; std::vector<PatternSpan> patterns;
 		struct Idx { size_t normOff, normLen, posOff, posLen, chunkOff, nChunks, patOff, nPat; };
 		std::vector<Idx> idx;
-		void append(const char16_t* raw, size_t n, uint64_t matchOptions, uint32_t textId);
+		void append(const char16_t* raw, size_t n, uint64_t matchOptions, uint32_t textId, const std::pair<uint32_t, uint32_t>* spans = nullptr, size_t nSpans = 0);
 		PreparedView view(size_t k) const
 		{
 			const Idx& x = idx[k]; PreparedView v;

@@ -168,8 +168,11 @@ namespace korc
 
 		// Builds the lattice of chunk str[0..n).  `patterns` are chunk-relative, sorted.  Returns false if
 		// the chunk has no lattice (<= 2 nodes).  Output node positions are offsets into the *text* (startOffset added).
+		// a pretokenized span of the chunk (chunk-relative units), the form makePretokenizedSpanGroup gave it, and whether that is a fallback form
+		// (one of the default tag forms: the node then carries the text as its own string, KTrie.cpp:1197-1200)
+		struct SpanNode { uint32_t begin, end, form; bool fallback; };
 		bool build(std::vector<LNode>& ret, const char16_t* s, uint32_t len, const uint8_t* c, const uint8_t* sc,
-			const PatternSpan* pat, const PatternSpan* patEnd, uint32_t startOffset)
+			const PatternSpan* pat, const PatternSpan* patEnd, uint32_t startOffset, const SpanNode* span = nullptr, const SpanNode* spanEnd = nullptr)
 		{
 			str = s; n = len; cls = c; script = sc;
 			nsToPos.clear(); posToNs.clear(); out.clear();
@@ -263,6 +266,19 @@ namespace korc
 						if (append(posToNs[ms], posToNs[pat->end], pat->tag - 1u, ms, pat->length)) cnt.otherNodes++;
 						++pat;
 					}
+				}
+				// a pretokenized span begins here (KTrie.cpp:1177-1210): the pending unknown-form spans are closed, ONE node with the span's form is appended,
+				// the walk restarts behind the span
+				if (span != spanEnd && span->begin == j)
+				{
+					unkPair(boundary, unkStart, posToNs[span->begin], false);
+					append(posToNs[span->begin], posToNs[span->end], span->form, span->fallback ? span->begin : 0, span->fallback ? span->end - span->begin : 0);
+					j += (span->end - span->begin) - 1;
+					++span;
+					lastType = T_UNKNOWN;
+					cur = 0;
+					specialStart = unkStart = boundary = posToNs[j + 1];
+					continue;
 				}
 				if (c32 >= 0x10000) { ++j; continue; }
 

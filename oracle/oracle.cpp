@@ -44,12 +44,76 @@ namespace
 	// a prepared typo transformer applied to an analysis (AnalyzeOption::typoTransformer / typoThreshold / allowedDialects)
 	struct TypoOpt { const korc::typo::Prepared* prepared = nullptr; float threshold = 2.5f; uint16_t dialect = 0; };
 
+	// Pretokenized spans (Kiwi::analyze(..., pretokenized): src/Kiwi.cpp:785-946, 1043-1051, 1120, 745-756; KTrie.cpp:782-790, 1177-1210), as far as they are
+	// restated: a span without tokens, and a span of one token that IS a single-candidate dictionary entry -- the cases in which makePretokenizedSpanGroup
+	// points at a form of the model.  A span that needs a temporary form or morpheme (any other single token, several tokens) is refused.  Pinned by
+	// tests/test_pretokenized_golden.py against tests/golden/pretokenized_small.json (the real reference's answers).
+	struct PtToken { U16 form; uint32_t begin, end; uint8_t tag, infer; };
+	struct PtSpan { uint32_t begin, end; std::vector<PtToken> toks; };
+
+	// findForm (src/KTrie.cpp:2172-2192): the form whose string is exactly `nrm`, -1 if none (or only a submatch marker) ends there
+	int32_t findFormId(const FlatModel& m, const U16& nrm)
+	{
+		uint32_t node = 0;
+		for (size_t i = 0; i < nrm.size(); ++i)
+		{
+			const uint16_t c = (uint16_t)nrm[i];
+			if (node == 0) { node = m.trieRoot[c]; if (!node) return -1; continue; }
+			const TrieNodeRec& t = m.trie[node];
+			const uint16_t* kb = m.trieKeys.data() + t.edgeOff;
+			const uint16_t* it = std::lower_bound(kb, kb + t.numNexts, c);
+			if (it == kb + t.numNexts || *it != c) return -1;
+			node = m.trieChild[t.edgeOff + (it - kb)];
+		}
+		if (node == 0 || m.trie[node].value < 0) return -1;
+		return m.trie[node].value;
+	}
+
 	std::vector<TokenResult> analyzeOne(OracleHandle& h, Counters& cnt, PersistentContainers* persistent, const char16_t* text, uint32_t len, uint32_t topN, uint64_t match, bool openEnding,
-		std::vector<std::vector<LNode>>* latticesOut = nullptr, TypoOpt typo = {})
+		std::vector<std::vector<LNode>>* latticesOut = nullptr, TypoOpt typo = {}, const std::vector<PtSpan>* pretok = nullptr)
 	{
 		if (topN < 1 || topN > 16) throw std::runtime_error{ "oracle: top_n must be 1..16" };
 		PreparedText pt;
-		prepareText(pt, text, len, match, 0);
+		std::vector<std::pair<uint32_t, uint32_t>> spanCut;      // the spans in normalised offsets
+		std::vector<LatticeBuilder::SpanNode> spanNodes;          // ... with their forms (offsets still text-relative here)
+		if (pretok && !pretok->empty())
+		{
+			if (typo.prepared) throw std::runtime_error{ "oracle: pretokenized spans with a typo transformer are not restated" };
+			U16 norm; std::vector<uint32_t> pos;
+			normalizeWithPosition(text, len, norm, pos);
+			if (match & M_NORMALIZE_CODA) normalizeCoda(norm);
+			for (const PtSpan& sp : *pretok)
+			{
+				if (sp.begin >= sp.end || sp.end > len) throw std::runtime_error{ "oracle: bad pretokenized span" };
+				const uint32_t b = pos[sp.begin], e = pos[sp.end];
+				LatticeBuilder::SpanNode sn{ b, e, 0, false };
+				if (sp.toks.empty())
+				{
+					const int32_t f = findFormId(h.model, norm.substr(b, e - b));
+					if (f >= 0) sn.form = (uint32_t)f;
+					else sn.form = (uint32_t)T_NNP - 1u;      // formTrie.value(POSTag::nnp): the default form of the tag
+				}
+				else if (sp.toks.size() == 1)
+				{
+					U16 fs, dummy; std::vector<uint32_t> dp;
+					normalizeWithPosition(sp.toks[0].form.data(), sp.toks[0].form.size(), fs, dp);
+					const int32_t f = findFormId(h.model, fs);
+					bool reuse = false;
+					if (f >= 0 && h.model.forms[f].candCnt == 1)
+					{
+						const uint8_t mt = h.model.morphs[h.model.formCand[h.model.forms[f].candOff]].tag, tt = sp.toks[0].tag;
+						reuse = sp.toks[0].infer ? ((mt & 0x7F) == (tt & 0x7F)) : (mt == tt);      // areTagsEqual (include/kiwi/Types.h:249-252)
+					}
+					if (!reuse) throw std::runtime_error{ "oracle: a pretokenized span that needs a temporary form or morpheme is not restated" };
+					sn.form = (uint32_t)f;
+				}
+				else throw std::runtime_error{ "oracle: a pretokenized span of several tokens is not restated" };
+				sn.fallback = sn.form + 1 >= (uint32_t)T_NNG && sn.form + 1 < (uint32_t)T_MAX;      // within(form, value(nng), value(max)): KTrie.cpp:1197
+				spanCut.emplace_back(b, e);
+				spanNodes.push_back(sn);
+			}
+		}
+		prepareText(pt, text, len, match, 0, spanCut.data(), spanCut.size());
 		SplitConfig sc = h.scfg; sc.match = match;
 		BestPathConfig bc = h.bcfg;
 		bc.topN = topN;
@@ -79,16 +143,32 @@ namespace
 		for (auto& ch : pt.chunks)
 		{
 			if (ch.empty) continue;
+			// the spans of this chunk (the cut never ends inside one), chunk-relative
+			std::vector<LatticeBuilder::SpanNode> chSpans;
+			for (const auto& sn : spanNodes) if (sn.begin >= ch.startOffset && sn.begin < ch.startOffset + ch.nChars) chSpans.push_back({ sn.begin - ch.startOffset, sn.end - ch.startOffset, sn.form, sn.fallback });
 			const bool ok = typo.prepared
 				? tlb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset, *typo.prepared, typo.threshold, typo.dialect)
 				: lb.build(nodes, pt.norm.data() + ch.startOffset, ch.nChars, pt.cls.data() + ch.startOffset, pt.script.data() + ch.startOffset,
-				pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset);
+				pt.patterns.data() + ch.patBegin, pt.patterns.data() + ch.patEnd, ch.startOffset, chSpans.data(), chSpans.data() + chSpans.size());
 			if (latticesOut) latticesOut->push_back(nodes);
 			if (!ok) continue;
 			BestPathConfig bc2 = bc;
 			bc2.openEnding = openEnding && ch.nextOffset == pt.norm.size();
 			BestPathSearch bp{ h.view, bc2, cnt, h.sbg, persistent, h.cong };
 			bp.run(paths, pt.norm, pt.cls, nodes.data(), (uint32_t)nodes.size(), rb.spStates());
+			if (!chSpans.empty())
+			{
+				// findPretokenizedGroupOfNode (src/Kiwi.cpp:949-969) + Kiwi.cpp:745-750: a token of a node inside span i of the CHUNK reports i + 1 as its typoFormId
+				std::vector<uint32_t> group(nodes.size(), 0);
+				size_t cur = 0;
+				for (size_t i = 0; i < nodes.size(); ++i)
+				{
+					while (cur < chSpans.size() && nodes[i].startPos >= chSpans[cur].end + ch.startOffset) ++cur;
+					if (cur == chSpans.size()) break;
+					if (chSpans[cur].begin + ch.startOffset <= nodes[i].startPos && nodes[i].endPos <= chSpans[cur].end + ch.startOffset) group[i] = (uint32_t)cur + 1;
+				}
+				for (auto& p : paths) for (auto& t : p.path) if (t.nodeId < group.size() && group[t.nodeId]) t.typoFormId = group[t.nodeId];
+			}
 			rb.insertPaths(paths);
 		}
 		return rb.finish(text, len);
@@ -339,6 +419,31 @@ extern "C"
 			writeResults(w, res);
 		}
 		catch (const std::exception& e) { fprintf(stderr, "korc_analyze: %s\n", e.what()); return 0; }
+		return w.need;
+	}
+
+	// Kiwi::analyze with pretokenized spans, as far as restated (see analyzeOne); the argument layout of kref_analyze_pretokenized (oracle/ref_bridge.cpp).
+	// Returns 0 -- with the reason on stderr -- for a span that is not restated.
+	size_t korc_analyze_pretokenized(void* hp, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, const uint32_t* spans, uint32_t nSpans, const uint16_t* forms, uint8_t* out, size_t cap)
+	{
+		auto& h = *(OracleHandle*)hp;
+		Writer w{ out, out + cap };
+		try
+		{
+			std::vector<PtSpan> pt;
+			const uint32_t* p = spans;
+			for (uint32_t i = 0; i < nSpans; ++i)
+			{
+				PtSpan sp{ p[0], p[1], {} };
+				const uint32_t nTok = p[2];
+				p += 3;
+				for (uint32_t t = 0; t < nTok; ++t, p += 6) sp.toks.push_back(PtToken{ U16{ (const char16_t*)forms + p[0], (const char16_t*)forms + p[0] + p[1] }, p[2], p[3], (uint8_t)p[4], (uint8_t)p[5] });
+				pt.push_back(std::move(sp));
+			}
+			auto res = analyzeOne(h, h.counters, &h.persistent, (const char16_t*)text, len, topN, match, false, nullptr, TypoOpt{}, &pt);
+			writeResults(w, res);
+		}
+		catch (const std::exception& e) { if (!std::getenv("KORC_QUIET")) fprintf(stderr, "korc_analyze_pretokenized: %s\n", e.what()); return 0; }
 		return w.need;
 	}
 

@@ -87,6 +87,24 @@ class OracleKiwi:
             raise RuntimeError("korc_analyze failed")
         return parse_results(buf)
 
+    def analyze_pretokenized(self, text: str, spans, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING):
+        """Kiwi::analyze with pretokenized spans as far as the oracle restates them (spans as in refbridge.RefKiwi.analyze_pretokenized); None when a span needs
+        a temporary form or morpheme (not restated)."""
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        desc, forms = [], []
+        for b, e, toks in spans:
+            desc += [b, e, len(toks)]
+            for form, tb, te, tag, infer in toks:
+                f = np.frombuffer(form.encode("utf-16-le"), np.uint16)
+                desc += [sum(len(x) for x in forms), len(f), tb, te, tag, infer]
+                forms.append(f)
+        d = np.array(desc if desc else [0], np.uint32)
+        fl = np.concatenate(forms) if forms else np.zeros(1, np.uint16)
+        self.lib.korc_analyze_pretokenized.restype = C.c_size_t
+        self.lib.korc_analyze_pretokenized.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t]
+        buf = self._call(lambda *a: self.lib.korc_analyze_pretokenized(self.h, u.ctypes.data, len(u), top_n, match, d.ctypes.data, len(spans), fl.ctypes.data, *a))
+        return parse_results(buf) if len(buf) else None
+
     def split(self, text: str, match: int = MATCH_ALL_WITH_NORMALIZING):
         u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
         buf = self._call(lambda *a: self.lib.korc_split(self.h, u.ctypes.data, len(u), match, *a))

@@ -53,3 +53,33 @@ def test_what_a_span_does_to_an_analysis(golden):
                 n_tok_cases += 1
                 assert [(t[0], t[1] & 0x7F) for t in inside] == [(tk[0], tk[3]) for tk in toks], (g["text"], inside, toks)
     assert n_tok_cases > 80
+
+
+def test_oracle_equals_the_reference_where_it_restates_spans(golden, small_model, monkeypatch):
+    """oracle/oracle.cpp analyzeOne with spans (the chunk cut stepping over a span, the span's node in the lattice, typoFormId of the tokens inside): the cases of
+    makePretokenizedSpanGroup that point at a form of the model -- no tokens given, or one token that is a single-candidate dictionary entry.  Every such golden
+    case: the reference's best analysis and every score bit for bit; beyond the best one up to exactly tied analyses (the top-N rule, include/kiwi_capi.h).
+    Spans that need a temporary form or morpheme are refused (None), not approximated."""
+    import oraclelib
+    monkeypatch.setenv("KORC_QUIET", "1")
+    sm, path = small_model
+    orc = oraclelib.OracleKiwi(path)
+    done = refused = 0
+    for g in golden["cases"]:
+        spans = [(sb, se, [tuple(tk) for tk in toks]) for sb, se, toks in g["spans"]]
+        res = orc.analyze_pretokenized(g["text"], spans, top_n=g["top_n"])
+        if res is None:
+            refused += 1
+            assert any(toks for _, _, toks in g["spans"]), g["spans"]      # (a span without tokens is always restated)
+            continue
+        got = json.loads(json.dumps([{"score": r[1], "tokens": [[x.form, x.tag, x.position, x.length, x.word_position, x.sent_position, x.score, x.typo_form_id, x.morph_id >= 0] for x in r[0]]} for r in res]))
+        assert [r["score"] for r in got] == [r["score"] for r in g["results"]], g["text"]
+        if g["top_n"] == 1:
+            assert got == g["results"], g["text"]
+        # (beyond the best analysis: which of exactly tied analyses come out, and in which order, is the reference's hash-bucket order -- the unknown-noun
+        # readings NNG / NNP of one form tie exactly; an analysis whose score is unique in both lists has to be the same one)
+        for a, b in zip(got, g["results"]):
+            if [r["score"] for r in got].count(a["score"]) == 1 and a is not got[-1]:      # (the last one may tie with an analysis beyond the cut)
+                assert a == b, g["text"]
+        done += 1
+    assert done >= 60 and refused > 60
