@@ -1279,6 +1279,19 @@ namespace kamd
 				stat(mhz, "shader clock (MHz)");
 			}
 			stat(start, "chunk start offset"); stat(nodes, "node loop"); stat(fin, "end-candidate stage"); stat(perNode, "node loop / node");
+			{
+				// the slowest chunks, phase by phase (a batch bound by its heaviest chunks: BASELINE config 3)
+				std::vector<uint32_t> ord;
+				for (uint32_t c = 0; c < nC; ++c) if (tl[16ull * c] && tl[16ull * c + 2]) ord.push_back(c);
+				std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b2) { return tl[16ull * a + 2] - tl[16ull * a] > tl[16ull * b2 + 2] - tl[16ull * b2]; });
+				for (size_t r = 0; r < ord.size() && r < 16; ++r)
+				{
+					const uint32_t c = ord[r];
+					fprintf(stderr, "[timeline] slow chunk %u: start %.0f us, total %.0f us, nodes %u; phases (us):", c, (tl[16ull * c] - t0) * 0.01, (tl[16ull * c + 2] - tl[16ull * c]) * 0.01, (uint32_t)tl[16ull * c + 3]);
+					for (int k = 0; k < 10; ++k) fprintf(stderr, " %d:%.0f", k, tl[16ull * c + 4 + k] * 0.01);
+					fprintf(stderr, "\n");
+				}
+			}
 		}
 #endif
 		for (uint32_t k = 0; timed && k < S; ++k)      // (the timing events are the engine's: only a batch that was waited for in launchAll reads them)

@@ -775,6 +775,13 @@ namespace kamd
 			packTop += __shfl(incl, 63);
 		}
 		waveSync();
+		// (uniform) the candidate records would not fit the chunk's pack region: report the overflow BEFORE anything of phase 8 is written -- the expansion
+		// below stores packs[cc[i] + ...] and would run into the neighbour chunk's region (or past the end of the batch's); kamd_run re-runs the chunk with 4 x capacities
+		if (packTop > W.packBase[chunk + 1] - W.packBase[chunk])
+		{
+			if (lane == 0) W.results[chunk].status = CS_ERR_NODE_OVERFLOW;
+			return;
+		}
 		// ---- 8. (expandMode bit 0) the candidate records and the position program of the position-step search, straight from the lattice in LDS
 		// -- what k_expand_cands and k_expand_pos (lattice_kernels.hip) make of the stored lattice in two more launches.  First every node's
 		// candidates: static records (reference order; CoNgram models: the transposed evaluator's class order) and how many of them are evaluated

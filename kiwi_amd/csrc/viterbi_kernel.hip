@@ -39,7 +39,7 @@
 // top-N (1 < N <= kMaxTopN): the N best paths per key are kept (each with its own values), pruning uses the N-th best score
 // of a root, the end stage hands on ceil(2N / groups) candidates per group; kept paths are handed on in item order (top-N).
 #include <hip/hip_runtime.h>
-#ifdef KAMD_LMSTATS
+#if defined(KAMD_LMSTATS) || defined(KAMD_POSSTATS)
 #include <atomic>
 #include <cstdio>
 #endif
@@ -992,7 +992,37 @@ namespace sbgk
 			// items per candidate, far too many for every item to scan its candidate's list.  top-N keeps the scan (its keys hold
 			// only the last four ring words, and the N-th-best pruning keeps those lists short).
 			const bool hashed = X.P.topN == 1;
+			// top-N: the items of a container key linked into a list through the same table (SbgScratch::next): the count of better items below walks the
+			// key's own list.  Same slots, same cleaning; the key leaves the previous root out and compares the last four ring words (keyMask / last4).
+			const bool listed = X.P.topN > 1 && !fast;
 			constexpr uint32_t TMASK = 2 * BIGQ_SBG - 1;
+			if (listed)
+			{
+				for (uint32_t qb = 0; qb < Qtot; qb += G)
+				{
+					const uint32_t q = qb + X.gl;
+					if (q >= Qtot) continue;
+					const uint64_t key = big ? X.scratch->key[q] : X.qKey()[q];
+					if (key == KINVALID) continue;
+					const uint64_t mkey = key & keyMask;
+					const Ring myRing = loadRing(X.sscr->hist[q], X.sscr->pos[q]); const uint32_t myDigest = X.sscr->hash[q];
+					uint32_t h = (uint32_t)mkey * 0x9E3779B1u ^ (uint32_t)(mkey >> 32) * 0x85EBCA77u ^ myDigest; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+					SbgSlot* e;
+					for (h &= TMASK; ; h = (h + 1) & TMASK)
+					{
+						e = &X.sscr->table[h];
+						uint32_t o = atomicCAS(&e->owner, 0u, q + 1u);
+						if (o == 0) break;                      // claimed a free slot: a new key
+						o -= 1;
+						if (o == q) break;
+						const uint64_t ko = big ? X.scratch->key[o] : X.qKey()[o];
+						if (((ko ^ key) & keyMask) == 0 && X.sscr->hash[o] == myDigest && sameRing(loadRing(X.sscr->hist[o], X.sscr->pos[o]), myRing, last4)) break;
+					}
+					X.sscr->next[q] = atomicExch(&e->firstInv, q + 1u);      // (push front: the order of the list does not matter, the count below is symmetric)
+					X.sscr->slot[q] = h;
+				}
+				waveSync();
+			}
 			if (hashed)
 			{
 				for (uint32_t qb = 0; qb < Qtot; qb += G)
@@ -1048,6 +1078,24 @@ namespace sbgk
 #define KAMD_OTHER_KEY(j, kj) otherKey(j, kj)
 #else
 #define KAMD_OTHER_KEY(j, kj) kj != key
+#endif
+#ifdef KAMD_SBG
+						if (listed)
+						{
+							const float sq = big ? X.scratch->score[q] : X.qScore()[q];
+							uint32_t beaten = 0;
+							// (the head was set by atomics of other lanes: read it the same way)
+							for (uint32_t jn = atomicOr(&X.sscr->table[X.sscr->slot[q]].firstInv, 0u); jn; )
+							{
+								const uint32_t j = jn - 1u;
+								jn = X.sscr->next[j];
+								if (j == q) continue;
+								const float sj = big ? X.scratch->score[j] : X.qScore()[j];
+								if (sj > sq || (sj == sq && j < q)) ++beaten;
+							}
+							rep = beaten < X.P.topN;
+						}
+						else
 #endif
 						if (X.P.topN > 1)
 						{
@@ -1125,7 +1173,7 @@ namespace sbgk
 				}
 			}
 #ifdef KAMD_SBG
-			if (hashed)
+			if (hashed || listed)
 			{
 				// leave the table as it was found: every item frees the slot of its key
 				waveSync();
@@ -1402,51 +1450,70 @@ namespace sbgk
 		}
 		if (topn)
 		{
-			// general sizes: every path counts the socket-free paths of its root that lie more than cutOff above it; the verdicts
-			// are collected first (one bit per block of G paths in a lane-private mask) and applied after all counting is done
-#ifdef KAMD_SBG
-			// (with rings in the keys a node can gain more than 64 x G paths: the verdicts are parked in the states' spare dword,
-			// DevState::pad1, instead of a lane-private bit mask)
-#define KAMD_VERDICT_SET(i, blk) X.st[E.nodeStart + (i)].pad1 = 1u
-#define KAMD_VERDICT_GET(i, blk) (X.st[E.nodeStart + (i)].pad1 != 0)
-#else
-			if (cnt > 64u * G) { X.pairOverflow = true; return; }
-			uint64_t verdict = 0;
-#define KAMD_VERDICT_SET(i, blk) verdict |= 1ull << (blk)
-#define KAMD_VERDICT_GET(i, blk) ((verdict >> (blk)) & 1)
-#endif
-			for (uint32_t b = 0, blk = 0; b < cnt; b += G, ++blk)
+			// general sizes.  A path dies iff at least N socket-free paths of its root lie more than cutOff above it, i.e. iff the N-th best socket-free
+			// score of the root (counted with multiplicity) exceeds its limit.  That threshold is found per root in at most N passes over the node's new paths
+			// ("the best score below the previous one" + how often it occurs), each a strided loop with a wave reduction: O(N x paths / G) -- where every path
+			// counting the paths above it was O(paths^2 / G), which for BASELINE config 3's nodes with thousands of new paths (SkipBigram keys) was 87 % of
+			// the slowest chunks' time (profiles/r05_b_timeline_c3_sbg_8k.txt).  What the passes read -- score, root slot, dead / socket bits -- is first
+			// compacted into the group's item scratch (free between two evaluations) when the paths are not staged in LDS: one dependent read of
+			// DevState + MorphRec per path instead of one per path and pass.
+			const bool compact = !staged && cnt <= BIGQ;
+			if (compact)
 			{
-				const uint32_t i = b + X.gl;
-				if (i >= cnt) continue;
-				float sc; uint32_t slot; bool dead;
-				if (staged) { const uint8_t bits = X.stBits()[i]; sc = X.stScore()[i]; slot = bits & SB_SLOT_MASK; dead = bits & SB_DEAD; }
-				else { const DevState* s = &X.st[E.nodeStart + i]; sc = s->accScore; slot = s->rootId == COMMON_ROOT ? 0 : s->rootId + 1u; dead = s->dead; }
-				if (dead) continue;
-				const float lim = sc + P.cutOff;
-				uint32_t above = 0;
-				for (uint32_t j = 0; j < cnt; ++j)
+				for (uint32_t b = 0; b < cnt; b += G)
 				{
-					float sj; uint32_t slj; bool dj, mj;
-					if (staged) { const uint8_t bj = X.stBits()[j]; sj = X.stScore()[j]; slj = bj & SB_SLOT_MASK; dj = bj & SB_DEAD; mj = bj & SB_MORPH_SOCKET; }
-					else { const DevState* t = &X.st[E.nodeStart + j]; sj = t->accScore; slj = t->rootId == COMMON_ROOT ? 0 : t->rootId + 1u; dj = t->dead; mj = M.morphs[t->morph].socket != 0; }
-					if (!dj && !mj && slj == slot && lim < sj) ++above;
+					const uint32_t i = b + X.gl;
+					if (i >= cnt) continue;
+					const DevState* t = &X.st[E.nodeStart + i];
+					X.scratch->score[i] = t->accScore;
+					X.scratch->key[i] = (uint64_t)((t->rootId == COMMON_ROOT ? 0u : t->rootId + 1u) | (t->dead ? 0x100u : 0u) | (M.morphs[t->morph].socket != 0 ? 0x200u : 0u));
 				}
-				if (above >= P.topN) KAMD_VERDICT_SET(i, blk);
+				waveSync();
+			}
+			// (score, root slot, dead, morpheme socket) of new path i
+			auto pathOf = [&](uint32_t i, float& sc, uint32_t& slot, bool& dead, bool& msock)
+			{
+				if (staged) { const uint8_t bits = X.stBits()[i]; sc = X.stScore()[i]; slot = bits & SB_SLOT_MASK; dead = bits & SB_DEAD; msock = bits & SB_MORPH_SOCKET; }
+				else if (compact) { const uint32_t w = (uint32_t)X.scratch->key[i]; sc = X.scratch->score[i]; slot = w & 0xFFu; dead = (w & 0x100u) != 0; msock = (w & 0x200u) != 0; }
+				else { const DevState* t = &X.st[E.nodeStart + i]; sc = t->accScore; slot = t->rootId == COMMON_ROOT ? 0 : t->rootId + 1u; dead = t->dead; msock = M.morphs[t->morph].socket != 0; }
+			};
+			for (uint32_t rs = 0; rs < nRootSlots; ++rs)
+			{
+				float bound = INFINITY, thr = -INFINITY; uint32_t have = 0; bool first = true;
+				for (uint32_t round = 0; round < P.topN; ++round)
+				{
+					float mx = -INFINITY; uint32_t c = 0;
+					for (uint32_t b = 0; b < cnt; b += G)
+					{
+						const uint32_t i = b + X.gl;
+						if (i >= cnt) continue;
+						float sc; uint32_t slot; bool dead, msock;
+						pathOf(i, sc, slot, dead, msock);
+						if (dead || msock || slot != rs || !(first || sc < bound)) continue;
+						if (sc > mx) { mx = sc; c = 1; } else if (sc == mx) ++c;
+					}
+					float all = mx;
+					for (int d = G / 2; d; d >>= 1) all = fmaxf(all, __shfl_xor(all, d, G));
+					uint32_t call = (mx == all) ? c : 0u;
+					for (int d = G / 2; d; d >>= 1) call += __shfl_xor(call, d, G);
+					if (!call) break;                 // fewer than N socket-free paths of this root: nothing of it dies
+					have += call;
+					if (have >= P.topN) { thr = all; break; }
+					bound = all; first = false;
+				}
+				if (thr == -INFINITY) continue;
+				for (uint32_t b = 0; b < cnt; b += G)
+				{
+					const uint32_t i = b + X.gl;
+					if (i >= cnt) continue;
+					float sc; uint32_t slot; bool dead, msock;
+					pathOf(i, sc, slot, dead, msock);
+					if (dead || slot != rs || !(sc + P.cutOff < thr)) continue;
+					if (staged) X.stBits()[i] = X.stBits()[i] | SB_DEAD;
+					markDead<G>(X, E.nodeStart + i);
+				}
 			}
 			waveSync();
-			for (uint32_t b = 0, blk = 0; b < cnt; b += G, ++blk)
-			{
-				const uint32_t i = b + X.gl;
-				if (i < cnt && KAMD_VERDICT_GET(i, blk))
-				{
-					if (staged) { X.stBits()[i] = X.stBits()[i] | SB_DEAD; markDead<G>(X, E.nodeStart + i); }
-					else markDead<G>(X, E.nodeStart + i);
-				}
-			}
-			waveSync();
-#undef KAMD_VERDICT_SET
-#undef KAMD_VERDICT_GET
 			TLMARK(X, 4)
 			return;
 		}
