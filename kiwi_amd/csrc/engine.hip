@@ -256,6 +256,7 @@ namespace kamd
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
 		bool posPathForced = false;      // KAMD_POS_PATH=2: also for typo correction (slower there: see launchAll)
+		int posGroupForced = 0;          // KAMD_POS_G=8 / 16: lane-group width of the position-step kernel (0: by batch size)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter, posScratch;
 		uint32_t posContSlots = 256;     // chunks per launch that k_pos_path carries on in the general search itself (KAMD_POS_CONT=0: none, all left to k_best_path)
@@ -400,6 +401,7 @@ namespace kamd
 		}
 		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2 or 3" }; }
 		if (const char* pp = std::getenv("KAMD_POS_PATH")) { impl->posPath = std::atoi(pp) != 0; impl->posPathForced = std::atoi(pp) == 2; }
+		if (const char* pg = std::getenv("KAMD_POS_G")) { const int v = std::atoi(pg); if (v == 8 || v == 16) impl->posGroupForced = v; else throw std::runtime_error{ "KAMD_POS_G must be 8 or 16" }; }
 		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
 		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
 		if (const char* lw = std::getenv("KAMD_LATTICE_WAVE")) impl->latticeWave = std::atoi(lw) != 0;
@@ -566,7 +568,7 @@ namespace kamd
 		if (posPath)
 		{
 			b.dPosRecs.ensure((size_t)b.packBase[nC] * sizeof(PosRec) + 16); b.dPosDesc.ensure(totNodes * sizeof(PosDesc) + 16);
-			b.dPosPrev.ensure(totNodes * 4 + 16); b.dPosNodeRec.ensure(totNodes * 4 + 16); b.dPosMask.ensure(totNodes * 4 + 16); b.dPosBig.ensure(((nC + 3) / 4 * 4) * (size_t)64 * 20 + 16);
+			b.dPosPrev.ensure(totNodes * 4 + 16); b.dPosNodeRec.ensure(totNodes * 4 + 16); b.dPosMask.ensure(totNodes * 4 + 16); b.dPosBig.ensure(((nC + 7) / 8 * 8) * (size_t)64 * 20 + 16);
 		}
 		if (I.hasSbg) b.dHist.ensure(totStates * 32 + 32);
 		// compact outputs of the end stage: as many token records as the arenas could hold, 16 path headers per chunk (x capacity scale)
@@ -1035,9 +1037,18 @@ namespace kamd
 			if (usePos)
 			{
 				const bool wide = I.wpsForced ? I.wpsForced == 3 : cn >= 16384;      // many chunks: three waves per SIMD (what the kernel's LDS allows; a 168-VGPR build); few: the latency-bound regime (KAMD_WPS overrides)
-				const uint32_t blocksP = (cn + 3) / 4;      // four chunks per one-wave block, no persistent loop (viterbi_pos.inc)
+				// lane-group width of the position steps: four chunks per wavefront (16-lane groups).  The eight-chunk build (8-lane groups, KAMD_POS_G=8) issues
+				// 20 % fewer vector instructions per position -- the bookkeeping of a step serves twice the positions, the rounds of 64 item lanes are fuller --
+				// and is NOT faster on the MI355X: c2-64k 3.24 against 3.19 ms, c2 0.96 against 0.63, c4-cong 20.9 against 17.7 (profiles/r05_d_*): a wavefront's
+				// step takes as much longer as it serves more positions (2.7 rounds of items per step against 1.6, each a chain of dependent LDS / memory round
+				// trips), and what bounds the kernel is that chain per resident wavefront, not the instruction issue
+				const bool narrow = I.posGroupForced == 8;
+				const uint32_t perBlock = narrow ? 8u : 4u;
+				const uint32_t blocksP = (cn + perBlock - 1) / perBlock;      // one chunk per lane group, one wavefront per block, no persistent loop (viterbi_pos.inc)
 				const float* nodeTypoP = b.typo.typo ? b.dNodeTypo.as<float>() : nullptr;
-#define KAMD_POS_LAUNCH(NS, ...) { if (wide) hipLaunchKernelGGL((NS k_pos_path<16, 3>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
+#define KAMD_POS_LAUNCH(NS, ...) { if (narrow && wide) hipLaunchKernelGGL((NS k_pos_path<8, 3>), dim3(blocksP), dim3(64), kPosKernelLdsBytes8, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
+				else if (narrow) hipLaunchKernelGGL((NS k_pos_path<8, 2>), dim3(blocksP), dim3(64), kPosKernelLdsBytes8, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
+				else if (wide) hipLaunchKernelGGL((NS k_pos_path<16, 3>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
 				else hipLaunchKernelGGL((NS k_pos_path<16, 2>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); }
 				if (I.hasCong && b.typo.typo) KAMD_POS_LAUNCH(typok::congk::, nodeTypoP, I.cong)
 				else if (I.hasCong) KAMD_POS_LAUNCH(congk::, I.cong)

@@ -307,6 +307,14 @@ namespace kamd
 				if (nBuckets > (size_t(1) << 32)) throw std::runtime_error{ "language model: the edge table would need more than 2^32 buckets (" + std::to_string(nEdges) + " edges)" };
 				m.lmHashMask = (uint32_t)(nBuckets - 1);
 				m.lmHash.assign(nBuckets * 4, LmSlot{ LM_SLOT_EMPTY, LM_SLOT_EMPTY, 0, 0.f });
+				if (std::getenv("KAMD_LM_STATS"))      // developer aid: the shape of the language model's trie
+				{
+					size_t hist[12] = {}; size_t edgesIn[12] = {};
+					for (uint32_t nd = 1; nd < nonLeaf; ++nd) { uint32_t k = m.lmNodes[nd].numNexts, b = 0; while ((1u << b) < k + 1 && b < 11) ++b; ++hist[b]; edgesIn[b] += k; }
+					fprintf(stderr, "[lm stats] unigrams %u, non-leaf nodes %zu, edges below the root's %zu, hash buckets %zu (%.1f MB), back-off records %.1f MB; nodes (edges) by fan-out < 2^b:", (unsigned)m.lmNodes[0].numNexts, nonLeaf, nEdges, nBuckets, nBuckets * 64e-6, m.lmBackoff.size() * 8e-6);
+					for (int b = 0; b < 12; ++b) fprintf(stderr, " %d:%zu(%zu)", b, hist[b], edgesIn[b]);
+					fprintf(stderr, "\n");
+				}
 				for (uint32_t nd = 1; nd < nonLeaf; ++nd)
 				{
 					const LmNodeRec& r = m.lmNodes[nd];

@@ -2220,6 +2220,8 @@ namespace sbgk
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
 	template __global__ void k_pos_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
+	template __global__ void k_pos_path<8, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
+	template __global__ void k_pos_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);
 }
 }
 #elif defined(KAMD_TYPO) && defined(KAMD_SBG)
@@ -2236,12 +2238,16 @@ namespace sbgk
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
 	template __global__ void k_pos_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
+	template __global__ void k_pos_path<8, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
+	template __global__ void k_pos_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*);
 }
 #elif defined(KAMD_CONG)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
 	template __global__ void k_pos_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
+	template __global__ void k_pos_path<8, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
+	template __global__ void k_pos_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, CongDev);
 }
 #else
 	template __global__ void k_best_path<4, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
@@ -2253,5 +2259,7 @@ namespace sbgk
 	template __global__ void k_best_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
 	template __global__ void k_pos_path<16, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
+	template __global__ void k_pos_path<8, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
+	template __global__ void k_pos_path<8, 3>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t);
 #endif
 }

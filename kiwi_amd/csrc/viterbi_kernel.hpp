@@ -36,7 +36,8 @@ namespace kamd
 	struct SbgScratch { uint32_t hist[BIGQ_SBG][8]; uint32_t pos[BIGQ_SBG]; uint32_t hash[BIGQ_SBG]; uint32_t slot[BIGQ_SBG]; uint32_t next[BIGQ_SBG]; SbgSlot table[2 * BIGQ_SBG]; };
 
 	uint32_t searchKernelLdsBytes(int G);
-	constexpr uint32_t kPosKernelLdsBytes = 12800;      // dynamic LDS of k_pos_path (four lane groups: ring + staged new states)
+	constexpr uint32_t kPosKernelLdsBytes = 12800;      // dynamic LDS of k_pos_path<16, .> (four lane groups: ring + staged new states)
+	constexpr uint32_t kPosKernelLdsBytes8 = 13312;     // ... of k_pos_path<8, .> (eight lane groups of half the size each; 26 x 512 bytes: twelve one-wave blocks per CU as before)
 
 	// G = lanes per chunk (4, 8, 16, 32 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
 	// WPS = waves per SIMD the instantiation is compiled for (2, or 3 for G = 8 / 16).

@@ -108,13 +108,19 @@ def pick_blocklist(analyzer, texts, k, any_tag_every=4):
 
 def force_lanes(monkeypatch, lanes):
     """KAMD_GROUP_LANES for a test's engine: a lane-group width forces the general search kernel k_best_path<lanes>; "pos" leaves the engine's own
-    choice in place -- top-1 searches then run the position-step kernel k_pos_path first (KAMD_WPS=3 selects its three-waves build)."""
-    if lanes == "pos":
+    choice in place -- top-1 searches then run the position-step kernel k_pos_path first (KAMD_WPS=3 selects its three-waves build); "pos8": its build with
+    eight chunks per wavefront (8-lane groups)."""
+    if lanes in ("pos", "pos8"):
         monkeypatch.delenv("KAMD_GROUP_LANES", raising=False)
         monkeypatch.setenv("KAMD_POS_PATH", "2")      # (also for typo correction, where the engine's own choice is the general kernel)
+        if lanes == "pos8":
+            monkeypatch.setenv("KAMD_POS_G", "8")     # k_pos_path<8, .>: eight chunks per wavefront (the engine's own choice is 16-lane groups)
+        else:
+            monkeypatch.delenv("KAMD_POS_G", raising=False)
     else:
         monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
         monkeypatch.delenv("KAMD_POS_PATH", raising=False)
+        monkeypatch.delenv("KAMD_POS_G", raising=False)
 
 
 def repeated_unknown_texts(sm, n, seed):

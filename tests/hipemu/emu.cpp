@@ -134,6 +134,7 @@ namespace hipemu
 
 	LaneCtx& ctx() { return B->lanes[B->cur].ctx; }
 	uint32_t width() { return B->width; }
+	void setWidth(uint32_t w) { if (w == 0 || w > 64 || (w & (w - 1))) die("unsupported convergence width"); B->width = w; }      // (between two block-wide rendezvous: no lane is inside a group-wide one)
 	bool dropWaveBarrier() { return B->dropBarrier; }
 
 	const uint64_t* exchange(Op op, uint32_t domain, uint64_t mine, uint64_t* active, uint32_t* domainBase)

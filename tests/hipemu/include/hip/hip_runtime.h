@@ -147,6 +147,20 @@ template<class T> inline T hipemu_shfl64(T var, int srcLane)
 	if (src >= blockDim.x || !((active >> src) & 1)) return var;
 	return hipemu::unpack<T>(v[base + src]);
 }
+// row_ror:n over the 16-lane rows of the whole wavefront (a kernel whose convergence width is narrower than a DPP row, in a phase all 64 lanes run together:
+// k_pos_path<8, .> packs the items of its eight lane groups into the four rows); an absent lane reads as 0
+inline int hipemu_row_ror64(int src, int n)
+{
+	uint64_t active; uint32_t base;
+	const uint64_t* v = hipemu::exchange(hipemu::OP_DPP, blockDim.x, hipemu::pack(src), &active, &base);
+	const uint32_t self = threadIdx.x, from = (self & ~15u) | ((self - (uint32_t)n) & 15u);
+	if (from >= blockDim.x || !((active >> from) & 1)) return 0;
+	return hipemu::unpack<int>(v[base + from]);
+}
+// the convergence width of the running kernel changes (all lanes of the block call this together): k_pos_path<8, .> carries chunks on in the general
+// search, whose lane groups are 16 wide
+namespace hipemu { void setWidth(uint32_t w); }
+inline void hipemu_set_width(uint32_t w) { uint64_t a; uint32_t b; (void)hipemu::exchange(hipemu::OP_SYNCTHREADS, blockDim.x, 0, &a, &b); hipemu::setWidth(w); (void)hipemu::exchange(hipemu::OP_SYNCTHREADS, blockDim.x, 0, &a, &b); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 // HIPEMU_TEST_DROP_WAVE_BARRIER=<kernel name> turns the wave barrier of that kernel into nothing: the self-test of the race detector
 // (the ThreadSanitizer build must then report the races the barrier exists to prevent; tests/test_hipemu.py)

@@ -16,7 +16,7 @@ def _norm(res):
     return [([astuple(t) for t in a[0]], a[1]) for a in res]
 
 
-@pytest.mark.parametrize("lanes,top_n", [("pos", 1), ("16", 1), ("64", 1), ("16", 2), ("64", 2)])
+@pytest.mark.parametrize("lanes,top_n", [("pos", 1), ("pos8", 1), ("16", 1), ("64", 1), ("16", 2), ("64", 2)])
 def test_cong_tokens_bit_exact_vs_oracle(small_cong_model, monkeypatch, lanes, top_n):
     import oraclelib
     from kiwi_amd.api import KiwiAmd

@@ -147,7 +147,7 @@ def test_lattice_hbm_kernel_matches_lds_kernel(engine, oracle, small_model, monk
     monkeypatch.delenv("KAMD_LATTICE_LDS")
 
 
-@pytest.mark.parametrize("lanes,wps", [("pos", "2"), ("pos", "3"), ("8", "3"), ("8", "2"), ("16", "3"), ("4", "2"), ("32", "2"), ("64", "2")])
+@pytest.mark.parametrize("lanes,wps", [("pos", "2"), ("pos", "3"), ("pos8", "2"), ("pos8", "3"), ("8", "3"), ("8", "2"), ("16", "3"), ("4", "2"), ("32", "2"), ("64", "2")])
 def test_lane_group_variants_match_oracle(oracle, small_model, monkeypatch, lanes, wps):
     """Every instantiation of the search kernel (lanes per chunk x register budget) gives the oracle's result; large batches
     select 8 lanes / 3 waves per SIMD on their own (engine.hip), the others are reachable through KAMD_GROUP_LANES / KAMD_WPS."""
@@ -155,7 +155,7 @@ def test_lane_group_variants_match_oracle(oracle, small_model, monkeypatch, lane
     sm, path = small_model
     texts = synthetic(sm, 300, 121, min_jamo=5, max_jamo=150) + dictionary_mix(sm, 150, 122) + EDGE_TEXTS
     force_lanes(monkeypatch, lanes)
-    if lanes in ("8", "16", "pos"):
+    if lanes in ("8", "16", "pos", "pos8"):
         monkeypatch.setenv("KAMD_WPS", wps)
     other = KiwiAmd(path)
     for top_n in (1, 2):
@@ -165,7 +165,7 @@ def test_lane_group_variants_match_oracle(oracle, small_model, monkeypatch, lane
     other.close()
 
 
-@pytest.mark.parametrize("lanes", ["pos", "16", "8", "64"])
+@pytest.mark.parametrize("lanes", ["pos", "pos8", "16", "8", "64"])
 def test_fallback_paths_with_small_capacities(small_model, monkeypatch, lanes):
     """The synthetic lattices are too unambiguous to reach the medium / large path containers (> 128 / > 512 incoming paths),
     the HBM work-item queue (> 32 items of one candidate), the HBM pruning path (> 32 new paths of a node) or the far-back node

@@ -52,7 +52,7 @@ def test_typo_analyses_through_the_capacity_ladder(small_model, monkeypatch):
     dev.close(); prod.close()
 
 
-@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("pos", 1, 1.0, 0.25), ("16", 1, 1.0, float("inf")), ("64", 2, 1.0, 0.25)])
+@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("pos", 1, 1.0, 0.25), ("pos8", 1, 1.0, 0.25), ("16", 1, 1.0, float("inf")), ("64", 2, 1.0, 0.25)])
 def test_typo_correction_with_a_cong_model(small_cong_model, monkeypatch, lanes, top_n, continual, lengthening):
     """The reference's default model type with typo correction: viterbi_kernel_cong_typo.hip (CoNgram scoring + node typo costs) on the MI355X
     against the oracle (pinned for this combination to the reference's SSE4.1 build) and, where it travelled, the real reference itself."""

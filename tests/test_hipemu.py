@@ -47,16 +47,16 @@ def test_the_product_library_is_not_the_emulator(emu_libs):
                 assert "hipemu" not in open(os.path.join(root, f), encoding="utf-8", errors="ignore").read(), f
 
 
-@pytest.mark.parametrize("lanes,wps", [("pos", "2"), ("pos", "3"), ("16", "2"), ("16", "3"), ("8", "3"), ("8", "2"), ("4", "2"), ("32", "2"), ("64", "2")])
+@pytest.mark.parametrize("lanes,wps", [("pos", "2"), ("pos", "3"), ("pos8", "2"), ("pos8", "3"), ("16", "2"), ("16", "3"), ("8", "3"), ("8", "2"), ("4", "2"), ("32", "2"), ("64", "2")])
 def test_emulated_knlm_kernels_match_oracle(emu_libs, oracle, small_model, monkeypatch, lanes, wps):
     """Dictionary scan, lattice build (LDS and HBM variants), candidate expansion, best-path search in every lane-group
     instantiation, end stage: tokens, positions and fp32 scores equal the oracle's, top-1 and top-2."""
     from kiwi_amd.api import KiwiAmd
     sm, path = small_model
     force_lanes(monkeypatch, lanes)
-    if lanes in ("8", "16", "pos"):
+    if lanes in ("8", "16", "pos", "pos8"):
         monkeypatch.setenv("KAMD_WPS", wps)
-    n = 100 if lanes in ("16", "pos") and wps == "2" else 40
+    n = 100 if lanes in ("16", "pos", "pos8") and wps == "2" else 40
     texts = synthetic(sm, n, 521, min_jamo=5, max_jamo=120) + dictionary_mix(sm, n // 2, 522) + (EDGE_TEXTS + fuzzed(sm, 150, 523) if n == 100 else [])      # (fuzzed: lone surrogates, pattern fragments, other scripts)
     dev = KiwiAmd(path, lib_path=emu_libs[0])
     _check(dev, oracle, texts, (1, 2))
@@ -111,7 +111,7 @@ def test_emulated_order_4_knlm(emu_libs, small_order4_model, monkeypatch, lanes)
     dev.close()
 
 
-@pytest.mark.parametrize("lanes", ["pos", "16", "8", "64"])
+@pytest.mark.parametrize("lanes", ["pos", "pos8", "16", "8", "64"])
 def test_emulated_fallback_paths_with_small_capacities(emu_libs, small_model, monkeypatch, lanes):
     """The `smallcaps` configuration (LDS capacities of 4) with the container limits cut to 3 / 8 / 2 on both sides:
     medium / large containers, HBM work-item queue, HBM pruning path, far-back node lookup."""
@@ -451,7 +451,7 @@ def test_emulated_typo_analyses_match_oracle(emu_libs, small_model, monkeypatch,
 
 
 
-@pytest.mark.parametrize("lanes,top_n", [("pos", 1), ("16", 1), ("64", 1), ("16", 2), ("16", 3)])
+@pytest.mark.parametrize("lanes,top_n", [("pos", 1), ("pos8", 1), ("16", 1), ("64", 1), ("16", 2), ("16", 3)])
 def test_emulated_cong_kernels_match_oracle(emu_libs, small_cong_model, monkeypatch, lanes, top_n):
     """The search kernel compiled for CoNgram models (viterbi_kernel_cong.hip: context trie + int8 embedding dot product, candidates in the
     transposed evaluator's order, the reference kernel's rounding per node) against the oracle, whose CoNgram path is pinned to the REAL
@@ -514,7 +514,7 @@ def test_emulated_blocklist_matches_oracle(emu_libs, small_model, small_cong_mod
     ms.close(); dev.close()
 
 
-@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("pos", 1, 1.0, 0.25), ("16", 1, 1.0, float("inf")), ("64", 1, 1.0, 0.25), ("16", 2, float("inf"), float("inf"))])
+@pytest.mark.parametrize("lanes,top_n,continual,lengthening", [("pos", 1, 1.0, 0.25), ("pos8", 1, 1.0, 0.25), ("16", 1, 1.0, float("inf")), ("64", 1, 1.0, 0.25), ("16", 2, float("inf"), float("inf"))])
 def test_emulated_typo_correction_with_a_cong_model(emu_libs, small_cong_model, monkeypatch, lanes, top_n, continual, lengthening):
     """Typo correction on a CoNgram model (the reference's default model type with its --typo configurations): the fifth compilation of the search
     kernel (viterbi_kernel_cong_typo.hip: CoNgram scoring + node typo costs) over the typo lattices, against the oracle -- pinned for this
