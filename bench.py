@@ -321,9 +321,17 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
 
+    tw0 = time.perf_counter()
     for _ in range(args.warmup):
         eng.run(batch)
     sync()
+    # --steps is a MINIMUM: the timed region lasts at least a second (a 20-step region of a 5 ms step is 0.1 s -- too short for a utilisation sampler, and
+    # for a stable mean); the step count actually timed is what the line reports.  Profiler passes (--kernels-only) time exactly what they were asked.
+    steps_requested = args.steps
+    if args.warmup and not args.kernels_only:
+        est = dist.max_over_ranks((time.perf_counter() - tw0) / args.warmup, device="cuda" if world > 1 else "cpu")
+        if est > 0 and args.steps * est < 1.0:
+            args.steps = min(100000, int(1.0 / est) + 1)
     t0 = time.perf_counter()
     kt = {"scan_ms": 0.0, "lattice_ms": 0.0, "search_ms": 0.0, "finish_ms": 0.0}
     for _ in range(args.steps):
@@ -387,23 +395,35 @@ def main():
         tkw = {} if typo is None else {"typo": typo, "typo_threshold": typo_cfg[2]}
         from kiwi_amd.api import pack_texts
         flat, offs = pack_texts(shard)
-        e2e_steps = max(3, min(args.steps, 10))
+        e2e_steps = 30      # (a spread needs a sample: >= 30 batches unless one takes seconds)
         tw = time.perf_counter()
         eng.analyze_packed(flat, offs, top_n, **tkw).close()      # warm-up (device blocks, pinned buffers, host pool)
-        if time.perf_counter() - tw > 2.0:
+        first = time.perf_counter() - tw
+        if first > 2.0:
             e2e_steps = 1      # a slow workload (seconds per batch): one timed batch
         else:
+            if first > 0.25:
+                e2e_steps = 5
             eng.analyze_packed(flat, offs, top_n, **tkw).close()
         sync()
         te = time.perf_counter()
         d2h = 0
+        per_batch = []
         for _ in range(e2e_steps):
+            tb = time.perf_counter()
             r = eng.analyze_packed(flat, offs, top_n, **tkw)
             d2h = r.d2h_bytes()
             r.close()
+            per_batch.append(1000.0 * (time.perf_counter() - tb))
         sync()
         e2e_elapsed = dist.max_over_ranks(time.perf_counter() - te, device="cuda" if world > 1 else "cpu")
+        per_batch.sort()
+        pct = lambda q: per_batch[min(len(per_batch) - 1, int(q * len(per_batch)))]
+        host_cores = cpu_quota_cores() or os.cpu_count() or 1
         e2e = {"value": n_job * e2e_steps / e2e_elapsed, "unit": "sentences/s", "ms_per_batch": 1000.0 * e2e_elapsed / e2e_steps, "steps": e2e_steps,
+               "ms_per_batch_median": pct(0.5), "ms_per_batch_p10": pct(0.1), "ms_per_batch_p90": pct(0.9),
+               # what the host side of a batch costs in CPU time if the whole quota works on it for the whole batch (an upper bound: the kernels hide behind it)
+               "host_cores": host_cores, "host_us_per_sentence_core": 1000.0 * pct(0.5) * host_cores / max(1, n),
                "region": "host UTF-16 strings -> kamd_analyze_batch -> host token records (text preparation, H2D, kernels, D2H, result assembly)",
                "h2d_bytes_per_batch": int(flat.nbytes), "d2h_bytes_per_batch": d2h}
 
@@ -412,7 +432,7 @@ def main():
         value = total_sent / elapsed
         out = {
             "metric": "sentences/sec on batched analyze(), device kernels with inputs resident in HBM (dictionary scan + lattice + Viterbi/%s, top-%d); host-to-host rate: see e2e" % ("Knlm+SkipBigram" if args.workload.endswith("-sbg") else "CoNgram (local, 8-bit)" if "cong" in args.workload else "Knlm, typo correction" if typo is not None else "Knlm", top_n),
-            "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "sentences/s", "n_gpus": world, "steps": args.steps, "steps_requested": steps_requested, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "int32+f32", "data": "synthetic",
             "config": {"workload": desc, "sentences_per_gpu": n, "chunks_per_gpu": info["chunks"], "jamo_per_gpu": info["units"],

@@ -187,6 +187,7 @@ namespace kamd
 		std::vector<ChunkRef> refs;
 		uint64_t match = 0;
 		uint32_t capScale = 1;
+		bool isRerun = false;                         // a batch of runRefs (chunks searched again): the engine's adaptive capacities do not learn from it
 		uint64_t units = 0, devBytes = 0;
 		// host layout
 		std::vector<uint32_t> charOff, patOff, spOff, matchBase, nodeBase, packBase;
@@ -250,7 +251,7 @@ namespace kamd
 		// state arenas: sixteenths of the worst-case capacity (48 states per text unit + 256; SkipBigram models x 8) a chunk's region gets.  Follows what the
 		// chunks of the batches so far needed (x 2, read from the downloaded per-chunk results); a batch in which a chunk ran out goes back to the full
 		// capacity (the capacity ladder inside run() has searched that chunk again meanwhile).  KAMD_STATE_SCALE=<sixteenths> fixes it
-		uint32_t stateScale16[2] = { 16, 0 }; bool stateScaleForced = false;      // [needed by top-1 batches, by top-N batches (0: none seen yet)]; a region gets the larger of the two (a batch is laid out before its top-N is known)
+		uint32_t stateScale16[2] = { 16, 16 }; bool stateScaleForced = false;      // [needed by top-1 batches, by top-N batches (0: none seen yet)]; a region gets the larger of the two (a batch is laid out before its top-N is known)
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
 		uint32_t latticeWaveBudget = 128 * 1024; // ... and k_lattice_wave, which is allowed beyond the default 64 KB limit (a 400-unit chunk needs ~70 KB; the CU has 160 KB)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
@@ -493,13 +494,16 @@ namespace kamd
 		const size_t oSpOff = take(4 * (nC + 1)), oSp = take(b.spOff[nC]), oFlags = take(nC), oTextOff = take(4 * nC);
 		// Match::oovChrFreqModel: the filtered normalised texts of the batch, once per text, and where each chunk's text lies
 		const bool chrFreq = ((b.match >> 8) & 3) > 1;
-		std::vector<uint32_t> filtAt;
+		// (only the texts this batch's chunks come from: a re-run of one chunk borrows the parent batch's whole `prep` -- ADVICE r04)
+		std::vector<uint32_t> filtAt; std::vector<uint32_t> filtTexts;
 		size_t totFilt = 0;
 		if (chrFreq)
 		{
-			filtAt.resize(b.prep.size() + 1);
-			for (size_t t = 0; t < b.prep.size(); ++t) { filtAt[t] = (uint32_t)totFilt; totFilt += b.prep[t].norm.size(); }
-			filtAt[b.prep.size()] = (uint32_t)totFilt;
+			constexpr uint32_t kUnused = 0xFFFFFFFFu;
+			filtAt.assign(b.prep.size(), kUnused);
+			for (const auto& r : b.refs) if (filtAt[r.text] == kUnused) { filtAt[r.text] = 0; filtTexts.push_back((uint32_t)r.text); }
+			std::sort(filtTexts.begin(), filtTexts.end());
+			for (const uint32_t t : filtTexts) { if (totFilt > 0xFFFFFFF0ull) break; filtAt[t] = (uint32_t)totFilt; totFilt += b.prep[t].norm.size(); }
 			if (totFilt > 0xFFFFFFF0ull) throw std::runtime_error{ "batch too large for 32-bit text offsets: split the batch" };
 		}
 		const size_t oFilt = take(2 * totFilt), oFiltOff = take(chrFreq ? 4 * nC : 0), oFiltLen = take(chrFreq ? 4 * nC : 0);
@@ -535,10 +539,11 @@ namespace kamd
 		{
 			// Kiwi.cpp:1064-1084: identifySpecialChr of every UTF-16 UNIT (a surrogate on its own, unlike `cls`, which types a pair at its first unit)
 			const uint8_t hiType = identifySpecialChr(0xD800), loType = identifySpecialChr(0xDC00);
-			HostPool::instance().run(b.prep.size(), 256, b.hostThreads, [&](size_t t0, size_t t1, int)
+			HostPool::instance().run(filtTexts.size(), 256, b.hostThreads, [&](size_t t0, size_t t1, int)
 			{
-				for (size_t t = t0; t < t1; ++t)
+				for (size_t ti = t0; ti < t1; ++ti)
 				{
+					const size_t t = filtTexts[ti];
 					const PreparedView& pt = b.prep[t];
 					uint16_t* o = reinterpret_cast<uint16_t*>(H + oFilt) + filtAt[t];
 					for (size_t k = 0; k < pt.norm.size(); ++k)
@@ -958,6 +963,8 @@ namespace kamd
 				// the size classes of k_lattice_wave go over four streams (forked from and joined back into sA; which one: decided with the classes): a class ends when its slowest
 				// wavefront does, and the next class's wavefronts fill the machine meanwhile
 				uint32_t nClass = 0;
+				// (the list of chunks for the wide launch starts empty for every sub-batch: entries of an earlier sub-batch, long built, would use its slots up -- ADVICE r04)
+				if (wave && k) HIPCHECK(hipMemsetAsync(b.dOutCounters.as<uint32_t>() + 3, 0, 4, sA));
 				if (wave) { HIPCHECK(hipEventRecord(I.latFork, sA)); for (auto ls : I.latStream) HIPCHECK(hipStreamWaitEvent(ls, I.latFork, 0)); }
 				for (const auto& lc : b.latClasses[k])
 				{
@@ -976,7 +983,7 @@ namespace kamd
 				}
 				if (wave) for (int t = 0; t < 3; ++t) { HIPCHECK(hipEventRecord(I.latJoin[t], I.latStream[t])); HIPCHECK(hipStreamWaitEvent(sA, I.latJoin[t], 0)); }
 				// what outgrew the first launch's LDS arrays: the same kernel with room for 3 matches and one other op per text unit, over the list the first launch left
-				if (wave && budget) hipLaunchKernelGGL(k_lattice_wave, dim3(std::min(cn, 1024u)), dim3(64), budget, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + c0, std::min(cn, 1024u), budget, kLatticeWideRatio16 | kLatticeWideBit | (ratio16 & 0x4000u), expandMode);
+				if (wave && budget) hipLaunchKernelGGL(k_lattice_wave, dim3(std::min(cn, 16384u)), dim3(64), budget, sA, I.dview, b.bv, b.wv, sp, b.dOrder.as<uint32_t>() + c0, std::min(cn, 16384u), budget, kLatticeWideRatio16 | kLatticeWideBit | (ratio16 & 0x4000u), expandMode);
 				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, budget, wave ? (ratio16 & 0x3FFFu) : 0u);
 			}
 			}
@@ -1199,7 +1206,7 @@ namespace kamd
 			for (int k2 = 0; k2 < 14; ++k2) fprintf(stderr, " %s %.0f (%.0f%%);", names[k2], steps ? acc[k2] / steps : 0.0, tot ? 100.0 * acc[k2] / tot : 0.0);
 			fprintf(stderr, " total %.0f\n", steps ? tot / steps : 0.0);
 		}
-		if (I.latticeWave && !I.latticeRatioForced && !b.typo.typo && nC)
+		if (I.latticeWave && !I.latticeRatioForced && !b.typo.typo && nC >= 256 && b.capScale == 1 && !b.isRerun)
 		{
 			// k_lattice_wave's LDS room for the next batch: 1.25 x the most matches per text unit any chunk of this batch had (+ 1/8), more at once
 			// when chunks had to go to the wide launch for lack of room; never below 3/4 nor above 3 per unit
@@ -1207,6 +1214,8 @@ namespace kamd
 			HIPCHECK(hipMemcpyAsync(c16, b.dOutCounters.p, 64, hipMemcpyDeviceToHost, I.streamCopy)); HIPCHECK(hipStreamSynchronize(I.streamCopy));
 			uint32_t want = (c16[13] * 16u * 5u / 4u + 99u) / 100u + 2u;
 			if (c16[4] + c16[5] > nC / 256) want = std::max(want, I.latticeRatio16 * 3u / 2u);
+			// (a decaying maximum, not the last value: one batch of plain text does not send the next dictionary-dense one to the wide and big fall-backs -- ADVICE r04)
+			want = std::max(want, I.latticeRatio16 - std::min(I.latticeRatio16, (I.latticeRatio16 + 7u) / 8u));
 			I.latticeRatio16 = std::min(kLatticeWideRatio16, std::max(12u, want));
 		}
 		if (getenv("KAMD_LATTICE_PROFILE") && lwProf.p)
@@ -1521,7 +1530,7 @@ namespace kamd
 				w += cw; ++r1;
 			}
 			StagedBatch b;
-			b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo; b.hostThreads = 1;
+			b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo; b.hostThreads = 1; b.isRerun = true;
 			b.refs.assign(refs.begin() + r0, refs.begin() + r1);
 			std::vector<size_t> failing;
 			b.prep.swap(parent.prep);   // borrow the prepared texts for the duration of the launch

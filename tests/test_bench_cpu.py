@@ -33,9 +33,11 @@ def test_bench_main_emits_the_contract_line(tmp_path):
     out = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in out, k
-    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["unit"] == "sentences/s" and out["higher_is_better"] is True
+    # (--steps is a minimum: the timed region lasts at least a second, the line reports the steps it timed)
+    assert out["n_gpus"] == 1 and out["steps_requested"] == 2 and out["steps"] >= 2 and out["warmup"] == 1 and out["unit"] == "sentences/s" and out["higher_is_better"] is True
+    assert out["steps"] * out["ms_per_step"] >= 999.0 or out["steps"] == 2
     assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["data"] == "synthetic" and "workload" in out["config"]
-    assert out["value"] > 0 and abs(out["value"] - 24 * 2 / (out["ms_per_step"] * 2 / 1000.0)) < 1e-6 * out["value"] + 1e-9
+    assert out["value"] > 0 and abs(out["value"] - 24 * out["steps"] / (out["ms_per_step"] * out["steps"] / 1000.0)) < 1e-6 * out["value"] + 1e-9
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in out["roofline"], k
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["unit"] == "GB/s" and abs(out["roofline"]["frac"] - out["roofline"]["achieved"] / out["roofline"]["peak"]) < 1e-12
