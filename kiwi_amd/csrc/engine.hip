@@ -1590,7 +1590,12 @@ namespace kamd
 			uint64_t need16 = 1; size_t seen = 0;
 			for (uint32_t k = 0; k < 18; ++k) { seen += hist[k]; need16 = std::max<uint64_t>(1, k); if (seen * 1000 >= counted * 999) break; }
 			impl->stateScale16[b.topN > 1 ? 1 : 0] = b.rerunChunks ? 16u : (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, need16 * 2));
-			if (std::getenv("KAMD_LATTICE_STATS")) fprintf(stderr, "[state arenas] top-%u batch of %zu chunks: most used %llu/16 of the worst-case capacity, %u re-run -> scale %u/16 (top-1) %u/16 (top-N)\n", b.topN, b.refs.size(), (unsigned long long)need16, b.rerunChunks, impl->stateScale16[0], impl->stateScale16[1]);
+			if (std::getenv("KAMD_LATTICE_STATS"))
+			{
+				fprintf(stderr, "[state arenas] top-%u batch of %zu chunks: most used %llu/16 of the worst-case capacity, %u re-run -> scale %u/16 (top-1) %u/16 (top-N); chunks by sixteenths used:", b.topN, b.refs.size(), (unsigned long long)need16, b.rerunChunks, impl->stateScale16[0], impl->stateScale16[1]);
+				for (uint32_t k = 0; k < 18; ++k) if (hist[k]) fprintf(stderr, " %u:%u", k, hist[k]);
+				fprintf(stderr, "\n");
+			}
 		}
 		const size_t nT = b.prep.size();
 		BatchResults ret;

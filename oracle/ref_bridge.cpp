@@ -166,6 +166,7 @@ namespace kiwi
 		static bool hasChr(const Kiwi& k) { return !!k.nounChrMdl; }
 #endif
 		static bool& congGlobalWanted() { static bool v = false; return v; }
+		static Dialect& enabledDialects() { static Dialect v = Dialect::standard; return v; }      // KiwiBuilder::enabledDialects of the bake below (kref_open_dialects)
 		static Kiwi build(const kamd::RawModel& raw, ArchType arch)
 		{
 			Vector<FormRaw> forms; Vector<MorphemeRaw> morphemes;
@@ -262,7 +263,7 @@ namespace kiwi
 					return m->dialect == Dialect::standard && tag != POSTag::unknown && tag != POSTag::pa && tag != POSTag::pv;
 				});
 				f.dialect = std::accumulate(f.candidate.begin(), f.candidate.end(), f.candidate[0]->dialect, reduceDialectR);
-				if (f.dialect != Dialect::standard) continue; // enabledDialects == standard
+				if (f.dialect != Dialect::standard && !(enabledDialects() & f.dialect)) continue;      // (KiwiBuilder.cpp:2500-2504)
 				sortedForms.emplace_back(&f);
 			}
 			std::sort(sortedForms.begin(), sortedForms.end(), [](const Form* a, const Form* b)
@@ -372,6 +373,15 @@ extern "C"
 			fprintf(stderr, "kref_open: %s\n", e.what());
 			return nullptr;
 		}
+	}
+
+	// the same with KiwiBuilder's enabledDialects (kiwi_init's last argument): forms whose candidates are all of disabled dialects stay out of the trie
+	void* kref_open_dialects(const char* rawModelPath, int arch, int enabledDialects)
+	{
+		Acc::enabledDialects() = (kiwi::Dialect)enabledDialects;
+		void* h = kref_open(rawModelPath, arch);
+		Acc::enabledDialects() = kiwi::Dialect::standard;
+		return h;
 	}
 
 #ifdef KREF_X86
@@ -697,8 +707,10 @@ extern "C"
 	{
 		return kref_analyze_typo(hp, nullptr, 2.5f, 0, text, len, topN, match, openEnding, out, cap);
 	}
+	size_t kref_analyze_dialect(void* hp, void* typoHp, float typoThreshold, int allowedDialect, float dialectCost, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap);
 	size_t kref_analyze_typo(void* hp, void* typoHp, float typoThreshold, int allowedDialect, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
 	{
+		if (!typoHp && allowedDialect) return kref_analyze_dialect(hp, nullptr, typoThreshold, allowedDialect, 3.f, text, len, topN, match, openEnding, out, cap);
 		auto& kw = ((RefHandle*)hp)->kw;
 		Writer w{ out, out + cap };
 		try
@@ -713,6 +725,30 @@ extern "C"
 		catch (const std::exception& e)
 		{
 			fprintf(stderr, "kref_analyze: %s\n", e.what());
+			return 0;
+		}
+		return w.need;
+	}
+
+	// AnalyzeOption::allowedDialects / dialectCost (include/kiwi/Kiwi.h); without a typo transformer the reference takes its built-in `dialect` set itself
+	// (src/Kiwi.cpp:1037-1041)
+	size_t kref_analyze_dialect(void* hp, void* typoHp, float typoThreshold, int allowedDialect, float dialectCost, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
+	{
+		auto& kw = ((RefHandle*)hp)->kw;
+		Writer w{ out, out + cap };
+		try
+		{
+			kiwi::AnalyzeOption opt{ (kiwi::Match)match };
+			opt.openEnding = !!openEnding;
+			if (typoHp) { opt.typoTransformer = ((TypoHandle*)typoHp)->ptt.get(); opt.typoThreshold = typoThreshold; }
+			opt.allowedDialects = (kiwi::Dialect)allowedDialect; opt.dialectCost = dialectCost;
+			if (!((RefHandle*)hp)->blocklist.empty()) opt.blocklist = &((RefHandle*)hp)->blocklist;
+			auto res = kw.analyze(std::u16string{ (const char16_t*)text, (const char16_t*)text + len }, topN, opt);
+			writeResults(w, res, kw);
+		}
+		catch (const std::exception& e)
+		{
+			fprintf(stderr, "kref_analyze_dialect: %s\n", e.what());
 			return 0;
 		}
 		return w.need;

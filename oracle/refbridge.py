@@ -129,6 +129,11 @@ class RefKiwi:
             L.kref_open_cong_global.restype = C.c_void_p
             L.kref_open_cong_global.argtypes = [C.c_char_p, C.c_int]
             self.h = L.kref_open_cong_global(raw_model_path.encode(), arch)
+        elif isinstance(model_dir_sbg, tuple) and model_dir_sbg[0] == "dialects":
+            # a raw container baked with KiwiBuilder's enabledDialects = model_dir_sbg[1] (kiwi_init's last argument)
+            L.kref_open_dialects.restype = C.c_void_p
+            L.kref_open_dialects.argtypes = [C.c_char_p, C.c_int, C.c_int]
+            self.h = L.kref_open_dialects(raw_model_path.encode(), arch, int(model_dir_sbg[1]))
         elif isinstance(model_dir_sbg, tuple) and model_dir_sbg[0] == "built":
             # a directory as Kiwi ships it, loaded and baked by the REAL KiwiBuilder (x86 library only): ("built", ModelType, BuildOption bits)
             L.kref_open_built.restype = C.c_void_p
@@ -221,6 +226,14 @@ class RefKiwi:
             n, split_end = r.get("II")
             chunks.append((split_end, [r.get("IIIIiIIIf") for _ in range(n)]))
         return chunks
+
+    def analyze_dialect(self, text: str, allowed_dialect: int, dialect_cost: float = 3.0, typo=None, threshold=2.5, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING, open_ending=False):
+        """AnalyzeOption::allowedDialects / dialectCost; typo None: the reference takes its built-in `dialect` typo set itself when a dialect is allowed."""
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        self.lib.kref_analyze_dialect.restype = C.c_size_t
+        self.lib.kref_analyze_dialect.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
+        buf = self._call(lambda *a: self.lib.kref_analyze_dialect(self.h, typo.h if typo is not None else None, threshold, allowed_dialect, dialect_cost, u.ctypes.data, len(u), top_n, match, int(open_ending), *a))
+        return parse_results(buf)
 
     def analyze_typo(self, typo, text: str, threshold=2.5, allowed_dialect=0, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING, open_ending=False):
         self.lib.kref_analyze_typo.restype = C.c_size_t

@@ -225,3 +225,33 @@ def test_c3_sbg_2k_sentences_top3_vs_oracle_and_reference():
         assert all([a[1] for a in r] == [a[1] for a in y] for r, y in zip(ref, got))
         same = sum(_norm(r) == _norm(y) for r, y in zip(ref, got))
         assert same >= 0.6 * len(texts), same
+
+
+def test_c3_sbg_corpus_8192_sentences_and_the_heaviest_top3_vs_oracle():
+    """BASELINE config 3 on the corpus its bench line times (c3-sbg: SkipBigram, top-3): the first 8192 sentences plus the corpus's 64 heaviest -- most
+    lattice nodes with more than 512 incoming paths, where the large path container, the top-N key lists of the item table and the N-th-best pruning
+    threshold run (tests/golden/c3_sbg_heaviest.json, tools/r05/sbg_heaviest.py) -- device vs the CPU oracle, analysis for analysis with fp32 scores."""
+    import json
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+    path, texts, _ = get_workload("c3-sbg")
+    heavy = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c3_sbg_heaviest.json")))
+    idx = list(range(8192)) + [h["index"] for h in heavy["heaviest"] if h["index"] >= 8192]
+    assert sum(1 for h in heavy["heaviest"][:20] if h["nodesOver512"] > 0) == 20      # (the corpus does have such nodes)
+    sample = [texts[i] for i in idx]
+    dev = KiwiAmd(path)
+    got = dev.analyze_batch(sample, top_n=3).to_python()
+    dev.close()
+    local = threading.local()
+
+    def one(s):
+        if not hasattr(local, "k"):
+            local.k = oraclelib.OracleKiwi(path)
+        return local.k.analyze(s, top_n=3)
+    with ThreadPoolExecutor(max(4, min(32, (os.cpu_count() or 8) // 2))) as ex:
+        want = list(ex.map(one, sample))
+    bad = [i for i, w, y in zip(idx, want, got) if _norm(w) != _norm(y)]
+    assert not bad, (len(bad), bad[:5])
