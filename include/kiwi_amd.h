@@ -34,6 +34,9 @@ typedef struct
 
 /* returns NULL on failure; kamd_last_error() (thread local) tells why.  device < 0: current/first device */
 kamd_engine_h kamd_open(const char* raw_model_path, int device);
+/* the same with KiwiBuilder's enabledDialects (kiwi_init's last argument, /root/reference/src/KiwiBuilder.cpp:963-967, 2500-2504; KIWI_DIALECT_* bits):
+ * dictionary forms whose morphemes all belong to dialects that are not enabled stay out of the trie */
+kamd_engine_h kamd_open_dialects(const char* raw_model_path, int device, int enabled_dialects);
 void kamd_close(kamd_engine_h h);
 const char* kamd_last_error(void);
 
@@ -127,6 +130,11 @@ void kamd_morphset_close(kamd_morphset_h m);
 /* kamd_analyze_batch with the per-call options of the reference's AnalyzeOption: a prepared typo transformer (or NULL) and a blocklist (or NULL) */
 kamd_results_h kamd_analyze_batch_opt(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, kamd_morphset_h blocklist,
                                       const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts, uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
+/* ... and AnalyzeOption::allowedDialects / dialectCost (/root/reference/include/kiwi/Kiwi.h:89-99, src/PathEvaluator.hpp:231-236, 386, 893): morphemes of a dialect
+ * that is neither standard nor allowed are not candidates, those of an allowed dialect cost dialect_cost.  With a dialect allowed and t == NULL the
+ * built-in typo set DefaultTypoSet::dialect is applied with threshold 2.5, as the reference does (src/Kiwi.cpp:1037-1041) */
+kamd_results_h kamd_analyze_batch_dialect(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, float dialect_cost, kamd_morphset_h blocklist,
+                                          const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts, uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
 /* parity hook: the lattices the device builds OVER the typo graphs of a text's chunks (csrc/typo_lattice_kernel.hip), in the layout of kamd_dump_lattices;
  * 0 + kamd_last_error() on failure */
 /* parity hook of the device typo-graph kernel (the analyze path generates typo graphs on the GPU): kamd_typo_graph's layout + two bytes per

@@ -16,9 +16,10 @@
  *     own deterministic one (candidates in lattice order); the reference's order of such ties follows the iteration order of its per-morpheme hash
  *     containers (src/BestPathContainer.hpp:279-483) and differs between its own builds.
  *   - option.blocklist (morpheme sets: kiwi_new_morphset / kiwi_morphset_add / _add_w / _close) is honoured;
- *     option.allowed_dialects / dialect_cost are accepted: they only concern dialect morphemes, which no model loaded here has (kiwi_init
- *     refuses enabled_dialects != 0); top_n > 16 and pretokenized spans are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of
- *     being silently ignored.
+ *     kiwi_init's enabled_dialects and option.allowed_dialects / dialect_cost are honoured (round 5): a model with dialect morphemes (MorphemeRaw::dialect of
+ *     sj.morph / a raw container) keeps the dictionary forms of enabled dialects, an analysis skips the morphemes of dialects it does not allow, charges
+ *     dialect_cost for the others and -- without a transformer of its own -- is corrected with the built-in `dialect` typo set (src/Kiwi.cpp:1037-1041);
+ *     tokens report their dialect.  top_n > 16 and pretokenized spans are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of being silently ignored.
  */
 #ifndef KIWI_CAPI_SUBSET_H
 #define KIWI_CAPI_SUBSET_H

@@ -210,9 +210,14 @@ class Batch:
 class KiwiAmd:
     """Batched analyzer on one MI355X."""
 
-    def __init__(self, raw_model_path: str, device: int = -1, lib_path: str = None):
+    def __init__(self, raw_model_path: str, device: int = -1, lib_path: str = None, enabled_dialects: int = 0):
         self.lib = load_library(lib_path)     # lib_path: another build of the same library (tests: the small-capacity build)
-        self.h = self.lib.kamd_open(raw_model_path.encode(), device)
+        if enabled_dialects:      # KiwiBuilder's enabledDialects (kiwi_init's last argument)
+            self.lib.kamd_open_dialects.restype = C.c_void_p
+            self.lib.kamd_open_dialects.argtypes = [C.c_char_p, C.c_int, C.c_int]
+            self.h = self.lib.kamd_open_dialects(raw_model_path.encode(), device, enabled_dialects)
+        else:
+            self.h = self.lib.kamd_open(raw_model_path.encode(), device)
         if not self.h:
             raise RuntimeError("kamd_open failed: " + self.lib.kamd_last_error().decode())
 
@@ -273,6 +278,18 @@ class KiwiAmd:
                                      flat.ctypes.data, offs.ctypes.data, len(texts), top_n, match, int(open_ending), host_threads)
         if not r:
             raise self._err("kamd_analyze_batch_opt")
+        return Results(self.lib, r)
+
+    def analyze_batch_dialect(self, texts, allowed_dialect, dialect_cost=3.0, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0, typo=None, typo_threshold=2.5, blocklist=None) -> Results:
+        """kamd_analyze_batch_dialect: AnalyzeOption::allowedDialects / dialectCost; typo None with a dialect allowed: the built-in `dialect` typo set, threshold 2.5."""
+        L = self.lib
+        L.kamd_analyze_batch_dialect.restype = C.c_void_p
+        L.kamd_analyze_batch_dialect.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_int]
+        flat, offs = pack_texts(texts)
+        r = L.kamd_analyze_batch_dialect(self.h, typo.h if typo is not None else None, typo_threshold, allowed_dialect, dialect_cost, blocklist.h if blocklist is not None else None,
+                                         flat.ctypes.data, offs.ctypes.data, len(texts), top_n, match, int(open_ending), host_threads)
+        if not r:
+            raise self._err("kamd_analyze_batch_dialect")
         return Results(self.lib, r)
 
     def analyze_packed(self, flat, offs, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0, typo=None, typo_threshold=2.5) -> Results:

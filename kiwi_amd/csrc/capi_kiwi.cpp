@@ -176,8 +176,8 @@ namespace
 	void checkOption(const kiwi_analyze_option_t& o, kiwi_pretokenized_h pt)
 	{
 		// allowed_dialects / dialect_cost: the candidate loops skip a morpheme whose dialect is neither standard nor allowed and charge dialect_cost for an
-		// allowed one (src/PathEvaluator.hpp:231, 386, 893).  Every model this library loads holds standard-dialect morphemes only (kiwi_init refuses
-		// enabled_dialects != 0, the bake refuses dialect morphemes), so both options are accepted and -- exactly as in the reference -- change nothing.
+		// allowed one (src/PathEvaluator.hpp:231, 386, 893): typoOf below hands them to the engine (round 5; a model without dialect morphemes: no effect,
+		// exactly as in the reference -- except that an analysis with a dialect allowed and no transformer is corrected with the built-in `dialect` set)
 		// a pretokenized object without spans is no constraint (kiwi_pt_init + nothing added); spans themselves are not built on the device path yet
 		if (pt && !pt->spans.empty()) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
 		// Match::oovChrModel (bits 8-9): the engine checks that the model carries the character model (nounchr.mdl next to a CoNgram model) and refuses
@@ -354,7 +354,9 @@ namespace
 	TypoOption typoOf(const kiwi_analyze_option_t& o)
 	{
 		TypoOption t;
-		if (o.typo_transformer) { t.typo = &o.typo_transformer->p; t.threshold = o.typo_threshold; t.allowedDialect = 0; }
+		t.allowedDialect = (uint16_t)o.allowed_dialects; t.dialectCost = o.dialect_cost;
+		if (o.typo_transformer) { t.typo = &o.typo_transformer->p; t.threshold = o.typo_threshold; }
+		else if (o.allowed_dialects) { t.typo = &kamd::defaultDialectTypo(); t.threshold = 2.5f; }      // src/Kiwi.cpp:1037-1041
 		if (o.blocklist && !o.blocklist->ids.empty()) t.blocked = &o.blocklist->bits;      // AnalyzeOption::blocklist (src/capi/kiwi_c.cpp:870)
 		return t;
 	}
@@ -499,11 +501,12 @@ extern "C"
 			case 0x0500: throw std::invalid_argument{ "kiwi_amd: CoNgram models with distant-token (global, window 7) scoring are not supported on the device path yet (the oracle restates them: tests/test_cong_global.py)" };
 			default: throw std::invalid_argument{ "kiwi_amd: unknown model type" };
 			}
-			if (enabled_dialects != 0) throw std::invalid_argument{ "kiwi_amd: only the standard dialect is supported" };
+			// enabled_dialects (KIWI_DIALECT_* bits; KiwiBuilder.cpp:963-967): forms of dialects that are not enabled stay out of the dictionary trie (:2500-2504)
+			if ((uint32_t)enabled_dialects > 1023u) throw std::invalid_argument{ "kiwi_amd: unknown dialect bits in enabled_dialects" };
 			const std::string path = model_path ? model_path : "";      // a directory with sj.morph + sj.knlm (+ skipbigram.mdl) or kiwi_amd.raw, or a raw container file
 			auto h = std::make_unique<kiwi_s>();
-			h->engine.reset(new Engine(path, -1, lm));      // (-1: the caller's current device)
-			if (knlmUnlessCong && !h->engine->usesCong() && h->engine->usesSbg()) h->engine.reset(new Engine(path, -1, Engine::LmMode::Knlm));
+			h->engine.reset(new Engine(path, -1, lm, (uint32_t)enabled_dialects));      // (-1: the caller's current device)
+			if (knlmUnlessCong && !h->engine->usesCong() && h->engine->usesSbg()) h->engine.reset(new Engine(path, -1, Engine::LmMode::Knlm, (uint32_t)enabled_dialects));
 			// LARGEST on a cong.mdl is the reference's congGlobal (KiwiBuilder.cpp:939-946): with distant-token sections in the file that is a different
 			// scoring from the local one built here -- refused rather than answered with another model's results
 			if (largest && h->engine->congWindow()) throw std::invalid_argument{ "kiwi_amd: KIWI_BUILD_MODEL_TYPE_LARGEST on a CoNgram model with distant-token sections means the global (window " + std::to_string(h->engine->congWindow()) + ") scoring, which the device path does not do yet; ask for KIWI_BUILD_MODEL_TYPE_CONG (local scoring) explicitly" };

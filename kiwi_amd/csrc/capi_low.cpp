@@ -60,6 +60,10 @@ extern "C"
 	{
 		return guarded([&]() { auto h = std::make_unique<kamd_engine>(); h->e.reset(new Engine(path, device)); return h.release(); }, (kamd_engine*)nullptr);
 	}
+	kamd_engine_h kamd_open_dialects(const char* path, int device, int enabled_dialects)
+	{
+		return guarded([&]() { auto h = std::make_unique<kamd_engine>(); h->e.reset(new Engine(path, device, Engine::LmMode::Auto, (uint32_t)enabled_dialects)); return h.release(); }, (kamd_engine*)nullptr);
+	}
 	void kamd_close(kamd_engine_h h) { delete h; }
 	const char* kamd_last_error(void) { return lastError.c_str(); }
 
@@ -409,6 +413,21 @@ extern "C"
 		return guarded([&]()
 		{
 			TypoOption o; if (t) { o.typo = t->prepared.get(); o.threshold = threshold; o.allowedDialect = (uint16_t)allowed_dialect; }
+			if (m && !m->ids.empty()) o.blocked = &m->bits;
+			return pack(h->e->analyzeBatch(views(texts, offsets, n), topN, match, !!openEnding, hostThreads, o));
+		}, (kamd_results*)nullptr);
+	}
+
+	kamd_results_h kamd_analyze_batch_dialect(kamd_engine_h h, kamd_typo* t, float threshold, int allowed_dialect, float dialect_cost, kamd_morphset_h blocklist, const uint16_t* texts, const uint64_t* offsets, uint32_t n, uint32_t topN, uint64_t match, int openEnding, int hostThreads)
+	{
+		if (!h || (t && !t->prepared)) { lastError = "invalid handle / typo transformer not prepared"; return nullptr; }
+		auto* m = reinterpret_cast<kamd_morphset_impl*>(blocklist);
+		if (m && m->owner != h) { lastError = "the morpheme set belongs to another engine"; return nullptr; }
+		return guarded([&]()
+		{
+			TypoOption o; o.allowedDialect = (uint16_t)allowed_dialect; o.dialectCost = dialect_cost;
+			if (t) { o.typo = t->prepared.get(); o.threshold = threshold; }
+			else if (allowed_dialect) { o.typo = &defaultDialectTypo(); o.threshold = 2.5f; }      // src/Kiwi.cpp:1037-1041
 			if (m && !m->ids.empty()) o.blocked = &m->bits;
 			return pack(h->e->analyzeBatch(views(texts, offsets, n), topN, match, !!openEnding, hostThreads, o));
 		}, (kamd_results*)nullptr);

@@ -123,6 +123,9 @@ namespace kamd
 		float oovChrBias;              // KiwiConfig::oovChrBias: subtracted from the character model's score of an unknown form (Match::oovChrModel)
 		// Match::oovChrFreqModel: KiwiConfig::oovGlobalWeight / oovLocalWeight / oovGlobalMinFreq, and the bias k_unk_chr_freq applies itself (oovChrBias is 0 then)
 		float oovGlobalWeight, oovLocalWeight, oovGlobalMinFreq, oovChrFreqBias;
+		// AnalyzeOption::allowedDialects (Dialect bits) / dialectCost: a dictionary form or a morpheme of another dialect is skipped, one of an allowed
+		// dialect costs dialectCost (KTrie.cpp:207-229, PathEvaluator.hpp:231, 386, 893); only read when the model has dialect morphemes
+		uint32_t allowedDialect; float dialectCost;
 	};
 	constexpr uint32_t kMaxTopN = 16;
 

@@ -187,6 +187,7 @@ namespace kamd
 		std::vector<ChunkRef> refs;
 		uint64_t match = 0;
 		uint32_t capScale = 1;
+		std::vector<uint32_t> blockBitsHost;          // a model with dialect morphemes: the blocklist united with the morphemes of dialects the analysis does not allow
 		bool isRerun = false;                         // a batch of runRefs (chunks searched again): the engine's adaptive capacities do not learn from it
 		uint64_t units = 0, devBytes = 0;
 		// host layout
@@ -287,9 +288,9 @@ namespace kamd
 		return n;
 	}
 
-	Engine::Engine(const std::string& path, int device, LmMode lm) : impl(new Impl(std::make_shared<FlatModel>()))
+	Engine::Engine(const std::string& path, int device, LmMode lm, uint32_t enabledDialects) : impl(new Impl(std::make_shared<FlatModel>()))
 	{
-		bakeModel(impl->model, path);
+		bakeModel(impl->model, path, enabledDialects);
 		if (lm == LmMode::Sbg && impl->model.sbgPtrs.empty()) throw std::runtime_error{ "Cannot open required files for skipbigram model" };   // KiwiBuilder.cpp:1008-1013
 		if (lm == LmMode::Cong && !impl->model.congDim) throw std::runtime_error{ "Cannot open ConG model file 'cong.mdl'" };      // KiwiBuilder.cpp:1018-1023
 		// a model without a Knlm blob (the layout of models/cong/base: sj.morph + cong.mdl) cannot serve the Knlm / SkipBigram types: the reference
@@ -361,6 +362,7 @@ namespace kamd
 		}
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
 		v.lmHtxNode = (m.congDim || m.lmHtxNode.empty()) ? nullptr : impl->up(m.lmHtxNode);      // history-transformed Knlm only
+		v.formDialect = m.formDialect.empty() ? nullptr : impl->up(m.formDialect); v.morphDialect = m.morphDialect.empty() ? nullptr : impl->up(m.morphDialect);
 		v.formUnkChr = nullptr; v.formChrTok = nullptr;
 		v.lmChain = nullptr;
 		if (!m.congDim && !m.lmBackoff.empty())
@@ -608,9 +610,20 @@ namespace kamd
 		w.unkChrForm = nullptr;
 		if ((b.match >> 8) & 3) { b.dUnkChr.ensure(totNodes * 4 + 16); w.unkChr = b.dUnkChr.as<float>(); }      // Match::oovChrModel (checked in stage())
 		if (((b.match >> 8) & 3) > 1) { b.dUnkChrForm.ensure(totNodes * 4 + 16); w.unkChrForm = b.dUnkChrForm.as<float>(); }      // Match::oovChrFreqModel / oovChrFreqBranchModel
-		if (b.typo.blocked && !b.typo.blocked->empty())
+		if (b.typo.blocked && !b.typo.blocked->empty() && b.typo.blocked->size() != (I.model.morphs.size() + 31) / 32) throw std::invalid_argument{ "kiwi_amd: blocklist bit set does not belong to this model" };
+		if (!I.model.morphDialect.empty())
 		{
-			if (b.typo.blocked->size() != (I.model.morphs.size() + 31) / 32) throw std::invalid_argument{ "kiwi_amd: blocklist bit set does not belong to this model" };
+			// a model with dialect morphemes: those of a dialect this analysis does not allow are skipped by the candidate loops exactly like blocked ones
+			// (PathEvaluator.hpp:386, 893 beside the blocklist test) -- one bit set per batch, the blocklist's united with them
+			std::vector<uint32_t>& bits = b.blockBitsHost;      // (kept with the batch: the upload is asynchronous)
+			bits.assign((I.model.morphs.size() + 31) / 32, 0u);
+			if (b.typo.blocked && !b.typo.blocked->empty()) bits = *b.typo.blocked;
+			for (size_t i = 0; i < I.model.morphDialect.size(); ++i) { const uint32_t d = I.model.morphDialect[i]; if (d && !(d & b.typo.allowedDialect)) bits[i >> 5] |= 1u << (i & 31); }
+			upload(b.dBlockBits, bits, s);
+			w.blockBits = b.dBlockBits.as<uint32_t>();
+		}
+		else if (b.typo.blocked && !b.typo.blocked->empty())
+		{
 			upload(b.dBlockBits, *b.typo.blocked, s);
 			w.blockBits = b.dBlockBits.as<uint32_t>();
 		}
@@ -759,9 +772,10 @@ namespace kamd
 		HIPCHECK(hipMemcpy(out, dOut.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	}
 
-	static SearchParams makeParams(const EngineConfig& c, uint64_t match, uint32_t topN = 1)
+	static SearchParams makeParams(const EngineConfig& c, uint64_t match, uint32_t topN = 1, const TypoOption* opt = nullptr)
 	{
 		SearchParams p{};
+		p.allowedDialect = opt ? opt->allowedDialect : 0u; p.dialectCost = opt ? opt->dialectCost : 3.f;
 		p.match = match; p.cutOff = c.cutOffThreshold; p.spacePenalty = c.spacePenalty; p.typoCostWeight = c.typoCostWeight;
 		p.oovRuleScale = c.oovRuleScale; p.oovRuleBias = c.oovRuleBias;
 		p.oovGlobalWeight = c.oovGlobalWeight; p.oovLocalWeight = c.oovLocalWeight; p.oovGlobalMinFreq = c.oovGlobalMinFreq; p.oovChrFreqBias = c.oovChrBias;
@@ -1440,7 +1454,7 @@ namespace kamd
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		HIPCHECK(hipSetDevice(impl->device));      // the device is bound per thread: callers come from any thread
 		b->typo = typo;
-		layoutAndUpload(*impl, *b, makeParams(config, match));
+		layoutAndUpload(*impl, *b, makeParams(config, match, 1, &b->typo));
 		tm.lap("layout + device buffers + upload");
 		return b;
 	}
@@ -1454,7 +1468,7 @@ namespace kamd
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		HIPCHECK(hipSetDevice(impl->device));
 		HostTimer tm{ "run" };
-		KernelTimes t = launchAll(*impl, b, makeParams(config, b.match, b.topN));
+		KernelTimes t = launchAll(*impl, b, makeParams(config, b.match, b.topN, &b.typo));
 		tm.lap("work order + launches + kernels");
 		rerunOverflows(b, t);
 		return t;
@@ -1466,7 +1480,7 @@ namespace kamd
 	{
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		HIPCHECK(hipSetDevice(impl->device));
-		launchAll(*impl, b, makeParams(config, b.match, b.topN), false);
+		launchAll(*impl, b, makeParams(config, b.match, b.topN, &b.typo), false);
 	}
 	void Engine::finish(StagedBatch& b)
 	{
@@ -1516,7 +1530,7 @@ namespace kamd
 		std::vector<std::vector<PathResult>>& out)
 	{
 		out.clear(); out.resize(refs.size());
-		const SearchParams sp = makeParams(E.config, parent.match, parent.topN);
+		const SearchParams sp = makeParams(E.config, parent.match, parent.topN, &parent.typo);
 		// ~ (48 n + 256) states of ~ 100 B per chunk and capacity step: 12 GB per slice
 		const uint64_t sliceBudget = 120000000ull;
 		size_t r0 = 0;

@@ -52,6 +52,7 @@ namespace kamd
 	class PreparedTypo;
 	// a prepared typo transformer applied to an analysis (AnalyzeOption::typoTransformer / typoThreshold / allowedDialects of the reference)
 	struct TypoOption { const PreparedTypo* typo = nullptr; float threshold = 2.5f; uint16_t allowedDialect = 0;
+		float dialectCost = 3.f;      // AnalyzeOption::dialectCost: what a morpheme of an allowed dialect costs (src/PathEvaluator.hpp:231)
 		// AnalyzeOption::blocklist: one bit per morpheme id (flat_model.hpp blockBitsOf), null = none; must outlive the batch
 		const std::vector<uint32_t>* blocked = nullptr; };
 
@@ -67,7 +68,8 @@ namespace kamd
 		// which language model of the container scores the search (reference ModelType, include/kiwi/Types.h:292-335): Auto = SkipBigram when the
 		// container carries its tables, else Knlm; Knlm = Knlm even then; Sbg = SkipBigram or an error
 		enum class LmMode { Auto, Knlm, Sbg, Cong };      // Auto: CoNgram when the container has a blob, else SkipBigram when it has tables, else Knlm
-		explicit Engine(const std::string& rawModelPath, int device = -1, LmMode lm = LmMode::Auto);
+		// enabledDialects: KiwiBuilder's enabledDialects (kiwi_init's last argument): forms of other dialects stay out of the dictionary trie
+		explicit Engine(const std::string& rawModelPath, int device = -1, LmMode lm = LmMode::Auto, uint32_t enabledDialects = 0);
 		Engine(const Engine& other, int device);      // replica of `other` on another GPU (shares the baked host model)
 		static int visibleDevices();
 		int deviceIndex() const;      // the HIP device this engine's tables and streams live on

@@ -149,6 +149,9 @@ namespace kamd
 		const float* formUnkChr;
 		// ... and the character model's token of every unit of formChars (Match::oovChrFreqModel walks a dictionary form's string per node: chr_freq.hpp)
 		const uint16_t* formChrTok;
+		// Dialect bits per form / per morpheme (null: the model has no dialect morphemes): the dictionary scan drops a form, the candidate expansion a
+		// morpheme whose dialect is neither standard nor allowed (KTrie.cpp:207-229, PathEvaluator.hpp:386, 893); an allowed dialect morpheme costs dialectCost
+		const uint16_t* formDialect; const uint16_t* morphDialect;
 		// device only (Knlm): per LM node the next two nodes of its back-off chain as absolute ids {node + lower, that node's lower node}; 0 = the root,
 		// where every chain ends.  A search state that carries this pair can probe all three contexts of its next transition at once (viterbi_pos.inc)
 		const uint32_t* lmChain;
@@ -346,6 +349,8 @@ namespace kamd
 		std::vector<uint32_t> morphPath;
 		std::vector<uint32_t> morphKform;    // form id of each morpheme's kform (host-side result building)
 		std::vector<uint8_t> morphSenseDialect;
+		// Dialect bits (include/kiwi/Types.h:320-335; 0 = standard) per morpheme / per form, EMPTY when the model has no dialect morpheme at all
+		std::vector<uint16_t> morphDialect, formDialect;
 		std::vector<TrieNodeRec> trie;
 		std::vector<uint16_t> trieKeys;
 		std::vector<uint32_t> trieChild;
@@ -427,6 +432,7 @@ namespace kamd
 			v.formUnkChr = formUnkChr.empty() ? nullptr : formUnkChr.data();
 			v.formChrTok = formChrTok.empty() ? nullptr : formChrTok.data();
 			v.lmChain = nullptr;
+			v.formDialect = formDialect.empty() ? nullptr : formDialect.data(); v.morphDialect = morphDialect.empty() ? nullptr : morphDialect.data();
 			return v;
 		}
 
@@ -437,7 +443,8 @@ namespace kamd
 	};
 
 	// model.cpp
-	void bakeModel(FlatModel& out, const std::string& rawModelPath);
+	// enabledDialects: KiwiBuilder's enabledDialects (kiwi_init's last argument; Dialect bits, 0 = standard only)
+	void bakeModel(FlatModel& out, const std::string& rawModelPath, uint32_t enabledDialects = 0);
 	// serialises the baked dictionary in the layout of oracle/ref_bridge.cpp:kref_dump_dict (tests compare both)
 	std::vector<uint8_t> dumpDict(const FlatModel& m);
 	// Kiwi::findMorphemes (src/Kiwi.cpp:1281-1297, findForm src/KTrie.cpp:2172-2192): the morphemes of the dictionary form spelled `s` (raw text: it is

@@ -998,7 +998,8 @@ namespace kamd
 				r.firstWid = mx.y; r.secondWid = mx.w; r.chunkOff = m0.z; r.lastSeqId = m0.y;
 				r.morph = mx.x; r.flagsFeat = m1.y; r.tagw = m1.z; r.cntw = m1.w;
 				r.additional = __uint_as_float(m0.w) + disc + leftBoundaryScore(((nd.nflags & NF_LEFT_BOUNDARY) ? T_MAX : 0) + clearIrregular(tag)) * 5.f;
-				const uint32_t ruleBits = ((isEClass(tag) && (nd.fflags & FF_STARTS_WITH_A)) ? 1u : 0u) | ((tag == T_SN && (nd.nflags & NF_UFORM_ENDS_POINT)) ? 2u : 0u);
+				const uint32_t ruleBits = ((isEClass(tag) && (nd.fflags & FF_STARTS_WITH_A)) ? 1u : 0u) | ((tag == T_SN && (nd.nflags & NF_UFORM_ENDS_POINT)) ? 2u : 0u)
+					| ((M.morphDialect && M.morphDialect[r.morph]) ? 4u : 0u);      // (RB_DIALECT of the search kernels)
 				r.nodeOwn = i | ((uint32_t)ownFeat << 16);
 				r.bits = (sbType & 0xFF) | (ruleBits << 8) | ((uint32_t)ownKind << 16) | ((uint32_t)nd.nflags << 24);
 				r.rq = R | (nl << 8) | extra;

@@ -874,7 +874,7 @@ namespace kamd
 		return score;
 	}
 
-	void bakeModel(FlatModel& m, const std::string& path)
+	void bakeModel(FlatModel& m, const std::string& path, uint32_t enabledDialects)
 	{
 		Container file;
 		ModelFiles files;
@@ -934,7 +934,7 @@ namespace kamd
 			if (complexRaw[i] && hasSaisiot) o.flags |= MF_SAISIOT;
 			if (r.nChunks == 0 || (o.flags & (MF_COMPLEX | MF_SAISIOT))) o.flags |= MF_SINGLE;
 			m.morphKform[i] = newId[r.kform];
-			if (r.dialect) throw std::runtime_error{ "raw model: dialect morphemes are not supported yet" };
+			if (r.dialect) { if (m.morphDialect.empty()) m.morphDialect.assign(nM, 0); m.morphDialect[i] = r.dialect; }      // Morpheme::dialect (Dialect bits; 0 = standard)
 		}
 		const uint32_t vocab = (uint32_t)raw.vocabSize();
 		for (size_t i = 0; i < nM; ++i)
@@ -1082,13 +1082,18 @@ namespace kamd
 			if (c0.vowel != CV_NONE) { uint8_t v = c0.vowel; for (uint32_t c = 0; c < f.candCnt; ++c) v = reduceVowel(v, m.morphs[cand[c]].vowel); f.vowelPolar = (uint8_t)((f.vowelPolar & 0xF0) | v); }
 			if (c0.polar != CP_NONE) { uint8_t p = c0.polar; for (uint32_t c = 0; c < f.candCnt; ++c) p = (p == m.morphs[cand[c]].polar) ? p : (uint8_t)CP_NONE; f.vowelPolar = (uint8_t)((f.vowelPolar & 0x0F) | (p << 4)); }
 			bool hasJ = false, anyFull = false;
+			// Form::dialect (KiwiBuilder.cpp:2284-2292, 2500): standard as soon as one candidate is, else the union of the candidates' dialects
+			uint32_t fDialect = m.morphDialect.empty() ? 0u : m.morphDialect[cand[0]];
 			for (uint32_t c = 0; c < f.candCnt; ++c)
 			{
 				const uint8_t t = m.morphs[cand[c]].tag;
 				hasJ = hasJ || isJClass(t) || t == T_EC || t == T_EF;
 				const uint8_t ct = clearIrregular(t);
-				anyFull = anyFull || (ct != T_UNKNOWN && ct != T_P && ct != T_P + 1);
+				const uint32_t md = m.morphDialect.empty() ? 0u : m.morphDialect[cand[c]];
+				anyFull = anyFull || (md == 0 && ct != T_UNKNOWN && ct != T_P && ct != T_P + 1);      // (hasAnyFullMorphemes counts standard morphemes only, :2494-2498)
+				fDialect = (fDialect == 0 || md == 0) ? 0u : (fDialect | md);
 			}
+			if (fDialect) { if (m.formDialect.empty()) m.formDialect.assign(nF + 1, 0); m.formDialect[i] = (uint16_t)fDialect; }
 			{
 				bool allPartial = true;
 				for (uint32_t c = 0; c < f.candCnt; ++c)
@@ -1101,6 +1106,7 @@ namespace kamd
 			}
 			if (hasJ) f.flags |= FF_HAS_JCLASS;
 			if (anyFull) f.flags |= FF_HAS_ANY_FULL;
+			if (fDialect && !(enabledDialects & fDialect)) continue;      // a form of dialects that are not enabled stays out of the trie (:2501-2504)
 			sortedForms.push_back((uint32_t)i);
 		}
 		{

@@ -405,7 +405,7 @@ namespace kamd
 					tk.senseId = chr2ScriptType(c);
 					if (tk.senseId == 1 /* latin */) tk.tag = T_SL;
 				}
-				tk.dialect = 0;
+				tk.dialect = mdl.morphDialect.empty() ? (uint16_t)0 : mdl.morphDialect[s.morph];      // Kiwi.cpp:747
 				tk.wordPosition = wordPositions[tk.position];
 				prevMorph = (int32_t)s.morph;
 			}

@@ -153,6 +153,12 @@ namespace kamd
 		}
 	}
 
+	const PreparedTypo& defaultDialectTypo()
+	{
+		static const PreparedTypo p{ defaultTypoSet(6), true };
+		return p;
+	}
+
 	void TypoTransformer::scaleCost(float scale)
 	{
 		if (!std::isfinite(scale) || scale <= 0) throw std::invalid_argument{ "`scale` must be positive real." };

@@ -54,6 +54,10 @@ namespace kamd
 	// Kiwi's built-in typo sets (reference getDefaultTypoSet, src/TypoTransformer.cpp:1058-1254; DefaultTypoSet ids 0..6 = capi.h:485-491):
 	// assembled once from the rule tables of typo_sets.inc; throws std::invalid_argument for any other id.  The objects live for the process.
 	const TypoTransformer& defaultTypoSet(int set);
+	class PreparedTypo;
+	// getDefaultPreparedTypoSet(DefaultTypoSet::dialect) (src/TypoTransformer.cpp:1263, 1278): what an analysis with allowed dialects and no transformer of
+	// its own is corrected with (src/Kiwi.cpp:1037-1041); prepared once per process
+	const PreparedTypo& defaultDialectTypo();
 
 	struct TypoGraphNode      // TypoGraphNode of the reference (include/kiwi/TypoTransformer.h:131-157), form as a span
 	{

@@ -3,10 +3,11 @@
 // (/root/reference/src/KTrie.cpp:897-996, 998-1464, 240-299) in their general form: one search state per (typo-graph node, way of
 // reaching it), positions multiplied by 2^posMultiplierBit for the halves of continual typos.
 //
-// STATUS: first, unoptimised form -- one THREAD per chunk over HBM arrays (the shape of k_build_lattice_big).  Two outputs: the dump records of
-// the parity hook (Engine::dumpTypoLattices / kamd_typo_lattices), or, in engine mode, the search kernel's DevNode records plus a typo cost
-// per node.  The typo graph itself comes from
-// the host (typo.cpp).  Its parity has so far been checked in the CPU test suite only -- it has not run on a GPU.
+// Two kernels over one build context: k_build_lattice_typo_lds -- one WAVEFRONT per chunk, text / index maps / node list / end-position index in LDS, the
+// replay itself on lane 0 (the default; DESIGN.md section 4 "Typo correction on the device") -- and k_build_lattice_typo -- one thread per chunk over
+// HBM arrays, for chunks that outgrow the LDS copy.  Two outputs: the dump records of the parity hook (Engine::dumpTypoLattices / kamd_typo_lattices), or,
+// in engine mode, the search kernel's DevNode records plus a typo cost per node.  The typo graphs come from k_typo_graph (typo_graph_kernel.hip).
+// GPU-green since round 2 (tests/test_gpu_typo.py: lattices and analyses bit-exact against the oracle = the real reference).
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <cstdlib>

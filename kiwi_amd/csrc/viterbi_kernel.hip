@@ -133,7 +133,7 @@ namespace sbgk
 	constexpr uint32_t RING = 32;    // most recent nodes whose state ranges are kept in LDS
 #endif
 	enum StageBits : uint8_t { SB_SLOT_MASK = 0x1F, SB_DEAD = 0x20, SB_MORPH_SOCKET = 0x40, SB_STATE_SOCKET = 0x80 };
-	enum { RB_POSITIVE_E = 1, RB_SN_POINT = 2 };
+	enum { RB_POSITIVE_E = 1, RB_SN_POINT = 2, RB_DIALECT = 4 };      // (RB_DIALECT: a morpheme of an allowed dialect: SearchParams::dialectCost comes off its score, PathEvaluator.hpp:231-236)
 
 	// All LDS of the kernel is one dynamic array; per-group slices are addressed by byte offsets so that every access
 	// keeps its address space (ds_* instructions) even inside non-inlined helpers.
@@ -857,6 +857,7 @@ namespace sbgk
 					}
 					const float rs = ruleScore(c, ps.prevFlags(), sp);
 					cand = cand + rs; firstChunk = firstChunk + rs;
+					if (c.ruleBits & RB_DIALECT) { cand = cand - X.P.dialectCost; firstChunk = firstChunk - X.P.dialectCost; }
 					sp = nextSpState(c, sp);
 				} while (0);
 			}
@@ -1382,7 +1383,8 @@ namespace sbgk
 				{
 					const uint8_t tag = (uint8_t)m1.z;
 					const float additional = __uint_as_float(m0.w) + nodeLevelDiscount + X.lb()[((E.nflags & NF_LEFT_BOUNDARY) ? T_MAX : 0) + clearIrregular(tag)] * 5.f;
-					const uint32_t ruleBits = ((isEClass(tag) && (E.fflags & FF_STARTS_WITH_A)) ? RB_POSITIVE_E : 0) | ((tag == T_SN && (E.nflags & NF_UFORM_ENDS_POINT)) ? RB_SN_POINT : 0);
+					const uint32_t ruleBits = ((isEClass(tag) && (E.fflags & FF_STARTS_WITH_A)) ? RB_POSITIVE_E : 0) | ((tag == T_SN && (E.nflags & NF_UFORM_ENDS_POINT)) ? RB_SN_POINT : 0)
+						| ((M.morphDialect && M.morphDialect[mid]) ? RB_DIALECT : 0);
 					const uint32_t o = X.candOff(myK);
 					ldsStore4(o, m0); ldsStore4(o + 16, m1);
 					ldsStore4(o + 32, make_uint4(mid, myOff, R, __float_as_uint(additional)));

@@ -340,7 +340,7 @@ class SynthSpec:
     cong_qgroup: int = 0
     use_nounchr: bool = False    # also emit a character-level CoNgram model (reference nounchr.mdl: Match::oovChrModel scores unknown forms with it, src/UnkFormScorer.cpp)
     cong_window: int = 0         # > 0: the file also carries the sections of the global model (confidences, distant embeddings, mask), as the reference's builder always writes them
-    extra_words: tuple = ()      # ((form, tag name), ...): real-text dictionary entries added to the generated lexicon (the eval_data parity corpus, workloads.eval_model)
+    extra_words: tuple = ()      # ((form, tag name[, Dialect bits]), ...): real-text dictionary entries added to the generated lexicon (the eval_data parity corpus, workloads.eval_model)
     seed: int = SEED_BASE
 
 
@@ -511,7 +511,9 @@ class SynthModel:
 
         # dictionary entries given by the caller (real text): a form is normalised as the dictionary holds it (syllable + split-out coda; a
         # compatibility consonant such as the 'ㄴ' of the gold annotations is the coda jamo it stands for)
-        for form, tag_name in sp.extra_words:
+        for entry in sp.extra_words:
+            form, tag_name = entry[0], entry[1]
+            dialect = int(entry[2]) if len(entry) > 2 else 0      # (Dialect bits of the entry, MorphemeRaw::dialect; 0 = standard)
             tid = tag_id(tag_name)
             cls = _CLASS_OF_TAG.get(tid & 0x7F)
             if tid is None or cls is None:
@@ -520,9 +522,9 @@ class SynthModel:
             if not s or " " in s:
                 continue
             fid = raw.form_map.get(s)
-            if fid is not None and any(raw.morphs[m].tag == tid for m in raw.form_cands[fid]):
+            if fid is not None and any(raw.morphs[m].tag == tid and raw.morphs[m].dialect in (0, dialect) for m in raw.form_cands[fid]):
                 continue
-            lex.add(cls, raw.add_morph(s, tid, vowel=CV_VOWEL if is_coda(s[0]) else CV_NONE))
+            lex.add(cls, raw.add_morph(s, tid, vowel=CV_VOWEL if is_coda(s[0]) else CV_NONE, dialect=dialect))
 
         base_end = len(raw.morphs)
 

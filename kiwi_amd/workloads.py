@@ -120,6 +120,29 @@ def eval_model(for_builder=False):
     return path, len(entries)
 
 
+DIALECT_BITS = {"gyeonggi": 1, "chungcheong": 2, "gangwon": 4, "gyeongsang": 8, "jeolla": 16, "jeju": 32, "hwanghae": 64, "hamgyeong": 128, "pyeongan": 256}      # kiwi::Dialect (include/kiwi/Types.h:320-335)
+
+
+def dialect_model():
+    """The small synthetic model + the gold lexicon of eval_data (as 'small-eval') + the gold (form, tag) pairs of the reference's eval_data/dialect files
+    that the standard files do not have, each tagged with the Dialect bits of the files it occurs in (tests/golden/eval_dialect_lexicon.json, written by
+    tools/make_golden_dialect.py): a model WITH dialect morphemes -- what AnalyzeOption::allowedDialects / dialectCost and kiwi_init's enabled_dialects
+    act on.  Returns the raw model path."""
+    import json
+    from dataclasses import replace
+    from .synth import SMALL_SPEC, SynthModel
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    std = json.load(open(os.path.join(gold, "eval_data_lexicon.json"), encoding="utf-8"))["entries"]
+    dia = json.load(open(os.path.join(gold, "eval_dialect_lexicon.json"), encoding="utf-8"))["entries"]
+    os.makedirs(DATA, exist_ok=True)
+    path = os.path.join(DATA, "small-eval-dialect.raw")
+    newest = max(os.path.getmtime(os.path.join(gold, f)) for f in ("eval_data_lexicon.json", "eval_dialect_lexicon.json"))
+    if not os.path.exists(path) or os.path.getmtime(path) < newest:
+        words = tuple((f, t) for f, t in std) + tuple((f, t, d) for f, t, d in dia)
+        SynthModel(replace(SMALL_SPEC, extra_words=words)).raw.save(path)
+    return path
+
+
 def get_workload(name: str):
     """Returns (raw_model_path, list_of_texts, description)."""
     spec_name, n, kw, idx = WORKLOADS[name]

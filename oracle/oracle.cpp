@@ -42,7 +42,7 @@ namespace
 	};
 
 	// a prepared typo transformer applied to an analysis (AnalyzeOption::typoTransformer / typoThreshold / allowedDialects)
-	struct TypoOpt { const korc::typo::Prepared* prepared = nullptr; float threshold = 2.5f; uint16_t dialect = 0; };
+	struct TypoOpt { const korc::typo::Prepared* prepared = nullptr; float threshold = 2.5f; uint16_t dialect = 0; float dialectCost = 3.f; };      // (dialect / dialectCost: AnalyzeOption::allowedDialects / dialectCost)
 
 	// Pretokenized spans (Kiwi::analyze(..., pretokenized): src/Kiwi.cpp:785-946, 1043-1051, 1120, 745-756; KTrie.cpp:782-790, 1177-1210), as far as they are
 	// restated: a span without tokens, and a span of one token that IS a single-candidate dictionary entry -- the cases in which makePretokenizedSpanGroup
@@ -117,6 +117,7 @@ namespace
 		SplitConfig sc = h.scfg; sc.match = match;
 		BestPathConfig bc = h.bcfg;
 		bc.topN = topN;
+		bc.allowedDialect = typo.dialect; bc.dialectCost = typo.dialectCost;
 		bc.splitComplex = match & M_SPLIT_COMPLEX; bc.splitSaisiot = match & M_SPLIT_SAISIOT; bc.mergeSaisiot = match & M_MERGE_SAISIOT;
 		bc.spaceTolerance = sc.spaceTol;
 		// Match::oovMask (include/kiwi/PatternMatcher.h:20-24): 1 = the character model scores unknown forms; 2 / 3: mixed with the substring counts of
@@ -190,6 +191,21 @@ extern "C"
 			return h.release();
 		}
 		catch (const std::exception& e) { fprintf(stderr, "korc_open: %s\n", e.what()); return nullptr; }
+	}
+	// the bake with KiwiBuilder's enabledDialects (kiwi_init's last argument)
+	void* korc_open_dialects(const char* rawModelPath, int enabledDialects)
+	{
+		try
+		{
+			auto h = std::make_unique<OracleHandle>();
+			bakeModel(h->model, rawModelPath, (uint32_t)enabledDialects);
+			h->view = h->model.view();
+			h->sbg = h->model.sbgView();
+			h->cong = h->model.congView();
+			if (h->cong.present()) h->sbg = SbgView{};
+			return h.release();
+		}
+		catch (const std::exception& e) { fprintf(stderr, "korc_open_dialects: %s\n", e.what()); return nullptr; }
 	}
 	void korc_close(void* h) { delete (OracleHandle*)h; }
 
@@ -419,6 +435,24 @@ extern "C"
 			writeResults(w, res);
 		}
 		catch (const std::exception& e) { fprintf(stderr, "korc_analyze: %s\n", e.what()); return 0; }
+		return w.need;
+	}
+
+	// AnalyzeOption::allowedDialects / dialectCost.  The caller hands in the typo transformer -- the reference takes its built-in `dialect` set by itself when a
+	// dialect is allowed and none is given (src/Kiwi.cpp:1037-1041): oraclelib.OracleKiwi.analyze_dialect does the same with that set's entries.
+	size_t korc_analyze_dialect(void* hp, void* typoHp, float typoThreshold, int allowedDialect, float dialectCost, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, uint8_t* out, size_t cap)
+	{
+		auto& h = *(OracleHandle*)hp;
+		Writer w{ out, out + cap };
+		try
+		{
+			TypoOpt typo;
+			if (typoHp) { typo.prepared = ((TypoHandle*)typoHp)->prepared.get(); typo.threshold = typoThreshold; }
+			typo.dialect = (uint16_t)allowedDialect; typo.dialectCost = dialectCost;
+			auto res = analyzeOne(h, h.counters, &h.persistent, (const char16_t*)text, len, topN, match, !!openEnding, nullptr, typo);
+			writeResults(w, res);
+		}
+		catch (const std::exception& e) { fprintf(stderr, "korc_analyze_dialect: %s\n", e.what()); return 0; }
 		return w.need;
 	}
 

@@ -23,7 +23,7 @@ def available() -> bool:
 
 
 class OracleKiwi:
-    def __init__(self, raw_model_path: str):
+    def __init__(self, raw_model_path: str, enabled_dialects: int = 0):
         self.lib = C.CDLL(LIB_PATH)
         L = self.lib
         L.korc_open.restype = C.c_void_p
@@ -46,7 +46,12 @@ class OracleKiwi:
         L.korc_analyze_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
         L.korc_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.korc_set_cong_global.argtypes = [C.c_void_p, C.c_int]
-        self.h = L.korc_open(raw_model_path.encode())
+        if enabled_dialects:      # KiwiBuilder's enabledDialects at the bake
+            L.korc_open_dialects.restype = C.c_void_p
+            L.korc_open_dialects.argtypes = [C.c_char_p, C.c_int]
+            self.h = L.korc_open_dialects(raw_model_path.encode(), enabled_dialects)
+        else:
+            self.h = L.korc_open(raw_model_path.encode())
         if not self.h:
             raise RuntimeError("korc_open failed")
         self._buf = np.zeros(1 << 20, np.uint8)
@@ -128,6 +133,31 @@ class OracleKiwi:
             n, split_end = r.get("II")
             chunks.append((split_end, [r.get("IIIIiIIIf") for _ in range(n)]))
         return chunks
+
+    def analyze_dialect(self, text: str, allowed_dialect: int, dialect_cost: float = 3.0, typo=None, threshold=2.5, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING, open_ending=False):
+        """AnalyzeOption::allowedDialects / dialectCost.  typo None with a dialect allowed: the caller's copy of the built-in `dialect` set (dialect_typo(), below)
+        at threshold 2.5 -- what the reference takes by itself (src/Kiwi.cpp:1037-1041)."""
+        if typo is None and allowed_dialect:
+            typo, threshold = self.dialect_typo(), 2.5
+        self.lib.korc_analyze_dialect.restype = C.c_size_t
+        self.lib.korc_analyze_dialect.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_size_t]
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        buf = self._call(lambda *a: self.lib.korc_analyze_dialect(self.h, typo.h if typo is not None else None, threshold, allowed_dialect, dialect_cost, u.ctypes.data, len(u), top_n, match, int(open_ending), *a))
+        if len(buf) == 0:
+            raise RuntimeError("korc_analyze_dialect failed")
+        return parse_results(buf)
+
+    def dialect_typo(self):
+        """The built-in typo set DefaultTypoSet::dialect as an OracleTypo, prepared: its entries come from the committed fixture tests/golden/typo_default_sets.json
+        where present, else from the reference itself (refbridge)."""
+        if getattr(self, "_dialect_typo", None) is None:
+            import refbridge
+            entries, continual, lengthening = refbridge.default_typo_entries("dialect")
+            t = OracleTypo()
+            t.update_entries(entries, continual, lengthening)
+            t.prepare(True)
+            self._dialect_typo = t
+        return self._dialect_typo
 
     def analyze_typo(self, typo, text: str, threshold=2.5, allowed_dialect=0, top_n: int = 1, match: int = MATCH_ALL_WITH_NORMALIZING, open_ending=False):
         self.lib.korc_analyze_typo.restype = C.c_size_t

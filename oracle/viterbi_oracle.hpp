@@ -43,6 +43,9 @@ namespace korc
 		uint32_t smallMax = 128, mediumMax = 512, bucketCap = 128;
 		// AnalyzeOption::blocklist as one bit per morpheme id, Morpheme::hasMorpheme already applied (flat_model.hpp blockBitsOf); null = none
 		const uint32_t* blockBits = nullptr;
+		// AnalyzeOption::allowedDialects (Dialect bits) / dialectCost: a candidate of a dialect that is neither standard nor allowed is not a candidate, one of
+		// an allowed dialect costs dialectCost (src/PathEvaluator.hpp:231-236, 386, 893); only models with dialect morphemes (ModelView::morphDialect) care
+		uint32_t allowedDialect = 0; float dialectCost = 3.f;
 		// `faithfulOrder`: the large top-1 container and the top-N container are the reference's own -- std::unordered_set / std::unordered_map
 		// + std heap algorithms of this libstdc++, PERSISTENT across calls like the reference's thread_local ones -- so that the order in
 		// which kept paths are handed on is the reference's as long as both sides analyse the same texts in the same sequence from a
@@ -604,7 +607,7 @@ namespace korc
 						if (rule.special == 0) sp |= 1; else if (rule.special == 1) sp &= ~1; else if (rule.special == 3) sp |= 2; else if (rule.special == 4) sp &= ~2;
 						if (rule.sbType) sp = (uint8_t)((sp & 3) | (Rule::hashSb((uint8_t)rule.sbType, (uint8_t)(rule.sbOrder + 1)) << 2));
 						WPath np;
-						np.morph = morphId; np.accScore = (cand + rs) - 0.f; np.firstChunkScore = (firstChunk + rs) - 0.f;
+						np.morph = morphId; np.accScore = (cand + rs) - dialectCostOf(morphId); np.firstChunkScore = (firstChunk + rs) - dialectCostOf(morphId);
 						np.accTypoCost = pp.accTypoCost + node->typoCost;
 						np.parentNode = (int32_t)(prev - graph); np.parentIdx = (int32_t)pi;
 						np.lmNode = lmSt.lmNode; np.histPos = lmSt.histPos; for (int hi = 0; hi < 8; ++hi) np.hist[hi] = lmSt.hist[hi];
@@ -701,7 +704,7 @@ namespace korc
 					if (rule.special == 0) sp |= 1; else if (rule.special == 1) sp &= ~1; else if (rule.special == 3) sp |= 2; else if (rule.special == 4) sp &= ~2;
 					if (rule.sbType) sp = (uint8_t)((sp & 3) | (Rule::hashSb((uint8_t)rule.sbType, (uint8_t)(rule.sbOrder + 1)) << 2));
 					WPath np;
-					np.morph = morphId; np.accScore = (cand + rs) - 0.f; np.firstChunkScore = (firstChunk + rs) - 0.f;
+					np.morph = morphId; np.accScore = (cand + rs) - dialectCostOf(morphId); np.firstChunkScore = (firstChunk + rs) - dialectCostOf(morphId);
 					np.accTypoCost = pp.accTypoCost + node->typoCost;
 					np.parentNode = (int32_t)(pr.node - graph); np.parentIdx = (int32_t)pr.idx;
 					np.lmNode = lmSt.lmNode; np.ctx = lmSt.ctx; for (int hi = 0; hi < 8; ++hi) np.hist[hi] = lmSt.hist[hi];
@@ -886,14 +889,22 @@ namespace korc
 			}
 		}
 
+		// curDialectCost (src/PathEvaluator.hpp:231)
+		float dialectCostOf(uint32_t morphId) const { return (M.morphDialect && M.morphDialect[morphId]) ? cfg.dialectCost : 0.f; }
 		void evaluate(uint32_t nodeIdx, uint16_t ownFormId, const uint32_t* cands, uint32_t nCands, float unkDiscount)
 		{
 			// `if (blocklist && curMorph->hasMorpheme(*blocklist)) continue;` is the first statement of both candidate loops
 			// (src/PathEvaluator.hpp:385, 892): a blocked candidate is not a candidate
 			std::vector<uint32_t> kept;
-			if (cfg.blockBits)
+			if (cfg.blockBits || M.morphDialect)
 			{
-				for (uint32_t k = 0; k < nCands; ++k) if (!((cfg.blockBits[cands[k] >> 5] >> (cands[k] & 31)) & 1)) kept.push_back(cands[k]);
+				for (uint32_t k = 0; k < nCands; ++k)
+				{
+					if (cfg.blockBits && ((cfg.blockBits[cands[k] >> 5] >> (cands[k] & 31)) & 1)) continue;
+					// `if (curMorph->dialect != Dialect::standard && !(curMorph->dialect & allowedDialect)) continue;` -- the statement after it (:386, 893)
+					if (M.morphDialect && M.morphDialect[cands[k]] && !(M.morphDialect[cands[k]] & cfg.allowedDialect)) continue;
+					kept.push_back(cands[k]);
+				}
 				cands = kept.data(); nCands = (uint32_t)kept.size();
 			}
 			const LNode* node = graph + nodeIdx;

@@ -246,13 +246,14 @@ def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
         oracle.set_config()
     assert not capi.kiwi_analyze(kiwi, s.encode(), 17, opt(), None)         # top_n beyond the device limit (16): refused, not ignored
     assert capi.kiwi_error()
-    # allowed_dialects / dialect_cost only ever concern dialect morphemes; a model built without enabled dialects has none: accepted, no effect
+    # allowed_dialects / dialect_cost on a model without dialect morphemes: no morpheme is skipped or charged, but -- as in the reference -- the analysis is
+    # corrected with the built-in `dialect` typo set (tests/test_dialect.py has the models WITH dialect morphemes)
     o = opt()
-    o.allowed_dialects, o.dialect_cost = 0x7FFF, 3.0
+    o.allowed_dialects, o.dialect_cost = 0x3FF, 3.0
     r = capi.kiwi_analyze(kiwi, s.encode(), 1, o, None)
-    assert r and read_result(capi, kiwi, r) == from_oracle(oracle.analyze(s))
+    assert r and read_result(capi, kiwi, r) == from_oracle(oracle.analyze_dialect(s, 0x3FF, 3.0))
     capi.kiwi_res_close(r)
-    assert not capi.kiwi_init(b"/nonexistent", 0, 15, 1) and capi.kiwi_error()      # enabled dialects at build time: refused (no dialect.dict loader)
+    assert not capi.kiwi_init(b"/nonexistent", 0, 15, 1) and capi.kiwi_error()      # (no such model; enabled dialects themselves are accepted)
     # pretokenized objects can be built and closed; without spans they constrain nothing, with a span the analysis is refused loudly
     import ctypes as C
     capi.kiwi_pt_init.restype = C.c_void_p
@@ -463,3 +464,30 @@ def test_blocklist_through_the_c_api(capi, kiwi, oracle, small_model):
     finally:
         oracle.set_blocklist([])
         assert L.kiwi_morphset_close(ms) == 0
+
+
+def test_dialects_through_the_c_api(capi):
+    """kiwi_init(..., enabled_dialects) and kiwi_analyze with the reference's kiwi_analyze_option_t (allowed_dialects, dialect_cost) on the model with dialect
+    morphemes (kiwi_amd.workloads.dialect_model): tokens, scores and the dialect field of kiwi_token_info_t as the REAL reference answered
+    (tests/golden/eval_dialect.json, tools/make_golden_dialect.py)."""
+    import json
+    from kiwi_amd.workloads import dialect_model
+    items = json.load(open(os.path.join(HERE, "golden", "eval_dialect.json"), encoding="utf-8"))["items"]
+    k = capi.kiwi_init(dialect_model().encode(), 1, 1 | 0x0200, 1023)      # integrate allomorphs, Knlm; every dialect enabled
+    assert k, capi.kiwi_error()
+    try:
+        for it in items[::9]:
+            for allowed, cost, key in ((0, 3.0, "allowed_0"), (it["bit"], 3.0, "allowed_own"), (1023, 1.5, "allowed_all_cost_1.5")):
+                o = opt()
+                o.allowed_dialects, o.dialect_cost = allowed, cost
+                r = capi.kiwi_analyze(k, it["text"].encode(), 1, o, None)
+                assert r, capi.kiwi_error()
+                want = it["enabled_all"][key]
+                assert capi.kiwi_res_word_num(r, 0) == len(want["tokens"]) and capi.kiwi_res_prob(r, 0) == C.c_float(want["score"]).value, (it["text"], key)
+                for j, w in enumerate(want["tokens"]):
+                    ti = capi.kiwi_res_token_info(r, 0, j).contents
+                    assert (capi.kiwi_res_form(r, 0, j).decode(), ti.tag, ti.chr_position, ti.length, ti.dialect) == (w[0], w[1], w[2], w[3], w[9]), (it["text"], key, j)
+                    assert ti.score == C.c_float(w[7]).value and ti.typo_cost == C.c_float(w[8]).value
+                capi.kiwi_res_close(r)
+    finally:
+        assert capi.kiwi_close(k) == 0
