@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None, time_reference=True):
+def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None, time_reference=True, cong_global=False):
     """Times the CPU path on this box's host cores on a bounded sample of the same workload.
     Uses the real reference TUs (oracle/_ref) when the prebuilt library travelled with the repo, else this
     repo's CPU oracle ("port").  Also returns the oracle's ALG_BYTES event counts on its sample."""
@@ -27,6 +27,9 @@ def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None, time_refe
     import refbridge
     cores = os.cpu_count() or 1
     orc = oraclelib.OracleKiwi(model_path)
+    if cong_global:
+        orc.set_cong_global(True)      # (the event counts of the global scoring; only with time_reference=False: the timed runners below open the model type the file names)
+        assert not time_reference
     orc_typo = ref_typo = None
     thr = 2.5
     if typo is not None:      # the same rules on both CPU sides
@@ -187,14 +190,14 @@ def side_measurement(eng, workload, steps=20, limit=0, min_seconds=0.0):
     model, or None -- then one is opened (and closed) here.  limit: only the first N sentences (named in the entry).  The algorithmic bytes per
     sentence come from the oracle's event counters on a bounded sample of the same workload, as for the headline workload."""
     from kiwi_amd.api import KiwiAmd, Typo
-    from kiwi_amd.workloads import fill_typo_rules, get_workload, workload_top_n, workload_typo
+    from kiwi_amd.workloads import fill_typo_rules, get_workload, workload_lm_mode, workload_top_n, workload_typo
     model_path, texts, desc = get_workload(workload)
     if limit and limit < len(texts):
         texts = texts[:limit]
         desc += f" [first {limit} sentences only]"
     own = eng is None
     if own:
-        eng = KiwiAmd(model_path, 0)
+        eng = KiwiAmd(model_path, 0, lm_mode=workload_lm_mode(workload))
     top_n = workload_top_n(workload)
     typo_cfg, typo = workload_typo(workload), None
     if typo_cfg is not None:
@@ -230,7 +233,7 @@ def side_measurement(eng, workload, steps=20, limit=0, min_seconds=0.0):
     out = {"workload": desc, "value": len(texts) * steps / el, "unit": "sentences/s", "steps": steps, "ms_per_step": 1000.0 * el / steps, "kernel_ms": {k: v / steps for k, v in kt.items()},
            "sentences": len(texts), "top_n": top_n, "device_bytes": info["device_bytes"], "rerun_chunks": rerun_chunks}
     try:
-        per = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg, time_reference=False)["alg_bytes_per_sentence"]
+        per = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg, time_reference=False, cong_global=workload_lm_mode(workload) == 4)["alg_bytes_per_sentence"]
         out["alg_bytes_per_sentence"] = per
         out["roofline_frac"] = per["search"] * len(texts) / (out["kernel_ms"]["search_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         out["all_kernels_achieved"] = per["total"] * len(texts) / (sum(out["kernel_ms"].values()) * 1e-3) / 1e9
@@ -386,7 +389,7 @@ def main():
         # synthetic tables do not prune like a real model -- seconds per batch, hence a bounded sample)
         also = [side_measurement(eng, "c2", min_seconds=0.5), side_measurement(eng, "c5", min_seconds=0.5)]
         if not args.no_side_models:
-            also += [side_measurement(None, "c4-cong", steps=10), side_measurement(None, "c3-sbg", steps=1)]
+            also += [side_measurement(None, "c4-cong", steps=10), side_measurement(None, "c4-cong-global", steps=3), side_measurement(None, "c3-sbg", steps=3)]
 
     # End to end: UTF-16 strings resident on the host -> kamd_analyze_batch (host text preparation, H2D, kernels,
     # D2H, result assembly) -> packed token records resident on the host.  Timed through the C ABI on an already packed buffer.

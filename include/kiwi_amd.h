@@ -37,6 +37,10 @@ kamd_engine_h kamd_open(const char* raw_model_path, int device);
 /* the same with KiwiBuilder's enabledDialects (kiwi_init's last argument, /root/reference/src/KiwiBuilder.cpp:963-967, 2500-2504; KIWI_DIALECT_* bits):
  * dictionary forms whose morphemes all belong to dialects that are not enabled stay out of the trie */
 kamd_engine_h kamd_open_dialects(const char* raw_model_path, int device, int enabled_dialects);
+/* ... and with the language-model type chosen as kiwi_init's KIWI_BUILD_MODEL_TYPE_* bits do (/root/reference/src/KiwiBuilder.cpp:939-961): lm_mode 0 = what the
+ * container offers (CoNgram local, else SkipBigram, else Knlm), 1 = Knlm, 2 = SkipBigram, 3 = CoNgram (local scoring), 4 = CoNgram GLOBAL (ModelType::congGlobal:
+ * distant tokens, window 7 -- the file must carry the window sections) */
+kamd_engine_h kamd_open_mode(const char* raw_model_path, int device, int lm_mode, int enabled_dialects);
 void kamd_close(kamd_engine_h h);
 const char* kamd_last_error(void);
 

@@ -7,11 +7,11 @@
  * Differences a caller can observe:
  *   - kiwi_init's model_path names a directory holding the reference's own model files (sj.morph + sj.knlm, optionally skipbigram.mdl; or
  *     sj.morph + cong.mdl, optionally nounchr.mdl -- the layout of the reference's models/cong/base), or a raw-model container (or a directory holding `kiwi_amd.raw`).  Its `options` are honoured as in the reference:
- *     KIWI_BUILD_INTEGRATE_ALLOMORPH sets integrate_allomorph; the model type bits select a CoNgram model (default / LARGEST when the
- *     container has one, CONG; local scoring), Knlm (default otherwise, KNLM) or SkipBigram (LARGEST when the container has the tables, SBG)
- *     and refuse CONG_GLOBAL; LARGEST on a cong.mdl that carries distant-token (window) sections is refused too -- the reference resolves it to the
- *     global scoring (KiwiBuilder.cpp:939-946), and a drop-in must not answer with another model's results; the LOAD_*_DICT bits are accepted
- *     (a raw container's dictionary is baked).
+ *     KIWI_BUILD_INTEGRATE_ALLOMORPH sets integrate_allomorph; the model type bits select, as KiwiBuilder::getModelType does (KiwiBuilder.cpp:939-961): a
+ *     CoNgram model when the container has one -- local scoring for the default and CONG, the GLOBAL scoring (ModelType::congGlobal: distant tokens,
+ *     window 7) for LARGEST and CONG_GLOBAL (round 5; a cong.mdl without window sections is scored locally under LARGEST and refused under CONG_GLOBAL,
+ *     where the reference would read past the file's sections) --, else Knlm (default, KNLM) or SkipBigram (LARGEST when the container has the tables,
+ *     SBG); the LOAD_*_DICT bits are accepted (a raw container's dictionary is baked).
  *   - top_n > 1: the analyses and their scores are the reference's.  Among analyses whose scores are EXACTLY equal the order is this library's
  *     own deterministic one (candidates in lattice order); the reference's order of such ties follows the iteration order of its per-morpheme hash
  *     containers (src/BestPathContainer.hpp:279-483) and differs between its own builds.

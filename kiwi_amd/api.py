@@ -210,9 +210,13 @@ class Batch:
 class KiwiAmd:
     """Batched analyzer on one MI355X."""
 
-    def __init__(self, raw_model_path: str, device: int = -1, lib_path: str = None, enabled_dialects: int = 0):
+    def __init__(self, raw_model_path: str, device: int = -1, lib_path: str = None, enabled_dialects: int = 0, lm_mode: int = 0):
         self.lib = load_library(lib_path)     # lib_path: another build of the same library (tests: the small-capacity build)
-        if enabled_dialects:      # KiwiBuilder's enabledDialects (kiwi_init's last argument)
+        if lm_mode:               # kamd_open_mode: 1 Knlm, 2 SkipBigram, 3 CoNgram local, 4 CoNgram global (distant tokens)
+            self.lib.kamd_open_mode.restype = C.c_void_p
+            self.lib.kamd_open_mode.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+            self.h = self.lib.kamd_open_mode(raw_model_path.encode(), device, lm_mode, enabled_dialects)
+        elif enabled_dialects:    # KiwiBuilder's enabledDialects (kiwi_init's last argument)
             self.lib.kamd_open_dialects.restype = C.c_void_p
             self.lib.kamd_open_dialects.argtypes = [C.c_char_p, C.c_int, C.c_int]
             self.h = self.lib.kamd_open_dialects(raw_model_path.encode(), device, enabled_dialects)

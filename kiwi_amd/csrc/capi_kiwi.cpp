@@ -491,14 +491,14 @@ extern "C"
 			switch (options & 0x0F00)
 			{
 			// default / largest: the reference looks for cong.mdl first (-> cong / congGlobal), then skipbigram.mdl (-> knlm / sbg), then sj.knlm
-			// (KiwiBuilder.cpp:939-961); here: a CoNgram blob when the container has one (local scoring: the global variant is not built),
-			// else Knlm by default and SkipBigram for `largest`
+			// (KiwiBuilder.cpp:939-961); here: the container's CoNgram blob when it has one -- scored locally by default, with its distant-token
+			// (window 7) sections for `largest` --, else Knlm by default and SkipBigram for `largest`
 			case 0x0000: lm = Engine::LmMode::Auto; knlmUnlessCong = true; break;
 			case 0x0100: lm = Engine::LmMode::Auto; largest = true; break;
 			case 0x0200: lm = Engine::LmMode::Knlm; break;
 			case 0x0300: lm = Engine::LmMode::Sbg; break;
 			case 0x0400: lm = Engine::LmMode::Cong; break;
-			case 0x0500: throw std::invalid_argument{ "kiwi_amd: CoNgram models with distant-token (global, window 7) scoring are not supported on the device path yet (the oracle restates them: tests/test_cong_global.py)" };
+			case 0x0500: lm = Engine::LmMode::CongGlobal; break;      // (a file without window sections is refused by the engine; the reference reads past the file's sections there)
 			default: throw std::invalid_argument{ "kiwi_amd: unknown model type" };
 			}
 			// enabled_dialects (KIWI_DIALECT_* bits; KiwiBuilder.cpp:963-967): forms of dialects that are not enabled stay out of the dictionary trie (:2500-2504)
@@ -507,9 +507,8 @@ extern "C"
 			auto h = std::make_unique<kiwi_s>();
 			h->engine.reset(new Engine(path, -1, lm, (uint32_t)enabled_dialects));      // (-1: the caller's current device)
 			if (knlmUnlessCong && !h->engine->usesCong() && h->engine->usesSbg()) h->engine.reset(new Engine(path, -1, Engine::LmMode::Knlm, (uint32_t)enabled_dialects));
-			// LARGEST on a cong.mdl is the reference's congGlobal (KiwiBuilder.cpp:939-946): with distant-token sections in the file that is a different
-			// scoring from the local one built here -- refused rather than answered with another model's results
-			if (largest && h->engine->congWindow()) throw std::invalid_argument{ "kiwi_amd: KIWI_BUILD_MODEL_TYPE_LARGEST on a CoNgram model with distant-token sections means the global (window " + std::to_string(h->engine->congWindow()) + ") scoring, which the device path does not do yet; ask for KIWI_BUILD_MODEL_TYPE_CONG (local scoring) explicitly" };
+			// LARGEST on a cong.mdl is the reference's congGlobal (KiwiBuilder.cpp:939-946); a blob without window sections can only be scored locally
+			if (largest && h->engine->usesCong() && h->engine->congWindow()) h->engine.reset(new Engine(path, -1, Engine::LmMode::CongGlobal, (uint32_t)enabled_dialects));
 			h->engine->config.integrateAllomorph = !!(options & 1);
 			h->numThreads = num_threads < 0 ? 0 : (num_threads == 0 ? 1 : num_threads);
 			if (const char* bs = std::getenv("KAMD_CAPI_BATCH")) { const int v = std::atoi(bs); if (v > 0) h->batchSize = v; }      // (developer knob; kiwi_set_option(KIWI_GPU_BATCH_SIZE) is the API)

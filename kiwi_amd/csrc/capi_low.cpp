@@ -64,6 +64,15 @@ extern "C"
 	{
 		return guarded([&]() { auto h = std::make_unique<kamd_engine>(); h->e.reset(new Engine(path, device, Engine::LmMode::Auto, (uint32_t)enabled_dialects)); return h.release(); }, (kamd_engine*)nullptr);
 	}
+	kamd_engine_h kamd_open_mode(const char* path, int device, int lm_mode, int enabled_dialects)
+	{
+		return guarded([&]()
+		{
+			if (lm_mode < 0 || lm_mode > 4) throw std::invalid_argument{ "kamd_open_mode: lm_mode must be 0 .. 4" };
+			static const Engine::LmMode modes[5] = { Engine::LmMode::Auto, Engine::LmMode::Knlm, Engine::LmMode::Sbg, Engine::LmMode::Cong, Engine::LmMode::CongGlobal };
+			auto h = std::make_unique<kamd_engine>(); h->e.reset(new Engine(path, device, modes[lm_mode], (uint32_t)enabled_dialects)); return h.release();
+		}, (kamd_engine*)nullptr);
+	}
 	void kamd_close(kamd_engine_h h) { delete h; }
 	const char* kamd_last_error(void) { return lastError.c_str(); }
 

@@ -218,6 +218,16 @@ namespace kamd
 
 	// CoNgram model on the device (flat_model.hpp CongView): embedding rows of dim x s8 + f32 scale + f32 bias (context) / f32 scale + 4 unused bytes (output)
 	struct CongDev { const uint8_t* ctxEmb; const uint8_t* outEmb; uint32_t dim, stride; uint32_t vlTMax, vlBits; };      // vlTMax / vlBits: CongView (variable-length trie keys; 0xFFFFFFFF = none)
+	// ... and what the GLOBAL model (ModelType::congGlobal, window 7: flat_model.hpp CongView, cong_global.hpp) adds: the window sections of the file, and the
+	// history storage of the search -- seven distant words + the newest slot per search state, parallel to WorkView::states like the SkipBigram rings.
+	// Only the congGlobal instantiations of the search kernel take this view (viterbi_kernel_congg.hip).
+	struct CongGDev
+	{
+		const float* ctxConf; const uint8_t* distEmb; const float* distConf; const float* posConf; const uint8_t* distMask;
+		uint32_t window, keyBytes;     // keyBytes: sizeof(KeyType) of the reference's instantiation -- its state hash reads 8 BYTES of the history
+		uint32_t* hist;                // [state][8]
+		uint8_t* itemScratch;          // per lane group: SbgScratch (viterbi_kernel.hpp): histories of the work items of one batch
+	};
 
 	// LDS layout of the wave-per-chunk lattice build (byte offsets): n text units, node capacity, packed-match capacity
 	struct LatticeLds { uint32_t str, cls, script, cflag, nsToPos, posToNs, mask, moff, endPosMap, fullMask, zAt, mforms, mfrec, out, spaceErr, queue, total; };

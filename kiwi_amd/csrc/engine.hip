@@ -30,7 +30,7 @@ namespace kamd
 	template<int GW> __global__ void k_build_lattice(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes);
 	__global__ void k_build_lattice_big(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t ldsBytes, uint32_t waveLayout);
 	__global__ void k_lattice_wave(ModelView M, BatchView B, WorkView W, SearchParams P, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes, uint32_t matchRatio16, uint32_t expandMode);
-	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder);
+	__global__ void k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder, const uint8_t* distMask);
 	__global__ void k_expand_pos(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, const float* nodeTypoAll, uint32_t useChr);
 	__global__ void k_unk_chr(ModelView M, BatchView B, WorkView W, ChrView C, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
 	__global__ void k_unk_chr_freq(ModelView M, BatchView B, WorkView W, ChrView C, ChrFreqParams Q, float chrBias, uint32_t chunkBegin, uint32_t chunkCount, uint32_t hiTok, uint32_t loTok);
@@ -257,6 +257,7 @@ namespace kamd
 		uint32_t latticeWaveBudget = 128 * 1024; // ... and k_lattice_wave, which is allowed beyond the default 64 KB limit (a 400-unit chunk needs ~70 KB; the CU has 160 KB)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
+		bool wantCongGlobal = false;     // LmMode::CongGlobal: score with the distant-token (window) sections of the CoNgram file
 		bool posPathForced = false;      // KAMD_POS_PATH=2: also for typo correction (slower there: see launchAll)
 		int posGroupForced = 0;          // KAMD_POS_G=8 / 16: lane-group width of the position-step kernel (0: by batch size)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
@@ -264,6 +265,8 @@ namespace kamd
 		uint32_t posContSlots = 256;     // chunks per launch that k_pos_path carries on in the general search itself (KAMD_POS_CONT=0: none, all left to k_best_path)
 		ChrView chr{};      // character model of Match::oovChrModel on the device (absent: dim 0)
 		CongDev cong{}; bool hasCong = false;   // CoNgram model: the context trie is uploaded where the Knlm tables would be (ModelView::lmHash / lmRoot2 / lmBackoff)
+		CongGDev congG{}; bool hasCongG = false;   // global CoNgram model (LmMode::CongGlobal): the window sections on the device; its search shares the SkipBigram kernel's history plumbing
+		bool histStates() const { return hasSbg || hasCongG; }      // search states carry eight history words beside DevState; item histories in sbgScratch
 		SbgDev sbg{}; bool hasSbg = false; DevBuf sbgScratch;   // SkipBigram tables on the device + per-lane-group item scratch of its search kernel
 		// the engine owns ONE pair of streams, one work counter and one scratch arena: device work of concurrent callers (the C API
 		// is callable from many threads, reference capi threading contract) is serialised per engine; host preparation is not
@@ -292,7 +295,8 @@ namespace kamd
 	{
 		bakeModel(impl->model, path, enabledDialects);
 		if (lm == LmMode::Sbg && impl->model.sbgPtrs.empty()) throw std::runtime_error{ "Cannot open required files for skipbigram model" };   // KiwiBuilder.cpp:1008-1013
-		if (lm == LmMode::Cong && !impl->model.congDim) throw std::runtime_error{ "Cannot open ConG model file 'cong.mdl'" };      // KiwiBuilder.cpp:1018-1023
+		if ((lm == LmMode::Cong || lm == LmMode::CongGlobal) && !impl->model.congDim) throw std::runtime_error{ "Cannot open ConG model file 'cong.mdl'" };      // KiwiBuilder.cpp:1018-1023
+		impl->wantCongGlobal = lm == LmMode::CongGlobal;
 		// a model without a Knlm blob (the layout of models/cong/base: sj.morph + cong.mdl) cannot serve the Knlm / SkipBigram types: the reference
 		// fails to open sj.knlm there (KiwiBuilder.cpp:985-1001); searching with empty LM tables would read out of bounds
 		if ((lm == LmMode::Knlm || lm == LmMode::Sbg) && impl->model.lmNodes.empty()) throw std::runtime_error{ "Cannot open required file 'sj.knlm' for the requested model type" };
@@ -310,7 +314,7 @@ namespace kamd
 	}
 
 	// a replica on another GPU: same baked model on the host, its own device tables, streams and scratch
-	Engine::Engine(const Engine& other, int device) : impl(new Impl(other.impl->modelOwner)), config(other.config) { openDevice(device); }
+	Engine::Engine(const Engine& other, int device) : impl(new Impl(other.impl->modelOwner)), config(other.config) { impl->wantCongGlobal = other.impl->wantCongGlobal; openDevice(device); }
 
 	void Engine::openDevice(int device)
 	{
@@ -359,6 +363,15 @@ namespace kamd
 			v.h.bosNode = 0;
 			impl->cong = CongDev{ impl->up(m.congCtxEmb), impl->up(m.congOutEmb), m.congDim, m.congDim + 8, m.congVlTMax, m.congVlBits };
 			impl->hasCong = true;
+			if (impl->wantCongGlobal)
+			{
+				if (!m.congWindow) throw std::runtime_error{ "Cannot open ConG model with distant tokens: the file has no window sections" };
+				if (m.congWindow != 7) throw std::runtime_error{ "kiwi_amd: CoNgram window size must be 7 (the reference instantiates CoNgramState<7> only)" };
+				CongGDev& g = impl->congG;
+				g.ctxConf = impl->up(m.congCtxConf); g.distEmb = impl->up(m.congDistEmb); g.distConf = impl->up(m.congDistConf); g.posConf = impl->up(m.congPosConf);
+				g.distMask = impl->up(m.congDistMask); g.window = m.congWindow; g.keyBytes = m.congKeyBytes; g.hist = nullptr; g.itemScratch = nullptr;
+				impl->hasCongG = true;
+			}
 		}
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
 		v.lmHtxNode = (m.congDim || m.lmHtxNode.empty()) ? nullptr : impl->up(m.lmHtxNode);      // history-transformed Knlm only
@@ -440,6 +453,7 @@ namespace kamd
 	const FlatModel& Engine::model() const { return impl->model; }
 	bool Engine::usesCong() const { return impl->hasCong; }
 	bool Engine::usesSbg() const { return impl->hasSbg; }
+	bool Engine::usesCongGlobal() const { return impl->hasCongG; }
 	uint32_t Engine::congWindow() const { return impl->hasCong ? impl->model.congWindow : 0u; }
 
 	namespace
@@ -472,7 +486,7 @@ namespace kamd
 			b.spOff[c + 1] = b.spOff[c] + (uint32_t)r.sp.size();
 			uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
 			// SkipBigram states carry their history ring in the container key: far fewer paths merge, a node keeps hundreds to thousands of them
-			if (I.hasSbg) scap *= 8;
+			if (I.histStates()) scap *= 8;
 			if (sc == 1 && !tinyArenas) scap = std::max<uint64_t>(scap * std::max(I.stateScale16[0], I.stateScale16[1]) / 16, 64);      // (what the batches so far needed; a re-run at a higher rung takes the whole capacity)
 			if (b.typo.typo) ncap = std::min<uint64_t>(2 * ncap, 0xFFE0);      // lattices over typo graphs come out about twice as large
 			if (tinyArenas)   // test hook (KAMD_TEST_TINY_ARENAS): regions far too small at scale 1, so that the overflow -> re-run ladder is exercised
@@ -571,13 +585,13 @@ namespace kamd
 		b.dPacks.ensure((size_t)b.packBase[nC] * sizeof(CandStatic) + 16);
 		b.dStates.ensure(totStates * sizeof(DevState) + 16); b.dNodeStOff.ensure(totNodes * 4 + 16); b.dNodeStCnt.ensure(totNodes * 4 + 16); b.dReach.ensure(totNodes + 16);
 		b.dTokens.ensure(totTokens * sizeof(DevToken) + 16); b.dResults.ensure(nC * sizeof(DevChunkResult) + 16);
-		const bool posPath = I.posPath && !I.hasSbg;
+		const bool posPath = I.posPath && !I.histStates();
 		if (posPath)
 		{
 			b.dPosRecs.ensure((size_t)b.packBase[nC] * sizeof(PosRec) + 16); b.dPosDesc.ensure(totNodes * sizeof(PosDesc) + 16);
 			b.dPosPrev.ensure(totNodes * 4 + 16); b.dPosNodeRec.ensure(totNodes * 4 + 16); b.dPosMask.ensure(totNodes * 4 + 16); b.dPosBig.ensure(((nC + 7) / 8 * 8) * (size_t)64 * 20 + 16);
 		}
-		if (I.hasSbg) b.dHist.ensure(totStates * 32 + 32);
+		if (I.histStates()) b.dHist.ensure(totStates * 32 + 32);
 		// compact outputs of the end stage: as many token records as the arenas could hold, 16 path headers per chunk (x capacity scale)
 		b.outTokCap = (uint32_t)std::min<uint64_t>(totTokens, 0xFFFFFFF0ull); b.outPathCap = (uint32_t)std::min<uint64_t>((uint64_t)nC * 16 * sc, 0xFFFFFFF0ull);
 		b.dOutTokens.ensure((size_t)b.outTokCap * sizeof(DevToken) + 16); b.dOutPaths.ensure((size_t)b.outPathCap * sizeof(DevPathHeader) + 16); b.dOutCounters.ensure(64);
@@ -861,17 +875,17 @@ namespace kamd
 		if (getenv("KAMD_HANGDUMP")) HIPCHECK(hipMemsetAsync(b.dNodeStCnt.p, 0xFF, (size_t)b.nodeBase[nC] * 4, sA));
 		// SkipBigram: one chunk per wave unless 16-lane groups are forced -- with history rings in the container keys a lattice node gathers
 		// thousands of work items, so a chunk's serial chain is items / lanes (MI355X, small model: 480 texts 0.7 s with 64 lanes, 7 s with 16)
-		const bool variant64 = I.hasSbg ? !(I.groupLanesForced && I.groupLanes == 16) : (I.groupLanesForced && I.groupLanes == 64);
-		const uint32_t nGroups = (I.hasSbg || b.typo.typo || I.hasCong) ? (variant64 ? 1u : 4u)
+		const bool variant64 = I.histStates() ? !(I.groupLanesForced && I.groupLanes == 16) : (I.groupLanesForced && I.groupLanes == 64);
+		const uint32_t nGroups = (I.histStates() || b.typo.typo || I.hasCong) ? (variant64 ? 1u : 4u)
 			: 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
 		// (the SkipBigram kernel is built for 2 waves per SIMD and carries 1.8 MB of item scratch per lane group: 8 persistent blocks per CU)
-		const uint32_t persistBlocks = I.hasSbg ? I.persistBlocks / 12 * 8 : I.persistBlocks;
+		const uint32_t persistBlocks = I.histStates() ? I.persistBlocks / 12 * 8 : I.persistBlocks;
 		const uint32_t maxBlocks = std::min(persistBlocks, (maxWork + nGroups - 1) / nGroups);
-		const size_t groupScratchBytes = I.hasSbg ? sizeof(GroupScratchT<BIGQ_SBG>) : I.hasCong ? sizeof(GroupScratchCong<BIGQ>) : sizeof(GroupScratch);
+		const size_t groupScratchBytes = I.hasSbg ? sizeof(GroupScratchT<BIGQ_SBG>) : I.hasCongG ? sizeof(GroupScratchCong<BIGQ_SBG>) : I.hasCong ? sizeof(GroupScratchCong<BIGQ>) : sizeof(GroupScratch);
 		I.bigScratch.ensure((size_t)maxBlocks * nGroups * groupScratchBytes * std::min(S, 2u));
 		b.wv.bigScratch = I.bigScratch.as<uint8_t>(); b.wv.bigScratchBytes = (uint32_t)groupScratchBytes;
-		if (I.hasSbg)
+		if (I.histStates())
 		{
 			// the kernel's key hash tables (SbgScratch::table) are handed over all-zero and left all-zero by every batch
 			const void* before = I.sbgScratch.p;
@@ -1001,7 +1015,7 @@ namespace kamd
 				hipLaunchKernelGGL(k_build_lattice_big, dim3((cn + 63) / 64), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, budget, wave ? (ratio16 & 0x3FFFu) : 0u);
 			}
 			}
-			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u);
+			hipLaunchKernelGGL(k_expand_cands, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, c0, cn, I.hasCong ? 1u : 0u, I.hasCongG ? I.congG.distMask : (const uint8_t*)nullptr);
 			if (b.wv.unkChrForm)      // Match::oovChrFreqModel / oovChrFreqBranchModel: ... mixed with the substring frequencies of the text (chr_freq.hpp)
 				hipLaunchKernelGGL(k_unk_chr_freq, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, I.chr, ChrFreqParams{ sp.oovGlobalWeight, sp.oovLocalWeight, sp.oovGlobalMinFreq }, sp.oovChrFreqBias,
 					c0, cn, chrToken(0xD800, identifySpecialChr(0xD800)), chrToken(0xDC00, identifySpecialChr(0xDC00)));
@@ -1050,7 +1064,7 @@ namespace kamd
 			// groups, 2 waves per SIMD measured best on 8192 x 40 jamo); with many chunks it is a throughput problem and narrower
 			// groups + a third wave per SIMD win (65536 x 40 jamo: 6.9 vs 9.3 ms).  KAMD_GROUP_LANES / KAMD_WPS override.
 			const bool many = cn >= 32768 && !usePos;      // (after the position-step kernel only a handful of chunks are left: what counts is one chunk's chain, not throughput)
-			const int gl = (I.hasSbg || b.typo.typo || I.hasCong) ? (variant64 ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
+			const int gl = (I.histStates() || b.typo.typo || I.hasCong) ? (variant64 ? 64 : 16) : I.groupLanesForced ? I.groupLanes : (many ? 8 : 16);
 			const int wps = b.typo.typo ? 2 : I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
 			const uint32_t blocksK = std::min(persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
@@ -1093,6 +1107,22 @@ namespace kamd
 				}
 				else if (gl == 64) hipLaunchKernelGGL((sbgk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
 				else hipLaunchKernelGGL((sbgk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsK, sB, I.dview, b.bv, wv, sp, counter, order, cn, sd);
+			}
+			else if (I.hasCongG)
+			{
+				// global CoNgram model (viterbi_kernel_congg.hip / _congg_typo.hip): CoNgram scoring with distant tokens + history words beside the states
+				CongGDev gd = I.congG;
+				gd.hist = b.dHist.as<uint32_t>();
+				gd.itemScratch = I.sbgScratch.as<uint8_t>() + (size_t)(k & 1) * ((S > 1) ? (size_t)maxBlocks * nGroups * sizeof(SbgScratch) : 0);
+				const uint32_t ldsC = ldsK + (64u / (uint32_t)gl) * 4u * QCAP;
+				if (b.typo.typo)
+				{
+					const float* nodeTypo = b.dNodeTypo.as<float>();
+					if (gl == 64) hipLaunchKernelGGL((typok::congk::gk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsC, sB, I.dview, b.bv, wv, sp, counter, order, cn, nodeTypo, I.cong, gd);
+					else hipLaunchKernelGGL((typok::congk::gk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsC, sB, I.dview, b.bv, wv, sp, counter, order, cn, nodeTypo, I.cong, gd);
+				}
+				else if (gl == 64) hipLaunchKernelGGL((congk::gk::k_best_path<64, 2>), dim3(blocksK), dim3(64), ldsC, sB, I.dview, b.bv, wv, sp, counter, order, cn, I.cong, gd);
+				else hipLaunchKernelGGL((congk::gk::k_best_path<16, 2>), dim3(blocksK), dim3(64), ldsC, sB, I.dview, b.bv, wv, sp, counter, order, cn, I.cong, gd);
 			}
 			else if (I.hasCong && b.typo.typo)
 			{
@@ -1539,7 +1569,7 @@ namespace kamd
 			uint64_t w = 0; size_t r1 = r0;
 			while (r1 < refs.size())
 			{
-				const uint64_t cw = (48ull * parent.prep[refs[r1].text].chunks[refs[r1].chunk].nChars + 256) * capScale * (I.hasSbg ? 8 : 1);
+				const uint64_t cw = (48ull * parent.prep[refs[r1].text].chunks[refs[r1].chunk].nChars + 256) * capScale * (I.histStates() ? 8 : 1);
 				if (r1 > r0 && w + cw > sliceBudget) break;
 				w += cw; ++r1;
 			}
@@ -1597,7 +1627,7 @@ namespace kamd
 			{
 				const DevChunkResult& r = b.hResults[c];
 				if (r.status >= 16) continue;
-				const uint64_t full = (48ull * (b.charOff[c + 1] - b.charOff[c]) + 256) * (impl->hasSbg ? 8 : 1);
+				const uint64_t full = (48ull * (b.charOff[c + 1] - b.charOff[c]) + 256) * (impl->histStates() ? 8 : 1);
 				const uint64_t used = (uint64_t)r.endOff + r.nEnd / 2 + (b.nodeBase[c + 1] - b.nodeBase[c]) / 12 + 16;
 				++hist[std::min<uint64_t>(17, (used * 16 + full - 1) / full)]; ++counted;
 			}

@@ -67,7 +67,7 @@ namespace kamd
 		EngineConfig config;
 		// which language model of the container scores the search (reference ModelType, include/kiwi/Types.h:292-335): Auto = SkipBigram when the
 		// container carries its tables, else Knlm; Knlm = Knlm even then; Sbg = SkipBigram or an error
-		enum class LmMode { Auto, Knlm, Sbg, Cong };      // Auto: CoNgram when the container has a blob, else SkipBigram when it has tables, else Knlm
+		enum class LmMode { Auto, Knlm, Sbg, Cong, CongGlobal };      // Auto: CoNgram (local) when the container has a blob, else SkipBigram when it has tables, else Knlm; CongGlobal: ModelType::congGlobal (window 7)
 		// enabledDialects: KiwiBuilder's enabledDialects (kiwi_init's last argument): forms of other dialects stay out of the dictionary trie
 		explicit Engine(const std::string& rawModelPath, int device = -1, LmMode lm = LmMode::Auto, uint32_t enabledDialects = 0);
 		Engine(const Engine& other, int device);      // replica of `other` on another GPU (shares the baked host model)
@@ -75,6 +75,7 @@ namespace kamd
 		int deviceIndex() const;      // the HIP device this engine's tables and streams live on
 		void bindThread() const;      // makes that device the calling thread's current one
 		bool usesCong() const; bool usesSbg() const;      // which language model scores the search
+		bool usesCongGlobal() const;                      // the distant-token (window) sections are scored
 		uint32_t congWindow() const;                      // window size of the CoNgram model's distant-token sections (0: none, or not a CoNgram model)
 		~Engine();
 		const FlatModel& model() const;

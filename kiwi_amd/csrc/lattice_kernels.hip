@@ -813,7 +813,9 @@ namespace kamd
 	// transposedOrder (CoNgram models): a node's records in the order the reference's transposed evaluator takes the candidates -- z-coda and
 	// z-siot shortcuts first, then the regular candidates, then the left halves of split stems, then the right halves (src/PathEvaluator.hpp:
 	// 884-915 + MorphemeEvaluator<CoNgramState>, src/CoNgramModel.cpp:86-135), each class in dictionary order
-	__global__ void __launch_bounds__(64) k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder)
+	// distMask (global CoNgram model, else null): regular candidates whose first word is a valid distant token come after the other regular ones
+	// (MorphemeEvaluator<CoNgramState<7>>, src/CoNgramModel.cpp:105-124)
+	__global__ void __launch_bounds__(64) k_expand_cands(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount, uint32_t transposedOrder, const uint8_t* distMask)
 	{
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t chunk = chunkBegin + blockIdx.x;
@@ -838,7 +840,13 @@ namespace kamd
 				uint32_t at = 0;
 				if (transposedOrder)
 				{
-					auto cls = [&](uint32_t m2) -> uint32_t { const MorphRec r = M.morphs[m2]; return candClassOf(r.tag, r.socket, r.flags); };
+					auto cls = [&](uint32_t m2) -> uint32_t
+					{
+						const MorphRec r = M.morphs[m2];
+						uint32_t c2 = 2u * candClassOf(r.tag, r.socket, r.flags);
+						if (distMask && c2 == 4u) { const uint32_t fw = (r.flags & MF_SINGLE) ? r.lmId : M.chunkLm[r.chunkOff]; c2 += (distMask[fw >> 3] >> (fw & 7)) & 1u; }
+						return c2;
+					};
 					const uint32_t mine = cls(mid);
 					for (uint32_t j = 0; j < nd.candCnt; ++j)
 					{

@@ -70,6 +70,22 @@
 #else
 #define CONG_ONLY(...)
 #endif
+// The GLOBAL CoNgram model (ModelType::congGlobal, window 7; viterbi_kernel_congg.hip: KAMD_CONG + KAMD_CONGG, namespace kamd::congk::gk): a state also
+// carries the last seven valid distant words of its path and the newest slot (cong_global.hpp).  The history travels exactly as the SkipBigram ring does
+// -- an arena parallel to the states, a copy per work item in the lane group's item scratch, a digest in the de-duplication keys --, so that plumbing is
+// spelled HIST_ONLY(...) / KAMD_HIST and serves both compilations; what differs is spelled CONGG_ONLY / SBG_ONLY.
+#ifdef KAMD_CONGG
+#include "cong_global.hpp"
+#define CONGG_ONLY(...) __VA_ARGS__
+#else
+#define CONGG_ONLY(...)
+#endif
+#if defined(KAMD_SBG) || defined(KAMD_CONGG)
+#define KAMD_HIST 1
+#define HIST_ONLY(...) __VA_ARGS__
+#else
+#define HIST_ONLY(...)
+#endif
 #if defined(KAMD_SBG) || defined(KAMD_CONG)
 #define STATE_EXTRA(...) __VA_ARGS__      // the state's spare dword carries part of the LM state (ring position / context id)
 #else
@@ -88,8 +104,16 @@ namespace typok
 #ifdef KAMD_CONG
 namespace congk
 {
+#ifdef KAMD_CONGG
+namespace gk
+{
+	// (with histories in the keys a node gathers many more paths: the SkipBigram kernel's staging capacity)
+	constexpr uint32_t BIGQ = BIGQ_SBG;
+	using GroupScratch = GroupScratchCong<BIGQ_SBG>;
+#else
 	// (the big queue of this namespace also carries the context id of every work item)
 	using GroupScratch = GroupScratchCong<BIGQ>;
+#endif
 #endif
 #ifdef KAMD_SBG
 namespace sbgk
@@ -485,10 +509,12 @@ namespace sbgk
 	}
 #endif
 
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 	// ---- SkipBigram LM state beyond the Knlm node: ring of the last 8 valid word ids + write position (SbgState,
 	// src/SkipBigramModel.hpp:141-182).  Rings are only ever indexed with compile-time constants or select chains, so they
 	// stay in registers.
+	// Global CoNgram model: the same eight words are CoNgramState<7>::history (h[0..6] the last seven valid distant words, h[7] the newest slot;
+	// cong_global.hpp pushHistory); pos is unused (0).
 	struct Ring { uint32_t h[8]; uint32_t pos; };
 	__device__ __forceinline__ Ring loadRing(const uint32_t* base, uint32_t pos)
 	{
@@ -515,6 +541,12 @@ namespace sbgk
 	__device__ __forceinline__ bool sameRing(const Ring& a, const Ring& b, bool last4)
 	{
 		bool eq = true;
+#ifdef KAMD_CONGG
+		// CoNgramState<7>::operator== (src/CoNgramModel.hpp:452-461): history[3..6] -- not the newest word, not the three oldest; top-N compares the same (PathHash)
+		(void)last4;
+		eq = (a.h[3] == b.h[3]) & (a.h[4] == b.h[4]) & (a.h[5] == b.h[5]) & (a.h[6] == b.h[6]);
+		return eq;
+#endif
 		if (last4)
 		{
 #pragma unroll
@@ -534,6 +566,12 @@ namespace sbgk
 #ifdef KAMD_TEST_WEAK_DIGEST
 		return 0;      // test build: every pair of items with equal keys reaches the exact comparison / the collision hand-over
 #else
+#ifdef KAMD_CONGG
+		{ uint32_t dg = 0x51ED270Bu; (void)last4;
+#pragma unroll
+		  for (uint32_t k = 3; k < 7; ++k) { dg = (dg ^ r.h[k]) * 0x9E3779B1u; dg ^= dg >> 15; }
+		  return dg; }
+#endif
 		uint32_t d = last4 ? 0x51ED270Bu : r.pos;
 		if (last4)
 		{
@@ -547,6 +585,41 @@ namespace sbgk
 		}
 		return d;
 #endif
+	}
+#endif
+
+#ifdef KAMD_CONGG
+	// CoNgramModel::progress with distant tokens (src/CoNgramModel.cpp:802-868) / one entry of progressMatrixWSort / WOSort (:1037-1466): a valid distant
+	// word is scored as a mixture over the context and the state's seven history words (cong_global.hpp: the arithmetic, written once for oracle and
+	// device), any other word as the local model scores it; then the context moves on and the word (or 0) enters the history.
+	__device__ INL3 float congStepG(const ModelView& M, const CongDev& CG, const CongGDev& GG, int32_t& node, uint32_t& ctx, Ring& ring, uint32_t next, bool outputFirst, bool matrix)
+	{
+		CongView C;
+		C.dim = CG.dim; C.stride = CG.stride; C.ctxEmb = CG.ctxEmb; C.outEmb = CG.outEmb; C.window = GG.window; C.keyBytes = GG.keyBytes;
+		C.ctxConf = GG.ctxConf; C.distEmb = GG.distEmb; C.distConf = GG.distConf; C.posConf = GG.posConf; C.distMask = GG.distMask;
+		float ll;
+		if (C.distant(next)) ll = matrix ? congg::scoreMatrix(C, ctx, ring.h, next, outputFirst) : congg::scoreSingle(C, ctx, ring.h, next);
+		else
+		{
+			const uint32_t* a = reinterpret_cast<const uint32_t*>(CG.ctxEmb + (size_t)ctx * CG.stride);
+			const uint32_t* b = reinterpret_cast<const uint32_t*>(CG.outEmb + (size_t)next * CG.stride);
+			const uint32_t nw = CG.dim >> 2;
+			int32_t acc = 0;
+			for (uint32_t k = 0; k < nw; ++k) acc = dot4s8(a[k], b[k], acc);
+			const float cs = __uint_as_float(a[nw]), bias = __uint_as_float(a[nw + 1]), os = __uint_as_float(b[nw]);
+			const float x = (float)acc;
+			ll = outputFirst ? x * os * cs + bias : x * cs * os + bias;
+		}
+		const LmRootRec rootRec = M.lmRoot2[next];
+		if (next < CG.vlTMax) ctx = congWalk(M, node, next, rootRec);
+		else
+		{
+			const uint32_t r = next - CG.vlTMax, k1 = CG.vlTMax + (r >> CG.vlBits), k2 = CG.vlTMax + (1u << CG.vlBits) + (r & ((1u << CG.vlBits) - 1));
+			congWalk(M, node, k1, M.lmRoot2[k1]);
+			ctx = congWalk(M, node, k2, M.lmRoot2[k2]);
+		}
+		congg::pushHistory(C, ring.h, next);
+		return ll;
 	}
 #endif
 
@@ -599,12 +672,16 @@ namespace sbgk
 			gl = o.gl; gshift = o.gshift; lds = o.lds; nodes = o.nodes; Gn = o.Gn; str = o.str; cls = o.cls; st = o.st; stCap = o.stCap; stTop = o.stTop;
 			nodeStOff = o.nodeStOff; nodeStCnt = o.nodeStCnt; nodeLive = o.nodeLive; uniq = o.uniq; nUniq = o.nUniq;
 			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; tl = o.tl;
-			SBG_ONLY(S = o.S; hist = o.hist; sscr = o.sscr;)
+			SBG_ONLY(S = o.S;) HIST_ONLY(hist = o.hist; sscr = o.sscr;)
 			TYPO_ONLY(typoAll = o.typoAll; nodeTypo = o.nodeTypo;)
 			CONG_ONLY(CG = o.CG; outFirst = o.outFirst;)
+			CONGG_ONLY(GG = o.GG; matrix = o.matrix;)
 		}
 		// SkipBigram: the model view, the chunk's state rings (parallel to st) and the lane group's item scratch
-		SBG_ONLY(const SbgDev* S; uint32_t* hist; SbgScratch* sscr;)
+		SBG_ONLY(const SbgDev* S;) HIST_ONLY(uint32_t* hist; SbgScratch* sscr;)
+		// global CoNgram model: the window sections; `matrix`: the regular candidates of this evaluation are scored by progressMatrix* (more than one path or
+		// candidate), not by state.next() -- other roundings (cong_global.hpp scoreMatrix / scoreSingle)
+		CONGG_ONLY(const CongGDev* GG; bool matrix;)
 		TYPO_ONLY(const float* typoAll; const float* nodeTypo;)      // typo cost of every node of the batch / of the chunk's nodes
 		CONG_ONLY(const CongDev* CG; bool outFirst;)                 // embedding tables; which kernel of the reference rounds the regular candidates' scores at this node
 		CONG_ONLY(__device__ __forceinline__ LDS_AS uint32_t* qCtx() const { return ldsPtr<uint32_t>(lds + Lay<G>::CTXQ); })
@@ -732,7 +809,7 @@ namespace sbgk
 #endif
 		uint64_t rKey = KINVALID; float rScore = 0, rFcs = 0, rTypo = 0;
 		CONG_ONLY(uint32_t rCtx = 0;)      // context id of the item's new LM state
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 		uint32_t rDigest = 0;      // digest of the item's history ring (the ring itself goes to X.sscr)
 		const bool last4 = X.P.topN > 1;   // what of the ring belongs to the container key (sameRing)
 #endif
@@ -745,7 +822,7 @@ namespace sbgk
 			uint32_t k = 0;
 			if (valid) { while (k + 1 < nC && q >= X.candQOff(k + 1)) ++k; }
 			float cand = 0, firstChunk = 0; int32_t lmNode = 0; uint8_t rootKey = 0, sp = 0;
-			SBG_ONLY(Ring ring{};)
+			HIST_ONLY(Ring ring{};)
 			CONG_ONLY(uint32_t ctx = 0; float icDeferred = 0;)
 			if (valid)
 			{
@@ -815,12 +892,18 @@ namespace sbgk
 					}
 					lmNode = ps.lmNode;
 					SBG_ONLY(ring = loadRing(X.hist + 8ull * (pBeg + p), X.st[pBeg + p].pad0);)
+					CONGG_ONLY(ring = loadRing(X.hist + 8ull * (pBeg + p), 0u);)
 					CONG_ONLY(ctx = X.st[pBeg + p].pad0;)
 					if (!(csock && single))
 					{
 						// prohibit <v> without <chunk> (PathEvaluator.hpp:604-608): static per candidate unless the word id was replaced above
 						if (widReplaced ? (M.morphs[firstWid].tag == T_P) : ((c.flags() & MF_FIRST_WID_IS_P) != 0)) { valid = false; break; }
-#ifdef KAMD_CONG
+#if defined(KAMD_CONGG)
+						// (a right half is scored by state.next(): progress(); regular candidates by the evaluation's matrix kernel or, one path and one candidate, next())
+						float ll = congStepG(M, *X.CG, *X.GG, lmNode, ctx, ring, firstWid, X.outFirst && !csock, X.matrix && !csock);
+						cand += ll; firstChunk += ll;
+						cand += icDeferred;
+#elif defined(KAMD_CONG)
 						float ll = congStep(M, *X.CG, lmNode, ctx, firstWid, X.outFirst && !csock);
 						cand += ll; firstChunk += ll;
 						cand += icDeferred;
@@ -836,7 +919,9 @@ namespace sbgk
 							{
 								const uint32_t wid = ch == 1 ? c.secondWid : M.chunkLm[c.chunkOff + ch];
 								if ((c.flags() & MF_ANY_REST_WID_IS_P) && M.morphs[wid].tag == T_P) { valid = false; break; }
-#ifdef KAMD_CONG
+#if defined(KAMD_CONGG)
+								ll = congStepG(M, *X.CG, *X.GG, lmNode, ctx, ring, wid, false, false);
+#elif defined(KAMD_CONG)
 								ll = congStep(M, *X.CG, lmNode, ctx, wid, false);
 #else
 								ll = lmProgress(M, lmNode, wid);
@@ -867,7 +952,7 @@ namespace sbgk
 				const uint64_t key = valid ? ((uint64_t)(uint32_t)lmNode | ((uint64_t)sp << 32) | ((uint64_t)rootKey << 40) | ((uint64_t)k << 48)) : KINVALID;
 				rKey = key; rScore = cand; rFcs = firstChunk;
 				CONG_ONLY(rCtx = ctx; if (!fast) { if (big) X.scratch->ctx[q] = ctx; else X.qCtx()[q] = ctx; })
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 				// the LM state of the item beyond the Knlm node; the queues are filled on the register path too, which hands a
 				// batch over to the scanning path when two digests collide
 				rDigest = ringDigest(ring, last4);
@@ -903,8 +988,9 @@ namespace sbgk
 			const uint8_t stSocket = single ? c.socket() : 0;
 			const bool own = single && ownKind;
 			const uint16_t lf = own ? (uint16_t)(ownFeat | (c.leftFeat() & (LF_TAG_SSC | LF_PREV_ZSIOT))) : c.leftFeat();
-#ifdef KAMD_SBG
-			// the ring of item qw (top-1: the key's winner has, by key equality, the ring of every item of the key)
+#ifdef KAMD_HIST
+			// the ring of item qw (top-1 SkipBigram: the key's winner has, by key equality, the ring of every item of the key; global CoNgram: the key holds
+			// history[3..6] only -- the WINNER's whole history is the state's, as the reference's container replaces the entry)
 			const Ring er = loadRing(X.sscr->hist[qw], X.sscr->pos[qw]);
 			storeRing(X.hist + 8ull * pos, er);
 #endif
@@ -912,9 +998,13 @@ namespace sbgk
 				own ? ownKind : 0, parent, c.morph, wfcs, (uint16_t)E.nodeIdx, own ? (uint16_t)E.nodeIdx : 0 SBG_ONLY(, er.pos) CONG_ONLY(, wctx));
 			stageState<G>(X, pos - E.nodeStart, wscore, newRoot, c.socket() != 0, stSocket != 0);
 		};
+#ifdef KAMD_HIST
 #ifdef KAMD_SBG
 		// top-N: the container key leaves the previous root out (PathHash<SbgState>::operator==, src/SkipBigramModel.cpp:26-29)
 		const uint64_t keyMask = last4 ? ~(0xFFull << 40) : ~0ull;
+#else
+		const uint64_t keyMask = ~0ull;      // (the generic PathHash compares the root as well, BestPathContainer.hpp:105-110)
+#endif
 		bool scan = !fast;      // the register path hands its batch to the scanning path when ring digests collide
 #endif
 		if (fast)
@@ -927,7 +1017,7 @@ namespace sbgk
 				bool rep = rKey != KINVALID;
 				float best = rScore; uint32_t qw = q;
 				uint32_t beaten = 0;      // top-N: items of the same key that beat this one (higher score, or equal and earlier)
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 				uint32_t firstSame = q;   // earliest item whose key and ring digest equal this one's
 				const uint32_t hiMask = (uint32_t)(keyMask >> 32);
 #define KAMD_SAME_ITEM(N) ((((orl ^ rl) & (16u - G)) == 0)) & (ol == keyLo) & ((((oh ^ keyHi) & hiMask) == 0)) & (rowRor<N>(rDigest) == rDigest)
@@ -949,7 +1039,7 @@ namespace sbgk
 #undef KAMD_SAME_ITEM
 #undef KAMD_TRACK_FIRST
 				TLMARK(X, 7)
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 				// the rotations compared digests: every item checks its ring against the earliest item of its digest class.
 				// All checks passing makes the classes exact (equality is transitive); a single mismatch sends the whole
 				// batch through the scanning path, which compares rings.
@@ -977,17 +1067,17 @@ namespace sbgk
 					else X.overflow = true;
 				}
 				X.stTop += __popcll(kbal);
-				SBG_ONLY(})
+				HIST_ONLY(})
 			}
 		}
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 		if (scan)
 #else
 		else
 #endif
 		{
 			const int nBuckets = mode == 1 ? 4 : 1;
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 			// top-1: representative and winner of every container key through a hash table in the group's HBM scratch (one slot
 			// per key, claimed by compare-and-swap, settled by atomic max) -- with rings in the keys a node gathers thousands of
 			// items per candidate, far too many for every item to scan its candidate's list.  top-N keeps the scan (its keys hold
@@ -1054,9 +1144,156 @@ namespace sbgk
 				waveSync();
 			}
 #endif
+#ifdef KAMD_CONGG
+			// Hash<WordLL<CoNgramState<7>>> of an item (BestPathContainer.hpp:80-85 over src/CoNgramModel.hpp:520-532): Hash<uint32_t>(node), then the last 8 BYTES of
+			// history[0..6] read as one word -- four 16-bit or two 32-bit ids --, then root and special state
+			auto wordHash = [&](uint64_t key, const Ring& ring) -> uint64_t
+			{
+				const uint64_t nv = (uint64_t)(uint32_t)key;
+				uint64_t lmv = (nv * 2305843009213693951ull) ^ ((nv << 33) | (nv >> 31));
+				uint64_t hw = X.GG->keyBytes == 2
+					? ((uint64_t)(uint16_t)ring.h[3] | ((uint64_t)(uint16_t)ring.h[4] << 16) | ((uint64_t)(uint16_t)ring.h[5] << 32) | ((uint64_t)(uint16_t)ring.h[6] << 48))
+					: ((uint64_t)ring.h[5] | ((uint64_t)ring.h[6] << 32));
+				hw = (hw * 2305843009213693951ull) ^ ((hw << 31) | (hw >> 33));
+				lmv = hw ^ ((lmv << 3) | (lmv >> 61));
+				return (uint64_t)(((key >> 40) & 0xFF) | (((key >> 32) & 0xFF) << 8)) ^ ((lmv << 3) | (lmv >> 61));
+			};
+			// The reference's container past 64 entries (BucketedHashContainer::insertOptimized of the SIMD builds, BestPathContainer.hpp:316-384; the oracle's
+			// contInsert has the two defects spelled out): entries 0..63 are never found again, a later item is looked up among the entries 64.. by hash BYTE and
+			// compared with the entry of the FIRST half at the same offset -- duplicates of an equal state stay alive, and with the global model their other
+			// history words change later scores.  A container is one candidate's (and in the medium mode one of its four buckets'); only a candidate with more
+			// than 64 items can get there, and for those the insertions are replayed in item order, one item per step, the lanes holding the entries.
+			bool anyBig = false;
+			if (hashed && mode != 2)
+			{
+				for (uint32_t k = X.gl; k < nC; k += G) anyBig |= ((k + 1 < nC) ? X.candQOff(k + 1) : Qtot) - X.candQOff(k) > 64u;
+				anyBig = X.any(anyBig);
+			}
+			const uint32_t contCap = mode == 1 ? X.P.bucketCap : 128u;
+			// entries of the candidate's container in order -> sscr->hash[lo ..] (the digests are not read again once the table is built); returns their number
+			auto replay = [&](uint32_t lo, uint32_t hi, int b) -> uint32_t
+			{
+				constexpr int R = 64 / G;
+				uint32_t eSlot[R], eItem[R], sItem[R], sHb[R]; float eScore[R], sScore[R];
+#pragma unroll
+				for (int r = 0; r < R; ++r) { eSlot[r] = eItem[r] = sItem[r] = sHb[r] = 0; eScore[r] = sScore[r] = 0.f; }
+				uint32_t size = 0;
+				for (uint32_t qb = lo; qb < hi; qb += G)
+				{
+					const uint32_t q = qb + X.gl;
+					bool act = false; uint32_t slot = 0, hb = 0; float sc = 0.f;
+					if (q < hi)
+					{
+						const uint64_t key = big ? X.scratch->key[q] : X.qKey()[q];
+						if (key != KINVALID)
+						{
+							const uint64_t h = wordHash(key, loadRing(X.sscr->hist[q], X.sscr->pos[q]));
+							if (mode != 1 || (int)((h >> 8) & 3) == b) { act = true; hb = (uint32_t)(h & 0xFF); slot = X.sscr->slot[q]; sc = big ? X.scratch->score[q] : X.qScore()[q]; }
+						}
+					}
+					for (uint64_t m = X.ballot(act); m; m &= m - 1)
+					{
+						const int l = __ffsll((unsigned long long)m) - 1;
+						const uint32_t js = X.bcast(slot, l), jh = X.bcast(hb, l), j = qb + (uint32_t)l; const float jsc = X.bcast(sc, l);
+						if (size < 64u)
+						{
+							bool found = false;
+#pragma unroll
+							for (int r = 0; r < R; ++r)
+							{
+								const bool mine = (uint32_t)r * G + X.gl < size && eSlot[r] == js;
+								if (mine && jsc > eScore[r]) { eScore[r] = jsc; eItem[r] = j; }
+								found |= mine;
+							}
+							if (!X.any(found))
+							{
+#pragma unroll
+								for (int r = 0; r < R; ++r) if ((uint32_t)r * G + X.gl == size) { eSlot[r] = js; eScore[r] = jsc; eItem[r] = j; }
+								++size;
+							}
+							continue;
+						}
+						const uint32_t n2 = size - 64u;
+						bool done = false;
+						if (n2 < 64u)
+						{
+#pragma unroll
+							for (int r = 0; r < R; ++r)
+							{
+								if (done) continue;      // (uniform)
+								const uint64_t hm = X.ballot((uint32_t)r * G + X.gl < n2 && sHb[r] == jh && eSlot[r] == js);
+								if (!hm) continue;
+								if ((int)X.gl == __ffsll((unsigned long long)hm) - 1 && jsc > sScore[r]) { sScore[r] = jsc; sItem[r] = j; }
+								done = true;
+							}
+						}
+						if (done || size >= contCap) continue;
+						if (n2 < 64u)
+						{
+#pragma unroll
+							for (int r = 0; r < R; ++r) if ((uint32_t)r * G + X.gl == n2) { sHb[r] = jh; sScore[r] = jsc; sItem[r] = j; }
+						}
+						else if (X.gl == 0) X.sscr->hash[lo + size] = j;      // (a capacity above 128 is a test knob: entries past 128 are never looked at again)
+						++size;
+					}
+				}
+#pragma unroll
+				for (int r = 0; r < R; ++r)
+				{
+					const uint32_t i = (uint32_t)r * G + X.gl;
+					if (i < size && i < 64u) X.sscr->hash[lo + i] = eItem[r];
+					if (size > 64u && i < size - 64u && i < 64u) X.sscr->hash[lo + 64u + i] = sItem[r];
+				}
+				return size;
+			};
+			// (uniform) the next candidate at or after k0 whose container -- of bucket b -- reaches 64 entries; repsUpTo = sscr->next, see below
+			auto nextReplayed = [&](uint32_t k0) -> uint32_t
+			{
+				for (uint32_t k = k0; k < nC; ++k)
+				{
+					const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
+					if (hi - lo > 64u && X.sscr->next[hi - 1] - (lo ? X.sscr->next[lo - 1] : 0u) >= 64u) return k;
+				}
+				return nC;
+			};
+#endif
 			for (int b = 0; b < nBuckets; ++b)
 			{
 				uint32_t emittedInBucket = 0;
+#ifdef KAMD_CONGG
+				uint32_t dk = nC;      // the next candidate whose container is replayed (nC: none)
+				if (anyBig)
+				{
+					// number of container keys of bucket b among the items 0..q -> sscr->next[q] (free while the keys are not listed)
+					uint32_t run = 0;
+					for (uint32_t qb = 0; qb < Qtot; qb += G)
+					{
+						const uint32_t q = qb + X.gl;
+						bool first = false;
+						if (q < Qtot)
+						{
+							const uint64_t key = big ? X.scratch->key[q] : X.qKey()[q];
+							if (key != KINVALID)
+							{
+								first = (0xFFFFFFFFu - atomicMax(&X.sscr->table[X.sscr->slot[q]].firstInv, 0u)) == q;
+								if (first && mode == 1) first = (int)((wordHash(key, loadRing(X.sscr->hist[q], X.sscr->pos[q])) >> 8) & 3) == b;
+							}
+						}
+						const uint64_t fb = X.ballot(first);
+						if (q < Qtot) X.sscr->next[q] = run + X.prefix(fb) + (first ? 1u : 0u);
+						run += __popcll(fb);
+					}
+					waveSync();
+					for (uint32_t k = nextReplayed(0); k < nC; k = nextReplayed(k + 1))
+					{
+						const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
+						const uint32_t n = replay(lo, hi, b);
+						if (X.gl == 0) X.sscr->next[lo] = n;      // (no count that is read again: lo is neither the last item of this candidate nor of the one before)
+					}
+					waveSync();
+					dk = nextReplayed(0);
+				}
+#endif
 				for (uint32_t qb = 0; qb < Qtot; qb += G)
 				{
 					const uint32_t q = qb + X.gl;
@@ -1068,7 +1305,7 @@ namespace sbgk
 						const uint32_t lo = X.candQOff(k), hi = (k + 1 < nC) ? X.candQOff(k + 1) : Qtot;
 						rep = true;
 						float best = -INFINITY; bool haveBest = false;
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 						// does item j (key kj) belong to another container key than this item?  Packed key, then digest, then the rings
 						const Ring myRing = loadRing(X.sscr->hist[q], X.sscr->pos[q]); const uint32_t myDigest = X.sscr->hash[q];
 						auto otherKey = [&](uint32_t j, uint64_t kj) -> bool
@@ -1080,7 +1317,7 @@ namespace sbgk
 #else
 #define KAMD_OTHER_KEY(j, kj) kj != key
 #endif
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 						if (listed)
 						{
 							const float sq = big ? X.scratch->score[q] : X.qScore()[q];
@@ -1111,7 +1348,7 @@ namespace sbgk
 							}
 							rep = beaten < X.P.topN;      // qw stays q: every kept item is written with its own values
 						}
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 						else if (hashed)
 						{
 							// (atomic reads: the slot was settled by atomics of other lanes, a plain load could be served from a stale cache line)
@@ -1135,11 +1372,13 @@ namespace sbgk
 						if (rep && mode == 1)
 						{
 							// bucket = (h >> 8) & 3 of Hash<WordLL> (BestPathContainer.hpp:80-85, 323)
-#ifdef KAMD_SBG
+#if defined(KAMD_SBG)
 							// Hash<SbgState> (src/SkipBigramModel.hpp:186-201): the ring words chained onto the Knlm node
 							uint64_t lmv = (uint64_t)(int64_t)(int32_t)(uint32_t)key;
 #pragma unroll
 							for (int w = 0; w < 8; ++w) lmv = (uint64_t)myRing.h[w] ^ ((lmv << 3) | (lmv >> 61));
+#elif defined(KAMD_CONGG)
+							const uint64_t hh = wordHash(key, myRing);
 #elif defined(KAMD_CONG)
 							// Hash<CoNgramState<0>> = Hash<uint32_t>(node) (src/CoNgramModel.hpp:505-541)
 							const uint64_t nv = (uint64_t)(uint32_t)key;
@@ -1147,18 +1386,43 @@ namespace sbgk
 #else
 							const uint64_t lmv = (uint64_t)(int64_t)(int32_t)(uint32_t)key;
 #endif
+#ifndef KAMD_CONGG
 							const uint64_t hh = (uint64_t)(((key >> 40) & 0xFF) | (((key >> 32) & 0xFF) << 8)) ^ ((lmv << 3) | (lmv >> 61));
+#endif
 							rep = (int)((hh >> 8) & 3) == b;
 						}
+#ifdef KAMD_CONGG
+						// a replayed container writes its own entries (below, where its first item lies)
+						if (anyBig && hi - lo > 64u && X.sscr->next[hi - 1] - (lo ? X.sscr->next[lo - 1] : 0u) >= 64u) rep = false;
+#endif
 					}
 					const uint64_t bal = X.ballot(rep);
 					// mode 1 runs exactly one candidate per batch, so the per-bucket rank is the container's per-bucket fill
 					const uint32_t rank = emittedInBucket + X.prefix(bal);
 					const bool keep = rep && (mode == 2 || X.P.topN > 1 || rank < (mode == 1 ? X.P.bucketCap : 128u));   // a full bucket drops later keys (BestPathContainer.hpp:363-367)
 					const uint64_t kbal = X.ballot(keep);
+					uint32_t extra = 0, blocks = 0;
+#ifdef KAMD_CONGG
+					for (; dk < nC && X.candQOff(dk) < qb + G; dk = nextReplayed(dk + 1))
+					{
+						// the entries of a replayed container, between the states of the items before its first item and of those after its last
+						const uint32_t lo = X.candQOff(dk), a = lo - qb, n = X.sscr->next[lo];
+						const uint32_t base = X.stTop + (uint32_t)__popcll(kbal & ((1ull << a) - 1ull)) + blocks;
+						for (uint32_t i = X.gl; i < n; i += G)
+						{
+							const uint32_t ew = X.sscr->hash[lo + i];
+							if (base + i < X.stCap)
+								emitState(dk, ew, big ? X.scratch->key[ew] : X.qKey()[ew], big ? X.scratch->score[ew] : X.qScore()[ew], big ? X.scratch->fcs[ew] : X.qFcs()[ew], base + i, false, 0.f,
+									big ? X.scratch->ctx[ew] : X.qCtx()[ew]);
+							else X.overflow = true;
+						}
+						if (X.gl >= a) extra += n;
+						blocks += n;
+					}
+#endif
 					if (keep)
 					{
-						const uint32_t pos = X.stTop + X.prefix(kbal);
+						const uint32_t pos = X.stTop + X.prefix(kbal) + extra;
 						if (pos < X.stCap)
 						{
 							const uint64_t wkey = big ? X.scratch->key[qw] : X.qKey()[qw];
@@ -1169,11 +1433,11 @@ namespace sbgk
 						}
 						else X.overflow = true;
 					}
-					X.stTop += __popcll(kbal);
+					X.stTop += __popcll(kbal) + blocks;
 					emittedInBucket += __popcll(bal);
 				}
 			}
-#ifdef KAMD_SBG
+#ifdef KAMD_HIST
 			if (hashed || listed)
 			{
 				// leave the table as it was found: every item frees the slot of its key
@@ -1229,6 +1493,7 @@ namespace sbgk
 					ns.leftFeat = ns.ownKind ? (uint16_t)((ns.leftFeat & (0x1FFF | LF_STR_SSC)) | (lfMorph & (LF_TAG_SSC | LF_PREV_ZSIOT))) : lfMorph;
 					ns.prevFlags = nm.prevFlags;
 					SBG_ONLY(storeRing(X.hist + 8ull * pos, loadRing(X.hist + 8ull * (E.pBeg + p), ns.pad0));)   // the LM state is handed on unchanged
+					CONGG_ONLY(storeRing(X.hist + 8ull * pos, loadRing(X.hist + 8ull * (E.pBeg + p), 0u));)
 					putState<G>(X, pos, ns.lmNode, ns.accScore, ns.accTypoCost, ns.wid, ns.leftFeat, ns.rootId, ns.spState, ns.socket, ns.prevFlags, ns.ownKind,
 						ns.parent, ns.morph, ns.firstChunkScore, ns.nodeId, ns.ownNode STATE_EXTRA(, ns.pad0));
 					stageState<G>(X, pos - E.nodeStart, ns.accScore, ns.rootId, newMorphSocket, ns.socket != 0);
@@ -1286,7 +1551,88 @@ namespace sbgk
 					nReg += __popcll(bal);
 				}
 			}
+#ifdef KAMD_CONGG
+			// Global model: the (path x candidate) matrix is scored by progressMatrixWOSort when it has at most 16 paths and 16 candidates (src/CoNgramModel.cpp:
+			// 1470-1480): m = paths + EVERY non-empty history slot of theirs, n = candidates; by progressMatrixWSort otherwise: m = unique contexts + unique
+			// history words, n = unique first words.  One path and one candidate: state.next().  (What decides is whether n == 1 and m >= 4, m != 8.)
+			X.matrix = false;
+			{
+				uint32_t nPrevReg = 0, slots = 0;
+				for (uint32_t pb = 0; pb < E.nP; pb += G)
+				{
+					const uint32_t p = pb + X.gl;
+					bool live = false; uint32_t ns = 0;
+					if (p < E.nP)
+					{
+						const Hot h = getHot<G>(X, E.pBeg + p);
+						live = !h.dead() && !h.socket();
+						if (live) { const Ring r = loadRing(X.hist + 8ull * (E.pBeg + p), 0u); for (uint32_t k = 0; k < congg::WINDOW; ++k) ns += r.h[k] ? 1u : 0u; }
+					}
+					nPrevReg += (uint32_t)__popcll(X.ballot(live));
+					for (int d = G / 2; d; d >>= 1) ns += __shfl_xor(ns, d, G);
+					slots += ns;
+				}
+				X.matrix = nReg && nPrevReg && !(nPrevReg == 1 && nReg == 1);
+				if (X.matrix && nPrevReg <= 16 && nReg <= 16)
+				{
+					const uint32_t m = nPrevReg + slots;
+					X.outFirst = nReg == 1 && m >= 4 && m != 8;
+				}
+				else if (X.matrix && oneWid)
+				{
+					// unique contexts + unique history words of the live socket-free paths, through the (free) key table of the item scratch: a slot is claimed
+					// per distinct value (contexts and words are numbered apart), the claims counted, the slots freed again
+					constexpr uint32_t TM = 2 * BIGQ_SBG - 1;
+					uint32_t m = 0, maxProbe = 0;      // (maxProbe: the longest probe sequence of the claims; the freeing pass walks that far past freed slots)
+					for (int pass = 0; pass < 2; ++pass)      // pass 0: claim and count; pass 1: free
+					{
+						for (uint32_t pb = 0; pb < E.nP; pb += G)
+						{
+							const uint32_t p = pb + X.gl;
+							uint32_t mine = 0;
+							if (p < E.nP)
+							{
+								const Hot h = getHot<G>(X, E.pBeg + p);
+								if (!h.dead() && !h.socket())
+								{
+									const Ring r = loadRing(X.hist + 8ull * (E.pBeg + p), 0u);
+									for (uint32_t k = 0; k <= congg::WINDOW; ++k)
+									{
+										// k < 7: history word k (0 = empty); k == 7: the path's context id
+										const uint32_t v = k < congg::WINDOW ? r.h[k] : X.st[E.pBeg + p].pad0;
+										if (k < congg::WINDOW && !v) continue;
+										const uint32_t tagged = (v << 1 | (k < congg::WINDOW ? 1u : 0u)) + 1u;
+										uint32_t probes = 0;
+										for (uint32_t hsh = (tagged * 0x9E3779B1u) >> 7 & TM; ; hsh = (hsh + 1) & TM, ++probes)
+										{
+											SbgSlot* e = &X.sscr->table[hsh];
+											if (pass == 0)
+											{
+												const uint32_t o = atomicCAS(&e->owner, 0u, tagged);
+												if (o == 0) { ++mine; break; }
+												if (o == tagged) break;
+											}
+											else
+											{
+												if (atomicCAS(&e->owner, tagged, 0u) == tagged || probes >= maxProbe) break;      // (another path's lane may have freed the value's slot already)
+											}
+										}
+										if (pass == 0) maxProbe = probes > maxProbe ? probes : maxProbe;
+									}
+								}
+							}
+							if (pass == 0) { for (int d = G / 2; d; d >>= 1) mine += __shfl_xor(mine, d, G); m += mine; }
+						}
+						if (pass == 0) for (int d = G / 2; d; d >>= 1) { const uint32_t o = __shfl_xor(maxProbe, d, G); maxProbe = o > maxProbe ? o : maxProbe; }
+						waveSync();
+					}
+					X.outFirst = m >= 4 && m != 8;
+				}
+			}
+			if (false)
+#else
 			if (nReg && oneWid && E.nP >= 4)
+#endif
 			{
 				uint32_t m = 0;
 				for (uint32_t pb = 0; pb < E.nP; pb += G)
@@ -1755,7 +2101,10 @@ namespace sbgk
 					if (!openEnding)
 					{
 						int32_t ln = ps.lmNode;
-#ifdef KAMD_CONG
+#if defined(KAMD_CONGG)
+						uint32_t ectx = ps.pad0;
+						{ Ring er = loadRing(X.hist + 8ull * (pBeg + p), 0u); first = congStepG(M, *X.CG, *X.GG, ln, ectx, er, 1u, false, false); }      // state.next(eos)
+#elif defined(KAMD_CONG)
 						uint32_t ectx = ps.pad0;
 						first = congStep(M, *X.CG, ln, ectx, 1u, false);
 #else
@@ -1919,6 +2268,7 @@ namespace sbgk
 		X.str = B.chars + cOff; X.cls = B.cls + cOff;
 		X.st = W.states + W.stateBase[chunk]; X.stCap = (uint32_t)(W.stateBase[chunk + 1] - W.stateBase[chunk]); X.stTop = 0;
 		SBG_ONLY(X.hist = X.S->hist + 8ull * W.stateBase[chunk];)
+		CONGG_ONLY(X.hist = X.GG->hist + 8ull * W.stateBase[chunk];)
 		TYPO_ONLY(X.nodeTypo = X.typoAll + nBase;)
 		X.nodeStOff = W.nodeStateOff + nBase; X.nodeStCnt = W.nodeStateCnt + nBase; X.nodeLive = W.tmpIdx + 2ull * nBase;
 		X.uniq = B.spStates + B.spOff[chunk]; X.nUniq = B.spOff[chunk + 1] - B.spOff[chunk];
@@ -1962,7 +2312,7 @@ namespace sbgk
 		{
 			const MorphRec m0 = M.morphs[0];
 			putState<G>(X, 0, M.h.bosNode, 0.f, 0.f, 0, m0.feat, COMMON_ROOT, 0, 0, m0.prevFlags, 0, 0xFFFFFFFFu, 0, 0.f, 0, 0);
-			SBG_ONLY({ const Ring z{}; storeRing(X.hist, z); })   // SbgState(): empty ring, position 0
+			HIST_ONLY({ const Ring z{}; storeRing(X.hist, z); })   // SbgState() / CoNgramState(): empty history, position 0
 			X.nodeStOff[0] = 0; X.nodeStCnt[0] = 1; X.nodeLive[0] = 1;
 			X.ringBeg()[0] = 0; X.ringEnd()[0] = 1; X.ringCum()[0] = 1;
 		}
@@ -2166,6 +2516,7 @@ namespace sbgk
 			GroupCtx<G> Y(X, Mc, Pc);
 			SBG_ONLY(const SbgDev Sc = *X.S; Y.S = &Sc;)
 			CONG_ONLY(const CongDev Cc = *X.CG; Y.CG = &Cc;)
+			CONGG_ONLY(const CongGDev Gc = *X.GG; Y.GG = &Gc;)
 			finishChunk<G>(Y, chunk, openEnding, res);
 		}
 #ifdef KAMD_TIMELINE
@@ -2179,7 +2530,7 @@ namespace sbgk
 	// WPS = waves per SIMD the kernel is compiled for (register budget 512 / WPS): 2 is fastest when a batch is small enough
 	// to be latency-bound (c2: 8192 chunks), 3 (with a few spills) when there are chunks to fill the extra wave slots
 	template<int G, int WPS>
-	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S) TYPO_ONLY(, const float* nodeTypoAll) CONG_ONLY(, CongDev CGv))
+	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S) TYPO_ONLY(, const float* nodeTypoAll) CONG_ONLY(, CongDev CGv) CONGG_ONLY(, CongGDev GGv))
 	{
 		constexpr int NG = 64 / G;
 		if (W.posHandOver && *W.posHandOver == 0) return;      // the position-step kernel ran before and left nothing to do
@@ -2204,6 +2555,7 @@ namespace sbgk
 		X.scratch = reinterpret_cast<GroupScratch*>(W.bigScratch) + ((size_t)blockIdx.x * NG + gid);
 		X.tl = nullptr;
 		SBG_ONLY(X.S = &S; X.hist = nullptr; X.sscr = reinterpret_cast<SbgScratch*>(S.itemScratch) + ((size_t)blockIdx.x * NG + gid);)
+		CONGG_ONLY(X.GG = &GGv; X.matrix = false; X.hist = nullptr; X.sscr = reinterpret_cast<SbgScratch*>(GGv.itemScratch) + ((size_t)blockIdx.x * NG + gid);)
 		TYPO_ONLY(X.typoAll = nodeTypoAll; X.nodeTypo = nullptr;)
 		CONG_ONLY(X.CG = &CGv; X.outFirst = false;)
 
@@ -2217,7 +2569,18 @@ namespace sbgk
 		}
 	}
 
-#if defined(KAMD_TYPO) && defined(KAMD_CONG)
+#if defined(KAMD_TYPO) && defined(KAMD_CONGG)
+	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev, CongGDev);
+	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev, CongGDev);
+}
+}
+}
+#elif defined(KAMD_CONGG)
+	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev, CongGDev);
+	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, CongDev, CongGDev);
+}
+}
+#elif defined(KAMD_TYPO) && defined(KAMD_CONG)
 	template __global__ void k_best_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev);
 	template __global__ void k_best_path<64, 2>(ModelView, BatchView, WorkView, SearchParams, uint32_t*, const uint32_t*, uint32_t, const float*, CongDev);
 	template __global__ void k_pos_path<16, 2>(ModelView, BatchView, WorkView, SearchParams, const uint32_t*, uint32_t, const float*, CongDev);

@@ -71,6 +71,18 @@ namespace kamd
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, const float* nodeTypo, CongDev CG);
 	} }
+	// ... and for the GLOBAL CoNgram model (viterbi_kernel_congg.hip / _congg_typo.hip: KAMD_CONG + KAMD_CONGG [+ KAMD_TYPO]): GG names the window sections and the
+	// history storage of the search (device_types.hpp CongGDev).  G = 16 or 64, WPS = 2; the general search only
+	namespace congk { namespace gk
+	{
+		template<int G, int WPS>
+		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, CongDev CG, CongGDev GG);
+	} }
+	namespace typok { namespace congk { namespace gk
+	{
+		template<int G, int WPS>
+		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, const float* nodeTypo, CongDev CG, CongGDev GG);
+	} } }
 	// ... and for typo correction with a SkipBigram model (viterbi_kernel_sbg_typo.hip, KAMD_TYPO + KAMD_SBG)
 	namespace typok { namespace sbgk
 	{

@@ -24,6 +24,9 @@ WORKLOADS = {
     # BASELINE config 4's model type and length distribution on one GPU: CoNgram model (local, 8-bit, dim 64), sentence lengths log-normal
     # (median 60 jamo, sigma 0.6, clipped to 5..400); 131072 sentences = one GPU's share of the 1M-sentence corpus on 8 GPUs
     "c4-cong": ("full-cong", 131072, dict(min_jamo=5, max_jamo=400, lognormal=(60, 0.6)), 4),
+    # ... and the reference's largest model type on the same lexicon and length distribution: CoNgram global (window 7: valid distant tokens are scored as a mixture over
+    # the context and the last seven such tokens of the path; kiwi_init's LARGEST / CONG_GLOBAL); the first 32768 sentences of the c4 corpus
+    "c4-cong-global": ("full-cong-global", 32768, dict(min_jamo=5, max_jamo=400, lognormal=(60, 0.6)), 4),
     "small-cong-c2": ("small-cong", 8192, dict(exact_jamo=40), 2),
     # c2 at the batch size the north-star throughput target is quoted on (>= 64k sentences): the throughput regime
     "c2-64k": ("full", 65536, dict(exact_jamo=40), 12),
@@ -93,8 +96,10 @@ def workload_typo(name: str):
 
 
 def _spec(name):
+    from dataclasses import replace
     from .synth import FULL_CONG_SPEC, FULL_SBG_SPEC, FULL_SPEC, SMALL_CONG_SPEC, SMALL_SPEC
-    return {"full": FULL_SPEC, "full-sbg": FULL_SBG_SPEC, "small": SMALL_SPEC, "full-cong": FULL_CONG_SPEC, "small-cong": SMALL_CONG_SPEC}[name]
+    return {"full": FULL_SPEC, "full-sbg": FULL_SBG_SPEC, "small": SMALL_SPEC, "full-cong": FULL_CONG_SPEC, "small-cong": SMALL_CONG_SPEC,
+            "full-cong-global": replace(FULL_CONG_SPEC, cong_window=7)}[name]
 
 
 # morphemes that the reference's shipped default.dict / typo.dict refer to as "original" morphemes (pre-analysed entries, allomorph definitions) beyond
@@ -168,10 +173,16 @@ def get_workload(name: str):
     with open(corpus_path, encoding="utf-8") as f:
         texts = f.read().split("\n")
     assert len(texts) == n, (len(texts), n)
-    lm = "Knlm + SkipBigram, top-3" if spec_name.endswith("-sbg") else "CoNgram (local, 8-bit), top-1" if spec_name.endswith("-cong") else "Knlm, top-1"
+    lm = ("Knlm + SkipBigram, top-3" if spec_name.endswith("-sbg") else "CoNgram (local, 8-bit), top-1" if spec_name.endswith("-cong")
+          else "CoNgram global (window 7, 8-bit), top-1" if spec_name.endswith("-cong-global") else "Knlm, top-1")
     desc = f"{name}: {n} synthetic sentences ({kw}), synthetic '{spec_name}' model (kiwi_amd/synth.py), {lm}"
     return model_path, texts, desc
 
 
 def workload_top_n(name: str) -> int:
     return 3 if WORKLOADS[name][0].endswith("-sbg") else 1
+
+
+def workload_lm_mode(name: str) -> int:
+    """kamd_open_mode's lm_mode for the workload's engine: 4 = CoNgram global (asked for explicitly, as kiwi_init's CONG_GLOBAL / LARGEST do), else 0 (the container's own)."""
+    return 4 if WORKLOADS[name][0].endswith("-cong-global") else 0

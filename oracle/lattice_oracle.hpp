@@ -42,6 +42,7 @@ namespace korc
 		// probes; congDim = the embedding dimension (0: not a CoNgram model)
 		uint64_t congCtxRows = 0, congOutRows = 0, congScores = 0, congProbes = 0, congProbeKeyBytes = 0, congRootProbes = 0, congDim = 0;
 		uint64_t congGlobalScores = 0;      // of congScores: mixtures over the history window (global model, valid distant tokens)
+		uint64_t congPast64 = 0;            // global model: insertions into a path container that already holds 64 entries (the reference's SIMD lookup misbehaves there)
 	};
 
 	struct SplitConfig { uint64_t match; uint32_t maxUnk, maxUnkJ, spaceTol; };

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 COUNTER_NAMES = ["inputUnits", "trieProbes", "trieProbeKeyBytes", "failHops", "candEmits", "otherNodes",
                  "transitions", "candMorphs", "statesWritten", "lmProbes", "lmProbeKeyBytes", "lmRootProbes", "tokens",
                  "maxPrevPaths", "nodesOver128", "nodesOver512", "lattNodes", "sbgEvals", "sbgProbeKeyBytes", "sbgHits", "sbgModel",
-                 "congCtxRows", "congOutRows", "congScores", "congProbes", "congProbeKeyBytes", "congRootProbes", "congDim", "congGlobalScores"]
+                 "congCtxRows", "congOutRows", "congScores", "congProbes", "congProbeKeyBytes", "congRootProbes", "congDim", "congGlobalScores", "congPast64"]
 
 
 def available() -> bool:
@@ -238,7 +238,8 @@ def alg_bytes(c: dict) -> dict:
     Returns the split used by bench.py: dictionary scan + lattice build ('lattice') and best-path search ('search')."""
     lattice = (2 * c["inputUnits"] + c["trieProbes"] * (12 + 4) + c["trieProbeKeyBytes"] + c["failHops"] * 8
                + c["candEmits"] * (16 + 24) + c["otherNodes"] * 24)
-    state = 48 if c.get("sbgModel") else 32     # S: the SkipBigram state carries the 8-word history ring (SURVEY.md section 8(d))
+    # S: the SkipBigram state carries the 8-word history ring (SURVEY.md section 8(d)); so does the state of the global CoNgram model (7 words + a spare)
+    state = 48 if (c.get("sbgModel") or c.get("congGlobalScores")) else 32
     search = (c["transitions"] * state + c["candMorphs"] * 16 + c["statesWritten"] * state
               + c["lmProbes"] * (20 + 4) + c["lmProbeKeyBytes"] + c["lmRootProbes"] * 4 + c["tokens"] * 24
               # "SBG extra": per evaluate() 8 B row pointers + 8 discounts + the key bytes of 8 partner searches + 4 B per hit
@@ -247,6 +248,9 @@ def alg_bytes(c: dict) -> dict:
     if dim:     # "CoNgram": unique context rows dim + 16 B, unique output rows dim + 8 B, 4 B per score, context-trie probe = Knlm probe with a 16-byte node
         search += (c["congCtxRows"] * (dim + 16) + c["congOutRows"] * (dim + 8) + c["congScores"] * 4
                    + c["congProbes"] * (16 + 4) + c["congProbeKeyBytes"] + c["congRootProbes"] * 4)
+        # "CoNgram global extra" (DESIGN.md, round 5): a mixture reads the distant rows of the seven history words (dim + 8 B each, as an output row) and the
+        # eight position confidences, on top of the context / output rows counted above
+        search += c.get("congGlobalScores", 0) * (7 * (dim + 8) + 8 * 4)
     return {"lattice": lattice, "search": search, "total": lattice + search}
 
 

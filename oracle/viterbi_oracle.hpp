@@ -465,6 +465,7 @@ namespace korc
 				//     entry of the FIRST half -- and on success entry 64 + j is the one that is compared by score and overwritten (:341-350).
 				auto& hb = bucketHash[mode == 1 ? ((h >> 8) & 3) : 0];
 				const size_t n2 = b.size() - 64;
+				cnt.congPast64++;
 				if (n2 < 64)
 					for (size_t bj = 0; bj < n2; ++bj)
 					{

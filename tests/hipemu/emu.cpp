@@ -45,7 +45,8 @@ namespace kamd
 	alignas(16) uint8_t tSmem[160 * 1024];      // typo_lattice_kernel.hip
 	namespace sbgk { alignas(16) uint8_t kSmem[160 * 1024]; }
 	namespace typok { alignas(16) uint8_t kSmem[160 * 1024]; namespace congk { alignas(16) uint8_t kSmem[160 * 1024]; } namespace sbgk { alignas(16) uint8_t kSmem[160 * 1024]; } }
-	namespace congk { alignas(16) uint8_t kSmem[160 * 1024]; }
+	namespace congk { alignas(16) uint8_t kSmem[160 * 1024]; namespace gk { alignas(16) uint8_t kSmem[160 * 1024]; } }
+	namespace typok { namespace congk { namespace gk { alignas(16) uint8_t kSmem[160 * 1024]; } } }
 }
 
 namespace hipemu
@@ -187,7 +188,7 @@ namespace hipemu
 		while (stacks.size() < block.x) stacks.push_back((char*)std::malloc(STACK));
 #ifdef HIPEMU_ASAN
 		// dynamic LDS beyond what the launch asked for does not exist
-		for (uint8_t* a : { kamd::lSmem, kamd::kSmem, kamd::tSmem, kamd::sbgk::kSmem, kamd::typok::kSmem, kamd::congk::kSmem, kamd::typok::congk::kSmem, kamd::typok::sbgk::kSmem })
+		for (uint8_t* a : { kamd::lSmem, kamd::kSmem, kamd::tSmem, kamd::sbgk::kSmem, kamd::typok::kSmem, kamd::congk::kSmem, kamd::typok::congk::kSmem, kamd::typok::sbgk::kSmem, kamd::congk::gk::kSmem, kamd::typok::congk::gk::kSmem })
 		{
 			__asan_unpoison_memory_region(a, 160 * 1024);
 			__asan_poison_memory_region(a + ((ldsBytes + 7) & ~(size_t)7), 160 * 1024 - ((ldsBytes + 7) & ~(size_t)7));

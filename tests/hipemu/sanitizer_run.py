@@ -20,6 +20,27 @@ path = os.path.join(ROOT, "_data", "small-sbg.raw" if kind in ("sbg", "sbgtypo")
 if not os.path.exists(path):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     sm.raw.save(path)
+if kind == "congg":
+    # the global CoNgram model (viterbi_kernel_congg.hip, viterbi_kernel_congg_typo.hip): sentences long enough for containers past 64 entries (the replay),
+    # top-1 and top-2, and the typo-correcting analysis
+    import random
+    from kiwi_amd.api import Typo
+    from kiwi_amd.synth import SMALL_CONG_GLOBAL_SPEC
+    from typo_cases import misspell
+    sm = SynthModel(SMALL_CONG_GLOBAL_SPEC)
+    path = os.path.join(ROOT, "_data", "small-cong-global32.raw")
+    sm.raw.save(path)
+    dev = KiwiAmd(path, lib_path=lib, lm_mode=4)
+    texts = synthetic(sm, 8, 941, min_jamo=60, max_jamo=140) + dictionary_mix(sm, 3, 942)
+    for top_n in (1, 2):
+        assert len(dev.analyze_batch(texts, top_n=top_n).to_python()) == len(texts)
+    ty = Typo.from_default(dev.lib, 3).prepare(True)
+    rnd = random.Random(7)
+    tt = [misspell(t, rnd, True, True) for t in synthetic(sm, 4, 943, min_jamo=10, max_jamo=40)]
+    assert len(dev.analyze_batch_opt(tt, typo=ty, typo_threshold=2.5).to_python()) == len(tt)
+    dev.close()
+    print("sanitizer run complete:", kind, len(texts), "texts")
+    sys.exit(0)
 dev = KiwiAmd(path, lib_path=lib)
 if kind == "chr":
     # Match::oovChrModel on a CoNgram model: k_unk_chr, the CoNgram search reading its scores -- plain and with a typo transformer (k_typo_graph,

@@ -6,9 +6,12 @@ where the reference library is absent.  32-bit and 16-bit ids: the reference's s
 
 What the pin found in the reference and the oracle reproduces (without it 1 sentence in ~400 differs): once a bucket of the path container holds 64
 entries, nst::findAll<sse4_1> returns nothing for its first half (a shift count of 64), and candidates of the second half are compared with the entry of
-the FIRST half at the same offset (BestPathContainer.hpp:341-350).  The device path for this model type is not built: kiwi_init refuses CONG_GLOBAL.  Its first
-piece is: kamd_debug_cong_global evaluates the same header on the device over the window sections in HBM (lane emulator here; `-m gpu`:
-tests/test_zzz_gpu_cong_global_probe.py on the MI355X)."""
+the FIRST half at the same offset (BestPathContainer.hpp:341-350).
+
+Device side (round 5: viterbi_kernel_congg.hip / viterbi_kernel_congg_typo.hip, kamd_open_mode(lm_mode = 4), kiwi_init with CONG_GLOBAL or LARGEST): the whole
+analysis through the lane emulator here -- golden analyses of the real reference (top-1, top-3, open ending, typo correction), random sentences against the
+oracle, the replay of the container past 64 entries --, and on the MI355X by tests/test_gpu_cong_global.py with the same checkers.  kamd_debug_cong_global
+evaluates the mixture arithmetic alone on the device over the window sections in HBM (tests/test_zzz_gpu_cong_global_probe.py)."""
 import json
 import os
 import struct
@@ -201,3 +204,81 @@ def test_emulated_device_arithmetic_equals_the_oracle():
     subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
     assert probe_device_arithmetic(os.path.join(emu, "_build", "libkiwi_hipemu.so")) == 24000
 
+
+
+def check_device_goldens(lib_path, which, sections=("top1", "top3", "open_ending", "typo"), limit=None):
+    """The device (lib_path: the emulated library; None: the product library on a GPU) with the global model against the golden analyses of the real reference
+    (tests/golden/cong_global_*.json; item 0 of the 32-bit file is the sentence that needs the container replay).  Returns the number of analyses compared."""
+    from kiwi_amd.api import KiwiAmd, Typo
+    _, path = _model(which)
+    g = json.load(open(os.path.join(HERE, "golden", f"cong_global_{which}.json"), encoding="utf-8"))
+    dev = KiwiAmd(path, lib_path=lib_path, lm_mode=4) if lib_path else KiwiAmd(path, lm_mode=4)
+    n = 0
+    for sec in sections:
+        items = g[sec][:limit]
+        texts = [it["text"] for it in items]
+        if sec == "typo":
+            ty = Typo.from_default(dev.lib, 3).prepare(True)      # basicTypoSetWithContinual, as tools/make_golden_cong_global.py asked the reference for
+            got = dev.analyze_batch_opt(texts, typo=ty, typo_threshold=2.5).to_python()
+            ty.close()
+        else:
+            got = dev.analyze_batch(texts, top_n=3 if sec == "top3" else 1, open_ending=sec == "open_ending").to_python()
+        for it, y in zip(items, got):
+            assert _rows(y) == it["res"], (which, sec, it["text"])
+        n += len(items)
+    dev.close()
+    return n
+
+
+def check_device_vs_oracle(lib_path, which, n_random, n_top3, max_jamo=140, seed=941, extra=()):
+    """Random sentences: device == oracle (top-1 on all, top-3 on the first n_top3).  The corpus must reach the container replay many times (the oracle counts
+    the insertions past 64 entries).  Returns (sentences, insertions past 64 entries)."""
+    import sys
+    sys.path.insert(0, HERE)
+    from corpora import dictionary_mix, synthetic
+    from kiwi_amd.api import KiwiAmd
+    sm, path = _model(which)
+    orc = _oracle(path)
+    dev = KiwiAmd(path, lib_path=lib_path, lm_mode=4) if lib_path else KiwiAmd(path, lm_mode=4)
+    texts = [t for t in synthetic(sm, n_random, seed, min_jamo=5, max_jamo=max_jamo) + dictionary_mix(sm, n_random // 4, seed + 1) + list(extra) if t.strip()]
+    orc.counters(reset=True)
+    got = dev.analyze_batch(texts).to_python()
+    for s, y in zip(texts, got):
+        assert _rows(orc.analyze(s)) == _rows(y), (which, s)
+    c = orc.counters()
+    assert c["congGlobalScores"] > 0
+    got = dev.analyze_batch(texts[:n_top3], top_n=3).to_python()
+    for s, y in zip(texts[:n_top3], got):
+        assert _rows(orc.analyze(s, top_n=3)) == _rows(y), (which, s)
+    dev.close()
+    return len(texts), c["congPast64"]
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    import subprocess
+    emu = os.path.join(HERE, "hipemu")
+    subprocess.check_call(["make", "-C", emu, "-j8"], stdout=subprocess.DEVNULL)
+    return os.path.join(emu, "_build", "libkiwi_hipemu.so")
+
+
+@pytest.mark.parametrize("which,lanes", [("32", "64"), ("16", "16")])
+def test_emulated_device_equals_the_golden_analyses_of_the_reference(emu_lib, monkeypatch, which, lanes):
+    """viterbi_kernel_congg.hip (+ _typo) compiled for the host: every golden analysis of the real reference's global model, 64-lane and 16-lane groups."""
+    monkeypatch.setenv("KAMD_GROUP_LANES", lanes)
+    assert check_device_goldens(emu_lib, which) == 271
+
+
+def test_emulated_device_equals_the_oracle_on_random_sentences(emu_lib, monkeypatch):
+    monkeypatch.setenv("KAMD_GROUP_LANES", "16")
+    n, past64 = check_device_vs_oracle(emu_lib, "32", 60, 12)
+    assert n >= 70 and past64 > 1000, (n, past64)
+
+
+def test_emulated_device_with_small_capacities(monkeypatch):
+    """The `make smallcaps` configuration (tiny LDS staging capacities, constant history digest: every equal-key pair reaches the exact comparison of the
+    history words) on the first golden sentences -- the one that needs the container replay among them."""
+    import subprocess
+    emu = os.path.join(HERE, "hipemu")
+    subprocess.check_call(["make", "-C", emu, "smallcaps", "-j8"], stdout=subprocess.DEVNULL)
+    assert check_device_goldens(os.path.join(emu, "_build", "libkiwi_hipemu_smallcaps.so"), "32", sections=("top1", "top3", "typo"), limit=24) == 72

@@ -267,7 +267,7 @@ def test_emulated_c_api_suite(emu_libs, devices):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("kind", ["knlm-tiny-arenas", "sbg", "typo", "chr", "sbgtypo"])
+@pytest.mark.parametrize("kind", ["knlm-tiny-arenas", "sbg", "typo", "chr", "sbgtypo", "congg"])
 def test_emulated_kernels_under_address_and_ub_sanitizers(kind):
     """The emulated kernels compiled with AddressSanitizer + UndefinedBehaviorSanitizer (`make -C tests/hipemu asan`): an access
     outside an HBM buffer or beyond the dynamic LDS a launch asked for -- which a GPU executes silently -- ends the run.  Knlm with
@@ -281,11 +281,11 @@ def test_emulated_kernels_under_address_and_ub_sanitizers(kind):
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     if kind == "sbg":
         env["KAMD_EXPERIMENTAL_SBG"] = "1"
-    elif kind not in ("chr", "sbgtypo"):
+    elif kind not in ("chr", "sbgtypo", "congg"):
         env["KAMD_TEST_TINY_ARENAS"] = "1"
     if kind == "typo":
         env["KAMD_EXPERIMENTAL_TYPO"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(EMU, "sanitizer_run.py"), os.path.join(EMU, "_build", "libkiwi_hipemu_asan.so"), kind if kind in ("sbg", "typo", "chr", "sbgtypo") else "knlm"],
+    r = subprocess.run([sys.executable, os.path.join(EMU, "sanitizer_run.py"), os.path.join(EMU, "_build", "libkiwi_hipemu_asan.so"), kind if kind in ("sbg", "typo", "chr", "sbgtypo", "congg") else "knlm"],
                        env=env, capture_output=True, text=True)
     assert r.returncode == 0 and "sanitizer run complete" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr.replace("WARNING: ASan doesn't fully support makecontext/swapcontext", ""), r.stderr[-3000:]
