@@ -69,6 +69,10 @@ int kamd_batch_info(kamd_batch_h b, uint64_t* info3);
    larger capacities before it returns.  Returns how many chunks of the last kamd_run that were (< 0: error); *ms_out (optional) = the wall
    time of those extra passes, which kamd_run's ms_out[4] (first pass only) does not contain */
 int kamd_batch_reruns(kamd_batch_h b, float* ms_out);
+/* State arenas of the staged batch: a chunk's arena holds what the typical chunk needs; one that fills its arena carries on in an arena twice as large taken from the
+   batch's pool (append-only, one atomic add per growth; the first pass only -- chunks the pool cannot serve are re-run as above).
+   out[0] = states in the chunks' own arenas, [1] = states of the pool, [2] = states of the pool asked for by the last fetched run (> [1]: the pool ran out) */
+int kamd_batch_pool(kamd_batch_h b, uint64_t* out3);
 void kamd_batch_close(kamd_batch_h b);
 
 uint32_t kamd_res_texts(kamd_results_h r);

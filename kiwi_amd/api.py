@@ -198,6 +198,13 @@ class Batch:
         self.lib.kamd_batch_info(self.h, a.ctypes.data)
         return {"chunks": int(a[0]), "units": int(a[1]), "device_bytes": int(a[2])}
 
+    def pool(self):
+        """kamd_batch_pool: states in the chunks' own arenas, in the pool behind them, and what the last fetched run asked the pool for."""
+        a = np.zeros(3, np.uint64)
+        self.lib.kamd_batch_pool.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.kamd_batch_pool(self.h, a.ctypes.data)
+        return {"arena_states": int(a[0]), "pool_states": int(a[1]), "pool_asked": int(a[2])}
+
     def close(self):
         if self.h:
             self.lib.kamd_batch_close(self.h)

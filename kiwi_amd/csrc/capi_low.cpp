@@ -131,6 +131,12 @@ extern "C"
 		if (!b) return -2;
 		return (int)Engine::rerunChunks(*b->b, ms);
 	}
+	int kamd_batch_pool(kamd_batch_h b, uint64_t* out3)
+	{
+		if (!b) return -2;
+		Engine::stagedPool(*b->b, out3);
+		return 0;
+	}
 	void kamd_batch_close(kamd_batch_h b) { delete b; }
 
 	uint32_t kamd_res_texts(kamd_results_h r) { return r ? (uint32_t)r->r.nTexts : 0; }

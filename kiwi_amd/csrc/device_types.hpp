@@ -170,6 +170,17 @@ namespace kamd
 		uint32_t* nNodes;              // [c]
 		const uint64_t* stateBase;     // [nChunks+1]
 		DevState* states;
+		// A chunk whose arena fills up carries on in one twice as large from the batch's pool -- the states [poolBase, poolBase + poolCap) behind the chunks' own arenas,
+		// handed out append-only through one counter -- so that the arenas are sized for the typical chunk, not for the worst one.  stateAt[c] = where chunk c's
+		// states lie now (stateBase[c] until it grows); state indices are arena-relative.  poolTop null: no pool (the arenas hold the worst case or the chunk is re-run).
+		// slotCap != 0 (models whose states carry histories: SkipBigram, global CoNgram): the arenas belong to the search kernel's lane groups, not to the chunks --
+		// group g of block b searches every chunk it takes in states [(b * groups + g) * slotCap, + slotCap), and runs the chunk's end stage itself (finishPathsSolo)
+		// before it takes the next chunk: the batch's state memory is what the chunks IN FLIGHT need, whatever the batch size
+		uint32_t slotCap;
+		uint64_t* slotTable;           // [2 * slots], zeroed before a run: a group that grew keeps the larger arena for its later chunks -- {first state, capacity}, capacity 0 = its own arena
+		uint64_t* stateAt;             // [nChunks]
+		unsigned long long* poolTop;   // states of the pool handed out so far
+		uint64_t poolBase, poolCap;
 		uint32_t* nodeStateOff;        // per node (same offsets as nodes): chunk-relative first state
 		uint32_t* nodeStateCnt;
 		uint8_t* reach;                // per node: the reference's `reachable` flags (PathEvaluator.hpp:1159-1176, 1286)

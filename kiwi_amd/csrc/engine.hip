@@ -200,6 +200,8 @@ namespace kamd
 		struct LatClass { uint32_t i, j, need, stream; };
 		std::vector<std::vector<LatClass>> latClasses; std::vector<uint32_t> latSkip; uint32_t latClassesKey = 0xFFFFFFFFu;
 		DevBuf dHist;   // SkipBigram models: history ring of every search state (8 x u32), parallel to dStates
+		uint32_t slotCap = 0; uint64_t ownStates = 0;   // slotCap != 0: the arenas are the search kernel's lane groups' (WorkView::slotCap); ownStates: states in the chunks' / groups' own arenas
+		DevBuf dStateAt, dSlotTable; uint64_t poolStates = 0, poolUsed = 0;   // where each chunk's arena lies now; the pool behind the arenas (WorkView::poolTop) and what the last run took of it
 		// typo correction: the transformer the batch is analysed with, the typo graph of every chunk and the
 		// working arrays of k_build_lattice_typo, the typo cost of every lattice node beside dNodes
 		TypoOption typo;
@@ -252,7 +254,12 @@ namespace kamd
 		// state arenas: sixteenths of the worst-case capacity (48 states per text unit + 256; SkipBigram models x 8) a chunk's region gets.  Follows what the
 		// chunks of the batches so far needed (x 2, read from the downloaded per-chunk results); a batch in which a chunk ran out goes back to the full
 		// capacity (the capacity ladder inside run() has searched that chunk again meanwhile).  KAMD_STATE_SCALE=<sixteenths> fixes it
-		uint32_t stateScale16[2] = { 16, 16 }; bool stateScaleForced = false;      // [needed by top-1 batches, by top-N batches (0: none seen yet)]; a region gets the larger of the two (a batch is laid out before its top-N is known)
+		// State arenas: a chunk gets stateScale64 / 64 of its worst-case capacity -- what 90 % of the chunks of the batches so far needed (SkipBigram / global CoNgram;
+		// otherwise twice what 99.9 % needed) -- and one that needs more grows
+		// into the batch's pool (WorkView::poolTop: twice the size each time, append-only); the pool holds poolFrac64 / 64 of the arenas' total, twice what the last batch took.
+		// [needed by top-1 batches, by top-N batches]; a region gets the larger of the two (a batch is laid out before its top-N is known)
+		uint32_t stateScale64[2] = { 0, 0 }; bool stateScaleForced = false;      // (0: no batch of that kind seen yet -- the other kind's scale serves, the pool covers the difference; neither: the whole worst case)
+		uint32_t poolFrac64 = 64; bool poolForced = false;
 		uint32_t latticeLdsBudget = 64 * 1024;   // dynamic LDS one lattice-build wave may ask for (KAMD_LATTICE_LDS; 0 = HBM kernel only)
 		uint32_t latticeWaveBudget = 128 * 1024; // ... and k_lattice_wave, which is allowed beyond the default 64 KB limit (a 400-unit chunk needs ~70 KB; the CU has 160 KB)
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
@@ -267,6 +274,9 @@ namespace kamd
 		CongDev cong{}; bool hasCong = false;   // CoNgram model: the context trie is uploaded where the Knlm tables would be (ModelView::lmHash / lmRoot2 / lmBackoff)
 		CongGDev congG{}; bool hasCongG = false;   // global CoNgram model (LmMode::CongGlobal): the window sections on the device; its search shares the SkipBigram kernel's history plumbing
 		bool histStates() const { return hasSbg || hasCongG; }      // search states carry eight history words beside DevState; item histories in sbgScratch
+		// ... and their state arenas belong to the search kernel's lane groups (WorkView::slotCap): so many arenas a launch can use -- 8 persistent one-wave blocks
+		// per CU, one group per wave unless 16-lane groups are forced (four)
+		uint32_t histSlots() const { return persistBlocks / 12 * 8 * ((groupLanesForced && groupLanes == 16) ? 4u : 1u); }
 		SbgDev sbg{}; bool hasSbg = false; DevBuf sbgScratch;   // SkipBigram tables on the device + per-lane-group item scratch of its search kernel
 		// the engine owns ONE pair of streams, one work counter and one scratch arena: device work of concurrent callers (the C API
 		// is callable from many threads, reference capi threading contract) is serialised per engine; host preparation is not
@@ -421,7 +431,8 @@ namespace kamd
 		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
 		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
 		if (const char* lw = std::getenv("KAMD_LATTICE_WAVE")) impl->latticeWave = std::atoi(lw) != 0;
-		if (const char* ss = std::getenv("KAMD_STATE_SCALE")) { impl->stateScale16[0] = impl->stateScale16[1] = (uint32_t)std::min(16, std::max(1, std::atoi(ss))); impl->stateScaleForced = true; }
+		if (const char* ss = std::getenv("KAMD_STATE_SCALE")) { impl->stateScale64[0] = impl->stateScale64[1] = (uint32_t)std::min(64, std::max(1, std::atoi(ss))); impl->stateScaleForced = true; }      // (64ths of the worst case)
+		if (const char* ps = std::getenv("KAMD_STATE_POOL")) { impl->poolFrac64 = (uint32_t)std::min(4096, std::max(0, std::atoi(ps))); impl->poolForced = true; }      // (64ths of the arenas' total; 0: no pool)
 		if (const char* lr = std::getenv("KAMD_LATTICE_RATIO")) { impl->latticeRatio16 = (uint32_t)std::min(4096, std::max(4, std::atoi(lr))); impl->latticeRatioForced = true; }
 		if (const char* l = std::getenv("KAMD_LATTICE_LDS")) { impl->latticeLdsBudget = (uint32_t)std::min(64 * 1024, std::max(0, std::atoi(l))); impl->latticeWaveBudget = (uint32_t)std::min(128 * 1024, std::max(0, std::atoi(l))); }
 		if (impl->latticeWaveBudget > 64 * 1024) HIPCHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lattice_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)impl->latticeWaveBudget));
@@ -476,6 +487,9 @@ namespace kamd
 		b.matchBase.assign(nC + 1, 0); b.nodeBase.assign(nC + 1, 0); b.packBase.assign(nC + 1, 0); b.stateBase.assign(nC + 1, 0); b.tokenBase.assign(nC + 1, 0);
 		const uint64_t sc = b.capScale;
 		const bool tinyArenas = std::getenv("KAMD_TEST_TINY_ARENAS") != nullptr;
+		static const bool noSlots = std::getenv("KAMD_NO_STATE_SLOTS") != nullptr;      // (developer switch: per-chunk arenas for the history models too)
+		const bool slotMode = I.histStates() && !noSlots;
+		uint64_t slotCap = 0;
 		for (size_t c = 0; c < nC; ++c)
 		{
 			const auto& r = b.refs[c];
@@ -487,7 +501,7 @@ namespace kamd
 			uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
 			// SkipBigram states carry their history ring in the container key: far fewer paths merge, a node keeps hundreds to thousands of them
 			if (I.histStates()) scap *= 8;
-			if (sc == 1 && !tinyArenas) scap = std::max<uint64_t>(scap * std::max(I.stateScale16[0], I.stateScale16[1]) / 16, 64);      // (what the batches so far needed; a re-run at a higher rung takes the whole capacity)
+			if (sc == 1 && !tinyArenas && !slotMode) scap = std::max<uint64_t>(scap * (std::max(I.stateScale64[0], I.stateScale64[1]) ? std::max(I.stateScale64[0], I.stateScale64[1]) : 64u) / 64, 64);      // (what the batches so far needed; a re-run at a higher rung takes the whole capacity)
 			if (b.typo.typo) ncap = std::min<uint64_t>(2 * ncap, 0xFFE0);      // lattices over typo graphs come out about twice as large
 			if (tinyArenas)   // test hook (KAMD_TEST_TINY_ARENAS): regions far too small at scale 1, so that the overflow -> re-run ladder is exercised
 			{
@@ -498,6 +512,8 @@ namespace kamd
 			b.nodeBase[c + 1] = b.nodeBase[c] + (uint32_t)ncap;
 			if ((uint64_t)b.packBase[c] + 3 * ncap > 0xFFFFFFFFull) throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
 			b.packBase[c + 1] = b.packBase[c] + (uint32_t)(3 * ncap);
+			if (slotMode && sc == 1 && !tinyArenas && I.stateScaleForced) scap = std::max<uint64_t>(scap * I.stateScale64[0] / 64, 64);      // (KAMD_STATE_SCALE: tests of the growth into the pool)
+			if (slotMode) { slotCap = std::max(slotCap, scap); scap = 0; }      // (the arenas are the search kernel's lane groups', each large enough for the batch's longest chunk)
 			b.stateBase[c + 1] = b.stateBase[c] + scap;
 			b.tokenBase[c + 1] = b.tokenBase[c] + tcap;
 		}
@@ -577,7 +593,14 @@ namespace kamd
 		uint8_t* D = b.dIn.as<uint8_t>();
 		const size_t perChar = totChars + nC + 16;
 		const size_t totNodes = b.nodeBase[nC], totMatch = b.matchBase[nC];
-		const uint64_t totStates = b.stateBase[nC], totTokens = b.tokenBase[nC];
+		// the pool behind the chunks' own arenas (none under KAMD_TEST_TINY_ARENAS: that hook is there to exercise the re-run ladder)
+		if (slotCap > 0x7FFFFFFFull) throw std::runtime_error{ "chunk too long for a state arena" };
+		b.slotCap = (uint32_t)slotCap;
+		const uint64_t ownStates = slotMode ? (uint64_t)I.histSlots() * slotCap : b.stateBase[nC];
+		b.poolStates = tinyArenas ? 0 : slotMode ? (I.poolForced ? ownStates * I.poolFrac64 / 64 : ownStates / 8)
+			: std::max<uint64_t>(ownStates * I.poolFrac64 / 64, I.poolFrac64 ? std::min<uint64_t>(ownStates, 1u << 16) : 0);
+		b.ownStates = ownStates;
+		const uint64_t totStates = ownStates + b.poolStates, totTokens = b.tokenBase[nC];
 		b.dNsToPos.ensure(perChar * 2); b.dPosToNs.ensure(perChar * 2); b.dCflag.ensure(perChar); b.dMask.ensure(perChar * 8); b.dMoff.ensure(perChar * 4);
 		b.dNNs.ensure(nC * 4 + 16); b.dMatchForm.ensure(totMatch * 4 + 16);
 		b.dNodes.ensure(totNodes * sizeof(DevNode) + 16); b.dTmpNodes.ensure(totNodes * sizeof(DevNode) + 16);
@@ -594,10 +617,11 @@ namespace kamd
 		if (I.histStates()) b.dHist.ensure(totStates * 32 + 32);
 		// compact outputs of the end stage: as many token records as the arenas could hold, 16 path headers per chunk (x capacity scale)
 		b.outTokCap = (uint32_t)std::min<uint64_t>(totTokens, 0xFFFFFFF0ull); b.outPathCap = (uint32_t)std::min<uint64_t>((uint64_t)nC * 16 * sc, 0xFFFFFFF0ull);
-		b.dOutTokens.ensure((size_t)b.outTokCap * sizeof(DevToken) + 16); b.dOutPaths.ensure((size_t)b.outPathCap * sizeof(DevPathHeader) + 16); b.dOutCounters.ensure(64);
+		b.dOutTokens.ensure((size_t)b.outTokCap * sizeof(DevToken) + 16); b.dOutPaths.ensure((size_t)b.outPathCap * sizeof(DevPathHeader) + 16); b.dOutCounters.ensure(128);
+		b.dStateAt.ensure(nC * 8 + 16); if (slotMode) b.dSlotTable.ensure((size_t)I.histSlots() * 16 + 16);
 		b.devBytes = 0;
 		for (const DevBuf* d : { &b.dIn, &b.dOutTokens, &b.dOutPaths, &b.dNsToPos, &b.dPosToNs, &b.dCflag, &b.dMask, &b.dMoff, &b.dMatchForm, &b.dNodes, &b.dTmpNodes, &b.dEndPosMap, &b.dTmpIdx,
-			&b.dPacks, &b.dStates, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults, &b.dPosRecs, &b.dPosDesc, &b.dPosPrev, &b.dPosNodeRec, &b.dPosMask, &b.dPosBig }) b.devBytes += d->cap;
+			&b.dPacks, &b.dStates, &b.dHist, &b.dStateAt, &b.dSlotTable, &b.dNodeStOff, &b.dNodeStCnt, &b.dReach, &b.dTokens, &b.dResults, &b.dPosRecs, &b.dPosDesc, &b.dPosPrev, &b.dPosNodeRec, &b.dPosMask, &b.dPosBig }) b.devBytes += d->cap;
 
 		BatchView& bv = b.bv;
 		bv.nChunks = (uint32_t)nC; bv.chars = (const uint16_t*)(D + oChars); bv.cls = D + oCls; bv.script = D + oScript;
@@ -612,6 +636,8 @@ namespace kamd
 		w.endPosMap = b.dEndPosMap.as<uint32_t>(); w.fullMask = b.dFullMask.as<uint64_t>(); w.zAt = b.dZAt.as<uint8_t>(); w.tmpIdx = b.dTmpIdx.as<uint16_t>(); w.nNodes = b.dNNodes.as<uint32_t>(); w.wideList = b.dWideList.as<uint32_t>(); w.expanded = b.dExpanded.as<uint8_t>();
 		w.packBase = (const uint32_t*)(D + oPackBase); w.packs = b.dPacks.as<CandStatic>();
 		w.stateBase = (const uint64_t*)(D + oStateBase); w.states = b.dStates.as<DevState>();
+		w.stateAt = b.dStateAt.as<uint64_t>(); w.poolTop = b.poolStates ? reinterpret_cast<unsigned long long*>(b.dOutCounters.as<uint32_t>() + 16) : nullptr;      // (counters[16..17]: cleared with the others before every run)
+		w.poolBase = b.ownStates; w.poolCap = b.poolStates; w.slotCap = b.slotCap; w.slotTable = b.slotCap ? b.dSlotTable.as<uint64_t>() : nullptr;
 		w.nodeStateOff = b.dNodeStOff.as<uint32_t>(); w.nodeStateCnt = b.dNodeStCnt.as<uint32_t>(); w.reach = b.dReach.as<uint8_t>();
 		w.tokenBase = (const uint64_t*)(D + oTokenBase); w.tokens = b.dTokens.as<DevToken>(); w.results = b.dResults.as<DevChunkResult>();
 		w.outTokens = b.dOutTokens.as<DevToken>(); w.outPaths = b.dOutPaths.as<DevPathHeader>(); w.outCounters = b.dOutCounters.as<uint32_t>();
@@ -868,7 +894,9 @@ namespace kamd
 		while (I.evs.size() < nEv) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); I.evs.push_back(e); }
 		if (I.haveLast) HIPCHECK(hipStreamWaitEvent(sA, I.lastDone, 0));      // the kernels of two batches do not overlap (shared scratch, counters, events)
 		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), sA));
-		HIPCHECK(hipMemsetAsync(b.dOutCounters.p, 0, 64, sA));
+		HIPCHECK(hipMemsetAsync(b.dOutCounters.p, 0, 128, sA));
+		HIPCHECK(hipMemcpyAsync(b.dStateAt.p, b.wv.stateBase, (size_t)nC * 8, hipMemcpyDeviceToDevice, sA));      // every chunk starts in its own arena
+		if (b.slotCap) HIPCHECK(hipMemsetAsync(b.dSlotTable.p, 0, (size_t)I.histSlots() * 16, sA));      // ... every lane group in its own
 		HIPCHECK(hipMemsetAsync(I.counter.p, 0, 256, sA));
 		HIPCHECK(hipMemsetAsync(b.dNNodes.p, 0, (size_t)nC * 4, sA));   // also clears the lattice kernels' hand-over flag
 		HIPCHECK(hipMemsetAsync(b.dExpanded.p, 0, nC, sA));
@@ -1162,6 +1190,7 @@ namespace kamd
 			{
 				static const uint32_t strideEnv = std::getenv("KAMD_FINISH_STRIDE") ? (uint32_t)std::atoi(std::getenv("KAMD_FINISH_STRIDE")) : 0u;      // EXPERIMENT
 				const uint32_t stride = (strideEnv == 1 || strideEnv == 2 || strideEnv == 4 || strideEnv == 8 || strideEnv == 16 || strideEnv == 32 || strideEnv == 64) ? strideEnv : cn <= 32768 ? 16u : 4u, perWave = 64 / stride;      // active lanes per wave: 4 up to 32k chunks, 16 beyond
+				if (!wv.slotCap)      // (slot mode: the search kernel has run every chunk's end stage itself)
 				hipLaunchKernelGGL(k_finish_paths, dim3((cn + perWave - 1) / perWave), dim3(64), 0, sB, I.dview, b.bv, wv, sp, c0, cn, stride);
 			}
 			HIPCHECK(hipEventRecord(e[5], sB));
@@ -1393,8 +1422,10 @@ namespace kamd
 		b.hOut.ensure(oRes + resBytes);
 		uint8_t* H = b.hOut.as<uint8_t>();
 		HIPCHECK(hipMemcpyAsync(H, b.dOutCounters.p, 8, hipMemcpyDeviceToHost, I.streamCopy));
+		HIPCHECK(hipMemcpyAsync(H + 16, b.dOutCounters.as<uint8_t>() + 64, 8, hipMemcpyDeviceToHost, I.streamCopy));      // (states of the pool handed out)
 		HIPCHECK(hipMemcpyAsync(H + oRes, b.dResults.p, nC * sizeof(DevChunkResult), hipMemcpyDeviceToHost, I.streamCopy));
 		HIPCHECK(hipStreamSynchronize(I.streamCopy));
+		b.poolUsed = *reinterpret_cast<const uint64_t*>(H + 16);
 		const uint32_t nPaths = std::min(reinterpret_cast<const uint32_t*>(H)[0], b.outPathCap), nTok = std::min(reinterpret_cast<const uint32_t*>(H)[1], b.outTokCap);
 		const size_t oTok = ((size_t)nPaths * sizeof(DevPathHeader) + 255) & ~(size_t)255;
 		b.hOut2.ensure(oTok + (size_t)nTok * sizeof(DevToken) + 16);
@@ -1553,6 +1584,7 @@ namespace kamd
 	size_t Engine::stagedChunks(const StagedBatch& b) { return b.refs.size(); }
 	uint64_t Engine::stagedUnits(const StagedBatch& b) { return b.units; }
 	uint64_t Engine::stagedDeviceBytes(const StagedBatch& b) { return b.devBytes; }
+	void Engine::stagedPool(const StagedBatch& b, uint64_t* out3) { out3[0] = b.ownStates; out3[1] = b.poolStates; out3[2] = b.poolUsed; }
 
 	// Runs an explicit list of chunks (re-runs with larger capacities or non-default special states).  Chunks that overflow again go
 	// up the capacity ladder TOGETHER (one launch per rung, not one per chunk); a rung is cut into slices of bounded device memory.
@@ -1618,26 +1650,36 @@ namespace kamd
 		HostTimer tm{ "fetch" };
 		download(*impl, b);
 		tm.lap("download");
-		if (!impl->stateScaleForced && b.capScale == 1 && b.refs.size() >= 64 && !std::getenv("KAMD_TEST_TINY_ARENAS"))
+		if (b.capScale == 1 && b.refs.size() >= 64 && !std::getenv("KAMD_TEST_TINY_ARENAS") && !b.slotCap)
 		{
-			// how much of the worst-case state capacity the chunks of this batch used (states + the end candidates and the back-trace chain behind them)
-			// (the 99.9th percentile of the chunks, not the maximum: the few chunks beyond it climb the capacity ladder inside run())
-			uint32_t hist[18] = {}; size_t counted = 0;
+			// how much of the worst-case state capacity the chunks of this batch used (states + the end candidates and the back-trace chain behind them), in 64ths:
+			// the next batches' arenas hold what 90 % of these chunks needed -- the others grow into the pool, which gets twice what this batch took of it
+			// (nothing grew? then the pool keeps a sixteenth of the arenas' total).  A batch that still had chunks re-run doubles both.
+			uint32_t hist[66] = {}; size_t counted = 0;
 			for (size_t c = 0; c < b.refs.size(); ++c)
 			{
 				const DevChunkResult& r = b.hResults[c];
 				if (r.status >= 16) continue;
 				const uint64_t full = (48ull * (b.charOff[c + 1] - b.charOff[c]) + 256) * (impl->histStates() ? 8 : 1);
 				const uint64_t used = (uint64_t)r.endOff + r.nEnd / 2 + (b.nodeBase[c + 1] - b.nodeBase[c]) / 12 + 16;
-				++hist[std::min<uint64_t>(17, (used * 16 + full - 1) / full)]; ++counted;
+				++hist[std::min<uint64_t>(65, (used * 64 + full - 1) / full)]; ++counted;
 			}
-			uint64_t need16 = 1; size_t seen = 0;
-			for (uint32_t k = 0; k < 18; ++k) { seen += hist[k]; need16 = std::max<uint64_t>(1, k); if (seen * 1000 >= counted * 999) break; }
-			impl->stateScale16[b.topN > 1 ? 1 : 0] = b.rerunChunks ? 16u : (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(2, need16 * 2));
+			uint64_t need64 = 1; size_t seen = 0;
+			// (models without histories in their states: the 99.9th percentile, doubled -- their arenas are small, and a chunk that fills its arena under the
+			// position-step kernel is handed to the slower general kernel, the one that can grow)
+			const bool lean = impl->histStates() && b.poolStates;
+			for (uint32_t k = 0; k < 66; ++k) { seen += hist[k]; need64 = std::max<uint64_t>(1, k); if (lean ? seen * 10 >= counted * 9 : seen * 1000 >= counted * 999) break; }
+			const int which = b.topN > 1 ? 1 : 0;
+			const uint64_t arenas = b.stateBase[b.refs.size()];
+			if (!impl->stateScaleForced)
+				impl->stateScale64[which] = b.rerunChunks ? std::min(64u, std::max(impl->stateScale64[which], 8u) * 2) : (uint32_t)std::min<uint64_t>(64, lean ? need64 : std::max<uint64_t>(8, need64 * 2));
+			if (!impl->poolForced && arenas)
+				impl->poolFrac64 = b.rerunChunks ? std::min(4096u, impl->poolFrac64 * 2) : (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(4, (b.poolUsed * 2 * 64 + arenas - 1) / arenas));
 			if (std::getenv("KAMD_LATTICE_STATS"))
 			{
-				fprintf(stderr, "[state arenas] top-%u batch of %zu chunks: most used %llu/16 of the worst-case capacity, %u re-run -> scale %u/16 (top-1) %u/16 (top-N); chunks by sixteenths used:", b.topN, b.refs.size(), (unsigned long long)need16, b.rerunChunks, impl->stateScale16[0], impl->stateScale16[1]);
-				for (uint32_t k = 0; k < 18; ++k) if (hist[k]) fprintf(stderr, " %u:%u", k, hist[k]);
+				fprintf(stderr, "[state arenas] top-%u batch of %zu chunks: 90 %% (models without state histories: 99.9 %%) of them used <= %llu/64 of the worst-case capacity, pool %llu of %llu states (arenas %llu), %u re-run -> scale %u/64 (top-1) %u/64 (top-N), pool %u/64; chunks by 64ths used:",
+					b.topN, b.refs.size(), (unsigned long long)need64, (unsigned long long)b.poolUsed, (unsigned long long)b.poolStates, (unsigned long long)arenas, b.rerunChunks, impl->stateScale64[0], impl->stateScale64[1], impl->poolFrac64);
+				for (uint32_t k = 0; k < 66; ++k) if (hist[k]) fprintf(stderr, " %u:%u", k, hist[k]);
 				fprintf(stderr, "\n");
 			}
 		}

@@ -98,6 +98,7 @@ namespace kamd
 		static size_t stagedChunks(const StagedBatch& b);
 		static uint64_t stagedUnits(const StagedBatch& b);     // non-space normalised units ("jamo")
 		static uint64_t stagedDeviceBytes(const StagedBatch& b);
+		static void stagedPool(const StagedBatch& b, uint64_t* out3);      // states in the chunks' own arenas, states of the pool behind them, states of the pool the last fetched run asked for
 		// chunks of the last run() that overflowed their scratch in the first pass and were searched again inside run(), and the wall time of that
 		static uint32_t rerunChunks(const StagedBatch& b, float* ms);
 

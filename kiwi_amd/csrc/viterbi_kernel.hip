@@ -1904,7 +1904,7 @@ namespace sbgk
 		TLMARK(X, 4)
 	}
 
-#ifndef KAMD_VARIANT    // (the end stage after the EOS transition does not depend on the LM type: one copy, in the Knlm translation unit)
+#if !defined(KAMD_VARIANT) || defined(KAMD_HIST)    // (the end stage after the EOS transition does not depend on the LM type: one copy, in the Knlm translation unit -- and one in each of the compilations that run it inside the search kernel, finishPathsSolo)
 	// libstdc++'s std::sort restated for the end-node candidate list (the reference sorts it with an unstable
 	// std::sort, PathEvaluator.hpp:1359-1368; equal keys must land where introsort puts them).  Runs on one lane.
 	__device__ __forceinline__ bool endLess(const EndCand& a, const EndCand& b)
@@ -2071,7 +2071,7 @@ namespace sbgk
 #endif
 	// End node, first half (PathEvaluator.hpp:1320-1358): EOS transition of every surviving path -> end-candidate list for k_finish_paths.
 	template<int G>
-	__device__ __noinline__ void finishChunk(GroupCtx<G>& X, uint32_t chunk, bool openEnding, DevChunkResult* res)
+	__device__ __noinline__ bool finishChunk(GroupCtx<G>& X, uint32_t chunk, bool openEnding, DevChunkResult* res)      // (false: the end candidates did not fit into the arena's tail)
 	{
 		const ModelView& M = X.M;
 		const uint32_t Gn = X.Gn;
@@ -2139,10 +2139,97 @@ namespace sbgk
 			res->nEnd = nEnd; res->endOff = X.stTop; res->nPaths = 0;
 			res->status = endOverflow ? CS_ERR_STATE_OVERFLOW : CS_OK;
 		}
+		return !endOverflow;
 	}
 
+#if !defined(KAMD_VARIANT) || defined(KAMD_HIST)
+	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418), the work of ONE thread, in three steps with the output ranges handed out between them:
+	// by wave prefix sums + one atomic per wave in k_finish_paths (one thread per chunk, a kernel of its own), by the chunk's own atomics in finishPathsSolo
+	// (called by the search kernel for a chunk it has just searched, so that the chunk's state arena is free for the group's next chunk).
+	struct FinishSel { uint32_t nEnd = 0, nBase = 0, Gn = 0, perGroup = 0, nSel = 0, bestOnly = 0xFFFFFFFFu; DevState* st = nullptr; EndCand* endBuf = nullptr; uint32_t* chain = nullptr; const uint8_t* uniq = nullptr; };
+	__device__ __forceinline__ void finishSelect(const BatchView& B, const WorkView& W, const SearchParams& P, uint32_t chunk, const DevChunkResult* res, DevState* st, FinishSel& F)
+	{
+		F.nEnd = res->nEnd; F.nBase = W.nodeBase[chunk]; F.Gn = W.nNodes[chunk];
+		F.st = st;
+		F.endBuf = reinterpret_cast<EndCand*>(st + res->endOff);
+		F.chain = reinterpret_cast<uint32_t*>(F.endBuf + F.nEnd);
+		F.uniq = B.spStates + B.spOff[chunk];
+		const uint32_t nEnd = F.nEnd; EndCand* endBuf = F.endBuf;
+		sortEndCands(endBuf, (int)nEnd);
+		// distinct (root, state) groups: the sort above made every group contiguous (its key starts with root and state), so they are counted at
+		// their boundaries -- one pass instead of comparing every candidate with all earlier ones
+		uint32_t numUniq = 0;
+		for (uint32_t a = 0; a < nEnd; ++a) if (!a || endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp) ++numUniq;
+		F.perGroup = numUniq ? (2 * P.topN + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq)
+		// paths this chunk hands on: the first perGroup candidates of every (root, state) group
+		for (uint32_t a = 0, startIdx = 0; a < nEnd; ++a)
+		{
+			if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
+			if (a - startIdx < F.perGroup) ++F.nSel;
+		}
+		// The only chunk of its text under top-1: of the 2 N paths the reference hands on (PathEvaluator.hpp:1359-1418) only the best one can become the
+		// analysis -- Kiwi::analyze sorts what insertPathIntoResults kept by score and cuts to N (Kiwi.cpp:1143-1158), and with no second chunk nothing
+		// is combined with the rest.  That is the first of the selected paths in the host's order: highest score, the earlier one of equal scores (its sort
+		// of these few paths is an insertion sort).  The groups' first candidates are their best ones, so it is the best of those.  One back-trace, one
+		// path and its tokens over PCIe instead of two.
+		if (P.topN == 1 && (B.chunkFlags[chunk] & 2) && F.nSel > 1)
+		{
+			for (uint32_t a = 0; a < nEnd; ++a)
+			{
+				if (a && endBuf[a].rootId == endBuf[a - 1].rootId && endBuf[a].sp == endBuf[a - 1].sp) continue;
+				if (F.bestOnly == 0xFFFFFFFFu || endBuf[a].score > endBuf[F.bestOnly].score) F.bestOnly = a;
+			}
+			F.nSel = 1;
+		}
+	}
+	// the back-traces of the selected candidates: path headers at outPaths[pathOff ..], token records into the chunk's own token region (tokTop of them)
+	__device__ __forceinline__ void finishTrace(const ModelView& M, const WorkView& W, const SearchParams& P, uint32_t chunk, const FinishSel& F, uint32_t pathOff, uint32_t& status, DevToken*& tok, uint32_t& tokTop, uint32_t& nPaths)
+	{
+		tok = W.tokens + W.tokenBase[chunk];
+		const uint32_t tokCap = (uint32_t)(W.tokenBase[chunk + 1] - W.tokenBase[chunk]);
+		for (uint32_t a = 0, startIdx = 0; a < F.nEnd; ++a)
+		{
+			if (a && (F.endBuf[a].rootId != F.endBuf[a - 1].rootId || F.endBuf[a].sp != F.endBuf[a - 1].sp)) startIdx = a;
+			if (a - startIdx >= F.perGroup) continue;
+			if (F.bestOnly != 0xFFFFFFFFu && a != F.bestOnly) continue;
+			const int nt = backTrace(M, P, W.nodes + F.nBase, F.st, F.endBuf[a].parent, tok + tokTop, tokCap - tokTop, F.chain, F.Gn);
+			if (nt < 0) { status = CS_ERR_TOKEN_OVERFLOW; break; }
+			DevPathHeader ph;
+			ph.score = F.endBuf[a].score; ph.tokOff = tokTop; ph.nTokens = (uint16_t)nt;
+			ph.prevState = F.uniq[F.endBuf[a].rootId]; ph.curState = F.endBuf[a].sp;
+			W.outPaths[pathOff + nPaths++] = ph;
+			tokTop += (uint32_t)nt;
+		}
+		if (status != CS_OK) tokTop = 0;
+	}
+	__device__ __forceinline__ void finishCopyTokens(const WorkView& W, const DevToken* tok, uint32_t tokTop, uint32_t tokOff)
+	{
+		const uint2* src = reinterpret_cast<const uint2*>(tok);            // 24-byte records, 8-byte aligned
+		uint2* dst = reinterpret_cast<uint2*>(W.outTokens + tokOff);
+		for (uint32_t i = 0; i < 3 * tokTop; ++i) dst[i] = src[i];
+	}
+	// the whole stage for one chunk by the calling thread alone (no cross-lane operation: lane groups of a wavefront get here at different times)
+	__device__ __noinline__ void finishPathsSolo(const ModelView& M, const BatchView& B, const WorkView& W, const SearchParams& P, uint32_t chunk, DevState* st)
+	{
+		DevChunkResult* res = &W.results[chunk];
+		if (res->status != CS_OK) { atomicAdd(&W.outCounters[2], 1u); return; }
+		FinishSel F;
+		finishSelect(B, W, P, chunk, res, st, F);
+		uint32_t status = CS_OK;
+		const uint32_t pathOff = F.nSel ? atomicAdd(&W.outCounters[0], F.nSel) : 0u;
+		if (pathOff + F.nSel > W.outPathCap) status = CS_ERR_PATH_OVERFLOW;
+		DevToken* tok = nullptr; uint32_t tokTop = 0, nPaths = 0;
+		if (status == CS_OK) finishTrace(M, W, P, chunk, F, pathOff, status, tok, tokTop, nPaths);
+		const uint32_t tokOff = tokTop ? atomicAdd(&W.outCounters[1], tokTop) : 0u;
+		if (status == CS_OK && tokOff + tokTop > W.outTokCap) status = CS_ERR_TOKEN_OVERFLOW;
+		if (status == CS_OK) finishCopyTokens(W, tok, tokTop, tokOff);
+		res->status = status; res->nPaths = status == CS_OK ? nPaths : 0;
+		res->pathOff = pathOff; res->tokOff = tokOff; res->nTok = status == CS_OK ? tokTop : 0;
+		if (status >= 16) atomicAdd(&W.outCounters[2], 1u);
+	}
+#endif
+
 #ifndef KAMD_VARIANT
-	// sort + selection + back-trace of one chunk (PathEvaluator.hpp:1359-1418); one thread per chunk
 	// `stride`: lanes between two active threads of a wave (64 = one chunk per wave): the stage is serial and branchy per chunk, so chunks that
 	// share a wavefront run at the sum of their paths -- few active lanes per wave spread them over the SIMDs instead
 	__global__ void __launch_bounds__(64) k_finish_paths(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t chunkBegin, uint32_t chunkCount, uint32_t stride)
@@ -2154,42 +2241,9 @@ namespace sbgk
 		const uint32_t chunk = chunkBegin + (t < chunkCount ? t : 0u);
 		DevChunkResult* res = &W.results[chunk];
 		const bool active = t < chunkCount && res->status == CS_OK;
-		uint32_t nEnd = 0, nBase = 0, Gn = 0, perGroup = 0, nSel = 0, bestOnly = 0xFFFFFFFFu;
-		DevState* st = nullptr; EndCand* endBuf = nullptr; uint32_t* chain = nullptr; const uint8_t* uniq = nullptr;
-		if (active)
-		{
-			nEnd = res->nEnd; nBase = W.nodeBase[chunk]; Gn = W.nNodes[chunk];
-			st = W.states + W.stateBase[chunk];
-			endBuf = reinterpret_cast<EndCand*>(st + res->endOff);
-			chain = reinterpret_cast<uint32_t*>(endBuf + nEnd);
-			uniq = B.spStates + B.spOff[chunk];
-			sortEndCands(endBuf, (int)nEnd);
-			// distinct (root, state) groups: the sort above made every group contiguous (its key starts with root and state), so they are counted at
-			// their boundaries -- one pass instead of comparing every candidate with all earlier ones
-			uint32_t numUniq = 0;
-			for (uint32_t a = 0; a < nEnd; ++a) if (!a || endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp) ++numUniq;
-			perGroup = numUniq ? (2 * P.topN + numUniq - 1) / numUniq : 0;   // ceil(topN*2 / numUniq)
-			// paths this chunk hands on: the first perGroup candidates of every (root, state) group
-			for (uint32_t a = 0, startIdx = 0; a < nEnd; ++a)
-			{
-				if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
-				if (a - startIdx < perGroup) ++nSel;
-			}
-			// The only chunk of its text under top-1: of the 2 N paths the reference hands on (PathEvaluator.hpp:1359-1418) only the best one can become the
-			// analysis -- Kiwi::analyze sorts what insertPathIntoResults kept by score and cuts to N (Kiwi.cpp:1143-1158), and with no second chunk nothing
-			// is combined with the rest.  That is the first of the selected paths in the host's order: highest score, the earlier one of equal scores (its sort
-			// of these few paths is an insertion sort).  The groups' first candidates are their best ones, so it is the best of those.  One back-trace, one
-			// path and its tokens over PCIe instead of two.
-			if (P.topN == 1 && (B.chunkFlags[chunk] & 2) && nSel > 1)
-			{
-				for (uint32_t a = 0; a < nEnd; ++a)
-				{
-					if (a && endBuf[a].rootId == endBuf[a - 1].rootId && endBuf[a].sp == endBuf[a - 1].sp) continue;
-					if (bestOnly == 0xFFFFFFFFu || endBuf[a].score > endBuf[bestOnly].score) bestOnly = a;
-				}
-				nSel = 1;
-			}
-		}
+		FinishSel F;
+		if (active) finishSelect(B, W, P, chunk, res, W.states + (W.stateAt ? W.stateAt[chunk] : W.stateBase[chunk]), F);      // (stateAt: where the chunk's arena lies after it grew)
+		const uint32_t nSel = F.nSel;
 		// output range of the path headers: wave prefix sum + one atomic per wave
 		uint32_t status = CS_OK;
 		uint32_t pathOff;
@@ -2204,25 +2258,7 @@ namespace sbgk
 			if (active && pathOff + nSel > W.outPathCap) status = CS_ERR_PATH_OVERFLOW;
 		}
 		DevToken* tok = nullptr; uint32_t tokTop = 0, nPaths = 0;
-		if (active && status == CS_OK)
-		{
-			tok = W.tokens + W.tokenBase[chunk];
-			const uint32_t tokCap = (uint32_t)(W.tokenBase[chunk + 1] - W.tokenBase[chunk]);
-			for (uint32_t a = 0, startIdx = 0; a < nEnd; ++a)
-			{
-				if (a && (endBuf[a].rootId != endBuf[a - 1].rootId || endBuf[a].sp != endBuf[a - 1].sp)) startIdx = a;
-				if (a - startIdx >= perGroup) continue;
-				if (bestOnly != 0xFFFFFFFFu && a != bestOnly) continue;
-				const int nt = backTrace(M, P, W.nodes + nBase, st, endBuf[a].parent, tok + tokTop, tokCap - tokTop, chain, Gn);
-				if (nt < 0) { status = CS_ERR_TOKEN_OVERFLOW; break; }
-				DevPathHeader ph;
-				ph.score = endBuf[a].score; ph.tokOff = tokTop; ph.nTokens = (uint16_t)nt;
-				ph.prevState = uniq[endBuf[a].rootId]; ph.curState = endBuf[a].sp;
-				W.outPaths[pathOff + nPaths++] = ph;
-				tokTop += (uint32_t)nt;
-			}
-			if (status != CS_OK) tokTop = 0;
-		}
+		if (active && status == CS_OK) finishTrace(M, W, P, chunk, F, pathOff, status, tok, tokTop, nPaths);
 		// output range of the token records, then the copy out of the chunk's arena
 		uint32_t tokOff;
 		{
@@ -2235,12 +2271,7 @@ namespace sbgk
 			tokOff = base + incl - tokTop;
 			if (active && status == CS_OK && tokOff + tokTop > W.outTokCap) status = CS_ERR_TOKEN_OVERFLOW;
 		}
-		if (active && status == CS_OK)
-		{
-			const uint2* src = reinterpret_cast<const uint2*>(tok);            // 24-byte records, 8-byte aligned
-			uint2* dst = reinterpret_cast<uint2*>(W.outTokens + tokOff);
-			for (uint32_t i = 0; i < 3 * tokTop; ++i) dst[i] = src[i];
-		}
+		if (active && status == CS_OK) finishCopyTokens(W, tok, tokTop, tokOff);
 		if (t < chunkCount && res->status == CS_OK)
 		{
 			res->status = status; res->nPaths = status == CS_OK ? nPaths : 0;
@@ -2255,13 +2286,52 @@ namespace sbgk
 	}
 #endif
 
+	// The chunk's state arena is full: carry on in one twice as large taken from the batch's pool (WorkView::poolTop; one atomic add per growth -- the pool is
+	// append-only, an arena that was left is not handed out again).  The first `keep` states and their history words move; state indices are arena-relative and
+	// stay what they are.  false: no pool, or the pool is used up (the chunk then ends with an overflow status and the host re-runs it with larger arenas).
+	template<int G>
+	__device__ __noinline__ bool growArena(GroupCtx<G>& X, const WorkView& W, uint32_t chunk, uint32_t keep)
+	{
+		if (!W.poolTop) return false;
+		const uint64_t newCap = 2ull * X.stCap;
+		if (newCap > 0x7FFFFFFFull) return false;
+		uint32_t atLo = 0, atHi = 0;
+		if (X.gl == 0) { const unsigned long long a = atomicAdd(W.poolTop, (unsigned long long)newCap); atLo = (uint32_t)a; atHi = (uint32_t)(a >> 32); }
+		const uint64_t at = (uint64_t)X.bcast(atLo, 0) | ((uint64_t)X.bcast(atHi, 0) << 32);
+		if (at + newCap > W.poolCap) return false;
+		DevState* ns = W.states + (W.poolBase + at);
+		{
+			const uint4* s4 = reinterpret_cast<const uint4*>(X.st); uint4* d4 = reinterpret_cast<uint4*>(ns);
+			static_assert(sizeof(DevState) == 48, "three 16-byte words per state");
+			for (uint64_t k = X.gl; k < 3ull * keep; k += G) d4[k] = s4[k];
+		}
+#ifdef KAMD_HIST
+		{
+			SBG_ONLY(uint32_t* nh = X.S->hist + 8ull * (W.poolBase + at);)
+			CONGG_ONLY(uint32_t* nh = X.GG->hist + 8ull * (W.poolBase + at);)
+			const uint4* s4 = reinterpret_cast<const uint4*>(X.hist); uint4* d4 = reinterpret_cast<uint4*>(nh);
+			for (uint64_t k = X.gl; k < 2ull * keep; k += G) d4[k] = s4[k];
+			X.hist = nh;
+		}
+#endif
+		X.st = ns; X.stCap = (uint32_t)newCap;
+		if (X.gl == 0)
+		{
+			if (!W.slotCap) W.stateAt[chunk] = W.poolBase + at;
+			else { const size_t slot = (size_t)blockIdx.x * (64 / G) + X.gshift / G; W.slotTable[2 * slot] = W.poolBase + at; W.slotTable[2 * slot + 1] = newCap; }
+		}
+		waveSync();
+		return true;
+	}
+
 	template<int G>
 	__device__ INL3 void searchChunk(GroupCtx<G>& X, const BatchView& B, const WorkView& W, uint32_t chunk, uint32_t resumeAt = 0xFFFFFFFFu)
 	{
 		const ModelView& M = X.M;
 		const SearchParams& P = X.P;
 		DevChunkResult* res = &W.results[chunk];
-		if (res->status != CS_OK) { if (X.gl == 0) res->nPaths = 0; return; }
+		// (slot mode: no k_finish_paths pass counts the chunks that ended with an error status -- every exit does it itself)
+		if (res->status != CS_OK) { if (X.gl == 0) { res->nPaths = 0; HIST_ONLY(if (W.slotCap) atomicAdd(&W.outCounters[2], 1u);) } return; }
 		const uint32_t cOff = B.charOff[chunk];
 		const uint32_t nBase = W.nodeBase[chunk];
 		X.nodes = W.nodes + nBase; X.Gn = W.nNodes[chunk];
@@ -2269,6 +2339,18 @@ namespace sbgk
 		X.st = W.states + W.stateBase[chunk]; X.stCap = (uint32_t)(W.stateBase[chunk + 1] - W.stateBase[chunk]); X.stTop = 0;
 		SBG_ONLY(X.hist = X.S->hist + 8ull * W.stateBase[chunk];)
 		CONGG_ONLY(X.hist = X.GG->hist + 8ull * W.stateBase[chunk];)
+#ifdef KAMD_HIST
+		if (W.slotCap)
+		{
+			// the lane group's own arena (WorkView::slotCap), used by one chunk after the other
+			const size_t slot = (size_t)blockIdx.x * (64 / G) + X.gshift / G;
+			uint64_t at = (uint64_t)slot * W.slotCap; uint32_t cap = W.slotCap;
+			if (W.slotTable[2 * slot + 1]) { at = W.slotTable[2 * slot]; cap = (uint32_t)W.slotTable[2 * slot + 1]; }      // (an earlier chunk of this group grew into the pool: the group keeps that arena)
+			X.st = W.states + at; X.stCap = cap;
+			SBG_ONLY(X.hist = X.S->hist + 8ull * at;)
+			CONGG_ONLY(X.hist = X.GG->hist + 8ull * at;)
+		}
+#endif
 		TYPO_ONLY(X.nodeTypo = X.typoAll + nBase;)
 		X.nodeStOff = W.nodeStateOff + nBase; X.nodeStCnt = W.nodeStateCnt + nBase; X.nodeLive = W.tmpIdx + 2ull * nBase;
 		X.uniq = B.spStates + B.spOff[chunk]; X.nUniq = B.spOff[chunk + 1] - B.spOff[chunk];
@@ -2276,7 +2358,7 @@ namespace sbgk
 		const uint32_t Gn = X.Gn;
 		const bool openEnding = B.chunkFlags[chunk] & 1;
 		uint8_t* reach = W.reach + nBase;
-		if (X.nUniq + 1 > SB_SLOT_MASK) { if (X.gl == 0) { res->status = CS_ERR_PATH_OVERFLOW; res->nPaths = 0; } return; }
+		if (X.nUniq + 1 > SB_SLOT_MASK) { if (X.gl == 0) { res->status = CS_ERR_PATH_OVERFLOW; res->nPaths = 0; HIST_ONLY(if (W.slotCap) atomicAdd(&W.outCounters[2], 1u);) } return; }
 		// a chunk the position-step kernel (viterbi_pos.inc) worked on before: nodes [0, resume) are done -- their states, state ranges, live counts and
 		// reachable flags are in HBM -- and this kernel carries on at node `resume` (Gn - 1: only the end stage is left)
 		// (resumeAt: k_pos_path carrying on by itself; otherwise the node is in DevChunkResult::pad, bits 24..31 = why it was handed over, developer statistics)
@@ -2478,6 +2560,21 @@ namespace sbgk
 				evaluateNode<G>(X, E, cl, clLds, clN, ok, of, disc);
 			}
 			TLMARK(X, 6)
+			if (X.overflow && !X.pairOverflow && W.poolTop)
+			{
+				// the arena is full: a larger one from the batch's pool, and the node is evaluated again from its first state (nothing of it is recorded yet).
+				// (a real function call on COPIES, like the end stage below: no address of X or of a kernel argument may escape from the node loop)
+				const ModelView Mc = X.M; const SearchParams Pc = X.P; const WorkView Wc = W;
+				GroupCtx<G> Y(X, Mc, Pc);
+				SBG_ONLY(const SbgDev Sc = *X.S; Y.S = &Sc;)
+				CONGG_ONLY(const CongGDev Gc = *X.GG; Y.GG = &Gc;)
+				if (growArena<G>(Y, Wc, chunk, nodeStart))
+				{
+					X.st = Y.st; X.stCap = Y.stCap; HIST_ONLY(X.hist = Y.hist;)
+					X.overflow = false; X.stTop = nodeStart;
+					--i; continue;
+				}
+			}
 			// node bookkeeping: state range + live count (LDS ring and HBM)
 			{
 				const uint32_t cntAll = X.stTop - nodeStart;
@@ -2502,12 +2599,13 @@ namespace sbgk
 		}
 		if (X.overflow || X.pairOverflow)
 		{
-			if (X.gl == 0) { res->status = X.overflow ? CS_ERR_STATE_OVERFLOW : CS_ERR_PAIR_OVERFLOW; res->nPaths = 0; }
+			if (X.gl == 0) { res->status = X.overflow ? CS_ERR_STATE_OVERFLOW : CS_ERR_PAIR_OVERFLOW; res->nPaths = 0; HIST_ONLY(if (W.slotCap) atomicAdd(&W.outCounters[2], 1u);) }
 			return;
 		}
 #ifdef KAMD_TIMELINE
 		if (tl && X.gl == 0) { const unsigned long long clkNow_ = clock64(); tl[1] = wall_clock64(); LDS_AS unsigned long long* a_ = ldsPtr<unsigned long long>(X.lds + Lay<G>::TLACC); for (int k = 0; k < 11; ++k) tl[4 + k] = a_[k]; tl[15] = clkNow_ - tlClk0; }
 #endif
+		for (;;)
 		{
 			// the end stage is a real function call; it gets COPIES of the context and of the views, so that no address of X or of
 			// a kernel argument escapes and all of them stay in registers / the kernarg segment throughout the node loop (with the
@@ -2517,8 +2615,21 @@ namespace sbgk
 			SBG_ONLY(const SbgDev Sc = *X.S; Y.S = &Sc;)
 			CONG_ONLY(const CongDev Cc = *X.CG; Y.CG = &Cc;)
 			CONGG_ONLY(const CongGDev Gc = *X.GG; Y.GG = &Gc;)
-			finishChunk<G>(Y, chunk, openEnding, res);
+			if (finishChunk<G>(Y, chunk, openEnding, res)) break;
+			// (its candidates go behind the states: a full arena grows here too, and the stage runs again)
+			const WorkView Wc = W;
+			if (!growArena<G>(Y, Wc, chunk, Y.stTop)) break;
+			X.st = Y.st; X.stCap = Y.stCap; HIST_ONLY(X.hist = Y.hist;)
 		}
+#ifdef KAMD_HIST
+		if (W.slotCap)
+		{
+			// the arena is this group's, not the chunk's: sort, selection and back-traces now (one lane; a thousandth of the chunk's search), then it is free
+			waveSync();
+			if (X.gl == 0) { const ModelView Mc = X.M; const SearchParams Pc = X.P; const WorkView Wc = W; const BatchView Bc = B; finishPathsSolo(Mc, Bc, Wc, Pc, chunk, X.st); }
+			waveSync();
+		}
+#endif
 #ifdef KAMD_TIMELINE
 		if (tl && X.gl == 0) tl[2] = wall_clock64();
 #endif

@@ -216,6 +216,37 @@ def test_emulated_skipbigram_kernel_matches_oracle(emu_libs, small_sbg_model, mo
     dev.close()
 
 
+@pytest.mark.parametrize("model,lanes,top_n,pool", [("sbg", "64", 1, "4096"), ("sbg", "16", 3, "4096"), ("sbg", "64", 2, "6"), ("knlm", "pos", 1, "2048"), ("knlm", "16", 2, "2048")])
+def test_emulated_state_arenas_grow_into_the_pool(emu_libs, small_model, small_sbg_model, monkeypatch, model, lanes, top_n, pool):
+    """Arenas of 1/64 of the worst case (KAMD_STATE_SCALE=1): most chunks fill theirs and carry on in arenas from the batch's pool (growArena: the states so far
+    move, the node that met the full arena is evaluated again; the end stage grows the same way) -- same analyses.  Pool of 6/64 of the arenas: it runs out, and
+    the chunks it could not serve go through the re-run ladder.  SkipBigram: the arenas are the search kernel's lane groups' (WorkView::slotCap; a group keeps
+    what it grew into for its later chunks) and the kernel runs every chunk's end stage itself (finishPathsSolo)."""
+    import oraclelib
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_sbg_model if model == "sbg" else small_model
+    monkeypatch.setenv("KAMD_EXPERIMENTAL_SBG", "1")
+    force_lanes(monkeypatch, lanes)
+    monkeypatch.setenv("KAMD_STATE_SCALE", "1")
+    monkeypatch.setenv("KAMD_STATE_POOL", pool)
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    texts = [t for t in synthetic(sm, 50, 571, min_jamo=20, max_jamo=90) + dictionary_mix(sm, 20, 572) if t.strip()]
+    b = dev.stage(texts)
+    got = dev.fetch(b, top_n).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), s
+    p = b.pool()
+    reruns, _ = dev.reruns(b)
+    assert p["pool_states"] >= p["arena_states"] * int(pool) // 64 and p["pool_asked"] > p["arena_states"] // 2, p
+    if pool == "6":
+        assert p["pool_asked"] > p["pool_states"] and reruns > 0, (p, reruns)
+    else:
+        assert p["pool_asked"] <= p["pool_states"] and (reruns == 0 or model == "knlm"), (p, reruns)      # (the position-step kernel's own end stage does not grow)
+    b.close()
+    dev.close()
+
+
 @pytest.mark.parametrize("lanes", ["16", "64"])
 def test_emulated_skipbigram_fallback_paths(emu_libs, small_sbg_model, monkeypatch, lanes):
     """SkipBigram kernel in the `smallcaps` configuration: tiny LDS capacities, container limits 3 / 8 / 2 on both sides (the medium
