@@ -276,7 +276,8 @@ namespace kamd
 		bool histStates() const { return hasSbg || hasCongG; }      // search states carry eight history words beside DevState; item histories in sbgScratch
 		// ... and their state arenas belong to the search kernel's lane groups (WorkView::slotCap): so many arenas a launch can use -- 8 persistent one-wave blocks
 		// per CU, one group per wave unless 16-lane groups are forced (four)
-		uint32_t histSlots() const { return persistBlocks / 12 * 8 * ((groupLanesForced && groupLanes == 16) ? 4u : 1u); }
+		uint32_t histBlocksPerCu() const { static const int v = std::getenv("KAMD_HIST_BLOCKS") ? std::atoi(std::getenv("KAMD_HIST_BLOCKS")) : 12; return (uint32_t)std::min(16, std::max(1, v)); }      // (12 = three waves per SIMD, what those kernels are built for; the knob is a developer's)
+		uint32_t histSlots() const { return persistBlocks / 12 * histBlocksPerCu() * ((groupLanesForced && groupLanes == 16) ? 4u : 1u); }
 		SbgDev sbg{}; bool hasSbg = false; DevBuf sbgScratch;   // SkipBigram tables on the device + per-lane-group item scratch of its search kernel
 		// the engine owns ONE pair of streams, one work counter and one scratch arena: device work of concurrent callers (the C API
 		// is callable from many threads, reference capi threading contract) is serialised per engine; host preparation is not
@@ -513,6 +514,8 @@ namespace kamd
 			if ((uint64_t)b.packBase[c] + 3 * ncap > 0xFFFFFFFFull) throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
 			b.packBase[c + 1] = b.packBase[c] + (uint32_t)(3 * ncap);
 			if (slotMode && sc == 1 && !tinyArenas && I.stateScaleForced) scap = std::max<uint64_t>(scap * I.stateScale64[0] / 64, 64);      // (KAMD_STATE_SCALE: tests of the growth into the pool)
+			// (half the worst case: two chunks in a thousand need more -- c3-sbg: the 99.9th percentile used 35/64 of it -- and grow into the pool)
+			if (slotMode && sc == 1 && !tinyArenas && !I.stateScaleForced) scap = std::max<uint64_t>(scap / 2, 64);
 			if (slotMode) { slotCap = std::max(slotCap, scap); scap = 0; }      // (the arenas are the search kernel's lane groups', each large enough for the batch's longest chunk)
 			b.stateBase[c + 1] = b.stateBase[c] + scap;
 			b.tokenBase[c + 1] = b.tokenBase[c] + tcap;
@@ -597,7 +600,7 @@ namespace kamd
 		if (slotCap > 0x7FFFFFFFull) throw std::runtime_error{ "chunk too long for a state arena" };
 		b.slotCap = (uint32_t)slotCap;
 		const uint64_t ownStates = slotMode ? (uint64_t)I.histSlots() * slotCap : b.stateBase[nC];
-		b.poolStates = tinyArenas ? 0 : slotMode ? (I.poolForced ? ownStates * I.poolFrac64 / 64 : ownStates / 8)
+		b.poolStates = tinyArenas ? 0 : slotMode ? (I.poolForced ? ownStates * I.poolFrac64 / 64 : ownStates / 4)
 			: std::max<uint64_t>(ownStates * I.poolFrac64 / 64, I.poolFrac64 ? std::min<uint64_t>(ownStates, 1u << 16) : 0);
 		b.ownStates = ownStates;
 		const uint64_t totStates = ownStates + b.poolStates, totTokens = b.tokenBase[nC];
@@ -907,8 +910,8 @@ namespace kamd
 		const uint32_t nGroups = (I.histStates() || b.typo.typo || I.hasCong) ? (variant64 ? 1u : 4u)
 			: 64u / (uint32_t)(I.groupLanesForced ? I.groupLanes : 8);   // most groups per wave a launch below may use
 		const uint32_t maxWork = (nC + S - 1) / S + 1;
-		// (the SkipBigram kernel is built for 2 waves per SIMD and carries 1.8 MB of item scratch per lane group: 8 persistent blocks per CU)
-		const uint32_t persistBlocks = I.histStates() ? I.persistBlocks / 12 * 8 : I.persistBlocks;
+		// (the history kernels are built for 3 waves per SIMD and carry 1.8 MB of item scratch per lane group: 12 persistent blocks per CU)
+		const uint32_t persistBlocks = I.histStates() ? I.persistBlocks / 12 * I.histBlocksPerCu() : I.persistBlocks;
 		const uint32_t maxBlocks = std::min(persistBlocks, (maxWork + nGroups - 1) / nGroups);
 		const size_t groupScratchBytes = I.hasSbg ? sizeof(GroupScratchT<BIGQ_SBG>) : I.hasCongG ? sizeof(GroupScratchCong<BIGQ_SBG>) : I.hasCong ? sizeof(GroupScratchCong<BIGQ>) : sizeof(GroupScratch);
 		I.bigScratch.ensure((size_t)maxBlocks * nGroups * groupScratchBytes * std::min(S, 2u));
@@ -1096,7 +1099,9 @@ namespace kamd
 			const int wps = b.typo.typo ? 2 : I.wpsForced ? I.wpsForced : ((many && (gl == 8 || gl == 16)) ? 3 : 2);
 			const uint32_t nGroupsK = 64u / (uint32_t)gl;
 			const uint32_t blocksK = std::min(persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
-			const uint32_t ldsK = searchKernelLdsBytes(gl);
+			// (the history compilations have their own LDS layout: smaller caches of the chunk, so that three waves per SIMD fit)
+			const uint32_t ldsK = I.hasSbg ? (b.typo.typo ? typok::sbgk::histKernelLdsBytes(gl) : sbgk::histKernelLdsBytes(gl))
+				: I.hasCongG ? (b.typo.typo ? typok::congk::gk::histKernelLdsBytes(gl) : congk::gk::histKernelLdsBytes(gl)) : searchKernelLdsBytes(gl);
 			if (usePos)
 			{
 				const bool wide = I.wpsForced ? I.wpsForced == 3 : cn >= 16384;      // many chunks: three waves per SIMD (what the kernel's LDS allows; a 168-VGPR build); few: the latency-bound regime (KAMD_WPS overrides)

@@ -202,9 +202,16 @@ namespace sbgk
 		static constexpr uint32_t RLIVE = REND + 4 * RING;          // u32[RING]: live paths of nodes 0..j (running total)
 		// G == 64 (one chunk per wave): the chunk's lattice, candidate records and path heads are kept LDS-resident, so
 		// that inside the node loop only the Knlm walk reads HBM
+#ifdef KAMD_HIST
+		// (the history compilations run three waves per SIMD, KAMD_HIST_WPS below: 13 KB of LDS per wave)
+		static constexpr uint32_t HCAP = G == 64 ? 192 : 0;
+		static constexpr uint32_t NCAP = G == 64 ? 64 : 0;
+		static constexpr uint32_t PCAP = G == 64 ? 64 : 0;
+#else
 		static constexpr uint32_t HCAP = G == 64 ? 256 : 0;         // hot state quads (+ typo cost) cached
 		static constexpr uint32_t NCAP = G == 64 ? 96 : 0;          // lattice nodes cached
 		static constexpr uint32_t PCAP = G == 64 ? 160 : 0;         // static candidate records cached
+#endif
 		static constexpr uint32_t HOT = (RLIVE + 4 * RING + 15) & ~15u;   // uint4[HCAP]
 		static constexpr uint32_t HTYPO = HOT + 16 * HCAP;          // f32[HCAP]
 		static constexpr uint32_t NODES = HTYPO + 4 * HCAP;         // 32 B x NCAP
@@ -218,6 +225,9 @@ namespace sbgk
 		static constexpr uint32_t LB = (64 / G) * SIZE;              // f32[2*T_MAX+1], shared by the groups
 		static constexpr uint32_t TOTAL = LB + 4 * (2 * T_MAX + 1);
 	};
+#ifdef KAMD_HIST
+	uint32_t histKernelLdsBytes(int G) { return G == 16 ? Lay<16>::TOTAL : Lay<64>::TOTAL; }      // (this compilation's own layout: its LDS caches of the chunk differ from the Knlm kernel's)
+#endif
 #ifndef KAMD_VARIANT
 	uint32_t searchKernelLdsBytes(int G)
 	{
@@ -1086,7 +1096,11 @@ namespace sbgk
 			// top-N: the items of a container key linked into a list through the same table (SbgScratch::next): the count of better items below walks the
 			// key's own list.  Same slots, same cleaning; the key leaves the previous root out and compares the last four ring words (keyMask / last4).
 			const bool listed = X.P.topN > 1 && !fast;
-			constexpr uint32_t TMASK = 2 * BIGQ_SBG - 1;
+			// the table's live part is sized by the node: four slots per item (a power of two, at least 256).  The whole table is 1 MB per lane group -- 2 GB over
+			// the groups of a launch, every atomic an L2 miss --; the part a typical node needs stays in the L2 from node to node (MI355X: 39 % of the kernel's L2
+			// requests missed, 549 M atomics per 8192 sentences, profiles/r05_o_*)
+			uint32_t TMASK = 255u;
+			while (TMASK + 1u < 4u * Qtot && TMASK < 2u * BIGQ_SBG - 1u) TMASK = 2u * TMASK + 1u;
 			if (listed)
 			{
 				for (uint32_t qb = 0; qb < Qtot; qb += G)
@@ -1582,7 +1596,8 @@ namespace sbgk
 				{
 					// unique contexts + unique history words of the live socket-free paths, through the (free) key table of the item scratch: a slot is claimed
 					// per distinct value (contexts and words are numbered apart), the claims counted, the slots freed again
-					constexpr uint32_t TM = 2 * BIGQ_SBG - 1;
+					uint32_t TM = 255u;      // (the live part of the table follows the node: at most eight values per path, two slots per value)
+					while (TM + 1u < 16u * E.nP && TM < 2u * BIGQ_SBG - 1u) TM = 2u * TM + 1u;
 					uint32_t m = 0, maxProbe = 0;      // (maxProbe: the longest probe sequence of the claims; the freeing pass walks that far past freed slots)
 					for (int pass = 0; pass < 2; ++pass)      // pass 0: claim and count; pass 1: free
 					{
@@ -2641,7 +2656,15 @@ namespace sbgk
 	// WPS = waves per SIMD the kernel is compiled for (register budget 512 / WPS): 2 is fastest when a batch is small enough
 	// to be latency-bound (c2: 8192 chunks), 3 (with a few spills) when there are chunks to fill the extra wave slots
 	template<int G, int WPS>
-	__global__ void __launch_bounds__(64, WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S) TYPO_ONLY(, const float* nodeTypoAll) CONG_ONLY(, CongDev CGv) CONGG_ONLY(, CongGDev GGv))
+#ifdef KAMD_HIST
+	// The history compilations (SkipBigram, global CoNgram) are built for THREE waves per SIMD whatever WPS says: their chunks take milliseconds each, a launch is
+	// bound by how many are in flight, and twelve one-wave blocks per CU measured 12 - 16 % faster than eight (MI355X: c3-sbg 159 -> 138 ms per 16 384 sentences,
+	// c4-cong-global 346 -> 308 ms per 32 768; four per SIMD: no further gain) although the 168-VGPR build spills more (profiles/r05_p_*)
+#define KAMD_KERNEL_WPS 3
+#else
+#define KAMD_KERNEL_WPS WPS
+#endif
+	__global__ void __launch_bounds__(64, KAMD_KERNEL_WPS) k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork SBG_ONLY(, SbgDev S) TYPO_ONLY(, const float* nodeTypoAll) CONG_ONLY(, CongDev CGv) CONGG_ONLY(, CongGDev GGv))
 	{
 		constexpr int NG = 64 / G;
 		if (W.posHandOver && *W.posHandOver == 0) return;      // the position-step kernel ran before and left nothing to do

@@ -48,6 +48,7 @@ namespace kamd
 	// code that was measured.  G = 16 or 64, WPS = 2.
 	namespace sbgk
 	{
+		uint32_t histKernelLdsBytes(int G);      // dynamic LDS of this compilation's k_best_path<G, .> (G = 16 or 64)
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, SbgDev S);
 	}
@@ -77,17 +78,20 @@ namespace kamd
 	{
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, CongDev CG, CongGDev GG);
+		uint32_t histKernelLdsBytes(int G);
 	} }
 	namespace typok { namespace congk { namespace gk
 	{
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, const float* nodeTypo, CongDev CG, CongGDev GG);
+		uint32_t histKernelLdsBytes(int G);
 	} } }
 	// ... and for typo correction with a SkipBigram model (viterbi_kernel_sbg_typo.hip, KAMD_TYPO + KAMD_SBG)
 	namespace typok { namespace sbgk
 	{
 		template<int G, int WPS>
 		__global__ void k_best_path(ModelView M, BatchView B, WorkView W, SearchParams P, uint32_t* chunkCounter, const uint32_t* chunkOrder, uint32_t nWork, SbgDev S, const float* nodeTypo);
+		uint32_t histKernelLdsBytes(int G);
 	} }
 	// The position-step search (viterbi_pos.inc): the common case of the search above, one END POSITION of the lattice per step over the position
 	// program written by k_expand_pos; it leaves in DevChunkResult::pad the node k_best_path -- launched over all chunks afterwards -- carries on at
