@@ -1364,7 +1364,7 @@ namespace kamd
 				fprintf(stderr, "[timeline] %-26s mean %9.1f  p50 %9.1f  p90 %9.1f  p99 %9.1f  max %9.1f  (us, n=%zu)\n", name, sum / v.size(), v[v.size() / 2], v[v.size() * 9 / 10], v[v.size() * 99 / 100], v.back(), v.size());
 			};
 			fprintf(stderr, "[timeline] first chunk start -> last chunk end: %.1f us\n", (tEnd - t0) * 0.01);
-			static const char* phName[12] = { "ph0 node setup", "ph1 cand record + misc", "ph2 scoring (+Knlm)", "ph3 emission: write states", "ph4 prune", "ph5 bookkeeping", "ph6 passes/reach", "ph7 emission: dedup", "ph8 classify (pack load)", "ph9 batch formation", "ph10", "ph11" };
+			static const char* phName[12] = { "ph0 node setup", "ph1 cand record + misc", "ph2 scoring (+Knlm)", "ph3 emission: write states", "ph4 prune", "ph5 bookkeeping", "ph6 passes/reach", "ph7 scoring: before the LM step", "ph8 classify (pack load)", "ph9 batch formation + key table build", "ph10 scoring: Knlm step", "ph11" };
 			for (int k = 0; k < 10; ++k)
 			{
 				std::vector<double> v;

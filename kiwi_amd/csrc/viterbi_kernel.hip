@@ -824,6 +824,46 @@ namespace sbgk
 		const bool last4 = X.P.topN > 1;   // what of the ring belongs to the container key (sameRing)
 #endif
 
+#ifndef KAMD_CONG
+		// A right half of a split stem (socket, several chunks) takes the combined word id of the LATEST matching left half among the paths up to its own
+		// (PathEvaluator.hpp:578-591: `firstWid` is assigned inside the loop over the paths and never reset).  Looked for path by path from every item, that is
+		// quadratic in the node's paths -- a SkipBigram node of a thousand paths spent a third of its time there (profiles/r05_s_*) --: with more items than the
+		// LDS queues hold, one pass over the paths per such candidate leaves every item the index of that path (0xFFFFFFFF: none) where its first-chunk score
+		// will go (GroupScratch::fcs, written by the item itself at the end of its scoring).
+		bool rightHalves = false;
+		if (big)
+		{
+			for (uint32_t k = X.gl; k < nC; k += G) { const Cand c = loadCand(X.candOff(k)); rightHalves |= c.socket() && !c.single(); }
+			rightHalves = X.any(rightHalves);
+		}
+		if (rightHalves)
+		{
+			const bool never = spaceBefore && !(X.P.spaceTol > 0);
+			for (uint32_t k = 0; k < nC; ++k)
+			{
+				const Cand c = loadCand(X.candOff(k));
+				if (!(c.socket() && !c.single())) continue;      // (uniform)
+				const uint8_t ctag = c.tag(), csock = c.socket();
+				uint32_t carry = 0xFFFFFFFFu;
+				for (uint32_t pb = 0; pb < E.nP; pb += G)
+				{
+					const uint32_t p = pb + X.gl;
+					bool m = false;
+					if (p < E.nP && !never)
+					{
+						const Hot qs = getHot<G>(X, pBeg + p);
+						m = !qs.dead() && qs.socket() && qs.socket() == csock && !((qs.leftFeat() & LF_PREV_ZSIOT) && (!isNNClass(ctag) || spaceBefore));
+					}
+					const uint64_t bal = X.ballot(m);
+					const uint64_t upTo = bal & (X.gl >= 63u ? ~0ull : ((2ull << X.gl) - 1ull));
+					const uint32_t last = upTo ? pb + 63u - (uint32_t)__builtin_clzll((unsigned long long)upTo) : carry;
+					if (p < E.nP) for (uint32_t r = 0; r < c.R; ++r) reinterpret_cast<uint32_t*>(X.scratch->fcs)[c.qOff + p * c.R + r] = last;
+					if (bal) carry = pb + 63u - (uint32_t)__builtin_clzll((unsigned long long)bal);
+				}
+			}
+			waveSync();
+		}
+#endif
 		// ---- scoring pass: one work item per lane -------------------------------------------------------
 		for (uint32_t qb = 0; qb < Qtot; qb += G)
 		{
@@ -873,7 +913,12 @@ namespace sbgk
 					if (csock && !single) { firstWid = M.morphs[M.morphs[X.st[pBeg + p].wid].combinedId].lmId; widReplaced = true; }
 					if (false)
 #else
-					if (csock && !single)
+					if (csock && !single && rightHalves)
+					{
+						const uint32_t pp = reinterpret_cast<const uint32_t*>(X.scratch->fcs)[q];      // (the pass over the paths above)
+						if (pp != 0xFFFFFFFFu) { firstWid = M.morphs[M.morphs[X.st[pBeg + pp].wid].combinedId].lmId; widReplaced = true; }
+					}
+					else if (csock && !single)
 #endif
 					{
 						// the reference keeps the combined word id of the latest matching split stem for all later predecessors
@@ -918,7 +963,9 @@ namespace sbgk
 						cand += ll; firstChunk += ll;
 						cand += icDeferred;
 #else
+						TLMARK(X, 7)      // (timeline builds: lane 0's item -- what came before the first LM step of the pass)
 						float ll = lmProgress(M, lmNode, firstWid);
+						TLMARK(X, 10)     // (... the Knlm step; the SkipBigram mixture and the rest of the pass go to phase 2)
 						SBG_ONLY(ll = sbgNext(*X.S, ring.h, ring.pos, firstWid, ll);)
 						cand += ll; firstChunk += ll;
 #endif
@@ -961,7 +1008,7 @@ namespace sbgk
 				// key: LM node | new special state | previous root | candidate ; r is recoverable from q
 				const uint64_t key = valid ? ((uint64_t)(uint32_t)lmNode | ((uint64_t)sp << 32) | ((uint64_t)rootKey << 40) | ((uint64_t)k << 48)) : KINVALID;
 				rKey = key; rScore = cand; rFcs = firstChunk;
-				CONG_ONLY(rCtx = ctx; if (!fast) { if (big) X.scratch->ctx[q] = ctx; else X.qCtx()[q] = ctx; })
+				CONG_ONLY(rCtx = ctx; if (!fast HIST_ONLY(|| true)) { if (big) X.scratch->ctx[q] = ctx; else X.qCtx()[q] = ctx; })      // (history compilations: the register path may hand the batch to the scanning path)
 #ifdef KAMD_HIST
 				// the LM state of the item beyond the Knlm node; the queues are filled on the register path too, which hands a
 				// batch over to the scanning path when two digests collide
@@ -1271,6 +1318,7 @@ namespace sbgk
 				return nC;
 			};
 #endif
+			TLMARK(X, 9)      // (timeline builds: the key table is built -- phase 9 otherwise holds the batch formation, a fraction of a microsecond per node)
 			for (int b = 0; b < nBuckets; ++b)
 			{
 				uint32_t emittedInBucket = 0;
