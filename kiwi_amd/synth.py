@@ -345,9 +345,9 @@ class SynthSpec:
 
 
 FULL_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
-                      n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3)  # order 3: build_knlm packs an n-gram into 63 bits
+                      n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=4)  # order 4, the reference's maximum and what SURVEY.md section 8(d) names (rounds 1-4: order 3 -- build_knlm packed an n-gram into 63 bits)
 FULL_SBG_SPEC = SynthSpec(n_words=118000, n_josa=90, n_eomi=260, n_contract=9000, n_irregular=400,
-                          n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=3, use_sbg=True,   # FULL_SPEC's lexicon + skip-bigram tables (32-bit keys)
+                          n_complex=3000, n_spaced=800, lm_sentences=400000, lm_order=4, use_sbg=True,   # FULL_SPEC's lexicon + skip-bigram tables (32-bit keys)
                           homonym_skew=4.0, lm_unk_rate=0.03)      # round 4: one reading of a homograph dominates, unknown NNG / NNP readings differ (a SkipBigram search needs both to prune: see the fields)
 SMALL_SPEC = SynthSpec()
 SMALL_ORDER4_SPEC = SynthSpec(lm_order=4, lm_sentences=60000)   # an order-4 Knlm (the reference's maximum, include/kiwi/Kiwi.h:611): contexts of three words, back-off chains one node longer than what a search state carries
@@ -923,7 +923,10 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
     hist = flat if htx is None else htx[flat]
     key_space = int(max(vocab_size, 0 if htx is None else int(htx.max()) + 1)) + 1
     bits = max(1, (key_space - 1).bit_length())
-    assert bits * order <= 63
+    # an n-gram is packed into ONE integer key: 64-bit where that holds `order` tokens, arbitrary-precision Python integers (numpy object arrays: the same
+    # operators, unique / searchsorted by Python comparisons -- minutes instead of seconds for the 'full' models) where it does not (order 4 over 2^17 words)
+    wide = bits * order > 63
+    kt = object if wide else np.int64
     # n-gram tables: dict order -> (keys[n, order] sorted, counts)
     grams = {}
     n_tok = len(flat)
@@ -934,9 +937,9 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
         cols = [flat[idx + k] for k in range(n)]
         if htx is not None and n >= 2:
             cols[0] = hist[idx]
-        code = np.zeros(len(idx), dtype=np.int64)
+        code = np.zeros(len(idx), dtype=kt)
         for c in cols:
-            code = (code << bits) | c
+            code = (code << bits) | (c.astype(kt) if wide else c)
         u, cnt = np.unique(code, return_counts=True)
         grams[n] = (u, cnt.astype(np.float64))
 
@@ -945,13 +948,13 @@ def build_knlm(sents, vocab_size, order, htx=None, discount=0.75, unk_id=2, bos_
         if htx is None or n < 2:
             return code
         sh = bits * (n - 1)
-        top = (code >> sh) & ((1 << bits) - 1)
-        return (code & ((1 << sh) - 1)) | (htx[top].astype(np.int64) << sh)
+        top = ((code >> sh) & ((1 << bits) - 1)).astype(np.int64)
+        return (code & ((1 << sh) - 1)) | (htx[top].astype(np.int64).astype(kt) << sh)
 
     def split(code, n):
         cols = []
         for k in range(n):
-            cols.append((code >> (bits * (n - 1 - k))) & ((1 << bits) - 1))
+            cols.append(((code >> (bits * (n - 1 - k))) & ((1 << bits) - 1)).astype(np.int64))
         return np.stack(cols, axis=1) if n else np.zeros((len(code), 0), np.int64)
 
     # continuation counts for lower orders: N1+(• w) of the (n+1)-grams whose suffix is this n-gram

@@ -148,16 +148,45 @@ def dialect_model():
     return path
 
 
+def _unpack_model(model_path: str) -> bool:
+    """The 'full' models travel xz-compressed (`_data/<spec>.raw.xz`, 35 MB instead of 120: the snapshot of the repository that goes to a GPU box is capped; the
+    uncompressed files are listed in .gpurunignore) and are unpacked on first use -- two seconds, against minutes for generating one.  True: the file is there."""
+    if os.path.exists(model_path):
+        return True
+    if not os.path.exists(model_path + ".xz"):
+        return False
+    import lzma
+    import shutil
+    tmp = f"{model_path}.{os.getpid()}.tmp"      # (several ranks may get here at once: each unpacks its own copy, the rename is atomic)
+    with lzma.open(model_path + ".xz", "rb") as src, open(tmp, "wb") as dst:
+        shutil.copyfileobj(src, dst, 1 << 24)
+    os.replace(tmp, model_path)
+    return True
+
+
+def _pack_model(model_path: str):
+    import subprocess
+    try:
+        with open(model_path + ".xz.tmp", "wb") as out:
+            subprocess.check_call(["xz", "-T0", "-3", "-k", "-c", model_path], stdout=out)
+        os.replace(model_path + ".xz.tmp", model_path + ".xz")
+    except (OSError, subprocess.CalledProcessError):      # (no xz binary: the uncompressed file alone)
+        if os.path.exists(model_path + ".xz.tmp"):
+            os.remove(model_path + ".xz.tmp")
+
+
 def get_workload(name: str):
     """Returns (raw_model_path, list_of_texts, description)."""
     spec_name, n, kw, idx = WORKLOADS[name]
     os.makedirs(DATA, exist_ok=True)
     model_path = os.path.join(DATA, f"{spec_name}.raw")
     corpus_path = os.path.join(DATA, f"{name}.corpus.txt")
-    if not (os.path.exists(model_path) and os.path.exists(corpus_path)):
+    if not (_unpack_model(model_path) and os.path.exists(corpus_path)):
         from .synth import SEED_BASE, SynthModel
         sm = SynthModel(_spec(spec_name))
         sm.raw.save(model_path)
+        if spec_name.startswith("full"):
+            _pack_model(model_path)
         for wname, (sname, wn, wkw, widx) in WORKLOADS.items():     # the grammar object is expensive: make every corpus of this model now
             if sname != spec_name:
                 continue

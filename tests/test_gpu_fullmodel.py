@@ -197,9 +197,7 @@ def test_c3_sbg_2k_sentences_top3_vs_oracle_and_reference():
     from kiwi_amd.workloads import get_workload
     from kiwi_amd.workloads import DATA
     _, texts, _ = get_workload("c3")      # (the same mixed 5-200 jamo sentence generator as c3-sbg over the same lexicon; its corpus file travels anyway)
-    path = os.path.join(DATA, "full-sbg.raw")
-    if not os.path.exists(path):
-        path, _, _ = get_workload("c3-sbg")      # (generates the model: minutes)
+    path, _, _ = get_workload("c3-sbg")      # (unpacks the model, or generates it: minutes)
     texts = texts[:2048]
     dev = KiwiAmd(path)
     got = dev.analyze_batch(texts, top_n=3).to_python()
