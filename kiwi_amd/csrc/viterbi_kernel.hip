@@ -443,8 +443,6 @@ namespace sbgk
 		return result;
 	}
 #endif
-	}
-#endif
 
 #ifdef KAMD_CONG
 	__device__ __forceinline__ int32_t dot4s8(uint32_t a, uint32_t b, int32_t acc)
