@@ -28,8 +28,7 @@ def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None, time_refe
     cores = os.cpu_count() or 1
     orc = oraclelib.OracleKiwi(model_path)
     if cong_global:
-        orc.set_cong_global(True)      # (the event counts of the global scoring; only with time_reference=False: the timed runners below open the model type the file names)
-        assert not time_reference
+        orc.set_cong_global(True)      # (the global scoring: event counts here, and both timed runners below)
     orc_typo = ref_typo = None
     thr = 2.5
     if typo is not None:      # the same rules on both CPU sides
@@ -60,7 +59,7 @@ def cpu_baseline(model_path, texts, budget_s=20.0, top_n=1, typo=None, time_refe
                 arch, arch_name = (4, "avx2") if " avx2" in flags else (3, "sse4_1") if " sse4_1" in flags else (0, "none")
             except OSError:
                 pass
-        ref = refbridge.RefKiwi(model_path, arch=arch, x86=arch > 0)
+        ref = refbridge.RefKiwi(model_path, arch=arch, x86=arch > 0, model_dir_sbg="cong_global") if cong_global else refbridge.RefKiwi(model_path, arch=arch, x86=arch > 0)
         kind, runner, rtypo = "reference", ref, ref_typo
     else:
         kind, runner, rtypo = "port", orc, orc_typo
@@ -280,7 +279,7 @@ def main():
     import torch
     from kiwi_amd import dist
     from kiwi_amd.api import KiwiAmd
-    from kiwi_amd.workloads import fill_typo_rules, get_workload, workload_top_n, workload_typo
+    from kiwi_amd.workloads import fill_typo_rules, get_workload, workload_lm_mode, workload_top_n, workload_typo
     rank, local_rank, world = dist.env_rank_world()
     if world > 1:
         dist.init("nccl", local_rank)
@@ -304,7 +303,7 @@ def main():
         # one process per GPU on one host: the ranks share the container's CPUs -- each takes its share of the two-workers-per-quota-CPU pool
         # (hostpool.hpp) instead of a whole one (N pools of that size used the quota up: CFS throttling, profiles/r04_t_cfs_throttling.txt)
         os.environ["KAMD_HOST_THREADS"] = str(max(2, int(2 * (cpu_quota_cores() or os.cpu_count() or 2) / world)))
-    eng = KiwiAmd(model_path, local_rank)
+    eng = KiwiAmd(model_path, local_rank, lm_mode=workload_lm_mode(args.workload))
     typo_cfg, typo = workload_typo(args.workload), None
     if typo_cfg is not None:
         from kiwi_amd.api import Typo
@@ -444,7 +443,7 @@ def main():
                        "kernel_ms": kt, "device_bytes": info["device_bytes"], "rerun_chunks": rerun_chunks, "rerun_ms": rerun_ms},
         }
         if not args.no_cpu_baseline and not args.kernels_only:
-            cb = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg, time_reference=world == 1)
+            cb = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg, time_reference=world == 1, cong_global=workload_lm_mode(args.workload) == 4)
             per = cb["alg_bytes_per_sentence"]
             search_bytes = per["search"] * n
             achieved = search_bytes / (kt["search_ms"] * 1e-3) / 1e9

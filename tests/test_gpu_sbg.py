@@ -78,3 +78,34 @@ def test_skipbigram_golden_sequence_from_reference(small_sbg_model):
     same = sum(1 for it, y in zip(g["items"], got) if y and y[0][1] == it["analyses"][0]["score"])
     assert same >= 0.99 * len(texts), (same, len(texts))
     dev.close()
+
+
+@pytest.mark.parametrize("model,lanes,top_n,pool", [("sbg", "64", 1, "4096"), ("sbg", "64", 3, "4096"), ("sbg", "64", 2, "6"), ("knlm", "pos", 1, "2048"), ("knlm", "16", 2, "2048")])
+def test_state_arenas_grow_into_the_pool(small_model, small_sbg_model, monkeypatch, model, lanes, top_n, pool):
+    """Arenas of 1/64 of the worst case (KAMD_STATE_SCALE=1): most chunks fill theirs and carry on in arenas from the batch's pool (growArena: one atomic add on
+    the pool's counter, the states so far move, the node that met the full arena is evaluated again; the end stage grows the same way) -- same analyses as the
+    oracle's.  A pool of 6/64 of the arenas runs out: the chunks it could not serve go through the re-run ladder.  SkipBigram: arenas of the lane groups, the end
+    stage inside the search kernel (finishPathsSolo)."""
+    import oraclelib
+    from corpora import force_lanes
+    from kiwi_amd.api import KiwiAmd
+    sm, path = small_sbg_model if model == "sbg" else small_model
+    force_lanes(monkeypatch, lanes)
+    monkeypatch.setenv("KAMD_STATE_SCALE", "1")
+    monkeypatch.setenv("KAMD_STATE_POOL", pool)
+    orc = oraclelib.OracleKiwi(path)
+    dev = KiwiAmd(path)
+    texts = [t for t in synthetic(sm, 400, 571, min_jamo=20, max_jamo=120) + dictionary_mix(sm, 100, 572) if t.strip()]
+    b = dev.stage(texts)
+    got = dev.fetch(b, top_n).to_python()
+    for s, y in zip(texts, got):
+        assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), s
+    p = b.pool()
+    reruns, _ = dev.reruns(b)
+    assert p["pool_states"] >= p["arena_states"] * int(pool) // 64 and p["pool_asked"] > p["arena_states"] // 2, p
+    if pool == "6":      # (a pool this small runs out where the arenas are few -- the emulator's handful of blocks; the MI355X's 3072 lane groups make even 6/64 of them large)
+        assert reruns > 0 or p["pool_asked"] <= p["pool_states"], (p, reruns)
+    else:
+        assert p["pool_asked"] <= p["pool_states"] and (reruns == 0 or model == "knlm"), (p, reruns)
+    b.close()
+    dev.close()

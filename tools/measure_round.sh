@@ -22,7 +22,7 @@ out, wl = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kamd::", "").replace("typok::", "").replace("congk::", "").replace("sbgk::", "")
+        k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("kamd::", "").replace("typok::", "").replace("congk::", "").replace("gk::", "").replace("sbgk::", "")
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items() if k.startswith("k_")}
 json.dump(summ, open(out + f"/pmc_summary_{wl}.json", "w"), indent=1, sort_keys=True)
