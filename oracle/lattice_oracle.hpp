@@ -42,6 +42,9 @@ namespace korc
 		// probes; congDim = the embedding dimension (0: not a CoNgram model)
 		uint64_t congCtxRows = 0, congOutRows = 0, congScores = 0, congProbes = 0, congProbeKeyBytes = 0, congRootProbes = 0, congDim = 0;
 		uint64_t congGlobalScores = 0;      // of congScores: mixtures over the history window (global model, valid distant tokens)
+		// typo lattices (round 5; the plain counters above count a typo lattice's events too): graph nodes visited (28-byte records), search-state transitions
+		// (progressNode calls: the 44-byte fixed part of a state read, and written for every state that lives on)
+		uint64_t typoGraphNodes = 0, typoStateSteps = 0, typoStatesKept = 0;
 		uint64_t congPast64 = 0;            // global model: insertions into a path container that already holds 64 entries (the reference's SIMD lookup misbehaves there)
 	};
 

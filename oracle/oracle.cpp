@@ -137,6 +137,7 @@ namespace
 		}
 		LatticeBuilder lb{ h.view, sc, cnt };
 		TypoLatticeBuilder tlb{ h.view, sc };
+		tlb.countInto(&cnt);
 		ResultBuilder rb{ h.model, topN, match, h.integrateAllomorph };
 		rb.begin(text, len, pt.position.data(), pt.position.size());
 		std::vector<LNode> nodes;

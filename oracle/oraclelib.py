@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 COUNTER_NAMES = ["inputUnits", "trieProbes", "trieProbeKeyBytes", "failHops", "candEmits", "otherNodes",
                  "transitions", "candMorphs", "statesWritten", "lmProbes", "lmProbeKeyBytes", "lmRootProbes", "tokens",
                  "maxPrevPaths", "nodesOver128", "nodesOver512", "lattNodes", "sbgEvals", "sbgProbeKeyBytes", "sbgHits", "sbgModel",
-                 "congCtxRows", "congOutRows", "congScores", "congProbes", "congProbeKeyBytes", "congRootProbes", "congDim", "congGlobalScores", "congPast64"]
+                 "congCtxRows", "congOutRows", "congScores", "congProbes", "congProbeKeyBytes", "congRootProbes", "congDim", "congGlobalScores", "typoGraphNodes", "typoStateSteps", "typoStatesKept", "congPast64"]
 
 
 def available() -> bool:
@@ -237,7 +237,10 @@ def alg_bytes(c: dict) -> dict:
     """ALG_BYTES v1: algorithmic bytes from oracle event counts, no cache credit.
     Returns the split used by bench.py: dictionary scan + lattice build ('lattice') and best-path search ('search')."""
     lattice = (2 * c["inputUnits"] + c["trieProbes"] * (12 + 4) + c["trieProbeKeyBytes"] + c["failHops"] * 8
-               + c["candEmits"] * (16 + 24) + c["otherNodes"] * 24)
+               + c["candEmits"] * (16 + 24) + c["otherNodes"] * 24
+               # typo lattices (DESIGN.md, round 5): 28 B per typo-graph node, 44 B (the fixed part of a search state) read per state transition and written per
+               # state that lives on; their trie probes, fail hops and node appends are in the counters above
+               + c.get("typoGraphNodes", 0) * 28 + c.get("typoStateSteps", 0) * 44 + c.get("typoStatesKept", 0) * 44)
     # S: the SkipBigram state carries the 8-word history ring (SURVEY.md section 8(d)); so does the state of the global CoNgram model (7 words + a spare)
     state = 48 if (c.get("sbgModel") or c.get("congGlobalScores")) else 32
     search = (c["transitions"] * state + c["candMorphs"] * 16 + c["statesWritten"] * state

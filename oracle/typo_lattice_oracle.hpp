@@ -29,6 +29,7 @@ namespace korc
 		float typoThreshold = 2.5f, lengtheningCost = INFINITY;
 		bool lengthening = false;
 		const PatternSpan* pat = nullptr; const PatternSpan* patEnd = nullptr;
+		Counters* cnt = nullptr;      // ALG_BYTES events, as LatticeBuilder counts them + the typo-graph / search-state events
 
 		struct SState
 		{
@@ -83,14 +84,14 @@ namespace korc
 				if (lastPos != s && !hasFormAlready(lastPos << pmb, e << pmb))
 				{
 					uint32_t o, l; trimmed(nsToPos[lastPos], nsToPos[e - 1] + 1 - nsToPos[lastPos], o, l);
-					append(lastPos << pmb, e << pmb, NOFORM, o, l);
+					if (append(lastPos << pmb, e << pmb, NOFORM, o, l) && cnt) cnt->otherNodes++;
 				}
 			}
 			const uint32_t limit = hasJ ? cfg.maxUnkJ : cfg.maxUnk;
 			if (e - s <= limit)
 			{
 				uint32_t o, l; trimmed(nsToPos[s], nsToPos[e - 1] + 1 - nsToPos[s], o, l);
-				append(s << pmb, e << pmb, NOFORM, o, l);
+				if (append(s << pmb, e << pmb, NOFORM, o, l) && cnt) cnt->otherNodes++;
 			}
 		}
 		void unkPair(uint32_t boundary, uint32_t unkStart, uint32_t e, bool hasJ)
@@ -113,8 +114,10 @@ namespace korc
 		}
 		int32_t trieNext(uint32_t node, uint16_t c) const
 		{
-			if (node == 0) { const uint32_t r = M.trieRoot[c]; return r ? (int32_t)r : -1; }
+			if (cnt) cnt->trieProbes++;
+			if (node == 0) { if (cnt) cnt->trieProbeKeyBytes += 4; const uint32_t r = M.trieRoot[c]; return r ? (int32_t)r : -1; }
 			const TrieNodeRec& t = M.trie[node];
+			if (cnt) { uint32_t l = 0; while ((1u << l) < t.numNexts) ++l; cnt->trieProbeKeyBytes += 2 * l; }
 			const uint16_t* kb = M.trieKeys + t.edgeOff;
 			const uint16_t* it = std::lower_bound(kb, kb + t.numNexts, c);
 			if (it == kb + t.numNexts || *it != c) return -1;
@@ -140,7 +143,7 @@ namespace korc
 				{
 					const uint32_t b2 = startCti ? (nb << pmb) + startCti : nb << pmb;
 					const uint32_t e2 = endCti ? ((ne - 1) << pmb) + endCti : ne << pmb;
-					if (append(b2, e2, fi, 0, 0, typoCost + (cd.lengthened ? lengtheningCost * (float)(3 + cd.lengthened) : 0.f))) out.back().spaceErrors = se;
+					if (append(b2, e2, fi, 0, 0, typoCost + (cd.lengthened ? lengtheningCost * (float)(3 + cd.lengthened) : 0.f))) { out.back().spaceErrors = se; if (cnt) cnt->candEmits++; }
 				}
 			}
 			cands.clear();
@@ -149,6 +152,7 @@ namespace korc
 		// progressNode (KTrie.cpp:998-1412), lengtheningTypoTolerant = false, no pretokenized spans
 		void progress(const typo::GraphNode& prevT, const typo::GraphNode& tn, const SState& st, std::vector<SState>& cur)
 		{
+			if (cnt) cnt->typoStateSteps++;
 			float typoCost = st.cost + tn.typoCost;
 			if (typoCost > typoThreshold) return;
 			uint32_t prevChr = st.lastChr;
@@ -185,7 +189,7 @@ namespace korc
 							const bool sj = T_SF <= lastType && lastType <= T_SW;
 							unkPair(boundary, unkStart, specialStart, sj);
 							uint32_t o, l; trimmed(nsToPos[specialStart], pos - nsToPos[specialStart], o, l);
-							append(specialStart << pmb, posToNs[pos] << pmb, lastType - 1u, o, l);
+							if (append(specialStart << pmb, posToNs[pos] << pmb, lastType - 1u, o, l) && cnt) cnt->otherNodes++;
 						}
 						unkStart = specialStart;
 						specialStart = posToNs[pos];
@@ -236,7 +240,7 @@ namespace korc
 						const uint32_t ms = pat->end - pat->length;
 						const bool wj = T_W_URL <= pat->tag && pat->tag <= T_W_EMOJI;
 						unkPair(boundary, unkStart, posToNs[ms], wj);
-						append(posToNs[ms] << pmb, posToNs[pat->end] << pmb, pat->tag - 1u, ms, pat->length);
+						if (append(posToNs[ms] << pmb, posToNs[pat->end] << pmb, pat->tag - 1u, ms, pat->length) && cnt) cnt->otherNodes++;
 						++pat;
 					}
 				}
@@ -276,6 +280,7 @@ namespace korc
 				while (nx < 0 && curNode >= 0)
 				{
 					curNode = M.trie[curNode].fail;      // -1 at the root
+					if (cnt) cnt->failHops++;
 					if (curNode < 0) break;
 					nx = trieNext((uint32_t)curNode, ch);
 				}
@@ -322,7 +327,7 @@ namespace korc
 					const bool sj = T_SF <= lastType && lastType <= T_SW;
 					unkPair(boundary, unkStart, specialStart, sj);
 					uint32_t o, l; trimmed(nsToPos[specialStart], tn.endPos - nsToPos[specialStart], o, l);
-					append(specialStart << pmb, posToNs[tn.endPos] << pmb, lastType - 1u, o, l);
+					if (append(specialStart << pmb, posToNs[tn.endPos] << pmb, lastType - 1u, o, l) && cnt) cnt->otherNodes++;
 					unkStart = specialStart;
 					if (sj) boundary = posToNs[tn.endPos];
 				}
@@ -343,12 +348,14 @@ namespace korc
 					ns.startCti = tn.continualTypoIdx ? tn.continualTypoIdx : st.startCti;
 					ns.lnodes = std::move(lnodes);
 					cur.push_back(std::move(ns));
+					if (cnt) cnt->typoStatesKept++;
 				}
 			}
 		}
 
 	public:
 		TypoLatticeBuilder(const ModelView& m, const SplitConfig& c) : M(m), cfg(c) {}
+		void countInto(Counters* c) { cnt = c; }
 
 		// The lattice of chunk str[0..len) over the typo graph `prepared` generates for it.  Same output conventions as LatticeBuilder::build.
 		bool build(std::vector<LNode>& ret, const char16_t* s, uint32_t len, const PatternSpan* patBegin, const PatternSpan* patEndIn, uint32_t startOffset,
@@ -371,6 +378,7 @@ namespace korc
 			// buildTypoGraph (KTrie.cpp:873-895)
 			size_t maxCti = 0;
 			graph = prepared.graph(std::u16string{ str, n }, allowedDialect, maxCti);
+			if (cnt) { cnt->inputUnits += n; cnt->typoGraphNodes += graph.size(); }
 			pmb = 0;
 			if (maxCti > 1) { size_t v = maxCti - 1; while (v > 0) { v >>= 1; ++pmb; } }
 			endPosMap.assign(((size_t)nNs << pmb) + 1, { 0xFFFFFFFFu, 0xFFFFFFFFu });
@@ -444,6 +452,7 @@ namespace korc
 				if (ret[i].uformLen) ret[i].uformOff += startOffset;
 			}
 			ret.back().startPos = ret.back().endPos = startOffset + n;
+			if (cnt) cnt->lattNodes += ret.size();
 			return ret.size() > 2;
 		}
 	};
