@@ -681,7 +681,7 @@ namespace sbgk
 		{
 			gl = o.gl; gshift = o.gshift; lds = o.lds; nodes = o.nodes; Gn = o.Gn; str = o.str; cls = o.cls; st = o.st; stCap = o.stCap; stTop = o.stTop;
 			nodeStOff = o.nodeStOff; nodeStCnt = o.nodeStCnt; nodeLive = o.nodeLive; uniq = o.uniq; nUniq = o.nUniq;
-			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; tl = o.tl;
+			overflow = o.overflow; pairOverflow = o.pairOverflow; stageOverflow = o.stageOverflow; scratch = o.scratch; tl = o.tl; compact = o.compact; nPE = o.nPE;
 			SBG_ONLY(S = o.S;) HIST_ONLY(hist = o.hist; sscr = o.sscr;)
 			TYPO_ONLY(typoAll = o.typoAll; nodeTypo = o.nodeTypo;)
 			CONG_ONLY(CG = o.CG; outFirst = o.outFirst;)
@@ -702,6 +702,7 @@ namespace sbgk
 		uint32_t* nodeStOff; uint32_t* nodeStCnt; uint16_t* nodeLive;   // HBM copies (far-back lookups, end node)
 		const uint8_t* uniq; uint32_t nUniq;
 		bool overflow, pairOverflow, stageOverflow;
+		bool compact; uint32_t nPE;      // the node's items are formed over its LIVE incoming paths (scratch->live, nPE of them) instead of all E.nP (evaluateNode)
 		GroupScratch* scratch;
 		unsigned long long* tl;     // per-chunk timeline record (KAMD_TIMELINE builds), else unused
 
@@ -845,20 +846,27 @@ namespace sbgk
 				if (!(c.socket() && !c.single())) continue;      // (uniform)
 				const uint8_t ctag = c.tag(), csock = c.socket();
 				uint32_t carry = 0xFFFFFFFFu;
-				for (uint32_t pb = 0; pb < E.nP; pb += G)
+				for (uint32_t jb = 0; jb < X.nPE; jb += G)
 				{
-					const uint32_t p = pb + X.gl;
+					const uint32_t j = jb + X.gl;      // the j-th path the items are formed over
+					uint32_t p = j;
 					bool m = false;
-					if (p < E.nP && !never)
+					if (j < X.nPE)
 					{
-						const Hot qs = getHot<G>(X, pBeg + p);
-						m = !qs.dead() && qs.socket() && qs.socket() == csock && !((qs.leftFeat() & LF_PREV_ZSIOT) && (!isNNClass(ctag) || spaceBefore));
+						if (X.compact) p = X.scratch->live[j];
+						if (!never)
+						{
+							const Hot qs = getHot<G>(X, pBeg + p);
+							m = !qs.dead() && qs.socket() && qs.socket() == csock && !((qs.leftFeat() & LF_PREV_ZSIOT) && (!isNNClass(ctag) || spaceBefore));
+						}
 					}
 					const uint64_t bal = X.ballot(m);
 					const uint64_t upTo = bal & (X.gl >= 63u ? ~0ull : ((2ull << X.gl) - 1ull));
-					const uint32_t last = upTo ? pb + 63u - (uint32_t)__builtin_clzll((unsigned long long)upTo) : carry;
-					if (p < E.nP) for (uint32_t r = 0; r < c.R; ++r) reinterpret_cast<uint32_t*>(X.scratch->fcs)[c.qOff + p * c.R + r] = last;
-					if (bal) carry = pb + 63u - (uint32_t)__builtin_clzll((unsigned long long)bal);
+					const uint32_t lastP = X.bcast(p, upTo ? 63 - (int)__builtin_clzll((unsigned long long)upTo) : 0);      // (the PATH of the latest match up to this lane)
+					const uint32_t last = upTo ? lastP : carry;
+					if (j < X.nPE) for (uint32_t r = 0; r < c.R; ++r) reinterpret_cast<uint32_t*>(X.scratch->fcs)[c.qOff + j * c.R + r] = last;
+					const uint32_t carryP = X.bcast(p, bal ? 63 - (int)__builtin_clzll((unsigned long long)bal) : 0);
+					if (bal) carry = carryP;
 				}
 			}
 			waveSync();
@@ -880,6 +888,7 @@ namespace sbgk
 				const uint32_t local = q - c.qOff;
 				uint32_t p = local, r = 0;
 				if (c.R != 1) { p = local / c.R; r = local % c.R; }      // R > 1 only for quote / sentence-break candidates under several start states
+				if (X.compact) p = X.scratch->live[p];
 				const Hot ps = getHot<G>(X, pBeg + p);
 				if (fast) rTypo = getTypo<G>(X, pBeg + p);      // rides along with the hot quad: the winner's is picked up by a lane read later
 				const bool single = c.single();
@@ -1032,8 +1041,10 @@ namespace sbgk
 		{
 			const Cand c = loadCand(X.candOff(k));
 			const uint32_t local = qw - c.qOff;
-			uint32_t parent = pBeg + local, r = 0;
-			if (c.R != 1) { parent = pBeg + local / c.R; r = local % c.R; }
+			uint32_t pl = local, r = 0;
+			if (c.R != 1) { pl = local / c.R; r = local % c.R; }
+			if (X.compact) pl = X.scratch->live[pl];
+			const uint32_t parent = pBeg + pl;
 #ifdef KAMD_TYPO
 			const float wtypo = (haveTypo ? parentTypo : getTypo<G>(X, parent)) + E.typoCost;      // accTypoCost + node->typoCost (PathEvaluator.hpp:235)
 #else
@@ -1579,6 +1590,27 @@ namespace sbgk
 		// top-N (> 1) uses one container for every size (PathEvaluator.hpp:450-453): batched like the small one, without its 128-key cap
 		const bool topn = P.topN > 1;
 		const int mode = topn ? 0 : E.nLive <= P.smallMax ? 0 : E.nLive <= P.mediumMax ? 1 : 2;
+		// Pruned paths keep their slots (nothing is moved, state indices stay valid), so a node's incoming range holds dead paths -- two thirds of it in a SkipBigram
+		// top-3 search -- and an item formed over a dead path costs its pass a lane.  A node with more than one pass's worth of paths, a quarter or more of
+		// them dead, forms its items over the list of its live paths instead (path order kept: the order of the items of a key, and with it every tie, is the same)
+		X.compact = false; X.nPE = E.nP;
+		if (E.nP > 64u && E.nP <= sizeof(X.scratch->live) / 4 && (uint64_t)E.nLive * 4u < (uint64_t)E.nP * 3u)
+		{
+			uint32_t n = 0;
+			for (uint32_t pb = 0; pb < E.nP; pb += G)
+			{
+				const uint32_t p = pb + X.gl;
+				const bool alive = p < E.nP && !getHot<G>(X, E.pBeg + p).dead();
+				const uint64_t bal = X.ballot(alive);
+				if (alive) X.scratch->live[n + X.prefix(bal)] = p;
+				n += (uint32_t)__popcll(bal);
+			}
+			waveSync();
+			X.compact = true; X.nPE = n;
+		}
+#ifdef KAMD_LIVESTATS
+		if (X.gl == 0) { static unsigned long long sP = 0, sL = 0, sN = 0; sP += E.nP; sL += E.nLive; ++sN; if ((sN & 0x3FF) == 0) fprintf(stderr, "[livestats] nodes %llu paths %llu live %llu\n", sN, sP, sL); }
+#endif
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		enum { K_NONE = 0, K_SKIP = 1, K_Z = 2, K_REG = 3 };
 		constexpr int MAXC = Lay<G>::MAXC;
@@ -1762,7 +1794,7 @@ namespace sbgk
 						kind = K_REG;
 						const bool quote = special == 0 || special == 1 || special == 3 || special == 4;
 						R = ((sbType || quote) && X.nUniq > 1) ? X.nUniq : 1;
-						Q = E.nP * R;
+						Q = X.nPE * R;
 					}
 				}
 				TLMARK(X, 8)

@@ -15,9 +15,10 @@ namespace kamd
 
 	struct EndCand { float score, fcs, typo; uint32_t parent; uint8_t rootId, sp; uint16_t pad; };
 	// scratch in HBM per lane group (items of oversized batches, end-node candidates)
-	template<uint32_t Q> struct GroupScratchT { uint64_t key[Q]; float score[Q]; float fcs[Q]; };
+	// (live: the node's incoming paths that are not pruned, in path order -- the items of a node with many dead paths are formed over this list, evaluateNode)
+	template<uint32_t Q> struct GroupScratchT { uint64_t key[Q]; float score[Q]; float fcs[Q]; uint32_t live[Q]; };
 	using GroupScratch = GroupScratchT<BIGQ>;
-	template<uint32_t Q> struct GroupScratchCong { uint64_t key[Q]; float score[Q]; float fcs[Q]; uint32_t ctx[Q]; };   // CoNgram search: + the context id of every item
+	template<uint32_t Q> struct GroupScratchCong { uint64_t key[Q]; float score[Q]; float fcs[Q]; uint32_t live[Q]; uint32_t ctx[Q]; };   // CoNgram search: + the context id of every item
 
 	// SkipBigram models: LM state of every work item of a batch beyond the Knlm node -- history ring, ring position, and a
 	// 32-bit digest that is compared before the rings are

@@ -102,10 +102,10 @@ def test_state_arenas_grow_into_the_pool(small_model, small_sbg_model, monkeypat
         assert _norm(orc.analyze(s, top_n=top_n)) == _norm(y), s
     p = b.pool()
     reruns, _ = dev.reruns(b)
-    assert p["pool_states"] >= p["arena_states"] * int(pool) // 64 and p["pool_asked"] > p["arena_states"] // 2, p
-    if pool == "6":      # (a pool this small runs out where the arenas are few -- the emulator's handful of blocks; the MI355X's 3072 lane groups make even 6/64 of them large)
+    assert p["pool_states"] >= p["arena_states"] * int(pool) // 64 and p["pool_asked"] > 0, p
+    if pool == "6":      # (a pool this small: chunks it cannot serve end with an overflow status and are re-run)
         assert reruns > 0 or p["pool_asked"] <= p["pool_states"], (p, reruns)
     else:
-        assert p["pool_asked"] <= p["pool_states"] and (reruns == 0 or model == "knlm"), (p, reruns)
+        assert p["pool_asked"] > p["arena_states"] // 2 and p["pool_asked"] <= p["pool_states"] and (reruns == 0 or model == "knlm"), (p, reruns)
     b.close()
     dev.close()

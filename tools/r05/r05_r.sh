@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, call r (second run; the first measured a 64-lane register de-duplication path -- no gain, removed): right halves of split stems find their left half through one pass over the paths instead of a scan per item -- SkipBigram / global CoNgram suites, c3-sbg and c4-cong-global
+# round 5, call r (third run): the items of a node formed over its LIVE incoming paths (two thirds of a SkipBigram top-3 node's paths are pruned ones) -- suites, c3-sbg, c4-cong-global
 mkdir -p gpurun_out/r05_r; O=$PWD/gpurun_out/r05_r
 timeout 1500 python -m pytest tests/test_gpu_sbg.py tests/test_gpu_cong_global.py tests/test_gpu_fullmodel.py -m gpu -x -q 2>&1 | tail -6 | tee $O/pytest_sbg_congg_fullmodel.txt
 for w in c3-sbg c4-cong-global; do
