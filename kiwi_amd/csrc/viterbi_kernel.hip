@@ -1591,10 +1591,10 @@ namespace sbgk
 		const bool topn = P.topN > 1;
 		const int mode = topn ? 0 : E.nLive <= P.smallMax ? 0 : E.nLive <= P.mediumMax ? 1 : 2;
 		// Pruned paths keep their slots (nothing is moved, state indices stay valid), so a node's incoming range holds dead paths -- two thirds of it in a SkipBigram
-		// top-3 search -- and an item formed over a dead path costs its pass a lane.  A node with more than one pass's worth of paths, a quarter or more of
+		// top-3 search -- and an item formed over a dead path costs its pass a lane.  A node with more paths than the group has lanes, a quarter or more of
 		// them dead, forms its items over the list of its live paths instead (path order kept: the order of the items of a key, and with it every tie, is the same)
 		X.compact = false; X.nPE = E.nP;
-		if (E.nP > 64u && E.nP <= sizeof(X.scratch->live) / 4 && (uint64_t)E.nLive * 4u < (uint64_t)E.nP * 3u)
+		if (E.nP > (uint32_t)G && E.nP <= sizeof(X.scratch->live) / 4 && (uint64_t)E.nLive * 4u < (uint64_t)E.nP * 3u)
 		{
 			uint32_t n = 0;
 			for (uint32_t pb = 0; pb < E.nP; pb += G)
