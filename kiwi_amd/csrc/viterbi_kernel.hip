@@ -1608,9 +1608,6 @@ namespace sbgk
 			waveSync();
 			X.compact = true; X.nPE = n;
 		}
-#ifdef KAMD_LIVESTATS
-		if (X.gl == 0) { static unsigned long long sP = 0, sL = 0, sN = 0; sP += E.nP; sL += E.nLive; ++sN; if ((sN & 0x3FF) == 0) fprintf(stderr, "[livestats] nodes %llu paths %llu live %llu\n", sN, sP, sL); }
-#endif
 		const bool spaceBefore = E.nflags & NF_SPACE_BEFORE;
 		enum { K_NONE = 0, K_SKIP = 1, K_Z = 2, K_REG = 3 };
 		constexpr int MAXC = Lay<G>::MAXC;
