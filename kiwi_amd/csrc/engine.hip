@@ -1446,14 +1446,15 @@ namespace kamd
 
 	static void chunkPaths(std::vector<PathResult>& out, const FlatModel& m, const StagedBatch& b, size_t c)
 	{
-		out.clear();
 		const DevChunkResult& r = b.hResults[c];
+		out.resize(r.nPaths);      // (not clear(): the paths' token vectors keep their capacity from text to text)
 		const auto& ref = b.refs[c];
 		const PreparedView& pt = b.prep[ref.text];
 		const uint32_t so = pt.chunks[ref.chunk].startOffset;
 		for (uint32_t p = 0; p < r.nPaths; ++p)
 		{
-			PathResult pr;
+			PathResult& pr = out[p];
+			pr.path.clear();
 			const DevPathHeader& ph = b.hPaths[r.pathOff + p];
 			pr.score = ph.score; pr.prevState = ph.prevState; pr.curState = ph.curState;
 			const DevToken* tk = b.hTokens + r.tokOff + ph.tokOff;
@@ -1466,7 +1467,6 @@ namespace kamd
 				else if (tk[k].ownKind) t.str = pt.normSubstr(so + tk[k].ownA, tk[k].ownLen);
 				pr.path.push_back(std::move(t));
 			}
-			out.push_back(std::move(pr));
 		}
 		std::sort(out.begin(), out.end(), [](const PathResult& a, const PathResult& b2) { return a.score > b2.score; });   // PathEvaluator.hpp:1414-1417
 	}
@@ -1701,18 +1701,26 @@ namespace kamd
 		// texts are independent: post-process them on the host workers, one segment of consecutive texts per task; a text whose chunk
 		// must be searched again (other start states than the speculative {0}, or a scratch overflow) needs the device and is finished
 		// afterwards, one by one
-		auto doText = [&](size_t i, bool mayRerun, ResultSegment& seg, std::vector<PathResult>& paths) -> bool
+		static const std::vector<uint8_t> kOnlyZero{ 0 };
+		auto doText = [&](size_t i, bool mayRerun, ResultSegment& seg, std::vector<PathResult>& paths, ResultBuilder& rb) -> bool
 		{
 			const char16_t* raw = b.rawFlat.data() + b.rawOff[i]; const size_t rawLen = (size_t)(b.rawOff[i + 1] - b.rawOff[i]);
-			ResultBuilder rb{ impl->model, topN, b.match, config.integrateAllomorph };
 			rb.begin(raw, rawLen, b.prep[i].position.data(), b.prep[i].position.size());
+			std::vector<uint8_t> uniqBuf;
 			for (size_t c = firstRef[i]; c < firstRef[i + 1]; ++c)
 			{
 				// special states actually carried into this chunk (Kiwi.cpp:1122-1140) vs. the ones it was searched with
-				std::vector<uint8_t> uniq = rb.spStates();
-				std::sort(uniq.begin(), uniq.end());
-				uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
-				if (uniq.empty()) uniq.push_back(0);
+				// (a text's first chunk, and every chunk behind analyses that all ended in state 0: the set {0}, no vector built)
+				const std::vector<uint8_t>& carried = rb.spStates();
+				bool onlyZero = true;
+				for (uint8_t v : carried) if (v) { onlyZero = false; break; }
+				if (!onlyZero)
+				{
+					uniqBuf = carried;
+					std::sort(uniqBuf.begin(), uniqBuf.end());
+					uniqBuf.erase(std::unique(uniqBuf.begin(), uniqBuf.end()), uniqBuf.end());
+				}
+				const std::vector<uint8_t>& uniq = onlyZero ? kOnlyZero : uniqBuf;
 				const uint32_t st = b.hResults[c].status;
 				if (st >= 16 && b.refs[c].sp == uniq && c < overIdx.size() && overIdx[c] != SIZE_MAX)
 				{
@@ -1740,21 +1748,23 @@ namespace kamd
 		HostPool::instance().run(ret.segs.size(), 1, postThreads, [&](size_t s0, size_t s1, int)
 		{
 			std::vector<PathResult> paths;
+			ResultBuilder rb{ impl->model, topN, b.match, config.integrateAllomorph };      // (one builder per task: begin() starts a text)
 			for (size_t sIdx = s0; sIdx < s1; ++sIdx)
 			{
 				ResultSegment& seg = ret.segs[sIdx];
 				const size_t t0 = sIdx * BatchResults::kSegTexts, t1 = std::min(nT, t0 + BatchResults::kSegTexts);
 				seg.toks.reserve(32 * (t1 - t0)); seg.forms.reserve(128 * (t1 - t0));
 				for (size_t i = t0; i < t1; ++i)
-					if (!doText(i, false, seg, paths)) { again[i] = 1; seg.appendText({}); }
+					if (!doText(i, false, seg, paths, rb)) { again[i] = 1; seg.appendText({}); }
 			}
 		});
 		// (the nested run above must not be re-entered: runRefs uses the device and the pool from this thread only)
 		std::vector<PathResult> paths;
+		ResultBuilder rbAgain{ impl->model, topN, b.match, config.integrateAllomorph };
 		for (size_t i = 0; i < nT; ++i) if (again[i])
 		{
 			ret.overrides.emplace_back(i, ResultSegment{});
-			doText(i, true, ret.overrides.back().second, paths);
+			doText(i, true, ret.overrides.back().second, paths, rbAgain);
 		}
 		tm.lap("post-processing");
 		return ret;

@@ -3,6 +3,7 @@
 #include <numeric>
 #include <stdexcept>
 #include "post.hpp"
+#include <string_view>
 #include "feature.hpp"
 #include "textprep.hpp"
 
@@ -329,7 +330,7 @@ namespace kamd
 
 	void ResultBuilder::insertPaths(const std::vector<PathResult>& pathes)
 	{
-		std::vector<size_t> parentMap;
+		parentMap.clear();
 		if (ret.empty())
 		{
 			const size_t n = std::min(pathes.size(), topN * 2);
@@ -377,16 +378,18 @@ namespace kamd
 			{
 				if (!s.str.empty() && s.str[0] == u' ') continue;
 				const MorphRec& mr = mdl.morphs[s.morph];
-				const U16 kform = mdl.formStr(mdl.morphKform[s.morph]);
+				// (the morpheme's form as a view into the model's character array: no copy per token)
+				const FormRec& kfr = mdl.forms[mdl.morphKform[s.morph]];
+				const std::u16string_view kform{ (const char16_t*)mdl.formChars.data() + kfr.charOff, kfr.len };
 				U16 joined;
 				bool done = false;
 				if (!integrateAllomorph && T_EP <= mr.tag && mr.tag <= T_ETM && !kform.empty() && kform[0] == 0xC5B4)
 				{
 					U16 pk; if (prevMorph >= 0) pk = mdl.formStr(mdl.morphKform[prevMorph]);
-					if (prevMorph >= 0 && !pk.empty() && pk.back() == 0xD558) { joined = joinHangul(U16(1, (char16_t)0xC5EC) + kform.substr(1)); done = true; }
-					else if (matchPolar((const uint16_t*)pk.data(), (uint32_t)pk.size(), CP_POSITIVE)) { joined = joinHangul(U16(1, (char16_t)0xC544) + kform.substr(1)); done = true; }
+					if (prevMorph >= 0 && !pk.empty() && pk.back() == 0xD558) { joined = joinHangul(U16(1, (char16_t)0xC5EC) + U16(kform.substr(1))); done = true; }
+					else if (matchPolar((const uint16_t*)pk.data(), (uint32_t)pk.size(), CP_POSITIVE)) { joined = joinHangul(U16(1, (char16_t)0xC544) + U16(kform.substr(1))); done = true; }
 				}
-				if (!done) joined = joinHangul(s.str.empty() ? kform : s.str);
+				if (!done) joined = s.str.empty() ? joinHangul(kform.data(), kform.size()) : joinHangul(s.str);
 				if (match & M_COMPATIBLE_JAMO) for (auto& c : joined) c = toCompatibleConsonant(c);
 				rarr.emplace_back();
 				Token& tk = rarr.back();
@@ -415,6 +418,11 @@ namespace kamd
 			spStatesByRet[valid] = r.curState;
 			spStateCnt[r.curState]++;
 			valid++;
+		}
+		if (valid <= 1)      // (one analysis carried on -- every top-1 text of one chunk: nothing to order, nothing to cut)
+		{
+			ret.resize(valid); spStatesByRet.resize(valid);
+			return;
 		}
 		std::vector<size_t> idx(valid);
 		std::iota(idx.begin(), idx.end(), 0);

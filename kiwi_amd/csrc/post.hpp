@@ -72,6 +72,7 @@ namespace kamd
 		std::vector<uint8_t> spStatesByRet;
 		const uint32_t* positionTable = nullptr; size_t positionLen = 0;
 		std::vector<uint16_t> wordPositions;
+		std::vector<size_t> parentMap;      // (scratch of insertPaths: a builder is reused for the texts of a task, its vectors keep their capacity)
 		size_t topN; uint64_t match; bool integrateAllomorph;
 	public:
 		ResultBuilder(const FlatModel& m, size_t _topN, uint64_t _match, bool _integrateAllomorph)
