@@ -156,7 +156,10 @@ namespace kamd
 		{
 			const size_t n = tokens.size();
 			if (!n) return;
-			std::vector<uint32_t> line(n), sent(n), sub(n);
+			// (three per-token arrays in one scratch block that lives as long as its thread: a host worker assembles thousands of texts)
+			thread_local std::vector<uint32_t> scratch;
+			scratch.assign(3 * n, 0u);
+			uint32_t* const line = scratch.data(); uint32_t* const sent = line + n; uint32_t* const sub = sent + n;
 
 			// ---- 1: lines ----
 			{
