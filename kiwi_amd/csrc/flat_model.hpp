@@ -445,6 +445,16 @@ namespace kamd
 	// model.cpp
 	// enabledDialects: KiwiBuilder's enabledDialects (kiwi_init's last argument; Dialect bits, 0 = standard only)
 	void bakeModel(FlatModel& out, const std::string& rawModelPath, uint32_t enabledDialects = 0);
+	// ... with temporary forms and morphemes behind the model's own (pretokenized spans, src/Kiwi.cpp:785-946; model.cpp).  Form j gets id nForms + j, morpheme k
+	// id nMorphs + k; `cands` / `chunks[].morph` are morpheme ids of the model or of these temporaries
+	struct TempEntries
+	{
+		struct Form { std::u16string str; std::vector<uint32_t> cands; };
+		struct Chunk { uint32_t morph; uint8_t begin, end; };
+		struct Morph { uint32_t tempForm; uint8_t tag; uint32_t lmId; std::vector<Chunk> chunks; };
+		std::vector<Form> forms; std::vector<Morph> morphs;
+	};
+	void bakeModelWithTemps(FlatModel& out, const std::string& rawModelPath, uint32_t enabledDialects, const TempEntries& temps);
 	// serialises the baked dictionary in the layout of oracle/ref_bridge.cpp:kref_dump_dict (tests compare both)
 	std::vector<uint8_t> dumpDict(const FlatModel& m);
 	// Kiwi::findMorphemes (src/Kiwi.cpp:1281-1297, findForm src/KTrie.cpp:2172-2192): the morphemes of the dictionary form spelled `s` (raw text: it is

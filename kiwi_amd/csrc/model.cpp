@@ -874,20 +874,76 @@ namespace kamd
 		return score;
 	}
 
+	namespace
+	{
+		void loadRaw(const std::string& path, Container& file, ModelFiles& files, RawModel& raw)
+		{
+			struct stat st;
+			if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode))
+			{
+				if (stat((path + "/sj.morph").c_str(), &st) == 0) loadModelDir(path, files, raw);
+				else { file.load(path + "/kiwi_amd.raw"); raw.bind(file); }
+			}
+			else { file.load(path); raw.bind(file); }
+		}
+		void bakeRaw(FlatModel& m, const RawModel& raw, uint32_t enabledDialects, size_t tempFrom);
+	}
+
 	void bakeModel(FlatModel& m, const std::string& path, uint32_t enabledDialects)
 	{
 		Container file;
 		ModelFiles files;
 		RawModel raw;
-		struct stat st;
-		if (stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode))
+		loadRaw(path, file, files, raw);
+		bakeRaw(m, raw, enabledDialects, (size_t)-1);
+	}
+
+	// The model with TEMPORARY forms and morphemes behind its own -- what Kiwi::analyze builds per call for pretokenized spans that name forms or tags the
+	// dictionary does not have (makePretokenizedSpanGroup, src/Kiwi.cpp:785-946: PretokenizedSpanGroup::forms / morphemes / formStrs).  They are baked like
+	// the model's own entries (the same derived fields), keep their raw order behind the sorted forms (form id = raw index) and stay out of the trie:
+	// only a span's lattice node refers to them.
+	void bakeModelWithTemps(FlatModel& m, const std::string& path, uint32_t enabledDialects, const TempEntries& t)
+	{
+		Container file;
+		ModelFiles files;
+		RawModel raw;
+		loadRaw(path, file, files, raw);
+		const size_t nF = raw.nForms(), nM = raw.nMorphs();
+		const size_t nCand = raw.formCandPtr[nF], nChars = raw.formPtr[nF];
+		size_t nChunk = 0;
+		for (size_t i = 0; i < nM; ++i) nChunk = std::max<size_t>(nChunk, (size_t)raw.morph[i].chunkPtr + raw.morph[i].nChunks);
+		std::vector<uint32_t> meta(raw.meta, raw.meta + 4), formPtr(raw.formPtr, raw.formPtr + nF + 1), formCandPtr(raw.formCandPtr, raw.formCandPtr + nF + 1),
+			formCand(raw.formCand, raw.formCand + nCand), chunkIds(raw.chunkIds, raw.chunkIds + nChunk);
+		std::vector<uint16_t> formChars(raw.formChars, raw.formChars + nChars);
+		std::vector<RawMorph> morph(raw.morph, raw.morph + nM);
+		std::vector<uint8_t> chunkPos(raw.chunkPos, raw.chunkPos + 2 * nChunk);
+		for (const auto& f : t.forms)
 		{
-			if (stat((path + "/sj.morph").c_str(), &st) == 0) loadModelDir(path, files, raw);
-			else { file.load(path + "/kiwi_amd.raw"); raw.bind(file); }
+			formChars.insert(formChars.end(), f.str.begin(), f.str.end());
+			formPtr.push_back((uint32_t)formChars.size());
+			for (uint32_t c : f.cands) formCand.push_back(c);
+			formCandPtr.push_back((uint32_t)formCand.size());
 		}
-		else { file.load(path); raw.bind(file); }
+		for (const auto& tm : t.morphs)
+		{
+			RawMorph r{};
+			r.kform = (uint32_t)(nF + tm.tempForm); r.lmId = tm.lmId; r.tag = tm.tag;
+			r.chunkPtr = (uint32_t)chunkIds.size(); r.nChunks = (uint8_t)tm.chunks.size();
+			for (const auto& c : tm.chunks) { chunkIds.push_back(c.morph); chunkPos.push_back(c.begin); chunkPos.push_back(c.end); }
+			morph.push_back(r);
+		}
+		meta[0] = (uint32_t)(nF + t.forms.size()); meta[1] = (uint32_t)(nM + t.morphs.size());
+		raw.meta = meta.data(); raw.formPtr = formPtr.data(); raw.formChars = formChars.data(); raw.formCandPtr = formCandPtr.data(); raw.formCand = formCand.data();
+		raw.morph = morph.data(); raw.chunkIds = chunkIds.data(); raw.chunkPos = chunkPos.data();
+		bakeRaw(m, raw, enabledDialects, nF);
+	}
+
+	namespace {
+	void bakeRaw(FlatModel& m, const RawModel& raw, uint32_t enabledDialects, size_t tempFrom)
+	{
 		const size_t nF = raw.nForms(), nM = raw.nMorphs();
 		if (nF < kDefaultFormSize) throw std::runtime_error{ "raw model: missing default forms" };
+		const size_t nSorted = std::min(nF, tempFrom);      // (temporary forms keep their raw order behind the sorted ones)
 
 		std::vector<U16> rawForm(nF);
 		for (size_t i = 0; i < nF; ++i) rawForm[i].assign((const char16_t*)raw.formChars + raw.formPtr[i], (const char16_t*)raw.formChars + raw.formPtr[i + 1]);
@@ -896,7 +952,7 @@ namespace kamd
 		// ---- form order: defaults fixed, the rest sorted by (string ignoring spaces, original index) ------
 		std::vector<uint32_t> order(nF);
 		std::iota(order.begin(), order.end(), 0u);
-		std::sort(order.begin() + kDefaultFormSize, order.end(), [&](uint32_t a, uint32_t b)
+		std::sort(order.begin() + kDefaultFormSize, order.begin() + nSorted, [&](uint32_t a, uint32_t b)
 		{
 			const int c = cmpIgnoringSpace(rawForm[a], rawForm[b]);
 			if (c == -1) return true;
@@ -1107,6 +1163,7 @@ namespace kamd
 			if (hasJ) f.flags |= FF_HAS_JCLASS;
 			if (anyFull) f.flags |= FF_HAS_ANY_FULL;
 			if (fDialect && !(enabledDialects & fDialect)) continue;      // a form of dialects that are not enabled stays out of the trie (:2501-2504)
+			if (i >= tempFrom) continue;      // (a temporary form: reached through its span's node only)
 			sortedForms.push_back((uint32_t)i);
 		}
 		{
@@ -1254,6 +1311,7 @@ namespace kamd
 			m.sbgWindow = window;
 		}
 		if (raw.knlm && vocab > m.lmRoot.size()) throw std::runtime_error{ "raw model: vocab larger than LM vocab" };
+	}
 	}
 
 	std::vector<uint32_t> findMorphemes(const FlatModel& m, const char16_t* s, size_t n, uint8_t tag)

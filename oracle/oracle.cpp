@@ -30,6 +30,7 @@ struct OracleHandle
 	korc::ChrFreqConfig freq;  // KiwiConfig::oovGlobalWeight / oovLocalWeight / oovGlobalMinFreq
 	Counters counters;
 	std::vector<uint32_t> blockIds, blockBits;      // AnalyzeOption::blocklist of the following analyses (korc_blocklist_*)
+	std::string rawPath; uint32_t enabledDialects = 0;      // where the model came from: a call with pretokenized spans that need temporary entries bakes it again with them
 };
 
 namespace
@@ -44,10 +45,11 @@ namespace
 	// a prepared typo transformer applied to an analysis (AnalyzeOption::typoTransformer / typoThreshold / allowedDialects)
 	struct TypoOpt { const korc::typo::Prepared* prepared = nullptr; float threshold = 2.5f; uint16_t dialect = 0; float dialectCost = 3.f; };      // (dialect / dialectCost: AnalyzeOption::allowedDialects / dialectCost)
 
-	// Pretokenized spans (Kiwi::analyze(..., pretokenized): src/Kiwi.cpp:785-946, 1043-1051, 1120, 745-756; KTrie.cpp:782-790, 1177-1210), as far as they are
-	// restated: a span without tokens, and a span of one token that IS a single-candidate dictionary entry -- the cases in which makePretokenizedSpanGroup
-	// points at a form of the model.  A span that needs a temporary form or morpheme (any other single token, several tokens) is refused.  Pinned by
-	// tests/test_pretokenized_golden.py against tests/golden/pretokenized_small.json (the real reference's answers).
+	// Pretokenized spans (Kiwi::analyze(..., pretokenized): src/Kiwi.cpp:785-946, 1043-1051, 1120, 745-756; KTrie.cpp:782-790, 1177-1210): a span without
+	// tokens and a span of one token that IS a single-candidate dictionary entry point at a form of the model; any other single token and a span of several
+	// tokens get TEMPORARY forms / morphemes (makePretokenizedSpanGroup's ret.forms / ret.morphemes / ret.formStrs), for which the model is baked once more
+	// with them behind its own entries (bakeModelWithTemps).  Pinned by tests/test_pretokenized_golden.py against tests/golden/pretokenized_small.json (the
+	// real reference's answers).
 	struct PtToken { U16 form; uint32_t begin, end; uint8_t tag, infer; };
 	struct PtSpan { uint32_t begin, end; std::vector<PtToken> toks; };
 
@@ -76,6 +78,8 @@ namespace
 		PreparedText pt;
 		std::vector<std::pair<uint32_t, uint32_t>> spanCut;      // the spans in normalised offsets
 		std::vector<LatticeBuilder::SpanNode> spanNodes;          // ... with their forms (offsets still text-relative here)
+		TempEntries temps;                                        // ... and the temporary forms / morphemes they need
+		const uint32_t nModelForms = (uint32_t)h.model.h.nForms, nModelMorphs = (uint32_t)h.model.h.nMorphs;
 		if (pretok && !pretok->empty())
 		{
 			if (typo.prepared) throw std::runtime_error{ "oracle: pretokenized spans with a typo transformer are not restated" };
@@ -104,14 +108,85 @@ namespace
 						const uint8_t mt = h.model.morphs[h.model.formCand[h.model.forms[f].candOff]].tag, tt = sp.toks[0].tag;
 						reuse = sp.toks[0].infer ? ((mt & 0x7F) == (tt & 0x7F)) : (mt == tt);      // areTagsEqual (include/kiwi/Types.h:249-252)
 					}
-					if (!reuse) throw std::runtime_error{ "oracle: a pretokenized span that needs a temporary form or morpheme is not restated" };
-					sn.form = (uint32_t)f;
+					if (reuse) sn.form = (uint32_t)f;
+					else
+					{
+						// a new form whose candidates are the entry's morphemes of that tag (at most two), or a new morpheme (src/Kiwi.cpp:838-870)
+						TempEntries::Form tf; tf.str = fs;
+						if (f >= 0)
+							for (uint32_t ci = 0; ci < h.model.forms[f].candCnt && tf.cands.size() < 2; ++ci)
+							{
+								const uint32_t mi = h.model.formCand[h.model.forms[f].candOff + ci];
+								const uint8_t mt = h.model.morphs[mi].tag, tt = sp.toks[0].tag;
+								if (sp.toks[0].infer ? ((mt & 0x7F) == (tt & 0x7F)) : (mt == tt)) tf.cands.push_back(mi);
+							}
+						if (tf.cands.empty())
+						{
+							tf.cands.push_back(nModelMorphs + (uint32_t)temps.morphs.size());
+							temps.morphs.push_back(TempEntries::Morph{ (uint32_t)temps.forms.size(), sp.toks[0].tag, (uint32_t)(sp.toks[0].tag & 0x7F) + 1u, {} });      // getDefaultMorphemeId (include/kiwi/Kiwi.h:64-67)
+						}
+						sn.form = nModelForms + (uint32_t)temps.forms.size();
+						temps.forms.push_back(std::move(tf));
+					}
 				}
-				else throw std::runtime_error{ "oracle: a pretokenized span of several tokens is not restated" };
+				else
+				{
+					// several tokens: one new form with one new morpheme whose chunks are the tokens -- dictionary morphemes of exactly that form and tag, or new
+					// ones with the tag's default LM id (src/Kiwi.cpp:872-934)
+					TempEntries::Morph whole{ 0, 0 /* POSTag::unknown */, 0, {} };
+					std::vector<TempEntries::Morph> news; std::vector<TempEntries::Form> newForms;
+					const uint32_t wholeForm = (uint32_t)temps.forms.size();
+					const uint32_t wholeMorph = nModelMorphs + (uint32_t)temps.morphs.size();
+					temps.forms.push_back(TempEntries::Form{ U16{}, { wholeMorph } });
+					temps.morphs.push_back(whole);      // (filled below: the vector may grow in between)
+					const size_t wholeAt = temps.morphs.size() - 1;
+					std::vector<TempEntries::Chunk> chunks;
+					for (const PtToken& t : sp.toks)
+					{
+						U16 fs; std::vector<uint32_t> dp;
+						normalizeWithPosition(t.form.data(), t.form.size(), fs, dp);
+						const int32_t f = findFormId(h.model, fs);
+						uint32_t found = 0xFFFFFFFFu;
+						if (f >= 0)
+							for (uint32_t ci = 0; ci < h.model.forms[f].candCnt; ++ci)
+							{
+								const uint32_t mi = h.model.formCand[h.model.forms[f].candOff + ci];
+								if (h.model.morphs[mi].tag == t.tag) { found = mi; break; }
+							}
+						if (found == 0xFFFFFFFFu)
+						{
+							found = nModelMorphs + (uint32_t)temps.morphs.size();
+							temps.morphs.push_back(TempEntries::Morph{ (uint32_t)temps.forms.size(), t.tag, (uint32_t)(t.tag & 0x7F) + 1u, {} });
+							temps.forms.push_back(TempEntries::Form{ fs, {} });      // (formStrs: the string alone, no candidates)
+						}
+						if (sp.begin + t.end > len) throw std::runtime_error{ "oracle: bad token range in a pretokenized span" };
+						chunks.push_back(TempEntries::Chunk{ found, (uint8_t)(pos[sp.begin + t.begin] - b), (uint8_t)(pos[sp.begin + t.end] - b) });
+					}
+					temps.morphs[wholeAt].tempForm = wholeForm;
+					temps.morphs[wholeAt].chunks = std::move(chunks);
+					sn.form = nModelForms + wholeForm;
+				}
 				sn.fallback = sn.form + 1 >= (uint32_t)T_NNG && sn.form + 1 < (uint32_t)T_MAX;      // within(form, value(nng), value(max)): KTrie.cpp:1197
 				spanCut.emplace_back(b, e);
 				spanNodes.push_back(sn);
 			}
+		}
+		// temporary entries: this call runs on the model baked once more with them behind its own (restored when the call returns)
+		struct ModelSwap      // (moving a FlatModel moves its vectors: the saved views stay valid for the saved model)
+		{
+			OracleHandle& h; FlatModel saved; ModelView view; SbgView sbg; CongView cong; bool on = false;
+			~ModelSwap() { if (on) { h.model = std::move(saved); h.view = view; h.sbg = sbg; h.cong = cong; } }
+		} swap{ h, {}, h.view, h.sbg, h.cong };
+		if (!temps.forms.empty())
+		{
+			if (h.rawPath.empty()) throw std::runtime_error{ "oracle: temporary morphemes need the path the model was opened from" };
+			FlatModel tm;
+			bakeModelWithTemps(tm, h.rawPath, h.enabledDialects, temps);
+			swap.saved = std::move(h.model); swap.on = true;
+			h.model = std::move(tm);
+			h.view = h.model.view();
+			h.sbg = swap.sbg.present() ? h.model.sbgView() : SbgView{};      // (the language model the handle scores with stays what it was)
+			h.cong = swap.cong.present() ? h.model.congView() : CongView{};
 		}
 		prepareText(pt, text, len, match, 0, spanCut.data(), spanCut.size());
 		SplitConfig sc = h.scfg; sc.match = match;
@@ -173,7 +248,9 @@ namespace
 			}
 			rb.insertPaths(paths);
 		}
-		return rb.finish(text, len);
+		auto res = rb.finish(text, len);
+		if (swap.on) for (auto& r : res) for (auto& t : r.first) if (t.morph >= (int32_t)nModelMorphs) t.morph = -1;      // (token.morph = nullptr for the span group's own morphemes, src/Kiwi.cpp:733)
+		return res;
 	}
 }
 
@@ -185,6 +262,7 @@ extern "C"
 		{
 			auto h = std::make_unique<OracleHandle>();
 			bakeModel(h->model, rawModelPath);
+			h->rawPath = rawModelPath;
 			h->view = h->model.view();
 			h->sbg = h->model.sbgView();
 			h->cong = h->model.congView();
@@ -200,6 +278,7 @@ extern "C"
 		{
 			auto h = std::make_unique<OracleHandle>();
 			bakeModel(h->model, rawModelPath, (uint32_t)enabledDialects);
+			h->rawPath = rawModelPath; h->enabledDialects = (uint32_t)enabledDialects;
 			h->view = h->model.view();
 			h->sbg = h->model.sbgView();
 			h->cong = h->model.congView();
