@@ -84,3 +84,33 @@ def test_oracle_equals_the_reference_where_it_restates_spans(golden, small_model
                 assert a == b, g["text"]
         done += 1
     assert done == len(golden["cases"]) == 190 and refused == 0
+
+
+def test_oracle_equals_the_live_reference_on_fresh_span_cases(small_model, monkeypatch):
+    """Beyond the committed fixture: 2 x 300 freshly generated cases (other seeds; every case kind, temporary morphemes included) through the REAL reference
+    (oracle/_ref, kref_analyze_pretokenized) and the oracle -- best analysis and score lists bit for bit, the rest up to exact ties."""
+    import oraclelib
+    import refbridge
+    if not refbridge.available():
+        pytest.skip("oracle/_ref/libkiwi_ref.so not built (needs /root/reference)")
+    import make_golden_pretokenized as gen
+    monkeypatch.setenv("KORC_QUIET", "1")
+    sm, path = small_model
+    ref = refbridge.RefKiwi(path)
+    orc = oraclelib.OracleKiwi(path)
+    kinds = set()
+    for seed in (2301, 3301):
+        for c in gen.make_cases(sm, n=240, seed=seed):
+            want = json.loads(json.dumps(gen.run(ref, c)))
+            spans = [(sb, se, [tuple(tk) for tk in toks]) for sb, se, toks in c["spans"]]
+            res = orc.analyze_pretokenized(c["text"], spans, top_n=c["top_n"])
+            assert res is not None, c
+            got = json.loads(json.dumps([{"score": r[1], "tokens": [[x.form, x.tag, x.position, x.length, x.word_position, x.sent_position, x.score, x.typo_form_id, x.morph_id >= 0] for x in r[0]]} for r in res]))
+            assert [r["score"] for r in got] == [r["score"] for r in want], c["text"]
+            if c["top_n"] == 1:
+                assert got == want, c["text"]
+            for a, b in zip(got, want):
+                if [r["score"] for r in got].count(a["score"]) == 1 and a is not got[-1]:
+                    assert a == b, c["text"]
+            kinds.update("none" if not toks else "one" if len(toks) == 1 else "multi" for _, _, toks in c["spans"])
+    assert kinds == {"none", "one", "multi"}
