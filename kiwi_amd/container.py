@@ -6,6 +6,7 @@ The C++ reader is ``kiwi_amd/csrc/container.hpp``.
 """
 from __future__ import annotations
 
+import os
 import struct
 
 import numpy as np
@@ -24,7 +25,9 @@ def write_container(path: str, sections: dict, kind: bytes = b"KAMDSEC1") -> Non
         entries.append((n.encode(), off, a.nbytes))
         blobs.append((off, a.tobytes()))
         off += a.nbytes
-    with open(path, "wb") as f:
+    # (written beside the target and renamed: a reader -- another test process, another rank -- sees the old file or the new one, never a part of it)
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "wb") as f:
         f.write(kind)
         f.write(struct.pack("<II", len(names), 0))
         for e in entries:
@@ -33,6 +36,7 @@ def write_container(path: str, sections: dict, kind: bytes = b"KAMDSEC1") -> Non
             f.seek(o)
             f.write(b)
         f.truncate(max(off, f.tell()))
+    os.replace(tmp, path)
 
 
 def read_container(path: str) -> tuple[bytes, dict]:
