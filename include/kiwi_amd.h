@@ -143,6 +143,14 @@ kamd_results_h kamd_analyze_batch_opt(kamd_engine_h h, kamd_typo_h t, float thre
  * built-in typo set DefaultTypoSet::dialect is applied with threshold 2.5, as the reference does (src/Kiwi.cpp:1037-1041) */
 kamd_results_h kamd_analyze_batch_dialect(kamd_engine_h h, kamd_typo_h t, float threshold, int allowed_dialect, float dialect_cost, kamd_morphset_h blocklist,
                                           const uint16_t* texts, const uint64_t* offsets, uint32_t n_texts, uint32_t top_n, uint64_t match_options, int open_ending, int host_threads);
+/* Kiwi::analyze(text, option, pretokenized) for ONE text -- the spans the caller has tokenised already (/root/reference/src/Kiwi.cpp:785-946, 1043-1051;
+ * src/KTrie.cpp:782-790, 1177-1210; include/kiwi/Types.h:393-413): `spans` holds, per span, {begin, end, n_tokens} followed by n_tokens x {offset of the token's
+ * form in `forms`, its length, begin, end (relative to the span's begin), tag id, inferRegularity}; offsets in UTF-16 units of `text`.  A span without tokens or with
+ * one token that is a single-candidate dictionary entry points at that form; anything else gets temporary forms / morphemes, uploaded behind the model's tables for
+ * this call (tokens of temporary morphemes report morph_id -1); every token inside span i of its chunk reports typo_form_id i + 1.  Not together with a typo
+ * transformer.  NULL + kamd_last_error() for overlapping or empty spans. */
+kamd_results_h kamd_analyze_pretokenized(kamd_engine_h h, const uint16_t* text, uint32_t len, uint32_t top_n, uint64_t match_options, int open_ending,
+                                         const uint32_t* spans, uint32_t n_spans, const uint16_t* forms);
 /* parity hook: the lattices the device builds OVER the typo graphs of a text's chunks (csrc/typo_lattice_kernel.hip), in the layout of kamd_dump_lattices;
  * 0 + kamd_last_error() on failure */
 /* parity hook of the device typo-graph kernel (the analyze path generates typo graphs on the GPU): kamd_typo_graph's layout + two bytes per

@@ -19,7 +19,12 @@
  *     kiwi_init's enabled_dialects and option.allowed_dialects / dialect_cost are honoured (round 5): a model with dialect morphemes (MorphemeRaw::dialect of
  *     sj.morph / a raw container) keeps the dictionary forms of enabled dialects, an analysis skips the morphemes of dialects it does not allow, charges
  *     dialect_cost for the others and -- without a transformer of its own -- is corrected with the built-in `dialect` typo set (src/Kiwi.cpp:1037-1041);
- *     tokens report their dialect.  top_n > 16 and pretokenized spans are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of being silently ignored.
+ *     tokens report their dialect.
+ *   - pretokenized spans (kiwi_pt_init / kiwi_pt_add_span / kiwi_pt_add_token_to_span{,_w} / kiwi_pt_close, the last argument of kiwi_analyze{,_w}) are
+ *     honoured (round 6): makePretokenizedSpanGroup (src/Kiwi.cpp:785-946) restated; a span's lattice node is forced on the device, temporary forms / morphemes
+ *     live behind the model's device tables for the call, tokens inside span i of their chunk report typo_form_id i + 1, kiwi_res_morpheme_id is -1 for a
+ *     temporary morpheme.  Not together with option.typo_transformer (refused).
+ *   - top_n > 16 and useOldSplitter are refused with NULL/KIWIERR_FAIL + kiwi_error() instead of being silently ignored.
  */
 #ifndef KIWI_CAPI_SUBSET_H
 #define KIWI_CAPI_SUBSET_H

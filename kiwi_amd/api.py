@@ -320,6 +320,27 @@ class KiwiAmd:
     def analyze(self, text, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False):
         return self.analyze_batch([text], top_n, match, open_ending, 1).to_python()[0]
 
+    def analyze_pretokenized(self, text, spans, top_n=1, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False):
+        """kamd_analyze_pretokenized: spans = [(begin, end, [(form, begin, end, tag id, infer_regularity), ...]), ...] in UTF-16 units of `text`
+        (token offsets relative to their span) -- Kiwi::analyze's `pretokenized` argument."""
+        L = self.lib
+        L.kamd_analyze_pretokenized.restype = C.c_void_p
+        L.kamd_analyze_pretokenized.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+        u = np.frombuffer(text.encode("utf-16-le", errors="surrogatepass"), np.uint16)
+        desc, forms = [], []
+        for b, e, toks in spans:
+            desc += [b, e, len(toks)]
+            for form, tb, te, tag, infer in toks:
+                f = np.frombuffer(form.encode("utf-16-le"), np.uint16)
+                desc += [sum(len(x) for x in forms), len(f), tb, te, tag, infer]
+                forms.append(f)
+        d = np.array(desc if desc else [0], np.uint32)
+        fl = np.concatenate(forms) if forms else np.zeros(1, np.uint16)
+        r = L.kamd_analyze_pretokenized(self.h, u.ctypes.data, len(u), top_n, match, int(open_ending), d.ctypes.data, len(spans), fl.ctypes.data)
+        if not r:
+            raise self._err("kamd_analyze_pretokenized")
+        return Results(self.lib, r).to_python()[0]
+
     def stage(self, texts, match=MATCH_ALL_WITH_NORMALIZING, open_ending=False, host_threads=0, typo=None, typo_threshold=2.5) -> Batch:
         """typo: a prepared `Typo` (kamd_stage_typo); it must outlive the batch."""
         flat, offs = pack_texts(texts)

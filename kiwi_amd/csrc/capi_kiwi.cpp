@@ -163,8 +163,8 @@ namespace
 	}
 
 }
-// kiwi_pretokenized (src/capi/kiwi_c.cpp: a std::vector<PretokenizedSpan>): the object can be built and closed through the reference's entry points;
-// analysing WITH spans is refused loudly by checkOption below
+// kiwi_pretokenized (src/capi/kiwi_c.cpp: a std::vector<PretokenizedSpan>), built through the reference's entry points; kiwi_analyze{,_w} hand its spans to
+// Engine::analyzePretokenized (pretok.hpp: makePretokenizedSpanGroup restated, temporary forms / morphemes as a per-batch overlay on the device)
 struct kiwi_pretokenized
 {
 	struct Token { std::u16string form; std::string tag; int begin, end; };
@@ -178,8 +178,7 @@ namespace
 		// allowed_dialects / dialect_cost: the candidate loops skip a morpheme whose dialect is neither standard nor allowed and charge dialect_cost for an
 		// allowed one (src/PathEvaluator.hpp:231, 386, 893): typoOf below hands them to the engine (round 5; a model without dialect morphemes: no effect,
 		// exactly as in the reference -- except that an analysis with a dialect allowed and no transformer is corrected with the built-in `dialect` set)
-		// a pretokenized object without spans is no constraint (kiwi_pt_init + nothing added); spans themselves are not built on the device path yet
-		if (pt && !pt->spans.empty()) throw std::invalid_argument{ "kiwi_amd: pretokenized spans are not supported on the device path yet" };
+		(void)pt;      // (a pretokenized object without spans is no constraint; with spans: spansOf below)
 		// Match::oovChrModel (bits 8-9): the engine checks that the model carries the character model (nounchr.mdl next to a CoNgram model) and refuses
 		// with the reference's own message otherwise; the two frequency-based modes are not built
 		if ((uint32_t)o.match_options & (1u << 30)) throw std::invalid_argument{ "kiwi_amd: useOldSplitter is not supported" };
@@ -187,6 +186,28 @@ namespace
 
 	// AnalyzeOption::typoTransformer / typoThreshold
 	TypoOption typoOf(const kiwi_analyze_option_t& o);
+
+	// the caller's spans as the engine takes them: offsets into the UTF-16 text.  bytePos (kiwi_analyze: UTF-8 text): the byte offset of every UTF-16 unit --
+	// Kiwi::mapPretokenizedSpansToU16 (src/Kiwi.cpp:34-44) maps a span's begin / end through it; the tokens' offsets, relative to their span, are taken as they
+	// are (the reference does not map them either)
+	std::vector<PtSpan> spansOf(const kiwi_pretokenized& pt, const std::vector<size_t>* bytePos)
+	{
+		std::vector<PtSpan> ret;
+		for (const auto& s : pt.spans)
+		{
+			if (s.begin < 0 || s.end < 0) throw std::invalid_argument{ "pretokenized span with a negative offset" };
+			PtSpan o;
+			if (bytePos)
+			{
+				o.begin = (uint32_t)(std::upper_bound(bytePos->begin(), bytePos->end(), (size_t)s.begin) - bytePos->begin() - 1);
+				o.end = (uint32_t)(std::lower_bound(bytePos->begin(), bytePos->end(), (size_t)s.end) - bytePos->begin());
+			}
+			else { o.begin = (uint32_t)s.begin; o.end = (uint32_t)s.end; }
+			for (const auto& tk : s.tokens) o.tokens.push_back(PtToken{ tk.form, (uint32_t)tk.begin, (uint32_t)tk.end, parseTag(tk.tag.c_str()), true });      // (BasicToken::inferRegularity defaults to 1; the C API cannot change it)
+			ret.push_back(std::move(o));
+		}
+		return ret;
+	}
 
 	void fillRes(kiwi_res& res, const std::shared_ptr<const BatchResults>& br, size_t text)
 	{
@@ -403,7 +424,8 @@ extern "C"
 		if (!h) return KIWIERR_INVALID_HANDLE;
 		try
 		{
-			if (span_id < 0 || (size_t)span_id >= h->spans.size()) throw std::invalid_argument{ "invalid span_id: " + std::to_string(span_id) };
+			if (begin < 0 || end < 0 || span_id < 0 || (size_t)span_id >= h->spans.size()) return KIWIERR_INVALID_INDEX;      // src/capi/kiwi_c.cpp:1994
+			(void)parseTag(tag ? tag : "");      // (parse_tag: an unknown tag is refused here, as the reference does, not at the analysis)
 			size_t n = 0; while (form[n]) ++n;
 			h->spans[(size_t)span_id].tokens.push_back(kiwi_pretokenized::Token{ std::u16string{ (const char16_t*)form, n }, tag ? tag : "", begin, end });
 			return 0;
@@ -584,6 +606,11 @@ extern "C"
 		{
 			checkOption(opt, pt);
 			size_t n = 0; while (text[n]) ++n;
+			if (pt && !pt->spans.empty())
+			{
+				auto res = h->engine->analyzePretokenized((const char16_t*)text, n, spansOf(*pt, nullptr), (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
+				return makeRes(std::make_shared<const BatchResults>(std::move(res)), 0);
+			}
 			std::vector<std::pair<const char16_t*, size_t>> v{ { (const char16_t*)text, n } };
 			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
 			return makeRes(std::make_shared<const BatchResults>(std::move(res)), 0);
@@ -598,6 +625,20 @@ extern "C"
 		{
 			checkOption(opt, pt);
 			const std::u16string u = utf8To16(text, std::strlen(text));
+			if (pt && !pt->spans.empty())
+			{
+				// byte offset of every UTF-16 unit (utf8To16(str, bytePositions), src/StrUtils.h:236-300: both units of a surrogate pair carry the pair's offset)
+				std::vector<size_t> bytePos; bytePos.reserve(u.size());
+				for (size_t i = 0, n8 = std::strlen(text); i < n8;)
+				{
+					const uint8_t c = (uint8_t)text[i];
+					const size_t len = c < 0x80 ? 1 : (c & 0xE0) == 0xC0 ? 2 : (c & 0xF0) == 0xE0 ? 3 : 4;
+					bytePos.push_back(i); if (len == 4) bytePos.push_back(i);
+					i += len;
+				}
+				auto res = h->engine->analyzePretokenized(u.data(), u.size(), spansOf(*pt, &bytePos), (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
+				return makeRes(std::make_shared<const BatchResults>(std::move(res)), 0);
+			}
 			std::vector<std::pair<const char16_t*, size_t>> v{ { u.data(), u.size() } };
 			auto res = h->engine->analyzeBatch(v, (size_t)top_n, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, 1, typoOf(opt));
 			return makeRes(std::make_shared<const BatchResults>(std::move(res)), 0);

@@ -448,6 +448,27 @@ extern "C"
 		}, (kamd_results*)nullptr);
 	}
 
+	// Kiwi::analyze(text, option, pretokenized) for ONE text (src/Kiwi.cpp:1014-1158 with :1043-1051, 785-946): `spans` = per span {begin, end, nTokens} followed by
+	// nTokens x {offset of the form in `forms`, its length, begin, end (relative to the span), tag id, inferRegularity}, offsets in UTF-16 units of `text`
+	kamd_results_h kamd_analyze_pretokenized(kamd_engine_h h, const uint16_t* text, uint32_t len, uint32_t topN, uint64_t match, int openEnding, const uint32_t* spans, uint32_t nSpans, const uint16_t* forms)
+	{
+		if (!h) { lastError = "invalid handle"; return nullptr; }
+		return guarded([&]()
+		{
+			std::vector<PtSpan> pt;
+			const uint32_t* p = spans;
+			for (uint32_t i = 0; i < nSpans; ++i)
+			{
+				PtSpan sp{ p[0], p[1], {} };
+				const uint32_t nTok = p[2];
+				p += 3;
+				for (uint32_t k = 0; k < nTok; ++k, p += 6) sp.tokens.push_back(PtToken{ std::u16string{ (const char16_t*)forms + p[0], (const char16_t*)forms + p[0] + p[1] }, p[2], p[3], (uint8_t)p[4], p[5] != 0 });
+				pt.push_back(std::move(sp));
+			}
+			return pack(h->e->analyzePretokenized((const char16_t*)text, len, pt, topN, match, !!openEnding, 1));
+		}, (kamd_results*)nullptr);
+	}
+
 	size_t kamd_dump_dict(kamd_engine_h h, uint8_t* out, size_t cap)
 	{
 		if (!h) return 0;

@@ -8,6 +8,10 @@
 namespace kamd
 {
 	struct DevPattern { uint32_t end, length; uint32_t tag; };   // chunk-relative (textprep.hpp PatternSpan)
+	// A pretokenized span of the chunk (pretok.hpp; KTrie.cpp:1177-1210) travels as an entry BEHIND the chunk's patterns: {end, length} chunk-relative, tag =
+	// kSpanTag | kSpanFallback (the node takes the text as its own string) | the form id of its lattice node.  Only the replay of the reference's splitter
+	// (latticeSerialBuild, lattice_kernels.hip) reads them: the engine sends a batch with spans to that kernel.
+	constexpr uint32_t kSpanTag = 0x80000000u, kSpanFallback = 0x40000000u, kSpanFormMask = 0x00FFFFFFu;
 
 	// lattice node, 32 B (reference: KGraphNode 56 B, src/KTrie.h:57-77)
 	struct alignas(16) DevNode

@@ -16,6 +16,7 @@
 #include <stdexcept>
 #include <thread>
 #include "engine.hpp"
+#include "pretok.hpp"
 #include "hostpool.hpp"
 #include "viterbi_kernel.hpp"
 #include "exact_math.hpp"
@@ -187,6 +188,9 @@ namespace kamd
 		std::vector<ChunkRef> refs;
 		uint64_t match = 0;
 		uint32_t capScale = 1;
+		// Pretokenized spans (Kiwi::analyze's `pretokenized`, pretok.hpp): the spans of text 0 in normalised offsets with the forms of their lattice nodes and the
+		// temporary forms / morphemes behind the model's tables (uploaded before the batch's first kernel); a batch of runRefs shares its parent's
+		std::shared_ptr<const PretokGroup> pretok;
 		std::vector<uint32_t> blockBitsHost;          // a model with dialect morphemes: the blocklist united with the morphemes of dialects the analysis does not allow
 		bool isRerun = false;                         // a batch of runRefs (chunks searched again): the engine's adaptive capacities do not learn from it
 		uint64_t units = 0, devBytes = 0;
@@ -283,11 +287,13 @@ namespace kamd
 		// is callable from many threads, reference capi threading contract) is serialised per engine; host preparation is not
 		std::recursive_mutex deviceMu;
 
-		template<class T> const T* up(const std::vector<T>& v)
+		// room behind the model's form / morpheme tables for the temporary entries of a batch with pretokenized spans (TempOverlay): elements per table
+		static constexpr size_t kTempForms = 4096, kTempMorphs = 8192, kTempChars = 1u << 17, kTempCand = 16384, kTempChunks = 16384;
+		template<class T> const T* up(const std::vector<T>& v, size_t slack = 0)
 		{
 			modelBufs.emplace_back(new DevBuf);
 			DevBuf& b = *modelBufs.back();
-			b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+			b.ensure(std::max<size_t>((v.size() + slack) * sizeof(T), 16));
 			if (!v.empty()) HIPCHECK(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
 			return b.as<T>();
 		}
@@ -346,12 +352,13 @@ namespace kamd
 		const FlatModel& m = impl->model;
 		ModelView& v = impl->dview;
 		v.h = m.h;
-		v.forms = impl->up(m.forms); v.formChars = impl->up(m.formChars); v.formCand = impl->up(m.formCand);
+		using I_ = Engine::Impl;
+		v.forms = impl->up(m.forms, I_::kTempForms); v.formChars = impl->up(m.formChars, I_::kTempChars); v.formCand = impl->up(m.formCand, I_::kTempCand);
 		{
 			// device copy of the morpheme table: `feat` / `prevFlags` are replaced by the path-side values (FlatModel::morphPath)
 			std::vector<MorphRec> dm = m.morphs;
 			for (size_t i = 0; i < dm.size(); ++i) { dm[i].feat = (uint16_t)m.morphPath[i]; dm[i].prevFlags = (uint8_t)(m.morphPath[i] >> 16); }
-			v.morphs = impl->up(dm);
+			v.morphs = impl->up(dm, I_::kTempMorphs);
 			std::vector<CandStatic> unk(2);
 			for (int k = 0; k < 2; ++k)
 			{
@@ -362,8 +369,8 @@ namespace kamd
 			}
 			v.unkPacks = impl->up(unk);
 		}
-		v.chunkMorph = impl->up(m.chunkMorph); v.chunkLm = impl->up(m.chunkLm); v.chunkPos = impl->up(m.chunkPos);
-		v.sbInfo = impl->up(m.sbInfo); v.morphPath = impl->up(m.morphPath);
+		v.chunkMorph = impl->up(m.chunkMorph, I_::kTempChunks); v.chunkLm = impl->up(m.chunkLm, I_::kTempChunks); v.chunkPos = impl->up(m.chunkPos, 2 * I_::kTempChunks);
+		v.sbInfo = impl->up(m.sbInfo, I_::kTempMorphs); v.morphPath = impl->up(m.morphPath, I_::kTempMorphs);
 		v.trie = impl->up(m.trie); v.trieKeys = impl->up(m.trieKeys); v.trieChild = impl->up(m.trieChild); v.trieRoot = impl->up(m.trieRoot);
 		v.lmNodes = impl->up(m.lmNodes); v.lmKeys = impl->up(m.lmKeys); v.lmValues = impl->up(m.lmValues); v.lmRoot = impl->up(m.lmRoot);
 		if (m.congDim)
@@ -386,7 +393,10 @@ namespace kamd
 		}
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
 		v.lmHtxNode = (m.congDim || m.lmHtxNode.empty()) ? nullptr : impl->up(m.lmHtxNode);      // history-transformed Knlm only
-		v.formDialect = m.formDialect.empty() ? nullptr : impl->up(m.formDialect); v.morphDialect = m.morphDialect.empty() ? nullptr : impl->up(m.morphDialect);
+		// (dialect bits: the room behind them is zero -- a temporary entry belongs to no dialect)
+		v.formDialect = m.formDialect.empty() ? nullptr : impl->up(m.formDialect, I_::kTempForms); v.morphDialect = m.morphDialect.empty() ? nullptr : impl->up(m.morphDialect, I_::kTempMorphs);
+		if (v.formDialect) HIPCHECK(hipMemset(const_cast<uint16_t*>(v.formDialect) + m.formDialect.size(), 0, 2 * I_::kTempForms));
+		if (v.morphDialect) HIPCHECK(hipMemset(const_cast<uint16_t*>(v.morphDialect) + m.morphDialect.size(), 0, 2 * I_::kTempMorphs));
 		v.formUnkChr = nullptr; v.formChrTok = nullptr;
 		v.lmChain = nullptr;
 		if (!m.congDim && !m.lmBackoff.empty())
@@ -407,7 +417,7 @@ namespace kamd
 			c.root = impl->up(m.chrRoot); c.inv = m.chrInv.empty() ? nullptr : impl->up(m.chrInv);
 			c.depth = impl->up(m.chrDepth); c.freqTab = impl->up(m.chrFreqTab);
 			impl->chr = c;
-			v.formUnkChr = impl->up(m.formUnkChr); v.formChrTok = impl->up(m.formChrTok);
+			v.formUnkChr = impl->up(m.formUnkChr, I_::kTempForms); v.formChrTok = impl->up(m.formChrTok, I_::kTempChars);
 		}
 		if (!m.sbgPtrs.empty())
 		{
@@ -481,6 +491,16 @@ namespace kamd
 
 	// Lays a set of chunks out in HBM.  Everything the kernels read about the batch -- text, character classes, scripts, patterns, special
 	// states, flags and the region offsets -- is assembled in ONE pinned host block and uploaded with ONE copy.
+	// The pretokenized spans that begin inside chunk `d` of text `text` (the chunk cut never ends inside one), as entries BEHIND the chunk's pattern list:
+	// {end, length} chunk-relative, tag = kSpanTag | fallback << 30 | form id (device_types.hpp; the lattice replay splits the list at the first such tag)
+	template<class F> static void forSpansOfChunk(const StagedBatch& b, uint32_t text, const ChunkDesc& d, F&& f)
+	{
+		if (!b.pretok || text != 0) return;
+		for (const auto& sn : b.pretok->spans)
+			if (sn.begin >= d.startOffset && sn.begin < d.startOffset + d.nChars)
+				f(DevPattern{ sn.end - d.startOffset, sn.end - sn.begin, kSpanTag | (sn.fallback ? kSpanFallback : 0u) | sn.form });
+	}
+
 	static void layoutAndUpload(Engine::Impl& I, StagedBatch& b, const SearchParams&)
 	{
 		const size_t nC = b.refs.size();
@@ -498,6 +518,7 @@ namespace kamd
 			const uint64_t n = d.nChars;
 			b.charOff[c + 1] = b.charOff[c] + (uint32_t)n;
 			b.patOff[c + 1] = b.patOff[c] + (d.patEnd - d.patBegin);
+			forSpansOfChunk(b, r.text, d, [&](const DevPattern&) { ++b.patOff[c + 1]; });
 			b.spOff[c + 1] = b.spOff[c] + (uint32_t)r.sp.size();
 			uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
 			// SkipBigram states carry their history ring in the container key: far fewer paths merge, a node keeps hundreds to thousands of them
@@ -562,6 +583,7 @@ namespace kamd
 				std::memcpy(H + oScript + b.charOff[c], pt.script.data() + d.startOffset, d.nChars);
 				DevPattern* pats = reinterpret_cast<DevPattern*>(H + oPats) + b.patOff[c];
 				for (uint32_t k = d.patBegin; k < d.patEnd; ++k) pats[k - d.patBegin] = DevPattern{ pt.patterns[k].end, pt.patterns[k].length, pt.patterns[k].tag };
+				{ uint32_t at = d.patEnd - d.patBegin; forSpansOfChunk(b, r.text, d, [&](const DevPattern& sp) { pats[at++] = sp; }); }
 				for (uint32_t k = 0; k < d.nChars; ++k) if (!isSpace(pt.norm[d.startOffset + k])) ++u;
 				if (!r.sp.empty()) std::memcpy(H + oSp + b.spOff[c], r.sp.data(), r.sp.size());
 				H[oFlags + c] = (r.openEnding ? 1 : 0) | (r.onlyChunk ? 2 : 0);
@@ -599,7 +621,9 @@ namespace kamd
 		// the pool behind the chunks' own arenas (none under KAMD_TEST_TINY_ARENAS: that hook is there to exercise the re-run ladder)
 		if (slotCap > 0x7FFFFFFFull) throw std::runtime_error{ "chunk too long for a state arena" };
 		b.slotCap = (uint32_t)slotCap;
-		const uint64_t ownStates = slotMode ? (uint64_t)I.histSlots() * slotCap : b.stateBase[nC];
+		// (slot mode: as many arenas as a launch can use -- lane group blockIdx * groups + g of min(persistent blocks, ceil(chunks / groups)) blocks --, not the whole
+		// machine's whatever the batch holds: a re-run of one chunk at a high rung of the capacity ladder took gigabytes otherwise)
+		const uint64_t ownStates = slotMode ? std::min<uint64_t>(I.histSlots(), (uint64_t)nC + 4) * slotCap : b.stateBase[nC];
 		b.poolStates = tinyArenas ? 0 : slotMode ? (I.poolForced ? ownStates * I.poolFrac64 / 64 : ownStates / 4)
 			: std::max<uint64_t>(ownStates * I.poolFrac64 / 64, I.poolFrac64 ? std::min<uint64_t>(ownStates, 1u << 16) : 0);
 		b.ownStates = ownStates;
@@ -654,16 +678,19 @@ namespace kamd
 		if ((b.match >> 8) & 3) { b.dUnkChr.ensure(totNodes * 4 + 16); w.unkChr = b.dUnkChr.as<float>(); }      // Match::oovChrModel (checked in stage())
 		if (((b.match >> 8) & 3) > 1) { b.dUnkChrForm.ensure(totNodes * 4 + 16); w.unkChrForm = b.dUnkChrForm.as<float>(); }      // Match::oovChrFreqModel / oovChrFreqBranchModel
 		if (b.typo.blocked && !b.typo.blocked->empty() && b.typo.blocked->size() != (I.model.morphs.size() + 31) / 32) throw std::invalid_argument{ "kiwi_amd: blocklist bit set does not belong to this model" };
-		if (!I.model.morphDialect.empty())
+		const size_t nTempMorphs = b.pretok ? b.pretok->temps.morphs.size() : 0;      // (a temporary morpheme is never blocked; its bit has to exist)
+		if (!I.model.morphDialect.empty() || (nTempMorphs && b.typo.blocked && !b.typo.blocked->empty()))
 		{
 			// a model with dialect morphemes: those of a dialect this analysis does not allow are skipped by the candidate loops exactly like blocked ones
 			// (PathEvaluator.hpp:386, 893 beside the blocklist test) -- one bit set per batch, the blocklist's united with them
 			std::vector<uint32_t>& bits = b.blockBitsHost;      // (kept with the batch: the upload is asynchronous)
 			bits.assign((I.model.morphs.size() + 31) / 32, 0u);
 			if (b.typo.blocked && !b.typo.blocked->empty()) bits = *b.typo.blocked;
-			for (size_t i = 0; i < I.model.morphDialect.size(); ++i) { const uint32_t d = I.model.morphDialect[i]; if (d && !(d & b.typo.allowedDialect)) bits[i >> 5] |= 1u << (i & 31); }
-			upload(b.dBlockBits, bits, s);
-			w.blockBits = b.dBlockBits.as<uint32_t>();
+			bool any = b.typo.blocked && !b.typo.blocked->empty();
+			for (size_t i = 0; i < I.model.morphDialect.size(); ++i) { const uint32_t d = I.model.morphDialect[i]; if (d && !(d & b.typo.allowedDialect)) { bits[i >> 5] |= 1u << (i & 31); any = true; } }
+			bits.resize((I.model.morphs.size() + nTempMorphs + 31) / 32, 0u);
+			// (nothing blocked -- every dialect allowed, no blocklist: no bit set is bound, and the lattice kernel keeps writing the search's records itself)
+			if (any) { upload(b.dBlockBits, bits, s); w.blockBits = b.dBlockBits.as<uint32_t>(); }
 		}
 		else if (b.typo.blocked && !b.typo.blocked->empty())
 		{
@@ -896,6 +923,24 @@ namespace kamd
 		const size_t nEv = 6 * (size_t)S + 2;
 		while (I.evs.size() < nEv) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); I.evs.push_back(e); }
 		if (I.haveLast) HIPCHECK(hipStreamWaitEvent(sA, I.lastDone, 0));      // the kernels of two batches do not overlap (shared scratch, counters, events)
+		if (b.pretok && b.pretok->hasTemps())
+		{
+			// the batch's temporary forms / morphemes go behind the model's tables (ids >= the model's counts): after the previous batch's last kernel, before
+			// this batch's first -- no other batch's kernels run in between, and a batch without spans never refers to an id up there
+			const TempOverlay& o = b.pretok->overlay; const FlatModel& m = I.model; const ModelView& v = I.dview;
+			using I_ = Engine::Impl;
+			if (o.forms.size() > I_::kTempForms || o.morphs.size() > I_::kTempMorphs || o.formChars.size() > I_::kTempChars || o.formCand.size() > I_::kTempCand || o.chunkMorph.size() > I_::kTempChunks)
+				throw std::invalid_argument{ "kiwi_amd: too many temporary forms / morphemes in the pretokenized spans of one call" };
+			auto put = [&](const auto* devBase, size_t at, const auto& vec)
+			{
+				using T = std::remove_cv_t<std::remove_pointer_t<decltype(devBase)>>;
+				if (!vec.empty()) HIPCHECK(hipMemcpyAsync(const_cast<T*>(devBase) + at, vec.data(), vec.size() * sizeof(T), hipMemcpyHostToDevice, sA));
+			};
+			put(v.forms, o.nBaseForms, o.forms); put(v.formChars, m.formChars.size() - 1, o.formChars); put(v.formCand, m.formCand.size(), o.formCand);
+			put(v.morphs, o.nBaseMorphs, b.pretok->devMorphs); put(v.chunkMorph, m.chunkMorph.size(), o.chunkMorph); put(v.chunkLm, m.chunkLm.size(), o.chunkLm);
+			put(v.chunkPos, m.chunkPos.size(), o.chunkPos); put(v.sbInfo, o.nBaseMorphs, o.sbInfo); put(v.morphPath, o.nBaseMorphs, o.morphPath);
+			if (v.formUnkChr) { put(v.formUnkChr, o.nBaseForms, o.formUnkChr); put(v.formChrTok, m.formChars.size() - 1, o.formChrTok); }
+		}
 		HIPCHECK(hipMemsetAsync(b.dResults.p, 0, nC * sizeof(DevChunkResult), sA));
 		HIPCHECK(hipMemsetAsync(b.dOutCounters.p, 0, 128, sA));
 		HIPCHECK(hipMemcpyAsync(b.dStateAt.p, b.wv.stateBase, (size_t)nC * 8, hipMemcpyDeviceToDevice, sA));      // every chunk starts in its own arena
@@ -931,7 +976,8 @@ namespace kamd
 			// chunks) and kept with the batch while the match ratio stays what it was
 			const bool wave = I.latticeWave && I.latticeGroupForced == 0;
 			const uint32_t ratioKey = wave ? (I.latticeRatio16 & 0x3FFFu) : 0x10000u;
-			const uint32_t budget = wave ? I.latticeWaveBudget : I.latticeLdsBudget;
+			// (a batch with pretokenized spans: every chunk to the replay of the reference's splitter, k_build_lattice_big -- the only lattice kernel that reads spans)
+			const uint32_t budget = b.pretok ? 0u : wave ? I.latticeWaveBudget : I.latticeLdsBudget;
 			const uint32_t classesKey = ratioKey * 31u + budget / 16u;
 			if (b.latClassesKey != classesKey || b.latClasses.size() != S)
 			{
@@ -1018,7 +1064,7 @@ namespace kamd
 				const bool posEarly = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8 && (!b.typo.typo || I.posPathForced);
 				const uint32_t expandMode = (fuseExpand && posEarly && !b.wv.unkChr && !b.wv.blockBits) ? (1u | (I.hasCong ? 2u : 0u)) : 0u;
 				if (getenv("KAMD_LATTICE_PROFILE")) { lwProf.ensure((size_t)nC * 64); HIPCHECK(hipMemsetAsync(lwProf.p, 0, (size_t)nC * 64, sA)); b.wv.beacon = lwProf.as<uint32_t>(); }
-				const uint32_t budget = wave ? I.latticeWaveBudget : I.latticeLdsBudget;
+				const uint32_t budget = b.pretok ? 0u : wave ? I.latticeWaveBudget : I.latticeLdsBudget;
 				// the size classes of k_lattice_wave go over four streams (forked from and joined back into sA; which one: decided with the classes): a class ends when its slowest
 				// wavefront does, and the next class's wavefronts fill the machine meanwhile
 				uint32_t nClass = 0;
@@ -1444,6 +1490,9 @@ namespace kamd
 		b.outBytes = 8 + nC * sizeof(DevChunkResult) + (size_t)nPaths * sizeof(DevPathHeader) + (size_t)nTok * sizeof(DevToken);
 	}
 
+	// the tables the result assembly reads: the model's, or the batch's copy with its temporary entries behind them
+	static const FlatModel& hostModelOf(const Engine::Impl& I, const StagedBatch& b) { return (b.pretok && b.pretok->hasTemps()) ? b.pretok->hostModel : I.model; }
+
 	static void chunkPaths(std::vector<PathResult>& out, const FlatModel& m, const StagedBatch& b, size_t c)
 	{
 		const DevChunkResult& r = b.hResults[c];
@@ -1468,11 +1517,35 @@ namespace kamd
 				pr.path.push_back(std::move(t));
 			}
 		}
+		if (b.pretok && ref.text == 0)
+		{
+			// findPretokenizedGroupOfNode (src/Kiwi.cpp:949-969) + Kiwi.cpp:745-750: a token of a lattice node inside span i of the CHUNK reports i + 1 as its
+			// typoFormId (no node straddles a span: the tokens of a node inside one lie inside it)
+			const ChunkDesc& d = pt.chunks[ref.chunk];
+			uint32_t idx = 0;
+			for (const auto& sn : b.pretok->spans)
+			{
+				if (!(sn.begin >= d.startOffset && sn.begin < d.startOffset + d.nChars)) continue;
+				++idx;
+				for (auto& pr : out) for (auto& t : pr.path) if (t.begin >= sn.begin && t.end <= sn.end && t.begin < t.end) t.typoFormId = idx;
+			}
+		}
 		std::sort(out.begin(), out.end(), [](const PathResult& a, const PathResult& b2) { return a.score > b2.score; });   // PathEvaluator.hpp:1414-1417
 	}
 
 	std::shared_ptr<StagedBatch> Engine::stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads, TypoOption typo)
 	{
+		return stagePretok(texts, match, openEnding, hostThreads, typo, nullptr);
+	}
+
+	std::shared_ptr<StagedBatch> Engine::stagePretok(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads, TypoOption typo,
+		std::shared_ptr<const PretokGroup> pretok)
+	{
+		if (pretok && pretok->spans.empty()) pretok.reset();
+		// (the reference steps over a span in the typo graph as well, KTrie.cpp:882 -- not restated: there is no pin for it)
+		if (pretok && typo.typo) throw std::invalid_argument{ "kiwi_amd: pretokenized spans together with a typo transformer are not supported" };
+		std::vector<std::pair<uint32_t, uint32_t>> spanCut;      // the spans of text 0 in normalised offsets: the chunk cut and the pattern recognisers step over them
+		if (pretok) for (const auto& sn : pretok->spans) spanCut.emplace_back(sn.begin, sn.end);
 		if (typo.typo)
 		{
 			if (impl->model.forms.size() >= (1u << 24)) throw std::runtime_error{ "kiwi_amd: typo correction supports up to 2^24 forms" };
@@ -1500,7 +1573,8 @@ namespace kamd
 			for (size_t i = i0; i < i1; ++i)
 			{
 				if (texts[i].second) std::memcpy(&b->rawFlat[b->rawOff[i]], texts[i].first, 2 * texts[i].second);
-				blk.append(texts[i].first, texts[i].second, match, (uint32_t)i);
+				if (i == 0 && !spanCut.empty()) blk.append(texts[i].first, texts[i].second, match, (uint32_t)i, spanCut.data(), spanCut.size());
+				else blk.append(texts[i].first, texts[i].second, match, (uint32_t)i);
 			}
 			for (size_t i = i0; i < i1; ++i) b->prep[i] = blk.view(i - i0);
 		});
@@ -1520,6 +1594,7 @@ namespace kamd
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		HIPCHECK(hipSetDevice(impl->device));      // the device is bound per thread: callers come from any thread
 		b->typo = typo;
+		b->pretok = std::move(pretok);
 		layoutAndUpload(*impl, *b, makeParams(config, match, 1, &b->typo));
 		tm.lap("layout + device buffers + upload");
 		return b;
@@ -1611,7 +1686,7 @@ namespace kamd
 				w += cw; ++r1;
 			}
 			StagedBatch b;
-			b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo; b.hostThreads = 1; b.isRerun = true;
+			b.match = parent.match; b.capScale = capScale; b.topN = parent.topN; b.typo = parent.typo; b.hostThreads = 1; b.isRerun = true; b.pretok = parent.pretok;
 			b.refs.assign(refs.begin() + r0, refs.begin() + r1);
 			std::vector<size_t> failing;
 			b.prep.swap(parent.prep);   // borrow the prepared texts for the duration of the launch
@@ -1627,7 +1702,7 @@ namespace kamd
 						if (capScale >= 64) throw std::runtime_error{ "analyze: device scratch overflow (status " + std::to_string(b.hResults[c].status) + ") even at 64x capacity" };
 						failing.push_back(c);
 					}
-					else chunkPaths(out[r0 + c], I.model, b, c);
+					else chunkPaths(out[r0 + c], hostModelOf(I, b), b, c);
 				}
 			}
 			catch (...) { b.prep.swap(parent.prep); throw; }
@@ -1737,10 +1812,18 @@ namespace kamd
 					continue;
 				}
 				if (st == CS_NO_LATTICE) continue;
-				chunkPaths(paths, impl->model, b, c);
+				chunkPaths(paths, hostModelOf(*impl, b), b, c);
 				rb.insertPaths(paths);
 			}
-			seg.appendText(rb.finish(raw, rawLen));
+			if (b.pretok && i == 0 && b.pretok->hasTemps())
+			{
+				// token.morph = nullptr for the span group's own morphemes (src/Kiwi.cpp:733): they do not outlive the call
+				auto res = rb.finish(raw, rawLen);
+				const int32_t nOwn = (int32_t)b.pretok->overlay.nBaseMorphs;
+				for (auto& r : res) for (auto& tk : r.first) if (tk.morph >= nOwn) tk.morph = -1;
+				seg.appendText(res);
+			}
+			else seg.appendText(rb.finish(raw, rawLen));
 			return true;
 		};
 		std::vector<uint8_t> again(nT, 0);
@@ -1748,7 +1831,7 @@ namespace kamd
 		HostPool::instance().run(ret.segs.size(), 1, postThreads, [&](size_t s0, size_t s1, int)
 		{
 			std::vector<PathResult> paths;
-			ResultBuilder rb{ impl->model, topN, b.match, config.integrateAllomorph };      // (one builder per task: begin() starts a text)
+			ResultBuilder rb{ hostModelOf(*impl, b), topN, b.match, config.integrateAllomorph };      // (one builder per task: begin() starts a text)
 			for (size_t sIdx = s0; sIdx < s1; ++sIdx)
 			{
 				ResultSegment& seg = ret.segs[sIdx];
@@ -1760,7 +1843,7 @@ namespace kamd
 		});
 		// (the nested run above must not be re-entered: runRefs uses the device and the pool from this thread only)
 		std::vector<PathResult> paths;
-		ResultBuilder rbAgain{ impl->model, topN, b.match, config.integrateAllomorph };
+		ResultBuilder rbAgain{ hostModelOf(*impl, b), topN, b.match, config.integrateAllomorph };
 		for (size_t i = 0; i < nT; ++i) if (again[i])
 		{
 			ret.overrides.emplace_back(i, ResultSegment{});
@@ -1828,6 +1911,20 @@ namespace kamd
 			throw;
 		}
 		return all;
+	}
+
+	// Kiwi::analyze(text, option, pretokenized): one text whose spans are fixed by the caller (pretok.hpp) -- the spans' forms (temporary ones behind the model's
+	// tables for this batch), the chunk cut and the recognisers stepping over them, ONE forced lattice node per span, typoFormId of the tokens inside
+	BatchResults Engine::analyzePretokenized(const char16_t* text, size_t n, const std::vector<PtSpan>& spans, size_t topN, uint64_t match, bool openEnding, int hostThreads, TypoOption typo)
+	{
+		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
+		auto g = std::make_shared<PretokGroup>();
+		makePretokGroup(impl->model, text, n, match, spans, *g);
+		std::vector<std::pair<const char16_t*, size_t>> texts{ { text, n } };
+		auto b = stagePretok(texts, match, openEnding, hostThreads, typo, g);
+		b->topN = (uint32_t)topN;
+		run(*b);
+		return fetch(*b, topN);
 	}
 
 	std::vector<uint8_t> Engine::dumpLattices(const char16_t* text, size_t n, uint64_t match)

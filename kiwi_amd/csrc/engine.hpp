@@ -10,6 +10,7 @@
 #include <vector>
 #include "device_types.hpp"
 #include "post.hpp"
+#include "pretok.hpp"
 #include "textprep.hpp"
 
 namespace kamd
@@ -88,6 +89,11 @@ namespace kamd
 		// the common case where no quote/bullet state crosses chunk boundaries); run() launches the three kernels on
 		// the resident batch and returns their event-timed durations; fetch() downloads and assembles results.
 		std::shared_ptr<StagedBatch> stage(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {});
+		// ... with the pretokenized spans of texts[0] (pretok.hpp; null / no spans: stage())
+		std::shared_ptr<StagedBatch> stagePretok(const std::vector<std::pair<const char16_t*, size_t>>& texts, uint64_t match, bool openEnding, int hostThreads, TypoOption typo,
+			std::shared_ptr<const PretokGroup> pretok);
+		// Kiwi::analyze(text, option, pretokenized) for one text (reference src/Kiwi.cpp:1014-1158 with :1043-1051)
+		BatchResults analyzePretokenized(const char16_t* text, size_t n, const std::vector<PtSpan>& spans, size_t topN, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {});
 		KernelTimes run(StagedBatch& b);
 		// run() in two halves: launch() enqueues the batch's kernels and returns, finish() waits for THIS batch and re-runs what overflowed -- the host
 		// prepares the next batch in between (analyzeBatch cuts a large batch into parts that way)

@@ -455,11 +455,30 @@ namespace kamd
 		std::vector<Form> forms; std::vector<Morph> morphs;
 	};
 	void bakeModelWithTemps(FlatModel& out, const std::string& rawModelPath, uint32_t enabledDialects, const TempEntries& temps);
+	// The same temporaries as an OVERLAY behind a baked model: exactly what bakeModelWithTemps appends to the tables a lattice node, the search and the result
+	// assembly index by form / morpheme id -- computed from the baked model alone (no second bake, no model file), so that an analysis with pretokenized spans
+	// costs the temporaries and not the dictionary.  The engine uploads it per batch behind the device copies of those tables (ids >= the model's counts).
+	// tests/test_pretok_overlay.py: equal to the tail of bakeModelWithTemps' tables on every golden span case.
+	struct TempOverlay
+	{
+		uint32_t nBaseForms = 0, nBaseMorphs = 0;
+		std::vector<FormRec> forms;          // the temporary forms, then the closing sentinel: forms[nBaseForms ...]
+		std::vector<uint16_t> formChars;     // formChars[base.formChars.size() - 1 ...]: over the base's closing 0, with its own
+		std::vector<uint32_t> formCand;      // appended
+		std::vector<MorphRec> morphs;        // appended (host values; the device copy takes feat / prevFlags from morphPath as the model's do)
+		std::vector<uint32_t> chunkMorph, chunkLm; std::vector<uint8_t> chunkPos;      // appended
+		std::vector<uint8_t> sbInfo; std::vector<uint32_t> morphPath, morphKform;      // per temporary morpheme
+		std::vector<float> formUnkChr; std::vector<uint16_t> formChrTok;                // a model with the character model: per temporary form / per unit of formChars
+		bool empty() const { return forms.empty(); }
+	};
+	void bakeTempsOverlay(const FlatModel& base, const TempEntries& temps, TempOverlay& out);
 	// serialises the baked dictionary in the layout of oracle/ref_bridge.cpp:kref_dump_dict (tests compare both)
 	std::vector<uint8_t> dumpDict(const FlatModel& m);
 	// Kiwi::findMorphemes (src/Kiwi.cpp:1281-1297, findForm src/KTrie.cpp:2172-2192): the morphemes of the dictionary form spelled `s` (raw text: it is
 	// normalised like the reference's normalizeHangul) whose tag, irregularity aside, is `tag` (0 = any tag); halves of split stems are not returned
 	std::vector<uint32_t> findMorphemes(const FlatModel& m, const char16_t* s, size_t n, uint8_t tag);
+	// findForm (src/KTrie.cpp:2172-2192): the dictionary form whose string, spaces aside, is exactly the NORMALISED string `nrm`; -1 if none ends there
+	int32_t formIdOfString(const FlatModel& m, const std::u16string& nrm);
 	// Morpheme::hasMorpheme over a set of morpheme ids (include/kiwi/Form.h:187-196), for every morpheme at once: bit m is set iff the set holds
 	// m's combined morpheme or one of its chunks -- what the candidate loops test a blocklist with (src/PathEvaluator.hpp:385, 892)
 	std::vector<uint32_t> blockBitsOf(const FlatModel& m, const std::vector<uint32_t>& ids);

@@ -349,10 +349,15 @@ namespace kamd
 		const uint64_t* mask = Q.mask; const uint32_t* moff = Q.moff; const uint32_t* mforms = Q.mforms; const uint2* mfrec = Q.mfrec;
 		const DevPattern* pat = B.patterns + B.patOff[chunk];
 		const DevPattern* patEnd = B.patterns + B.patOff[chunk + 1];
+		// pretokenized spans of the chunk: the entries behind its patterns (device_types.hpp kSpanTag), in text order
+		const DevPattern* spanEnd = patEnd;
+		while (patEnd != pat && (patEnd[-1].tag & kSpanTag)) --patEnd;
+		const DevPattern* span = patEnd;
 
 		uint8_t lastType = T_UNKNOWN, lastScript = 0;
 		uint32_t specialStart = 0, unkStart = 0, boundary = 0;
 		uint32_t resetNs = 0;   // dictionary matches starting before this ns position are void (see k_dict_scan step 1)
+		bool staleZ = false; uint32_t staleZform = 0;      // a z-coda / saisiot candidate raised at a span's first unit: the reference flushes it with the NEXT flush (its list is not cleared)
 		const uint8_t scriptVS = 98;
 		for (uint32_t j = 0; j < n; ++j)
 		{
@@ -412,19 +417,36 @@ namespace kamd
 					++pat;
 				}
 			}
+			// a pretokenized span begins here (KTrie.cpp:1177-1210): the pending unknown-form spans are closed, ONE node with the span's form is appended -- a
+			// fallback form takes the text as its own string --, the dictionary walk restarts behind the span (matches that start before its end are void)
+			if (span != spanEnd && span->end - span->length == j)
+			{
+				const uint32_t sb = j, se_ = span->end, sform = span->tag & kSpanFormMask; const bool fb = (span->tag & kSpanFallback) != 0;
+				latUnkPair(L, boundary, unkStart, L.posToNs[sb], false, nMap);
+				const FormRec sf = M.forms[sform];
+				latAppend(L, L.posToNs[sb], L.posToNs[se_], sform, fb ? sb : 0u, fb ? se_ - sb : 0u, nMap, (sf.flags & FF_HAS_ANY_FULL) != 0, fb ? se_ - sb : (uint32_t)(sf.len - sf.numSpaces), sf.flags & 3);
+				j += (se_ - sb) - 1;
+				++span;
+				lastType = T_UNKNOWN;
+				resetNs = L.posToNs[j + 1];
+				specialStart = unkStart = boundary = L.posToNs[j + 1];
+				if (zcand && !staleZ) { staleZ = true; staleZform = zform; }
+				continue;
+			}
 			if (pair) { ++j; continue; }
 
 			// flushCandidates (KTrie.cpp:955-996) over [z-coda shortcut] + the packed dictionary matches ending here
 			const uint32_t endNs = L.posToNs[j + 1];
 			const uint32_t m0 = moff[endNs], m1 = m0 + __popcll(mask[endNs]);
-			const uint32_t kFirst = zcand ? m0 - 1 : m0;
+			const uint32_t nZ = (staleZ ? 1u : 0u) + (zcand ? 1u : 0u);
+			const uint32_t kFirst = m0 - nZ;
 			if (kFirst == m1) continue;
 			// every candidate of this run ends at endNs: that position's index entry / length mask / flag bits stay in registers (latAppendAt)
 			uint32_t epmE = L.endPosMap[endNs]; uint64_t fmE = L.fullMask[endNs]; uint8_t zE = L.zAt[endNs];
 			const uint32_t epm0 = epmE; const uint64_t fm0 = fmE; const uint8_t z0 = zE;
 			for (uint32_t k = kFirst; k != m1; ++k)
 			{
-				const bool isZ = zcand && k == m0 - 1;
+				const bool isZ = k - kFirst < nZ;      // (unsigned: the z entries sit in front of the matches)
 				if (!isZ && mfrec)
 				{
 					// wave-per-chunk variant: the match's facts were computed by the staging pass
@@ -452,7 +474,7 @@ namespace kamd
 					}
 					continue;
 				}
-				const uint32_t fi = isZ ? zform : mforms[k];
+				const uint32_t fi = isZ ? ((staleZ && k == kFirst) ? staleZform : zform) : mforms[k];
 				const FormRec f = M.forms[fi];
 				const uint32_t flen = f.len - f.numSpaces;
 				if (flen > endNs) continue;
@@ -490,6 +512,7 @@ namespace kamd
 			if (epmE != epm0) L.endPosMap[endNs] = epmE;
 			if (fmE != fm0) L.fullMask[endNs] = fmE;
 			if (zE != z0) L.zAt[endNs] = zE;
+			staleZ = false;
 		}
 		if (lastType != T_MAX && lastType != T_UNKNOWN && lastType != T_SS)
 		{

@@ -886,7 +886,7 @@ namespace kamd
 			}
 			else { file.load(path); raw.bind(file); }
 		}
-		void bakeRaw(FlatModel& m, const RawModel& raw, uint32_t enabledDialects, size_t tempFrom);
+		void bakeRaw(FlatModel& m, const RawModel& raw, uint32_t enabledDialects, size_t tempFrom, size_t tempMorphFrom = (size_t)-1);
 	}
 
 	void bakeModel(FlatModel& m, const std::string& path, uint32_t enabledDialects)
@@ -935,11 +935,191 @@ namespace kamd
 		meta[0] = (uint32_t)(nF + t.forms.size()); meta[1] = (uint32_t)(nM + t.morphs.size());
 		raw.meta = meta.data(); raw.formPtr = formPtr.data(); raw.formChars = formChars.data(); raw.formCandPtr = formCandPtr.data(); raw.formCand = formCand.data();
 		raw.morph = morph.data(); raw.chunkIds = chunkIds.data(); raw.chunkPos = chunkPos.data();
-		bakeRaw(m, raw, enabledDialects, nF);
+		bakeRaw(m, raw, enabledDialects, nF, nM);
+	}
+
+	// What bakeRaw derives for the temporaries of bakeModelWithTemps, from the baked model alone (see TempOverlay): the per-morpheme fields (:965-1062 below), the
+	// per-form fields and reductions (:1080-1165), in the same order and with the same tests -- a temporary has no vowel / polarity condition, no socket, no
+	// sense id, no score, is its own combined morpheme and belongs to no dialect (RawMorph{} in bakeModelWithTemps).
+	void bakeTempsOverlay(const FlatModel& m, const TempEntries& t, TempOverlay& o)
+	{
+		o = TempOverlay{};
+		const uint32_t nF = m.h.nForms, nM = m.h.nMorphs, vocab = m.h.vocabSize;
+		o.nBaseForms = nF; o.nBaseMorphs = nM;
+		if (t.forms.empty() && t.morphs.empty()) return;
+		const size_t nTM = t.morphs.size(), nTF = t.forms.size();
+		auto tagOf = [&](uint32_t mi) -> uint8_t { return mi < nM ? m.morphs[mi].tag : t.morphs[mi - nM].tag; };
+		auto lmIdOf = [&](uint32_t mi) -> uint32_t { return mi < nM ? m.morphs[mi].lmId : t.morphs[mi - nM].lmId; };
+		auto kformOf = [&](uint32_t mi) -> U16 { return mi < nM ? m.formStr(m.morphKform[mi]) : U16(t.forms[t.morphs[mi - nM].tempForm].str); };
+		auto checkId = [&](uint32_t mi) { if (mi >= nM + nTM) throw std::invalid_argument{ "temporary entries: morpheme id out of range" }; };
+		// ---- morphemes ----
+		o.morphs.assign(nTM, MorphRec{}); o.morphKform.resize(nTM); o.sbInfo.assign(nTM, 0); o.morphPath.assign(nTM, 0);
+		auto morphAt = [&](uint32_t mi) -> const MorphRec& { return mi < nM ? m.morphs[mi] : o.morphs[mi - nM]; };
+		auto chunkMorphAt = [&](uint32_t off) -> uint32_t { return off < m.chunkMorph.size() ? m.chunkMorph[off] : o.chunkMorph[off - m.chunkMorph.size()]; };
+		auto chunkLmAt = [&](uint32_t off) -> uint32_t { return off < m.chunkLm.size() ? m.chunkLm[off] : o.chunkLm[off - m.chunkLm.size()]; };
+		for (size_t k = 0; k < nTM; ++k)
+		{
+			const TempEntries::Morph& tm = t.morphs[k];
+			if (tm.tempForm >= nTF) throw std::invalid_argument{ "temporary entries: form index out of range" };
+			if (tm.chunks.size() > 255) throw std::invalid_argument{ "temporary entries: more than 255 chunks" };
+			MorphRec& r = o.morphs[k];
+			r.lmId = tm.lmId; r.userScore = 0; r.combinedId = (int32_t)(nM + k);
+			r.tag = tm.tag; r.vowel = 0; r.polar = 0; r.socket = 0; r.senseId = 0; r.nChunks = (uint8_t)tm.chunks.size();
+			r.chunkOff = (uint32_t)(m.chunkMorph.size() + o.chunkMorph.size());
+			for (const auto& c : tm.chunks)
+			{
+				checkId(c.morph);
+				o.chunkMorph.push_back(c.morph); o.chunkLm.push_back(lmIdOf(c.morph)); o.chunkPos.push_back(c.begin); o.chunkPos.push_back(c.end);
+			}
+			if (r.nChunks == 0) r.flags |= MF_SINGLE;
+			o.morphKform[k] = nF + tm.tempForm;
+		}
+		for (size_t k = 0; k < nTM; ++k)
+		{
+			MorphRec& r = o.morphs[k];
+			const U16& kf = t.forms[t.morphs[k].tempForm].str;
+			const uint8_t tag = r.tag;
+			bool hc = false;      // (its combined morpheme is itself, and not complex)
+			for (uint32_t c = 0; c < r.nChunks; ++c) hc = hc || (morphAt(chunkMorphAt(r.chunkOff + c)).flags & MF_COMPLEX);
+			if (hc) r.flags |= MF_HAS_COMPLEX;
+			if (kf.empty()) r.flags |= MF_KFORM_EMPTY;
+			r.feat = featMask((const uint16_t*)kf.data(), (uint32_t)kf.size());
+			if (!kf.empty() && identifySpecialChr(kf.back()) == T_SSC) r.flags |= MF_ENDS_WITH_SSC;
+			const uint16_t f0 = kf.empty() ? 0 : kf[0];
+			if (isEClass(tag) && 0xC544 <= f0 && f0 <= 0xC774) r.flags |= MF_VOWEL_E;
+			if ((tag == T_JKS || tag == T_JKC) && kf.size() == 1 && f0 == 0xAC00) r.flags |= MF_INF_J;
+			if (f0 == 0xC73C || f0 == 0xB290 || (0xC0AC <= f0 && f0 <= 0xC2DC)) r.flags |= MF_BAD_PAIR_OF_L;
+			if (isEClass(tag) && f0 == 0xC5B4) r.flags |= MF_CONTRACTABLE_E;
+			uint32_t lastMorph, firstWid;
+			if (r.flags & MF_SINGLE) { lastMorph = (uint32_t)r.combinedId; firstWid = r.lmId; }
+			else { lastMorph = chunkMorphAt(r.chunkOff + r.nChunks - 1); firstWid = chunkLmAt(r.chunkOff); }
+			r.lastSeqId = lastMorph >= vocab ? lastMorph : lmIdOf(lastMorph);
+			if (lastMorph < vocab) r.flags |= MF_IN_VOCAB_LAST;
+			if (firstWid < nM + nTM && tagOf(firstWid) == T_P) r.flags |= MF_FIRST_WID_IS_P;
+			for (uint32_t c = 1; c < r.nChunks; ++c)
+			{
+				const uint32_t w = chunkLmAt(r.chunkOff + c);
+				if (w < nM + nTM && tagOf(w) == T_P) r.flags |= MF_ANY_REST_WID_IS_P;
+			}
+			if (!(r.flags & MF_SINGLE) && kf.size() == 1 && (f0 == 0xB2E4 || f0 == 0xAC8C || f0 == 0xC9C0))
+			{
+				const U16 c0 = kformOf(chunkMorphAt(r.chunkOff));
+				if (c0.size() == 1 && c0[0] == 0xD558) r.flags |= MF_HA_CONTRACTION;
+			}
+			uint8_t pf = 0;
+			if (isIrregularTag(tag)) pf |= PF_IRREGULAR;
+			if (tag == T_NP && kf.size() == 1 && (f0 == 0xB098 || f0 == 0xB108 || f0 == 0xC800)) pf |= PF_INFLECTENDA_NP;
+			if (isVerbClass(tag) && !kf.empty() && kf.back() == 0x11AF) pf |= PF_VERB_L;
+			if (isVerbClass(tag) && matchPolar((const uint16_t*)kf.data(), (uint32_t)kf.size(), CP_POSITIVE)) pf |= PF_POSITIVE_VERB;
+			if (isVerbClass(tag) && !kf.empty() && !isHangulCoda(kf.back())) pf |= PF_VERB_VOWEL;
+			if (tag == T_VA || tag == T_XSA) pf |= PF_VA_OR_XSA;
+			if (isEClass(tag) && tag != T_EF) pf |= PF_E_NOT_EF;
+			if (tag == T_UNKNOWN || tag == T_EF || tag == T_SF) pf |= PF_UNK_EF_SF;
+			r.prevFlags = pf;
+			r.special = 6;
+			if (tag == T_SB) o.sbInfo[k] = (uint8_t)getSBType(joinHangul(kf));
+		}
+		for (size_t k = 0; k < nTM; ++k)
+		{
+			const MorphRec& cm = o.morphs[k];
+			const MorphRec& wm = morphAt(cm.lastSeqId);
+			uint16_t f;
+			if (!(wm.flags & MF_KFORM_EMPTY)) f = wm.feat | ((wm.flags & MF_ENDS_WITH_SSC) ? LF_STR_SSC : 0);
+			else if (cm.tag == T_UNKNOWN && cm.nChunks)
+			{
+				const MorphRec& lm = morphAt(chunkMorphAt(cm.chunkOff + cm.nChunks - 1));
+				f = lm.feat | ((lm.flags & MF_ENDS_WITH_SSC) ? LF_STR_SSC : 0);
+			}
+			else f = cm.feat | ((cm.flags & MF_ENDS_WITH_SSC) ? LF_STR_SSC : 0);
+			if (cm.tag == T_SSC) f |= LF_TAG_SSC;
+			if (cm.tag == T_Z_SIOT) f |= LF_PREV_ZSIOT;
+			o.morphPath[k] = (uint32_t)f | ((uint32_t)wm.prevFlags << 16);
+		}
+		// ---- forms (they keep their order behind the model's and stay out of the trie) ----
+		o.forms.assign(nTF + 1, FormRec{});
+		const uint32_t charBase = (uint32_t)m.formChars.size() - 1;      // (the model's closing 0 is where the first temporary string begins)
+		uint8_t hash = m.forms[nF - 1].formHash;
+		for (size_t j = 0; j < nTF; ++j)
+		{
+			const U16& s = t.forms[j].str;
+			if (s.size() > 255) throw std::invalid_argument{ "temporary entries: form longer than 255 units" };
+			if (t.forms[j].cands.size() > 65535) throw std::invalid_argument{ "temporary entries: too many candidates" };
+			FormRec& f = o.forms[j];
+			f.charOff = charBase + (uint32_t)o.formChars.size();
+			f.len = (uint8_t)s.size();
+			f.numSpaces = (uint8_t)std::count(s.begin(), s.end(), u' ');
+			o.formChars.insert(o.formChars.end(), s.begin(), s.end());
+			f.candOff = (uint32_t)(m.formCand.size() + o.formCand.size());
+			f.candCnt = (uint16_t)t.forms[j].cands.size();
+			for (uint32_t c : t.forms[j].cands) { checkId(c); o.formCand.push_back(c); }
+			const uint32_t* cand = o.formCand.data() + (f.candOff - m.formCand.size());
+			if (!s.empty() && isHangulSyllable(s.back()))
+			{
+				bool zc = false, zs = false;
+				for (uint32_t c = 0; c < f.candCnt; ++c)
+				{
+					const uint32_t mi = cand[c];
+					const MorphRec& mr = morphAt(mi);
+					uint8_t tag = mr.tag;
+					if (tag == T_UNKNOWN && mr.nChunks) tag = tagOf(chunkMorphAt(mr.chunkOff + mr.nChunks - 1));
+					if (isJClass(tag) || isEClass(tag)) zc = true;
+					const uint8_t t2 = mr.tag;
+					if (isNNClass(t2) && mr.lmId != (uint32_t)clearIrregular(t2) + 1) zs = true;
+				}
+				if (zc) f.flags |= FF_ZCODA_APPENDABLE;
+				if (zs) f.flags |= FF_ZSIOT_APPENDABLE;
+			}
+			if (!s.empty() && isHangulCoda(s[0])) f.flags |= FF_FIRST_IS_CODA;
+			if (s.size() == 1) { const uint8_t st = identifySpecialChr(s[0]); if (T_SF <= st && st <= T_SW) f.flags |= FF_IS_STAG; }
+			if (!s.empty() && s[0] == 0xC544) f.flags |= FF_STARTS_WITH_A;
+			if (!s.empty() && identifySpecialChr(s.back()) == T_SSC) f.flags |= FF_ENDS_WITH_SSC;
+			{
+				const U16 prev = j ? t.forms[j - 1].str : m.formStr(nF - 1);
+				if (!equalIgnoringSpace(s, prev)) ++hash;
+				f.formHash = hash;
+			}
+			if (f.candCnt)
+			{
+				const MorphRec& c0 = morphAt(cand[0]);
+				if (c0.vowel != CV_NONE) { uint8_t v = c0.vowel; for (uint32_t c = 0; c < f.candCnt; ++c) v = reduceVowel(v, morphAt(cand[c]).vowel); f.vowelPolar = (uint8_t)((f.vowelPolar & 0xF0) | v); }
+				if (c0.polar != CP_NONE) { uint8_t p = c0.polar; for (uint32_t c = 0; c < f.candCnt; ++c) p = (p == morphAt(cand[c]).polar) ? p : (uint8_t)CP_NONE; f.vowelPolar = (uint8_t)((f.vowelPolar & 0x0F) | (p << 4)); }
+				bool hasJ = false, anyFull = false, allPartial = true;
+				for (uint32_t c = 0; c < f.candCnt; ++c)
+				{
+					const MorphRec& mm = morphAt(cand[c]);
+					const uint8_t tg = mm.tag;
+					hasJ = hasJ || isJClass(tg) || tg == T_EC || tg == T_EF;
+					const uint8_t ct = clearIrregular(tg);
+					const uint32_t md = (cand[c] < nM && !m.morphDialect.empty()) ? m.morphDialect[cand[c]] : 0u;
+					anyFull = anyFull || (md == 0 && ct != T_UNKNOWN && ct != T_P && ct != T_P + 1);
+					if (!(mm.socket || !(mm.flags & MF_SINGLE))) allPartial = false;
+				}
+				if (f.candCnt == 1 && morphAt(cand[0]).tag == T_UNKNOWN && morphAt(cand[0]).nChunks) allPartial = false;
+				if (allPartial) f.flags2 |= FF2_ALL_PARTIAL;
+				if (hasJ) f.flags |= FF_HAS_JCLASS;
+				if (anyFull) f.flags |= FF_HAS_ANY_FULL;
+			}
+		}
+		o.forms[nTF].charOff = charBase + (uint32_t)o.formChars.size();
+		o.forms[nTF].candOff = (uint32_t)(m.formCand.size() + o.formCand.size());
+		{
+			const U16 prev = nTF ? t.forms[nTF - 1].str : m.formStr(nF - 1);
+			if (!equalIgnoringSpace(U16{}, prev)) ++hash;
+			o.forms[nTF].formHash = hash;
+		}
+		o.formChars.push_back(0);
+		if (m.chrDim && !m.formUnkChr.empty())
+		{
+			const ChrView C = m.chrView();
+			o.formUnkChr.assign(nTF, 0.f);
+			for (size_t j = 0; j < nTF; ++j) o.formUnkChr[j] = chrScoreHost(C, o.formChars.data() + (o.forms[j].charOff - charBase), o.forms[j].len);
+			o.formChrTok.resize(o.formChars.size());
+			for (size_t i = 0; i < o.formChars.size(); ++i) o.formChrTok[i] = (uint16_t)chrToken(o.formChars[i], identifySpecialChr(o.formChars[i]));
+		}
 	}
 
 	namespace {
-	void bakeRaw(FlatModel& m, const RawModel& raw, uint32_t enabledDialects, size_t tempFrom)
+	void bakeRaw(FlatModel& m, const RawModel& raw, uint32_t enabledDialects, size_t tempFrom, size_t tempMorphFrom)
 	{
 		const size_t nF = raw.nForms(), nM = raw.nMorphs();
 		if (nF < kDefaultFormSize) throw std::runtime_error{ "raw model: missing default forms" };
@@ -1062,7 +1242,7 @@ namespace kamd
 		}
 		// KiwiBuilder::getSpecialMorphs (KiwiBuilder.cpp:2642-2662)
 		for (auto& s : m.h.specialMorph) s = 0;
-		for (size_t i = 0; i < nM; ++i)
+		for (size_t i = 0; i < std::min(nM, tempMorphFrom); ++i)      // (the special morphemes are fixed when the model is built: a call's temporary morphemes never take their place)
 		{
 			const U16& fs = rawForm[raw.morph[i].kform];
 			size_t base;
@@ -1312,6 +1492,23 @@ namespace kamd
 		}
 		if (raw.knlm && vocab > m.lmRoot.size()) throw std::runtime_error{ "raw model: vocab larger than LM vocab" };
 	}
+	}
+
+	int32_t formIdOfString(const FlatModel& m, const std::u16string& nrm)
+	{
+		uint32_t node = 0;
+		for (size_t i = 0; i < nrm.size(); ++i)
+		{
+			const uint16_t c = (uint16_t)nrm[i];
+			if (node == 0) { node = m.trieRoot[c]; if (!node) return -1; continue; }
+			const TrieNodeRec& t = m.trie[node];
+			const uint16_t* kb = m.trieKeys.data() + t.edgeOff;
+			const uint16_t* it = std::lower_bound(kb, kb + t.numNexts, c);
+			if (it == kb + t.numNexts || *it != c) return -1;
+			node = m.trieChild[t.edgeOff + (it - kb)];
+		}
+		if (node == 0 || m.trie[node].value < 0) return -1;
+		return m.trie[node].value;
 	}
 
 	std::vector<uint32_t> findMorphemes(const FlatModel& m, const char16_t* s, size_t n, uint8_t tag)

@@ -182,6 +182,25 @@ namespace
 			if (h.rawPath.empty()) throw std::runtime_error{ "oracle: temporary morphemes need the path the model was opened from" };
 			FlatModel tm;
 			bakeModelWithTemps(tm, h.rawPath, h.enabledDialects, temps);
+			// (test hook, KORC_CHECK_OVERLAY=1: the product's per-batch overlay -- bakeTempsOverlay, computed from the baked model alone -- must be exactly what the
+			// second bake appended to the tables; tests/test_pretokenized_golden.py runs every golden and live case with it)
+			if (std::getenv("KORC_CHECK_OVERLAY"))
+			{
+				TempOverlay o; bakeTempsOverlay(h.model, temps, o);
+				const FlatModel& b0 = h.model;
+				auto fail = [](const char* what) { throw std::runtime_error{ std::string{ "overlay != second bake: " } + what }; };
+				auto tailEq = [&](const auto& full, const auto& base, const auto& ov, size_t drop, const char* what)
+				{
+					if (full.size() != base.size() - drop + ov.size() || (ov.size() && std::memcmp(full.data() + (base.size() - drop), ov.data(), ov.size() * sizeof(ov[0])))) fail(what);
+				};
+				tailEq(tm.morphs, b0.morphs, o.morphs, 0, "morphs"); tailEq(tm.morphKform, b0.morphKform, o.morphKform, 0, "morphKform"); tailEq(tm.sbInfo, b0.sbInfo, o.sbInfo, 0, "sbInfo");
+				tailEq(tm.morphPath, b0.morphPath, o.morphPath, 0, "morphPath"); tailEq(tm.chunkMorph, b0.chunkMorph, o.chunkMorph, 0, "chunkMorph"); tailEq(tm.chunkLm, b0.chunkLm, o.chunkLm, 0, "chunkLm");
+				tailEq(tm.chunkPos, b0.chunkPos, o.chunkPos, 0, "chunkPos"); tailEq(tm.formCand, b0.formCand, o.formCand, 0, "formCand"); tailEq(tm.formChars, b0.formChars, o.formChars, 1, "formChars");
+				tailEq(tm.forms, b0.forms, o.forms, 1, "forms");
+				if (!b0.formUnkChr.empty()) { tailEq(tm.formUnkChr, b0.formUnkChr, o.formUnkChr, 0, "formUnkChr"); tailEq(tm.formChrTok, b0.formChrTok, o.formChrTok, 1, "formChrTok"); }
+				if (std::memcmp(tm.morphs.data(), b0.morphs.data(), b0.morphs.size() * sizeof(MorphRec)) || std::memcmp(tm.forms.data(), b0.forms.data(), (b0.forms.size() - 1) * sizeof(FormRec))) fail("the model's own entries moved");
+				if (const char* log = std::getenv("KORC_CHECK_OVERLAY_LOG")) { if (FILE* f = std::fopen(log, "a")) { std::fprintf(f, "%zu %zu\n", temps.forms.size(), temps.morphs.size()); std::fclose(f); } }
+			}
 			swap.saved = std::move(h.model); swap.on = true;
 			h.model = std::move(tm);
 			h.view = h.model.view();

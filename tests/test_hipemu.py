@@ -298,6 +298,18 @@ def test_emulated_c_api_suite(emu_libs, devices):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_emulated_pretokenized_spans_suite(emu_libs):
+    """Pretokenized spans on the device path, on the CPU: tests/test_gpu_pretokenized.py (all 190 golden analyses of the real reference through the batch ABI and
+    through kiwi_analyze_w with a kiwi_pretokenized_h, 480 fresh cases against the live reference and the oracle, byte offsets through kiwi_analyze, the error
+    convention, SkipBigram / CoNgram / character-model variants) re-run against the emulated build of the same sources: the span entries behind a chunk's
+    patterns, the forced node of the splitter's replay, the per-batch overlay of temporary forms / morphemes behind the model's tables."""
+    import sys
+    env = dict(os.environ, KAMD_TEST_LIB=emu_libs[0])
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_pretokenized.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-p", "no:xdist"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("kind", ["knlm-tiny-arenas", "sbg", "typo", "chr", "sbgtypo", "congg"])
 def test_emulated_kernels_under_address_and_ub_sanitizers(kind):
     """The emulated kernels compiled with AddressSanitizer + UndefinedBehaviorSanitizer (`make -C tests/hipemu asan`): an access

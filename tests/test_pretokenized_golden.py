@@ -63,6 +63,9 @@ def test_oracle_equals_the_reference_where_it_restates_spans(golden, small_model
     beyond the best one up to exactly tied analyses (the top-N rule, include/kiwi_capi.h)."""
     import oraclelib
     monkeypatch.setenv("KORC_QUIET", "1")
+    # (... and the product's per-batch overlay of the temporaries -- model.cpp bakeTempsOverlay, computed from the baked model alone -- is compared with what the
+    # second bake appended to every table, case by case: a mismatch refuses the case)
+    monkeypatch.setenv("KORC_CHECK_OVERLAY", "1")
     sm, path = small_model
     orc = oraclelib.OracleKiwi(path)
     done = refused = 0
@@ -95,6 +98,7 @@ def test_oracle_equals_the_live_reference_on_fresh_span_cases(small_model, monke
         pytest.skip("oracle/_ref/libkiwi_ref.so not built (needs /root/reference)")
     import make_golden_pretokenized as gen
     monkeypatch.setenv("KORC_QUIET", "1")
+    monkeypatch.setenv("KORC_CHECK_OVERLAY", "1")
     sm, path = small_model
     ref = refbridge.RefKiwi(path)
     orc = oraclelib.OracleKiwi(path)
