@@ -25,8 +25,8 @@ WORKLOADS = {
     # (median 60 jamo, sigma 0.6, clipped to 5..400); 131072 sentences = one GPU's share of the 1M-sentence corpus on 8 GPUs
     "c4-cong": ("full-cong", 131072, dict(min_jamo=5, max_jamo=400, lognormal=(60, 0.6)), 4),
     # ... and the reference's largest model type on the same lexicon and length distribution: CoNgram global (window 7: valid distant tokens are scored as a mixture over
-    # the context and the last seven such tokens of the path; kiwi_init's LARGEST / CONG_GLOBAL); the first 32768 sentences of the c4 corpus
-    "c4-cong-global": ("full-cong-global", 32768, dict(min_jamo=5, max_jamo=400, lognormal=(60, 0.6)), 4),
+    # the context and the last seven such tokens of the path; kiwi_init's LARGEST / CONG_GLOBAL); the c4 corpus itself (rounds 5: its first 32768 sentences)
+    "c4-cong-global": ("full-cong-global", 131072, dict(min_jamo=5, max_jamo=400, lognormal=(60, 0.6)), 4),
     "small-cong-c2": ("small-cong", 8192, dict(exact_jamo=40), 2),
     # c2 at the batch size the north-star throughput target is quoted on (>= 64k sentences): the throughput regime
     "c2-64k": ("full", 65536, dict(exact_jamo=40), 12),
@@ -181,7 +181,10 @@ def get_workload(name: str):
     os.makedirs(DATA, exist_ok=True)
     model_path = os.path.join(DATA, f"{spec_name}.raw")
     corpus_path = os.path.join(DATA, f"{name}.corpus.txt")
-    if not (_unpack_model(model_path) and os.path.exists(corpus_path)):
+    def _stale(path):      # (a corpus cached before the workload's size changed)
+        with open(path, encoding="utf-8") as f:
+            return f.read().count("\n") + 1 != n
+    if not (_unpack_model(model_path) and os.path.exists(corpus_path) and not (name != "c5" and _stale(corpus_path))):
         from .synth import SEED_BASE, SynthModel
         sm = SynthModel(_spec(spec_name))
         sm.raw.save(model_path)

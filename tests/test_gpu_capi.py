@@ -254,7 +254,8 @@ def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
     assert r and read_result(capi, kiwi, r) == from_oracle(oracle.analyze_dialect(s, 0x3FF, 3.0))
     capi.kiwi_res_close(r)
     assert not capi.kiwi_init(b"/nonexistent", 0, 15, 1) and capi.kiwi_error()      # (no such model; enabled dialects themselves are accepted)
-    # pretokenized objects can be built and closed; without spans they constrain nothing, with a span the analysis is refused loudly
+    # pretokenized objects can be built and closed; without spans they constrain nothing; with a span the analysis honours it (round 6: the whole argument is
+    # tests/test_gpu_pretokenized.py's) -- what stays refused is a span together with a typo transformer
     import ctypes as C
     capi.kiwi_pt_init.restype = C.c_void_p
     capi.kiwi_pt_add_span.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -267,7 +268,17 @@ def test_config_roundtrip_and_refusals(capi, kiwi, oracle):
     capi.kiwi_res_close(r)
     assert capi.kiwi_pt_add_span(pt, 0, 3) == 0 and capi.kiwi_pt_add_token_to_span(pt, 0, "가나다".encode(), b"NNP", 0, 3) == 0
     assert capi.kiwi_pt_add_token_to_span(pt, 5, "가".encode(), b"NNP", 0, 1) != 0
-    assert not capi.kiwi_analyze(kiwi, s.encode(), 1, opt(), pt) and b"pretokenized" in capi.kiwi_error()
+    r = capi.kiwi_analyze(kiwi, s.encode(), 1, opt(), pt)
+    assert r, capi.kiwi_error()
+    first = capi.kiwi_res_token_info(r, 0, 0).contents
+    assert (capi.kiwi_res_form(r, 0, 0).decode(), capi.kiwi_res_tag(r, 0, 0), first.chr_position, first.typo_form_id) == ("가나다", b"NNP", 0, 1)
+    capi.kiwi_res_close(r)
+    capi.kiwi_typo_get_default.restype = C.c_void_p
+    capi.kiwi_typo_get_default.argtypes = [C.c_int]
+    o = opt()
+    o.typo_transformer = capi.kiwi_typo_get_default(1)      # KIWI_TYPO_BASIC_TYPO_SET
+    o.typo_threshold = 2.5
+    assert o.typo_transformer and not capi.kiwi_analyze(kiwi, s.encode(), 1, o, pt) and b"pretokenized" in capi.kiwi_error()
     assert capi.kiwi_pt_close(pt) == 0
 
 

@@ -253,3 +253,43 @@ def test_c3_sbg_corpus_8192_sentences_and_the_heaviest_top3_vs_oracle():
         want = list(ex.map(one, sample))
     bad = [i for i, w, y in zip(idx, want, got) if _norm(w) != _norm(y)]
     assert not bad, (len(bad), bad[:5])
+
+
+def test_c4_cong_global_4k_sentences_and_the_longest_vs_oracle_and_reference():
+    """The reference's largest model type on the model and corpus its bench line times (bench.py `c4-cong-global`: 'full-cong-global', window 7, the c4 corpus):
+    the first 4096 sentences plus the corpus's 64 longest (hundreds of paths per node: the medium / large containers, the replay of the reference's container
+    behaviour past 64 entries) -- device (kamd_open_mode lm_mode 4) vs the CPU oracle, top-1 and top-3 (first 512), analysis for analysis with fp32 scores; and vs
+    the REAL src/CoNgramModel.cpp (SSE4.1 build, useDistantTokens) where the x86 reference library travelled (src/CoNgramModel.cpp:802-868, 1037, 1304, 1470-1490)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
+    import oraclelib
+    import refbridge
+    from kiwi_amd.api import KiwiAmd
+    from kiwi_amd.workloads import get_workload
+    path, texts, _ = get_workload("c4-cong-global")
+    longest = sorted(range(len(texts)), key=lambda i: -len(texts[i]))[:64]
+    idx = list(range(4096)) + [i for i in longest if i >= 4096]
+    sample = [texts[i] for i in idx]
+    dev = KiwiAmd(path, lm_mode=4)
+    got1 = dev.analyze_batch(sample).to_python()
+    got3 = dev.analyze_batch(sample[:512], top_n=3).to_python()
+    dev.close()
+    local = threading.local()
+
+    def orc():
+        if not hasattr(local, "k"):
+            local.k = oraclelib.OracleKiwi(path)
+            local.k.set_cong_global(True)
+        return local.k
+    with ThreadPoolExecutor(max(4, min(32, (os.cpu_count() or 8) // 2))) as ex:
+        want1 = list(ex.map(lambda s: orc().analyze(s), sample))
+        want3 = list(ex.map(lambda s: orc().analyze(s, top_n=3), sample[:512]))
+    bad = [i for i, w, y in zip(idx, want1, got1) if _norm(w) != _norm(y)]
+    assert not bad, (len(bad), bad[:5])
+    bad = [i for i, w, y in zip(idx, want3, got3) if _norm(w) != _norm(y)]
+    assert not bad, (len(bad), bad[:5])
+    if refbridge.x86_available():
+        ref = refbridge.RefKiwi(path, arch=3, model_dir_sbg="cong_global", x86=True)
+        sub = list(range(0, 4096, 4)) + list(range(4096, len(sample)))
+        bad = [idx[i] for i in sub if _norm(ref.analyze(sample[i])) != _norm(got1[i])]
+        assert not bad, (len(bad), bad[:5])
