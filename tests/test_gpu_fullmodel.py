@@ -228,7 +228,7 @@ def test_c3_sbg_2k_sentences_top3_vs_oracle_and_reference():
 def test_c3_sbg_corpus_8192_sentences_and_the_heaviest_top3_vs_oracle():
     """BASELINE config 3 on the corpus its bench line times (c3-sbg: SkipBigram, top-3): the first 8192 sentences plus the corpus's 64 heaviest -- most
     lattice nodes with more than 512 incoming paths, where the large path container, the top-N key lists of the item table and the N-th-best pruning
-    threshold run (tests/golden/c3_sbg_heaviest.json, tools/r05/sbg_heaviest.py) -- device vs the CPU oracle, analysis for analysis with fp32 scores."""
+    threshold run (tests/golden/c3_sbg_heaviest.json, tools/sbg_heaviest.py) -- device vs the CPU oracle, analysis for analysis with fp32 scores."""
     import json
     from concurrent.futures import ThreadPoolExecutor
     import threading

@@ -1,7 +1,7 @@
 """Developer aid: host time of kamd_fetch (D2H + result assembly) per sentence on ONE core, measured on a batch whose kernels ran once (lane emulator: LIB=tests/hipemu/_build/libkiwi_hipemu.so,
-or the product library on a GPU box).  KAMD_HOST_THREADS=1 python tools/r05/host_fetch_time.py <sentences> <repetitions>"""
+or the product library on a GPU box).  KAMD_HOST_THREADS=1 python tools/host_fetch_time.py <sentences> <repetitions>"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kiwi_amd.api import KiwiAmd
 from kiwi_amd.workloads import get_workload
 p,t,d = get_workload('c2-64k')

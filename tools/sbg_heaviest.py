@@ -1,9 +1,9 @@
 """Which sentences of the c3-sbg corpus are the heaviest for the SkipBigram search -- most lattice nodes with more than 512 incoming paths (the oracle's
 event counters), then most incoming paths of one node.  Writes tests/golden/c3_sbg_heaviest.json (indices into the corpus, read by tests/test_gpu_fullmodel.py).
-  python tools/r05/sbg_heaviest.py [threads]"""
+  python tools/sbg_heaviest.py [threads]"""
 import json, os, sys, threading, time
 from concurrent.futures import ThreadPoolExecutor
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oraclelib
 from kiwi_amd.workloads import get_workload

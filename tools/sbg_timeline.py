@@ -1,7 +1,7 @@
 """Developer aid (round 5): per-chunk timeline of the SkipBigram search on the first N sentences of c3-sbg (top-3) -- the slowest chunks phase by phase.
-KAMD_LIB=$PWD/kiwi_amd/libkiwi_hip_timeline.so python tools/r05/sbg_timeline.py [N]"""
+KAMD_LIB=$PWD/kiwi_amd/libkiwi_hip_timeline.so python tools/sbg_timeline.py [N]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kiwi_amd.api import KiwiAmd
 from kiwi_amd.workloads import get_workload
 p, t, d = get_workload("c3-sbg")
