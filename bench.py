@@ -230,7 +230,8 @@ def side_measurement(eng, workload, steps=20, limit=0, min_seconds=0.0):
     if own:
         eng.close()
     out = {"workload": desc, "value": len(texts) * steps / el, "unit": "sentences/s", "steps": steps, "ms_per_step": 1000.0 * el / steps, "kernel_ms": {k: v / steps for k, v in kt.items()},
-           "sentences": len(texts), "top_n": top_n, "device_bytes": info["device_bytes"], "rerun_chunks": rerun_chunks}
+           "sentences": len(texts), "top_n": top_n, "device_bytes": info["device_bytes"], "rerun_chunks": rerun_chunks,
+           "m_jamo_per_s": info["units"] * steps / el / 1e6}
     try:
         per = cpu_baseline(model_path, texts, top_n=top_n, typo=typo_cfg, time_reference=False, cong_global=workload_lm_mode(workload) == 4)["alg_bytes_per_sentence"]
         out["alg_bytes_per_sentence"] = per
@@ -449,6 +450,7 @@ def main():
             achieved = search_bytes / (kt["search_ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_pos_path + k_best_path (the search: position steps, then what they hand over and the end stage)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload, ("k_pos_path", "k_best_path")),
+                               "traffic_source": "profiles/traffic.json: FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes over this command with --kernels-only (tools/measure_round.sh), NOT counted during this run",
                                "measured_copy_GBs": copy_bandwidth_gbs() if world == 1 else None,
                                "alg_bytes_per_sentence": per, "all_kernels_achieved": per["total"] * n / ((kt["scan_ms"] + kt["lattice_ms"] + kt["search_ms"] + kt["finish_ms"]) * 1e-3) / 1e9}
             if "cpu_baseline" in cb:
