@@ -372,6 +372,7 @@ namespace kamd
 		v.chunkMorph = impl->up(m.chunkMorph, I_::kTempChunks); v.chunkLm = impl->up(m.chunkLm, I_::kTempChunks); v.chunkPos = impl->up(m.chunkPos, 2 * I_::kTempChunks);
 		v.sbInfo = impl->up(m.sbInfo, I_::kTempMorphs); v.morphPath = impl->up(m.morphPath, I_::kTempMorphs);
 		v.trie = impl->up(m.trie); v.trieKeys = impl->up(m.trieKeys); v.trieChild = impl->up(m.trieChild); v.trieRoot = impl->up(m.trieRoot);
+		v.trieEdges = impl->up(m.trieEdges); v.trieEdgeMask = m.trieEdgeMask;
 		v.lmNodes = impl->up(m.lmNodes); v.lmKeys = impl->up(m.lmKeys); v.lmValues = impl->up(m.lmValues); v.lmRoot = impl->up(m.lmRoot);
 		if (m.congDim)
 		{
@@ -394,8 +395,8 @@ namespace kamd
 		else { v.lmHash = impl->up(m.lmHash); v.lmHashMask = m.lmHashMask; v.lmRoot2 = impl->up(m.lmRoot2); v.lmBackoff = impl->up(m.lmBackoff); }
 		v.lmHtxNode = (m.congDim || m.lmHtxNode.empty()) ? nullptr : impl->up(m.lmHtxNode);      // history-transformed Knlm only
 		// (dialect bits: the room behind them is zero -- a temporary entry belongs to no dialect)
-		v.formDialect = m.formDialect.empty() ? nullptr : impl->up(m.formDialect, I_::kTempForms); v.morphDialect = m.morphDialect.empty() ? nullptr : impl->up(m.morphDialect, I_::kTempMorphs);
-		if (v.formDialect) HIPCHECK(hipMemset(const_cast<uint16_t*>(v.formDialect) + m.formDialect.size(), 0, 2 * I_::kTempForms));
+		v.formDialect = nullptr;      // (a bake-time fact: flat_model.hpp ModelView::formDialect)
+		v.morphDialect = m.morphDialect.empty() ? nullptr : impl->up(m.morphDialect, I_::kTempMorphs);
 		if (v.morphDialect) HIPCHECK(hipMemset(const_cast<uint16_t*>(v.morphDialect) + m.morphDialect.size(), 0, 2 * I_::kTempMorphs));
 		v.formUnkChr = nullptr; v.formChrTok = nullptr;
 		v.lmChain = nullptr;

@@ -84,6 +84,14 @@ namespace kamd
 		int32_t value;       // form id, TRIE_NONE, or TRIE_SUBMATCH
 	};
 	static_assert(sizeof(TrieNodeRec) == 16, "TrieNodeRec");
+	// Edge (node, key) -> child of the form trie as ONE memory round trip: an open-addressing table of 16-byte slots (linear probing, at most a quarter full)
+	// over every edge below the root (the root has its direct table).  The sorted keys per node stay (host walks, the bake's fail links): a device walk through
+	// them costs 2 + log2(fan-out) DEPENDENT loads per character -- the record, the halving steps, the child --, which is what bounds the dictionary scan and
+	// the typo lattice's automaton steps.
+	struct TrieEdgeSlot { uint32_t node, key, child, pad; };
+	static_assert(sizeof(TrieEdgeSlot) == 16, "TrieEdgeSlot");
+	constexpr uint32_t TRIE_EDGE_EMPTY = 0xFFFFFFFFu;
+	KAMD_HD uint32_t trieEdgeHash(uint32_t node, uint32_t key) { uint32_t h = node * 0x9E3779B1u + key * 0x85EBCA6Bu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13; return h; }
 	constexpr int32_t TRIE_NONE = -1, TRIE_SUBMATCH = -2;
 	// bits 13..15 of a left-feature mask (bits 0..12: feature.hpp featMask)
 	constexpr uint16_t LF_STR_SSC = 1u << 13, LF_PREV_ZSIOT = 1u << 14, LF_TAG_SSC = 1u << 15;
@@ -149,12 +157,17 @@ namespace kamd
 		const float* formUnkChr;
 		// ... and the character model's token of every unit of formChars (Match::oovChrFreqModel walks a dictionary form's string per node: chr_freq.hpp)
 		const uint16_t* formChrTok;
-		// Dialect bits per form / per morpheme (null: the model has no dialect morphemes): the dictionary scan drops a form, the candidate expansion a
-		// morpheme whose dialect is neither standard nor allowed (KTrie.cpp:207-229, PathEvaluator.hpp:386, 893); an allowed dialect morpheme costs dialectCost
+		// Dialect bits per form / per morpheme (null: the model has no dialect morphemes).  morphDialect: a morpheme whose dialect is neither standard nor allowed
+		// is no candidate (PathEvaluator.hpp:386, 893: blockBits per batch), an allowed one costs dialectCost.  formDialect is a BAKE-time fact only -- a form of
+		// dialects that are not enabled stays out of the trie (KiwiBuilder.cpp:2501-2504); the splitter this library restates (flushCandidates, KTrie.cpp:955-996)
+		// does not test a form's dialect when it builds the lattice (the test of KTrie.cpp:207-229 belongs to insertCandidates, the legacy splitter behind
+		// useOldSplitter, which is refused): the pointer stays null on the device
 		const uint16_t* formDialect; const uint16_t* morphDialect;
 		// device only (Knlm): per LM node the next two nodes of its back-off chain as absolute ids {node + lower, that node's lower node}; 0 = the root,
 		// where every chain ends.  A search state that carries this pair can probe all three contexts of its next transition at once (viterbi_pos.inc)
 		const uint32_t* lmChain;
+		// form-trie edges as a hash (TrieEdgeSlot): slot (trieEdgeHash(node, key) + i) & trieEdgeMask, i = 0, 1, ... until the edge or an empty slot
+		const TrieEdgeSlot* trieEdges; uint32_t trieEdgeMask;
 	};
 
 	// SkipBigram tables (reference src/SkipBigramModel.hpp:40-105), kept apart from ModelView: only the CPU restatement uses
@@ -355,6 +368,7 @@ namespace kamd
 		std::vector<uint16_t> trieKeys;
 		std::vector<uint32_t> trieChild;
 		std::vector<uint32_t> trieRoot;
+		std::vector<TrieEdgeSlot> trieEdges; uint32_t trieEdgeMask = 0;      // ModelView::trieEdges (model.cpp buildTrieEdges)
 		std::vector<LmNodeRec> lmNodes;
 		std::vector<uint32_t> lmKeys;
 		std::vector<int32_t> lmValues;
@@ -432,6 +446,7 @@ namespace kamd
 			v.formUnkChr = formUnkChr.empty() ? nullptr : formUnkChr.data();
 			v.formChrTok = formChrTok.empty() ? nullptr : formChrTok.data();
 			v.lmChain = nullptr;
+			v.trieEdges = trieEdges.empty() ? nullptr : trieEdges.data(); v.trieEdgeMask = trieEdgeMask;
 			v.formDialect = formDialect.empty() ? nullptr : formDialect.data(); v.morphDialect = morphDialect.empty() ? nullptr : morphDialect.data();
 			return v;
 		}
@@ -445,6 +460,7 @@ namespace kamd
 	// model.cpp
 	// enabledDialects: KiwiBuilder's enabledDialects (kiwi_init's last argument; Dialect bits, 0 = standard only)
 	void bakeModel(FlatModel& out, const std::string& rawModelPath, uint32_t enabledDialects = 0);
+	void buildTrieEdges(FlatModel& m);      // FlatModel::trieEdges from trie / trieKeys / trieChild (the end of every bake)
 	// ... with temporary forms and morphemes behind the model's own (pretokenized spans, src/Kiwi.cpp:785-946; model.cpp).  Form j gets id nForms + j, morpheme k
 	// id nMorphs + k; `cands` / `chunks[].morph` are morpheme ids of the model or of these temporaries
 	struct TempEntries

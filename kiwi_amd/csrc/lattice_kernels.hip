@@ -27,20 +27,19 @@
 
 namespace kamd
 {
+	// child of `node` over `c` (0: none): the root's direct table, below it the edge hash -- one 16-byte load per probe, 1.1 probes on average (flat_model.hpp
+	// TrieEdgeSlot); rounds 1 - 5 searched the node's sorted keys: record + log2(fan-out) halving steps + child, each a dependent load
 	__device__ __forceinline__ uint32_t trieChild(const ModelView& M, uint32_t node, uint16_t c)
 	{
 		if (node == 0) return M.trieRoot[c];
-		const TrieNodeRec t = M.trie[node];
-		const uint16_t* keys = M.trieKeys + t.edgeOff;
-		uint32_t lo = 0, hi = t.numNexts;
-		while (lo < hi)
+		uint32_t h = trieEdgeHash(node, c) & M.trieEdgeMask;
+		for (;;)
 		{
-			const uint32_t mid = (lo + hi) >> 1;
-			const uint16_t k = keys[mid];
-			if (k < c) lo = mid + 1; else hi = mid;
+			const uint4 s = reinterpret_cast<const uint4*>(M.trieEdges)[h];
+			if (s.x == node && s.y == (uint32_t)c) return s.z;
+			if (s.x == TRIE_EDGE_EMPTY) return 0;
+			h = (h + 1) & M.trieEdgeMask;
 		}
-		if (lo < t.numNexts && keys[lo] == c) return M.trieChild[t.edgeOff + lo];
-		return 0;
 	}
 
 	__global__ void __launch_bounds__(256) k_dict_scan(ModelView M, BatchView B, WorkView W, uint32_t chunkBegin, uint32_t chunkCount)

@@ -1445,6 +1445,7 @@ namespace kamd
 			}
 		}
 
+		buildTrieEdges(m);
 		m.h.nForms = (uint32_t)nF; m.h.nMorphs = (uint32_t)nM; m.h.vocabSize = vocab;
 		m.h.nTrieNodes = (uint32_t)nT; m.h.nTrieEdges = (uint32_t)m.trieKeys.size();
 		m.h.maxFormLen = maxLen;
@@ -1492,6 +1493,28 @@ namespace kamd
 		}
 		if (raw.knlm && vocab > m.lmRoot.size()) throw std::runtime_error{ "raw model: vocab larger than LM vocab" };
 	}
+	}
+
+	void buildTrieEdges(FlatModel& m)
+	{
+		size_t edges = 0;
+		for (size_t n = 1; n < m.trie.size(); ++n) edges += m.trie[n].numNexts;
+		size_t cap = 64;
+		while (cap < 4 * edges) cap <<= 1;      // at most a quarter full: a lookup that misses ends at an empty slot after 1.2 probes on average
+		if (cap > (1ull << 31)) throw std::runtime_error{ "form trie too large for the edge table" };
+		m.trieEdges.assign(cap, TrieEdgeSlot{ TRIE_EDGE_EMPTY, 0, 0, 0 });
+		m.trieEdgeMask = (uint32_t)cap - 1;
+		for (size_t n = 1; n < m.trie.size(); ++n)
+		{
+			const TrieNodeRec& t = m.trie[n];
+			for (uint32_t e = 0; e < t.numNexts; ++e)
+			{
+				const uint32_t key = m.trieKeys[t.edgeOff + e];
+				uint32_t h = trieEdgeHash((uint32_t)n, key) & m.trieEdgeMask;
+				while (m.trieEdges[h].node != TRIE_EDGE_EMPTY) h = (h + 1) & m.trieEdgeMask;
+				m.trieEdges[h] = TrieEdgeSlot{ (uint32_t)n, key, m.trieChild[t.edgeOff + e], 0 };
+			}
+		}
 	}
 
 	int32_t formIdOfString(const FlatModel& m, const std::u16string& nrm)

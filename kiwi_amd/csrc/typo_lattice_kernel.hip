@@ -184,12 +184,15 @@ namespace kamd
 			__device__ __forceinline__ int32_t trieNext(uint32_t node, uint16_t c) const
 			{
 				if (node == 0) { const uint32_t r = M.trieRoot[c]; return r ? (int32_t)r : -1; }
-				const TrieNodeRec t = M.trie[node];
-				uint32_t lo = 0, hi = t.numNexts;
-				const uint16_t* kb = M.trieKeys + t.edgeOff;
-				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (kb[mid] < c) lo = mid + 1; else hi = mid; }
-				if (lo == t.numNexts || kb[lo] != c) return -1;
-				return (int32_t)M.trieChild[t.edgeOff + lo];
+				// (the edge hash: one dependent load per probe instead of record + binary search + child, flat_model.hpp TrieEdgeSlot)
+				uint32_t h = trieEdgeHash(node, c) & M.trieEdgeMask;
+				for (;;)
+				{
+					const uint4 s = reinterpret_cast<const uint4*>(M.trieEdges)[h];
+					if (s.x == node && s.y == (uint32_t)c) return (int32_t)s.z;
+					if (s.x == TRIE_EDGE_EMPTY) return -1;
+					h = (h + 1) & M.trieEdgeMask;
+				}
 			}
 			__device__ __forceinline__ uint16_t formChar(const TypoGraphNode& g, uint32_t j) const
 			{

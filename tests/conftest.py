@@ -28,6 +28,16 @@ def _locked_make():
             # (a multi-process gloo job next to seven busy test processes: a rank was seen to abort in its rendezvous once in three runs of the suite -- such a job
             # gets ONE more try; a real defect fails twice)
             if retry_torchrun and isinstance(cmd, (list, tuple)) and "torch.distributed.run" in [str(c) for c in cmd] and getattr(r, "returncode", 0) != 0:
+                # (never silently: the first attempt's end goes to stderr -- pytest shows it with a failure, `-rA` / `-s` always -- and into _data/torchrun_retries.log)
+                tail = (getattr(r, "stderr", None) or "")
+                tail = tail[-1500:] if isinstance(tail, str) else tail[-1500:].decode("utf-8", "replace")
+                note = f"[conftest] torch.distributed.run job failed (rc {r.returncode}) and is tried ONCE more: {' '.join(str(c) for c in cmd)[-300:]}\n{tail}\n"
+                sys.stderr.write(note)
+                try:
+                    with open(os.path.join(ROOT, "_data", "torchrun_retries.log"), "a") as f:
+                        f.write(note)
+                except OSError:
+                    pass
                 r = fn(cmd, *a, **kw)
             return r
         return call
@@ -38,6 +48,7 @@ def _locked_make():
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "xdist_group: tests of one file stay in one worker process (pytest-xdist's loadgroup; a no-op without it)")
     _locked_make()
     # The CPU suite (-m "not gpu": oracle vs reference vs goldens, the kernels on the lane emulator) is half an hour of single-core work; its files are independent, so
     # it runs them on several processes when pytest-xdist is there -- file by file (module-scoped fixtures, a file's torchrun tests stay in one process; the two long

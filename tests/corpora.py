@@ -136,3 +136,11 @@ def repeated_unknown_texts(sm, n, seed):
             parts.insert(rnd.randint(0, len(parts)), rnd.choice(made) + rnd.choice(["", "", "은", "를", "이"]))
         out.append(" ".join(parts) + ("" if i % 4 else " " + t))
     return out
+
+
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of a torch.distributed.run job: the test files run side by side under pytest-xdist)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+from corpora import free_port
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
@@ -74,7 +76,7 @@ def test_bench_main_with_two_ranks(tmp_path):
     drv = tmp_path / "bench_two_ranks.py"
     drv.write_text(DRIVER2 % {"root": ROOT})
     env = dict(os.environ, KAMD_LIB=os.path.join(HERE, "hipemu", "_build", "libkiwi_hipemu.so"))
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29633", str(drv)],
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(drv)],
                        env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -84,7 +86,7 @@ def test_bench_main_with_two_ranks(tmp_path):
     assert abs(out["value"] - 16 * 2 * 2 / (out["ms_per_step"] * 2 / 1000.0)) < 1e-6 * out["value"] + 1e-9      # all ranks' sentences / max time
     assert out["gather"]["merged_texts"] == 32 and out["gather"]["bytes_per_rank"] > 1000      # the packed token records of both ranks arrived on rank 0
     # strong scaling: ONE corpus split by index, the gathered records merged in input order
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29635", str(drv), "--scaling", "strong"],
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(drv), "--scaling", "strong"],
                        env=env, capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
@@ -101,7 +103,7 @@ def test_bench_main_with_eight_ranks_strong_scaling(tmp_path):
     drv.write_text(DRIVER2 % {"root": ROOT})
     env = dict(os.environ, KAMD_LIB=os.path.join(HERE, "hipemu", "_build", "libkiwi_hipemu.so"), KAMD_TEST_WORLD="8", OMP_NUM_THREADS="1")
     for extra, per_rank, merged in ((["--scaling", "strong"], 2, 16), ([], 16, 128)):
-        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29641" if extra else "29643", str(drv)] + extra,
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(drv)] + extra,
                            env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+from corpora import free_port
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
@@ -36,7 +38,7 @@ def test_two_rank_gloo_driver(small_model, tmp_path):
     script.write_text(WORKER.format(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29613", str(script)], capture_output=True, text=True, env=env, timeout=600)
+                          "--master-port", str(free_port()), str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -93,7 +95,7 @@ def test_two_rank_gather_of_packed_token_records_equals_single_process(small_mod
     script.write_text(GATHER_WORKER.format(root=ROOT, lib=lib))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29617", str(script)], capture_output=True, text=True, env=env, timeout=900)
+                          "--master-port", str(free_port()), str(script)], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["world"] == 2 and r["texts"] == 304 and r["equal"], r
