@@ -619,7 +619,10 @@ namespace kamd
 	// the chunk's own data is an LDS access instead of a dependent HBM round trip; search states and the typo graph stay in HBM (read once per
 	// step).  The final reorder and the per-node facts run one node per lane.  A chunk whose node list outgrows its LDS copy is handed to
 	// the thread-per-chunk kernel (TypoLatChunk::status = kTypoLdsNeedsBig).
-	__global__ void __launch_bounds__(64) k_build_lattice_typo_lds(ModelView M, TypoLatView V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
+	#ifndef KAMD_TYPO_LDS_WPS
+#define KAMD_TYPO_LDS_WPS 4
+#endif
+	__global__ void __launch_bounds__(64, KAMD_TYPO_LDS_WPS) k_build_lattice_typo_lds(ModelView M, TypoLatView V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
 	{
 		if (blockIdx.x >= chunkCount) return;
 		const uint32_t lane = threadIdx.x;

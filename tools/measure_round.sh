@@ -7,14 +7,14 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
-timeout 600 python bench.py --workload $WL > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; cut -c1-600 $OUT/bench_$WL.json
+timeout 900 python bench.py --workload $WL > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; cut -c1-600 $OUT/bench_$WL.json
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --kernels-only > $OUT/trace_$WL.log 2>&1
+timeout ${TO:-400} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --kernels-only > $OUT/trace_$WL.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$WL.csv 2>/dev/null; rm -rf $OUT/trace
 head -8 $OUT/kernel_stats_$WL.csv | cut -c1-60,150-260
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   n=$(echo $c | cut -d' ' -f1)
-  timeout 200 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $ROOT/bench.py --workload $WL --steps 4 --warmup 1 --kernels-only > $OUT/pmc_$n.log 2>&1
+  timeout ${TO:-400} rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -- python $ROOT/bench.py --workload $WL --steps 4 --warmup 1 --kernels-only > $OUT/pmc_$n.log 2>&1
 done
 python3 - $OUT $WL <<'PY'
 import csv, sys, glob, collections, json
