@@ -620,7 +620,7 @@ namespace kamd
 	// step).  The final reorder and the per-node facts run one node per lane.  A chunk whose node list outgrows its LDS copy is handed to
 	// the thread-per-chunk kernel (TypoLatChunk::status = kTypoLdsNeedsBig).
 	#ifndef KAMD_TYPO_LDS_WPS
-#define KAMD_TYPO_LDS_WPS 4
+#define KAMD_TYPO_LDS_WPS 5      // (79 VGPRs, five wavefronts per SIMD = the 20 per CU its 8 KB of LDS allow: c5 lattice 2.16 -> 2.01 ms, profiles/r06_g; 8: no gain)
 #endif
 	__global__ void __launch_bounds__(64, KAMD_TYPO_LDS_WPS) k_build_lattice_typo_lds(ModelView M, TypoLatView V, const uint32_t* chunkList, uint32_t chunkCount, uint32_t ldsBytes)
 	{
