@@ -4,11 +4,12 @@
 #include <unistd.h>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <chrono>
-#include <cstring>
+#include <condition_variable>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -18,6 +19,7 @@
 #include "engine.hpp"
 #include "pretok.hpp"
 #include "hostpool.hpp"
+#include "post_fast.hpp"
 #include "viterbi_kernel.hpp"
 #include "exact_math.hpp"
 #include "cong_global.hpp"
@@ -221,7 +223,16 @@ namespace kamd
 		const DevChunkResult* hResults = nullptr; const DevPathHeader* hPaths = nullptr; const DevToken* hTokens = nullptr;   // inside hOut
 		bool ran = false;
 		hipEvent_t evDone = nullptr; bool launched = false; uint32_t launchS = 1;      // recorded behind the batch's last kernel (Engine::launch); Engine::finish waits for it
-		~StagedBatch() { if (evDone) (void)hipEventDestroy(evDone); }
+		~StagedBatch()
+		{
+			if (evDone) (void)hipEventDestroy(evDone);
+			// the prepared texts go back to the allocator on the workers (a thousand blocks of six vectors each: 1.4 ms per 65 536 texts on one thread)
+			if (prepBlocks.size() >= 64)
+			{
+				try { HostPool::instance().run(prepBlocks.size(), 16, hostThreads, [&](size_t i0, size_t i1, int) { for (size_t i = i0; i < i1; ++i) { PrepBlock dead = std::move(prepBlocks[i]); } }); }
+				catch (...) {}
+			}
+		}
 		uint32_t subBatches = 0;
 		uint32_t topN = 1;            // the search of the last run() kept this many paths per key
 		// chunks of the last run that overflowed and were searched again with larger capacities: index into overPaths per chunk (SIZE_MAX: none)
@@ -286,6 +297,7 @@ namespace kamd
 		// the engine owns ONE pair of streams, one work counter and one scratch arena: device work of concurrent callers (the C API
 		// is callable from many threads, reference capi threading contract) is serialised per engine; host preparation is not
 		std::recursive_mutex deviceMu;
+		TokenTemplates tokTmpl;      // (post_fast.hpp; built with the first fetch)
 
 		// room behind the model's form / morpheme tables for the temporary entries of a batch with pretokenized spans (TempOverlay): elements per table
 		static constexpr size_t kTempForms = 4096, kTempMorphs = 8192, kTempChars = 1u << 17, kTempCand = 16384, kTempChunks = 16384;
@@ -485,8 +497,17 @@ namespace kamd
 		struct HostTimer
 		{
 			bool on = std::getenv("KAMD_HOST_TIMING") != nullptr; const char* what; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+			double cpu0 = on ? cpuNow() : 0.0;
 			explicit HostTimer(const char* w) : what(w) {}
-			void lap(const char* name) { if (!on) return; const auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[host] %s: %s %.2f ms\n", what, name, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; }
+			// CPU time of the whole process (every worker): what a CFS quota meters
+			static double cpuNow() { timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+			void lap(const char* name)
+			{
+				if (!on) return;
+				const auto t1 = std::chrono::steady_clock::now(); const double c1 = cpuNow();
+				fprintf(stderr, "[host] %s: %s %.2f ms (process CPU %.1f ms)\n", what, name, std::chrono::duration<double, std::milli>(t1 - t0).count(), c1 - cpu0);
+				t0 = t1; cpu0 = c1;
+			}
 		};
 	}
 
@@ -504,6 +525,7 @@ namespace kamd
 
 	static void layoutAndUpload(Engine::Impl& I, StagedBatch& b, const SearchParams&)
 	{
+		HostTimer tmL{ "layout" };
 		const size_t nC = b.refs.size();
 		b.charOff.assign(nC + 1, 0); b.patOff.assign(nC + 1, 0); b.spOff.assign(nC + 1, 0);
 		b.matchBase.assign(nC + 1, 0); b.nodeBase.assign(nC + 1, 0); b.packBase.assign(nC + 1, 0); b.stateBase.assign(nC + 1, 0); b.tokenBase.assign(nC + 1, 0);
@@ -512,36 +534,80 @@ namespace kamd
 		static const bool noSlots = std::getenv("KAMD_NO_STATE_SLOTS") != nullptr;      // (developer switch: per-chunk arenas for the history models too)
 		const bool slotMode = I.histStates() && !noSlots;
 		uint64_t slotCap = 0;
-		for (size_t c = 0; c < nC; ++c)
+		// what chunk c takes of each region (the offsets are running sums of these)
+		struct ChunkSizes { uint64_t n, pat, sp, mcap, ncap, scap, tcap, slot; };
+		const uint32_t scale64 = std::max(I.stateScale64[0], I.stateScale64[1]) ? std::max(I.stateScale64[0], I.stateScale64[1]) : 64u;
+		auto sizesOf = [&](size_t c)
 		{
+			ChunkSizes z{};
 			const auto& r = b.refs[c];
 			const ChunkDesc& d = b.prep[r.text].chunks[r.chunk];
 			const uint64_t n = d.nChars;
-			b.charOff[c + 1] = b.charOff[c] + (uint32_t)n;
-			b.patOff[c + 1] = b.patOff[c] + (d.patEnd - d.patBegin);
-			forSpansOfChunk(b, r.text, d, [&](const DevPattern&) { ++b.patOff[c + 1]; });
-			b.spOff[c + 1] = b.spOff[c] + (uint32_t)r.sp.size();
+			z.n = n;
+			z.pat = d.patEnd - d.patBegin;
+			forSpansOfChunk(b, r.text, d, [&](const DevPattern&) { ++z.pat; });
+			z.sp = r.sp.size();
 			uint64_t mcap = (6 * n + 64) * sc, ncap = std::min<uint64_t>((4 * n + 32) * sc, 0xFFE0), scap = (48 * n + 256) * sc, tcap = (4 * n + 32) * sc;
 			// SkipBigram states carry their history ring in the container key: far fewer paths merge, a node keeps hundreds to thousands of them
 			if (I.histStates()) scap *= 8;
-			if (sc == 1 && !tinyArenas && !slotMode) scap = std::max<uint64_t>(scap * (std::max(I.stateScale64[0], I.stateScale64[1]) ? std::max(I.stateScale64[0], I.stateScale64[1]) : 64u) / 64, 64);      // (what the batches so far needed; a re-run at a higher rung takes the whole capacity)
+			if (sc == 1 && !tinyArenas && !slotMode) scap = std::max<uint64_t>(scap * scale64 / 64, 64);      // (what the batches so far needed; a re-run at a higher rung takes the whole capacity)
 			if (b.typo.typo) ncap = std::min<uint64_t>(2 * ncap, 0xFFE0);      // lattices over typo graphs come out about twice as large
 			if (tinyArenas)   // test hook (KAMD_TEST_TINY_ARENAS): regions far too small at scale 1, so that the overflow -> re-run ladder is exercised
 			{
 				mcap = (n / 2 + 8) * sc; ncap = std::min<uint64_t>((n / 2 + 8) * sc, 0xFFE0); scap = (n + 16) * sc; tcap = (n / 4 + 4) * sc;
 			}
-			if ((uint64_t)b.matchBase[c] + mcap > 0xFFFFFFFFull || (uint64_t)b.nodeBase[c] + ncap > 0xFFFFFFFFull) throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
-			b.matchBase[c + 1] = b.matchBase[c] + (uint32_t)mcap;
-			b.nodeBase[c + 1] = b.nodeBase[c] + (uint32_t)ncap;
-			if ((uint64_t)b.packBase[c] + 3 * ncap > 0xFFFFFFFFull) throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
-			b.packBase[c + 1] = b.packBase[c] + (uint32_t)(3 * ncap);
 			if (slotMode && sc == 1 && !tinyArenas && I.stateScaleForced) scap = std::max<uint64_t>(scap * I.stateScale64[0] / 64, 64);      // (KAMD_STATE_SCALE: tests of the growth into the pool)
 			// (half the worst case: two chunks in a thousand need more -- c3-sbg: the 99.9th percentile used 35/64 of it -- and grow into the pool)
 			if (slotMode && sc == 1 && !tinyArenas && !I.stateScaleForced) scap = std::max<uint64_t>(scap / 2, 64);
-			if (slotMode) { slotCap = std::max(slotCap, scap); scap = 0; }      // (the arenas are the search kernel's lane groups', each large enough for the batch's longest chunk)
-			b.stateBase[c + 1] = b.stateBase[c] + scap;
-			b.tokenBase[c + 1] = b.tokenBase[c] + tcap;
+			if (slotMode) { z.slot = scap; scap = 0; }      // (the arenas are the search kernel's lane groups', each large enough for the batch's longest chunk)
+			z.mcap = mcap; z.ncap = ncap; z.scap = scap; z.tcap = tcap;
+			return z;
+		};
+		// running sums in two passes over blocks of chunks on the workers (one loop on the calling thread was 0.9 ms per 65 536 chunks): the blocks' totals,
+		// their prefix on this thread, then every block writes its chunks' offsets from its own base
+		constexpr size_t kOffBlock = 2048;
+		const size_t nBlk = (nC + kOffBlock - 1) / kOffBlock;
+		std::vector<ChunkSizes> blkBase(nBlk + 1, ChunkSizes{});
+		HostPool::instance().run(nBlk, 1, b.hostThreads, [&](size_t k0, size_t k1, int)
+		{
+			for (size_t k = k0; k < k1; ++k)
+			{
+				ChunkSizes t{};
+				for (size_t c = k * kOffBlock; c < std::min(nC, (k + 1) * kOffBlock); ++c)
+				{
+					const ChunkSizes z = sizesOf(c);
+					t.n += z.n; t.pat += z.pat; t.sp += z.sp; t.mcap += z.mcap; t.ncap += z.ncap; t.scap += z.scap; t.tcap += z.tcap; t.slot = std::max(t.slot, z.slot);
+				}
+				blkBase[k + 1] = t;
+			}
+		});
+		for (size_t k = 0; k < nBlk; ++k)
+		{
+			ChunkSizes& t = blkBase[k + 1]; const ChunkSizes& p = blkBase[k];
+			slotCap = std::max(slotCap, t.slot);
+			t.n += p.n; t.pat += p.pat; t.sp += p.sp; t.mcap += p.mcap; t.ncap += p.ncap; t.scap += p.scap; t.tcap += p.tcap;
 		}
+		{
+			const ChunkSizes& t = blkBase[nBlk];
+			if (t.mcap > 0xFFFFFFFFull || t.ncap > 0xFFFFFFFFull || 3 * t.ncap > 0xFFFFFFFFull || t.n > 0xFFFFFFFFull || t.pat > 0xFFFFFFFFull || t.sp > 0xFFFFFFFFull)
+				throw std::runtime_error{ "batch too large for 32-bit scratch offsets: split the batch" };
+		}
+		HostPool::instance().run(nBlk, 1, b.hostThreads, [&](size_t k0, size_t k1, int)
+		{
+			for (size_t k = k0; k < k1; ++k)
+			{
+				ChunkSizes t = blkBase[k];
+				for (size_t c = k * kOffBlock; c < std::min(nC, (k + 1) * kOffBlock); ++c)
+				{
+					const ChunkSizes z = sizesOf(c);
+					t.n += z.n; t.pat += z.pat; t.sp += z.sp; t.mcap += z.mcap; t.ncap += z.ncap; t.scap += z.scap; t.tcap += z.tcap;
+					b.charOff[c + 1] = (uint32_t)t.n; b.patOff[c + 1] = (uint32_t)t.pat; b.spOff[c + 1] = (uint32_t)t.sp;
+					b.matchBase[c + 1] = (uint32_t)t.mcap; b.nodeBase[c + 1] = (uint32_t)t.ncap; b.packBase[c + 1] = (uint32_t)(3 * t.ncap);
+					b.stateBase[c + 1] = t.scap; b.tokenBase[c + 1] = t.tcap;
+				}
+			}
+		});
+		tmL.lap("offsets per chunk");
 		const size_t totChars = b.charOff[nC];
 		// the input block: sections at 256-byte boundaries, same layout on the host (pinned) and on the device
 		size_t top = 0;
@@ -614,6 +680,7 @@ namespace kamd
 			});
 		}
 		b.units = units;
+		tmL.lap("input block (workers)");
 		hipStream_t s = I.streamCopy;      // (uploads, and the typo graph kernels over this batch's own buffers: never behind another batch's kernels)
 		if (top) HIPCHECK(hipMemcpyAsync(b.dIn.p, H, top, hipMemcpyHostToDevice, s));
 		uint8_t* D = b.dIn.as<uint8_t>();
@@ -700,6 +767,7 @@ namespace kamd
 		}
 		w.bigScratch = nullptr; w.bigScratchBytes = 0;   // bound at launch
 		b.subBatches = 0;
+		tmL.lap("device buffers");
 		if (b.typo.typo)
 		{
 			// typo graphs on the DEVICE (typo_graph_kernel.hip; row f3): a count pass over the text block that is already on its way, the counts
@@ -786,6 +854,7 @@ namespace kamd
 			HIPCHECK(hipStreamSynchronize(s));      // the host vectors above are the sources of asynchronous copies: they must outlive them
 		}
 		HIPCHECK(hipStreamSynchronize(s));
+		tmL.lap("waiting for the upload");
 		b.ran = false;
 	}
 
@@ -1301,7 +1370,7 @@ namespace kamd
 		HIPCHECK(hipGetLastError());
 		// the end of the batch on the device: stream B behind everything stream A was given
 		HIPCHECK(hipEventRecord(I.joinEv, sA)); HIPCHECK(hipStreamWaitEvent(sB, I.joinEv, 0));
-		if (!b.evDone) HIPCHECK(hipEventCreateWithFlags(&b.evDone, hipEventDisableTiming));
+		if (!b.evDone) HIPCHECK(hipEventCreateWithFlags(&b.evDone, hipEventDisableTiming | hipEventBlockingSync));      // (blocking: a spinning wait was 10 ms of CPU per 65 536-sentence batch, counted against the host workers' quota)
 		HIPCHECK(hipEventRecord(b.evDone, sB)); HIPCHECK(hipEventRecord(I.lastDone, sB));
 		I.haveLast = true; b.launched = true; b.launchS = S;
 		tm.lap("enqueueing the launches");
@@ -1569,7 +1638,7 @@ namespace kamd
 			PrepBlock& blk = b->prepBlocks[i0 / StagedBatch::kPrepBlock];
 			size_t units = 0;
 			for (size_t i = i0; i < i1; ++i) units += texts[i].second;
-			blk.norm.reserve(units + units / 2 + 16); blk.position.reserve(units + (i1 - i0) + 16); blk.cls.reserve(units + units / 2 + 16); blk.script.reserve(units + units / 2 + 16);
+			blk.norm.reserve(2 * units + 16); blk.position.reserve(units + (i1 - i0) + 16); blk.cls.reserve(2 * units + 16); blk.script.reserve(2 * units + 16);
 			blk.chunks.reserve(2 * (i1 - i0)); blk.idx.reserve(i1 - i0);
 			for (size_t i = i0; i < i1; ++i)
 			{
@@ -1579,6 +1648,8 @@ namespace kamd
 			}
 			for (size_t i = i0; i < i1; ++i) b->prep[i] = blk.view(i - i0);
 		});
+		tm.lap("text preparation (workers)");
+		{ size_t cap = 0; for (const PrepBlock& blk : b->prepBlocks) cap += blk.chunks.size(); b->refs.reserve(cap); }      // (growing by doubling moved every entry twice: 1.8 ms per 65 536 texts)
 		for (size_t i = 0; i < texts.size(); ++i)
 		{
 			const auto& pt = b->prep[i];
@@ -1591,7 +1662,7 @@ namespace kamd
 				b->refs.push_back(ChunkRef{ (uint32_t)i, (uint32_t)c, { 0 }, openEnding && pt.chunks[c].nextOffset == pt.norm.size(), live == 1 });
 			}
 		}
-		tm.lap("text preparation");
+		tm.lap("chunk list");
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		HIPCHECK(hipSetDevice(impl->device));      // the device is bound per thread: callers come from any thread
 		b->typo = typo;
@@ -1626,11 +1697,11 @@ namespace kamd
 	}
 	void Engine::finish(StagedBatch& b)
 	{
-		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
-		HIPCHECK(hipSetDevice(impl->device));
 		HostTimer tm{ "finish" };
-		if (b.evDone) HIPCHECK(hipEventSynchronize(b.evDone));
+		HIPCHECK(hipSetDevice(impl->device));
+		if (b.evDone) HIPCHECK(hipEventSynchronize(b.evDone));      // (not under the device lock: another thread may be staging / launching the next part)
 		tm.lap("waiting for the batch's kernels");
+		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
 		KernelTimes t;
 		afterLaunch(*impl, b, t, false);
 		rerunOverflows(b, t);
@@ -1725,7 +1796,9 @@ namespace kamd
 	BatchResults Engine::fetch(StagedBatch& b, size_t topN)
 	{
 		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
-		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		// (the device -- and the engine's adaptive sizes below -- are held for the download only: the assembly of the results is host work, and a caller
+		// that pipelines batches, analyzeBatch below, stages and launches the next part meanwhile; the lock is taken again for chunks that must be searched again)
+		std::unique_lock<std::recursive_mutex> devLock{ impl->deviceMu };
 		HIPCHECK(hipSetDevice(impl->device));
 		if (!b.ran || b.topN != (uint32_t)topN) { b.topN = (uint32_t)topN; run(b); }
 		HostTimer tm{ "fetch" };
@@ -1764,6 +1837,9 @@ namespace kamd
 				fprintf(stderr, "\n");
 			}
 		}
+		const bool fastAssembly = FastAssembly::applies(topN, b.match, (bool)b.pretok);
+		if (fastAssembly && !impl->tokTmpl.built) impl->tokTmpl.build(impl->model);
+		devLock.unlock();
 		const size_t nT = b.prep.size();
 		BatchResults ret;
 		ret.nTexts = nT; ret.d2hBytes = b.outBytes;
@@ -1778,10 +1854,32 @@ namespace kamd
 		// must be searched again (other start states than the speculative {0}, or a scratch overflow) needs the device and is finished
 		// afterwards, one by one
 		static const std::vector<uint8_t> kOnlyZero{ 0 };
-		auto doText = [&](size_t i, bool mayRerun, ResultSegment& seg, std::vector<PathResult>& paths, ResultBuilder& rb) -> bool
+		// developer aid (KAMD_HOST_TIMING=1): the assembly's time by stage, summed over the workers
+		std::atomic<uint64_t> stageNs[5] = {};
+		const bool stageTiming = tm.on;
+		auto nowNs = [] { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		auto doText = [&](size_t i, bool mayRerun, ResultSegment& seg, std::vector<PathResult>& paths, ResultBuilder& rb, FastAssembly& fa) -> bool
 		{
+			uint64_t tLast = stageTiming ? nowNs() : 0;
+			auto lapNs = [&](int k) { if (stageTiming) { const uint64_t t = nowNs(); stageNs[k] += t - tLast; tLast = t; } };
 			const char16_t* raw = b.rawFlat.data() + b.rawOff[i]; const size_t rawLen = (size_t)(b.rawOff[i + 1] - b.rawOff[i]);
+			if (fastAssembly && firstRef[i + 1] - firstRef[i] == 1)
+			{
+				// one chunk searched from state 0 that came back with one path: packed records straight from the device's token records (post_fast.hpp)
+				const size_t c = firstRef[i];
+				const DevChunkResult& r = b.hResults[c];
+				if (r.status == CS_OK && r.nPaths == 1 && b.refs[c].sp.size() == 1 && b.refs[c].sp.data()[0] == 0)
+				{
+					const DevPathHeader& ph = b.hPaths[r.pathOff];
+					const PreparedView& pt = b.prep[i];
+					fa.text(impl->model, impl->tokTmpl, b.match, config.integrateAllomorph, raw, rawLen, pt, pt.chunks[b.refs[c].chunk].startOffset,
+						b.hTokens + r.tokOff + ph.tokOff, ph.nTokens, ph.score, seg);
+					lapNs(4);
+					return true;
+				}
+			}
 			rb.begin(raw, rawLen, b.prep[i].position.data(), b.prep[i].position.size());
+			lapNs(0);
 			std::vector<uint8_t> uniqBuf;
 			for (size_t c = firstRef[i]; c < firstRef[i + 1]; ++c)
 			{
@@ -1814,7 +1912,9 @@ namespace kamd
 				}
 				if (st == CS_NO_LATTICE) continue;
 				chunkPaths(paths, hostModelOf(*impl, b), b, c);
+				lapNs(1);
 				rb.insertPaths(paths);
+				lapNs(2);
 			}
 			if (b.pretok && i == 0 && b.pretok->hasTemps())
 			{
@@ -1824,7 +1924,13 @@ namespace kamd
 				for (auto& r : res) for (auto& tk : r.first) if (tk.morph >= nOwn) tk.morph = -1;
 				seg.appendText(res);
 			}
-			else seg.appendText(rb.finish(raw, rawLen));
+			else
+			{
+				auto res = rb.finish(raw, rawLen);
+				lapNs(3);
+				seg.appendText(res);
+				lapNs(4);
+			}
 			return true;
 		};
 		std::vector<uint8_t> again(nT, 0);
@@ -1832,25 +1938,34 @@ namespace kamd
 		HostPool::instance().run(ret.segs.size(), 1, postThreads, [&](size_t s0, size_t s1, int)
 		{
 			std::vector<PathResult> paths;
+			FastAssembly fa;
 			ResultBuilder rb{ hostModelOf(*impl, b), topN, b.match, config.integrateAllomorph };      // (one builder per task: begin() starts a text)
 			for (size_t sIdx = s0; sIdx < s1; ++sIdx)
 			{
 				ResultSegment& seg = ret.segs[sIdx];
 				const size_t t0 = sIdx * BatchResults::kSegTexts, t1 = std::min(nT, t0 + BatchResults::kSegTexts);
-				seg.toks.reserve(32 * (t1 - t0)); seg.forms.reserve(128 * (t1 - t0));
+				// (room for what the device reports for these texts' chunks -- 32 tokens per text reserved twice what c2 needs, and every reserved page is a fault)
+				size_t nTokSeg = 0;
+				for (size_t c = firstRef[t0]; c < firstRef[t1]; ++c) if (b.hResults[c].status < 16) nTokSeg += b.hResults[c].nTok;
+				seg.toks.reserve(nTokSeg + 8); seg.forms.reserve(4 * nTokSeg + 64);
+				seg.textAna.reserve(t1 - t0 + 1); seg.anaTok.reserve(t1 - t0 + 1); seg.anaScore.reserve(t1 - t0);
 				for (size_t i = t0; i < t1; ++i)
-					if (!doText(i, false, seg, paths, rb)) { again[i] = 1; seg.appendText({}); }
+					if (!doText(i, false, seg, paths, rb, fa)) { again[i] = 1; seg.appendText({}); }
 			}
 		});
 		// (the nested run above must not be re-entered: runRefs uses the device and the pool from this thread only)
 		std::vector<PathResult> paths;
 		ResultBuilder rbAgain{ hostModelOf(*impl, b), topN, b.match, config.integrateAllomorph };
+		FastAssembly faAgain;
 		for (size_t i = 0; i < nT; ++i) if (again[i])
 		{
+			if (!devLock.owns_lock()) { devLock.lock(); HIPCHECK(hipSetDevice(impl->device)); }
 			ret.overrides.emplace_back(i, ResultSegment{});
-			doText(i, true, ret.overrides.back().second, paths, rbAgain);
+			doText(i, true, ret.overrides.back().second, paths, rbAgain, faAgain);
 		}
 		tm.lap("post-processing");
+		if (stageTiming && nT) fprintf(stderr, "[host] fetch: per text, summed over the workers: begin %.0f ns, chunk paths %.0f, insert paths %.0f, finish %.0f, append %.0f\n",
+			(double)stageNs[0] / nT, (double)stageNs[1] / nT, (double)stageNs[2] / nT, (double)stageNs[3] / nT, (double)stageNs[4] / nT);
 		return ret;
 	}
 
@@ -1891,26 +2006,78 @@ namespace kamd
 			all.nTexts += r.nTexts; all.d2hBytes += r.d2hBytes;
 			staged[k].reset();
 		};
-		size_t collected = 0;
+		// Two host threads: the caller prepares, uploads and launches part after part; a collector waits for each part's kernels, downloads, assembles
+		// and releases it.  The stages that run on ONE thread (layout + upload 1.9 ms, work order + launches 0.5, download 0.5, release of the part's buffers
+		// 1.4 per 65 536 sentences on the MI355X box) then overlap the other thread's pooled stages (text preparation 4.4 ms, result assembly 5.3) instead
+		// of leaving the pool idle: profiles/r06_h_*.  KAMD_BATCH_PIPELINE=0: one thread, as in rounds 2 - 5.
+		const bool pipelined = [] { const char* e = std::getenv("KAMD_BATCH_PIPELINE"); return !e || std::atoi(e) != 0; }();
+		auto waitInFlight = [&]
+		{
+			// parts still in flight read their buffers: wait before anything is released
+			for (auto& sb : staged) if (sb && sb->launched && sb->evDone) (void)hipEventSynchronize(sb->evDone);
+		};
+		if (!pipelined)
+		{
+			size_t collected = 0;
+			try
+			{
+				for (size_t k = 0; k < parts; ++k)
+				{
+					std::vector<std::pair<const char16_t*, size_t>> part(texts.begin() + cut[k], texts.begin() + cut[k + 1]);
+					staged[k] = stage(part, match, openEnding, hostThreads, typo);
+					staged[k]->topN = (uint32_t)topN;
+					launch(*staged[k]);
+					if (k >= 1) { collect(collected); ++collected; }      // (part k - 1: its kernels ran while part k was prepared)
+				}
+				for (; collected < parts; ++collected) collect(collected);
+			}
+			catch (...) { waitInFlight(); throw; }
+			return all;
+		}
+		std::mutex qmu; std::condition_variable qcv;
+		size_t launchedParts = 0; bool stop = false;
+		std::exception_ptr collectorError;
+		std::thread collector{ [&]
+		{
+			try
+			{
+				for (size_t k = 0; k < parts; ++k)
+				{
+					{
+						std::unique_lock<std::mutex> lk{ qmu };
+						qcv.wait(lk, [&] { return launchedParts > k || stop; });
+						if (launchedParts <= k) return;
+					}
+					collect(k);
+				}
+			}
+			catch (...) { collectorError = std::current_exception(); }
+		} };
 		try
 		{
 			for (size_t k = 0; k < parts; ++k)
 			{
 				std::vector<std::pair<const char16_t*, size_t>> part(texts.begin() + cut[k], texts.begin() + cut[k + 1]);
-				staged[k] = stage(part, match, openEnding, hostThreads, typo);
-				staged[k]->topN = (uint32_t)topN;
-				launch(*staged[k]);
-				if (k >= 1) { collect(collected); ++collected; }      // (part k - 1: its kernels ran while part k was prepared)
+				std::shared_ptr<StagedBatch> sb = stage(part, match, openEnding, hostThreads, typo);
+				sb->topN = (uint32_t)topN;
+				{ std::lock_guard<std::mutex> g{ qmu }; staged[k] = sb; }      // (from here on the part is waited for if anything throws)
+				launch(*sb);
+				{ std::lock_guard<std::mutex> g{ qmu }; ++launchedParts; }
+				qcv.notify_one();
 			}
-			for (; collected < parts; ++collected) collect(collected);
 		}
 		catch (...)
 		{
-			// parts still in flight read their buffers: wait before anything is released
-			std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
-			for (auto& sb : staged) if (sb && sb->launched && sb->evDone) (void)hipEventSynchronize(sb->evDone);
+			{ std::lock_guard<std::mutex> g{ qmu }; stop = true; }
+			qcv.notify_one();
+			collector.join();
+			waitInFlight();
 			throw;
 		}
+		{ std::lock_guard<std::mutex> g{ qmu }; stop = true; }
+		qcv.notify_one();
+		collector.join();
+		if (collectorError) { waitInFlight(); std::rethrow_exception(collectorError); }
 		return all;
 	}
 

@@ -2,6 +2,7 @@
 // Each function cites the reference behaviour it reproduces; code is this repo's own.
 #pragma once
 #include <string>
+#include <string_view>
 #include <vector>
 #include "kchars.hpp"
 
@@ -91,7 +92,7 @@ namespace kamd
 	inline U16 joinHangul(const U16& s) { return joinHangul(s.data(), s.size()); }
 
 	// src/Utils.cpp:264-298 — bullet ("SB") shape class of a form; an empty form yields 0 there as well.
-	inline uint32_t getSBType(const U16& form)
+	inline uint32_t getSBType(std::u16string_view form)
 	{
 		if (form.empty()) return 0;
 		uint32_t format = 0, group = 0;

@@ -221,6 +221,7 @@ inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return
 inline double hipemu_now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)std::malloc(8); *(double*)*e = 0; return hipSuccess; }
 constexpr unsigned hipEventDisableTiming = 2;
+constexpr unsigned hipEventBlockingSync = 1;
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)std::malloc(8); *(double*)*e = 0; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { *(double*)e = hipemu_now_ms(); return hipSuccess; }      // (everything before it has finished)

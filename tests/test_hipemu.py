@@ -91,6 +91,30 @@ def test_emulated_batch_in_parts(emu_libs, oracle, small_model, monkeypatch, tin
     dev.close()
 
 
+@pytest.mark.parametrize("match_extra", [0, 1 << 24, 1 << 17])
+def test_emulated_fast_assembly_equals_the_general_assembly(emu_libs, oracle, small_model, monkeypatch, match_extra):
+    """Result assembly of the common case (one chunk, top-1: kiwi_amd/csrc/post_fast.hpp, packed records straight from the device's token records through
+    a per-morpheme template table) against the general assembly (post.cpp, the code the oracle runs): the same packed bytes on texts with brackets, quotes,
+    line breaks, several sentences, other scripts and lone surrogates; with compatibility jamo; and with an affix-joining option (which the fast path must
+    leave to the general one).  Oracle == device on the same texts."""
+    from kiwi_amd.api import KiwiAmd, MATCH_ALL_WITH_NORMALIZING
+    sm, path = small_model
+    texts = synthetic(sm, 300, 1301, min_jamo=5, max_jamo=120) + EDGE_TEXTS + dictionary_mix(sm, 150, 1302) + fuzzed(sm, 150, 1303)
+    texts += ["(" + texts[k] + ') "' + texts[k + 1] + '"\n\n' + texts[k + 2] + "\r\n[" + texts[k + 3] + "]" for k in range(0, 80, 4)]
+    match = MATCH_ALL_WITH_NORMALIZING | match_extra
+    dev = KiwiAmd(path, lib_path=emu_libs[0])
+    monkeypatch.setenv("KAMD_FAST_ASSEMBLY", "0")
+    general = dev.analyze_batch(texts, top_n=1, match=match)
+    packed_general = bytes(general.pack()); py_general = general.to_python()
+    monkeypatch.delenv("KAMD_FAST_ASSEMBLY")
+    fast = dev.analyze_batch(texts, top_n=1, match=match)
+    assert bytes(fast.pack()) == packed_general
+    if not match_extra:
+        for s, y in zip(texts, py_general):
+            assert _norm(oracle.analyze(s, top_n=1)) == _norm(y), s
+    dev.close()
+
+
 @pytest.mark.parametrize("lanes", ["pos", "16", "64"])
 def test_emulated_order_4_knlm(emu_libs, small_order4_model, monkeypatch, lanes):
     """An order-4 Knlm (the reference's maximum): back-off chains one node longer than the pair a search state carries (ModelView::lmChain) -- the
