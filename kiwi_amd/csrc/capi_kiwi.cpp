@@ -312,24 +312,26 @@ namespace
 				for (size_t i = 0; i < cnt; ++i) (*receiver)(receiverIdx++, slabRes(slab, i, job.parts[d], i), ud);   // in input order; the receiver owns the result
 			}
 		};
-		// The first batches are short -- 8 192 lines, then twice as many each time up to the batch size: the device side starts after a fraction of the
-		// reading instead of after all of it, and the last batch's results are delivered while little is left to do (an input of one batch size was
-		// read, analysed and delivered strictly one after the other).
-		int batchNo = 0;
+		// A batch is handed over when it is full -- or, from 8 192 lines on, as soon as the device side has nothing to do: the first batch of a call starts
+		// after a fraction of the reading instead of after all of it, and from then on a batch holds whatever was read while its predecessor was analysed (a
+		// reader as fast as memory fills the second batch at once -- two batches, where the round-5 ramp of 8 192, 16 384, 32 768, ... lines cut 65 536 lines
+		// into four small ones whose host stages did not overlap: 16.5 of a pass' 20.9 ms waiting for them, profiles/r06_m_*; a slow reader gets the short
+		// batches the ramp was made for).
+		std::unique_ptr<Job> running, finished;
+		std::future<void> pending;
+		constexpr size_t kMinBatch = 8192;
+		auto deviceIdle = [&] { return !running || pending.wait_for(std::chrono::seconds(0)) == std::future_status::ready; };
 		auto readBatch = [&](Job& job)
 		{
-			const int want = (int)std::min<long long>(h->batchSize, 8192ll << std::min(batchNo, 20));
-			++batchNo;
 			if (job.off.empty()) job.off.push_back(0);
-			while ((int)job.count() < want)
+			while ((long long)job.count() < (long long)h->batchSize)
 			{
 				if (!readNext(readerIdx, job.raw8, job.w, job.off, job.len)) return false;
 				++readerIdx;
+				if (job.count() >= kMinBatch && (job.count() & 1023) == 0 && deviceIdle()) break;
 			}
 			return true;
 		};
-		std::unique_ptr<Job> running, finished;
-		std::future<void> pending;
 		bool more = true;
 		// developer aid (KAMD_CAPI_TIMING=1): where the calling thread's time goes
 		static const bool timing = std::getenv("KAMD_CAPI_TIMING") != nullptr;

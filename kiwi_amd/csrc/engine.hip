@@ -220,7 +220,7 @@ namespace kamd
 		PinBuf hOut, hOut2;       // D2H landing zones: counters + chunk results; then the path headers and token records that were produced
 		uint64_t outBytes = 0;    // bytes the last download copied
 		BatchView bv{}; WorkView wv{};
-		const DevChunkResult* hResults = nullptr; const DevPathHeader* hPaths = nullptr; const DevToken* hTokens = nullptr;   // inside hOut
+		const DevChunkResult* hResults = nullptr; const DevPathHeader* hPaths = nullptr; const DevToken* hTokens = nullptr; size_t hTokCount = 0;   // inside hOut
 		bool ran = false;
 		hipEvent_t evDone = nullptr; bool launched = false; uint32_t launchS = 1;      // recorded behind the batch's last kernel (Engine::launch); Engine::finish waits for it
 		~StagedBatch()
@@ -1556,7 +1556,7 @@ namespace kamd
 		HIPCHECK(hipStreamSynchronize(I.streamCopy));
 		b.hResults = reinterpret_cast<const DevChunkResult*>(H + oRes);
 		b.hPaths = reinterpret_cast<const DevPathHeader*>(H2);
-		b.hTokens = reinterpret_cast<const DevToken*>(H2 + oTok);
+		b.hTokens = reinterpret_cast<const DevToken*>(H2 + oTok); b.hTokCount = nTok;
 		b.outBytes = 8 + nC * sizeof(DevChunkResult) + (size_t)nPaths * sizeof(DevPathHeader) + (size_t)nTok * sizeof(DevToken);
 	}
 
@@ -1873,7 +1873,7 @@ namespace kamd
 					const DevPathHeader& ph = b.hPaths[r.pathOff];
 					const PreparedView& pt = b.prep[i];
 					fa.text(impl->model, impl->tokTmpl, b.match, config.integrateAllomorph, raw, rawLen, pt, pt.chunks[b.refs[c].chunk].startOffset,
-						b.hTokens + r.tokOff + ph.tokOff, ph.nTokens, ph.score, seg);
+						b.hTokens + r.tokOff + ph.tokOff, ph.nTokens, b.hTokens + b.hTokCount, ph.score, seg);
 					lapNs(4);
 					return true;
 				}

@@ -71,8 +71,10 @@ namespace kamd
 
 		// the text's only chunk, its only path: tk[0 .. nTok) with offsets relative to `so` in the normalised text `pt`
 		void text(const FlatModel& mdl, const TokenTemplates& T, uint64_t match, bool integrateAllomorph, const char16_t* raw, size_t rawLen,
-			const PreparedView& pt, uint32_t so, const DevToken* tk, uint32_t nTok, float score, ResultSegment& seg)
+			const PreparedView& pt, uint32_t so, const DevToken* tk, uint32_t nTok, const DevToken* tkEnd, float score, ResultSegment& seg)
 		{
+			// (the template records of the tokens behind this text's -- the next text's, as the device wrote them -- are asked for now: they arrive while this text is assembled)
+			for (const DevToken* q = tk + nTok; q < tkEnd && q < tk + nTok + 24; ++q) __builtin_prefetch(&T.recs[q->morph]);
 			// getWordPositions (Kiwi.cpp:465-487)
 			wordPositions.resize(rawLen);
 			{
@@ -85,6 +87,13 @@ namespace kamd
 				}
 			}
 			const size_t tok0 = seg.toks.size();
+			// (records and characters are written through pointers into room made once per text -- what the tokens can need at most: a form joins into no more
+			// units than it has, except a syllable followed by an old coda, which becomes three -- and the vectors are cut back at the end)
+			size_t formRoom = 0;
+			for (uint32_t k = 0; k < nTok; ++k) formRoom += (tk[k].ownKind ? (tk[k].ownKind == 2 ? (size_t)mdl.forms[tk[k].ownA].len : (size_t)tk[k].ownLen) * 3 / 2 + 2 : (size_t)T.recs[tk[k].morph].joinedLen + 3) + 1;
+			const size_t form0 = seg.forms.size();
+			seg.toks.resize(tok0 + nTok); seg.forms.resize(form0 + formRoom);
+			FlatToken* outTok = seg.toks.data() + tok0; char16_t* const formBase = seg.forms.data(); char16_t* outForm = formBase + form0;
 			const uint32_t* ptBegin = pt.position.p; const uint32_t* ptEnd = pt.position.p + pt.position.n;
 			const bool compat = (match & M_COMPATIBLE_JAMO) != 0;
 			int32_t prevMorph = -1;
@@ -100,7 +109,8 @@ namespace kamd
 				if (!own.empty() && own[0] == u' ') continue;
 				const TokenTemplates::Rec& r = T.recs[d.morph];
 				FlatToken o{};
-				o.formOff = seg.forms.size();
+				o.formOff = (uint64_t)(outForm - formBase);
+				char16_t* const formAt = outForm;
 				bool done = false;
 				if (!integrateAllomorph && (r.flags & TokenTemplates::EO_ALLOMORPH))
 				{
@@ -112,18 +122,18 @@ namespace kamd
 						U16 s(1, first);
 						s.append((const char16_t*)mdl.formChars.data() + kfr.charOff + 1, kfr.len - 1);
 						const U16 j = joinHangul(s);
-						seg.forms.insert(seg.forms.end(), j.begin(), j.end());
+						std::copy(j.begin(), j.end(), outForm); outForm += j.size();
 						done = true;
 					}
 				}
 				if (!done)
 				{
-					if (own.empty()) seg.forms.insert(seg.forms.end(), T.pool.begin() + r.joinedOff, T.pool.begin() + r.joinedOff + r.joinedLen);
-					else { const U16 j = joinHangul(own.data(), own.size()); seg.forms.insert(seg.forms.end(), j.begin(), j.end()); }
+					if (own.empty()) { const char16_t* src = T.pool.data() + r.joinedOff; for (uint32_t q = 0; q < r.joinedLen; ++q) outForm[q] = src[q]; outForm += r.joinedLen; }
+					else { const U16 j = joinHangul(own.data(), own.size()); std::copy(j.begin(), j.end(), outForm); outForm += j.size(); }
 				}
-				o.formLen = (uint16_t)(seg.forms.size() - o.formOff);
-				if (compat) for (size_t q = o.formOff; q < seg.forms.size(); ++q) seg.forms[q] = postc::toCompatibleConsonant(seg.forms[q]);
-				seg.forms.push_back(0);
+				o.formLen = (uint16_t)(outForm - formAt);
+				if (compat) for (char16_t* q = formAt; q < outForm; ++q) *q = postc::toCompatibleConsonant(*q);
+				*outForm++ = 0;
 				o.tag = r.tag; o.morph = (int32_t)d.morph;
 				const uint32_t begin = (uint32_t)d.begin + so, end = (uint32_t)d.end + so;
 				// (upper_bound(begin) - 1 and lower_bound(end) of the general path: tokens come in text order, so both are a few steps from the previous token's)
@@ -148,8 +158,8 @@ namespace kamd
 				// updateTokenInfoScript (Kiwi.cpp:590-605)
 				if ((o.tag == T_SL || o.tag == T_SH || o.tag == T_SW || o.tag == T_W_EMOJI) && (r.flags & TokenTemplates::KFORM_EMPTY) && o.formLen)
 				{
-					uint32_t c = seg.forms[o.formOff];
-					if (isHighSurrogate(c)) c = mergeSurrogate(c, o.formLen > 1 ? seg.forms[o.formOff + 1] : 0);
+					uint32_t c = formAt[0];
+					if (isHighSurrogate(c)) c = mergeSurrogate(c, o.formLen > 1 ? formAt[1] : 0);
 					o.senseOrScript = chr2ScriptType(c);
 					if (o.senseOrScript == 1 /* latin */) o.tag = T_SL;
 				}
@@ -158,8 +168,9 @@ namespace kamd
 				o.pairedToken = (uint32_t)-1;
 				prevMorph = (int32_t)d.morph;
 				anyPairTag = anyPairTag || o.tag == T_SSO || o.tag == T_SSC || o.tag == T_SB;
-				seg.toks.push_back(o);
+				*outTok++ = o;
 			}
+			seg.toks.resize((size_t)(outTok - seg.toks.data())); seg.forms.resize((size_t)(outForm - formBase));
 			postc::newLinePositions(raw, rawLen, newlines);
 			FlatToken* toks = seg.toks.data() + tok0; const size_t n = seg.toks.size() - tok0;
 			const char16_t* forms = seg.forms.data();

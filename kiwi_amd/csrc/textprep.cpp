@@ -339,13 +339,43 @@ namespace kamd
 		const PrepTables& T = prepTables();
 		Idx x{};
 		x.normOff = norm.size(); x.posOff = position.size(); x.chunkOff = chunks.size(); x.patOff = patterns.size();
-		appendNormalized(raw, n, norm, position);
-		const size_t L = norm.size() - x.normOff;
-		char16_t* nrm = L ? &norm[x.normOff] : nullptr;
-		if (mo & M_NORMALIZE_CODA) normalizeCoda(nrm, L);
-		cls.resize(x.normOff + L); script.resize(x.normOff + L);
+		// normalisation (src/StrUtils.h:494-521: a syllable with a coda becomes syllable + coda jamo) and the typing of what it makes -- ASCII, Hangul syllables,
+		// coda jamo: tables -- in ONE pass over the raw text, written through pointers into arrays sized for the worst case (two units per raw unit) and cut
+		// back; anything else in the text (other scripts, surrogates, emoji: the typing needs the following code point), or a compatibility jamo behind a coda
+		// (normalizeCoda rewrites the coda), sends the whole text through the general typing loop below
+		const size_t pbase = position.size();
+		norm.resize(x.normOff + 2 * n); position.resize(pbase + n + 1);
+		cls.resize(x.normOff + 2 * n); script.resize(x.normOff + 2 * n);
+		char16_t* nrm = n ? &norm[x.normOff] : nullptr;
 		uint8_t* ocls = cls.data() + x.normOff; uint8_t* oscript = script.data() + x.normOff;
-		for (size_t i = 0; i < L; ++i)
+		size_t L = 0;
+		bool general = false, compatJamo = false;
+		{
+			uint32_t* p = &position[pbase];
+			for (size_t i = 0; i < n; ++i)
+			{
+				char16_t c = raw[i];
+				p[i] = (uint32_t)L;
+				if (c < 128) { nrm[L] = c; ocls[L] = T.cls[c]; oscript[L] = T.script[c]; ++L; continue; }
+				if (c == 0xB42C) c = 0xB410;
+				if (0xAC00 <= c && c < 0xD7A4)
+				{
+					const int coda = (c - 0xAC00) % 28;
+					nrm[L] = (char16_t)(c - coda); ocls[L] = T_MAX; oscript[L] = T.hangulSyllableScript; ++L;
+					if (coda) { nrm[L] = (char16_t)(coda + 0x11A7); ocls[L] = T_MAX; oscript[L] = T.hangulJamoScript; ++L; }
+					continue;
+				}
+				if (0x11A8 <= c && c <= 0x11C2) { nrm[L] = c; ocls[L] = T_MAX; oscript[L] = T.hangulJamoScript; ++L; continue; }
+				if (0x3131 <= c && c <= 0x314E) compatJamo = true;
+				general = true;
+				nrm[L++] = c;
+			}
+			p[n] = (uint32_t)L;
+		}
+		norm.resize(x.normOff + L); cls.resize(x.normOff + L); script.resize(x.normOff + L);
+		nrm = L ? &norm[x.normOff] : nullptr; ocls = cls.data() + x.normOff; oscript = script.data() + x.normOff;
+		if ((mo & M_NORMALIZE_CODA) && compatJamo) normalizeCoda(nrm, L);
+		if (general) for (size_t i = 0; i < L; ++i)
 		{
 			uint32_t c = nrm[i];
 			if (c < 128) { ocls[i] = T.cls[c]; oscript[i] = T.script[c]; continue; }                                  // (no emoji starts below U+0080 is flagged here: see below)
