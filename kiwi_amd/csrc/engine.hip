@@ -814,6 +814,9 @@ namespace kamd
 			HIPCHECK(hipStreamSynchronize(s));
 			uint64_t mapTop = 0, nsTop = 0, stateTop = 0, graphTop = 0;
 			scrTop = 0;
+			// (developer knob KAMD_TYPO_LDS_CAP="<mul4>x<add>": nodes per text unit x 4 and the constant of typoLdsNodeCap)
+			uint32_t typoCapMul4 = 16, typoCapAdd = 48;
+			if (const char* e = std::getenv("KAMD_TYPO_LDS_CAP")) { unsigned a = 0, c2 = 0; if (std::sscanf(e, "%ux%u", &a, &c2) == 2 && a) { typoCapMul4 = a; typoCapAdd = c2; } }
 			for (size_t c = 0; c < nC; ++c)
 			{
 				TypoLatChunk& t = tch[c];
@@ -821,7 +824,8 @@ namespace kamd
 				t.graphCnt = gout[c].graphCnt;
 				if (gout[c].maxCti > 1) { size_t v = gout[c].maxCti - 1; while (v > 0) { v >>= 1; ++t.pmb; } }
 				t.mapLen = (t.nNs << t.pmb) + 1;
-				t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.nodeCap).total;
+				t.ldsCap = typoLdsNodeCap(t.nChars, t.nodeCap, typoCapMul4, typoCapAdd);
+				t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.ldsCap).total;
 				t.graphOff = (uint32_t)graphTop; graphTop += t.graphCnt;
 				t.mapOff = (uint32_t)mapTop; mapTop += t.mapLen;
 				t.nsOff = (uint32_t)nsTop; nsTop += t.nChars + 2;
@@ -1525,8 +1529,17 @@ namespace kamd
 			std::vector<TypoLatChunk> tch(nC);
 			HIPCHECK(hipMemcpy(tch.data(), b.dTypoChunks.p, nC * sizeof(TypoLatChunk), hipMemcpyDeviceToHost));
 			uint64_t need = 0, big = 0, over = 0, nodes = 0, cap = 0; uint32_t maxNeed = 0;
-			for (auto& c : tch) { need += c.ldsNeed; maxNeed = std::max(maxNeed, c.ldsNeed); over += c.ldsNeed > I.latticeLdsBudget; nodes += c.nOutFinal; cap += typoLdsNodeCap(c.nChars, c.nodeCap); }
-			for (auto& c : tch) big += c.pad;
+			for (auto& c : tch) { need += c.ldsNeed; maxNeed = std::max(maxNeed, c.ldsNeed); over += c.ldsNeed > I.latticeLdsBudget; nodes += c.nOutFinal; cap += c.ldsCap; }
+			for (auto& c : tch) big += c.pad & 1;
+			{
+				// nodes BUILT (unconnected ones included: what the LDS copy has to hold) per text unit, x 100
+				std::vector<uint32_t> ratio, built;
+				for (auto& c : tch) if (!(c.pad & 1) && c.nChars) { built.push_back(c.pad >> 1); ratio.push_back((c.pad >> 1) * 100 / c.nChars); }
+				std::sort(ratio.begin(), ratio.end()); std::sort(built.begin(), built.end());
+				auto q = [](const std::vector<uint32_t>& v, double f) { return v.empty() ? 0u : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+				fprintf(stderr, "[host] typo lattices: nodes built p50 %u p99 %u p99.9 %u max %u; per text unit x 100: p50 %u p99 %u p99.9 %u max %u\n",
+					q(built, 0.5), q(built, 0.99), q(built, 0.999), q(built, 1.0), q(ratio, 0.5), q(ratio, 0.99), q(ratio, 0.999), q(ratio, 1.0));
+			}
 			fprintf(stderr, "[host] typo lattices: LDS need avg %.0f max %u B, %llu chunks over the budget, %llu outgrew their LDS copy; connected nodes avg %.1f of LDS capacity avg %.1f\n",
 				(double)need / nC, maxNeed, (unsigned long long)over, (unsigned long long)big, (double)nodes / nC, (double)cap / nC);
 		}

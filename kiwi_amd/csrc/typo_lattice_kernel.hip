@@ -629,7 +629,7 @@ namespace kamd
 		TypoLatChunk& C = V.chunks[chunkList[blockIdx.x]];
 		if (V.results[C.chunkId].status >= 16) { if (lane == 0) C.status = V.results[C.chunkId].status; return; }
 		const uint32_t n = C.nChars, pmb = C.pmb;
-		const TypoLds lay = typoLdsLayout(n, C.nNs, pmb, C.nodeCap);
+		const TypoLds lay = typoLdsLayout(n, C.nNs, pmb, C.ldsCap);
 		if (lay.total > ldsBytes || C.mapLen > 0xFFF0 || C.nodeCap > 0xFFF0 || C.mapLen != (C.nNs << pmb) + 1 || C.mapLen > 64 * (C.nNs + 1)) { if (lane == 0) C.status = kTypoLdsNeedsBig; return; }
 		uint16_t* str = reinterpret_cast<uint16_t*>(tSmem + lay.str); uint8_t* cls = tSmem + lay.cls; uint8_t* script = tSmem + lay.script;
 		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(tSmem + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(tSmem + lay.posToNs);
@@ -694,7 +694,7 @@ namespace kamd
 				lout[X.nOut - 1].endPos = (uint16_t)(nNs << pmb);
 				if (X.outgrown || (X.nOut + 1 >= lay.nodeCap && lay.nodeCap < C.nodeCap)) err = kTypoLdsNeedsBig;
 				else if (X.overflow || X.nOut + 1 >= C.nodeCap) err = CS_ERR_NODE_OVERFLOW;
-				else G = X.nOut;
+				else { G = X.nOut; C.pad = G << 1; }      // (developer statistics: nodes built; bit 0 = outgrew its LDS copy -- set by the thread-per-chunk kernel)
 			}
 		}
 		waveSync();

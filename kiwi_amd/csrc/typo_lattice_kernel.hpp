@@ -20,6 +20,7 @@ namespace kamd
 		uint32_t textOffset;           // offset of the chunk in the normalised text (added to final positions of the dump records)
 		uint32_t chunkId, packCap;     // engine mode: index of the chunk in the batch, capacity of its candidate-pack region
 		uint32_t nOutFinal, status;    // out: number of connected nodes, ChunkStatus
+		uint32_t ldsCap;               // engine mode: nodes the chunk's LDS copy holds (typoLdsNodeCap, host-computed: the kernel lays its LDS out from it)
 		uint32_t ldsNeed, pad;         // engine mode: dynamic LDS the wave-per-chunk kernel needs for this chunk (typoLdsLayout().total)
 	};
 	// lattice node in the layout of the parity dumps (kamd_dump_lattices; the reference bridge writes the same): positions are text offsets when final
@@ -60,18 +61,20 @@ namespace kamd
 	// node of the build in LDS (24 bytes; positions are multiplied positions < 65536)
 	struct TypoLdsNode { uint32_t form; uint16_t startPos, endPos, prev, sibling, uformOff, uformLen; float typoCost; uint8_t spaceErrors, pad[3]; };
 	struct TypoLds { uint32_t str, cls, script, nsToPos, posToNs, epm, fullMask, zAt, cands, nodes, queue, conn, nodeCap, total; };
+	// nodes a chunk's LDS copy holds: mul4 / 4 per text unit + add (the defaults cover every chunk of the bench corpora; a chunk that outgrows its copy is
+	// built again by the thread-per-chunk kernel).  Host side only -- the kernel reads TypoLatChunk::ldsCap.
 #ifdef KAMD_TEST_SMALL_CAPS
 	// test build (make smallcaps): most chunks outgrow their LDS node list and are handed to the thread-per-chunk kernel
-	__host__ __device__ inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap) { const uint32_t c = nChars / 2 + 4; return c < nodeCap ? c : nodeCap; }
+	inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap, uint32_t = 0, uint32_t = 0) { const uint32_t c = nChars / 2 + 4; return c < nodeCap ? c : nodeCap; }
 #else
-	__host__ __device__ inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap) { const uint32_t c = 4 * nChars + 48; return c < nodeCap ? c : nodeCap; }
+	inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap, uint32_t mul4 = 16, uint32_t add = 48) { const uint32_t c = mul4 * nChars / 4 + add; return c < nodeCap ? c : nodeCap; }
 #endif
-	__host__ __device__ inline TypoLds typoLdsLayout(uint32_t nChars, uint32_t nNs, uint32_t pmb, uint32_t nodeCap)
+	__host__ __device__ inline TypoLds typoLdsLayout(uint32_t nChars, uint32_t nNs, uint32_t pmb, uint32_t ldsNodeCap)
 	{
 		TypoLds l; uint32_t top = 0;
 		auto take = [&](uint32_t bytes, uint32_t align) { top = (top + align - 1) / align * align; const uint32_t o = top; top += bytes; return o; };
 		const uint32_t mapLen = (nNs << pmb) + 1;
-		l.nodeCap = typoLdsNodeCap(nChars, nodeCap);
+		l.nodeCap = ldsNodeCap;
 		l.fullMask = take(8 * (nNs + 1), 8);
 		l.nodes = take(24 * l.nodeCap, 8);
 		l.epm = take(4 * mapLen, 4);

@@ -1,6 +1,6 @@
 """Developer aid: where one end-to-end batch spends its host time on the GPU box (KAMD_HOST_TIMING laps of stage / fetch / release) for several
 part counts.   python tools/r06/host_timing.py [workload]"""
-import os, sys, time
+import os, sys, time, resource
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from kiwi_amd.api import KiwiAmd, pack_texts
 from kiwi_amd.workloads import get_workload
@@ -23,8 +23,9 @@ for parts in os.environ.get("PARTS", "1,2,4,8").split(","):
     def throttled():
         try: return dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat")).get("nr_throttled", "?")
         except Exception: return "?"
-    th0 = throttled(); c0 = time.process_time(); w0 = time.perf_counter()
+    th0 = throttled(); c0 = time.process_time(); w0 = time.perf_counter(); r0 = resource.getrusage(resource.RUSAGE_SELF)
     for _ in range(20): e.analyze_packed(flat, offs, 1).close()
-    c1 = time.process_time(); w1 = time.perf_counter()
+    c1 = time.process_time(); w1 = time.perf_counter(); r1 = resource.getrusage(resource.RUSAGE_SELF)
+    print(f"{name} parts={parts}: per batch: user {(r1.ru_utime-r0.ru_utime)/20*1e3:.1f} ms, system {(r1.ru_stime-r0.ru_stime)/20*1e3:.1f} ms, minor faults {(r1.ru_minflt-r0.ru_minflt)/20:.0f}, voluntary switches {(r1.ru_nvcsw-r0.ru_nvcsw)/20:.0f}, involuntary {(r1.ru_nivcsw-r0.ru_nivcsw)/20:.0f}", flush=True)
     print(f"{name} parts={parts}: 20 batches back to back: {(w1-w0)/20*1e3:.2f} ms wall, {(c1-c0)/20*1e3:.1f} ms CPU per batch ({(c1-c0)/(w1-w0):.1f} cores busy), throttled periods {th0} -> {throttled()}", flush=True)
     print(f"{name} parts={parts}: median {a*1e3:.2f} ms per batch ({len(t)/a/1e6:.2f} M sentences/s), close {sorted(y for x, y in ts)[len(ts)//2]*1e3:.2f} ms", flush=True)
