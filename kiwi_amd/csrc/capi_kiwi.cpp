@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstring>
 #include <future>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -256,7 +258,12 @@ namespace
 			std::vector<size_t> off, len;      // line i: units [off[i], off[i] + len[i]) of w (and bytes [off[i], off[i + 1]) of raw8); off has one more entry
 			size_t count() const { return len.size(); }
 			std::vector<size_t> cut;
-			std::vector<std::shared_ptr<const BatchResults>> parts;
+			// results, in text order, as they complete: a part of a large batch (one device: Engine::analyzeBatch hands its parts over one by one while the
+			// later ones are still on the device), or a device's whole share (several devices); `done`: nothing more will come
+			struct Part { size_t count; std::shared_ptr<const BatchResults> br; };
+			std::mutex mu; std::condition_variable cv; std::deque<Part> ready; bool done = false;
+			void push(size_t count, BatchResults&& r) { { std::lock_guard<std::mutex> g{ mu }; ready.push_back(Part{ count, std::make_shared<const BatchResults>(std::move(r)) }); } cv.notify_one(); }
+			void finish() { { std::lock_guard<std::mutex> g{ mu }; done = true; } cv.notify_one(); }
 		};
 		auto analyse = [h, topN, &opt](Job& job)
 		{
@@ -283,14 +290,21 @@ namespace
 				for (size_t i = 0; i < job.count() && d < nDev; ++i) { acc += job.len[i] + 8; if (acc * nDev >= total * d) job.cut[d++] = i + 1; }
 				for (; d <= nDev; ++d) job.cut[d] = job.count();
 			}
-			job.parts.assign(nDev, nullptr);
+			struct Finish { Job& j; ~Finish() { j.finish(); } } finishGuard{ job };      // (also when the analysis throws: the calling thread must not wait for parts that never come)
+			if (nDev == 1)
+			{
+				const Engine::PartSink sink = [&job](size_t, BatchResults&& r) { const size_t n = r.nTexts; job.push(n, std::move(r)); };
+				h->device(0).analyzeBatch(views, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt), &sink);
+				return;
+			}
+			std::vector<BatchResults> shares(nDev);
 			std::vector<std::exception_ptr> errs(nDev);
 			auto work = [&](size_t d)
 			{
 				try
 				{
 					std::vector<std::pair<const char16_t*, size_t>> v(views.begin() + job.cut[d], views.begin() + job.cut[d + 1]);
-					job.parts[d] = std::make_shared<const BatchResults>(h->device(d).analyzeBatch(v, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt)));
+					shares[d] = h->device(d).analyzeBatch(v, (size_t)topN, (uint64_t)(uint32_t)opt.match_options, !!opt.open_ending, h->numThreads, typoOf(opt));
 				}
 				catch (...) { errs[d] = std::current_exception(); }
 			};
@@ -299,17 +313,26 @@ namespace
 			work(0);
 			for (auto& w : workers) w.join();
 			for (auto& e : errs) if (e) std::rethrow_exception(e);
+			for (size_t d = 0; d < nDev; ++d) if (job.cut[d + 1] > job.cut[d]) job.push(job.cut[d + 1] - job.cut[d], std::move(shares[d]));
 		};
 		int readerIdx = 0, receiverIdx = 0;
-		auto deliver = [&](Job& job)
+		// Delivers the parts of `job` that are ready, in order (handles are constructed one at a time, right before their delivery: a receiver that throws leaves no
+		// constructed-but-undelivered ones behind).  untilAnalysed: waits for parts and returns as soon as the analysis has ended -- what is still queued then is
+		// delivered by the next call, after the following batch has been started; otherwise: everything that is left.
+		auto deliver = [&](Job& job, bool untilAnalysed)
 		{
-			for (size_t d = 0; d + 1 < job.cut.size(); ++d)
+			for (;;)
 			{
-				// (handles are constructed one at a time, right before their delivery: a receiver that throws leaves no constructed-but-undelivered ones behind)
-				const size_t cnt = job.cut[d + 1] - job.cut[d];
-				if (!cnt) continue;
-				const auto slab = makeResSlab(cnt);
-				for (size_t i = 0; i < cnt; ++i) (*receiver)(receiverIdx++, slabRes(slab, i, job.parts[d], i), ud);   // in input order; the receiver owns the result
+				typename Job::Part part;
+				{
+					std::unique_lock<std::mutex> lk{ job.mu };
+					if (untilAnalysed) { job.cv.wait(lk, [&] { return job.done || !job.ready.empty(); }); if (job.done) return; }
+					else if (job.ready.empty()) return;
+					part = std::move(job.ready.front()); job.ready.pop_front();
+				}
+				if (!part.count) continue;
+				const auto slab = makeResSlab(part.count);
+				for (size_t i = 0; i < part.count; ++i) (*receiver)(receiverIdx++, slabRes(slab, i, part.br, i), ud);   // in input order; the receiver owns the result
 			}
 		};
 		// A batch is handed over when it is full -- or, from 8 192 lines on, as soon as the device side has nothing to do: the first batch of a call starts
@@ -320,15 +343,18 @@ namespace
 		std::unique_ptr<Job> running, finished;
 		std::future<void> pending;
 		constexpr size_t kMinBatch = 8192;
+		constexpr double kMinReadSeconds = 1.5e-3;      // (a reader that delivers a whole batch in less fills it: short batches cost the device side more than they start it earlier)
 		auto deviceIdle = [&] { return !running || pending.wait_for(std::chrono::seconds(0)) == std::future_status::ready; };
 		auto readBatch = [&](Job& job)
 		{
 			if (job.off.empty()) job.off.push_back(0);
+			const auto started = std::chrono::steady_clock::now();
 			while ((long long)job.count() < (long long)h->batchSize)
 			{
 				if (!readNext(readerIdx, job.raw8, job.w, job.off, job.len)) return false;
 				++readerIdx;
-				if (job.count() >= kMinBatch && (job.count() & 1023) == 0 && deviceIdle()) break;
+				if (job.count() >= kMinBatch && (job.count() & 1023) == 0 && deviceIdle()
+					&& std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count() >= kMinReadSeconds) break;
 			}
 			return true;
 		};
@@ -350,10 +376,12 @@ namespace
 					if (!next->count()) next.reset();
 				}
 				const double t1 = clk();
-				if (running) { pending.get(); finished = std::move(running); }
+				// (the running batch's parts are delivered as they complete -- its later parts are still on the device --, what is left when its analysis ends after the
+				// next batch has been started)
+				if (running) { deliver(*running, true); pending.get(); finished = std::move(running); }
 				const double t2 = clk();
 				if (next) { running = std::move(next); Job* j = running.get(); pending = std::async(std::launch::async, [&analyse, j] { analyse(*j); }); }
-				if (finished) { deliver(*finished); finished.reset(); }      // (overlaps the next batch on the device)
+				if (finished) { deliver(*finished, false); finished.reset(); }      // (overlaps the next batch on the device)
 				tRead += t1 - t0; tWait += t2 - t1; tDeliver += clk() - t2;
 			}
 		}
@@ -362,7 +390,7 @@ namespace
 			if (pending.valid()) { try { pending.get(); } catch (...) {} }
 			throw;
 		}
-		if (timing) fprintf(stderr, "[kiwi_analyze_m] %d texts: reading %.1f ms, waiting for the device side %.1f ms, delivering %.1f ms\n", readerIdx, 1e3 * tRead, 1e3 * tWait, 1e3 * tDeliver);
+		if (timing) fprintf(stderr, "[kiwi_analyze_m] %d texts: reading %.1f ms, waiting for the device side + delivering its parts as they complete %.1f ms, delivering the rest %.1f ms\n", readerIdx, 1e3 * tRead, 1e3 * tWait, 1e3 * tDeliver);
 		return readerIdx;
 	}
 

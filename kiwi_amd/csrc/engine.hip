@@ -1666,21 +1666,23 @@ namespace kamd
 		// workers (one loop on the calling thread was 1.5 ms per 65 536 texts, and the caller's chain is what the pipelined parts wait for)
 		{
 			const size_t nBlk = b->prepBlocks.size();
-			std::vector<size_t> blkAt(nBlk + 1, 0);
+			// (a block holds the texts ONE call of the preparation appended to it: kPrepBlock of them when the pool cut the batch, all of them when it ran on one thread)
+			std::vector<size_t> blkAt(nBlk + 1, 0), textAt(nBlk + 1, 0);
 			for (size_t k = 0; k < nBlk; ++k)
 			{
 				size_t live = 0;
 				for (const ChunkDesc& d : b->prepBlocks[k].chunks) live += d.empty ? 0 : 1;
 				blkAt[k + 1] = blkAt[k] + live;
+				textAt[k + 1] = textAt[k] + b->prepBlocks[k].idx.size();
 			}
+			if (textAt[nBlk] != texts.size()) throw std::logic_error{ "kiwi_amd: prepared texts and blocks disagree" };
 			b->refs.resize(blkAt[nBlk]);
 			HostPool::instance().run(nBlk, 16, hostThreads, [&](size_t k0, size_t k1, int)
 			{
 				for (size_t k = k0; k < k1; ++k)
 				{
 					size_t at = blkAt[k];
-					const size_t i0 = k * StagedBatch::kPrepBlock, i1 = std::min(texts.size(), i0 + StagedBatch::kPrepBlock);
-					for (size_t i = i0; i < i1; ++i)
+					for (size_t i = textAt[k]; i < textAt[k + 1]; ++i)
 					{
 						const auto& pt = b->prep[i];
 						size_t live = 0;
@@ -2003,7 +2005,7 @@ namespace kamd
 	}
 
 	BatchResults Engine::analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
-		size_t topN, uint64_t match, bool openEnding, int hostThreads, TypoOption typo)
+		size_t topN, uint64_t match, bool openEnding, int hostThreads, TypoOption typo, const PartSink* onPart)
 	{
 		if (topN < 1 || topN > kMaxTopN) throw std::invalid_argument{ "kiwi_amd: top_n must be 1.." + std::to_string(kMaxTopN) + " on the device path" };
 		// A large batch goes through in PARTS whose host stages overlap the kernels of their neighbours: while part k is searched on the device the host
@@ -2024,6 +2026,7 @@ namespace kamd
 			HostTimer tm{ "batch" };
 			b.reset();
 			tm.lap("release of the staged batch");
+			if (onPart) { (*onPart)(0, std::move(r)); return BatchResults{}; }
 			return r;
 		}
 		std::vector<size_t> cut(parts + 1, texts.size());
@@ -2034,6 +2037,7 @@ namespace kamd
 		{
 			finish(*staged[k]);
 			BatchResults r = fetch(*staged[k], topN);
+			if (onPart) { staged[k].reset(); (*onPart)(cut[k], std::move(r)); return; }
 			for (auto& sg : r.segs) all.segs.push_back(std::move(sg));
 			for (auto& o : r.overrides) all.overrides.emplace_back(o.first + cut[k], std::move(o.second));
 			all.nTexts += r.nTexts; all.d2hBytes += r.d2hBytes;

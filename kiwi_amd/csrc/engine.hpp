@@ -5,6 +5,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -82,8 +83,11 @@ namespace kamd
 		const FlatModel& model() const;
 
 		// Full path: prepare -> kernels -> results, for a batch of raw UTF-16 texts.  Results are per text.
+		// onPart (optional): the results are handed over PART BY PART, in text order, as the parts of a large batch complete -- onPart(first text of the part, its
+		// results), called from the thread that assembled them while later parts are still on the device; the call then returns an empty BatchResults
+		using PartSink = std::function<void(size_t, BatchResults&&)>;
 		BatchResults analyzeBatch(const std::vector<std::pair<const char16_t*, size_t>>& texts,
-			size_t topN, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {});
+			size_t topN, uint64_t match, bool openEnding, int hostThreads = 0, TypoOption typo = {}, const PartSink* onPart = nullptr);
 
 		// Staged path (benchmarks): stage() does host preparation + upload of every chunk of the texts (one round,
 		// the common case where no quote/bullet state crosses chunk boundaries); run() launches the three kernels on
