@@ -193,6 +193,38 @@ def test_analyze_many_delivers_in_input_order(capi, kiwi, oracle, small_model):
         assert y == from_oracle(oracle.analyze(s)), s
 
 
+def test_analyze_many_delivers_the_parts_of_a_batch_in_input_order(capi, kiwi, oracle, small_model, monkeypatch):
+    """kiwi_analyze_m over ONE device batch that the engine cuts into parts (Engine::analyzeBatch: stage / launch on one host thread, wait / download /
+    assembly on another): the parts' results are handed to the calling thread while the later parts are still on the device and delivered to the
+    receiver in input order -- same analyses as the oracle's, line by line, with texts of several chunks among them."""
+    sm, _ = small_model
+    monkeypatch.setenv("KAMD_BATCH_PARTS", "3")
+    texts = [t for t in synthetic(sm, 420, 171, min_jamo=5, max_jamo=80) + dictionary_mix(sm, 60, 172)]
+    texts += [". ".join(texts[k:k + 4]) + "." for k in range(0, 40, 4)]
+    enc = [t.encode("utf-8") for t in texts]
+    got = []
+
+    def reader(i, buf, ud):
+        if i >= len(enc):
+            return 0
+        if not buf:
+            return len(enc[i])
+        C.memmove(buf, enc[i], len(enc[i]))
+        return 0
+
+    def receiver(i, r, ud):
+        got.append((i, read_result(capi, kiwi, r)))
+        capi.kiwi_res_close(r)
+        return 0
+
+    capi.kiwi_set_option(kiwi, 0x9001, 65536)   # KIWI_GPU_BATCH_SIZE: everything in one device batch
+    n = capi.kiwi_analyze_m(kiwi, READER(reader), RECEIVER(receiver), None, 1, opt())
+    assert n == len(texts), capi.kiwi_error()
+    assert [i for i, _ in got] == list(range(len(texts)))
+    for (i, y), s in zip(got, texts):
+        assert y == from_oracle(oracle.analyze(s)), s
+
+
 def test_concurrent_callers_on_one_handle(capi, kiwi, oracle, small_model):
     """kiwi_analyze* is callable from many threads on one handle (reference capi threading contract): device work is
     serialised per engine, results are unaffected."""
