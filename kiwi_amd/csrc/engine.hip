@@ -815,7 +815,8 @@ namespace kamd
 			uint64_t mapTop = 0, nsTop = 0, stateTop = 0, graphTop = 0;
 			scrTop = 0;
 			// (developer knob KAMD_TYPO_LDS_CAP="<mul4>x<add>": nodes per text unit x 4 and the constant of typoLdsNodeCap)
-			uint32_t typoCapMul4 = 16, typoCapAdd = 48;
+			uint32_t typoCapMul4 = 14, typoCapAdd = 40;      // (3.5 nodes per text unit + 40: the chunks of c5 build 2.2 at the median, 3.5 at most -- profiles/r06_p)
+			const bool typoLdsTables = [] { const char* e = std::getenv("KAMD_TYPO_LDS_TABLES"); return !e || std::atoi(e) != 0; }();      // (developer switch: 0 = graph / state ranges / state heads in HBM as in rounds 2 - 5)
 			if (const char* e = std::getenv("KAMD_TYPO_LDS_CAP")) { unsigned a = 0, c2 = 0; if (std::sscanf(e, "%ux%u", &a, &c2) == 2 && a) { typoCapMul4 = a; typoCapAdd = c2; } }
 			for (size_t c = 0; c < nC; ++c)
 			{
@@ -825,7 +826,8 @@ namespace kamd
 				if (gout[c].maxCti > 1) { size_t v = gout[c].maxCti - 1; while (v > 0) { v >>= 1; ++t.pmb; } }
 				t.mapLen = (t.nNs << t.pmb) + 1;
 				t.ldsCap = typoLdsNodeCap(t.nChars, t.nodeCap, typoCapMul4, typoCapAdd);
-				t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.ldsCap).total;
+				t.ldsGraphCap = (typoLdsTables && t.graphCnt <= kTypoLdsGraphMax && t.stateCap <= 0xFFFFu && t.nChars <= 0xFFF0u) ? t.graphCnt : 0u;      // (what the 16-byte graph records and the packed state ranges can hold)
+				t.ldsNeed = typoLdsLayout(t.nChars, t.nNs, t.pmb, t.ldsCap, t.ldsGraphCap).total;
 				t.graphOff = (uint32_t)graphTop; graphTop += t.graphCnt;
 				t.mapOff = (uint32_t)mapTop; mapTop += t.mapLen;
 				t.nsOff = (uint32_t)nsTop; nsTop += t.nChars + 2;

@@ -88,7 +88,7 @@ namespace kamd
 	// over every edge below the root (the root has its direct table).  The sorted keys per node stay (host walks, the bake's fail links): a device walk through
 	// them costs 2 + log2(fan-out) DEPENDENT loads per character -- the record, the halving steps, the child --, which is what bounds the dictionary scan and
 	// the typo lattice's automaton steps.
-	struct TrieEdgeSlot { uint32_t node, key, child, pad; };
+	struct TrieEdgeSlot { uint32_t node, key, child; int32_t value; };      // value: the child's TrieNodeRec::value (a walk that only asks "does a form end here" needs no second load)
 	static_assert(sizeof(TrieEdgeSlot) == 16, "TrieEdgeSlot");
 	constexpr uint32_t TRIE_EDGE_EMPTY = 0xFFFFFFFFu;
 	KAMD_HD uint32_t trieEdgeHash(uint32_t node, uint32_t key) { uint32_t h = node * 0x9E3779B1u + key * 0x85EBCA6Bu; h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13; return h; }

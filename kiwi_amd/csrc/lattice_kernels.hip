@@ -29,15 +29,16 @@ namespace kamd
 {
 	// child of `node` over `c` (0: none): the root's direct table, below it the edge hash -- one 16-byte load per probe, 1.1 probes on average (flat_model.hpp
 	// TrieEdgeSlot); rounds 1 - 5 searched the node's sorted keys: record + log2(fan-out) halving steps + child, each a dependent load
-	__device__ __forceinline__ uint32_t trieChild(const ModelView& M, uint32_t node, uint16_t c)
+	// `value`: the child's TrieNodeRec::value -- a slot carries it (TrieEdgeSlot::value), so that a step below the root is ONE load; below the root's table it is read
+	__device__ __forceinline__ uint32_t trieChild(const ModelView& M, uint32_t node, uint16_t c, int32_t& value)
 	{
-		if (node == 0) return M.trieRoot[c];
+		if (node == 0) { const uint32_t ch = M.trieRoot[c]; value = ch ? M.trie[ch].value : TRIE_NONE; return ch; }
 		uint32_t h = trieEdgeHash(node, c) & M.trieEdgeMask;
 		for (;;)
 		{
 			const uint4 s = reinterpret_cast<const uint4*>(M.trieEdges)[h];
-			if (s.x == node && s.y == (uint32_t)c) return s.z;
-			if (s.x == TRIE_EDGE_EMPTY) return 0;
+			if (s.x == node && s.y == (uint32_t)c) { value = (int32_t)s.w; return s.z; }
+			if (s.x == TRIE_EDGE_EMPTY) { value = TRIE_NONE; return 0; }
 			h = (h + 1) & M.trieEdgeMask;
 		}
 	}
@@ -107,10 +108,10 @@ namespace kamd
 			{
 				const uint32_t p = nsToPos[i];
 				if (cflag[p] & 2) continue;
-				node = trieChild(M, node, str[p]);
+				int32_t v;
+				node = trieChild(M, node, str[p], v);
 				if (!node) break;
 				++depth;
-				const int32_t v = M.trie[node].value;
 				if (v >= 0)
 				{
 					atomicOr((unsigned long long*)&mask[i + 1], 1ull << (depth - 1));
@@ -168,10 +169,10 @@ namespace kamd
 			{
 				const uint32_t p = nsToPos[i];
 				if (cflag[p] & 2) continue;
-				node = trieChild(M, node, str[p]);
+				int32_t v;
+				node = trieChild(M, node, str[p], v);
 				if (!node) break;
 				++depth;
-				const int32_t v = M.trie[node].value;
 				if (v >= 0)
 				{
 					const uint64_t mk = mask[i + 1];

@@ -1502,7 +1502,7 @@ namespace kamd
 		size_t cap = 64;
 		while (cap < 4 * edges) cap <<= 1;      // at most a quarter full: a lookup that misses ends at an empty slot after 1.2 probes on average
 		if (cap > (1ull << 31)) throw std::runtime_error{ "form trie too large for the edge table" };
-		m.trieEdges.assign(cap, TrieEdgeSlot{ TRIE_EDGE_EMPTY, 0, 0, 0 });
+		m.trieEdges.assign(cap, TrieEdgeSlot{ TRIE_EDGE_EMPTY, 0, 0, TRIE_NONE });
 		m.trieEdgeMask = (uint32_t)cap - 1;
 		for (size_t n = 1; n < m.trie.size(); ++n)
 		{
@@ -1512,7 +1512,8 @@ namespace kamd
 				const uint32_t key = m.trieKeys[t.edgeOff + e];
 				uint32_t h = trieEdgeHash((uint32_t)n, key) & m.trieEdgeMask;
 				while (m.trieEdges[h].node != TRIE_EDGE_EMPTY) h = (h + 1) & m.trieEdgeMask;
-				m.trieEdges[h] = TrieEdgeSlot{ (uint32_t)n, key, m.trieChild[t.edgeOff + e], 0 };
+				const uint32_t child = m.trieChild[t.edgeOff + e];
+				m.trieEdges[h] = TrieEdgeSlot{ (uint32_t)n, key, child, m.trie[child].value };
 			}
 		}
 	}

@@ -181,19 +181,23 @@ namespace kamd
 				}
 				return nErr;
 			}
-			__device__ __forceinline__ int32_t trieNext(uint32_t node, uint16_t c) const
+			// value: the child's TrieNodeRec::value where the edge slot carries it (every step below the root); kValueUnknown below the root's table
+			static constexpr int32_t kValueUnknown = -3;
+			__device__ __forceinline__ int32_t trieNext(uint32_t node, uint16_t c, int32_t& value) const
 			{
+				value = kValueUnknown;
 				if (node == 0) { const uint32_t r = M.trieRoot[c]; return r ? (int32_t)r : -1; }
 				// (the edge hash: one dependent load per probe instead of record + binary search + child, flat_model.hpp TrieEdgeSlot)
 				uint32_t h = trieEdgeHash(node, c) & M.trieEdgeMask;
 				for (;;)
 				{
 					const uint4 s = reinterpret_cast<const uint4*>(M.trieEdges)[h];
-					if (s.x == node && s.y == (uint32_t)c) return (int32_t)s.z;
+					if (s.x == node && s.y == (uint32_t)c) { value = (int32_t)s.w; return (int32_t)s.z; }
 					if (s.x == TRIE_EDGE_EMPTY) return -1;
 					h = (h + 1) & M.trieEdgeMask;
 				}
 			}
+			__device__ __forceinline__ int32_t trieNext(uint32_t node, uint16_t c) const { int32_t v; return trieNext(node, c, v); }
 			__device__ __forceinline__ uint16_t formChar(const TypoGraphNode& g, uint32_t j) const
 			{
 				return (g.formOff & TYPO_FORM_IN_POOL) ? V.pool[(g.formOff & ~TYPO_FORM_IN_POOL) + j] : str[g.formOff + j];
@@ -224,13 +228,29 @@ namespace kamd
 				nCands = 0;
 			}
 
-			// progressNode: state `st` of graph node `prevT` continued through graph node `tn`; new states go to cur[0..nCur)
-			__device__ __forceinline__ void progress(const TypoGraphNode& prevT, const TypoGraphNode& tn, uint32_t tnIdx, const TypoState& stRef, TypoState* cur, uint32_t& nCur, uint32_t curCap)
+			// (a state's fixed part: its lengthening lists are read entry by entry, nL of them)
+			struct Head { int32_t node; float cost; uint32_t minFormLen; int32_t startPosOffset; uint32_t specialStart, unkStart, boundary; uint8_t lastType, lastScript, hasLast, pad; uint16_t startCti, pad2; uint32_t lastChr, nL; };
+			static_assert(sizeof(Head) == offsetof(TypoState, lsize) && sizeof(Head) == 4 * kTypoStateHeadWords, "TypoState head");
+
+			// progressNode: state `st` of graph node `prevT` continued through graph node `tn`; new states go to cur[0..nCur).  stHead: the state's head where the
+			// caller holds it (the LDS ring of recent states), null: read from stRef; ring: where the head of a NEW state is mirrored (slot = absolute state index
+			// modulo kTypoLdsRing; null: nowhere), ringTop: absolute index of cur[0]
+			__device__ __forceinline__ static Head headOf(const TypoState& s) { return *reinterpret_cast<const Head*>(&s); }
+			// (the eleven words of a head, field by field: a head whose address is taken lives in scratch memory)
+			__device__ __forceinline__ static void headWords(const Head& h, uint32_t (&w)[kTypoStateHeadWords])
 			{
-				// (the state's fixed part only: its lengthening lists are read entry by entry, nL of them)
-				struct Head { int32_t node; float cost; uint32_t minFormLen; int32_t startPosOffset; uint32_t specialStart, unkStart, boundary; uint8_t lastType, lastScript, hasLast, pad; uint16_t startCti, pad2; uint32_t lastChr, nL; };
-				static_assert(sizeof(Head) == offsetof(TypoState, lsize), "TypoState head");
-				const Head st = *reinterpret_cast<const Head*>(&stRef);
+				w[0] = (uint32_t)h.node; w[1] = __float_as_uint(h.cost); w[2] = h.minFormLen; w[3] = (uint32_t)h.startPosOffset; w[4] = h.specialStart; w[5] = h.unkStart; w[6] = h.boundary;
+				w[7] = (uint32_t)h.lastType | ((uint32_t)h.lastScript << 8) | ((uint32_t)h.hasLast << 16) | ((uint32_t)h.pad << 24); w[8] = (uint32_t)h.startCti | ((uint32_t)h.pad2 << 16); w[9] = h.lastChr; w[10] = h.nL;
+			}
+			__device__ __forceinline__ static Head headFromWords(const uint32_t (&w)[kTypoStateHeadWords])
+			{
+				Head h; h.node = (int32_t)w[0]; h.cost = __uint_as_float(w[1]); h.minFormLen = w[2]; h.startPosOffset = (int32_t)w[3]; h.specialStart = w[4]; h.unkStart = w[5]; h.boundary = w[6];
+				h.lastType = (uint8_t)w[7]; h.lastScript = (uint8_t)(w[7] >> 8); h.hasLast = (uint8_t)(w[7] >> 16); h.pad = (uint8_t)(w[7] >> 24); h.startCti = (uint16_t)w[8]; h.pad2 = (uint16_t)(w[8] >> 16); h.lastChr = w[9]; h.nL = w[10];
+				return h;
+			}
+			__device__ __forceinline__ void progress(const TypoGraphNode& prevT, const TypoGraphNode& tn, uint32_t tnIdx, const TypoState& stRef, const Head st, TypoState* cur, uint32_t& nCur, uint32_t curCap,
+				uint32_t* ring = nullptr, uint32_t ringTop = 0, int32_t lastPair = -1)
+			{
 				float typoCost = st.cost + tn.typoCost;
 				if (typoCost > V.threshold) return;
 				uint8_t lastType = st.hasLast ? st.lastType : (uint8_t)T_UNKNOWN;
@@ -241,7 +261,13 @@ namespace kamd
 				int32_t startPosOffset = st.startPosOffset;
 				const uint32_t fsz = tn.formLen;
 				if (tn.typoCost > 0) startPosOffset += (int32_t)fsz - (int32_t)(tn.endPos - prevT.endPos);
-				if (fsz) { outType = V.graphLast[2 * tnIdx]; outScript = V.graphLast[2 * tnIdx + 1]; outHas = outType != 0xFF; }
+				// (type and script of the node's last character: from the caller where it holds them -- lastPair = type | script << 8, the LDS copy --, else TypoLatView::graphLast)
+				if (fsz)
+				{
+					if (lastPair >= 0) { outType = (uint8_t)(lastPair & 0xFF); outScript = (uint8_t)(lastPair >> 8); }
+					else { outType = V.graphLast[2 * tnIdx]; outScript = V.graphLast[2 * tnIdx + 1]; }
+					outHas = outType != 0xFF;
+				}
 				int32_t curNode = st.node;
 				const uint8_t scriptVS = 98;
 				uint32_t candsLocal[LDS ? 1 : MAXCAND]; uint32_t* cands; uint32_t nCands = 0;
@@ -354,19 +380,22 @@ namespace kamd
 					prevChr = c32;
 
 					if (minFormLen > 0 || tn.typoCost > 0) ++minFormLen;
-					int32_t nx = trieNext((uint32_t)curNode, ch);
+					int32_t nxValue;
+					int32_t nx = trieNext((uint32_t)curNode, ch, nxValue);
 					while (nx < 0)
 					{
 						curNode = M.trie[curNode].fail;
 						if (curNode < 0) break;
-						nx = trieNext((uint32_t)curNode, ch);
+						nx = trieNext((uint32_t)curNode, ch, nxValue);
 					}
 					if (nx >= 0)
 					{
 						curNode = nx;
 						if (tn.typoCost == 0 || j == fsz - 1)
 						{
-							if (typoCost > 0 && M.trie[curNode].depth < minFormLen) {}      // early pruning
+							// (no form and no submatch ends at this node -- the edge slot said so: the chain below would stop at its first record, which is not read)
+							if (nxValue == TRIE_NONE) {}
+							else if (typoCost > 0 && M.trie[curNode].depth < minFormLen) {}      // early pruning
 							else for (int32_t sm = curNode; sm >= 0; sm = M.trie[sm].fail)
 							{
 								const int32_t v = M.trie[sm].value;
@@ -416,8 +445,15 @@ namespace kamd
 					ns.lastType = outType; ns.lastScript = outScript; ns.hasLast = outHas; ns.pad = 0;
 					ns.startCti = tn.continualTypoIdx ? tn.continualTypoIdx : st.startCti; ns.pad2 = 0;
 					ns.lastChr = prevChr; ns.nL = nL;
+					uint32_t nw[kTypoStateHeadWords];
+					headWords(ns, nw);
+					if (ring)
+					{
+						uint32_t* slot = ring + ((ringTop + nCur) % kTypoLdsRing) * kTypoStateHeadWords;
+						for (uint32_t q = 0; q < kTypoStateHeadWords; ++q) slot[q] = nw[q];
+					}
 					TypoState& dst = cur[nCur++];
-					*reinterpret_cast<Head*>(&dst) = ns;
+					{ uint32_t* dw = reinterpret_cast<uint32_t*>(&dst); for (uint32_t q = 0; q < kTypoStateHeadWords; ++q) dw[q] = nw[q]; }
 					for (uint32_t k = 0; k < nL; ++k) { dst.lsize[k] = lsz[k]; dst.lnode[k] = lnd[k]; }
 				}
 			}
@@ -474,7 +510,7 @@ namespace kamd
 			{
 				const TypoGraphNode pt = graph[p];
 				for (uint32_t k = 0; k < sIdx[2 * p + 1]; ++k)
-					X.progress(pt, tn, C.graphOff + i, states[sIdx[2 * p] + k], states + curBeg, nCur, C.stateCap - curBeg);
+					{ const TypoState& sr = states[sIdx[2 * p] + k]; X.progress(pt, tn, C.graphOff + i, sr, CtxT<false>::headOf(sr), states + curBeg, nCur, C.stateCap - curBeg); }
 			}
 			sIdx[2 * i] = curBeg; sIdx[2 * i + 1] = nCur; top = curBeg + nCur;
 			if (tn.typoCost == 0 && tn.endPos == totEnd)
@@ -629,7 +665,7 @@ namespace kamd
 		TypoLatChunk& C = V.chunks[chunkList[blockIdx.x]];
 		if (V.results[C.chunkId].status >= 16) { if (lane == 0) C.status = V.results[C.chunkId].status; return; }
 		const uint32_t n = C.nChars, pmb = C.pmb;
-		const TypoLds lay = typoLdsLayout(n, C.nNs, pmb, C.ldsCap);
+		const TypoLds lay = typoLdsLayout(n, C.nNs, pmb, C.ldsCap, C.ldsGraphCap);
 		if (lay.total > ldsBytes || C.mapLen > 0xFFF0 || C.nodeCap > 0xFFF0 || C.mapLen != (C.nNs << pmb) + 1 || C.mapLen > 64 * (C.nNs + 1)) { if (lane == 0) C.status = kTypoLdsNeedsBig; return; }
 		uint16_t* str = reinterpret_cast<uint16_t*>(tSmem + lay.str); uint8_t* cls = tSmem + lay.cls; uint8_t* script = tSmem + lay.script;
 		uint16_t* nsToPos = reinterpret_cast<uint16_t*>(tSmem + lay.nsToPos); uint16_t* posToNs = reinterpret_cast<uint16_t*>(tSmem + lay.posToNs);
@@ -640,6 +676,18 @@ namespace kamd
 			for (uint32_t i = lane; i < n; i += 64) { str[i] = gstr[i]; cls[i] = gcls[i]; script[i] = gscript[i]; }
 			for (uint32_t i = lane; i < C.mapLen; i += 64) epm[i] = 0;      // first == last + 1 - 1 ... : lo == hi, empty
 			for (uint32_t i = lane; i <= C.nNs; i += 64) { fullMask[i] = 0; zAt[i] = 0; }
+		}
+		// the chunk's typo graph beside them (28 bytes per node, read word by word: coalesced), the state ranges and the ring of state heads follow
+		const uint32_t gCap = lay.graphCap;
+		TypoLdsGraphNode* gL = reinterpret_cast<TypoLdsGraphNode*>(tSmem + lay.graph); uint32_t* sL = reinterpret_cast<uint32_t*>(tSmem + lay.sidx); uint32_t* ringL = gCap ? reinterpret_cast<uint32_t*>(tSmem + lay.ring) : nullptr;
+		uint16_t* glL = reinterpret_cast<uint16_t*>(tSmem + lay.glast);
+		for (uint32_t i = lane; i < gCap; i += 64)
+		{
+			glL[i] = reinterpret_cast<const uint16_t*>(V.graphLast)[C.graphOff + i];      // (type | script << 8)
+			const TypoGraphNode g = V.graph[C.graphOff + i];
+			TypoLdsGraphNode c; c.formOff = g.formOff; c.typoCost = g.typoCost; c.formLen = (uint16_t)g.formLen; c.endPos = (uint16_t)g.endPos;
+			c.prevOffset = (uint8_t)g.prevOffset; c.siblingOffset = (uint8_t)g.siblingOffset; c.continualTypoIdx = g.continualTypoIdx; c.pad = 0;
+			gL[i] = c;
 		}
 		waveSync();
 		CtxT<true> X{ M, V, C };
@@ -673,20 +721,53 @@ namespace kamd
 				const TypoGraphNode* graph = V.graph + C.graphOff;
 				TypoState* states = V.states + C.stateOff;
 				uint32_t* sIdx = V.stateIdx + 2 * C.graphOff;
+				// (graph records / state ranges from the LDS copies when the chunk has them, gCap = graphCnt, else from HBM)
+				auto graphAt = [&](uint32_t i) -> TypoGraphNode
+				{
+					if (i < gCap)
+					{
+						const TypoLdsGraphNode c = gL[i];
+						TypoGraphNode r; r.formOff = c.formOff; r.formLen = c.formLen; r.endPos = c.endPos; r.typoCost = c.typoCost; r.prevOffset = c.prevOffset; r.siblingOffset = c.siblingOffset;
+						r.continualTypoIdx = c.continualTypoIdx; r.pad = 0; r.dialect = 0;      // (the dialect of a replacement was applied when the graph was made: the lattice build does not read it)
+						return r;
+					}
+					return graph[i];
+				};
+				auto setRange = [&](uint32_t i, uint32_t beg, uint32_t cnt) { if (i < gCap) sL[i] = beg | (cnt << 16); else { sIdx[2 * i] = beg; sIdx[2 * i + 1] = cnt; } };      // (beg < stateCap <= 65535 where the tables exist; a node has far fewer states)
 				const uint32_t totEnd = nNs ? (uint32_t)nsToPos[nNs - 1] + 1 : 0;
 				uint32_t top = 0;
-				{ TypoState s0{}; states[top] = s0; sIdx[0] = 0; sIdx[1] = 1; ++top; }
+				{
+					TypoState s0{}; states[top] = s0; setRange(0, 0, 1);
+					if (ringL) for (uint32_t q = 0; q < kTypoStateHeadWords; ++q) ringL[q] = 0;
+					++top;
+				}
 				for (uint32_t i = 1; i < C.graphCnt; ++i)
 				{
-					const TypoGraphNode tn = graph[i];
+					const TypoGraphNode tn = graphAt(i);
+					const int32_t lastPair = i < gCap ? (int32_t)glL[i] : -1;
 					const uint32_t curBeg = top; uint32_t nCur = 0;
-					for (uint32_t p = tn.prevOffset ? i - tn.prevOffset : NPOS; p != NPOS; p = graph[p].siblingOffset ? p + graph[p].siblingOffset : NPOS)
+					for (uint32_t p = tn.prevOffset ? i - tn.prevOffset : NPOS; p != NPOS; )
 					{
-						const TypoGraphNode pt = graph[p];
-						for (uint32_t k = 0; k < sIdx[2 * p + 1]; ++k)
-							X.progress(pt, tn, C.graphOff + i, states[sIdx[2 * p] + k], states + curBeg, nCur, C.stateCap - curBeg);
+						const TypoGraphNode pt = graphAt(p);
+						const uint32_t pr = p < gCap ? sL[p] : 0u;
+						const uint32_t pBeg = p < gCap ? (pr & 0xFFFFu) : sIdx[2 * p], pCnt = p < gCap ? (pr >> 16) : sIdx[2 * p + 1];
+						for (uint32_t k = 0; k < pCnt; ++k)
+						{
+							const uint32_t a = pBeg + k;      // absolute index of the state: its head is in the ring while it is one of the last kTypoLdsRing
+							CtxT<true>::Head hd;
+							if (ringL && curBeg + nCur - a <= kTypoLdsRing)
+							{
+								uint32_t w[kTypoStateHeadWords];
+								const uint32_t* slot = ringL + (a % kTypoLdsRing) * kTypoStateHeadWords;
+								for (uint32_t q = 0; q < kTypoStateHeadWords; ++q) w[q] = slot[q];
+								hd = CtxT<true>::headFromWords(w);
+							}
+							else hd = CtxT<true>::headOf(states[a]);
+							X.progress(pt, tn, C.graphOff + i, states[a], hd, states + curBeg, nCur, C.stateCap - curBeg, ringL, curBeg, lastPair);
+						}
+						p = pt.siblingOffset ? p + pt.siblingOffset : NPOS;
 					}
-					sIdx[2 * i] = curBeg; sIdx[2 * i + 1] = nCur; top = curBeg + nCur;
+					setRange(i, curBeg, nCur); top = curBeg + nCur;
 					if (tn.typoCost == 0 && tn.endPos == totEnd)
 						for (uint32_t k = 0; k < nCur; ++k) X.unkPair(states[curBeg + k].boundary, states[curBeg + k].unkStart, posToNs[totEnd], true);
 				}

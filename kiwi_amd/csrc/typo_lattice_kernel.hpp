@@ -20,6 +20,7 @@ namespace kamd
 		uint32_t textOffset;           // offset of the chunk in the normalised text (added to final positions of the dump records)
 		uint32_t chunkId, packCap;     // engine mode: index of the chunk in the batch, capacity of its candidate-pack region
 		uint32_t nOutFinal, status;    // out: number of connected nodes, ChunkStatus
+		uint32_t ldsGraphCap;          // engine mode: graph nodes whose records / state ranges are kept in LDS (graphCnt, or 0: in HBM)
 		uint32_t ldsCap;               // engine mode: nodes the chunk's LDS copy holds (typoLdsNodeCap, host-computed: the kernel lays its LDS out from it)
 		uint32_t ldsNeed, pad;         // engine mode: dynamic LDS the wave-per-chunk kernel needs for this chunk (typoLdsLayout().total)
 	};
@@ -60,16 +61,22 @@ namespace kamd
 	constexpr uint32_t kTypoMaxCand = 96;               // dictionary candidates of one input position
 	// node of the build in LDS (24 bytes; positions are multiplied positions < 65536)
 	struct TypoLdsNode { uint32_t form; uint16_t startPos, endPos, prev, sibling, uformOff, uformLen; float typoCost; uint8_t spaceErrors, pad[3]; };
-	struct TypoLds { uint32_t str, cls, script, nsToPos, posToNs, epm, fullMask, zAt, cands, nodes, queue, conn, nodeCap, total; };
+	// graph / sidx / ring (round 6): the chunk's typo graph, its per-node state ranges and the heads of the most recent search states, which the replay read from
+	// HBM once per (node, predecessor, state) -- over half of its 2 500 dependent loads per chunk; graphCap = 0: left in HBM (graphs of more than kTypoLdsGraphMax nodes, KAMD_TYPO_LDS_TABLES=0)
+	constexpr uint32_t kTypoLdsGraphMax = 255, kTypoLdsRing = 24, kTypoStateHeadWords = 11;
+	// a graph node as the LDS copy keeps it (16 bytes: offsets inside a graph of at most kTypoLdsGraphMax nodes fit a byte, positions of a chunk sixteen bits)
+	struct TypoLdsGraphNode { uint32_t formOff; float typoCost; uint16_t formLen, endPos; uint8_t prevOffset, siblingOffset, continualTypoIdx, pad; };
+	static_assert(sizeof(TypoLdsGraphNode) == 16, "TypoLdsGraphNode");
+	struct TypoLds { uint32_t str, cls, script, nsToPos, posToNs, epm, fullMask, zAt, cands, nodes, queue, conn, nodeCap, graph, sidx, ring, glast, graphCap, total; };
 	// nodes a chunk's LDS copy holds: mul4 / 4 per text unit + add (the defaults cover every chunk of the bench corpora; a chunk that outgrows its copy is
 	// built again by the thread-per-chunk kernel).  Host side only -- the kernel reads TypoLatChunk::ldsCap.
 #ifdef KAMD_TEST_SMALL_CAPS
 	// test build (make smallcaps): most chunks outgrow their LDS node list and are handed to the thread-per-chunk kernel
 	inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap, uint32_t = 0, uint32_t = 0) { const uint32_t c = nChars / 2 + 4; return c < nodeCap ? c : nodeCap; }
 #else
-	inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap, uint32_t mul4 = 16, uint32_t add = 48) { const uint32_t c = mul4 * nChars / 4 + add; return c < nodeCap ? c : nodeCap; }
+	inline uint32_t typoLdsNodeCap(uint32_t nChars, uint32_t nodeCap, uint32_t mul4 = 14, uint32_t add = 40) { const uint32_t c = mul4 * nChars / 4 + add; return c < nodeCap ? c : nodeCap; }
 #endif
-	__host__ __device__ inline TypoLds typoLdsLayout(uint32_t nChars, uint32_t nNs, uint32_t pmb, uint32_t ldsNodeCap)
+	__host__ __device__ inline TypoLds typoLdsLayout(uint32_t nChars, uint32_t nNs, uint32_t pmb, uint32_t ldsNodeCap, uint32_t ldsGraphCap)
 	{
 		TypoLds l; uint32_t top = 0;
 		auto take = [&](uint32_t bytes, uint32_t align) { top = (top + align - 1) / align * align; const uint32_t o = top; top += bytes; return o; };
@@ -82,11 +89,22 @@ namespace kamd
 		l.str = take(2 * nChars, 2);
 		l.nsToPos = take(2 * (nChars + 2), 2);
 		l.posToNs = take(2 * (nChars + 2), 2);
-		l.queue = take(2 * l.nodeCap, 2);
-		l.conn = take(2 * l.nodeCap, 2);
 		l.cls = take(nChars, 1);
 		l.script = take(nChars, 1);
 		l.zAt = take(nNs + 1, 1);
+		// the tables of the SEARCH (graph copy, state ranges, ring of state heads) and the arrays of what follows it (the queue and the flags of removeUnconnected)
+		// share their bytes: the search has ended when the sweep starts
+		l.graphCap = ldsGraphCap;
+		const uint32_t shared = take(0, 16);
+		l.graph = take(16 * ldsGraphCap, 16);
+		l.sidx = take(4 * ldsGraphCap, 4);
+		l.ring = take(ldsGraphCap ? 4 * kTypoStateHeadWords * kTypoLdsRing : 0, 4);
+		l.glast = take(2 * ldsGraphCap, 2);      // TypoLatView::graphLast of the chunk's nodes
+		const uint32_t searchEnd = top;
+		top = shared;
+		l.queue = take(2 * l.nodeCap, 2);
+		l.conn = take(2 * l.nodeCap, 2);
+		if (top < searchEnd) top = searchEnd;
 		l.total = (top + 15) / 16 * 16;
 		return l;
 	}
