@@ -39,6 +39,7 @@ namespace kamd
 			uint2* endPosMap; TypoLatNode* out;                                                     // HBM variant
 			uint32_t* epm; TypoLdsNode* lout; uint64_t* fullMask; uint8_t* zAt; uint32_t* candBuf;   // LDS variant
 			uint32_t ldsCap, lastEnd; bool outgrown;
+			uint32_t mapLen;      // (TypoLatChunk::mapLen, read once: the chunk record is in HBM and every append asked for it)
 			uint32_t nOut;
 			const DevPattern* pat; const DevPattern* patEnd;
 			bool overflow;
@@ -56,7 +57,7 @@ namespace kamd
 					nn.uformOff = (uint16_t)uOff; nn.uformLen = (uint16_t)uLen; nn.typoCost = typoCost; nn.spaceErrors = 0; nn.pad[0] = nn.pad[1] = nn.pad[2] = 0;
 					lout[id] = nn;
 					lastEnd = e;
-					if (e >= C.mapLen) return true;
+					if (e >= mapLen) return true;
 					if ((e & ((1u << pmb) - 1)) == 0)      // only whole positions are ever asked about (insertUnk, the z-coda test)
 					{
 						uint8_t fl = 0; uint32_t flen = 0;
@@ -86,7 +87,7 @@ namespace kamd
 					const uint32_t id = nOut++;
 					TypoLatNode nn; nn.startPos = s; nn.endPos = e; nn.prev = id - endPosMap[s].x; nn.sibling = 0; nn.form = (int32_t)form; nn.uformLen = uLen; nn.uformOff = uOff; nn.spaceErrors = 0; nn.typoCost = typoCost;
 					out[id] = nn;
-					if (e >= C.mapLen) return true;
+					if (e >= mapLen) return true;
 					uint2 m = endPosMap[e];
 					if (m.x == m.y) { m.x = id; m.y = id + 1; }
 					else { out[m.y - 1].sibling = id - (m.y - 1); m.y = id + 1; }
@@ -472,6 +473,7 @@ namespace kamd
 		if (ldsBudget && C.ldsNeed <= ldsBudget && C.status != kTypoLdsNeedsBig) return;      // done by the wave-per-chunk kernel
 		C.pad = C.status == kTypoLdsNeedsBig ? 1u : 0u;      // (developer statistics: this chunk outgrew its LDS copy)
 		CtxT<false> X{ M, V, C };
+		X.mapLen = C.mapLen;
 		X.str = V.chars + C.charOff; X.cls = V.cls + C.charOff; X.script = V.script + C.charOff; X.n = C.nChars; X.pmb = C.pmb;
 		uint16_t* nsToPos = V.nsToPos + C.nsOff; uint16_t* posToNs = V.posToNs + C.nsOff;
 		uint32_t nNs = 0;
@@ -691,6 +693,7 @@ namespace kamd
 		}
 		waveSync();
 		CtxT<true> X{ M, V, C };
+		X.mapLen = C.mapLen;
 		X.str = str; X.cls = cls; X.script = script; X.n = n; X.pmb = pmb; X.nsToPos = nsToPos; X.posToNs = posToNs;
 		X.endPosMap = nullptr; X.out = nullptr; X.epm = epm; X.lout = lout; X.fullMask = fullMask; X.zAt = zAt; X.candBuf = reinterpret_cast<uint32_t*>(tSmem + lay.cands);
 		X.ldsCap = lay.nodeCap; X.lastEnd = 0; X.outgrown = false; X.nOut = 0; X.overflow = false;
@@ -741,11 +744,26 @@ namespace kamd
 					if (ringL) for (uint32_t q = 0; q < kTypoStateHeadWords; ++q) ringL[q] = 0;
 					++top;
 				}
-				for (uint32_t i = 1; i < C.graphCnt; ++i)
+#if defined(KAMD_HIPEMU) && defined(KAMD_TYPOSTATS)
+				// developer statistics of a host (lane-emulated) build: automaton steps of the replay as it is (one (node, predecessor, state) after the other), with the
+				// triples of a NODE side by side, and with the triples of a LEVEL (nodes none of whose predecessors is in the level) side by side
+				unsigned long long wSeq = 0, wNode = 0, wLevel = 0, calls = 0; uint32_t levelStart = 1, levelMax = 0;
+#endif
+				const uint32_t graphCnt = C.graphCnt, graphOff = C.graphOff, stateCap = C.stateCap;      // (the chunk record is in HBM: read once)
+				for (uint32_t i = 1; i < graphCnt; ++i)
 				{
 					const TypoGraphNode tn = graphAt(i);
 					const int32_t lastPair = i < gCap ? (int32_t)glL[i] : -1;
 					const uint32_t curBeg = top; uint32_t nCur = 0;
+#if defined(KAMD_HIPEMU) && defined(KAMD_TYPOSTATS)
+					{
+						uint32_t nCalls = 0, maxPred = 0;
+						for (uint32_t p = tn.prevOffset ? i - tn.prevOffset : NPOS; p != NPOS; ) { const TypoGraphNode pt = graphAt(p); nCalls += p < gCap ? (sL[p] >> 16) : sIdx[2 * p + 1]; if (p > maxPred) maxPred = p; p = pt.siblingOffset ? p + pt.siblingOffset : NPOS; }
+						if (maxPred >= levelStart) { wLevel += levelMax; levelStart = i; levelMax = 0; }
+						if (nCalls) { wSeq += (unsigned long long)nCalls * tn.formLen; wNode += tn.formLen; if (tn.formLen > levelMax) levelMax = tn.formLen; calls += nCalls; }
+						if (i + 1 == graphCnt) { wLevel += levelMax; fprintf(stderr, "[typostats] graph %u nodes, %llu calls, automaton steps: sequential %llu, per node %llu, per level %llu\n", graphCnt, calls, wSeq, wNode, wLevel); }
+					}
+#endif
 					for (uint32_t p = tn.prevOffset ? i - tn.prevOffset : NPOS; p != NPOS; )
 					{
 						const TypoGraphNode pt = graphAt(p);
@@ -763,7 +781,7 @@ namespace kamd
 								hd = CtxT<true>::headFromWords(w);
 							}
 							else hd = CtxT<true>::headOf(states[a]);
-							X.progress(pt, tn, C.graphOff + i, states[a], hd, states + curBeg, nCur, C.stateCap - curBeg, ringL, curBeg, lastPair);
+							X.progress(pt, tn, graphOff + i, states[a], hd, states + curBeg, nCur, stateCap - curBeg, ringL, curBeg, lastPair);
 						}
 						p = pt.siblingOffset ? p + pt.siblingOffset : NPOS;
 					}

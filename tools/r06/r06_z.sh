@@ -3,7 +3,7 @@
 # rocprofv3 kernel statistics of the default workload and of c5 (the typo lattice kernel is built for five wavefronts per SIMD since r06_g), c5's bench line.
 # The search / lattice kernels are those of r06_x (PMC summaries and traffic.json of that run stay valid: this round's later commits are host-side).
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
-OUT=$ROOT/gpurun_out/r06_z; mkdir -p $OUT; cd $ROOT
+OUT=$ROOT/gpurun_out/${TAG:-r06_z}; mkdir -p $OUT; cd $ROOT
 timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/pytest_gpu.txt; tail -3 $OUT/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
 timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cut -c1-300 $OUT/bench_default.json
