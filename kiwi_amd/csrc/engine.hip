@@ -280,7 +280,8 @@ namespace kamd
 		bool groupLanesForced = false; int wpsForced = 0;   // KAMD_GROUP_LANES / KAMD_WPS given
 		bool posPath = true;  // the position-step search kernel runs first, the general one on what it hands over (KAMD_POS_PATH=0: general kernel only)
 		bool wantCongGlobal = false;     // LmMode::CongGlobal: score with the distant-token (window) sections of the CoNgram file
-		bool posPathForced = false;      // KAMD_POS_PATH=2: also for typo correction (slower there: see launchAll)
+		bool posPathForced = false;      // KAMD_POS_PATH=2 (kept for the parity suites: the position steps wherever a compilation has them)
+		bool posPathTypo = true;         // ... also over typo lattices (KAMD_POS_PATH=3: not there, the behaviour of rounds 3 - 5)
 		int posGroupForced = 0;          // KAMD_POS_G=8 / 16: lane-group width of the position-step kernel (0: by batch size)
 		int groupLanes = 16;  // lanes per chunk in the search kernel (KAMD_GROUP_LANES = 4 | 8 | 16 | 32 | 64); 16 measured best
 		DevBuf bigScratch, counter, posScratch;
@@ -450,7 +451,7 @@ namespace kamd
 			else throw std::runtime_error{ "KAMD_GROUP_LANES must be 4, 8, 16, 32 or 64" };
 		}
 		if (const char* w = std::getenv("KAMD_WPS")) { const int v = std::atoi(w); if (v == 2 || v == 3) impl->wpsForced = v; else throw std::runtime_error{ "KAMD_WPS must be 2 or 3" }; }
-		if (const char* pp = std::getenv("KAMD_POS_PATH")) { impl->posPath = std::atoi(pp) != 0; impl->posPathForced = std::atoi(pp) == 2; }
+		if (const char* pp = std::getenv("KAMD_POS_PATH")) { impl->posPath = std::atoi(pp) != 0; impl->posPathForced = std::atoi(pp) == 2; impl->posPathTypo = std::atoi(pp) != 3; }
 		if (const char* pg = std::getenv("KAMD_POS_G")) { const int v = std::atoi(pg); if (v == 8 || v == 16) impl->posGroupForced = v; else throw std::runtime_error{ "KAMD_POS_G must be 8 or 16" }; }
 		if (const char* pc = std::getenv("KAMD_POS_CONT")) impl->posContSlots = (uint32_t)std::max(0, std::min(4096, std::atoi(pc)));
 		if (const char* lg = std::getenv("KAMD_LATTICE_GROUP")) { const int v = std::atoi(lg); if (v == 16 || v == 64) impl->latticeGroupForced = v; }
@@ -1137,7 +1138,7 @@ namespace kamd
 				// for the position-step search without a blocklist and without character-model scores of unknown forms (k_unk_chr sits between the two);
 				// bit 1: a CoNgram model (records in the transposed evaluator's order).  KAMD_LATTICE_EXPAND=0: the two kernels do it
 				static const bool fuseExpand = !(getenv("KAMD_LATTICE_EXPAND") && std::atoi(getenv("KAMD_LATTICE_EXPAND")) == 0);
-				const bool posEarly = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8 && (!b.typo.typo || I.posPathForced);
+				const bool posEarly = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8 && (!b.typo.typo || I.posPathTypo);
 				const uint32_t expandMode = (fuseExpand && posEarly && !b.wv.unkChr && !b.wv.blockBits) ? (1u | (I.hasCong ? 2u : 0u)) : 0u;
 				if (getenv("KAMD_LATTICE_PROFILE")) { lwProf.ensure((size_t)nC * 64); HIPCHECK(hipMemsetAsync(lwProf.p, 0, (size_t)nC * 64, sA)); b.wv.beacon = lwProf.as<uint32_t>(); }
 				const uint32_t budget = b.pretok ? 0u : wave ? I.latticeWaveBudget : I.latticeLdsBudget;
@@ -1175,9 +1176,11 @@ namespace kamd
 			else if (b.wv.unkChr)      // Match::oovChrModel: every node's unknown form scored by the character model, once, before the search
 				hipLaunchKernelGGL(k_unk_chr, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, I.chr, c0, cn, chrToken(0xD800, identifySpecialChr(0xD800)), chrToken(0xDC00, identifySpecialChr(0xDC00)));
 			// position-step search first (viterbi_pos.inc): top-1, 16-lane groups, not for SkipBigram models; what it cannot finish is resumed by the general kernel below
-			// (not for typo correction unless asked for: the lattices over typo graphs hold positions the step kernel leaves to the general one -- MI355X, c5:
-			// search 3.97 ms with the position steps, 2.25 ms without, profiles/r04_j_c5_pos_path.txt; KAMD_POS_PATH=2 forces it, as the parity suites do)
-			const bool usePos = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8 && (!b.typo.typo || I.posPathForced);      // (per-sub-batch counters: 8 of each)
+			// (typo correction: until round 6 the lattices over typo graphs held positions the step kernel left to the general one -- nodes of equal TEXT end that feed
+			// each other, the halves of a continual typo: 86 % of c5's chunks were handed over, search 3.97 ms with the position steps against 2.25 without,
+			// profiles/r04_j_c5_pos_path.txt.  A step is now the nodes of equal MULTIPLIED end (DevNode::pad, k_expand_pos) and the typo compilations keep the
+			// state ranges of 64 nodes in LDS: 16 of 8 192 chunks leave the steps, search 2.44 -> 1.95 ms, profiles/r06_rr_*; KAMD_POS_PATH=3 is the old behaviour)
+			const bool usePos = b.wv.posRecs && sp.topN == 1 && !I.groupLanesForced && S <= 8 && (!b.typo.typo || I.posPathTypo);      // (per-sub-batch counters: 8 of each)
 			if (usePos)
 				hipLaunchKernelGGL(k_expand_pos, dim3(cn), dim3(64), 0, sA, I.dview, b.bv, b.wv, sp, c0, cn, b.typo.typo ? b.dNodeTypo.as<float>() : (const float*)nullptr, ((I.hasCong && b.wv.unkChr) ? 1u : 0u) | (I.hasCong ? 2u : 0u));      // (bit 0: unknown forms scored by the character model; bit 1: a CoNgram model)
 			HIPCHECK(hipEventRecord(e[2], sA));
@@ -1223,7 +1226,8 @@ namespace kamd
 			const uint32_t blocksK = std::min(persistBlocks, (cn + nGroupsK - 1) / nGroupsK);
 			// (the history compilations have their own LDS layout: smaller caches of the chunk, so that three waves per SIMD fit)
 			const uint32_t ldsK = I.hasSbg ? (b.typo.typo ? typok::sbgk::histKernelLdsBytes(gl) : sbgk::histKernelLdsBytes(gl))
-				: I.hasCongG ? (b.typo.typo ? typok::congk::gk::histKernelLdsBytes(gl) : congk::gk::histKernelLdsBytes(gl)) : searchKernelLdsBytes(gl);
+				: I.hasCongG ? (b.typo.typo ? typok::congk::gk::histKernelLdsBytes(gl) : congk::gk::histKernelLdsBytes(gl))
+				: searchKernelLdsBytes(gl) + (b.typo.typo ? nGroupsK * kTypoRingExtra : 0u);      // (typok:: / typok::congk::: the state ranges of 64 nodes per lane group)
 			if (usePos)
 			{
 				const bool wide = I.wpsForced ? I.wpsForced == 3 : cn >= 16384;      // many chunks: three waves per SIMD (what the kernel's LDS allows; a 168-VGPR build); few: the latency-bound regime (KAMD_WPS overrides)
@@ -1236,10 +1240,11 @@ namespace kamd
 				const uint32_t perBlock = narrow ? 8u : 4u;
 				const uint32_t blocksP = (cn + perBlock - 1) / perBlock;      // one chunk per lane group, one wavefront per block, no persistent loop (viterbi_pos.inc)
 				const float* nodeTypoP = b.typo.typo ? b.dNodeTypo.as<float>() : nullptr;
-#define KAMD_POS_LAUNCH(NS, ...) { if (narrow && wide) hipLaunchKernelGGL((NS k_pos_path<8, 3>), dim3(blocksP), dim3(64), kPosKernelLdsBytes8, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
-				else if (narrow) hipLaunchKernelGGL((NS k_pos_path<8, 2>), dim3(blocksP), dim3(64), kPosKernelLdsBytes8, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
-				else if (wide) hipLaunchKernelGGL((NS k_pos_path<16, 3>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
-				else hipLaunchKernelGGL((NS k_pos_path<16, 2>), dim3(blocksP), dim3(64), kPosKernelLdsBytes, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); }
+				const uint32_t posLds16 = kPosKernelLdsBytes + (b.typo.typo ? 4 * kTypoRingExtra : 0u), posLds8 = kPosKernelLdsBytes8 + (b.typo.typo ? 8 * kTypoRingExtra : 0u);
+#define KAMD_POS_LAUNCH(NS, ...) { if (narrow && wide) hipLaunchKernelGGL((NS k_pos_path<8, 3>), dim3(blocksP), dim3(64), posLds8, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
+				else if (narrow) hipLaunchKernelGGL((NS k_pos_path<8, 2>), dim3(blocksP), dim3(64), posLds8, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
+				else if (wide) hipLaunchKernelGGL((NS k_pos_path<16, 3>), dim3(blocksP), dim3(64), posLds16, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); \
+				else hipLaunchKernelGGL((NS k_pos_path<16, 2>), dim3(blocksP), dim3(64), posLds16, sB, I.dview, b.bv, wv, sp, order, cn, ##__VA_ARGS__); }
 				if (I.hasCong && b.typo.typo) KAMD_POS_LAUNCH(typok::congk::, nodeTypoP, I.cong)
 				else if (I.hasCong) KAMD_POS_LAUNCH(congk::, I.cong)
 				else if (b.typo.typo) KAMD_POS_LAUNCH(typok::, nodeTypoP)
@@ -1460,6 +1465,7 @@ namespace kamd
 				if (at == kPosChunkDone || at + 1 >= nn[c]) continue;
 				++early; frac += (double)at / nn[c]; atStart += at <= 1; ++why[(res[c].pad >> 24) & 15];
 			}
+			{ uint32_t c32[32]; HIPCHECK(hipMemcpy(c32, b.dOutCounters.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[pos] positions left to the general search by k_expand_pos: more than 16 nodes %u, more than 16 records %u, no record %u, node-level (feeds its step / nothing to evaluate / > 256 predecessors) %u\n", c32[20], c32[21], c32[22], c32[23]); }
 			fprintf(stderr, "[pos] chunks %u (searched %u), carried on in the general search by the kernel itself %u, left to k_best_path %u (%.2f %%), of those from the start %u, mean hand-over point %.2f of the lattice; reasons: static %u, ring %u, container %u, record size %u, staging %u, retry %u, disconnected %u, no program %u\n",
 				nC, seen, carried, early, seen ? 100.0 * early / seen : 0.0, atStart, early ? frac / early : 0.0, why[1], why[2], why[3], why[4], why[5], why[6], why[7], why[8]);
 		}

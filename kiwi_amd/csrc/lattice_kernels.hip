@@ -940,13 +940,14 @@ namespace kamd
 					if (nd.nflags & NF_ALL_PARTIAL) ++cnt;
 				}
 				else cnt = 2;
-				isFirst = i == 1 || nodes[i - 1].endPos != nd.endPos;
+				// (a step = the nodes of equal end: the text end, and for a lattice over a typo graph the multiplied end the build left in DevNode::pad -- 0 everywhere else)
+				isFirst = i == 1 || nodes[i - 1].endPos != nd.endPos || nodes[i - 1].pad != nd.pad;
 				const uint32_t firstPrev = i - nd.prev;
 				prev[i] = firstPrev;      // (completed in pass B': | (predecessor count - 1) << 16 | position of the predecessors << 24)
 				// the nodes of one step must not feed each other: true for spans of the text (a predecessor ends where the node starts, before its end);
 				// a lattice over a typo graph may hold nodes of equal text end that do -- such a position is left to the general kernel
 				uint32_t j0 = i;
-				while (j0 > 1 && nodes[j0 - 1].endPos == nd.endPos) --j0;
+				while (j0 > 1 && nodes[j0 - 1].endPos == nd.endPos && nodes[j0 - 1].pad == nd.pad) --j0;
 				if (firstPrev + nd.nPrev > j0) slow = true;
 			}
 			uint32_t incl = cnt;
@@ -972,6 +973,9 @@ namespace kamd
 			const uint32_t n0 = desc[p].firstNode, n1 = desc[p + 1].firstNode, r0 = desc[p].firstRec, r1 = desc[p + 1].firstRec;
 			bool slow = n1 - n0 > 16 || r1 - r0 > 16 || r1 == r0;
 			for (uint32_t j = n0; j < n1 && !slow; ++j) slow = (nodeRec[j] >> 31) != 0 || nodes[j].nPrev > 256;
+			// (developer statistics, KAMD_POS_STATS: why a position is left to the general search -- counters 20 .. 23 of the batch: more than 16 nodes, more than 16
+			// records, no record, a node that feeds its step / has nothing to evaluate / has more than 256 predecessors)
+			if (slow) atomicAdd(W.outCounters + (n1 - n0 > 16 ? 20 : r1 - r0 > 16 ? 21 : r1 == r0 ? 22 : 23), 1u);
 			// the distinct start positions of the position's nodes, four bytes (morphemes of a handful of lengths end at one place); more than four, or a
 			// chunk of more than 255 positions: no propagation for this chunk (header flag), the general kernel does its tests
 			uint32_t st4[4] = { 0, 0, 0, 0 }, nSt = 0; bool over = nPos > 255;

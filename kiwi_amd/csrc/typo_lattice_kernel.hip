@@ -617,6 +617,7 @@ namespace kamd
 				}
 				else if (i + 1 == nConn) nn.startPos = nn.endPos = (uint16_t)X.n;
 				else nn.startPos = nn.endPos = 0;
+				nn.pad = (uint16_t)g.endPos;      // (the MULTIPLIED end position: nodes of equal text end but different halves of a continual typo are different steps of the position-step search, k_expand_pos)
 				nn.packOff = packTop; packTop += nn.candCnt;
 				dn[i] = nn; tc[i] = g.typoCost;
 			}
@@ -873,6 +874,7 @@ namespace kamd
 				}
 				else if (ni + 1 == nConn) nn.startPos = nn.endPos = (uint16_t)n;
 				else nn.startPos = nn.endPos = 0;
+				nn.pad = g.endPos;      // (the multiplied end position, see the thread-per-chunk kernel)
 				nn.packOff = 0;
 				dn[ni] = nn; tc[ni] = g.typoCost;
 				cnt = nn.candCnt;

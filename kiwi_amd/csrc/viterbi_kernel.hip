@@ -152,6 +152,13 @@ namespace sbgk
 #endif
 #ifdef KAMD_TEST_SMALL_CAPS
 	constexpr uint32_t SCAP = 4, RING = 4;
+#elif defined(KAMD_TYPO) && !defined(KAMD_HIST)
+	constexpr uint32_t SCAP = 32;
+	// lattices over typo graphs hold 2.3 nodes per (multiplied) position: a form of fourteen positions has its predecessors more than 32 nodes back, and the
+	// position-step search handed 8.5 % of c5's chunks over for that alone (profiles/r06_qq_*).  kTypoRingExtra (viterbi_kernel.hpp) is what the larger ring
+	// adds to a lane group's LDS; the engine adds it to the launches of these compilations
+	constexpr uint32_t RING = 64;
+	static_assert(12 * (RING - 32) == kTypoRingExtra, "kTypoRingExtra");
 #else
 	constexpr uint32_t SCAP = 32;    // new states of one node whose scores are staged in LDS for pruning
 	constexpr uint32_t RING = 32;    // most recent nodes whose state ranges are kept in LDS

@@ -38,6 +38,7 @@ namespace kamd
 
 	uint32_t searchKernelLdsBytes(int G);
 	constexpr uint32_t kPosKernelLdsBytes = 12800;      // dynamic LDS of k_pos_path<16, .> (four lane groups: ring + staged new states)
+	constexpr uint32_t kTypoRingExtra = 384;            // per lane group: the typo compilations without history states (typok::, typok::congk::) keep the state ranges of 64 instead of 32 nodes in LDS
 	constexpr uint32_t kPosKernelLdsBytes8 = 13312;     // ... of k_pos_path<8, .> (eight lane groups of half the size each; 26 x 512 bytes: twelve one-wave blocks per CU as before)
 
 	// G = lanes per chunk (4, 8, 16, 32 or 64): a 64-lane wavefront searches 64/G chunks concurrently.
