@@ -1461,7 +1461,7 @@ namespace kamd
 				const uint32_t at = res[c].pad & 0xFFFFFFu;
 				if (!at || !nn[c]) continue;
 				++seen;
-				if (at == kPosChunkDone && (res[c].pad >> 24)) { ++carried; ++why[(res[c].pad >> 24) & 15]; continue; }
+				if (at == kPosChunkDone && (res[c].pad >> 24)) { ++carried; ++why[(res[c].pad >> 24) & 15]; if (carried <= 8) fprintf(stderr, "[pos] carried on: chunk %u of %u, reason %u\n", c, (uint32_t)nC, (res[c].pad >> 24) & 15); continue; }
 				if (at == kPosChunkDone || at + 1 >= nn[c]) continue;
 				++early; frac += (double)at / nn[c]; atStart += at <= 1; ++why[(res[c].pad >> 24) & 15];
 			}
