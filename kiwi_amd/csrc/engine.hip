@@ -708,7 +708,7 @@ namespace kamd
 		if (posPath)
 		{
 			b.dPosRecs.ensure((size_t)b.packBase[nC] * sizeof(PosRec) + 16); b.dPosDesc.ensure(totNodes * sizeof(PosDesc) + 16);
-			b.dPosPrev.ensure(totNodes * 4 + 16); b.dPosNodeRec.ensure(totNodes * 4 + 16); b.dPosMask.ensure(totNodes * 4 + 16); b.dPosBig.ensure(((nC + 7) / 8 * 8) * (size_t)64 * 20 + 16);
+			b.dPosPrev.ensure(totNodes * 4 + 16); b.dPosNodeRec.ensure(totNodes * 4 + 16); b.dPosMask.ensure(totNodes * (b.typo.typo ? 8 : 4) + 16) /* typo lattices: a second word per position, one batch of nodes behind the first */; b.dPosBig.ensure(((nC + 7) / 8 * 8) * (size_t)64 * 20 + 16);
 		}
 		if (I.histStates()) b.dHist.ensure(totStates * 32 + 32);
 		// compact outputs of the end stage: as many token records as the arenas could hold, 16 path headers per chunk (x capacity scale)
@@ -1466,8 +1466,8 @@ namespace kamd
 				++early; frac += (double)at / nn[c]; atStart += at <= 1; ++why[(res[c].pad >> 24) & 15];
 			}
 			{ uint32_t c32[32]; HIPCHECK(hipMemcpy(c32, b.dOutCounters.p, 128, hipMemcpyDeviceToHost)); fprintf(stderr, "[pos] positions left to the general search by k_expand_pos: more than 16 nodes %u, more than 16 records %u, no record %u, node-level (feeds its step / nothing to evaluate / > 256 predecessors) %u\n", c32[20], c32[21], c32[22], c32[23]); }
-			fprintf(stderr, "[pos] chunks %u (searched %u), carried on in the general search by the kernel itself %u, left to k_best_path %u (%.2f %%), of those from the start %u, mean hand-over point %.2f of the lattice; reasons: static %u, ring %u, container %u, record size %u, staging %u, retry %u, disconnected %u, no program %u\n",
-				nC, seen, carried, early, seen ? 100.0 * early / seen : 0.0, atStart, early ? frac / early : 0.0, why[1], why[2], why[3], why[4], why[5], why[6], why[7], why[8]);
+			fprintf(stderr, "[pos] chunks %u (searched %u), carried on in the general search by the kernel itself %u, left to k_best_path %u (%.2f %%), of those from the start %u, mean hand-over point %.2f of the lattice; reasons: static %u, ring %u, container %u, record size %u, staging %u, retry %u, disconnected %u, no program %u, test cannot run %u\n",
+				nC, seen, carried, early, seen ? 100.0 * early / seen : 0.0, atStart, early ? frac / early : 0.0, why[1], why[2], why[3], why[4], why[5], why[6], why[7], why[8], why[9]);
 		}
 #ifdef KAMD_TIMELINE
 		if (getenv("KAMD_TIMELINE_PRINT") && gTimeline)

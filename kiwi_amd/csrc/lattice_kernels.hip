@@ -978,18 +978,22 @@ namespace kamd
 			if (slow) atomicAdd(W.outCounters + (n1 - n0 > 16 ? 20 : r1 - r0 > 16 ? 21 : r1 == r0 ? 22 : 23), 1u);
 			// the distinct start positions of the position's nodes, four bytes (morphemes of a handful of lengths end at one place); more than four, or a
 			// chunk of more than 255 positions: no propagation for this chunk (header flag), the general kernel does its tests
-			uint32_t st4[4] = { 0, 0, 0, 0 }, nSt = 0; bool over = nPos > 255;
+			// (a lattice over a typo graph -- nodeTypoAll is bound -- gets EIGHT: the alternatives of a typo end at one place with many lengths, 8 of c5's 8 192 chunks had a
+			// position with more than four; the second word lies one whole batch of nodes behind the first, W.posMask[total nodes + ...], read by the typo compilations)
+			const uint32_t maxSt = nodeTypoAll ? 8u : 4u;
+			uint32_t st4[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, nSt = 0; bool over = nPos > 255;
 			for (uint32_t j = n0; j < n1 && !over; ++j)
 			{
 				const uint32_t sp = startPosOf(j);
 				bool seen = false;
 				for (uint32_t t = 0; t < nSt; ++t) seen = seen || st4[t] == sp;
 				if (seen) continue;
-				if (nSt == 4) { over = true; break; }
+				if (nSt == maxSt) { over = true; break; }
 				st4[nSt++] = sp;
 			}
-			for (uint32_t t = nSt; t < 4; ++t) st4[t] = st4[0];
+			for (uint32_t t = nSt; t < 8; ++t) st4[t] = st4[0];
 			W.posMask[nBase + p] = over ? 0xFFFFFFFFu : (st4[0] | (st4[1] << 8) | (st4[2] << 16) | (st4[3] << 24));
+			if (nodeTypoAll) W.posMask[W.nodeBase[B.nChunks] + nBase + p] = over ? 0xFFFFFFFFu : (st4[4] | (st4[5] << 8) | (st4[6] << 16) | (st4[7] << 24));
 			if (over) desc[0].nNodes = 1;
 			uint32_t formless = 0;      // bit j: node n0 + j has no dictionary form (the reference never sets its `reachable` flag itself, PathEvaluator.hpp:1300-1318)
 			for (uint32_t j = n0; j < n1 && j < n0 + 16; ++j) if (nodes[j].form == NOFORM) formless |= 1u << (j - n0);
