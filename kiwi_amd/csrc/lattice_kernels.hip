@@ -971,11 +971,12 @@ namespace kamd
 		for (uint32_t p = 1 + lane; p <= nPos; p += 64)
 		{
 			const uint32_t n0 = desc[p].firstNode, n1 = desc[p + 1].firstNode, r0 = desc[p].firstRec, r1 = desc[p + 1].firstRec;
-			bool slow = n1 - n0 > 16 || r1 - r0 > 16 || r1 == r0;
+			const uint32_t maxRec = nodeTypoAll ? 32u : 16u;      // (the typo compilations of the position steps take a position's records in two passes of 16)
+			bool slow = n1 - n0 > 16 || r1 - r0 > maxRec || r1 == r0;
 			for (uint32_t j = n0; j < n1 && !slow; ++j) slow = (nodeRec[j] >> 31) != 0 || nodes[j].nPrev > 256;
 			// (developer statistics, KAMD_POS_STATS: why a position is left to the general search -- counters 20 .. 23 of the batch: more than 16 nodes, more than 16
 			// records, no record, a node that feeds its step / has nothing to evaluate / has more than 256 predecessors)
-			if (slow) atomicAdd(W.outCounters + (n1 - n0 > 16 ? 20 : r1 - r0 > 16 ? 21 : r1 == r0 ? 22 : 23), 1u);
+			if (slow) atomicAdd(W.outCounters + (n1 - n0 > 16 ? 20 : r1 - r0 > maxRec ? 21 : r1 == r0 ? 22 : 23), 1u);
 			// the distinct start positions of the position's nodes, four bytes (morphemes of a handful of lengths end at one place); more than four, or a
 			// chunk of more than 255 positions: no propagation for this chunk (header flag), the general kernel does its tests
 			// (a lattice over a typo graph -- nodeTypoAll is bound -- gets EIGHT: the alternatives of a typo end at one place with many lengths, 8 of c5's 8 192 chunks had a
