@@ -357,7 +357,17 @@ namespace kamd
 		HIPCHECK(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));
 		HIPCHECK(hipStreamCreateWithFlags(&impl->stream2, hipStreamNonBlocking));
 		for (auto& ls : impl->latStream) HIPCHECK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
-		HIPCHECK(hipStreamCreateWithFlags(&impl->streamCopy, hipStreamNonBlocking));
+		// (KAMD_COPY_PRIORITY=1: the copy stream at the highest priority.  Streams share a handful of hardware queues, and a copy that lands in the queue of a compute stream
+		// waits for every kernel enqueued there before it: on c4-cong the 64-byte counter read-back of a batch's FIRST part took 32 ms, until the kernels of all four parts had
+		// run.  With its own queue the parts are collected under the later parts' kernels -- and the batch takes as long as before, 67 ms: what bounds c4-cong end to end is
+		// that the kernels of a PART have a floor (14.6 / 17.9 / 27.0 ms for 32 768 / 65 536 / 131 072 sentences: the chain of the longest chunks), so four parts cost 58 ms of
+		// kernels where one batch costs 27; c2-64k is no faster either (its kernels are hidden): profiles/r06_c4_*.  Left off.)
+		{
+			int least = 0, greatest = 0;
+			const bool plain = [] { const char* e = std::getenv("KAMD_COPY_PRIORITY"); return !(e && std::atoi(e) == 1); }();
+			if (plain || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) HIPCHECK(hipStreamCreateWithFlags(&impl->streamCopy, hipStreamNonBlocking));
+			else HIPCHECK(hipStreamCreateWithPriority(&impl->streamCopy, hipStreamNonBlocking, greatest));
+		}
 		HIPCHECK(hipEventCreateWithFlags(&impl->lastDone, hipEventDisableTiming)); HIPCHECK(hipEventCreateWithFlags(&impl->joinEv, hipEventDisableTiming));
 		HIPCHECK(hipEventCreate(&impl->latFork)); for (auto& ev : impl->latJoin) HIPCHECK(hipEventCreate(&ev));
 
@@ -1745,9 +1755,12 @@ namespace kamd
 		if (b.evDone) HIPCHECK(hipEventSynchronize(b.evDone));      // (not under the device lock: another thread may be staging / launching the next part)
 		tm.lap("waiting for the batch's kernels");
 		std::lock_guard<std::recursive_mutex> devLock{ impl->deviceMu };
+		tm.lap("waiting for the device lock");
 		KernelTimes t;
 		afterLaunch(*impl, b, t, false);
+		tm.lap("counters of the launch");
 		rerunOverflows(b, t);
+		tm.lap("chunk statuses, re-runs");
 	}
 
 	void Engine::rerunOverflows(StagedBatch& b, KernelTimes& t)
@@ -2049,7 +2062,9 @@ namespace kamd
 			for (auto& sg : r.segs) all.segs.push_back(std::move(sg));
 			for (auto& o : r.overrides) all.overrides.emplace_back(o.first + cut[k], std::move(o.second));
 			all.nTexts += r.nTexts; all.d2hBytes += r.d2hBytes;
+			HostTimer tmR{ "collect" };
 			staged[k].reset();
+			tmR.lap("release of the part");
 		};
 		// Two host threads: the caller prepares, uploads and launches part after part; a collector waits for each part's kernels, downloads, assembles
 		// and releases it.  The stages that run on ONE thread (layout + upload 1.9 ms, work order + launches 0.5, download 0.5, release of the part's buffers
@@ -2119,9 +2134,11 @@ namespace kamd
 			waitInFlight();
 			throw;
 		}
+		HostTimer tmJ{ "batch" };
 		{ std::lock_guard<std::mutex> g{ qmu }; stop = true; }
 		qcv.notify_one();
 		collector.join();
+		tmJ.lap("caller waiting for the collector after its last launch");
 		if (collectorError) { waitInFlight(); std::rethrow_exception(collectorError); }
 		return all;
 	}
